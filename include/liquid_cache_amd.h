@@ -1,0 +1,255 @@
+/*
+ * liquid_cache_amd — C ABI of the MI355X-native LiquidCache decode + predicate-pushdown path.
+ *
+ * This header is the drop-in boundary: plain C, pointers and sizes only.  It replaces, for entries
+ * whose state is `CacheEntry::MemoryLiquid`, the reference calls (paths relative to the reference
+ * repository root, crate `liquid-cache` v0.1.12):
+ *
+ *   LiquidCache::insert / transcode          src/core/src/cache/core.rs:122-128, cache/transcode.rs:46-290
+ *   LiquidCache::get().with_selection()      src/core/src/cache/builders.rs:218-276, cache/core.rs:595-634
+ *   LiquidCache::eval_predicate()            src/core/src/cache/builders.rs:314-356, cache/core.rs:862-930
+ *   LiquidArray::{filter,try_eval_predicate} src/core/src/liquid_array/mod.rs:117-130
+ *   boolean_buffer_and_then                  src/datafusion/src/utils.rs:62-83
+ *   read_from_bytes (Liquid IPC)             src/core/src/liquid_array/ipc.rs:250-283
+ *
+ * Conventions (same as the reference / Arrow): little endian, LSB-first bitmaps, i32 offsets for
+ * Utf8/Binary.  Cached arrays are immutable once staged.  All functions are thread-safe and
+ * re-entrant; none of them aborts or throws across the ABI — they return an lc_status.
+ * `LC_NOT_STAGED` corresponds to the reference's `None` ("not cached"), `LC_UNSUPPORTED` means
+ * "run the reference CPU path for this call".
+ *
+ * One lc_ctx drives ONE HIP device (one process per GPU); multi-GPU = one ctx per rank, entries
+ * sharded by row range (file,row-group,batch), see DESIGN.md.
+ */
+#ifndef LIQUID_CACHE_AMD_H
+#define LIQUID_CACHE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_API __attribute__((visibility("default")))
+
+typedef int32_t lc_status;
+#define LC_OK 0
+#define LC_NOT_STAGED 1      /* == Option::None from the cache (core.rs:595, :862) */
+#define LC_UNSUPPORTED 2     /* caller must fall back to the reference CPU path */
+#define LC_ERR_INVALID (-1)  /* bad argument */
+#define LC_ERR_CORRUPT (-2)  /* malformed Liquid IPC bytes (the reference panics: ipc.rs:221-226) */
+#define LC_ERR_DEVICE (-3)   /* HIP runtime error */
+#define LC_ERR_OOM (-4)      /* HBM arena exhausted (reference: CacheFull on insert) */
+#define LC_ERR_NO_SYMTAB (-5)/* ByteView entry staged without its FSST symbol table */
+
+/* Comparison operators: datafusion Operator subset accepted by LiquidExpr::try_new
+ * (src/core/src/cache/liquid_expr.rs:85-125) and ByteViewOperator (byte_view_array/operator.rs:54-105). */
+#define LC_OP_EQ 0
+#define LC_OP_NE 1
+#define LC_OP_LT 2
+#define LC_OP_LE 3
+#define LC_OP_GT 4
+#define LC_OP_GE 5
+#define LC_OP_LIKE 6      /* LikeExpr / LikeMatch, case sensitive */
+#define LC_OP_NOT_LIKE 7  /* negated */
+
+/* Literal tags (ScalarValue subset). */
+#define LC_LIT_I64 0    /* 8 bytes: Int8..Int64, Date32/64, Timestamp(_, None) */
+#define LC_LIT_U64 1    /* 8 bytes: UInt8..UInt64 */
+#define LC_LIT_F32 2    /* 4 bytes */
+#define LC_LIT_F64 3    /* 8 bytes */
+#define LC_LIT_BYTES 4  /* Utf8/Binary needle or LIKE pattern */
+#define LC_LIT_I128 5   /* 16 bytes LE: Decimal128 unscaled value (same scale as the column) */
+#define LC_LIT_BOOL 6   /* 1 byte: Literal(Boolean) on byte-like columns (liquid_expr.rs:78-80) */
+
+/* CacheExpression hints (src/core/src/cache/expressions.rs:36-51) that change the encoding. */
+#define LC_HINT_NONE 0
+#define LC_HINT_SUBSTRING_SEARCH 1 /* build 32-bucket string fingerprints (byte_view_array/fingerprint.rs) */
+#define LC_HINT_PREDICATE_COLUMN 2
+
+typedef struct {
+    int32_t op;       /* LC_OP_* */
+    int32_t lit_tag;  /* LC_LIT_* */
+    const void* lit;  /* literal bytes */
+    uint64_t lit_len; /* byte length of `lit` */
+} lc_predicate;
+
+typedef struct lc_ctx lc_ctx;
+typedef struct lc_scan lc_scan;
+
+typedef struct {
+    int32_t device_id;
+    int32_t compute_units;
+    uint64_t hbm_total_bytes;
+    uint64_t hbm_staged_bytes;   /* bytes of Liquid data resident in HBM */
+    uint64_t staged_entries;
+    char name[64];
+    char gcn_arch[32];
+} lc_device_info;
+
+typedef struct {
+    int32_t logical_type;   /* LiquidDataType (liquid_array/mod.rs:50-65): 1 int, 2 float, 4 byte-view, 6 decimal */
+    int32_t physical_type;  /* ipc.rs:28-45, or ArrowByteType for byte views (byte_view_array/mod.rs:113-122) */
+    uint32_t len;           /* rows */
+    int32_t nullable;
+    int32_t all_null;
+    int32_t bit_width;      /* W, 0 if all-null */
+    uint32_t dict_len;      /* D for byte views */
+    int32_t has_fingerprints;
+    uint64_t device_bytes;  /* HBM bytes held by the entry */
+    uint64_t algorithmic_pred_bytes; /* SURVEY §8(d) bytes one predicate evaluation reads+writes */
+} lc_entry_info;
+
+/* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html), declared here so the
+ * header is self-contained; layout-identical to arrow's own structs. */
+#ifndef ARROW_C_DATA_INTERFACE
+#define ARROW_C_DATA_INTERFACE
+struct ArrowSchema {
+    const char* format;
+    const char* name;
+    const char* metadata;
+    int64_t flags;
+    int64_t n_children;
+    struct ArrowSchema** children;
+    struct ArrowSchema* dictionary;
+    void (*release)(struct ArrowSchema*);
+    void* private_data;
+};
+struct ArrowArray {
+    int64_t length;
+    int64_t null_count;
+    int64_t offset;
+    int64_t n_buffers;
+    int64_t n_children;
+    const void** buffers;
+    struct ArrowArray** children;
+    struct ArrowArray* dictionary;
+    void (*release)(struct ArrowArray*);
+    void* private_data;
+};
+#endif
+
+/* ------------------------------------------------------------------ context */
+
+/* LiquidCacheBuilder::new().build() (builders.rs:50-157).  `n_devices` must be 1 (one process per GPU);
+ * device_ids == NULL selects the current HIP device.  n_devices == 0 with device_ids == NULL creates a HOST-ONLY
+ * context that can transcode Arrow -> Liquid bytes and hold symbol tables but fails every staging / evaluation
+ * call with LC_ERR_DEVICE (there is no CPU fallback for the compute path).  `max_hbm_bytes` == 0 means "as much as is free"
+ * (reference default max_memory_bytes is 1 GiB; HBM has 288 GB, the arena grows in slabs). */
+LC_API lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t max_hbm_bytes, lc_ctx** out);
+LC_API void lc_ctx_destroy(lc_ctx* ctx);
+LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
+LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);
+LC_API const char* lc_version(void);
+
+/* ------------------------------------------------------------------ staging */
+
+/* FSST symbol table of one ColumnAccessPath (file,row-group,column): src/datafusion/src/cache/id.rs:141-146.
+ * `bytes` in the reference's own save_symbol_table format (raw/fsst_buffer.rs:848-883):
+ * [n:u8][len:u8 x n][symbol:u64 LE x n].  Must be set before ByteView entries of that path are staged
+ * (the table is NOT part of LiquidArray::to_bytes(), ipc.rs:238-264). */
+LC_API lc_status lc_symtab_set(lc_ctx* ctx, uint64_t path_id, const uint8_t* bytes, size_t len);
+
+/* Stage `n` entries given as the reference's serialized LiquidArray bytes (LiquidArray::to_bytes(),
+ * ipc.rs:158-236, bit_pack_array.rs:181-256, primitive_array.rs:603-679, decimal_array.rs:197-220,
+ * float_array.rs:397-519, byte_view_array/serialization.rs:87-220).  `path_ids` may be NULL when no entry
+ * is a byte view.  Replaces an entry that is already staged.  Data is copied; the caller keeps `bytes`. */
+LC_API lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes,
+                          const size_t* lens, const uint64_t* path_ids);
+LC_API lc_status lc_evict(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids);
+LC_API lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out);
+
+/* Arrow -> Liquid transcoder (transcode_liquid_inner_with_hint, cache/transcode.rs:46-290).  Produces the same
+ * Liquid IPC bytes a Rust `to_bytes()` would stage.  For byte-like arrays the symbol table of `path_id`
+ * is trained from this array if none is registered yet (transcode.rs:16-33) and registered on `ctx`.
+ * `*out_bytes` is malloc'ed; release with lc_free.  Returns LC_UNSUPPORTED for types the reference does not
+ * transcode (they stay Arrow in the cache). */
+LC_API lc_status lc_transcode_arrow(lc_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema,
+                                    int32_t hint, uint64_t path_id, uint8_t** out_bytes, size_t* out_len);
+/* cache.insert(entry_id, array) with eager transcoding (benchmark/README.md:42 `liquid_eager_transcode`). */
+LC_API lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArray* array,
+                                 const struct ArrowSchema* schema, int32_t hint, uint64_t path_id);
+LC_API void lc_free(void* p);
+/* Export the registered symbol table of `path_id` in save_symbol_table format (malloc'ed). */
+LC_API lc_status lc_symtab_get(lc_ctx* ctx, uint64_t path_id, uint8_t** out_bytes, size_t* out_len);
+
+/* ------------------------------------------------------------------ per-entry API (drop-in) */
+
+/* cache.eval_predicate(&entry_id, &expr).with_selection(&sel).read()  (builders.rs:336-346).
+ *   selection: `len` bits, LSB first, or NULL == BooleanBuffer::new_set(len) (core.rs:907-911)
+ *   out_values / out_validity: caller-allocated, ceil(len/8) bytes each is always enough;
+ *   the result BooleanArray has *out_len = popcount(selection) bits (Appendix B.1 of SURVEY.md);
+ *   *out_nullable != 0 iff the result carries a validity bitmap (written to out_validity).
+ * Value bits under null slots are unspecified (as in Arrow). */
+LC_API lc_status lc_eval_predicate(lc_ctx* ctx, uint64_t entry_id, const lc_predicate* pred,
+                                   const uint8_t* selection, uint8_t* out_values, uint8_t* out_validity,
+                                   uint32_t* out_len, int32_t* out_nullable);
+
+/* Same for `n` entries in one device pass (launch amortisation: 8192 rows x 1-8 B per entry is far too little
+ * for one launch).  selections[i] may be NULL; statuses[i] receives the per-entry status. */
+LC_API lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids,
+                                         const lc_predicate* pred, const uint8_t* const* selections,
+                                         uint8_t* const* out_values, uint8_t* const* out_validity,
+                                         uint32_t* out_lens, int32_t* out_nullable, lc_status* statuses);
+
+/* cache.get(&entry_id).with_selection(&sel).read()  (builders.rs:236-266): rows whose selection bit is set, in
+ * order, in the entry's original Arrow type, exported through the Arrow C Data Interface (caller releases).
+ * selection NULL == no selection (to_arrow_array). */
+LC_API lc_status lc_get_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection,
+                                       struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+
+/* boolean_buffer_and_then(left, right) (src/datafusion/src/utils.rs:62-83): `left` has left_bits bits of which
+ * right_bits are set; out (ceil(left_bits/8) bytes) keeps the set bits of `left` whose `right` bit is 1. */
+LC_API lc_status lc_mask_and_then(lc_ctx* ctx, const uint8_t* left, uint64_t left_bits, const uint8_t* right,
+                                  uint64_t right_bits, uint8_t* out);
+
+/* ------------------------------------------------------------------ device-resident column scans */
+
+/* A scan is an ordered list of staged entries of ONE column (consecutive 8192-row batches of a row range).
+ * Its hit mask lives in HBM as per-entry segments of ceil(len/64) 64-bit words, concatenated in entry order
+ * (row-range shards concatenate across ranks without bit shifting).  Conjunctions chain on the device:
+ * the mask produced by one predicate is the selection of the next (what LiquidCacheReader::build_predicate_filter
+ * does with boolean_buffer_and_then, src/datafusion/src/reader/runtime/liquid_cache_reader.rs:297-339). */
+LC_API lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out);
+LC_API void lc_scan_destroy(lc_scan* scan);
+LC_API uint64_t lc_scan_mask_words(const lc_scan* scan);  /* total u64 words of the mask */
+LC_API uint64_t lc_scan_rows(const lc_scan* scan);
+LC_API uint64_t lc_scan_entries(const lc_scan* scan);
+LC_API uint64_t lc_scan_algorithmic_bytes(const lc_scan* scan, const lc_predicate* pred, int32_t with_selection);
+/* word offset of entry i's segment inside the mask (n+1 values, host memory owned by the scan) */
+LC_API const uint64_t* lc_scan_segment_offsets(const lc_scan* scan);
+
+/* Evaluate `pred` over every entry of the scan.
+ *   d_selection: device pointer to a mask in scan layout or NULL (all rows); rows outside it are not evaluated.
+ *   d_mask_out : device pointer, lc_scan_mask_words() words: hit = pred(row) AND valid(row) AND selected(row)
+ *                (i.e. prep_null_mask_filter + boolean_buffer_and_then already applied).
+ *   d_counts_out: device pointer to one u32 per entry (popcount of its segment) or NULL.
+ *   stream: hipStream_t (NULL = default stream).  Asynchronous; the caller synchronises the stream. */
+LC_API lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
+                              void* d_mask_out, void* d_counts_out, void* stream);
+
+/* get-with-selection over a whole scan for fixed-width columns: compacts the selected rows' decoded values
+ * (original Arrow value width) into d_values_out in row order.  d_row_offsets (n+1 u64, device) receives the
+ * exclusive prefix sum of per-entry selected counts.  Asynchronous on `stream`. */
+LC_API lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_values_out,
+                                      uint64_t values_capacity_bytes, void* d_row_offsets, void* stream);
+
+/* Convenience for hosts without their own HIP runtime binding. */
+LC_API lc_status lc_device_alloc(lc_ctx* ctx, uint64_t bytes, void** out_dptr);
+LC_API lc_status lc_device_free(lc_ctx* ctx, void* dptr);
+LC_API lc_status lc_device_memset(lc_ctx* ctx, void* dptr, int value, uint64_t bytes, void* stream);
+LC_API lc_status lc_device_to_host(lc_ctx* ctx, void* host_dst, const void* dptr, uint64_t bytes, void* stream);
+LC_API lc_status lc_host_to_device(lc_ctx* ctx, void* dptr, const void* host_src, uint64_t bytes, void* stream);
+LC_API lc_status lc_stream_synchronize(lc_ctx* ctx, void* stream);
+
+/* Time `iters` back-to-back lc_scan_eval launches with HIP events recorded on `stream` (the stream the kernels
+ * run on); returns the average milliseconds per launch.  Used by bench.py for the roofline figure. */
+LC_API lc_status lc_scan_eval_timed(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
+                                    void* d_mask_out, void* d_counts_out, void* stream, int32_t iters,
+                                    float* out_avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIQUID_CACHE_AMD_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of libliquid_cache_amd.so (the C ABI in include/liquid_cache_amd.h).
+
+The product path has NO fallback: if the in-tree HIP library is missing this module raises at import time of the
+symbols, and if no HIP device is present every compute call returns LC_ERR_DEVICE (surfaced as LiquidCacheError).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libliquid_cache_amd.so")
+
+LC_OK, LC_NOT_STAGED, LC_UNSUPPORTED = 0, 1, 2
+LC_ERR_INVALID, LC_ERR_CORRUPT, LC_ERR_DEVICE, LC_ERR_OOM, LC_ERR_NO_SYMTAB = -1, -2, -3, -4, -5
+OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_LIKE, OP_NOT_LIKE = range(8)
+LIT_I64, LIT_U64, LIT_F32, LIT_F64, LIT_BYTES, LIT_I128, LIT_BOOL = range(7)
+HINT_NONE, HINT_SUBSTRING_SEARCH, HINT_PREDICATE_COLUMN = 0, 1, 2
+
+
+class LiquidCacheError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"liquid_cache_amd status {status}: {message}")
+        self.status = status
+
+
+class Predicate(C.Structure):
+    _fields_ = [("op", C.c_int32), ("lit_tag", C.c_int32), ("lit", C.c_void_p), ("lit_len", C.c_uint64)]
+
+
+class DeviceInfo(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("compute_units", C.c_int32), ("hbm_total_bytes", C.c_uint64),
+                ("hbm_staged_bytes", C.c_uint64), ("staged_entries", C.c_uint64), ("name", C.c_char * 64),
+                ("gcn_arch", C.c_char * 32)]
+
+
+class EntryInfo(C.Structure):
+    _fields_ = [("logical_type", C.c_int32), ("physical_type", C.c_int32), ("len", C.c_uint32),
+                ("nullable", C.c_int32), ("all_null", C.c_int32), ("bit_width", C.c_int32), ("dict_len", C.c_uint32),
+                ("has_fingerprints", C.c_int32), ("device_bytes", C.c_uint64), ("algorithmic_pred_bytes", C.c_uint64)]
+
+
+class ArrowSchema(C.Structure):
+    pass
+
+
+class ArrowArray(C.Structure):
+    pass
+
+
+ArrowSchema._fields_ = [("format", C.c_char_p), ("name", C.c_char_p), ("metadata", C.c_char_p),
+                        ("flags", C.c_int64), ("n_children", C.c_int64), ("children", C.c_void_p),
+                        ("dictionary", C.c_void_p), ("release", C.c_void_p), ("private_data", C.c_void_p)]
+ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offset", C.c_int64),
+                       ("n_buffers", C.c_int64), ("n_children", C.c_int64), ("buffers", C.c_void_p),
+                       ("children", C.c_void_p), ("dictionary", C.c_void_p), ("release", C.c_void_p),
+                       ("private_data", C.c_void_p)]
+
+# every symbol include/liquid_cache_amd.h declares (tests check that the built library exports all of them)
+EXPORTED_SYMBOLS = [
+    "lc_ctx_create", "lc_ctx_destroy", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
+    "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
+    "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_mask_and_then", "lc_scan_create",
+    "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
+    "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
+    "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
+]
+
+_lib = None
+
+
+def load():
+    """Load the in-tree shared library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). liquid_cache_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, sz = C.c_void_p, C.c_uint64, C.c_int32, C.c_size_t
+    P = C.POINTER
+    L.lc_version.restype = C.c_char_p
+    L.lc_last_error.restype = C.c_char_p; L.lc_last_error.argtypes = [vp]
+    L.lc_ctx_create.restype = i32; L.lc_ctx_create.argtypes = [P(C.c_int32), i32, u64, P(vp)]
+    L.lc_ctx_destroy.restype = None; L.lc_ctx_destroy.argtypes = [vp]
+    L.lc_device_info_get.restype = i32; L.lc_device_info_get.argtypes = [vp, P(DeviceInfo)]
+    L.lc_symtab_set.restype = i32; L.lc_symtab_set.argtypes = [vp, u64, vp, sz]
+    L.lc_symtab_get.restype = i32; L.lc_symtab_get.argtypes = [vp, u64, P(vp), P(sz)]
+    L.lc_stage.restype = i32; L.lc_stage.argtypes = [vp, u64, P(u64), P(vp), P(sz), P(u64)]
+    L.lc_evict.restype = i32; L.lc_evict.argtypes = [vp, u64, P(u64)]
+    L.lc_entry_info_get.restype = i32; L.lc_entry_info_get.argtypes = [vp, u64, P(EntryInfo)]
+    L.lc_transcode_arrow.restype = i32; L.lc_transcode_arrow.argtypes = [vp, vp, vp, i32, u64, P(vp), P(sz)]
+    L.lc_insert_arrow.restype = i32; L.lc_insert_arrow.argtypes = [vp, u64, vp, vp, i32, u64]
+    L.lc_free.restype = None; L.lc_free.argtypes = [vp]
+    L.lc_eval_predicate.restype = i32
+    L.lc_eval_predicate.argtypes = [vp, u64, P(Predicate), vp, vp, vp, P(C.c_uint32), P(C.c_int32)]
+    L.lc_eval_predicate_batch.restype = i32
+    L.lc_eval_predicate_batch.argtypes = [vp, u64, P(u64), P(Predicate), P(vp), P(vp), P(vp), P(C.c_uint32),
+                                          P(C.c_int32), P(C.c_int32)]
+    L.lc_get_with_selection.restype = i32; L.lc_get_with_selection.argtypes = [vp, u64, vp, vp, vp]
+    L.lc_mask_and_then.restype = i32; L.lc_mask_and_then.argtypes = [vp, vp, u64, vp, u64, vp]
+    L.lc_scan_create.restype = i32; L.lc_scan_create.argtypes = [vp, u64, P(u64), P(vp)]
+    L.lc_scan_destroy.restype = None; L.lc_scan_destroy.argtypes = [vp]
+    for name in ("lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries"):
+        getattr(L, name).restype = u64; getattr(L, name).argtypes = [vp]
+    L.lc_scan_algorithmic_bytes.restype = u64; L.lc_scan_algorithmic_bytes.argtypes = [vp, P(Predicate), i32]
+    L.lc_scan_segment_offsets.restype = P(u64); L.lc_scan_segment_offsets.argtypes = [vp]
+    L.lc_scan_eval.restype = i32; L.lc_scan_eval.argtypes = [vp, vp, P(Predicate), vp, vp, vp, vp]
+    L.lc_scan_eval_timed.restype = i32
+    L.lc_scan_eval_timed.argtypes = [vp, vp, P(Predicate), vp, vp, vp, vp, i32, P(C.c_float)]
+    L.lc_scan_gather_fixed.restype = i32; L.lc_scan_gather_fixed.argtypes = [vp, vp, vp, vp, u64, vp, vp]
+    L.lc_device_alloc.restype = i32; L.lc_device_alloc.argtypes = [vp, u64, P(vp)]
+    L.lc_device_free.restype = i32; L.lc_device_free.argtypes = [vp, vp]
+    L.lc_device_memset.restype = i32; L.lc_device_memset.argtypes = [vp, vp, i32, u64, vp]
+    L.lc_device_to_host.restype = i32; L.lc_device_to_host.argtypes = [vp, vp, vp, u64, vp]
+    L.lc_host_to_device.restype = i32; L.lc_host_to_device.argtypes = [vp, vp, vp, u64, vp]
+    L.lc_stream_synchronize.restype = i32; L.lc_stream_synchronize.argtypes = [vp, vp]
+    _lib = L
+    return L
+
+
+def check(status: int, ctx=None):
+    if status < 0 or status == LC_UNSUPPORTED:
+        msg = load().lc_last_error(ctx).decode(errors="replace")
+        raise LiquidCacheError(status, msg)
+    return status

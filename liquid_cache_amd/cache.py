@@ -1,0 +1,512 @@
+"""Host-side mirror of the reference's cache API for the decode + predicate-pushdown path.
+
+Names, argument meaning and error behaviour follow the reference (paths relative to its repository root):
+
+    LiquidCacheBuilder / LiquidCache::{insert,get,eval_predicate}   src/core/src/cache/builders.rs:32-356,
+                                                                     src/core/src/cache/core.rs:122-142
+    EntryID                                                          src/core/src/cache/utils.rs:70-84
+    ParquetArrayID (file16|rg16|col16|batch16)                       src/datafusion/src/cache/id.rs:7-30
+    LiquidExpr::try_new                                              src/core/src/cache/liquid_expr.rs:33-202
+    CacheExpression                                                  src/core/src/cache/expressions.rs:36-51
+    boolean_buffer_and_then                                          src/datafusion/src/utils.rs:62-83
+
+All arithmetic on cached data runs in the HIP library behind include/liquid_cache_amd.h; this module only
+marshals Arrow buffers.  `None` results mean exactly what they mean in the reference: entry not cached /
+expression not supported ("caller falls back").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import datetime
+import decimal
+from typing import Iterable, Optional, Sequence, Union
+
+import numpy as np
+import pyarrow as pa
+
+from . import _native as N
+from ._native import LiquidCacheError
+
+__all__ = ["EntryID", "ParquetArrayID", "CacheExpression", "LiquidExpr", "LiquidCacheBuilder", "LiquidCache",
+           "Scan", "LiquidCacheError", "boolean_buffer_and_then"]
+
+
+class EntryID(int):
+    """Opaque cache key (reference: `EntryID(usize)`)."""
+
+    def __new__(cls, value: int):
+        if value < 0 or value >= 1 << 64:
+            raise ValueError("EntryID must fit usize")
+        return super().__new__(cls, value)
+
+
+class ParquetArrayID:
+    """file16 | rg16 | col16 | batch16 packing of the DataFusion layer (datafusion/src/cache/id.rs:15-21)."""
+
+    @staticmethod
+    def new(file_id: int, row_group_id: int, column_id: int, batch_id: int) -> EntryID:
+        for v in (file_id, row_group_id, column_id, batch_id):
+            if not 0 <= v <= 0xFFFF:
+                raise ValueError("ParquetArrayID fields are 16 bit")
+        return EntryID(file_id << 48 | row_group_id << 32 | column_id << 16 | batch_id)
+
+    @staticmethod
+    def column_access_path(entry_id: int) -> int:
+        """(file, row group, column) — the unit that shares one FSST compressor (id.rs:141-146)."""
+        return int(entry_id) >> 16
+
+
+class CacheExpression:
+    """Squeeze / encoding hints (only the ones that influence this path)."""
+    SUBSTRING_SEARCH = N.HINT_SUBSTRING_SEARCH
+    PREDICATE_COLUMN = N.HINT_PREDICATE_COLUMN
+
+    @staticmethod
+    def substring_search() -> int:
+        return N.HINT_SUBSTRING_SEARCH
+
+
+_OPS = {"=": N.OP_EQ, "==": N.OP_EQ, "eq": N.OP_EQ, "!=": N.OP_NE, "<>": N.OP_NE, "ne": N.OP_NE, "noteq": N.OP_NE,
+        "<": N.OP_LT, "lt": N.OP_LT, "<=": N.OP_LE, "le": N.OP_LE, "lteq": N.OP_LE, ">": N.OP_GT, "gt": N.OP_GT,
+        ">=": N.OP_GE, "ge": N.OP_GE, "gteq": N.OP_GE, "like": N.OP_LIKE, "not like": N.OP_NOT_LIKE,
+        "not_like": N.OP_NOT_LIKE}
+
+
+def _is_byte_like(t: pa.DataType) -> bool:
+    if pa.types.is_dictionary(t):
+        return _is_byte_like(t.value_type)
+    return (pa.types.is_string(t) or pa.types.is_binary(t) or pa.types.is_string_view(t)
+            or pa.types.is_binary_view(t))
+
+
+def _is_numeric_like(t: pa.DataType) -> bool:
+    return (pa.types.is_integer(t) or pa.types.is_floating(t) or pa.types.is_date(t) or pa.types.is_decimal(t)
+            or (pa.types.is_timestamp(t) and t.tz is None))
+
+
+class LiquidExpr:
+    """A predicate validated for evaluation on Liquid data: `column OP literal`, `column [NOT] LIKE pattern`
+    or a boolean literal on byte-like columns.  `try_new` returns None where the reference's
+    `LiquidExpr::try_new` returns None (liquid_expr.rs:65-148)."""
+
+    def __init__(self, op: int, lit_tag: int, lit_bytes: bytes):
+        self.op, self.lit_tag, self.lit_bytes = op, lit_tag, lit_bytes
+        self._buf = C.create_string_buffer(lit_bytes, max(len(lit_bytes), 1))
+
+    def as_predicate(self) -> N.Predicate:
+        return N.Predicate(self.op, self.lit_tag, C.cast(self._buf, C.c_void_p), len(self.lit_bytes))
+
+    @staticmethod
+    def try_new(op: Union[str, int, None], literal, data_type: pa.DataType,
+                expression_hint: Optional[int] = None) -> Optional["LiquidExpr"]:
+        if op is None:  # Literal(Boolean) (liquid_expr.rs:78-80)
+            if isinstance(literal, bool) and _is_byte_like(data_type):
+                return LiquidExpr(N.OP_EQ, N.LIT_BOOL, bytes([1 if literal else 0]))
+            return None
+        code = _OPS.get(op.lower()) if isinstance(op, str) else op
+        if code is None:
+            return None
+        if _is_byte_like(data_type):
+            if isinstance(literal, str):
+                literal = literal.encode("utf-8")
+            if not isinstance(literal, (bytes, bytearray)):
+                return None
+            if code in (N.OP_LIKE, N.OP_NOT_LIKE) and expression_hint != N.HINT_SUBSTRING_SEARCH:
+                return None  # LIKE needs the SubstringSearch hint (liquid_expr.rs:106-109, 135-137)
+            return LiquidExpr(code, N.LIT_BYTES, bytes(literal))
+        if _is_numeric_like(data_type):
+            if code > N.OP_GE:
+                return None
+            enc = _encode_numeric_literal(literal, data_type)
+            if enc is None:
+                return None
+            return LiquidExpr(code, enc[0], enc[1])
+        return None
+
+
+def _encode_numeric_literal(v, t: pa.DataType):
+    try:
+        if pa.types.is_floating(t):
+            if t.bit_width == 32:
+                return N.LIT_F32, np.float32(v).tobytes()
+            return N.LIT_F64, np.float64(v).tobytes()
+        if pa.types.is_decimal(t):
+            d = v if isinstance(v, decimal.Decimal) else decimal.Decimal(str(v))
+            unscaled = int(d.scaleb(t.scale).to_integral_value())
+            if d.scaleb(t.scale) != unscaled:
+                return None
+            return N.LIT_I128, (unscaled & ((1 << 128) - 1)).to_bytes(16, "little")
+        if pa.types.is_date32(t) and isinstance(v, datetime.date):
+            v = (v - datetime.date(1970, 1, 1)).days
+        if pa.types.is_date64(t) and isinstance(v, datetime.date):
+            v = (v - datetime.date(1970, 1, 1)).days * 86_400_000
+        if pa.types.is_timestamp(t) and isinstance(v, datetime.datetime):
+            v = pa.scalar(v, type=t).value
+        iv = int(v)
+        if pa.types.is_unsigned_integer(t):
+            if iv < 0:
+                return N.LIT_I64, int(max(iv, -(1 << 63))).to_bytes(8, "little", signed=True)
+            return N.LIT_U64, min(iv, (1 << 64) - 1).to_bytes(8, "little")
+        if iv > (1 << 63) - 1:
+            return N.LIT_U64, min(iv, (1 << 64) - 1).to_bytes(8, "little")
+        return N.LIT_I64, max(iv, -(1 << 63)).to_bytes(8, "little", signed=True)
+    except (TypeError, ValueError, decimal.InvalidOperation, pa.ArrowInvalid):
+        return None
+
+
+def _selection_bytes(selection, n: Optional[int] = None) -> np.ndarray:
+    """BooleanBuffer -> LSB-first bitmap bytes (a BooleanBuffer is not nullable)."""
+    if isinstance(selection, pa.BooleanArray):
+        if selection.null_count:
+            raise ValueError("selection must not contain nulls")
+        b = selection.to_numpy(zero_copy_only=False)
+    else:
+        b = np.asarray(selection, dtype=bool)
+    if n is not None and len(b) != n:
+        raise ValueError(f"selection has {len(b)} bits, entry has {n} rows")
+    out = np.packbits(b, bitorder="little") if b.size else np.zeros(0, np.uint8)
+    return np.ascontiguousarray(np.concatenate([out, np.zeros(8, np.uint8)]))
+
+
+def _bits_to_bool(buf: np.ndarray, n: int) -> np.ndarray:
+    if n == 0:
+        return np.zeros(0, dtype=bool)
+    return np.unpackbits(buf, bitorder="little")[:n].astype(bool)
+
+
+class LiquidCacheBuilder:
+    """`LiquidCacheBuilder::new()...build()` — options that belong to the cache manager (policies, disk store) are
+    out of scope here; batch size and the memory budget are kept."""
+
+    def __init__(self):
+        self.batch_size = 8192
+        self.max_memory_bytes = 0  # 0: bounded by HBM only (the reference default is 1 GiB of host RAM)
+        self.device: Optional[int] = None
+        self.host_only = False
+
+    @staticmethod
+    def new() -> "LiquidCacheBuilder":
+        return LiquidCacheBuilder()
+
+    def with_batch_size(self, batch_size: int) -> "LiquidCacheBuilder":
+        self.batch_size = batch_size
+        return self
+
+    def with_max_memory_bytes(self, n: int) -> "LiquidCacheBuilder":
+        self.max_memory_bytes = n
+        return self
+
+    def with_device(self, device: int) -> "LiquidCacheBuilder":
+        self.device = device
+        return self
+
+    def with_host_only(self) -> "LiquidCacheBuilder":
+        """Transcoding / symbol tables only (no GPU): every staging or evaluation call raises."""
+        self.host_only = True
+        return self
+
+    def build(self) -> "LiquidCache":
+        return LiquidCache(self)
+
+
+class _Get:
+    def __init__(self, cache: "LiquidCache", entry_id: int):
+        self._cache, self._id, self._sel = cache, entry_id, None
+
+    def with_selection(self, selection) -> "_Get":
+        self._sel = selection
+        return self
+
+    def with_expression_hint(self, _hint) -> "_Get":
+        return self
+
+    def read(self) -> Optional[pa.Array]:
+        return self._cache._read_arrow_array(self._id, self._sel)
+
+
+class _EvaluatePredicate:
+    def __init__(self, cache: "LiquidCache", entry_id: int, expr: LiquidExpr):
+        self._cache, self._id, self._expr, self._sel = cache, entry_id, expr, None
+
+    def with_selection(self, selection) -> "_EvaluatePredicate":
+        self._sel = selection
+        return self
+
+    def read(self) -> Optional[pa.BooleanArray]:
+        return self._cache._eval_predicate_internal(self._id, self._sel, self._expr)
+
+
+class LiquidCache:
+    def __init__(self, builder: LiquidCacheBuilder):
+        self._lib = N.load()
+        self._batch_size = builder.batch_size
+        ctx = C.c_void_p()
+        if builder.host_only:
+            st = self._lib.lc_ctx_create(None, 0, builder.max_memory_bytes, C.byref(ctx))
+        elif builder.device is None:
+            st = self._lib.lc_ctx_create(None, 1, builder.max_memory_bytes, C.byref(ctx))
+        else:
+            dev = (C.c_int32 * 1)(builder.device)
+            st = self._lib.lc_ctx_create(dev, 1, builder.max_memory_bytes, C.byref(ctx))
+        N.check(st, None)
+        self._ctx = ctx
+        self._types = {}
+
+    # -- lifecycle ---------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.lc_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def batch_size(self) -> int:
+        return self._batch_size
+
+    @property
+    def handle(self) -> C.c_void_p:
+        return self._ctx
+
+    def device_info(self) -> N.DeviceInfo:
+        info = N.DeviceInfo()
+        N.check(self._lib.lc_device_info_get(self._ctx, C.byref(info)), self._ctx)
+        return info
+
+    # -- staging -----------------------------------------------------------------------------------
+    def set_symbol_table(self, path_id: int, table_bytes: bytes):
+        buf = (C.c_uint8 * len(table_bytes)).from_buffer_copy(table_bytes)
+        N.check(self._lib.lc_symtab_set(self._ctx, path_id, buf, len(table_bytes)), self._ctx)
+
+    def symbol_table(self, path_id: int) -> Optional[bytes]:
+        out, ln = C.c_void_p(), C.c_size_t()
+        st = self._lib.lc_symtab_get(self._ctx, path_id, C.byref(out), C.byref(ln))
+        if st == N.LC_NOT_STAGED:
+            return None
+        N.check(st, self._ctx)
+        data = C.string_at(out, ln.value)
+        self._lib.lc_free(out)
+        return data
+
+    def stage(self, entry_ids: Sequence[int], liquid_bytes: Sequence[bytes], path_ids: Optional[Sequence[int]] = None,
+              data_types: Optional[Sequence[pa.DataType]] = None):
+        """Stage serialized LiquidArrays (`LiquidArray::to_bytes()` output) in HBM."""
+        n = len(entry_ids)
+        ids = (C.c_uint64 * n)(*[int(e) for e in entry_ids])
+        keep = [(C.c_uint8 * len(b)).from_buffer_copy(b) for b in liquid_bytes]
+        ptrs = (C.c_void_p * n)(*[C.cast(k, C.c_void_p) for k in keep])
+        lens = (C.c_size_t * n)(*[len(b) for b in liquid_bytes])
+        if path_ids is None:
+            path_ids = [ParquetArrayID.column_access_path(e) for e in entry_ids]
+        pids = (C.c_uint64 * n)(*[int(p) for p in path_ids])
+        N.check(self._lib.lc_stage(self._ctx, n, ids, ptrs, lens, pids), self._ctx)
+        if data_types is not None:
+            for e, t in zip(entry_ids, data_types):
+                self._types[int(e)] = t
+
+    def transcode(self, array: pa.Array, squeeze_hint: Optional[int] = None, path_id: int = 0) -> Optional[bytes]:
+        """Arrow -> Liquid bytes (transcode_liquid_inner_with_hint); None for types that stay Arrow."""
+        c_arr, c_schema = N.ArrowArray(), N.ArrowSchema()
+        array._export_to_c(C.addressof(c_arr), C.addressof(c_schema))
+        out, ln = C.c_void_p(), C.c_size_t()
+        try:
+            st = self._lib.lc_transcode_arrow(self._ctx, C.addressof(c_arr), C.addressof(c_schema),
+                                              squeeze_hint or N.HINT_NONE, path_id, C.byref(out), C.byref(ln))
+        finally:
+            _release(c_arr, c_schema)
+        if st == N.LC_UNSUPPORTED:
+            return None
+        N.check(st, self._ctx)
+        data = C.string_at(out, ln.value)
+        self._lib.lc_free(out)
+        return data
+
+    def insert(self, entry_id: int, batch_to_cache: pa.Array, squeeze_hint: Optional[int] = None,
+               path_id: Optional[int] = None):
+        """`cache.insert(entry_id, array)` with eager transcoding (bench mode `liquid_eager_transcode`)."""
+        if isinstance(batch_to_cache, pa.ChunkedArray):
+            batch_to_cache = batch_to_cache.combine_chunks()
+        pid = ParquetArrayID.column_access_path(entry_id) if path_id is None else path_id
+        c_arr, c_schema = N.ArrowArray(), N.ArrowSchema()
+        batch_to_cache._export_to_c(C.addressof(c_arr), C.addressof(c_schema))
+        try:
+            st = self._lib.lc_insert_arrow(self._ctx, int(entry_id), C.addressof(c_arr), C.addressof(c_schema),
+                                           squeeze_hint or N.HINT_NONE, pid)
+        finally:
+            _release(c_arr, c_schema)
+        N.check(st, self._ctx)
+        self._types[int(entry_id)] = batch_to_cache.type
+
+    def evict(self, entry_ids: Iterable[int]):
+        ids = [int(e) for e in entry_ids]
+        arr = (C.c_uint64 * len(ids))(*ids)
+        N.check(self._lib.lc_evict(self._ctx, len(ids), arr), self._ctx)
+        for e in ids:
+            self._types.pop(e, None)
+
+    def entry_info(self, entry_id: int) -> Optional[N.EntryInfo]:
+        info = N.EntryInfo()
+        st = self._lib.lc_entry_info_get(self._ctx, int(entry_id), C.byref(info))
+        if st == N.LC_NOT_STAGED:
+            return None
+        N.check(st, self._ctx)
+        return info
+
+    def is_cached(self, entry_id: int) -> bool:
+        return self.entry_info(entry_id) is not None
+
+    # -- the two hot-path calls ----------------------------------------------------------------------
+    def get(self, entry_id: int) -> _Get:
+        return _Get(self, int(entry_id))
+
+    def eval_predicate(self, entry_id: int, predicate: LiquidExpr) -> _EvaluatePredicate:
+        return _EvaluatePredicate(self, int(entry_id), predicate)
+
+    def _eval_predicate_internal(self, entry_id: int, selection, expr: LiquidExpr) -> Optional[pa.BooleanArray]:
+        info = self.entry_info(entry_id)
+        if info is None:
+            return None
+        n = info.len
+        sel = _selection_bytes(selection, n) if selection is not None else None
+        nb = (n + 7) // 8 + 8
+        values = np.zeros(nb, np.uint8)
+        validity = np.zeros(nb, np.uint8)
+        out_len, nullable = C.c_uint32(), C.c_int32()
+        pred = expr.as_predicate()
+        st = self._lib.lc_eval_predicate(self._ctx, entry_id, C.byref(pred),
+                                         sel.ctypes.data_as(C.c_void_p) if sel is not None else None,
+                                         values.ctypes.data_as(C.c_void_p), validity.ctypes.data_as(C.c_void_p),
+                                         C.byref(out_len), C.byref(nullable))
+        if st == N.LC_NOT_STAGED:
+            return None
+        N.check(st, self._ctx)
+        k = out_len.value
+        v = _bits_to_bool(values, k)
+        if nullable.value:
+            valid = _bits_to_bool(validity, k)
+            return pa.array(v, type=pa.bool_(), mask=~valid)
+        return pa.array(v, type=pa.bool_())
+
+    def _read_arrow_array(self, entry_id: int, selection) -> Optional[pa.Array]:
+        info = self.entry_info(entry_id)
+        if info is None:
+            return None
+        sel = _selection_bytes(selection, info.len) if selection is not None else None
+        c_arr, c_schema = N.ArrowArray(), N.ArrowSchema()
+        st = self._lib.lc_get_with_selection(self._ctx, entry_id,
+                                             sel.ctypes.data_as(C.c_void_p) if sel is not None else None,
+                                             C.addressof(c_arr), C.addressof(c_schema))
+        if st == N.LC_NOT_STAGED:
+            return None
+        N.check(st, self._ctx)
+        arr = pa.Array._import_from_c(C.addressof(c_arr), C.addressof(c_schema))
+        want = self._types.get(int(entry_id))
+        if want is not None and arr.type != want:
+            arr = arr.cast(want)
+        return arr
+
+    # -- scans ---------------------------------------------------------------------------------------
+    def scan(self, entry_ids: Sequence[int]) -> "Scan":
+        return Scan(self, entry_ids)
+
+
+def _release(c_arr: N.ArrowArray, c_schema: N.ArrowSchema):
+    for s in (c_arr, c_schema):
+        if s.release:
+            C.CFUNCTYPE(None, C.c_void_p)(s.release)(C.addressof(s))
+
+
+class Scan:
+    """Device-resident column scan (lc_scan_*): ordered entries of one column, hit mask kept in HBM."""
+
+    def __init__(self, cache: LiquidCache, entry_ids: Sequence[int]):
+        self._cache = cache
+        self._lib = cache._lib
+        ids = np.ascontiguousarray(np.asarray([int(e) for e in entry_ids], dtype=np.uint64))
+        h = C.c_void_p()
+        N.check(self._lib.lc_scan_create(cache.handle, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                         C.byref(h)), cache.handle)
+        self._h = h
+        self.entries = len(ids)
+        self.rows = self._lib.lc_scan_rows(h)
+        self.mask_words = self._lib.lc_scan_mask_words(h)
+        seg = self._lib.lc_scan_segment_offsets(h)
+        self.segment_offsets = np.ctypeslib.as_array(seg, shape=(self.entries + 1,)).copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lc_scan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def algorithmic_bytes(self, expr: LiquidExpr, with_selection: bool = False) -> int:
+        pred = expr.as_predicate()
+        return self._lib.lc_scan_algorithmic_bytes(self._h, C.byref(pred), int(with_selection))
+
+    def eval(self, expr: LiquidExpr, mask_out_ptr: int, selection_ptr: int = 0, counts_ptr: int = 0,
+             stream: int = 0):
+        """Asynchronous: raw device pointers (e.g. torch tensor .data_ptr()) and a hipStream_t handle."""
+        pred = expr.as_predicate()
+        N.check(self._lib.lc_scan_eval(self._cache.handle, self._h, C.byref(pred), C.c_void_p(selection_ptr or None),
+                                       C.c_void_p(mask_out_ptr), C.c_void_p(counts_ptr or None),
+                                       C.c_void_p(stream or None)), self._cache.handle)
+
+    def eval_timed(self, expr: LiquidExpr, mask_out_ptr: int, iters: int, selection_ptr: int = 0,
+                   counts_ptr: int = 0, stream: int = 0) -> float:
+        """Average kernel-side milliseconds per evaluation, HIP events on `stream`."""
+        pred = expr.as_predicate()
+        ms = C.c_float()
+        N.check(self._lib.lc_scan_eval_timed(self._cache.handle, self._h, C.byref(pred),
+                                             C.c_void_p(selection_ptr or None), C.c_void_p(mask_out_ptr),
+                                             C.c_void_p(counts_ptr or None), C.c_void_p(stream or None), iters,
+                                             C.byref(ms)), self._cache.handle)
+        return ms.value
+
+    def eval_to_host(self, expr: LiquidExpr, selection: Optional[np.ndarray] = None):
+        """Convenience for tests: runs the scan and returns (mask words as uint64 ndarray, per-entry counts)."""
+        lib, ctx = self._lib, self._cache.handle
+        words = max(int(self.mask_words), 1)
+        d_mask, d_counts, d_sel = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(lib.lc_device_alloc(ctx, words * 8, C.byref(d_mask)), ctx)
+        N.check(lib.lc_device_alloc(ctx, max(self.entries, 1) * 4, C.byref(d_counts)), ctx)
+        try:
+            if selection is not None:
+                sel = np.ascontiguousarray(selection, dtype=np.uint64)
+                assert sel.size == self.mask_words
+                N.check(lib.lc_device_alloc(ctx, words * 8, C.byref(d_sel)), ctx)
+                N.check(lib.lc_host_to_device(ctx, d_sel, sel.ctypes.data_as(C.c_void_p), sel.size * 8, None), ctx)
+            pred = expr.as_predicate()
+            N.check(lib.lc_scan_eval(ctx, self._h, C.byref(pred), d_sel if selection is not None else None, d_mask,
+                                     d_counts, None), ctx)
+            mask = np.zeros(words, np.uint64)
+            counts = np.zeros(max(self.entries, 1), np.uint32)
+            N.check(lib.lc_device_to_host(ctx, mask.ctypes.data_as(C.c_void_p), d_mask, words * 8, None), ctx)
+            N.check(lib.lc_device_to_host(ctx, counts.ctypes.data_as(C.c_void_p), d_counts, counts.size * 4, None), ctx)
+        finally:
+            for p in (d_mask, d_counts, d_sel):
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+        return mask[: int(self.mask_words)], counts[: self.entries]
+
+
+def boolean_buffer_and_then(cache: LiquidCache, left, right) -> np.ndarray:
+    """`boolean_buffer_and_then(left, right)`; popcount(left) must equal len(right)."""
+    lb = np.asarray(left, dtype=bool)
+    rb = np.asarray(right, dtype=bool)
+    if int(lb.sum()) != len(rb):
+        raise ValueError("the right selection must have as many bits as the left selection has set bits")
+    l_bytes, r_bytes = _selection_bytes(lb), _selection_bytes(rb)
+    out = np.zeros(len(l_bytes), np.uint8)
+    N.check(cache._lib.lc_mask_and_then(cache.handle, l_bytes.ctypes.data_as(C.c_void_p), len(lb),
+                                        r_bytes.ctypes.data_as(C.c_void_p), len(rb),
+                                        out.ctypes.data_as(C.c_void_p)), cache.handle)
+    return _bits_to_bool(out, len(lb))

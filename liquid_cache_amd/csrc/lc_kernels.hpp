@@ -1,0 +1,118 @@
+// Device-side descriptors and kernel launchers (implemented in lc_kernels.hip).
+//
+// HBM layout: every staged entry owns one blob inside a context slab; sections are 128-byte aligned.
+//   fixed-width entry : [FastLanes packed values: ceil(len/1024) blocks of 128*W bytes][validity as u64 words]
+//                       [ALP patch indices u64][ALP patch values]
+//   byte-view entry   : [keys u16 x n, plain row order][validity u64 words][prefix keys 8 x D][fingerprints u32 x D]
+//                       [offset residuals (1|2|4) x (D+1)][FSST bytes + 16 pad][shared prefix]
+// A scan owns a device array of descriptors (one per entry, in scan order).  Masks are per-entry segments of
+// ceil(len/64) u64 words (LSB first == Arrow bitmap bytes on little endian).
+#pragma once
+
+#include <cstdint>
+
+#include <hip/hip_runtime.h>
+
+namespace lc {
+
+constexpr int kMaxNeedleAutomaton = 63;  // KMP automaton states must fit a u8 table staged in LDS
+constexpr int kMaxNeedleBytes = 4096;
+
+enum FixedKind : uint8_t { kKindInt = 0, kKindDecimal = 1, kKindF32 = 2, kKindF64 = 3 };
+
+struct alignas(16) FixedDesc {
+    const uint8_t* packed;     // 128-byte aligned
+    const uint64_t* validity;  // nullptr when the entry has no validity buffer
+    const uint64_t* patch_idx; // ALP
+    const uint8_t* patch_val;  // ALP
+    uint64_t reference;        // FoR reference, sign-extended to 64 bits for signed logical types
+    uint64_t mask_word_off;    // first u64 word of this entry's mask segment inside the scan mask
+    uint32_t len;
+    uint32_t patch_len;
+    uint8_t W;                 // 0 => all null
+    uint8_t lane_log2;         // 3..6
+    uint8_t is_signed;
+    uint8_t kind;              // FixedKind
+    uint8_t alp_e, alp_f;
+    uint8_t value_width;       // bytes of a decoded Arrow value
+    uint8_t pad;
+};
+static_assert(sizeof(FixedDesc) == 64, "FixedDesc layout");
+
+struct alignas(16) StrDesc {
+    const uint16_t* keys;
+    const uint64_t* validity;
+    const uint8_t* prefix_keys;
+    const uint32_t* fingerprints;  // nullptr when absent
+    const uint8_t* residuals;
+    const uint8_t* fsst;
+    const uint8_t* shared_prefix;
+    uint64_t mask_word_off;
+    int32_t slope, intercept;
+    uint32_t n, d;
+    uint32_t fsst_len, shared_prefix_len;
+    uint32_t symtab_slot;
+    uint8_t offset_bytes;
+    uint8_t pad[3];
+};
+static_assert(sizeof(StrDesc) == 96, "StrDesc layout");
+
+// Symbol table as the kernels see it.
+struct DevSymtab {
+    uint64_t sym[256];
+    uint8_t len[256];
+};
+
+// Integer-domain predicate after host normalisation of the literal.
+struct FixedPred {
+    int32_t op;           // LC_OP_EQ..LC_OP_GE
+    int32_t lit_class;    // -1: literal below every representable value, +1: above, 0: `lit` is exact
+    uint64_t lit;         // int64 bits (signed logical types) or uint64
+    uint32_t lit_f32;     // float predicates: raw IEEE bits of the literal
+    uint32_t pad;
+    uint64_t lit_f64;
+};
+
+constexpr int kInlineNeedle = 64;
+
+struct StrPred {
+    int32_t op;            // LC_OP_*
+    int32_t mode;          // 0: Eq/Ne/ordering on `needle`, 1: substring automaton (LIKE %needle%), 2: constant
+    uint32_t needle_len;
+    int32_t use_fingerprints;  // LIKE: prune with fingerprints (and apply the reference's candidate quirk)
+    const uint8_t* needle;     // device copy when needle_len > kInlineNeedle (padded by 8 bytes)
+    const uint8_t* automata;   // mode 1: per symbol-table-slot transition tables, (m+1)*512 bytes each
+    uint32_t automaton_stride;
+    int32_t const_value;       // mode 2: Literal(Boolean)
+    uint8_t needle_inline[kInlineNeedle];
+};
+
+struct ScanLaunch {
+    uint32_t n_entries;
+    uint32_t blocks_per_entry;  // ceil(max entry len / 1024)
+    const uint64_t* d_selection;
+    uint64_t* d_hit;      // pred & valid & selected
+    uint64_t* d_valid;    // optional: valid & selected
+    uint32_t* d_counts;   // optional, must be zeroed by the launcher
+    uint32_t* d_cand_bytes;  // optional (byte views): per entry, compressed bytes of the candidates that were walked
+};
+
+hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
+                             hipStream_t stream);
+hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, const uint8_t* needle,
+                               uint32_t needle_len, uint8_t* d_automata, hipStream_t stream);
+hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, const StrPred& pred,
+                           const ScanLaunch& L, hipStream_t stream);
+// per-block selected-row counts -> exclusive offsets, then compaction of decoded values
+hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
+                               uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
+                               uint8_t* d_validity_bytes_out, hipStream_t stream);
+// bit compress (PEXT) / deposit (PDEP) per entry segment
+hipError_t launch_mask_compress(const uint64_t* d_src, const uint64_t* d_sel, const uint64_t* d_seg_offsets,
+                                uint32_t n_entries, uint64_t* d_out, uint32_t* d_out_bits, hipStream_t stream);
+hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, const uint64_t* d_right, uint64_t* d_out,
+                                hipStream_t stream);
+hipError_t launch_str_gather_lengths(const StrDesc* d_descs, const DevSymtab* d_symtabs, uint32_t entry,
+                                     const uint64_t* d_selection, uint32_t* d_dict_len, hipStream_t stream);
+
+}  // namespace lc

@@ -1,0 +1,1013 @@
+// Runtime behind the C ABI (include/liquid_cache_amd.h): context, HBM arena, staging of Liquid IPC bytes,
+// column scans and the per-entry drop-in calls.  Host logic only — all arithmetic on cached data happens in
+// lc_kernels.hip.  There is deliberately NO CPU fallback: without a HIP device every call fails with LC_ERR_DEVICE.
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "lc_host.hpp"
+#include "lc_kernels.hpp"
+#include "lc_transcode.hpp"
+
+using namespace lc;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+lc_status fail(lc_status st, const std::string& msg) {
+    g_last_error = msg;
+    return st;
+}
+
+#define LC_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(LC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+    } while (0)
+
+constexpr size_t kSlabBytes = size_t(256) << 20;
+constexpr size_t kSectionAlign = 128;
+
+struct Slab {
+    uint8_t* base = nullptr;
+    size_t size = 0, used = 0;
+    int64_t live = 0;
+};
+
+struct Entry {
+    bool is_str = false;
+    int logical = 0, phys = 0;
+    uint32_t len = 0;
+    bool nullable = false, all_null = false;
+    int W = 0;
+    FixedDesc fd{};
+    StrDesc sd{};
+    uint64_t path_id = 0;
+    uint32_t dict_len = 0;
+    bool has_fp = false;
+    int dec_precision = 0, dec_scale = 0, dec_is256 = 0;
+    size_t device_bytes = 0;
+    int slab = -1;
+    uint32_t offsets_bytes = 0;  // compact offset residual bytes (byte views)
+    uint32_t fsst_len = 0;
+};
+
+}  // namespace
+
+struct lc_ctx {
+    int device = 0;
+    hipDeviceProp_t props{};
+    std::shared_mutex mu;
+    std::unordered_map<uint64_t, Entry> entries;
+    std::vector<Slab> slabs;
+    uint64_t max_hbm = 0;
+    uint64_t staged_bytes = 0;
+    // symbol tables
+    std::mutex st_mu;
+    std::unordered_map<uint64_t, uint32_t> symtab_slot;
+    std::vector<std::unique_ptr<SymbolTable>> symtabs;
+    DevSymtab* d_symtabs = nullptr;
+    size_t d_symtabs_cap = 0;
+    size_t d_symtabs_uploaded = 0;
+};
+
+struct lc_scan {
+    lc_ctx* ctx = nullptr;
+    bool is_str = false;
+    int lane_log2 = 0;
+    uint32_t n = 0, bpe = 0;
+    std::vector<uint64_t> seg_offsets;  // n+1 word offsets
+    uint64_t total_rows = 0;
+    void* d_descs = nullptr;
+    uint64_t* d_seg_offsets = nullptr;
+    std::vector<Entry> meta;  // copies of the entries' metadata (descs have mask_word_off filled in)
+    // LIKE scratch
+    uint8_t* d_automata = nullptr;
+    size_t automata_cap = 0;
+    uint8_t* d_needle = nullptr;
+    size_t needle_cap = 0;
+    std::mutex mu;
+};
+
+namespace {
+
+// ------------------------------------------------------------------ arena
+lc_status arena_alloc(lc_ctx* ctx, size_t bytes, uint8_t** out, int* slab_idx) {
+    bytes = align_up(bytes, kSectionAlign);
+    if (!ctx->slabs.empty()) {
+        Slab& s = ctx->slabs.back();
+        if (s.base && s.used + bytes <= s.size) {
+            *out = s.base + s.used;
+            s.used += bytes;
+            s.live++;
+            *slab_idx = int(ctx->slabs.size()) - 1;
+            return LC_OK;
+        }
+    }
+    const size_t want = std::max(bytes, kSlabBytes);
+    if (ctx->max_hbm && ctx->staged_bytes + want > ctx->max_hbm)
+        return fail(LC_ERR_OOM, "HBM budget exhausted (max_hbm_bytes)");
+    Slab s;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.base), want);
+    if (e != hipSuccess) return fail(LC_ERR_OOM, std::string("hipMalloc slab: ") + hipGetErrorString(e));
+    s.size = want;
+    s.used = bytes;
+    s.live = 1;
+    ctx->slabs.push_back(s);
+    ctx->staged_bytes += want;
+    *out = s.base;
+    *slab_idx = int(ctx->slabs.size()) - 1;
+    return LC_OK;
+}
+
+void arena_release(lc_ctx* ctx, int slab_idx) {
+    if (slab_idx < 0 || size_t(slab_idx) >= ctx->slabs.size()) return;
+    Slab& s = ctx->slabs[size_t(slab_idx)];
+    if (--s.live == 0 && size_t(slab_idx) + 1 != ctx->slabs.size() && s.base) {
+        (void)hipFree(s.base);
+        ctx->staged_bytes -= s.size;
+        s.base = nullptr;
+    }
+}
+
+// ------------------------------------------------------------------ symbol tables
+struct CtxSymtabs : SymtabProvider {
+    lc_ctx* ctx;
+    explicit CtxSymtabs(lc_ctx* c) : ctx(c) {}
+    const SymbolTable* find(uint64_t path_id) override {
+        std::lock_guard<std::mutex> g(ctx->st_mu);
+        auto it = ctx->symtab_slot.find(path_id);
+        return it == ctx->symtab_slot.end() ? nullptr : ctx->symtabs[it->second].get();
+    }
+    const SymbolTable* insert(uint64_t path_id, const SymbolTable& st) override {
+        std::lock_guard<std::mutex> g(ctx->st_mu);
+        auto it = ctx->symtab_slot.find(path_id);
+        if (it != ctx->symtab_slot.end()) return ctx->symtabs[it->second].get();
+        ctx->symtab_slot[path_id] = uint32_t(ctx->symtabs.size());
+        ctx->symtabs.emplace_back(new SymbolTable(st));
+        return ctx->symtabs.back().get();
+    }
+};
+
+// make sure every registered symbol table is resident on the device
+lc_status sync_symtabs(lc_ctx* ctx) {
+    std::lock_guard<std::mutex> g(ctx->st_mu);
+    const size_t n = ctx->symtabs.size();
+    if (n == ctx->d_symtabs_uploaded) return LC_OK;
+    if (n > ctx->d_symtabs_cap) {
+        const size_t cap = std::max<size_t>(1024, n * 2);
+        DevSymtab* fresh = nullptr;
+        LC_HIP(hipMalloc(reinterpret_cast<void**>(&fresh), cap * sizeof(DevSymtab)));
+        if (ctx->d_symtabs) {
+            LC_HIP(hipDeviceSynchronize());
+            LC_HIP(hipMemcpy(fresh, ctx->d_symtabs, ctx->d_symtabs_uploaded * sizeof(DevSymtab),
+                             hipMemcpyDeviceToDevice));
+            LC_HIP(hipFree(ctx->d_symtabs));
+        }
+        ctx->d_symtabs = fresh;
+        ctx->d_symtabs_cap = cap;
+    }
+    std::vector<DevSymtab> host(n - ctx->d_symtabs_uploaded);
+    for (size_t i = ctx->d_symtabs_uploaded; i < n; i++) {
+        DevSymtab& d = host[i - ctx->d_symtabs_uploaded];
+        const SymbolTable& s = *ctx->symtabs[i];
+        for (int c = 0; c < 256; c++) {
+            d.sym[c] = c < s.n ? s.sym[c] : 0;
+            d.len[c] = c < s.n ? s.len[c] : 0;
+        }
+    }
+    LC_HIP(hipMemcpy(ctx->d_symtabs + ctx->d_symtabs_uploaded, host.data(), host.size() * sizeof(DevSymtab),
+                     hipMemcpyHostToDevice));
+    ctx->d_symtabs_uploaded = n;
+    return LC_OK;
+}
+
+// ------------------------------------------------------------------ staging
+struct Blob {
+    std::vector<uint8_t> bytes;
+    size_t add(const void* src, size_t n, size_t pad_to = kSectionAlign, size_t extra_zero = 0) {
+        const size_t off = align_up(bytes.size(), pad_to);
+        bytes.resize(off + n + extra_zero, 0);
+        if (n && src) std::memcpy(bytes.data() + off, src, n);
+        return off;
+    }
+};
+
+// validity bitmap -> u64 words (zero padded)
+size_t add_validity(Blob& b, const uint8_t* validity, size_t nbits) {
+    const size_t words = (nbits + 63) / 64;
+    const size_t off = b.add(nullptr, 0);
+    b.bytes.resize(off + words * 8, 0);
+    std::memcpy(b.bytes.data() + off, validity, bitmap_bytes(nbits));
+    if (nbits & 7) b.bytes[off + bitmap_bytes(nbits) - 1] &= uint8_t((1u << (nbits & 7)) - 1);
+    return off;
+}
+
+lc_status build_fixed(const uint8_t* bytes, size_t len, Entry* e, Blob* blob, size_t* off_packed, size_t* off_valid,
+                      size_t* off_pidx, size_t* off_pval) {
+    FixedView v;
+    if (!parse_fixed(bytes, len, &v)) return fail(LC_ERR_CORRUPT, "malformed Liquid fixed-width array");
+    e->is_str = false;
+    e->logical = v.logical;
+    e->phys = v.phys;
+    e->len = v.bp.len;
+    e->nullable = v.bp.has_nulls || v.bp.all_null;
+    e->all_null = v.bp.all_null;
+    e->W = v.bp.all_null ? 0 : v.bp.bit_width;
+    e->dec_is256 = v.dec_is256;
+    e->dec_precision = v.dec_precision;
+    e->dec_scale = v.dec_scale;
+    FixedDesc& d = e->fd;
+    d = FixedDesc{};
+    d.len = e->len;
+    d.W = uint8_t(e->W);
+    d.lane_log2 = uint8_t(v.lane_bits == 8 ? 3 : v.lane_bits == 16 ? 4 : v.lane_bits == 32 ? 5 : 6);
+    d.value_width = uint8_t(v.value_width);
+    if (v.logical == kInteger) {
+        d.kind = kKindInt;
+        d.is_signed = phys_unsigned(v.phys) ? 0 : 1;
+        uint64_t r = v.reference;
+        if (d.is_signed) {  // sign-extend the native-width reference
+            const int w = phys_width(v.phys);
+            if (w == 1) r = uint64_t(int64_t(int8_t(r)));
+            else if (w == 2) r = uint64_t(int64_t(int16_t(r)));
+            else if (w == 4) r = uint64_t(int64_t(int32_t(r)));
+        }
+        d.reference = r;
+    } else if (v.logical == kDecimal) {
+        d.kind = kKindDecimal;
+        d.is_signed = 0;
+        d.reference = v.reference;
+    } else {
+        d.kind = v.phys == kF32 ? kKindF32 : kKindF64;
+        d.is_signed = 1;
+        d.reference = v.phys == kF32 ? uint64_t(int64_t(int32_t(uint32_t(v.reference)))) : v.reference;
+        d.alp_e = uint8_t(v.alp_e);
+        d.alp_f = uint8_t(v.alp_f);
+        d.patch_len = uint32_t(v.patch_len);
+    }
+    *off_packed = *off_valid = *off_pidx = *off_pval = size_t(-1);
+    if (!e->all_null) {
+        // +128 zero bytes so 16-byte loads of the last block never leave the blob
+        *off_packed = blob->add(v.bp.values, packed_bytes(e->W, e->len), kSectionAlign, 128);
+        if (v.bp.has_nulls) *off_valid = add_validity(*blob, v.bp.nulls, e->len);
+        if (v.patch_len) {
+            *off_pidx = blob->add(v.patch_indices, size_t(v.patch_len) * 8);
+            *off_pval = blob->add(v.patch_values, size_t(v.patch_len) * size_t(v.value_width));
+        }
+    }
+    return LC_OK;
+}
+
+lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path_id, Entry* e, Blob* blob,
+                    size_t offs[7]) {
+    ByteViewParsed v;
+    if (!parse_byte_view(bytes, len, &v)) return fail(LC_ERR_CORRUPT, "malformed Liquid byte-view array");
+    uint32_t slot;
+    {
+        std::lock_guard<std::mutex> g(ctx->st_mu);
+        auto it = ctx->symtab_slot.find(path_id);
+        if (it == ctx->symtab_slot.end())
+            return fail(LC_ERR_NO_SYMTAB, "byte-view entry staged before lc_symtab_set for its path");
+        slot = it->second;
+        // every code in the compressed bytes must exist in the table
+        const SymbolTable& st = *ctx->symtabs[slot];
+        for (uint32_t i = 0; i < v.fsst_len; i++) {
+            const uint8_t c = v.fsst[i];
+            if (c == kFsstEscape) { i++; continue; }
+            if (c >= st.n) return fail(LC_ERR_CORRUPT, "FSST code outside the registered symbol table");
+        }
+    }
+    e->is_str = true;
+    e->logical = kByteView;
+    e->phys = v.arrow_type;
+    e->len = v.n;
+    e->nullable = v.nullable;
+    e->all_null = v.all_null;
+    e->W = 16;
+    e->path_id = path_id;
+    e->dict_len = v.d;
+    e->has_fp = v.fingerprints != nullptr;
+    e->offsets_bytes = v.residual_count * uint32_t(v.offset_bytes);
+    e->fsst_len = v.fsst_len;
+    StrDesc& d = e->sd;
+    d = StrDesc{};
+    d.n = v.n;
+    d.d = v.d;
+    d.slope = v.slope;
+    d.intercept = v.intercept;
+    d.offset_bytes = uint8_t(v.offset_bytes);
+    d.fsst_len = v.fsst_len;
+    d.shared_prefix_len = v.shared_prefix_len;
+    d.symtab_slot = slot;
+    for (int i = 0; i < 7; i++) offs[i] = size_t(-1);
+    // keys padded to a multiple of 8 (16-byte loads)
+    offs[0] = blob->add(v.keys.data(), size_t(v.n) * 2, kSectionAlign, 16);
+    if (v.nullable) {
+        if (v.all_null) {
+            std::vector<uint8_t> zeros(bitmap_bytes(v.n) + 8, 0);
+            offs[1] = add_validity(*blob, zeros.data(), v.n);
+        } else {
+            offs[1] = add_validity(*blob, v.key_validity, v.n);
+        }
+    }
+    offs[2] = blob->add(v.prefix_keys, size_t(v.d) * 8);
+    if (v.fingerprints) offs[3] = blob->add(v.fingerprints, size_t(v.d) * 4);
+    offs[4] = blob->add(v.residuals, size_t(v.residual_count) * size_t(v.offset_bytes), kSectionAlign, 8);
+    offs[5] = blob->add(v.fsst, v.fsst_len, kSectionAlign, 16);
+    offs[6] = blob->add(v.shared_prefix, v.shared_prefix_len, kSectionAlign, 8);
+    return LC_OK;
+}
+
+uint64_t fixed_alg_bytes(const Entry& e, bool with_sel) {
+    // n*W/8 packed + n/8 selection + n/8 validity (nullable) + n/8 output
+    const uint64_t n = e.len, m = (n + 7) / 8;
+    return n * uint64_t(e.W) / 8 + (with_sel ? m : 0) + (e.nullable ? m : 0) + m;
+}
+
+// ------------------------------------------------------------------ predicate normalisation
+lc_status make_fixed_pred(const Entry& e, const lc_predicate* p, FixedPred* out) {
+    if (p->op < LC_OP_EQ || p->op > LC_OP_GE) return fail(LC_UNSUPPORTED, "operator not supported on numeric columns");
+    *out = FixedPred{};
+    out->op = p->op;
+    if (e.fd.kind == kKindF32 || e.fd.kind == kKindF64)
+        return fail(LC_UNSUPPORTED, "float predicates run on the reference CPU path in this build");
+    if (!p->lit) return fail(LC_ERR_INVALID, "literal is null");
+    if (e.fd.kind == kKindDecimal) {
+        __int128 v;
+        if (p->lit_tag == LC_LIT_I128 && p->lit_len == 16) std::memcpy(&v, p->lit, 16);
+        else if (p->lit_tag == LC_LIT_I64 && p->lit_len == 8) { int64_t t; std::memcpy(&t, p->lit, 8); v = t; }
+        else return fail(LC_ERR_INVALID, "decimal predicate needs an i128/i64 literal");
+        if (v < 0) out->lit_class = -1;
+        else if (v > __int128(UINT64_MAX)) out->lit_class = 1;
+        else out->lit = uint64_t(v);
+        return LC_OK;
+    }
+    if (p->lit_len != 8 || (p->lit_tag != LC_LIT_I64 && p->lit_tag != LC_LIT_U64))
+        return fail(LC_ERR_INVALID, "integer predicate needs an i64/u64 literal");
+    uint64_t raw;
+    std::memcpy(&raw, p->lit, 8);
+    if (e.fd.is_signed) {
+        if (p->lit_tag == LC_LIT_U64 && raw > uint64_t(INT64_MAX)) out->lit_class = 1;
+        else out->lit = raw;
+    } else {
+        if (p->lit_tag == LC_LIT_I64 && int64_t(raw) < 0) out->lit_class = -1;
+        else out->lit = raw;
+    }
+    return LC_OK;
+}
+
+struct StrPredHost {
+    StrPred p{};
+    std::vector<uint8_t> needle;
+};
+
+lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
+    out->p = StrPred{};
+    out->p.op = p->op;
+    if (p->lit_tag == LC_LIT_BOOL) {  // liquid_expr.rs:78-80 + helpers.rs:72-79
+        if (!p->lit || p->lit_len < 1) return fail(LC_ERR_INVALID, "boolean literal missing");
+        out->p.mode = 2;
+        out->p.const_value = static_cast<const uint8_t*>(p->lit)[0] ? 1 : 0;
+        return LC_OK;
+    }
+    if (p->lit_tag != LC_LIT_BYTES) return fail(LC_UNSUPPORTED, "byte-view predicate needs a bytes literal");
+    const uint8_t* lit = static_cast<const uint8_t*>(p->lit);
+    const size_t ll = size_t(p->lit_len);
+    if (p->op >= LC_OP_EQ && p->op <= LC_OP_GE) {
+        if (ll > size_t(kMaxNeedleBytes)) return fail(LC_UNSUPPORTED, "needle longer than 4096 bytes");
+        out->p.mode = 0;
+        out->needle.assign(lit, lit + ll);
+    } else if (p->op == LC_OP_LIKE || p->op == LC_OP_NOT_LIKE) {
+        const uint8_t* inner;
+        size_t il;
+        if (!substring_pattern(lit, ll, &inner, &il))
+            return fail(LC_UNSUPPORTED, "only %needle% LIKE patterns are evaluated on the device");
+        if (il > size_t(kMaxNeedleAutomaton)) return fail(LC_UNSUPPORTED, "LIKE needle longer than 63 bytes");
+        out->p.mode = 1;
+        out->p.use_fingerprints = 1;
+        out->needle.assign(inner, inner + il);
+    } else {
+        return fail(LC_UNSUPPORTED, "operator not supported on byte-view columns");
+    }
+    out->p.needle_len = uint32_t(out->needle.size());
+    if (out->needle.size() <= size_t(kInlineNeedle))
+        std::memcpy(out->p.needle_inline, out->needle.data(), out->needle.size());
+    return LC_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+const char* lc_version(void) { return "liquid_cache_amd 0.1 (gfx950)"; }
+
+const char* lc_last_error(lc_ctx*) { return g_last_error.c_str(); }
+
+lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t max_hbm_bytes, lc_ctx** out) {
+    if (!out) return fail(LC_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (n_devices == 0 && !device_ids) {
+        // host-only context: Arrow->Liquid transcoding and symbol tables only; every device call fails loudly
+        std::unique_ptr<lc_ctx> host(new lc_ctx());
+        host->device = -1;
+        *out = host.release();
+        return LC_OK;
+    }
+    if (n_devices != 1)
+        return fail(LC_ERR_INVALID, "one lc_ctx drives one device: run one process (or ctx) per GPU");
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(LC_ERR_DEVICE, "no HIP device available (this library has no CPU fallback)");
+    int dev = 0;
+    if (device_ids) dev = device_ids[0];
+    else LC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= count) return fail(LC_ERR_INVALID, "device id out of range");
+    LC_HIP(hipSetDevice(dev));
+    std::unique_ptr<lc_ctx> ctx(new lc_ctx());
+    ctx->device = dev;
+    LC_HIP(hipGetDeviceProperties(&ctx->props, dev));
+    ctx->max_hbm = max_hbm_bytes;
+    *out = ctx.release();
+    return LC_OK;
+}
+
+void lc_ctx_destroy(lc_ctx* ctx) {
+    if (!ctx) return;
+    if (ctx->device < 0) { delete ctx; return; }
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (Slab& s : ctx->slabs)
+        if (s.base) (void)hipFree(s.base);
+    if (ctx->d_symtabs) (void)hipFree(ctx->d_symtabs);
+    delete ctx;
+}
+
+lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out) {
+    if (!ctx || !out) return fail(LC_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->device_id = ctx->device;
+    out->compute_units = ctx->props.multiProcessorCount;
+    out->hbm_total_bytes = ctx->props.totalGlobalMem;
+    std::shared_lock<std::shared_mutex> g(ctx->mu);
+    out->hbm_staged_bytes = ctx->staged_bytes;
+    out->staged_entries = ctx->entries.size();
+    std::snprintf(out->name, sizeof(out->name), "%s", ctx->props.name);
+    std::snprintf(out->gcn_arch, sizeof(out->gcn_arch), "%s", ctx->props.gcnArchName);
+    return LC_OK;
+}
+
+lc_status lc_symtab_set(lc_ctx* ctx, uint64_t path_id, const uint8_t* bytes, size_t len) {
+    if (!ctx || !bytes) return fail(LC_ERR_INVALID, "null argument");
+    SymbolTable st;
+    if (!st.load(bytes, len)) return fail(LC_ERR_CORRUPT, "malformed symbol table");
+    std::lock_guard<std::mutex> g(ctx->st_mu);
+    if (ctx->symtab_slot.count(path_id)) return fail(LC_ERR_INVALID, "symbol table of this path is already set");
+    ctx->symtab_slot[path_id] = uint32_t(ctx->symtabs.size());
+    ctx->symtabs.emplace_back(new SymbolTable(st));
+    return LC_OK;
+}
+
+lc_status lc_symtab_get(lc_ctx* ctx, uint64_t path_id, uint8_t** out_bytes, size_t* out_len) {
+    if (!ctx || !out_bytes || !out_len) return fail(LC_ERR_INVALID, "null argument");
+    CtxSymtabs s(ctx);
+    const SymbolTable* st = s.find(path_id);
+    if (!st) return fail(LC_NOT_STAGED, "no symbol table for this path");
+    const std::vector<uint8_t> b = st->save();
+    *out_bytes = static_cast<uint8_t*>(std::malloc(b.size() ? b.size() : 1));
+    std::memcpy(*out_bytes, b.data(), b.size());
+    *out_len = b.size();
+    return LC_OK;
+}
+
+void lc_free(void* p) { std::free(p); }
+
+lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes,
+                   const size_t* lens, const uint64_t* path_ids) {
+    if (!ctx || (n && (!entry_ids || !bytes || !lens))) return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    // group entries into upload batches of <= 64 MiB
+    uint64_t i = 0;
+    while (i < n) {
+        Blob blob;
+        struct Pending {
+            uint64_t id;
+            Entry e;
+            size_t off[7];
+            size_t blob_begin;
+        };
+        std::vector<Pending> pend;
+        while (i < n && blob.bytes.size() < (size_t(64) << 20)) {
+            Pending p;
+            p.id = entry_ids[i];
+            int logical = 0, phys = 0;
+            if (!bytes[i] || !read_ipc_header(bytes[i], lens[i], &logical, &phys))
+                return fail(LC_ERR_CORRUPT, "bad Liquid IPC header");
+            p.blob_begin = align_up(blob.bytes.size(), kSectionAlign);
+            blob.bytes.resize(p.blob_begin, 0);
+            for (auto& o : p.off) o = size_t(-1);
+            lc_status st;
+            if (logical == kByteView) {
+                st = build_str(ctx, bytes[i], lens[i], path_ids ? path_ids[i] : 0, &p.e, &blob, p.off);
+            } else if (logical == kInteger || logical == kDecimal || logical == kFloat) {
+                st = build_fixed(bytes[i], lens[i], &p.e, &blob, &p.off[0], &p.off[1], &p.off[2], &p.off[3]);
+            } else {
+                return fail(LC_UNSUPPORTED, "Liquid logical type not handled on the device (FixedLen/Linear)");
+            }
+            if (st != LC_OK) return st;
+            p.e.device_bytes = align_up(blob.bytes.size(), kSectionAlign) - p.blob_begin;
+            pend.push_back(std::move(p));
+            i++;
+        }
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        uint8_t* dbase = nullptr;
+        int slab = -1;
+        const size_t total = align_up(blob.bytes.size(), kSectionAlign) + 256;
+        blob.bytes.resize(total, 0);
+        lc_status st = arena_alloc(ctx, total, &dbase, &slab);
+        if (st != LC_OK) return st;
+        ctx->slabs[size_t(slab)].live += int64_t(pend.size()) - 1;
+        LC_HIP(hipMemcpy(dbase, blob.bytes.data(), total, hipMemcpyHostToDevice));
+        for (Pending& p : pend) {
+            auto ptr = [&](size_t off) -> uint8_t* { return off == size_t(-1) ? nullptr : dbase + off; };
+            p.e.slab = slab;
+            if (p.e.is_str) {
+                StrDesc& d = p.e.sd;
+                d.keys = reinterpret_cast<const uint16_t*>(ptr(p.off[0]));
+                d.validity = reinterpret_cast<const uint64_t*>(ptr(p.off[1]));
+                d.prefix_keys = ptr(p.off[2]);
+                d.fingerprints = reinterpret_cast<const uint32_t*>(ptr(p.off[3]));
+                d.residuals = ptr(p.off[4]);
+                d.fsst = ptr(p.off[5]);
+                d.shared_prefix = ptr(p.off[6]);
+            } else {
+                FixedDesc& d = p.e.fd;
+                d.packed = ptr(p.off[0]);
+                d.validity = reinterpret_cast<const uint64_t*>(ptr(p.off[1]));
+                d.patch_idx = reinterpret_cast<const uint64_t*>(ptr(p.off[2]));
+                d.patch_val = ptr(p.off[3]);
+            }
+            auto old = ctx->entries.find(p.id);
+            if (old != ctx->entries.end()) {
+                arena_release(ctx, old->second.slab);
+                ctx->entries.erase(old);
+            }
+            ctx->entries.emplace(p.id, std::move(p.e));
+        }
+    }
+    return sync_symtabs(ctx);
+}
+
+lc_status lc_evict(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids) {
+    if (!ctx || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    LC_HIP(hipDeviceSynchronize());  // in-flight scans may still read the blobs
+    std::unique_lock<std::shared_mutex> g(ctx->mu);
+    for (uint64_t i = 0; i < n; i++) {
+        auto it = ctx->entries.find(entry_ids[i]);
+        if (it == ctx->entries.end()) continue;
+        arena_release(ctx, it->second.slab);
+        ctx->entries.erase(it);
+    }
+    return LC_OK;
+}
+
+lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out) {
+    if (!ctx || !out) return fail(LC_ERR_INVALID, "null argument");
+    std::shared_lock<std::shared_mutex> g(ctx->mu);
+    auto it = ctx->entries.find(entry_id);
+    if (it == ctx->entries.end()) return LC_NOT_STAGED;
+    const Entry& e = it->second;
+    std::memset(out, 0, sizeof(*out));
+    out->logical_type = e.logical;
+    out->physical_type = e.phys;
+    out->len = e.len;
+    out->nullable = e.nullable;
+    out->all_null = e.all_null;
+    out->bit_width = e.all_null ? 0 : e.W;
+    out->dict_len = e.dict_len;
+    out->has_fingerprints = e.has_fp;
+    out->device_bytes = e.device_bytes;
+    out->algorithmic_pred_bytes = e.is_str ? 0 : fixed_alg_bytes(e, false);
+    return LC_OK;
+}
+
+lc_status lc_transcode_arrow(lc_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema,
+                             int32_t hint, uint64_t path_id, uint8_t** out_bytes, size_t* out_len) {
+    if (!ctx || !array || !schema || !out_bytes || !out_len) return fail(LC_ERR_INVALID, "null argument");
+    CtxSymtabs st(ctx);
+    std::vector<uint8_t> out;
+    const lc_status rc = transcode_arrow(array, schema, hint, st, path_id, out);
+    if (rc != LC_OK) return fail(rc, "array type is not transcoded to a Liquid encoding");
+    *out_bytes = static_cast<uint8_t*>(std::malloc(out.size() ? out.size() : 1));
+    if (!*out_bytes) return fail(LC_ERR_OOM, "malloc");
+    std::memcpy(*out_bytes, out.data(), out.size());
+    *out_len = out.size();
+    return LC_OK;
+}
+
+lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArray* array,
+                          const struct ArrowSchema* schema, int32_t hint, uint64_t path_id) {
+    uint8_t* b = nullptr;
+    size_t l = 0;
+    lc_status rc = lc_transcode_arrow(ctx, array, schema, hint, path_id, &b, &l);
+    if (rc != LC_OK) return rc;
+    const uint8_t* bp = b;
+    rc = lc_stage(ctx, 1, &entry_id, &bp, &l, &path_id);
+    std::free(b);
+    return rc;
+}
+
+// ------------------------------------------------------------------ scans
+lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out) {
+    if (!ctx || !out || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (n > 0xFFFFFFFFull) return fail(LC_ERR_INVALID, "too many entries in one scan");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<lc_scan> s(new lc_scan());
+    s->ctx = ctx;
+    s->n = uint32_t(n);
+    s->seg_offsets.assign(n + 1, 0);
+    s->meta.reserve(n);
+    {
+        std::shared_lock<std::shared_mutex> g(ctx->mu);
+        uint32_t max_len = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            auto it = ctx->entries.find(entry_ids[i]);
+            if (it == ctx->entries.end()) return fail(LC_NOT_STAGED, "entry is not staged");
+            Entry e = it->second;
+            if (i == 0) {
+                s->is_str = e.is_str;
+                s->lane_log2 = e.is_str ? 4 : e.fd.lane_log2;
+            } else if (e.is_str != s->is_str || (!e.is_str && e.fd.lane_log2 != s->lane_log2)) {
+                return fail(LC_ERR_INVALID, "a scan covers entries of ONE column (same encoding and lane width)");
+            }
+            const uint64_t off = s->seg_offsets[i];
+            if (e.is_str) e.sd.mask_word_off = off;
+            else e.fd.mask_word_off = off;
+            s->seg_offsets[i + 1] = off + (uint64_t(e.len) + 63) / 64;
+            s->total_rows += e.len;
+            max_len = std::max(max_len, e.len);
+            s->meta.push_back(e);
+        }
+        s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
+    }
+    const size_t desc_size = s->is_str ? sizeof(StrDesc) : sizeof(FixedDesc);
+    std::vector<uint8_t> host(desc_size * std::max<uint64_t>(n, 1));
+    for (uint64_t i = 0; i < n; i++) {
+        if (s->is_str) std::memcpy(host.data() + i * desc_size, &s->meta[i].sd, desc_size);
+        else std::memcpy(host.data() + i * desc_size, &s->meta[i].fd, desc_size);
+    }
+    LC_HIP(hipMalloc(&s->d_descs, host.size()));
+    LC_HIP(hipMemcpy(s->d_descs, host.data(), host.size(), hipMemcpyHostToDevice));
+    LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_seg_offsets), (n + 1) * 8));
+    LC_HIP(hipMemcpy(s->d_seg_offsets, s->seg_offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    const lc_status st = sync_symtabs(ctx);
+    if (st != LC_OK) return st;
+    *out = s.release();
+    return LC_OK;
+}
+
+void lc_scan_destroy(lc_scan* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->ctx->device);
+    (void)hipDeviceSynchronize();
+    if (s->d_descs) (void)hipFree(s->d_descs);
+    if (s->d_seg_offsets) (void)hipFree(s->d_seg_offsets);
+    if (s->d_automata) (void)hipFree(s->d_automata);
+    if (s->d_needle) (void)hipFree(s->d_needle);
+    delete s;
+}
+
+uint64_t lc_scan_mask_words(const lc_scan* s) { return s ? s->seg_offsets.back() : 0; }
+uint64_t lc_scan_rows(const lc_scan* s) { return s ? s->total_rows : 0; }
+uint64_t lc_scan_entries(const lc_scan* s) { return s ? s->n : 0; }
+const uint64_t* lc_scan_segment_offsets(const lc_scan* s) { return s ? s->seg_offsets.data() : nullptr; }
+
+static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pred, const void* d_selection,
+                                void* d_mask_out, void* d_valid_out, void* d_counts_out, void* d_cand_bytes,
+                                hipStream_t stream) {
+    if (!ctx || !s || !pred || !d_mask_out) return fail(LC_ERR_INVALID, "null argument");
+    if (s->n == 0) return LC_OK;
+    ScanLaunch L{};
+    L.n_entries = s->n;
+    L.blocks_per_entry = s->bpe;
+    L.d_selection = static_cast<const uint64_t*>(d_selection);
+    L.d_hit = static_cast<uint64_t*>(d_mask_out);
+    L.d_valid = static_cast<uint64_t*>(d_valid_out);
+    L.d_counts = static_cast<uint32_t*>(d_counts_out);
+    L.d_cand_bytes = static_cast<uint32_t*>(d_cand_bytes);
+    if (!s->is_str) {
+        FixedPred fp;
+        const lc_status st = make_fixed_pred(s->meta[0], pred, &fp);
+        if (st != LC_OK) return st;
+        if (L.d_counts) LC_HIP(hipMemsetAsync(L.d_counts, 0, size_t(s->n) * 4, stream));
+        LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, L, stream));
+        return LC_OK;
+    }
+    StrPredHost sp;
+    const lc_status st = make_str_pred(pred, &sp);
+    if (st != LC_OK) return st;
+    std::lock_guard<std::mutex> g(s->mu);
+    if (sp.p.mode == 1) {
+        const uint32_t stride = (sp.p.needle_len + 1) * 512;
+        const size_t nst = ctx->d_symtabs_uploaded;
+        const size_t need = size_t(stride) * std::max<size_t>(nst, 1);
+        if (need > s->automata_cap) {
+            LC_HIP(hipStreamSynchronize(stream));
+            if (s->d_automata) LC_HIP(hipFree(s->d_automata));
+            LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_automata), need));
+            s->automata_cap = need;
+        }
+        LC_HIP(launch_str_automata(ctx->d_symtabs, uint32_t(nst), sp.needle.data(), sp.p.needle_len, s->d_automata,
+                                   stream));
+        sp.p.automata = s->d_automata;
+        sp.p.automaton_stride = stride;
+    } else if (sp.p.mode == 0 && sp.needle.size() > size_t(kInlineNeedle)) {
+        const size_t need = sp.needle.size() + 16;
+        LC_HIP(hipStreamSynchronize(stream));  // previous evaluation may still read the old needle
+        if (need > s->needle_cap) {
+            if (s->d_needle) LC_HIP(hipFree(s->d_needle));
+            LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_needle), need));
+            s->needle_cap = need;
+        }
+        LC_HIP(hipMemcpy(s->d_needle, sp.needle.data(), sp.needle.size(), hipMemcpyHostToDevice));
+        sp.p.needle = s->d_needle;
+    }
+    LC_HIP(launch_str_pred(static_cast<const StrDesc*>(s->d_descs), ctx->d_symtabs, sp.p, L, stream));
+    return LC_OK;
+}
+
+lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
+                       void* d_mask_out, void* d_counts_out, void* stream) {
+    return scan_eval_impl(ctx, scan, pred, d_selection, d_mask_out, nullptr, d_counts_out, nullptr,
+                          static_cast<hipStream_t>(stream));
+}
+
+lc_status lc_scan_eval_timed(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
+                             void* d_mask_out, void* d_counts_out, void* stream, int32_t iters, float* out_avg_ms) {
+    if (!out_avg_ms || iters <= 0) return fail(LC_ERR_INVALID, "bad iters/out");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipEvent_t a, b;
+    LC_HIP(hipEventCreate(&a));
+    LC_HIP(hipEventCreate(&b));
+    LC_HIP(hipEventRecord(a, st));
+    for (int i = 0; i < iters; i++) {
+        const lc_status rc = scan_eval_impl(ctx, scan, pred, d_selection, d_mask_out, nullptr, d_counts_out, nullptr, st);
+        if (rc != LC_OK) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); return rc; }
+    }
+    LC_HIP(hipEventRecord(b, st));
+    LC_HIP(hipEventSynchronize(b));
+    float ms = 0;
+    LC_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *out_avg_ms = ms / float(iters);
+    return LC_OK;
+}
+
+uint64_t lc_scan_algorithmic_bytes(const lc_scan* s_const, const lc_predicate* pred, int32_t with_selection) {
+    lc_scan* s = const_cast<lc_scan*>(s_const);
+    if (!s || !pred) return 0;
+    uint64_t total = 0;
+    if (!s->is_str) {
+        for (const Entry& e : s->meta) total += fixed_alg_bytes(e, with_selection != 0);
+        return total;
+    }
+    // byte views: 2n keys + n/8 out (+ n/8 selection, + n/8 validity) and
+    //   LIKE        : 4D fingerprints + offsets + compressed bytes of the fingerprint candidates
+    //   Eq/ordering : 8D prefix keys + compressed bytes of the ambiguous entries
+    // candidate bytes are data dependent: measured by one instrumented device pass.
+    lc_ctx* ctx = s->ctx;
+    uint32_t* d_cand = nullptr;
+    uint64_t* d_mask = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d_cand), size_t(s->n) * 4) != hipSuccess) return 0;
+    if (hipMalloc(reinterpret_cast<void**>(&d_mask), std::max<uint64_t>(s->seg_offsets.back(), 1) * 8) != hipSuccess) {
+        (void)hipFree(d_cand);
+        return 0;
+    }
+    (void)hipMemset(d_cand, 0, size_t(s->n) * 4);
+    std::vector<uint32_t> cand(s->n, 0);
+    if (scan_eval_impl(ctx, s, pred, nullptr, d_mask, nullptr, nullptr, d_cand, nullptr) == LC_OK &&
+        hipDeviceSynchronize() == hipSuccess)
+        (void)hipMemcpy(cand.data(), d_cand, size_t(s->n) * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_cand);
+    (void)hipFree(d_mask);
+    const bool like = pred->op == LC_OP_LIKE || pred->op == LC_OP_NOT_LIKE;
+    for (uint32_t i = 0; i < s->n; i++) {
+        const Entry& e = s->meta[i];
+        const uint64_t n = e.len, m = (n + 7) / 8;
+        total += 2 * n + m + (with_selection ? m : 0) + (e.nullable ? m : 0) + cand[i];
+        if (like) total += (e.has_fp ? 4ull * e.dict_len : 0) + e.offsets_bytes;
+        else if (pred->lit_tag == LC_LIT_BYTES) total += 8ull * e.dict_len + (cand[i] ? e.offsets_bytes : 0);
+    }
+    return total;
+}
+
+// ------------------------------------------------------------------ small device helpers
+lc_status lc_device_alloc(lc_ctx* ctx, uint64_t bytes, void** out) {
+    if (!ctx || !out) return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    LC_HIP(hipMalloc(out, bytes ? bytes : 8));
+    return LC_OK;
+}
+lc_status lc_device_free(lc_ctx* ctx, void* p) {
+    if (!ctx) return fail(LC_ERR_INVALID, "null argument");
+    if (p) LC_HIP(hipFree(p));
+    return LC_OK;
+}
+lc_status lc_device_memset(lc_ctx* ctx, void* p, int v, uint64_t bytes, void* stream) {
+    if (!ctx || !p) return fail(LC_ERR_INVALID, "null argument");
+    LC_HIP(hipMemsetAsync(p, v, bytes, static_cast<hipStream_t>(stream)));
+    return LC_OK;
+}
+lc_status lc_device_to_host(lc_ctx* ctx, void* dst, const void* src, uint64_t bytes, void* stream) {
+    if (!ctx || !dst || !src) return fail(LC_ERR_INVALID, "null argument");
+    LC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    LC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return LC_OK;
+}
+lc_status lc_host_to_device(lc_ctx* ctx, void* dst, const void* src, uint64_t bytes, void* stream) {
+    if (!ctx || !dst || !src) return fail(LC_ERR_INVALID, "null argument");
+    LC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    LC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return LC_OK;
+}
+lc_status lc_stream_synchronize(lc_ctx* ctx, void* stream) {
+    if (!ctx) return fail(LC_ERR_INVALID, "null argument");
+    LC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return LC_OK;
+}
+
+// ------------------------------------------------------------------ per-entry drop-in calls
+lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const lc_predicate* pred,
+                                  const uint8_t* const* selections, uint8_t* const* out_values,
+                                  uint8_t* const* out_validity, uint32_t* out_lens, int32_t* out_nullable,
+                                  lc_status* statuses) {
+    if (!ctx || !pred || (n && (!entry_ids || !out_values || !out_lens)))
+        return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    // entries that are not staged answer LC_NOT_STAGED individually (Option::None in the reference)
+    std::vector<uint64_t> present_ids;
+    std::vector<uint64_t> present_idx;
+    {
+        std::shared_lock<std::shared_mutex> g(ctx->mu);
+        for (uint64_t i = 0; i < n; i++) {
+            const bool ok = ctx->entries.count(entry_ids[i]) != 0;
+            if (statuses) statuses[i] = ok ? LC_OK : LC_NOT_STAGED;
+            if (ok) { present_ids.push_back(entry_ids[i]); present_idx.push_back(i); }
+            else if (!statuses) return LC_NOT_STAGED;
+        }
+    }
+    if (present_ids.empty()) return LC_OK;
+    lc_scan* scan = nullptr;
+    lc_status rc = lc_scan_create(ctx, present_ids.size(), present_ids.data(), &scan);
+    if (rc != LC_OK) return rc;
+    std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
+    const uint64_t words = std::max<uint64_t>(scan->seg_offsets.back(), 1);
+    const uint32_t m = scan->n;
+    bool any_sel = false;
+    if (selections)
+        for (uint64_t i : present_idx) any_sel |= selections[i] != nullptr;
+    // host selection in scan layout (entries without a selection get all ones)
+    std::vector<uint64_t> h_sel;
+    if (any_sel) {
+        h_sel.assign(words, 0);
+        for (uint32_t k = 0; k < m; k++) {
+            const Entry& e = scan->meta[k];
+            uint8_t* dst = reinterpret_cast<uint8_t*>(h_sel.data() + scan->seg_offsets[k]);
+            const uint8_t* src = selections[present_idx[k]];
+            const size_t nb = bitmap_bytes(e.len);
+            if (src) std::memcpy(dst, src, nb);
+            else std::memset(dst, 0xFF, nb);
+            if (e.len & 7) dst[nb - 1] &= uint8_t((1u << (e.len & 7)) - 1);
+        }
+    }
+    uint64_t *d_sel = nullptr, *d_hit = nullptr, *d_valid = nullptr, *d_chit = nullptr, *d_cvalid = nullptr;
+    uint32_t* d_bits = nullptr;
+    auto cleanup = [&]() {
+        for (void* p : {(void*)d_sel, (void*)d_hit, (void*)d_valid, (void*)d_chit, (void*)d_cvalid, (void*)d_bits})
+            if (p) (void)hipFree(p);
+    };
+#define LC_HIP_C(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            cleanup();                                                                          \
+            return fail(LC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+        }                                                                                       \
+    } while (0)
+    LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_hit), words * 8));
+    LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_valid), words * 8));
+    if (any_sel) {
+        LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_sel), words * 8));
+        LC_HIP_C(hipMemcpy(d_sel, h_sel.data(), words * 8, hipMemcpyHostToDevice));
+        LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_chit), words * 8));
+        LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_cvalid), words * 8));
+        LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_bits), size_t(m) * 4));
+    }
+    rc = scan_eval_impl(ctx, scan, pred, d_sel, d_hit, d_valid, nullptr, nullptr, nullptr);
+    if (rc != LC_OK) { cleanup(); return rc; }
+    std::vector<uint64_t> h_hit(words), h_valid(words);
+    std::vector<uint32_t> h_bits(m);
+    if (any_sel) {
+        // the reference returns a BooleanArray of popcount(selection) rows: compress hit/valid by the selection
+        LC_HIP_C(launch_mask_compress(d_hit, d_sel, scan->d_seg_offsets, m, d_chit, d_bits, nullptr));
+        LC_HIP_C(launch_mask_compress(d_valid, d_sel, scan->d_seg_offsets, m, d_cvalid, nullptr, nullptr));
+        LC_HIP_C(hipMemcpy(h_hit.data(), d_chit, words * 8, hipMemcpyDeviceToHost));
+        LC_HIP_C(hipMemcpy(h_valid.data(), d_cvalid, words * 8, hipMemcpyDeviceToHost));
+        LC_HIP_C(hipMemcpy(h_bits.data(), d_bits, size_t(m) * 4, hipMemcpyDeviceToHost));
+    } else {
+        LC_HIP_C(hipMemcpy(h_hit.data(), d_hit, words * 8, hipMemcpyDeviceToHost));
+        LC_HIP_C(hipMemcpy(h_valid.data(), d_valid, words * 8, hipMemcpyDeviceToHost));
+        for (uint32_t k = 0; k < m; k++) h_bits[k] = scan->meta[k].len;
+    }
+    cleanup();
+#undef LC_HIP_C
+    for (uint32_t k = 0; k < m; k++) {
+        const uint64_t i = present_idx[k];
+        const Entry& e = scan->meta[k];
+        const size_t nb = bitmap_bytes(h_bits[k]);
+        out_lens[i] = h_bits[k];
+        if (out_values[i]) std::memcpy(out_values[i], h_hit.data() + scan->seg_offsets[k], nb);
+        if (out_validity && out_validity[i]) std::memcpy(out_validity[i], h_valid.data() + scan->seg_offsets[k], nb);
+        if (out_nullable) out_nullable[i] = e.nullable ? 1 : 0;
+    }
+    return LC_OK;
+}
+
+lc_status lc_eval_predicate(lc_ctx* ctx, uint64_t entry_id, const lc_predicate* pred, const uint8_t* selection,
+                            uint8_t* out_values, uint8_t* out_validity, uint32_t* out_len, int32_t* out_nullable) {
+    if (!out_values || !out_len) return fail(LC_ERR_INVALID, "null output");
+    const uint8_t* sels[1] = {selection};
+    uint8_t* ov[1] = {out_values};
+    uint8_t* ovalid[1] = {out_validity};
+    lc_status st = LC_OK;
+    int32_t nullable = 0;
+    const lc_status rc = lc_eval_predicate_batch(ctx, 1, &entry_id, pred, sels, ov, ovalid, out_len, &nullable, &st);
+    if (out_nullable) *out_nullable = nullable;
+    return rc != LC_OK ? rc : st;
+}
+
+lc_status lc_mask_and_then(lc_ctx* ctx, const uint8_t* left, uint64_t left_bits, const uint8_t* right,
+                           uint64_t right_bits, uint8_t* out) {
+    if (!ctx || !left || !out || (right_bits && !right)) return fail(LC_ERR_INVALID, "null argument");
+    if (left_bits == right_bits) {  // datafusion/src/utils.rs:69-72
+        std::memcpy(out, right, bitmap_bytes(left_bits));
+        return LC_OK;
+    }
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    const uint64_t lw = (left_bits + 63) / 64, rw = (right_bits + 63) / 64 + 1;
+    std::vector<uint64_t> hl(lw, 0), hr(rw, 0);
+    std::memcpy(hl.data(), left, bitmap_bytes(left_bits));
+    if (left_bits & 63) hl[lw - 1] &= (uint64_t(1) << (left_bits & 63)) - 1;
+    if (right_bits) std::memcpy(hr.data(), right, bitmap_bytes(right_bits));
+    uint64_t *dl = nullptr, *dr = nullptr, *dout = nullptr;
+    lc_status rc = LC_OK;
+    if (hipMalloc(reinterpret_cast<void**>(&dl), lw * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dr), rw * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&dout), lw * 8) != hipSuccess)
+        rc = fail(LC_ERR_OOM, "hipMalloc");
+    if (rc == LC_OK && (hipMemcpy(dl, hl.data(), lw * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                        hipMemcpy(dr, hr.data(), rw * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                        launch_mask_and_then(dl, left_bits, dr, dout, nullptr) != hipSuccess ||
+                        hipMemcpy(hl.data(), dout, lw * 8, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(LC_ERR_DEVICE, "and_then device pass failed");
+    if (dl) (void)hipFree(dl);
+    if (dr) (void)hipFree(dr);
+    if (dout) (void)hipFree(dout);
+    if (rc == LC_OK) std::memcpy(out, hl.data(), bitmap_bytes(left_bits));
+    return rc;
+}
+
+lc_status lc_get_with_selection(lc_ctx*, uint64_t, const uint8_t*, struct ArrowArray*, struct ArrowSchema*) {
+    return fail(LC_UNSUPPORTED, "get-with-selection lands in the next milestone");
+}
+
+lc_status lc_scan_gather_fixed(lc_ctx*, lc_scan*, const void*, void*, uint64_t, void*, void*) {
+    return fail(LC_UNSUPPORTED, "scan gather lands in the next milestone");
+}
+
+}  // extern "C"
