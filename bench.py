@@ -1,0 +1,288 @@
+#!/usr/bin/env python3
+"""bench.py — ClickBench "Q21" hot-cache filter scan on MI355X (liquid_cache_amd).
+
+One "step" = one pass of the decode + predicate-pushdown hot path over the whole staged column chunk:
+`URL LIKE '%google%'` (benchmark/clickbench/queries/q20.sql / q21.sql of the reference share this scan) over a
+synthetic 100 M-row ClickBench-shaped URL column that is fully transcoded (dictionary + FSST + fingerprints) and
+resident in HBM before the timed region starts.  Reported: filtered rows/s (value), algorithmic GB/s, the
+roofline object of the dominant kernel (live HIP-event timing on the launch stream) and a CPU baseline (the C
+oracle restating the reference's algorithm) on a bounded sample of the same data.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: one process per GPU, row-range sharding (every rank stages and scans its own 8192-row batches; weak
+scaling: per-GPU rows fixed).  The only exchange step of the COUNT(*)-style query is the sum of per-rank hit
+counts: one 8-byte all-reduce over RCCL per step.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--rows", type=int, default=99_997_497, help="rows per GPU (ClickBench hits = 99,997,497)")
+    p.add_argument("--batch-size", type=int, default=8192)
+    p.add_argument("--uniques", type=int, default=2200, help="distinct URLs per batch (nano_hits: ~2,150-2,250)")
+    p.add_argument("--row-group-batches", type=int, default=54, help="batches sharing one FSST symbol table")
+    p.add_argument("--needle", default="google")
+    p.add_argument("--workload", default="url_like", choices=["url_like", "int64_gt"])
+    p.add_argument("--int-bits", type=int, default=62, help="int64_gt: FoR bit width of every batch (WatchID ~62)")
+    p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = auto)")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--seed", type=int, default=42)
+    return p.parse_args()
+
+
+def stage_url_column(cache, lc, N, args, rank, n_batches, threads):
+    """Generate + transcode + stage the URL column through the public API; returns entry ids."""
+    L = N.load()
+    import pyarrow as pa
+    rows_total = args.rows
+    bs = args.batch_size
+    ids = [lc.ParquetArrayID.new(rank, b // args.row_group_batches, 13, b % args.row_group_batches)
+           for b in range(n_batches)]
+
+    def do_row_group(rg):
+        offs = np.zeros(bs + 1, np.int32)
+        data = np.zeros(bs * 512, np.uint8)
+        first = rg * args.row_group_batches
+        for b in range(first, min(first + args.row_group_batches, n_batches)):
+            rows = min(bs, rows_total - b * bs)
+            n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), 60,
+                                     offs.ctypes.data, data.ctypes.data, data.size)
+            arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
+            cache.insert(ids[b], arr, lc.CacheExpression.SUBSTRING_SEARCH)
+        return rg
+
+    n_rg = (n_batches + args.row_group_batches - 1) // args.row_group_batches
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(do_row_group, range(n_rg)))
+    return ids
+
+
+def stage_int_column(cache, lc, N, args, rank, n_batches, threads):
+    L = N.load()
+    import pyarrow as pa
+    bs = args.batch_size
+    ids = [lc.ParquetArrayID.new(rank, b // args.row_group_batches, 0, b % args.row_group_batches)
+           for b in range(n_batches)]
+
+    def do_chunk(c):
+        buf = np.zeros(bs, np.int64)
+        for b in range(c, n_batches, threads):
+            rows = min(bs, args.rows - b * bs)
+            L.lc_synth_int64_batch(args.seed + rank * 1_000_003, b, rows, args.int_bits, 4_000_000_000_000_000_000 >> (64 - args.int_bits) if args.int_bits < 63 else 0, buf.ctypes.data)
+            cache.insert(ids[b], pa.array(buf[:rows]))
+        return c
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(do_chunk, range(threads)))
+    return ids
+
+
+def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
+    """Oracle (CPU restatement of the reference algorithm) on the first n_sample batches, single thread."""
+    from oracle import liquid_oracle as lo
+    import pyarrow as pa
+    L = N.load()
+    bs = args.batch_size
+    blobs, symtabs = [None] * n_sample, {}
+    rows_total = sum(min(bs, args.rows - b * bs) for b in range(n_sample))
+
+    def prep(c):  # regenerate + transcode the sample's batches (same bytes the GPU scanned), untimed
+        offs = np.zeros(bs + 1, np.int32)
+        data = np.zeros(bs * 512, np.uint8)
+        for b in range(c, n_sample, threads):
+            rows = min(bs, args.rows - b * bs)
+            n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), 60,
+                                     offs.ctypes.data, data.ctypes.data, data.size)
+            arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
+            eid = lc.ParquetArrayID.new(rank, b // args.row_group_batches, 13, b % args.row_group_batches)
+            path = lc.ParquetArrayID.column_access_path(eid)
+            blobs[b] = (cache.transcode(arr, lc.CacheExpression.SUBSTRING_SEARCH, path), path)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(prep, range(threads)))
+    for _, path in blobs:
+        if path not in symtabs:
+            symtabs[path] = lo.symtab_load(cache.symbol_table(path))
+    lo.eval_predicate(blobs[0][0], lo.LIKE, pattern, symtab=symtabs[blobs[0][1]])  # warm
+    t0 = time.perf_counter()
+    hits = 0
+    for blob, path in blobs:
+        r = lo.eval_predicate(blob, lo.LIKE, pattern, symtab=symtabs[path])
+        hits += int(r.values.sum())
+    dt = time.perf_counter() - t0
+    return rows_total / dt, rows_total, hits, dt
+
+
+def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal):
+    from oracle import liquid_oracle as lo
+    import pyarrow as pa
+    L = N.load()
+    bs = args.batch_size
+    buf = np.zeros(bs, np.int64)
+    blobs = []
+    rows_total = 0
+    base = 4_000_000_000_000_000_000 >> (64 - args.int_bits) if args.int_bits < 63 else 0
+    for b in range(n_sample):
+        rows = min(bs, args.rows - b * bs)
+        L.lc_synth_int64_batch(args.seed + rank * 1_000_003, b, rows, args.int_bits, base, buf.ctypes.data)
+        blobs.append(cache.transcode(pa.array(buf[:rows])))
+        rows_total += rows
+    t0 = time.perf_counter()
+    hits = 0
+    for blob in blobs:
+        hits += int(lo.eval_predicate(blob, lo.GT, literal).values.sum())
+    dt = time.perf_counter() - t0
+    return rows_total / dt, rows_total, hits, dt
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: liquid_cache_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as g
+    if rank == 0:
+        g.build()
+    if world > 1:
+        dist.barrier()
+    import liquid_cache_amd as lc
+    from liquid_cache_amd import _native as N
+
+    cache = lc.LiquidCacheBuilder.new().with_device(local_rank).with_batch_size(args.batch_size).build()
+    n_batches = (args.rows + args.batch_size - 1) // args.batch_size
+    threads = max(1, min(32, (os.cpu_count() or 8) // max(1, min(world, 8))))
+
+    t_stage = time.perf_counter()
+    if args.workload == "url_like":
+        ids = stage_url_column(cache, lc, N, args, rank, n_batches, threads)
+        pattern = ("%" + args.needle + "%").encode()
+        import pyarrow as pa
+        expr = lc.LiquidExpr.try_new("like", pattern, pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
+        workload = "clickbench_q21_url_like_%s" % args.needle
+        dtype = "u8"
+    else:
+        ids = stage_int_column(cache, lc, N, args, rank, n_batches, threads)
+        import pyarrow as pa
+        base = 4_000_000_000_000_000_000 >> (64 - args.int_bits) if args.int_bits < 63 else 0
+        literal = base + (1 << (args.int_bits - 1)) if args.int_bits < 64 else 0
+        expr = lc.LiquidExpr.try_new(">", literal, pa.int64())
+        workload = "clickbench_int64_gt_w%d" % args.int_bits
+        dtype = "int64"
+    t_stage = time.perf_counter() - t_stage
+
+    scan = cache.scan(ids)
+    words = int(scan.mask_words)
+    mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
+    counts = torch.zeros(max(scan.entries, 1), dtype=torch.int32, device="cuda")
+    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
+        total.copy_(counts.sum(dtype=torch.int64))
+        if world > 1:
+            dist.all_reduce(total)  # the query's only exchange step: COUNT(*) partials -> global count
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    rows_all = scan.rows * world
+    hits = int(total.item())
+
+    # roofline of the dominant kernel: HIP events on the launch stream, same launches as the timed region
+    alg_bytes = scan.algorithmic_bytes(expr, with_selection=False)
+    kernel_ms = scan.eval_timed(expr, mask.data_ptr(), max(5, args.steps), 0, counts.data_ptr(), stream)
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "filtered rows/s (+ GB/s scanned), ClickBench Q21 hot cache",
+            "value": rows_all / elapsed * args.steps,
+            "unit": "rows/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": workload, "rows_per_gpu": int(scan.rows), "batch_rows": args.batch_size,
+                       "batches_per_gpu": int(scan.entries), "distinct_per_batch": args.uniques,
+                       "parallelism": "row-range shards x%d, count all-reduce" % world,
+                       "predicate": ("URL LIKE '%%%s%%'" % args.needle) if args.workload == "url_like" else "col > literal",
+                       "hits": hits, "stage_seconds": round(t_stage, 2)},
+            "gb_per_s_scanned": alg_bytes * world / (elapsed / args.steps) / 1e9,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_str_pred" if args.workload == "url_like" else "k_fixed_pred<u64>",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            n_sample = args.cpu_batches or n_batches  # ~5 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
+            if args.workload == "url_like":
+                v, rows_s, hits_s, dt = cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads)
+            else:
+                v, rows_s, hits_s, dt = cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal)
+            out["cpu_baseline"] = {"value": v, "unit": "rows/s", "cores": 1, "kind": "port",
+                                   "sample": "first %d batches (%d rows) of the same column, %.1f s" % (n_sample, rows_s, dt)}
+        print(json.dumps(out), flush=True)
+    scan.close()
+    cache.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,37 @@
+/*
+ * Synthetic ClickBench-shaped column generators used by bench.py and the full-size tests.
+ * They only produce Arrow-layout host buffers; everything downstream goes through the public API in
+ * liquid_cache_amd.h (lc_insert_arrow / lc_scan_*).  There is no dataset access on the benchmark machines
+ * (hits.parquet is download-only), hence generators that mimic the statistics measured on the
+ * reference's examples/nano_hits.parquet: ~2,200 distinct URLs per 8192-row batch, mean length ~76 bytes,
+ * Zipf-distributed repetition, ~40 % of distinct values passing the 32-bucket fingerprint of "google".
+ */
+#ifndef LIQUID_CACHE_AMD_BENCH_H
+#define LIQUID_CACHE_AMD_BENCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LC_BENCH_API __attribute__((visibility("default")))
+
+/* Fill one batch of a URL-like Utf8 column.  Deterministic in (seed, batch_index).
+ *   offsets: rows + 1 int32; data: capacity data_cap bytes; returns the number of data bytes written,
+ *   or 0 if data_cap is too small (rows * 512 is always enough).
+ *   n_unique: distinct values to draw from in this batch; needle_ppm: parts-per-million of DISTINCT values that
+ *   contain the token "google" (true matches of LIKE '%google%'). */
+LC_BENCH_API size_t lc_synth_url_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, uint32_t n_unique,
+                                       uint32_t needle_ppm, int32_t* offsets, uint8_t* data, size_t data_cap);
+
+/* Fill `rows` 64-bit integers uniform in [base, base + 2^bit_width) (bit_width 1..64).
+ * Deterministic in (seed, batch_index). */
+LC_BENCH_API void lc_synth_int64_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, int32_t bit_width,
+                                       int64_t base, int64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -64,6 +64,8 @@ EXPORTED_SYMBOLS = [
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
+    # include/liquid_cache_amd_bench.h
+    "lc_synth_url_batch", "lc_synth_int64_batch",
 ]
 
 _lib = None
@@ -117,6 +119,10 @@ def load():
     L.lc_device_to_host.restype = i32; L.lc_device_to_host.argtypes = [vp, vp, vp, u64, vp]
     L.lc_host_to_device.restype = i32; L.lc_host_to_device.argtypes = [vp, vp, vp, u64, vp]
     L.lc_stream_synchronize.restype = i32; L.lc_stream_synchronize.argtypes = [vp, vp]
+    L.lc_synth_url_batch.restype = sz
+    L.lc_synth_url_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
+    L.lc_synth_int64_batch.restype = None
+    L.lc_synth_int64_batch.argtypes = [u64, u64, C.c_uint32, i32, C.c_int64, vp]
     _lib = L
     return L
 

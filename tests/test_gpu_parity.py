@@ -48,7 +48,8 @@ def _check_pred(cache, lo, eid, liquid, op, literal, dtype, selection, symtab=No
 def _random_ints(rng, np_dtype, n, width_bits):
     info = np.iinfo(np_dtype)
     span = min((1 << width_bits) - 1, int(info.max) - int(info.min))
-    lo_ = int(rng.integers(int(info.min), int(info.max) - span, endpoint=True))
+    room = int(info.max) - span - int(info.min)
+    lo_ = int(info.min) + (int(rng.integers(0, 1 << 62)) % (room + 1))
     if span == 0:
         return np.full(n, lo_, dtype=np_dtype)
     vals = rng.integers(0, span, size=n, endpoint=True, dtype=np.uint64)
