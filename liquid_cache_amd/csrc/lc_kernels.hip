@@ -260,7 +260,8 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
     for (uint32_t s = 0; s <= m; s++) {
         uint32_t cur = s;
         for (uint32_t k = 0; k < sl; k++) cur = delta[cur * 256 + uint32_t((sym >> (8 * k)) & 0xFF)];
-        t[s * 512 + code] = uint8_t(cur);
+        // code 255 is the escape marker: never a transition, flagged non-zero so the scanner never skips it
+        t[s * 512 + code] = code == 255u ? uint8_t(0xFF) : uint8_t(cur);
         t[s * 512 + 256 + code] = delta[s * 256 + code];
     }
 }
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(kThreads) void k_str_pred(const StrDesc* __restrict
     } else if (uniform_result < 0) {
         for (uint32_t chunk = 0; chunk < d.d; chunk += kDictChunk) {
             // ---- phase A ----
-            const uint32_t chunk_end = min(d.d, chunk + kDictChunk);
+            const uint32_t chunk_end = (pred.debug_flags & 4) ? chunk : min(d.d, chunk + kDictChunk);
             for (uint32_t base = chunk; base < chunk_end; base += kThreads) {
                 const uint32_t i = base + tid;
                 bool is_cand = false, decided_true = false;
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(kThreads) void k_str_pred(const StrDesc* __restrict
             }
             __syncthreads();
             // ---- phase B: lanes pull candidates from the LDS queue ----
-            const uint32_t nc = n_cand;
+            const uint32_t nc = (pred.debug_flags & 1) ? 0u : n_cand;
             for (;;) {
                 const uint32_t q = atomicAdd(&q_head, 1u);
                 if (q >= nc) break;
@@ -474,17 +475,41 @@ __global__ __launch_bounds__(kThreads) void k_str_pred(const StrDesc* __restrict
                 if (L.d_cand_bytes) atomicAdd(&cand_bytes, stop - start);
                 bool res;
                 if (substring) {
-                    ByteReader r;
-                    r.init(d.fsst, start, stop);
-                    uint32_t s = 0;
-                    while (r.more() && s != nl) {
-                        const uint32_t c = r.next();
+                    // Walk the FSST codes 8 at a time.  While no partial match is pending (state 0) whole runs of
+                    // codes whose symbol cannot start a match are skipped with one table lookup per code
+                    // (row 0 of the automaton; the escape code 255 is flagged so it is never skipped); only the
+                    // "interesting" codes take the dependent state-transition step.
+                    uint32_t pos = start, s = 0, wbase = 0xFFFFFFFFu;
+                    uint64_t w = 0, flags = 0;
+                    while (pos < stop) {
+                        const uint32_t base = pos & ~7u;
+                        if (base != wbase) {
+                            w = *reinterpret_cast<const uint64_t*>(d.fsst + base);
+                            wbase = base;
+                            flags = 0;
+#pragma unroll
+                            for (int k = 0; k < 8; k++)
+                                flags |= uint64_t(tbl[uint32_t(w >> (8 * k)) & 0xFFu]) << (8 * k);
+                            if (base + 8 > stop) flags &= (uint64_t(1) << (8 * (stop - base))) - 1;
+                        }
+                        const uint32_t sh = 8u * (pos & 7u);
+                        if (s == 0) {
+                            const uint64_t f = (flags >> sh) << sh;
+                            if (f == 0) { pos = base + 8; continue; }
+                            pos = base + ((uint32_t(__ffsll((long long)f)) - 1u) >> 3);
+                        }
+                        const uint32_t c = uint32_t(w >> (8u * (pos & 7u))) & 0xFFu;
                         if (c == 255u) {
-                            if (!r.more()) break;
-                            s = tbl[s * 512 + 256 + r.next()];
+                            if (pos + 1 >= stop) break;
+                            const uint32_t lit = (pos & 7u) < 7u ? (uint32_t(w >> (8u * ((pos & 7u) + 1u))) & 0xFFu)
+                                                                 : uint32_t(d.fsst[pos + 1]);
+                            s = tbl[s * 512 + 256 + lit];
+                            pos += 2;
                         } else {
                             s = tbl[s * 512 + c];
+                            pos += 1;
                         }
+                        if (s == nl) break;
                     }
                     res = s == nl;
                 } else {
@@ -509,7 +534,7 @@ __global__ __launch_bounds__(kThreads) void k_str_pred(const StrDesc* __restrict
 
     // ---- phase C: rows ----
     const uint32_t xorm = invert ? 1u : 0u;
-    for (uint32_t base = 0; base < d.n; base += kThreads * 8) {
+    for (uint32_t base = 0; base < ((pred.debug_flags & 2) ? 0u : d.n); base += kThreads * 8) {
         const uint32_t r0 = base + tid * 8;  // this lane's 8 consecutive rows
         uint32_t bits = 0;
         if (r0 < d.n) {
@@ -658,6 +683,327 @@ __global__ __launch_bounds__(kThreads) void k_mask_and_then(const uint64_t* __re
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// get-with-selection for fixed-width encodings (LiquidArray::filter, primitive_array.rs:370-374 et al.):
+//   k_sel_block_counts  popcount of the selection per 1024-row block
+//   k_exclusive_scan    block counts -> output row offset of every block (+ per-entry row offsets)
+//   k_fixed_gather      unpack + FoR (+ ALP decode / decimal widening) and compact the selected rows, in order
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_sel_block_counts(const FixedDesc* __restrict__ descs, ScanLaunch L,
+                                                               uint32_t* __restrict__ block_counts) {
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + uint32_t(wave);
+    const uint32_t entry = gw / L.blocks_per_entry, blk = gw % L.blocks_per_entry;
+    if (entry >= L.n_entries) return;
+    const uint32_t len = descs[entry].len;
+    const uint32_t row0 = blk * 1024u;
+    uint32_t c = 0;
+    if (row0 < len) {
+        const uint32_t rows = min(1024u, len - row0);
+        const uint32_t nwords = (rows + 63u) >> 6;
+        if (uint32_t(lane) < nwords) {
+            uint64_t tail = ~uint64_t(0);
+            if (uint32_t(lane) == nwords - 1 && (rows & 63u)) tail = (uint64_t(1) << (rows & 63u)) - 1;
+            const uint64_t w = L.d_selection ? L.d_selection[descs[entry].mask_word_off + uint64_t(blk) * 16u + lane]
+                                             : ~uint64_t(0);
+            c = uint32_t(__popcll(w & tail));
+        }
+    }
+    c = uint32_t(wave_sum_u64(c));
+    if (lane == 0) block_counts[gw] = c;
+}
+
+// single workgroup exclusive scan; also emits per-entry row offsets (n_entries + 1 values)
+__global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restrict__ counts, uint64_t n,
+                                                         uint32_t blocks_per_entry, uint64_t* __restrict__ offsets,
+                                                         uint64_t* __restrict__ entry_offsets) {
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint64_t carry;
+    const int lane = lane_id(), wave = wave_id();
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n ? counts[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint64_t t = __shfl_up(incl, o, kWave);
+            if (lane >= o) incl += t;
+        }
+        if (lane == kWave - 1) wave_tot[wave] = incl;
+        __syncthreads();
+        uint64_t wbase = carry;
+        for (int w = 0; w < wave; w++) wbase += wave_tot[w];
+        const uint64_t excl = wbase + incl - v;
+        if (i < n) {
+            offsets[i] = excl;
+            if (entry_offsets && (i % blocks_per_entry) == 0) entry_offsets[i / blocks_per_entry] = excl;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = wbase + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        offsets[n] = carry;
+        if (entry_offsets) entry_offsets[n / blocks_per_entry] = carry;
+    }
+}
+
+// ALP decode constants (float_array.rs:127-224); evaluation order (i as f) * F10[f] * IF10[e] without contraction
+__device__ const float kF10f[11] = {1.0f, 10.0f, 100.0f, 1000.0f, 10000.0f, 100000.0f, 1000000.0f, 10000000.0f,
+                                    100000000.0f, 1000000000.0f, 10000000000.0f};
+__device__ const float kIF10f[11] = {1.0f, 0.1f, 0.01f, 0.001f, 0.0001f, 0.00001f, 0.000001f, 0.0000001f,
+                                     0.00000001f, 0.000000001f, 0.0000000001f};
+__device__ const double kF10d[24] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                     1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22, 1e23};
+__device__ const double kIF10d[24] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001, 0.00000001,
+                                      0.000000001, 0.0000000001, 0.00000000001, 0.000000000001, 0.0000000000001,
+                                      0.00000000000001, 0.000000000000001, 0.0000000000000001, 0.00000000000000001,
+                                      0.000000000000000001, 0.0000000000000000001, 0.00000000000000000001,
+                                      0.000000000000000000001, 0.0000000000000000000001, 0.00000000000000000000001};
+
+__device__ __forceinline__ float alp_decode(int32_t i, uint32_t e, uint32_t f) {
+    return __fmul_rn(__fmul_rn(float(i), kF10f[f]), kIF10f[e]);
+}
+__device__ __forceinline__ double alp_decode(int64_t i, uint32_t e, uint32_t f) {
+    return __dmul_rn(__dmul_rn(double(i), kF10d[f]), kIF10d[e]);
+}
+
+template <typename U>
+__global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __restrict__ descs, ScanLaunch L,
+                                                            const uint64_t* __restrict__ block_offsets,
+                                                            uint8_t* __restrict__ out) {
+    constexpr uint32_t TB = LaneTraits<U>::kBits;
+    constexpr uint32_t kBlockBytesMax = 128u * TB;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][kBlockBytesMax + 128];
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t gw = blockIdx.x * kWavesPerBlock + uint32_t(wave);
+    const uint32_t entry = gw / L.blocks_per_entry, blk = gw % L.blocks_per_entry;
+    if (entry >= L.n_entries) return;
+    const FixedDesc d = descs[entry];
+    const uint32_t row0 = blk * 1024u;
+    if (row0 >= d.len) return;
+    const uint32_t rows = min(1024u, d.len - row0);
+    const uint32_t nwords = (rows + 63u) >> 6;
+    const uint64_t word_base = d.mask_word_off + uint64_t(blk) * 16u;
+    uint64_t act = 0;
+    if (uint32_t(lane) < nwords) {
+        uint64_t tail = ~uint64_t(0);
+        if (uint32_t(lane) == nwords - 1 && (rows & 63u)) tail = (uint64_t(1) << (rows & 63u)) - 1;
+        act = (L.d_selection ? L.d_selection[word_base + lane] : ~uint64_t(0)) & tail;
+    }
+    if (__ballot(act != 0) == 0) return;
+    const uint32_t vw = d.value_width;
+    uint64_t out_row = block_offsets[gw];
+    uint8_t* buf = lds[wave];
+    const uint32_t W = d.W;
+    if (W != 0) {
+        const uint32_t nchunks = 8u * W;
+        const uint4* src = reinterpret_cast<const uint4*>(d.packed + uint64_t(blk) * 128u * W);
+        constexpr int kSteps = int(kBlockBytesMax / 1024u) > 0 ? int(kBlockBytesMax / 1024u) : 1;
+#pragma unroll
+        for (int s = 0; s < kSteps; s++) {
+            if (uint32_t(s) * 64u < nchunks) {
+                const uint32_t c = uint32_t(s) * 64u + uint32_t(lane);
+                if (c < nchunks) async_copy16(src + c, buf + s * 1024);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    const U mask = (W >= TB) ? U(~U(0)) : U((U(1) << (W & (TB - 1))) - 1);
+    for (uint32_t it = 0; it < nwords; it++) {
+        const uint32_t alo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act)), int(it)));
+        const uint32_t ahi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act >> 32)), int(it)));
+        const uint64_t aw = uint64_t(alo) | (uint64_t(ahi) << 32);
+        if (aw == 0) continue;
+        if ((aw >> lane) & 1) {
+            U u = 0;
+            if (W != 0) {  // all-null entries decode to zeros (PrimitiveArray::new_null)
+                uint32_t row, fl;
+                fl_row_lane<U>(it * 64u + uint32_t(lane), &row, &fl);
+                u = extract_packed<U>(buf, row, fl, W, mask);
+            }
+            const uint64_t o = out_row + lanes_below(aw);
+            if (d.kind == kKindInt) {
+                const U v = W != 0 ? U(u + U(d.reference)) : U(0);  // add_wrapping (primitive_array.rs:357)
+                reinterpret_cast<U*>(out)[o] = v;
+            } else if (d.kind == kKindDecimal) {
+                if constexpr (TB == 64) {
+                    const uint64_t v = W != 0 ? uint64_t(u) + d.reference : 0;  // decimal_array.rs:189, :285
+                    uint64_t* p = reinterpret_cast<uint64_t*>(out + o * vw);
+                    p[0] = v;
+                    p[1] = 0;
+                    if (vw == 32) { p[2] = 0; p[3] = 0; }
+                }
+            } else if (d.kind == kKindF32) {
+                if constexpr (TB == 32) {
+                    const int32_t iv = int32_t(uint32_t(u) + uint32_t(d.reference));
+                    reinterpret_cast<float*>(out)[o] = W != 0 ? alp_decode(iv, d.alp_e, d.alp_f) : 0.0f;
+                }
+            } else {
+                if constexpr (TB == 64) {
+                    const int64_t iv = int64_t(uint64_t(u) + d.reference);
+                    reinterpret_cast<double*>(out)[o] = W != 0 ? alp_decode(iv, d.alp_e, d.alp_f) : 0.0;
+                }
+            }
+        }
+        out_row += uint32_t(__popcll(aw));
+    }
+    // ALP patches overwrite the decoded value (float_array.rs:306-310); patch indices are ascending
+    if ((d.kind == kKindF32 || d.kind == kKindF64) && d.patch_len) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t lo_i = 0, hi_i = d.patch_len;  // first patch with index >= row0
+        while (lo_i < hi_i) {
+            const uint32_t mid = (lo_i + hi_i) >> 1;
+            if (d.patch_idx[mid] < row0) lo_i = mid + 1; else hi_i = mid;
+        }
+        const uint64_t base_row = block_offsets[gw];
+        for (uint32_t p = lo_i + uint32_t(lane); p < d.patch_len; p += kWave) {
+            const uint64_t idx = d.patch_idx[p];
+            if (idx >= uint64_t(row0) + rows) break;
+            const uint32_t r = uint32_t(idx - row0);
+            // selection word of this row lives in lane r>>6: every lane keeps a private copy via shuffles
+            const uint32_t wl = r >> 6;
+            uint64_t rank = 0;
+            bool selected = false;
+            for (uint32_t w = 0; w <= wl; w++) {
+                const uint64_t sw = (L.d_selection ? L.d_selection[word_base + w] : ~uint64_t(0));
+                uint64_t m = sw;
+                if (w == nwords - 1 && (rows & 63u)) m &= (uint64_t(1) << (rows & 63u)) - 1;
+                if (w < wl) rank += uint64_t(__popcll(m));
+                else {
+                    selected = (m >> (r & 63u)) & 1;
+                    rank += uint64_t(__popcll(m & ((uint64_t(1) << (r & 63u)) - 1)));
+                }
+            }
+            if (selected) {
+                if (d.kind == kKindF32) reinterpret_cast<uint32_t*>(out)[base_row + rank] = reinterpret_cast<const uint32_t*>(d.patch_val)[p];
+                else reinterpret_cast<uint64_t*>(out)[base_row + rank] = reinterpret_cast<const uint64_t*>(d.patch_val)[p];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// get-with-selection for byte views (byte_view_array/mod.rs:421-424, 266-290): one workgroup per entry.
+//   pass 1: decoded length of every dictionary entry (sum of symbol lengths)
+//   pass 2: selected rows -> i32 offsets (exclusive scan of the referenced lengths, nulls contribute 0)
+//   pass 3: every selected row decodes its dictionary entry at its offset
+// Outputs: offsets (k+1 i32), data; the caller sizes `data` from the entry's uncompressed size bound.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_str_dict_lengths(const StrDesc* __restrict__ descs,
+                                                               const DevSymtab* __restrict__ symtabs, uint32_t entry,
+                                                               uint32_t* __restrict__ dlen) {
+    const StrDesc d = descs[entry];
+    const DevSymtab& st = symtabs[d.symtab_slot];
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < d.d; i += gridDim.x * kThreads) {
+        const uint32_t start = str_offset(d, i), stop = str_offset(d, i + 1);
+        ByteReader r;
+        r.init(d.fsst, start, stop);
+        uint32_t n = 0;
+        while (r.more()) {
+            const uint32_t c = r.next();
+            if (c == 255u) { if (!r.more()) break; r.next(); n++; }
+            else n += st.len[c];
+        }
+        dlen[i] = n;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_str_row_offsets(const StrDesc* __restrict__ descs, uint32_t entry,
+                                                          const uint64_t* __restrict__ selection,
+                                                          const uint32_t* __restrict__ dlen,
+                                                          int32_t* __restrict__ out_offsets,
+                                                          uint32_t* __restrict__ out_rows /* selected row ids */,
+                                                          uint64_t* __restrict__ totals /* [k, bytes] */) {
+    __shared__ uint32_t wave_cnt[16];
+    __shared__ uint64_t wave_len[16];
+    __shared__ uint32_t carry_cnt;
+    __shared__ uint64_t carry_len;
+    const StrDesc d = descs[entry];
+    const int lane = lane_id(), wave = wave_id();
+    if (threadIdx.x == 0) { carry_cnt = 0; carry_len = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < d.n; base += 1024) {
+        const uint32_t i = base + threadIdx.x;
+        bool sel = false;
+        uint32_t l = 0;
+        if (i < d.n) {
+            sel = selection ? ((selection[i >> 6] >> (i & 63u)) & 1) : true;
+            const bool valid = d.validity ? ((d.validity[i >> 6] >> (i & 63u)) & 1) : true;
+            if (sel && valid) l = dlen[d.keys[i]];
+        }
+        uint32_t ci = sel ? 1u : 0u;
+        uint64_t li = l;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint32_t tc = __shfl_up(ci, o, kWave);
+            const uint64_t tl = __shfl_up(li, o, kWave);
+            if (lane >= o) { ci += tc; li += tl; }
+        }
+        if (lane == kWave - 1) { wave_cnt[wave] = ci; wave_len[wave] = li; }
+        __syncthreads();
+        uint32_t cb = carry_cnt;
+        uint64_t lb = carry_len;
+        for (int w = 0; w < wave; w++) { cb += wave_cnt[w]; lb += wave_len[w]; }
+        if (sel) {
+            const uint32_t r = cb + ci - 1;
+            out_offsets[r] = int32_t(lb + li - l);
+            out_rows[r] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) { carry_cnt = cb + ci; carry_len = lb + li; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out_offsets[carry_cnt] = int32_t(carry_len);
+        totals[0] = carry_cnt;
+        totals[1] = carry_len;
+    }
+}
+
+__device__ __forceinline__ void str_decode_rows_body(const StrDesc* __restrict__ descs,
+                                                              const DevSymtab* __restrict__ symtabs, uint32_t entry,
+                                                              const int32_t* __restrict__ offsets,
+                                                              const uint32_t* __restrict__ rows, uint32_t k,
+                                                              uint8_t* __restrict__ data) {
+    const StrDesc d = descs[entry];
+    const DevSymtab& st = symtabs[d.symtab_slot];
+    for (uint32_t r = blockIdx.x * kThreads + threadIdx.x; r < k; r += gridDim.x * kThreads) {
+        const uint32_t i = rows[r];
+        const bool valid = d.validity ? ((d.validity[i >> 6] >> (i & 63u)) & 1) : true;
+        if (!valid) continue;
+        const uint32_t key = d.keys[i];
+        const uint32_t start = str_offset(d, key), stop = str_offset(d, key + 1);
+        uint8_t* o = data + offsets[r];
+        ByteReader br;
+        br.init(d.fsst, start, stop);
+        while (br.more()) {
+            const uint32_t c = br.next();
+            if (c == 255u) { if (!br.more()) break; *o++ = uint8_t(br.next()); }
+            else {
+                const uint64_t sym = st.sym[c];
+                const uint32_t sl = st.len[c];
+                for (uint32_t b = 0; b < sl; b++) o[b] = uint8_t(sym >> (8 * b));
+                o += sl;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_str_decode_rows_dyn(const StrDesc* __restrict__ descs,
+                                                                  const DevSymtab* __restrict__ symtabs, uint32_t entry,
+                                                                  const int32_t* __restrict__ offsets,
+                                                                  const uint32_t* __restrict__ rows,
+                                                                  const uint64_t* __restrict__ totals,
+                                                                  uint8_t* __restrict__ data) {
+    str_decode_rows_body(descs, symtabs, entry, offsets, rows, uint32_t(totals[0]), data);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -691,6 +1037,41 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     if (L.n_entries == 0) return hipSuccess;
     const size_t dyn_lds = pred.mode == 1 ? size_t(pred.needle_len + 1) * 512 : 16;
     hipLaunchKernelGGL(k_str_pred, dim3(L.n_entries), dim3(kThreads), dyn_lds, stream, d_descs, d_symtabs, pred, L);
+    return hipGetLastError();
+}
+
+
+hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
+                               uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
+                               hipStream_t stream) {
+    const uint64_t waves = uint64_t(L.n_entries) * L.blocks_per_entry;
+    if (waves == 0) return hipSuccess;
+    const dim3 grid(uint32_t((waves + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
+    hipLaunchKernelGGL(k_sel_block_counts, grid, block, 0, stream, d_descs, L, d_block_counts);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, d_block_counts, waves, L.blocks_per_entry,
+                       d_block_offsets, d_entry_row_offsets);
+    switch (lane_log2) {
+        case 3: hipLaunchKernelGGL(k_fixed_gather<uint8_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
+        case 4: hipLaunchKernelGGL(k_fixed_gather<uint16_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
+        case 5: hipLaunchKernelGGL(k_fixed_gather<uint32_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
+        case 6: hipLaunchKernelGGL(k_fixed_gather<uint64_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_str_gather(const StrDesc* d_descs, const DevSymtab* d_symtabs, uint32_t entry, uint32_t dict_len,
+                             uint32_t n_rows, const uint64_t* d_selection, uint32_t* d_dict_len, int32_t* d_offsets,
+                             uint32_t* d_rows, uint64_t* d_totals, uint8_t* d_data, hipStream_t stream) {
+    const uint32_t g1 = dict_len ? (dict_len + kThreads - 1) / kThreads : 1;
+    hipLaunchKernelGGL(k_str_dict_lengths, dim3(g1), dim3(kThreads), 0, stream, d_descs, d_symtabs, entry, d_dict_len);
+    hipLaunchKernelGGL(k_str_row_offsets, dim3(1), dim3(1024), 0, stream, d_descs, entry, d_selection, d_dict_len,
+                       d_offsets, d_rows, d_totals);
+    if (!d_data) return hipGetLastError();  // sizing pass only
+    const uint32_t g3 = n_rows ? (n_rows + kThreads - 1) / kThreads : 1;
+    // k is only known on the device: every thread bounds itself by totals[0]
+    hipLaunchKernelGGL(k_str_decode_rows_dyn, dim3(g3), dim3(kThreads), 0, stream, d_descs, d_symtabs, entry, d_offsets,
+                       d_rows, d_totals, d_data);
     return hipGetLastError();
 }
 

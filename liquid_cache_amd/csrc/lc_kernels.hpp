@@ -84,6 +84,7 @@ struct StrPred {
     const uint8_t* automata;   // mode 1: per symbol-table-slot transition tables, (m+1)*512 bytes each
     uint32_t automaton_stride;
     int32_t const_value;       // mode 2: Literal(Boolean)
+    int32_t debug_flags;       // profiling only (env LC_DEBUG_FLAGS): 1 skip phase B, 2 skip phase C, 4 skip phase A
     uint8_t needle_inline[kInlineNeedle];
 };
 
@@ -104,15 +105,19 @@ hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, c
 hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, const StrPred& pred,
                            const ScanLaunch& L, hipStream_t stream);
 // per-block selected-row counts -> exclusive offsets, then compaction of decoded values
+// d_block_counts: n_entries*blocks_per_entry u32; d_block_offsets: that + 1 u64; d_entry_row_offsets: n_entries + 1 u64
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
-                               uint8_t* d_validity_bytes_out, hipStream_t stream);
+                               hipStream_t stream);
 // bit compress (PEXT) / deposit (PDEP) per entry segment
 hipError_t launch_mask_compress(const uint64_t* d_src, const uint64_t* d_sel, const uint64_t* d_seg_offsets,
                                 uint32_t n_entries, uint64_t* d_out, uint32_t* d_out_bits, hipStream_t stream);
 hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, const uint64_t* d_right, uint64_t* d_out,
                                 hipStream_t stream);
-hipError_t launch_str_gather_lengths(const StrDesc* d_descs, const DevSymtab* d_symtabs, uint32_t entry,
-                                     const uint64_t* d_selection, uint32_t* d_dict_len, hipStream_t stream);
+// byte-view get-with-selection of ONE entry: d_dict_len (D u32 scratch), d_offsets (n+1 i32), d_rows (n u32 scratch),
+// d_totals (2 u64: selected rows, data bytes), d_data (>= uncompressed bytes of the referenced values + 8)
+hipError_t launch_str_gather(const StrDesc* d_descs, const DevSymtab* d_symtabs, uint32_t entry, uint32_t dict_len,
+                             uint32_t n_rows, const uint64_t* d_selection, uint32_t* d_dict_len, int32_t* d_offsets,
+                             uint32_t* d_rows, uint64_t* d_totals, uint8_t* d_data, hipStream_t stream);
 
 }  // namespace lc

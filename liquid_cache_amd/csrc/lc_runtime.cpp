@@ -402,6 +402,7 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
     } else {
         return fail(LC_UNSUPPORTED, "operator not supported on byte-view columns");
     }
+    if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->p.debug_flags = std::atoi(dbg);
     out->p.needle_len = uint32_t(out->needle.size());
     if (out->needle.size() <= size_t(kInlineNeedle))
         std::memcpy(out->p.needle_inline, out->needle.data(), out->needle.size());
@@ -1002,12 +1003,215 @@ lc_status lc_mask_and_then(lc_ctx* ctx, const uint8_t* left, uint64_t left_bits,
     return rc;
 }
 
-lc_status lc_get_with_selection(lc_ctx*, uint64_t, const uint8_t*, struct ArrowArray*, struct ArrowSchema*) {
-    return fail(LC_UNSUPPORTED, "get-with-selection lands in the next milestone");
+// ---- Arrow C Data Interface export helpers ----
+extern "C++" {
+namespace {
+struct ExportPriv {
+    std::vector<void*> owned;
+    const void* buffers[3] = {nullptr, nullptr, nullptr};
+    std::string format;
+};
+void release_array(struct ArrowArray* a) {
+    if (!a || !a->release) return;
+    ExportPriv* p = static_cast<ExportPriv*>(a->private_data);
+    for (void* q : p->owned) std::free(q);
+    delete p;
+    a->release = nullptr;
+}
+void release_schema(struct ArrowSchema* s) {
+    if (!s || !s->release) return;
+    delete static_cast<std::string*>(s->private_data);
+    s->release = nullptr;
+}
+void fill_schema(struct ArrowSchema* s, const std::string& fmt) {
+    std::memset(s, 0, sizeof(*s));
+    std::string* keep = new std::string(fmt);
+    s->format = keep->c_str();
+    s->name = "";
+    s->flags = 2;  // ARROW_FLAG_NULLABLE
+    s->release = release_schema;
+    s->private_data = keep;
+}
+std::string arrow_format(const Entry& e) {
+    if (e.is_str) return (e.phys == kBinary || e.phys == kBinaryView || e.phys == kDict16Binary) ? "z" : "u";
+    if (e.logical == kDecimal) {
+        char buf[48];
+        std::snprintf(buf, sizeof(buf), e.dec_is256 ? "d:%d,%d,256" : "d:%d,%d", e.dec_precision, e.dec_scale);
+        return buf;
+    }
+    switch (e.phys) {
+        case kI8: return "c"; case kI16: return "s"; case kI32: return "i"; case kI64: return "l";
+        case kU8: return "C"; case kU16: return "S"; case kU32: return "I"; case kU64: return "L";
+        case kF32: return "f"; case kF64: return "g"; case kDate32: return "tdD"; case kDate64: return "tdm";
+        case kTsS: return "tss:"; case kTsMs: return "tsm:"; case kTsUs: return "tsu:"; case kTsNs: return "tsn:";
+        default: return "l";
+    }
+}
+}  // namespace
+}  // extern "C++"
+
+// cache.get(&id).with_selection(&sel).read(): decode + compact on the device, export through the C Data Interface
+lc_status lc_get_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection,
+                                struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+    if (!ctx || !out_array || !out_schema) return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    lc_scan* scan = nullptr;
+    lc_status rc = lc_scan_create(ctx, 1, &entry_id, &scan);
+    if (rc != LC_OK) return rc;
+    std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
+    const Entry& e = scan->meta[0];
+    const uint64_t words = std::max<uint64_t>((uint64_t(e.len) + 63) / 64, 1);
+    std::vector<void*> dev;
+    auto dalloc = [&](size_t bytes) -> void* {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr;
+        dev.push_back(p);
+        return p;
+    };
+    auto dfree = [&]() { for (void* p : dev) (void)hipFree(p); dev.clear(); };
+#define LC_HIP_G(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            dfree();                                                                            \
+            return fail(LC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+        }                                                                                       \
+    } while (0)
+    uint64_t* d_sel = nullptr;
+    std::vector<uint64_t> h_sel(words, 0);
+    if (selection) {
+        std::memcpy(h_sel.data(), selection, bitmap_bytes(e.len));
+        if (e.len & 63) h_sel[words - 1] &= (uint64_t(1) << (e.len & 63)) - 1;
+        d_sel = static_cast<uint64_t*>(dalloc(words * 8));
+        if (!d_sel) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
+        LC_HIP_G(hipMemcpy(d_sel, h_sel.data(), words * 8, hipMemcpyHostToDevice));
+    }
+    // compacted validity (k bits)
+    std::vector<uint64_t> h_valid(words, 0);
+    uint32_t k_bits = 0;
+    {
+        uint64_t* d_vsrc = static_cast<uint64_t*>(dalloc(words * 8));
+        uint64_t* d_vout = static_cast<uint64_t*>(dalloc(words * 8));
+        uint32_t* d_bits = static_cast<uint32_t*>(dalloc(4));
+        if (!d_vsrc || !d_vout || !d_bits) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
+        const uint64_t* vptr = e.is_str ? e.sd.validity : e.fd.validity;
+        if (e.all_null) LC_HIP_G(hipMemset(d_vsrc, 0, words * 8));
+        else if (vptr) LC_HIP_G(hipMemcpy(d_vsrc, vptr, ((uint64_t(e.len) + 63) / 64) * 8, hipMemcpyDeviceToDevice));
+        else LC_HIP_G(hipMemset(d_vsrc, 0xFF, words * 8));
+        std::vector<uint64_t> sel_all;
+        const uint64_t* d_selc = d_sel;
+        if (!d_selc) {  // no selection: "all rows", with the tail masked
+            sel_all.assign(words, ~uint64_t(0));
+            if (e.len & 63) sel_all[words - 1] = (uint64_t(1) << (e.len & 63)) - 1;
+            if (e.len == 0) sel_all[0] = 0;
+            uint64_t* d_all = static_cast<uint64_t*>(dalloc(words * 8));
+            if (!d_all) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
+            LC_HIP_G(hipMemcpy(d_all, sel_all.data(), words * 8, hipMemcpyHostToDevice));
+            d_selc = d_all;
+        }
+        LC_HIP_G(launch_mask_compress(d_vsrc, d_selc, scan->d_seg_offsets, 1, d_vout, d_bits, nullptr));
+        LC_HIP_G(hipMemcpy(h_valid.data(), d_vout, words * 8, hipMemcpyDeviceToHost));
+        LC_HIP_G(hipMemcpy(&k_bits, d_bits, 4, hipMemcpyDeviceToHost));
+    }
+    const uint64_t k = k_bits;
+    std::unique_ptr<ExportPriv> priv(new ExportPriv());
+    auto host_alloc = [&](size_t bytes) -> uint8_t* {
+        uint8_t* p = static_cast<uint8_t*>(std::calloc(bytes + 64, 1));
+        priv->owned.push_back(p);
+        return p;
+    };
+    int64_t null_count = 0;
+    if (e.nullable) {
+        uint8_t* vb = host_alloc(bitmap_bytes(k));
+        std::memcpy(vb, h_valid.data(), bitmap_bytes(k));
+        null_count = int64_t(k) - int64_t(count_bits(vb, k));
+        priv->buffers[0] = vb;
+    }
+    int64_t n_buffers = 2;
+    if (!e.is_str) {
+        ScanLaunch L{};
+        L.n_entries = 1;
+        L.blocks_per_entry = scan->bpe;
+        L.d_selection = d_sel;
+        const size_t vw = e.fd.value_width;
+        uint32_t* d_bc = static_cast<uint32_t*>(dalloc(size_t(scan->bpe) * 4));
+        uint64_t* d_bo = static_cast<uint64_t*>(dalloc((size_t(scan->bpe) + 1) * 8));
+        uint64_t* d_eo = static_cast<uint64_t*>(dalloc(2 * 8));
+        uint8_t* d_vals = static_cast<uint8_t*>(dalloc(std::max<size_t>(k, 1) * vw + 64));
+        if (!d_bc || !d_bo || !d_eo || !d_vals) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
+        LC_HIP_G(hipMemset(d_vals, 0, std::max<size_t>(k, 1) * vw + 64));
+        LC_HIP_G(launch_fixed_gather(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, d_bc, d_bo, d_eo,
+                                     d_vals, nullptr));
+        uint8_t* vals = host_alloc(std::max<size_t>(k, 1) * vw);
+        LC_HIP_G(hipMemcpy(vals, d_vals, k * vw, hipMemcpyDeviceToHost));
+        priv->buffers[1] = vals;
+    } else {
+        n_buffers = 3;
+        uint32_t* d_dlen = static_cast<uint32_t*>(dalloc((size_t(e.dict_len) + 1) * 4));
+        int32_t* d_offs = static_cast<int32_t*>(dalloc((size_t(e.len) + 2) * 4));
+        uint32_t* d_rows = static_cast<uint32_t*>(dalloc((size_t(e.len) + 1) * 4));
+        uint64_t* d_tot = static_cast<uint64_t*>(dalloc(16));
+        if (!d_dlen || !d_offs || !d_rows || !d_tot) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
+        const StrDesc* descs = static_cast<const StrDesc*>(scan->d_descs);
+        // passes 1+2 size the output, pass 3 decodes (two launches of the same helper keep the code in one place)
+        LC_HIP_G(launch_str_gather(descs, ctx->d_symtabs, 0, e.dict_len, 0, d_sel, d_dlen, d_offs, d_rows, d_tot, nullptr,
+                                   nullptr));
+        uint64_t tot[2] = {0, 0};
+        LC_HIP_G(hipMemcpy(tot, d_tot, 16, hipMemcpyDeviceToHost));
+        if (tot[1] > uint64_t(INT32_MAX)) { dfree(); return fail(LC_UNSUPPORTED, "selected strings exceed 2 GiB (i32 offsets)"); }
+        uint8_t* d_data = static_cast<uint8_t*>(dalloc(tot[1] + 64));
+        if (!d_data) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
+        LC_HIP_G(launch_str_gather(descs, ctx->d_symtabs, 0, e.dict_len, uint32_t(tot[0]), d_sel, d_dlen, d_offs, d_rows,
+                                   d_tot, d_data, nullptr));
+        int32_t* offs = reinterpret_cast<int32_t*>(host_alloc((k + 1) * 4));
+        uint8_t* data = host_alloc(tot[1]);
+        LC_HIP_G(hipMemcpy(offs, d_offs, (k + 1) * 4, hipMemcpyDeviceToHost));
+        LC_HIP_G(hipMemcpy(data, d_data, tot[1], hipMemcpyDeviceToHost));
+        priv->buffers[1] = offs;
+        priv->buffers[2] = data;
+    }
+    dfree();
+#undef LC_HIP_G
+    std::memset(out_array, 0, sizeof(*out_array));
+    out_array->length = int64_t(k);
+    out_array->null_count = null_count;
+    out_array->offset = 0;
+    out_array->n_buffers = n_buffers;
+    out_array->buffers = priv->buffers;
+    out_array->release = release_array;
+    fill_schema(out_schema, arrow_format(e));
+    out_array->private_data = priv.release();
+    return LC_OK;
 }
 
-lc_status lc_scan_gather_fixed(lc_ctx*, lc_scan*, const void*, void*, uint64_t, void*, void*) {
-    return fail(LC_UNSUPPORTED, "scan gather lands in the next milestone");
+lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_values_out,
+                               uint64_t values_capacity_bytes, void* d_row_offsets, void* stream) {
+    if (!ctx || !scan || !d_values_out || !d_row_offsets) return fail(LC_ERR_INVALID, "null argument");
+    if (scan->is_str) return fail(LC_UNSUPPORTED, "scan-wide gather covers fixed-width columns");
+    if (scan->n == 0) return LC_OK;
+    const uint64_t vw = scan->meta[0].fd.value_width;
+    if (values_capacity_bytes < scan->total_rows * vw && !d_selection)
+        return fail(LC_ERR_INVALID, "values buffer too small for an unselected gather");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> g(scan->mu);
+    const size_t nblk = size_t(scan->n) * scan->bpe;
+    const size_t need = nblk * 4 + (nblk + 1) * 8 + 64;
+    if (need > scan->needle_cap) {  // reuse the scan's scratch allocation
+        LC_HIP(hipStreamSynchronize(st));
+        if (scan->d_needle) LC_HIP(hipFree(scan->d_needle));
+        LC_HIP(hipMalloc(reinterpret_cast<void**>(&scan->d_needle), need));
+        scan->needle_cap = need;
+    }
+    uint64_t* d_bo = reinterpret_cast<uint64_t*>(scan->d_needle);
+    uint32_t* d_bc = reinterpret_cast<uint32_t*>(scan->d_needle + (nblk + 1) * 8);
+    ScanLaunch L{};
+    L.n_entries = scan->n;
+    L.blocks_per_entry = scan->bpe;
+    L.d_selection = static_cast<const uint64_t*>(d_selection);
+    LC_HIP(launch_fixed_gather(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, d_bc, d_bo,
+                               static_cast<uint64_t*>(d_row_offsets), static_cast<uint8_t*>(d_values_out), st));
+    return LC_OK;
 }
 
 }  // extern "C"

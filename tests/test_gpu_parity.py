@@ -212,3 +212,112 @@ def test_scan_conjunction_chain(gpu_cache, oracle):
     got = np.concatenate([bits[int(sb.segment_offsets[k]) * 64: int(sb.segment_offsets[k]) * 64 +
                                (min((k + 1) * n, len(a)) - k * n)] for k in range(n_batches)]).astype(bool)
     assert got.tolist() == want.tolist()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# get().with_selection()  (LiquidCache::read_arrow_array -> LiquidArray::filter)
+# ---------------------------------------------------------------------------------------------------------------
+def _arrow_values_valid(arr: pa.Array):
+    valid = ~np.asarray(arr.is_null().to_numpy(zero_copy_only=False), dtype=bool)
+    return arr, valid
+
+
+@pytest.mark.parametrize("name,dtype", INT_TYPES)
+def test_get_with_selection_integers(gpu_cache, oracle, name, dtype):
+    lo = oracle
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    np_dtype = lo.PHYS_NP[lo.PHYS[name]]
+    bits = np.dtype(np_dtype).itemsize * 8
+    eid = 100
+    for W in sorted({1, 5, min(13, bits), bits - 1, bits}):
+        for n in (8192, 1030, 1, 64):
+            vals = _random_ints(rng, np_dtype, n, W)
+            valid = rng.random(n) < 0.7 if rng.integers(2) else None
+            liquid = lo.encode_primitive(lo.PHYS[name], vals, valid)
+            eid += 1
+            gpu_cache.stage([eid], [liquid], data_types=[dtype])
+            for p in (None, 0.0, 0.03, 0.5, 1.0):
+                sel = None if p is None else (rng.random(n) < p)
+                g = gpu_cache.get(eid)
+                got = (g.with_selection(sel) if sel is not None else g).read()
+                want_vals, want_valid = lo.filter_fixed(liquid, sel if sel is not None else np.ones(n, bool))
+                assert got.type == dtype
+                assert len(got) == len(want_vals)
+                storage = pa.from_numpy_dtype(np_dtype)
+                gnp = got.view(storage).fill_null(0).to_numpy(zero_copy_only=False)
+                gvalid = ~np.asarray(got.is_null().to_numpy(zero_copy_only=False), dtype=bool)
+                if want_valid is None:
+                    assert gvalid.all()
+                    assert gnp.astype(np_dtype).tolist() == want_vals.tolist()
+                else:
+                    assert gvalid.tolist() == want_valid.tolist()
+                    assert gnp.astype(np_dtype)[want_valid].tolist() == want_vals[want_valid].tolist()
+
+
+def test_get_with_selection_reference_vectors(gpu_cache):
+    # primitive_array.rs:928-944: [1,2,3,None,5] filter [T,F,T,F,T] -> [1,3,5]; README.md:43-60
+    gpu_cache.insert(1, pa.array([1, 2, 3, None, 5], type=pa.int32()))
+    assert gpu_cache.get(1).with_selection([True, False, True, False, True]).read().to_pylist() == [1, 3, 5]
+    gpu_cache.insert(2, pa.array([10, 11, 12, 13, 14, 15], type=pa.uint64()))
+    assert gpu_cache.get(2).with_selection([True, False, True, False, True, False]).read().to_pylist() == [10, 12, 14]
+    # primitive_array.rs:953-968 all-null filter
+    gpu_cache.insert(3, pa.array([None, None, None, None], type=pa.int32()))
+    assert gpu_cache.get(3).with_selection([True, False, False, True]).read().to_pylist() == [None, None]
+    assert gpu_cache.get(3).with_selection([False] * 4).read().to_pylist() == []
+    assert gpu_cache.get(99).read() is None
+
+
+def test_get_with_selection_floats_and_decimals(gpu_cache, oracle):
+    lo = oracle
+    import decimal
+    rng = np.random.default_rng(77)
+    for dt, pat in ((np.float32, pa.float32()), (np.float64, pa.float64())):
+        for n in (8192, 3000, 5):
+            base = rng.normal(size=n).astype(dt).round(2)
+            base[rng.random(n) < 0.02] = dt(np.pi)          # forces ALP patches
+            if n > 4:
+                base[1], base[2] = np.nan, np.inf
+            arr = pa.array(base, type=pat, mask=(rng.random(n) < 0.1))
+            liquid = gpu_cache.transcode(arr)
+            gpu_cache.stage([500 + n], [liquid], data_types=[pat])
+            for p in (None, 0.2, 1.0):
+                sel = None if p is None else (rng.random(n) < p)
+                g = gpu_cache.get(500 + n)
+                got = (g.with_selection(sel) if sel is not None else g).read()
+                # the oracle decodes the same Liquid bytes (ALP maps -0.0 to +0.0 exactly like the reference:
+                # float_array.rs:636 compares with `==`, so -0.0 is not patched)
+                wv, valid = lo.filter_fixed(liquid, sel if sel is not None else np.ones(n, bool))
+                assert got.type == pat and len(got) == len(wv)
+                gv = got.to_numpy(zero_copy_only=False)
+                assert (~np.asarray(got.is_null().to_numpy(zero_copy_only=False), dtype=bool)).tolist() == valid.tolist()
+                bits = np.uint32 if dt == np.float32 else np.uint64
+                assert gv[valid].view(bits).tolist() == wv[valid].view(bits).tolist()  # bit-exact
+                want = arr if sel is None else arr.filter(pa.array(sel))
+                np.testing.assert_array_equal(gv[valid], want.to_numpy(zero_copy_only=False)[valid])
+    vals = [decimal.Decimal(int(x)) / 100 for x in rng.integers(0, 100000, size=5000)]
+    vals[7] = None
+    arr = pa.array(vals, type=pa.decimal128(15, 2))
+    gpu_cache.insert(900, arr)
+    sel = rng.random(5000) < 0.3
+    assert gpu_cache.get(900).with_selection(sel).read().to_pylist() == arr.filter(pa.array(sel)).to_pylist()
+    assert gpu_cache.get(900).read().to_pylist() == arr.to_pylist()
+
+
+@pytest.mark.parametrize("arrow_type", [pa.string(), pa.binary(), pa.string_view()])
+def test_get_with_selection_strings(gpu_cache, oracle, arrow_type):
+    rng = np.random.default_rng(91)
+    for n, d, nulls in ((8192, 2200, True), (500, 400, False), (2, 2, False)):
+        strs = _make_strings(rng, n, d, nulls)
+        arr = pa.array([None if s is None else (s.encode() if pa.types.is_binary(arrow_type) else s) for s in strs],
+                       type=arrow_type)
+        eid = lc.ParquetArrayID.new(1, n % 7, 3, 0)
+        gpu_cache.insert(eid, arr, lc.CacheExpression.SUBSTRING_SEARCH)
+        for p in (None, 0.0, 0.01, 0.4, 1.0):
+            sel = None if p is None else (rng.random(n) < p)
+            g = gpu_cache.get(eid)
+            got = (g.with_selection(sel) if sel is not None else g).read()
+            plain = arr.cast(pa.string()) if pa.types.is_string_view(arrow_type) else arr
+            want = plain if sel is None else plain.filter(pa.array(sel))
+            assert got.type == arrow_type
+            assert got.to_pylist() == want.to_pylist()
