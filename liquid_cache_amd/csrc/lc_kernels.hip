@@ -15,6 +15,8 @@
 
 #include "../../include/liquid_cache_amd.h"
 
+#include <utility>
+
 namespace lc {
 
 namespace {
@@ -44,6 +46,13 @@ __device__ __forceinline__ void async_copy16(const void* gsrc_lane, void* lds_ba
                                      reinterpret_cast<__attribute__((address_space(3))) void*>(
                                          uint32_t(reinterpret_cast<uintptr_t>(lds_base))),
                                      16, 0, 0);
+}
+
+// v_writelane_b32 with a compile-time lane (inline constant: does not occupy the constant bus)
+template <uint32_t LANE>
+__device__ __forceinline__ uint32_t writelane_c(uint32_t sval, uint32_t old) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(LANE));
+    return old;
 }
 
 // FL_ORDER[x] = 3-bit reversal, stored as nibbles
@@ -111,104 +120,180 @@ __device__ __forceinline__ void fl_row_lane(uint32_t i, uint32_t* row, uint32_t*
     *row = o * 8u + s;
 }
 
+// Uniform (per block) form of the predicate in the packed domain: hit = ((u - lo) <= span) != negate, or a constant.
+template <typename U>
+struct PackedRange {
+    U lo, span;
+    bool negate;
+    int constant;  // -1: evaluate; 0/1: every row gives this result
+};
+
+template <typename U>
+__device__ __forceinline__ PackedRange<U> packed_range(const FixedDesc& d, const FixedPred& pred) {
+    PackedRange<U> r{0, 0, false, -1};
+    const int op = pred.op;
+    int mode = pred.lit_class;  // -1: literal below every value, +1: above
+    uint64_t dlit = 0;
+    const uint64_t umax = d.W >= 64 ? ~uint64_t(0) : ((uint64_t(1) << d.W) - 1);
+    if (mode == 0) {
+        const bool below = d.is_signed ? (int64_t(pred.lit) < int64_t(d.reference)) : (pred.lit < d.reference);
+        if (below) mode = -1;
+        else {
+            dlit = pred.lit - d.reference;
+            if (dlit > umax) mode = 1;
+        }
+    }
+    if (mode != 0) {  // lit < all values: v > lit, v >= lit, v != lit hold; lit > all values: v < lit, v <= lit, v != lit
+        const bool gt_like = (op == LC_OP_GT) || (op == LC_OP_GE) || (op == LC_OP_NE);
+        const bool lt_like = (op == LC_OP_LT) || (op == LC_OP_LE) || (op == LC_OP_NE);
+        r.constant = (mode < 0 ? gt_like : lt_like) ? 1 : 0;
+        return r;
+    }
+    switch (op) {
+        case LC_OP_EQ: r.lo = U(dlit); r.span = 0; break;
+        case LC_OP_NE: r.lo = U(dlit); r.span = 0; r.negate = true; break;
+        case LC_OP_LT: if (dlit == 0) r.constant = 0; else { r.lo = 0; r.span = U(dlit - 1); } break;
+        case LC_OP_LE: r.lo = 0; r.span = U(dlit); break;
+        case LC_OP_GT: if (dlit == umax) r.constant = 0; else { r.lo = U(dlit + 1); r.span = U(umax - (dlit + 1)); } break;
+        default: r.lo = U(dlit); r.span = U(umax - dlit); break;  // GE
+    }
+    return r;
+}
+
+// one 64-row group: lane i extracts logical row IT*64+i, a single range compare yields the ballot
+template <typename U, bool SKIP, uint32_t IT>
+__device__ __forceinline__ void fixed_pred_step(const uint8_t* buf, uint64_t act, uint32_t b0, uint32_t b1, uint32_t W,
+                                                uint32_t fo0, uint32_t fo1, U mask, const PackedRange<U>& pr,
+                                                uint32_t& res_lo, uint32_t& res_hi) {
+    constexpr uint32_t TB = LaneTraits<U>::kBits;
+    // act word of this 64-row group is wave uniform (lives in lane IT)
+    const uint32_t alo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act)), int(IT)));
+    const uint32_t ahi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act >> 32)), int(IT)));
+    if (SKIP && (alo | ahi) == 0) return;
+    const uint32_t bitpos = ((IT & 1u) ? b1 : b0) + (IT >> 1) * W;
+    const uint32_t wi = bitpos / TB, sh = bitpos % TB;
+    const uint8_t* p = buf + wi * 128u + ((IT & 1u) ? fo1 : fo0);
+    U u;
+    if constexpr (TB == 64) {
+        const uint64_t lo = *reinterpret_cast<const uint64_t*>(p);
+        const uint64_t hi = *reinterpret_cast<const uint64_t*>(p + 128);
+        u = ((lo >> sh) | ((hi << 1) << (63u - sh))) & mask;
+    } else if constexpr (TB == 32) {
+        const uint32_t lo = *reinterpret_cast<const uint32_t*>(p);
+        const uint32_t hi = *reinterpret_cast<const uint32_t*>(p + 128);
+        u = __builtin_amdgcn_alignbit(hi, lo, sh) & mask;
+    } else {
+        const uint32_t lo = *reinterpret_cast<const U*>(p);
+        const uint32_t hi = *reinterpret_cast<const U*>(p + 128);
+        u = U(((lo | (hi << TB)) >> sh) & mask);
+    }
+    uint64_t b = __ballot(U(u - pr.lo) <= pr.span);
+    if (pr.negate) b = ~b;
+    res_lo = writelane_c<IT>(uint32_t(b) & alo, res_lo);
+    res_hi = writelane_c<IT>(uint32_t(b >> 32) & ahi, res_hi);
+}
+
+template <typename U, bool SKIP, uint32_t... ITS>
+__device__ __forceinline__ void fixed_pred_steps(std::integer_sequence<uint32_t, ITS...>, const uint8_t* buf,
+                                                 uint64_t act, uint32_t b0, uint32_t b1, uint32_t W, uint32_t fo0,
+                                                 uint32_t fo1, U mask, const PackedRange<U>& pr, uint32_t& res_lo,
+                                                 uint32_t& res_hi) {
+    (fixed_pred_step<U, SKIP, ITS>(buf, act, b0, b1, W, fo0, fo1, mask, pr, res_lo, res_hi), ...);
+}
+
 template <typename U>
 __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __restrict__ descs, FixedPred pred,
                                                           ScanLaunch L) {
     constexpr uint32_t TB = LaneTraits<U>::kBits;
+    constexpr uint32_t LANES = 1024u / TB;
     constexpr uint32_t kBlockBytesMax = 128u * TB;
     // one staging buffer per wave (+128 bytes so the "next word" read of the last word row stays in bounds)
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][kBlockBytesMax + 128];
 
-    const int lane = lane_id(), wave = wave_id();
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + uint32_t(wave);
-    const uint32_t entry = gw / L.blocks_per_entry, blk = gw % L.blocks_per_entry;
-    if (entry >= L.n_entries) return;
-    const FixedDesc d = descs[entry];
-    const uint32_t row0 = blk * 1024u;
-    if (row0 >= d.len) return;
-    const uint32_t rows = min(1024u, d.len - row0);
-    const uint32_t nwords = (rows + 63u) >> 6;
-    const uint64_t word_base = d.mask_word_off + uint64_t(blk) * 16u;
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    uint8_t* buf = lds[wave];
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
 
-    // selection & validity words of this block: lane w (< 16) owns word w
-    uint64_t act = 0, valid = 0;
-    if (uint32_t(lane) < nwords) {
-        uint64_t tail = ~uint64_t(0);
-        if (uint32_t(lane) == nwords - 1 && (rows & 63u)) tail = (uint64_t(1) << (rows & 63u)) - 1;
-        const uint64_t selw = L.d_selection ? L.d_selection[word_base + lane] : ~uint64_t(0);
-        valid = d.W == 0 ? 0 : (d.validity ? d.validity[uint64_t(blk) * 16u + lane] : ~uint64_t(0));
-        valid &= tail & selw;
-        act = valid;
-    }
-    const bool any_active = __ballot(act != 0) != 0;
+    // FastLanes un-transposition, constant per lane: logical row it*64+lane -> (row, fl_lane);
+    // row = o*8 + (it >> 1) where o only depends on the lane and on the parity of `it`.
+    uint32_t o8[2], fl[2];  // (for 8-bit lanes the FastLanes lane differs between even and odd groups too)
+    fl_row_lane<U>(uint32_t(lane), &o8[0], &fl[0]);        // it == 0  (s == 0)
+    fl_row_lane<U>(64u + uint32_t(lane), &o8[1], &fl[1]);  // it == 1  (s == 0)
+    (void)LANES;
 
-    // packed-domain rewrite: v = ref + u, u in [0, 2^W)
-    const OpTable ot = op_table(pred.op);
-    int mode = 0;  // -1: lit below the block's range, +1: above, 0: compare u with `dlit`
-    uint64_t dlit = 0;
-    if (d.kind == kKindInt || d.kind == kKindDecimal) {
-        if (pred.lit_class != 0) mode = pred.lit_class;
-        else {
-            const bool below = d.is_signed ? (int64_t(pred.lit) < int64_t(d.reference)) : (pred.lit < d.reference);
-            if (below) mode = -1;
-            else {
-                dlit = pred.lit - d.reference;
-                const uint64_t umax = d.W >= 64 ? ~uint64_t(0) : ((uint64_t(1) << d.W) - 1);
-                if (dlit > umax) mode = 1;
-            }
+    // one wave owns whole entries (their 1024-row blocks in turn): the descriptor and the packed-domain rewrite of
+    // the predicate are read / computed once per entry, not once per block
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
+      const FixedDesc d = descs[entry];  // wave-uniform address: scalar loads
+      const uint32_t len = d.len;
+      const uint32_t W = d.W;
+      const PackedRange<U> pr = packed_range<U>(d, pred);
+      uint32_t entry_count = 0;
+      for (uint32_t blk = 0, row0 = 0; row0 < len; blk++, row0 += 1024u) {
+        const uint32_t rows = min(1024u, len - row0);
+        const uint32_t nwords = (rows + 63u) >> 6;
+        const uint64_t word_base = d.mask_word_off + uint64_t(blk) * 16u;
+
+        // selection & validity words of this block: lane w (< 16) owns word w
+        uint64_t act = 0;
+        if (uint32_t(lane) < nwords) {
+            uint64_t tail = ~uint64_t(0);
+            if (uint32_t(lane) == nwords - 1 && (rows & 63u)) tail = (uint64_t(1) << (rows & 63u)) - 1;
+            const uint64_t selw = L.d_selection ? L.d_selection[word_base + lane] : ~uint64_t(0);
+            const uint64_t* vp = d.validity;
+            act = W == 0 ? 0 : (vp ? vp[uint64_t(blk) * 16u + lane] : ~uint64_t(0));
+            act &= tail & selw;
         }
-    }
-
-    uint64_t result = 0;
-    if (any_active) {
-        if (mode != 0) {
-            // every value compares the same way: lit < all values -> "gt" outcome, lit > all values -> "lt" outcome
-            const bool all_true = mode < 0 ? ot.on_gt : ot.on_lt;
-            result = all_true ? act : 0;
-        } else {
-            uint8_t* buf = lds[wave];
-            const uint32_t W = d.W;
-            const uint32_t nchunks = 8u * W;  // 16-byte chunks in this block
-            const uint4* src = reinterpret_cast<const uint4*>(d.packed + uint64_t(blk) * 128u * W);
-            // LDS-DMA: 16 bytes per lane straight from HBM into this wave's LDS buffer, no VGPR round trip and no
-            // wait between the requests; one vmcnt(0) covers them all (lane l of request s lands at s*1024 + l*16).
-            constexpr int kSteps = int(kBlockBytesMax / 1024u) > 0 ? int(kBlockBytesMax / 1024u) : 1;
+        const bool any_active = __ballot(act != 0) != 0;
+        uint32_t res_lo = 0, res_hi = 0;  // lane w holds result word w
+        if (any_active) {
+            if (pr.constant >= 0) {
+                if (pr.constant) { res_lo = uint32_t(act); res_hi = uint32_t(act >> 32); }
+            } else {
+                // LDS-DMA: 16 bytes per lane straight from HBM into this wave's LDS buffer, no VGPR round trip and
+                // no wait between the requests (lane l of request s lands at s*1024 + l*16)
+                const uint32_t nchunks = 8u * W;
+                const uint4* src = reinterpret_cast<const uint4*>(d.packed + uint64_t(blk) * 128u * W);
+                constexpr int kSteps = int(kBlockBytesMax / 1024u) > 0 ? int(kBlockBytesMax / 1024u) : 1;
 #pragma unroll
-            for (int s = 0; s < kSteps; s++) {
-                if (uint32_t(s) * 64u < nchunks) {
-                    const uint32_t c = uint32_t(s) * 64u + uint32_t(lane);
-                    if (c < nchunks) async_copy16(src + c, buf + s * 1024);
+                for (int s = 0; s < kSteps; s++) {
+                    if (uint32_t(s) * 64u < nchunks && !(pred.pad & 2)) {
+                        const uint32_t c = uint32_t(s) * 64u + uint32_t(lane);
+                        if (c < nchunks) async_copy16(src + c, buf + s * 1024);
+                    }
                 }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-
-            const U mask = (W >= TB) ? U(~U(0)) : U((U(1) << W) - 1);
-            const U dl = U(dlit);
-#pragma unroll
-            for (uint32_t it = 0; it < 16; it++) {
-                // skip 64-row groups with nothing selected (wave-uniform: the word lives in lane `it`)
-                const uint32_t alo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act)), int(it)));
-                const uint32_t ahi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act >> 32)), int(it)));
-                if ((alo | ahi) != 0) {
-                    uint32_t row, fl;
-                    fl_row_lane<U>(it * 64u + uint32_t(lane), &row, &fl);
-                    const U u = extract_packed<U>(buf, row, fl, W, mask);
-                    const bool hit = (u < dl) ? ot.on_lt : ((u == dl) ? ot.on_eq : ot.on_gt);
-                    const uint64_t b = __ballot(hit);
-                    if (uint32_t(lane) == it) result = b & act;
+                const U mask = (W >= TB) ? U(~U(0)) : U((U(1) << W) - 1);
+                const uint32_t b0 = o8[0] * W, b1 = o8[1] * W;  // bit position of this lane's row for s == 0
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (!(pred.pad & 1))
+                {
+                    const uint32_t fo0 = fl[0] * uint32_t(sizeof(U)), fo1 = fl[1] * uint32_t(sizeof(U));
+                    // dense groups (no selection / everything selected): no per-group branch, so the compiler can
+                    // batch the LDS reads of all 16 groups; sparse selections skip empty 64-row groups instead
+                    const bool dense = __ballot(uint32_t(lane) < nwords && act == 0) == 0 && nwords == 16;
+                    if (dense)
+                        fixed_pred_steps<U, false>(std::make_integer_sequence<uint32_t, 16>{}, buf, act, b0, b1, W, fo0,
+                                                   fo1, mask, pr, res_lo, res_hi);
+                    else
+                        fixed_pred_steps<U, true>(std::make_integer_sequence<uint32_t, 16>{}, buf, act, b0, b1, W, fo0,
+                                                  fo1, mask, pr, res_lo, res_hi);
                 }
             }
         }
-    }
-    if (uint32_t(lane) < nwords) {
-        L.d_hit[word_base + lane] = result;
-        if (L.d_valid) L.d_valid[word_base + lane] = valid;
-    }
-    if (L.d_counts) {
-        const uint64_t c = wave_sum_u64(uint64_t(__popcll(result)));
-        if (lane == 0 && c) atomicAdd(&L.d_counts[entry], uint32_t(c));
+        const uint64_t result = uint64_t(res_lo) | (uint64_t(res_hi) << 32);
+        if (uint32_t(lane) < nwords) {
+            L.d_hit[word_base + lane] = result;
+            if (L.d_valid) L.d_valid[word_base + lane] = act;
+        }
+        if (L.d_counts) entry_count += uint32_t(__popcll(result));
+      }
+      if (L.d_counts) {  // one wave per entry: plain store, no atomics
+          const uint64_t c = wave_sum_u64(uint64_t(entry_count));
+          if (lane == 0) L.d_counts[entry] = uint32_t(c);
+      }
     }
 }
 
@@ -1011,7 +1096,17 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
                              hipStream_t stream) {
     const uint64_t waves = uint64_t(L.n_entries) * L.blocks_per_entry;
     if (waves == 0) return hipSuccess;
-    const dim3 grid(uint32_t((waves + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
+    // persistent-style launch: enough workgroups to fill every CU at the kernel's occupancy, each wave strides over blocks
+    static int n_cus = 0;
+    if (n_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
+        if (n_cus <= 0) n_cus = 256;
+    }
+    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint64_t wgs_resident = uint64_t(n_cus) * (lane_log2 == 6 ? 4 : 8);
+    const dim3 grid(uint32_t(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), block(kThreads);
     switch (lane_log2) {
         case 3: hipLaunchKernelGGL(k_fixed_pred<uint8_t>, grid, block, 0, stream, d_descs, pred, L); break;
         case 4: hipLaunchKernelGGL(k_fixed_pred<uint16_t>, grid, block, 0, stream, d_descs, pred, L); break;

