@@ -15,6 +15,7 @@
 
 #include "../../include/liquid_cache_amd.h"
 
+#include <algorithm>
 #include <utility>
 
 namespace lc {
@@ -352,14 +353,16 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
-// Byte-view predicate: one workgroup per entry (batch).
-//   phase A  per dictionary entry: fingerprint / prefix-key tests decide or nominate candidates (LDS list)
-//   phase B  candidates are pulled from an LDS work queue by individual lanes; each walks the entry's FSST codes
-//            (automaton for LIKE, streaming decode-compare for Eq / ordering) and sets its bit in the LDS
-//            dictionary-result bitmap
-//   phase C  rows: 8 u16 keys per 16-byte load, bitmap lookup in LDS, ballot-free byte transposition into mask words
+// Byte-view predicate: ONE WAVE per entry (batch), four entries per workgroup, no workgroup barriers after setup.
+// Many independent waves per CU (up to 32) hide the memory latency of the short dependent phases:
+//   phase A  per dictionary entry (8 x 64 entries per round, all loads issued before use): bigram-signature /
+//            fingerprint tests for LIKE, 8-byte prefix-key tests for Eq / ordering; decided entries are written to
+//            the wave's LDS result bitmap as whole ballot words, undecided ones are appended to an LDS list
+//   phase B  candidates: each lane walks the FSST codes of one dictionary value (LIKE: KMP automaton folded over
+//            the symbols, one lookup per compressed code; Eq / ordering: streaming decode-compare)
+//   phase C  rows: 8 u16 keys per 16-byte load, bitmap lookup in LDS, 8 lanes x 8 bits shuffled into mask words
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kDictChunk = 4096;
+constexpr uint32_t kCandCap = 1024;  // candidate list entries per wave (flushed when it could overflow)
 
 __device__ __forceinline__ uint32_t str_offset(const StrDesc& d, uint32_t i) {
     int32_t r;
@@ -387,7 +390,7 @@ struct ByteReader {
 };
 
 // lexicographic compare of the decoded value of dictionary entry [start,end) with the needle: -1 / 0 / +1
-__device__ int decode_compare(const DevSymtab& st, const uint8_t* fsst, uint32_t start, uint32_t end,
+__device__ __noinline__ int decode_compare(const DevSymtab& st, const uint8_t* fsst, uint32_t start, uint32_t end,
                               const uint8_t* needle, uint32_t nl) {
     ByteReader r;
     r.init(fsst, start, end);
@@ -414,49 +417,96 @@ __device__ int decode_compare(const DevSymtab& st, const uint8_t* fsst, uint32_t
     return j < nl ? -1 : 0;
 }
 
-__global__ __launch_bounds__(kThreads) void k_str_pred(const StrDesc* __restrict__ descs,
-                                                        const DevSymtab* __restrict__ symtabs, StrPred pred,
-                                                        ScanLaunch L) {
-    __shared__ uint32_t dres[2048];          // dictionary result bitmap, 65536 bits (keys under nulls may be garbage)
-    __shared__ uint16_t cand[kDictChunk];    // candidate dictionary indices of the current chunk
-    __shared__ uint32_t n_cand, q_head, total_cand;
-    extern __shared__ __attribute__((aligned(16))) uint8_t tbl[];  // (needle_len + 1) * 512 bytes in LIKE mode
-    __shared__ uint8_t needle_lds[256];
-    __shared__ uint32_t hit_count, cand_bytes;
-
-    const uint32_t entry = blockIdx.x;
-    if (entry >= L.n_entries) return;
-    const StrDesc d = descs[entry];
-    const int lane = lane_id(), wave = wave_id();
-    const uint32_t tid = threadIdx.x;
-    const DevSymtab& st = symtabs[d.symtab_slot];
-    const uint32_t nl = pred.needle_len;
-    const uint32_t nwords = (d.n + 63u) >> 6;
-
-    // early out: nothing selected in this entry
-    if (L.d_selection) {
-        uint32_t any = 0;
-        for (uint32_t w = tid; w < nwords; w += kThreads) any |= L.d_selection[d.mask_word_off + w] != 0;
-        if (!__syncthreads_or(int(any))) {
-            for (uint32_t w = tid; w < nwords; w += kThreads) {
-                L.d_hit[d.mask_word_off + w] = 0;
-                if (L.d_valid) L.d_valid[d.mask_word_off + w] = 0;
+// LIKE '%needle%' on one FSST-compressed value without decoding it: `tbl` is the needle's automaton folded over the
+// symbol table (k_str_automata).  64 bytes (8 words) are requested at once, so a lane pays one memory latency per 64
+// compressed bytes.  While no partial match is pending (state 0), runs of codes whose symbol cannot start a match are
+// skipped with one table lookup per code (row 0; the escape code 255 is flagged non-zero so it is never skipped);
+// only the "interesting" codes take the dependent state-transition step.
+template <typename TblPtr>
+__device__ __noinline__ bool like_walk(const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop, TblPtr tbl,
+                                       uint32_t nl, int dbg) {
+    uint32_t pos = start, s = 0;
+    if (dbg & 256) return false;
+    for (uint32_t wb = start & ~7u; wb < stop; wb += 64) {
+        uint64_t pw[8], fl[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            pw[k] = (wb + 8u * uint32_t(k) < stop && !(dbg & 64)) ? *reinterpret_cast<const uint64_t*>(fsst + wb + 8u * uint32_t(k)) : 0;
+        if (dbg & 128) return pw[0] == 12345;
+        // state-0 flags of all 64 codes up front (independent lookups), so the walk below only pays for the few
+        // codes that can start or continue a match
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint64_t f = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) f |= uint64_t(tbl[uint32_t(pw[k] >> (8 * q)) & 0xFFu]) << (8 * q);
+            fl[k] = f;
+        }
+        // word loop kept ROLLED (the register arrays rotate by one word per iteration): small code, see DESIGN.md
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t base = wb + 8u * k;
+            if (base >= stop) break;
+            const uint64_t w = pw[0];
+            uint64_t flags = fl[0];
+            const uint64_t wnext = pw[1];
+#pragma unroll
+            for (int r = 0; r < 7; r++) { pw[r] = pw[r + 1]; fl[r] = fl[r + 1]; }
+            if (pos >= base + 8) continue;
+            if (base + 8 > stop) flags &= (uint64_t(1) << (8 * (stop - base))) - 1;
+            const uint32_t wend = min(base + 8, stop);
+            while (pos < wend) {
+                const uint32_t sh = 8u * (pos & 7u);
+                if (s == 0) {
+                    const uint64_t f = (flags >> sh) << sh;
+                    if (f == 0) { pos = base + 8; break; }
+                    pos = base + ((uint32_t(__ffsll((long long)f)) - 1u) >> 3);
+                }
+                const uint32_t c = uint32_t(w >> (8u * (pos & 7u))) & 0xFFu;
+                if (c == 255u) {
+                    if (pos + 1 >= stop) return false;
+                    uint32_t lit;
+                    if ((pos & 7u) < 7u) lit = uint32_t(w >> (8u * ((pos & 7u) + 1u))) & 0xFFu;
+                    else if (k < 7) lit = uint32_t(wnext) & 0xFFu;
+                    else lit = uint32_t(fsst[pos + 1]);
+                    s = tbl[s * 512 + 256 + lit];
+                    pos += 2;
+                } else {
+                    s = tbl[s * 512 + c];
+                    pos += 1;
+                }
+                if (s == nl) return true;
             }
-            if (tid == 0) {
-                if (L.d_counts) L.d_counts[entry] = 0;
-                if (L.d_cand_bytes) L.d_cand_bytes[entry] = 0;
-            }
-            return;
         }
     }
+    return false;
+}
 
-    for (uint32_t i = tid; i < 2048; i += kThreads) dres[i] = 0;
-    if (tid == 0) { n_cand = 0; q_head = 0; total_cand = 0; hit_count = 0; cand_bytes = 0; }
+typedef const __attribute__((address_space(3))) uint8_t* LdsBytePtr;
+
+__global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
+                                                           const DevSymtab* __restrict__ symtabs, StrPred pred,
+                                                           ScanLaunch L, uint32_t dres_words) {
+    // dynamic LDS: [automaton table of the workgroup's first entry][per wave: result bitmap | candidate list]
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint8_t needle_lds[256];
+
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nl = pred.needle_len;
     const bool substring = pred.mode == 1;
+    const uint32_t tbl_bytes = substring ? ((nl + 1) * 512u + 15u) & ~15u : 0u;
+    const uint32_t per_wave = dres_words * 8u + kCandCap * 2u;
+    uint32_t* dres = reinterpret_cast<uint32_t*>(smem + tbl_bytes + wave * per_wave);
+    uint64_t* cmask = reinterpret_cast<uint64_t*>(dres + dres_words);  // signature candidates, dres_words/2 u64 words
+    uint16_t* cand = reinterpret_cast<uint16_t*>(dres + 2 * dres_words);
+
+    const uint32_t entry = blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t slot0 = descs[min(blockIdx.x * kWavesPerBlock, L.n_entries - 1)].symtab_slot;
     if (substring) {
-        const uint32_t bytes = (nl + 1) * 512;
-        const uint4* src = reinterpret_cast<const uint4*>(pred.automata + size_t(d.symtab_slot) * pred.automaton_stride);
-        for (uint32_t i = tid; i < bytes / 16; i += kThreads) reinterpret_cast<uint4*>(tbl)[i] = src[i];
+        const uint4* src = reinterpret_cast<const uint4*>(pred.automata + size_t(slot0) * pred.automaton_stride);
+        for (uint32_t i = tid; i < (nl + 1) * 32u; i += kThreads) reinterpret_cast<uint4*>(smem)[i] = src[i];
     }
     // needle bytes: kernel argument (short needles) or the device copy; staged in LDS when they fit
     const bool needle_in_lds = nl <= sizeof(needle_lds);
@@ -465,6 +515,33 @@ __global__ __launch_bounds__(kThreads) void k_str_pred(const StrDesc* __restrict
             needle_lds[i] = nl <= uint32_t(kInlineNeedle) ? pred.needle_inline[i] : pred.needle[i];
     const uint8_t* np = needle_in_lds ? needle_lds : pred.needle;
     __syncthreads();
+    if (entry >= L.n_entries) return;
+
+    const StrDesc d = descs[entry];
+    const DevSymtab& st = symtabs[d.symtab_slot];
+    // shared LDS copy of the automaton when this entry uses the workgroup's symbol table, else the global one
+    const bool tbl_in_lds = d.symtab_slot == slot0;
+    const uint8_t* tbl_global = substring ? pred.automata + size_t(d.symtab_slot) * pred.automaton_stride : nullptr;
+    const LdsBytePtr tbl_lds = reinterpret_cast<LdsBytePtr>(uint32_t(reinterpret_cast<uintptr_t>(smem)));
+    const uint32_t nwords = (d.n + 63u) >> 6;
+
+    // early out: nothing selected in this entry
+    if (L.d_selection) {
+        uint32_t any = 0;
+        for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) any |= L.d_selection[d.mask_word_off + w] != 0;
+        if (__ballot(any != 0) == 0) {
+            for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
+                L.d_hit[d.mask_word_off + w] = 0;
+                if (L.d_valid) L.d_valid[d.mask_word_off + w] = 0;
+            }
+            if (lane == 0) {
+                if (L.d_counts) L.d_counts[entry] = 0;
+                if (L.d_cand_bytes) L.d_cand_bytes[entry] = 0;
+            }
+            return;
+        }
+    }
+    for (uint32_t i = uint32_t(lane); i < dres_words; i += kWave) dres[i] = 0;
 
     // ---- shared-prefix short circuits (comparisons.rs:24-26 for Eq, :469-501 for ordering) ----
     const uint32_t spl = d.shared_prefix_len;
@@ -489,175 +566,241 @@ __global__ __launch_bounds__(kThreads) void k_str_pred(const StrDesc* __restrict
         }
     }
     const uint32_t nsl = nl >= spl ? nl - spl : 0;  // needle suffix length after the shared prefix
-    const uint8_t* nsuf = np + spl;
-    uint64_t nsuf7 = 0;  // first min(7, nsl) suffix bytes, little endian
+    uint64_t nsuf7 = 0;                             // first min(7, nsl) suffix bytes, little endian
     if (!substring && uniform_result < 0)
-        for (uint32_t i = 0; i < 7 && i < nsl; i++) nsuf7 |= uint64_t(nsuf[i]) << (8 * i);
-    const uint32_t needle_fp = [&]() {
-        uint32_t fp = 0;
-        if (substring) for (uint32_t i = 0; i < nl; i++) fp |= 1u << (np[i] & 31);
-        return fp;
-    }();
+        for (uint32_t i = 0; i < 7 && i < nsl; i++) nsuf7 |= uint64_t(np[spl + i]) << (8 * i);
+    uint32_t needle_fp = 0;
+    if (substring)
+        for (uint32_t i = 0; i < nl; i++) needle_fp |= 1u << (np[i] & 31);
     const bool prune = substring && pred.use_fingerprints && d.fingerprints != nullptr;
+    // bigram signature probe (needles of >= 2 bytes): AND of the needle's bit slices = candidate bitmap
+    const bool use_sig = prune && d.signatures != nullptr && pred.n_sig_bits > 0 && !(pred.debug_flags & 8);
+    // with signatures the (weaker) fingerprint only matters for the NOT LIKE candidate-count rule and for the
+    // algorithmic-byte instrumentation: its 4*D bytes are skipped otherwise
+    const bool need_fp = prune && (!use_sig || op == LC_OP_NOT_LIKE || L.d_cand_bytes != nullptr);
 
+    uint32_t dbg_cands = 0;
+    uint32_t n_cand = 0;        // wave uniform
+    uint32_t fp_cand = 0;       // wave uniform: fingerprint candidates seen (NOT LIKE rule)
+    uint32_t cand_bytes = 0;    // per lane, summed at the end (instrumented pass only)
+    __builtin_amdgcn_wave_barrier();
+
+    auto run_phase_b = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t nc = (pred.debug_flags & 1) ? 0u : n_cand;
+        dbg_cands += n_cand;
+        for (uint32_t j = uint32_t(lane); j < nc; j += kWave) {
+            const uint32_t i = cand[j];
+            uint32_t start = 0, stop = 0;
+            if (!(pred.debug_flags & 32)) { start = str_offset(d, i); stop = str_offset(d, i + 1); }
+            if (L.d_cand_bytes && !prune) cand_bytes += stop - start;
+            bool res;
+            if (pred.debug_flags & 16) {
+                res = (start ^ stop) == 0xFFFFFFFFu;
+            } else if (substring) {
+                res = tbl_in_lds ? like_walk(d.fsst, start, stop, tbl_lds, nl, pred.debug_flags)
+                                 : like_walk(d.fsst, start, stop, tbl_global, nl, pred.debug_flags);
+            } else {
+                const int o = decode_compare(st, d.fsst, start, stop, np, nl);
+                res = is_eq ? o == 0
+                            : (op == LC_OP_LT ? o < 0 : op == LC_OP_LE ? o <= 0 : op == LC_OP_GT ? o > 0 : o >= 0);
+            }
+            if (res) atomicOr(&dres[i >> 5], 1u << (i & 31));
+        }
+        n_cand = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    };
+
+    constexpr int KH = 8;
+    const uint32_t nw = (d.d + 63u) >> 6;  // u64 words of a dictionary bitmap
+    if (use_sig && uniform_result < 0) {
+        for (uint32_t w = uint32_t(lane); w < nw; w += kWave) {
+            uint64_t m = ~uint64_t(0);
+#pragma unroll
+            for (int k = 0; k < kMaxSigProbe; k++)
+                if (uint32_t(k) < pred.n_sig_bits) m &= d.signatures[size_t(pred.sig_bits[k]) * nw + w];
+            if (w == nw - 1 && (d.d & 63u)) m &= (uint64_t(1) << (d.d & 63u)) - 1;
+            cmask[w] = m;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     if (uniform_result == 1) {
-        for (uint32_t i = tid; i < 2048; i += kThreads) dres[i] = 0xFFFFFFFFu;
-        __syncthreads();
-    } else if (uniform_result < 0) {
-        for (uint32_t chunk = 0; chunk < d.d; chunk += kDictChunk) {
-            // ---- phase A ----
-            const uint32_t chunk_end = (pred.debug_flags & 4) ? chunk : min(d.d, chunk + kDictChunk);
-            for (uint32_t base = chunk; base < chunk_end; base += kThreads) {
-                const uint32_t i = base + tid;
+        for (uint32_t i = uint32_t(lane); i < dres_words; i += kWave) dres[i] = 0xFFFFFFFFu;
+    } else if (uniform_result < 0 && use_sig && !need_fp && !(pred.debug_flags & 4)) {
+        // LIKE fast path: the candidates ARE the set bits of the signature bitmap; no per-entry pass at all
+        for (uint32_t w0 = 0; w0 < nw; w0 += kWave) {
+            const uint32_t w = w0 + uint32_t(lane);
+            uint64_t m = w < nw ? cmask[w] : 0;
+            const uint32_t cnt = uint32_t(__popcll(m));
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const uint32_t t = __shfl_up(incl, o, kWave);
+                if (lane >= o) incl += t;
+            }
+            const uint32_t total = __shfl(incl, kWave - 1, kWave);
+            if (n_cand + total > kCandCap) {
+                // pathological density: fall back to one flush per 64-entry word group
+                for (uint32_t l = 0; l < kWave; l++) {
+                    uint64_t ml = __shfl(m, int(l), kWave);
+                    while (ml) {  // wave-uniform loop
+                        if (n_cand >= kCandCap) run_phase_b();
+                        const uint32_t bit = uint32_t(__ffsll((long long)ml)) - 1u;
+                        if (lane == 0) cand[n_cand] = uint16_t((w0 + l) * 64u + bit);
+                        n_cand++;
+                        ml &= ml - 1;
+                    }
+                }
+            } else {
+                uint32_t o = n_cand + incl - cnt;
+                while (m) {
+                    const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+                    cand[o++] = uint16_t(w * 64u + bit);
+                    m &= m - 1;
+                }
+                n_cand += total;
+            }
+        }
+        run_phase_b();
+    } else if (uniform_result < 0 && !(pred.debug_flags & 4)) {
+        for (uint32_t base = 0; base < d.d; base += KH * kWave) {
+            uint32_t fpv[KH];
+            uint64_t pkv[KH];
+            if (substring) {
+#pragma unroll
+                for (int k = 0; k < KH; k++) {
+                    const uint32_t ii = min(base + uint32_t(k) * kWave + uint32_t(lane), d.d - 1);
+                    fpv[k] = need_fp ? d.fingerprints[ii] : 0xFFFFFFFFu;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < KH; k++) {
+                    const uint32_t ii = min(base + uint32_t(k) * kWave + uint32_t(lane), d.d - 1);
+                    pkv[k] = reinterpret_cast<const uint64_t*>(d.prefix_keys)[ii];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KH; k++) {
+                const uint32_t g0 = base + uint32_t(k) * kWave;
+                if (g0 >= d.d) break;  // uniform
+                const uint32_t i = g0 + uint32_t(lane);
+                const bool in = i < d.d;
                 bool is_cand = false, decided_true = false;
-                if (i < chunk_end) {
-                    if (substring) {
-                        is_cand = prune ? ((d.fingerprints[i] & needle_fp) == needle_fp) : true;
-                    } else {
-                        const uint64_t pk = reinterpret_cast<const uint64_t*>(d.prefix_keys)[i];
-                        const uint32_t plen = uint32_t(pk >> 56);
-                        const uint64_t p7 = pk & 0x00FFFFFFFFFFFFFFull;
-                        if (is_eq) {
-                            // comparisons.rs:33-79
-                            if (nsl <= 7) {
-                                decided_true = plen != 255 && plen == nsl && p7 == nsuf7;
-                            } else {
-                                const bool len_ok = plen == 255 ? nsl >= 255 : plen == nsl;
-                                is_cand = len_ok && p7 == nsuf7;
-                            }
+                if (substring) {
+                    // reference prefilter (fingerprint.rs:33-35): its candidates define the algorithmic bytes
+                    const bool fp_ok = in && (!need_fp || (fpv[k] & needle_fp) == needle_fp);
+                    is_cand = fp_ok;
+                    // the stronger bigram signature decides whether the value is walked at all
+                    if (use_sig) is_cand = fp_ok && ((cmask[g0 >> 6] >> uint32_t(lane)) & 1);
+                    if (need_fp) {
+                        if (L.d_cand_bytes && fp_ok) cand_bytes += str_offset(d, i + 1) - str_offset(d, i);
+                        fp_cand += uint32_t(__popcll(__ballot(fp_ok)));
+                    }
+                } else if (in) {
+                    const uint64_t pk = pkv[k];
+                    const uint32_t plen = uint32_t(pk >> 56);
+                    const uint64_t p7 = pk & 0x00FFFFFFFFFFFFFFull;
+                    if (is_eq) {
+                        // comparisons.rs:33-79
+                        if (nsl <= 7) {
+                            decided_true = plen != 255 && plen == nsl && p7 == nsuf7;
                         } else {
-                            // comparisons.rs:361-404: compare the first min(7, nsl) bytes
-                            const uint32_t cl = min(nsl, 7u);
-                            if (cl == 0) {
-                                const bool empty = plen == 0;
-                                decided_true = op == LC_OP_LT ? false : op == LC_OP_LE ? empty : op == LC_OP_GT ? !empty : true;
-                            } else {
-                                const uint64_t mk = cl >= 8 ? ~uint64_t(0) : ((uint64_t(1) << (8 * cl)) - 1);
-                                // bytewise lexicographic order == numeric order of byte-swapped words
-                                const uint64_t a = __builtin_bswap64(p7 & mk), b = __builtin_bswap64(nsuf7 & mk);
-                                if (a < b) decided_true = (op == LC_OP_LT || op == LC_OP_LE);
-                                else if (a > b) decided_true = (op == LC_OP_GT || op == LC_OP_GE);
-                                else is_cand = true;
-                            }
+                            const bool len_ok = plen == 255 ? nsl >= 255 : plen == nsl;
+                            is_cand = len_ok && p7 == nsuf7;
+                        }
+                    } else {
+                        // comparisons.rs:361-404: compare the first min(7, nsl) bytes
+                        const uint32_t cl = min(nsl, 7u);
+                        if (cl == 0) {
+                            const bool empty = plen == 0;
+                            decided_true = op == LC_OP_LT ? false : op == LC_OP_LE ? empty : op == LC_OP_GT ? !empty : true;
+                        } else {
+                            const uint64_t mk = (uint64_t(1) << (8 * cl)) - 1;
+                            // bytewise lexicographic order == numeric order of byte-swapped words
+                            const uint64_t a = __builtin_bswap64(p7 & mk), b = __builtin_bswap64(nsuf7 & mk);
+                            if (a < b) decided_true = (op == LC_OP_LT || op == LC_OP_LE);
+                            else if (a > b) decided_true = (op == LC_OP_GT || op == LC_OP_GE);
+                            else is_cand = true;
                         }
                     }
-                    if (decided_true) atomicOr(&dres[i >> 5], 1u << (i & 31));
+                }
+                // the 64 entries of this group own two whole bitmap words: plain stores, no atomics
+                const uint64_t dm = __ballot(decided_true);
+                if (lane == 0) {
+                    dres[g0 >> 5] = uint32_t(dm);
+                    if ((g0 >> 5) + 1 < dres_words) dres[(g0 >> 5) + 1] = uint32_t(dm >> 32);
                 }
                 const uint64_t cm = __ballot(is_cand);
-                uint32_t wbase = 0;
-                if (lane == 0 && cm) wbase = atomicAdd(&n_cand, uint32_t(__popcll(cm)));
-                wbase = __builtin_amdgcn_readfirstlane(wbase);
-                if (is_cand) cand[wbase + lanes_below(cm)] = uint16_t(i - chunk);
+                if (is_cand) cand[n_cand + lanes_below(cm)] = uint16_t(i);
+                n_cand += uint32_t(__popcll(cm));
             }
-            __syncthreads();
-            // ---- phase B: lanes pull candidates from the LDS queue ----
-            const uint32_t nc = (pred.debug_flags & 1) ? 0u : n_cand;
-            for (;;) {
-                const uint32_t q = atomicAdd(&q_head, 1u);
-                if (q >= nc) break;
-                const uint32_t i = chunk + cand[q];
-                const uint32_t start = str_offset(d, i), stop = str_offset(d, i + 1);
-                if (L.d_cand_bytes) atomicAdd(&cand_bytes, stop - start);
-                bool res;
-                if (substring) {
-                    // Walk the FSST codes 8 at a time.  While no partial match is pending (state 0) whole runs of
-                    // codes whose symbol cannot start a match are skipped with one table lookup per code
-                    // (row 0 of the automaton; the escape code 255 is flagged so it is never skipped); only the
-                    // "interesting" codes take the dependent state-transition step.
-                    uint32_t pos = start, s = 0, wbase = 0xFFFFFFFFu;
-                    uint64_t w = 0, flags = 0;
-                    while (pos < stop) {
-                        const uint32_t base = pos & ~7u;
-                        if (base != wbase) {
-                            w = *reinterpret_cast<const uint64_t*>(d.fsst + base);
-                            wbase = base;
-                            flags = 0;
-#pragma unroll
-                            for (int k = 0; k < 8; k++)
-                                flags |= uint64_t(tbl[uint32_t(w >> (8 * k)) & 0xFFu]) << (8 * k);
-                            if (base + 8 > stop) flags &= (uint64_t(1) << (8 * (stop - base))) - 1;
-                        }
-                        const uint32_t sh = 8u * (pos & 7u);
-                        if (s == 0) {
-                            const uint64_t f = (flags >> sh) << sh;
-                            if (f == 0) { pos = base + 8; continue; }
-                            pos = base + ((uint32_t(__ffsll((long long)f)) - 1u) >> 3);
-                        }
-                        const uint32_t c = uint32_t(w >> (8u * (pos & 7u))) & 0xFFu;
-                        if (c == 255u) {
-                            if (pos + 1 >= stop) break;
-                            const uint32_t lit = (pos & 7u) < 7u ? (uint32_t(w >> (8u * ((pos & 7u) + 1u))) & 0xFFu)
-                                                                 : uint32_t(d.fsst[pos + 1]);
-                            s = tbl[s * 512 + 256 + lit];
-                            pos += 2;
-                        } else {
-                            s = tbl[s * 512 + c];
-                            pos += 1;
-                        }
-                        if (s == nl) break;
-                    }
-                    res = s == nl;
-                } else {
-                    const int o = decode_compare(st, d.fsst, start, stop, np, nl);
-                    res = is_eq ? o == 0
-                                : (op == LC_OP_LT ? o < 0 : op == LC_OP_LE ? o <= 0 : op == LC_OP_GT ? o > 0 : o >= 0);
-                }
-                if (res) atomicOr(&dres[i >> 5], 1u << (i & 31));
-            }
-            __syncthreads();
-            if (tid == 0) { total_cand += nc; n_cand = 0; q_head = 0; }
-            __syncthreads();
+            if (n_cand > kCandCap - KH * kWave || base + KH * kWave >= d.d) run_phase_b();
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     // dictionary-level negation:
-    //   NotContains inverts the dictionary results only when at least one candidate existed (comparisons.rs:167-180,
-    //   :644-648 — bit-exact with the reference); Ne inverts row values (:85-90), folded in below.
+    //   NotContains inverts the dictionary results only when at least one fingerprint candidate existed
+    //   (comparisons.rs:167-180, :644-648 — bit-exact with the reference); Ne inverts row values (:85-90).
     bool invert = false;
-    if (substring && op == LC_OP_NOT_LIKE) invert = prune ? (total_cand > 0) : true;
+    if (substring && op == LC_OP_NOT_LIKE) invert = prune ? (fp_cand > 0) : true;
     if (pred.mode == 0 && op == LC_OP_NE) invert = true;
 
     // ---- phase C: rows ----
     const uint32_t xorm = invert ? 1u : 0u;
-    for (uint32_t base = 0; base < ((pred.debug_flags & 2) ? 0u : d.n); base += kThreads * 8) {
-        const uint32_t r0 = base + tid * 8;  // this lane's 8 consecutive rows
-        uint32_t bits = 0;
-        if (r0 < d.n) {
-            const uint4 kv = *reinterpret_cast<const uint4*>(d.keys + r0);  // keys are padded to a multiple of 8
-            const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
+    const uint32_t n_rows = (pred.debug_flags & 2) ? 0u : d.n;
+    const uint32_t key_max = dres_words * 32u - 1u;  // keys under null slots may be garbage: clamp, validity masks them
+    uint32_t hit_count = 0;
+    constexpr int KC = 4;  // 4 x 512 rows per pass: all key / selection / validity loads in flight together
+    for (uint32_t pass = 0; pass < n_rows; pass += KC * kWave * 8) {
+        uint4 kv[KC];
+        uint64_t selw[KC], valw[KC];
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const uint32_t r0 = pass + uint32_t(k) * kWave * 8 + uint32_t(lane) * 8;
+            kv[k] = r0 < n_rows ? *reinterpret_cast<const uint4*>(d.keys + r0) : make_uint4(0, 0, 0, 0);
+            const uint32_t widx = r0 >> 6;
+            const bool leader = (lane & 7) == 0 && r0 < n_rows;
+            selw[k] = (leader && L.d_selection) ? L.d_selection[d.mask_word_off + widx] : ~uint64_t(0);
+            valw[k] = (leader && d.validity) ? d.validity[widx] : ~uint64_t(0);
+        }
+#pragma unroll
+        for (int k = 0; k < KC; k++) {
+            const uint32_t r0 = pass + uint32_t(k) * kWave * 8 + uint32_t(lane) * 8;  // this lane's 8 consecutive rows
+            if (pass + uint32_t(k) * kWave * 8 >= n_rows) break;                      // uniform
+            uint32_t bits = 0;
+            const uint32_t kw[4] = {kv[k].x, kv[k].y, kv[k].z, kv[k].w};
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                const uint32_t key = (kw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+                const uint32_t key = min((kw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu, key_max);
                 const uint32_t hit = ((dres[key >> 5] >> (key & 31)) & 1u) ^ xorm;
                 bits |= hit << q;
             }
-        }
-        // 8 lanes x 8 bits -> one 64-row word in the group leader
-        uint64_t w = bits;
-        w |= uint64_t(__shfl_down(uint32_t(w), 1, kWave)) << 8;
-        w |= uint64_t(__shfl_down(uint32_t(w), 2, kWave)) << 16;
-        w |= __shfl_down(w, 4, kWave) << 32;
-        if ((lane & 7) == 0 && r0 < d.n) {
-            const uint32_t widx = r0 >> 6;
-            const uint32_t rows_left = d.n - (widx << 6);
-            const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
-            const uint64_t selw = L.d_selection ? L.d_selection[d.mask_word_off + widx] : ~uint64_t(0);
-            const uint64_t vw = (d.validity ? d.validity[widx] : ~uint64_t(0)) & tail & selw;
-            const uint64_t hitw = w & vw;
-            L.d_hit[d.mask_word_off + widx] = hitw;
-            if (L.d_valid) L.d_valid[d.mask_word_off + widx] = vw;
-            if (L.d_counts && hitw) atomicAdd(&hit_count, uint32_t(__popcll(hitw)));
+            // 8 lanes x 8 bits -> one 64-row word in the group leader
+            uint64_t w = bits;
+            w |= uint64_t(__shfl_down(uint32_t(w), 1, kWave)) << 8;
+            w |= uint64_t(__shfl_down(uint32_t(w), 2, kWave)) << 16;
+            w |= __shfl_down(w, 4, kWave) << 32;
+            if ((lane & 7) == 0 && r0 < n_rows) {
+                const uint32_t widx = r0 >> 6;
+                const uint32_t rows_left = d.n - (widx << 6);
+                const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
+                const uint64_t vw = valw[k] & tail & selw[k];
+                const uint64_t hitw = w & vw;
+                L.d_hit[d.mask_word_off + widx] = hitw;
+                if (L.d_valid) L.d_valid[d.mask_word_off + widx] = vw;
+                hit_count += uint32_t(__popcll(hitw));
+            }
         }
     }
     if (L.d_counts) {
-        __syncthreads();
-        if (tid == 0) L.d_counts[entry] = hit_count;  // one workgroup per entry: plain store
+        const uint64_t c = wave_sum_u64(uint64_t(hit_count));
+        if (lane == 0) L.d_counts[entry] = (pred.debug_flags & 512) ? dbg_cands : uint32_t(c);
     }
     if (L.d_cand_bytes) {
-        __syncthreads();
-        if (tid == 0) L.d_cand_bytes[entry] = cand_bytes;
+        const uint64_t c = wave_sum_u64(uint64_t(cand_bytes));
+        if (lane == 0) L.d_cand_bytes[entry] = uint32_t(c);
     }
-    (void)wave;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1130,8 +1273,12 @@ hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, c
 hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, const StrPred& pred,
                            const ScanLaunch& L, hipStream_t stream) {
     if (L.n_entries == 0) return hipSuccess;
-    const size_t dyn_lds = pred.mode == 1 ? size_t(pred.needle_len + 1) * 512 : 16;
-    hipLaunchKernelGGL(k_str_pred, dim3(L.n_entries), dim3(kThreads), dyn_lds, stream, d_descs, d_symtabs, pred, L);
+    // result bitmap words per wave: enough for the largest dictionary of the scan (multiple of 4 words)
+    const uint32_t dres_words = ((std::max<uint32_t>(L.max_dict_len, 1u) + 31u) / 32u + 3u) & ~3u;
+    const size_t tbl_bytes = pred.mode == 1 ? ((size_t(pred.needle_len + 1) * 512 + 15) & ~size_t(15)) : 0;
+    const size_t dyn_lds = tbl_bytes + size_t(kWavesPerBlock) * (size_t(dres_words) * 8 + kCandCap * 2);
+    const uint32_t grid = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(k_str_pred, dim3(grid), dim3(kThreads), dyn_lds, stream, d_descs, d_symtabs, pred, L, dres_words);
     return hipGetLastError();
 }
 

@@ -47,15 +47,28 @@ struct alignas(16) StrDesc {
     const uint8_t* residuals;
     const uint8_t* fsst;
     const uint8_t* shared_prefix;
+    const uint64_t* signatures;    // bit-sliced bigram signatures: 128 slices x ceil(D/64) u64 words, or nullptr
     uint64_t mask_word_off;
     int32_t slope, intercept;
     uint32_t n, d;
     uint32_t fsst_len, shared_prefix_len;
     uint32_t symtab_slot;
     uint8_t offset_bytes;
-    uint8_t pad[3];
+    uint8_t pad[11];
 };
-static_assert(sizeof(StrDesc) == 96, "StrDesc layout");
+static_assert(sizeof(StrDesc) == 112, "StrDesc layout");
+
+// Bigram Bloom signature (device-side acceleration index, built at staging for entries that carry fingerprints):
+// bit h(a,b) of a 128-bit set for every pair of adjacent bytes of the dictionary value.  A value can only contain
+// `needle` if it has every needle bigram — a necessary condition exactly like the reference's 32-bucket byte
+// fingerprint (byte_view_array/fingerprint.rs:33-35), only far more selective.  The signatures are stored BIT-SLICED:
+// slice b is a bitmap over the dictionary entries (ceil(D/64) u64 words) telling which values have bit b, so a query
+// ANDs only the slices of the needle's bigrams (<= 8 x D/8 bytes) instead of reading 16 bytes per entry.
+constexpr int kSigBits = 128;
+constexpr int kMaxSigProbe = 8;
+__host__ __device__ inline uint32_t bigram_bit(uint32_t a, uint32_t b) {
+    return ((((a << 8) | b) * 40503u) >> 7) & 127u;
+}
 
 // Symbol table as the kernels see it.
 struct DevSymtab {
@@ -85,6 +98,8 @@ struct StrPred {
     uint32_t automaton_stride;
     int32_t const_value;       // mode 2: Literal(Boolean)
     int32_t debug_flags;       // profiling only (env LC_DEBUG_FLAGS): 1 skip phase B, 2 skip phase C, 4 skip phase A
+    uint32_t n_sig_bits;       // LIKE: distinct bigram-signature bits of the needle that are probed (<= kMaxSigProbe)
+    uint8_t sig_bits[kMaxSigProbe];
     uint8_t needle_inline[kInlineNeedle];
 };
 
@@ -96,6 +111,8 @@ struct ScanLaunch {
     uint64_t* d_valid;    // optional: valid & selected
     uint32_t* d_counts;   // optional, must be zeroed by the launcher
     uint32_t* d_cand_bytes;  // optional (byte views): per entry, compressed bytes of the candidates that were walked
+    uint32_t max_dict_len;   // byte views: largest dictionary in the scan (sizes the LDS result bitmap)
+    uint32_t pad;
 };
 
 hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,

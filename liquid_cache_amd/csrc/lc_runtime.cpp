@@ -78,6 +78,7 @@ struct lc_ctx {
     std::mutex st_mu;
     std::unordered_map<uint64_t, uint32_t> symtab_slot;
     std::vector<std::unique_ptr<SymbolTable>> symtabs;
+    bool build_signatures = true;  // LC_NO_SIGNATURES=1 disables the bigram index (plain reference layout only)
     DevSymtab* d_symtabs = nullptr;
     size_t d_symtabs_cap = 0;
     size_t d_symtabs_uploaded = 0;
@@ -272,10 +273,11 @@ lc_status build_fixed(const uint8_t* bytes, size_t len, Entry* e, Blob* blob, si
 }
 
 lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path_id, Entry* e, Blob* blob,
-                    size_t offs[7]) {
+                    size_t offs[8]) {
     ByteViewParsed v;
     if (!parse_byte_view(bytes, len, &v)) return fail(LC_ERR_CORRUPT, "malformed Liquid byte-view array");
     uint32_t slot;
+    const SymbolTable* host_st = nullptr;
     {
         std::lock_guard<std::mutex> g(ctx->st_mu);
         auto it = ctx->symtab_slot.find(path_id);
@@ -284,6 +286,7 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
         slot = it->second;
         // every code in the compressed bytes must exist in the table
         const SymbolTable& st = *ctx->symtabs[slot];
+        host_st = ctx->symtabs[slot].get();  // unique_ptr targets are stable
         for (uint32_t i = 0; i < v.fsst_len; i++) {
             const uint8_t c = v.fsst[i];
             if (c == kFsstEscape) { i++; continue; }
@@ -312,7 +315,7 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
     d.fsst_len = v.fsst_len;
     d.shared_prefix_len = v.shared_prefix_len;
     d.symtab_slot = slot;
-    for (int i = 0; i < 7; i++) offs[i] = size_t(-1);
+    for (int i = 0; i < 8; i++) offs[i] = size_t(-1);
     // keys padded to a multiple of 8 (16-byte loads)
     offs[0] = blob->add(v.keys.data(), size_t(v.n) * 2, kSectionAlign, 16);
     if (v.nullable) {
@@ -328,6 +331,20 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
     offs[4] = blob->add(v.residuals, size_t(v.residual_count) * size_t(v.offset_bytes), kSectionAlign, 8);
     offs[5] = blob->add(v.fsst, v.fsst_len, kSectionAlign, 16);
     offs[6] = blob->add(v.shared_prefix, v.shared_prefix_len, kSectionAlign, 8);
+    if (v.fingerprints && ctx->build_signatures) {
+        // substring-search columns: bit-sliced 128-bit bigram signatures of the dictionary values (lc_kernels.hpp)
+        const size_t nw = (size_t(v.d) + 63) / 64;
+        std::vector<uint64_t> sig(size_t(kSigBits) * std::max<size_t>(nw, 1), 0);
+        std::vector<uint8_t> tmp;
+        for (uint32_t i = 0; i < v.d; i++) {
+            const uint32_t a = v.offset_at(i), b = v.offset_at(i + 1);
+            tmp.resize(size_t(b - a) * 8 + 16);
+            const size_t dl = fsst_decode(*host_st, v.fsst + a, b - a, tmp.data());
+            for (size_t k = 0; k + 1 < dl; k++)
+                sig[size_t(bigram_bit(tmp[k], tmp[k + 1])) * nw + (i >> 6)] |= uint64_t(1) << (i & 63);
+        }
+        offs[7] = blob->add(sig.data(), sig.size() * 8);
+    }
     return LC_OK;
 }
 
@@ -400,6 +417,12 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
         out->p.mode = 1;
         out->p.use_fingerprints = 1;
         out->needle.assign(inner, inner + il);
+        for (size_t k = 0; k + 1 < il && out->p.n_sig_bits < uint32_t(kMaxSigProbe); k++) {
+            const uint8_t bit = uint8_t(bigram_bit(inner[k], inner[k + 1]));
+            bool dup = false;
+            for (uint32_t q = 0; q < out->p.n_sig_bits; q++) dup |= out->p.sig_bits[q] == bit;
+            if (!dup) out->p.sig_bits[out->p.n_sig_bits++] = bit;
+        }
     } else {
         return fail(LC_UNSUPPORTED, "operator not supported on byte-view columns");
     }
@@ -446,6 +469,7 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     ctx->device = dev;
     LC_HIP(hipGetDeviceProperties(&ctx->props, dev));
     ctx->max_hbm = max_hbm_bytes;
+    if (const char* ns = std::getenv("LC_NO_SIGNATURES")) ctx->build_signatures = std::atoi(ns) == 0;
     *out = ctx.release();
     return LC_OK;
 }
@@ -512,7 +536,7 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
         struct Pending {
             uint64_t id;
             Entry e;
-            size_t off[7];
+            size_t off[8];
             size_t blob_begin;
         };
         std::vector<Pending> pend;
@@ -559,6 +583,7 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
                 d.residuals = ptr(p.off[4]);
                 d.fsst = ptr(p.off[5]);
                 d.shared_prefix = ptr(p.off[6]);
+                d.signatures = reinterpret_cast<const uint64_t*>(ptr(p.off[7]));
             } else {
                 FixedDesc& d = p.e.fd;
                 d.packed = ptr(p.off[0]);
@@ -718,6 +743,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     L.d_valid = static_cast<uint64_t*>(d_valid_out);
     L.d_counts = static_cast<uint32_t*>(d_counts_out);
     L.d_cand_bytes = static_cast<uint32_t*>(d_cand_bytes);
+    for (const Entry& e : s->meta) L.max_dict_len = std::max(L.max_dict_len, e.dict_len);
     if (!s->is_str) {
         FixedPred fp;
         const lc_status st = make_fixed_pred(s->meta[0], pred, &fp);
