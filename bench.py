@@ -234,6 +234,9 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    if os.environ.get("LC_DUMP_COUNTS"):  # kernel-instrumentation aid (see LC_DEBUG_FLAGS in lc_kernels.hip)
+        import numpy as _np
+        _np.save(os.environ["LC_DUMP_COUNTS"], counts.cpu().numpy())
     ms_per_step = elapsed / args.steps * 1e3
     rows_all = scan.rows * world
     hits = int(total.item())

@@ -362,7 +362,21 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
 //            the symbols, one lookup per compressed code; Eq / ordering: streaming decode-compare)
 //   phase C  rows: 8 u16 keys per 16-byte load, bitmap lookup in LDS, 8 lanes x 8 bits shuffled into mask words
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kCandCap = 1024;  // candidate list entries per wave (flushed when it could overflow)
+constexpr uint32_t kCandCap = 1024;  // candidate list capacity per wave (u16 entries)
+
+// Pointers read out of descriptors are generic to the compiler; these casts make the accesses global_load (own
+// vmcnt counter, no coupling with LDS waits) instead of flat_load.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+using GlobalPtr = const __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ GlobalPtr<T> as_global(const T* p) { return (GlobalPtr<T>)p; }
+template <typename T>
+__device__ __forceinline__ T load_unaligned(const uint8_t* p) {
+    T v;
+    __builtin_memcpy(&v, (const __attribute__((address_space(1))) uint8_t*)p, sizeof(T));
+    return v;
+}
 
 __device__ __forceinline__ uint32_t str_offset(const StrDesc& d, uint32_t i) {
     int32_t r;
@@ -371,6 +385,20 @@ __device__ __forceinline__ uint32_t str_offset(const StrDesc& d, uint32_t i) {
     else r = reinterpret_cast<const int32_t*>(d.residuals)[i];
     return uint32_t(d.slope) * i + uint32_t(d.intercept) + uint32_t(r);
 }
+
+// offsets of dictionary entries i and i+1 with ONE (unaligned, 8-byte) load: the residual width only selects shifts,
+// so there is no branch between the load and its use (sections are padded, reading a few bytes past is safe)
+__device__ __forceinline__ void str_offset_pair(const StrDesc& d, uint32_t i, uint32_t& start, uint32_t& stop) {
+    const uint32_t ob = d.offset_bytes;  // 1, 2 or 4
+    const uint64_t v = load_unaligned<uint64_t>(d.residuals + size_t(i) * ob);
+    const uint32_t sh = 32u - 8u * ob;
+    const int32_t r0 = int32_t(uint32_t(v) << sh) >> sh;
+    const int32_t r1 = int32_t(uint32_t(v >> (8u * ob)) << sh) >> sh;
+    start = uint32_t(d.slope) * i + uint32_t(d.intercept) + uint32_t(r0);
+    stop = uint32_t(d.slope) * (i + 1u) + uint32_t(d.intercept) + uint32_t(r1);
+}
+
+__device__ const uint64_t kAllOnesWord = ~uint64_t(0);
 
 // byte stream over global memory with aligned 4-byte loads
 struct ByteReader {
@@ -418,76 +446,110 @@ __device__ __noinline__ int decode_compare(const DevSymtab& st, const uint8_t* f
 }
 
 // LIKE '%needle%' on one FSST-compressed value without decoding it: `tbl` is the needle's automaton folded over the
-// symbol table (k_str_automata).  64 bytes (8 words) are requested at once, so a lane pays one memory latency per 64
-// compressed bytes.  While no partial match is pending (state 0), runs of codes whose symbol cannot start a match are
-// skipped with one table lookup per code (row 0; the escape code 255 is flagged non-zero so it is never skipped);
-// only the "interesting" codes take the dependent state-transition step.
-template <typename TblPtr>
-__device__ __noinline__ bool like_walk(const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop, TblPtr tbl,
-                                       uint32_t nl, int dbg) {
-    uint32_t pos = start, s = 0;
-    if (dbg & 256) return false;
-    for (uint32_t wb = start & ~7u; wb < stop; wb += 64) {
-        uint64_t pw[8], fl[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-            pw[k] = (wb + 8u * uint32_t(k) < stop && !(dbg & 64)) ? *reinterpret_cast<const uint64_t*>(fsst + wb + 8u * uint32_t(k)) : 0;
-        if (dbg & 128) return pw[0] == 12345;
-        // state-0 flags of all 64 codes up front (independent lookups), so the walk below only pays for the few
-        // codes that can start or continue a match
+// symbol table (k_str_automata), one lookup per compressed code.  State `nl` is absorbing, so there is no per-code
+// hit test; the escape code 255 is flagged 0xFF in every row and redirects the next byte to the literal half of the
+// row.  64 compressed bytes are requested at once (unaligned 8-byte loads; the arena keeps slack behind every
+// section, lc_runtime.cpp arena_alloc); bytes past `stop` never update the state.
+// This is the general walker (table in global memory): ~9 instructions per compressed byte.
+__device__ __forceinline__ bool like_walk_global(const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop,
+                                                 const uint8_t* __restrict__ tbl, uint32_t nl) {
+    uint32_t sb = 0;   // state * 512
+    uint32_t esc = 0;  // 256 while the next byte is an escaped literal
+    for (uint32_t p0 = start; p0 < stop; p0 += 64) {
+        uint64_t pw[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            uint64_t f = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) f |= uint64_t(tbl[uint32_t(pw[k] >> (8 * q)) & 0xFFu]) << (8 * q);
-            fl[k] = f;
+            pw[k] = 0;
+            if (p0 + 8u * uint32_t(k) < stop) pw[k] = load_unaligned<uint64_t>(fsst + p0 + 8u * uint32_t(k));
         }
-        // word loop kept ROLLED (the register arrays rotate by one word per iteration): small code, see DESIGN.md
 #pragma unroll 1
         for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t base = wb + 8u * k;
-            if (base >= stop) break;
+            const uint32_t p = p0 + 8u * k;
+            if (p >= stop) break;
+            const uint32_t rem = stop - p;
             const uint64_t w = pw[0];
-            uint64_t flags = fl[0];
-            const uint64_t wnext = pw[1];
 #pragma unroll
-            for (int r = 0; r < 7; r++) { pw[r] = pw[r + 1]; fl[r] = fl[r + 1]; }
-            if (pos >= base + 8) continue;
-            if (base + 8 > stop) flags &= (uint64_t(1) << (8 * (stop - base))) - 1;
-            const uint32_t wend = min(base + 8, stop);
-            while (pos < wend) {
-                const uint32_t sh = 8u * (pos & 7u);
-                if (s == 0) {
-                    const uint64_t f = (flags >> sh) << sh;
-                    if (f == 0) { pos = base + 8; break; }
-                    pos = base + ((uint32_t(__ffsll((long long)f)) - 1u) >> 3);
-                }
-                const uint32_t c = uint32_t(w >> (8u * (pos & 7u))) & 0xFFu;
-                if (c == 255u) {
-                    if (pos + 1 >= stop) return false;
-                    uint32_t lit;
-                    if ((pos & 7u) < 7u) lit = uint32_t(w >> (8u * ((pos & 7u) + 1u))) & 0xFFu;
-                    else if (k < 7) lit = uint32_t(wnext) & 0xFFu;
-                    else lit = uint32_t(fsst[pos + 1]);
-                    s = tbl[s * 512 + 256 + lit];
-                    pos += 2;
-                } else {
-                    s = tbl[s * 512 + c];
-                    pos += 1;
-                }
-                if (s == nl) return true;
+            for (int r = 0; r < 7; r++) pw[r] = pw[r + 1];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                const uint32_t c = uint32_t(w >> (8 * q)) & 0xFFu;
+                const uint32_t t = tbl[sb + esc + c];
+                const bool is_esc = t == 0xFFu;
+                esc = is_esc ? 256u : 0u;
+                if (q < rem && !is_esc) sb = t << 9;
             }
         }
     }
-    return false;
+    return sb == (nl << 9);
 }
 
 typedef const __attribute__((address_space(3))) uint8_t* LdsBytePtr;
+typedef const __attribute__((address_space(3))) uint16_t* LdsU16Ptr;
+__device__ __forceinline__ uint32_t lds_u16(uint32_t addr) { return *reinterpret_cast<LdsU16Ptr>(addr); }
+__device__ __forceinline__ uint32_t lds_u8(uint32_t addr) { return *reinterpret_cast<LdsBytePtr>(addr); }
 
+constexpr uint32_t kMaxLdsNeedle = 15;    // LDS automaton: (nl + 1) KB per workgroup
+constexpr uint32_t kMaxByteTable = 4096;  // dictionary results as one byte per entry up to this dictionary size
+constexpr uint32_t kRoleTableBytes = 1024;
+
+// ---- the lane-parallel LIKE walker -------------------------------------------------------------------------------
+// The kernel is bound by instruction issue and by the length of dependent chains (a wave instruction costs four
+// cycles however few lanes are live, an LDS lookup ~100), so the handful of candidate values of an entry are NOT
+// walked one per lane.  Their compressed bytes are cut into 8-byte words and every word gets its own lane:
+//   1. byte roles: in FSST the byte after an escape marker (255 in code position) is a literal.  The role of a
+//      word's first byte is the exit role of the previous word; per word both are a lookup in a 512-entry table
+//      (entry role, marker mask) -> (literal mask, exit role), iterated across neighbouring lanes to a fixpoint
+//      (exit roles differ only for words made of markers, so this is one step in practice);
+//   2. states: every lane walks its word from state 0 (8 dependent LDS lookups in the workgroup's copy of the
+//      automaton, whose u16 entries are the LDS address of the next state's row; literals use the second half of a
+//      row, markers map a state to itself), then takes its left neighbour's end state as start state and re-walks
+//      while any start state changed.  The recurrence s[k] = walk(word k-1, s[k-1]) is exact at the fixpoint; a match
+//      (absorbing state) is recorded and not propagated.
+// An entry's ~9 candidates x ~6 words fit one pass of the wave: the chain is ~16-24 lookups instead of ~90 per value.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], uint32_t rem) {
+    const uint32_t s1 = lds_u16(sb + x[0]);
+    const uint32_t s2 = lds_u16(s1 + x[1]);
+    const uint32_t s3 = lds_u16(s2 + x[2]);
+    const uint32_t s4 = lds_u16(s3 + x[3]);
+    const uint32_t s5 = lds_u16(s4 + x[4]);
+    const uint32_t s6 = lds_u16(s5 + x[5]);
+    const uint32_t s7 = lds_u16(s6 + x[6]);
+    const uint32_t s8 = lds_u16(s7 + x[7]);
+    // state after the first min(rem, 8) bytes
+    const uint32_t r = min(rem, 8u) - 1u;
+    const uint32_t a0 = (r & 1u) ? s2 : s1, a1 = (r & 1u) ? s4 : s3, a2 = (r & 1u) ? s6 : s5, a3 = (r & 1u) ? s8 : s7;
+    const uint32_t b0 = (r & 2u) ? a1 : a0, b1 = (r & 2u) ? a3 : a2;
+    const uint32_t sel = (r & 4u) ? b1 : b0;
+    return rem == 0 ? sb : sel;
+}
+
+// 8-bit mask of the bytes of (lo, hi) that equal 0xFF
+__device__ __forceinline__ uint32_t marker_mask(uint32_t lo, uint32_t hi) {
+    auto m4 = [](uint32_t w) {
+        const uint32_t v = ~w;  // zero bytes of v <=> 0xFF bytes of w
+        const uint32_t t = ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu;
+        return (((~t) >> 7) * 0x00204081u >> 21) & 0xFu;
+    };
+    return m4(lo) | (m4(hi) << 4);
+}
+
+// Byte-view predicate: ONE WAVE per entry (batch), four entries per workgroup, no workgroup barriers after setup.
+//   phase A  candidates of the dictionary: LIKE with the bigram signature index: AND of the needle's bit slices,
+//            set bits scattered into an LDS list;  otherwise per entry (8 x 64 entries per round, all loads issued
+//            before use): fingerprints for LIKE, 8-byte prefix keys for Eq / ordering
+//   phase B  candidates: lane-parallel automaton walk (LIKE), streaming decode-compare (Eq / ordering)
+//   phase C  rows: skipped when every dictionary entry got the same result; else 8 u16 keys per 16-byte load, one LDS
+//            byte (or bitmap) lookup per row, result bits transposed through LDS into whole mask words
+// kBytes: dictionary results are one LDS byte per entry (dictionaries up to kMaxByteTable), else a bitmap.
+// kSub:   LIKE / NOT LIKE '%needle%';  else Eq / Ne / ordering / constant.
+template <bool kBytes, bool kSub>
 __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
                                                            const DevSymtab* __restrict__ symtabs, StrPred pred,
-                                                           ScanLaunch L, uint32_t dres_words) {
-    // dynamic LDS: [automaton table of the workgroup's first entry][per wave: result bitmap | candidate list]
+                                                           ScanLaunch L, uint32_t dres_bytes, uint32_t cmask_bytes) {
+    // dynamic LDS: [automaton (u16 row addresses)][role table]   (kSub with a short needle only)
+    //              [per wave: dictionary results | signature candidate bitmap | candidate list / phase-C staging |
+    //                         64 hit flags + head mask]
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint8_t needle_lds[256];
 
@@ -495,18 +557,54 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     const uint32_t tid = threadIdx.x;
     const uint32_t nl = pred.needle_len;
-    const bool substring = pred.mode == 1;
-    const uint32_t tbl_bytes = substring ? ((nl + 1) * 512u + 15u) & ~15u : 0u;
-    const uint32_t per_wave = dres_words * 8u + kCandCap * 2u;
-    uint32_t* dres = reinterpret_cast<uint32_t*>(smem + tbl_bytes + wave * per_wave);
-    uint64_t* cmask = reinterpret_cast<uint64_t*>(dres + dres_words);  // signature candidates, dres_words/2 u64 words
-    uint16_t* cand = reinterpret_cast<uint16_t*>(dres + 2 * dres_words);
+    const bool lds_tbl = kSub && nl <= kMaxLdsNeedle;
+    const uint32_t tbl_bytes = lds_tbl ? (nl + 1u) * 1024u + kRoleTableBytes : 0u;
+    constexpr uint32_t kFlagBytes = 80;
+    const uint32_t per_wave = dres_bytes + cmask_bytes + kCandCap * 2u + kFlagBytes;
+    uint8_t* wbase = smem + tbl_bytes + wave * per_wave;
+    uint32_t* dres = reinterpret_cast<uint32_t*>(wbase);  // bitmap words or bytes
+    uint8_t* dresb = wbase;
+    uint64_t* cmask = reinterpret_cast<uint64_t*>(wbase + dres_bytes);
+    uint16_t* cand = reinterpret_cast<uint16_t*>(wbase + dres_bytes + cmask_bytes);
+    uint8_t* hitflag = wbase + dres_bytes + cmask_bytes + kCandCap * 2u;
+    uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
+    const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));  // LDS byte address of the automaton
+    const uint32_t role_addr = row0 + (nl + 1u) * 1024u;
+    const uint32_t dres_addr = uint32_t(reinterpret_cast<uintptr_t>(wbase));
 
     const uint32_t entry = blockIdx.x * kWavesPerBlock + wave;
-    const uint32_t slot0 = descs[min(blockIdx.x * kWavesPerBlock, L.n_entries - 1)].symtab_slot;
-    if (substring) {
-        const uint4* src = reinterpret_cast<const uint4*>(pred.automata + size_t(slot0) * pred.automaton_stride);
-        for (uint32_t i = tid; i < (nl + 1) * 32u; i += kThreads) reinterpret_cast<uint4*>(smem)[i] = src[i];
+    const uint64_t rt_start = __builtin_amdgcn_s_memrealtime();
+    const uint32_t slot0 = L.uniform_slot >= 0 ? uint32_t(L.uniform_slot)
+                                               : descs[min(blockIdx.x * kWavesPerBlock, L.n_entries - 1)].symtab_slot;
+    if (lds_tbl) {
+        // u8 next-state table -> u16 row addresses, 8 entries per thread and iteration; the escape marker (0xFF in
+        // the code half) keeps the state
+        const GlobalPtr<uint2> src =
+            reinterpret_cast<GlobalPtr<uint2>>(as_global(pred.automata) + size_t(slot0) * pred.automaton_stride);
+        for (uint32_t i = tid; i < (nl + 1u) * 64u; i += kThreads) {
+            const uint32_t vx = src[i].x, vy = src[i].y;
+            const uint32_t self = row0 + (i >> 6) * 1024u;
+            uint32_t o[4];
+#pragma unroll
+            for (int h = 0; h < 4; h++) {
+                const uint32_t pair = h < 2 ? (vx >> (16 * h)) & 0xFFFFu : (vy >> (16 * (h - 2))) & 0xFFFFu;
+                const uint32_t b0 = pair & 0xFFu, b1 = pair >> 8;
+                const uint32_t t0 = b0 == 0xFFu ? self : row0 + b0 * 1024u;
+                const uint32_t t1 = b1 == 0xFFu ? self : row0 + b1 * 1024u;
+                o[h] = t0 | (t1 << 16);
+            }
+            reinterpret_cast<uint4*>(smem)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        // role table: index (entry role << 8 | marker mask) -> literal mask | exit role << 8
+        for (uint32_t i = tid; i < 512u; i += kThreads) {
+            uint32_t lit = i >> 8, lmask = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                lmask |= lit << q;
+                lit = (lit ^ 1u) & (i >> q) & 1u;  // a marker in code position makes the next byte a literal
+            }
+            reinterpret_cast<uint16_t*>(smem + (nl + 1u) * 1024u)[i] = uint16_t(lmask | (lit << 8));
+        }
     }
     // needle bytes: kernel argument (short needles) or the device copy; staged in LDS when they fit
     const bool needle_in_lds = nl <= sizeof(needle_lds);
@@ -520,9 +618,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const StrDesc d = descs[entry];
     const DevSymtab& st = symtabs[d.symtab_slot];
     // shared LDS copy of the automaton when this entry uses the workgroup's symbol table, else the global one
-    const bool tbl_in_lds = d.symtab_slot == slot0;
-    const uint8_t* tbl_global = substring ? pred.automata + size_t(d.symtab_slot) * pred.automaton_stride : nullptr;
-    const LdsBytePtr tbl_lds = reinterpret_cast<LdsBytePtr>(uint32_t(reinterpret_cast<uintptr_t>(smem)));
+    const bool tbl_in_lds = lds_tbl && d.symtab_slot == slot0;
+    const uint8_t* tbl_global = kSub ? pred.automata + size_t(d.symtab_slot) * pred.automaton_stride : nullptr;
     const uint32_t nwords = (d.n + 63u) >> 6;
 
     // early out: nothing selected in this entry
@@ -541,96 +638,83 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             return;
         }
     }
-    for (uint32_t i = uint32_t(lane); i < dres_words; i += kWave) dres[i] = 0;
 
     // ---- shared-prefix short circuits (comparisons.rs:24-26 for Eq, :469-501 for ordering) ----
     const uint32_t spl = d.shared_prefix_len;
     int uniform_result = -1;  // -1: evaluate per entry; 0/1: every dictionary entry gets this result
     const int op = pred.op;
     const bool is_eq = (op == LC_OP_EQ || op == LC_OP_NE);
-    if (pred.mode == 2) {
-        uniform_result = pred.const_value ? 1 : 0;  // helpers.rs:72-79 (UnsupportedExpression::Constant)
-    } else if (!substring) {
-        const uint32_t m = min(nl, spl);
-        int c = 0;
-        for (uint32_t i = 0; i < m && c == 0; i++) {
-            const uint32_t a = d.shared_prefix[i], b = np[i];
-            c = a < b ? -1 : (a > b ? 1 : 0);
-        }
-        if (is_eq) {
-            if (nl < spl || c != 0) uniform_result = 0;
+    if (!kSub) {
+        if (pred.mode == 2) {
+            uniform_result = pred.const_value ? 1 : 0;  // helpers.rs:72-79 (UnsupportedExpression::Constant)
         } else {
-            if (c < 0) uniform_result = (op == LC_OP_LT || op == LC_OP_LE) ? 1 : 0;
-            else if (c > 0) uniform_result = (op == LC_OP_GT || op == LC_OP_GE) ? 1 : 0;
-            else if (nl < spl) uniform_result = (op == LC_OP_GT || op == LC_OP_GE) ? 1 : 0;
+            const uint32_t m = min(nl, spl);
+            int c = 0;
+            for (uint32_t i = 0; i < m && c == 0; i++) {
+                const uint32_t a = d.shared_prefix[i], b = np[i];
+                c = a < b ? -1 : (a > b ? 1 : 0);
+            }
+            if (is_eq) {
+                if (nl < spl || c != 0) uniform_result = 0;
+            } else {
+                if (c < 0) uniform_result = (op == LC_OP_LT || op == LC_OP_LE) ? 1 : 0;
+                else if (c > 0) uniform_result = (op == LC_OP_GT || op == LC_OP_GE) ? 1 : 0;
+                else if (nl < spl) uniform_result = (op == LC_OP_GT || op == LC_OP_GE) ? 1 : 0;
+            }
         }
     }
+    // dictionary results start all false (bytes / bitmap words)
+    for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)
+        reinterpret_cast<uint4*>(wbase)[i] = make_uint4(0, 0, 0, 0);
     const uint32_t nsl = nl >= spl ? nl - spl : 0;  // needle suffix length after the shared prefix
     uint64_t nsuf7 = 0;                             // first min(7, nsl) suffix bytes, little endian
-    if (!substring && uniform_result < 0)
+    if (!kSub && uniform_result < 0)
         for (uint32_t i = 0; i < 7 && i < nsl; i++) nsuf7 |= uint64_t(np[spl + i]) << (8 * i);
     uint32_t needle_fp = 0;
-    if (substring)
+    if (kSub)
         for (uint32_t i = 0; i < nl; i++) needle_fp |= 1u << (np[i] & 31);
-    const bool prune = substring && pred.use_fingerprints && d.fingerprints != nullptr;
+    const bool prune = kSub && pred.use_fingerprints && d.fingerprints != nullptr;
     // bigram signature probe (needles of >= 2 bytes): AND of the needle's bit slices = candidate bitmap
     const bool use_sig = prune && d.signatures != nullptr && pred.n_sig_bits > 0 && !(pred.debug_flags & 8);
     // with signatures the (weaker) fingerprint only matters for the NOT LIKE candidate-count rule and for the
     // algorithmic-byte instrumentation: its 4*D bytes are skipped otherwise
     const bool need_fp = prune && (!use_sig || op == LC_OP_NOT_LIKE || L.d_cand_bytes != nullptr);
 
-    uint32_t dbg_cands = 0;
-    uint32_t n_cand = 0;        // wave uniform
-    uint32_t fp_cand = 0;       // wave uniform: fingerprint candidates seen (NOT LIKE rule)
-    uint32_t cand_bytes = 0;    // per lane, summed at the end (instrumented pass only)
+    uint32_t fp_cand = 0;     // wave uniform: fingerprint candidates seen (NOT LIKE rule)
+    uint32_t cand_bytes = 0;  // per lane, summed at the end (instrumented pass only)
+    uint64_t any_true = 0;    // wave uniform: some dictionary entry evaluated true
     __builtin_amdgcn_wave_barrier();
 
-    auto run_phase_b = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        const uint32_t nc = (pred.debug_flags & 1) ? 0u : n_cand;
-        dbg_cands += n_cand;
-        for (uint32_t j = uint32_t(lane); j < nc; j += kWave) {
-            const uint32_t i = cand[j];
-            uint32_t start = 0, stop = 0;
-            if (!(pred.debug_flags & 32)) { start = str_offset(d, i); stop = str_offset(d, i + 1); }
-            if (L.d_cand_bytes && !prune) cand_bytes += stop - start;
-            bool res;
-            if (pred.debug_flags & 16) {
-                res = (start ^ stop) == 0xFFFFFFFFu;
-            } else if (substring) {
-                res = tbl_in_lds ? like_walk(d.fsst, start, stop, tbl_lds, nl, pred.debug_flags)
-                                 : like_walk(d.fsst, start, stop, tbl_global, nl, pred.debug_flags);
-            } else {
-                const int o = decode_compare(st, d.fsst, start, stop, np, nl);
-                res = is_eq ? o == 0
-                            : (op == LC_OP_LT ? o < 0 : op == LC_OP_LE ? o <= 0 : op == LC_OP_GT ? o > 0 : o >= 0);
-            }
-            if (res) atomicOr(&dres[i >> 5], 1u << (i & 31));
-        }
-        n_cand = 0;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    };
-
-    constexpr int KH = 8;
     const uint32_t nw = (d.d + 63u) >> 6;  // u64 words of a dictionary bitmap
-    if (use_sig && uniform_result < 0) {
+    if (kSub && use_sig) {
         for (uint32_t w = uint32_t(lane); w < nw; w += kWave) {
-            uint64_t m = ~uint64_t(0);
+            uint64_t sv[kMaxSigProbe];  // sig_bits is padded with repeats: all loads are issued before the first use
 #pragma unroll
-            for (int k = 0; k < kMaxSigProbe; k++)
-                if (uint32_t(k) < pred.n_sig_bits) m &= d.signatures[size_t(pred.sig_bits[k]) * nw + w];
+            for (int k = 0; k < kMaxSigProbe; k++) sv[k] = as_global(d.signatures)[size_t(pred.sig_bits[k]) * nw + w];
+            uint64_t m = sv[0];
+#pragma unroll
+            for (int k = 1; k < kMaxSigProbe; k++) m &= sv[k];
             if (w == nw - 1 && (d.d & 63u)) m &= (uint64_t(1) << (d.d & 63u)) - 1;
             cmask[w] = m;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (uniform_result == 1) {
-        for (uint32_t i = uint32_t(lane); i < dres_words; i += kWave) dres[i] = 0xFFFFFFFFu;
-    } else if (uniform_result < 0 && use_sig && !need_fp && !(pred.debug_flags & 4)) {
-        // LIKE fast path: the candidates ARE the set bits of the signature bitmap; no per-entry pass at all
-        for (uint32_t w0 = 0; w0 < nw; w0 += kWave) {
-            const uint32_t w = w0 + uint32_t(lane);
-            uint64_t m = w < nw ? cmask[w] : 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    // Candidates are collected into the wave's LDS list by rounds (64 bitmap words, or KH x 64 entries); when the next
+    // round might not fit, the list is walked first.  One loop, so phase B has exactly one call site and, for the
+    // usual handful of candidates, runs once per entry.
+    constexpr int KH = 8;
+    const bool sig_only = kSub && use_sig && !need_fp;  // the candidates ARE the set bits of the bitmap
+    const uint32_t d_eval = uniform_result < 0 ? d.d : 0u;
+    uint32_t pos = 0;              // next dictionary entry to look at (multiple of 64)
+    uint32_t n_cand = 0;           // wave uniform
+    uint32_t round_words = kWave;  // bitmap words per signature round (drops to 16 if 64 words overflow an empty list)
+    while (pos < d_eval || n_cand > 0) {
+        bool took = false;
+        if (kSub && pos < d_eval && sig_only) {
+            // phase A (signature only): one bitmap word per lane, prefix sum of popcounts, scatter into the list
+            const uint32_t w = (pos >> 6) + uint32_t(lane);
+            uint64_t m = (uint32_t(lane) < round_words && w < nw) ? cmask[w] : 0;
             const uint32_t cnt = uint32_t(__popcll(m));
             uint32_t incl = cnt;
 #pragma unroll
@@ -639,19 +723,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 if (lane >= o) incl += t;
             }
             const uint32_t total = __shfl(incl, kWave - 1, kWave);
-            if (n_cand + total > kCandCap) {
-                // pathological density: fall back to one flush per 64-entry word group
-                for (uint32_t l = 0; l < kWave; l++) {
-                    uint64_t ml = __shfl(m, int(l), kWave);
-                    while (ml) {  // wave-uniform loop
-                        if (n_cand >= kCandCap) run_phase_b();
-                        const uint32_t bit = uint32_t(__ffsll((long long)ml)) - 1u;
-                        if (lane == 0) cand[n_cand] = uint16_t((w0 + l) * 64u + bit);
-                        n_cand++;
-                        ml &= ml - 1;
-                    }
-                }
-            } else {
+            if (n_cand + total <= kCandCap) {
                 uint32_t o = n_cand + incl - cnt;
                 while (m) {
                     const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
@@ -659,34 +731,38 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     m &= m - 1;
                 }
                 n_cand += total;
+                pos += round_words * 64u;
+                took = true;
+            } else if (n_cand == 0) {
+                round_words = 16;  // 16 words hold at most 1024 candidates: always fits an empty list
+                took = true;
             }
-        }
-        run_phase_b();
-    } else if (uniform_result < 0 && !(pred.debug_flags & 4)) {
-        for (uint32_t base = 0; base < d.d; base += KH * kWave) {
+        } else if (pos < d_eval && n_cand + KH * kWave <= kCandCap) {
+            // phase A (per entry): fingerprints for LIKE, prefix keys for Eq / ordering
+            const uint32_t base = pos;
             uint32_t fpv[KH];
             uint64_t pkv[KH];
-            if (substring) {
+            if (kSub) {
 #pragma unroll
                 for (int k = 0; k < KH; k++) {
                     const uint32_t ii = min(base + uint32_t(k) * kWave + uint32_t(lane), d.d - 1);
-                    fpv[k] = need_fp ? d.fingerprints[ii] : 0xFFFFFFFFu;
+                    fpv[k] = need_fp ? as_global(d.fingerprints)[ii] : 0xFFFFFFFFu;
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < KH; k++) {
                     const uint32_t ii = min(base + uint32_t(k) * kWave + uint32_t(lane), d.d - 1);
-                    pkv[k] = reinterpret_cast<const uint64_t*>(d.prefix_keys)[ii];
+                    pkv[k] = reinterpret_cast<GlobalPtr<uint64_t>>(as_global(d.prefix_keys))[ii];
                 }
             }
 #pragma unroll
             for (int k = 0; k < KH; k++) {
                 const uint32_t g0 = base + uint32_t(k) * kWave;
-                if (g0 >= d.d) break;  // uniform
+                if (g0 >= d_eval) break;  // uniform
                 const uint32_t i = g0 + uint32_t(lane);
                 const bool in = i < d.d;
                 bool is_cand = false, decided_true = false;
-                if (substring) {
+                if (kSub) {
                     // reference prefilter (fingerprint.rs:33-35): its candidates define the algorithmic bytes
                     const bool fp_ok = in && (!need_fp || (fpv[k] & needle_fp) == needle_fp);
                     is_cand = fp_ok;
@@ -724,78 +800,222 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                         }
                     }
                 }
-                // the 64 entries of this group own two whole bitmap words: plain stores, no atomics
-                const uint64_t dm = __ballot(decided_true);
-                if (lane == 0) {
-                    dres[g0 >> 5] = uint32_t(dm);
-                    if ((g0 >> 5) + 1 < dres_words) dres[(g0 >> 5) + 1] = uint32_t(dm >> 32);
+                if (!kSub) {
+                    const uint64_t dm = __ballot(decided_true);
+                    any_true |= dm;
+                    if (kBytes) {
+                        if (decided_true) dresb[i] = 1;
+                    } else if (lane == 0) {
+                        // the 64 entries of this group own two whole bitmap words: plain stores, no atomics
+                        dres[g0 >> 5] = uint32_t(dm);
+                        dres[(g0 >> 5) + 1] = uint32_t(dm >> 32);
+                    }
                 }
                 const uint64_t cm = __ballot(is_cand);
                 if (is_cand) cand[n_cand + lanes_below(cm)] = uint16_t(i);
                 n_cand += uint32_t(__popcll(cm));
             }
-            if (n_cand > kCandCap - KH * kWave || base + KH * kWave >= d.d) run_phase_b();
+            pos += KH * kWave;
+            took = true;
         }
+        if (took) continue;
+
+        // ---- phase B: walk the candidate list ----
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t n_walk = (pred.debug_flags & 1) ? 0u : n_cand;
+        for (uint32_t jb = 0; jb < n_walk; jb += kWave) {
+            const uint32_t j = jb + uint32_t(lane);
+            const bool cl = j < n_walk;
+            const uint32_t id = cl ? cand[j] : 0u;
+            uint32_t start = 0, stop = 0;
+            if (cl) str_offset_pair(d, id, start, stop);
+            if (L.d_cand_bytes && !prune) cand_bytes += stop - start;
+            bool res = false;
+            if (kSub && tbl_in_lds) {
+                // lane-parallel walk: one lane per 8-byte word of every candidate (see above)
+                const uint32_t hitrow = row0 + nl * 1024u;
+                const uint32_t words = cl ? max(1u, (stop - start + 7u) >> 3) : 0u;
+                uint32_t incl = words;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const uint32_t t = __shfl_up(incl, o, kWave);
+                    if (lane >= o) incl += t;
+                }
+                const uint32_t off = incl - words;
+                const uint32_t total = __shfl(incl, kWave - 1, kWave);
+                hitflag[lane] = 0;
+                uint32_t carry_state = row0, carry_role = 0;
+                for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
+                    // owner of task t = t0 + lane: the last candidate whose first word is at or before t
+                    if (lane == 0) *headmask = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const bool head = cl && off >= t0 && off < t0 + kWave;
+                    if (head) atomicOr(reinterpret_cast<unsigned long long*>(headmask), 1ull << (off - t0));
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const uint64_t hm = *headmask;
+                    const uint32_t before = uint32_t(__popcll(__ballot(cl && off < t0)));
+                    const uint64_t upto = lane == 63 ? ~uint64_t(0) : ((uint64_t(2) << lane) - 1);
+                    const uint32_t r = before + uint32_t(__popcll(hm & upto)) - 1u;  // owner lane (>= 0: off[0] == 0)
+                    const bool live = t0 + uint32_t(lane) < total;
+                    const uint32_t o_off = __shfl(off, int(r), kWave);
+                    const uint32_t o_start = __shfl(start, int(r), kWave);
+                    const uint32_t o_stop = __shfl(stop, int(r), kWave);
+                    const uint32_t k = t0 + uint32_t(lane) - o_off;  // word index within the value
+                    const uint32_t p = o_start + 8u * k;
+                    const uint32_t rem = live && p < o_stop ? o_stop - p : 0u;
+                    uint64_t w = 0;
+                    if (rem) w = load_unaligned<uint64_t>(d.fsst + p);
+                    const uint32_t lo = uint32_t(w), hi = uint32_t(w >> 32);
+                    const bool first = k == 0;  // first word of its value (a value continuing from the previous pass
+                                                // has k > 0 in lane 0 and takes the carried role / state)
+                    // byte roles
+                    const uint32_t mm = marker_mask(lo, hi);
+                    uint32_t role_in = 0, rl = lds_u16(role_addr + 2u * mm);
+                    for (;;) {
+                        uint32_t prev = __shfl_up(rl >> 8, 1, kWave);
+                        if (lane == 0) prev = carry_role;
+                        if (first) prev = 0;
+                        const bool changed = prev != role_in;
+                        if (__ballot(changed) == 0) break;
+                        if (changed) {
+                            role_in = prev;
+                            rl = lds_u16(role_addr + 2u * ((role_in << 8) | mm));
+                        }
+                    }
+                    carry_role = __shfl(rl >> 8, kWave - 1, kWave);
+                    uint32_t x[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const uint32_t c = ((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu;
+                        x[q] = (c << 1) + (((rl >> q) & 1u) << 9);
+                    }
+                    // states
+                    uint32_t s_in = row0;
+                    uint32_t e = walk8(s_in, x, rem);
+                    bool hit = e == hitrow;
+                    for (;;) {
+                        uint32_t prev = __shfl_up(e, 1, kWave);
+                        if (lane == 0) prev = carry_state;
+                        if (first || prev == hitrow) prev = row0;
+                        const bool changed = prev != s_in;
+                        if (__ballot(changed) == 0) break;
+                        if (changed) {
+                            s_in = prev;
+                            e = walk8(s_in, x, rem);
+                            hit |= e == hitrow;
+                        }
+                    }
+                    carry_state = __shfl(e, kWave - 1, kWave);
+                    if (carry_state == hitrow) carry_state = row0;
+                    if (hit && live) hitflag[r] = 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                res = cl && hitflag[lane] != 0;
+            } else if (kSub) {
+                if (cl) res = like_walk_global(d.fsst, start, stop, tbl_global, nl);
+            } else if (cl) {
+                const int o = decode_compare(st, d.fsst, start, stop, np, nl);
+                res = is_eq ? o == 0
+                            : (op == LC_OP_LT ? o < 0 : op == LC_OP_LE ? o <= 0 : op == LC_OP_GT ? o > 0 : o >= 0);
+            }
+            any_true |= __ballot(res);
+            if (res) {
+                if (kBytes) dresb[id] = 1;
+                else atomicOr(&dres[id >> 5], 1u << (id & 31));
+            }
+        }
+        n_cand = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     // dictionary-level negation:
     //   NotContains inverts the dictionary results only when at least one fingerprint candidate existed
     //   (comparisons.rs:167-180, :644-648 — bit-exact with the reference); Ne inverts row values (:85-90).
     bool invert = false;
-    if (substring && op == LC_OP_NOT_LIKE) invert = prune ? (fp_cand > 0) : true;
-    if (pred.mode == 0 && op == LC_OP_NE) invert = true;
+    if (kSub && op == LC_OP_NOT_LIKE) invert = prune ? (fp_cand > 0) : true;
+    if (!kSub && pred.mode == 0 && op == LC_OP_NE) invert = true;
+    if (uniform_result == 1) invert = !invert;  // all-true dictionary == all-false inverted
 
     // ---- phase C: rows ----
-    const uint32_t xorm = invert ? 1u : 0u;
+    // Every dictionary entry false (the usual case for a selective LIKE): no key is read at all, the hit words are
+    // 0 (or, inverted, the valid & selected rows).  Otherwise all 16 KB of an 8192-row entry's keys are requested
+    // before the first one is used; each lane looks up its 8 consecutive rows and drops the 8 result bits as one byte
+    // into LDS; the bytes of 8 neighbouring lanes ARE the 64-row mask word, so lane l picks up words l and l+64 with
+    // one ds_read_b64 each, combines them with the selection / validity words it loaded itself and stores them
+    // (coalesced).  The candidate list is dead by now and provides the staging space.
+    const bool all_false = any_true == 0;
+    const uint32_t xor8 = invert ? 0xFFu : 0u;
     const uint32_t n_rows = (pred.debug_flags & 2) ? 0u : d.n;
-    const uint32_t key_max = dres_words * 32u - 1u;  // keys under null slots may be garbage: clamp, validity masks them
+    const uint32_t key_max = dres_bytes * 8u - 1u;  // bitmap: keys under null slots may be garbage (clamped)
     uint32_t hit_count = 0;
-    constexpr int KC = 4;  // 4 x 512 rows per pass: all key / selection / validity loads in flight together
+    constexpr int KC = 16;
+    uint8_t* stage = reinterpret_cast<uint8_t*>(cand);
+    static_assert(kCandCap * 2 >= KC * kWave, "phase C staging must fit in the candidate list");
     for (uint32_t pass = 0; pass < n_rows; pass += KC * kWave * 8) {
-        uint4 kv[KC];
-        uint64_t selw[KC], valw[KC];
+        u32x4 kv[KC];
+        if (!all_false) {
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
-            const uint32_t r0 = pass + uint32_t(k) * kWave * 8 + uint32_t(lane) * 8;
-            kv[k] = r0 < n_rows ? *reinterpret_cast<const uint4*>(d.keys + r0) : make_uint4(0, 0, 0, 0);
-            const uint32_t widx = r0 >> 6;
-            const bool leader = (lane & 7) == 0 && r0 < n_rows;
-            selw[k] = (leader && L.d_selection) ? L.d_selection[d.mask_word_off + widx] : ~uint64_t(0);
-            valw[k] = (leader && d.validity) ? d.validity[widx] : ~uint64_t(0);
+            for (int k = 0; k < KC; k++) {
+                const uint32_t r0 = pass + uint32_t(k) * kWave * 8 + uint32_t(lane) * 8;
+                // rows past the end re-read the last 8-row group (never stored)
+                kv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(d.keys) + min(r0, (n_rows - 1u) & ~7u));
+            }
+        }
+        uint64_t vw[KC * 8 / kWave];
+#pragma unroll
+        for (int h = 0; h < KC * 8 / kWave; h++) {
+            const uint32_t widx = (pass >> 6) + uint32_t(h) * kWave + uint32_t(lane);
+            // both words are always loaded (a constant all-ones word stands in for an absent bitmap), so the two
+            // loads are in flight together with the key loads above
+            const uint32_t wc = min(widx, nwords - 1u);
+            const uint64_t* sp = L.d_selection ? L.d_selection + d.mask_word_off + wc : &kAllOnesWord;
+            const uint64_t* vp = d.validity ? d.validity + wc : &kAllOnesWord;
+            const uint64_t sv = *as_global(sp), vv = *as_global(vp);
+            const uint32_t rows_left = d.n - (wc << 6);
+            const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
+            vw[h] = widx < nwords ? (sv & vv & tail) : 0;
+        }
+        if (!all_false) {
+#pragma unroll
+            for (int k = 0; k < KC; k++) {
+                uint32_t bits = 0;
+                const uint32_t kw[4] = {kv[k].x, kv[k].y, kv[k].z, kv[k].w};
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t key = (q & 1) ? kw[q >> 1] >> 16 : kw[q >> 1] & 0xFFFFu;
+                    uint32_t hit;
+                    if (kBytes) {
+                        hit = lds_u8(dres_addr + key);  // garbage keys under nulls read other LDS bytes: masked below
+                    } else {
+                        const uint32_t kc = min(key, key_max);
+                        hit = (dres[kc >> 5] >> (kc & 31)) & 1u;
+                    }
+                    bits |= hit << q;
+                }
+                stage[uint32_t(k) * kWave + uint32_t(lane)] = uint8_t(bits ^ xor8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
 #pragma unroll
-        for (int k = 0; k < KC; k++) {
-            const uint32_t r0 = pass + uint32_t(k) * kWave * 8 + uint32_t(lane) * 8;  // this lane's 8 consecutive rows
-            if (pass + uint32_t(k) * kWave * 8 >= n_rows) break;                      // uniform
-            uint32_t bits = 0;
-            const uint32_t kw[4] = {kv[k].x, kv[k].y, kv[k].z, kv[k].w};
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const uint32_t key = min((kw[q >> 1] >> (16 * (q & 1))) & 0xFFFFu, key_max);
-                const uint32_t hit = ((dres[key >> 5] >> (key & 31)) & 1u) ^ xorm;
-                bits |= hit << q;
-            }
-            // 8 lanes x 8 bits -> one 64-row word in the group leader
-            uint64_t w = bits;
-            w |= uint64_t(__shfl_down(uint32_t(w), 1, kWave)) << 8;
-            w |= uint64_t(__shfl_down(uint32_t(w), 2, kWave)) << 16;
-            w |= __shfl_down(w, 4, kWave) << 32;
-            if ((lane & 7) == 0 && r0 < n_rows) {
-                const uint32_t widx = r0 >> 6;
-                const uint32_t rows_left = d.n - (widx << 6);
-                const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
-                const uint64_t vw = valw[k] & tail & selw[k];
-                const uint64_t hitw = w & vw;
+        for (int h = 0; h < KC * 8 / kWave; h++) {
+            const uint32_t wl = uint32_t(h) * kWave + uint32_t(lane);
+            const uint32_t widx = (pass >> 6) + wl;
+            if (widx < nwords) {
+                const uint64_t rw = all_false ? (invert ? ~uint64_t(0) : uint64_t(0))
+                                              : reinterpret_cast<const uint64_t*>(stage)[wl];
+                const uint64_t hitw = rw & vw[h];
                 L.d_hit[d.mask_word_off + widx] = hitw;
-                if (L.d_valid) L.d_valid[d.mask_word_off + widx] = vw;
+                if (L.d_valid) L.d_valid[d.mask_word_off + widx] = vw[h];
                 hit_count += uint32_t(__popcll(hitw));
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     if (L.d_counts) {
-        const uint64_t c = wave_sum_u64(uint64_t(hit_count));
-        if (lane == 0) L.d_counts[entry] = (pred.debug_flags & 512) ? dbg_cands : uint32_t(c);
+        uint64_t c = wave_sum_u64(uint64_t(hit_count));
+        if (((pred.debug_flags >> 10) & 7u) == 7u)  // timing instrumentation (LC_DEBUG_FLAGS, scripts/occupancy.py)
+            c = ((rt_start & 0xFFFFu) << 16) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFu);
+        if (lane == 0) L.d_counts[entry] = uint32_t(c);
     }
     if (L.d_cand_bytes) {
         const uint64_t c = wave_sum_u64(uint64_t(cand_bytes));
@@ -1273,12 +1493,27 @@ hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, c
 hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, const StrPred& pred,
                            const ScanLaunch& L, hipStream_t stream) {
     if (L.n_entries == 0) return hipSuccess;
-    // result bitmap words per wave: enough for the largest dictionary of the scan (multiple of 4 words)
-    const uint32_t dres_words = ((std::max<uint32_t>(L.max_dict_len, 1u) + 31u) / 32u + 3u) & ~3u;
-    const size_t tbl_bytes = pred.mode == 1 ? ((size_t(pred.needle_len + 1) * 512 + 15) & ~size_t(15)) : 0;
-    const size_t dyn_lds = tbl_bytes + size_t(kWavesPerBlock) * (size_t(dres_words) * 8 + kCandCap * 2);
+    const uint32_t dmax = std::max<uint32_t>(L.max_dict_len, 1u);
+    const bool bytes = dmax <= kMaxByteTable;
+    const bool sub = pred.mode == 1;
+    // per-wave dictionary results: one byte per entry, or a bitmap (+ one spare word pair for the group stores)
+    const uint32_t dres_bytes = bytes ? (dmax + 15u) & ~15u : (((dmax + 63u) / 64u) * 8u + 15u) & ~15u;
+    const uint32_t cmask_bytes = sub ? (((dmax + 63u) / 64u) * 8u + 15u) & ~15u : 0u;
+    const bool lds_tbl = sub && pred.needle_len <= kMaxLdsNeedle;
+    const size_t tbl_bytes = lds_tbl ? size_t(pred.needle_len + 1) * 1024 + kRoleTableBytes : 0;
+    const size_t dyn_lds = tbl_bytes + size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + kCandCap * 2 + 80);
     const uint32_t grid = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(k_str_pred, dim3(grid), dim3(kThreads), dyn_lds, stream, d_descs, d_symtabs, pred, L, dres_words);
+    void (*kern)(const StrDesc*, const DevSymtab*, StrPred, ScanLaunch, uint32_t, uint32_t) =
+        bytes ? (sub ? k_str_pred<true, true> : k_str_pred<true, false>)
+              : (sub ? k_str_pred<false, true> : k_str_pred<false, false>);
+    if (dyn_lds > 64 * 1024) {
+        // large dictionaries: gfx950 has 160 KB of LDS per CU, a workgroup may use more than the default 64 KB
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), dyn_lds, stream, d_descs, d_symtabs, pred, L, dres_bytes,
+                       cmask_bytes);
     return hipGetLastError();
 }
 

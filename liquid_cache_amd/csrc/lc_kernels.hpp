@@ -112,7 +112,7 @@ struct ScanLaunch {
     uint32_t* d_counts;   // optional, must be zeroed by the launcher
     uint32_t* d_cand_bytes;  // optional (byte views): per entry, compressed bytes of the candidates that were walked
     uint32_t max_dict_len;   // byte views: largest dictionary in the scan (sizes the LDS result bitmap)
-    uint32_t pad;
+    int32_t uniform_slot;    // byte views: symbol-table slot shared by every entry of the scan, or -1
 };
 
 hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,

@@ -423,6 +423,9 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
             for (uint32_t q = 0; q < out->p.n_sig_bits; q++) dup |= out->p.sig_bits[q] == bit;
             if (!dup) out->p.sig_bits[out->p.n_sig_bits++] = bit;
         }
+        // the kernel always ANDs kMaxSigProbe slices (all loads in flight together): pad with repeats
+        for (uint32_t q = out->p.n_sig_bits; q < uint32_t(kMaxSigProbe) && out->p.n_sig_bits > 0; q++)
+            out->p.sig_bits[q] = out->p.sig_bits[q % out->p.n_sig_bits];
     } else {
         return fail(LC_UNSUPPORTED, "operator not supported on byte-view columns");
     }
@@ -743,7 +746,13 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     L.d_valid = static_cast<uint64_t*>(d_valid_out);
     L.d_counts = static_cast<uint32_t*>(d_counts_out);
     L.d_cand_bytes = static_cast<uint32_t*>(d_cand_bytes);
+    L.uniform_slot = -1;
     for (const Entry& e : s->meta) L.max_dict_len = std::max(L.max_dict_len, e.dict_len);
+    if (s->is_str && !s->meta.empty()) {
+        L.uniform_slot = int32_t(s->meta[0].sd.symtab_slot);
+        for (const Entry& e : s->meta)
+            if (e.sd.symtab_slot != s->meta[0].sd.symtab_slot) L.uniform_slot = -1;
+    }
     if (!s->is_str) {
         FixedPred fp;
         const lc_status st = make_fixed_pred(s->meta[0], pred, &fp);

@@ -169,6 +169,35 @@ def test_string_predicates(gpu_cache, oracle, fingerprints):
                 _check_pred(gpu_cache, lo, eid, liquid, op, pat.encode(), pa.string(), sel, symtab=st, hint=hint)
 
 
+def test_string_large_dictionary_and_long_needles(gpu_cache, oracle):
+    """Dictionaries above the byte-table limit (bitmap result variant, > 64 KB of LDS per workgroup), needles longer
+    than the LDS automaton limit (table walked from global memory), escaped bytes inside the needle."""
+    lo = oracle
+    rng = np.random.default_rng(77)
+    hint = lc.CacheExpression.SUBSTRING_SEARCH
+    for eid, (n, d, fingerprints) in enumerate(((30000, 20000, True), (9000, 5000, False), (8192, 2200, True)), start=1):
+        pool = _make_strings(rng, d, d, False)
+        pool = [s + "#%d" % i for i, s in enumerate(pool)]       # all distinct
+        keys = rng.integers(0, d, size=n)
+        strs = [pool[k] for k in keys]
+        for i in rng.choice(n, size=n // 50, replace=False):
+            strs[int(i)] = None
+        liquid, st = lo.encode_byte_view(strs, fingerprints=fingerprints)
+        path = 2000 + eid
+        gpu_cache.set_symbol_table(path, lo.symtab_bytes(st))
+        gpu_cache.stage([eid], [liquid], [path])
+        nonnull = [s for s in strs if s is not None]
+        long_piece = max(nonnull, key=len)
+        pats = ["%google%", "%" + nonnull[3][2:30] + "%", "%" + long_piece[5:60] + "%", "%ÿéz%", "%#1999%", "%e.g%"]
+        for op in ("like", "not_like"):
+            for pat in pats:
+                sel = (rng.random(n) < 0.4) if rng.integers(2) else None
+                _check_pred(gpu_cache, lo, eid, liquid, op, pat.encode(), pa.string(), sel, symtab=st, hint=hint)
+        for op in OPS:
+            for needle in (nonnull[0], nonnull[7][:12], "http://goo"):
+                _check_pred(gpu_cache, lo, eid, liquid, op, needle.encode(), pa.string(), None, symtab=st)
+
+
 def test_and_then(gpu_cache, oracle):
     lo = oracle
     rng = np.random.default_rng(3)
