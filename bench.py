@@ -158,6 +158,22 @@ def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal):
     return rows_total / dt, rows_total, hits, dt
 
 
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel, from the rocprofv3 --pmc passes of the newest profiled round
+    (profiles/<round>/hbm_traffic.json, produced by scripts/profile_round.sh; counters cannot be read from inside the
+    process).  None when this workload has not been profiled."""
+    import glob
+    root = os.path.dirname(os.path.abspath(__file__))
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "*", "hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if workload in d:
+            return int(d[workload]["traffic_bytes"]), os.path.relpath(f, root)
+    return None, None
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -209,12 +225,12 @@ def main():
     words = int(scan.mask_words)
     mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
     counts = torch.zeros(max(scan.entries, 1), dtype=torch.int32, device="cuda")
-    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    total = torch.zeros((), dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
-        total.copy_(counts.sum(dtype=torch.int64))
+        torch.sum(counts, dim=(0,), dtype=torch.int64, out=total)  # COUNT(*) of this shard: one reduce kernel, no copy
         if world > 1:
             dist.all_reduce(total)  # the query's only exchange step: COUNT(*) partials -> global count
 
@@ -248,6 +264,7 @@ def main():
 
     out = None
     if rank == 0:
+        traffic, traffic_src = measured_traffic(workload)
         out = {
             "metric": "filtered rows/s (+ GB/s scanned), ClickBench Q21 hot cache",
             "value": rows_all / elapsed * args.steps,
@@ -268,7 +285,7 @@ def main():
                        "hits": hits, "stage_seconds": round(t_stage, 2)},
             "gb_per_s_scanned": alg_bytes * world / (elapsed / args.steps) / 1e9,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_str_pred" if args.workload == "url_like" else "k_fixed_pred<u64>",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes)},
         }

@@ -16,6 +16,7 @@
 #include "../../include/liquid_cache_amd.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <utility>
 
 namespace lc {
@@ -39,6 +40,28 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
     return v;  // lane 0 holds the total
 }
+
+// Cross-lane steps on the VALU's DPP path (a few cycles) instead of ds_bpermute (an LDS round trip, ~100 cycles):
+// the byte-view kernel is bound by the length of its dependent chains.
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kCtrl, kRowMask, 0xF, false));
+}
+// inclusive prefix sum over the 64 lanes (gfx9 DPP: row_shr within rows of 16, then row_bcast15 / row_bcast31)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+    v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1
+    v += dpp_or_zero<0x112, 0xF>(v);  // row_shr:2
+    v += dpp_or_zero<0x114, 0xF>(v);  // row_shr:4
+    v += dpp_or_zero<0x118, 0xF>(v);  // row_shr:8
+    v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+    return v;
+}
+// value of the previous lane (lane 0 gets `first`)
+__device__ __forceinline__ uint32_t lane_shift_up1(uint32_t v, uint32_t first) {
+    return uint32_t(__builtin_amdgcn_update_dpp(int(first), int(v), 0x138, 0xF, 0xF, false));  // wave_shr:1
+}
+__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) { return uint32_t(__builtin_amdgcn_readlane(int(v), lane)); }
 
 // global -> LDS DMA of 16 bytes per active lane: lane l writes lds_base + l*16 (lds_base must be wave-uniform)
 __device__ __forceinline__ void async_copy16(const void* gsrc_lane, void* lds_base) {
@@ -339,16 +362,34 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
     }
     __syncthreads();
     const DevSymtab& st = symtabs[blockIdx.x];
-    uint8_t* t = out + size_t(blockIdx.x) * size_t(m + 1) * 512;
+    uint8_t* t = out + size_t(blockIdx.x) * automaton_stride(m);
+    // LDS image (short needles): u16 entries = LDS byte address of the next state's row, rows of 1 KB from address 0
+    uint16_t* img = automaton_image_bytes(m) ? reinterpret_cast<uint16_t*>(t + automaton_u8_bytes(m)) : nullptr;
     const uint32_t code = threadIdx.x;
     const uint64_t sym = st.sym[code];
     const uint32_t sl = st.len[code];  // 0 for unused codes (and for 255, handled as escape by the scanner)
     for (uint32_t s = 0; s <= m; s++) {
         uint32_t cur = s;
         for (uint32_t k = 0; k < sl; k++) cur = delta[cur * 256 + uint32_t((sym >> (8 * k)) & 0xFF)];
-        // code 255 is the escape marker: never a transition, flagged non-zero so the scanner never skips it
+        // code 255 is the escape marker: never a transition (0xFF flag in the u8 table, state kept in the image)
         t[s * 512 + code] = code == 255u ? uint8_t(0xFF) : uint8_t(cur);
         t[s * 512 + 256 + code] = delta[s * 256 + code];
+        if (img) {
+            img[s * 512 + code] = uint16_t((code == 255u ? s : cur) * 1024u);
+            img[s * 512 + 256 + code] = uint16_t(uint32_t(delta[s * 256 + code]) * 1024u);
+        }
+    }
+    if (img) {
+        // escape-role table: index (entry role << 8 | marker mask) -> literal mask | exit role << 8
+        uint16_t* role = img + (m + 1) * 512;
+        for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) {
+            uint32_t lit = i >> 8, lmask = 0;
+            for (uint32_t q = 0; q < 8; q++) {
+                lmask |= lit << q;
+                lit = (lit ^ 1u) & (i >> q) & 1u;  // a marker in code position makes the next byte a literal
+            }
+            role[i] = uint16_t(lmask | (lit << 8));
+        }
     }
 }
 
@@ -483,14 +524,22 @@ __device__ __forceinline__ bool like_walk_global(const uint8_t* __restrict__ fss
     return sb == (nl << 9);
 }
 
+// Per-phase cycle checkpoints of k_str_pred: compiled in only with -DLC_KERNEL_TIMING (make TIMING=1); selected through
+// LC_DEBUG_FLAGS bits 16..19 and reported in place of the per-entry counts (scripts/abl.sh).
+#ifdef LC_KERNEL_TIMING
+#define LC_TM_DECL uint64_t tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define LC_TM(i, dep) tm[i] = __builtin_readcyclecounter() + ((dep) & 0)
+#else
+#define LC_TM_DECL
+#define LC_TM(i, dep)
+#endif
+
 typedef const __attribute__((address_space(3))) uint8_t* LdsBytePtr;
 typedef const __attribute__((address_space(3))) uint16_t* LdsU16Ptr;
 __device__ __forceinline__ uint32_t lds_u16(uint32_t addr) { return *reinterpret_cast<LdsU16Ptr>(addr); }
 __device__ __forceinline__ uint32_t lds_u8(uint32_t addr) { return *reinterpret_cast<LdsBytePtr>(addr); }
 
-constexpr uint32_t kMaxLdsNeedle = 15;    // LDS automaton: (nl + 1) KB per workgroup
 constexpr uint32_t kMaxByteTable = 4096;  // dictionary results as one byte per entry up to this dictionary size
-constexpr uint32_t kRoleTableBytes = 1024;
 
 // ---- the lane-parallel LIKE walker -------------------------------------------------------------------------------
 // The kernel is bound by instruction issue and by the length of dependent chains (a wave instruction costs four
@@ -551,70 +600,66 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     //              [per wave: dictionary results | signature candidate bitmap | candidate list / phase-C staging |
     //                         64 hit flags + head mask]
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    __shared__ uint8_t needle_lds[256];
+    const uint64_t rt_kernel = __builtin_amdgcn_s_memrealtime();
 
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     const uint32_t tid = threadIdx.x;
     const uint32_t nl = pred.needle_len;
     const bool lds_tbl = kSub && nl <= kMaxLdsNeedle;
-    const uint32_t tbl_bytes = lds_tbl ? (nl + 1u) * 1024u + kRoleTableBytes : 0u;
+    const uint32_t tbl_bytes = lds_tbl ? automaton_image_bytes(nl) : 0u;
+    constexpr uint32_t kNeedleLds = 256;
     constexpr uint32_t kFlagBytes = 80;
     const uint32_t per_wave = dres_bytes + cmask_bytes + kCandCap * 2u + kFlagBytes;
-    uint8_t* wbase = smem + tbl_bytes + wave * per_wave;
+    uint8_t* needle_lds = smem + tbl_bytes;
+    uint8_t* wbase = smem + tbl_bytes + kNeedleLds + wave * per_wave;
     uint32_t* dres = reinterpret_cast<uint32_t*>(wbase);  // bitmap words or bytes
     uint8_t* dresb = wbase;
     uint64_t* cmask = reinterpret_cast<uint64_t*>(wbase + dres_bytes);
     uint16_t* cand = reinterpret_cast<uint16_t*>(wbase + dres_bytes + cmask_bytes);
     uint8_t* hitflag = wbase + dres_bytes + cmask_bytes + kCandCap * 2u;
     uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
-    const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));  // LDS byte address of the automaton
+    // The automaton image holds absolute LDS addresses computed for a table at LDS address 0: this kernel has no
+    // static LDS, so its dynamic segment starts there.
+    const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
+    if (lds_tbl && row0 != 0) __builtin_trap();
     const uint32_t role_addr = row0 + (nl + 1u) * 1024u;
     const uint32_t dres_addr = uint32_t(reinterpret_cast<uintptr_t>(wbase));
 
-    const uint32_t entry = blockIdx.x * kWavesPerBlock + wave;
-    const uint64_t rt_start = __builtin_amdgcn_s_memrealtime();
     const uint32_t slot0 = L.uniform_slot >= 0 ? uint32_t(L.uniform_slot)
                                                : descs[min(blockIdx.x * kWavesPerBlock, L.n_entries - 1)].symtab_slot;
     if (lds_tbl) {
-        // u8 next-state table -> u16 row addresses, 8 entries per thread and iteration; the escape marker (0xFF in
-        // the code half) keeps the state
-        const GlobalPtr<uint2> src =
-            reinterpret_cast<GlobalPtr<uint2>>(as_global(pred.automata) + size_t(slot0) * pred.automaton_stride);
-        for (uint32_t i = tid; i < (nl + 1u) * 64u; i += kThreads) {
-            const uint32_t vx = src[i].x, vy = src[i].y;
-            const uint32_t self = row0 + (i >> 6) * 1024u;
-            uint32_t o[4];
-#pragma unroll
-            for (int h = 0; h < 4; h++) {
-                const uint32_t pair = h < 2 ? (vx >> (16 * h)) & 0xFFFFu : (vy >> (16 * (h - 2))) & 0xFFFFu;
-                const uint32_t b0 = pair & 0xFFu, b1 = pair >> 8;
-                const uint32_t t0 = b0 == 0xFFu ? self : row0 + b0 * 1024u;
-                const uint32_t t1 = b1 == 0xFFu ? self : row0 + b1 * 1024u;
-                o[h] = t0 | (t1 << 16);
-            }
-            reinterpret_cast<uint4*>(smem)[i] = make_uint4(o[0], o[1], o[2], o[3]);
-        }
-        // role table: index (entry role << 8 | marker mask) -> literal mask | exit role << 8
-        for (uint32_t i = tid; i < 512u; i += kThreads) {
-            uint32_t lit = i >> 8, lmask = 0;
-#pragma unroll
-            for (uint32_t q = 0; q < 8; q++) {
-                lmask |= lit << q;
-                lit = (lit ^ 1u) & (i >> q) & 1u;  // a marker in code position makes the next byte a literal
-            }
-            reinterpret_cast<uint16_t*>(smem + (nl + 1u) * 1024u)[i] = uint16_t(lmask | (lit << 8));
-        }
+        // verbatim copy of the image k_str_automata built for this symbol table
+        const GlobalPtr<u32x4> src = reinterpret_cast<GlobalPtr<u32x4>>(
+            as_global(pred.automata) + size_t(slot0) * pred.automaton_stride + automaton_u8_bytes(nl));
+        for (uint32_t i = tid; i < tbl_bytes / 16u; i += kThreads) reinterpret_cast<u32x4*>(smem)[i] = src[i];
     }
     // needle bytes: kernel argument (short needles) or the device copy; staged in LDS when they fit
-    const bool needle_in_lds = nl <= sizeof(needle_lds);
+    const bool needle_in_lds = !kSub && nl <= kNeedleLds;
     if (needle_in_lds)
         for (uint32_t i = tid; i < nl; i += kThreads)
             needle_lds[i] = nl <= uint32_t(kInlineNeedle) ? pred.needle_inline[i] : pred.needle[i];
     const uint8_t* np = needle_in_lds ? needle_lds : pred.needle;
     __syncthreads();
-    if (entry >= L.n_entries) return;
 
+    // Persistent waves: the workgroup's setup above is paid once; every wave then draws entries on its own (entries
+    // differ in cost, a static split leaves a long tail).  One hot counter would serialise ~16K far atomics (measured:
+    // 250 us), so the entries are cut into `work_groups` contiguous ranges, each with its own counter on its own cache
+    // line, shared by the few workgroups with the same blockIdx % work_groups.  The last wave of a group to finish
+    // zeroes the group's counters for the next launch.
+    const uint32_t wg_group = blockIdx.x % L.work_groups;
+    uint32_t* work = L.d_work + wg_group * 16u;
+    const uint32_t per_group = (L.n_entries + L.work_groups - 1u) / L.work_groups;
+    const uint32_t group_begin = wg_group * per_group;
+    const uint32_t group_end = min(L.n_entries, group_begin + per_group);
+    for (;;) {
+        uint32_t entry = 0;
+        if (lane == 0) entry = group_begin + atomicAdd(&work[0], 1u);
+        entry = uint32_t(__builtin_amdgcn_readfirstlane(int(entry)));
+        if (entry >= group_end) break;
+    const uint64_t rt_start = __builtin_amdgcn_s_memrealtime();
+    LC_TM_DECL;
+    LC_TM(0, 0);
     const StrDesc d = descs[entry];
     const DevSymtab& st = symtabs[d.symtab_slot];
     // shared LDS copy of the automaton when this entry uses the workgroup's symbol table, else the global one
@@ -635,7 +680,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 if (L.d_counts) L.d_counts[entry] = 0;
                 if (L.d_cand_bytes) L.d_cand_bytes[entry] = 0;
             }
-            return;
+            continue;
         }
     }
 
@@ -663,16 +708,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             }
         }
     }
-    // dictionary results start all false (bytes / bitmap words)
-    for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)
-        reinterpret_cast<uint4*>(wbase)[i] = make_uint4(0, 0, 0, 0);
+    // dictionary results start all false (bytes / bitmap words).  LIKE only writes them from phase B, and the row
+    // phase never reads them while no entry matched: they are cleared lazily, on the first match.
+    if (!kSub)
+        for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)
+            reinterpret_cast<uint4*>(wbase)[i] = make_uint4(0, 0, 0, 0);
     const uint32_t nsl = nl >= spl ? nl - spl : 0;  // needle suffix length after the shared prefix
     uint64_t nsuf7 = 0;                             // first min(7, nsl) suffix bytes, little endian
     if (!kSub && uniform_result < 0)
         for (uint32_t i = 0; i < 7 && i < nsl; i++) nsuf7 |= uint64_t(np[spl + i]) << (8 * i);
-    uint32_t needle_fp = 0;
-    if (kSub)
-        for (uint32_t i = 0; i < nl; i++) needle_fp |= 1u << (np[i] & 31);
+    const uint32_t needle_fp = pred.needle_fp;
     const bool prune = kSub && pred.use_fingerprints && d.fingerprints != nullptr;
     // bigram signature probe (needles of >= 2 bytes): AND of the needle's bit slices = candidate bitmap
     const bool use_sig = prune && d.signatures != nullptr && pred.n_sig_bits > 0 && !(pred.debug_flags & 8);
@@ -699,6 +744,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    LC_TM(1, 0);
 
     // Candidates are collected into the wave's LDS list by rounds (64 bitmap words, or KH x 64 entries); when the next
     // round might not fit, the list is walked first.  One loop, so phase B has exactly one call site and, for the
@@ -716,13 +762,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             const uint32_t w = (pos >> 6) + uint32_t(lane);
             uint64_t m = (uint32_t(lane) < round_words && w < nw) ? cmask[w] : 0;
             const uint32_t cnt = uint32_t(__popcll(m));
-            uint32_t incl = cnt;
-#pragma unroll
-            for (int o = 1; o < kWave; o <<= 1) {
-                const uint32_t t = __shfl_up(incl, o, kWave);
-                if (lane >= o) incl += t;
-            }
-            const uint32_t total = __shfl(incl, kWave - 1, kWave);
+            const uint32_t incl = wave_inclusive_sum(cnt);
+            const uint32_t total = read_lane(incl, kWave - 1);
             if (n_cand + total <= kCandCap) {
                 uint32_t o = n_cand + incl - cnt;
                 while (m) {
@@ -822,6 +863,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
 
         // ---- phase B: walk the candidate list ----
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        LC_TM(2, 0);
         const uint32_t n_walk = (pred.debug_flags & 1) ? 0u : n_cand;
         for (uint32_t jb = 0; jb < n_walk; jb += kWave) {
             const uint32_t j = jb + uint32_t(lane);
@@ -830,19 +872,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             uint32_t start = 0, stop = 0;
             if (cl) str_offset_pair(d, id, start, stop);
             if (L.d_cand_bytes && !prune) cand_bytes += stop - start;
+            LC_TM(3, start);
             bool res = false;
             if (kSub && tbl_in_lds) {
                 // lane-parallel walk: one lane per 8-byte word of every candidate (see above)
                 const uint32_t hitrow = row0 + nl * 1024u;
                 const uint32_t words = cl ? max(1u, (stop - start + 7u) >> 3) : 0u;
-                uint32_t incl = words;
-#pragma unroll
-                for (int o = 1; o < kWave; o <<= 1) {
-                    const uint32_t t = __shfl_up(incl, o, kWave);
-                    if (lane >= o) incl += t;
-                }
+                const uint32_t incl = wave_inclusive_sum(words);
                 const uint32_t off = incl - words;
-                const uint32_t total = __shfl(incl, kWave - 1, kWave);
+                const uint32_t total = read_lane(incl, kWave - 1);
                 hitflag[lane] = 0;
                 uint32_t carry_state = row0, carry_role = 0;
                 for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
@@ -866,14 +904,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     uint64_t w = 0;
                     if (rem) w = load_unaligned<uint64_t>(d.fsst + p);
                     const uint32_t lo = uint32_t(w), hi = uint32_t(w >> 32);
+                    LC_TM(4, lo);
                     const bool first = k == 0;  // first word of its value (a value continuing from the previous pass
                                                 // has k > 0 in lane 0 and takes the carried role / state)
                     // byte roles
                     const uint32_t mm = marker_mask(lo, hi);
                     uint32_t role_in = 0, rl = lds_u16(role_addr + 2u * mm);
                     for (;;) {
-                        uint32_t prev = __shfl_up(rl >> 8, 1, kWave);
-                        if (lane == 0) prev = carry_role;
+                        uint32_t prev = lane_shift_up1(rl >> 8, carry_role);
                         if (first) prev = 0;
                         const bool changed = prev != role_in;
                         if (__ballot(changed) == 0) break;
@@ -882,7 +920,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                             rl = lds_u16(role_addr + 2u * ((role_in << 8) | mm));
                         }
                     }
-                    carry_role = __shfl(rl >> 8, kWave - 1, kWave);
+                    carry_role = read_lane(rl >> 8, kWave - 1);
+                    LC_TM(5, carry_role);
                     uint32_t x[8];
 #pragma unroll
                     for (int q = 0; q < 8; q++) {
@@ -894,8 +933,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     uint32_t e = walk8(s_in, x, rem);
                     bool hit = e == hitrow;
                     for (;;) {
-                        uint32_t prev = __shfl_up(e, 1, kWave);
-                        if (lane == 0) prev = carry_state;
+                        uint32_t prev = lane_shift_up1(e, carry_state);
                         if (first || prev == hitrow) prev = row0;
                         const bool changed = prev != s_in;
                         if (__ballot(changed) == 0) break;
@@ -905,7 +943,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                             hit |= e == hitrow;
                         }
                     }
-                    carry_state = __shfl(e, kWave - 1, kWave);
+                    carry_state = read_lane(e, kWave - 1);
+                    LC_TM(6, carry_state);
                     if (carry_state == hitrow) carry_state = row0;
                     if (hit && live) hitflag[r] = 1;
                 }
@@ -918,7 +957,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 res = is_eq ? o == 0
                             : (op == LC_OP_LT ? o < 0 : op == LC_OP_LE ? o <= 0 : op == LC_OP_GT ? o > 0 : o >= 0);
             }
-            any_true |= __ballot(res);
+            const uint64_t res_mask = __ballot(res);
+            if (kSub && res_mask != 0 && any_true == 0) {
+                for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)
+                    reinterpret_cast<uint4*>(wbase)[i] = make_uint4(0, 0, 0, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            any_true |= res_mask;
             if (res) {
                 if (kBytes) dresb[id] = 1;
                 else atomicOr(&dres[id >> 5], 1u << (id & 31));
@@ -928,6 +973,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 
+    LC_TM(7, 0);
     // dictionary-level negation:
     //   NotContains inverts the dictionary results only when at least one fingerprint candidate existed
     //   (comparisons.rs:167-180, :644-648 — bit-exact with the reference); Ne inverts row values (:85-90).
@@ -948,7 +994,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const uint32_t n_rows = (pred.debug_flags & 2) ? 0u : d.n;
     const uint32_t key_max = dres_bytes * 8u - 1u;  // bitmap: keys under null slots may be garbage (clamped)
     uint32_t hit_count = 0;
-    constexpr int KC = 16;
+    constexpr int KC = 8;
     uint8_t* stage = reinterpret_cast<uint8_t*>(cand);
     static_assert(kCandCap * 2 >= KC * kWave, "phase C staging must fit in the candidate list");
     for (uint32_t pass = 0; pass < n_rows; pass += KC * kWave * 8) {
@@ -1014,12 +1060,31 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     if (L.d_counts) {
         uint64_t c = wave_sum_u64(uint64_t(hit_count));
         if (((pred.debug_flags >> 10) & 7u) == 7u)  // timing instrumentation (LC_DEBUG_FLAGS, scripts/occupancy.py)
-            c = ((rt_start & 0xFFFFu) << 16) | (__builtin_amdgcn_s_memrealtime() & 0xFFFFu);
+            c = ((((pred.debug_flags >> 14) & 1) ? rt_kernel : rt_start) & 0xFFFFu) << 16 | (__builtin_amdgcn_s_memrealtime() & 0xFFFFu);
+#ifdef LC_KERNEL_TIMING
+        LC_TM(8, 0);
+        const uint32_t tsel = (uint32_t(pred.debug_flags) >> 16) & 15u;  // cycles between checkpoints tsel-1 and tsel
+#pragma unroll
+        for (int i = 1; i <= 8; i++)
+            if (tsel == uint32_t(i)) c = tm[i] > tm[i - 1] && tm[i - 1] ? tm[i] - tm[i - 1] : 0;
+        if (tsel == 9) c = tm[8] - tm[0];
+#endif
         if (lane == 0) L.d_counts[entry] = uint32_t(c);
     }
     if (L.d_cand_bytes) {
         const uint64_t c = wave_sum_u64(uint64_t(cand_bytes));
         if (lane == 0) L.d_cand_bytes[entry] = uint32_t(c);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }  // entries
+    if (lane == 0) {
+        // workgroups of this group: blockIdx = wg_group, wg_group + work_groups, ...
+        const uint32_t group_waves = ((gridDim.x - wg_group + L.work_groups - 1u) / L.work_groups) * kWavesPerBlock;
+        if (atomicAdd(&work[1], 1u) == group_waves - 1u) {
+            // every wave has made its last draw (the one that told it to stop) before it counts itself here
+            __atomic_store_n(&work[0], 0u, __ATOMIC_RELAXED);
+            __atomic_store_n(&work[1], 0u, __ATOMIC_RELAXED);
+        }
     }
 }
 
@@ -1455,11 +1520,7 @@ __global__ __launch_bounds__(kThreads) void k_str_decode_rows_dyn(const StrDesc*
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
-hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
-                             hipStream_t stream) {
-    const uint64_t waves = uint64_t(L.n_entries) * L.blocks_per_entry;
-    if (waves == 0) return hipSuccess;
-    // persistent-style launch: enough workgroups to fill every CU at the kernel's occupancy, each wave strides over blocks
+static int device_cus() {
     static int n_cus = 0;
     if (n_cus == 0) {
         int dev = 0;
@@ -1467,6 +1528,15 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cus = prop.multiProcessorCount;
         if (n_cus <= 0) n_cus = 256;
     }
+    return n_cus;
+}
+
+hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
+                             hipStream_t stream) {
+    const uint64_t waves = uint64_t(L.n_entries) * L.blocks_per_entry;
+    if (waves == 0) return hipSuccess;
+    // persistent-style launch: enough workgroups to fill every CU at the kernel's occupancy, each wave strides over blocks
+    const int n_cus = device_cus();
     const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint64_t wgs_resident = uint64_t(n_cus) * (lane_log2 == 6 ? 4 : 8);
     const dim3 grid(uint32_t(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), block(kThreads);
@@ -1500,9 +1570,10 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     const uint32_t dres_bytes = bytes ? (dmax + 15u) & ~15u : (((dmax + 63u) / 64u) * 8u + 15u) & ~15u;
     const uint32_t cmask_bytes = sub ? (((dmax + 63u) / 64u) * 8u + 15u) & ~15u : 0u;
     const bool lds_tbl = sub && pred.needle_len <= kMaxLdsNeedle;
-    const size_t tbl_bytes = lds_tbl ? size_t(pred.needle_len + 1) * 1024 + kRoleTableBytes : 0;
-    const size_t dyn_lds = tbl_bytes + size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + kCandCap * 2 + 80);
-    const uint32_t grid = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
+    const size_t tbl_bytes = lds_tbl ? automaton_image_bytes(pred.needle_len) : 0;
+    const size_t dyn_lds = tbl_bytes + 256 + size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + kCandCap * 2 + 80);
+    // persistent launch: as many workgroups as fit on the device at once; the waves draw entries dynamically
+    const uint32_t wgs_needed = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
     void (*kern)(const StrDesc*, const DevSymtab*, StrPred, ScanLaunch, uint32_t, uint32_t) =
         bytes ? (sub ? k_str_pred<true, true> : k_str_pred<true, false>)
               : (sub ? k_str_pred<false, true> : k_str_pred<false, false>);
@@ -1512,7 +1583,22 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), dyn_lds, stream, d_descs, d_symtabs, pred, L, dres_bytes,
+    int wgs_per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void*>(kern), kThreads,
+                                                     dyn_lds) != hipSuccess || wgs_per_cu <= 0)
+        wgs_per_cu = 2;
+    static const char* env_k = std::getenv("LC_STR_WGS_PER_CU");  // tuning aid
+    if (env_k && std::atoi(env_k) > 0) wgs_per_cu = std::atoi(env_k);
+    // Measured (100M-row URL scan): one workgroup per four entries under the hardware dispatcher takes 51 us, the
+    // persistent grid 80 us: with every slot always occupied the waves run in phase and the kernel, which is bound by
+    // dependent LDS / cross-lane chains rather than by issue or bandwidth, loses the overlap between phases.
+    static const bool persistent = std::getenv("LC_STR_PERSISTENT") != nullptr;
+    const uint32_t grid = persistent ? std::min<uint32_t>(wgs_needed, uint32_t(device_cus()) * uint32_t(wgs_per_cu)) : wgs_needed;
+    ScanLaunch Lw = L;
+    static const char* env_g = std::getenv("LC_STR_WGS_PER_GROUP");  // tuning aid
+    const uint32_t wgs_per_group = env_g && std::atoi(env_g) > 0 ? uint32_t(std::atoi(env_g)) : (persistent ? 4u : 1u);
+    Lw.work_groups = std::max<uint32_t>(1u, std::min<uint32_t>(kWorkGroupsMax, grid / wgs_per_group));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), dyn_lds, stream, d_descs, d_symtabs, pred, Lw, dres_bytes,
                        cmask_bytes);
     return hipGetLastError();
 }

@@ -15,7 +15,17 @@
 
 namespace lc {
 
-constexpr int kMaxNeedleAutomaton = 63;  // KMP automaton states must fit a u8 table staged in LDS
+constexpr int kMaxNeedleAutomaton = 63;  // KMP automaton states must fit a u8 table
+constexpr uint32_t kMaxLdsNeedle = 15;   // needles up to this length also get an LDS image of the automaton
+constexpr uint32_t kRoleTableBytes = 1024;
+// Per symbol table, k_str_automata emits: the u8 next-state table ((m+1) x 512 bytes) and, for short needles, the
+// image the scan kernel copies verbatim to LDS address 0: (m+1) rows x 512 u16 entries holding the LDS byte address of
+// the next state's row, followed by the 512-entry escape-role table.
+__host__ __device__ inline uint32_t automaton_u8_bytes(uint32_t m) { return (m + 1u) * 512u; }
+__host__ __device__ inline uint32_t automaton_image_bytes(uint32_t m) {
+    return m <= kMaxLdsNeedle ? (m + 1u) * 1024u + kRoleTableBytes : 0u;
+}
+__host__ __device__ inline uint32_t automaton_stride(uint32_t m) { return automaton_u8_bytes(m) + automaton_image_bytes(m); }
 constexpr int kMaxNeedleBytes = 4096;
 
 enum FixedKind : uint8_t { kKindInt = 0, kKindDecimal = 1, kKindF32 = 2, kKindF64 = 3 };
@@ -94,14 +104,17 @@ struct StrPred {
     uint32_t needle_len;
     int32_t use_fingerprints;  // LIKE: prune with fingerprints (and apply the reference's candidate quirk)
     const uint8_t* needle;     // device copy when needle_len > kInlineNeedle (padded by 8 bytes)
-    const uint8_t* automata;   // mode 1: per symbol-table-slot transition tables, (m+1)*512 bytes each
+    const uint8_t* automata;   // mode 1: per symbol-table slot, automaton_stride(m) bytes (see above)
     uint32_t automaton_stride;
     int32_t const_value;       // mode 2: Literal(Boolean)
-    int32_t debug_flags;       // profiling only (env LC_DEBUG_FLAGS): 1 skip phase B, 2 skip phase C, 4 skip phase A
+    int32_t debug_flags;       // profiling only (env LC_DEBUG_FLAGS): 1 skip phase B, 2 skip phase C, 8 no signatures
+    uint32_t needle_fp;        // LIKE: 32-bucket fingerprint of the needle (fingerprint.rs:33-35)
     uint32_t n_sig_bits;       // LIKE: distinct bigram-signature bits of the needle that are probed (<= kMaxSigProbe)
     uint8_t sig_bits[kMaxSigProbe];
     uint8_t needle_inline[kInlineNeedle];
 };
+
+constexpr uint32_t kWorkGroupsMax = 4096;
 
 struct ScanLaunch {
     uint32_t n_entries;
@@ -113,6 +126,10 @@ struct ScanLaunch {
     uint32_t* d_cand_bytes;  // optional (byte views): per entry, compressed bytes of the candidates that were walked
     uint32_t max_dict_len;   // byte views: largest dictionary in the scan (sizes the LDS result bitmap)
     int32_t uniform_slot;    // byte views: symbol-table slot shared by every entry of the scan, or -1
+    uint32_t* d_work;        // byte views: kWorkGroupsMax x {next, finished waves} at a 64-byte stride, zero between
+                             // launches (self-resetting)
+    uint32_t work_groups;    // byte views: number of counter groups used by this launch (set by the launcher)
+    uint32_t pad_;
 };
 
 hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,

@@ -97,8 +97,12 @@ struct lc_scan {
     // LIKE scratch
     uint8_t* d_automata = nullptr;
     size_t automata_cap = 0;
+    std::vector<uint8_t> automata_needle;  // the automata in d_automata were built for this needle ...
+    size_t automata_symtabs = 0;           // ... over this many symbol tables (0: nothing cached)
     uint8_t* d_needle = nullptr;
     size_t needle_cap = 0;
+    uint32_t* d_work = nullptr;  // kWorkGroupsMax x {next entry, finished waves} (64-byte stride): dynamic entry
+                                 // assignment of the persistent byte-view scan kernel
     std::mutex mu;
 };
 
@@ -417,6 +421,7 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
         out->p.mode = 1;
         out->p.use_fingerprints = 1;
         out->needle.assign(inner, inner + il);
+        for (size_t k = 0; k < il; k++) out->p.needle_fp |= 1u << (inner[k] & 31);
         for (size_t k = 0; k + 1 < il && out->p.n_sig_bits < uint32_t(kMaxSigProbe); k++) {
             const uint8_t bit = uint8_t(bigram_bit(inner[k], inner[k + 1]));
             bool dup = false;
@@ -711,6 +716,8 @@ lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_
     LC_HIP(hipMemcpy(s->d_descs, host.data(), host.size(), hipMemcpyHostToDevice));
     LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_seg_offsets), (n + 1) * 8));
     LC_HIP(hipMemcpy(s->d_seg_offsets, s->seg_offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work), kWorkGroupsMax * 64));
+    LC_HIP(hipMemset(s->d_work, 0, kWorkGroupsMax * 64));
     const lc_status st = sync_symtabs(ctx);
     if (st != LC_OK) return st;
     *out = s.release();
@@ -725,6 +732,7 @@ void lc_scan_destroy(lc_scan* s) {
     if (s->d_seg_offsets) (void)hipFree(s->d_seg_offsets);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
+    if (s->d_work) (void)hipFree(s->d_work);
     delete s;
 }
 
@@ -747,6 +755,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     L.d_counts = static_cast<uint32_t*>(d_counts_out);
     L.d_cand_bytes = static_cast<uint32_t*>(d_cand_bytes);
     L.uniform_slot = -1;
+    L.d_work = s->d_work;
     for (const Entry& e : s->meta) L.max_dict_len = std::max(L.max_dict_len, e.dict_len);
     if (s->is_str && !s->meta.empty()) {
         L.uniform_slot = int32_t(s->meta[0].sd.symtab_slot);
@@ -765,7 +774,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     if (st != LC_OK) return st;
     std::lock_guard<std::mutex> g(s->mu);
     if (sp.p.mode == 1) {
-        const uint32_t stride = (sp.p.needle_len + 1) * 512;
+        const uint32_t stride = automaton_stride(sp.p.needle_len);
         const size_t nst = ctx->d_symtabs_uploaded;
         const size_t need = size_t(stride) * std::max<size_t>(nst, 1);
         if (need > s->automata_cap) {
@@ -773,9 +782,16 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
             if (s->d_automata) LC_HIP(hipFree(s->d_automata));
             LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_automata), need));
             s->automata_cap = need;
+            s->automata_symtabs = 0;
         }
-        LC_HIP(launch_str_automata(ctx->d_symtabs, uint32_t(nst), sp.needle.data(), sp.p.needle_len, s->d_automata,
-                                   stream));
+        // a query evaluates one pattern over and over: the folded automata are rebuilt only when the needle or the
+        // set of symbol tables changed (stream order keeps earlier launches valid)
+        if (s->automata_symtabs != nst || s->automata_needle != sp.needle) {
+            LC_HIP(launch_str_automata(ctx->d_symtabs, uint32_t(nst), sp.needle.data(), sp.p.needle_len,
+                                       s->d_automata, stream));
+            s->automata_needle = sp.needle;
+            s->automata_symtabs = nst;
+        }
         sp.p.automata = s->d_automata;
         sp.p.automaton_stride = stride;
     } else if (sp.p.mode == 0 && sp.needle.size() > size_t(kInlineNeedle)) {

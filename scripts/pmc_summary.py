@@ -14,4 +14,5 @@ for k, cs in sorted(acc.items()):
         continue
     print(k)
     for c, v in sorted(cs.items()):
-        print("   %-24s mean/launch %.4g  (n=%d)" % (c, sum(v) / len(v), len(v)))
+        sv = sorted(v)
+        print("   %-24s median/launch %.5g  mean %.5g  min %.5g  max %.5g  (n=%d)" % (c, sv[len(sv) // 2], sum(v) / len(v), sv[0], sv[-1], len(v)))
