@@ -143,6 +143,21 @@ def _make_strings(rng, n, n_unique, with_nulls):
     return out
 
 
+@pytest.fixture()
+def gpu_cache_no_signatures(product_lib, monkeypatch):
+    """A context that stages byte views WITHOUT the bigram signature index (LC_NO_SIGNATURES is read when the context
+    is created): the kernel then runs the reference's fingerprint filter."""
+    monkeypatch.setenv("LC_NO_SIGNATURES", "1")
+    cache = lc.LiquidCacheBuilder.new().build()
+    yield cache
+    cache.close()
+
+
+@pytest.mark.parametrize("fingerprints", [True, False])
+def test_string_predicates_without_signature_index(gpu_cache_no_signatures, oracle, fingerprints):
+    test_string_predicates(gpu_cache_no_signatures, oracle, fingerprints)
+
+
 @pytest.mark.parametrize("fingerprints", [True, False])
 def test_string_predicates(gpu_cache, oracle, fingerprints):
     lo = oracle
