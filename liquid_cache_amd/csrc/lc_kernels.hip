@@ -144,6 +144,83 @@ __device__ __forceinline__ void fl_row_lane(uint32_t i, uint32_t* row, uint32_t*
     *row = o * 8u + s;
 }
 
+// ALP decode constants (float_array.rs:127-224); evaluation order (i as f) * F10[f] * IF10[e] without contraction
+__device__ const float kF10f[11] = {1.0f, 10.0f, 100.0f, 1000.0f, 10000.0f, 100000.0f, 1000000.0f, 10000000.0f,
+                                    100000000.0f, 1000000000.0f, 10000000000.0f};
+__device__ const float kIF10f[11] = {1.0f, 0.1f, 0.01f, 0.001f, 0.0001f, 0.00001f, 0.000001f, 0.0000001f,
+                                     0.00000001f, 0.000000001f, 0.0000000001f};
+__device__ const double kF10d[24] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                     1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22, 1e23};
+__device__ const double kIF10d[24] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001, 0.00000001,
+                                      0.000000001, 0.0000000001, 0.00000000001, 0.000000000001, 0.0000000000001,
+                                      0.00000000000001, 0.000000000000001, 0.0000000000000001, 0.00000000000000001,
+                                      0.000000000000000001, 0.0000000000000000001, 0.00000000000000000001,
+                                      0.000000000000000000001, 0.0000000000000000000001, 0.00000000000000000000001};
+
+__device__ __forceinline__ float alp_decode(int32_t i, uint32_t e, uint32_t f) {
+    return __fmul_rn(__fmul_rn(float(i), kF10f[f]), kIF10f[e]);
+}
+__device__ __forceinline__ double alp_decode(int64_t i, uint32_t e, uint32_t f) {
+    return __dmul_rn(__dmul_rn(double(i), kF10d[f]), kIF10d[e]);
+}
+
+// ---- ALP float predicates in the packed domain -------------------------------------------------------------------
+// decode(i) = (i as float) * F10[f] * IF10[e] is monotone non-decreasing in i (int->float conversion and the two
+// correctly rounded multiplications by positive constants are), so `decode(ref + u) OP lit` under Arrow's totalOrder
+// comparison is a RANGE test on the packed value u.  The two boundaries (first u with decode >= lit, first u with
+// decode > lit) are found per entry by a 64-ary search: the 64 lanes probe 63 points per round, 6 bits of the answer
+// per round.  Rows stored as ALP exceptions hold an arbitrary packed value; k_alp_patch_fix re-evaluates them.
+template <typename F> struct FloatBits;
+template <> struct FloatBits<float> {
+    typedef int32_t I;
+    // totalOrder key: sign-magnitude -> two's complement order
+    static __device__ __forceinline__ int32_t key(float v) { int32_t b = __float_as_int(v); return b ^ int32_t(uint32_t(b >> 31) >> 1); }
+    static __device__ __forceinline__ float from_bits(uint64_t bits) { return __uint_as_float(uint32_t(bits)); }
+};
+template <> struct FloatBits<double> {
+    typedef int64_t I;
+    static __device__ __forceinline__ int64_t key(double v) { int64_t b = __double_as_longlong(v); return b ^ int64_t(uint64_t(b >> 63) >> 1); }
+    static __device__ __forceinline__ double from_bits(uint64_t bits) { return __longlong_as_double((long long)bits); }
+};
+
+// number of u in [0, umax] whose decoded value compares BELOW the literal (strict: key < litkey, else key <= litkey);
+// `all` is set when every u does (the count would be umax + 1, which may not fit U)
+template <typename U, typename F, bool kStrict>
+__device__ __forceinline__ U alp_count_below(const FixedDesc& d, typename FloatBits<F>::I litkey, uint64_t umax, int lane,
+                                             bool* all) {
+    typedef typename FloatBits<F>::I I;
+    auto below = [&](uint64_t u) {
+        const I iv = I(d.reference + u);  // wrapping add, like the decoder
+        const I k = FloatBits<F>::key(alp_decode(iv, d.alp_e, d.alp_f));
+        return kStrict ? k < litkey : k <= litkey;
+    };
+    *all = false;
+    if (!below(0)) return 0;
+    // invariant: below(base) holds; the last `below` index lies in [base, base + 2^(s+6) - 1]
+    uint64_t base = 0;
+    const int rounds = (int(d.W) + 5) / 6;
+    for (int s = 6 * (rounds - 1); s >= 0; s -= 6) {
+        const uint64_t j = uint64_t(lane) + 1;  // lane 63 (j = 64) does not probe
+        const uint64_t step = j << s;
+        const bool overflow = (s > 0 && (j >> (64 - s)) != 0) || base + step < base;
+        const uint64_t p = base + step;
+        const bool ok = lane < 63 && !overflow && p <= umax && below(p);
+        const uint32_t c = uint32_t(__popcll(__ballot(ok)));  // monotone: the true lanes are a prefix
+        base += uint64_t(c) << s;
+    }
+    if (base == umax) *all = true;
+    return U(base + 1);  // count = last index + 1 (wraps to 0 only together with *all)
+}
+
+template <typename U, typename F>
+__device__ __forceinline__ void alp_bounds(const FixedDesc& d, uint64_t lit_bits, int lane, U* n_lt, bool* all_lt, U* n_le,
+                                           bool* all_le) {
+    const uint64_t umax = d.W >= 64 ? ~uint64_t(0) : ((uint64_t(1) << d.W) - 1);
+    const typename FloatBits<F>::I litkey = FloatBits<F>::key(FloatBits<F>::from_bits(lit_bits));
+    *n_lt = alp_count_below<U, F, true>(d, litkey, umax, lane, all_lt);
+    *n_le = alp_count_below<U, F, false>(d, litkey, umax, lane, all_le);
+}
+
 // Uniform (per block) form of the predicate in the packed domain: hit = ((u - lo) <= span) != negate, or a constant.
 template <typename U>
 struct PackedRange {
@@ -180,6 +257,41 @@ __device__ __forceinline__ PackedRange<U> packed_range(const FixedDesc& d, const
         case LC_OP_LE: r.lo = 0; r.span = U(dlit); break;
         case LC_OP_GT: if (dlit == umax) r.constant = 0; else { r.lo = U(dlit + 1); r.span = U(umax - (dlit + 1)); } break;
         default: r.lo = U(dlit); r.span = U(umax - dlit); break;  // GE
+    }
+    return r;
+}
+
+// ALP entries: counts of packed values below / not above the literal -> the same range form
+template <typename U>
+__device__ __forceinline__ PackedRange<U> packed_range_alp(const FixedDesc& d, const FixedPred& pred, int lane) {
+    PackedRange<U> r{0, 0, false, -1};
+    const uint64_t umax = d.W >= 64 ? ~uint64_t(0) : ((uint64_t(1) << d.W) - 1);
+    U n_lt = 0, n_le = 0;  // #u with decode < lit, #u with decode <= lit
+    bool all_lt = false, all_le = false;
+    if constexpr (sizeof(U) == 4) alp_bounds<U, float>(d, pred.lit, lane, &n_lt, &all_lt, &n_le, &all_le);
+    else if constexpr (sizeof(U) == 8) alp_bounds<U, double>(d, pred.lit, lane, &n_lt, &all_lt, &n_le, &all_le);
+    auto from_count = [&](U n, bool all, bool want_below) {
+        // rows with u < n (want_below) or u >= n
+        if (all) { r.constant = want_below ? 1 : 0; return; }
+        if (n == 0) { r.constant = want_below ? 0 : 1; return; }
+        if (want_below) { r.lo = 0; r.span = U(n - 1); }
+        else { r.lo = n; r.span = U(U(umax) - n); }
+    };
+    switch (pred.op) {
+        case LC_OP_LT: from_count(n_lt, all_lt, true); break;
+        case LC_OP_LE: from_count(n_le, all_le, true); break;
+        case LC_OP_GE: from_count(n_lt, all_lt, false); break;
+        case LC_OP_GT: from_count(n_le, all_le, false); break;
+        default: {  // EQ / NE: n_lt <= u < n_le
+            const bool empty = !all_le && !all_lt ? n_le == n_lt : all_lt;
+            if (empty) { r.constant = pred.op == LC_OP_EQ ? 0 : 1; break; }
+            r.lo = all_lt ? U(0) : n_lt;
+            const U hi = all_le ? U(umax) : U(n_le - 1);
+            r.span = U(hi - r.lo);
+            r.negate = pred.op == LC_OP_NE;
+            if (r.lo == 0 && hi == U(umax)) { r.constant = pred.op == LC_OP_EQ ? 1 : 0; r.negate = false; }
+            break;
+        }
     }
     return r;
 }
@@ -252,7 +364,8 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
       const FixedDesc d = descs[entry];  // wave-uniform address: scalar loads
       const uint32_t len = d.len;
       const uint32_t W = d.W;
-      const PackedRange<U> pr = packed_range<U>(d, pred);
+      const PackedRange<U> pr = (d.kind == kKindF32 || d.kind == kKindF64) ? packed_range_alp<U>(d, pred, lane)
+                                                                           : packed_range<U>(d, pred);
       uint32_t entry_count = 0;
       for (uint32_t blk = 0, row0 = 0; row0 < len; blk++, row0 += 1024u) {
         const uint32_t rows = min(1024u, len - row0);
@@ -318,6 +431,50 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
           const uint64_t c = wave_sum_u64(uint64_t(entry_count));
           if (lane == 0) L.d_counts[entry] = uint32_t(c);
       }
+    }
+}
+
+// ALP exceptions: re-evaluate the rows whose value lives in the patch list (their packed slot holds a filler).
+// Runs after k_fixed_pred on the same stream; one wave per entry, one lane per patch.
+template <typename F>
+__global__ __launch_bounds__(kThreads) void k_alp_patch_fix(const FixedDesc* __restrict__ descs, FixedPred pred, ScanLaunch L) {
+    typedef typename FloatBits<F>::I I;
+    const int lane = lane_id();
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    const I litkey = FloatBits<F>::key(FloatBits<F>::from_bits(pred.lit));
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < L.n_entries; entry += total_waves) {
+        const FixedDesc d = descs[entry];
+        if (d.patch_len == 0 || d.W == 0) continue;
+        int delta = 0;
+        for (uint32_t k = uint32_t(lane); k < d.patch_len; k += kWave) {
+            const uint64_t row = d.patch_idx[k];
+            if (row >= d.len) continue;
+            const I key = FloatBits<F>::key(reinterpret_cast<const F*>(d.patch_val)[k]);
+            bool want;
+            switch (pred.op) {
+                case LC_OP_EQ: want = key == litkey; break;
+                case LC_OP_NE: want = key != litkey; break;
+                case LC_OP_LT: want = key < litkey; break;
+                case LC_OP_LE: want = key <= litkey; break;
+                case LC_OP_GT: want = key > litkey; break;
+                default: want = key >= litkey; break;
+            }
+            const uint64_t word = d.mask_word_off + (row >> 6), bit = uint64_t(1) << (row & 63);
+            bool active = d.validity ? ((d.validity[row >> 6] >> (row & 63)) & 1) != 0 : true;
+            if (L.d_selection) active = active && (L.d_selection[word] & bit) != 0;
+            want = want && active;
+            const bool have = (L.d_hit[word] & bit) != 0;
+            if (want != have) {
+                atomicXor(reinterpret_cast<unsigned long long*>(&L.d_hit[word]), (unsigned long long)bit);
+                delta += want ? 1 : -1;
+            }
+        }
+        if (L.d_counts) {
+            int64_t t = delta;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, kWave);
+            if (lane == 0 && t != 0) L.d_counts[entry] = uint32_t(int64_t(L.d_counts[entry]) + t);
+        }
     }
 }
 
@@ -1264,25 +1421,6 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restr
     }
 }
 
-// ALP decode constants (float_array.rs:127-224); evaluation order (i as f) * F10[f] * IF10[e] without contraction
-__device__ const float kF10f[11] = {1.0f, 10.0f, 100.0f, 1000.0f, 10000.0f, 100000.0f, 1000000.0f, 10000000.0f,
-                                    100000000.0f, 1000000000.0f, 10000000000.0f};
-__device__ const float kIF10f[11] = {1.0f, 0.1f, 0.01f, 0.001f, 0.0001f, 0.00001f, 0.000001f, 0.0000001f,
-                                     0.00000001f, 0.000000001f, 0.0000000001f};
-__device__ const double kF10d[24] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
-                                     1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22, 1e23};
-__device__ const double kIF10d[24] = {1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001, 0.00000001,
-                                      0.000000001, 0.0000000001, 0.00000000001, 0.000000000001, 0.0000000000001,
-                                      0.00000000000001, 0.000000000000001, 0.0000000000000001, 0.00000000000000001,
-                                      0.000000000000000001, 0.0000000000000000001, 0.00000000000000000001,
-                                      0.000000000000000000001, 0.0000000000000000000001, 0.00000000000000000000001};
-
-__device__ __forceinline__ float alp_decode(int32_t i, uint32_t e, uint32_t f) {
-    return __fmul_rn(__fmul_rn(float(i), kF10f[f]), kIF10f[e]);
-}
-__device__ __forceinline__ double alp_decode(int64_t i, uint32_t e, uint32_t f) {
-    return __dmul_rn(__dmul_rn(double(i), kF10d[f]), kIF10d[e]);
-}
 
 template <typename U>
 __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __restrict__ descs, ScanLaunch L,
@@ -1547,6 +1685,17 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
         case 6: hipLaunchKernelGGL(k_fixed_pred<uint64_t>, grid, block, 0, stream, d_descs, pred, L); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
+                                hipStream_t stream) {
+    if (L.n_entries == 0) return hipSuccess;
+    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8))), block(kThreads);
+    if (lane_log2 == 5) hipLaunchKernelGGL(k_alp_patch_fix<float>, grid, block, 0, stream, d_descs, pred, L);
+    else if (lane_log2 == 6) hipLaunchKernelGGL(k_alp_patch_fix<double>, grid, block, 0, stream, d_descs, pred, L);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -134,6 +134,8 @@ struct ScanLaunch {
 
 hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
                              hipStream_t stream);
+hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
+                                hipStream_t stream);
 hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, const uint8_t* needle,
                                uint32_t needle_len, uint8_t* d_automata, hipStream_t stream);
 hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, const StrPred& pred,

@@ -364,9 +364,21 @@ lc_status make_fixed_pred(const Entry& e, const lc_predicate* p, FixedPred* out)
     *out = FixedPred{};
     out->op = p->op;
     if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->pad = uint32_t(std::atoi(dbg));  // profiling only
-    if (e.fd.kind == kKindF32 || e.fd.kind == kKindF64)
-        return fail(LC_UNSUPPORTED, "float predicates run on the reference CPU path in this build");
     if (!p->lit) return fail(LC_ERR_INVALID, "literal is null");
+    if (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) {
+        // the literal arrives in the column's own type (DataFusion casts it); its bits travel to the kernel, which
+        // compares in Arrow's totalOrder
+        if (e.fd.kind == kKindF32 && p->lit_tag == LC_LIT_F32 && p->lit_len == 4) {
+            uint32_t b;
+            std::memcpy(&b, p->lit, 4);
+            out->lit = b;
+        } else if (e.fd.kind == kKindF64 && p->lit_tag == LC_LIT_F64 && p->lit_len == 8) {
+            std::memcpy(&out->lit, p->lit, 8);
+        } else {
+            return fail(LC_ERR_INVALID, "float predicate needs a literal of the column's float type");
+        }
+        return LC_OK;
+    }
     if (e.fd.kind == kKindDecimal) {
         __int128 v;
         if (p->lit_tag == LC_LIT_I128 && p->lit_len == 16) std::memcpy(&v, p->lit, 16);
@@ -767,6 +779,10 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         const lc_status st = make_fixed_pred(s->meta[0], pred, &fp);
         if (st != LC_OK) return st;
         LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, L, stream));
+        bool any_patch = false;
+        for (const Entry& e : s->meta) any_patch |= (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) && e.fd.patch_len > 0;
+        if (any_patch)
+            LC_HIP(launch_alp_patch_fix(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, L, stream));
         return LC_OK;
     }
     StrPredHost sp;

@@ -125,6 +125,42 @@ def test_decimal_predicates(gpu_cache, oracle):
             assert gv.tolist() == (want.values & want.validity).tolist(), (op, lit)
 
 
+@pytest.mark.parametrize("name,dtype,np_dtype", [("float32", pa.float32(), np.float32), ("float64", pa.float64(), np.float64)])
+def test_float_predicates_alp(gpu_cache, oracle, name, dtype, np_dtype):
+    """ALP float entries: the device compares in the packed domain (decode is monotone) and re-evaluates the exception
+    rows; the oracle decodes the same Liquid bytes and compares like Arrow (totalOrder).  Bit-exact."""
+    lo = oracle
+    rng = np.random.default_rng(1234)
+    eid = 0
+    cases = []
+    for n in (8192, 3001, 9):
+        prices = (rng.integers(-50000, 50000, size=n) / 100.0).astype(np_dtype)        # 2 decimals: W ~ 17
+        prices[rng.random(n) < 0.03] = np_dtype(np.pi)                                  # exceptions
+        if n > 8:
+            prices[1], prices[2], prices[3], prices[4] = np.nan, np.inf, -np.inf, -0.0
+        cases.append((prices, rng.random(n) < 0.9))
+        small = rng.integers(0, 8, size=n).astype(np_dtype)                             # tiny W, no exceptions
+        cases.append((small, None))
+        big = (rng.integers(-2**40, 2**40, size=n) * 1000.0).astype(np_dtype) if np_dtype == np.float64 else \
+            (rng.integers(-2**22, 2**22, size=n) * 4.0).astype(np_dtype)               # wide W
+        cases.append((big, rng.random(n) < 0.5))
+        const = np.full(n, np_dtype(7.25))                                              # W = 0 region
+        cases.append((const, None))
+    for vals, valid in cases:
+        n = len(vals)
+        liquid = lo.encode_primitive(lo.PHYS[name], vals, valid)
+        eid += 1
+        gpu_cache.stage([eid], [liquid], data_types=[dtype])
+        finite = vals[np.isfinite(vals)]
+        lits = [float(finite[0]), float(finite[-1]), float(np.nextafter(finite[0], np_dtype(np.inf))),
+                float(np.nextafter(finite[0], np_dtype(-np.inf))), float(np.median(finite)), 0.0, -0.0, float(np.pi),
+                float("inf"), float("-inf"), float("nan"), 1e30, -1e30, float(np_dtype(np.pi))]
+        for op in OPS:
+            for lit in lits:
+                sel = (rng.random(n) < rng.choice([0.05, 0.5])) if rng.integers(2) else None
+                _check_pred(gpu_cache, lo, eid, liquid, op, lit, dtype, sel)
+
+
 def _make_strings(rng, n, n_unique, with_nulls):
     hosts = ["google", "yandex", "mail", "goo", "gle", "oogle", "googl", "example", "ya", "g"]
     pool = []
