@@ -199,6 +199,20 @@ LC_API lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t
 LC_API lc_status lc_get_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection,
                                        struct ArrowArray* out_array, struct ArrowSchema* out_schema);
 
+/* cache.get(&entry_id).with_expression_hint(CacheExpression::extract_date32(field)).with_selection(&sel).read()
+ * (builders.rs:242-266 -> core.rs:725-745 try_read_squeezed_date32_array): for Date32 / Timestamp entries, the
+ * selected rows with only `field` preserved — SqueezedDate32Array's lossy reconstruction
+ * (squeezed_date32_array.rs:267-359: Year -> (y,1,1), Month -> (1970,m,1), Day -> (1970,1,d), DayOfWeek -> 1970-01-04
+ * + dow; timestamps at midnight UTC of that date, days = value.div_euclid(ticks_per_day) :406-414), in the entry's
+ * original Arrow type.  LC_UNSUPPORTED for other types. */
+#define LC_DATE_YEAR 0
+#define LC_DATE_MONTH 1
+#define LC_DATE_DAY 2
+#define LC_DATE_DAY_OF_WEEK 3
+LC_API lc_status lc_get_date_part_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection,
+                                                 int32_t field, struct ArrowArray* out_array,
+                                                 struct ArrowSchema* out_schema);
+
 /* boolean_buffer_and_then(left, right) (src/datafusion/src/utils.rs:62-83): `left` has left_bits bits of which
  * right_bits are set; out (ceil(left_bits/8) bytes) keeps the set bits of `left` whose `right` bit is 1. */
 LC_API lc_status lc_mask_and_then(lc_ctx* ctx, const uint8_t* left, uint64_t left_bits, const uint8_t* right,
@@ -234,6 +248,12 @@ LC_API lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
  * exclusive prefix sum of per-entry selected counts.  Asynchronous on `stream`. */
 LC_API lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_values_out,
                                       uint64_t values_capacity_bytes, void* d_row_offsets, void* stream);
+
+/* ExtractDate32 over gathered values of a Date32 / Timestamp scan: replaces `n_values` decoded values in d_values
+ * (as written by lc_scan_gather_fixed) in place by their lossy date-part reconstruction (see
+ * lc_get_date_part_with_selection).  Asynchronous on `stream`. */
+LC_API lc_status lc_scan_date_part(lc_ctx* ctx, lc_scan* scan, void* d_values, uint64_t n_values, int32_t field,
+                                   void* stream);
 
 /* Convenience for hosts without their own HIP runtime binding. */
 LC_API lc_status lc_device_alloc(lc_ctx* ctx, uint64_t bytes, void** out_dptr);

@@ -65,6 +65,22 @@ class CacheExpression:
     def substring_search() -> int:
         return N.HINT_SUBSTRING_SEARCH
 
+    @staticmethod
+    def extract_date32(field) -> "ExtractDate32":
+        """CacheExpression::extract_date32(Date32Field) (cache/expressions.rs:82-84)."""
+        return ExtractDate32(field)
+
+
+class Date32Field:
+    """liquid_array::Date32Field (squeezed_date32_array.rs:26-38)."""
+    YEAR, MONTH, DAY, DAY_OF_WEEK = 0, 1, 2, 3
+    _NAMES = {"year": 0, "month": 1, "day": 2, "dow": 3, "dayofweek": 3, "day_of_week": 3}
+
+
+class ExtractDate32:
+    def __init__(self, field):
+        self.field = Date32Field._NAMES[field.lower()] if isinstance(field, str) else int(field)
+
 
 _OPS = {"=": N.OP_EQ, "==": N.OP_EQ, "eq": N.OP_EQ, "!=": N.OP_NE, "<>": N.OP_NE, "ne": N.OP_NE, "noteq": N.OP_NE,
         "<": N.OP_LT, "lt": N.OP_LT, "<=": N.OP_LE, "le": N.OP_LE, "lteq": N.OP_LE, ">": N.OP_GT, "gt": N.OP_GT,
@@ -211,17 +227,20 @@ class LiquidCacheBuilder:
 
 class _Get:
     def __init__(self, cache: "LiquidCache", entry_id: int):
-        self._cache, self._id, self._sel = cache, entry_id, None
+        self._cache, self._id, self._sel, self._hint = cache, entry_id, None, None
 
     def with_selection(self, selection) -> "_Get":
         self._sel = selection
         return self
 
-    def with_expression_hint(self, _hint) -> "_Get":
+    def with_expression_hint(self, hint) -> "_Get":
+        """builders.rs:242-246; only ExtractDate32 changes what a read returns (core.rs:725-745)."""
+        self._hint = hint
         return self
 
     def read(self) -> Optional[pa.Array]:
-        return self._cache._read_arrow_array(self._id, self._sel)
+        field = self._hint.field if isinstance(self._hint, ExtractDate32) else None
+        return self._cache._read_arrow_array(self._id, self._sel, date_field=field)
 
 
 class _EvaluatePredicate:
@@ -391,15 +410,18 @@ class LiquidCache:
             return pa.array(v, type=pa.bool_(), mask=~valid)
         return pa.array(v, type=pa.bool_())
 
-    def _read_arrow_array(self, entry_id: int, selection) -> Optional[pa.Array]:
+    def _read_arrow_array(self, entry_id: int, selection, date_field: Optional[int] = None) -> Optional[pa.Array]:
         info = self.entry_info(entry_id)
         if info is None:
             return None
         sel = _selection_bytes(selection, info.len) if selection is not None else None
         c_arr, c_schema = N.ArrowArray(), N.ArrowSchema()
-        st = self._lib.lc_get_with_selection(self._ctx, entry_id,
-                                             sel.ctypes.data_as(C.c_void_p) if sel is not None else None,
-                                             C.addressof(c_arr), C.addressof(c_schema))
+        sel_ptr = sel.ctypes.data_as(C.c_void_p) if sel is not None else None
+        if date_field is None:
+            st = self._lib.lc_get_with_selection(self._ctx, entry_id, sel_ptr, C.addressof(c_arr), C.addressof(c_schema))
+        else:
+            st = self._lib.lc_get_date_part_with_selection(self._ctx, entry_id, sel_ptr, int(date_field),
+                                                           C.addressof(c_arr), C.addressof(c_schema))
         if st == N.LC_NOT_STAGED:
             return None
         N.check(st, self._ctx)

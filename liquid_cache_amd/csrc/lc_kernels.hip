@@ -1246,6 +1246,61 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// Date-part truncation (SqueezedDate32Array, squeezed_date32_array.rs): values decoded by k_fixed_gather are replaced
+// in place by the lossy reconstruction of ONE component — what the reference serves for an ExtractDate32 hint:
+//   days (Date32) or value.div_euclid(ticks_per_day) (Timestamp, :406-414) -> civil date (:364-397)
+//   -> Year: (y,1,1)  Month: (1970,m,1)  Day: (1970,1,d)  DayOfWeek: 1970-01-04 + (days+4).rem_euclid(7)   (:289-359)
+//   -> days since epoch, times ticks_per_day for timestamps (:289-323).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int64_t floor_div(int64_t a, int64_t b) {
+    int64_t q = a / b;
+    if ((a % b) < 0) q -= 1;
+    return q;
+}
+__device__ __forceinline__ int32_t ymd_to_epoch_days(int64_t year, int64_t month, int64_t day) {
+    const int64_t y = year - (month <= 2 ? 1 : 0);
+    const int64_t era = floor_div(y, 400);
+    const int64_t yoe = y - era * 400;
+    const int64_t mp = month + (month > 2 ? -3 : 9);
+    const int64_t doy = (153 * mp + 2) / 5 + day - 1;
+    const int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+    return int32_t(era * 146097 + doe - 719468);
+}
+__device__ __forceinline__ int32_t date_lossy_days(int32_t days, int field) {
+    const int64_t z = int64_t(days) + 719468;
+    const int64_t era = floor_div(z, 146097);
+    const int64_t doe = z - era * 146097;
+    const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    int64_t y = yoe + era * 400;
+    const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    const int64_t mp = (5 * doy + 2) / 153;
+    const int64_t d = (doy - (153 * mp + 2) / 5) + 1;
+    const int64_t m = mp + (mp < 10 ? 3 : -9);
+    if (m <= 2) y += 1;
+    switch (field) {
+        case 0: return ymd_to_epoch_days(int32_t(y), 1, 1);
+        case 1: return ymd_to_epoch_days(1970, m, 1);
+        case 2: return ymd_to_epoch_days(1970, 1, d);
+        default: {
+            int64_t dow = (int64_t(days) + 4) % 7;
+            if (dow < 0) dow += 7;
+            return int32_t(3 + dow);  // 1970-01-04 is day 3
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_date_lossy(T* __restrict__ values, uint64_t n, int field, int64_t ticks_per_day) {
+    for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
+        if constexpr (sizeof(T) == 4) {
+            values[i] = T(date_lossy_days(int32_t(values[i]), field));
+        } else {
+            const int32_t days = int32_t(floor_div(int64_t(values[i]), ticks_per_day));
+            values[i] = T(int64_t(date_lossy_days(days, field)) * ticks_per_day);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Mask utilities.  One wave per entry segment; a segment has at most 1024 words here (65536 rows).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t pext64(uint64_t v, uint64_t m) {
@@ -1769,6 +1824,18 @@ hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const Sc
         case 6: hipLaunchKernelGGL(k_fixed_gather<uint64_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_date_lossy(void* d_values, uint64_t n, int value_width, int field, int64_t ticks_per_day,
+                             hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((n + 255) / 256, uint64_t(device_cus()) * 16));
+    if (value_width == 4)
+        hipLaunchKernelGGL(k_date_lossy<int32_t>, dim3(grid), dim3(256), 0, stream, static_cast<int32_t*>(d_values), n, field, ticks_per_day);
+    else if (value_width == 8)
+        hipLaunchKernelGGL(k_date_lossy<int64_t>, dim3(grid), dim3(256), 0, stream, static_cast<int64_t*>(d_values), n, field, ticks_per_day);
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 

@@ -136,6 +136,8 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
                              hipStream_t stream);
 hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
                                 hipStream_t stream);
+hipError_t launch_date_lossy(void* d_values, uint64_t n, int value_width, int field, int64_t ticks_per_day,
+                             hipStream_t stream);
 hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, const uint8_t* needle,
                                uint32_t needle_len, uint8_t* d_automata, hipStream_t stream);
 hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, const StrPred& pred,

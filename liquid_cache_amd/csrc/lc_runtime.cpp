@@ -1117,9 +1117,36 @@ std::string arrow_format(const Entry& e) {
 }  // namespace
 }  // extern "C++"
 
+// ticks per day of a Date32 / Timestamp entry for the date-part path; 0: Date32; -1: not a date-like entry
+static int64_t date_ticks_per_day(const Entry& e) {
+    if (e.is_str || e.logical == kDecimal) return -1;
+    switch (e.phys) {
+        case kDate32: return 0;
+        case kTsS: return 86400LL;
+        case kTsMs: return 86400000LL;
+        case kTsUs: return 86400000000LL;
+        case kTsNs: return 86400000000000LL;
+        default: return -1;
+    }
+}
+
+static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection, int date_field,
+                                         struct ArrowArray* out_array, struct ArrowSchema* out_schema);
+
 // cache.get(&id).with_selection(&sel).read(): decode + compact on the device, export through the C Data Interface
 lc_status lc_get_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection,
                                 struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+    return get_with_selection_impl(ctx, entry_id, selection, -1, out_array, out_schema);
+}
+
+lc_status lc_get_date_part_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection, int32_t field,
+                                          struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+    if (field < LC_DATE_YEAR || field > LC_DATE_DAY_OF_WEEK) return fail(LC_ERR_INVALID, "unknown date field");
+    return get_with_selection_impl(ctx, entry_id, selection, field, out_array, out_schema);
+}
+
+static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection, int date_field,
+                                         struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
     if (!ctx || !out_array || !out_schema) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
@@ -1128,6 +1155,8 @@ lc_status lc_get_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* s
     if (rc != LC_OK) return rc;
     std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
     const Entry& e = scan->meta[0];
+    if (date_field >= 0 && date_ticks_per_day(e) < 0)
+        return fail(LC_UNSUPPORTED, "ExtractDate32 applies to Date32 / Timestamp entries");
     const uint64_t words = std::max<uint64_t>((uint64_t(e.len) + 63) / 64, 1);
     std::vector<void*> dev;
     auto dalloc = [&](size_t bytes) -> void* {
@@ -1210,6 +1239,8 @@ lc_status lc_get_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* s
         LC_HIP_G(hipMemset(d_vals, 0, std::max<size_t>(k, 1) * vw + 64));
         LC_HIP_G(launch_fixed_gather(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, d_bc, d_bo, d_eo,
                                      d_vals, nullptr));
+        if (date_field >= 0)
+            LC_HIP_G(launch_date_lossy(d_vals, k, int(vw), date_field, date_ticks_per_day(e), nullptr));
         uint8_t* vals = host_alloc(std::max<size_t>(k, 1) * vw);
         LC_HIP_G(hipMemcpy(vals, d_vals, k * vw, hipMemcpyDeviceToHost));
         priv->buffers[1] = vals;
@@ -1278,6 +1309,17 @@ lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selecti
     L.d_selection = static_cast<const uint64_t*>(d_selection);
     LC_HIP(launch_fixed_gather(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, d_bc, d_bo,
                                static_cast<uint64_t*>(d_row_offsets), static_cast<uint8_t*>(d_values_out), st));
+    return LC_OK;
+}
+
+lc_status lc_scan_date_part(lc_ctx* ctx, lc_scan* scan, void* d_values, uint64_t n_values, int32_t field, void* stream) {
+    if (!ctx || !scan || !d_values) return fail(LC_ERR_INVALID, "null argument");
+    if (field < LC_DATE_YEAR || field > LC_DATE_DAY_OF_WEEK) return fail(LC_ERR_INVALID, "unknown date field");
+    if (scan->n == 0 || n_values == 0) return LC_OK;
+    const int64_t tpd = scan->is_str ? -1 : date_ticks_per_day(scan->meta[0]);
+    if (tpd < 0) return fail(LC_UNSUPPORTED, "ExtractDate32 applies to Date32 / Timestamp columns");
+    LC_HIP(launch_date_lossy(d_values, n_values, int(scan->meta[0].fd.value_width), field, tpd,
+                             static_cast<hipStream_t>(stream)));
     return LC_OK;
 }
 

@@ -384,6 +384,51 @@ def test_get_with_selection_floats_and_decimals(gpu_cache, oracle):
     assert gpu_cache.get(900).read().to_pylist() == arr.to_pylist()
 
 
+def test_get_with_date_part_hint(gpu_cache, oracle):
+    """cache.get(id).with_expression_hint(extract_date32(field)) == SqueezedDate32Array's lossy reconstruction."""
+    lo = oracle
+    # reference test cache/core.rs:1053-1084: [2, 366, null, 465] / Year -> [0, 365, null, 365]
+    arr = pa.array([2, 366, None, 465], type=pa.date32())
+    gpu_cache.insert(lc.EntryID(42), arr)
+    got = gpu_cache.get(lc.EntryID(42)).with_expression_hint(lc.CacheExpression.extract_date32(lc.Date32Field.YEAR)).read()
+    assert got.type == pa.date32()
+    assert got.view(pa.int32()).to_pylist() == [0, 365, None, 365]
+    rng = np.random.default_rng(8)
+    n = 5000
+    days = rng.integers(-800000, 800000, size=n).astype(np.int32)   # years -220 .. 4160, incl. negative days
+    days[:6] = [0, -1, 59, 60, 11016, -719468]
+    mask = rng.random(n) < 0.1
+    eid = 100
+    for field in (lc.Date32Field.YEAR, lc.Date32Field.MONTH, lc.Date32Field.DAY, lc.Date32Field.DAY_OF_WEEK):
+        hint = lc.CacheExpression.extract_date32(field)
+        want_days = np.array([lo.date_lossy_days(field, lo.date_component(field, int(d))) for d in days], dtype=np.int64)
+        eid += 1
+        gpu_cache.insert(eid, pa.array(days, type=pa.date32(), mask=mask))
+        for sel in (None, rng.random(n) < 0.3):
+            g = gpu_cache.get(eid).with_expression_hint(hint)
+            got = (g.with_selection(sel) if sel is not None else g).read()
+            keep = np.ones(n, bool) if sel is None else sel
+            assert got.type == pa.date32()
+            assert got.is_null().to_pylist() == mask[keep].tolist()
+            gv = got.view(pa.int32()).to_numpy(zero_copy_only=False)
+            assert gv[~mask[keep]].astype(np.int64).tolist() == want_days[keep][~mask[keep]].tolist()
+        for unit_code, unit, tpd in ((0, "s", 86400), (1, "ms", 86400000), (2, "us", 86400000000), (3, "ns", 86400000000000)):
+            span = 100000 if unit == "ns" else 800000                  # keep ns inside i64
+            ts = rng.integers(-span, span, size=n).astype(np.int64) * tpd + rng.integers(0, tpd, size=n)
+            want = np.array([lo.date_lossy_days(field, lo.date_component(field, lo.timestamp_to_days(int(t), unit_code)))
+                             for t in ts], dtype=np.int64) * tpd
+            eid += 1
+            gpu_cache.insert(eid, pa.array(ts, type=pa.timestamp(unit)))
+            sel = rng.random(n) < 0.5
+            got = gpu_cache.get(eid).with_expression_hint(hint).with_selection(sel).read()
+            assert got.type == pa.timestamp(unit)
+            assert got.view(pa.int64()).to_pylist() == want[sel].tolist()
+    # not a date-like entry: the C ABI answers LC_UNSUPPORTED (the reference only squeezes Date32 / Timestamp)
+    gpu_cache.insert(999, pa.array([1, 2, 3], type=pa.int32()))
+    with pytest.raises(lc.LiquidCacheError):
+        gpu_cache.get(999).with_expression_hint(lc.CacheExpression.extract_date32("year")).read()
+
+
 @pytest.mark.parametrize("arrow_type", [pa.string(), pa.binary(), pa.string_view()])
 def test_get_with_selection_strings(gpu_cache, oracle, arrow_type):
     rng = np.random.default_rng(91)
