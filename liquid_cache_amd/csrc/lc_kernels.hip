@@ -643,6 +643,88 @@ __device__ __noinline__ int decode_compare(const DevSymtab& st, const uint8_t* f
     return j < nl ? -1 : 0;
 }
 
+// General SQL LIKE (`%`, `_` = one UTF-8 character, `\` escape; Arrow's `like`, which the reference runs for
+// patterns that are not %needle% on entries without fingerprints: helpers.rs:86-91 -> mod.rs:360-361) on one
+// FSST-compressed value.  The classic single-backtrack-point wildcard match runs over a decoding iterator whose state
+// (position in the code stream + byte index inside the current symbol) is small enough to save at every `%` and to
+// restore when the match has to be retried one character further — no decoded copy of the value is ever made.
+struct FsstIter {
+    uint32_t pos, stop;  // next code, end of the value
+    uint64_t sym;        // bytes of the current symbol
+    uint32_t len, k;     // its length, index of the current byte
+    bool at_end;
+};
+__device__ __forceinline__ void fsst_iter_load(FsstIter& it, const DevSymtab& st, const uint8_t* __restrict__ fsst) {
+    while (it.pos < it.stop) {
+        const uint32_t c = fsst[it.pos++];
+        if (c == 255u) {
+            if (it.pos >= it.stop) break;  // dangling escape marker: ignored, like the reference decoder
+            it.sym = fsst[it.pos++];
+            it.len = 1;
+        } else {
+            it.sym = st.sym[c];
+            it.len = st.len[c];
+        }
+        it.k = 0;
+        if (it.len) return;
+    }
+    it.at_end = true;
+}
+__device__ __forceinline__ uint32_t fsst_iter_cur(const FsstIter& it) { return uint32_t(it.sym >> (8u * it.k)) & 0xFFu; }
+__device__ __forceinline__ void fsst_iter_next(FsstIter& it, const DevSymtab& st, const uint8_t* __restrict__ fsst) {
+    if (++it.k == it.len) fsst_iter_load(it, st, fsst);
+}
+__device__ __forceinline__ uint32_t utf8_char_len(uint32_t c) {
+    if (c < 0x80u) return 1;
+    if ((c >> 5) == 0x6u) return 2;
+    if ((c >> 4) == 0xEu) return 3;
+    if ((c >> 3) == 0x1Eu) return 4;
+    return 1;
+}
+__device__ __noinline__ bool like_generic(const DevSymtab& st, const uint8_t* __restrict__ fsst, uint32_t start,
+                                          uint32_t stop, const uint8_t* __restrict__ pat, uint32_t pl) {
+    FsstIter s{start, stop, 0, 0, 0, false};
+    fsst_iter_load(s, st, fsst);
+    FsstIter star_s = s;
+    uint32_t pi = 0, star_p = 0;
+    bool has_star = false;
+    while (!s.at_end) {
+        if (pi < pl && pat[pi] == '%') {
+            star_p = ++pi;
+            star_s = s;
+            has_star = true;
+            continue;
+        }
+        bool matched = false;
+        if (pi < pl) {
+            if (pat[pi] == '_') {
+                const uint32_t cl = utf8_char_len(fsst_iter_cur(s));
+                for (uint32_t j = 0; j < cl && !s.at_end; j++) fsst_iter_next(s, st, fsst);
+                pi++;
+                matched = true;
+            } else {
+                uint32_t lp = pi;
+                if (pat[pi] == '\\' && pi + 1 < pl) lp = pi + 1;  // escaped literal
+                if (uint32_t(pat[lp]) == fsst_iter_cur(s)) {
+                    fsst_iter_next(s, st, fsst);
+                    pi = lp + 1;
+                    matched = true;
+                }
+            }
+        }
+        if (!matched) {
+            if (!has_star) return false;
+            // advance the `%` match by one character and retry
+            const uint32_t cl = utf8_char_len(fsst_iter_cur(star_s));
+            for (uint32_t j = 0; j < cl && !star_s.at_end; j++) fsst_iter_next(star_s, st, fsst);
+            s = star_s;
+            pi = star_p;
+        }
+    }
+    while (pi < pl && pat[pi] == '%') pi++;
+    return pi == pl;
+}
+
 // LIKE '%needle%' on one FSST-compressed value without decoding it: `tbl` is the needle's automaton folded over the
 // symbol table (k_str_automata), one lookup per compressed code.  State `nl` is absorbing, so there is no per-code
 // hit test; the escape code 255 is flagged 0xFF in every row and redirects the next byte to the literal half of the
@@ -849,7 +931,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     if (!kSub) {
         if (pred.mode == 2) {
             uniform_result = pred.const_value ? 1 : 0;  // helpers.rs:72-79 (UnsupportedExpression::Constant)
-        } else {
+        } else if (pred.mode == 0) {
             const uint32_t m = min(nl, spl);
             int c = 0;
             for (uint32_t i = 0; i < m && c == 0; i++) {
@@ -970,6 +1052,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                         if (L.d_cand_bytes && fp_ok) cand_bytes += str_offset(d, i + 1) - str_offset(d, i);
                         fp_cand += uint32_t(__popcll(__ballot(fp_ok)));
                     }
+                } else if (pred.mode == 3) {
+                    is_cand = in;  // general LIKE: every dictionary value is matched
                 } else if (in) {
                     const uint64_t pk = pkv[k];
                     const uint32_t plen = uint32_t(pk >> 56);
@@ -1109,6 +1193,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 res = cl && hitflag[lane] != 0;
             } else if (kSub) {
                 if (cl) res = like_walk_global(d.fsst, start, stop, tbl_global, nl);
+            } else if (pred.mode == 3) {
+                if (cl) res = like_generic(st, d.fsst, start, stop, np, nl);
             } else if (cl) {
                 const int o = decode_compare(st, d.fsst, start, stop, np, nl);
                 res = is_eq ? o == 0
@@ -1137,6 +1223,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     bool invert = false;
     if (kSub && op == LC_OP_NOT_LIKE) invert = prune ? (fp_cand > 0) : true;
     if (!kSub && pred.mode == 0 && op == LC_OP_NE) invert = true;
+    if (!kSub && pred.mode == 3 && op == LC_OP_NOT_LIKE) invert = true;  // Arrow `nlike` on the rows
     if (uniform_result == 1) invert = !invert;  // all-true dictionary == all-false inverted
 
     // ---- phase C: rows ----

@@ -100,7 +100,8 @@ constexpr int kInlineNeedle = 64;
 
 struct StrPred {
     int32_t op;            // LC_OP_*
-    int32_t mode;          // 0: Eq/Ne/ordering on `needle`, 1: substring automaton (LIKE %needle%), 2: constant
+    int32_t mode;          // 0: Eq/Ne/ordering on `needle`, 1: substring automaton (LIKE %needle%), 2: constant,
+                           // 3: general LIKE pattern in `needle` (entries without fingerprints)
     uint32_t needle_len;
     int32_t use_fingerprints;  // LIKE: prune with fingerprints (and apply the reference's candidate quirk)
     const uint8_t* needle;     // device copy when needle_len > kInlineNeedle (padded by 8 bytes)

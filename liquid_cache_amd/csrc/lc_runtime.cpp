@@ -427,9 +427,19 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
     } else if (p->op == LC_OP_LIKE || p->op == LC_OP_NOT_LIKE) {
         const uint8_t* inner;
         size_t il;
-        if (!substring_pattern(lit, ll, &inner, &il))
-            return fail(LC_UNSUPPORTED, "only %needle% LIKE patterns are evaluated on the device");
-        if (il > size_t(kMaxNeedleAutomaton)) return fail(LC_UNSUPPORTED, "LIKE needle longer than 63 bytes");
+        if (!substring_pattern(lit, ll, &inner, &il) || il > size_t(kMaxNeedleAutomaton)) {
+            // general pattern (prefix / suffix / `_` / several parts), or a needle too long for the folded automaton:
+            // Arrow `like` on every dictionary value.  The reference only gets here for entries WITHOUT fingerprints
+            // (with them it `expect()`s a %needle% pattern, comparisons.rs:150-166); the caller checks that.
+            if (ll > size_t(kMaxNeedleBytes)) return fail(LC_UNSUPPORTED, "LIKE pattern longer than 4096 bytes");
+            out->p.mode = 3;
+            out->needle.assign(lit, lit + ll);
+            if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->p.debug_flags = std::atoi(dbg);
+            out->p.needle_len = uint32_t(out->needle.size());
+            if (out->needle.size() <= size_t(kInlineNeedle))
+                std::memcpy(out->p.needle_inline, out->needle.data(), out->needle.size());
+            return LC_OK;
+        }
         out->p.mode = 1;
         out->p.use_fingerprints = 1;
         out->needle.assign(inner, inner + il);
@@ -788,6 +798,11 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     StrPredHost sp;
     const lc_status st = make_str_pred(pred, &sp);
     if (st != LC_OK) return st;
+    if (sp.p.mode == 3)
+        for (const Entry& e : s->meta)
+            if (e.has_fp)
+                return fail(LC_UNSUPPORTED, "general LIKE patterns apply to byte views without fingerprints (the "
+                                            "reference requires %needle% on SubstringSearch columns)");
     std::lock_guard<std::mutex> g(s->mu);
     if (sp.p.mode == 1) {
         const uint32_t stride = automaton_stride(sp.p.needle_len);
@@ -810,7 +825,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         }
         sp.p.automata = s->d_automata;
         sp.p.automaton_stride = stride;
-    } else if (sp.p.mode == 0 && sp.needle.size() > size_t(kInlineNeedle)) {
+    } else if ((sp.p.mode == 0 || sp.p.mode == 3) && sp.needle.size() > size_t(kInlineNeedle)) {
         const size_t need = sp.needle.size() + 16;
         LC_HIP(hipStreamSynchronize(stream));  // previous evaluation may still read the old needle
         if (need > s->needle_cap) {

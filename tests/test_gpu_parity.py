@@ -218,6 +218,18 @@ def test_string_predicates(gpu_cache, oracle, fingerprints):
             for pat in ("%google%", "%goo%", "%zzzz%", "%g%", "%le.goo%", "%ÿé%", "%" + nonnull[0][-5:] + "%"):
                 sel = (rng.random(n) < 0.3) if rng.integers(2) else None
                 _check_pred(gpu_cache, lo, eid, liquid, op, pat.encode(), pa.string(), sel, symtab=st, hint=hint)
+        # general patterns: Arrow `like` on the dictionary for entries without fingerprints; with fingerprints the
+        # reference insists on %needle% (comparisons.rs:150-166) and the device answers LC_UNSUPPORTED
+        general = ["http://goo%", "%le" + nonnull[0][-2:], "%goo%gle%", "h_tp%", "%\\%%", "http://%/x_" + "%", "%", "_%",
+                   nonnull[0], nonnull[0][:-1] + "_", "%ÿ_z%", "%" + "o" * 70 + "%", "__________%"]
+        for op in ("like", "not_like"):
+            for pat in general:
+                if fingerprints:
+                    with pytest.raises(lc.LiquidCacheError):
+                        gpu_cache.eval_predicate(eid, lc.LiquidExpr.try_new(op, pat.encode(), pa.string(), hint)).read()
+                    continue
+                sel = (rng.random(n) < 0.3) if rng.integers(2) else None
+                _check_pred(gpu_cache, lo, eid, liquid, op, pat.encode(), pa.string(), sel, symtab=st, hint=hint)
 
 
 def test_string_large_dictionary_and_long_needles(gpu_cache, oracle):
