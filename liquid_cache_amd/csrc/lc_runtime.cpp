@@ -82,6 +82,14 @@ struct lc_ctx {
     DevSymtab* d_symtabs = nullptr;
     size_t d_symtabs_cap = 0;
     size_t d_symtabs_uploaded = 0;
+    // Recycled device scratch for the per-call drop-in API (descriptor arrays, masks, gather buffers): hipMalloc /
+    // hipFree cost 0.1-1 ms each and hipFree synchronises the device, which would dominate an 8192-row call.
+    std::mutex pool_mu;
+    std::unordered_map<void*, size_t> pool_live;                // pointer -> size class (bytes)
+    std::unordered_map<size_t, std::vector<void*>> pool_free;   // size class -> cached blocks
+    // same for pinned host staging (pageable hipMemcpy runs at a fraction of the PCIe rate)
+    std::unordered_map<void*, size_t> hpool_live;
+    std::unordered_map<size_t, std::vector<void*>> hpool_free;
 };
 
 struct lc_scan {
@@ -107,6 +115,99 @@ struct lc_scan {
 };
 
 namespace {
+
+// ------------------------------------------------------------------ scratch pool
+constexpr size_t kPoolMinClass = 4096, kPoolMaxClass = size_t(64) << 20, kPoolKeepPerClass = 16;
+
+void* pool_alloc(lc_ctx* ctx, size_t bytes) {
+    size_t cls = kPoolMinClass;
+    while (cls < bytes) cls <<= 1;
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        auto it = ctx->pool_free.find(cls);
+        if (it != ctx->pool_free.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            ctx->pool_live[p] = cls;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, cls) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    ctx->pool_live[p] = cls;
+    return p;
+}
+
+// The caller guarantees that no kernel or copy still uses `p` (the per-call API synchronises before it returns).
+void pool_release(lc_ctx* ctx, void* p) {
+    if (!p) return;
+    size_t cls = 0;
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        auto it = ctx->pool_live.find(p);
+        if (it == ctx->pool_live.end()) return;
+        cls = it->second;
+        ctx->pool_live.erase(it);
+        std::vector<void*>& fl = ctx->pool_free[cls];
+        if (cls <= kPoolMaxClass && fl.size() < kPoolKeepPerClass) {
+            fl.push_back(p);
+            return;
+        }
+    }
+    (void)hipFree(p);
+}
+
+void* host_pool_alloc(lc_ctx* ctx, size_t bytes) {
+    size_t cls = kPoolMinClass;
+    while (cls < bytes) cls <<= 1;
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        auto it = ctx->hpool_free.find(cls);
+        if (it != ctx->hpool_free.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            ctx->hpool_live[p] = cls;
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    ctx->hpool_live[p] = cls;
+    return p;
+}
+
+void host_pool_release(lc_ctx* ctx, void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        auto it = ctx->hpool_live.find(p);
+        if (it == ctx->hpool_live.end()) return;
+        const size_t cls = it->second;
+        ctx->hpool_live.erase(it);
+        std::vector<void*>& fl = ctx->hpool_free[cls];
+        if (cls <= kPoolMaxClass && fl.size() < kPoolKeepPerClass) {
+            fl.push_back(p);
+            return;
+        }
+    }
+    (void)hipHostFree(p);
+}
+
+void pool_destroy(lc_ctx* ctx) {
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    for (auto& kv : ctx->pool_free)
+        for (void* p : kv.second) (void)hipFree(p);
+    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
+    for (auto& kv : ctx->hpool_free)
+        for (void* p : kv.second) (void)hipHostFree(p);
+    for (auto& kv : ctx->hpool_live) (void)hipHostFree(kv.first);
+    ctx->pool_free.clear();
+    ctx->pool_live.clear();
+    ctx->hpool_free.clear();
+    ctx->hpool_live.clear();
+}
 
 // ------------------------------------------------------------------ arena
 lc_status arena_alloc(lc_ctx* ctx, size_t bytes, uint8_t** out, int* slab_idx) {
@@ -511,6 +612,7 @@ void lc_ctx_destroy(lc_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (Slab& s : ctx->slabs)
         if (s.base) (void)hipFree(s.base);
+    pool_destroy(ctx);
     if (ctx->d_symtabs) (void)hipFree(ctx->d_symtabs);
     delete ctx;
 }
@@ -734,14 +836,20 @@ lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_
         if (s->is_str) std::memcpy(host.data() + i * desc_size, &s->meta[i].sd, desc_size);
         else std::memcpy(host.data() + i * desc_size, &s->meta[i].fd, desc_size);
     }
-    LC_HIP(hipMalloc(&s->d_descs, host.size()));
-    LC_HIP(hipMemcpy(s->d_descs, host.data(), host.size(), hipMemcpyHostToDevice));
-    LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_seg_offsets), (n + 1) * 8));
-    LC_HIP(hipMemcpy(s->d_seg_offsets, s->seg_offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice));
-    LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_work), kWorkGroupsMax * 64));
-    LC_HIP(hipMemset(s->d_work, 0, kWorkGroupsMax * 64));
-    const lc_status st = sync_symtabs(ctx);
-    if (st != LC_OK) return st;
+    s->d_descs = pool_alloc(ctx, host.size());
+    s->d_seg_offsets = static_cast<uint64_t*>(pool_alloc(ctx, (n + 1) * 8));
+    lc_status st = (!s->d_descs || !s->d_seg_offsets) ? fail(LC_ERR_OOM, "hipMalloc (scan descriptors)") : LC_OK;
+    if (st == LC_OK && hipMemcpy(s->d_descs, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess)
+        st = fail(LC_ERR_DEVICE, "hipMemcpy (scan descriptors)");
+    if (st == LC_OK &&
+        hipMemcpy(s->d_seg_offsets, s->seg_offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
+        st = fail(LC_ERR_DEVICE, "hipMemcpy (scan offsets)");
+    if (st == LC_OK) st = sync_symtabs(ctx);
+    if (st != LC_OK) {
+        pool_release(ctx, s->d_descs);
+        pool_release(ctx, s->d_seg_offsets);
+        return st;
+    }
     *out = s.release();
     return LC_OK;
 }
@@ -749,12 +857,12 @@ lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_
 void lc_scan_destroy(lc_scan* s) {
     if (!s) return;
     (void)hipSetDevice(s->ctx->device);
-    (void)hipDeviceSynchronize();
-    if (s->d_descs) (void)hipFree(s->d_descs);
-    if (s->d_seg_offsets) (void)hipFree(s->d_seg_offsets);
+    (void)hipDeviceSynchronize();  // nothing in flight may still read the scan's buffers when they are recycled
+    pool_release(s->ctx, s->d_descs);
+    pool_release(s->ctx, s->d_seg_offsets);
+    pool_release(s->ctx, s->d_work);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
-    if (s->d_work) (void)hipFree(s->d_work);
     delete s;
 }
 
@@ -804,6 +912,12 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
                 return fail(LC_UNSUPPORTED, "general LIKE patterns apply to byte views without fingerprints (the "
                                             "reference requires %needle% on SubstringSearch columns)");
     std::lock_guard<std::mutex> g(s->mu);
+    if (!s->d_work) {  // entry-draw counters of k_str_pred: zero once, the kernel leaves them zero
+        s->d_work = static_cast<uint32_t*>(pool_alloc(ctx, kWorkGroupsMax * 64));
+        if (!s->d_work) return fail(LC_ERR_OOM, "hipMalloc (scan work counters)");
+        LC_HIP(hipMemsetAsync(s->d_work, 0, kWorkGroupsMax * 64, stream));
+    }
+    L.d_work = s->d_work;
     if (sp.p.mode == 1) {
         const uint32_t stride = automaton_stride(sp.p.needle_len);
         const size_t nst = ctx->d_symtabs_uploaded;
@@ -974,12 +1088,23 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     if (selections)
         for (uint64_t i : present_idx) any_sel |= selections[i] != nullptr;
     // host selection in scan layout (entries without a selection get all ones)
-    std::vector<uint64_t> h_sel;
+    // pinned staging: [selection | hit | valid] words + per-entry bit counts
+    uint64_t* h_stage = static_cast<uint64_t*>(host_pool_alloc(ctx, words * 8 * 3 + size_t(m) * 4 + 64));
+    if (!h_stage) return fail(LC_ERR_OOM, "hipHostMalloc (predicate staging)");
+    struct HostStage {
+        lc_ctx* c;
+        void* p;
+        ~HostStage() { host_pool_release(c, p); }
+    } stage_guard{ctx, h_stage};
+    uint64_t* h_sel = h_stage;
+    uint64_t* h_hit = h_stage + words;
+    uint64_t* h_valid = h_stage + 2 * words;
+    uint32_t* h_bits = reinterpret_cast<uint32_t*>(h_stage + 3 * words);
     if (any_sel) {
-        h_sel.assign(words, 0);
+        std::memset(h_sel, 0, words * 8);
         for (uint32_t k = 0; k < m; k++) {
             const Entry& e = scan->meta[k];
-            uint8_t* dst = reinterpret_cast<uint8_t*>(h_sel.data() + scan->seg_offsets[k]);
+            uint8_t* dst = reinterpret_cast<uint8_t*>(h_sel + scan->seg_offsets[k]);
             const uint8_t* src = selections[present_idx[k]];
             const size_t nb = bitmap_bytes(e.len);
             if (src) std::memcpy(dst, src, nb);
@@ -991,7 +1116,7 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     uint32_t* d_bits = nullptr;
     auto cleanup = [&]() {
         for (void* p : {(void*)d_sel, (void*)d_hit, (void*)d_valid, (void*)d_chit, (void*)d_cvalid, (void*)d_bits})
-            if (p) (void)hipFree(p);
+            pool_release(ctx, p);  // every use below is followed by a blocking copy
     };
 #define LC_HIP_C(expr)                                                                          \
     do {                                                                                        \
@@ -1001,29 +1126,30 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             return fail(LC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
         }                                                                                       \
     } while (0)
-    LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_hit), words * 8));
-    LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_valid), words * 8));
+    d_hit = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
+    d_valid = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
+    bool oom = !d_hit || !d_valid;
     if (any_sel) {
-        LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_sel), words * 8));
-        LC_HIP_C(hipMemcpy(d_sel, h_sel.data(), words * 8, hipMemcpyHostToDevice));
-        LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_chit), words * 8));
-        LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_cvalid), words * 8));
-        LC_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_bits), size_t(m) * 4));
+        d_sel = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
+        d_chit = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
+        d_cvalid = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
+        d_bits = static_cast<uint32_t*>(pool_alloc(ctx, size_t(m) * 4));
+        oom = oom || !d_sel || !d_chit || !d_cvalid || !d_bits;
     }
+    if (oom) { cleanup(); return fail(LC_ERR_OOM, "hipMalloc (predicate scratch)"); }
+    if (any_sel) LC_HIP_C(hipMemcpy(d_sel, h_sel, words * 8, hipMemcpyHostToDevice));
     rc = scan_eval_impl(ctx, scan, pred, d_sel, d_hit, d_valid, nullptr, nullptr, nullptr);
     if (rc != LC_OK) { cleanup(); return rc; }
-    std::vector<uint64_t> h_hit(words), h_valid(words);
-    std::vector<uint32_t> h_bits(m);
     if (any_sel) {
         // the reference returns a BooleanArray of popcount(selection) rows: compress hit/valid by the selection
         LC_HIP_C(launch_mask_compress(d_hit, d_sel, scan->d_seg_offsets, m, d_chit, d_bits, nullptr));
         LC_HIP_C(launch_mask_compress(d_valid, d_sel, scan->d_seg_offsets, m, d_cvalid, nullptr, nullptr));
-        LC_HIP_C(hipMemcpy(h_hit.data(), d_chit, words * 8, hipMemcpyDeviceToHost));
-        LC_HIP_C(hipMemcpy(h_valid.data(), d_cvalid, words * 8, hipMemcpyDeviceToHost));
-        LC_HIP_C(hipMemcpy(h_bits.data(), d_bits, size_t(m) * 4, hipMemcpyDeviceToHost));
+        LC_HIP_C(hipMemcpy(h_hit, d_chit, words * 8, hipMemcpyDeviceToHost));
+        LC_HIP_C(hipMemcpy(h_valid, d_cvalid, words * 8, hipMemcpyDeviceToHost));
+        LC_HIP_C(hipMemcpy(h_bits, d_bits, size_t(m) * 4, hipMemcpyDeviceToHost));
     } else {
-        LC_HIP_C(hipMemcpy(h_hit.data(), d_hit, words * 8, hipMemcpyDeviceToHost));
-        LC_HIP_C(hipMemcpy(h_valid.data(), d_valid, words * 8, hipMemcpyDeviceToHost));
+        LC_HIP_C(hipMemcpy(h_hit, d_hit, words * 8, hipMemcpyDeviceToHost));
+        LC_HIP_C(hipMemcpy(h_valid, d_valid, words * 8, hipMemcpyDeviceToHost));
         for (uint32_t k = 0; k < m; k++) h_bits[k] = scan->meta[k].len;
     }
     cleanup();
@@ -1033,8 +1159,8 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         const Entry& e = scan->meta[k];
         const size_t nb = bitmap_bytes(h_bits[k]);
         out_lens[i] = h_bits[k];
-        if (out_values[i]) std::memcpy(out_values[i], h_hit.data() + scan->seg_offsets[k], nb);
-        if (out_validity && out_validity[i]) std::memcpy(out_validity[i], h_valid.data() + scan->seg_offsets[k], nb);
+        if (out_values[i]) std::memcpy(out_values[i], h_hit + scan->seg_offsets[k], nb);
+        if (out_validity && out_validity[i]) std::memcpy(out_validity[i], h_valid + scan->seg_offsets[k], nb);
         if (out_nullable) out_nullable[i] = e.nullable ? 1 : 0;
     }
     return LC_OK;
@@ -1069,18 +1195,18 @@ lc_status lc_mask_and_then(lc_ctx* ctx, const uint8_t* left, uint64_t left_bits,
     if (right_bits) std::memcpy(hr.data(), right, bitmap_bytes(right_bits));
     uint64_t *dl = nullptr, *dr = nullptr, *dout = nullptr;
     lc_status rc = LC_OK;
-    if (hipMalloc(reinterpret_cast<void**>(&dl), lw * 8) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&dr), rw * 8) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void**>(&dout), lw * 8) != hipSuccess)
-        rc = fail(LC_ERR_OOM, "hipMalloc");
+    dl = static_cast<uint64_t*>(pool_alloc(ctx, lw * 8));
+    dr = static_cast<uint64_t*>(pool_alloc(ctx, rw * 8));
+    dout = static_cast<uint64_t*>(pool_alloc(ctx, lw * 8));
+    if (!dl || !dr || !dout) rc = fail(LC_ERR_OOM, "hipMalloc");
     if (rc == LC_OK && (hipMemcpy(dl, hl.data(), lw * 8, hipMemcpyHostToDevice) != hipSuccess ||
                         hipMemcpy(dr, hr.data(), rw * 8, hipMemcpyHostToDevice) != hipSuccess ||
                         launch_mask_and_then(dl, left_bits, dr, dout, nullptr) != hipSuccess ||
                         hipMemcpy(hl.data(), dout, lw * 8, hipMemcpyDeviceToHost) != hipSuccess))
         rc = fail(LC_ERR_DEVICE, "and_then device pass failed");
-    if (dl) (void)hipFree(dl);
-    if (dr) (void)hipFree(dr);
-    if (dout) (void)hipFree(dout);
+    pool_release(ctx, dl);
+    pool_release(ctx, dr);
+    pool_release(ctx, dout);
     if (rc == LC_OK) std::memcpy(out, hl.data(), bitmap_bytes(left_bits));
     return rc;
 }
@@ -1175,12 +1301,12 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
     const uint64_t words = std::max<uint64_t>((uint64_t(e.len) + 63) / 64, 1);
     std::vector<void*> dev;
     auto dalloc = [&](size_t bytes) -> void* {
-        void* p = nullptr;
-        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr;
-        dev.push_back(p);
+        void* p = pool_alloc(ctx, bytes ? bytes : 8);
+        if (p) dev.push_back(p);
         return p;
     };
-    auto dfree = [&]() { for (void* p : dev) (void)hipFree(p); dev.clear(); };
+    // every device buffer of this call is last used by a blocking copy or followed by the synchronize below
+    auto dfree = [&]() { (void)hipDeviceSynchronize(); for (void* p : dev) pool_release(ctx, p); dev.clear(); };
 #define LC_HIP_G(expr)                                                                          \
     do {                                                                                        \
         hipError_t _e = (expr);                                                                 \
