@@ -45,6 +45,8 @@ def parse_args():
     p.add_argument("--uniques", type=int, default=2200, help="distinct URLs per batch (nano_hits: ~2,150-2,250)")
     p.add_argument("--row-group-batches", type=int, default=54, help="batches sharing one FSST symbol table")
     p.add_argument("--needle", default="google")
+    p.add_argument("--needle-ppm", type=int, default=159,
+                   help="distinct URLs per million that contain the needle (ClickBench hits: 15,911 of 99,997,497 rows match)")
     p.add_argument("--workload", default="url_like", choices=["url_like", "int64_gt"])
     p.add_argument("--int-bits", type=int, default=62, help="int64_gt: FoR bit width of every batch (WatchID ~62)")
     p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = auto)")
@@ -68,7 +70,7 @@ def stage_url_column(cache, lc, N, args, rank, n_batches, threads):
         first = rg * args.row_group_batches
         for b in range(first, min(first + args.row_group_batches, n_batches)):
             rows = min(bs, rows_total - b * bs)
-            n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), 60,
+            n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
                                      offs.ctypes.data, data.ctypes.data, data.size)
             arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
             cache.insert(ids[b], arr, lc.CacheExpression.SUBSTRING_SEARCH)
@@ -114,7 +116,7 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
         data = np.zeros(bs * 512, np.uint8)
         for b in range(c, n_sample, threads):
             rows = min(bs, args.rows - b * bs)
-            n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), 60,
+            n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
                                      offs.ctypes.data, data.ctypes.data, data.size)
             arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
             eid = lc.ParquetArrayID.new(rank, b // args.row_group_batches, 13, b % args.row_group_batches)

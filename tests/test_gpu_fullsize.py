@@ -22,7 +22,7 @@ BS = 8192
 
 def _args(**kw):
     a = argparse.Namespace(rows=ROWS, batch_size=BS, uniques=2200, row_group_batches=54, needle="google", int_bits=62,
-                           seed=42)
+                           seed=42, needle_ppm=159)
     a.__dict__.update(kw)
     return a
 
@@ -112,7 +112,7 @@ def test_url_like_scan_full_size(product_lib, bench_mod):
         sample += [int(b) for b in np.nonzero(c)[0][:10]]           # and batches that do have matches
         for b in sample:
             rows = min(BS, ROWS - b * BS)
-            n = L.lc_synth_url_batch(args.seed, b, rows, min(args.uniques, rows), 60, offs.ctypes.data, data.ctypes.data,
+            n = L.lc_synth_url_batch(args.seed, b, rows, min(args.uniques, rows), args.needle_ppm, offs.ctypes.data, data.ctypes.data,
                                      data.size)
             raw = data[:n].tobytes()
             want = np.array([b"google" in raw[offs[i]:offs[i + 1]] for i in range(rows)])
