@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libliquid_cache_amd.so")
+# LC_LIB_PATH: A/B runs of two in-tree builds of the same library (kernel tuning); the default is the in-tree build
+LIB_PATH = os.environ.get("LC_LIB_PATH") or os.path.join(_HERE, "libliquid_cache_amd.so")
 
 LC_OK, LC_NOT_STAGED, LC_UNSUPPORTED = 0, 1, 2
 LC_ERR_INVALID, LC_ERR_CORRUPT, LC_ERR_DEVICE, LC_ERR_OOM, LC_ERR_NO_SYMTAB = -1, -2, -3, -4, -5

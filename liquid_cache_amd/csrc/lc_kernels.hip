@@ -1862,7 +1862,9 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     const uint32_t cmask_bytes = sub ? (((dmax + 63u) / 64u) * 8u + 15u) & ~15u : 0u;
     const bool lds_tbl = sub && pred.needle_len <= kMaxLdsNeedle;
     const size_t tbl_bytes = lds_tbl ? automaton_image_bytes(pred.needle_len) : 0;
-    const size_t dyn_lds = tbl_bytes + 256 + size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + kCandCap * 2 + 80);
+    static const char* env_pad = std::getenv("LC_STR_LDS_PAD");  // tuning aid: extra LDS per workgroup lowers occupancy
+    const size_t dyn_lds = tbl_bytes + 256 + size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + kCandCap * 2 + 80) +
+                           (env_pad ? size_t(std::atoi(env_pad)) : 0);
     // persistent launch: as many workgroups as fit on the device at once; the waves draw entries dynamically
     const uint32_t wgs_needed = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
     void (*kern)(const StrDesc*, const DevSymtab*, StrPred, ScanLaunch, uint32_t, uint32_t) =
@@ -1874,17 +1876,20 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
         if (e != hipSuccess) return e;
     }
-    int wgs_per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void*>(kern), kThreads,
-                                                     dyn_lds) != hipSuccess || wgs_per_cu <= 0)
-        wgs_per_cu = 2;
-    static const char* env_k = std::getenv("LC_STR_WGS_PER_CU");  // tuning aid
-    if (env_k && std::atoi(env_k) > 0) wgs_per_cu = std::atoi(env_k);
-    // Measured (100M-row URL scan): one workgroup per four entries under the hardware dispatcher takes 51 us, the
-    // persistent grid 80 us: with every slot always occupied the waves run in phase and the kernel, which is bound by
+    // Measured (100M-row URL scan): one workgroup per four entries under the hardware dispatcher takes 48 us, a
+    // persistent grid 68 us: with every slot always occupied the waves run in phase and the kernel, which is bound by
     // dependent LDS / cross-lane chains rather than by issue or bandwidth, loses the overlap between phases.
-    static const bool persistent = std::getenv("LC_STR_PERSISTENT") != nullptr;
-    const uint32_t grid = persistent ? std::min<uint32_t>(wgs_needed, uint32_t(device_cus()) * uint32_t(wgs_per_cu)) : wgs_needed;
+    static const bool persistent = std::getenv("LC_STR_PERSISTENT") != nullptr;  // tuning aid
+    uint32_t grid = wgs_needed;
+    if (persistent) {
+        int wgs_per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void*>(kern), kThreads,
+                                                         dyn_lds) != hipSuccess || wgs_per_cu <= 0)
+            wgs_per_cu = 2;
+        static const char* env_k = std::getenv("LC_STR_WGS_PER_CU");
+        if (env_k && std::atoi(env_k) > 0) wgs_per_cu = std::atoi(env_k);
+        grid = std::min<uint32_t>(wgs_needed, uint32_t(device_cus()) * uint32_t(wgs_per_cu));
+    }
     ScanLaunch Lw = L;
     static const char* env_g = std::getenv("LC_STR_WGS_PER_GROUP");  // tuning aid
     const uint32_t wgs_per_group = env_g && std::atoi(env_g) > 0 ? uint32_t(std::atoi(env_g)) : (persistent ? 4u : 1u);

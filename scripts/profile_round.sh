@@ -13,5 +13,8 @@ for wl in url_like int64_gt; do
     timeout 240 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_str_pred|k_fixed_pred" --output-format csv -d $O/${wl}_$c -- python $R/bench.py --workload $wl --no-cpu-baseline --steps 3 --warmup 1 > $O/${wl}_$c.log 2>&1
   done
 done
+# the same LIKE scan with the reference's own prefilter only (no bigram signature index staged)
+LC_NO_SIGNATURES=1 timeout 300 python $R/bench.py --workload url_like --steps 5 --warmup 1 --no-cpu-baseline > $O/url_like_no_signatures.log 2>&1
 python $R/scripts/pmc_summary.py $O
-for wl in url_like int64_gt; do tail -1 $O/${wl}_trace.log; f=$(find $O/${wl}_trace -name "*kernel_stats.csv" | head -1); head -4 $f; done
+grep -h '^{"metric"' $O/url_like_no_signatures.log | cut -c1-2000
+for wl in url_like int64_gt; do grep -h '^{"metric"' $O/${wl}_trace.log; f=$(find $O/${wl}_trace -name "*kernel_stats.csv" | head -1); head -4 $f; done
