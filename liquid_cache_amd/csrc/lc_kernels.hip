@@ -812,6 +812,44 @@ __device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], u
     return rem == 0 ? sb : sel;
 }
 
+// Sequential walker over the same LDS image, one candidate per lane: used when an entry has at least a full wave of
+// candidates (no signature index, or no fingerprints at all: every dictionary value is walked), where one lane per value
+// keeps all 64 lanes busy and needs no cross-lane bookkeeping.  Escape handling inline: a marker (255 in code
+// position) leaves the state unchanged in the image and sends the next byte to the literal half of the row.
+__device__ __forceinline__ bool like_walk_seq(const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop,
+                                              uint32_t row0, uint32_t nl) {
+    uint32_t sb = row0;  // LDS address of the current state's row
+    uint32_t lit = 0;    // 512 while the next byte is an escaped literal
+    for (uint32_t p0 = start; p0 < stop; p0 += 64) {
+        uint64_t pw[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            pw[k] = 0;
+            if (p0 + 8u * uint32_t(k) < stop) pw[k] = load_unaligned<uint64_t>(fsst + p0 + 8u * uint32_t(k));
+        }
+#pragma unroll 1
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t p = p0 + 8u * k;
+            if (p >= stop) break;
+            const uint32_t rem = stop - p;
+            const uint64_t w = pw[0];
+#pragma unroll
+            for (int r = 0; r < 7; r++) pw[r] = pw[r + 1];
+#pragma unroll
+            for (uint32_t q = 0; q < 8; q++) {
+                const uint32_t c = uint32_t(w >> (8 * q)) & 0xFFu;
+                const uint32_t t = lds_u16(sb + lit + 2u * c);
+                const uint32_t next_lit = (lit == 0 && c == 255u) ? 512u : 0u;
+                if (q < rem) {
+                    sb = t;  // a marker maps the state to itself
+                    lit = next_lit;
+                }
+            }
+        }
+    }
+    return sb == row0 + nl * 1024u;
+}
+
 // 8-bit mask of the bytes of (lo, hi) that equal 0xFF
 __device__ __forceinline__ uint32_t marker_mask(uint32_t lo, uint32_t hi) {
     auto m4 = [](uint32_t w) {
@@ -1115,7 +1153,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             if (L.d_cand_bytes && !prune) cand_bytes += stop - start;
             LC_TM(3, start);
             bool res = false;
-            if (kSub && tbl_in_lds) {
+            if (kSub && tbl_in_lds && n_walk - jb >= uint32_t(kWave)) {
+                // a full wave of candidates: one value per lane
+                res = like_walk_seq(d.fsst, start, stop, row0, nl);
+            } else if (kSub && tbl_in_lds) {
                 // lane-parallel walk: one lane per 8-byte word of every candidate (see above)
                 const uint32_t hitrow = row0 + nl * 1024u;
                 const uint32_t words = cl ? max(1u, (stop - start + 7u) >> 3) : 0u;
