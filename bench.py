@@ -284,6 +284,33 @@ def main():
     kernel_ms = scan.eval_timed(expr, mask.data_ptr(), max(5, args.steps), 0, counts.data_ptr(), stream)
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
 
+    # get-with-selection over the same column: selected rows' decoded values compacted in row order.
+    # Extra measurement next to the headline (not part of `value`): ~10 % of the rows, chosen by a second predicate.
+    gather = None
+    if args.workload == "int64_gt" and rank == 0:
+        import pyarrow as pa
+        sel_lit = base + int((1 << args.int_bits) * 0.9)
+        sel_mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
+        scan.eval(lc.LiquidExpr.try_new(">", sel_lit, pa.int64()), sel_mask.data_ptr(), 0, counts.data_ptr(), stream)
+        k_sel = int(counts.sum(dtype=torch.int64).item())
+        vals = torch.zeros(max(k_sel, 1) + 8, dtype=torch.int64, device="cuda")
+        offs = torch.zeros(scan.entries + 1, dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            scan.gather_fixed(vals.data_ptr(), vals.numel() * 8, offs.data_ptr(), sel_mask.data_ptr(), stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = max(5, args.steps)
+        e0.record()
+        for _ in range(iters):
+            scan.gather_fixed(vals.data_ptr(), vals.numel() * 8, offs.data_ptr(), sel_mask.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        g_ms = e0.elapsed_time(e1) / iters
+        # algorithmic bytes: n*W/8 packed + n/8 selection read, k*sizeof(T) written
+        g_bytes = scan.rows * args.int_bits // 8 + scan.rows // 8 + k_sel * 8
+        gather = {"kernels": "k_sel_block_counts + k_scan_{tile_sums,tiles,apply} + k_fixed_gather<u64>", "selected_rows": k_sel,
+                  "ms": g_ms, "algorithmic_bytes": int(g_bytes), "achieved_gbs": g_bytes / (g_ms * 1e-3) / 1e9,
+                  "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "rows_per_s": scan.rows / (g_ms * 1e-3)}
+
     out = None
     if rank == 0:
         traffic, traffic_src = measured_traffic(workload)
@@ -314,6 +341,8 @@ def main():
                          "kernel": "k_str_pred" if args.workload == "url_like" else "k_fixed_pred<u64>",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes)},
         }
+        if gather is not None:
+            out["get_with_selection"] = gather
         if world == 1 and not args.no_cpu_baseline:
             n_sample = args.cpu_batches or n_batches  # ~5 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
             if args.workload == "url_like":

@@ -493,6 +493,47 @@ class Scan:
                                              C.byref(ms)), self._cache.handle)
         return ms.value
 
+    def gather_fixed(self, values_out_ptr: int, capacity_bytes: int, row_offsets_ptr: int, selection_ptr: int = 0,
+                     stream: int = 0):
+        """get-with-selection over the whole scan (fixed-width columns): decoded values of the selected rows, compacted
+        in row order into `values_out_ptr` (device); `row_offsets_ptr` (entries+1 u64, device) receives the exclusive
+        prefix sum of per-entry selected counts.  Asynchronous on `stream`."""
+        N.check(self._lib.lc_scan_gather_fixed(self._cache.handle, self._h, C.c_void_p(selection_ptr or None),
+                                               C.c_void_p(values_out_ptr), capacity_bytes, C.c_void_p(row_offsets_ptr),
+                                               C.c_void_p(stream or None)), self._cache.handle)
+
+    def date_part(self, values_ptr: int, n_values: int, field: int, stream: int = 0):
+        """ExtractDate32 over gathered Date32 / Timestamp values, in place (lc_scan_date_part)."""
+        N.check(self._lib.lc_scan_date_part(self._cache.handle, self._h, C.c_void_p(values_ptr), n_values, int(field),
+                                            C.c_void_p(stream or None)), self._cache.handle)
+
+    def gather_fixed_to_host(self, np_dtype, selection: Optional[np.ndarray] = None, date_field: Optional[int] = None):
+        """Convenience for tests: (values ndarray of the selected rows, row offsets)."""
+        lib, ctx = self._lib, self._cache.handle
+        width = np.dtype(np_dtype).itemsize
+        k_max = int(self.rows)
+        d_vals, d_offs, d_sel = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(lib.lc_device_alloc(ctx, max(k_max, 1) * width + 64, C.byref(d_vals)), ctx)
+        N.check(lib.lc_device_alloc(ctx, (self.entries + 1) * 8, C.byref(d_offs)), ctx)
+        try:
+            if selection is not None:
+                sel = np.ascontiguousarray(selection, dtype=np.uint64)
+                N.check(lib.lc_device_alloc(ctx, max(sel.size, 1) * 8, C.byref(d_sel)), ctx)
+                N.check(lib.lc_host_to_device(ctx, d_sel, sel.ctypes.data_as(C.c_void_p), sel.size * 8, None), ctx)
+            self.gather_fixed(d_vals.value, max(k_max, 1) * width, d_offs.value, d_sel.value or 0)
+            offs = np.zeros(self.entries + 1, np.uint64)
+            N.check(lib.lc_device_to_host(ctx, offs.ctypes.data_as(C.c_void_p), d_offs, offs.size * 8, None), ctx)
+            k = int(offs[-1])
+            if date_field is not None:
+                self.date_part(d_vals.value, k, date_field)
+            vals = np.zeros(max(k, 1), np_dtype)
+            N.check(lib.lc_device_to_host(ctx, vals.ctypes.data_as(C.c_void_p), d_vals, k * width, None), ctx)
+        finally:
+            for p in (d_vals, d_offs, d_sel):
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+        return vals[:k], offs
+
     def eval_to_host(self, expr: LiquidExpr, selection: Optional[np.ndarray] = None):
         """Convenience for tests: runs the scan and returns (mask words as uint64 ndarray, per-entry counts)."""
         lib, ctx = self._lib, self._cache.handle

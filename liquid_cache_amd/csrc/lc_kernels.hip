@@ -1540,7 +1540,7 @@ __global__ __launch_bounds__(kThreads) void k_mask_and_then(const uint64_t* __re
 // ------------------------------------------------------------------------------------------------
 // get-with-selection for fixed-width encodings (LiquidArray::filter, primitive_array.rs:370-374 et al.):
 //   k_sel_block_counts  popcount of the selection per 1024-row block
-//   k_exclusive_scan    block counts -> output row offset of every block (+ per-entry row offsets)
+//   k_scan_*            block counts -> output row offset of every block (+ per-entry row offsets)
 //   k_fixed_gather      unpack + FoR (+ ALP decode / decimal widening) and compact the selected rows, in order
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_sel_block_counts(const FixedDesc* __restrict__ descs, ScanLaunch L,
@@ -1568,39 +1568,73 @@ __global__ __launch_bounds__(kThreads) void k_sel_block_counts(const FixedDesc* 
 }
 
 // single workgroup exclusive scan; also emits per-entry row offsets (n_entries + 1 values)
-__global__ __launch_bounds__(1024) void k_exclusive_scan(const uint32_t* __restrict__ counts, uint64_t n,
-                                                         uint32_t blocks_per_entry, uint64_t* __restrict__ offsets,
-                                                         uint64_t* __restrict__ entry_offsets) {
-    __shared__ uint64_t wave_tot[16];
-    __shared__ uint64_t carry;
+// Exclusive scan of the block counts in three small launches (a single workgroup walking ~100 K counts took 150 us):
+//   k_scan_tile_sums   one workgroup per 1024 counts -> tile sum
+//   k_scan_tiles       one workgroup scans the tile sums (exclusive, in place; total appended)
+//   k_scan_apply       every workgroup rescans its tile on top of its tile offset
+__device__ __forceinline__ uint64_t block_inclusive_scan_1024(uint64_t v, uint64_t* wave_tot /* [16] shared */,
+                                                              uint64_t* block_total) {
     const int lane = lane_id(), wave = wave_id();
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < n; base += 1024) {
-        const uint64_t i = base + threadIdx.x;
-        const uint64_t v = i < n ? counts[i] : 0;
-        uint64_t incl = v;
+    uint64_t incl = v;
 #pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) {
-            const uint64_t t = __shfl_up(incl, o, kWave);
-            if (lane >= o) incl += t;
-        }
-        if (lane == kWave - 1) wave_tot[wave] = incl;
-        __syncthreads();
-        uint64_t wbase = carry;
-        for (int w = 0; w < wave; w++) wbase += wave_tot[w];
-        const uint64_t excl = wbase + incl - v;
-        if (i < n) {
-            offsets[i] = excl;
-            if (entry_offsets && (i % blocks_per_entry) == 0) entry_offsets[i / blocks_per_entry] = excl;
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = wbase + incl;
-        __syncthreads();
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint64_t t = __shfl_up(incl, o, kWave);
+        if (lane >= o) incl += t;
     }
-    if (threadIdx.x == 0) {
-        offsets[n] = carry;
-        if (entry_offsets) entry_offsets[n / blocks_per_entry] = carry;
+    if (lane == kWave - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    uint64_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        const uint64_t t = wave_tot[w];
+        if (w < wave) wbase += t;
+        total += t;
+    }
+    __syncthreads();
+    *block_total = total;
+    return wbase + incl;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tile_sums(const uint32_t* __restrict__ counts, uint64_t n,
+                                                         uint64_t* __restrict__ tile_sums) {
+    __shared__ uint64_t wave_tot[16];
+    const uint64_t i = uint64_t(blockIdx.x) * 1024 + threadIdx.x;
+    uint64_t total;
+    (void)block_inclusive_scan_1024(i < n ? counts[i] : 0, wave_tot, &total);
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_tiles(uint64_t* __restrict__ tile_sums, uint64_t n_tiles) {
+    __shared__ uint64_t wave_tot[16];
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n_tiles; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n_tiles ? tile_sums[i] : 0;
+        uint64_t total;
+        const uint64_t incl = block_inclusive_scan_1024(v, wave_tot, &total);
+        if (i < n_tiles) tile_sums[i] = carry + incl - v;
+        carry += total;
+    }
+    if (threadIdx.x == 0) tile_sums[n_tiles] = carry;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict__ counts, uint64_t n,
+                                                     uint32_t blocks_per_entry, const uint64_t* __restrict__ tile_offsets,
+                                                     uint64_t n_tiles, uint64_t* __restrict__ offsets,
+                                                     uint64_t* __restrict__ entry_offsets) {
+    __shared__ uint64_t wave_tot[16];
+    const uint64_t i = uint64_t(blockIdx.x) * 1024 + threadIdx.x;
+    const uint64_t v = i < n ? counts[i] : 0;
+    uint64_t total;
+    const uint64_t incl = block_inclusive_scan_1024(v, wave_tot, &total);
+    const uint64_t excl = tile_offsets[blockIdx.x] + incl - v;
+    if (i < n) {
+        offsets[i] = excl;
+        if (entry_offsets && (i % blocks_per_entry) == 0) entry_offsets[i / blocks_per_entry] = excl;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        offsets[n] = tile_offsets[n_tiles];
+        if (entry_offsets) entry_offsets[n / blocks_per_entry] = tile_offsets[n_tiles];
     }
 }
 
@@ -1948,8 +1982,13 @@ hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const Sc
     if (waves == 0) return hipSuccess;
     const dim3 grid(uint32_t((waves + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
     hipLaunchKernelGGL(k_sel_block_counts, grid, block, 0, stream, d_descs, L, d_block_counts);
-    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, stream, d_block_counts, waves, L.blocks_per_entry,
-                       d_block_offsets, d_entry_row_offsets);
+    // tile sums live behind the n + 1 block offsets (the callers size d_block_offsets with fixed_gather_offsets_len)
+    const uint64_t n_tiles = (waves + 1023) / 1024;
+    uint64_t* d_tiles = d_block_offsets + waves + 1;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_block_counts, waves, d_tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, d_tiles, n_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_block_counts, waves,
+                       L.blocks_per_entry, d_tiles, n_tiles, d_block_offsets, d_entry_row_offsets);
     switch (lane_log2) {
         case 3: hipLaunchKernelGGL(k_fixed_gather<uint8_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
         case 4: hipLaunchKernelGGL(k_fixed_gather<uint16_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;

@@ -145,6 +145,8 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
                            const ScanLaunch& L, hipStream_t stream);
 // per-block selected-row counts -> exclusive offsets, then compaction of decoded values
 // d_block_counts: n_entries*blocks_per_entry u32; d_block_offsets: that + 1 u64; d_entry_row_offsets: n_entries + 1 u64
+// u64 elements the caller provides for d_block_offsets: n_blocks + 1 offsets followed by the scan's tile sums
+inline size_t fixed_gather_offsets_len(size_t n_blocks) { return n_blocks + 1 + (n_blocks + 1023) / 1024 + 1; }
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
                                hipStream_t stream);

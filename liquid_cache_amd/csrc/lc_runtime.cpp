@@ -1373,7 +1373,7 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
         L.d_selection = d_sel;
         const size_t vw = e.fd.value_width;
         uint32_t* d_bc = static_cast<uint32_t*>(dalloc(size_t(scan->bpe) * 4));
-        uint64_t* d_bo = static_cast<uint64_t*>(dalloc((size_t(scan->bpe) + 1) * 8));
+        uint64_t* d_bo = static_cast<uint64_t*>(dalloc(fixed_gather_offsets_len(scan->bpe) * 8));
         uint64_t* d_eo = static_cast<uint64_t*>(dalloc(2 * 8));
         uint8_t* d_vals = static_cast<uint8_t*>(dalloc(std::max<size_t>(k, 1) * vw + 64));
         if (!d_bc || !d_bo || !d_eo || !d_vals) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
@@ -1435,7 +1435,7 @@ lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selecti
     hipStream_t st = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> g(scan->mu);
     const size_t nblk = size_t(scan->n) * scan->bpe;
-    const size_t need = nblk * 4 + (nblk + 1) * 8 + 64;
+    const size_t need = nblk * 4 + fixed_gather_offsets_len(nblk) * 8 + 64;
     if (need > scan->needle_cap) {  // reuse the scan's scratch allocation
         LC_HIP(hipStreamSynchronize(st));
         if (scan->d_needle) LC_HIP(hipFree(scan->d_needle));
@@ -1443,7 +1443,7 @@ lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selecti
         scan->needle_cap = need;
     }
     uint64_t* d_bo = reinterpret_cast<uint64_t*>(scan->d_needle);
-    uint32_t* d_bc = reinterpret_cast<uint32_t*>(scan->d_needle + (nblk + 1) * 8);
+    uint32_t* d_bc = reinterpret_cast<uint32_t*>(scan->d_needle + fixed_gather_offsets_len(nblk) * 8);
     ScanLaunch L{};
     L.n_entries = scan->n;
     L.blocks_per_entry = scan->bpe;

@@ -396,6 +396,44 @@ def test_get_with_selection_floats_and_decimals(gpu_cache, oracle):
     assert gpu_cache.get(900).read().to_pylist() == arr.to_pylist()
 
 
+def test_scan_gather_fixed(gpu_cache, oracle):
+    """get-with-selection over a whole scan: mask of a predicate -> compacted decoded values, row order."""
+    rng = np.random.default_rng(31)
+    n_batches, n = 7, 8192
+    total = n_batches * n - 333
+    for np_dt, pa_dt, lo_hi in ((np.int64, pa.int64(), (-2**40, 2**40)), (np.int32, pa.int32(), (0, 4000)),
+                                (np.int32, pa.date32(), (7000, 12000)), (np.float64, pa.float64(), None)):
+        if lo_hi is None:
+            vals = (rng.integers(-10**6, 10**6, size=total) / 100.0).astype(np_dt)
+        else:
+            vals = rng.integers(lo_hi[0], lo_hi[1], size=total).astype(np_dt)
+        ids = []
+        for k in range(n_batches):
+            eid = lc.ParquetArrayID.new(3, int(np.dtype(np_dt).itemsize) + (pa_dt == pa.date32()), len(ids), k)
+            gpu_cache.insert(eid, pa.array(vals[k * n: min((k + 1) * n, total)], type=pa_dt))
+            ids.append(eid)
+        scan = gpu_cache.scan(ids)
+        got, offs = scan.gather_fixed_to_host(np_dt)                       # no selection: everything, in order
+        assert got.view(np.uint8).tobytes() == vals.view(np.uint8).tobytes()
+        assert offs.tolist() == [min(k * n, total) for k in range(n_batches + 1)]
+        keep = rng.random(total) < 0.13
+        words = np.zeros(int(scan.mask_words), np.uint64)
+        for k in range(n_batches):
+            seg = keep[k * n: min((k + 1) * n, total)]
+            packed = np.packbits(seg, bitorder="little")
+            w0 = int(scan.segment_offsets[k])
+            words[w0: w0 + (len(seg) + 63) // 64].view(np.uint8)[: len(packed)] = packed
+        got, offs = scan.gather_fixed_to_host(np_dt, selection=words)
+        assert got.view(np.uint8).tobytes() == vals[keep].view(np.uint8).tobytes()
+        assert int(offs[-1]) == int(keep.sum())
+        if pa_dt == pa.date32():
+            lo = oracle
+            got, _ = scan.gather_fixed_to_host(np_dt, selection=words, date_field=lc.Date32Field.MONTH)
+            want = [lo.date_lossy_days(1, lo.date_component(1, int(d))) for d in vals[keep]]
+            assert got.tolist() == want
+        scan.close()
+
+
 def test_get_with_date_part_hint(gpu_cache, oracle):
     """cache.get(id).with_expression_hint(extract_date32(field)) == SqueezedDate32Array's lossy reconstruction."""
     lo = oracle
