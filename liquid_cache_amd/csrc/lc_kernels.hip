@@ -1667,9 +1667,13 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
     uint64_t out_row = block_offsets[gw];
     uint8_t* buf = lds[wave];
     const uint32_t W = d.W;
-    if (W != 0) {
+    // Sparse blocks (the usual case after a selective filter): fetch only the one or two packed words of each selected
+    // row straight from HBM instead of staging the whole 128*W-byte block (break-even ~30 rows of two 128-byte lines).
+    const uint8_t* gblk = d.packed + uint64_t(blk) * 128u * W;
+    const bool sparse = block_offsets[gw + 1] - out_row <= 16u;
+    if (W != 0 && !sparse) {
         const uint32_t nchunks = 8u * W;
-        const uint4* src = reinterpret_cast<const uint4*>(d.packed + uint64_t(blk) * 128u * W);
+        const uint4* src = reinterpret_cast<const uint4*>(gblk);
         constexpr int kSteps = int(kBlockBytesMax / 1024u) > 0 ? int(kBlockBytesMax / 1024u) : 1;
 #pragma unroll
         for (int s = 0; s < kSteps; s++) {
@@ -1693,7 +1697,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
             if (W != 0) {  // all-null entries decode to zeros (PrimitiveArray::new_null)
                 uint32_t row, fl;
                 fl_row_lane<U>(it * 64u + uint32_t(lane), &row, &fl);
-                u = extract_packed<U>(buf, row, fl, W, mask);
+                u = sparse ? extract_packed<U>(gblk, row, fl, W, mask) : extract_packed<U>(buf, row, fl, W, mask);
             }
             const uint64_t o = out_row + lanes_below(aw);
             if (d.kind == kKindInt) {

@@ -416,16 +416,17 @@ def test_scan_gather_fixed(gpu_cache, oracle):
         got, offs = scan.gather_fixed_to_host(np_dt)                       # no selection: everything, in order
         assert got.view(np.uint8).tobytes() == vals.view(np.uint8).tobytes()
         assert offs.tolist() == [min(k * n, total) for k in range(n_batches + 1)]
-        keep = rng.random(total) < 0.13
-        words = np.zeros(int(scan.mask_words), np.uint64)
-        for k in range(n_batches):
-            seg = keep[k * n: min((k + 1) * n, total)]
-            packed = np.packbits(seg, bitorder="little")
-            w0 = int(scan.segment_offsets[k])
-            words[w0: w0 + (len(seg) + 63) // 64].view(np.uint8)[: len(packed)] = packed
-        got, offs = scan.gather_fixed_to_host(np_dt, selection=words)
-        assert got.view(np.uint8).tobytes() == vals[keep].view(np.uint8).tobytes()
-        assert int(offs[-1]) == int(keep.sum())
+        for p_sel in (0.13, 0.002):   # dense blocks are staged through LDS, sparse ones fetch single words
+            keep = rng.random(total) < p_sel
+            words = np.zeros(int(scan.mask_words), np.uint64)
+            for k in range(n_batches):
+                seg = keep[k * n: min((k + 1) * n, total)]
+                packed = np.packbits(seg, bitorder="little")
+                w0 = int(scan.segment_offsets[k])
+                words[w0: w0 + (len(seg) + 63) // 64].view(np.uint8)[: len(packed)] = packed
+            got, offs = scan.gather_fixed_to_host(np_dt, selection=words)
+            assert got.view(np.uint8).tobytes() == vals[keep].view(np.uint8).tobytes()
+            assert int(offs[-1]) == int(keep.sum())
         if pa_dt == pa.date32():
             lo = oracle
             got, _ = scan.gather_fixed_to_host(np_dt, selection=words, date_field=lc.Date32Field.MONTH)
