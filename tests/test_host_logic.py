@@ -217,3 +217,12 @@ def test_row_range_sharding_keeps_columns_together():
                 k = sh.row_range_key(e)
                 assert last is None or k >= last
                 last = k
+
+
+def test_expression_hint_mirror():
+    """CacheExpression::extract_date32 / Date32Field mirror (cache/expressions.rs:82-84, squeezed_date32_array.rs)."""
+    import liquid_cache_amd as lc
+    h = lc.CacheExpression.extract_date32(lc.Date32Field.MONTH)
+    assert isinstance(h, lc.ExtractDate32) and h.field == 1
+    assert lc.CacheExpression.extract_date32("year").field == 0
+    assert lc.CacheExpression.extract_date32("DayOfWeek").field == 3
