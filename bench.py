@@ -309,7 +309,7 @@ def main():
         g_ms = e0.elapsed_time(e1) / iters
         # algorithmic bytes: n*W/8 packed + n/8 selection read, k*sizeof(T) written
         g_bytes = scan.rows * args.int_bits // 8 + scan.rows // 8 + k_sel * 8
-        gather = {"kernels": "k_sel_block_counts + k_scan_{tile_sums,tiles,apply} + k_fixed_gather<u64>", "selected_rows": k_sel,
+        gather = {"kernels": "k_sel_entry_counts + k_scan_{tile_sums,tiles,apply} + k_fixed_gather<u64>", "selected_rows": k_sel,
                   "ms": g_ms, "algorithmic_bytes": int(g_bytes), "achieved_gbs": g_bytes / (g_ms * 1e-3) / 1e9,
                   "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "rows_per_s": scan.rows / (g_ms * 1e-3)}
         gather_all[sel_name] = gather

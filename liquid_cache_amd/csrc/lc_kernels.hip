@@ -1539,36 +1539,31 @@ __global__ __launch_bounds__(kThreads) void k_mask_and_then(const uint64_t* __re
 
 // ------------------------------------------------------------------------------------------------
 // get-with-selection for fixed-width encodings (LiquidArray::filter, primitive_array.rs:370-374 et al.):
-//   k_sel_block_counts  popcount of the selection per 1024-row block
+//   k_sel_entry_counts  popcount of the selection per entry
 //   k_scan_*            block counts -> output row offset of every block (+ per-entry row offsets)
 //   k_fixed_gather      unpack + FoR (+ ALP decode / decimal widening) and compact the selected rows, in order
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_sel_block_counts(const FixedDesc* __restrict__ descs, ScanLaunch L,
-                                                               uint32_t* __restrict__ block_counts) {
-    const int lane = lane_id(), wave = wave_id();
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + uint32_t(wave);
-    const uint32_t entry = gw / L.blocks_per_entry, blk = gw % L.blocks_per_entry;
-    if (entry >= L.n_entries) return;
-    const uint32_t len = descs[entry].len;
-    const uint32_t row0 = blk * 1024u;
-    uint32_t c = 0;
-    if (row0 < len) {
-        const uint32_t rows = min(1024u, len - row0);
-        const uint32_t nwords = (rows + 63u) >> 6;
-        if (uint32_t(lane) < nwords) {
+__global__ __launch_bounds__(kThreads) void k_sel_entry_counts(const FixedDesc* __restrict__ descs, ScanLaunch L,
+                                                               uint32_t* __restrict__ entry_counts) {
+    const int lane = lane_id();
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < L.n_entries; entry += total_waves) {
+        const uint32_t len = descs[entry].len;
+        const uint64_t word_base = descs[entry].mask_word_off;
+        const uint32_t nwords = (len + 63u) >> 6;
+        uint32_t c = 0;
+        for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
             uint64_t tail = ~uint64_t(0);
-            if (uint32_t(lane) == nwords - 1 && (rows & 63u)) tail = (uint64_t(1) << (rows & 63u)) - 1;
-            const uint64_t w = L.d_selection ? L.d_selection[descs[entry].mask_word_off + uint64_t(blk) * 16u + lane]
-                                             : ~uint64_t(0);
-            c = uint32_t(__popcll(w & tail));
+            if (w == nwords - 1 && (len & 63u)) tail = (uint64_t(1) << (len & 63u)) - 1;
+            const uint64_t sw = L.d_selection ? L.d_selection[word_base + w] : ~uint64_t(0);
+            c += uint32_t(__popcll(sw & tail));
         }
+        c = uint32_t(wave_sum_u64(c));
+        if (lane == 0) entry_counts[entry] = c;
     }
-    c = uint32_t(wave_sum_u64(c));
-    if (lane == 0) block_counts[gw] = c;
 }
 
-// single workgroup exclusive scan; also emits per-entry row offsets (n_entries + 1 values)
-// Exclusive scan of the block counts in three small launches (a single workgroup walking ~100 K counts took 150 us):
+// Exclusive scan of the counts in three small launches (a single workgroup walking ~100 K counts took 150 us):
 //   k_scan_tile_sums   one workgroup per 1024 counts -> tile sum
 //   k_scan_tiles       one workgroup scans the tile sums (exclusive, in place; total appended)
 //   k_scan_apply       every workgroup rescans its tile on top of its tile offset
@@ -1641,18 +1636,18 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
 
 template <typename U>
 __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __restrict__ descs, ScanLaunch L,
-                                                            const uint64_t* __restrict__ block_offsets,
+                                                            const uint64_t* __restrict__ entry_offsets,
                                                             uint8_t* __restrict__ out) {
     constexpr uint32_t TB = LaneTraits<U>::kBits;
     constexpr uint32_t kBlockBytesMax = 128u * TB;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][kBlockBytesMax + 128];
     const int lane = lane_id(), wave = wave_id();
-    const uint32_t gw = blockIdx.x * kWavesPerBlock + uint32_t(wave);
-    const uint32_t entry = gw / L.blocks_per_entry, blk = gw % L.blocks_per_entry;
-    if (entry >= L.n_entries) return;
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    // persistent grid, one wave per ENTRY (descriptor read once, blocks in turn, running output row)
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave); entry < L.n_entries; entry += total_waves) {
     const FixedDesc d = descs[entry];
-    const uint32_t row0 = blk * 1024u;
-    if (row0 >= d.len) return;
+    uint64_t entry_out_row = entry_offsets[entry];
+    for (uint32_t blk = 0, row0 = 0; row0 < d.len; blk++, row0 += 1024u) {
     const uint32_t rows = min(1024u, d.len - row0);
     const uint32_t nwords = (rows + 63u) >> 6;
     const uint64_t word_base = d.mask_word_off + uint64_t(blk) * 16u;
@@ -1662,15 +1657,18 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
         if (uint32_t(lane) == nwords - 1 && (rows & 63u)) tail = (uint64_t(1) << (rows & 63u)) - 1;
         act = (L.d_selection ? L.d_selection[word_base + lane] : ~uint64_t(0)) & tail;
     }
-    if (__ballot(act != 0) == 0) return;
+    const uint32_t blk_count = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(wave_sum_u64(uint64_t(__popcll(act)))))));
+    if (blk_count == 0) continue;
+    const uint64_t blk_out_row = entry_out_row;
+    entry_out_row += blk_count;
     const uint32_t vw = d.value_width;
-    uint64_t out_row = block_offsets[gw];
+    uint64_t out_row = blk_out_row;
     uint8_t* buf = lds[wave];
     const uint32_t W = d.W;
     // Sparse blocks (the usual case after a selective filter): fetch only the one or two packed words of each selected
     // row straight from HBM instead of staging the whole 128*W-byte block (break-even ~30 rows of two 128-byte lines).
     const uint8_t* gblk = d.packed + uint64_t(blk) * 128u * W;
-    const bool sparse = block_offsets[gw + 1] - out_row <= 16u;
+    const bool sparse = blk_count <= 16u;
     if (W != 0 && !sparse) {
         const uint32_t nchunks = 8u * W;
         const uint4* src = reinterpret_cast<const uint4*>(gblk);
@@ -1733,7 +1731,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
             const uint32_t mid = (lo_i + hi_i) >> 1;
             if (d.patch_idx[mid] < row0) lo_i = mid + 1; else hi_i = mid;
         }
-        const uint64_t base_row = block_offsets[gw];
+        const uint64_t base_row = blk_out_row;
         for (uint32_t p = lo_i + uint32_t(lane); p < d.patch_len; p += kWave) {
             const uint64_t idx = d.patch_idx[p];
             if (idx >= uint64_t(row0) + rows) break;
@@ -1758,6 +1756,9 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
             }
         }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the LDS block buffer is reused by the next block
+    }  // blocks
+    }  // entries
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1982,22 +1983,26 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
                                hipStream_t stream) {
-    const uint64_t waves = uint64_t(L.n_entries) * L.blocks_per_entry;
-    if (waves == 0) return hipSuccess;
-    const dim3 grid(uint32_t((waves + kWavesPerBlock - 1) / kWavesPerBlock)), block(kThreads);
-    hipLaunchKernelGGL(k_sel_block_counts, grid, block, 0, stream, d_descs, L, d_block_counts);
-    // tile sums live behind the n + 1 block offsets (the callers size d_block_offsets with fixed_gather_offsets_len)
-    const uint64_t n_tiles = (waves + 1023) / 1024;
-    uint64_t* d_tiles = d_block_offsets + waves + 1;
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_block_counts, waves, d_tiles);
+    if (L.n_entries == 0) return hipSuccess;
+    // per-entry selected counts -> exclusive scan (= the entry row offsets the API returns) -> gather; the first two
+    // scratch arrays are sized per 1024-row block by the callers, which covers the per-entry use here
+    const uint64_t n = L.n_entries;
+    const uint64_t wgs_needed = (n + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 block(kThreads);
+    const dim3 grid_counts(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8)));
+    hipLaunchKernelGGL(k_sel_entry_counts, grid_counts, block, 0, stream, d_descs, L, d_block_counts);
+    const uint64_t n_tiles = (n + 1023) / 1024;
+    uint64_t* d_tiles = d_block_offsets;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_block_counts, n, d_tiles);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, d_tiles, n_tiles);
-    hipLaunchKernelGGL(k_scan_apply, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_block_counts, waves,
-                       L.blocks_per_entry, d_tiles, n_tiles, d_block_offsets, d_entry_row_offsets);
+    hipLaunchKernelGGL(k_scan_apply, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_block_counts, n, 1u, d_tiles, n_tiles,
+                       d_entry_row_offsets, static_cast<uint64_t*>(nullptr));
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * (lane_log2 == 6 ? 4 : 8))));
     switch (lane_log2) {
-        case 3: hipLaunchKernelGGL(k_fixed_gather<uint8_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
-        case 4: hipLaunchKernelGGL(k_fixed_gather<uint16_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
-        case 5: hipLaunchKernelGGL(k_fixed_gather<uint32_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
-        case 6: hipLaunchKernelGGL(k_fixed_gather<uint64_t>, grid, block, 0, stream, d_descs, L, d_block_offsets, d_values_out); break;
+        case 3: hipLaunchKernelGGL(k_fixed_gather<uint8_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
+        case 4: hipLaunchKernelGGL(k_fixed_gather<uint16_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
+        case 5: hipLaunchKernelGGL(k_fixed_gather<uint32_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
+        case 6: hipLaunchKernelGGL(k_fixed_gather<uint64_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
