@@ -249,6 +249,21 @@ LC_API lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
 LC_API lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_values_out,
                                       uint64_t values_capacity_bytes, void* d_row_offsets, void* stream);
 
+/* get-with-selection over a whole byte-view scan, device resident (LiquidByteViewArray::filter + to_arrow,
+ * byte_view_array/mod.rs:421-424, 266-290, for every entry of the scan): the selected rows' decoded values in row order
+ * as (value offsets, bytes), i.e. the buffers of an Arrow LargeBinary / LargeUtf8 array.
+ *   plan: d_row_offsets (n+1 u64) receives the exclusive prefix sum of per-entry selected counts; d_row_refs
+ *         (capacity_rows u64: entry index << 32 | row) and d_value_offsets (capacity_rows+1 u64) describe the k selected
+ *         rows; d_row_valid (capacity_rows bytes, optional) their validity; nulls have length 0.  *out_rows = k,
+ *         *out_bytes = total decoded bytes.  Synchronises `stream`.  LC_ERR_INVALID (with *out_rows set) when k exceeds
+ *         capacity_rows.
+ *   fill: decodes the k values into d_data (>= *out_bytes).  Asynchronous on `stream`. */
+LC_API lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_row_offsets,
+                                           void* d_row_refs, void* d_value_offsets, void* d_row_valid,
+                                           uint64_t capacity_rows, uint64_t* out_rows, uint64_t* out_bytes, void* stream);
+LC_API lc_status lc_scan_gather_bytes(lc_ctx* ctx, lc_scan* scan, const void* d_row_refs, const void* d_value_offsets,
+                                      uint64_t rows, void* d_data, void* stream);
+
 /* ExtractDate32 over gathered values of a Date32 / Timestamp scan: replaces `n_values` decoded values in d_values
  * (as written by lc_scan_gather_fixed) in place by their lossy date-part reconstruction (see
  * lc_get_date_part_with_selection).  Asynchronous on `stream`. */

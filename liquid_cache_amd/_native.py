@@ -61,7 +61,7 @@ ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offse
 EXPORTED_SYMBOLS = [
     "lc_ctx_create", "lc_ctx_destroy", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
-    "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_mask_and_then", "lc_scan_create",
+    "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
@@ -106,6 +106,9 @@ def load():
     L.lc_get_date_part_with_selection.restype = i32
     L.lc_get_date_part_with_selection.argtypes = [vp, u64, vp, i32, vp, vp]
     L.lc_scan_date_part.restype = i32; L.lc_scan_date_part.argtypes = [vp, vp, vp, u64, i32, vp]
+    L.lc_scan_gather_bytes_plan.restype = i32
+    L.lc_scan_gather_bytes_plan.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, P(u64), P(u64), vp]
+    L.lc_scan_gather_bytes.restype = i32; L.lc_scan_gather_bytes.argtypes = [vp, vp, vp, vp, u64, vp, vp]
     L.lc_mask_and_then.restype = i32; L.lc_mask_and_then.argtypes = [vp, vp, u64, vp, u64, vp]
     L.lc_scan_create.restype = i32; L.lc_scan_create.argtypes = [vp, u64, P(u64), P(vp)]
     L.lc_scan_destroy.restype = None; L.lc_scan_destroy.argtypes = [vp]

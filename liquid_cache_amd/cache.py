@@ -17,6 +17,7 @@ expression not supported ("caller falls back").
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import datetime
 import decimal
 from typing import Iterable, Optional, Sequence, Union
@@ -274,6 +275,12 @@ class LiquidCache:
     # -- lifecycle ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None):
+            # scans hold device buffers of this context: destroy the ones still open before the context goes away
+            for ref in list(getattr(self, "_scans", [])):
+                scan = ref()
+                if scan is not None:
+                    scan.close()
+            self._scans = []
             self._lib.lc_ctx_destroy(self._ctx)
             self._ctx = None
 
@@ -453,6 +460,9 @@ class Scan:
         N.check(self._lib.lc_scan_create(cache.handle, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint64)),
                                          C.byref(h)), cache.handle)
         self._h = h
+        if not hasattr(cache, "_scans"):
+            cache._scans = []
+        cache._scans.append(weakref.ref(self))
         self.entries = len(ids)
         self.rows = self._lib.lc_scan_rows(h)
         self.mask_words = self._lib.lc_scan_mask_words(h)
@@ -506,6 +516,54 @@ class Scan:
         """ExtractDate32 over gathered Date32 / Timestamp values, in place (lc_scan_date_part)."""
         N.check(self._lib.lc_scan_date_part(self._cache.handle, self._h, C.c_void_p(values_ptr), n_values, int(field),
                                             C.c_void_p(stream or None)), self._cache.handle)
+
+    def gather_bytes_plan(self, row_offsets_ptr: int, row_refs_ptr: int, value_offsets_ptr: int, capacity_rows: int,
+                          selection_ptr: int = 0, row_valid_ptr: int = 0, stream: int = 0):
+        """First half of get-with-selection over a byte-view scan: (selected rows k, total decoded bytes)."""
+        k, nbytes = C.c_uint64(), C.c_uint64()
+        N.check(self._lib.lc_scan_gather_bytes_plan(self._cache.handle, self._h, C.c_void_p(selection_ptr or None),
+                                                    C.c_void_p(row_offsets_ptr), C.c_void_p(row_refs_ptr),
+                                                    C.c_void_p(value_offsets_ptr), C.c_void_p(row_valid_ptr or None),
+                                                    capacity_rows, C.byref(k), C.byref(nbytes),
+                                                    C.c_void_p(stream or None)), self._cache.handle)
+        return int(k.value), int(nbytes.value)
+
+    def gather_bytes(self, row_refs_ptr: int, value_offsets_ptr: int, rows: int, data_ptr: int, stream: int = 0):
+        N.check(self._lib.lc_scan_gather_bytes(self._cache.handle, self._h, C.c_void_p(row_refs_ptr),
+                                               C.c_void_p(value_offsets_ptr), rows, C.c_void_p(data_ptr),
+                                               C.c_void_p(stream or None)), self._cache.handle)
+
+    def gather_bytes_to_host(self, selection: Optional[np.ndarray] = None):
+        """Convenience for tests: list of bytes / None for the selected rows, in row order."""
+        lib, ctx = self._lib, self._cache.handle
+        cap = int(self.rows) if selection is None else int(np.unpackbits(np.ascontiguousarray(selection, np.uint64).view(np.uint8)).sum())
+        cap = max(cap, 1)
+        ptrs = [C.c_void_p() for _ in range(6)]
+        d_ro, d_refs, d_vo, d_valid, d_sel, d_data = ptrs
+        N.check(lib.lc_device_alloc(ctx, (self.entries + 1) * 8, C.byref(d_ro)), ctx)
+        N.check(lib.lc_device_alloc(ctx, cap * 8, C.byref(d_refs)), ctx)
+        N.check(lib.lc_device_alloc(ctx, (cap + 1) * 8, C.byref(d_vo)), ctx)
+        N.check(lib.lc_device_alloc(ctx, cap, C.byref(d_valid)), ctx)
+        try:
+            if selection is not None:
+                sel = np.ascontiguousarray(selection, dtype=np.uint64)
+                N.check(lib.lc_device_alloc(ctx, max(sel.size, 1) * 8, C.byref(d_sel)), ctx)
+                N.check(lib.lc_host_to_device(ctx, d_sel, sel.ctypes.data_as(C.c_void_p), sel.size * 8, None), ctx)
+            k, nbytes = self.gather_bytes_plan(d_ro.value, d_refs.value, d_vo.value, cap, d_sel.value or 0, d_valid.value)
+            N.check(lib.lc_device_alloc(ctx, max(nbytes, 1), C.byref(d_data)), ctx)
+            self.gather_bytes(d_refs.value, d_vo.value, k, d_data.value)
+            offs = np.zeros(k + 1, np.uint64)
+            valid = np.zeros(max(k, 1), np.uint8)
+            data = np.zeros(max(nbytes, 1), np.uint8)
+            N.check(lib.lc_device_to_host(ctx, offs.ctypes.data_as(C.c_void_p), d_vo, (k + 1) * 8, None), ctx)
+            N.check(lib.lc_device_to_host(ctx, valid.ctypes.data_as(C.c_void_p), d_valid, k, None), ctx)
+            N.check(lib.lc_device_to_host(ctx, data.ctypes.data_as(C.c_void_p), d_data, nbytes, None), ctx)
+        finally:
+            for p in ptrs:
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+        raw = data.tobytes()
+        return [raw[int(offs[i]): int(offs[i + 1])] if valid[i] else None for i in range(k)]
 
     def gather_fixed_to_host(self, np_dtype, selection: Optional[np.ndarray] = None, date_field: Optional[int] = None):
         """Convenience for tests: (values ndarray of the selected rows, row offsets)."""

@@ -1543,12 +1543,16 @@ __global__ __launch_bounds__(kThreads) void k_mask_and_then(const uint64_t* __re
 //   k_scan_*            block counts -> output row offset of every block (+ per-entry row offsets)
 //   k_fixed_gather      unpack + FoR (+ ALP decode / decimal widening) and compact the selected rows, in order
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_sel_entry_counts(const FixedDesc* __restrict__ descs, ScanLaunch L,
+__device__ __forceinline__ uint32_t desc_rows(const FixedDesc& d) { return d.len; }
+__device__ __forceinline__ uint32_t desc_rows(const StrDesc& d) { return d.n; }
+
+template <typename Desc>
+__global__ __launch_bounds__(kThreads) void k_sel_entry_counts(const Desc* __restrict__ descs, ScanLaunch L,
                                                                uint32_t* __restrict__ entry_counts) {
     const int lane = lane_id();
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < L.n_entries; entry += total_waves) {
-        const uint32_t len = descs[entry].len;
+        const uint32_t len = desc_rows(descs[entry]);
         const uint64_t word_base = descs[entry].mask_word_off;
         const uint32_t nwords = (len + 63u) >> 6;
         uint32_t c = 0;
@@ -1877,6 +1881,102 @@ __global__ __launch_bounds__(kThreads) void k_str_decode_rows_dyn(const StrDesc*
     str_decode_rows_body(descs, symtabs, entry, offsets, rows, uint32_t(totals[0]), data);
 }
 
+// ------------------------------------------------------------------------------------------------
+// get-with-selection over a whole byte-view scan, device resident (the projection step after a filter):
+//   k_sel_entry_counts<StrDesc> + k_scan_*   selected rows per entry -> entry row offsets (k = total)
+//   k_str_sel_rows    one wave per entry: selected rows in order -> (entry,row) reference + decoded length (nulls 0)
+//   k_scan_*          exclusive scan of the lengths -> value offsets
+//   k_str_decode_sel  one lane per selected row: decode its dictionary value at its offset
+// Cost is proportional to the selected rows (typically a tiny fraction after a LIKE / range filter).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t str_decoded_len(const StrDesc& d, const DevSymtab& st, uint32_t key) {
+    uint32_t start, stop;
+    str_offset_pair(d, key, start, stop);
+    ByteReader r;
+    r.init(d.fsst, start, stop);
+    uint32_t n = 0;
+    while (r.more()) {
+        const uint32_t c = r.next();
+        if (c == 255u) { if (!r.more()) break; r.next(); n++; }
+        else n += st.len[c];
+    }
+    return n;
+}
+
+__global__ __launch_bounds__(kThreads) void k_str_sel_rows(const StrDesc* __restrict__ descs,
+                                                           const DevSymtab* __restrict__ symtabs, ScanLaunch L,
+                                                           const uint64_t* __restrict__ entry_offsets, uint64_t capacity,
+                                                           uint64_t* __restrict__ row_refs, uint32_t* __restrict__ row_len,
+                                                           uint8_t* __restrict__ row_valid) {
+    const int lane = lane_id();
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < L.n_entries; entry += total_waves) {
+        const StrDesc d = descs[entry];
+        const DevSymtab& st = symtabs[d.symtab_slot];
+        const uint32_t nwords = (d.n + 63u) >> 6;
+        uint64_t out_row = entry_offsets[entry];
+        if (entry_offsets[entry + 1] == out_row) continue;  // nothing selected here
+        for (uint32_t wb = 0; wb < nwords; wb += kWave) {
+            // 64 selection words at once: lane l holds word wb + l; only the non-zero ones are visited
+            const uint32_t w = wb + uint32_t(lane);
+            uint64_t sw = 0;
+            if (w < nwords) {
+                sw = L.d_selection ? L.d_selection[d.mask_word_off + w] : ~uint64_t(0);
+                if (w == nwords - 1 && (d.n & 63u)) sw &= (uint64_t(1) << (d.n & 63u)) - 1;
+            }
+            const uint32_t cnt = uint32_t(__popcll(sw));
+            const uint32_t incl = wave_inclusive_sum(cnt);
+            uint64_t nz = __ballot(sw != 0);
+            while (nz) {  // wave uniform
+                const int src = __ffsll((long long)nz) - 1;
+                nz &= nz - 1;
+                const uint64_t word = __shfl(sw, src, kWave);
+                const uint32_t before = __shfl(incl - cnt, src, kWave);
+                if ((word >> lane) & 1) {
+                    const uint32_t row = (wb + uint32_t(src)) * 64u + uint32_t(lane);
+                    const uint64_t o = out_row + before + lanes_below(word);
+                    if (o < capacity) {
+                        const bool valid = d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true;
+                        row_refs[o] = (uint64_t(entry) << 32) | row;
+                        row_len[o] = valid ? str_decoded_len(d, st, d.keys[row]) : 0u;
+                        if (row_valid) row_valid[o] = valid ? 1 : 0;
+                    }
+                }
+            }
+            out_row += read_lane(incl, kWave - 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_str_decode_sel(const StrDesc* __restrict__ descs,
+                                                             const DevSymtab* __restrict__ symtabs,
+                                                             const uint64_t* __restrict__ row_refs,
+                                                             const uint64_t* __restrict__ value_offsets, uint64_t k,
+                                                             uint8_t* __restrict__ data) {
+    for (uint64_t r = uint64_t(blockIdx.x) * kThreads + threadIdx.x; r < k; r += uint64_t(gridDim.x) * kThreads) {
+        if (value_offsets[r + 1] == value_offsets[r]) continue;  // null or empty
+        const uint64_t ref = row_refs[r];
+        const StrDesc& d = descs[uint32_t(ref >> 32)];
+        const DevSymtab& st = symtabs[d.symtab_slot];
+        const uint32_t key = d.keys[uint32_t(ref)];
+        uint32_t start, stop;
+        str_offset_pair(d, key, start, stop);
+        uint8_t* o = data + value_offsets[r];
+        ByteReader br;
+        br.init(d.fsst, start, stop);
+        while (br.more()) {
+            const uint32_t c = br.next();
+            if (c == 255u) { if (!br.more()) break; *o++ = uint8_t(br.next()); }
+            else {
+                const uint64_t sym = st.sym[c];
+                const uint32_t sl = st.len[c];
+                for (uint32_t b = 0; b < sl; b++) o[b] = uint8_t(sym >> (8 * b));
+                o += sl;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -1990,7 +2090,7 @@ hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const Sc
     const uint64_t wgs_needed = (n + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 block(kThreads);
     const dim3 grid_counts(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8)));
-    hipLaunchKernelGGL(k_sel_entry_counts, grid_counts, block, 0, stream, d_descs, L, d_block_counts);
+    hipLaunchKernelGGL(k_sel_entry_counts<FixedDesc>, grid_counts, block, 0, stream, d_descs, L, d_block_counts);
     const uint64_t n_tiles = (n + 1023) / 1024;
     uint64_t* d_tiles = d_block_offsets;
     hipLaunchKernelGGL(k_scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_block_counts, n, d_tiles);
@@ -2005,6 +2105,48 @@ hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const Sc
         case 6: hipLaunchKernelGGL(k_fixed_gather<uint64_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+static void launch_scan_u32(const uint32_t* d_counts, uint64_t n, uint64_t* d_tiles, uint64_t* d_offsets, hipStream_t stream) {
+    const uint64_t n_tiles = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_tile_sums, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_counts, n, d_tiles);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, stream, d_tiles, n_tiles);
+    hipLaunchKernelGGL(k_scan_apply, dim3(uint32_t(n_tiles)), dim3(1024), 0, stream, d_counts, n, 1u, d_tiles, n_tiles,
+                       d_offsets, static_cast<uint64_t*>(nullptr));
+}
+
+// entry row offsets of a byte-view scan under a selection (d_entry_counts: n u32 scratch, d_tiles: n/1024 + 2 u64 scratch)
+hipError_t launch_str_entry_offsets(const StrDesc* d_descs, const ScanLaunch& L, uint32_t* d_entry_counts, uint64_t* d_tiles,
+                                    uint64_t* d_entry_row_offsets, hipStream_t stream) {
+    if (L.n_entries == 0) return hipSuccess;
+    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8)));
+    hipLaunchKernelGGL(k_sel_entry_counts<StrDesc>, grid, dim3(kThreads), 0, stream, d_descs, L, d_entry_counts);
+    launch_scan_u32(d_entry_counts, L.n_entries, d_tiles, d_entry_row_offsets, stream);
+    return hipGetLastError();
+}
+
+// references + decoded lengths of the selected rows, then the value offsets (exclusive scan of the lengths)
+hipError_t launch_str_sel_rows(const StrDesc* d_descs, const DevSymtab* d_symtabs, const ScanLaunch& L,
+                               const uint64_t* d_entry_row_offsets, uint64_t capacity, uint64_t k, uint64_t* d_row_refs,
+                               uint32_t* d_row_len, uint8_t* d_row_valid, uint64_t* d_tiles, uint64_t* d_value_offsets,
+                               hipStream_t stream) {
+    if (L.n_entries == 0) return hipSuccess;
+    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8)));
+    hipLaunchKernelGGL(k_str_sel_rows, grid, dim3(kThreads), 0, stream, d_descs, d_symtabs, L, d_entry_row_offsets, capacity,
+                       d_row_refs, d_row_len, d_row_valid);
+    if (k) launch_scan_u32(d_row_len, k, d_tiles, d_value_offsets, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_str_decode_sel(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_row_refs,
+                                 const uint64_t* d_value_offsets, uint64_t k, uint8_t* d_data, hipStream_t stream) {
+    if (k == 0) return hipSuccess;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((k + kThreads - 1) / kThreads, uint64_t(device_cus()) * 16));
+    hipLaunchKernelGGL(k_str_decode_sel, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_row_refs,
+                       d_value_offsets, k, d_data);
     return hipGetLastError();
 }
 

@@ -137,6 +137,14 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
                              hipStream_t stream);
 hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
                                 hipStream_t stream);
+hipError_t launch_str_entry_offsets(const StrDesc* d_descs, const ScanLaunch& L, uint32_t* d_entry_counts, uint64_t* d_tiles,
+                                    uint64_t* d_entry_row_offsets, hipStream_t stream);
+hipError_t launch_str_sel_rows(const StrDesc* d_descs, const DevSymtab* d_symtabs, const ScanLaunch& L,
+                               const uint64_t* d_entry_row_offsets, uint64_t capacity, uint64_t k, uint64_t* d_row_refs,
+                               uint32_t* d_row_len, uint8_t* d_row_valid, uint64_t* d_tiles, uint64_t* d_value_offsets,
+                               hipStream_t stream);
+hipError_t launch_str_decode_sel(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_row_refs,
+                                 const uint64_t* d_value_offsets, uint64_t k, uint8_t* d_data, hipStream_t stream);
 hipError_t launch_date_lossy(void* d_values, uint64_t n, int value_width, int field, int64_t ticks_per_day,
                              hipStream_t stream);
 hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, const uint8_t* needle,

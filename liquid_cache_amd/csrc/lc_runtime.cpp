@@ -1453,6 +1453,66 @@ lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selecti
     return LC_OK;
 }
 
+lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_row_offsets,
+                                    void* d_row_refs, void* d_value_offsets, void* d_row_valid, uint64_t capacity_rows,
+                                    uint64_t* out_rows, uint64_t* out_bytes, void* stream) {
+    if (!ctx || !scan || !d_row_offsets || !d_row_refs || !d_value_offsets || !out_rows || !out_bytes)
+        return fail(LC_ERR_INVALID, "null argument");
+    if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
+    *out_rows = 0;
+    *out_bytes = 0;
+    if (scan->n == 0) return LC_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t n = scan->n;
+    const uint64_t tiles_len = std::max<uint64_t>(n, capacity_rows) / 1024 + 4;
+    uint32_t* d_counts = static_cast<uint32_t*>(pool_alloc(ctx, n * 4));
+    uint64_t* d_tiles = static_cast<uint64_t*>(pool_alloc(ctx, tiles_len * 8));
+    uint32_t* d_len = static_cast<uint32_t*>(pool_alloc(ctx, std::max<uint64_t>(capacity_rows, 1) * 4));
+    auto release = [&]() {
+        (void)hipStreamSynchronize(st);
+        pool_release(ctx, d_counts);
+        pool_release(ctx, d_tiles);
+        pool_release(ctx, d_len);
+    };
+    if (!d_counts || !d_tiles || !d_len) { release(); return fail(LC_ERR_OOM, "hipMalloc (gather scratch)"); }
+    ScanLaunch L{};
+    L.n_entries = scan->n;
+    L.blocks_per_entry = scan->bpe;
+    L.d_selection = static_cast<const uint64_t*>(d_selection);
+    const StrDesc* descs = static_cast<const StrDesc*>(scan->d_descs);
+    uint64_t k = 0, bytes = 0;
+    lc_status rc = LC_OK;
+    if (launch_str_entry_offsets(descs, L, d_counts, d_tiles, static_cast<uint64_t*>(d_row_offsets), st) != hipSuccess ||
+        hipMemcpyAsync(&k, static_cast<uint64_t*>(d_row_offsets) + n, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        rc = fail(LC_ERR_DEVICE, "gather plan: counting pass failed");
+    *out_rows = k;
+    if (rc == LC_OK && k > capacity_rows) rc = fail(LC_ERR_INVALID, "gather plan: capacity_rows is smaller than the selection");
+    if (rc == LC_OK && k > 0) {
+        if (launch_str_sel_rows(descs, ctx->d_symtabs, L, static_cast<const uint64_t*>(d_row_offsets), capacity_rows, k,
+                                static_cast<uint64_t*>(d_row_refs), d_len, static_cast<uint8_t*>(d_row_valid), d_tiles,
+                                static_cast<uint64_t*>(d_value_offsets), st) != hipSuccess ||
+            hipMemcpyAsync(&bytes, static_cast<uint64_t*>(d_value_offsets) + k, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            rc = fail(LC_ERR_DEVICE, "gather plan: length pass failed");
+    } else if (rc == LC_OK) {
+        if (hipMemsetAsync(d_value_offsets, 0, 8, st) != hipSuccess) rc = fail(LC_ERR_DEVICE, "gather plan: memset failed");
+    }
+    *out_bytes = bytes;
+    release();
+    return rc;
+}
+
+lc_status lc_scan_gather_bytes(lc_ctx* ctx, lc_scan* scan, const void* d_row_refs, const void* d_value_offsets,
+                               uint64_t rows, void* d_data, void* stream) {
+    if (!ctx || !scan || (rows && (!d_row_refs || !d_value_offsets || !d_data))) return fail(LC_ERR_INVALID, "null argument");
+    if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
+    LC_HIP(launch_str_decode_sel(static_cast<const StrDesc*>(scan->d_descs), ctx->d_symtabs,
+                                 static_cast<const uint64_t*>(d_row_refs), static_cast<const uint64_t*>(d_value_offsets), rows,
+                                 static_cast<uint8_t*>(d_data), static_cast<hipStream_t>(stream)));
+    return LC_OK;
+}
+
 lc_status lc_scan_date_part(lc_ctx* ctx, lc_scan* scan, void* d_values, uint64_t n_values, int32_t field, void* stream) {
     if (!ctx || !scan || !d_values) return fail(LC_ERR_INVALID, "null argument");
     if (field < LC_DATE_YEAR || field > LC_DATE_DAY_OF_WEEK) return fail(LC_ERR_INVALID, "unknown date field");

@@ -435,6 +435,41 @@ def test_scan_gather_fixed(gpu_cache, oracle):
         scan.close()
 
 
+def test_scan_gather_bytes(gpu_cache, oracle):
+    """get-with-selection over a whole byte-view scan (device resident): selected rows' values in row order."""
+    rng = np.random.default_rng(41)
+    n_batches, n = 6, 8192
+    total = n_batches * n - 777
+    pool = _make_strings(rng, 3000, 3000, False) + ["", "ÿ", "a" * 700]
+    keys = rng.integers(0, len(pool), size=total)
+    strs = [pool[k] for k in keys]
+    for i in rng.choice(total, size=total // 40, replace=False):
+        strs[int(i)] = None
+    ids = []
+    for k in range(n_batches):
+        eid = lc.ParquetArrayID.new(9, 0, 7, k)
+        gpu_cache.insert(eid, pa.array(strs[k * n: min((k + 1) * n, total)], type=pa.string()),
+                         lc.CacheExpression.SUBSTRING_SEARCH if k % 2 else None)
+        ids.append(eid)
+    scan = gpu_cache.scan(ids)
+    want_all = [None if s is None else s.encode() for s in strs]
+    assert scan.gather_bytes_to_host() == want_all                       # no selection: everything
+    for p_sel in (0.2, 0.001, 0.0):
+        keep = rng.random(total) < p_sel
+        words = np.zeros(int(scan.mask_words), np.uint64)
+        for k in range(n_batches):
+            seg = keep[k * n: min((k + 1) * n, total)]
+            packed = np.packbits(seg, bitorder="little")
+            w0 = int(scan.segment_offsets[k])
+            words[w0: w0 + (len(seg) + 63) // 64].view(np.uint8)[: len(packed)] = packed
+        assert scan.gather_bytes_to_host(selection=words) == [w for w, kp in zip(want_all, keep) if kp]
+    # the projection step of a filter: LIKE mask -> the matching URLs
+    m, c = scan.eval_to_host(lc.LiquidExpr.try_new("like", b"%google%", pa.string(), lc.CacheExpression.SUBSTRING_SEARCH))
+    got = scan.gather_bytes_to_host(selection=m)
+    assert got == [w for w in want_all if w is not None and b"google" in w] and len(got) == int(c.sum())
+    scan.close()
+
+
 def test_get_with_date_part_hint(gpu_cache, oracle):
     """cache.get(id).with_expression_hint(extract_date32(field)) == SqueezedDate32Array's lossy reconstruction."""
     lo = oracle
