@@ -51,6 +51,7 @@ def parse_args():
     p.add_argument("--int-bits", type=int, default=62, help="int64_gt: FoR bit width of every batch (WatchID ~62)")
     p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = auto)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
     p.add_argument("--seed", type=int, default=42)
     return p.parse_args()
 
@@ -80,6 +81,85 @@ def stage_url_column(cache, lc, N, args, rank, n_batches, threads):
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(do_row_group, range(n_rg)))
     return ids
+
+
+def stage_phrase_column(cache, lc, N, args, rank, n_batches, threads):
+    """SearchPhrase-shaped column (no SubstringSearch hint: its predicate is `<> ''`), same row ranges as the URLs."""
+    L = N.load()
+    import pyarrow as pa
+    bs = args.batch_size
+    ids = [lc.ParquetArrayID.new(rank, b // args.row_group_batches, 39, b % args.row_group_batches)
+           for b in range(n_batches)]
+
+    def do_row_group(rg):
+        offs = np.zeros(bs + 1, np.int32)
+        data = np.zeros(bs * 64, np.uint8)
+        first = rg * args.row_group_batches
+        for b in range(first, min(first + args.row_group_batches, n_batches)):
+            rows = min(bs, args.rows - b * bs)
+            n = L.lc_synth_phrase_batch(args.seed + rank * 1_000_003, b, rows, 600, 870, offs.ctypes.data,
+                                        data.ctypes.data, data.size)
+            arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:max(n, 1)]))
+            cache.insert(ids[b], arr)
+        return rg
+
+    n_rg = (n_batches + args.row_group_batches - 1) // args.row_group_batches
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(do_row_group, range(n_rg)))
+    return ids
+
+
+def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_expr, torch, stream):
+    """The other reading of "Q21" (SURVEY §8d (ii)): q21.sql = SELECT "SearchPhrase", MIN("URL"), COUNT(*) ... WHERE
+    "URL" LIKE '%google%' AND "SearchPhrase" <> '' GROUP BY ...: pushed-down part = `SearchPhrase <> ''` first (NotEq
+    sorts before LIKE, row_filter.rs:499-515), URL LIKE on the narrowed selection, then get().with_selection() of both
+    columns for the surviving rows; everything stays on the device."""
+    import pyarrow as pa
+    sp_ids = stage_phrase_column(cache, lc, N, args, rank, n_batches, threads)
+    sp_scan = cache.scan(sp_ids)
+    words = int(url_scan.mask_words)
+    assert int(sp_scan.mask_words) == words
+    ne_expr = lc.LiquidExpr.try_new("!=", b"", pa.string(), None)
+    m1 = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
+    m2 = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
+    counts = torch.zeros(max(url_scan.entries, 1), dtype=torch.int32, device="cuda")
+    c1 = torch.zeros(max(url_scan.entries, 1), dtype=torch.int32, device="cuda")
+    cap = 1 << 20
+    row_offs = torch.zeros(url_scan.entries + 1, dtype=torch.int64, device="cuda")
+    row_offs2 = torch.zeros(url_scan.entries + 1, dtype=torch.int64, device="cuda")
+    refs = [torch.zeros(cap, dtype=torch.int64, device="cuda") for _ in range(2)]
+    voffs = [torch.zeros(cap + 1, dtype=torch.int64, device="cuda") for _ in range(2)]
+    data = [torch.zeros(cap * 64, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    out = {}
+
+    def run():
+        sp_scan.eval(ne_expr, m1.data_ptr(), 0, c1.data_ptr(), stream)
+        url_scan.eval(like_expr, m2.data_ptr(), m1.data_ptr(), counts.data_ptr(), stream)
+        # both projections in stream order, no host round trip; sizes are read once after the timed loop
+        url_scan.gather_bytes_async(row_offs.data_ptr(), refs[0].data_ptr(), voffs[0].data_ptr(), cap, data[0].data_ptr(),
+                                    data[0].numel(), m2.data_ptr(), 0, stream)
+        sp_scan.gather_bytes_async(row_offs2.data_ptr(), refs[1].data_ptr(), voffs[1].data_ptr(), cap, data[1].data_ptr(),
+                                   data[1].numel(), m2.data_ptr(), 0, stream)
+
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    iters = max(5, args.steps)
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    n_ne = int(c1.sum(dtype=torch.int64).item())
+    k_out = int(row_offs[-1].item())
+    assert k_out == int(row_offs2[-1].item()) == int(counts.sum(dtype=torch.int64).item()) and k_out <= cap
+    out.update(rows_out=k_out, url_bytes=int(voffs[0][k_out].item()), phrase_bytes=int(voffs[1][k_out].item()))
+    assert out["url_bytes"] <= data[0].numel() and out["phrase_bytes"] <= data[1].numel()
+    res = {"query": "q21.sql pushdown: SearchPhrase <> '' -> URL LIKE '%%%s%%' -> get(URL), get(SearchPhrase)" % args.needle,
+           "ms": ms, "rows_per_s": url_scan.rows / (ms * 1e-3), "rows_after_searchphrase": n_ne,
+           "rows_out": out["rows_out"], "url_bytes_out": out["url_bytes"], "phrase_bytes_out": out["phrase_bytes"]}
+    sp_scan.close()
+    return res
 
 
 def stage_int_column(cache, lc, N, args, rank, n_batches, threads):
@@ -315,6 +395,10 @@ def main():
         gather_all[sel_name] = gather
     gather = gather_all or None
 
+    q21 = None
+    if args.workload == "url_like" and rank == 0 and world == 1 and not args.no_q21:
+        q21 = q21_pipeline(cache, lc, N, args, rank, n_batches, threads, scan, expr, torch, stream)
+
     out = None
     if rank == 0:
         traffic, traffic_src = measured_traffic(workload)
@@ -347,6 +431,8 @@ def main():
         }
         if gather is not None:
             out["get_with_selection"] = gather
+        if q21 is not None:
+            out["q21_pipeline"] = q21
         if world == 1 and not args.no_cpu_baseline:
             n_sample = args.cpu_batches or n_batches  # ~5 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
             if args.workload == "url_like":

@@ -264,6 +264,14 @@ LC_API lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const voi
 LC_API lc_status lc_scan_gather_bytes(lc_ctx* ctx, lc_scan* scan, const void* d_row_refs, const void* d_value_offsets,
                                       uint64_t rows, void* d_data, void* stream);
 
+/* The same in ONE asynchronous call, for callers that pre-size the outputs (the projection after a selective filter):
+ * no host round trip.  Afterwards (stream order) d_row_offsets[n] holds k, d_value_offsets[min(k, capacity_rows)] the
+ * total bytes; rows beyond capacity_rows are dropped, values ending beyond capacity_bytes are not written — the caller
+ * compares both with its capacities and retries with larger buffers if needed. */
+LC_API lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_row_offsets,
+                                            void* d_row_refs, void* d_value_offsets, void* d_row_valid,
+                                            uint64_t capacity_rows, void* d_data, uint64_t capacity_bytes, void* stream);
+
 /* ExtractDate32 over gathered values of a Date32 / Timestamp scan: replaces `n_values` decoded values in d_values
  * (as written by lc_scan_gather_fixed) in place by their lossy date-part reconstruction (see
  * lc_get_date_part_with_selection).  Asynchronous on `stream`. */

@@ -61,12 +61,12 @@ ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offse
 EXPORTED_SYMBOLS = [
     "lc_ctx_create", "lc_ctx_destroy", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
-    "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_mask_and_then", "lc_scan_create",
+    "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
     # include/liquid_cache_amd_bench.h
-    "lc_synth_url_batch", "lc_synth_int64_batch",
+    "lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch",
 ]
 
 _lib = None
@@ -109,6 +109,8 @@ def load():
     L.lc_scan_gather_bytes_plan.restype = i32
     L.lc_scan_gather_bytes_plan.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, P(u64), P(u64), vp]
     L.lc_scan_gather_bytes.restype = i32; L.lc_scan_gather_bytes.argtypes = [vp, vp, vp, vp, u64, vp, vp]
+    L.lc_scan_gather_bytes_async.restype = i32
+    L.lc_scan_gather_bytes_async.argtypes = [vp, vp, vp, vp, vp, vp, vp, u64, vp, u64, vp]
     L.lc_mask_and_then.restype = i32; L.lc_mask_and_then.argtypes = [vp, vp, u64, vp, u64, vp]
     L.lc_scan_create.restype = i32; L.lc_scan_create.argtypes = [vp, u64, P(u64), P(vp)]
     L.lc_scan_destroy.restype = None; L.lc_scan_destroy.argtypes = [vp]
@@ -128,6 +130,8 @@ def load():
     L.lc_stream_synchronize.restype = i32; L.lc_stream_synchronize.argtypes = [vp, vp]
     L.lc_synth_url_batch.restype = sz
     L.lc_synth_url_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
+    L.lc_synth_phrase_batch.restype = sz
+    L.lc_synth_phrase_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
     L.lc_synth_int64_batch.restype = None
     L.lc_synth_int64_batch.argtypes = [u64, u64, C.c_uint32, i32, C.c_int64, vp]
     _lib = L

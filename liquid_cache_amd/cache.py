@@ -533,6 +533,16 @@ class Scan:
                                                C.c_void_p(value_offsets_ptr), rows, C.c_void_p(data_ptr),
                                                C.c_void_p(stream or None)), self._cache.handle)
 
+    def gather_bytes_async(self, row_offsets_ptr: int, row_refs_ptr: int, value_offsets_ptr: int, capacity_rows: int,
+                           data_ptr: int, capacity_bytes: int, selection_ptr: int = 0, row_valid_ptr: int = 0,
+                           stream: int = 0):
+        """Plan + fill in one asynchronous call (lc_scan_gather_bytes_async): no host round trip."""
+        N.check(self._lib.lc_scan_gather_bytes_async(self._cache.handle, self._h, C.c_void_p(selection_ptr or None),
+                                                     C.c_void_p(row_offsets_ptr), C.c_void_p(row_refs_ptr),
+                                                     C.c_void_p(value_offsets_ptr), C.c_void_p(row_valid_ptr or None),
+                                                     capacity_rows, C.c_void_p(data_ptr), capacity_bytes,
+                                                     C.c_void_p(stream or None)), self._cache.handle)
+
     def gather_bytes_to_host(self, selection: Optional[np.ndarray] = None):
         """Convenience for tests: list of bytes / None for the selected rows, in row order."""
         lib, ctx = self._lib, self._cache.handle
@@ -558,6 +568,17 @@ class Scan:
             N.check(lib.lc_device_to_host(ctx, offs.ctypes.data_as(C.c_void_p), d_vo, (k + 1) * 8, None), ctx)
             N.check(lib.lc_device_to_host(ctx, valid.ctypes.data_as(C.c_void_p), d_valid, k, None), ctx)
             N.check(lib.lc_device_to_host(ctx, data.ctypes.data_as(C.c_void_p), d_data, nbytes, None), ctx)
+            # the one-call asynchronous form must produce the same buffers
+            N.check(lib.lc_device_memset(ctx, d_data, 0, max(nbytes, 1), None), ctx)
+            N.check(lib.lc_device_memset(ctx, d_vo, 0xEE, (cap + 1) * 8, None), ctx)
+            self.gather_bytes_async(d_ro.value, d_refs.value, d_vo.value, cap, d_data.value, max(nbytes, 1),
+                                    d_sel.value or 0, d_valid.value)
+            offs2 = np.zeros(k + 1, np.uint64)
+            data2 = np.zeros(max(nbytes, 1), np.uint8)
+            N.check(lib.lc_device_to_host(ctx, offs2.ctypes.data_as(C.c_void_p), d_vo, (k + 1) * 8, None), ctx)
+            N.check(lib.lc_device_to_host(ctx, data2.ctypes.data_as(C.c_void_p), d_data, nbytes, None), ctx)
+            assert offs2.tolist() == offs.tolist() and data2[:nbytes].tobytes() == data[:nbytes].tobytes(), \
+                "lc_scan_gather_bytes_async differs from plan + fill"
         finally:
             for p in ptrs:
                 if p.value:

@@ -1908,14 +1908,19 @@ __global__ __launch_bounds__(kThreads) void k_str_sel_rows(const StrDesc* __rest
                                                            const uint64_t* __restrict__ entry_offsets, uint64_t capacity,
                                                            uint64_t* __restrict__ row_refs, uint32_t* __restrict__ row_len,
                                                            uint8_t* __restrict__ row_valid) {
+    // selected rows of one 64-word group (<= 4096), in row order: listed first, then measured one row per lane — the
+    // matches of a filter cluster (one URL repeated in many rows of a batch), so walking them word by word would
+    // serialise dozens of dependent FSST walks in a single wave
+    __shared__ uint16_t rowlist[kWavesPerBlock][4096];
     const int lane = lane_id();
+    uint16_t* list = rowlist[wave_id()];
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < L.n_entries; entry += total_waves) {
+        uint64_t out_row = entry_offsets[entry];
+        if (entry_offsets[entry + 1] == out_row) continue;  // nothing selected here
         const StrDesc d = descs[entry];
         const DevSymtab& st = symtabs[d.symtab_slot];
         const uint32_t nwords = (d.n + 63u) >> 6;
-        uint64_t out_row = entry_offsets[entry];
-        if (entry_offsets[entry + 1] == out_row) continue;  // nothing selected here
         for (uint32_t wb = 0; wb < nwords; wb += kWave) {
             // 64 selection words at once: lane l holds word wb + l; only the non-zero ones are visited
             const uint32_t w = wb + uint32_t(lane);
@@ -1926,24 +1931,31 @@ __global__ __launch_bounds__(kThreads) void k_str_sel_rows(const StrDesc* __rest
             }
             const uint32_t cnt = uint32_t(__popcll(sw));
             const uint32_t incl = wave_inclusive_sum(cnt);
-            uint64_t nz = __ballot(sw != 0);
-            while (nz) {  // wave uniform
-                const int src = __ffsll((long long)nz) - 1;
-                nz &= nz - 1;
-                const uint64_t word = __shfl(sw, src, kWave);
-                const uint32_t before = __shfl(incl - cnt, src, kWave);
-                if ((word >> lane) & 1) {
-                    const uint32_t row = (wb + uint32_t(src)) * 64u + uint32_t(lane);
-                    const uint64_t o = out_row + before + lanes_below(word);
-                    if (o < capacity) {
-                        const bool valid = d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true;
-                        row_refs[o] = (uint64_t(entry) << 32) | row;
-                        row_len[o] = valid ? str_decoded_len(d, st, d.keys[row]) : 0u;
-                        if (row_valid) row_valid[o] = valid ? 1 : 0;
-                    }
+            const uint32_t group_rows = read_lane(incl, kWave - 1);
+            if (group_rows == 0) continue;
+            // every lane lists the rows of its own word (positions [incl - cnt, incl) of the group)
+            {
+                uint32_t pos = incl - cnt;
+                uint64_t m = sw;
+                while (m) {
+                    const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+                    list[pos++] = uint16_t((w & 1023u) * 64u + bit);  // row within the entry (entries have <= 65536 rows)
+                    m &= m - 1;
                 }
             }
-            out_row += read_lane(incl, kWave - 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t j = uint32_t(lane); j < group_rows; j += kWave) {
+                const uint32_t row = list[j];
+                const uint64_t o = out_row + j;
+                if (o < capacity) {
+                    const bool valid = d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true;
+                    row_refs[o] = (uint64_t(entry) << 32) | row;
+                    row_len[o] = valid ? str_decoded_len(d, st, d.keys[row]) : 0u;
+                    if (row_valid) row_valid[o] = valid ? 1 : 0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            out_row += group_rows;
         }
     }
 }
@@ -1951,10 +1963,14 @@ __global__ __launch_bounds__(kThreads) void k_str_sel_rows(const StrDesc* __rest
 __global__ __launch_bounds__(kThreads) void k_str_decode_sel(const StrDesc* __restrict__ descs,
                                                              const DevSymtab* __restrict__ symtabs,
                                                              const uint64_t* __restrict__ row_refs,
-                                                             const uint64_t* __restrict__ value_offsets, uint64_t k,
-                                                             uint8_t* __restrict__ data) {
+                                                             const uint64_t* __restrict__ value_offsets, uint64_t k_host,
+                                                             const uint64_t* __restrict__ k_dev, uint64_t capacity_rows,
+                                                             uint64_t capacity_bytes, uint8_t* __restrict__ data) {
+    // the row count is either known to the host (plan / fill) or still on the device (fully asynchronous form)
+    const uint64_t k = k_dev ? min(*k_dev, capacity_rows) : k_host;
     for (uint64_t r = uint64_t(blockIdx.x) * kThreads + threadIdx.x; r < k; r += uint64_t(gridDim.x) * kThreads) {
         if (value_offsets[r + 1] == value_offsets[r]) continue;  // null or empty
+        if (value_offsets[r + 1] > capacity_bytes) continue;      // does not fit: the caller sees the total and retries
         const uint64_t ref = row_refs[r];
         const StrDesc& d = descs[uint32_t(ref >> 32)];
         const DevSymtab& st = symtabs[d.symtab_slot];
@@ -2142,11 +2158,13 @@ hipError_t launch_str_sel_rows(const StrDesc* d_descs, const DevSymtab* d_symtab
 }
 
 hipError_t launch_str_decode_sel(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_row_refs,
-                                 const uint64_t* d_value_offsets, uint64_t k, uint8_t* d_data, hipStream_t stream) {
-    if (k == 0) return hipSuccess;
-    const uint32_t grid = uint32_t(std::min<uint64_t>((k + kThreads - 1) / kThreads, uint64_t(device_cus()) * 16));
+                                 const uint64_t* d_value_offsets, uint64_t k, const uint64_t* d_k, uint64_t capacity_rows,
+                                 uint64_t capacity_bytes, uint8_t* d_data, hipStream_t stream) {
+    const uint64_t bound = d_k ? capacity_rows : k;
+    if (bound == 0) return hipSuccess;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((bound + kThreads - 1) / kThreads, uint64_t(device_cus()) * 16));
     hipLaunchKernelGGL(k_str_decode_sel, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_row_refs,
-                       d_value_offsets, k, d_data);
+                       d_value_offsets, k, d_k, capacity_rows, capacity_bytes, d_data);
     return hipGetLastError();
 }
 

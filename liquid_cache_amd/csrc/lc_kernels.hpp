@@ -144,7 +144,8 @@ hipError_t launch_str_sel_rows(const StrDesc* d_descs, const DevSymtab* d_symtab
                                uint32_t* d_row_len, uint8_t* d_row_valid, uint64_t* d_tiles, uint64_t* d_value_offsets,
                                hipStream_t stream);
 hipError_t launch_str_decode_sel(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_row_refs,
-                                 const uint64_t* d_value_offsets, uint64_t k, uint8_t* d_data, hipStream_t stream);
+                                 const uint64_t* d_value_offsets, uint64_t k, const uint64_t* d_k, uint64_t capacity_rows,
+                                 uint64_t capacity_bytes, uint8_t* d_data, hipStream_t stream);
 hipError_t launch_date_lossy(void* d_values, uint64_t n, int value_width, int field, int64_t ticks_per_day,
                              hipStream_t stream);
 hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, const uint8_t* needle,

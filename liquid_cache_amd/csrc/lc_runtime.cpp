@@ -109,6 +109,8 @@ struct lc_scan {
     size_t automata_symtabs = 0;           // ... over this many symbol tables (0: nothing cached)
     uint8_t* d_needle = nullptr;
     size_t needle_cap = 0;
+    uint8_t* d_gather = nullptr;  // scratch of lc_scan_gather_bytes_async (grow only)
+    size_t gather_cap = 0;
     uint32_t* d_work = nullptr;  // kWorkGroupsMax x {next entry, finished waves} (64-byte stride): dynamic entry
                                  // assignment of the persistent byte-view scan kernel
     std::mutex mu;
@@ -861,6 +863,7 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_descs);
     pool_release(s->ctx, s->d_seg_offsets);
     pool_release(s->ctx, s->d_work);
+    pool_release(s->ctx, s->d_gather);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
     delete s;
@@ -1509,7 +1512,48 @@ lc_status lc_scan_gather_bytes(lc_ctx* ctx, lc_scan* scan, const void* d_row_ref
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
     LC_HIP(launch_str_decode_sel(static_cast<const StrDesc*>(scan->d_descs), ctx->d_symtabs,
                                  static_cast<const uint64_t*>(d_row_refs), static_cast<const uint64_t*>(d_value_offsets), rows,
-                                 static_cast<uint8_t*>(d_data), static_cast<hipStream_t>(stream)));
+                                 nullptr, rows, ~uint64_t(0), static_cast<uint8_t*>(d_data), static_cast<hipStream_t>(stream)));
+    return LC_OK;
+}
+
+lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_row_offsets,
+                                     void* d_row_refs, void* d_value_offsets, void* d_row_valid, uint64_t capacity_rows,
+                                     void* d_data, uint64_t capacity_bytes, void* stream) {
+    if (!ctx || !scan || !d_row_offsets || !d_row_refs || !d_value_offsets || !d_data || capacity_rows == 0)
+        return fail(LC_ERR_INVALID, "null argument");
+    if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
+    if (scan->n == 0) return LC_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const uint64_t n = scan->n;
+    // scratch owned by the scan (grow only): [entry counts u32 x n | row lengths u32 x capacity | tile sums u64]
+    const uint64_t tiles_len = std::max<uint64_t>(n, capacity_rows) / 1024 + 4;
+    const size_t need = align_up(n * 4, 256) + align_up(capacity_rows * 4, 256) + tiles_len * 8;
+    std::lock_guard<std::mutex> g(scan->mu);
+    if (need > scan->gather_cap) {
+        LC_HIP(hipStreamSynchronize(st));
+        pool_release(ctx, scan->d_gather);
+        scan->d_gather = static_cast<uint8_t*>(pool_alloc(ctx, need));
+        scan->gather_cap = scan->d_gather ? need : 0;
+        if (!scan->d_gather) return fail(LC_ERR_OOM, "hipMalloc (gather scratch)");
+    }
+    uint32_t* d_counts = reinterpret_cast<uint32_t*>(scan->d_gather);
+    uint32_t* d_len = reinterpret_cast<uint32_t*>(scan->d_gather + align_up(n * 4, 256));
+    uint64_t* d_tiles = reinterpret_cast<uint64_t*>(scan->d_gather + align_up(n * 4, 256) + align_up(capacity_rows * 4, 256));
+    ScanLaunch L{};
+    L.n_entries = scan->n;
+    L.blocks_per_entry = scan->bpe;
+    L.d_selection = static_cast<const uint64_t*>(d_selection);
+    const StrDesc* descs = static_cast<const StrDesc*>(scan->d_descs);
+    LC_HIP(launch_str_entry_offsets(descs, L, d_counts, d_tiles, static_cast<uint64_t*>(d_row_offsets), st));
+    // rows beyond the (device-side) count keep length 0, so the scan over the whole capacity yields their offsets too
+    LC_HIP(hipMemsetAsync(d_len, 0, capacity_rows * 4, st));
+    LC_HIP(launch_str_sel_rows(descs, ctx->d_symtabs, L, static_cast<const uint64_t*>(d_row_offsets), capacity_rows,
+                               capacity_rows, static_cast<uint64_t*>(d_row_refs), d_len, static_cast<uint8_t*>(d_row_valid),
+                               d_tiles, static_cast<uint64_t*>(d_value_offsets), st));
+    LC_HIP(launch_str_decode_sel(descs, ctx->d_symtabs, static_cast<const uint64_t*>(d_row_refs),
+                                 static_cast<const uint64_t*>(d_value_offsets), 0,
+                                 static_cast<const uint64_t*>(d_row_offsets) + n, capacity_rows, capacity_bytes,
+                                 static_cast<uint8_t*>(d_data), st));
     return LC_OK;
 }
 

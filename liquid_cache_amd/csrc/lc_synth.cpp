@@ -126,6 +126,37 @@ size_t lc_synth_url_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, ui
     return pos;
 }
 
+size_t lc_synth_phrase_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, uint32_t n_unique,
+                             uint32_t empty_permille, int32_t* offsets, uint8_t* data, size_t data_cap) {
+    if (n_unique == 0) n_unique = 1;
+    Rng r(seed * 0x100000001B3ull + batch_index * 0xA24BAED4963EE407ull + 3);
+    std::vector<std::string> pool(n_unique);
+    for (uint32_t i = 0; i < n_unique; i++) {
+        std::string& p = pool[i];
+        const uint32_t nw = 1 + r.below(5);
+        for (uint32_t w = 0; w < nw; w++) {
+            if (w) p.push_back(' ');
+            p += kWords[r.below(kNWords)];
+        }
+        if (r.below(4) == 0) { p.push_back(' '); append_num(p, r, 1 + r.below(4)); }
+    }
+    size_t pos = 0;
+    offsets[0] = 0;
+    for (uint32_t row = 0; row < rows; row++) {
+        if (r.below(1000) >= empty_permille) {
+            const double u = r.unit();
+            uint32_t k = uint32_t(double(n_unique) * u * u);
+            if (k >= n_unique) k = n_unique - 1;
+            const std::string& p = pool[k];
+            if (pos + p.size() > data_cap) return 0;
+            std::memcpy(data + pos, p.data(), p.size());
+            pos += p.size();
+        }
+        offsets[row + 1] = int32_t(pos);
+    }
+    return pos;
+}
+
 void lc_synth_int64_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, int32_t bit_width, int64_t base,
                           int64_t* out) {
     Rng r(seed * 0x100000001B3ull + batch_index * 0x9E3779B97F4A7C15ull + 7);
