@@ -10,6 +10,15 @@
 //                   liquid_array/mod.rs:265-280)
 //   k_str_pred     LiquidByteViewArray::compare_with + map_dictionary_results_to_array_results
 //                  (src/core/src/liquid_array/byte_view_array/comparisons.rs:21-183, 325-501, 598-651)
+//   k_alp_patch_fix  LiquidFloatArray exception rows of a predicate (float_array.rs:306-310 applied to the mask)
+//   k_fixed_gather / k_sel_entry_counts / k_scan_*   LiquidPrimitiveArray / Decimal / Float ::filter + to_arrow over a
+//                  scan (primitive_array.rs:350-379, decimal_array.rs:185-195, float_array.rs:294-316)
+//   k_date_lossy   SqueezedDate32Array component + lossy reconstruction (squeezed_date32_array.rs:267-429)
+//   k_str_sel_rows / k_str_decode_sel, k_str_dict_lengths / k_str_row_offsets / k_str_decode_rows
+//                  LiquidByteViewArray::filter + to_arrow (byte_view_array/mod.rs:266-290, 421-424; FSST decode
+//                  raw/fsst_buffer.rs:642-663)
+//   k_str_automata needle automaton folded over the FSST symbol table (no reference counterpart: the reference
+//                  decodes candidates and runs memmem, comparisons.rs:598-651)
 //   k_mask_*       boolean_buffer_and_then / arrow filter on bitmaps (src/datafusion/src/utils.rs:17-236)
 #include "lc_kernels.hpp"
 
