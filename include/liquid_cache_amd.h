@@ -239,7 +239,9 @@ LC_API const uint64_t* lc_scan_segment_offsets(const lc_scan* scan);
  *   d_mask_out : device pointer, lc_scan_mask_words() words: hit = pred(row) AND valid(row) AND selected(row)
  *                (i.e. prep_null_mask_filter + boolean_buffer_and_then already applied).
  *   d_counts_out: device pointer to one u32 per entry (popcount of its segment) or NULL.
- *   stream: hipStream_t (NULL = default stream).  Asynchronous; the caller synchronises the stream. */
+ *   stream: hipStream_t (NULL = default stream).  Asynchronous; the caller synchronises the stream.
+ * A scan owns device scratch (folded automata, work counters, gather buffers): calls on ONE scan must be ordered on
+ * one stream (or otherwise serialised); different scans are independent. */
 LC_API lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
                               void* d_mask_out, void* d_counts_out, void* stream);
 
