@@ -51,6 +51,9 @@ def parse_args():
     p.add_argument("--int-bits", type=int, default=62, help="int64_gt: FoR bit width of every batch (WatchID ~62)")
     p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = auto)")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-fingerprints", action="store_true",
+                   help="url_like: stage the column without the SubstringSearch hint (no fingerprints, no signature index: "
+                        "every dictionary value is walked)")
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
     p.add_argument("--seed", type=int, default=42)
     return p.parse_args()
@@ -74,7 +77,7 @@ def stage_url_column(cache, lc, N, args, rank, n_batches, threads):
             n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
                                      offs.ctypes.data, data.ctypes.data, data.size)
             arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
-            cache.insert(ids[b], arr, lc.CacheExpression.SUBSTRING_SEARCH)
+            cache.insert(ids[b], arr, None if args.no_fingerprints else lc.CacheExpression.SUBSTRING_SEARCH)
         return rg
 
     n_rg = (n_batches + args.row_group_batches - 1) // args.row_group_batches
@@ -232,7 +235,7 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
             arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
             eid = lc.ParquetArrayID.new(rank, b // args.row_group_batches, 13, b % args.row_group_batches)
             path = lc.ParquetArrayID.column_access_path(eid)
-            blobs[b] = (cache.transcode(arr, lc.CacheExpression.SUBSTRING_SEARCH, path), path)
+            blobs[b] = (cache.transcode(arr, None if args.no_fingerprints else lc.CacheExpression.SUBSTRING_SEARCH, path), path)
 
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(prep, range(threads)))
@@ -322,7 +325,7 @@ def main():
         pattern = ("%" + args.needle + "%").encode()
         import pyarrow as pa
         expr = lc.LiquidExpr.try_new("like", pattern, pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
-        workload = "clickbench_q21_url_like_%s" % args.needle
+        workload = "clickbench_q21_url_like_%s%s" % (args.needle, "_no_fingerprints" if args.no_fingerprints else "")
         dtype = "u8"
     else:
         ids = stage_int_column(cache, lc, N, args, rank, n_batches, threads)
