@@ -341,32 +341,21 @@ def main():
     words = int(scan.mask_words)
     mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
     counts = torch.zeros(max(scan.entries, 1), dtype=torch.int32, device="cuda")
-    # COUNT(*) partials: two buffers so that the all-reduce of step i (RCCL's own stream) overlaps the scan of step i+1
+    # COUNT(*) partials: two buffers so that the all-reduce of step i (RCCL's own stream) overlaps the scan of step i+1;
     # int32 accumulators while the global count fits (one reduce kernel; an int64 sum of int32 counts costs torch an
     # extra cast kernel per step)
+    from liquid_cache_amd.sharding import PipelinedCountAllReduce
     acc_dtype = torch.int32 if scan.rows * world < 2**31 else torch.int64
-    totals = [torch.zeros((), dtype=acc_dtype, device="cuda") for _ in range(2)]
-    pending = [None, None]
+    reducer = PipelinedCountAllReduce(lambda: torch.zeros((), dtype=acc_dtype, device="cuda"), world)
     stream = torch.cuda.current_stream().cuda_stream
-    step_no = [0]
 
     def step():
-        b = step_no[0] & 1
-        step_no[0] += 1
-        if pending[b] is not None:
-            pending[b].wait()  # stream-side wait: the buffer's previous all-reduce is done before it is overwritten
-            pending[b] = None
+        total = reducer.acquire()
         scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
-        torch.sum(counts, dim=(0,), dtype=acc_dtype, out=totals[b])  # COUNT(*) of this shard
-        if world > 1:
-            # the query's only exchange step: COUNT(*) partials -> global count (8 bytes)
-            pending[b] = dist.all_reduce(totals[b], async_op=True)
+        torch.sum(counts, dim=(0,), dtype=acc_dtype, out=total)  # COUNT(*) of this shard
+        reducer.submit()  # the query's only exchange step: COUNT(*) partials -> global count (4-8 bytes)
 
-    def drain():
-        for b in range(2):
-            if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+    drain = reducer.drain
 
     for _ in range(args.warmup):
         step()
@@ -391,7 +380,7 @@ def main():
         _np.save(os.environ["LC_DUMP_COUNTS"], counts.cpu().numpy())
     ms_per_step = elapsed / args.steps * 1e3
     rows_all = scan.rows * world
-    hits = int(totals[(step_no[0] - 1) & 1].item())
+    hits = int(reducer.last().item())
 
     # roofline of the dominant kernel: HIP events on the launch stream, same launches as the timed region
     alg_bytes = scan.algorithmic_bytes(expr, with_selection=False)

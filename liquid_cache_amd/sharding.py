@@ -79,3 +79,45 @@ def all_gather_mask_segments(local_words, group=None):
     out = [torch.zeros_like(padded) for _ in range(world)]
     dist.all_gather(out, padded, group=group)
     return [o[: int(s.item())] for o, s in zip(out, sizes)]
+
+
+class PipelinedCountAllReduce:
+    """COUNT(*) exchange of a repeated scan, overlapped with the next scan.
+
+    Two count buffers alternate: step i reduces into buffer i & 1 and starts its all-reduce asynchronously (RCCL runs it
+    on its own stream, after the kernels already queued on the current stream); step i + 2 waits for that all-reduce
+    (a stream-side wait) before it overwrites the buffer.  `drain()` waits for everything outstanding."""
+
+    def __init__(self, make_buffer, world_size: int, group=None):
+        self.buffers = [make_buffer(), make_buffer()]
+        self.pending = [None, None]
+        self.world = world_size
+        self.group = group
+        self.steps = 0
+
+    def acquire(self):
+        """Buffer for this step's local count (its previous all-reduce, if any, has completed in stream order)."""
+        b = self.steps & 1
+        self.steps += 1
+        if self.pending[b] is not None:
+            self.pending[b].wait()
+            self.pending[b] = None
+        self._current = b
+        return self.buffers[b]
+
+    def submit(self):
+        """Start the all-reduce of the buffer handed out by the last acquire()."""
+        if self.world > 1:
+            import torch.distributed as dist
+            self.pending[self._current] = dist.all_reduce(self.buffers[self._current], op=dist.ReduceOp.SUM,
+                                                          group=self.group, async_op=True)
+
+    def drain(self):
+        for b in range(2):
+            if self.pending[b] is not None:
+                self.pending[b].wait()
+                self.pending[b] = None
+
+    def last(self):
+        """The (globally reduced, after drain()) count of the most recent step."""
+        return self.buffers[(self.steps - 1) & 1]

@@ -89,3 +89,36 @@ def test_sharded_scan_matches_single_process(tmp_path, world):
     assert int(open(out + ".count").read()) == want_count
     # shards are contiguous row ranges in order, so rank-order concatenation == table order
     assert got.tolist() == np.concatenate(want_segments).tolist()
+
+
+def _reducer_worker(rank, world, port, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    from liquid_cache_amd.sharding import PipelinedCountAllReduce
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    red = PipelinedCountAllReduce(lambda: torch.zeros((), dtype=torch.int64), world)
+    seen = []
+    for step in range(7):
+        buf = red.acquire()
+        buf.fill_(1000 * step + rank + 1)     # this rank's COUNT(*) of step `step`
+        red.submit()
+        if step >= 2:                          # the buffer of step-2 was waited for by acquire(): it holds the global sum
+            pass
+    red.drain()
+    seen.append(int(red.last().item()))
+    # the other buffer holds the reduced value of the step before the last one
+    seen.append(int(red.buffers[(red.steps - 2) & 1].item()))
+    if rank == 0:
+        with open(out_path, "w") as f:
+            f.write(",".join(map(str, seen)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_count_all_reduce(tmp_path, world):
+    """bench.py's exchange step: asynchronous all-reduce of step i overlapping step i+1 (two alternating buffers)."""
+    out = str(tmp_path / "red.txt")
+    mp.spawn(_reducer_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    last, before = map(int, open(out).read().split(","))
+    ranks = sum(r + 1 for r in range(world))
+    assert last == 1000 * 6 * world + ranks and before == 1000 * 5 * world + ranks
