@@ -22,7 +22,7 @@ BS = 8192
 
 def _args(**kw):
     a = argparse.Namespace(rows=ROWS, batch_size=BS, uniques=2200, row_group_batches=54, needle="google", int_bits=62,
-                           seed=42, needle_ppm=159)
+                           seed=42, needle_ppm=159, no_fingerprints=False)
     a.__dict__.update(kw)
     return a
 
