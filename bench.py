@@ -35,7 +35,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def parse_args():
+def parse_args(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
@@ -56,7 +56,7 @@ def parse_args():
                         "every dictionary value is walked)")
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
     p.add_argument("--seed", type=int, default=42)
-    return p.parse_args()
+    return p.parse_args(argv)
 
 
 def stage_url_column(cache, lc, N, args, rank, n_batches, threads):

@@ -21,8 +21,10 @@ BS = 8192
 
 
 def _args(**kw):
-    a = argparse.Namespace(rows=ROWS, batch_size=BS, uniques=2200, row_group_batches=54, needle="google", int_bits=62,
-                           seed=42, needle_ppm=159, no_fingerprints=False)
+    """bench.py's own defaults (so that a new staging option can never be missing here), at the full ClickBench size."""
+    import bench
+    a = bench.parse_args([])
+    a.rows, a.batch_size = ROWS, BS
     a.__dict__.update(kw)
     return a
 

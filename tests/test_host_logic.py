@@ -226,3 +226,12 @@ def test_expression_hint_mirror():
     assert isinstance(h, lc.ExtractDate32) and h.field == 1
     assert lc.CacheExpression.extract_date32("year").field == 0
     assert lc.CacheExpression.extract_date32("DayOfWeek").field == 3
+
+
+def test_bench_defaults_name_the_metric_workload():
+    """bench.py with no flags = BASELINE.json's metric configuration; the full-size GPU tests stage with these args."""
+    import bench
+    a = bench.parse_args([])
+    assert (a.gpus, a.workload, a.rows, a.batch_size, a.needle) == (1, "url_like", 99_997_497, 8192, "google")
+    for name in ("uniques", "row_group_batches", "needle_ppm", "no_fingerprints", "int_bits", "seed", "steps", "warmup"):
+        assert hasattr(a, name)
