@@ -235,3 +235,18 @@ def test_bench_defaults_name_the_metric_workload():
     assert (a.gpus, a.workload, a.rows, a.batch_size, a.needle) == (1, "url_like", 99_997_497, 8192, "google")
     for name in ("uniques", "row_group_batches", "needle_ppm", "no_fingerprints", "int_bits", "seed", "steps", "warmup"):
         assert hasattr(a, name)
+
+
+def test_headers_are_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: both headers must compile as C99 (and as C++) without torch / HIP types."""
+    import shutil
+    import subprocess
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "liquid_cache_amd.h"\n#include "liquid_cache_amd_bench.h"\n'
+                   'int main(void) { return (int)sizeof(lc_predicate) * 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    if shutil.which("gcc"):
+        subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)],
+                       check=True)
+    if shutil.which("g++"):
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
