@@ -216,6 +216,28 @@ def stage_int_column(cache, lc, N, args, rank, n_batches, threads):
     return ids
 
 
+def usable_cores() -> int:
+    """Cores this process may really use: CPU affinity capped by the cgroup CPU quota (a container on a 256-thread host
+    is often limited to a handful of cores, and os.cpu_count() does not see that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
     """Oracle (CPU restatement of the reference algorithm) on the first n_sample batches, single thread."""
     from oracle import liquid_oracle as lo
@@ -242,13 +264,21 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
     for _, path in blobs:
         if path not in symtabs:
             symtabs[path] = lo.symtab_load(cache.symbol_table(path))
-    lo.eval_predicate(blobs[0][0], lo.LIKE, pattern, symtab=symtabs[blobs[0][1]])  # warm
+    # native loops over the batches (oracle/lo_bench.c): single thread = the reported baseline; one batch per OpenMP task
+    # over all host cores = the figure SURVEY §8d asks to report beside it
+    bl = [blob for blob, _ in blobs]
+    sts = [symtabs[path] for _, path in blobs]
+    lo.bench_eval_batches(bl[:8], sts[:8], lo.LIKE, pattern, 1)  # warm
     t0 = time.perf_counter()
-    hits = 0
-    for blob, path in blobs:
-        r = lo.eval_predicate(blob, lo.LIKE, pattern, symtab=symtabs[path])
-        hits += int(r.values.sum())
+    hits = lo.bench_eval_batches(bl, sts, lo.LIKE, pattern, 1)
     dt = time.perf_counter() - t0
+    cores = usable_cores()
+    t1 = time.perf_counter()
+    hits_mt = lo.bench_eval_batches(bl, sts, lo.LIKE, pattern, cores)
+    dt_mt = time.perf_counter() - t1
+    cpu_baseline_url.all_cores = {"value": rows_total / dt_mt, "unit": "rows/s", "cores": cores, "kind": "port",
+                                  "sample": "same batches, one batch per OpenMP task, %.2f s" % dt_mt,
+                                  "hits_match": hits_mt == hits}
     return rows_total / dt, rows_total, hits, dt
 
 
@@ -267,10 +297,15 @@ def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal):
         blobs.append(cache.transcode(pa.array(buf[:rows])))
         rows_total += rows
     t0 = time.perf_counter()
-    hits = 0
-    for blob in blobs:
-        hits += int(lo.eval_predicate(blob, lo.GT, literal).values.sum())
+    hits = lo.bench_eval_batches(blobs, None, lo.GT, literal, 1)
     dt = time.perf_counter() - t0
+    cores = usable_cores()
+    t1 = time.perf_counter()
+    hits_mt = lo.bench_eval_batches(blobs, None, lo.GT, literal, cores)
+    dt_mt = time.perf_counter() - t1
+    cpu_baseline_url.all_cores = {"value": rows_total / dt_mt, "unit": "rows/s", "cores": cores, "kind": "port",
+                                  "sample": "same batches, one batch per OpenMP task, %.2f s" % dt_mt,
+                                  "hits_match": hits_mt == hits}
     return rows_total / dt, rows_total, hits, dt
 
 
@@ -443,6 +478,8 @@ def main():
                 v, rows_s, hits_s, dt = cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal)
             out["cpu_baseline"] = {"value": v, "unit": "rows/s", "cores": 1, "kind": "port",
                                    "sample": "first %d batches (%d rows) of the same column, %.1f s" % (n_sample, rows_s, dt)}
+            if getattr(cpu_baseline_url, "all_cores", None):
+                out["cpu_baseline_all_cores"] = cpu_baseline_url.all_cores
         print(json.dumps(out), flush=True)
     scan.close()
     cache.close()

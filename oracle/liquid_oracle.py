@@ -423,6 +423,27 @@ def eval_predicate(liquid: bytes, op: int, literal, selection: Optional[np.ndarr
     return BoolResult(unpack_bits(ov, k), unpack_bits(ovalid, k) if nl.value else None)
 
 
+def bench_eval_batches(blobs, symtabs, op: int, literal, threads: int = 1) -> int:
+    """Native loop over many batches (lo_bench.c): rows whose predicate is true.  `symtabs[i]` is the SymTab of byte-view
+    batch i or None for fixed-width batches.  Used by bench.py's cpu_baseline leg only."""
+    n = len(blobs)
+    arrs = [_u8(b) for b in blobs]
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    lens = (C.c_size_t * n)(*[a.size for a in arrs])
+    is_str = symtabs is not None and any(s is not None for s in symtabs)
+    st_ptrs = (C.c_void_p * n)(*[C.addressof(s) if s is not None else None for s in symtabs]) if is_str else None
+    lg = logical_type(blobs[0])
+    info = None if lg == LOGICAL_BYTE_VIEW else array_info(blobs[0])
+    tag, buf, ln = _literal(lg, 0 if info is None else info.phys, literal)
+    fn = lib().lo_bench_eval_batches
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int]
+    r = fn(n, ptrs, lens, st_ptrs, op, tag, _ptr(buf), ln, threads)
+    if r < 0:
+        raise RuntimeError("lo_bench_eval_batches failed")
+    return int(r)
+
+
 def byte_view_len(liquid: bytes) -> int:
     a = _u8(liquid)
     # header(16) + view header(20) -> fsst at 40; keys section follows (serialization.rs:223-252)
