@@ -157,6 +157,9 @@ LC_API lc_status lc_symtab_set(lc_ctx* ctx, uint64_t path_id, const uint8_t* byt
  * is a byte view.  Replaces an entry that is already staged.  Data is copied; the caller keeps `bytes`. */
 LC_API lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes,
                           const size_t* lens, const uint64_t* path_ids);
+/* Drop entries (CacheEntry eviction / squeeze to disk in the reference); unknown ids are ignored.  A scan captures the
+ * device addresses of its entries when it is created: destroy the scans that cover an entry before evicting or
+ * re-staging it. */
 LC_API lc_status lc_evict(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids);
 LC_API lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out);
 
