@@ -912,8 +912,20 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const uint32_t role_addr = row0 + (nl + 1u) * 1024u;
     const uint32_t dres_addr = uint32_t(reinterpret_cast<uintptr_t>(wbase));
 
+    // This workgroup's entries: a precomputed range of at most four entries that share one symbol table (so the LDS
+    // automaton serves all of them), or — persistent / very large launches — an even split over the counter groups.
+    const uint32_t wg_group = blockIdx.x % L.work_groups;
+    uint32_t group_begin, group_end;
+    if (L.d_wg_ranges) {
+        group_begin = L.d_wg_ranges[2u * wg_group];
+        group_end = L.d_wg_ranges[2u * wg_group + 1u];
+    } else {
+        const uint32_t per_group = (L.n_entries + L.work_groups - 1u) / L.work_groups;
+        group_begin = wg_group * per_group;
+        group_end = min(L.n_entries, group_begin + per_group);
+    }
     const uint32_t slot0 = L.uniform_slot >= 0 ? uint32_t(L.uniform_slot)
-                                               : descs[min(blockIdx.x * kWavesPerBlock, L.n_entries - 1)].symtab_slot;
+                                               : descs[min(group_begin, L.n_entries - 1)].symtab_slot;
     if (lds_tbl) {
         // verbatim copy of the image k_str_automata built for this symbol table
         const GlobalPtr<u32x4> src = reinterpret_cast<GlobalPtr<u32x4>>(
@@ -933,11 +945,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     // 250 us), so the entries are cut into `work_groups` contiguous ranges, each with its own counter on its own cache
     // line, shared by the few workgroups with the same blockIdx % work_groups.  The last wave of a group to finish
     // zeroes the group's counters for the next launch.
-    const uint32_t wg_group = blockIdx.x % L.work_groups;
     uint32_t* work = L.d_work + wg_group * 16u;
-    const uint32_t per_group = (L.n_entries + L.work_groups - 1u) / L.work_groups;
-    const uint32_t group_begin = wg_group * per_group;
-    const uint32_t group_end = min(L.n_entries, group_begin + per_group);
     for (;;) {
         uint32_t entry = 0;
         if (lane == 0) entry = group_begin + atomicAdd(&work[0], 1u);
@@ -2099,6 +2107,13 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     static const char* env_g = std::getenv("LC_STR_WGS_PER_GROUP");  // tuning aid
     const uint32_t wgs_per_group = env_g && std::atoi(env_g) > 0 ? uint32_t(std::atoi(env_g)) : (persistent ? 4u : 1u);
     Lw.work_groups = std::max<uint32_t>(1u, std::min<uint32_t>(kWorkGroupsMax, grid / wgs_per_group));
+    if (!persistent && L.d_wg_ranges && L.n_wg_ranges <= kWorkGroupsMax) {
+        // one workgroup per precomputed range (<= 4 entries of one symbol table)
+        grid = L.n_wg_ranges;
+        Lw.work_groups = grid;
+    } else {
+        Lw.d_wg_ranges = nullptr;
+    }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), dyn_lds, stream, d_descs, d_symtabs, pred, Lw, dres_bytes,
                        cmask_bytes);
     return hipGetLastError();

@@ -115,7 +115,7 @@ struct StrPred {
     uint8_t needle_inline[kInlineNeedle];
 };
 
-constexpr uint32_t kWorkGroupsMax = 4096;
+constexpr uint32_t kWorkGroupsMax = 16384;
 
 struct ScanLaunch {
     uint32_t n_entries;
@@ -130,7 +130,8 @@ struct ScanLaunch {
     uint32_t* d_work;        // byte views: kWorkGroupsMax x {next, finished waves} at a 64-byte stride, zero between
                              // launches (self-resetting)
     uint32_t work_groups;    // byte views: number of counter groups used by this launch (set by the launcher)
-    uint32_t pad_;
+    uint32_t n_wg_ranges;    // byte views: entries of d_wg_ranges (0: entries are split evenly over the groups)
+    const uint32_t* d_wg_ranges;  // byte views: {begin, end} entry range per workgroup; a range never mixes symbol tables
 };
 
 hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,

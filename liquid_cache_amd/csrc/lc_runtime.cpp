@@ -109,6 +109,8 @@ struct lc_scan {
     size_t automata_symtabs = 0;           // ... over this many symbol tables (0: nothing cached)
     uint8_t* d_needle = nullptr;
     size_t needle_cap = 0;
+    uint32_t* d_wg_ranges = nullptr;  // byte views: {begin, end} per workgroup (<= 4 entries, one symbol table each)
+    uint32_t n_wg_ranges = 0;
     uint8_t* d_gather = nullptr;  // scratch of lc_scan_gather_bytes_async (grow only)
     size_t gather_cap = 0;
     uint32_t* d_work = nullptr;  // kWorkGroupsMax x {next entry, finished waves} (64-byte stride): dynamic entry
@@ -864,6 +866,7 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_seg_offsets);
     pool_release(s->ctx, s->d_work);
     pool_release(s->ctx, s->d_gather);
+    pool_release(s->ctx, s->d_wg_ranges);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
     delete s;
@@ -915,10 +918,31 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
                 return fail(LC_UNSUPPORTED, "general LIKE patterns apply to byte views without fingerprints (the "
                                             "reference requires %needle% on SubstringSearch columns)");
     std::lock_guard<std::mutex> g(s->mu);
+    if (!s->d_wg_ranges) {
+        // workgroup ranges: consecutive entries, at most four, never across a symbol-table change (row-group boundary)
+        std::vector<uint32_t> r;
+        uint32_t begin = 0;
+        for (uint32_t i = 1; i <= s->n; i++) {
+            if (i == s->n || i - begin == 4 || s->meta[i].sd.symtab_slot != s->meta[begin].sd.symtab_slot) {
+                r.push_back(begin);
+                r.push_back(i);
+                begin = i;
+            }
+        }
+        s->n_wg_ranges = uint32_t(r.size() / 2);
+        s->d_wg_ranges = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(r.size(), 2) * 4));
+        if (!s->d_wg_ranges) return fail(LC_ERR_OOM, "hipMalloc (scan workgroup ranges)");
+        LC_HIP(hipMemcpyAsync(s->d_wg_ranges, r.data(), r.size() * 4, hipMemcpyHostToDevice, stream));
+        LC_HIP(hipStreamSynchronize(stream));  // `r` is a local
+    }
+    L.d_wg_ranges = s->d_wg_ranges;
+    L.n_wg_ranges = s->n_wg_ranges;
     if (!s->d_work) {  // entry-draw counters of k_str_pred: zero once, the kernel leaves them zero
-        s->d_work = static_cast<uint32_t*>(pool_alloc(ctx, kWorkGroupsMax * 64));
+        // one 64-byte counter line per workgroup of the largest launch this scan can make
+        const size_t groups = std::min<size_t>(kWorkGroupsMax, std::max<size_t>({s->n_wg_ranges, (size_t(s->n) + 3) / 4, 1}));
+        s->d_work = static_cast<uint32_t*>(pool_alloc(ctx, groups * 64));
         if (!s->d_work) return fail(LC_ERR_OOM, "hipMalloc (scan work counters)");
-        LC_HIP(hipMemsetAsync(s->d_work, 0, kWorkGroupsMax * 64, stream));
+        LC_HIP(hipMemsetAsync(s->d_work, 0, groups * 64, stream));
     }
     L.d_work = s->d_work;
     if (sp.p.mode == 1) {
