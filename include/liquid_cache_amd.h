@@ -14,7 +14,8 @@
  *
  * Conventions (same as the reference / Arrow): little endian, LSB-first bitmaps, i32 offsets for
  * Utf8/Binary.  Cached arrays are immutable once staged.  All functions are thread-safe and
- * re-entrant; none of them aborts or throws across the ABI — they return an lc_status.
+ * re-entrant (calls on ONE lc_scan must be serialised by the caller, see lc_scan_eval); none of them aborts or
+ * throws across the ABI — every entry point catches C++ exceptions and returns an lc_status.
  * `LC_NOT_STAGED` corresponds to the reference's `None` ("not cached"), `LC_UNSUPPORTED` means
  * "run the reference CPU path for this call".
  *
@@ -157,9 +158,10 @@ LC_API lc_status lc_symtab_set(lc_ctx* ctx, uint64_t path_id, const uint8_t* byt
  * is a byte view.  Replaces an entry that is already staged.  Data is copied; the caller keeps `bytes`. */
 LC_API lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes,
                           const size_t* lens, const uint64_t* path_ids);
-/* Drop entries (CacheEntry eviction / squeeze to disk in the reference); unknown ids are ignored.  A scan captures the
- * device addresses of its entries when it is created: destroy the scans that cover an entry before evicting or
- * re-staging it. */
+/* Drop entries (CacheEntry eviction / squeeze to disk in the reference); unknown ids are ignored.  A scan pins the
+ * entries it was created over (the reference's scans hold `Arc<dyn LiquidArray>` clones): evicting or re-staging an
+ * entry under a live scan is safe — the scan keeps evaluating the data it captured, and the HBM is returned once the
+ * last scan holding it is destroyed. */
 LC_API lc_status lc_evict(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids);
 LC_API lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out);
 
@@ -233,7 +235,19 @@ LC_API void lc_scan_destroy(lc_scan* scan);
 LC_API uint64_t lc_scan_mask_words(const lc_scan* scan);  /* total u64 words of the mask */
 LC_API uint64_t lc_scan_rows(const lc_scan* scan);
 LC_API uint64_t lc_scan_entries(const lc_scan* scan);
-LC_API uint64_t lc_scan_algorithmic_bytes(const lc_scan* scan, const lc_predicate* pred, int32_t with_selection);
+/* Byte accounting of ONE evaluation of `pred` over the scan, for roofline reports:
+ *   *out_algorithmic  the reference algorithm's bytes: packed values / keys + selection + validity + output, and for
+ *                     byte views the prefilter (4D fingerprints or 8D prefix keys), the offsets and the compressed
+ *                     bytes of the prefilter's candidates;
+ *   *out_kernel_bytes the bytes this library's kernel itself has to move for the same result (it skips the packed
+ *                     data of entries whose FoR range decides the predicate, reads bigram-signature slices instead of
+ *                     fingerprints, walks only the candidates that survive them and reads keys only for entries in
+ *                     which some dictionary value matched) — the numerator of an honest HBM-roofline fraction.
+ * For byte views both are data dependent and are measured by one instrumented device pass on the default stream
+ * (synchronises; same serialisation rule as lc_scan_eval).  lc_scan_algorithmic_bytes returns the first figure. */
+LC_API lc_status lc_scan_traffic_model(lc_scan* scan, const lc_predicate* pred, int32_t with_selection,
+                                       uint64_t* out_algorithmic, uint64_t* out_kernel_bytes);
+LC_API uint64_t lc_scan_algorithmic_bytes(lc_scan* scan, const lc_predicate* pred, int32_t with_selection);
 /* word offset of entry i's segment inside the mask (n+1 values, host memory owned by the scan) */
 LC_API const uint64_t* lc_scan_segment_offsets(const lc_scan* scan);
 

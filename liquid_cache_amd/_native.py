@@ -63,6 +63,7 @@ EXPORTED_SYMBOLS = [
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
+    "lc_scan_traffic_model",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
     # include/liquid_cache_amd_bench.h
@@ -117,6 +118,7 @@ def load():
     for name in ("lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries"):
         getattr(L, name).restype = u64; getattr(L, name).argtypes = [vp]
     L.lc_scan_algorithmic_bytes.restype = u64; L.lc_scan_algorithmic_bytes.argtypes = [vp, P(Predicate), i32]
+    L.lc_scan_traffic_model.restype = i32; L.lc_scan_traffic_model.argtypes = [vp, P(Predicate), i32, P(u64), P(u64)]
     L.lc_scan_segment_offsets.restype = P(u64); L.lc_scan_segment_offsets.argtypes = [vp]
     L.lc_scan_eval.restype = i32; L.lc_scan_eval.argtypes = [vp, vp, P(Predicate), vp, vp, vp, vp]
     L.lc_scan_eval_timed.restype = i32

@@ -484,6 +484,14 @@ class Scan:
         pred = expr.as_predicate()
         return self._lib.lc_scan_algorithmic_bytes(self._h, C.byref(pred), int(with_selection))
 
+    def traffic_model(self, expr: LiquidExpr, with_selection: bool = False):
+        """(algorithmic bytes of the reference algorithm, bytes this kernel itself moves) for one evaluation."""
+        pred = expr.as_predicate()
+        alg, own = C.c_uint64(), C.c_uint64()
+        N.check(self._lib.lc_scan_traffic_model(self._h, C.byref(pred), int(with_selection), C.byref(alg),
+                                                C.byref(own)), self._cache.handle)
+        return int(alg.value), int(own.value)
+
     def eval(self, expr: LiquidExpr, mask_out_ptr: int, selection_ptr: int = 0, counts_ptr: int = 0,
              stream: int = 0):
         """Asynchronous: raw device pointers (e.g. torch tensor .data_ptr()) and a hipStream_t handle."""

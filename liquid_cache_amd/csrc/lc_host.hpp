@@ -164,7 +164,8 @@ struct BitPackedView {
 };
 
 // returns false on malformed input (the reference panics: bit_pack_array.rs:265-301)
-inline bool parse_bitpacked(const uint8_t* sec, size_t sec_len, BitPackedView* v) {
+// `max_width`: bit width of the lane type the section is unpacked into (a wider field is malformed input)
+inline bool parse_bitpacked(const uint8_t* sec, size_t sec_len, BitPackedView* v, int max_width = 64) {
     if (sec_len < 16) return false;
     *v = BitPackedView{};
     v->len = rd<uint32_t>(sec);
@@ -186,7 +187,7 @@ inline bool parse_bitpacked(const uint8_t* sec, size_t sec_len, BitPackedView* v
     v->values = sec + values_off;
     if (v->has_nulls && count_bits(v->nulls, v->len) == 0) v->all_null = true;  // :323-325
     if (!v->all_null) {
-        if (v->bit_width == 0 || v->bit_width > 64) return false;
+        if (v->bit_width == 0 || v->bit_width > max_width) return false;
         if (size_t(v->values_len) < packed_bytes(v->bit_width, v->len)) return false;
     }
     return true;
@@ -289,7 +290,7 @@ inline bool parse_fixed(const uint8_t* b, size_t len, FixedView* v) {
         return false;
     }
     if (bp_off > len) return false;
-    if (!parse_bitpacked(b + bp_off, len - bp_off, &v->bp)) return false;
+    if (!parse_bitpacked(b + bp_off, len - bp_off, &v->bp, v->lane_bits)) return false;
     return true;
 }
 
@@ -335,7 +336,7 @@ inline bool parse_byte_view(const uint8_t* b, size_t len, ByteViewParsed* v) {
     cur = align8(cur + fsst_size);
     if (cur + keys_size > len) return false;
     BitPackedView kv;
-    if (!parse_bitpacked(b + cur, keys_size, &kv)) return false;
+    if (!parse_bitpacked(b + cur, keys_size, &kv, 16)) return false;
     v->n = kv.len;
     v->nullable = kv.has_nulls || kv.all_null;
     v->all_null = kv.all_null;
@@ -392,11 +393,15 @@ inline uint32_t fingerprint(const uint8_t* s, size_t l) {
     return bits;
 }
 
-// fingerprint.rs:59-74
+// fingerprint.rs:59-74.  One deliberate narrowing: the reference re-forms "%inner%" and runs Arrow `like`
+// (comparisons.rs:629-634), in which a backslash escapes the next character, so an inner part holding a backslash is
+// NOT a plain memmem needle.  Such patterns are not treated as substring searches here: entries without fingerprints
+// evaluate them with the general Arrow-LIKE matcher (which implements the escape), entries with fingerprints answer
+// LC_UNSUPPORTED (the caller runs the reference CPU path).
 inline bool substring_pattern(const uint8_t* p, size_t pl, const uint8_t** inner, size_t* il) {
     if (pl < 3 || p[0] != '%' || p[pl - 1] != '%') return false;
     for (size_t i = 1; i + 1 < pl; i++)
-        if (p[i] == '%' || p[i] == '_') return false;
+        if (p[i] == '%' || p[i] == '_' || p[i] == '\\') return false;
     *inner = p + 1;
     *il = pl - 2;
     return true;

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
                 constexpr int kSteps = int(kBlockBytesMax / 1024u) > 0 ? int(kBlockBytesMax / 1024u) : 1;
 #pragma unroll
                 for (int s = 0; s < kSteps; s++) {
-                    if (uint32_t(s) * 64u < nchunks && !(pred.pad & 2)) {
+                    if (uint32_t(s) * 64u < nchunks && !LC_ABL(pred.pad & 2)) {
                         const uint32_t c = uint32_t(s) * 64u + uint32_t(lane);
                         if (c < nchunks) async_copy16(src + c, buf + s * 1024);
                     }
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (!(pred.pad & 1))
+                if (!LC_ABL(pred.pad & 1))
                 {
                     const uint32_t fo0 = fl[0] * uint32_t(sizeof(U)), fo1 = fl[1] * uint32_t(sizeof(U));
                     // dense groups (no selection / everything selected): no per-group branch, so the compiler can
@@ -886,13 +886,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     //              [per wave: dictionary results | signature candidate bitmap | candidate list / phase-C staging |
     //                         64 hit flags + head mask]
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+#ifdef LC_ABLATION
     const uint64_t rt_kernel = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     const uint32_t tid = threadIdx.x;
     const uint32_t nl = pred.needle_len;
-    const bool lds_tbl = kSub && nl <= kMaxLdsNeedle;
+    // The automaton image holds absolute LDS addresses computed for a table at LDS address 0: this kernel has no static
+    // LDS, so its dynamic segment starts there.  Should a toolchain ever place it elsewhere, the walkers fall back to the
+    // table in global memory (same results) instead of aborting the process.
+    const bool lds_tbl = kSub && nl <= kMaxLdsNeedle && uint32_t(reinterpret_cast<uintptr_t>(smem)) == 0u;
     const uint32_t tbl_bytes = lds_tbl ? automaton_image_bytes(nl) : 0u;
     constexpr uint32_t kNeedleLds = 256;
     constexpr uint32_t kFlagBytes = 80;
@@ -905,10 +910,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint16_t* cand = reinterpret_cast<uint16_t*>(wbase + dres_bytes + cmask_bytes);
     uint8_t* hitflag = wbase + dres_bytes + cmask_bytes + kCandCap * 2u;
     uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
-    // The automaton image holds absolute LDS addresses computed for a table at LDS address 0: this kernel has no
-    // static LDS, so its dynamic segment starts there.
     const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
-    if (lds_tbl && row0 != 0) __builtin_trap();
     const uint32_t role_addr = row0 + (nl + 1u) * 1024u;
     const uint32_t dres_addr = uint32_t(reinterpret_cast<uintptr_t>(wbase));
 
@@ -951,7 +953,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         if (lane == 0) entry = group_begin + atomicAdd(&work[0], 1u);
         entry = uint32_t(__builtin_amdgcn_readfirstlane(int(entry)));
         if (entry >= group_end) break;
+#ifdef LC_ABLATION
     const uint64_t rt_start = __builtin_amdgcn_s_memrealtime();
+#endif
     LC_TM_DECL;
     LC_TM(0, 0);
     const StrDesc d = descs[entry];
@@ -973,6 +977,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             if (lane == 0) {
                 if (L.d_counts) L.d_counts[entry] = 0;
                 if (L.d_cand_bytes) L.d_cand_bytes[entry] = 0;
+                if (L.d_own_bytes) L.d_own_bytes[entry] = uint32_t(sizeof(StrDesc)) + nwords * (L.d_valid ? 24u : 16u);
             }
             continue;
         }
@@ -1014,13 +1019,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const uint32_t needle_fp = pred.needle_fp;
     const bool prune = kSub && pred.use_fingerprints && d.fingerprints != nullptr;
     // bigram signature probe (needles of >= 2 bytes): AND of the needle's bit slices = candidate bitmap
-    const bool use_sig = prune && d.signatures != nullptr && pred.n_sig_bits > 0 && !(pred.debug_flags & 8);
+    const bool use_sig = prune && d.signatures != nullptr && pred.n_sig_bits > 0 && !LC_ABL(pred.debug_flags & 8);
     // with signatures the (weaker) fingerprint only matters for the NOT LIKE candidate-count rule and for the
     // algorithmic-byte instrumentation: its 4*D bytes are skipped otherwise
     const bool need_fp = prune && (!use_sig || op == LC_OP_NOT_LIKE || L.d_cand_bytes != nullptr);
 
     uint32_t fp_cand = 0;     // wave uniform: fingerprint candidates seen (NOT LIKE rule)
     uint32_t cand_bytes = 0;  // per lane, summed at the end (instrumented pass only)
+    uint32_t own_bytes = 0;   // per lane (instrumented pass only): bytes this kernel itself moves for the entry
     uint64_t any_true = 0;    // wave uniform: some dictionary entry evaluated true
     __builtin_amdgcn_wave_barrier();
 
@@ -1160,7 +1166,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         // ---- phase B: walk the candidate list ----
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         LC_TM(2, 0);
-        const uint32_t n_walk = (pred.debug_flags & 1) ? 0u : n_cand;
+        const uint32_t n_walk = LC_ABL(pred.debug_flags & 1) ? 0u : n_cand;
         for (uint32_t jb = 0; jb < n_walk; jb += kWave) {
             const uint32_t j = jb + uint32_t(lane);
             const bool cl = j < n_walk;
@@ -1168,6 +1174,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             uint32_t start = 0, stop = 0;
             if (cl) str_offset_pair(d, id, start, stop);
             if (L.d_cand_bytes && !prune) cand_bytes += stop - start;
+            if (L.d_own_bytes && cl) own_bytes += (stop - start) + 2u * d.offset_bytes;
             LC_TM(3, start);
             bool res = false;
             if (kSub && tbl_in_lds && n_walk - jb >= uint32_t(kWave)) {
@@ -1293,7 +1300,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     // (coalesced).  The candidate list is dead by now and provides the staging space.
     const bool all_false = any_true == 0;
     const uint32_t xor8 = invert ? 0xFFu : 0u;
-    const uint32_t n_rows = (pred.debug_flags & 2) ? 0u : d.n;
+    const uint32_t n_rows = LC_ABL(pred.debug_flags & 2) ? 0u : d.n;
     const uint32_t key_max = dres_bytes * 8u - 1u;  // bitmap: keys under null slots may be garbage (clamped)
     uint32_t hit_count = 0;
     constexpr int KC = 8;
@@ -1361,8 +1368,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     }
     if (L.d_counts) {
         uint64_t c = wave_sum_u64(uint64_t(hit_count));
+#ifdef LC_ABLATION
         if (((pred.debug_flags >> 10) & 7u) == 7u)  // timing instrumentation (LC_DEBUG_FLAGS, scripts/occupancy.py)
             c = ((((pred.debug_flags >> 14) & 1) ? rt_kernel : rt_start) & 0xFFFFu) << 16 | (__builtin_amdgcn_s_memrealtime() & 0xFFFFu);
+#endif
 #ifdef LC_KERNEL_TIMING
         LC_TM(8, 0);
         const uint32_t tsel = (uint32_t(pred.debug_flags) >> 16) & 15u;  // cycles between checkpoints tsel-1 and tsel
@@ -1376,6 +1385,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     if (L.d_cand_bytes) {
         const uint64_t c = wave_sum_u64(uint64_t(cand_bytes));
         if (lane == 0) L.d_cand_bytes[entry] = uint32_t(c);
+    }
+    if (L.d_own_bytes) {
+        // descriptor + phase A index (signature slices of the needle's distinct bigrams | fingerprints | prefix keys)
+        // + phase B (offset pairs and compressed bytes of the walked candidates, summed per lane above)
+        // + phase C (keys only when some dictionary value matched; selection / validity words in, mask words out)
+        uint32_t u = uint32_t(sizeof(StrDesc));
+        if (kSub) u += use_sig ? pred.n_sig_bits * nw * 8u : 0u;
+        if (kSub) u += need_fp ? 4u * d.d : 0u;
+        if (!kSub && pred.mode == 0 && uniform_result < 0) u += 8u * d.d;
+        if (!all_false) u += 2u * d.n;
+        u += nwords * 8u * ((L.d_selection ? 1u : 0u) + (d.validity ? 1u : 0u) + 1u + (L.d_valid ? 1u : 0u));
+        const uint64_t c = wave_sum_u64(uint64_t(own_bytes));
+        if (lane == 0) L.d_own_bytes[entry] = uint32_t(c) + u;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }  // entries
@@ -1658,7 +1680,8 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
 template <typename U>
 __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __restrict__ descs, ScanLaunch L,
                                                             const uint64_t* __restrict__ entry_offsets,
-                                                            uint8_t* __restrict__ out) {
+                                                            uint8_t* __restrict__ out, uint64_t capacity_rows) {
+    // rows at or beyond capacity_rows are not stored (the caller compares entry_offsets[n] with its capacity)
     constexpr uint32_t TB = LaneTraits<U>::kBits;
     constexpr uint32_t kBlockBytesMax = 128u * TB;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][kBlockBytesMax + 128];
@@ -1711,7 +1734,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
         const uint32_t ahi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act >> 32)), int(it)));
         const uint64_t aw = uint64_t(alo) | (uint64_t(ahi) << 32);
         if (aw == 0) continue;
-        if ((aw >> lane) & 1) {
+        if (((aw >> lane) & 1) && out_row + lanes_below(aw) < capacity_rows) {
             U u = 0;
             if (W != 0) {  // all-null entries decode to zeros (PrimitiveArray::new_null)
                 uint32_t row, fl;
@@ -1771,7 +1794,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
                     rank += uint64_t(__popcll(m & ((uint64_t(1) << (r & 63u)) - 1)));
                 }
             }
-            if (selected) {
+            if (selected && base_row + rank < capacity_rows) {
                 if (d.kind == kKindF32) reinterpret_cast<uint32_t*>(out)[base_row + rank] = reinterpret_cast<const uint32_t*>(d.patch_val)[p];
                 else reinterpret_cast<uint64_t*>(out)[base_row + rank] = reinterpret_cast<const uint64_t*>(d.patch_val)[p];
             }
@@ -2122,7 +2145,7 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
 
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
-                               hipStream_t stream) {
+                               uint64_t capacity_rows, hipStream_t stream) {
     if (L.n_entries == 0) return hipSuccess;
     // per-entry selected counts -> exclusive scan (= the entry row offsets the API returns) -> gather; the first two
     // scratch arrays are sized per 1024-row block by the callers, which covers the per-entry use here
@@ -2139,10 +2162,10 @@ hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const Sc
                        d_entry_row_offsets, static_cast<uint64_t*>(nullptr));
     const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * (lane_log2 == 6 ? 4 : 8))));
     switch (lane_log2) {
-        case 3: hipLaunchKernelGGL(k_fixed_gather<uint8_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
-        case 4: hipLaunchKernelGGL(k_fixed_gather<uint16_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
-        case 5: hipLaunchKernelGGL(k_fixed_gather<uint32_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
-        case 6: hipLaunchKernelGGL(k_fixed_gather<uint64_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out); break;
+        case 3: hipLaunchKernelGGL(k_fixed_gather<uint8_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out, capacity_rows); break;
+        case 4: hipLaunchKernelGGL(k_fixed_gather<uint16_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out, capacity_rows); break;
+        case 5: hipLaunchKernelGGL(k_fixed_gather<uint32_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out, capacity_rows); break;
+        case 6: hipLaunchKernelGGL(k_fixed_gather<uint64_t>, grid, block, 0, stream, d_descs, L, d_entry_row_offsets, d_values_out, capacity_rows); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

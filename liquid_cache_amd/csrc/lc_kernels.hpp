@@ -13,6 +13,14 @@
 
 #include <hip/hip_runtime.h>
 
+// Ablation hooks (skip a kernel phase, replace counts by timestamps) are compiled ONLY into profiling builds
+// (`make ABLATION=1`): in the shipped library no environment variable can change a result.
+#ifdef LC_ABLATION
+#define LC_ABL(expr) (expr)
+#else
+#define LC_ABL(expr) (false)
+#endif
+
 namespace lc {
 
 constexpr int kMaxNeedleAutomaton = 63;  // KMP automaton states must fit a u8 table
@@ -108,7 +116,7 @@ struct StrPred {
     const uint8_t* automata;   // mode 1: per symbol-table slot, automaton_stride(m) bytes (see above)
     uint32_t automaton_stride;
     int32_t const_value;       // mode 2: Literal(Boolean)
-    int32_t debug_flags;       // profiling only (env LC_DEBUG_FLAGS): 1 skip phase B, 2 skip phase C, 8 no signatures
+    int32_t debug_flags;       // -DLC_ABLATION builds only (env LC_DEBUG_FLAGS): 1 skip phase B, 2 skip phase C, 8 no signatures
     uint32_t needle_fp;        // LIKE: 32-bucket fingerprint of the needle (fingerprint.rs:33-35)
     uint32_t n_sig_bits;       // LIKE: distinct bigram-signature bits of the needle that are probed (<= kMaxSigProbe)
     uint8_t sig_bits[kMaxSigProbe];
@@ -124,7 +132,8 @@ struct ScanLaunch {
     uint64_t* d_hit;      // pred & valid & selected
     uint64_t* d_valid;    // optional: valid & selected
     uint32_t* d_counts;   // optional, must be zeroed by the launcher
-    uint32_t* d_cand_bytes;  // optional (byte views): per entry, compressed bytes of the candidates that were walked
+    uint32_t* d_cand_bytes;  // optional (byte views): per entry, compressed bytes of the reference's fingerprint candidates
+    uint32_t* d_own_bytes;   // optional (byte views): per entry, bytes this kernel had to read + write for the entry
     uint32_t max_dict_len;   // byte views: largest dictionary in the scan (sizes the LDS result bitmap)
     int32_t uniform_slot;    // byte views: symbol-table slot shared by every entry of the scan, or -1
     uint32_t* d_work;        // byte views: kWorkGroupsMax x {next, finished waves} at a 64-byte stride, zero between
@@ -159,7 +168,7 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
 inline size_t fixed_gather_offsets_len(size_t n_blocks) { return n_blocks + 1 + (n_blocks + 1023) / 1024 + 1; }
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
-                               hipStream_t stream);
+                               uint64_t capacity_rows, hipStream_t stream);
 // bit compress (PEXT) / deposit (PDEP) per entry segment
 hipError_t launch_mask_compress(const uint64_t* d_src, const uint64_t* d_sel, const uint64_t* d_seg_offsets,
                                 uint32_t n_entries, uint64_t* d_out, uint32_t* d_out_bits, hipStream_t stream);

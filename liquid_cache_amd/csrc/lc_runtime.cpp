@@ -23,18 +23,34 @@ using namespace lc;
 
 namespace {
 
-thread_local std::string g_last_error;
+// Message of the last failing call on this thread.  A fixed buffer: recording an error can never throw.
+thread_local char g_last_error[512] = {0};
 
-lc_status fail(lc_status st, const std::string& msg) {
-    g_last_error = msg;
+lc_status fail(lc_status st, const char* msg) noexcept {
+    std::snprintf(g_last_error, sizeof(g_last_error), "%s", msg ? msg : "");
     return st;
+}
+lc_status fail(lc_status st, const std::string& msg) noexcept { return fail(st, msg.c_str()); }
+
+// Nothing may unwind across the C ABI (include/liquid_cache_amd.h): every entry point runs its body through this.
+template <typename F>
+lc_status guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(LC_ERR_OOM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(LC_ERR_INVALID, e.what());
+    } catch (...) {
+        return fail(LC_ERR_INVALID, "unexpected exception");
+    }
 }
 
 #define LC_HIP(expr)                                                                              \
     do {                                                                                          \
         hipError_t _e = (expr);                                                                   \
         if (_e != hipSuccess)                                                                     \
-            return fail(LC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+            return fail(LC_ERR_DEVICE, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
     } while (0)
 
 constexpr size_t kSlabBytes = size_t(256) << 20;
@@ -73,7 +89,8 @@ struct lc_ctx {
     std::unordered_map<uint64_t, Entry> entries;
     std::vector<Slab> slabs;
     uint64_t max_hbm = 0;
-    uint64_t staged_bytes = 0;
+    uint64_t staged_bytes = 0;  // slab capacity reserved on the device (what max_hbm bounds)
+    uint64_t entry_bytes = 0;   // sum of the staged entries' blobs (what lc_device_info reports)
     // symbol tables
     std::mutex st_mu;
     std::unordered_map<uint64_t, uint32_t> symtab_slot;
@@ -82,6 +99,9 @@ struct lc_ctx {
     DevSymtab* d_symtabs = nullptr;
     size_t d_symtabs_cap = 0;
     size_t d_symtabs_uploaded = 0;
+    // earlier (smaller) generations of the device array: launches that captured them may still be in flight on some
+    // stream, so they are kept until the context goes away (a few hundred KB per doubling)
+    std::vector<DevSymtab*> d_symtabs_retired;
     // Recycled device scratch for the per-call drop-in API (descriptor arrays, masks, gather buffers): hipMalloc /
     // hipFree cost 0.1-1 ms each and hipFree synchronises the device, which would dominate an 8192-row call.
     std::mutex pool_mu;
@@ -115,6 +135,11 @@ struct lc_scan {
     size_t gather_cap = 0;
     uint32_t* d_work = nullptr;  // kWorkGroupsMax x {next entry, finished waves} (64-byte stride): dynamic entry
                                  // assignment of the persistent byte-view scan kernel
+    // device symbol tables as of scan creation: every entry of the scan references a slot below n_symtabs, and an array
+    // generation is never freed while the context lives, so launches need no lock against concurrent staging
+    const DevSymtab* d_symtabs = nullptr;
+    size_t n_symtabs = 0;
+    bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
     std::mutex mu;
 };
 
@@ -214,6 +239,10 @@ void pool_destroy(lc_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------ arena
+// Bump allocation inside 256 MiB slabs.  A slab is returned to the device as soon as nothing references it any more:
+// `live` counts its staged entries PLUS the scans that pinned one of its entries (lc_scan_create), which is what lets
+// lc_evict / re-staging run under a live scan — the scan keeps reading the old blob, like a cloned Arc in the reference,
+// and the slab goes away with the last of them.  `max_hbm_bytes` bounds the slab capacity that is reserved.
 lc_status arena_alloc(lc_ctx* ctx, size_t bytes, uint8_t** out, int* slab_idx) {
     bytes = align_up(bytes, kSectionAlign);
     if (!ctx->slabs.empty()) {
@@ -226,29 +255,40 @@ lc_status arena_alloc(lc_ctx* ctx, size_t bytes, uint8_t** out, int* slab_idx) {
             return LC_OK;
         }
     }
-    const size_t want = std::max(bytes, kSlabBytes);
-    if (ctx->max_hbm && ctx->staged_bytes + want > ctx->max_hbm)
-        return fail(LC_ERR_OOM, "HBM budget exhausted (max_hbm_bytes)");
+    size_t want = std::max(bytes, kSlabBytes);
+    if (ctx->max_hbm) {
+        const uint64_t left = ctx->max_hbm > ctx->staged_bytes ? ctx->max_hbm - ctx->staged_bytes : 0;
+        if (bytes > left) return fail(LC_ERR_OOM, "HBM budget exhausted (max_hbm_bytes)");
+        want = std::max<size_t>(bytes, std::min<uint64_t>(want, left));  // small budgets get small slabs
+    }
     Slab s;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.base), want);
     if (e != hipSuccess) return fail(LC_ERR_OOM, std::string("hipMalloc slab: ") + hipGetErrorString(e));
     s.size = want;
     s.used = bytes;
     s.live = 1;
+    // reuse the slot of a slab that was freed (indices held by entries / scans stay valid)
+    size_t idx = ctx->slabs.size();
     ctx->slabs.push_back(s);
     ctx->staged_bytes += want;
     *out = s.base;
-    *slab_idx = int(ctx->slabs.size()) - 1;
+    *slab_idx = int(idx);
     return LC_OK;
 }
 
+void arena_pin(lc_ctx* ctx, int slab_idx) {
+    if (slab_idx >= 0 && size_t(slab_idx) < ctx->slabs.size()) ctx->slabs[size_t(slab_idx)].live++;
+}
+
+// Caller holds ctx->mu exclusively and guarantees that no kernel still reads the slab's blobs.
 void arena_release(lc_ctx* ctx, int slab_idx) {
     if (slab_idx < 0 || size_t(slab_idx) >= ctx->slabs.size()) return;
     Slab& s = ctx->slabs[size_t(slab_idx)];
-    if (--s.live == 0 && size_t(slab_idx) + 1 != ctx->slabs.size() && s.base) {
+    if (--s.live == 0 && s.base) {
         (void)hipFree(s.base);
         ctx->staged_bytes -= s.size;
         s.base = nullptr;
+        s.size = s.used = 0;  // a drained LAST slab is not bumped into again: the next entry opens a new slab
     }
 }
 
@@ -281,10 +321,10 @@ lc_status sync_symtabs(lc_ctx* ctx) {
         DevSymtab* fresh = nullptr;
         LC_HIP(hipMalloc(reinterpret_cast<void**>(&fresh), cap * sizeof(DevSymtab)));
         if (ctx->d_symtabs) {
-            LC_HIP(hipDeviceSynchronize());
+            // uploads are synchronous copies, so the old array is complete; it is retired, not freed (see lc_ctx)
             LC_HIP(hipMemcpy(fresh, ctx->d_symtabs, ctx->d_symtabs_uploaded * sizeof(DevSymtab),
                              hipMemcpyDeviceToDevice));
-            LC_HIP(hipFree(ctx->d_symtabs));
+            ctx->d_symtabs_retired.push_back(ctx->d_symtabs);
         }
         ctx->d_symtabs = fresh;
         ctx->d_symtabs_cap = cap;
@@ -385,6 +425,9 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
                     size_t offs[8]) {
     ByteViewParsed v;
     if (!parse_byte_view(bytes, len, &v)) return fail(LC_ERR_CORRUPT, "malformed Liquid byte-view array");
+    // the row lists and mask utilities of the byte-view kernels address rows of an entry with 16 bits (the reference's
+    // batches are 8192 rows); larger arrays stay on the caller's CPU path
+    if (v.n > 65536) return fail(LC_UNSUPPORTED, "byte-view entries of more than 65536 rows are not handled on the device");
     uint32_t slot;
     const SymbolTable* host_st = nullptr;
     {
@@ -468,7 +511,9 @@ lc_status make_fixed_pred(const Entry& e, const lc_predicate* p, FixedPred* out)
     if (p->op < LC_OP_EQ || p->op > LC_OP_GE) return fail(LC_UNSUPPORTED, "operator not supported on numeric columns");
     *out = FixedPred{};
     out->op = p->op;
-    if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->pad = uint32_t(std::atoi(dbg));  // profiling only
+#ifdef LC_ABLATION
+    if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->pad = uint32_t(std::atoi(dbg));  // profiling builds only
+#endif
     if (!p->lit) return fail(LC_ERR_INVALID, "literal is null");
     if (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) {
         // the literal arrives in the column's own type (DataFusion casts it); its bits travel to the kernel, which
@@ -539,7 +584,9 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
             if (ll > size_t(kMaxNeedleBytes)) return fail(LC_UNSUPPORTED, "LIKE pattern longer than 4096 bytes");
             out->p.mode = 3;
             out->needle.assign(lit, lit + ll);
+#ifdef LC_ABLATION
             if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->p.debug_flags = std::atoi(dbg);
+#endif
             out->p.needle_len = uint32_t(out->needle.size());
             if (out->needle.size() <= size_t(kInlineNeedle))
                 std::memcpy(out->p.needle_inline, out->needle.data(), out->needle.size());
@@ -561,7 +608,9 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
     } else {
         return fail(LC_UNSUPPORTED, "operator not supported on byte-view columns");
     }
+#ifdef LC_ABLATION
     if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->p.debug_flags = std::atoi(dbg);
+#endif
     out->p.needle_len = uint32_t(out->needle.size());
     if (out->needle.size() <= size_t(kInlineNeedle))
         std::memcpy(out->p.needle_inline, out->needle.data(), out->needle.size());
@@ -577,9 +626,10 @@ extern "C" {
 
 const char* lc_version(void) { return "liquid_cache_amd 0.1 (gfx950)"; }
 
-const char* lc_last_error(lc_ctx*) { return g_last_error.c_str(); }
+const char* lc_last_error(lc_ctx*) { return g_last_error; }
 
 lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t max_hbm_bytes, lc_ctx** out) {
+    return guarded([&]() -> lc_status {
     if (!out) return fail(LC_ERR_INVALID, "out is null");
     *out = nullptr;
     if (n_devices == 0 && !device_ids) {
@@ -607,10 +657,12 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     if (const char* ns = std::getenv("LC_NO_SIGNATURES")) ctx->build_signatures = std::atoi(ns) == 0;
     *out = ctx.release();
     return LC_OK;
+    });
 }
 
 void lc_ctx_destroy(lc_ctx* ctx) {
     if (!ctx) return;
+    try {
     if (ctx->device < 0) { delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
@@ -618,24 +670,30 @@ void lc_ctx_destroy(lc_ctx* ctx) {
         if (s.base) (void)hipFree(s.base);
     pool_destroy(ctx);
     if (ctx->d_symtabs) (void)hipFree(ctx->d_symtabs);
+    for (DevSymtab* p : ctx->d_symtabs_retired) (void)hipFree(p);
     delete ctx;
+    } catch (...) {
+    }
 }
 
 lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !out) return fail(LC_ERR_INVALID, "null argument");
     std::memset(out, 0, sizeof(*out));
     out->device_id = ctx->device;
     out->compute_units = ctx->props.multiProcessorCount;
     out->hbm_total_bytes = ctx->props.totalGlobalMem;
     std::shared_lock<std::shared_mutex> g(ctx->mu);
-    out->hbm_staged_bytes = ctx->staged_bytes;
+    out->hbm_staged_bytes = ctx->entry_bytes;
     out->staged_entries = ctx->entries.size();
     std::snprintf(out->name, sizeof(out->name), "%s", ctx->props.name);
     std::snprintf(out->gcn_arch, sizeof(out->gcn_arch), "%s", ctx->props.gcnArchName);
     return LC_OK;
+    });
 }
 
 lc_status lc_symtab_set(lc_ctx* ctx, uint64_t path_id, const uint8_t* bytes, size_t len) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !bytes) return fail(LC_ERR_INVALID, "null argument");
     SymbolTable st;
     if (!st.load(bytes, len)) return fail(LC_ERR_CORRUPT, "malformed symbol table");
@@ -644,9 +702,11 @@ lc_status lc_symtab_set(lc_ctx* ctx, uint64_t path_id, const uint8_t* bytes, siz
     ctx->symtab_slot[path_id] = uint32_t(ctx->symtabs.size());
     ctx->symtabs.emplace_back(new SymbolTable(st));
     return LC_OK;
+    });
 }
 
 lc_status lc_symtab_get(lc_ctx* ctx, uint64_t path_id, uint8_t** out_bytes, size_t* out_len) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !out_bytes || !out_len) return fail(LC_ERR_INVALID, "null argument");
     CtxSymtabs s(ctx);
     const SymbolTable* st = s.find(path_id);
@@ -656,12 +716,14 @@ lc_status lc_symtab_get(lc_ctx* ctx, uint64_t path_id, uint8_t** out_bytes, size
     std::memcpy(*out_bytes, b.data(), b.size());
     *out_len = b.size();
     return LC_OK;
+    });
 }
 
 void lc_free(void* p) { std::free(p); }
 
 lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes,
                    const size_t* lens, const uint64_t* path_ids) {
+    return guarded([&]() -> lc_status {
     if (!ctx || (n && (!entry_ids || !bytes || !lens))) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
@@ -729,16 +791,20 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
             }
             auto old = ctx->entries.find(p.id);
             if (old != ctx->entries.end()) {
-                arena_release(ctx, old->second.slab);
+                ctx->entry_bytes -= old->second.device_bytes;
+                arena_release(ctx, old->second.slab);  // scans that pinned it keep the old blob alive
                 ctx->entries.erase(old);
             }
+            ctx->entry_bytes += p.e.device_bytes;
             ctx->entries.emplace(p.id, std::move(p.e));
         }
     }
     return sync_symtabs(ctx);
+    });
 }
 
 lc_status lc_evict(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids) {
+    return guarded([&]() -> lc_status {
     if (!ctx || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
@@ -747,13 +813,16 @@ lc_status lc_evict(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids) {
     for (uint64_t i = 0; i < n; i++) {
         auto it = ctx->entries.find(entry_ids[i]);
         if (it == ctx->entries.end()) continue;
+        ctx->entry_bytes -= it->second.device_bytes;
         arena_release(ctx, it->second.slab);
         ctx->entries.erase(it);
     }
     return LC_OK;
+    });
 }
 
 lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !out) return fail(LC_ERR_INVALID, "null argument");
     std::shared_lock<std::shared_mutex> g(ctx->mu);
     auto it = ctx->entries.find(entry_id);
@@ -771,10 +840,12 @@ lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out) 
     out->device_bytes = e.device_bytes;
     out->algorithmic_pred_bytes = e.is_str ? 0 : fixed_alg_bytes(e, false);
     return LC_OK;
+    });
 }
 
 lc_status lc_transcode_arrow(lc_ctx* ctx, const struct ArrowArray* array, const struct ArrowSchema* schema,
                              int32_t hint, uint64_t path_id, uint8_t** out_bytes, size_t* out_len) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !array || !schema || !out_bytes || !out_len) return fail(LC_ERR_INVALID, "null argument");
     CtxSymtabs st(ctx);
     std::vector<uint8_t> out;
@@ -785,10 +856,12 @@ lc_status lc_transcode_arrow(lc_ctx* ctx, const struct ArrowArray* array, const 
     std::memcpy(*out_bytes, out.data(), out.size());
     *out_len = out.size();
     return LC_OK;
+    });
 }
 
 lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArray* array,
                           const struct ArrowSchema* schema, int32_t hint, uint64_t path_id) {
+    return guarded([&]() -> lc_status {
     uint8_t* b = nullptr;
     size_t l = 0;
     lc_status rc = lc_transcode_arrow(ctx, array, schema, hint, path_id, &b, &l);
@@ -797,10 +870,12 @@ lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArra
     rc = lc_stage(ctx, 1, &entry_id, &bp, &l, &path_id);
     std::free(b);
     return rc;
+    });
 }
 
 // ------------------------------------------------------------------ scans
 lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !out || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
     *out = nullptr;
     if (n > 0xFFFFFFFFull) return fail(LC_ERR_INVALID, "too many entries in one scan");
@@ -834,6 +909,13 @@ lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_
         }
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
     }
+    {
+        // pin the slabs of the scan's entries: evicting or re-staging an entry under a live scan is then safe (the scan
+        // keeps the blob it captured; lc_scan_destroy drops the pins)
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        for (const Entry& e : s->meta) arena_pin(ctx, e.slab);
+        s->pinned = true;
+    }
     const size_t desc_size = s->is_str ? sizeof(StrDesc) : sizeof(FixedDesc);
     std::vector<uint8_t> host(desc_size * std::max<uint64_t>(n, 1));
     for (uint64_t i = 0; i < n; i++) {
@@ -849,17 +931,26 @@ lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_
         hipMemcpy(s->d_seg_offsets, s->seg_offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
         st = fail(LC_ERR_DEVICE, "hipMemcpy (scan offsets)");
     if (st == LC_OK) st = sync_symtabs(ctx);
+    if (st == LC_OK) {
+        std::lock_guard<std::mutex> g(ctx->st_mu);
+        s->d_symtabs = ctx->d_symtabs;
+        s->n_symtabs = ctx->d_symtabs_uploaded;
+    }
     if (st != LC_OK) {
         pool_release(ctx, s->d_descs);
         pool_release(ctx, s->d_seg_offsets);
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        for (const Entry& e : s->meta) arena_release(ctx, e.slab);
         return st;
     }
     *out = s.release();
     return LC_OK;
+    });
 }
 
 void lc_scan_destroy(lc_scan* s) {
     if (!s) return;
+    try {
     (void)hipSetDevice(s->ctx->device);
     (void)hipDeviceSynchronize();  // nothing in flight may still read the scan's buffers when they are recycled
     pool_release(s->ctx, s->d_descs);
@@ -869,7 +960,13 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_wg_ranges);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
+    if (s->pinned) {
+        std::unique_lock<std::shared_mutex> g(s->ctx->mu);
+        for (const Entry& e : s->meta) arena_release(s->ctx, e.slab);
+    }
     delete s;
+    } catch (...) {
+    }
 }
 
 uint64_t lc_scan_mask_words(const lc_scan* s) { return s ? s->seg_offsets.back() : 0; }
@@ -880,6 +977,7 @@ const uint64_t* lc_scan_segment_offsets(const lc_scan* s) { return s ? s->seg_of
 static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pred, const void* d_selection,
                                 void* d_mask_out, void* d_valid_out, void* d_counts_out, void* d_cand_bytes,
                                 hipStream_t stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !s || !pred || !d_mask_out) return fail(LC_ERR_INVALID, "null argument");
     if (s->n == 0) return LC_OK;
     ScanLaunch L{};
@@ -889,7 +987,8 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     L.d_hit = static_cast<uint64_t*>(d_mask_out);
     L.d_valid = static_cast<uint64_t*>(d_valid_out);
     L.d_counts = static_cast<uint32_t*>(d_counts_out);
-    L.d_cand_bytes = static_cast<uint32_t*>(d_cand_bytes);
+    L.d_cand_bytes = static_cast<uint32_t*>(d_cand_bytes);  // instrumented pass: [candidate bytes x n | kernel bytes x n]
+    L.d_own_bytes = d_cand_bytes ? static_cast<uint32_t*>(d_cand_bytes) + s->n : nullptr;
     L.uniform_slot = -1;
     L.d_work = s->d_work;
     for (const Entry& e : s->meta) L.max_dict_len = std::max(L.max_dict_len, e.dict_len);
@@ -947,7 +1046,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     L.d_work = s->d_work;
     if (sp.p.mode == 1) {
         const uint32_t stride = automaton_stride(sp.p.needle_len);
-        const size_t nst = ctx->d_symtabs_uploaded;
+        const size_t nst = s->n_symtabs;
         const size_t need = size_t(stride) * std::max<size_t>(nst, 1);
         if (need > s->automata_cap) {
             LC_HIP(hipStreamSynchronize(stream));
@@ -959,7 +1058,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         // a query evaluates one pattern over and over: the folded automata are rebuilt only when the needle or the
         // set of symbol tables changed (stream order keeps earlier launches valid)
         if (s->automata_symtabs != nst || s->automata_needle != sp.needle) {
-            LC_HIP(launch_str_automata(ctx->d_symtabs, uint32_t(nst), sp.needle.data(), sp.p.needle_len,
+            LC_HIP(launch_str_automata(s->d_symtabs, uint32_t(nst), sp.needle.data(), sp.p.needle_len,
                                        s->d_automata, stream));
             s->automata_needle = sp.needle;
             s->automata_symtabs = nst;
@@ -977,18 +1076,22 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         LC_HIP(hipMemcpy(s->d_needle, sp.needle.data(), sp.needle.size(), hipMemcpyHostToDevice));
         sp.p.needle = s->d_needle;
     }
-    LC_HIP(launch_str_pred(static_cast<const StrDesc*>(s->d_descs), ctx->d_symtabs, sp.p, L, stream));
+    LC_HIP(launch_str_pred(static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, sp.p, L, stream));
     return LC_OK;
+    });
 }
 
 lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
                        void* d_mask_out, void* d_counts_out, void* stream) {
+    return guarded([&]() -> lc_status {
     return scan_eval_impl(ctx, scan, pred, d_selection, d_mask_out, nullptr, d_counts_out, nullptr,
                           static_cast<hipStream_t>(stream));
+    });
 }
 
 lc_status lc_scan_eval_timed(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
                              void* d_mask_out, void* d_counts_out, void* stream, int32_t iters, float* out_avg_ms) {
+    return guarded([&]() -> lc_status {
     if (!out_avg_ms || iters <= 0) return fail(LC_ERR_INVALID, "bad iters/out");
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t a, b;
@@ -1007,80 +1110,131 @@ lc_status lc_scan_eval_timed(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pre
     (void)hipEventDestroy(b);
     *out_avg_ms = ms / float(iters);
     return LC_OK;
+    });
 }
 
-uint64_t lc_scan_algorithmic_bytes(const lc_scan* s_const, const lc_predicate* pred, int32_t with_selection) {
-    lc_scan* s = const_cast<lc_scan*>(s_const);
-    if (!s || !pred) return 0;
-    uint64_t total = 0;
+// Host-side form of packed_range()'s constant test for integer / decimal entries: an entry whose FoR range excludes the
+// literal is answered from its metadata and its packed data is never read.
+static bool fixed_entry_is_constant(const Entry& e, const FixedPred& fp) {
+    if (e.all_null || e.W == 0) return true;
+    if (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) return false;  // decided by the per-entry boundary search
+    if (fp.lit_class != 0) return true;
+    const uint64_t umax = e.W >= 64 ? ~uint64_t(0) : ((uint64_t(1) << e.W) - 1);
+    const bool below = e.fd.is_signed ? (int64_t(fp.lit) < int64_t(e.fd.reference)) : (fp.lit < e.fd.reference);
+    if (below) return true;
+    const uint64_t dlit = fp.lit - e.fd.reference;
+    if (dlit > umax) return true;
+    return (fp.op == LC_OP_LT && dlit == 0) || (fp.op == LC_OP_GT && dlit == umax);
+}
+
+lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t with_selection, uint64_t* out_algorithmic,
+                                uint64_t* out_kernel_bytes) {
+    return guarded([&]() -> lc_status {
+    if (!s || !pred || !out_algorithmic || !out_kernel_bytes) return fail(LC_ERR_INVALID, "null argument");
+    *out_algorithmic = *out_kernel_bytes = 0;
+    uint64_t alg = 0, own = 0;
     if (!s->is_str) {
-        for (const Entry& e : s->meta) total += fixed_alg_bytes(e, with_selection != 0);
-        return total;
+        if (s->n == 0) return LC_OK;
+        FixedPred fp;
+        const lc_status st = make_fixed_pred(s->meta[0], pred, &fp);
+        if (st != LC_OK) return st;
+        for (const Entry& e : s->meta) {
+            const uint64_t full = fixed_alg_bytes(e, with_selection != 0);
+            alg += full;
+            own += sizeof(FixedDesc) + (fixed_entry_is_constant(e, fp) ? full - uint64_t(e.len) * uint64_t(e.W) / 8 : full);
+        }
+        *out_algorithmic = alg;
+        *out_kernel_bytes = own;
+        return LC_OK;
     }
     // byte views: 2n keys + n/8 out (+ n/8 selection, + n/8 validity) and
     //   LIKE        : 4D fingerprints + offsets + compressed bytes of the fingerprint candidates
     //   Eq/ordering : 8D prefix keys + compressed bytes of the ambiguous entries
-    // candidate bytes are data dependent: measured by one instrumented device pass.
+    // Candidate bytes are data dependent: measured by ONE instrumented device pass (default stream, synchronised; the
+    // serialisation rule of lc_scan_eval applies).  The same pass counts the bytes this library's kernel itself has to
+    // move for the predicate (signature slices instead of fingerprints, only the candidates that survive them, keys
+    // only for entries in which some dictionary value matched).
     lc_ctx* ctx = s->ctx;
-    uint32_t* d_cand = nullptr;
-    uint64_t* d_mask = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&d_cand), size_t(s->n) * 4) != hipSuccess) return 0;
-    if (hipMalloc(reinterpret_cast<void**>(&d_mask), std::max<uint64_t>(s->seg_offsets.back(), 1) * 8) != hipSuccess) {
-        (void)hipFree(d_cand);
-        return 0;
-    }
-    (void)hipMemset(d_cand, 0, size_t(s->n) * 4);
-    std::vector<uint32_t> cand(s->n, 0);
-    if (scan_eval_impl(ctx, s, pred, nullptr, d_mask, nullptr, nullptr, d_cand, nullptr) == LC_OK &&
-        hipDeviceSynchronize() == hipSuccess)
-        (void)hipMemcpy(cand.data(), d_cand, size_t(s->n) * 4, hipMemcpyDeviceToHost);
-    (void)hipFree(d_cand);
-    (void)hipFree(d_mask);
+    LC_HIP(hipSetDevice(ctx->device));
+    uint32_t* d_cand = static_cast<uint32_t*>(pool_alloc(ctx, size_t(s->n) * 8 + 8));
+    uint64_t* d_mask = static_cast<uint64_t*>(pool_alloc(ctx, std::max<uint64_t>(s->seg_offsets.back(), 1) * 8));
+    std::vector<uint32_t> cand(size_t(s->n) * 2, 0);
+    lc_status rc = (!d_cand || !d_mask) ? fail(LC_ERR_OOM, "hipMalloc (traffic model scratch)") : LC_OK;
+    if (rc == LC_OK && hipMemset(d_cand, 0, size_t(s->n) * 8) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipMemset");
+    if (rc == LC_OK) rc = scan_eval_impl(ctx, s, pred, nullptr, d_mask, nullptr, nullptr, d_cand, nullptr);
+    if (rc == LC_OK && (hipDeviceSynchronize() != hipSuccess ||
+                        hipMemcpy(cand.data(), d_cand, size_t(s->n) * 8, hipMemcpyDeviceToHost) != hipSuccess))
+        rc = fail(LC_ERR_DEVICE, "traffic model: instrumented pass failed");
+    (void)hipDeviceSynchronize();
+    pool_release(ctx, d_cand);
+    pool_release(ctx, d_mask);
+    if (rc != LC_OK) return rc;
     const bool like = pred->op == LC_OP_LIKE || pred->op == LC_OP_NOT_LIKE;
     for (uint32_t i = 0; i < s->n; i++) {
         const Entry& e = s->meta[i];
         const uint64_t n = e.len, m = (n + 7) / 8;
-        total += 2 * n + m + (with_selection ? m : 0) + (e.nullable ? m : 0) + cand[i];
-        if (like) total += (e.has_fp ? 4ull * e.dict_len : 0) + e.offsets_bytes;
-        else if (pred->lit_tag == LC_LIT_BYTES) total += 8ull * e.dict_len + (cand[i] ? e.offsets_bytes : 0);
+        alg += 2 * n + m + (with_selection ? m : 0) + (e.nullable ? m : 0) + cand[i];
+        if (like) alg += (e.has_fp ? 4ull * e.dict_len : 0) + e.offsets_bytes;
+        else if (pred->lit_tag == LC_LIT_BYTES) alg += 8ull * e.dict_len + (cand[i] ? e.offsets_bytes : 0);
+        own += cand[size_t(s->n) + i];
     }
-    return total;
+    *out_algorithmic = alg;
+    *out_kernel_bytes = own;
+    return LC_OK;
+    });
+}
+
+uint64_t lc_scan_algorithmic_bytes(lc_scan* s, const lc_predicate* pred, int32_t with_selection) {
+    uint64_t alg = 0, own = 0;
+    return lc_scan_traffic_model(s, pred, with_selection, &alg, &own) == LC_OK ? alg : 0;
 }
 
 // ------------------------------------------------------------------ small device helpers
 lc_status lc_device_alloc(lc_ctx* ctx, uint64_t bytes, void** out) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !out) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
     LC_HIP(hipMalloc(out, bytes ? bytes : 8));
     return LC_OK;
+    });
 }
 lc_status lc_device_free(lc_ctx* ctx, void* p) {
+    return guarded([&]() -> lc_status {
     if (!ctx) return fail(LC_ERR_INVALID, "null argument");
     if (p) LC_HIP(hipFree(p));
     return LC_OK;
+    });
 }
 lc_status lc_device_memset(lc_ctx* ctx, void* p, int v, uint64_t bytes, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !p) return fail(LC_ERR_INVALID, "null argument");
     LC_HIP(hipMemsetAsync(p, v, bytes, static_cast<hipStream_t>(stream)));
     return LC_OK;
+    });
 }
 lc_status lc_device_to_host(lc_ctx* ctx, void* dst, const void* src, uint64_t bytes, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !dst || !src) return fail(LC_ERR_INVALID, "null argument");
     LC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
     LC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return LC_OK;
+    });
 }
 lc_status lc_host_to_device(lc_ctx* ctx, void* dst, const void* src, uint64_t bytes, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !dst || !src) return fail(LC_ERR_INVALID, "null argument");
     LC_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
     LC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return LC_OK;
+    });
 }
 lc_status lc_stream_synchronize(lc_ctx* ctx, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx) return fail(LC_ERR_INVALID, "null argument");
     LC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return LC_OK;
+    });
 }
 
 // ------------------------------------------------------------------ per-entry drop-in calls
@@ -1088,6 +1242,7 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
                                   const uint8_t* const* selections, uint8_t* const* out_values,
                                   uint8_t* const* out_validity, uint32_t* out_lens, int32_t* out_nullable,
                                   lc_status* statuses) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !pred || (n && (!entry_ids || !out_values || !out_lens)))
         return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
@@ -1191,10 +1346,12 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         if (out_nullable) out_nullable[i] = e.nullable ? 1 : 0;
     }
     return LC_OK;
+    });
 }
 
 lc_status lc_eval_predicate(lc_ctx* ctx, uint64_t entry_id, const lc_predicate* pred, const uint8_t* selection,
                             uint8_t* out_values, uint8_t* out_validity, uint32_t* out_len, int32_t* out_nullable) {
+    return guarded([&]() -> lc_status {
     if (!out_values || !out_len) return fail(LC_ERR_INVALID, "null output");
     const uint8_t* sels[1] = {selection};
     uint8_t* ov[1] = {out_values};
@@ -1204,10 +1361,12 @@ lc_status lc_eval_predicate(lc_ctx* ctx, uint64_t entry_id, const lc_predicate* 
     const lc_status rc = lc_eval_predicate_batch(ctx, 1, &entry_id, pred, sels, ov, ovalid, out_len, &nullable, &st);
     if (out_nullable) *out_nullable = nullable;
     return rc != LC_OK ? rc : st;
+    });
 }
 
 lc_status lc_mask_and_then(lc_ctx* ctx, const uint8_t* left, uint64_t left_bits, const uint8_t* right,
                            uint64_t right_bits, uint8_t* out) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !left || !out || (right_bits && !right)) return fail(LC_ERR_INVALID, "null argument");
     if (left_bits == right_bits) {  // datafusion/src/utils.rs:69-72
         std::memcpy(out, right, bitmap_bytes(left_bits));
@@ -1236,6 +1395,7 @@ lc_status lc_mask_and_then(lc_ctx* ctx, const uint8_t* left, uint64_t left_bits,
     pool_release(ctx, dout);
     if (rc == LC_OK) std::memcpy(out, hl.data(), bitmap_bytes(left_bits));
     return rc;
+    });
 }
 
 // ---- Arrow C Data Interface export helpers ----
@@ -1304,17 +1464,22 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
 // cache.get(&id).with_selection(&sel).read(): decode + compact on the device, export through the C Data Interface
 lc_status lc_get_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection,
                                 struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+    return guarded([&]() -> lc_status {
     return get_with_selection_impl(ctx, entry_id, selection, -1, out_array, out_schema);
+    });
 }
 
 lc_status lc_get_date_part_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection, int32_t field,
                                           struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+    return guarded([&]() -> lc_status {
     if (field < LC_DATE_YEAR || field > LC_DATE_DAY_OF_WEEK) return fail(LC_ERR_INVALID, "unknown date field");
     return get_with_selection_impl(ctx, entry_id, selection, field, out_array, out_schema);
+    });
 }
 
 static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection, int date_field,
                                          struct ArrowArray* out_array, struct ArrowSchema* out_schema) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !out_array || !out_schema) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
@@ -1406,7 +1571,7 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
         if (!d_bc || !d_bo || !d_eo || !d_vals) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
         LC_HIP_G(hipMemset(d_vals, 0, std::max<size_t>(k, 1) * vw + 64));
         LC_HIP_G(launch_fixed_gather(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, d_bc, d_bo, d_eo,
-                                     d_vals, nullptr));
+                                     d_vals, std::max<uint64_t>(k, 1), nullptr));
         if (date_field >= 0)
             LC_HIP_G(launch_date_lossy(d_vals, k, int(vw), date_field, date_ticks_per_day(e), nullptr));
         uint8_t* vals = host_alloc(std::max<size_t>(k, 1) * vw);
@@ -1421,14 +1586,14 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
         if (!d_dlen || !d_offs || !d_rows || !d_tot) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
         const StrDesc* descs = static_cast<const StrDesc*>(scan->d_descs);
         // passes 1+2 size the output, pass 3 decodes (two launches of the same helper keep the code in one place)
-        LC_HIP_G(launch_str_gather(descs, ctx->d_symtabs, 0, e.dict_len, 0, d_sel, d_dlen, d_offs, d_rows, d_tot, nullptr,
+        LC_HIP_G(launch_str_gather(descs, scan->d_symtabs, 0, e.dict_len, 0, d_sel, d_dlen, d_offs, d_rows, d_tot, nullptr,
                                    nullptr));
         uint64_t tot[2] = {0, 0};
         LC_HIP_G(hipMemcpy(tot, d_tot, 16, hipMemcpyDeviceToHost));
         if (tot[1] > uint64_t(INT32_MAX)) { dfree(); return fail(LC_UNSUPPORTED, "selected strings exceed 2 GiB (i32 offsets)"); }
         uint8_t* d_data = static_cast<uint8_t*>(dalloc(tot[1] + 64));
         if (!d_data) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
-        LC_HIP_G(launch_str_gather(descs, ctx->d_symtabs, 0, e.dict_len, uint32_t(tot[0]), d_sel, d_dlen, d_offs, d_rows,
+        LC_HIP_G(launch_str_gather(descs, scan->d_symtabs, 0, e.dict_len, uint32_t(tot[0]), d_sel, d_dlen, d_offs, d_rows,
                                    d_tot, d_data, nullptr));
         int32_t* offs = reinterpret_cast<int32_t*>(host_alloc((k + 1) * 4));
         uint8_t* data = host_alloc(tot[1]);
@@ -1449,16 +1614,21 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
     fill_schema(out_schema, arrow_format(e));
     out_array->private_data = priv.release();
     return LC_OK;
+    });
 }
 
 lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_values_out,
                                uint64_t values_capacity_bytes, void* d_row_offsets, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_values_out || !d_row_offsets) return fail(LC_ERR_INVALID, "null argument");
     if (scan->is_str) return fail(LC_UNSUPPORTED, "scan-wide gather covers fixed-width columns");
     if (scan->n == 0) return LC_OK;
     const uint64_t vw = scan->meta[0].fd.value_width;
     if (values_capacity_bytes < scan->total_rows * vw && !d_selection)
         return fail(LC_ERR_INVALID, "values buffer too small for an unselected gather");
+    // with a selection the row count is only known on the device: rows beyond the capacity are not written, and
+    // d_row_offsets[n] tells the caller how many there were
+    const uint64_t capacity_rows = values_capacity_bytes / vw;
     hipStream_t st = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> g(scan->mu);
     const size_t nblk = size_t(scan->n) * scan->bpe;
@@ -1476,13 +1646,16 @@ lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selecti
     L.blocks_per_entry = scan->bpe;
     L.d_selection = static_cast<const uint64_t*>(d_selection);
     LC_HIP(launch_fixed_gather(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, d_bc, d_bo,
-                               static_cast<uint64_t*>(d_row_offsets), static_cast<uint8_t*>(d_values_out), st));
+                               static_cast<uint64_t*>(d_row_offsets), static_cast<uint8_t*>(d_values_out), capacity_rows,
+                               st));
     return LC_OK;
+    });
 }
 
 lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_row_offsets,
                                     void* d_row_refs, void* d_value_offsets, void* d_row_valid, uint64_t capacity_rows,
                                     uint64_t* out_rows, uint64_t* out_bytes, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_row_offsets || !d_row_refs || !d_value_offsets || !out_rows || !out_bytes)
         return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
@@ -1516,7 +1689,7 @@ lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const void* d_se
     *out_rows = k;
     if (rc == LC_OK && k > capacity_rows) rc = fail(LC_ERR_INVALID, "gather plan: capacity_rows is smaller than the selection");
     if (rc == LC_OK && k > 0) {
-        if (launch_str_sel_rows(descs, ctx->d_symtabs, L, static_cast<const uint64_t*>(d_row_offsets), capacity_rows, k,
+        if (launch_str_sel_rows(descs, scan->d_symtabs, L, static_cast<const uint64_t*>(d_row_offsets), capacity_rows, k,
                                 static_cast<uint64_t*>(d_row_refs), d_len, static_cast<uint8_t*>(d_row_valid), d_tiles,
                                 static_cast<uint64_t*>(d_value_offsets), st) != hipSuccess ||
             hipMemcpyAsync(&bytes, static_cast<uint64_t*>(d_value_offsets) + k, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -1528,21 +1701,25 @@ lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const void* d_se
     *out_bytes = bytes;
     release();
     return rc;
+    });
 }
 
 lc_status lc_scan_gather_bytes(lc_ctx* ctx, lc_scan* scan, const void* d_row_refs, const void* d_value_offsets,
                                uint64_t rows, void* d_data, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !scan || (rows && (!d_row_refs || !d_value_offsets || !d_data))) return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
-    LC_HIP(launch_str_decode_sel(static_cast<const StrDesc*>(scan->d_descs), ctx->d_symtabs,
+    LC_HIP(launch_str_decode_sel(static_cast<const StrDesc*>(scan->d_descs), scan->d_symtabs,
                                  static_cast<const uint64_t*>(d_row_refs), static_cast<const uint64_t*>(d_value_offsets), rows,
                                  nullptr, rows, ~uint64_t(0), static_cast<uint8_t*>(d_data), static_cast<hipStream_t>(stream)));
     return LC_OK;
+    });
 }
 
 lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_row_offsets,
                                      void* d_row_refs, void* d_value_offsets, void* d_row_valid, uint64_t capacity_rows,
                                      void* d_data, uint64_t capacity_bytes, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_row_offsets || !d_row_refs || !d_value_offsets || !d_data || capacity_rows == 0)
         return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
@@ -1571,17 +1748,19 @@ lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_s
     LC_HIP(launch_str_entry_offsets(descs, L, d_counts, d_tiles, static_cast<uint64_t*>(d_row_offsets), st));
     // rows beyond the (device-side) count keep length 0, so the scan over the whole capacity yields their offsets too
     LC_HIP(hipMemsetAsync(d_len, 0, capacity_rows * 4, st));
-    LC_HIP(launch_str_sel_rows(descs, ctx->d_symtabs, L, static_cast<const uint64_t*>(d_row_offsets), capacity_rows,
+    LC_HIP(launch_str_sel_rows(descs, scan->d_symtabs, L, static_cast<const uint64_t*>(d_row_offsets), capacity_rows,
                                capacity_rows, static_cast<uint64_t*>(d_row_refs), d_len, static_cast<uint8_t*>(d_row_valid),
                                d_tiles, static_cast<uint64_t*>(d_value_offsets), st));
-    LC_HIP(launch_str_decode_sel(descs, ctx->d_symtabs, static_cast<const uint64_t*>(d_row_refs),
+    LC_HIP(launch_str_decode_sel(descs, scan->d_symtabs, static_cast<const uint64_t*>(d_row_refs),
                                  static_cast<const uint64_t*>(d_value_offsets), 0,
                                  static_cast<const uint64_t*>(d_row_offsets) + n, capacity_rows, capacity_bytes,
                                  static_cast<uint8_t*>(d_data), st));
     return LC_OK;
+    });
 }
 
 lc_status lc_scan_date_part(lc_ctx* ctx, lc_scan* scan, void* d_values, uint64_t n_values, int32_t field, void* stream) {
+    return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_values) return fail(LC_ERR_INVALID, "null argument");
     if (field < LC_DATE_YEAR || field > LC_DATE_DAY_OF_WEEK) return fail(LC_ERR_INVALID, "unknown date field");
     if (scan->n == 0 || n_values == 0) return LC_OK;
@@ -1590,6 +1769,7 @@ lc_status lc_scan_date_part(lc_ctx* ctx, lc_scan* scan, void* d_values, uint64_t
     LC_HIP(launch_date_lossy(d_values, n_values, int(scan->meta[0].fd.value_width), field, tpd,
                              static_cast<hipStream_t>(stream)));
     return LC_OK;
+    });
 }
 
 }  // extern "C"

@@ -407,15 +407,19 @@ static void dict_ordering(const lo_bv* bv, const lo_symtab* st, const uint8_t* n
 static void dict_like_substring(const lo_bv* bv, const lo_symtab* st, const uint8_t* inner, size_t il, int negate,
                                 uint8_t* res, uint32_t* n_candidates) {
     memset(res, 0, bv->d ? bv->d : 1);
-    uint32_t nfp = lo_fingerprint(inner, il);
+    uint32_t nfp = lo_fingerprint(inner, il); /* fingerprint of the RAW inner bytes (compute_fingerprint_candidates) */
     uint32_t cands = 0;
+    int has_escape = 0; /* `inner` always sits inside its pattern: inner[-1] and inner[il] are the two '%' */
+    for (size_t i = 0; i < il; i++) has_escape |= inner[i] == '\\';
     for (uint32_t i = 0; i < bv->d; i++) {
         uint32_t fp = lo_rd_u32(bv->fingerprints + 4 * (size_t)i);
         if ((fp & nfp) != nfp) continue;
         cands++;
         size_t vl;
         uint8_t* v = decode_entry(bv, st, i, &vl);
-        if (lo_contains(v, vl, inner, il)) res[i] = 1;
+        /* apply_like_match_on_candidates re-forms "%inner%" and runs Arrow LIKE (comparisons.rs:629-634): identical
+         * to memmem unless the inner part holds a backslash, which Arrow treats as an escape */
+        if (has_escape ? lo_like_match(v, vl, inner - 1, il + 2) : lo_contains(v, vl, inner, il)) res[i] = 1;
         free(v);
     }
     if (cands > 0 && negate)
