@@ -1,25 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — ClickBench "Q21" hot-cache filter scan on MI355X (liquid_cache_amd).
 
-One "step" = one pass of the decode + predicate-pushdown hot path over the whole staged column chunk:
-`URL LIKE '%google%'` (benchmark/clickbench/queries/q20.sql / q21.sql of the reference share this scan) over a
+One "step" = one pass of the decode + predicate-pushdown hot path over the whole staged column chunk, COUNT(*)
+included: `URL LIKE '%google%'` (benchmark/clickbench/queries/q20.sql / q21.sql of the reference share this scan) over a
 synthetic 100 M-row ClickBench-shaped URL column that is fully transcoded (dictionary + FSST + fingerprints) and
-resident in HBM before the timed region starts.  Reported: filtered rows/s (value), algorithmic GB/s, the
-roofline object of the dominant kernel (live HIP-event timing on the launch stream) and a CPU baseline (the C
-oracle restating the reference's algorithm) on a bounded sample of the same data.
+resident in HBM before the timed region starts.  Reported on ONE JSON line: filtered rows/s (value), the roofline
+object of the dominant kernel (live HIP-event timing on the launch stream; `achieved` counts the bytes the kernel itself
+has to move, `effective_gbs` the reference algorithm's bytes of SURVEY §8d; hot and L3-cold), a CPU baseline (the C oracle
+restating the reference's algorithm on the same bytes, whose hit count must equal the GPU's), and — at N=1 — the
+secondary workloads of BASELINE.json's other configs (Int64 `>`, narrow integer / date / decimal columns, the TPC-H Q6
+chain, get-with-selection, the q21.sql pushdown pipeline, LIKE without the signature index / without fingerprints).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: one process per GPU, row-range sharding (every rank stages and scans its own 8192-row batches; weak
-scaling: per-GPU rows fixed).  The only exchange step of the COUNT(*)-style query is the sum of per-rank hit
-counts: one 8-byte all-reduce over RCCL per step.
+Multi-GPU: one process per GPU, row-range sharding (every rank stages and scans its own 8192-row batches; weak scaling
+by default: per-GPU rows fixed; `--rows-total` fixes the table instead = strong scaling).  Exchange step per scan:
+`--exchange count` (default) one 8-byte all-reduce of the per-rank COUNT(*) over RCCL; `--exchange mask` the all-gather
+of the per-rank hit-mask segments into the single Arrow BooleanArray north_star names (12.5 MB for 100 M rows).
 """
 from __future__ import annotations
 
 import argparse
-import ctypes as C
+import datetime
+import decimal
 import json
 import os
 import sys
@@ -33,6 +38,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FLUSH_BYTES = 1 << 30  # scratch overwritten between cold launches (Infinity Cache: 256 MiB)
 
 
 def parse_args(argv=None):
@@ -41,6 +47,8 @@ def parse_args(argv=None):
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--rows", type=int, default=99_997_497, help="rows per GPU (ClickBench hits = 99,997,497)")
+    p.add_argument("--rows-total", type=int, default=0,
+                   help="strong scaling: rows of the whole table, split evenly over the ranks (overrides --rows)")
     p.add_argument("--batch-size", type=int, default=8192)
     p.add_argument("--uniques", type=int, default=2200, help="distinct URLs per batch (nano_hits: ~2,150-2,250)")
     p.add_argument("--row-group-batches", type=int, default=54, help="batches sharing one FSST symbol table")
@@ -49,23 +57,29 @@ def parse_args(argv=None):
                    help="distinct URLs per million that contain the needle (ClickBench hits: 15,911 of 99,997,497 rows match)")
     p.add_argument("--workload", default="url_like", choices=["url_like", "int64_gt"])
     p.add_argument("--int-bits", type=int, default=62, help="int64_gt: FoR bit width of every batch (WatchID ~62)")
-    p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = auto)")
+    p.add_argument("--exchange", default="count", choices=["count", "mask"],
+                   help="multi-GPU exchange step per scan: COUNT(*) all-reduce or all-gather of the hit-mask segments")
+    p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = whole column)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-fingerprints", action="store_true",
                    help="url_like: stage the column without the SubstringSearch hint (no fingerprints, no signature index: "
                         "every dictionary value is walked)")
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
+    p.add_argument("--no-secondary", action="store_true", help="skip every secondary workload (profiling runs)")
+    p.add_argument("--secondary-rows", type=int, default=0, help="rows of the secondary workloads (0 = --rows)")
     p.add_argument("--seed", type=int, default=42)
     return p.parse_args(argv)
 
 
-def stage_url_column(cache, lc, N, args, rank, n_batches, threads):
+# ---------------------------------------------------------------------------------------------------------- staging
+def stage_url_column(cache, lc, N, args, rank, n_batches, threads, file_id=None):
     """Generate + transcode + stage the URL column through the public API; returns entry ids."""
     L = N.load()
     import pyarrow as pa
     rows_total = args.rows
     bs = args.batch_size
-    ids = [lc.ParquetArrayID.new(rank, b // args.row_group_batches, 13, b % args.row_group_batches)
+    fid = rank if file_id is None else file_id
+    ids = [lc.ParquetArrayID.new(fid, b // args.row_group_batches, 13, b % args.row_group_batches)
            for b in range(n_batches)]
 
     def do_row_group(rg):
@@ -112,6 +126,125 @@ def stage_phrase_column(cache, lc, N, args, rank, n_batches, threads):
     return ids
 
 
+def int_base(bits: int) -> int:
+    return 4_000_000_000_000_000_000 >> (64 - bits) if bits < 63 else 0
+
+
+def _dec_array(pa, unscaled: np.ndarray):
+    buf = np.zeros((len(unscaled), 2), np.int64)
+    buf[:, 0] = unscaled
+    return pa.Array.from_buffers(pa.decimal128(15, 2), len(unscaled), [None, pa.py_buffer(buf)])
+
+
+def stage_int_column(cache, lc, N, args, rank, rows_total, threads, bits=None, base=None, col=0, kind="int64",
+                     on_batch=None):
+    """Uniform integers in [base, base + 2^bits) per batch, staged as Int64 / Int16 / Date32 / Decimal128(15,2).
+    `on_batch(b, values)` sees the generated int64 values (expected results are accumulated while staging)."""
+    L = N.load()
+    import pyarrow as pa
+    bs = args.batch_size
+    bits = args.int_bits if bits is None else bits
+    base = int_base(bits) if base is None else base
+    n_batches = (rows_total + bs - 1) // bs
+    ids = [lc.ParquetArrayID.new(rank, b // args.row_group_batches, col, b % args.row_group_batches)
+           for b in range(n_batches)]
+
+    def do_chunk(c):
+        buf = np.zeros(bs, np.int64)
+        for b in range(c, n_batches, threads):
+            rows = min(bs, rows_total - b * bs)
+            L.lc_synth_int64_batch(args.seed + rank * 1_000_003 + col * 7919, b, rows, bits, base, buf.ctypes.data)
+            v = buf[:rows]
+            if on_batch is not None:
+                on_batch(b, v)
+            if kind == "int64":
+                arr = pa.array(v)
+            elif kind == "int16":
+                arr = pa.array(v.astype(np.int16))
+            elif kind == "date32":
+                arr = pa.array(v.astype(np.int32), type=pa.date32())
+            else:
+                arr = _dec_array(pa, v)
+            cache.insert(ids[b], arr)
+        return c
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(do_chunk, range(threads)))
+    return ids
+
+
+# ---------------------------------------------------------------------------------------------------------- helpers
+def usable_cores() -> int:
+    """Cores this process may really use: CPU affinity capped by the cgroup CPU quota (a container on a 256-thread host
+    is often limited to a handful of cores, and os.cpu_count() does not see that)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:  # cgroup v1
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                quota = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                period = int(f.read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
+def measured_traffic(workload):
+    """HBM bytes per launch of the dominant kernel, from the rocprofv3 --pmc passes of the newest profiled round
+    (profiles/<round>/hbm_traffic.json, produced by scripts/profile_round.sh; counters cannot be read from inside the
+    process).  None when this workload has not been profiled."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if workload in d:
+            return int(d[workload]["traffic_bytes"]), os.path.relpath(f, ROOT)
+    return None, None
+
+
+def roofline(kernel, kernel_ms, alg_bytes, kernel_bytes, cold_ms=None, traffic=None, traffic_src=None):
+    """`achieved` = bytes the kernel itself has to move (lc_scan_traffic_model) / kernel time: a true fraction of the
+    HBM peak.  `effective_gbs` = the reference algorithm's bytes / the same time: what the scan is worth
+    to the query; it exceeds `achieved` wherever the kernel's index structures spare it bytes."""
+    ach = kernel_bytes / (kernel_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "traffic": traffic, "traffic_source": traffic_src,
+           "traffic_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+           "kernel": kernel, "kernel_ms": kernel_ms, "kernel_bytes_per_launch": int(kernel_bytes),
+           "algorithmic_bytes_per_launch": int(alg_bytes), "effective_gbs": alg_bytes / (kernel_ms * 1e-3) / 1e9}
+    if cold_ms is not None:
+        out.update({"kernel_ms_l3_cold": cold_ms, "achieved_l3_cold": kernel_bytes / (cold_ms * 1e-3) / 1e9,
+                    "frac_l3_cold": kernel_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+    return out
+
+
+def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=True):
+    """HIP-event kernel time (hot, and with the Infinity Cache flushed before every launch) + byte model of one predicate."""
+    words = int(scan.mask_words) if words is None else words
+    mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
+    counts = torch.zeros(max(scan.entries, 1), dtype=torch.int32, device="cuda")
+    scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ms = scan.eval_timed(expr, mask.data_ptr(), iters, 0, counts.data_ptr(), stream)
+    cold = scan.eval_timed_cold(expr, mask.data_ptr(), max(3, iters // 4), FLUSH_BYTES, 0, counts.data_ptr(), stream) \
+        if with_cold else None
+    alg, own = scan.traffic_model(expr, False)
+    r = roofline(kernel, ms, alg, own, cold)
+    r["hits"] = int(counts.sum(dtype=torch.int64).item())
+    r["rows_per_s"] = scan.rows / (ms * 1e-3)
+    return r, mask, counts
+
+
+# -------------------------------------------------------------------------------------------------- secondary workloads
 def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_expr, torch, stream):
     """The other reading of "Q21" (SURVEY §8d (ii)): q21.sql = SELECT "SearchPhrase", MIN("URL"), COUNT(*) ... WHERE
     "URL" LIKE '%google%' AND "SearchPhrase" <> '' GROUP BY ...: pushed-down part = `SearchPhrase <> ''` first (NotEq
@@ -165,13 +298,15 @@ def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_ex
     return res
 
 
-def measure_get_with_selection(scan, lc, args, base, words, counts, torch, stream):
-    """get-with-selection over the same Int64 column: the selected rows' decoded values compacted in row
-    order.  Extra measurement next to the headline (not part of `value`); rows chosen by a second predicate."""
+def measure_get_with_selection(scan, lc, bits, base, counts, torch, stream, iters):
+    """get-with-selection over an Int64 column: the selected rows' decoded values compacted in row order.
+    `necessary_bytes`: selection words + the packed blocks that hold a selected row (whole 128*W-byte block when more than
+    16 of its rows are selected, else two 8-byte words per selected row) + the values written."""
     import pyarrow as pa
     res = {}
+    words = int(scan.mask_words)
     for sel_name, sel_frac in (("10pct", 0.1), ("0.1pct", 0.001)):
-        sel_lit = base + int((1 << args.int_bits) * (1.0 - sel_frac))
+        sel_lit = base + int((1 << bits) * (1.0 - sel_frac))
         sel_mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
         scan.eval(lc.LiquidExpr.try_new(">", sel_lit, pa.int64()), sel_mask.data_ptr(), 0, counts.data_ptr(), stream)
         k_sel = int(counts.sum(dtype=torch.int64).item())
@@ -180,64 +315,185 @@ def measure_get_with_selection(scan, lc, args, base, words, counts, torch, strea
         for _ in range(2):
             scan.gather_fixed(vals.data_ptr(), vals.numel() * 8, offs.data_ptr(), sel_mask.data_ptr(), stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        iters = max(5, args.steps)
         e0.record()
         for _ in range(iters):
             scan.gather_fixed(vals.data_ptr(), vals.numel() * 8, offs.data_ptr(), sel_mask.data_ptr(), stream)
         e1.record()
         torch.cuda.synchronize()
         g_ms = e0.elapsed_time(e1) / iters
-        # algorithmic bytes: n*W/8 packed + n/8 selection read, k*sizeof(T) written
-        g_bytes = scan.rows * args.int_bits // 8 + scan.rows // 8 + k_sel * 8
+        # per 1024-row block (16 mask words; every batch but the last is 8 full blocks, entry segments are word aligned)
+        m = sel_mask.cpu().numpy().view(np.uint64)
+        pc = np.unpackbits(m.view(np.uint8)).reshape(-1, 64).sum(axis=1)
+        pad = (-len(pc)) % 16
+        per_block = np.concatenate([pc, np.zeros(pad, pc.dtype)]).reshape(-1, 16).sum(axis=1)
+        dense = per_block > 16
+        necessary = scan.rows // 8 + int(dense.sum()) * 128 * bits + int(per_block[~dense].sum()) * 16 + k_sel * 8
+        alg = scan.rows * bits // 8 + scan.rows // 8 + k_sel * 8   # n*W/8 + n/8 read, k*sizeof(T) written
         res[sel_name] = {"kernels": "k_sel_entry_counts + k_scan_{tile_sums,tiles,apply} + k_fixed_gather<u64>",
-                         "selected_rows": k_sel, "ms": g_ms, "algorithmic_bytes": int(g_bytes),
-                         "achieved_gbs": g_bytes / (g_ms * 1e-3) / 1e9,
-                         "frac": g_bytes / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "rows_per_s": scan.rows / (g_ms * 1e-3)}
+                         "selected_rows": k_sel, "ms": g_ms, "necessary_bytes": int(necessary),
+                         "achieved_gbs": necessary / (g_ms * 1e-3) / 1e9,
+                         "frac": necessary / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes": int(alg), "effective_gbs": alg / (g_ms * 1e-3) / 1e9,
+                         "rows_per_s": scan.rows / (g_ms * 1e-3)}
     return res
 
 
-def stage_int_column(cache, lc, N, args, rank, n_batches, threads):
-    L = N.load()
+def secondary_int_columns(cache, lc, N, args, rows, threads, torch, stream, iters):
+    """`col > literal` (50 % selective) over integer-like columns of the widths the other BASELINE configs use."""
     import pyarrow as pa
-    bs = args.batch_size
-    ids = [lc.ParquetArrayID.new(rank, b // args.row_group_batches, 0, b % args.row_group_batches)
-           for b in range(n_batches)]
+    out = {}
+    specs = [("int64_gt_w62", "int64", 62, None, pa.int64(), "k_fixed_pred<u64> (LDS staged)", 50),
+             ("date32_gt_w12", "date32", 12, 8036, pa.date32(), "k_fixed_pred_reg<u32>", 51),
+             ("int16_gt_w12", "int16", 12, 0, pa.int16(), "k_fixed_pred_reg<u16>", 52),
+             ("decimal_gt_w4", "decimal", 4, 0, pa.decimal128(15, 2), "k_fixed_pred_reg<u64>", 53),
+             ("int64_gt_w17", "int64", 17, 1000, pa.int64(), "k_fixed_pred_reg<u64>", 54)]
+    for name, kind, bits, base, dtype, kernel, col in specs:
+        try:
+            base_v = int_base(bits) if base is None else base
+            ids = stage_int_column(cache, lc, N, args, 1, rows, threads, bits=bits, base=base_v, col=col, kind=kind)
+            scan = cache.scan(ids)
+            lit = base_v + (1 << (bits - 1))
+            if kind == "decimal":
+                lit_v = decimal.Decimal(lit) / 100
+            elif kind == "date32":
+                lit_v = datetime.date(1970, 1, 1) + datetime.timedelta(days=lit)
+            else:
+                lit_v = lit
+            r, _, counts = time_pred(scan, lc.LiquidExpr.try_new(">", lit_v, dtype), torch, stream, iters, kernel)
+            r["rows"] = int(scan.rows)
+            if name == "int64_gt_w62":
+                r["get_with_selection"] = measure_get_with_selection(scan, lc, bits, base_v, counts, torch, stream, iters)
+            out[name] = r
+            scan.close()
+            cache.evict(ids)
+        except Exception as e:  # noqa: BLE001 - a secondary measurement must never cost the headline line
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
-    def do_chunk(c):
-        buf = np.zeros(bs, np.int64)
-        for b in range(c, n_batches, threads):
-            rows = min(bs, args.rows - b * bs)
-            L.lc_synth_int64_batch(args.seed + rank * 1_000_003, b, rows, args.int_bits, 4_000_000_000_000_000_000 >> (64 - args.int_bits) if args.int_bits < 63 else 0, buf.ctypes.data)
-            cache.insert(ids[b], pa.array(buf[:rows]))
-        return c
+
+def secondary_tpch_q6(cache, lc, N, args, rows, threads, torch, stream, iters):
+    """TPC-H Q6-shaped pushdown: l_shipdate >= d1 AND l_shipdate < d2 AND l_discount >= 0.05 AND
+    l_discount <= 0.07 AND l_quantity < 24, every mask the selection of the next predicate; `fused` evaluates the two
+    range pairs in one pass each (lc_scan_eval_and).  COUNT(*) per batch is checked against numpy, exactly."""
+    import pyarrow as pa
+    DEC = pa.decimal128(15, 2)
+    epoch = datetime.date(1970, 1, 1)
+    d_lo = (datetime.date(1992, 1, 2) - epoch).days
+    d1, d2 = (datetime.date(1994, 1, 1) - epoch).days, (datetime.date(1995, 1, 1) - epoch).days
+    bs = args.batch_size
+    n_batches = (rows + bs - 1) // bs
+    L = N.load()
+    ids = {c: [lc.ParquetArrayID.new(2, b // args.row_group_batches, c, b % args.row_group_batches)
+               for b in range(n_batches)] for c in (10, 6, 4)}
+    expected = np.zeros(n_batches, np.int64)
+
+    def stage(chunk):
+        # ship: 2^12 days from 1992-01-02 (W=12; the SF100 column spans 2,526 days); discount 0..15 hundredths (W=4, TPC-H
+        # has 0..10); quantity 1..64 (W=13 after the x100 scale, TPC-H has 1..50)
+        ship, disc, qty = np.zeros(bs, np.int64), np.zeros(bs, np.int64), np.zeros(bs, np.int64)
+        for b in range(chunk, n_batches, threads):
+            n = min(bs, rows - b * bs)
+            L.lc_synth_int64_batch(args.seed + 101, b, n, 12, d_lo, ship.ctypes.data)
+            L.lc_synth_int64_batch(args.seed + 102, b, n, 4, 0, disc.ctypes.data)
+            L.lc_synth_int64_batch(args.seed + 103, b, n, 6, 1, qty.ctypes.data)
+            sh, di, qt = ship[:n], disc[:n], qty[:n] * 100
+            expected[b] = int(((sh >= d1) & (sh < d2) & (di >= 5) & (di <= 7) & (qt < 2400)).sum())
+            cache.insert(ids[10][b], pa.array(sh.astype(np.int32), type=pa.date32()))
+            cache.insert(ids[6][b], _dec_array(pa, di))
+            cache.insert(ids[4][b], _dec_array(pa, qt))
 
     with ThreadPoolExecutor(max_workers=threads) as ex:
-        list(ex.map(do_chunk, range(threads)))
-    return ids
+        list(ex.map(stage, range(threads)))
+    ids_ship, ids_disc, ids_qty = ids[10], ids[6], ids[4]
+    s_ship, s_disc, s_qty = cache.scan(ids_ship), cache.scan(ids_disc), cache.scan(ids_qty)
+    words = int(s_ship.mask_words)
+    masks = [torch.zeros(words, dtype=torch.int64, device="cuda") for _ in range(2)]
+    counts = torch.zeros(s_ship.entries, dtype=torch.int32, device="cuda")
+    E = lc.LiquidExpr.try_new
+    conj = [(s_ship, E(">=", datetime.date(1994, 1, 1), pa.date32())), (s_ship, E("<", datetime.date(1995, 1, 1), pa.date32())),
+            (s_disc, E(">=", decimal.Decimal("0.05"), DEC)), (s_disc, E("<=", decimal.Decimal("0.07"), DEC)),
+            (s_qty, E("<", decimal.Decimal("24.00"), DEC))]
+    fused = [(s_ship, [conj[0][1], conj[1][1]]), (s_disc, [conj[2][1], conj[3][1]]), (s_qty, [conj[4][1]])]
+
+    def run_chain():
+        sel = 0
+        for i, (scan, expr) in enumerate(conj):
+            out = masks[i & 1]
+            scan.eval(expr, out.data_ptr(), sel, counts.data_ptr(), stream)
+            sel = out.data_ptr()
+
+    def run_fused():
+        sel = 0
+        for i, (scan, exprs) in enumerate(fused):
+            out = masks[i & 1]
+            ok = scan.eval_and(exprs, out.data_ptr(), sel, counts.data_ptr(), stream)
+            assert ok
+            sel = out.data_ptr()
+
+    res = {"rows": int(rows), "conjuncts": 5, "count": int(expected.sum())}
+    widths = {"ship": 12, "disc": 4, "qty": 13}
+    for tag, fn, passes in (("chained_5_passes", run_chain, [("ship", 0), ("ship", 1), ("disc", 1), ("disc", 1), ("qty", 1)]),
+                            ("fused_3_passes", run_fused, [("ship", 0), ("disc", 1), ("qty", 1)])):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        got = counts.cpu().numpy().astype(np.int64)
+        assert got.tolist() == expected.tolist(), "device COUNT(*) per batch differs from numpy (%s)" % tag
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        # algorithmic bytes of the passes that are run (SURVEY §8d: n*W/8 + selection n/8 (all but the first) + n/8 out)
+        alg = sum(rows * widths[c] // 8 + (rows // 8 if has_sel else 0) + rows // 8 for c, has_sel in passes)
+        res[tag] = {"ms": ms, "rows_per_s": rows / (ms * 1e-3), "algorithmic_bytes": int(alg),
+                    "achieved_gbs": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    # the chain is worth the 5-pass algorithmic bytes to the query whichever way it is run
+    alg5 = res["chained_5_passes"]["algorithmic_bytes"]
+    res["fused_3_passes"]["effective_gbs_vs_5_pass_bytes"] = alg5 / (res["fused_3_passes"]["ms"] * 1e-3) / 1e9
+    for s in (s_ship, s_disc, s_qty):
+        s.close()
+    cache.evict(ids_ship + ids_disc + ids_qty)
+    return res
 
 
-def usable_cores() -> int:
-    """Cores this process may really use: CPU affinity capped by the cgroup CPU quota (a container on a 256-thread host
-    is often limited to a handful of cores, and os.cpu_count() does not see that)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    try:
-        with open("/sys/fs/cgroup/cpu.max") as f:  # cgroup v2: "<quota> <period>" or "max <period>"
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        try:  # cgroup v1
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
-                quota = int(f.read())
-            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
-                period = int(f.read())
-            if quota > 0 and period > 0:
-                n = min(n, max(1, quota // period))
-        except (OSError, ValueError):
-            pass
-    return max(1, n)
+def secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream, iters, pattern):
+    """The LIKE scan in the reference-algorithm regimes: the reference's fingerprint prefilter only (no bigram signature
+    index staged), and a column staged without the SubstringSearch hint (no fingerprints: every dictionary value walked)."""
+    import copy
+    import pyarrow as pa
+    out = {}
+    for name, env, nofp in (("url_like_no_signatures", {"LC_NO_SIGNATURES": "1"}, False),
+                            ("url_like_no_fingerprints", {}, True)):
+        try:
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                cache2 = lc.LiquidCacheBuilder.new().with_device(torch.cuda.current_device()).build()
+            finally:
+                for k, v in old.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+            a2 = copy.copy(args)
+            a2.no_fingerprints = nofp
+            ids = stage_url_column(cache2, lc, N, a2, rank, n_batches, threads)
+            scan = cache2.scan(ids)
+            hint = lc.CacheExpression.SUBSTRING_SEARCH
+            expr = lc.LiquidExpr.try_new("like", pattern, pa.string(), hint)
+            r, _, _ = time_pred(scan, expr, torch, stream, max(3, iters // 2), "k_str_pred", with_cold=True)
+            out[name] = r
+            scan.close()
+            cache2.close()
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
 
 
+# ---------------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
     """Oracle (CPU restatement of the reference algorithm) on the first n_sample batches, single thread."""
     from oracle import liquid_oracle as lo
@@ -276,10 +532,9 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
     t1 = time.perf_counter()
     hits_mt = lo.bench_eval_batches(bl, sts, lo.LIKE, pattern, cores)
     dt_mt = time.perf_counter() - t1
-    cpu_baseline_url.all_cores = {"value": rows_total / dt_mt, "unit": "rows/s", "cores": cores, "kind": "port",
-                                  "sample": "same batches, one batch per OpenMP task, %.2f s" % dt_mt,
-                                  "hits_match": hits_mt == hits}
-    return rows_total / dt, rows_total, hits, dt
+    all_cores = {"value": rows_total / dt_mt, "unit": "rows/s", "cores": cores, "kind": "port",
+                 "sample": "same batches, one batch per OpenMP task, %.2f s" % dt_mt, "hits": int(hits_mt)}
+    return rows_total / dt, rows_total, int(hits), dt, all_cores
 
 
 def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal):
@@ -290,7 +545,7 @@ def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal):
     buf = np.zeros(bs, np.int64)
     blobs = []
     rows_total = 0
-    base = 4_000_000_000_000_000_000 >> (64 - args.int_bits) if args.int_bits < 63 else 0
+    base = int_base(args.int_bits)
     for b in range(n_sample):
         rows = min(bs, args.rows - b * bs)
         L.lc_synth_int64_batch(args.seed + rank * 1_000_003, b, rows, args.int_bits, base, buf.ctypes.data)
@@ -303,28 +558,12 @@ def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal):
     t1 = time.perf_counter()
     hits_mt = lo.bench_eval_batches(blobs, None, lo.GT, literal, cores)
     dt_mt = time.perf_counter() - t1
-    cpu_baseline_url.all_cores = {"value": rows_total / dt_mt, "unit": "rows/s", "cores": cores, "kind": "port",
-                                  "sample": "same batches, one batch per OpenMP task, %.2f s" % dt_mt,
-                                  "hits_match": hits_mt == hits}
-    return rows_total / dt, rows_total, hits, dt
+    all_cores = {"value": rows_total / dt_mt, "unit": "rows/s", "cores": cores, "kind": "port",
+                 "sample": "same batches, one batch per OpenMP task, %.2f s" % dt_mt, "hits": int(hits_mt)}
+    return rows_total / dt, rows_total, int(hits), dt, all_cores
 
 
-def measured_traffic(workload):
-    """HBM bytes per launch of the dominant kernel, from the rocprofv3 --pmc passes of the newest profiled round
-    (profiles/<round>/hbm_traffic.json, produced by scripts/profile_round.sh; counters cannot be read from inside the
-    process).  None when this workload has not been profiled."""
-    import glob
-    root = os.path.dirname(os.path.abspath(__file__))
-    for f in sorted(glob.glob(os.path.join(root, "profiles", "*", "hbm_traffic.json")), reverse=True):
-        try:
-            d = json.load(open(f))
-        except (OSError, ValueError):
-            continue
-        if workload in d:
-            return int(d[workload]["traffic_bytes"]), os.path.relpath(f, root)
-    return None, None
-
-
+# ---------------------------------------------------------------------------------------------------------- main
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -332,6 +571,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world != 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    scaling = "weak"
+    if args.rows_total:
+        # strong scaling: contiguous, batch-aligned row ranges per rank (liquid_cache_amd.sharding.assign_row_ranges
+        # over equally weighted batches gives exactly this split)
+        total_batches = (args.rows_total + args.batch_size - 1) // args.batch_size
+        b0, b1 = total_batches * rank // world, total_batches * (rank + 1) // world
+        args.rows = min(args.rows_total, b1 * args.batch_size) - b0 * args.batch_size
+        scaling = "strong"
 
     import torch
     import torch.distributed as dist
@@ -349,6 +596,7 @@ def main():
         dist.barrier()
     import liquid_cache_amd as lc
     from liquid_cache_amd import _native as N
+    import pyarrow as pa
 
     cache = lc.LiquidCacheBuilder.new().with_device(local_rank).with_batch_size(args.batch_size).build()
     n_batches = (args.rows + args.batch_size - 1) // args.batch_size
@@ -358,37 +606,36 @@ def main():
     if args.workload == "url_like":
         ids = stage_url_column(cache, lc, N, args, rank, n_batches, threads)
         pattern = ("%" + args.needle + "%").encode()
-        import pyarrow as pa
         expr = lc.LiquidExpr.try_new("like", pattern, pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
         workload = "clickbench_q21_url_like_%s%s" % (args.needle, "_no_fingerprints" if args.no_fingerprints else "")
-        dtype = "u8"
+        dtype, kernel = "u8", "k_str_pred"
     else:
-        ids = stage_int_column(cache, lc, N, args, rank, n_batches, threads)
-        import pyarrow as pa
-        base = 4_000_000_000_000_000_000 >> (64 - args.int_bits) if args.int_bits < 63 else 0
+        ids = stage_int_column(cache, lc, N, args, rank, args.rows, threads)
+        base = int_base(args.int_bits)
         literal = base + (1 << (args.int_bits - 1)) if args.int_bits < 64 else 0
         expr = lc.LiquidExpr.try_new(">", literal, pa.int64())
         workload = "clickbench_int64_gt_w%d" % args.int_bits
-        dtype = "int64"
+        dtype, kernel = "int64", ("k_fixed_pred_reg<u64>" if args.int_bits <= 32 else "k_fixed_pred<u64>")
     t_stage = time.perf_counter() - t_stage
 
     scan = cache.scan(ids)
     words = int(scan.mask_words)
     mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
     counts = torch.zeros(max(scan.entries, 1), dtype=torch.int32, device="cuda")
-    # COUNT(*) partials: two buffers so that the all-reduce of step i (RCCL's own stream) overlaps the scan of step i+1;
-    # int32 accumulators while the global count fits (one reduce kernel; an int64 sum of int32 counts costs torch an
-    # extra cast kernel per step)
-    from liquid_cache_amd.sharding import PipelinedCountAllReduce
-    acc_dtype = torch.int32 if scan.rows * world < 2**31 else torch.int64
-    reducer = PipelinedCountAllReduce(lambda: torch.zeros((), dtype=acc_dtype, device="cuda"), world)
+    # COUNT(*) partials: written by the predicate kernel itself (lc_scan_eval_count); two buffers so that the all-reduce
+    # of step i (RCCL's own stream) overlaps the scan of step i+1
+    from liquid_cache_amd.sharding import PipelinedCountAllReduce, all_gather_mask_segments
+    reducer = PipelinedCountAllReduce(lambda: torch.zeros((), dtype=torch.int64, device="cuda"), world)
     stream = torch.cuda.current_stream().cuda_stream
+    gathered = [None]
 
     def step():
         total = reducer.acquire()
-        scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
-        torch.sum(counts, dim=(0,), dtype=acc_dtype, out=total)  # COUNT(*) of this shard
-        reducer.submit()  # the query's only exchange step: COUNT(*) partials -> global count (4-8 bytes)
+        scan.eval_count(expr, mask.data_ptr(), total.data_ptr(), 0, 0, stream)  # mask + COUNT(*) of this shard, one kernel
+        reducer.submit()  # exchange step of COUNT(*) queries: the partial counts -> global count (8 bytes)
+        if args.exchange == "mask" and world > 1:
+            # exchange step of mask consumers: the per-rank segments -> one BooleanArray (row-range shards concatenate)
+            gathered[0] = all_gather_mask_segments(mask)
 
     drain = reducer.drain
 
@@ -410,31 +657,27 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    if os.environ.get("LC_DUMP_COUNTS"):  # kernel-instrumentation aid (see LC_DEBUG_FLAGS in lc_kernels.hip)
-        import numpy as _np
-        _np.save(os.environ["LC_DUMP_COUNTS"], counts.cpu().numpy())
     ms_per_step = elapsed / args.steps * 1e3
-    rows_all = scan.rows * world
+    rows_t = torch.tensor([scan.rows], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(rows_t, op=dist.ReduceOp.SUM)
+    rows_all = int(rows_t.item())
     hits = int(reducer.last().item())
+    # the fused total must be the sum of the per-entry counts of the same predicate (separate launch, plain reduction)
+    scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
+    local_hits = int(counts.sum(dtype=torch.int64).item())
+    lh = torch.tensor([local_hits], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(lh, op=dist.ReduceOp.SUM)
+    assert int(lh.item()) == hits, "fused COUNT(*) %d != sum of per-entry counts %d" % (hits, int(lh.item()))
+    if args.exchange == "mask" and world > 1:
+        assert sum(int(x.numel()) for x in gathered[0]) * 64 >= rows_all
 
     # roofline of the dominant kernel: HIP events on the launch stream, same launches as the timed region
-    alg_bytes = scan.algorithmic_bytes(expr, with_selection=False)
-    kernel_ms = scan.eval_timed(expr, mask.data_ptr(), max(5, args.steps), 0, counts.data_ptr(), stream)
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-
-    gather = None
-    if args.workload == "int64_gt" and rank == 0:
-        try:  # secondary measurement: it must never cost the headline line
-            gather = measure_get_with_selection(scan, lc, args, base, words, counts, torch, stream)
-        except Exception as e:  # noqa: BLE001
-            gather = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    q21 = None
-    if args.workload == "url_like" and rank == 0 and world == 1 and not args.no_q21:
-        try:  # secondary measurement: it must never cost the headline line
-            q21 = q21_pipeline(cache, lc, N, args, rank, n_batches, threads, scan, expr, torch, stream)
-        except Exception as e:  # noqa: BLE001
-            q21 = {"error": "%s: %s" % (type(e).__name__, e)}
+    alg_bytes, own_bytes = scan.traffic_model(expr, False)
+    iters = max(5, args.steps)
+    kernel_ms = scan.eval_timed(expr, mask.data_ptr(), iters, 0, counts.data_ptr(), stream)
+    cold_ms = scan.eval_timed_cold(expr, mask.data_ptr(), max(3, iters // 4), FLUSH_BYTES, 0, counts.data_ptr(), stream)
 
     out = None
     if rank == 0:
@@ -448,38 +691,54 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": workload, "rows_per_gpu": int(scan.rows), "batch_rows": args.batch_size,
-                       "batches_per_gpu": int(scan.entries), "distinct_per_batch": args.uniques,
-                       "parallelism": "row-range shards x%d, 8-byte count all-reduce per step (overlapped with the next scan)" % world,
+            "config": {"workload": workload, "rows_per_gpu": int(scan.rows), "rows_all_gpus": rows_all,
+                       "batch_rows": args.batch_size, "batches_per_gpu": int(scan.entries),
+                       "distinct_per_batch": args.uniques,
+                       "parallelism": "row-range shards x%d, %s per step" % (
+                           world, "8-byte COUNT(*) all-reduce (overlapped with the next scan)" if args.exchange == "count"
+                           else "COUNT(*) all-reduce + all-gather of the hit-mask segments"),
                        "predicate": ("URL LIKE '%%%s%%'" % args.needle) if args.workload == "url_like" else "col > literal",
                        "hits": hits, "stage_seconds": round(t_stage, 2)},
+            # what the scan is worth to the query: the reference algorithm's bytes per second of wall clock
             "gb_per_s_scanned": alg_bytes * world / (elapsed / args.steps) / 1e9,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         # what the kernel really pulls through HBM (the signature index and the skipped row phase
-                         # make it far less than the algorithmic bytes of the reference algorithm for LIKE)
-                         "traffic_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-                         "kernel": "k_str_pred" if args.workload == "url_like" else "k_fixed_pred<u64>",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": int(alg_bytes)},
+            "roofline": roofline(kernel, kernel_ms, alg_bytes, own_bytes, cold_ms, traffic, traffic_src),
         }
-        if gather is not None:
-            out["get_with_selection"] = gather
-        if q21 is not None:
-            out["q21_pipeline"] = q21
-        if world == 1 and not args.no_cpu_baseline:
-            n_sample = args.cpu_batches or n_batches  # ~5 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
-            if args.workload == "url_like":
-                v, rows_s, hits_s, dt = cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads)
-            else:
-                v, rows_s, hits_s, dt = cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal)
-            out["cpu_baseline"] = {"value": v, "unit": "rows/s", "cores": 1, "kind": "port",
-                                   "sample": "first %d batches (%d rows) of the same column, %.1f s" % (n_sample, rows_s, dt)}
-            if getattr(cpu_baseline_url, "all_cores", None):
-                out["cpu_baseline_all_cores"] = cpu_baseline_url.all_cores
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_sample = args.cpu_batches or n_batches  # ~4 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
+        if args.workload == "url_like":
+            v, rows_s, hits_s, dt, all_cores = cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads)
+        else:
+            v, rows_s, hits_s, dt, all_cores = cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal)
+        out["cpu_baseline"] = {"value": v, "unit": "rows/s", "cores": 1, "kind": "port", "hits": hits_s,
+                               "sample": "first %d batches (%d rows) of the same column, %.1f s" % (n_sample, rows_s, dt)}
+        out["cpu_baseline_all_cores"] = all_cores
+        out["config"]["cpu_hits"] = hits_s
+        if n_sample == n_batches:
+            # the CPU restatement of the reference algorithm and the GPU scan saw the same bytes: same COUNT(*)
+            assert hits_s == hits == all_cores["hits"], "GPU hits %d != CPU oracle hits %d" % (hits, hits_s)
+            out["config"]["hits_match_cpu_oracle"] = True
+
+    if rank == 0 and world == 1 and not args.no_secondary:
+        sec = {}
+        sec_rows = args.secondary_rows or args.rows
+        if args.workload == "url_like" and not args.no_q21:
+            try:
+                sec["q21_pipeline"] = q21_pipeline(cache, lc, N, args, rank, n_batches, threads, scan, expr, torch, stream)
+            except Exception as e:  # noqa: BLE001
+                sec["q21_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        sec.update(secondary_int_columns(cache, lc, N, args, sec_rows, threads, torch, stream, iters))
+        try:
+            sec["tpch_q6_pushdown"] = secondary_tpch_q6(cache, lc, N, args, sec_rows, threads, torch, stream, iters)
+        except Exception as e:  # noqa: BLE001
+            sec["tpch_q6_pushdown"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if args.workload == "url_like" and not args.no_fingerprints:
+            sec.update(secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream, iters, pattern))
+        out["secondary"] = sec
+    if rank == 0:
         print(json.dumps(out), flush=True)
     scan.close()
     cache.close()

@@ -262,6 +262,22 @@ LC_API const uint64_t* lc_scan_segment_offsets(const lc_scan* scan);
 LC_API lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
                               void* d_mask_out, void* d_counts_out, void* stream);
 
+/* The same for a conjunction of `n_preds` (1 or 2) predicates on THIS column evaluated in one pass — the common
+ * `col >= a AND col < b` pair that the reference's conjunct split (src/datafusion/src/reader/plantime/row_filter.rs:
+ * 428-515) turns into two passes over the same array: hit = preds[0] AND preds[1] AND valid AND selected, identical to
+ * chaining the two evaluations.  Fixed-width columns, operators Eq / Lt / LtEq / Gt / GtEq; LC_UNSUPPORTED otherwise
+ * (the caller chains two lc_scan_eval calls). */
+LC_API lc_status lc_scan_eval_and(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
+                                  const void* d_selection, void* d_mask_out, void* d_counts_out, void* stream);
+
+/* lc_scan_eval_and plus the COUNT(*) of the launch: *d_total_out (one u64, device) receives the number of hits of the
+ * whole scan, produced by the predicate kernel itself (no reduction pass, no memset between launches) — what a
+ * `SELECT COUNT(*) ... WHERE <pushed-down predicate>` consumer (ClickBench q20) or the 8-byte count all-reduce of a
+ * sharded scan reads.  d_counts_out (per entry) stays optional. */
+LC_API lc_status lc_scan_eval_count(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
+                                    const void* d_selection, void* d_mask_out, void* d_counts_out, void* d_total_out,
+                                    void* stream);
+
 /* get-with-selection over a whole scan for fixed-width columns: compacts the selected rows' decoded values
  * (original Arrow value width) into d_values_out in row order.  d_row_offsets (n+1 u64, device) receives the
  * exclusive prefix sum of per-entry selected counts.  Asynchronous on `stream`. */
@@ -310,6 +326,12 @@ LC_API lc_status lc_stream_synchronize(lc_ctx* ctx, void* stream);
 LC_API lc_status lc_scan_eval_timed(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
                                     void* d_mask_out, void* d_counts_out, void* stream, int32_t iters,
                                     float* out_avg_ms);
+
+/* The same with the memory-side cache flushed before every launch (`flush_bytes` of scratch are overwritten between
+ * launches; >= 512 MiB defeats the 256 MiB Infinity Cache): the cold-L3 kernel time of one evaluation. */
+LC_API lc_status lc_scan_eval_timed_cold(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
+                                         void* d_mask_out, void* d_counts_out, void* stream, int32_t iters,
+                                         uint64_t flush_bytes, float* out_avg_ms);
 
 #ifdef __cplusplus
 }

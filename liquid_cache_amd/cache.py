@@ -500,6 +500,42 @@ class Scan:
                                        C.c_void_p(mask_out_ptr), C.c_void_p(counts_ptr or None),
                                        C.c_void_p(stream or None)), self._cache.handle)
 
+    def eval_and(self, exprs: Sequence[LiquidExpr], mask_out_ptr: int, selection_ptr: int = 0, counts_ptr: int = 0,
+                 stream: int = 0) -> bool:
+        """One pass for a conjunction of one or two predicates on this column (lc_scan_eval_and).  Returns False when
+        the pair cannot be fused (the caller chains two `eval` calls instead)."""
+        preds = (N.Predicate * len(exprs))(*[e.as_predicate() for e in exprs])
+        st = self._lib.lc_scan_eval_and(self._cache.handle, self._h, preds, len(exprs), C.c_void_p(selection_ptr or None),
+                                        C.c_void_p(mask_out_ptr), C.c_void_p(counts_ptr or None),
+                                        C.c_void_p(stream or None))
+        if st == N.LC_UNSUPPORTED:
+            return False
+        N.check(st, self._cache.handle)
+        return True
+
+    def eval_count(self, exprs, mask_out_ptr: int, total_out_ptr: int, selection_ptr: int = 0, counts_ptr: int = 0,
+                   stream: int = 0):
+        """Predicate pass (one predicate or a fusable pair) whose kernel also produces the COUNT(*) of the launch in
+        `total_out_ptr` (one u64 on the device): lc_scan_eval_count."""
+        if isinstance(exprs, LiquidExpr):
+            exprs = [exprs]
+        preds = (N.Predicate * len(exprs))(*[e.as_predicate() for e in exprs])
+        N.check(self._lib.lc_scan_eval_count(self._cache.handle, self._h, preds, len(exprs),
+                                             C.c_void_p(selection_ptr or None), C.c_void_p(mask_out_ptr),
+                                             C.c_void_p(counts_ptr or None), C.c_void_p(total_out_ptr),
+                                             C.c_void_p(stream or None)), self._cache.handle)
+
+    def eval_timed_cold(self, expr: LiquidExpr, mask_out_ptr: int, iters: int, flush_bytes: int = 1 << 30,
+                        selection_ptr: int = 0, counts_ptr: int = 0, stream: int = 0) -> float:
+        """Average kernel milliseconds per evaluation with the Infinity Cache flushed before every launch."""
+        pred = expr.as_predicate()
+        ms = C.c_float()
+        N.check(self._lib.lc_scan_eval_timed_cold(self._cache.handle, self._h, C.byref(pred),
+                                                  C.c_void_p(selection_ptr or None), C.c_void_p(mask_out_ptr),
+                                                  C.c_void_p(counts_ptr or None), C.c_void_p(stream or None), iters,
+                                                  flush_bytes, C.byref(ms)), self._cache.handle)
+        return ms.value
+
     def eval_timed(self, expr: LiquidExpr, mask_out_ptr: int, iters: int, selection_ptr: int = 0,
                    counts_ptr: int = 0, stream: int = 0) -> float:
         """Average kernel-side milliseconds per evaluation, HIP events on `stream`."""

@@ -70,6 +70,11 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
 __device__ __forceinline__ uint32_t lane_shift_up1(uint32_t v, uint32_t first) {
     return uint32_t(__builtin_amdgcn_update_dpp(int(first), int(v), 0x138, 0xF, 0xF, false));  // wave_shr:1
 }
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
+    const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))));
+    return uint64_t(lo) | (uint64_t(hi) << 32);
+}
 __device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) { return uint32_t(__builtin_amdgcn_readlane(int(v), lane)); }
 
 // global -> LDS DMA of 16 bytes per active lane: lane l writes lds_base + l*16 (lds_base must be wave-uniform)
@@ -86,6 +91,37 @@ template <uint32_t LANE>
 __device__ __forceinline__ uint32_t writelane_c(uint32_t sval, uint32_t old) {
     asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(LANE));
     return old;
+}
+
+// Pointers read out of descriptors are generic to the compiler; these casts make the accesses global_load (own
+// vmcnt counter, no coupling with LDS waits) instead of flat_load.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+using GlobalPtr = const __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ GlobalPtr<T> as_global(const T* p) { return (GlobalPtr<T>)p; }
+
+// Fused COUNT(*): called by ONE lane of every wave of the launch (`unit` = its index, `n_units` = how many there are)
+// with the hits of the entries that wave evaluated.  Two levels of {arrivals : 24 | hits : 40} words: the last arrival
+// of a shard forwards the shard's sum to the top word, the last shard writes the total and leaves every word zero
+// for the next launch.  One returning far atomic per wave, nothing spins.
+__device__ __forceinline__ void total_contribute(const ScanLaunch& L, uint32_t unit, uint32_t n_units, uint64_t hits) {
+    constexpr unsigned long long kOne = 1ull << 40, kMask = kOne - 1;
+    const uint32_t n_shards = n_units < kTotalShards ? n_units : kTotalShards;
+    const uint32_t shard = unit % n_shards;
+    const uint32_t in_shard = (n_units - shard + n_shards - 1) / n_shards;
+    unsigned long long* sw = L.d_total_acc + 8u * (shard + 1u);
+    const unsigned long long inc = kOne | (hits & kMask);
+    const unsigned long long old = atomicAdd(sw, inc);
+    if ((old >> 40) + 1ull != in_shard) return;
+    const unsigned long long shard_hits = (old + inc) & kMask;
+    atomicExch(sw, 0ull);
+    const unsigned long long tinc = kOne | shard_hits;
+    const unsigned long long told = atomicAdd(L.d_total_acc, tinc);
+    if ((told >> 40) + 1ull != n_shards) return;
+    atomicExch(L.d_total_acc, 0ull);
+    // an atomic store: the value must land in memory, not in this XCD's L2 behind a later k_alp_patch_fix adjustment
+    atomicExch(reinterpret_cast<unsigned long long*>(L.d_total_out), (told + tinc) & kMask);
 }
 
 // FL_ORDER[x] = 3-bit reversal, stored as nibbles
@@ -305,6 +341,41 @@ __device__ __forceinline__ PackedRange<U> packed_range_alp(const FixedDesc& d, c
     return r;
 }
 
+// intersection of two packed-domain range tests on the same column (a fused conjunct pair such as `a >= x AND a < y`)
+template <typename U>
+__device__ __forceinline__ PackedRange<U> intersect_ranges(const PackedRange<U>& a, const PackedRange<U>& b) {
+    if (a.constant == 0 || b.constant == 0) return PackedRange<U>{0, 0, false, 0};
+    if (a.constant == 1) return b;
+    if (b.constant == 1) return a;
+    // neither is negated (the host only fuses Eq / Lt / LtEq / Gt / GtEq conjuncts)
+    const U lo = a.lo > b.lo ? a.lo : b.lo;
+    const U ahi = U(a.lo + a.span), bhi = U(b.lo + b.span);
+    const U hi = ahi < bhi ? ahi : bhi;
+    if (lo > hi) return PackedRange<U>{0, 0, false, 0};
+    return PackedRange<U>{lo, U(hi - lo), false, -1};
+}
+
+template <typename U>
+__device__ __forceinline__ PackedRange<U> entry_range(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2, int lane) {
+    const bool alp = d.kind == kKindF32 || d.kind == kKindF64;
+    PackedRange<U> pr = alp ? packed_range_alp<U>(d, pred, lane) : packed_range<U>(d, pred);
+    if (pred2.op >= 0) {
+        const PackedRange<U> pr2 = alp ? packed_range_alp<U>(d, pred2, lane) : packed_range<U>(d, pred2);
+        pr = intersect_ranges<U>(pr, pr2);
+    }
+    // every field is wave uniform (descriptor, literal, ballots); saying so keeps them in scalar registers
+    if constexpr (sizeof(U) == 8) {
+        pr.lo = U(uniform_u64(uint64_t(pr.lo)));
+        pr.span = U(uniform_u64(uint64_t(pr.span)));
+    } else {
+        pr.lo = U(__builtin_amdgcn_readfirstlane(int(uint32_t(pr.lo))));
+        pr.span = U(__builtin_amdgcn_readfirstlane(int(uint32_t(pr.span))));
+    }
+    pr.negate = __builtin_amdgcn_readfirstlane(int(pr.negate)) != 0;
+    pr.constant = __builtin_amdgcn_readfirstlane(pr.constant);
+    return pr;
+}
+
 // one 64-row group: lane i extracts logical row IT*64+i, a single range compare yields the ballot
 template <typename U, bool SKIP, uint32_t IT>
 __device__ __forceinline__ void fixed_pred_step(const uint8_t* buf, uint64_t act, uint32_t b0, uint32_t b1, uint32_t W,
@@ -348,7 +419,7 @@ __device__ __forceinline__ void fixed_pred_steps(std::integer_sequence<uint32_t,
 
 template <typename U>
 __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __restrict__ descs, FixedPred pred,
-                                                          ScanLaunch L) {
+                                                          FixedPred pred2, ScanLaunch L) {
     constexpr uint32_t TB = LaneTraits<U>::kBits;
     constexpr uint32_t LANES = 1024u / TB;
     constexpr uint32_t kBlockBytesMax = 128u * TB;
@@ -369,12 +440,12 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
 
     // one wave owns whole entries (their 1024-row blocks in turn): the descriptor and the packed-domain rewrite of
     // the predicate are read / computed once per entry, not once per block
+    uint64_t wave_hits = 0;  // fused COUNT(*): hits of every entry this wave evaluates (lane 0)
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
       const FixedDesc d = descs[entry];  // wave-uniform address: scalar loads
       const uint32_t len = d.len;
       const uint32_t W = d.W;
-      const PackedRange<U> pr = (d.kind == kKindF32 || d.kind == kKindF64) ? packed_range_alp<U>(d, pred, lane)
-                                                                           : packed_range<U>(d, pred);
+      const PackedRange<U> pr = entry_range<U>(d, pred, pred2, lane);
       uint32_t entry_count = 0;
       for (uint32_t blk = 0, row0 = 0; row0 < len; blk++, row0 += 1024u) {
         const uint32_t rows = min(1024u, len - row0);
@@ -434,23 +505,270 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
             L.d_hit[word_base + lane] = result;
             if (L.d_valid) L.d_valid[word_base + lane] = act;
         }
-        if (L.d_counts) entry_count += uint32_t(__popcll(result));
+        if (L.d_counts || L.d_total_out) entry_count += uint32_t(__popcll(result));
       }
-      if (L.d_counts) {  // one wave per entry: plain store, no atomics
+      if (L.d_counts || L.d_total_out) {  // one wave per entry: plain store, no atomics
           const uint64_t c = wave_sum_u64(uint64_t(entry_count));
-          if (lane == 0) L.d_counts[entry] = uint32_t(c);
+          if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(c);
+          wave_hits += c;
       }
     }
+    if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, total_waves, wave_hits);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fixed_pred_reg: the same predicate for entries of at most 32 bits per value, REGISTER RESIDENT.
+//
+// The LDS kernel above spends ~14 issue slots per 64 rows (LDS read pair, funnel shift, mask, subtract, compare, two
+// scalar ANDs, two lane writes, loop bookkeeping) whatever the width, so narrow columns (TPC-H dates W=12, decimals
+// W=4..13, the Int16 columns of ClickBench) ran at 0.16-0.34 of the HBM roofline.  Here the FastLanes layout is used
+// the way it was designed for SIMD: thread = FastLanes lane.  Word w of lane l lives at packed[LANES*w + l], so for a
+// fixed w the lanes of a wave read ONE contiguous 128-byte line (coalesced, straight into registers: no LDS, no
+// staging wait), every thread ends up holding its lane's bit stream, and — the width being a template parameter —
+// the position of every row in that stream is a compile-time constant: one shift (or funnel shift for a field that
+// straddles two words) puts the field at the TOP of a register, where the range test needs no mask:
+//     (u - lo) <= span   <=>   (t - (lo << (32-W))) <= (span << (32-W) | low ones),   t = field << (32-W) | junk below
+// A wave ballot of that compare IS one 64-row mask word, because the un-transposition of FastLanes maps "row r of all
+// lanes" to consecutive bits of one output word:
+//   u32 lanes (32 per block): thread = (block A|B of a pair, lane); step r gives bits [32*(r>>4), +32) of word
+//                             2*(r&7) + ((r>>3)&1) of block A in the low half of the ballot and of block B in the high half
+//   u16 lanes (64 per block): thread = lane; step r gives word 2*(r&7) + (r>>3) whole
+//   u64 lanes (16 per block): thread = (q, lane); q owns rows 16*{0,2,1,3}[q] .. +15; step r' gives word 2*(r'&7) + (r'>>3)
+// ~5 issue slots per 64 rows.  The words are parked in lanes 0..31 / 0..15 and combined with selection & validity once
+// per pass.  Constant outcomes (literal outside the entry's FoR range) still skip the packed data.
+// ------------------------------------------------------------------------------------------------
+template <int W, uint32_t R, int NW>
+__device__ __forceinline__ uint32_t field_top(const uint32_t (&w)[NW]) {
+    constexpr uint32_t pos = R * uint32_t(W), k = pos >> 5, off = pos & 31u;
+    if constexpr (off + uint32_t(W) <= 32u) {
+        constexpr uint32_t sh = 32u - off - uint32_t(W);
+        if constexpr (sh == 0) return w[k];
+        else return w[k] << sh;
+    } else {
+        return __builtin_amdgcn_alignbit(w[k + 1], w[k], off + uint32_t(W) - 32u);
+    }
+}
+
+// u32 lanes: one step = row R of blocks A (lanes 0..31) and B (lanes 32..63)
+template <int W, uint32_t R, int NW>
+__device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t span_t, uint32_t& X, uint32_t& Y) {
+    const uint32_t t = field_top<W, R, NW>(w);
+    const uint64_t b = __ballot(uint32_t(t - lo_t) <= span_t);
+    const uint32_t blo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b))));
+    const uint32_t bhi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32))));
+    constexpr uint32_t word = 2u * (R & 7u) + ((R >> 3) & 1u);
+    if constexpr ((R >> 4) == 0) {
+        X = writelane_c<word>(blo, X);
+        X = writelane_c<16u + word>(bhi, X);
+    } else {
+        Y = writelane_c<word>(blo, Y);
+        Y = writelane_c<16u + word>(bhi, Y);
+    }
+}
+template <int W, int NW, uint32_t... RS>
+__device__ __forceinline__ void reg_steps32(std::integer_sequence<uint32_t, RS...>, const uint32_t (&w)[NW], uint32_t lo_t,
+                                            uint32_t span_t, uint32_t& X, uint32_t& Y) {
+    (reg_step32<W, RS, NW>(w, lo_t, span_t, X, Y), ...);
+}
+// u16 / u64 lanes: one step = one whole 64-row word of the block
+template <int W, uint32_t R, int NW>
+__device__ __forceinline__ void reg_step16(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t span_t, uint32_t& X, uint32_t& Y) {
+    const uint32_t t = field_top<W, R, NW>(w);
+    const uint64_t b = __ballot(uint32_t(t - lo_t) <= span_t);
+    constexpr uint32_t word = 2u * (R & 7u) + (R >> 3);
+    X = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b)))), X);
+    Y = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32)))), Y);
+}
+template <int W, int NW, uint32_t... RS>
+__device__ __forceinline__ void reg_steps16(std::integer_sequence<uint32_t, RS...>, const uint32_t (&w)[NW], uint32_t lo_t,
+                                            uint32_t span_t, uint32_t& X, uint32_t& Y) {
+    (reg_step16<W, RS, NW>(w, lo_t, span_t, X, Y), ...);
+}
+
+// What one entry's passes need, passed BY VALUE to a non-inlined function per width: with all 32 widths inlined into
+// one kernel body the compiler hoists address arithmetic of every variant out of the entry loop and the kernel ends up
+// at 130-256 VGPRs; as separate functions each variant gets its own allocation (~40 VGPRs, 8 waves per SIMD).  One call
+// per entry (8 blocks) costs nothing next to the ~800 instructions it runs.
+struct RegEntryArgs {
+    const uint8_t* packed;
+    const uint64_t* validity;
+    const uint64_t* selection;  // already offset to the entry's segment, or null
+    uint64_t* hit;              // already offset to the entry's segment
+    uint64_t* valid_out;        // idem, or null
+    uint32_t len;
+    uint32_t lo, span;          // packed-domain range (values fit 32 bits: W <= 32)
+    int32_t constant;           // -1: evaluate; 0/1: every valid selected row gives this result
+    uint32_t negate;
+    uint32_t all_null;
+};
+
+__device__ __forceinline__ const uint8_t* uniform_ptr(const void* p) {
+    return reinterpret_cast<const uint8_t*>(uintptr_t(uniform_u64(uint64_t(reinterpret_cast<uintptr_t>(p)))));
+}
+
+// All passes of one entry.  Returns this lane's share of the entry's hit count.
+template <typename U, int W>
+__device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
+    constexpr uint32_t TB = LaneTraits<U>::kBits;
+    constexpr uint32_t kBlocksPerPass = TB == 32 ? 2u : 1u;
+    constexpr uint32_t kWordsPerPass = 16u * kBlocksPerPass;
+    // dwords of the thread's stream: u32 lanes hold all 32 rows of their lane, u16 / u64 threads hold 16 rows
+    constexpr int NW = TB == 32 ? W : (16 * W + 31) / 32;
+    const int lane = lane_id();
+    // arguments arrive in vector registers; they are wave uniform
+    const uint8_t* packed = uniform_ptr(a.packed);
+    const uint64_t* validity = reinterpret_cast<const uint64_t*>(uniform_ptr(a.validity));
+    const uint64_t* selection = reinterpret_cast<const uint64_t*>(uniform_ptr(a.selection));
+    uint64_t* hit = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(uniform_ptr(a.hit)));
+    uint64_t* valid_out = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(uniform_ptr(a.valid_out)));
+    const uint32_t len = uint32_t(__builtin_amdgcn_readfirstlane(int(a.len)));
+    const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(a.lo)));
+    const uint32_t span = uint32_t(__builtin_amdgcn_readfirstlane(int(a.span)));
+    const int constant = __builtin_amdgcn_readfirstlane(a.constant);
+    const bool all_null = __builtin_amdgcn_readfirstlane(int(a.all_null)) != 0;
+    const uint64_t neg = __builtin_amdgcn_readfirstlane(int(a.negate)) ? ~uint64_t(0) : uint64_t(0);
+    const uint32_t nwords_entry = (len + 63u) >> 6;
+    const uint32_t nblocks = (len + 1023u) >> 10;
+    const uint32_t lo_t = lo << (32 - W);
+    const uint32_t span_t = (span << (32 - W)) | (W == 32 ? 0u : ((1u << ((32 - W) & 31)) - 1u));
+    uint32_t count = 0;
+    for (uint32_t blk0 = 0; blk0 < nblocks; blk0 += kBlocksPerPass) {
+        // selection & validity: lane i (< kWordsPerPass) owns mask word 16*blk0 + i of the entry
+        const uint32_t widx = blk0 * 16u + uint32_t(lane);
+        uint64_t act = 0;
+        const bool own = uint32_t(lane) < kWordsPerPass && widx < nwords_entry;
+        if (own) {
+            uint64_t tail = ~uint64_t(0);
+            if (widx == nwords_entry - 1 && (len & 63u)) tail = (uint64_t(1) << (len & 63u)) - 1;
+            const uint64_t selw = selection ? as_global(selection)[widx] : ~uint64_t(0);
+            const uint64_t vw = validity ? as_global(validity)[widx] : ~uint64_t(0);
+            act = all_null ? 0 : (selw & vw & tail);  // all-null entries carry no validity buffer: no row is valid
+        }
+        uint64_t result = 0;
+        if (__ballot(act != 0) != 0) {  // blocks without a selected valid row do not touch their packed data
+            if (constant >= 0) {
+                result = constant ? act : 0;
+            } else {
+                uint32_t w[NW];
+                const uint8_t* base = packed + uint64_t(blk0) * 128u * uint32_t(W);
+                if constexpr (TB == 32) {
+                    // word k of FastLanes lane l of block A|B: one 128-byte line per block and k
+                    const bool have = blk0 + (uint32_t(lane) >> 5) < nblocks;
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + (uint32_t(lane) >> 5) * 32u * uint32_t(W) +
+                                        (uint32_t(lane) & 31u);
+#pragma unroll
+                    for (int k = 0; k < NW; k++) w[k] = have ? as_global(p)[k * 32] : 0u;
+                } else if constexpr (TB == 16) {
+                    // u16 word j of lane l at j*128 + 2l; two of them make one dword of the stream
+                    const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + uint32_t(lane);
+#pragma unroll
+                    for (int k = 0; k < NW; k++) {
+                        const uint32_t x = as_global(p)[(2 * k) * 64];
+                        const uint32_t y = (2 * k + 1 < W) ? uint32_t(as_global(p)[(2 * k + 1) * 64]) : 0u;
+                        w[k] = x | (y << 16);
+                    }
+                } else {
+                    // u64 lanes: thread (q, l) owns rows 16*g .. 16*g+15 of lane l, g = {0,2,1,3}[q]: bits [16*g*W, +16*W) of
+                    // the lane's stream of u64 words (word j at j*128 + 8l), read as dwords
+                    const uint32_t q = uint32_t(lane) >> 4, l = uint32_t(lane) & 15u;
+                    const uint32_t g = ((q & 1u) << 1) | (q >> 1);
+                    const uint32_t bit0 = 16u * g * uint32_t(W);
+                    const uint32_t d0 = bit0 >> 5;  // first dword of the thread's stream; dword i of a lane's stream is
+                                                    // half (i & 1) of u64 word i >> 1, i.e. at byte (i >> 1) * 128 + (i & 1) * 4
+                    // two per-thread bases so that every load has a compile-time offset whatever the parity of d0:
+                    //   d0 even: dword d0+k at base + (k>>1)*128 + (k&1)*4;   d0 odd: the same + 4 (k even) or + 124 (k odd)
+                    const uint8_t* b0 = base + l * 8u + (d0 >> 1) * 128u + (d0 & 1u) * 4u;
+                    const uint32_t* pe = reinterpret_cast<const uint32_t*>(b0);
+                    const uint32_t* po = reinterpret_cast<const uint32_t*>(b0 + (d0 & 1u) * 120u);
+#pragma unroll
+                    for (int k = 0; k < NW; k++) w[k] = (k & 1) ? as_global(po)[(k >> 1) * 32 + 1] : as_global(pe)[(k >> 1) * 32];
+                    if constexpr (W & 1) {  // odd widths: the 16-row groups start on a 16-bit boundary
+                        const uint32_t bo = bit0 & 31u;
+#pragma unroll
+                        for (int k = 0; k + 1 < NW; k++) w[k] = __builtin_amdgcn_alignbit(w[k + 1], w[k], bo);
+                        w[NW - 1] >>= bo;  // its last 16 stream bits
+                    }
+                }
+                uint32_t X = 0, Y = 0;
+                if constexpr (TB == 32) reg_steps32<W, NW>(std::make_integer_sequence<uint32_t, 32>{}, w, lo_t, span_t, X, Y);
+                else reg_steps16<W, NW>(std::make_integer_sequence<uint32_t, 16>{}, w, lo_t, span_t, X, Y);
+                result = ((uint64_t(X) | (uint64_t(Y) << 32)) ^ neg) & act;
+            }
+        }
+        if (own) {
+            hit[widx] = result;
+            if (valid_out) valid_out[widx] = act;
+        }
+        count += uint32_t(__popcll(result));
+    }
+    return count;
+}
+
+template <typename U, int... WS>
+__device__ __forceinline__ uint32_t fixed_pred_entry_dispatch(std::integer_sequence<int, WS...>, uint32_t W,
+                                                              const RegEntryArgs& a) {
+    uint32_t c = 0;
+    // W is wave uniform: exactly one of these branches runs
+    ((int(W) == WS + 1 ? (void)(c = fixed_pred_entry_reg<U, WS + 1>(a)) : (void)0), ...);
+    return c;
+}
+
+// kMaxW: widest entry the instantiation handles (16 or 32).  The register allocation of a kernel is the maximum over the
+// per-width functions it can call, so scans of narrow columns get the instantiation with the smaller footprint.
+template <typename U, int kMaxW>
+__global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __restrict__ descs, FixedPred pred,
+                                                              FixedPred pred2, ScanLaunch L) {
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    uint64_t wave_hits = 0;
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
+        const FixedDesc d = descs[entry];
+        const PackedRange<U> pr = entry_range<U>(d, pred, pred2, lane);
+        RegEntryArgs a;
+        a.packed = d.packed;
+        a.validity = d.validity;
+        a.selection = L.d_selection ? L.d_selection + d.mask_word_off : nullptr;
+        a.hit = L.d_hit + d.mask_word_off;
+        a.valid_out = L.d_valid ? L.d_valid + d.mask_word_off : nullptr;
+        a.len = d.len;
+        a.lo = uint32_t(pr.lo);
+        a.span = uint32_t(pr.span);
+        a.constant = d.W == 0 ? 0 : pr.constant;
+        a.negate = pr.negate ? 1u : 0u;
+        a.all_null = d.W == 0 ? 1u : 0u;
+        const uint32_t c = fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, max(uint32_t(d.W), 1u), a);
+        if (L.d_counts || L.d_total_out) {
+            const uint64_t t = wave_sum_u64(uint64_t(c));
+            if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(t);
+            wave_hits += t;
+        }
+    }
+    if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, total_waves, wave_hits);
 }
 
 // ALP exceptions: re-evaluate the rows whose value lives in the patch list (their packed slot holds a filler).
 // Runs after k_fixed_pred on the same stream; one wave per entry, one lane per patch.
+template <typename I>
+__device__ __forceinline__ bool key_compare(int op, I key, I litkey) {
+    switch (op) {
+        case LC_OP_EQ: return key == litkey;
+        case LC_OP_NE: return key != litkey;
+        case LC_OP_LT: return key < litkey;
+        case LC_OP_LE: return key <= litkey;
+        case LC_OP_GT: return key > litkey;
+        default: return key >= litkey;
+    }
+}
+
 template <typename F>
-__global__ __launch_bounds__(kThreads) void k_alp_patch_fix(const FixedDesc* __restrict__ descs, FixedPred pred, ScanLaunch L) {
+__global__ __launch_bounds__(kThreads) void k_alp_patch_fix(const FixedDesc* __restrict__ descs, FixedPred pred,
+                                                             FixedPred pred2, ScanLaunch L) {
     typedef typename FloatBits<F>::I I;
     const int lane = lane_id();
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
     const I litkey = FloatBits<F>::key(FloatBits<F>::from_bits(pred.lit));
+    const I litkey2 = FloatBits<F>::key(FloatBits<F>::from_bits(pred2.lit));
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < L.n_entries; entry += total_waves) {
         const FixedDesc d = descs[entry];
         if (d.patch_len == 0 || d.W == 0) continue;
@@ -459,15 +777,8 @@ __global__ __launch_bounds__(kThreads) void k_alp_patch_fix(const FixedDesc* __r
             const uint64_t row = d.patch_idx[k];
             if (row >= d.len) continue;
             const I key = FloatBits<F>::key(reinterpret_cast<const F*>(d.patch_val)[k]);
-            bool want;
-            switch (pred.op) {
-                case LC_OP_EQ: want = key == litkey; break;
-                case LC_OP_NE: want = key != litkey; break;
-                case LC_OP_LT: want = key < litkey; break;
-                case LC_OP_LE: want = key <= litkey; break;
-                case LC_OP_GT: want = key > litkey; break;
-                default: want = key >= litkey; break;
-            }
+            bool want = key_compare<I>(pred.op, key, litkey);
+            if (pred2.op >= 0) want = want && key_compare<I>(pred2.op, key, litkey2);
             const uint64_t word = d.mask_word_off + (row >> 6), bit = uint64_t(1) << (row & 63);
             bool active = d.validity ? ((d.validity[row >> 6] >> (row & 63)) & 1) != 0 : true;
             if (L.d_selection) active = active && (L.d_selection[word] & bit) != 0;
@@ -478,11 +789,14 @@ __global__ __launch_bounds__(kThreads) void k_alp_patch_fix(const FixedDesc* __r
                 delta += want ? 1 : -1;
             }
         }
-        if (L.d_counts) {
+        if (L.d_counts || L.d_total_out) {
             int64_t t = delta;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, kWave);
-            if (lane == 0 && t != 0) L.d_counts[entry] = uint32_t(int64_t(L.d_counts[entry]) + t);
+            if (lane == 0 && t != 0) {
+                if (L.d_counts) L.d_counts[entry] = uint32_t(int64_t(L.d_counts[entry]) + t);
+                if (L.d_total_out) atomicAdd(reinterpret_cast<unsigned long long*>(L.d_total_out), (unsigned long long)t);
+            }
         }
     }
 }
@@ -571,13 +885,6 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kCandCap = 1024;  // candidate list capacity per wave (u16 entries)
 
-// Pointers read out of descriptors are generic to the compiler; these casts make the accesses global_load (own
-// vmcnt counter, no coupling with LDS waits) instead of flat_load.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <typename T>
-using GlobalPtr = const __attribute__((address_space(1))) T*;
-template <typename T>
-__device__ __forceinline__ GlobalPtr<T> as_global(const T* p) { return (GlobalPtr<T>)p; }
 template <typename T>
 __device__ __forceinline__ T load_unaligned(const uint8_t* p) {
     T v;
@@ -948,6 +1255,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     // line, shared by the few workgroups with the same blockIdx % work_groups.  The last wave of a group to finish
     // zeroes the group's counters for the next launch.
     uint32_t* work = L.d_work + wg_group * 16u;
+    uint64_t wave_hits = 0;  // fused COUNT(*): hits of the entries this wave evaluated (lane 0)
     for (;;) {
         uint32_t entry = 0;
         if (lane == 0) entry = group_begin + atomicAdd(&work[0], 1u);
@@ -1366,8 +1674,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
-    if (L.d_counts) {
-        uint64_t c = wave_sum_u64(uint64_t(hit_count));
+    if (L.d_counts || L.d_total_out) {
+        // no dictionary value matched and nothing is inverted: every lane counted zero
+        uint64_t c = (all_false && !invert) ? 0 : wave_sum_u64(uint64_t(hit_count));
+        wave_hits += c;
 #ifdef LC_ABLATION
         if (((pred.debug_flags >> 10) & 7u) == 7u)  // timing instrumentation (LC_DEBUG_FLAGS, scripts/occupancy.py)
             c = ((((pred.debug_flags >> 14) & 1) ? rt_kernel : rt_start) & 0xFFFFu) << 16 | (__builtin_amdgcn_s_memrealtime() & 0xFFFFu);
@@ -1380,7 +1690,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             if (tsel == uint32_t(i)) c = tm[i] > tm[i - 1] && tm[i - 1] ? tm[i] - tm[i - 1] : 0;
         if (tsel == 9) c = tm[8] - tm[0];
 #endif
-        if (lane == 0) L.d_counts[entry] = uint32_t(c);
+        if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(c);
     }
     if (L.d_cand_bytes) {
         const uint64_t c = wave_sum_u64(uint64_t(cand_bytes));
@@ -1401,6 +1711,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }  // entries
+    if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, gridDim.x * kWavesPerBlock, wave_hits);
     if (lane == 0) {
         // workgroups of this group: blockIdx = wg_group, wg_group + work_groups, ...
         const uint32_t group_waves = ((gridDim.x - wg_group + L.work_groups - 1u) / L.work_groups) * kWavesPerBlock;
@@ -2047,32 +2358,55 @@ static int device_cus() {
     return n_cus;
 }
 
-hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
-                             hipStream_t stream) {
+hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const FixedPred* pred2,
+                             uint32_t max_width, const ScanLaunch& L, hipStream_t stream) {
     const uint64_t waves = uint64_t(L.n_entries) * L.blocks_per_entry;
     if (waves == 0) return hipSuccess;
-    // persistent-style launch: enough workgroups to fill every CU at the kernel's occupancy, each wave strides over blocks
+    FixedPred p2{};
+    p2.op = -1;  // absent
+    if (pred2) p2 = *pred2;
+    // persistent-style launch: enough workgroups to fill every CU at the kernel's occupancy, each wave strides over entries
     const int n_cus = device_cus();
     const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
-    const uint64_t wgs_resident = uint64_t(n_cus) * (lane_log2 == 6 ? 4 : 8);
+    // widths up to 32 bits on u16 / u32 / u64 lanes: register-resident kernel (no LDS: 8 workgroups per CU)
+    const bool reg = max_width <= 32 && lane_log2 >= 4;
+    const uint64_t wgs_resident = uint64_t(n_cus) * ((lane_log2 == 6 && !reg) ? 4 : 8);
     const dim3 grid(uint32_t(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), block(kThreads);
+    if (reg) {
+        const bool narrow = max_width <= 16;
+        switch (lane_log2) {
+            case 4: hipLaunchKernelGGL((k_fixed_pred_reg<uint16_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L); break;
+            case 5:
+                if (narrow) hipLaunchKernelGGL((k_fixed_pred_reg<uint32_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L);
+                else hipLaunchKernelGGL((k_fixed_pred_reg<uint32_t, 32>), grid, block, 0, stream, d_descs, pred, p2, L);
+                break;
+            default:
+                if (narrow) hipLaunchKernelGGL((k_fixed_pred_reg<uint64_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L);
+                else hipLaunchKernelGGL((k_fixed_pred_reg<uint64_t, 32>), grid, block, 0, stream, d_descs, pred, p2, L);
+                break;
+        }
+        return hipGetLastError();
+    }
     switch (lane_log2) {
-        case 3: hipLaunchKernelGGL(k_fixed_pred<uint8_t>, grid, block, 0, stream, d_descs, pred, L); break;
-        case 4: hipLaunchKernelGGL(k_fixed_pred<uint16_t>, grid, block, 0, stream, d_descs, pred, L); break;
-        case 5: hipLaunchKernelGGL(k_fixed_pred<uint32_t>, grid, block, 0, stream, d_descs, pred, L); break;
-        case 6: hipLaunchKernelGGL(k_fixed_pred<uint64_t>, grid, block, 0, stream, d_descs, pred, L); break;
+        case 3: hipLaunchKernelGGL(k_fixed_pred<uint8_t>, grid, block, 0, stream, d_descs, pred, p2, L); break;
+        case 4: hipLaunchKernelGGL(k_fixed_pred<uint16_t>, grid, block, 0, stream, d_descs, pred, p2, L); break;
+        case 5: hipLaunchKernelGGL(k_fixed_pred<uint32_t>, grid, block, 0, stream, d_descs, pred, p2, L); break;
+        case 6: hipLaunchKernelGGL(k_fixed_pred<uint64_t>, grid, block, 0, stream, d_descs, pred, p2, L); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
-                                hipStream_t stream) {
+hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const FixedPred* pred2,
+                                const ScanLaunch& L, hipStream_t stream) {
     if (L.n_entries == 0) return hipSuccess;
+    FixedPred p2{};
+    p2.op = -1;
+    if (pred2) p2 = *pred2;
     const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8))), block(kThreads);
-    if (lane_log2 == 5) hipLaunchKernelGGL(k_alp_patch_fix<float>, grid, block, 0, stream, d_descs, pred, L);
-    else if (lane_log2 == 6) hipLaunchKernelGGL(k_alp_patch_fix<double>, grid, block, 0, stream, d_descs, pred, L);
+    if (lane_log2 == 5) hipLaunchKernelGGL(k_alp_patch_fix<float>, grid, block, 0, stream, d_descs, pred, p2, L);
+    else if (lane_log2 == 6) hipLaunchKernelGGL(k_alp_patch_fix<double>, grid, block, 0, stream, d_descs, pred, p2, L);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

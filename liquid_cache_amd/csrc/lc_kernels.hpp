@@ -141,12 +141,22 @@ struct ScanLaunch {
     uint32_t work_groups;    // byte views: number of counter groups used by this launch (set by the launcher)
     uint32_t n_wg_ranges;    // byte views: entries of d_wg_ranges (0: entries are split evenly over the groups)
     const uint32_t* d_wg_ranges;  // byte views: {begin, end} entry range per workgroup; a range never mixes symbol tables
+    // Fused COUNT(*) of the launch (optional): every wave adds the hits of its entries to a sharded accumulator and the
+    // wave that arrives last writes the total to *d_total_out — no separate reduction kernel, no memset between launches.
+    unsigned long long* d_total_acc;  // kTotalWords u64 owned by the scan, zero between launches (self-resetting)
+    uint64_t* d_total_out;            // null: no total wanted
 };
+// accumulator layout: word 0 = top level, words 8, 16, ... = shards (one 64-byte line each).  A word packs
+// {arrivals : 24 | hits : 40}, so ONE returning atomic both adds a count and tells the caller whether it was the last.
+constexpr uint32_t kTotalShards = 64;
+constexpr uint32_t kTotalWords = 8 * (kTotalShards + 1);
 
-hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
-                             hipStream_t stream);
-hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
-                                hipStream_t stream);
+// pred2 (optional): a second conjunct on the same column, fused into the same pass (both must be Eq/Lt/LtEq/Gt/GtEq);
+// max_width: largest bit width among the scan's entries (<= 32 selects the register-resident kernel)
+hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const FixedPred* pred2,
+                             uint32_t max_width, const ScanLaunch& L, hipStream_t stream);
+hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const FixedPred* pred2,
+                                const ScanLaunch& L, hipStream_t stream);
 hipError_t launch_str_entry_offsets(const StrDesc* d_descs, const ScanLaunch& L, uint32_t* d_entry_counts, uint64_t* d_tiles,
                                     uint64_t* d_entry_row_offsets, hipStream_t stream);
 hipError_t launch_str_sel_rows(const StrDesc* d_descs, const DevSymtab* d_symtabs, const ScanLaunch& L,

@@ -117,6 +117,7 @@ struct lc_scan {
     bool is_str = false;
     int lane_log2 = 0;
     uint32_t n = 0, bpe = 0;
+    uint32_t max_w = 0;  // widest entry (fixed width): <= 32 selects the register-resident predicate kernel
     std::vector<uint64_t> seg_offsets;  // n+1 word offsets
     uint64_t total_rows = 0;
     void* d_descs = nullptr;
@@ -139,6 +140,7 @@ struct lc_scan {
     // generation is never freed while the context lives, so launches need no lock against concurrent staging
     const DevSymtab* d_symtabs = nullptr;
     size_t n_symtabs = 0;
+    unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
     bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
     std::mutex mu;
 };
@@ -905,6 +907,7 @@ lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_
             s->seg_offsets[i + 1] = off + (uint64_t(e.len) + 63) / 64;
             s->total_rows += e.len;
             max_len = std::max(max_len, e.len);
+            if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
             s->meta.push_back(e);
         }
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
@@ -958,6 +961,7 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_work);
     pool_release(s->ctx, s->d_gather);
     pool_release(s->ctx, s->d_wg_ranges);
+    pool_release(s->ctx, s->d_total_acc);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
     if (s->pinned) {
@@ -976,11 +980,24 @@ const uint64_t* lc_scan_segment_offsets(const lc_scan* s) { return s ? s->seg_of
 
 static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pred, const void* d_selection,
                                 void* d_mask_out, void* d_valid_out, void* d_counts_out, void* d_cand_bytes,
-                                hipStream_t stream) {
+                                hipStream_t stream, const lc_predicate* pred2 = nullptr, void* d_total_out = nullptr) {
     return guarded([&]() -> lc_status {
     if (!ctx || !s || !pred || !d_mask_out) return fail(LC_ERR_INVALID, "null argument");
-    if (s->n == 0) return LC_OK;
+    if (s->n == 0) {
+        if (d_total_out) LC_HIP(hipMemsetAsync(d_total_out, 0, 8, stream));
+        return LC_OK;
+    }
     ScanLaunch L{};
+    if (d_total_out) {
+        std::lock_guard<std::mutex> g(s->mu);
+        if (!s->d_total_acc) {
+            s->d_total_acc = static_cast<unsigned long long*>(pool_alloc(ctx, size_t(kTotalWords) * 8));
+            if (!s->d_total_acc) return fail(LC_ERR_OOM, "hipMalloc (count accumulator)");
+            LC_HIP(hipMemsetAsync(s->d_total_acc, 0, size_t(kTotalWords) * 8, stream));  // once: launches leave it zero
+        }
+        L.d_total_acc = s->d_total_acc;
+        L.d_total_out = static_cast<uint64_t*>(d_total_out);
+    }
     L.n_entries = s->n;
     L.blocks_per_entry = s->bpe;
     L.d_selection = static_cast<const uint64_t*>(d_selection);
@@ -998,16 +1015,28 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
             if (e.sd.symtab_slot != s->meta[0].sd.symtab_slot) L.uniform_slot = -1;
     }
     if (!s->is_str) {
-        FixedPred fp;
-        const lc_status st = make_fixed_pred(s->meta[0], pred, &fp);
+        FixedPred fp, fp2;
+        lc_status st = make_fixed_pred(s->meta[0], pred, &fp);
         if (st != LC_OK) return st;
-        LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, L, stream));
+        if (pred2) {
+            // a second conjunct on the same column rides in the same pass: the two packed-domain ranges are intersected
+            // per entry.  Ne is a range with a hole, not a range: the caller evaluates it as its own pass.
+            if (pred->op == LC_OP_NE || pred2->op == LC_OP_NE)
+                return fail(LC_UNSUPPORTED, "fused conjuncts must be Eq / Lt / LtEq / Gt / GtEq");
+            st = make_fixed_pred(s->meta[0], pred2, &fp2);
+            if (st != LC_OK) return st;
+        }
+        LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, pred2 ? &fp2 : nullptr,
+                                 s->max_w, L, stream));
         bool any_patch = false;
         for (const Entry& e : s->meta) any_patch |= (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) && e.fd.patch_len > 0;
-        if (any_patch)
-            LC_HIP(launch_alp_patch_fix(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, L, stream));
+        if (any_patch) {
+            LC_HIP(launch_alp_patch_fix(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, pred2 ? &fp2 : nullptr, L,
+                                        stream));
+        }
         return LC_OK;
     }
+    if (pred2) return fail(LC_UNSUPPORTED, "fused conjuncts are evaluated on fixed-width columns only");
     StrPredHost sp;
     const lc_status st = make_str_pred(pred, &sp);
     if (st != LC_OK) return st;
@@ -1086,6 +1115,56 @@ lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, con
     return guarded([&]() -> lc_status {
     return scan_eval_impl(ctx, scan, pred, d_selection, d_mask_out, nullptr, d_counts_out, nullptr,
                           static_cast<hipStream_t>(stream));
+    });
+}
+
+lc_status lc_scan_eval_and(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds, const void* d_selection,
+                           void* d_mask_out, void* d_counts_out, void* stream) {
+    if (!preds || n_preds == 0 || n_preds > 2) return fail(LC_ERR_INVALID, "lc_scan_eval_and takes one or two predicates");
+    return scan_eval_impl(ctx, scan, &preds[0], d_selection, d_mask_out, nullptr, d_counts_out, nullptr,
+                          static_cast<hipStream_t>(stream), n_preds == 2 ? &preds[1] : nullptr);
+}
+
+lc_status lc_scan_eval_count(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
+                             const void* d_selection, void* d_mask_out, void* d_counts_out, void* d_total_out,
+                             void* stream) {
+    if (!preds || n_preds == 0 || n_preds > 2) return fail(LC_ERR_INVALID, "lc_scan_eval_count takes one or two predicates");
+    if (!d_total_out) return fail(LC_ERR_INVALID, "d_total_out is null");
+    return scan_eval_impl(ctx, scan, &preds[0], d_selection, d_mask_out, nullptr, d_counts_out, nullptr,
+                          static_cast<hipStream_t>(stream), n_preds == 2 ? &preds[1] : nullptr, d_total_out);
+}
+
+// Kernel time of ONE evaluation with the memory-side cache flushed before every launch: `flush_bytes` of scratch are
+// overwritten between launches (the 256 MiB Infinity Cache of MI355X keeps a 150 MB working set resident across
+// back-to-back identical passes, which a hot-cache QUERY over a 100-column table never enjoys).
+lc_status lc_scan_eval_timed_cold(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
+                                  void* d_mask_out, void* d_counts_out, void* stream, int32_t iters, uint64_t flush_bytes,
+                                  float* out_avg_ms) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !scan || !out_avg_ms || iters <= 0) return fail(LC_ERR_INVALID, "bad iters/out");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    void* d_flush = nullptr;
+    if (flush_bytes) LC_HIP(hipMalloc(&d_flush, flush_bytes));
+    hipEvent_t a, b;
+    lc_status rc = LC_OK;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipEventCreate");
+    double total = 0;
+    for (int i = 0; i < iters && rc == LC_OK; i++) {
+        if (d_flush && hipMemsetAsync(d_flush, i & 0xFF, flush_bytes, st) != hipSuccess) rc = fail(LC_ERR_DEVICE, "flush");
+        if (rc == LC_OK && hipEventRecord(a, st) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipEventRecord");
+        if (rc == LC_OK) rc = scan_eval_impl(ctx, scan, pred, d_selection, d_mask_out, nullptr, d_counts_out, nullptr, st);
+        if (rc == LC_OK && (hipEventRecord(b, st) != hipSuccess || hipEventSynchronize(b) != hipSuccess))
+            rc = fail(LC_ERR_DEVICE, "hipEventRecord/Synchronize");
+        float ms = 0;
+        if (rc == LC_OK && hipEventElapsedTime(&ms, a, b) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipEventElapsedTime");
+        total += ms;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipStreamSynchronize(st);
+    if (d_flush) (void)hipFree(d_flush);
+    if (rc == LC_OK) *out_avg_ms = float(total / iters);
+    return rc;
     });
 }
 

@@ -50,7 +50,7 @@ def test_int64_scan_full_size(product_lib, bench_mod):
     threads = max(1, min(32, os.cpu_count() or 8))
     cache = lc.LiquidCacheBuilder.new().build()
     try:
-        ids = bench_mod.stage_int_column(cache, lc, N, args, 0, n_batches, threads)
+        ids = bench_mod.stage_int_column(cache, lc, N, args, 0, ROWS, threads)
         scan = cache.scan(ids)
         assert scan.rows == ROWS and scan.entries == n_batches
         base = 4_000_000_000_000_000_000 >> (64 - args.int_bits)
@@ -126,5 +126,83 @@ def test_url_like_scan_full_size(product_lib, bench_mod):
         m3, c3 = scan.eval_to_host(like("%google%", "not_like"), selection=m)
         assert int(c3.sum()) == 0
         scan.close()
+    finally:
+        cache.close()
+
+
+def test_q21_pipeline_contents_full_size(product_lib, bench_mod, oracle):
+    """q21.sql pushdown at the full ClickBench size: `SearchPhrase <> ''` -> `URL LIKE '%google%'` on the narrowed
+    selection -> get().with_selection() of both columns.  The gathered URL / SearchPhrase BYTES of every batch that has
+    surviving rows (and of a sample that has none) are compared with the oracle's evaluation of the same Liquid bytes:
+    eval_predicate twice, then filter_byte_view (LiquidByteViewArray::filter + to_arrow, byte_view_array/mod.rs:421-424)."""
+    import torch
+    lo = oracle
+    args = _args()
+    n_batches = (ROWS + BS - 1) // BS
+    threads = max(1, min(32, os.cpu_count() or 8))
+    cache = lc.LiquidCacheBuilder.new().build()
+    try:
+        url_ids = bench_mod.stage_url_column(cache, lc, N, args, 0, n_batches, threads)
+        sp_ids = bench_mod.stage_phrase_column(cache, lc, N, args, 0, n_batches, threads)
+        url_scan, sp_scan = cache.scan(url_ids), cache.scan(sp_ids)
+        hint = lc.CacheExpression.SUBSTRING_SEARCH
+        like = lc.LiquidExpr.try_new("like", b"%google%", pa.string(), hint)
+        ne = lc.LiquidExpr.try_new("!=", b"", pa.string(), None)
+        words = int(url_scan.mask_words)
+        m1 = torch.zeros(words, dtype=torch.int64, device="cuda")
+        m2 = torch.zeros(words, dtype=torch.int64, device="cuda")
+        c1 = torch.zeros(n_batches, dtype=torch.int32, device="cuda")
+        c2 = torch.zeros(n_batches, dtype=torch.int32, device="cuda")
+        cap = 1 << 16
+        outs = []
+        sp_scan.eval(ne, m1.data_ptr(), 0, c1.data_ptr(), 0)
+        url_scan.eval(like, m2.data_ptr(), m1.data_ptr(), c2.data_ptr(), 0)
+        for scan in (url_scan, sp_scan):
+            ro = torch.zeros(n_batches + 1, dtype=torch.int64, device="cuda")
+            refs = torch.zeros(cap, dtype=torch.int64, device="cuda")
+            vo = torch.zeros(cap + 1, dtype=torch.int64, device="cuda")
+            data = torch.zeros(cap * 256, dtype=torch.uint8, device="cuda")
+            scan.gather_bytes_async(ro.data_ptr(), refs.data_ptr(), vo.data_ptr(), cap, data.data_ptr(), data.numel(),
+                                    m2.data_ptr(), 0, 0)
+            torch.cuda.synchronize()
+            outs.append((ro.cpu().numpy(), vo.cpu().numpy(), data.cpu().numpy().tobytes()))
+        counts = c2.cpu().numpy()
+        k = int(counts.sum())
+        assert 0 < k <= cap and int(outs[0][0][-1]) == k == int(outs[1][0][-1])
+        L = N.load()
+        rng = np.random.default_rng(4)
+        with_rows = [int(b) for b in np.nonzero(counts)[0]]
+        sample = with_rows[:150] + [int(x) for x in rng.integers(0, n_batches, size=25)]
+        offs = np.zeros(BS + 1, np.int32)
+        data = np.zeros(BS * 512, np.uint8)
+        symtabs = {}
+        checked_rows = 0
+        for b in sample:
+            rows = min(BS, ROWS - b * BS)
+            liquids = []
+            for col, synth, extra, eid, h in ((13, L.lc_synth_url_batch, (min(args.uniques, rows), args.needle_ppm), url_ids[b], hint),
+                                              (39, L.lc_synth_phrase_batch, (600, 870), sp_ids[b], None)):
+                n = synth(args.seed, b, rows, *extra, offs.ctypes.data, data.ctypes.data, data.size)
+                arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1].copy()), pa.py_buffer(data[:max(n, 1)].copy()))
+                path = lc.ParquetArrayID.column_access_path(eid)
+                liquids.append((cache.transcode(arr, h, path), path))
+                if path not in symtabs:
+                    symtabs[path] = lo.symtab_load(cache.symbol_table(path))
+            (url_l, url_p), (sp_l, sp_p) = liquids
+            r1 = lo.eval_predicate(sp_l, lo.NE, b"", None, symtab=symtabs[sp_p])
+            sel1 = r1.values if r1.validity is None else (r1.values & r1.validity)
+            r2 = lo.eval_predicate(url_l, lo.LIKE, b"%google%", None, symtab=symtabs[url_p])
+            sel2 = (r2.values if r2.validity is None else (r2.values & r2.validity)) & sel1
+            assert int(counts[b]) == int(sel2.sum()), b
+            want_urls = lo.filter_byte_view(url_l, symtabs[url_p], sel2)
+            want_sps = lo.filter_byte_view(sp_l, symtabs[sp_p], sel2)
+            for (ro, vo, raw), want in zip(outs, (want_urls, want_sps)):
+                r0, r1_ = int(ro[b]), int(ro[b + 1])
+                got = [raw[int(vo[i]): int(vo[i + 1])] for i in range(r0, r1_)]
+                assert got == want, b
+            checked_rows += len(want_urls)
+        assert checked_rows > 0
+        url_scan.close()
+        sp_scan.close()
     finally:
         cache.close()

@@ -1,0 +1,540 @@
+"""GPU parity, round 2: the register-resident predicate kernel over every width, fused conjuncts, the TPC-H Q6 chain and
+the q21 projection against the oracle, and the hardened boundary (capacity bounds, stage-time validation, eviction under
+a live scan).  Everything goes through the C ABI (ctypes) and is compared bit for bit with the CPU oracle.
+"""
+import ctypes as C
+import datetime
+import decimal
+import os
+
+import numpy as np
+import pyarrow as pa
+import pyarrow.parquet as pq
+import pytest
+
+import liquid_cache_amd as lc
+from liquid_cache_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+OPS = ["eq", "ne", "lt", "le", "gt", "ge"]
+
+
+def _sel_words(scan, keep_by_entry):
+    words = np.zeros(int(scan.mask_words), np.uint64)
+    for k, seg in enumerate(keep_by_entry):
+        packed = np.packbits(seg, bitorder="little")
+        w0 = int(scan.segment_offsets[k])
+        words[w0: w0 + (len(seg) + 63) // 64].view(np.uint8)[: len(packed)] = packed
+    return words
+
+
+def _entry_bits(mask, scan, k, rows):
+    w0 = int(scan.segment_offsets[k])
+    return np.unpackbits(mask[w0: w0 + (rows + 63) // 64].view(np.uint8), bitorder="little")[:rows].astype(bool)
+
+
+def _oracle_hits(lo, liquid, op, literal, sel):
+    """pred AND valid AND selected over all rows of one entry (what a device scan writes)."""
+    r = lo.eval_predicate(liquid, lo.OP_NAMES[op], literal, None)
+    hit = r.values if r.validity is None else (r.values & r.validity)
+    return hit if sel is None else (hit & sel)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# k_fixed_pred_reg: every width 1..32 on u16 / u32 / u64 lanes, multi-block entries, tails, nulls, selections
+# ------------------------------------------------------------------------------------------------------------------
+LANE_CASES = [("int16", np.int16, pa.int16(), 16), ("uint16", np.uint16, pa.uint16(), 16),
+              ("int32", np.int32, pa.int32(), 32), ("date32", np.int32, pa.date32(), 32),
+              ("uint32", np.uint32, pa.uint32(), 32), ("int64", np.int64, pa.int64(), 32),
+              ("timestamp[us]", np.int64, pa.timestamp("us"), 32)]
+
+
+@pytest.mark.parametrize("name,np_dtype,dtype,max_w", LANE_CASES)
+def test_register_kernel_every_width(gpu_cache, oracle, name, np_dtype, dtype, max_w):
+    lo = oracle
+    rng = np.random.default_rng(abs(hash(name)) % 10007)
+    lens = [8192, 3000, 1, 1024 + 65, 2048]
+    info = np.iinfo(np_dtype)
+    for W in range(1, max_w + 1):
+        ids, liquids, vals_by_entry = [], [], []
+        base = int(rng.integers(int(info.min) // 2, int(info.max) // 2 - (1 << W) + 1)) if max_w - W > 1 else int(info.min)
+        for k, n in enumerate(lens):
+            span = min((1 << W) - 1, int(info.max) - base)
+            v = (rng.integers(0, span, size=n, endpoint=True, dtype=np.uint64).astype(object) + base)
+            v = np.array(v.tolist(), dtype=np_dtype)
+            v[rng.integers(n)] = base            # the entry really spans W bits
+            v[rng.integers(n)] = base + span
+            valid = (rng.random(n) < 0.85) if (k % 2) else None
+            liquid = lo.encode_primitive(lo.PHYS[name], v, valid)
+            eid = lc.ParquetArrayID.new(1, W, 3, k)
+            ids.append(eid)
+            liquids.append(liquid)
+            vals_by_entry.append(v)
+        gpu_cache.stage(ids, liquids, data_types=[dtype] * len(ids))
+        scan = gpu_cache.scan(ids)
+        for op in OPS:
+            src = vals_by_entry[int(rng.integers(len(lens)))]
+            lit = int(src[rng.integers(len(src))]) + int(rng.integers(-1, 2))
+            lit = max(int(info.min), min(int(info.max), lit))
+            mode = int(rng.integers(3))
+            keep = None if mode == 0 else [rng.random(n) < (0.6 if mode == 1 else 0.003) for n in lens]
+            words = None if keep is None else _sel_words(scan, keep)
+            expr = lc.LiquidExpr.try_new(op, lit, dtype)
+            m, c = scan.eval_to_host(expr, selection=words)
+            for k, n in enumerate(lens):
+                want = _oracle_hits(lo, liquids[k], op, lit, None if keep is None else keep[k])
+                assert np.array_equal(_entry_bits(m, scan, k, n), want), (name, W, op, lit, k)
+                assert int(c[k]) == int(want.sum()), (name, W, op, k)
+        scan.close()
+        gpu_cache.evict(ids)
+
+
+def test_register_kernel_decimals_and_mixed_widths(gpu_cache, oracle):
+    """u64 lanes at small widths (TPC-H decimals), and scans whose entries mix widths below / above 32 bits (the
+    launcher then takes the LDS kernel for the whole scan)."""
+    lo = oracle
+    rng = np.random.default_rng(77)
+    DEC = pa.decimal128(15, 2)
+    for W in (1, 4, 5, 13, 16, 17, 24, 31):
+        ids, liquids, ns = [], [], [8192, 5000, 1024]
+        for k, n in enumerate(ns):
+            unscaled = [int(x) for x in rng.integers(0, 1 << W, size=n)]
+            unscaled[0], unscaled[-1] = 0, (1 << W) - 1
+            if k == 1:
+                unscaled[7] = None
+            liquids.append(lo.encode_decimal(unscaled, precision=15, scale=2))
+            ids.append(lc.ParquetArrayID.new(2, W, 4, k))
+        gpu_cache.stage(ids, liquids)
+        scan = gpu_cache.scan(ids)
+        for op in OPS:
+            lit_unscaled = int(rng.integers(0, 1 << W))
+            expr = lc.LiquidExpr.try_new(op, decimal.Decimal(lit_unscaled) / 100, DEC)
+            m, c = scan.eval_to_host(expr)
+            for k, n in enumerate(ns):
+                want = _oracle_hits(lo, liquids[k], op, lit_unscaled, None)
+                assert _entry_bits(m, scan, k, n).tolist() == want.tolist(), (W, op, k)
+        scan.close()
+    # mixed widths in one Int64 scan: 12, 40, 31, 62 bits
+    ids, liquids, vals = [], [], []
+    for k, W in enumerate((12, 40, 31, 62, 3)):
+        v = rng.integers(0, 1 << W, size=4096 + k, dtype=np.int64) - (1 << (W - 1))
+        liquids.append(lo.encode_primitive(lo.PHYS["int64"], v))
+        ids.append(lc.ParquetArrayID.new(2, 99, 5, k))
+        vals.append(v)
+    gpu_cache.stage(ids, liquids)
+    scan = gpu_cache.scan(ids)
+    for op in OPS:
+        for lit in (0, -3, 1 << 30, -(1 << 39)):
+            m, c = scan.eval_to_host(lc.LiquidExpr.try_new(op, lit, pa.int64()))
+            for k, v in enumerate(vals):
+                want = _oracle_hits(lo, liquids[k], op, lit, None)
+                assert _entry_bits(m, scan, k, len(v)).tolist() == want.tolist(), (op, lit, k)
+    scan.close()
+
+
+def test_fused_conjunct_pair_equals_chaining(gpu_cache, oracle):
+    """lc_scan_eval_and: `a OP1 x AND a OP2 y` in one pass == the two chained passes == the oracle's AND."""
+    lo = oracle
+    rng = np.random.default_rng(91)
+    cases = [("date32", np.int32, pa.date32(), 8000, 12),
+             ("int16", np.int16, pa.int16(), -300, 11),
+             ("int64", np.int64, pa.int64(), -(1 << 40), 45),
+             ("int64", np.int64, pa.int64(), 100, 9)]
+    fusable = ["eq", "lt", "le", "gt", "ge"]
+    for ci, (name, np_dtype, dtype, base, W) in enumerate(cases):
+        ids, liquids, ns = [], [], [8192, 8192, 777]
+        for k, n in enumerate(ns):
+            v = (rng.integers(0, 1 << W, size=n, dtype=np.int64) + base).astype(np_dtype)
+            valid = rng.random(n) < 0.9 if k == 1 else None
+            liquids.append(lo.encode_primitive(lo.PHYS[name], v, valid))
+            ids.append(lc.ParquetArrayID.new(3, ci, 6, k))
+        gpu_cache.stage(ids, liquids, data_types=[dtype] * 3)
+        scan = gpu_cache.scan(ids)
+        for _ in range(12):
+            op1, op2 = rng.choice(fusable), rng.choice(fusable)
+            l1 = base + int(rng.integers(-5, (1 << W) + 5))
+            l2 = base + int(rng.integers(-5, (1 << W) + 5))
+            keep = [rng.random(n) < 0.5 for n in ns] if rng.integers(2) else None
+            words = None if keep is None else _sel_words(scan, keep)
+            e1, e2 = lc.LiquidExpr.try_new(op1, l1, dtype), lc.LiquidExpr.try_new(op2, l2, dtype)
+            lib, ctx = scan._lib, gpu_cache.handle
+            d_mask, d_counts, d_sel = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            N.check(lib.lc_device_alloc(ctx, int(scan.mask_words) * 8, C.byref(d_mask)), ctx)
+            N.check(lib.lc_device_alloc(ctx, scan.entries * 4, C.byref(d_counts)), ctx)
+            if words is not None:
+                N.check(lib.lc_device_alloc(ctx, words.size * 8, C.byref(d_sel)), ctx)
+                N.check(lib.lc_host_to_device(ctx, d_sel, words.ctypes.data_as(C.c_void_p), words.size * 8, None), ctx)
+            assert scan.eval_and([e1, e2], d_mask.value, d_sel.value or 0, d_counts.value)
+            m = np.zeros(int(scan.mask_words), np.uint64)
+            c = np.zeros(scan.entries, np.uint32)
+            N.check(lib.lc_device_to_host(ctx, m.ctypes.data_as(C.c_void_p), d_mask, m.size * 8, None), ctx)
+            N.check(lib.lc_device_to_host(ctx, c.ctypes.data_as(C.c_void_p), d_counts, c.size * 4, None), ctx)
+            for p in (d_mask, d_counts, d_sel):
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+            m1, _ = scan.eval_to_host(e1, selection=words)
+            m2, c2 = scan.eval_to_host(e2, selection=m1)
+            assert (m == m2).all() and (c == c2).all(), (name, op1, l1, op2, l2)
+            for k, n in enumerate(ns):
+                want = _oracle_hits(lo, liquids[k], op1, l1, None if keep is None else keep[k]) & \
+                       _oracle_hits(lo, liquids[k], op2, l2, None)
+                assert _entry_bits(m, scan, k, n).tolist() == want.tolist(), (name, op1, l1, op2, l2, k)
+        # a hole is not a range: Ne is refused, the caller chains
+        e_ne = lc.LiquidExpr.try_new("ne", base + 3, dtype)
+        d_mask = C.c_void_p()
+        N.check(scan._lib.lc_device_alloc(gpu_cache.handle, int(scan.mask_words) * 8, C.byref(d_mask)), gpu_cache.handle)
+        assert scan.eval_and([e_ne, e1], d_mask.value) is False
+        scan._lib.lc_device_free(gpu_cache.handle, d_mask)
+        scan.close()
+
+
+def test_fused_conjunct_pair_floats_with_patches(gpu_cache, oracle):
+    lo = oracle
+    rng = np.random.default_rng(17)
+    vals = np.round(rng.normal(100.0, 40.0, size=8192), 2)
+    vals[rng.choice(8192, 60, replace=False)] = rng.normal(0, 1e-7, size=60)      # ALP exceptions
+    vals[5], vals[6], vals[7] = np.nan, np.inf, -np.inf
+    gpu_cache.insert(1, pa.array(vals, type=pa.float64()))
+    liquid = gpu_cache.transcode(pa.array(vals, type=pa.float64()))
+    scan = gpu_cache.scan([1])
+    for a, b in ((80.0, 120.0), (99.99, 100.01), (-1e-6, 1e-6), (150.0, 50.0)):
+        e1, e2 = lc.LiquidExpr.try_new(">=", a, pa.float64()), lc.LiquidExpr.try_new("<", b, pa.float64())
+        d_mask, d_counts = C.c_void_p(), C.c_void_p()
+        N.check(scan._lib.lc_device_alloc(gpu_cache.handle, int(scan.mask_words) * 8, C.byref(d_mask)), gpu_cache.handle)
+        N.check(scan._lib.lc_device_alloc(gpu_cache.handle, 4, C.byref(d_counts)), gpu_cache.handle)
+        assert scan.eval_and([e1, e2], d_mask.value, 0, d_counts.value)
+        m = np.zeros(int(scan.mask_words), np.uint64)
+        c = np.zeros(1, np.uint32)
+        N.check(scan._lib.lc_device_to_host(gpu_cache.handle, m.ctypes.data_as(C.c_void_p), d_mask, m.size * 8, None), gpu_cache.handle)
+        N.check(scan._lib.lc_device_to_host(gpu_cache.handle, c.ctypes.data_as(C.c_void_p), d_counts, 4, None), gpu_cache.handle)
+        want = _oracle_hits(lo, liquid, "ge", a, None) & _oracle_hits(lo, liquid, "lt", b, None)
+        assert _entry_bits(m, scan, 0, 8192).tolist() == want.tolist(), (a, b)
+        assert int(c[0]) == int(want.sum())
+        for p in (d_mask, d_counts):
+            scan._lib.lc_device_free(gpu_cache.handle, p)
+    scan.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# config 4: TPC-H Q6-shaped chain (l_shipdate range + l_discount range + l_quantity), device vs oracle
+# ------------------------------------------------------------------------------------------------------------------
+def _dec_array(unscaled: np.ndarray) -> pa.Array:
+    buf = np.zeros((len(unscaled), 2), np.int64)
+    buf[:, 0] = unscaled
+    return pa.Array.from_buffers(pa.decimal128(15, 2), len(unscaled), [None, pa.py_buffer(buf)])
+
+
+def _q6_chain(cache, lo, ship, disc, qty, bs, fused):
+    """Runs the five Q6 conjuncts as the reader would (each mask the selection of the next; with `fused` the two range
+    pairs ride in one pass each) and checks every intermediate mask against the oracle's evaluation of the same Liquid
+    bytes.  Returns the final per-batch counts."""
+    DEC = pa.decimal128(15, 2)
+    epoch = datetime.date(1970, 1, 1)
+    n_batches = (len(ship) + bs - 1) // bs
+    cols = {"ship": (10, pa.array(ship, type=pa.date32()), pa.date32()), "disc": (6, _dec_array(disc), DEC),
+            "qty": (4, _dec_array(qty), DEC)}
+    ids, liquids = {}, {}
+    for name, (col, arr, _) in cols.items():
+        ids[name] = [lc.ParquetArrayID.new(7, b // 54, col, b % 54) for b in range(n_batches)]
+        liquids[name] = []
+        for b in range(n_batches):
+            chunk = arr.slice(b * bs, min(bs, len(arr) - b * bs))
+            cache.insert(ids[name][b], chunk)
+            liquids[name].append(cache.transcode(chunk))
+    scans = {name: cache.scan(ids[name]) for name in cols}
+    d1, d2 = datetime.date(1994, 1, 1), datetime.date(1995, 1, 1)
+    E = lc.LiquidExpr.try_new
+    conj = [("ship", "ge", d1, (d1 - epoch).days), ("ship", "lt", d2, (d2 - epoch).days),
+            ("disc", "ge", decimal.Decimal("0.05"), 5), ("disc", "le", decimal.Decimal("0.07"), 7),
+            ("qty", "lt", decimal.Decimal("24.00"), 2400)]
+    sel = None
+    want_sel = [None] * n_batches
+    counts = None
+    i = 0
+    while i < len(conj):
+        name, op, lit, olit = conj[i]
+        scan = scans[name]
+        pair = fused and i + 1 < len(conj) and conj[i + 1][0] == name
+        steps = conj[i:i + 2] if pair else conj[i:i + 1]
+        exprs = [E(o, l, cols[name][2]) for (_, o, l, _) in steps]
+        assert all(e is not None for e in exprs)
+        if pair:
+            lib, ctx = scan._lib, cache.handle
+            d_mask, d_counts, d_sel = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            N.check(lib.lc_device_alloc(ctx, int(scan.mask_words) * 8, C.byref(d_mask)), ctx)
+            N.check(lib.lc_device_alloc(ctx, scan.entries * 4, C.byref(d_counts)), ctx)
+            if sel is not None:
+                N.check(lib.lc_device_alloc(ctx, sel.size * 8, C.byref(d_sel)), ctx)
+                N.check(lib.lc_host_to_device(ctx, d_sel, sel.ctypes.data_as(C.c_void_p), sel.size * 8, None), ctx)
+            assert scan.eval_and(exprs, d_mask.value, d_sel.value or 0, d_counts.value)
+            m = np.zeros(int(scan.mask_words), np.uint64)
+            counts = np.zeros(scan.entries, np.uint32)
+            N.check(lib.lc_device_to_host(ctx, m.ctypes.data_as(C.c_void_p), d_mask, m.size * 8, None), ctx)
+            N.check(lib.lc_device_to_host(ctx, counts.ctypes.data_as(C.c_void_p), d_counts, counts.size * 4, None), ctx)
+            for p in (d_mask, d_counts, d_sel):
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+        else:
+            m, counts = scan.eval_to_host(exprs[0], selection=sel)
+        for b in range(n_batches):
+            rows = min(bs, len(ship) - b * bs)
+            w = want_sel[b]
+            for (_, o, _, ol) in steps:
+                h = _oracle_hits(lo, liquids[name][b], o, ol, w)
+                w = h
+            want_sel[b] = w
+            assert np.array_equal(_entry_bits(m, scan, b, rows), w), (i, name, b)
+            assert int(counts[b]) == int(w.sum())
+        sel = m
+        i += len(steps)
+    for s in scans.values():
+        s.close()
+    return counts
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_tpch_q6_chain_vs_oracle(gpu_cache, oracle, fused):
+    """1,048,576 + 37 synthetic lineitem rows (SURVEY §8d config 4 distributions): 5 chained conjuncts, every mask checked
+    against the oracle, final COUNT(*) against numpy."""
+    rng = np.random.default_rng(2024)
+    rows, bs = (1 << 20) + 37, 8192
+    epoch = datetime.date(1970, 1, 1)
+    d_lo, d_hi = (datetime.date(1992, 1, 2) - epoch).days, (datetime.date(1998, 12, 1) - epoch).days
+    ship = rng.integers(d_lo, d_hi + 1, size=rows, dtype=np.int32)
+    disc = rng.integers(0, 11, size=rows, dtype=np.int64)
+    qty = rng.integers(1, 51, size=rows, dtype=np.int64) * 100
+    counts = _q6_chain(gpu_cache, oracle, ship, disc, qty, bs, fused)
+    d1, d2 = (datetime.date(1994, 1, 1) - epoch).days, (datetime.date(1995, 1, 1) - epoch).days
+    want = (ship >= d1) & (ship < d2) & (disc >= 5) & (disc <= 7) & (qty < 2400)
+    assert int(counts.sum()) == int(want.sum())
+
+
+def test_tpch_q6_chain_on_reference_lineitem(gpu_cache, oracle):
+    """The reference's own benchmark/tpch/data/sf0.001/lineitem.parquet (6,005 rows; fixture made by make_golden.py)."""
+    t = pq.read_table(os.path.join(GOLDEN, "lineitem_sf0001.parquet"))
+    ship = t["l_shipdate"].combine_chunks().cast(pa.int32()).to_numpy()
+    disc = np.array([int(x.as_py() * 100) for x in t["l_discount"].combine_chunks()], dtype=np.int64)
+    qty = np.array([int(x.as_py() * 100) for x in t["l_quantity"].combine_chunks()], dtype=np.int64)
+    epoch = datetime.date(1970, 1, 1)
+    for fused in (False, True):
+        counts = _q6_chain(gpu_cache, oracle, ship, disc, qty, 2048, fused)
+        d1, d2 = (datetime.date(1994, 1, 1) - epoch).days, (datetime.date(1995, 1, 1) - epoch).days
+        want = (ship >= d1) & (ship < d2) & (disc >= 5) & (disc <= 7) & (qty < 2400)
+        assert int(counts.sum()) == int(want.sum())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# hardened boundary
+# ------------------------------------------------------------------------------------------------------------------
+def test_gather_fixed_respects_capacity(gpu_cache, oracle):
+    rng = np.random.default_rng(3)
+    vals = rng.integers(-1000, 1000, size=3 * 8192, dtype=np.int64)
+    ids = [lc.ParquetArrayID.new(5, 0, 1, k) for k in range(3)]
+    for k, e in enumerate(ids):
+        gpu_cache.insert(e, pa.array(vals[k * 8192:(k + 1) * 8192]))
+    scan = gpu_cache.scan(ids)
+    keep = rng.random(len(vals)) < 0.3
+    words = _sel_words(scan, [keep[k * 8192:(k + 1) * 8192] for k in range(3)])
+    k_total = int(keep.sum())
+    cap_rows = 1000
+    lib, ctx = scan._lib, gpu_cache.handle
+    d_vals, d_offs, d_sel = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    guard_rows = 4096
+    N.check(lib.lc_device_alloc(ctx, (cap_rows + guard_rows) * 8, C.byref(d_vals)), ctx)
+    N.check(lib.lc_device_memset(ctx, d_vals, 0xAB, (cap_rows + guard_rows) * 8, None), ctx)
+    N.check(lib.lc_device_alloc(ctx, 4 * 8, C.byref(d_offs)), ctx)
+    N.check(lib.lc_device_alloc(ctx, words.size * 8, C.byref(d_sel)), ctx)
+    N.check(lib.lc_host_to_device(ctx, d_sel, words.ctypes.data_as(C.c_void_p), words.size * 8, None), ctx)
+    scan.gather_fixed(d_vals.value, cap_rows * 8, d_offs.value, d_sel.value)
+    out = np.zeros(cap_rows + guard_rows, np.int64)
+    offs = np.zeros(4, np.uint64)
+    N.check(lib.lc_device_to_host(ctx, out.ctypes.data_as(C.c_void_p), d_vals, out.size * 8, None), ctx)
+    N.check(lib.lc_device_to_host(ctx, offs.ctypes.data_as(C.c_void_p), d_offs, 32, None), ctx)
+    assert int(offs[-1]) == k_total > cap_rows                      # the caller learns the required size
+    assert out[:cap_rows].tolist() == vals[keep][:cap_rows].tolist()  # what fits is correct
+    assert (out[cap_rows:].view(np.uint8) == 0xAB).all()            # nothing past the capacity was written
+    for p in (d_vals, d_offs, d_sel):
+        lib.lc_device_free(ctx, p)
+    scan.close()
+
+
+def test_stage_rejects_out_of_contract_entries(gpu_cache, oracle):
+    lo = oracle
+    # bit width beyond the lane type: Int8 array claiming W = 64
+    liquid = bytearray(lo.encode_primitive(lo.PHYS["int8"], np.arange(100, dtype=np.int8)))
+    assert liquid[24 + 4] <= 8
+    liquid[24 + 4] = 64
+    with pytest.raises(lc.LiquidCacheError) as e:
+        gpu_cache.stage([1], [bytes(liquid)])
+    assert e.value.status == N.LC_ERR_CORRUPT
+    # byte-view entry of more than 65536 rows: not handled on the device -> caller's CPU path
+    strs = ["v%d" % (i % 100) for i in range(65537)]
+    host = lc.LiquidCacheBuilder.new().with_host_only().build()
+    big = host.transcode(pa.array(strs), None, 77)
+    gpu_cache.set_symbol_table(77, host.symbol_table(77))
+    with pytest.raises(lc.LiquidCacheError) as e:
+        gpu_cache.stage([2], [big], path_ids=[77])
+    assert e.value.status == N.LC_UNSUPPORTED
+    host.close()
+    assert gpu_cache.entry_info(1) is None and gpu_cache.entry_info(2) is None
+
+
+def test_evict_and_restage_under_a_live_scan(gpu_cache, oracle):
+    """The reference's scans hold Arc clones: eviction cannot pull data from under them.  Same here: a scan pins its
+    entries, evicting / re-staging them leaves the scan's view intact, and the cache answers for the new state."""
+    a = np.arange(8192, dtype=np.int64)
+    ids = [lc.ParquetArrayID.new(8, 0, 1, k) for k in range(4)]
+    for e in ids:
+        gpu_cache.insert(e, pa.array(a))
+    scan = gpu_cache.scan(ids)
+    expr = lc.LiquidExpr.try_new(">", 100, pa.int64())
+    _, c0 = scan.eval_to_host(expr)
+    gpu_cache.evict(ids[:2])
+    gpu_cache.insert(ids[2], pa.array(a * 0))       # re-stage under the scan
+    assert gpu_cache.entry_info(ids[0]) is None
+    for _ in range(3):                              # churn the arena while the scan lives
+        junk = [lc.ParquetArrayID.new(8, 1, 1, k) for k in range(64)]
+        for e in junk:
+            gpu_cache.insert(e, pa.array(a[::-1].copy()))
+        gpu_cache.evict(junk)
+    _, c1 = scan.eval_to_host(expr)
+    assert c1.tolist() == c0.tolist() == [8192 - 101] * 4
+    scan.close()
+    fresh = gpu_cache.scan(ids[2:])
+    _, c2 = fresh.eval_to_host(expr)
+    assert c2.tolist() == [0, 8192 - 101]
+    fresh.close()
+    info = gpu_cache.device_info()
+    assert info.staged_entries == 2
+
+
+def test_small_hbm_budget_is_usable_and_enforced(product_lib):
+    """max_hbm_bytes below one 256 MiB slab used to fail the first lc_stage."""
+    cache = lc.LiquidCacheBuilder.new().with_max_memory_bytes(8 << 20).build()
+    try:
+        a = np.arange(8192, dtype=np.int64) * 1_000_003
+        for k in range(16):
+            cache.insert(lc.ParquetArrayID.new(9, 0, 1, k), pa.array(a))
+        with pytest.raises(lc.LiquidCacheError) as e:
+            for k in range(16, 400):
+                cache.insert(lc.ParquetArrayID.new(9, 0, 1, k), pa.array(a))
+        assert e.value.status == N.LC_ERR_OOM
+    finally:
+        cache.close()
+
+
+def test_like_with_backslash_is_not_a_plain_substring(gpu_cache, oracle):
+    """Arrow LIKE treats `\\` as an escape: `%a\\_b%` finds the literal "a_b".  Entries without fingerprints
+    run the general matcher; entries with fingerprints answer LC_UNSUPPORTED (caller's CPU path), never a wrong mask."""
+    lo = oracle
+    strs = ["xa_by", "xaxby", "a\\_b", "plain", "a_b", None, "a\\b"] * 50
+    arr = pa.array(strs, type=pa.string())
+    gpu_cache.insert(1, arr)                                             # no fingerprints
+    gpu_cache.insert(2, arr, lc.CacheExpression.SUBSTRING_SEARCH)
+    for pat in ("%a\\_b%", "%a\\\\b%", "%a\\b%"):
+        e = lc.LiquidExpr.try_new("like", pat, pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
+        got = gpu_cache.eval_predicate(1, e).read().to_pylist()
+        want = [None if s is None else bool(lo.like_match(s.encode(), pat.encode())) for s in strs]
+        assert got == want, pat
+        with pytest.raises(lc.LiquidCacheError) as ex:
+            gpu_cache.eval_predicate(2, e).read()
+        assert ex.value.status == N.LC_UNSUPPORTED
+
+
+def test_traffic_model_is_consistent(gpu_cache, oracle):
+    """kernel bytes <= algorithmic bytes + descriptors for integer scans; entries decided by their FoR range drop their
+    packed bytes; for LIKE both figures come from the instrumented pass and the kernel moves fewer bytes than the
+    reference algorithm would."""
+    rng = np.random.default_rng(8)
+    ids = []
+    for k in range(6):
+        e = lc.ParquetArrayID.new(10, 0, 1, k)
+        gpu_cache.insert(e, pa.array(rng.integers(k * 10_000, k * 10_000 + 4096, size=8192, dtype=np.int64)))
+        ids.append(e)
+    scan = gpu_cache.scan(ids)
+    alg, own = scan.traffic_model(lc.LiquidExpr.try_new(">", 22_000, pa.int64()))
+    assert alg == 6 * (8192 * 12 // 8 + 1024)
+    assert own == 6 * (64 + 1024) + 1 * (8192 * 12 // 8)          # only batch 2 straddles the literal
+    scan.close()
+    words = ["google", "yandex", "mail", "maps", "search", "news"]
+    strs = ["http://%s.%s/%s?q=%d" % (words[rng.integers(6)], words[rng.integers(6)], words[rng.integers(6)],
+                                      rng.integers(3000)) for _ in range(8192)]
+    gpu_cache.insert(99, pa.array(strs), lc.CacheExpression.SUBSTRING_SEARCH)
+    s2 = gpu_cache.scan([99])
+    like = lc.LiquidExpr.try_new("like", "%yandex%", pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
+    alg, own = s2.traffic_model(like)
+    assert 0 < own and 2 * 8192 < alg
+    s2.close()
+
+
+def _eval_count(scan, cache, exprs, words=None, repeat=1):
+    lib, ctx = scan._lib, cache.handle
+    d_mask, d_counts, d_total, d_sel = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+    N.check(lib.lc_device_alloc(ctx, max(int(scan.mask_words), 1) * 8, C.byref(d_mask)), ctx)
+    N.check(lib.lc_device_alloc(ctx, max(scan.entries, 1) * 4, C.byref(d_counts)), ctx)
+    N.check(lib.lc_device_alloc(ctx, 8, C.byref(d_total)), ctx)
+    N.check(lib.lc_device_memset(ctx, d_total, 0xEE, 8, None), ctx)
+    if words is not None:
+        N.check(lib.lc_device_alloc(ctx, words.size * 8, C.byref(d_sel)), ctx)
+        N.check(lib.lc_host_to_device(ctx, d_sel, words.ctypes.data_as(C.c_void_p), words.size * 8, None), ctx)
+    totals = []
+    for _ in range(repeat):
+        scan.eval_count(exprs, d_mask.value, d_total.value, d_sel.value or 0, d_counts.value)
+        t = np.zeros(1, np.uint64)
+        N.check(lib.lc_device_to_host(ctx, t.ctypes.data_as(C.c_void_p), d_total, 8, None), ctx)
+        totals.append(int(t[0]))
+    c = np.zeros(max(scan.entries, 1), np.uint32)
+    N.check(lib.lc_device_to_host(ctx, c.ctypes.data_as(C.c_void_p), d_counts, c.size * 4, None), ctx)
+    for p in (d_mask, d_counts, d_total, d_sel):
+        if p.value:
+            lib.lc_device_free(ctx, p)
+    return totals, c[: scan.entries]
+
+
+def test_fused_count_total(gpu_cache, oracle):
+    """lc_scan_eval_count: the COUNT(*) written by the predicate kernel == sum of the per-entry counts == numpy, for every
+    kernel family, repeated launches (the accumulator resets itself), few and many entries."""
+    rng = np.random.default_rng(12)
+    for n_entries, np_dt, pa_dt, hi in ((1, np.int64, pa.int64(), 1 << 50), (3, np.int32, pa.int32(), 4000),
+                                        (700, np.int16, pa.int16(), 3000), (2500, np.int64, pa.int64(), 100)):
+        rows = 512 if n_entries > 100 else 8192
+        vals = rng.integers(0, hi, size=n_entries * rows).astype(np_dt)
+        ids = [lc.ParquetArrayID.new(11, n_entries % 7, 1, k) for k in range(n_entries)]
+        for k, e in enumerate(ids):
+            gpu_cache.insert(e, pa.array(vals[k * rows:(k + 1) * rows], type=pa_dt))
+        scan = gpu_cache.scan(ids)
+        lit = int(hi // 3)
+        totals, c = _eval_count(scan, gpu_cache, lc.LiquidExpr.try_new("<", lit, pa_dt), repeat=3)
+        assert totals == [int((vals < lit).sum())] * 3 and int(c.sum()) == totals[0]
+        keep = rng.random(len(vals)) < 0.4
+        words = _sel_words(scan, [keep[k * rows:(k + 1) * rows] for k in range(n_entries)])
+        pair = [lc.LiquidExpr.try_new(">=", lit // 2, pa_dt), lc.LiquidExpr.try_new("<", lit, pa_dt)]
+        totals, c = _eval_count(scan, gpu_cache, pair, words, repeat=2)
+        assert totals == [int(((vals >= lit // 2) & (vals < lit) & keep).sum())] * 2
+        scan.close()
+        gpu_cache.evict(ids)
+    # ALP floats with exceptions (k_alp_patch_fix adjusts the total) and strings
+    f = np.round(rng.normal(10.0, 3.0, size=3 * 8192), 1)
+    f[rng.choice(len(f), 200, replace=False)] = rng.normal(0, 1e-9, size=200)
+    ids = [lc.ParquetArrayID.new(11, 9, 2, k) for k in range(3)]
+    for k, e in enumerate(ids):
+        gpu_cache.insert(e, pa.array(f[k * 8192:(k + 1) * 8192], type=pa.float64()))
+    scan = gpu_cache.scan(ids)
+    totals, c = _eval_count(scan, gpu_cache, lc.LiquidExpr.try_new("<", 1e-3, pa.float64()), repeat=2)
+    assert totals == [int((f < 1e-3).sum())] * 2 and int(c.sum()) == totals[0]
+    scan.close()
+    words_ = ["google", "yandex", "mail", "maps"]
+    strs = ["http://%s.ru/%s/%d" % (words_[rng.integers(4)], words_[rng.integers(4)], rng.integers(500)) for _ in range(5 * 4096)]
+    ids = [lc.ParquetArrayID.new(11, 9, 3, k) for k in range(5)]
+    for k, e in enumerate(ids):
+        gpu_cache.insert(e, pa.array(strs[k * 4096:(k + 1) * 4096]), lc.CacheExpression.SUBSTRING_SEARCH)
+    scan = gpu_cache.scan(ids)
+    hint = lc.CacheExpression.SUBSTRING_SEARCH
+    for op, pat, want in (("like", "%google%", sum("google" in s for s in strs)),
+                          ("not_like", "%google%", sum("google" not in s for s in strs)),
+                          ("eq", strs[5], sum(s == strs[5] for s in strs)),
+                          ("like", "%nomatch%", 0)):
+        totals, c = _eval_count(scan, gpu_cache, lc.LiquidExpr.try_new(op, pat, pa.string(), hint), repeat=2)
+        assert totals == [want] * 2 and int(c.sum()) == want, (op, pat)
+    scan.close()
