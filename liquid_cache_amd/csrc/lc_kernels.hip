@@ -28,6 +28,8 @@
 #include <cstdlib>
 #include <utility>
 
+extern "C" __device__ int __llvm_amdgcn_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+
 namespace lc {
 
 namespace {
@@ -86,11 +88,14 @@ __device__ __forceinline__ void async_copy16(const void* gsrc_lane, void* lds_ba
                                      16, 0, 0);
 }
 
-// v_writelane_b32 with a compile-time lane (inline constant: does not occupy the constant bus)
+// v_writelane_b32 with a compile-time lane.  The LLVM intrinsic, not inline assembly: gfx950 needs two wait states
+// between a VALU instruction that writes an SGPR / VCC (v_cmp) and a v_writelane that reads it.  The compiler's hazard
+// recognizer provides them (s_nop, or independent work scheduled in between) for its own instructions only; a
+// hand-written v_writelane placed right behind the v_cmp reads the PREVIOUS mask (found the hard way: counts stayed
+// plausible, bits did not).
 template <uint32_t LANE>
 __device__ __forceinline__ uint32_t writelane_c(uint32_t sval, uint32_t old) {
-    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(LANE));
-    return old;
+    return uint32_t(__llvm_amdgcn_writelane_i32(int(sval), int(LANE), int(old)));
 }
 
 // Pointers read out of descriptors are generic to the compiler; these casts make the accesses global_load (own
@@ -653,11 +658,12 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
                 const uint8_t* base = packed + uint64_t(blk0) * 128u * uint32_t(W);
                 if constexpr (TB == 32) {
                     // word k of FastLanes lane l of block A|B: one 128-byte line per block and k
-                    const bool have = blk0 + (uint32_t(lane) >> 5) < nblocks;
-                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + (uint32_t(lane) >> 5) * 32u * uint32_t(W) +
-                                        (uint32_t(lane) & 31u);
+                    // (an entry with an odd number of blocks has no block B in its last pass: those lanes re-read block A,
+                    // their mask words are outside the entry and are never stored)
+                    const uint32_t which = (blk0 + 1u < nblocks) ? (uint32_t(lane) >> 5) : 0u;
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + which * 32u * uint32_t(W) + (uint32_t(lane) & 31u);
 #pragma unroll
-                    for (int k = 0; k < NW; k++) w[k] = have ? as_global(p)[k * 32] : 0u;
+                    for (int k = 0; k < NW; k++) w[k] = as_global(p)[k * 32];
                 } else if constexpr (TB == 16) {
                     // u16 word j of lane l at j*128 + 2l; two of them make one dword of the stream
                     const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + uint32_t(lane);
@@ -2344,9 +2350,25 @@ __global__ __launch_bounds__(kThreads) void k_str_decode_sel(const StrDesc* __re
     }
 }
 
+// Reads `n16` 16-byte words and keeps one word per workgroup: replaces whatever the memory-side cache held by CLEAN lines
+// of a scratch buffer (a memset would leave 256 MiB of dirty lines whose write-back the next kernel pays for).
+__global__ __launch_bounds__(256) void k_flush_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += uint64_t(gridDim.x) * 256) {
+        const uint4 v = src[i];
+        acc ^= v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;  // practically never true: keeps the loads alive, writes nothing
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
+hipError_t launch_flush_read(const void* d_buf, uint64_t bytes, uint32_t* d_sink, hipStream_t stream) {
+    hipLaunchKernelGGL(k_flush_read, dim3(2048), dim3(256), 0, stream, static_cast<const uint4*>(d_buf), bytes / 16, d_sink);
+    return hipGetLastError();
+}
+
 static int device_cus() {
     static int n_cus = 0;
     if (n_cus == 0) {

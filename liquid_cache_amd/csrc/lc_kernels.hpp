@@ -180,6 +180,8 @@ hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const Sc
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
                                uint64_t capacity_rows, hipStream_t stream);
 // bit compress (PEXT) / deposit (PDEP) per entry segment
+// cache flush for cold timings: streams `bytes` of d_buf through the memory-side cache (d_sink: >= 2048 u32)
+hipError_t launch_flush_read(const void* d_buf, uint64_t bytes, uint32_t* d_sink, hipStream_t stream);
 hipError_t launch_mask_compress(const uint64_t* d_src, const uint64_t* d_sel, const uint64_t* d_seg_offsets,
                                 uint32_t n_entries, uint64_t* d_out, uint32_t* d_out_bits, hipStream_t stream);
 hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, const uint64_t* d_right, uint64_t* d_out,

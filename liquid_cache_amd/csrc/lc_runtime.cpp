@@ -1135,7 +1135,7 @@ lc_status lc_scan_eval_count(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pre
 }
 
 // Kernel time of ONE evaluation with the memory-side cache flushed before every launch: `flush_bytes` of scratch are
-// overwritten between launches (the 256 MiB Infinity Cache of MI355X keeps a 150 MB working set resident across
+// READ between launches (the 256 MiB Infinity Cache of MI355X keeps a 150 MB working set resident across
 // back-to-back identical passes, which a hot-cache QUERY over a 100-column table never enjoys).
 lc_status lc_scan_eval_timed_cold(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
                                   void* d_mask_out, void* d_counts_out, void* stream, int32_t iters, uint64_t flush_bytes,
@@ -1144,13 +1144,24 @@ lc_status lc_scan_eval_timed_cold(lc_ctx* ctx, lc_scan* scan, const lc_predicate
     if (!ctx || !scan || !out_avg_ms || iters <= 0) return fail(LC_ERR_INVALID, "bad iters/out");
     hipStream_t st = static_cast<hipStream_t>(stream);
     void* d_flush = nullptr;
-    if (flush_bytes) LC_HIP(hipMalloc(&d_flush, flush_bytes));
+    if (flush_bytes) {
+        flush_bytes = std::max<uint64_t>(flush_bytes, 1 << 20);
+        LC_HIP(hipMalloc(&d_flush, flush_bytes + 8192));
+        if (hipMemset(d_flush, 1, flush_bytes + 8192) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(d_flush);
+            return fail(LC_ERR_DEVICE, "flush buffer initialisation failed");
+        }
+    }
     hipEvent_t a, b;
     lc_status rc = LC_OK;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipEventCreate");
     double total = 0;
     for (int i = 0; i < iters && rc == LC_OK; i++) {
-        if (d_flush && hipMemsetAsync(d_flush, i & 0xFF, flush_bytes, st) != hipSuccess) rc = fail(LC_ERR_DEVICE, "flush");
+        // two read passes over the scratch: the memory-side cache ends up holding clean scratch lines only
+        for (int pass = 0; pass < 2 && d_flush && rc == LC_OK; pass++)
+            if (launch_flush_read(d_flush, flush_bytes, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_flush) + flush_bytes),
+                                  st) != hipSuccess)
+                rc = fail(LC_ERR_DEVICE, "flush");
         if (rc == LC_OK && hipEventRecord(a, st) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipEventRecord");
         if (rc == LC_OK) rc = scan_eval_impl(ctx, scan, pred, d_selection, d_mask_out, nullptr, d_counts_out, nullptr, st);
         if (rc == LC_OK && (hipEventRecord(b, st) != hipSuccess || hipEventSynchronize(b) != hipSuccess))
