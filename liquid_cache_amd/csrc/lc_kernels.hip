@@ -539,8 +539,8 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
 //                             2*(r&7) + ((r>>3)&1) of block A in the low half of the ballot and of block B in the high half
 //   u16 lanes (64 per block): thread = lane; step r gives word 2*(r&7) + (r>>3) whole
 //   u64 lanes (16 per block): thread = (q, lane); q owns rows 16*{0,2,1,3}[q] .. +15; step r' gives word 2*(r'&7) + (r'>>3)
-// ~5 issue slots per 64 rows.  The words are parked in lanes 0..31 / 0..15 and combined with selection & validity once
-// per pass.  Constant outcomes (literal outside the entry's FoR range) still skip the packed data.
+// 4-5 issue slots per 64 rows.  A pass covers two blocks; their 32 mask words are parked in lanes 0..31 and combined with
+// selection & validity once per pass.  Constant outcomes (literal outside the entry's FoR range) still skip the packed data.
 // ------------------------------------------------------------------------------------------------
 template <int W, uint32_t R, int NW>
 __device__ __forceinline__ uint32_t field_top(const uint32_t (&w)[NW]) {
@@ -554,11 +554,18 @@ __device__ __forceinline__ uint32_t field_top(const uint32_t (&w)[NW]) {
     }
 }
 
+// One compare per row when the range is one sided (`u <= bound`: Lt / LtEq directly, Gt / GtEq as the complement of
+// `u <= lit - 1`), subtract + compare for a genuine interval (Eq, fused conjunct pairs).
+template <bool kTwoSided>
+__device__ __forceinline__ uint64_t range_ballot(uint32_t t, uint32_t lo_t, uint32_t bound_t) {
+    if constexpr (kTwoSided) return __ballot(uint32_t(t - lo_t) <= bound_t);
+    else return __ballot(t <= bound_t);
+}
+
 // u32 lanes: one step = row R of blocks A (lanes 0..31) and B (lanes 32..63)
-template <int W, uint32_t R, int NW>
-__device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t span_t, uint32_t& X, uint32_t& Y) {
-    const uint32_t t = field_top<W, R, NW>(w);
-    const uint64_t b = __ballot(uint32_t(t - lo_t) <= span_t);
+template <int W, bool kTwoSided, uint32_t R, int NW>
+__device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t bound_t, uint32_t& X, uint32_t& Y) {
+    const uint64_t b = range_ballot<kTwoSided>(field_top<W, R, NW>(w), lo_t, bound_t);
     const uint32_t blo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b))));
     const uint32_t bhi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32))));
     constexpr uint32_t word = 2u * (R & 7u) + ((R >> 3) & 1u);
@@ -570,30 +577,65 @@ __device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_
         Y = writelane_c<16u + word>(bhi, Y);
     }
 }
-template <int W, int NW, uint32_t... RS>
+template <int W, bool kTwoSided, int NW, uint32_t... RS>
 __device__ __forceinline__ void reg_steps32(std::integer_sequence<uint32_t, RS...>, const uint32_t (&w)[NW], uint32_t lo_t,
-                                            uint32_t span_t, uint32_t& X, uint32_t& Y) {
-    (reg_step32<W, RS, NW>(w, lo_t, span_t, X, Y), ...);
+                                            uint32_t bound_t, uint32_t& X, uint32_t& Y) {
+    (reg_step32<W, kTwoSided, RS, NW>(w, lo_t, bound_t, X, Y), ...);
 }
-// u16 / u64 lanes: one step = one whole 64-row word of the block
-template <int W, uint32_t R, int NW>
-__device__ __forceinline__ void reg_step16(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t span_t, uint32_t& X, uint32_t& Y) {
-    const uint32_t t = field_top<W, R, NW>(w);
-    const uint64_t b = __ballot(uint32_t(t - lo_t) <= span_t);
-    constexpr uint32_t word = 2u * (R & 7u) + (R >> 3);
+// u16 / u64 lanes: one step = one whole 64-row word of block B of the pass (its words are parked in lanes 16*B ..)
+template <int W, bool kTwoSided, uint32_t B, uint32_t R, int NW>
+__device__ __forceinline__ void reg_step16(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t bound_t, uint32_t& X, uint32_t& Y) {
+    const uint64_t b = range_ballot<kTwoSided>(field_top<W, R, NW>(w), lo_t, bound_t);
+    constexpr uint32_t word = 16u * B + 2u * (R & 7u) + (R >> 3);
     X = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b)))), X);
     Y = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32)))), Y);
 }
-template <int W, int NW, uint32_t... RS>
+template <int W, bool kTwoSided, uint32_t B, int NW, uint32_t... RS>
 __device__ __forceinline__ void reg_steps16(std::integer_sequence<uint32_t, RS...>, const uint32_t (&w)[NW], uint32_t lo_t,
-                                            uint32_t span_t, uint32_t& X, uint32_t& Y) {
-    (reg_step16<W, RS, NW>(w, lo_t, span_t, X, Y), ...);
+                                            uint32_t bound_t, uint32_t& X, uint32_t& Y) {
+    (reg_step16<W, kTwoSided, B, RS, NW>(w, lo_t, bound_t, X, Y), ...);
+}
+
+// the thread's 16-row bit stream of one block on u16 / u64 lanes
+template <typename U, int W, int NW>
+__device__ __forceinline__ void load_stream16(const uint8_t* base, int lane, uint32_t (&w)[NW]) {
+    if constexpr (LaneTraits<U>::kBits == 16) {
+        // u16 word j of lane l at j*128 + 2l; two of them make one dword of the stream
+        const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + uint32_t(lane);
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const uint32_t x = as_global(p)[(2 * k) * 64];
+            const uint32_t y = (2 * k + 1 < W) ? uint32_t(as_global(p)[(2 * k + 1) * 64]) : 0u;
+            w[k] = x | (y << 16);
+        }
+    } else {
+        // u64 lanes: thread (q, l) owns rows 16*g .. 16*g+15 of lane l, g = {0,2,1,3}[q]: bits [16*g*W, +16*W) of the
+        // lane's stream of u64 words (word j at j*128 + 8l), read as dwords
+        const uint32_t q = uint32_t(lane) >> 4, l = uint32_t(lane) & 15u;
+        const uint32_t g = ((q & 1u) << 1) | (q >> 1);
+        const uint32_t bit0 = 16u * g * uint32_t(W);
+        const uint32_t d0 = bit0 >> 5;  // first dword of the thread's stream; dword i of a lane's stream is half (i & 1)
+                                        // of u64 word i >> 1, i.e. at byte (i >> 1) * 128 + (i & 1) * 4
+        // two per-thread bases so that every load has a compile-time offset whatever the parity of d0:
+        //   d0 even: dword d0+k at base + (k>>1)*128 + (k&1)*4;   d0 odd: the same + 4 (k even) or + 124 (k odd)
+        const uint8_t* b0 = base + l * 8u + (d0 >> 1) * 128u + (d0 & 1u) * 4u;
+        const uint32_t* pe = reinterpret_cast<const uint32_t*>(b0);
+        const uint32_t* po = reinterpret_cast<const uint32_t*>(b0 + (d0 & 1u) * 120u);
+#pragma unroll
+        for (int k = 0; k < NW; k++) w[k] = (k & 1) ? as_global(po)[(k >> 1) * 32 + 1] : as_global(pe)[(k >> 1) * 32];
+        if constexpr (W & 1) {  // odd widths: the 16-row groups start on a 16-bit boundary
+            const uint32_t bo = bit0 & 31u;
+#pragma unroll
+            for (int k = 0; k + 1 < NW; k++) w[k] = __builtin_amdgcn_alignbit(w[k + 1], w[k], bo);
+            w[NW - 1] >>= bo;  // its last 16 stream bits
+        }
+    }
 }
 
 // What one entry's passes need, passed BY VALUE to a non-inlined function per width: with all 32 widths inlined into
 // one kernel body the compiler hoists address arithmetic of every variant out of the entry loop and the kernel ends up
 // at 130-256 VGPRs; as separate functions each variant gets its own allocation (~40 VGPRs, 8 waves per SIMD).  One call
-// per entry (8 blocks) costs nothing next to the ~800 instructions it runs.
+// per entry (8 blocks) costs nothing next to the ~700 instructions it runs.
 struct RegEntryArgs {
     const uint8_t* packed;
     const uint64_t* validity;
@@ -601,9 +643,9 @@ struct RegEntryArgs {
     uint64_t* hit;              // already offset to the entry's segment
     uint64_t* valid_out;        // idem, or null
     uint32_t len;
-    uint32_t lo, span;          // packed-domain range (values fit 32 bits: W <= 32)
+    uint32_t lo, bound;         // two sided: (u - lo) <= bound; one sided: u <= bound   (values fit 32 bits: W <= 32)
     int32_t constant;           // -1: evaluate; 0/1: every valid selected row gives this result
-    uint32_t negate;
+    uint32_t flip;              // complement the compare
     uint32_t all_null;
 };
 
@@ -611,12 +653,11 @@ __device__ __forceinline__ const uint8_t* uniform_ptr(const void* p) {
     return reinterpret_cast<const uint8_t*>(uintptr_t(uniform_u64(uint64_t(reinterpret_cast<uintptr_t>(p)))));
 }
 
-// All passes of one entry.  Returns this lane's share of the entry's hit count.
-template <typename U, int W>
+// All passes of one entry; a pass is two 1024-row blocks, whose 32 mask words end up in lanes 0..31.  Returns this lane's
+// share of the entry's hit count.
+template <typename U, int W, bool kTwoSided>
 __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     constexpr uint32_t TB = LaneTraits<U>::kBits;
-    constexpr uint32_t kBlocksPerPass = TB == 32 ? 2u : 1u;
-    constexpr uint32_t kWordsPerPass = 16u * kBlocksPerPass;
     // dwords of the thread's stream: u32 lanes hold all 32 rows of their lane, u16 / u64 threads hold 16 rows
     constexpr int NW = TB == 32 ? W : (16 * W + 31) / 32;
     const int lane = lane_id();
@@ -628,20 +669,20 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     uint64_t* valid_out = reinterpret_cast<uint64_t*>(const_cast<uint8_t*>(uniform_ptr(a.valid_out)));
     const uint32_t len = uint32_t(__builtin_amdgcn_readfirstlane(int(a.len)));
     const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(a.lo)));
-    const uint32_t span = uint32_t(__builtin_amdgcn_readfirstlane(int(a.span)));
+    const uint32_t bound = uint32_t(__builtin_amdgcn_readfirstlane(int(a.bound)));
     const int constant = __builtin_amdgcn_readfirstlane(a.constant);
     const bool all_null = __builtin_amdgcn_readfirstlane(int(a.all_null)) != 0;
-    const uint64_t neg = __builtin_amdgcn_readfirstlane(int(a.negate)) ? ~uint64_t(0) : uint64_t(0);
+    const uint64_t flip = __builtin_amdgcn_readfirstlane(int(a.flip)) ? ~uint64_t(0) : uint64_t(0);
     const uint32_t nwords_entry = (len + 63u) >> 6;
     const uint32_t nblocks = (len + 1023u) >> 10;
     const uint32_t lo_t = lo << (32 - W);
-    const uint32_t span_t = (span << (32 - W)) | (W == 32 ? 0u : ((1u << ((32 - W) & 31)) - 1u));
+    const uint32_t bound_t = (bound << (32 - W)) | (W == 32 ? 0u : ((1u << ((32 - W) & 31)) - 1u));
     uint32_t count = 0;
-    for (uint32_t blk0 = 0; blk0 < nblocks; blk0 += kBlocksPerPass) {
-        // selection & validity: lane i (< kWordsPerPass) owns mask word 16*blk0 + i of the entry
+    for (uint32_t blk0 = 0; blk0 < nblocks; blk0 += 2u) {
+        // selection & validity: lane i (< 32) owns mask word 16*blk0 + i of the entry
         const uint32_t widx = blk0 * 16u + uint32_t(lane);
         uint64_t act = 0;
-        const bool own = uint32_t(lane) < kWordsPerPass && widx < nwords_entry;
+        const bool own = uint32_t(lane) < 32u && widx < nwords_entry;
         if (own) {
             uint64_t tail = ~uint64_t(0);
             if (widx == nwords_entry - 1 && (len & 63u)) tail = (uint64_t(1) << (len & 63u)) - 1;
@@ -650,55 +691,30 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
             act = all_null ? 0 : (selw & vw & tail);  // all-null entries carry no validity buffer: no row is valid
         }
         uint64_t result = 0;
-        if (__ballot(act != 0) != 0) {  // blocks without a selected valid row do not touch their packed data
+        if (__ballot(act != 0) != 0) {  // passes without a selected valid row do not touch their packed data
             if (constant >= 0) {
                 result = constant ? act : 0;
             } else {
-                uint32_t w[NW];
+                // (an entry with an odd number of blocks has no block B in its last pass: block A is read again, its mask
+                // words lie outside the entry and are never stored)
+                const uint32_t b_off = (blk0 + 1u < nblocks) ? 128u * uint32_t(W) : 0u;
                 const uint8_t* base = packed + uint64_t(blk0) * 128u * uint32_t(W);
+                uint32_t X = 0, Y = 0;
                 if constexpr (TB == 32) {
                     // word k of FastLanes lane l of block A|B: one 128-byte line per block and k
-                    // (an entry with an odd number of blocks has no block B in its last pass: those lanes re-read block A,
-                    // their mask words are outside the entry and are never stored)
-                    const uint32_t which = (blk0 + 1u < nblocks) ? (uint32_t(lane) >> 5) : 0u;
-                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base) + which * 32u * uint32_t(W) + (uint32_t(lane) & 31u);
+                    uint32_t w[NW];
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (uint32_t(lane) >> 5) * b_off) + (uint32_t(lane) & 31u);
 #pragma unroll
                     for (int k = 0; k < NW; k++) w[k] = as_global(p)[k * 32];
-                } else if constexpr (TB == 16) {
-                    // u16 word j of lane l at j*128 + 2l; two of them make one dword of the stream
-                    const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + uint32_t(lane);
-#pragma unroll
-                    for (int k = 0; k < NW; k++) {
-                        const uint32_t x = as_global(p)[(2 * k) * 64];
-                        const uint32_t y = (2 * k + 1 < W) ? uint32_t(as_global(p)[(2 * k + 1) * 64]) : 0u;
-                        w[k] = x | (y << 16);
-                    }
+                    reg_steps32<W, kTwoSided, NW>(std::make_integer_sequence<uint32_t, 32>{}, w, lo_t, bound_t, X, Y);
                 } else {
-                    // u64 lanes: thread (q, l) owns rows 16*g .. 16*g+15 of lane l, g = {0,2,1,3}[q]: bits [16*g*W, +16*W) of
-                    // the lane's stream of u64 words (word j at j*128 + 8l), read as dwords
-                    const uint32_t q = uint32_t(lane) >> 4, l = uint32_t(lane) & 15u;
-                    const uint32_t g = ((q & 1u) << 1) | (q >> 1);
-                    const uint32_t bit0 = 16u * g * uint32_t(W);
-                    const uint32_t d0 = bit0 >> 5;  // first dword of the thread's stream; dword i of a lane's stream is
-                                                    // half (i & 1) of u64 word i >> 1, i.e. at byte (i >> 1) * 128 + (i & 1) * 4
-                    // two per-thread bases so that every load has a compile-time offset whatever the parity of d0:
-                    //   d0 even: dword d0+k at base + (k>>1)*128 + (k&1)*4;   d0 odd: the same + 4 (k even) or + 124 (k odd)
-                    const uint8_t* b0 = base + l * 8u + (d0 >> 1) * 128u + (d0 & 1u) * 4u;
-                    const uint32_t* pe = reinterpret_cast<const uint32_t*>(b0);
-                    const uint32_t* po = reinterpret_cast<const uint32_t*>(b0 + (d0 & 1u) * 120u);
-#pragma unroll
-                    for (int k = 0; k < NW; k++) w[k] = (k & 1) ? as_global(po)[(k >> 1) * 32 + 1] : as_global(pe)[(k >> 1) * 32];
-                    if constexpr (W & 1) {  // odd widths: the 16-row groups start on a 16-bit boundary
-                        const uint32_t bo = bit0 & 31u;
-#pragma unroll
-                        for (int k = 0; k + 1 < NW; k++) w[k] = __builtin_amdgcn_alignbit(w[k + 1], w[k], bo);
-                        w[NW - 1] >>= bo;  // its last 16 stream bits
-                    }
+                    uint32_t wa[NW], wb[NW];  // both blocks' loads are in flight before the first compare
+                    load_stream16<U, W, NW>(base, lane, wa);
+                    load_stream16<U, W, NW>(base + b_off, lane, wb);
+                    reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, wa, lo_t, bound_t, X, Y);
+                    reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, wb, lo_t, bound_t, X, Y);
                 }
-                uint32_t X = 0, Y = 0;
-                if constexpr (TB == 32) reg_steps32<W, NW>(std::make_integer_sequence<uint32_t, 32>{}, w, lo_t, span_t, X, Y);
-                else reg_steps16<W, NW>(std::make_integer_sequence<uint32_t, 16>{}, w, lo_t, span_t, X, Y);
-                result = ((uint64_t(X) | (uint64_t(Y) << 32)) ^ neg) & act;
+                result = ((uint64_t(X) | (uint64_t(Y) << 32)) ^ flip) & act;
             }
         }
         if (own) {
@@ -711,11 +727,12 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
 }
 
 template <typename U, int... WS>
-__device__ __forceinline__ uint32_t fixed_pred_entry_dispatch(std::integer_sequence<int, WS...>, uint32_t W,
+__device__ __forceinline__ uint32_t fixed_pred_entry_dispatch(std::integer_sequence<int, WS...>, uint32_t W, bool two_sided,
                                                               const RegEntryArgs& a) {
     uint32_t c = 0;
-    // W is wave uniform: exactly one of these branches runs
-    ((int(W) == WS + 1 ? (void)(c = fixed_pred_entry_reg<U, WS + 1>(a)) : (void)0), ...);
+    // W and two_sided are wave uniform: exactly one of these branches runs
+    if (two_sided) ((int(W) == WS + 1 ? (void)(c = fixed_pred_entry_reg<U, WS + 1, true>(a)) : (void)0), ...);
+    else ((int(W) == WS + 1 ? (void)(c = fixed_pred_entry_reg<U, WS + 1, false>(a)) : (void)0), ...);
     return c;
 }
 
@@ -731,6 +748,9 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
         const FixedDesc d = descs[entry];
         const PackedRange<U> pr = entry_range<U>(d, pred, pred2, lane);
+        const uint32_t W = max(uint32_t(d.W), 1u);
+        const uint32_t umax = W >= 32 ? ~0u : ((1u << W) - 1u);
+        const uint32_t lo = uint32_t(pr.lo), span = uint32_t(pr.span);
         RegEntryArgs a;
         a.packed = d.packed;
         a.validity = d.validity;
@@ -738,12 +758,18 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __
         a.hit = L.d_hit + d.mask_word_off;
         a.valid_out = L.d_valid ? L.d_valid + d.mask_word_off : nullptr;
         a.len = d.len;
-        a.lo = uint32_t(pr.lo);
-        a.span = uint32_t(pr.span);
         a.constant = d.W == 0 ? 0 : pr.constant;
-        a.negate = pr.negate ? 1u : 0u;
         a.all_null = d.W == 0 ? 1u : 0u;
-        const uint32_t c = fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, max(uint32_t(d.W), 1u), a);
+        bool two_sided = false;
+        if (lo == 0) {                    // u <= span
+            a.lo = 0; a.bound = span; a.flip = pr.negate ? 1u : 0u;
+        } else if (lo + span == umax) {   // u >= lo  ==  not (u <= lo - 1)
+            a.lo = 0; a.bound = lo - 1u; a.flip = pr.negate ? 0u : 1u;
+        } else {
+            two_sided = true;
+            a.lo = lo; a.bound = span; a.flip = pr.negate ? 1u : 0u;
+        }
+        const uint32_t c = fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, W, two_sided, a);
         if (L.d_counts || L.d_total_out) {
             const uint64_t t = wave_sum_u64(uint64_t(c));
             if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(t);
