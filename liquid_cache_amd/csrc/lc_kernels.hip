@@ -875,7 +875,11 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
     __syncthreads();
     const DevSymtab& st = symtabs[blockIdx.x];
     uint8_t* t = out + size_t(blockIdx.x) * automaton_stride(m);
-    // LDS image (short needles): u16 entries = LDS byte address of the next state's row, rows of 1 KB from address 0
+    // LDS image (short needles): 2 (m + 1) rows of 256 u16 entries, each the LDS byte address of the next state's row
+    // (the image sits at LDS address 0).  Row s (s <= m): automaton state s, next byte is a CODE: entry[c] = row of the
+    // state after the whole symbol c, entry[255] (the FSST escape marker) = row m + 1 + s.  Row m + 1 + s: state s, next
+    // byte is an escaped LITERAL: entry[b] = row of delta(s, b).  The escape handling is part of the state, so a scan is
+    // ONE dependent lookup per compressed byte with nothing else to track; state m is absorbing.
     uint16_t* img = automaton_image_bytes(m) ? reinterpret_cast<uint16_t*>(t + automaton_u8_bytes(m)) : nullptr;
     const uint32_t code = threadIdx.x;
     const uint64_t sym = st.sym[code];
@@ -883,24 +887,13 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
     for (uint32_t s = 0; s <= m; s++) {
         uint32_t cur = s;
         for (uint32_t k = 0; k < sl; k++) cur = delta[cur * 256 + uint32_t((sym >> (8 * k)) & 0xFF)];
-        // code 255 is the escape marker: never a transition (0xFF flag in the u8 table, state kept in the image)
+        // code 255 is the escape marker: never a transition (0xFF flag in the u8 table)
         t[s * 512 + code] = code == 255u ? uint8_t(0xFF) : uint8_t(cur);
         t[s * 512 + 256 + code] = delta[s * 256 + code];
         if (img) {
-            img[s * 512 + code] = uint16_t((code == 255u ? s : cur) * 1024u);
-            img[s * 512 + 256 + code] = uint16_t(uint32_t(delta[s * 256 + code]) * 1024u);
-        }
-    }
-    if (img) {
-        // escape-role table: index (entry role << 8 | marker mask) -> literal mask | exit role << 8
-        uint16_t* role = img + (m + 1) * 512;
-        for (uint32_t i = threadIdx.x; i < 512u; i += blockDim.x) {
-            uint32_t lit = i >> 8, lmask = 0;
-            for (uint32_t q = 0; q < 8; q++) {
-                lmask |= lit << q;
-                lit = (lit ^ 1u) & (i >> q) & 1u;  // a marker in code position makes the next byte a literal
-            }
-            role[i] = uint16_t(lmask | (lit << 8));
+            const uint32_t after_code = code == 255u ? (s == m ? m : m + 1u + s) : cur;
+            img[s * 256 + code] = uint16_t(after_code * 512u);
+            img[(m + 1u + s) * 256 + code] = uint16_t(uint32_t(delta[s * 256 + code]) * 512u);
         }
     }
 }
@@ -1160,52 +1153,42 @@ __device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], u
     return rem == 0 ? sb : sel;
 }
 
-// Sequential walker over the same LDS image, one candidate per lane: used when an entry has at least a full wave of
-// candidates (no signature index, or no fingerprints at all: every dictionary value is walked), where one lane per value
-// keeps all 64 lanes busy and needs no cross-lane bookkeeping.  Escape handling inline: a marker (255 in code
-// position) leaves the state unchanged in the image and sends the next byte to the literal half of the row.
-__device__ __forceinline__ bool like_walk_seq(const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop,
-                                              uint32_t row0, uint32_t nl) {
-    uint32_t sb = row0;  // LDS address of the current state's row
-    uint32_t lit = 0;    // 512 while the next byte is an escaped literal
-    for (uint32_t p0 = start; p0 < stop; p0 += 64) {
-        uint64_t pw[8];
+// Sequential walker over the same LDS image, NC candidates per lane side by side: used when an entry has at least a full
+// wave of candidates (no signature index, or no fingerprints at all: every dictionary value is walked), where one lane
+// per value keeps all 64 lanes busy and needs no cross-lane bookkeeping.  Per compressed byte: extract, address, one
+// ds_read_u16, and the guard that keeps bytes past the end of the value from moving the state; the NC independent
+// chains of a lane overlap their LDS latencies.
+template <int NC>
+__device__ __forceinline__ void like_walk_seq(const uint8_t* __restrict__ fsst, const uint32_t (&start)[NC],
+                                              const uint32_t (&stop)[NC], uint32_t row0, uint32_t hitrow, bool (&res)[NC]) {
+    uint32_t sb[NC], pos[NC];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            pw[k] = 0;
-            if (p0 + 8u * uint32_t(k) < stop) pw[k] = load_unaligned<uint64_t>(fsst + p0 + 8u * uint32_t(k));
+    for (int c = 0; c < NC; c++) { sb[c] = row0; pos[c] = start[c]; }
+    for (;;) {
+        uint64_t w[NC];
+        uint32_t rem[NC];
+        bool more = false;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            rem[c] = pos[c] < stop[c] ? stop[c] - pos[c] : 0u;
+            w[c] = 0;
+            if (rem[c]) w[c] = load_unaligned<uint64_t>(fsst + pos[c]);
+            more |= rem[c] != 0;
+            pos[c] += 8u;
         }
-#pragma unroll 1
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t p = p0 + 8u * k;
-            if (p >= stop) break;
-            const uint32_t rem = stop - p;
-            const uint64_t w = pw[0];
+        if (__ballot(more) == 0) break;
 #pragma unroll
-            for (int r = 0; r < 7; r++) pw[r] = pw[r + 1];
+        for (uint32_t q = 0; q < 8; q++) {
 #pragma unroll
-            for (uint32_t q = 0; q < 8; q++) {
-                const uint32_t c = uint32_t(w >> (8 * q)) & 0xFFu;
-                const uint32_t t = lds_u16(sb + lit + 2u * c);
-                const uint32_t next_lit = (lit == 0 && c == 255u) ? 512u : 0u;
-                if (q < rem) {
-                    sb = t;  // a marker maps the state to itself
-                    lit = next_lit;
-                }
+            for (int c = 0; c < NC; c++) {
+                const uint32_t code = (q < 4 ? uint32_t(w[c]) >> (8 * q) : uint32_t(w[c] >> 32) >> (8 * (q - 4))) & 0xFFu;
+                const uint32_t t = lds_u16(sb[c] + 2u * code);
+                sb[c] = q < rem[c] ? t : sb[c];
             }
         }
     }
-    return sb == row0 + nl * 1024u;
-}
-
-// 8-bit mask of the bytes of (lo, hi) that equal 0xFF
-__device__ __forceinline__ uint32_t marker_mask(uint32_t lo, uint32_t hi) {
-    auto m4 = [](uint32_t w) {
-        const uint32_t v = ~w;  // zero bytes of v <=> 0xFF bytes of w
-        const uint32_t t = ((v & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | v | 0x7F7F7F7Fu;
-        return (((~t) >> 7) * 0x00204081u >> 21) & 0xFu;
-    };
-    return m4(lo) | (m4(hi) << 4);
+#pragma unroll
+    for (int c = 0; c < NC; c++) res[c] = sb[c] == hitrow;
 }
 
 // Byte-view predicate: ONE WAVE per entry (batch), four entries per workgroup, no workgroup barriers after setup.
@@ -1250,7 +1233,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint8_t* hitflag = wbase + dres_bytes + cmask_bytes + kCandCap * 2u;
     uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
     const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
-    const uint32_t role_addr = row0 + (nl + 1u) * 1024u;
+    const uint32_t hitrow = row0 + nl * 512u;  // LDS address of the absorbing (matched) state's row
     const uint32_t dres_addr = uint32_t(reinterpret_cast<uintptr_t>(wbase));
 
     // This workgroup's entries: a precomputed range of at most four entries that share one symbol table (so the LDS
@@ -1288,10 +1271,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     // zeroes the group's counters for the next launch.
     uint32_t* work = L.d_work + wg_group * 16u;
     uint64_t wave_hits = 0;  // fused COUNT(*): hits of the entries this wave evaluated (lane 0)
-    for (;;) {
+    // A precomputed range holds at most one entry per wave: wave w simply takes entry w of the range.  The draw (a
+    // returning far atomic, ~1-2 us before the wave can even load its descriptor) is only paid by launches that hand a
+    // workgroup more entries than it has waves.
+    const bool static_draw = L.d_wg_ranges != nullptr && group_end - group_begin <= uint32_t(kWavesPerBlock);
+    for (uint32_t draw = 0;; draw++) {
         uint32_t entry = 0;
-        if (lane == 0) entry = group_begin + atomicAdd(&work[0], 1u);
-        entry = uint32_t(__builtin_amdgcn_readfirstlane(int(entry)));
+        if (static_draw) {
+            if (draw) break;
+            entry = group_begin + wave;
+        } else {
+            if (lane == 0) entry = group_begin + atomicAdd(&work[0], 1u);
+            entry = uint32_t(__builtin_amdgcn_readfirstlane(int(entry)));
+        }
         if (entry >= group_end) break;
 #ifdef LC_ABLATION
     const uint64_t rt_start = __builtin_amdgcn_s_memrealtime();
@@ -1508,6 +1500,28 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         LC_TM(2, 0);
         const uint32_t n_walk = LC_ABL(pred.debug_flags & 1) ? 0u : n_cand;
         for (uint32_t jb = 0; jb < n_walk; jb += kWave) {
+            if (kSub && tbl_in_lds && n_walk - jb >= 2u * uint32_t(kWave)) {
+                // two full waves of candidates: two values per lane, walked side by side (their LDS latencies overlap)
+                uint32_t st2[2], sp2[2];
+                bool r2[2];
+                const uint32_t id0 = cand[jb + uint32_t(lane)], id1 = cand[jb + uint32_t(kWave) + uint32_t(lane)];
+                str_offset_pair(d, id0, st2[0], sp2[0]);
+                str_offset_pair(d, id1, st2[1], sp2[1]);
+                if (L.d_cand_bytes && !prune) cand_bytes += (sp2[0] - st2[0]) + (sp2[1] - st2[1]);
+                if (L.d_own_bytes) own_bytes += (sp2[0] - st2[0]) + (sp2[1] - st2[1]) + 4u * d.offset_bytes;
+                like_walk_seq<2>(d.fsst, st2, sp2, row0, hitrow, r2);
+                const uint64_t rm = __ballot(r2[0] || r2[1]);
+                if (rm != 0 && any_true == 0) {
+                    for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)
+                        reinterpret_cast<uint4*>(wbase)[i] = make_uint4(0, 0, 0, 0);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+                any_true |= rm;
+                if (r2[0]) { if (kBytes) dresb[id0] = 1; else atomicOr(&dres[id0 >> 5], 1u << (id0 & 31)); }
+                if (r2[1]) { if (kBytes) dresb[id1] = 1; else atomicOr(&dres[id1 >> 5], 1u << (id1 & 31)); }
+                jb += kWave;  // this round took two waves of candidates
+                continue;
+            }
             const uint32_t j = jb + uint32_t(lane);
             const bool cl = j < n_walk;
             const uint32_t id = cl ? cand[j] : 0u;
@@ -1519,16 +1533,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             bool res = false;
             if (kSub && tbl_in_lds && n_walk - jb >= uint32_t(kWave)) {
                 // a full wave of candidates: one value per lane
-                res = like_walk_seq(d.fsst, start, stop, row0, nl);
+                const uint32_t st1[1] = {start}, sp1[1] = {stop};
+                bool r1[1];
+                like_walk_seq<1>(d.fsst, st1, sp1, row0, hitrow, r1);
+                res = r1[0];
             } else if (kSub && tbl_in_lds) {
                 // lane-parallel walk: one lane per 8-byte word of every candidate (see above)
-                const uint32_t hitrow = row0 + nl * 1024u;
                 const uint32_t words = cl ? max(1u, (stop - start + 7u) >> 3) : 0u;
                 const uint32_t incl = wave_inclusive_sum(words);
                 const uint32_t off = incl - words;
                 const uint32_t total = read_lane(incl, kWave - 1);
                 hitflag[lane] = 0;
-                uint32_t carry_state = row0, carry_role = 0;
+                uint32_t carry_state = row0;
                 for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
                     // owner of task t = t0 + lane: the last candidate whose first word is at or before t
                     if (lane == 0) *headmask = 0;
@@ -1552,29 +1568,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     const uint32_t lo = uint32_t(w), hi = uint32_t(w >> 32);
                     LC_TM(4, lo);
                     const bool first = k == 0;  // first word of its value (a value continuing from the previous pass
-                                                // has k > 0 in lane 0 and takes the carried role / state)
-                    // byte roles
-                    const uint32_t mm = marker_mask(lo, hi);
-                    uint32_t role_in = 0, rl = lds_u16(role_addr + 2u * mm);
-                    for (;;) {
-                        uint32_t prev = lane_shift_up1(rl >> 8, carry_role);
-                        if (first) prev = 0;
-                        const bool changed = prev != role_in;
-                        if (__ballot(changed) == 0) break;
-                        if (changed) {
-                            role_in = prev;
-                            rl = lds_u16(role_addr + 2u * ((role_in << 8) | mm));
-                        }
-                    }
-                    carry_role = read_lane(rl >> 8, kWave - 1);
-                    LC_TM(5, carry_role);
+                                                // has k > 0 in lane 0 and takes the carried state)
                     uint32_t x[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const uint32_t c = ((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu;
-                        x[q] = (c << 1) + (((rl >> q) & 1u) << 9);
-                    }
-                    // states
+                    for (int q = 0; q < 8; q++) x[q] = (((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu) << 1;
+                    LC_TM(5, x[0]);
+                    // states (the escape position is part of the state: nothing else crosses word boundaries)
                     uint32_t s_in = row0;
                     uint32_t e = walk8(s_in, x, rem);
                     bool hit = e == hitrow;
@@ -1734,7 +1733,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         // + phase C (keys only when some dictionary value matched; selection / validity words in, mask words out)
         uint32_t u = uint32_t(sizeof(StrDesc));
         if (kSub) u += use_sig ? pred.n_sig_bits * nw * 8u : 0u;
-        if (kSub) u += need_fp ? 4u * d.d : 0u;
+        // (the instrumented pass itself reads the fingerprints to count the reference's candidates; a normal pass only
+        // reads them when there is no signature index or for the NOT LIKE candidate rule)
+        if (kSub) u += (prune && (!use_sig || op == LC_OP_NOT_LIKE)) ? 4u * d.d : 0u;
         if (!kSub && pred.mode == 0 && uniform_result < 0) u += 8u * d.d;
         if (!all_false) u += 2u * d.n;
         u += nwords * 8u * ((L.d_selection ? 1u : 0u) + (d.validity ? 1u : 0u) + 1u + (L.d_valid ? 1u : 0u));
@@ -1744,7 +1745,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }  // entries
     if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, gridDim.x * kWavesPerBlock, wave_hits);
-    if (lane == 0) {
+    if (lane == 0 && !static_draw) {
         // workgroups of this group: blockIdx = wg_group, wg_group + work_groups, ...
         const uint32_t group_waves = ((gridDim.x - wg_group + L.work_groups - 1u) / L.work_groups) * kWavesPerBlock;
         if (atomicAdd(&work[1], 1u) == group_waves - 1u) {

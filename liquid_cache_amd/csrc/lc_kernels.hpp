@@ -25,13 +25,12 @@ namespace lc {
 
 constexpr int kMaxNeedleAutomaton = 63;  // KMP automaton states must fit a u8 table
 constexpr uint32_t kMaxLdsNeedle = 15;   // needles up to this length also get an LDS image of the automaton
-constexpr uint32_t kRoleTableBytes = 1024;
 // Per symbol table, k_str_automata emits: the u8 next-state table ((m+1) x 512 bytes) and, for short needles, the
-// image the scan kernel copies verbatim to LDS address 0: (m+1) rows x 512 u16 entries holding the LDS byte address of
-// the next state's row, followed by the 512-entry escape-role table.
+// image the scan kernel copies verbatim to LDS address 0: 2 (m+1) rows x 256 u16 entries holding the LDS byte address
+// of the next state's row (rows 0..m: next byte is a code; rows m+1..2m+1: next byte is an escaped literal).
 __host__ __device__ inline uint32_t automaton_u8_bytes(uint32_t m) { return (m + 1u) * 512u; }
 __host__ __device__ inline uint32_t automaton_image_bytes(uint32_t m) {
-    return m <= kMaxLdsNeedle ? (m + 1u) * 1024u + kRoleTableBytes : 0u;
+    return m <= kMaxLdsNeedle ? (m + 1u) * 1024u : 0u;
 }
 __host__ __device__ inline uint32_t automaton_stride(uint32_t m) { return automaton_u8_bytes(m) + automaton_image_bytes(m); }
 constexpr int kMaxNeedleBytes = 4096;
