@@ -1153,30 +1153,71 @@ __device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], u
     return rem == 0 ? sb : sel;
 }
 
-// Sequential walker over the same LDS image, NC candidates per lane side by side: used when an entry has at least a full
-// wave of candidates (no signature index, or no fingerprints at all: every dictionary value is walked), where one lane
-// per value keeps all 64 lanes busy and needs no cross-lane bookkeeping.  Per compressed byte: extract, address, one
-// ds_read_u16, and the guard that keeps bytes past the end of the value from moving the state; the NC independent
-// chains of a lane overlap their LDS latencies.
-template <int NC>
-__device__ __forceinline__ void like_walk_seq(const uint8_t* __restrict__ fsst, const uint32_t (&start)[NC],
-                                              const uint32_t (&stop)[NC], uint32_t row0, uint32_t hitrow, bool (&res)[NC]) {
-    uint32_t sb[NC], pos[NC];
+// Sequential walker over the same LDS image for entries with at least a wave of candidates (no signature index, or no
+// fingerprints at all: every dictionary value is walked).  Every lane owns NC independent chains; chain c of lane l walks
+// candidates l + 64 c, l + 64 c + 64 NC, ... ONE AFTER THE OTHER without waiting for its neighbours, so the wave stays
+// busy until the list runs out (values differ 10x in length: walking 64 of them in lock step would idle most lanes most
+// of the time) and the offsets of a chain's next value are fetched while the current one is walked.  Per compressed
+// byte: extract, address, one ds_read_u16, and the guard that keeps bytes past the end of a value from moving the state.
+// Returns the ballot of lanes that found a matching value; matches are written to the dictionary result table.
+template <bool kBytes, int NC>
+__device__ __forceinline__ uint64_t like_walk_many(const StrDesc& d, const uint16_t* cand, uint32_t n_walk, uint32_t row0,
+                                                   uint32_t hitrow, uint8_t* dresb, uint32_t* dres, int lane,
+                                                   uint32_t* walked_bytes) {
+    constexpr uint32_t kStride = uint32_t(kWave) * NC;
+    uint32_t j[NC], id[NC], pos[NC], stop[NC], sb[NC], nid[NC], nstart[NC], nstop[NC];
+    bool active[NC];
+    bool found = false;
+    uint32_t bytes = 0;
 #pragma unroll
-    for (int c = 0; c < NC; c++) { sb[c] = row0; pos[c] = start[c]; }
+    for (int c = 0; c < NC; c++) {
+        j[c] = uint32_t(lane) + uint32_t(kWave) * c;
+        active[c] = j[c] < n_walk;
+        id[c] = pos[c] = stop[c] = nid[c] = nstart[c] = nstop[c] = 0;
+        sb[c] = row0;
+        if (active[c]) {
+            id[c] = cand[j[c]];
+            str_offset_pair(d, id[c], pos[c], stop[c]);
+            bytes += stop[c] - pos[c];
+            if (j[c] + kStride < n_walk) {
+                nid[c] = cand[j[c] + kStride];
+                str_offset_pair(d, nid[c], nstart[c], nstop[c]);
+            }
+        }
+    }
     for (;;) {
-        uint64_t w[NC];
-        uint32_t rem[NC];
-        bool more = false;
+        bool any_active = false;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            rem[c] = pos[c] < stop[c] ? stop[c] - pos[c] : 0u;
-            w[c] = 0;
-            if (rem[c]) w[c] = load_unaligned<uint64_t>(fsst + pos[c]);
-            more |= rem[c] != 0;
-            pos[c] += 8u;
+            if (active[c] && pos[c] >= stop[c]) {  // this chain's value is finished: record it, move to the chain's next one
+                if (sb[c] == hitrow) {
+                    found = true;
+                    if (kBytes) dresb[id[c]] = 1;
+                    else atomicOr(&dres[id[c] >> 5], 1u << (id[c] & 31));
+                }
+                j[c] += kStride;
+                active[c] = j[c] < n_walk;
+                if (active[c]) {
+                    id[c] = nid[c]; pos[c] = nstart[c]; stop[c] = nstop[c]; sb[c] = row0;
+                    bytes += stop[c] - pos[c];
+                    if (j[c] + kStride < n_walk) {
+                        nid[c] = cand[j[c] + kStride];
+                        str_offset_pair(d, nid[c], nstart[c], nstop[c]);
+                    }
+                }
+            }
+            any_active |= active[c];
         }
-        if (__ballot(more) == 0) break;
+        if (__ballot(any_active) == 0) break;
+        uint64_t w[NC];
+        uint32_t rem[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            rem[c] = (active[c] && pos[c] < stop[c]) ? stop[c] - pos[c] : 0u;
+            w[c] = 0;
+            if (rem[c]) w[c] = load_unaligned<uint64_t>(d.fsst + pos[c]);
+            pos[c] += rem[c] ? 8u : 0u;
+        }
 #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {
 #pragma unroll
@@ -1187,8 +1228,8 @@ __device__ __forceinline__ void like_walk_seq(const uint8_t* __restrict__ fsst, 
             }
         }
     }
-#pragma unroll
-    for (int c = 0; c < NC; c++) res[c] = sb[c] == hitrow;
+    *walked_bytes = bytes;
+    return __ballot(found);
 }
 
 // Byte-view predicate: ONE WAVE per entry (batch), four entries per workgroup, no workgroup barriers after setup.
@@ -1360,6 +1401,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint32_t cand_bytes = 0;  // per lane, summed at the end (instrumented pass only)
     uint32_t own_bytes = 0;   // per lane (instrumented pass only): bytes this kernel itself moves for the entry
     uint64_t any_true = 0;    // wave uniform: some dictionary entry evaluated true
+    bool table_cleared = !kSub;  // wave uniform: the dictionary result table holds zeros + the matches set so far
     __builtin_amdgcn_wave_barrier();
 
     const uint32_t nw = (d.d + 63u) >> 6;  // u64 words of a dictionary bitmap
@@ -1500,27 +1542,19 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         LC_TM(2, 0);
         const uint32_t n_walk = LC_ABL(pred.debug_flags & 1) ? 0u : n_cand;
         for (uint32_t jb = 0; jb < n_walk; jb += kWave) {
-            if (kSub && tbl_in_lds && n_walk - jb >= 2u * uint32_t(kWave)) {
-                // two full waves of candidates: two values per lane, walked side by side (their LDS latencies overlap)
-                uint32_t st2[2], sp2[2];
-                bool r2[2];
-                const uint32_t id0 = cand[jb + uint32_t(lane)], id1 = cand[jb + uint32_t(kWave) + uint32_t(lane)];
-                str_offset_pair(d, id0, st2[0], sp2[0]);
-                str_offset_pair(d, id1, st2[1], sp2[1]);
-                if (L.d_cand_bytes && !prune) cand_bytes += (sp2[0] - st2[0]) + (sp2[1] - st2[1]);
-                if (L.d_own_bytes) own_bytes += (sp2[0] - st2[0]) + (sp2[1] - st2[1]) + 4u * d.offset_bytes;
-                like_walk_seq<2>(d.fsst, st2, sp2, row0, hitrow, r2);
-                const uint64_t rm = __ballot(r2[0] || r2[1]);
-                if (rm != 0 && any_true == 0) {
+            if (kSub && tbl_in_lds && n_walk >= uint32_t(kWave)) {
+                // at least a wave of candidates: sequential chains, every lane works through its own share of the list
+                if (!table_cleared) {  // the result table is cleared lazily (LIKE): do it before the first match is set
                     for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)
                         reinterpret_cast<uint4*>(wbase)[i] = make_uint4(0, 0, 0, 0);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    table_cleared = true;
                 }
-                any_true |= rm;
-                if (r2[0]) { if (kBytes) dresb[id0] = 1; else atomicOr(&dres[id0 >> 5], 1u << (id0 & 31)); }
-                if (r2[1]) { if (kBytes) dresb[id1] = 1; else atomicOr(&dres[id1 >> 5], 1u << (id1 & 31)); }
-                jb += kWave;  // this round took two waves of candidates
-                continue;
+                uint32_t walked = 0;
+                any_true |= like_walk_many<kBytes, 2>(d, cand, n_walk, row0, hitrow, dresb, dres, lane, &walked);
+                if (L.d_cand_bytes && !prune) cand_bytes += walked;
+                if (L.d_own_bytes) own_bytes += walked + 2u * d.offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
+                break;
             }
             const uint32_t j = jb + uint32_t(lane);
             const bool cl = j < n_walk;
@@ -1531,12 +1565,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             if (L.d_own_bytes && cl) own_bytes += (stop - start) + 2u * d.offset_bytes;
             LC_TM(3, start);
             bool res = false;
-            if (kSub && tbl_in_lds && n_walk - jb >= uint32_t(kWave)) {
-                // a full wave of candidates: one value per lane
-                const uint32_t st1[1] = {start}, sp1[1] = {stop};
-                bool r1[1];
-                like_walk_seq<1>(d.fsst, st1, sp1, row0, hitrow, r1);
-                res = r1[0];
+            if (false) {
             } else if (kSub && tbl_in_lds) {
                 // lane-parallel walk: one lane per 8-byte word of every candidate (see above)
                 const uint32_t words = cl ? max(1u, (stop - start + 7u) >> 3) : 0u;
@@ -1605,10 +1634,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                             : (op == LC_OP_LT ? o < 0 : op == LC_OP_LE ? o <= 0 : op == LC_OP_GT ? o > 0 : o >= 0);
             }
             const uint64_t res_mask = __ballot(res);
-            if (kSub && res_mask != 0 && any_true == 0) {
+            if (kSub && res_mask != 0 && !table_cleared) {
                 for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)
                     reinterpret_cast<uint4*>(wbase)[i] = make_uint4(0, 0, 0, 0);
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                table_cleared = true;
             }
             any_true |= res_mask;
             if (res) {
