@@ -1154,34 +1154,63 @@ __device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], u
 }
 
 // Sequential walker over the same LDS image for entries with at least a wave of candidates (no signature index, or no
-// fingerprints at all: every dictionary value is walked).  Every lane owns NC independent chains; chain c of lane l walks
-// candidates l + 64 c, l + 64 c + 64 NC, ... ONE AFTER THE OTHER without waiting for its neighbours, so the wave stays
-// busy until the list runs out (values differ 10x in length: walking 64 of them in lock step would idle most lanes most
-// of the time) and the offsets of a chain's next value are fetched while the current one is walked.  Per compressed
-// byte: extract, address, one ds_read_u16, and the guard that keeps bytes past the end of a value from moving the state.
-// Returns the ballot of lanes that found a matching value; matches are written to the dictionary result table.
-template <bool kBytes, int NC>
-__device__ __forceinline__ uint64_t like_walk_many(const StrDesc& d, const uint16_t* cand, uint32_t n_walk, uint32_t row0,
-                                                   uint32_t hitrow, uint8_t* dresb, uint32_t* dres, int lane,
-                                                   uint32_t* walked_bytes) {
+// fingerprints at all: every dictionary value is walked).  Every lane owns two independent chains; chain c of lane l walks
+// candidates l + 64 c, l + 64 c + 128, ... ONE AFTER THE OTHER without waiting for its neighbours, so the wave stays
+// busy until the list runs out (values differ 10x in length: walking 64 of them in lock step idles most lanes most of
+// the time).  A chain fetches 32 compressed bytes at a time (one memory round trip per 32 table lookups) and the offsets
+// of its next value while it walks the current one.  Per compressed byte: extract, address, one ds_read_u16, and the
+// guard that keeps bytes past the end of a value from moving the state.
+// Only instantiated in the kMany variants of k_str_pred (scans whose entries carry no signature index): its ~60 registers
+// must not add to the pressure of the few-candidate path of the headline kernel.
+struct WalkManyArgs {
+    const uint8_t* fsst;
+    const uint8_t* residuals;
+    uint32_t slope, intercept, offset_bytes;
+    uint32_t cand_lds;   // LDS address of the u16 candidate list
+    uint32_t n_walk;
+    uint32_t row0, hitrow;
+    uint32_t dres_lds;   // LDS address of the dictionary result table
+    uint32_t bytes_mode; // table is bytes (1) or a bitmap (0)
+};
+struct WalkManyResult {
+    uint32_t found;   // this lane set at least one dictionary entry
+    uint32_t bytes;   // compressed bytes this lane walked
+};
+
+__device__ __forceinline__ void walk_offsets(const WalkManyArgs& a, uint32_t i, uint32_t& start, uint32_t& stop) {
+    const uint32_t ob = a.offset_bytes;
+    const uint64_t v = load_unaligned<uint64_t>(a.residuals + size_t(i) * ob);
+    const uint32_t sh = 32u - 8u * ob;
+    const int32_t r0 = int32_t(uint32_t(v) << sh) >> sh;
+    const int32_t r1 = int32_t(uint32_t(v >> (8u * ob)) << sh) >> sh;
+    start = a.slope * i + a.intercept + uint32_t(r0);
+    stop = a.slope * (i + 1u) + a.intercept + uint32_t(r1);
+}
+
+__device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) {
+    constexpr int NC = 2, CH = 4;  // chains per lane, 8-byte words per fetch
     constexpr uint32_t kStride = uint32_t(kWave) * NC;
+    const int lane = lane_id();
+    typedef const __attribute__((address_space(3))) uint16_t* LdsList;
+    typedef __attribute__((address_space(3))) uint8_t* LdsBytes;
+    typedef __attribute__((address_space(3))) uint32_t* LdsWords;
+    const LdsList cand = reinterpret_cast<LdsList>(a.cand_lds);
     uint32_t j[NC], id[NC], pos[NC], stop[NC], sb[NC], nid[NC], nstart[NC], nstop[NC];
     bool active[NC];
-    bool found = false;
-    uint32_t bytes = 0;
+    WalkManyResult out{0, 0};
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         j[c] = uint32_t(lane) + uint32_t(kWave) * c;
-        active[c] = j[c] < n_walk;
+        active[c] = j[c] < a.n_walk;
         id[c] = pos[c] = stop[c] = nid[c] = nstart[c] = nstop[c] = 0;
-        sb[c] = row0;
+        sb[c] = a.row0;
         if (active[c]) {
             id[c] = cand[j[c]];
-            str_offset_pair(d, id[c], pos[c], stop[c]);
-            bytes += stop[c] - pos[c];
-            if (j[c] + kStride < n_walk) {
+            walk_offsets(a, id[c], pos[c], stop[c]);
+            out.bytes += stop[c] - pos[c];
+            if (j[c] + kStride < a.n_walk) {
                 nid[c] = cand[j[c] + kStride];
-                str_offset_pair(d, nid[c], nstart[c], nstop[c]);
+                walk_offsets(a, nid[c], nstart[c], nstop[c]);
             }
         }
     }
@@ -1189,47 +1218,54 @@ __device__ __forceinline__ uint64_t like_walk_many(const StrDesc& d, const uint1
         bool any_active = false;
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            if (active[c] && pos[c] >= stop[c]) {  // this chain's value is finished: record it, move to the chain's next one
-                if (sb[c] == hitrow) {
-                    found = true;
-                    if (kBytes) dresb[id[c]] = 1;
-                    else atomicOr(&dres[id[c] >> 5], 1u << (id[c] & 31));
+            // a finished value is recorded and the chain moves on (empty values finish at once: hence `while`)
+            while (active[c] && pos[c] >= stop[c]) {
+                if (sb[c] == a.hitrow) {
+                    out.found = 1;
+                    if (a.bytes_mode) reinterpret_cast<LdsBytes>(a.dres_lds)[id[c]] = 1;
+                    else atomicOr((uint32_t*)(reinterpret_cast<LdsWords>(a.dres_lds) + (id[c] >> 5)), 1u << (id[c] & 31));
                 }
                 j[c] += kStride;
-                active[c] = j[c] < n_walk;
+                active[c] = j[c] < a.n_walk;
                 if (active[c]) {
-                    id[c] = nid[c]; pos[c] = nstart[c]; stop[c] = nstop[c]; sb[c] = row0;
-                    bytes += stop[c] - pos[c];
-                    if (j[c] + kStride < n_walk) {
+                    id[c] = nid[c]; pos[c] = nstart[c]; stop[c] = nstop[c]; sb[c] = a.row0;
+                    out.bytes += stop[c] - pos[c];
+                    if (j[c] + kStride < a.n_walk) {
                         nid[c] = cand[j[c] + kStride];
-                        str_offset_pair(d, nid[c], nstart[c], nstop[c]);
+                        walk_offsets(a, nid[c], nstart[c], nstop[c]);
                     }
                 }
             }
             any_active |= active[c];
         }
         if (__ballot(any_active) == 0) break;
-        uint64_t w[NC];
+        uint64_t w[NC][CH];
         uint32_t rem[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
-            rem[c] = (active[c] && pos[c] < stop[c]) ? stop[c] - pos[c] : 0u;
-            w[c] = 0;
-            if (rem[c]) w[c] = load_unaligned<uint64_t>(d.fsst + pos[c]);
-            pos[c] += rem[c] ? 8u : 0u;
+            rem[c] = active[c] ? stop[c] - pos[c] : 0u;  // > 0 for an active chain here
+#pragma unroll
+            for (int k = 0; k < CH; k++) {
+                w[c][k] = 0;
+                if (rem[c] > 8u * uint32_t(k)) w[c][k] = load_unaligned<uint64_t>(a.fsst + pos[c] + 8u * uint32_t(k));
+            }
+            pos[c] += min(rem[c], 8u * uint32_t(CH));
         }
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) {
+        for (int k = 0; k < CH; k++) {
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const uint32_t code = (q < 4 ? uint32_t(w[c]) >> (8 * q) : uint32_t(w[c] >> 32) >> (8 * (q - 4))) & 0xFFu;
-                const uint32_t t = lds_u16(sb[c] + 2u * code);
-                sb[c] = q < rem[c] ? t : sb[c];
+            for (uint32_t q = 0; q < 8; q++) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) {
+                    const uint64_t ww = w[c][k];
+                    const uint32_t code = (q < 4 ? uint32_t(ww) >> (8 * q) : uint32_t(ww >> 32) >> (8 * (q - 4))) & 0xFFu;
+                    const uint32_t t = lds_u16(sb[c] + 2u * code);
+                    sb[c] = (8u * uint32_t(k) + q) < rem[c] ? t : sb[c];
+                }
             }
         }
     }
-    *walked_bytes = bytes;
-    return __ballot(found);
+    return out;
 }
 
 // Byte-view predicate: ONE WAVE per entry (batch), four entries per workgroup, no workgroup barriers after setup.
@@ -1241,7 +1277,7 @@ __device__ __forceinline__ uint64_t like_walk_many(const StrDesc& d, const uint1
 //            byte (or bitmap) lookup per row, result bits transposed through LDS into whole mask words
 // kBytes: dictionary results are one LDS byte per entry (dictionaries up to kMaxByteTable), else a bitmap.
 // kSub:   LIKE / NOT LIKE '%needle%';  else Eq / Ne / ordering / constant.
-template <bool kBytes, bool kSub>
+template <bool kBytes, bool kSub, bool kMany>
 __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
                                                            const DevSymtab* __restrict__ symtabs, StrPred pred,
                                                            ScanLaunch L, uint32_t dres_bytes, uint32_t cmask_bytes) {
@@ -1542,7 +1578,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         LC_TM(2, 0);
         const uint32_t n_walk = LC_ABL(pred.debug_flags & 1) ? 0u : n_cand;
         for (uint32_t jb = 0; jb < n_walk; jb += kWave) {
-            if (kSub && tbl_in_lds && n_walk >= uint32_t(kWave)) {
+            if (kMany && kSub && tbl_in_lds && n_walk >= uint32_t(kWave)) {
                 // at least a wave of candidates: sequential chains, every lane works through its own share of the list
                 if (!table_cleared) {  // the result table is cleared lazily (LIKE): do it before the first match is set
                     for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)
@@ -1550,10 +1586,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     table_cleared = true;
                 }
-                uint32_t walked = 0;
-                any_true |= like_walk_many<kBytes, 2>(d, cand, n_walk, row0, hitrow, dresb, dres, lane, &walked);
-                if (L.d_cand_bytes && !prune) cand_bytes += walked;
-                if (L.d_own_bytes) own_bytes += walked + 2u * d.offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
+                WalkManyArgs wa;
+                wa.fsst = d.fsst;
+                wa.residuals = d.residuals;
+                wa.slope = uint32_t(d.slope);
+                wa.intercept = uint32_t(d.intercept);
+                wa.offset_bytes = d.offset_bytes;
+                wa.cand_lds = uint32_t(reinterpret_cast<uintptr_t>(cand));
+                wa.n_walk = n_walk;
+                wa.row0 = row0;
+                wa.hitrow = hitrow;
+                wa.dres_lds = dres_addr;
+                wa.bytes_mode = kBytes ? 1u : 0u;
+                const WalkManyResult wr = like_walk_many(wa);
+                any_true |= __ballot(wr.found != 0);
+                if (L.d_cand_bytes && !prune) cand_bytes += wr.bytes;
+                if (L.d_own_bytes) own_bytes += wr.bytes + 2u * d.offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
                 break;
             }
             const uint32_t j = jb + uint32_t(lane);
@@ -2516,9 +2564,11 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
                            (env_pad ? size_t(std::atoi(env_pad)) : 0);
     // persistent launch: as many workgroups as fit on the device at once; the waves draw entries dynamically
     const uint32_t wgs_needed = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
+    // kMany: LIKE over entries without the signature index (hundreds to thousands of candidates per entry)
+    const bool many = sub && L.many_candidates;
     void (*kern)(const StrDesc*, const DevSymtab*, StrPred, ScanLaunch, uint32_t, uint32_t) =
-        bytes ? (sub ? k_str_pred<true, true> : k_str_pred<true, false>)
-              : (sub ? k_str_pred<false, true> : k_str_pred<false, false>);
+        bytes ? (sub ? (many ? k_str_pred<true, true, true> : k_str_pred<true, true, false>) : k_str_pred<true, false, false>)
+              : (sub ? (many ? k_str_pred<false, true, true> : k_str_pred<false, true, false>) : k_str_pred<false, false, false>);
     if (dyn_lds > 64 * 1024) {
         // large dictionaries: gfx950 has 160 KB of LDS per CU, a workgroup may use more than the default 64 KB
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

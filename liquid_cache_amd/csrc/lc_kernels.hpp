@@ -140,6 +140,7 @@ struct ScanLaunch {
     uint32_t work_groups;    // byte views: number of counter groups used by this launch (set by the launcher)
     uint32_t n_wg_ranges;    // byte views: entries of d_wg_ranges (0: entries are split evenly over the groups)
     const uint32_t* d_wg_ranges;  // byte views: {begin, end} entry range per workgroup; a range never mixes symbol tables
+    uint32_t many_candidates;     // byte views: some entry has no bigram signature index (LIKE walks whole dictionaries)
     // Fused COUNT(*) of the launch (optional): every wave adds the hits of its entries to a sharded accumulator and the
     // wave that arrives last writes the total to *d_total_out — no separate reduction kernel, no memset between launches.
     unsigned long long* d_total_acc;  // kTotalWords u64 owned by the scan, zero between launches (self-resetting)

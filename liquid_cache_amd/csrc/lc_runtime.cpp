@@ -1010,6 +1010,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     L.d_work = s->d_work;
     for (const Entry& e : s->meta) L.max_dict_len = std::max(L.max_dict_len, e.dict_len);
     if (s->is_str && !s->meta.empty()) {
+        for (const Entry& e : s->meta) L.many_candidates |= e.sd.signatures == nullptr ? 1u : 0u;
         L.uniform_slot = int32_t(s->meta[0].sd.symtab_slot);
         for (const Entry& e : s->meta)
             if (e.sd.symtab_slot != s->meta[0].sd.symtab_slot) L.uniform_slot = -1;
