@@ -67,6 +67,7 @@ def parse_args(argv=None):
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
     p.add_argument("--no-secondary", action="store_true", help="skip every secondary workload (profiling runs)")
     p.add_argument("--secondary-rows", type=int, default=0, help="rows of the secondary workloads (0 = --rows)")
+    p.add_argument("--sweep-rows", type=int, default=33_554_432, help="rows of the ClickBench pushdown sweep (config 5)")
     p.add_argument("--seed", type=int, default=42)
     return p.parse_args(argv)
 
@@ -493,6 +494,50 @@ def secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream
     return out
 
 
+def secondary_clickbench_sweep(cache, lc, args, rows, threads, torch, stream, iters):
+    """BASELINE.json config 5: the pushed-down predicates of all 43 ClickBench queries (24 have a WHERE clause) over a
+    synthetic hits-shaped table, each run as the reference's row filter would (conjunct order of row_filter.rs:499-515,
+    every mask the selection of the next conjunct, adjacent ranges on one column fused, IN list as a Kleene OR) — device
+    resident, no host round trip inside a query.  Per query: milliseconds per evaluation and surviving rows."""
+    from liquid_cache_amd import clickbench as cb
+    from liquid_cache_amd.pushdown import LiquidRowFilter, PushdownExecutor
+    t0 = time.perf_counter()
+    columns, ids, _ = cb.stage_hits(cache, rows, seed=args.seed, batch_size=args.batch_size,
+                                    row_group_batches=args.row_group_batches, threads=threads)
+    t_stage = time.perf_counter() - t0
+    ex = PushdownExecutor(columns)
+    any_scan = next(iter(columns.values())).scan
+    words = int(any_scan.mask_words)
+    masks = [torch.zeros(max(words, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
+    counts = torch.zeros(max(any_scan.entries, 1), dtype=torch.int32, device="cuda")
+    out = {"rows": int(rows), "columns": len(columns), "stage_seconds": round(t_stage, 1), "queries": {}}
+    total_ms = 0.0
+    for q in range(cb.N_QUERIES):
+        conj = cb.QUERIES.get(q)
+        if not conj:
+            continue
+        rf = LiquidRowFilter(conj)
+        ptrs = [masks[0].data_ptr(), masks[1].data_ptr()]
+        for _ in range(2):
+            ex.evaluate(rf, ptrs, counts.data_ptr(), 0, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            ex.evaluate(rf, ptrs, counts.data_ptr(), 0, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        total_ms += ms
+        out["queries"]["q%d" % q] = {"passes": len(ex.plan(rf)), "conjuncts": sum(len(s.exprs) for s in ex.plan(rf)),
+                                     "ms": ms, "rows_per_s": rows / (ms * 1e-3),
+                                     "rows_out": int(counts.sum(dtype=torch.int64).item())}
+    out["total_ms_all_queries"] = total_ms
+    for c in columns.values():
+        c.scan.close()
+    cache.evict([e for v in ids.values() for e in v])
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------- CPU baseline
 def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
     """Oracle (CPU restatement of the reference algorithm) on the first n_sample batches, single thread."""
@@ -735,6 +780,12 @@ def main():
             sec["tpch_q6_pushdown"] = secondary_tpch_q6(cache, lc, N, args, sec_rows, threads, torch, stream, iters)
         except Exception as e:  # noqa: BLE001
             sec["tpch_q6_pushdown"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            sweep_rows = min(sec_rows, args.sweep_rows)
+            sec["clickbench_pushdown_sweep"] = secondary_clickbench_sweep(cache, lc, args, sweep_rows, threads, torch, stream,
+                                                                          max(3, iters // 2))
+        except Exception as e:  # noqa: BLE001
+            sec["clickbench_pushdown_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.workload == "url_like" and not args.no_fingerprints:
             sec.update(secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream, iters, pattern))
         out["secondary"] = sec

@@ -198,6 +198,16 @@ LC_API lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t
                                          uint8_t* const* out_values, uint8_t* const* out_validity,
                                          uint32_t* out_lens, int32_t* out_nullable, lc_status* statuses);
 
+/* A predicate that is an OR over two or more COLUMNS of one batch (`a = 1 OR b LIKE '%x%'`): what
+ * CachedRowGroup::evaluate_selection_with_predicate does for such predicates (src/datafusion/src/cache/mod.rs:111-150,
+ * extract_multi_column_or): every (entry, predicate) pair is evaluated on the encoded data over the SAME selection and
+ * the BooleanArrays are combined with arrow's or_kleene (true if any side is true; else null if any side is null; else
+ * false).  entry_ids[i] is column i's entry of the batch.  Outputs as lc_eval_predicate; LC_NOT_STAGED if any entry is
+ * absent (the reference returns None and materialises instead). */
+LC_API lc_status lc_eval_predicate_or(lc_ctx* ctx, uint32_t n, const uint64_t* entry_ids, const lc_predicate* preds,
+                                      const uint8_t* selection, uint8_t* out_values, uint8_t* out_validity,
+                                      uint32_t* out_len, int32_t* out_nullable);
+
 /* cache.get(&entry_id).with_selection(&sel).read()  (builders.rs:236-266): rows whose selection bit is set, in
  * order, in the entry's original Arrow type, exported through the Arrow C Data Interface (caller releases).
  * selection NULL == no selection (to_arrow_array). */
@@ -269,6 +279,16 @@ LC_API lc_status lc_scan_eval(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
  * (the caller chains two lc_scan_eval calls). */
 LC_API lc_status lc_scan_eval_and(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
                                   const void* d_selection, void* d_mask_out, void* d_counts_out, void* stream);
+
+/* Multi-column OR over whole scans (the device-resident form of lc_eval_predicate_or): scans[i] / preds[i] are the
+ * columns of the OR, all covering the same row ranges (same entry lengths, hence the same mask layout); every pair is
+ * evaluated over d_selection and combined with Kleene OR.  d_mask_out: hit = (any side true) AND selected;
+ * d_valid_out (optional): the validity of the Kleene result restricted to the selection; d_counts_out (optional): hits
+ * per entry.  The same scan may appear several times (`col IN (a, b)` == `col = a OR col = b`).  Calls that share
+ * scans[0] must be serialised by the caller (its scratch holds the intermediate masks). */
+LC_API lc_status lc_scan_eval_or(lc_ctx* ctx, uint32_t n, lc_scan* const* scans, const lc_predicate* preds,
+                                 const void* d_selection, void* d_mask_out, void* d_valid_out, void* d_counts_out,
+                                 void* stream);
 
 /* lc_scan_eval_and plus the COUNT(*) of the launch: *d_total_out (one u64, device) receives the number of hits of the
  * whole scan, produced by the predicate kernel itself (no reduction pass, no memset between launches) — what a

@@ -32,6 +32,11 @@ LC_BENCH_API size_t lc_synth_url_batch(uint64_t seed, uint64_t batch_index, uint
 LC_BENCH_API size_t lc_synth_phrase_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, uint32_t n_unique,
                                           uint32_t empty_permille, int32_t* offsets, uint8_t* data, size_t data_cap);
 
+/* Fill one batch of a ClickBench-"Title"-shaped column: 3-9 capitalised words plus " - <host>", Zipf repetition over
+ * `n_unique` distinct titles; needle_ppm parts-per-million of the DISTINCT titles contain the token "Google". */
+LC_BENCH_API size_t lc_synth_title_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, uint32_t n_unique,
+                                         uint32_t needle_ppm, int32_t* offsets, uint8_t* data, size_t data_cap);
+
 /* Fill `rows` 64-bit integers uniform in [base, base + 2^bit_width) (bit_width 1..64).
  * Deterministic in (seed, batch_index). */
 LC_BENCH_API void lc_synth_int64_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, int32_t bit_width,

@@ -63,11 +63,11 @@ EXPORTED_SYMBOLS = [
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
-    "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold",
+    "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold", "lc_scan_eval_or", "lc_eval_predicate_or",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
     # include/liquid_cache_amd_bench.h
-    "lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch",
+    "lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
 ]
 
 _lib = None
@@ -122,6 +122,9 @@ def load():
     L.lc_scan_segment_offsets.restype = P(u64); L.lc_scan_segment_offsets.argtypes = [vp]
     L.lc_scan_eval.restype = i32; L.lc_scan_eval.argtypes = [vp, vp, P(Predicate), vp, vp, vp, vp]
     L.lc_scan_eval_and.restype = i32; L.lc_scan_eval_and.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, vp, vp]
+    L.lc_scan_eval_or.restype = i32; L.lc_scan_eval_or.argtypes = [vp, C.c_uint32, P(vp), P(Predicate), vp, vp, vp, vp, vp]
+    L.lc_eval_predicate_or.restype = i32
+    L.lc_eval_predicate_or.argtypes = [vp, C.c_uint32, P(u64), P(Predicate), vp, vp, vp, P(C.c_uint32), P(C.c_int32)]
     L.lc_scan_eval_count.restype = i32
     L.lc_scan_eval_count.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, vp, vp, vp]
     L.lc_scan_eval_timed_cold.restype = i32
@@ -137,6 +140,8 @@ def load():
     L.lc_stream_synchronize.restype = i32; L.lc_stream_synchronize.argtypes = [vp, vp]
     L.lc_synth_url_batch.restype = sz
     L.lc_synth_url_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
+    L.lc_synth_title_batch.restype = sz
+    L.lc_synth_title_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
     L.lc_synth_phrase_batch.restype = sz
     L.lc_synth_phrase_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
     L.lc_synth_int64_batch.restype = None

@@ -417,6 +417,34 @@ class LiquidCache:
             return pa.array(v, type=pa.bool_(), mask=~valid)
         return pa.array(v, type=pa.bool_())
 
+    def eval_predicate_or(self, entry_ids: Sequence[int], exprs: Sequence[LiquidExpr], selection=None
+                          ) -> Optional[pa.BooleanArray]:
+        """A predicate that is an OR over the columns of one batch: entry_ids[i] / exprs[i] are its column-literal
+        disjuncts (CachedRowGroup::evaluate_selection_with_predicate, cache/mod.rs:111-150).  Kleene OR of the per-column
+        results over the same selection; None when an entry is not cached."""
+        infos = [self.entry_info(e) for e in entry_ids]
+        if any(i is None for i in infos):
+            return None
+        n = infos[0].len
+        sel = _selection_bytes(selection, n) if selection is not None else None
+        nb = (n + 7) // 8 + 8
+        values, validity = np.zeros(nb, np.uint8), np.zeros(nb, np.uint8)
+        out_len, nullable = C.c_uint32(), C.c_int32()
+        ids = (C.c_uint64 * len(entry_ids))(*[int(e) for e in entry_ids])
+        preds = (N.Predicate * len(exprs))(*[e.as_predicate() for e in exprs])
+        st = self._lib.lc_eval_predicate_or(self._ctx, len(entry_ids), ids, preds,
+                                            sel.ctypes.data_as(C.c_void_p) if sel is not None else None,
+                                            values.ctypes.data_as(C.c_void_p), validity.ctypes.data_as(C.c_void_p),
+                                            C.byref(out_len), C.byref(nullable))
+        if st == N.LC_NOT_STAGED:
+            return None
+        N.check(st, self._ctx)
+        k = out_len.value
+        v = _bits_to_bool(values, k)
+        if nullable.value:
+            return pa.array(v, type=pa.bool_(), mask=~_bits_to_bool(validity, k))
+        return pa.array(v, type=pa.bool_())
+
     def _read_arrow_array(self, entry_id: int, selection, date_field: Optional[int] = None) -> Optional[pa.Array]:
         info = self.entry_info(entry_id)
         if info is None:
@@ -524,6 +552,18 @@ class Scan:
                                              C.c_void_p(selection_ptr or None), C.c_void_p(mask_out_ptr),
                                              C.c_void_p(counts_ptr or None), C.c_void_p(total_out_ptr),
                                              C.c_void_p(stream or None)), self._cache.handle)
+
+    @staticmethod
+    def eval_or(scans: Sequence["Scan"], exprs: Sequence[LiquidExpr], mask_out_ptr: int, selection_ptr: int = 0,
+                counts_ptr: int = 0, valid_out_ptr: int = 0, stream: int = 0):
+        """Multi-column OR over whole scans (lc_scan_eval_or): scans[i] / exprs[i] are the disjuncts, all over the same
+        row ranges; the same scan may appear twice (`col IN (a, b)`)."""
+        cache = scans[0]._cache
+        hs = (C.c_void_p * len(scans))(*[s._h for s in scans])
+        preds = (N.Predicate * len(exprs))(*[e.as_predicate() for e in exprs])
+        N.check(cache._lib.lc_scan_eval_or(cache.handle, len(scans), hs, preds, C.c_void_p(selection_ptr or None),
+                                           C.c_void_p(mask_out_ptr), C.c_void_p(valid_out_ptr or None),
+                                           C.c_void_p(counts_ptr or None), C.c_void_p(stream or None)), cache.handle)
 
     def eval_timed_cold(self, expr: LiquidExpr, mask_out_ptr: int, iters: int, flush_bytes: int = 1 << 30,
                         selection_ptr: int = 0, counts_ptr: int = 0, stream: int = 0) -> float:

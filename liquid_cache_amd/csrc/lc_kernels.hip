@@ -2455,6 +2455,19 @@ __global__ __launch_bounds__(kThreads) void k_str_decode_sel(const StrDesc* __re
     }
 }
 
+// Kleene OR of two predicate results in scan-mask form (hit = value AND valid AND selected, valid = valid AND selected),
+// what arrow's or_kleene gives on the two BooleanArrays (cache/mod.rs:111-150): true if either side is true, null if
+// neither is true and one is null, false if both are false.  In place on (hit, valid).
+__global__ __launch_bounds__(256) void k_mask_or_kleene(uint64_t* __restrict__ hit, uint64_t* __restrict__ valid,
+                                                         const uint64_t* __restrict__ hit_b,
+                                                         const uint64_t* __restrict__ valid_b, uint64_t n_words) {
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n_words; i += uint64_t(gridDim.x) * 256) {
+        const uint64_t h = hit[i] | hit_b[i];
+        hit[i] = h;
+        if (valid) valid[i] = (valid[i] & valid_b[i]) | h;
+    }
+}
+
 // Reads `n16` 16-byte words and keeps one word per workgroup: replaces whatever the memory-side cache held by CLEAN lines
 // of a scratch buffer (a memset would leave 256 MiB of dirty lines whose write-back the next kernel pays for).
 __global__ __launch_bounds__(256) void k_flush_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
@@ -2469,6 +2482,32 @@ __global__ __launch_bounds__(256) void k_flush_read(const uint4* __restrict__ sr
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
+static int device_cus();
+
+hipError_t launch_mask_or_kleene(uint64_t* d_hit, uint64_t* d_valid, const uint64_t* d_hit_b, const uint64_t* d_valid_b,
+                                 uint64_t n_words, hipStream_t stream) {
+    if (n_words == 0) return hipSuccess;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((n_words + 255) / 256, uint64_t(device_cus()) * 8));
+    hipLaunchKernelGGL(k_mask_or_kleene, dim3(grid), dim3(256), 0, stream, d_hit, d_valid, d_hit_b, d_valid_b, n_words);
+    return hipGetLastError();
+}
+
+// per-entry popcounts of a mask in scan layout (+ optional fused total through the scan's accumulator is not needed here:
+// the counts are reduced by the caller)
+hipError_t launch_mask_entry_counts(const void* d_descs, bool is_str, const ScanLaunch& L, uint32_t* d_entry_counts,
+                                    hipStream_t stream) {
+    if (L.n_entries == 0) return hipSuccess;
+    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8)));
+    if (is_str)
+        hipLaunchKernelGGL(k_sel_entry_counts<StrDesc>, grid, dim3(kThreads), 0, stream, static_cast<const StrDesc*>(d_descs), L,
+                           d_entry_counts);
+    else
+        hipLaunchKernelGGL(k_sel_entry_counts<FixedDesc>, grid, dim3(kThreads), 0, stream,
+                           static_cast<const FixedDesc*>(d_descs), L, d_entry_counts);
+    return hipGetLastError();
+}
+
 hipError_t launch_flush_read(const void* d_buf, uint64_t bytes, uint32_t* d_sink, hipStream_t stream) {
     hipLaunchKernelGGL(k_flush_read, dim3(2048), dim3(256), 0, stream, static_cast<const uint4*>(d_buf), bytes / 16, d_sink);
     return hipGetLastError();

@@ -180,6 +180,12 @@ hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const Sc
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
                                uint64_t capacity_rows, hipStream_t stream);
 // bit compress (PEXT) / deposit (PDEP) per entry segment
+// (hit, valid) <- Kleene OR with (hit_b, valid_b); d_valid may be null (hit only)
+hipError_t launch_mask_or_kleene(uint64_t* d_hit, uint64_t* d_valid, const uint64_t* d_hit_b, const uint64_t* d_valid_b,
+                                 uint64_t n_words, hipStream_t stream);
+// per-entry popcounts of the mask passed as L.d_selection
+hipError_t launch_mask_entry_counts(const void* d_descs, bool is_str, const ScanLaunch& L, uint32_t* d_entry_counts,
+                                    hipStream_t stream);
 // cache flush for cold timings: streams `bytes` of d_buf through the memory-side cache (d_sink: >= 2048 u32)
 hipError_t launch_flush_read(const void* d_buf, uint64_t bytes, uint32_t* d_sink, hipStream_t stream);
 hipError_t launch_mask_compress(const uint64_t* d_src, const uint64_t* d_sel, const uint64_t* d_seg_offsets,

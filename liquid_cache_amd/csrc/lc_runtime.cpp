@@ -140,6 +140,8 @@ struct lc_scan {
     // generation is never freed while the context lives, so launches need no lock against concurrent staging
     const DevSymtab* d_symtabs = nullptr;
     size_t n_symtabs = 0;
+    uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
+    size_t or_tmp_words = 0;
     unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
     bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
     std::mutex mu;
@@ -962,6 +964,7 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_gather);
     pool_release(s->ctx, s->d_wg_ranges);
     pool_release(s->ctx, s->d_total_acc);
+    pool_release(s->ctx, s->d_or_tmp);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
     if (s->pinned) {
@@ -1133,6 +1136,59 @@ lc_status lc_scan_eval_count(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pre
     if (!d_total_out) return fail(LC_ERR_INVALID, "d_total_out is null");
     return scan_eval_impl(ctx, scan, &preds[0], d_selection, d_mask_out, nullptr, d_counts_out, nullptr,
                           static_cast<hipStream_t>(stream), n_preds == 2 ? &preds[1] : nullptr, d_total_out);
+}
+
+// Multi-column OR (CachedRowGroup::evaluate_selection_with_predicate, src/datafusion/src/cache/mod.rs:111-150): every
+// (column scan, predicate) pair is evaluated over the SAME selection and the results are combined with Kleene OR.
+static lc_status scan_eval_or_impl(lc_ctx* ctx, uint32_t n, lc_scan* const* scans, const lc_predicate* preds,
+                                   const void* d_selection, void* d_mask_out, void* d_valid_out, void* d_counts_out,
+                                   hipStream_t stream) {
+    if (!ctx || !scans || !preds || !d_mask_out || n == 0) return fail(LC_ERR_INVALID, "null argument");
+    lc_scan* s0 = scans[0];
+    if (!s0) return fail(LC_ERR_INVALID, "null scan");
+    for (uint32_t i = 1; i < n; i++) {
+        if (!scans[i] || scans[i]->ctx != s0->ctx || scans[i]->seg_offsets != s0->seg_offsets)
+            return fail(LC_ERR_INVALID, "the scans of a multi-column OR must cover the same row ranges (same entry lengths)");
+    }
+    const uint64_t words = s0->seg_offsets.back();
+    if (s0->n == 0) return LC_OK;
+    uint64_t* tmp = nullptr;
+    {
+        std::lock_guard<std::mutex> g(s0->mu);
+        if (s0->or_tmp_words < 3 * words) {
+            LC_HIP(hipStreamSynchronize(stream));  // earlier launches may still use the smaller scratch
+            pool_release(ctx, s0->d_or_tmp);
+            s0->d_or_tmp = static_cast<uint64_t*>(pool_alloc(ctx, std::max<uint64_t>(3 * words, 1) * 8));
+            s0->or_tmp_words = s0->d_or_tmp ? 3 * words : 0;
+            if (!s0->d_or_tmp) return fail(LC_ERR_OOM, "hipMalloc (OR scratch)");
+        }
+        tmp = s0->d_or_tmp;
+    }
+    uint64_t* hit = static_cast<uint64_t*>(d_mask_out);
+    uint64_t* valid = d_valid_out ? static_cast<uint64_t*>(d_valid_out) : tmp + 2 * words;
+    lc_status rc = scan_eval_impl(ctx, s0, &preds[0], d_selection, hit, valid, nullptr, nullptr, stream);
+    for (uint32_t i = 1; i < n && rc == LC_OK; i++) {
+        rc = scan_eval_impl(ctx, scans[i], &preds[i], d_selection, tmp, tmp + words, nullptr, nullptr, stream);
+        if (rc == LC_OK && launch_mask_or_kleene(hit, valid, tmp, tmp + words, words, stream) != hipSuccess)
+            rc = fail(LC_ERR_DEVICE, "k_mask_or_kleene launch failed");
+    }
+    if (rc == LC_OK && d_counts_out) {
+        ScanLaunch L{};
+        L.n_entries = s0->n;
+        L.blocks_per_entry = s0->bpe;
+        L.d_selection = hit;
+        if (launch_mask_entry_counts(s0->d_descs, s0->is_str, L, static_cast<uint32_t*>(d_counts_out), stream) != hipSuccess)
+            rc = fail(LC_ERR_DEVICE, "entry count launch failed");
+    }
+    return rc;
+}
+
+lc_status lc_scan_eval_or(lc_ctx* ctx, uint32_t n, lc_scan* const* scans, const lc_predicate* preds, const void* d_selection,
+                          void* d_mask_out, void* d_valid_out, void* d_counts_out, void* stream) {
+    return guarded([&]() -> lc_status {
+        return scan_eval_or_impl(ctx, n, scans, preds, d_selection, d_mask_out, d_valid_out, d_counts_out,
+                                 static_cast<hipStream_t>(stream));
+    });
 }
 
 // Kernel time of ONE evaluation with the memory-side cache flushed before every launch: `flush_bytes` of scratch are
@@ -1452,6 +1508,62 @@ lc_status lc_eval_predicate(lc_ctx* ctx, uint64_t entry_id, const lc_predicate* 
     const lc_status rc = lc_eval_predicate_batch(ctx, 1, &entry_id, pred, sels, ov, ovalid, out_len, &nullable, &st);
     if (out_nullable) *out_nullable = nullable;
     return rc != LC_OK ? rc : st;
+    });
+}
+
+lc_status lc_eval_predicate_or(lc_ctx* ctx, uint32_t n, const uint64_t* entry_ids, const lc_predicate* preds,
+                               const uint8_t* selection, uint8_t* out_values, uint8_t* out_validity, uint32_t* out_len,
+                               int32_t* out_nullable) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !entry_ids || !preds || !out_values || !out_validity || !out_len || n == 0)
+        return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    std::vector<lc_scan*> scans(n, nullptr);
+    struct Guard {
+        std::vector<lc_scan*>& v;
+        ~Guard() { for (lc_scan* s : v) lc_scan_destroy(s); }
+    } guard{scans};
+    for (uint32_t i = 0; i < n; i++) {
+        const lc_status rc = lc_scan_create(ctx, 1, &entry_ids[i], &scans[i]);
+        if (rc != LC_OK) return rc;  // LC_NOT_STAGED == the reference's early `None` (try_read_liquid, mod.rs:128-134)
+    }
+    const uint32_t len = scans[0]->meta[0].len;
+    for (uint32_t i = 1; i < n; i++)
+        if (scans[i]->meta[0].len != len) return fail(LC_ERR_INVALID, "the columns of a multi-column OR have different lengths");
+    const uint64_t words = std::max<uint64_t>((uint64_t(len) + 63) / 64, 1);
+    uint64_t* d_buf = static_cast<uint64_t*>(pool_alloc(ctx, words * 8 * 5 + 64));
+    uint64_t* h_buf = static_cast<uint64_t*>(host_pool_alloc(ctx, words * 8 * 3 + 64));
+    struct Bufs {
+        lc_ctx* c; void* d; void* h;
+        ~Bufs() { (void)hipDeviceSynchronize(); pool_release(c, d); host_pool_release(c, h); }
+    } bufs{ctx, d_buf, h_buf};
+    if (!d_buf || !h_buf) return fail(LC_ERR_OOM, "hipMalloc (OR scratch)");
+    uint64_t *d_sel = d_buf, *d_hit = d_buf + words, *d_valid = d_buf + 2 * words, *d_chit = d_buf + 3 * words,
+             *d_cvalid = d_buf + 4 * words;
+    uint32_t* d_bits = reinterpret_cast<uint32_t*>(d_buf + 5 * words);
+    // selection (all rows when absent), tail masked
+    std::memset(h_buf, 0, words * 8);
+    const size_t nb = bitmap_bytes(len);
+    if (selection) std::memcpy(h_buf, selection, nb);
+    else std::memset(h_buf, 0xFF, nb);
+    if (len & 7) reinterpret_cast<uint8_t*>(h_buf)[nb - 1] &= uint8_t((1u << (len & 7)) - 1);
+    LC_HIP(hipMemcpy(d_sel, h_buf, words * 8, hipMemcpyHostToDevice));
+    lc_status rc = scan_eval_or_impl(ctx, n, scans.data(), preds, d_sel, d_hit, d_valid, nullptr, nullptr);
+    if (rc != LC_OK) return rc;
+    LC_HIP(launch_mask_compress(d_hit, d_sel, scans[0]->d_seg_offsets, 1, d_chit, d_bits, nullptr));
+    LC_HIP(launch_mask_compress(d_valid, d_sel, scans[0]->d_seg_offsets, 1, d_cvalid, nullptr, nullptr));
+    uint32_t bits = 0;
+    LC_HIP(hipMemcpy(h_buf, d_chit, words * 8, hipMemcpyDeviceToHost));
+    LC_HIP(hipMemcpy(h_buf + words, d_cvalid, words * 8, hipMemcpyDeviceToHost));
+    LC_HIP(hipMemcpy(&bits, d_bits, 4, hipMemcpyDeviceToHost));
+    std::memcpy(out_values, h_buf, bitmap_bytes(bits));
+    std::memcpy(out_validity, h_buf + words, bitmap_bytes(bits));
+    *out_len = bits;
+    bool nullable = false;
+    for (uint32_t i = 0; i < n; i++) nullable |= scans[i]->meta[0].nullable;
+    if (out_nullable) *out_nullable = nullable ? 1 : 0;
+    return LC_OK;
     });
 }
 

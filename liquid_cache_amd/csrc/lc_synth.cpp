@@ -157,6 +157,48 @@ size_t lc_synth_phrase_batch(uint64_t seed, uint64_t batch_index, uint32_t rows,
     return pos;
 }
 
+size_t lc_synth_title_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, uint32_t n_unique, uint32_t needle_ppm,
+                            int32_t* offsets, uint8_t* data, size_t data_cap) {
+    if (n_unique == 0) n_unique = 1;
+    Rng r(seed * 0x100000001B3ull + batch_index * 0xC2B2AE3D27D4EB4Full + 5);
+    std::vector<std::string> pool(n_unique);
+    for (uint32_t i = 0; i < n_unique; i++) {
+        std::string& p = pool[i];
+        const bool needle = needle_ppm && (r.next() % 1000000ull) < needle_ppm;
+        const uint32_t nw = 3 + r.below(7);
+        const uint32_t at = needle ? r.below(nw) : 99;
+        for (uint32_t w = 0; w < nw; w++) {
+            if (w) p.push_back(' ');
+            if (w == at) { p += "Google"; continue; }
+            const char* word = kWords[r.below(kNWords)];
+            p.push_back(char(word[0] - 32));  // capitalised (the vocabulary is lower-case ASCII)
+            p += word + 1;
+        }
+        p += " - ";
+        p += kHosts[r.below(kNHosts)];
+        p += '#';
+        uint32_t v = i;
+        do { p.push_back(char('a' + v % 26)); v /= 26; } while (v);
+    }
+    size_t pos = 0;
+    offsets[0] = 0;
+    for (uint32_t row = 0; row < rows; row++) {
+        uint32_t k;
+        if (row < n_unique) k = row;
+        else {
+            const double u = r.unit();
+            k = uint32_t(double(n_unique) * u * u * u);
+            if (k >= n_unique) k = n_unique - 1;
+        }
+        const std::string& t = pool[k];
+        if (pos + t.size() > data_cap) return 0;
+        std::memcpy(data + pos, t.data(), t.size());
+        pos += t.size();
+        offsets[row + 1] = int32_t(pos);
+    }
+    return pos;
+}
+
 void lc_synth_int64_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, int32_t bit_width, int64_t base,
                           int64_t* out) {
     Rng r(seed * 0x100000001B3ull + batch_index * 0x9E3779B97F4A7C15ull + 7);

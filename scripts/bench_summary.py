@@ -26,5 +26,8 @@ for k, v in d.get('secondary', {}).items():
               v['kernel_ms_l3_cold'], v['frac_l3_cold'], v.get('hits')))
         for kk, vv in v.get('get_with_selection', {}).items():
             print('   gather %-7s ms %.4f frac %.3f eff GB/s %.0f' % (kk, vv['ms'], vv['frac'], vv['effective_gbs']))
+    elif 'queries' in v:
+        print('%s: %d rows, %d columns, all queries %.3f ms' % (k, v['rows'], v['columns'], v['total_ms_all_queries']))
+        print('   ' + '  '.join('%s %.3fms/%d' % (q, r['ms'], r['rows_out']) for q, r in v['queries'].items()))
     else:
         print(k, json.dumps(v)[:700])
