@@ -57,6 +57,10 @@ def parse_args(argv=None):
                    help="distinct URLs per million that contain the needle (ClickBench hits: 15,911 of 99,997,497 rows match)")
     p.add_argument("--workload", default="url_like", choices=["url_like", "int64_gt"])
     p.add_argument("--int-bits", type=int, default=62, help="int64_gt: FoR bit width of every batch (WatchID ~62)")
+    p.add_argument("--int-kind", default="int64", choices=["int64", "int16", "date32", "decimal"],
+                   help="int64_gt: Arrow type the integers are staged as (int16 / date32 / decimal128(15,2) for the narrow-"
+                        "column kernels)")
+    p.add_argument("--int-base", type=int, default=None, help="int64_gt: smallest value (default: a large id-like base)")
     p.add_argument("--exchange", default="count", choices=["count", "mask"],
                    help="multi-GPU exchange step per scan: COUNT(*) all-reduce or all-gather of the hit-mask segments")
     p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = whole column)")
@@ -582,7 +586,7 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads):
     return rows_total / dt, rows_total, int(hits), dt, all_cores
 
 
-def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal):
+def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal, base):
     from oracle import liquid_oracle as lo
     import pyarrow as pa
     L = N.load()
@@ -590,11 +594,19 @@ def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal):
     buf = np.zeros(bs, np.int64)
     blobs = []
     rows_total = 0
-    base = int_base(args.int_bits)
     for b in range(n_sample):
         rows = min(bs, args.rows - b * bs)
         L.lc_synth_int64_batch(args.seed + rank * 1_000_003, b, rows, args.int_bits, base, buf.ctypes.data)
-        blobs.append(cache.transcode(pa.array(buf[:rows])))
+        v = buf[:rows]
+        if args.int_kind == "int16":
+            arr = pa.array(v.astype(np.int16))
+        elif args.int_kind == "date32":
+            arr = pa.array(v.astype(np.int32), type=pa.date32())
+        elif args.int_kind == "decimal":
+            arr = _dec_array(pa, v)
+        else:
+            arr = pa.array(v)
+        blobs.append(cache.transcode(arr))
         rows_total += rows
     t0 = time.perf_counter()
     hits = lo.bench_eval_batches(blobs, None, lo.GT, literal, 1)
@@ -655,12 +667,18 @@ def main():
         workload = "clickbench_q21_url_like_%s%s" % (args.needle, "_no_fingerprints" if args.no_fingerprints else "")
         dtype, kernel = "u8", "k_str_pred"
     else:
-        ids = stage_int_column(cache, lc, N, args, rank, args.rows, threads)
-        base = int_base(args.int_bits)
+        base = int_base(args.int_bits) if args.int_base is None else args.int_base
+        ids = stage_int_column(cache, lc, N, args, rank, args.rows, threads, base=base, kind=args.int_kind)
         literal = base + (1 << (args.int_bits - 1)) if args.int_bits < 64 else 0
-        expr = lc.LiquidExpr.try_new(">", literal, pa.int64())
-        workload = "clickbench_int64_gt_w%d" % args.int_bits
-        dtype, kernel = "int64", ("k_fixed_pred_reg<u64>" if args.int_bits <= 32 else "k_fixed_pred<u64>")
+        if args.int_kind == "decimal":
+            expr = lc.LiquidExpr.try_new(">", decimal.Decimal(literal) / 100, pa.decimal128(15, 2))
+        elif args.int_kind == "date32":
+            expr = lc.LiquidExpr.try_new(">", datetime.date(1970, 1, 1) + datetime.timedelta(days=literal), pa.date32())
+        else:
+            expr = lc.LiquidExpr.try_new(">", literal, pa.int16() if args.int_kind == "int16" else pa.int64())
+        workload = "clickbench_%s_gt_w%d" % (args.int_kind, args.int_bits)
+        lanes = {"int64": "u64", "decimal": "u64", "date32": "u32", "int16": "u16"}[args.int_kind]
+        dtype, kernel = args.int_kind, ("k_fixed_pred_reg<%s>" % lanes if args.int_bits <= 32 else "k_fixed_pred<%s>" % lanes)
     t_stage = time.perf_counter() - t_stage
 
     scan = cache.scan(ids)
@@ -757,7 +775,7 @@ def main():
         if args.workload == "url_like":
             v, rows_s, hits_s, dt, all_cores = cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads)
         else:
-            v, rows_s, hits_s, dt, all_cores = cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal)
+            v, rows_s, hits_s, dt, all_cores = cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal, base)
         out["cpu_baseline"] = {"value": v, "unit": "rows/s", "cores": 1, "kind": "port", "hits": hits_s,
                                "sample": "first %d batches (%d rows) of the same column, %.1f s" % (n_sample, rows_s, dt)}
         out["cpu_baseline_all_cores"] = all_cores

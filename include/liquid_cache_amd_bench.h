@@ -42,6 +42,12 @@ LC_BENCH_API size_t lc_synth_title_batch(uint64_t seed, uint64_t batch_index, ui
 LC_BENCH_API void lc_synth_int64_batch(uint64_t seed, uint64_t batch_index, uint32_t rows, int32_t bit_width,
                                        int64_t base, int64_t* out);
 
+/* Profiling aid (scripts/pmc_calibrate.py): launches `iters` kernels that read exactly `bytes` bytes of a scratch buffer
+ * with a given access shape — 4 / 8 / 16 = coalesced bytes per lane, 1008 = 8 unaligned bytes out of every 64-byte
+ * sector — so that rocprofv3's FETCH_SIZE can be calibrated on the access patterns of the scan kernels (the counter's
+ * unit is only documented for 16-byte coalesced reads).  `ctx` is an lc_ctx*. */
+LC_BENCH_API int32_t lc_calibrate_read(void* ctx, uint64_t bytes, int32_t shape, int32_t iters);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,7 +67,7 @@ EXPORTED_SYMBOLS = [
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
     # include/liquid_cache_amd_bench.h
-    "lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
+    "lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch", "lc_calibrate_read",
 ]
 
 _lib = None
@@ -140,6 +140,7 @@ def load():
     L.lc_stream_synchronize.restype = i32; L.lc_stream_synchronize.argtypes = [vp, vp]
     L.lc_synth_url_batch.restype = sz
     L.lc_synth_url_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
+    L.lc_calibrate_read.restype = i32; L.lc_calibrate_read.argtypes = [vp, u64, i32, i32]
     L.lc_synth_title_batch.restype = sz
     L.lc_synth_title_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
     L.lc_synth_phrase_batch.restype = sz

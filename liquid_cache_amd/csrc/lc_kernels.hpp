@@ -186,6 +186,9 @@ hipError_t launch_mask_or_kleene(uint64_t* d_hit, uint64_t* d_valid, const uint6
 // per-entry popcounts of the mask passed as L.d_selection
 hipError_t launch_mask_entry_counts(const void* d_descs, bool is_str, const ScanLaunch& L, uint32_t* d_entry_counts,
                                     hipStream_t stream);
+// counter calibration: read `bytes` of d_buf with access shape 4 / 8 / 16 (coalesced bytes per lane) or 1008 (8 unaligned
+// bytes per 64-byte sector); d_sink: >= 2048 u32
+hipError_t launch_calib_read(const void* d_buf, uint64_t bytes, int shape, uint32_t* d_sink, hipStream_t stream);
 // cache flush for cold timings: streams `bytes` of d_buf through the memory-side cache (d_sink: >= 2048 u32)
 hipError_t launch_flush_read(const void* d_buf, uint64_t bytes, uint32_t* d_sink, hipStream_t stream);
 hipError_t launch_mask_compress(const uint64_t* d_src, const uint64_t* d_sel, const uint64_t* d_seg_offsets,

@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../../include/liquid_cache_amd_bench.h"
 #include "lc_host.hpp"
 #include "lc_kernels.hpp"
 #include "lc_transcode.hpp"
@@ -1188,6 +1189,25 @@ lc_status lc_scan_eval_or(lc_ctx* ctx, uint32_t n, lc_scan* const* scans, const 
     return guarded([&]() -> lc_status {
         return scan_eval_or_impl(ctx, n, scans, preds, d_selection, d_mask_out, d_valid_out, d_counts_out,
                                  static_cast<hipStream_t>(stream));
+    });
+}
+
+int32_t lc_calibrate_read(void* ctx_, uint64_t bytes, int32_t shape, int32_t iters) {
+    lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
+    return guarded([&]() -> lc_status {
+    if (!ctx || bytes < 4096 || iters <= 0) return fail(LC_ERR_INVALID, "bad argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    void* d = nullptr;
+    LC_HIP(hipMalloc(&d, bytes + 8192));
+    lc_status rc = LC_OK;
+    if (hipMemset(d, 1, bytes + 8192) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(LC_ERR_DEVICE, "memset");
+    for (int i = 0; i < iters && rc == LC_OK; i++)
+        if (launch_calib_read(d, bytes, shape, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d) + bytes), nullptr) != hipSuccess)
+            rc = fail(LC_ERR_INVALID, "unknown access shape (4, 8, 16 or 1008)");
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d);
+    return rc;
     });
 }
 

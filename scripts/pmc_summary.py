@@ -1,18 +1,58 @@
-"""Summarise rocprofv3 --pmc CSVs: per kernel name, mean counter value per launch."""
-import csv, glob, os, sys
+"""Summarise the rocprofv3 --pmc passes of scripts/profile_round.sh into hbm_traffic.json.
+
+usage: pmc_summary.py <gpurun_out/tag>   (expects <workload>_FETCH_SIZE/, <workload>_WRITE_SIZE/, calib_FETCH_SIZE/)
+FETCH_SIZE / WRITE_SIZE are reported in KB by rocprofv3.  The unit of FETCH_SIZE on gfx950 is only documented for
+16-byte coalesced streaming reads (it reports half the bytes); the calibration pass measures it for the access shapes
+the scan kernels use, and every workload's fetch is reported raw and scaled by the factor of its dominant shape."""
+import csv
+import glob
+import json
+import os
+import sys
 from collections import defaultdict
+
 root = sys.argv[1]
-acc = defaultdict(lambda: defaultdict(list))
-for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
-    with open(f) as fh:
-        for row in csv.DictReader(fh):
-            k = row["Kernel_Name"]
-            k = "k_str_pred" if "k_str_pred" in k else ("k_fixed_pred" if "k_fixed_pred" in k else k[:40])
-            acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
-for k, cs in sorted(acc.items()):
-    if not any(s in k for s in ("k_str_pred", "k_fixed_pred")):
+CALIB_BYTES = 1 << 30
+
+
+def medians(pattern):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(root, pattern, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: sorted(v)[len(v) // 2] for k, v in acc.items()}, {k: len(v) for k, v in acc.items()}
+
+
+out = {"_comment": "HBM bytes per launch of the dominant kernel from rocprofv3 --pmc (one pass per counter, "
+                   "scripts/profile_round.sh); FETCH_SIZE / WRITE_SIZE are KB, medians over launches; "
+                   "fetch_factor = real bytes per FETCH_SIZE byte measured by scripts/pmc_calibrate.py for the kernel's "
+                   "dominant access shape; traffic_bytes = FETCH_SIZE*1024*fetch_factor + WRITE_SIZE*1024."}
+calib, _ = medians("calib_FETCH_SIZE")
+factors = {}
+for k, kb in calib.items():
+    shape = "scattered8" if "scattered8" in k else ("coalesced%s" % k.split("<")[1].split(">")[0] if "<" in k else k)
+    factors[shape] = CALIB_BYTES / (kb * 1024.0) if kb else None
+out["fetch_size_calibration"] = {"bytes_per_launch": CALIB_BYTES, "real_bytes_per_reported_byte": factors}
+# dominant access shape of each kernel family
+SHAPE = {"k_str_pred": "coalesced8", "k_fixed_pred_reg": "coalesced4", "k_fixed_pred": "coalesced16"}
+for d in sorted(glob.glob(os.path.join(root, "*_FETCH_SIZE"))):
+    wl = os.path.basename(d)[: -len("_FETCH_SIZE")]
+    if wl == "calib":
         continue
-    print(k)
-    for c, v in sorted(cs.items()):
-        sv = sorted(v)
-        print("   %-24s median/launch %.5g  mean %.5g  min %.5g  max %.5g  (n=%d)" % (c, sv[len(sv) // 2], sum(v) / len(v), sv[0], sv[-1], len(v)))
+    fetch, n = medians(wl + "_FETCH_SIZE")
+    write, _ = medians(wl + "_WRITE_SIZE")
+    for k, kb in fetch.items():
+        fam = "k_fixed_pred_reg" if "k_fixed_pred_reg" in k else ("k_fixed_pred" if "k_fixed_pred" in k else
+                                                                  ("k_str_pred" if "k_str_pred" in k else None))
+        if fam is None:
+            continue
+        factor = factors.get(SHAPE[fam]) or 2.0
+        wkb = write.get(k, 0.0)
+        out.setdefault(wl, {})[k[:60]] = {"FETCH_SIZE_KB": kb, "WRITE_SIZE_KB": wkb, "launches": n[k],
+                                          "fetch_shape": SHAPE[fam], "fetch_factor": factor,
+                                          "traffic_bytes": int(kb * 1024 * factor + wkb * 1024),
+                                          "traffic_bytes_raw_counter": int(kb * 1024 + wkb * 1024)}
+        out[wl]["traffic_bytes"] = max(out[wl].get("traffic_bytes", 0), int(kb * 1024 * factor + wkb * 1024))
+json.dump(out, open(os.path.join(root, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))

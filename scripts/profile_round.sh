@@ -1,20 +1,34 @@
 #!/bin/bash
 # usage: scripts/profile_round.sh <round-tag>
-# rocprofv3 kernel-trace stats + HBM traffic counters (one --pmc pass per counter, no other trace domains) for both
-# bench workloads.  Outputs land in gpurun_out/<tag>/; copy the summaries into profiles/<tag>/.
-tag=${1:-r1}
+# rocprofv3 kernel-trace stats + HBM traffic counters (one --pmc pass per counter, no other trace domains) for the bench
+# workloads.  Outputs land in gpurun_out/<tag>/; copy the summaries into profiles/<tag>/ (scripts/collect_profiles.sh).
+tag=${1:-r2}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for wl in url_like int64_gt; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${wl}_trace -- python $R/bench.py --workload $wl --no-q21 --steps 20 --warmup 3 > $O/${wl}_trace.log 2>&1
+B="python $R/bench.py --no-secondary --steps 20 --warmup 3"
+declare -A WL
+WL[url_like]="--workload url_like"
+WL[url_like_no_fingerprints]="--workload url_like --no-fingerprints"
+WL[int64_gt_w62]="--workload int64_gt --int-bits 62"
+WL[date32_gt_w12]="--workload int64_gt --int-kind date32 --int-bits 12 --int-base 8036"
+WL[int16_gt_w12]="--workload int64_gt --int-kind int16 --int-bits 12 --int-base 0"
+WL[decimal_gt_w4]="--workload int64_gt --int-kind decimal --int-bits 4 --int-base 0"
+run_one() {  # name, env prefix, args
+  local wl=$1 envp=$2 a=$3
+  env $envp timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${wl}_trace -- $B $a > $O/${wl}_trace.log 2>&1
+  f=$(find $O/${wl}_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${wl}_kernel_stats.csv
+  grep -h '^{"metric"' $O/${wl}_trace.log > $O/${wl}_bench_line.json
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 240 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_str_pred|k_fixed_pred" --output-format csv -d $O/${wl}_$c -- python $R/bench.py --workload $wl --no-cpu-baseline --no-q21 --steps 3 --warmup 1 > $O/${wl}_$c.log 2>&1
+    env $envp timeout 240 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_str_pred|k_fixed_pred" --output-format csv -d $O/${wl}_$c -- $B $a --no-cpu-baseline --steps 3 --warmup 1 > $O/${wl}_$c.log 2>&1
   done
-done
+}
+for wl in url_like url_like_no_fingerprints int64_gt_w62 date32_gt_w12 int16_gt_w12 decimal_gt_w4; do run_one $wl "LC_X=0" "${WL[$wl]}"; done
 # the same LIKE scan with the reference's own prefilter only (no bigram signature index staged)
-LC_NO_SIGNATURES=1 timeout 300 python $R/bench.py --workload url_like --steps 5 --warmup 1 --no-cpu-baseline --no-q21 > $O/url_like_no_signatures.log 2>&1
-python $R/scripts/pmc_summary.py $O
-grep -h '^{"metric"' $O/url_like_no_signatures.log | cut -c1-2000
-for wl in url_like int64_gt; do grep -h '^{"metric"' $O/${wl}_trace.log; f=$(find $O/${wl}_trace -name "*kernel_stats.csv" | head -1); head -4 $f; done
+run_one url_like_no_signatures "LC_NO_SIGNATURES=1" "--workload url_like"
+# FETCH_SIZE calibration on known byte counts
+timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "k_calib" --output-format csv -d $O/calib_FETCH_SIZE -- python $R/scripts/pmc_calibrate.py > $O/calib.log 2>&1
+python $R/scripts/pmc_summary.py $O > $O/pmc_summary.txt 2>&1
+for wl in url_like url_like_no_signatures url_like_no_fingerprints int64_gt_w62 date32_gt_w12 int16_gt_w12 decimal_gt_w4; do echo "== $wl"; head -3 $O/${wl}_kernel_stats.csv; done
+tail -40 $O/pmc_summary.txt
