@@ -70,6 +70,8 @@ def parse_args(argv=None):
                         "every dictionary value is walked)")
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
     p.add_argument("--no-secondary", action="store_true", help="skip every secondary workload (profiling runs)")
+    p.add_argument("--no-cold", action="store_true",
+                   help="skip the L3-cold timing (rocprofv3 --stats runs: the kernel average then only holds hot launches)")
     p.add_argument("--secondary-rows", type=int, default=0, help="rows of the secondary workloads (0 = --rows)")
     p.add_argument("--sweep-rows", type=int, default=33_554_432, help="rows of the ClickBench pushdown sweep (config 5)")
     p.add_argument("--seed", type=int, default=42)
@@ -201,18 +203,19 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def measured_traffic(workload):
+def measured_traffic(key):
     """HBM bytes per launch of the dominant kernel, from the rocprofv3 --pmc passes of the newest profiled round
-    (profiles/<round>/hbm_traffic.json, produced by scripts/profile_round.sh; counters cannot be read from inside the
-    process).  None when this workload has not been profiled."""
+    (profiles/<round>/hbm_traffic.json, produced by scripts/profile_round.sh + scripts/pmc_summary.py: FETCH_SIZE scaled
+    by the factor calibrated on known byte counts, plus WRITE_SIZE; counters cannot be read from inside the process).
+    None when this workload has not been profiled."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "hbm_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if workload in d:
-            return int(d[workload]["traffic_bytes"]), os.path.relpath(f, ROOT)
+        if key in d and "traffic_bytes" in d[key]:
+            return int(d[key]["traffic_bytes"]), os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -740,11 +743,17 @@ def main():
     alg_bytes, own_bytes = scan.traffic_model(expr, False)
     iters = max(5, args.steps)
     kernel_ms = scan.eval_timed(expr, mask.data_ptr(), iters, 0, counts.data_ptr(), stream)
-    cold_ms = scan.eval_timed_cold(expr, mask.data_ptr(), max(3, iters // 4), FLUSH_BYTES, 0, counts.data_ptr(), stream)
+    cold_ms = None if args.no_cold else scan.eval_timed_cold(expr, mask.data_ptr(), max(3, iters // 4), FLUSH_BYTES, 0,
+                                                             counts.data_ptr(), stream)
 
     out = None
     if rank == 0:
-        traffic, traffic_src = measured_traffic(workload)
+        if args.workload == "url_like":
+            tkey = "url_like_no_fingerprints" if args.no_fingerprints else (
+                "url_like_no_signatures" if os.environ.get("LC_NO_SIGNATURES", "0") not in ("", "0") else "url_like")
+        else:
+            tkey = "%s_gt_w%d" % (args.int_kind, args.int_bits)
+        traffic, traffic_src = measured_traffic(tkey)
         out = {
             "metric": "filtered rows/s (+ GB/s scanned), ClickBench Q21 hot cache",
             "value": rows_all / elapsed * args.steps,

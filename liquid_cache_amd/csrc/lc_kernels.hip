@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include <utility>
 
 extern "C" __device__ int __llvm_amdgcn_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
@@ -1277,7 +1278,9 @@ __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) 
 //            byte (or bitmap) lookup per row, result bits transposed through LDS into whole mask words
 // kBytes: dictionary results are one LDS byte per entry (dictionaries up to kMaxByteTable), else a bitmap.
 // kSub:   LIKE / NOT LIKE '%needle%';  else Eq / Ne / ordering / constant.
-template <bool kBytes, bool kSub, bool kMany>
+// kInstr: the byte-accounting pass of lc_scan_traffic_model (per-entry candidate / kernel bytes).  A separate
+// instantiation, so that the accounting costs the shipped kernel nothing and a kernel trace keeps the two apart.
+template <bool kBytes, bool kSub, bool kMany, bool kInstr>
 __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
                                                            const DevSymtab* __restrict__ symtabs, StrPred pred,
                                                            ScanLaunch L, uint32_t dres_bytes, uint32_t cmask_bytes) {
@@ -1385,8 +1388,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             }
             if (lane == 0) {
                 if (L.d_counts) L.d_counts[entry] = 0;
-                if (L.d_cand_bytes) L.d_cand_bytes[entry] = 0;
-                if (L.d_own_bytes) L.d_own_bytes[entry] = uint32_t(sizeof(StrDesc)) + nwords * (L.d_valid ? 24u : 16u);
+                if (kInstr && L.d_cand_bytes) L.d_cand_bytes[entry] = 0;
+                if (kInstr && L.d_own_bytes) L.d_own_bytes[entry] = uint32_t(sizeof(StrDesc)) + nwords * (L.d_valid ? 24u : 16u);
             }
             continue;
         }
@@ -1431,7 +1434,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const bool use_sig = prune && d.signatures != nullptr && pred.n_sig_bits > 0 && !LC_ABL(pred.debug_flags & 8);
     // with signatures the (weaker) fingerprint only matters for the NOT LIKE candidate-count rule and for the
     // algorithmic-byte instrumentation: its 4*D bytes are skipped otherwise
-    const bool need_fp = prune && (!use_sig || op == LC_OP_NOT_LIKE || L.d_cand_bytes != nullptr);
+    const bool need_fp = prune && (!use_sig || op == LC_OP_NOT_LIKE || (kInstr && L.d_cand_bytes != nullptr));
 
     uint32_t fp_cand = 0;     // wave uniform: fingerprint candidates seen (NOT LIKE rule)
     uint32_t cand_bytes = 0;  // per lane, summed at the end (instrumented pass only)
@@ -1520,7 +1523,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     // the stronger bigram signature decides whether the value is walked at all
                     if (use_sig) is_cand = fp_ok && ((cmask[g0 >> 6] >> uint32_t(lane)) & 1);
                     if (need_fp) {
-                        if (L.d_cand_bytes && fp_ok) cand_bytes += str_offset(d, i + 1) - str_offset(d, i);
+                        if (kInstr && L.d_cand_bytes && fp_ok) cand_bytes += str_offset(d, i + 1) - str_offset(d, i);
                         fp_cand += uint32_t(__popcll(__ballot(fp_ok)));
                     }
                 } else if (pred.mode == 3) {
@@ -1600,8 +1603,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 wa.bytes_mode = kBytes ? 1u : 0u;
                 const WalkManyResult wr = like_walk_many(wa);
                 any_true |= __ballot(wr.found != 0);
-                if (L.d_cand_bytes && !prune) cand_bytes += wr.bytes;
-                if (L.d_own_bytes) own_bytes += wr.bytes + 2u * d.offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
+                if (kInstr && L.d_cand_bytes && !prune) cand_bytes += wr.bytes;
+                if (kInstr && L.d_own_bytes) own_bytes += wr.bytes + 2u * d.offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
                 break;
             }
             const uint32_t j = jb + uint32_t(lane);
@@ -1609,8 +1612,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             const uint32_t id = cl ? cand[j] : 0u;
             uint32_t start = 0, stop = 0;
             if (cl) str_offset_pair(d, id, start, stop);
-            if (L.d_cand_bytes && !prune) cand_bytes += stop - start;
-            if (L.d_own_bytes && cl) own_bytes += (stop - start) + 2u * d.offset_bytes;
+            if (kInstr && L.d_cand_bytes && !prune) cand_bytes += stop - start;
+            if (kInstr && L.d_own_bytes && cl) own_bytes += (stop - start) + 2u * d.offset_bytes;
             LC_TM(3, start);
             bool res = false;
             if (false) {
@@ -1801,11 +1804,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
 #endif
         if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(c);
     }
-    if (L.d_cand_bytes) {
+    if (kInstr && L.d_cand_bytes) {
         const uint64_t c = wave_sum_u64(uint64_t(cand_bytes));
         if (lane == 0) L.d_cand_bytes[entry] = uint32_t(c);
     }
-    if (L.d_own_bytes) {
+    if (kInstr && L.d_own_bytes) {
         // descriptor + phase A index (signature slices of the needle's distinct bigrams | fingerprints | prefix keys)
         // + phase B (offset pairs and compressed bytes of the walked candidates, summed per lane above)
         // + phase C (keys only when some dictionary value matched; selection / validity words in, mask words out)
@@ -2479,6 +2482,151 @@ __global__ __launch_bounds__(256) void k_flush_read(const uint4* __restrict__ sr
     if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;  // practically never true: keeps the loads alive, writes nothing
 }
 
+// ------------------------------------------------------------------------------------------------
+// On-device Arrow -> Liquid transcoder for fixed-width integers (LiquidPrimitiveArray::from_arrow_array,
+// primitive_array.rs:159-206 + BitPackedArray::from_primitive, raw/bit_pack_array.rs:71-124):
+//   k_col_minmax   min / max over the valid values of every entry (the frame of reference and the bit width)
+//   k_fl_pack      (v - reference) packed at W bits into FastLanes blocks, byte-identical to the host transcoder
+// Thread = (block, FastLanes lane): for a fixed row the lanes of a block read consecutive values (coalesced) and for a
+// fixed output word they write consecutive words.  k_date_component feeds the same two kernels for the squeezed
+// date-part form (SqueezedDate32Array::from_liquid_date32 / from_liquid_timestamp, squeezed_date32_array.rs:63-221).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ uint64_t load_native(const uint8_t* p, uint32_t i, bool is_signed) {
+    const T v = reinterpret_cast<const T*>(p)[i];
+    if (!is_signed) return uint64_t(v);
+    typedef typename std::make_signed<T>::type S;
+    return uint64_t(int64_t(S(v)));
+}
+__device__ __forceinline__ uint64_t load_native_any(const EncodeDesc& d, uint32_t i) {
+    switch (d.value_log2) {
+        case 0: return load_native<uint8_t>(d.values, i, d.is_signed);
+        case 1: return load_native<uint16_t>(d.values, i, d.is_signed);
+        case 2: return load_native<uint32_t>(d.values, i, d.is_signed);
+        default: return load_native<uint64_t>(d.values, i, d.is_signed);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_col_minmax(const EncodeDesc* __restrict__ descs, EncodeMinMax* __restrict__ out) {
+    __shared__ uint64_t s_mn[4], s_mx[4];
+    __shared__ uint32_t s_cnt[4];
+    const EncodeDesc d = descs[blockIdx.x];
+    // signed types compare as int64 (sign-extended), unsigned as uint64: bias the signed ones so that one unsigned
+    // comparison serves both
+    const uint64_t bias = d.is_signed ? (uint64_t(1) << 63) : 0;
+    uint64_t mn = ~uint64_t(0), mx = 0;
+    uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x; i < d.n; i += 256) {
+        const bool valid = d.validity ? ((d.validity[i >> 6] >> (i & 63u)) & 1) != 0 : true;
+        if (!valid) continue;
+        const uint64_t v = load_native_any(d, i) ^ bias;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+        cnt++;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = __shfl_down(mn, o, kWave), b = __shfl_down(mx, o, kWave);
+        const uint32_t c = __shfl_down(cnt, o, kWave);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+        cnt += c;
+    }
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_cnt[wave_id()] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; w++) {
+            mn = s_mn[w] < mn ? s_mn[w] : mn;
+            mx = s_mx[w] > mx ? s_mx[w] : mx;
+            cnt += s_cnt[w];
+        }
+        out[blockIdx.x].mn = mn ^ bias;
+        out[blockIdx.x].mx = mx ^ bias;
+        out[blockIdx.x].n_valid = cnt;
+    }
+}
+
+template <typename U>
+__global__ __launch_bounds__(256) void k_fl_pack(const EncodeDesc* __restrict__ descs) {
+    constexpr uint32_t TB = LaneTraits<U>::kBits, LANES = 1024u / TB;
+    const EncodeDesc d = descs[blockIdx.y];
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t blk = t / LANES, l = t % LANES;
+    if (d.W == 0 || blk >= (d.n + 1023u) / 1024u) return;
+    const uint32_t W = d.W;
+    const U mask = W >= TB ? U(~U(0)) : U((U(1) << W) - 1);
+    U* out = reinterpret_cast<U*>(d.packed + size_t(blk) * 128u * W);
+    U acc = 0;
+    uint32_t bit = 0, word = 0;
+    for (uint32_t r = 0; r < TB; r++) {
+        const uint32_t idx = blk * 1024u + fl_order(r >> 3) * 16u + (r & 7u) * 128u + l;
+        // every slot is packed, null slots included (they hold whatever the Arrow buffer holds, like the host path);
+        // slots past the end are zero (bit_pack_array.rs:97-113)
+        const U v = idx < d.n ? U(U(load_native_any(d, idx)) - U(d.reference)) & mask : U(0);
+        acc = U(acc | U(v << bit));
+        uint32_t nb = bit + W;
+        if (nb >= TB) {
+            out[LANES * word + l] = acc;
+            word++;
+            nb -= TB;
+            acc = nb ? U(v >> (W - nb)) : U(0);
+        }
+        bit = nb;
+    }
+}
+
+// date / timestamp values -> one calendar component as i32 (component_from_days, squeezed_date32_array.rs:364-429)
+__device__ __forceinline__ int32_t date_component(int32_t days, int field) {
+    const int64_t z = int64_t(days) + 719468;
+    const int64_t era = floor_div(z, 146097);
+    const int64_t doe = z - era * 146097;
+    const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+    int64_t y = yoe + era * 400;
+    const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+    const int64_t mp = (5 * doy + 2) / 153;
+    const int64_t dd = (doy - (153 * mp + 2) / 5) + 1;
+    const int64_t m = mp + (mp < 10 ? 3 : -9);
+    if (m <= 2) y += 1;
+    switch (field) {
+        case 0: return int32_t(y);
+        case 1: return int32_t(m);
+        case 2: return int32_t(dd);
+        default: {
+            int64_t dow = (int64_t(days) + 4) % 7;
+            if (dow < 0) dow += 7;
+            return int32_t(dow);
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_date_component(const T* __restrict__ values, uint64_t n, int field,
+                                                         int64_t ticks_per_day, int32_t* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
+        int32_t days;
+        if constexpr (sizeof(T) == 4) days = int32_t(values[i]);
+        else days = int32_t(floor_div(int64_t(values[i]), ticks_per_day));
+        out[i] = date_component(days, field);
+    }
+}
+// component (as decoded from a squeezed entry) -> the lossy date of to_arrow_date32_lossy (:289-359), in the entry's
+// original Arrow type
+template <typename T>
+__global__ __launch_bounds__(256) void k_component_lossy(const int32_t* __restrict__ comps, uint64_t n, int field,
+                                                          int64_t ticks_per_day, T* __restrict__ out) {
+    for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
+        const int32_t c = comps[i];
+        int32_t days;
+        switch (field) {
+            case 0: days = ymd_to_epoch_days(c, 1, 1); break;
+            case 1: days = ymd_to_epoch_days(1970, c, 1); break;
+            case 2: days = ymd_to_epoch_days(1970, 1, c); break;
+            default: days = 3 + c; break;  // 1970-01-04 (a Sunday) + dow
+        }
+        if constexpr (sizeof(T) == 4) out[i] = T(days);
+        else out[i] = T(int64_t(days) * ticks_per_day);
+    }
+}
+
 // Counter calibration (scripts/pmc_calibrate.py): read a KNOWN number of bytes with a given access shape, so that
 // rocprofv3's FETCH_SIZE can be converted into bytes for that shape instead of assuming the factor of another one.
 //   k_calib_read<W>          every lane reads W consecutive bytes, lanes adjacent (coalesced): W = 4, 8, 16
@@ -2510,6 +2658,51 @@ __global__ __launch_bounds__(256) void k_calib_read_scattered8(const uint8_t* __
 
 // ------------------------------------------------------------------------------------------------ launchers
 static int device_cus();
+
+hipError_t launch_col_minmax(const EncodeDesc* d_descs, uint32_t n_entries, EncodeMinMax* d_out, hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_col_minmax, dim3(n_entries), dim3(256), 0, stream, d_descs, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_fl_pack(const EncodeDesc* d_descs, uint32_t n_entries, uint32_t max_rows, int lane_log2, hipStream_t stream) {
+    if (n_entries == 0 || max_rows == 0) return hipSuccess;
+    const uint32_t lanes = 1024u >> lane_log2;
+    const uint32_t threads = ((max_rows + 1023u) / 1024u) * lanes;
+    const dim3 grid((threads + 255u) / 256u, n_entries), block(256);
+    switch (lane_log2) {
+        case 3: hipLaunchKernelGGL(k_fl_pack<uint8_t>, grid, block, 0, stream, d_descs); break;
+        case 4: hipLaunchKernelGGL(k_fl_pack<uint16_t>, grid, block, 0, stream, d_descs); break;
+        case 5: hipLaunchKernelGGL(k_fl_pack<uint32_t>, grid, block, 0, stream, d_descs); break;
+        case 6: hipLaunchKernelGGL(k_fl_pack<uint64_t>, grid, block, 0, stream, d_descs); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_date_component(const void* d_values, uint64_t n, int value_width, int field, int64_t ticks_per_day,
+                                 int32_t* d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((n + 255) / 256, uint64_t(device_cus()) * 16));
+    if (value_width == 4)
+        hipLaunchKernelGGL(k_date_component<int32_t>, dim3(grid), dim3(256), 0, stream, static_cast<const int32_t*>(d_values), n, field, ticks_per_day, d_out);
+    else if (value_width == 8)
+        hipLaunchKernelGGL(k_date_component<int64_t>, dim3(grid), dim3(256), 0, stream, static_cast<const int64_t*>(d_values), n, field, ticks_per_day, d_out);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_component_lossy(const int32_t* d_comps, uint64_t n, int value_width, int field, int64_t ticks_per_day,
+                                  void* d_out, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((n + 255) / 256, uint64_t(device_cus()) * 16));
+    if (value_width == 4)
+        hipLaunchKernelGGL(k_component_lossy<int32_t>, dim3(grid), dim3(256), 0, stream, d_comps, n, field, ticks_per_day, static_cast<int32_t*>(d_out));
+    else if (value_width == 8)
+        hipLaunchKernelGGL(k_component_lossy<int64_t>, dim3(grid), dim3(256), 0, stream, d_comps, n, field, ticks_per_day, static_cast<int64_t*>(d_out));
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
 
 hipError_t launch_calib_read(const void* d_buf, uint64_t bytes, int shape, uint32_t* d_sink, hipStream_t stream) {
     const uint8_t* p = static_cast<const uint8_t*>(d_buf);
@@ -2646,9 +2839,18 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     const uint32_t wgs_needed = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
     // kMany: LIKE over entries without the signature index (hundreds to thousands of candidates per entry)
     const bool many = sub && L.many_candidates;
-    void (*kern)(const StrDesc*, const DevSymtab*, StrPred, ScanLaunch, uint32_t, uint32_t) =
-        bytes ? (sub ? (many ? k_str_pred<true, true, true> : k_str_pred<true, true, false>) : k_str_pred<true, false, false>)
-              : (sub ? (many ? k_str_pred<false, true, true> : k_str_pred<false, true, false>) : k_str_pred<false, false, false>);
+    const bool instr = L.d_cand_bytes != nullptr || L.d_own_bytes != nullptr;
+    typedef void (*Kern)(const StrDesc*, const DevSymtab*, StrPred, ScanLaunch, uint32_t, uint32_t);
+    static const Kern table[2][2][2][2] = {  // [bytes][sub][many][instr]
+        {{{k_str_pred<false, false, false, false>, k_str_pred<false, false, false, true>},
+          {k_str_pred<false, false, false, false>, k_str_pred<false, false, false, true>}},
+         {{k_str_pred<false, true, false, false>, k_str_pred<false, true, false, true>},
+          {k_str_pred<false, true, true, false>, k_str_pred<false, true, true, true>}}},
+        {{{k_str_pred<true, false, false, false>, k_str_pred<true, false, false, true>},
+          {k_str_pred<true, false, false, false>, k_str_pred<true, false, false, true>}},
+         {{k_str_pred<true, true, false, false>, k_str_pred<true, true, false, true>},
+          {k_str_pred<true, true, true, false>, k_str_pred<true, true, true, true>}}}};
+    Kern kern = table[bytes ? 1 : 0][sub ? 1 : 0][many ? 1 : 0][instr ? 1 : 0];
     if (dyn_lds > 64 * 1024) {
         // large dictionaries: gfx950 has 160 KB of LDS per CU, a workgroup may use more than the default 64 KB
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

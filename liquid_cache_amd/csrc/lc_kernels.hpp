@@ -93,6 +93,24 @@ struct DevSymtab {
     uint8_t len[256];
 };
 
+// On-device transcoder (k_col_minmax / k_fl_pack): one array to encode.
+struct EncodeDesc {
+    const uint8_t* values;     // native-width values on the device
+    const uint64_t* validity;  // u64 words, or null
+    uint8_t* packed;           // output of the pack phase (ceil(n/1024) blocks of 128*W bytes)
+    uint64_t reference;        // pack phase: frame of reference (sign-extended for signed types)
+    uint32_t n;
+    uint8_t W;                 // pack phase: bit width (0: nothing to pack)
+    uint8_t value_log2;        // 0..3: bytes per value = 1 << value_log2
+    uint8_t is_signed;
+    uint8_t pad;
+};
+struct EncodeMinMax {
+    uint64_t mn, mx;  // as int64 bits for signed types
+    uint32_t n_valid;
+    uint32_t pad;
+};
+
 // Integer-domain predicate after host normalisation of the literal.
 struct FixedPred {
     int32_t op;           // LC_OP_EQ..LC_OP_GE
@@ -186,6 +204,13 @@ hipError_t launch_mask_or_kleene(uint64_t* d_hit, uint64_t* d_valid, const uint6
 // per-entry popcounts of the mask passed as L.d_selection
 hipError_t launch_mask_entry_counts(const void* d_descs, bool is_str, const ScanLaunch& L, uint32_t* d_entry_counts,
                                     hipStream_t stream);
+hipError_t launch_col_minmax(const EncodeDesc* d_descs, uint32_t n_entries, EncodeMinMax* d_out, hipStream_t stream);
+hipError_t launch_fl_pack(const EncodeDesc* d_descs, uint32_t n_entries, uint32_t max_rows, int lane_log2, hipStream_t stream);
+// date / timestamp values -> one calendar component (i32), and its lossy reconstruction in the original Arrow type
+hipError_t launch_date_component(const void* d_values, uint64_t n, int value_width, int field, int64_t ticks_per_day,
+                                 int32_t* d_out, hipStream_t stream);
+hipError_t launch_component_lossy(const int32_t* d_comps, uint64_t n, int value_width, int field, int64_t ticks_per_day,
+                                  void* d_out, hipStream_t stream);
 // counter calibration: read `bytes` of d_buf with access shape 4 / 8 / 16 (coalesced bytes per lane) or 1008 (8 unaligned
 // bytes per 64-byte sector); d_sink: >= 2048 u32
 hipError_t launch_calib_read(const void* d_buf, uint64_t bytes, int shape, uint32_t* d_sink, hipStream_t stream);

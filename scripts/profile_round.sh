@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-secondary --steps 20 --warmup 3"
+B="python $R/bench.py --no-secondary --no-cold --steps 20 --warmup 3"
 declare -A WL
 WL[url_like]="--workload url_like"
 WL[url_like_no_fingerprints]="--workload url_like --no-fingerprints"
