@@ -38,6 +38,9 @@ typedef int32_t lc_status;
 #define LC_OK 0
 #define LC_NOT_STAGED 1      /* == Option::None from the cache (core.rs:595, :862) */
 #define LC_UNSUPPORTED 2     /* caller must fall back to the reference CPU path */
+#define LC_NEEDS_BACKING 3   /* the entry is squeezed: this read needs the full array from the caller's disk tier
+                              * (the reference's squeezed arrays `read_backing()` in these cases,
+                              * squeezed_date32_array.rs:231-241, :440-486; hybrid_primitive_array.rs "NeedsBacking") */
 #define LC_ERR_INVALID (-1)  /* bad argument */
 #define LC_ERR_CORRUPT (-2)  /* malformed Liquid IPC bytes (the reference panics: ipc.rs:221-226) */
 #define LC_ERR_DEVICE (-3)   /* HIP runtime error */
@@ -100,6 +103,8 @@ typedef struct {
     int32_t has_fingerprints;
     uint64_t device_bytes;  /* HBM bytes held by the entry */
     uint64_t algorithmic_pred_bytes; /* SURVEY §8(d) bytes one predicate evaluation reads+writes */
+    int32_t squeezed_date_field;     /* LC_DATE_* if the entry is a squeezed date component (lc_squeeze_date), else -1 */
+    int32_t reserved;
 } lc_entry_info;
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html), declared here so the
@@ -175,6 +180,16 @@ LC_API lc_status lc_transcode_arrow(lc_ctx* ctx, const struct ArrowArray* array,
 /* cache.insert(entry_id, array) with eager transcoding (benchmark/README.md:42 `liquid_eager_transcode`). */
 LC_API lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArray* array,
                                  const struct ArrowSchema* schema, int32_t hint, uint64_t path_id);
+/* Arrow -> Liquid transcoding ON THE DEVICE for integer-like arrays (Int8..UInt64, Date32/64, Timestamp without zone):
+ * the raw values cross PCIe once and min / max (frame of reference, bit width) and the FastLanes packing run as kernels
+ * (LiquidPrimitiveArray::from_arrow_array, primitive_array.rs:159-206; BitPackedArray::from_primitive,
+ * bit_pack_array.rs:71-124).  The staged entries are byte-identical to what lc_insert_arrow stages (checked through
+ * lc_entry_to_liquid_bytes).  LC_UNSUPPORTED for other array types: use lc_insert_arrow. */
+LC_API lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids,
+                                        const struct ArrowArray* const* arrays, const struct ArrowSchema* const* schemas);
+/* LiquidArray::to_bytes() of a staged fixed-width entry, rebuilt from HBM (malloc'ed; release with lc_free): what the
+ * reference writes to its disk tier when an entry is squeezed or evicted (core.rs:246, :314). */
+LC_API lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out_bytes, size_t* out_len);
 LC_API void lc_free(void* p);
 /* Export the registered symbol table of `path_id` in save_symbol_table format (malloc'ed). */
 LC_API lc_status lc_symtab_get(lc_ctx* ctx, uint64_t path_id, uint8_t** out_bytes, size_t* out_len);
@@ -227,6 +242,15 @@ LC_API lc_status lc_get_with_selection(lc_ctx* ctx, uint64_t entry_id, const uin
 LC_API lc_status lc_get_date_part_with_selection(lc_ctx* ctx, uint64_t entry_id, const uint8_t* selection,
                                                  int32_t field, struct ArrowArray* out_array,
                                                  struct ArrowSchema* out_schema);
+
+/* Squeeze Date32 / Timestamp entries to ONE calendar component (LiquidPrimitiveArray::squeeze with the hint
+ * CacheExpression::extract_date32(field), primitive_array.rs:389-420 -> SqueezedDate32Array, squeezed_date32_array.rs:
+ * 46-221): the entry is replaced in HBM by the component, frame-of-reference + bit-packed on u32 lanes (TPC-H ship dates
+ * squeezed to YEAR: 3 bits per row).  Afterwards lc_get_date_part_with_selection(field) is served from the component
+ * (same values as before the squeeze); every other read or predicate on the entry answers LC_NEEDS_BACKING — the caller
+ * keeps the full bytes on its disk tier (lc_entry_to_liquid_bytes BEFORE squeezing gives them) exactly like the
+ * reference's `read_backing()`.  Decode, component extraction, min / max and packing run on the device. */
+LC_API lc_status lc_squeeze_date(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, int32_t field);
 
 /* boolean_buffer_and_then(left, right) (src/datafusion/src/utils.rs:62-83): `left` has left_bits bits of which
  * right_bits are set; out (ceil(left_bits/8) bytes) keeps the set bits of `left` whose `right` bit is 1. */

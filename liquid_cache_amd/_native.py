@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # LC_LIB_PATH: A/B runs of two in-tree builds of the same library (kernel tuning); the default is the in-tree build
 LIB_PATH = os.environ.get("LC_LIB_PATH") or os.path.join(_HERE, "libliquid_cache_amd.so")
 
-LC_OK, LC_NOT_STAGED, LC_UNSUPPORTED = 0, 1, 2
+LC_OK, LC_NOT_STAGED, LC_UNSUPPORTED, LC_NEEDS_BACKING = 0, 1, 2, 3
 LC_ERR_INVALID, LC_ERR_CORRUPT, LC_ERR_DEVICE, LC_ERR_OOM, LC_ERR_NO_SYMTAB = -1, -2, -3, -4, -5
 OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_LIKE, OP_NOT_LIKE = range(8)
 LIT_I64, LIT_U64, LIT_F32, LIT_F64, LIT_BYTES, LIT_I128, LIT_BOOL = range(7)
@@ -38,7 +38,8 @@ class DeviceInfo(C.Structure):
 class EntryInfo(C.Structure):
     _fields_ = [("logical_type", C.c_int32), ("physical_type", C.c_int32), ("len", C.c_uint32),
                 ("nullable", C.c_int32), ("all_null", C.c_int32), ("bit_width", C.c_int32), ("dict_len", C.c_uint32),
-                ("has_fingerprints", C.c_int32), ("device_bytes", C.c_uint64), ("algorithmic_pred_bytes", C.c_uint64)]
+                ("has_fingerprints", C.c_int32), ("device_bytes", C.c_uint64), ("algorithmic_pred_bytes", C.c_uint64),
+                ("squeezed_date_field", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ArrowSchema(C.Structure):
@@ -63,7 +64,7 @@ EXPORTED_SYMBOLS = [
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
-    "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold", "lc_scan_eval_or", "lc_eval_predicate_or",
+    "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold", "lc_scan_eval_or", "lc_eval_predicate_or", "lc_insert_arrow_device", "lc_entry_to_liquid_bytes", "lc_squeeze_date",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
     # include/liquid_cache_amd_bench.h
@@ -97,6 +98,9 @@ def load():
     L.lc_entry_info_get.restype = i32; L.lc_entry_info_get.argtypes = [vp, u64, P(EntryInfo)]
     L.lc_transcode_arrow.restype = i32; L.lc_transcode_arrow.argtypes = [vp, vp, vp, i32, u64, P(vp), P(sz)]
     L.lc_insert_arrow.restype = i32; L.lc_insert_arrow.argtypes = [vp, u64, vp, vp, i32, u64]
+    L.lc_insert_arrow_device.restype = i32; L.lc_insert_arrow_device.argtypes = [vp, u64, P(u64), P(vp), P(vp)]
+    L.lc_entry_to_liquid_bytes.restype = i32; L.lc_entry_to_liquid_bytes.argtypes = [vp, u64, P(vp), P(sz)]
+    L.lc_squeeze_date.restype = i32; L.lc_squeeze_date.argtypes = [vp, u64, P(u64), i32]
     L.lc_free.restype = None; L.lc_free.argtypes = [vp]
     L.lc_eval_predicate.restype = i32
     L.lc_eval_predicate.argtypes = [vp, u64, P(Predicate), vp, vp, vp, P(C.c_uint32), P(C.c_int32)]
@@ -152,7 +156,7 @@ def load():
 
 
 def check(status: int, ctx=None):
-    if status < 0 or status == LC_UNSUPPORTED:
+    if status < 0 or status in (LC_UNSUPPORTED, LC_NEEDS_BACKING):
         msg = load().lc_last_error(ctx).decode(errors="replace")
         raise LiquidCacheError(status, msg)
     return status

@@ -367,6 +367,48 @@ class LiquidCache:
         N.check(st, self._ctx)
         self._types[int(entry_id)] = batch_to_cache.type
 
+    def insert_device(self, entry_ids: Sequence[int], arrays: Sequence[pa.Array]):
+        """`cache.insert` for a batch of integer-like arrays with the transcoding done ON THE DEVICE
+        (lc_insert_arrow_device): raw values cross PCIe once, min / max and FastLanes packing run as kernels.  Raises
+        LiquidCacheError(LC_UNSUPPORTED) for other types (use `insert`)."""
+        n = len(entry_ids)
+        c_arrs = [N.ArrowArray() for _ in range(n)]
+        c_schemas = [N.ArrowSchema() for _ in range(n)]
+        try:
+            for a, ca, cs in zip(arrays, c_arrs, c_schemas):
+                if isinstance(a, pa.ChunkedArray):
+                    a = a.combine_chunks()
+                a._export_to_c(C.addressof(ca), C.addressof(cs))
+            ids = (C.c_uint64 * n)(*[int(e) for e in entry_ids])
+            ap = (C.c_void_p * n)(*[C.addressof(x) for x in c_arrs])
+            sp = (C.c_void_p * n)(*[C.addressof(x) for x in c_schemas])
+            st = self._lib.lc_insert_arrow_device(self._ctx, n, ids, ap, sp)
+        finally:
+            for ca, cs in zip(c_arrs, c_schemas):
+                _release(ca, cs)
+        N.check(st, self._ctx)
+        for e, a in zip(entry_ids, arrays):
+            self._types[int(e)] = a.type
+
+    def entry_bytes(self, entry_id: int) -> Optional[bytes]:
+        """`LiquidArray::to_bytes()` of a staged fixed-width entry, rebuilt from HBM (lc_entry_to_liquid_bytes)."""
+        out, ln = C.c_void_p(), C.c_size_t()
+        st = self._lib.lc_entry_to_liquid_bytes(self._ctx, int(entry_id), C.byref(out), C.byref(ln))
+        if st == N.LC_NOT_STAGED:
+            return None
+        N.check(st, self._ctx)
+        data = C.string_at(out, ln.value)
+        self._lib.lc_free(out)
+        return data
+
+    def squeeze_date(self, entry_ids: Sequence[int], field):
+        """Squeeze Date32 / Timestamp entries to one calendar component in HBM (LiquidPrimitiveArray::squeeze with an
+        ExtractDate32 hint).  Afterwards only `get(...).with_expression_hint(extract_date32(field))` is served; other
+        reads raise LiquidCacheError(LC_NEEDS_BACKING)."""
+        f = field.field if isinstance(field, ExtractDate32) else (Date32Field._NAMES[field.lower()] if isinstance(field, str) else int(field))
+        ids = (C.c_uint64 * len(entry_ids))(*[int(e) for e in entry_ids])
+        N.check(self._lib.lc_squeeze_date(self._ctx, len(entry_ids), ids, f), self._ctx)
+
     def evict(self, entry_ids: Iterable[int]):
         ids = [int(e) for e in entry_ids]
         arr = (C.c_uint64 * len(ids))(*ids)

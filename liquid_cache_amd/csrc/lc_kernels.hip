@@ -2552,6 +2552,7 @@ __global__ __launch_bounds__(256) void k_fl_pack(const EncodeDesc* __restrict__ 
     const EncodeDesc d = descs[blockIdx.y];
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t blk = t / LANES, l = t % LANES;
+    if (d.validity_out && d.validity && t < (d.n + 63u) / 64u) d.validity_out[t] = d.validity[t];
     if (d.W == 0 || blk >= (d.n + 1023u) / 1024u) return;
     const uint32_t W = d.W;
     const U mask = W >= TB ? U(~U(0)) : U((U(1) << W) - 1);

@@ -98,6 +98,7 @@ struct EncodeDesc {
     const uint8_t* values;     // native-width values on the device
     const uint64_t* validity;  // u64 words, or null
     uint8_t* packed;           // output of the pack phase (ceil(n/1024) blocks of 128*W bytes)
+    uint64_t* validity_out;    // pack phase: the validity words are copied here (or null)
     uint64_t reference;        // pack phase: frame of reference (sign-extended for signed types)
     uint32_t n;
     uint8_t W;                 // pack phase: bit width (0: nothing to pack)

@@ -79,6 +79,9 @@ struct Entry {
     int slab = -1;
     uint32_t offsets_bytes = 0;  // compact offset residual bytes (byte views)
     uint32_t fsst_len = 0;
+    // SqueezedDate32Array form (squeezed_date32_array.rs:46-53): the entry holds ONE calendar component of a Date32 /
+    // Timestamp column, FoR + bit-packed on u32 lanes; `phys` keeps the original type.  -1: not squeezed.
+    int squeezed_field = -1;
 };
 
 }  // namespace
@@ -843,6 +846,7 @@ lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out) 
     out->dict_len = e.dict_len;
     out->has_fingerprints = e.has_fp;
     out->device_bytes = e.device_bytes;
+    out->squeezed_date_field = e.squeezed_field;
     out->algorithmic_pred_bytes = e.is_str ? 0 : fixed_alg_bytes(e, false);
     return LC_OK;
     });
@@ -878,8 +882,332 @@ lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArra
     });
 }
 
+// ------------------------------------------------------------------ on-device transcoder (fixed-width integers)
+static int int_phys_of_format(const char* f) {
+    if (!f) return -1;
+    const std::string fmt = f;
+    if (fmt == "c") return kI8;
+    if (fmt == "C") return kU8;
+    if (fmt == "s") return kI16;
+    if (fmt == "S") return kU16;
+    if (fmt == "i") return kI32;
+    if (fmt == "I") return kU32;
+    if (fmt == "l") return kI64;
+    if (fmt == "L") return kU64;
+    if (fmt == "tdD") return kDate32;
+    if (fmt == "tdm") return kDate64;
+    if (fmt.rfind("ts", 0) == 0 && fmt.size() == 4 && fmt[3] == ':') {  // timestamps without a time zone
+        switch (fmt[2]) {
+            case 's': return kTsS;
+            case 'm': return kTsMs;
+            case 'u': return kTsUs;
+            case 'n': return kTsNs;
+            default: return -1;
+        }
+    }
+    return -1;
+}
+
+// One array to encode on the device: where its values / validity words sit in the staging buffer, and what comes out.
+namespace {
+struct DevEncodeItem {
+    uint64_t id = 0;
+    int phys = 0, vw = 0;
+    bool is_signed = false, has_validity = false;
+    uint32_t n = 0;
+    size_t in_values = 0, in_validity = 0;  // byte offsets in the staging buffer (insert path)
+    const uint8_t* d_values = nullptr;      // device pointers the kernels read
+    const uint64_t* d_validity = nullptr;
+    int squeezed_field = -1;                // >= 0: the values are date components of an entry of type `phys`
+    bool force_all_null = false;            // the source entry is all null (it carries no validity buffer to tell)
+    // results
+    bool all_null = false;
+    int W = 0;
+    uint64_t reference = 0;
+    size_t out_packed = size_t(-1), out_validity = size_t(-1), blob_begin = 0, blob_bytes = 0;
+};
+
+// min/max -> FoR reference + bit width, then pack into a fresh arena blob and register the entries.
+lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& items) {
+    const size_t n = items.size();
+    if (n == 0) return LC_OK;
+    std::vector<EncodeDesc> descs(n);
+    uint32_t max_rows = 0;
+    for (size_t i = 0; i < n; i++) {
+        DevEncodeItem& it = items[i];
+        EncodeDesc& d = descs[i];
+        d = EncodeDesc{};
+        d.values = it.d_values;
+        d.validity = it.has_validity ? it.d_validity : nullptr;
+        d.n = it.n;
+        d.value_log2 = uint8_t(it.vw == 1 ? 0 : it.vw == 2 ? 1 : it.vw == 4 ? 2 : 3);
+        d.is_signed = it.is_signed ? 1 : 0;
+        max_rows = std::max(max_rows, it.n);
+    }
+    EncodeDesc* d_descs = static_cast<EncodeDesc*>(pool_alloc(ctx, n * sizeof(EncodeDesc)));
+    EncodeMinMax* d_mm = static_cast<EncodeMinMax*>(pool_alloc(ctx, n * sizeof(EncodeMinMax)));
+    struct Scratch {
+        lc_ctx* c; void* a; void* b;
+        ~Scratch() { (void)hipDeviceSynchronize(); pool_release(c, a); pool_release(c, b); }
+    } scratch{ctx, d_descs, d_mm};
+    if (!d_descs || !d_mm) return fail(LC_ERR_OOM, "hipMalloc (encoder scratch)");
+    LC_HIP(hipMemcpy(d_descs, descs.data(), n * sizeof(EncodeDesc), hipMemcpyHostToDevice));
+    LC_HIP(launch_col_minmax(d_descs, uint32_t(n), d_mm, nullptr));
+    std::vector<EncodeMinMax> mm(n);
+    LC_HIP(hipMemcpy(mm.data(), d_mm, n * sizeof(EncodeMinMax), hipMemcpyDeviceToHost));
+    // layout of the batch's blob: per entry [packed + 128 slack][validity words]
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        DevEncodeItem& it = items[i];
+        it.all_null = mm[i].n_valid == 0 || it.force_all_null;  // also empty arrays (primitive_array.rs:160-170)
+        it.blob_begin = align_up(total, kSectionAlign);
+        size_t cur = it.blob_begin;
+        if (!it.all_null) {
+            uint64_t range;
+            if (it.is_signed) range = uint64_t(int64_t(mm[i].mx)) - uint64_t(int64_t(mm[i].mn));
+            else range = mm[i].mx - mm[i].mn;
+            if (it.vw < 8) range &= (uint64_t(1) << (8 * it.vw)) - 1;  // wrapping subtraction in the native width (:173-180)
+            it.W = bit_width_of(range);
+            it.reference = mm[i].mn;
+            it.out_packed = cur;
+            cur = align_up(cur + packed_bytes(it.W, it.n) + 128, kSectionAlign);
+            if (it.has_validity) {
+                it.out_validity = cur;
+                cur = align_up(cur + ((size_t(it.n) + 63) / 64) * 8, kSectionAlign);
+            }
+        }
+        it.blob_bytes = cur - it.blob_begin;
+        total = cur;
+    }
+    total = align_up(total, kSectionAlign) + 256;
+    std::unique_lock<std::shared_mutex> g(ctx->mu);
+    uint8_t* dbase = nullptr;
+    int slab = -1;
+    lc_status st = arena_alloc(ctx, total, &dbase, &slab);
+    if (st != LC_OK) return st;
+    ctx->slabs[size_t(slab)].live += int64_t(n) - 1;
+    LC_HIP(hipMemsetAsync(dbase, 0, total, nullptr));  // slack behind packed sections and tail words must be zero
+    for (size_t i = 0; i < n; i++) {
+        const DevEncodeItem& it = items[i];
+        EncodeDesc& d = descs[i];
+        d.W = uint8_t(it.all_null ? 0 : it.W);
+        d.reference = it.reference;
+        d.packed = it.all_null ? nullptr : dbase + it.out_packed;
+        d.validity_out = it.out_validity == size_t(-1) ? nullptr : reinterpret_cast<uint64_t*>(dbase + it.out_validity);
+    }
+    LC_HIP(hipMemcpy(d_descs, descs.data(), n * sizeof(EncodeDesc), hipMemcpyHostToDevice));
+    // one pack launch per lane width present in the batch (the kernel is templated on the lane type)
+    for (int ll = 0; ll < 4; ll++) {
+        // entries of other widths are skipped by giving the launch a filtered copy of the descriptors
+        std::vector<EncodeDesc> sub;
+        uint32_t sub_rows = 0;
+        for (size_t i = 0; i < n; i++)
+            if (descs[i].value_log2 == ll) { sub.push_back(descs[i]); sub_rows = std::max(sub_rows, descs[i].n); }
+        if (sub.empty()) continue;
+        if (sub.size() == n) {
+            LC_HIP(launch_fl_pack(d_descs, uint32_t(n), sub_rows, ll + 3, nullptr));
+        } else {
+            EncodeDesc* d_sub = static_cast<EncodeDesc*>(pool_alloc(ctx, sub.size() * sizeof(EncodeDesc)));
+            if (!d_sub) return fail(LC_ERR_OOM, "hipMalloc (encoder scratch)");
+            const hipError_t e1 = hipMemcpy(d_sub, sub.data(), sub.size() * sizeof(EncodeDesc), hipMemcpyHostToDevice);
+            const hipError_t e2 = e1 == hipSuccess ? launch_fl_pack(d_sub, uint32_t(sub.size()), sub_rows, ll + 3, nullptr) : e1;
+            (void)hipDeviceSynchronize();
+            pool_release(ctx, d_sub);
+            if (e2 != hipSuccess) return fail(LC_ERR_DEVICE, "k_fl_pack launch failed");
+        }
+    }
+    LC_HIP(hipDeviceSynchronize());
+    for (size_t i = 0; i < n; i++) {
+        const DevEncodeItem& it = items[i];
+        Entry e;
+        e.is_str = false;
+        e.logical = kInteger;
+        e.phys = it.phys;
+        e.len = it.n;
+        e.all_null = it.all_null;
+        e.nullable = it.has_validity || it.all_null;
+        e.W = it.all_null ? 0 : it.W;
+        e.slab = slab;
+        e.device_bytes = it.blob_bytes;
+        e.squeezed_field = it.squeezed_field;
+        FixedDesc& d = e.fd;
+        d = FixedDesc{};
+        d.len = it.n;
+        d.W = uint8_t(e.W);
+        d.lane_log2 = uint8_t(it.vw == 1 ? 3 : it.vw == 2 ? 4 : it.vw == 4 ? 5 : 6);
+        d.value_width = uint8_t(it.vw);
+        d.kind = kKindInt;
+        d.is_signed = it.is_signed ? 1 : 0;
+        d.reference = it.all_null ? 0 : it.reference;  // already sign-extended by k_col_minmax for signed types
+        d.packed = it.all_null ? nullptr : dbase + it.out_packed;
+        d.validity = it.out_validity == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + it.out_validity);
+        auto old = ctx->entries.find(it.id);
+        if (old != ctx->entries.end()) {
+            ctx->entry_bytes -= old->second.device_bytes;
+            arena_release(ctx, old->second.slab);
+            ctx->entries.erase(old);
+        }
+        ctx->entry_bytes += e.device_bytes;
+        ctx->entries.emplace(it.id, std::move(e));
+    }
+    return LC_OK;
+}
+}  // namespace
+
+lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const struct ArrowArray* const* arrays,
+                                 const struct ArrowSchema* const* schemas) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || (n && (!entry_ids || !arrays || !schemas))) return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    std::vector<DevEncodeItem> items(n);
+    size_t stage_bytes = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const struct ArrowArray* a = arrays[i];
+        const struct ArrowSchema* s = schemas[i];
+        if (!a || !s) return fail(LC_ERR_INVALID, "null array");
+        const int phys = int_phys_of_format(s->format);
+        if (phys < 0 || s->dictionary || a->length > int64_t(UINT32_MAX))
+            return fail(LC_UNSUPPORTED, "the on-device transcoder takes integer / date / timestamp arrays (use lc_insert_arrow)");
+        DevEncodeItem& it = items[i];
+        it.id = entry_ids[i];
+        it.phys = phys;
+        it.vw = phys_width(phys);
+        it.is_signed = !phys_unsigned(phys);
+        it.n = uint32_t(a->length);
+        it.has_validity = a->n_buffers >= 1 && a->buffers[0] != nullptr;
+        it.in_values = align_up(stage_bytes, 16);
+        stage_bytes = it.in_values + size_t(it.n) * size_t(it.vw) + 16;
+        if (it.has_validity) {
+            it.in_validity = align_up(stage_bytes, 16);
+            stage_bytes = it.in_validity + ((size_t(it.n) + 63) / 64) * 8;
+        }
+    }
+    if (n == 0) return LC_OK;
+    stage_bytes = align_up(stage_bytes, 256);
+    uint8_t* h = static_cast<uint8_t*>(host_pool_alloc(ctx, stage_bytes));
+    uint8_t* d_in = static_cast<uint8_t*>(pool_alloc(ctx, stage_bytes));
+    struct Bufs {
+        lc_ctx* c; void* h; void* d;
+        ~Bufs() { (void)hipDeviceSynchronize(); host_pool_release(c, h); pool_release(c, d); }
+    } bufs{ctx, h, d_in};
+    if (!h || !d_in) return fail(LC_ERR_OOM, "staging buffers of the on-device transcoder");
+    for (uint64_t i = 0; i < n; i++) {
+        const DevEncodeItem& it = items[i];
+        const struct ArrowArray* a = arrays[i];
+        const uint8_t* v = static_cast<const uint8_t*>(a->buffers[1]);
+        if (v) std::memcpy(h + it.in_values, v + size_t(a->offset) * size_t(it.vw), size_t(it.n) * size_t(it.vw));
+        else std::memset(h + it.in_values, 0, size_t(it.n) * size_t(it.vw));
+        if (it.has_validity) {
+            const size_t words = (size_t(it.n) + 63) / 64;
+            std::memset(h + it.in_validity, 0, words * 8);
+            const std::vector<uint8_t> bm = [&]() {
+                std::vector<uint8_t> out(bitmap_bytes(it.n) + 1, 0);
+                const uint8_t* src = static_cast<const uint8_t*>(a->buffers[0]);
+                if ((a->offset & 7) == 0) {
+                    std::memcpy(out.data(), src + (a->offset >> 3), bitmap_bytes(it.n));
+                    if (it.n & 7) out[bitmap_bytes(it.n) - 1] &= uint8_t((1u << (it.n & 7)) - 1);
+                } else {
+                    for (size_t k = 0; k < it.n; k++)
+                        if (get_bit(src, size_t(a->offset) + k)) set_bit(out.data(), k);
+                }
+                return out;
+            }();
+            std::memcpy(h + it.in_validity, bm.data(), bitmap_bytes(it.n));
+        }
+    }
+    LC_HIP(hipMemcpy(d_in, h, stage_bytes, hipMemcpyHostToDevice));
+    for (DevEncodeItem& it : items) {
+        it.d_values = d_in + it.in_values;
+        it.d_validity = reinterpret_cast<const uint64_t*>(d_in + it.in_validity);
+    }
+    return device_encode_and_register(ctx, items);
+    });
+}
+
+// LiquidArray::to_bytes() of a staged fixed-width entry (primitive_array.rs:603-679, decimal_array.rs:197-220,
+// float_array.rs:397-519, bit_pack_array.rs:181-256): what the reference writes to its disk tier when it squeezes or
+// evicts an entry, rebuilt from the HBM-resident form.
+lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out_bytes, size_t* out_len) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !out_bytes || !out_len) return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    Entry e;
+    {
+        std::shared_lock<std::shared_mutex> g(ctx->mu);
+        auto it = ctx->entries.find(entry_id);
+        if (it == ctx->entries.end()) return LC_NOT_STAGED;
+        e = it->second;
+    }
+    if (e.is_str) return fail(LC_UNSUPPORTED, "byte-view entries are re-serialised by the host (their bytes are what was staged)");
+    if (e.squeezed_field >= 0) return fail(LC_NEEDS_BACKING, "a squeezed entry holds one date component only");
+    std::vector<uint8_t> out(16, 0);
+    write_ipc_header(out.data(), e.logical, e.phys);
+    const FixedDesc& d = e.fd;
+    auto pad8 = [&]() { while (out.size() & 7) out.push_back(0); };
+    if (e.logical == kInteger) {
+        out.resize(24, 0);
+        if (!e.all_null) std::memcpy(out.data() + 16, &d.reference, size_t(d.value_width));
+    } else if (e.logical == kDecimal) {
+        out.resize(32, 0);
+        out[16] = uint8_t(e.dec_is256);
+        out[17] = uint8_t(e.dec_precision);
+        out[18] = uint8_t(int8_t(e.dec_scale));
+        if (!e.all_null) std::memcpy(out.data() + 24, &d.reference, 8);
+    } else {  // ALP float
+        const size_t w = d.value_width;
+        out.resize(16 + w, 0);
+        if (!e.all_null) std::memcpy(out.data() + 16, &d.reference, w);
+        pad8();
+        out.push_back(d.alp_e);
+        out.push_back(d.alp_f);
+        out.resize(out.size() + 6, 0);
+        const uint64_t pl = d.patch_len;
+        const size_t o = out.size();
+        out.resize(o + 8 + pl * 8 + pl * w, 0);
+        std::memcpy(out.data() + o, &pl, 8);
+        if (pl) {
+            LC_HIP(hipMemcpy(out.data() + o + 8, d.patch_idx, pl * 8, hipMemcpyDeviceToHost));
+            LC_HIP(hipMemcpy(out.data() + o + 8 + pl * 8, d.patch_val, pl * w, hipMemcpyDeviceToHost));
+        }
+        pad8();
+    }
+    // BitPackedArray section (:181-256)
+    const size_t n = e.len, lane_bytes = size_t(1) << (d.lane_log2 - 3);
+    const bool has_nulls = e.nullable;
+    const size_t nulls_len = has_nulls ? bitmap_bytes(n) : 0;
+    const size_t values_len = e.all_null ? n * lane_bytes : packed_bytes(e.W, n);
+    const size_t start = out.size(), values_off = align8(16 + nulls_len);
+    out.resize(start + values_off + values_len, 0);
+    uint8_t* p = out.data() + start;
+    wr<uint32_t>(p, uint32_t(n));
+    p[4] = uint8_t(e.all_null ? 0 : e.W);
+    p[5] = has_nulls ? 1 : 0;
+    wr<uint32_t>(p + 6, uint32_t(nulls_len));
+    wr<uint32_t>(p + 10, uint32_t(values_len));
+    if (has_nulls && nulls_len && !e.all_null) {
+        if (d.validity) LC_HIP(hipMemcpy(p + 16, d.validity, nulls_len, hipMemcpyDeviceToHost));
+        else std::memset(p + 16, 0xFF, nulls_len);
+        if (n & 7) p[16 + nulls_len - 1] &= uint8_t((1u << (n & 7)) - 1);
+    }
+    if (!e.all_null && values_len) LC_HIP(hipMemcpy(p + values_off, d.packed, values_len, hipMemcpyDeviceToHost));
+    *out_bytes = static_cast<uint8_t*>(std::malloc(out.size() ? out.size() : 1));
+    if (!*out_bytes) return fail(LC_ERR_OOM, "malloc");
+    std::memcpy(*out_bytes, out.data(), out.size());
+    *out_len = out.size();
+    return LC_OK;
+    });
+}
+
 // ------------------------------------------------------------------ scans
+static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed);
+
 lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out) {
+    return scan_create_impl(ctx, n, entry_ids, out, false);
+}
+
+static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed) {
     return guarded([&]() -> lc_status {
     if (!ctx || !out || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
     *out = nullptr;
@@ -898,6 +1226,9 @@ lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_
             auto it = ctx->entries.find(entry_ids[i]);
             if (it == ctx->entries.end()) return fail(LC_NOT_STAGED, "entry is not staged");
             Entry e = it->second;
+            if (e.squeezed_field >= 0 && !allow_squeezed)
+                return fail(LC_NEEDS_BACKING, "entry is squeezed to one date component: predicates and plain reads need the "
+                                              "full array from the disk tier");
             if (i == 0) {
                 s->is_str = e.is_str;
                 s->lane_log2 = e.is_str ? 4 : e.fd.lane_log2;
@@ -1707,12 +2038,15 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
     lc_scan* scan = nullptr;
-    lc_status rc = lc_scan_create(ctx, 1, &entry_id, &scan);
+    lc_status rc = scan_create_impl(ctx, 1, &entry_id, &scan, date_field >= 0);
     if (rc != LC_OK) return rc;
     std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
     const Entry& e = scan->meta[0];
     if (date_field >= 0 && date_ticks_per_day(e) < 0)
         return fail(LC_UNSUPPORTED, "ExtractDate32 applies to Date32 / Timestamp entries");
+    if (e.squeezed_field >= 0 && e.squeezed_field != date_field)
+        return fail(LC_NEEDS_BACKING, "entry is squeezed to another date component");
+    const bool squeezed = e.squeezed_field >= 0;
     const uint64_t words = std::max<uint64_t>((uint64_t(e.len) + 63) / 64, 1);
     std::vector<void*> dev;
     auto dalloc = [&](size_t bytes) -> void* {
@@ -1786,16 +2120,23 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
         L.n_entries = 1;
         L.blocks_per_entry = scan->bpe;
         L.d_selection = d_sel;
-        const size_t vw = e.fd.value_width;
+        // a squeezed entry stores i32 components; the Arrow value keeps the width of the original type
+        const size_t vw = squeezed ? size_t(phys_width(e.phys)) : size_t(e.fd.value_width);
+        const size_t gw = e.fd.value_width;
         uint32_t* d_bc = static_cast<uint32_t*>(dalloc(size_t(scan->bpe) * 4));
         uint64_t* d_bo = static_cast<uint64_t*>(dalloc(fixed_gather_offsets_len(scan->bpe) * 8));
         uint64_t* d_eo = static_cast<uint64_t*>(dalloc(2 * 8));
         uint8_t* d_vals = static_cast<uint8_t*>(dalloc(std::max<size_t>(k, 1) * vw + 64));
-        if (!d_bc || !d_bo || !d_eo || !d_vals) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
+        uint8_t* d_comp = squeezed ? static_cast<uint8_t*>(dalloc(std::max<size_t>(k, 1) * gw + 64)) : d_vals;
+        if (!d_bc || !d_bo || !d_eo || !d_vals || !d_comp) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
         LC_HIP_G(hipMemset(d_vals, 0, std::max<size_t>(k, 1) * vw + 64));
+        if (squeezed) LC_HIP_G(hipMemset(d_comp, 0, std::max<size_t>(k, 1) * gw + 64));
         LC_HIP_G(launch_fixed_gather(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, d_bc, d_bo, d_eo,
-                                     d_vals, std::max<uint64_t>(k, 1), nullptr));
-        if (date_field >= 0)
+                                     d_comp, std::max<uint64_t>(k, 1), nullptr));
+        if (squeezed)  // SqueezedDate32Array::to_component_array (squeezed_date32_array.rs:267-359)
+            LC_HIP_G(launch_component_lossy(reinterpret_cast<const int32_t*>(d_comp), k, int(vw), date_field,
+                                            std::max<int64_t>(date_ticks_per_day(e), 1), d_vals, nullptr));
+        else if (date_field >= 0)
             LC_HIP_G(launch_date_lossy(d_vals, k, int(vw), date_field, date_ticks_per_day(e), nullptr));
         uint8_t* vals = host_alloc(std::max<size_t>(k, 1) * vw);
         LC_HIP_G(hipMemcpy(vals, d_vals, k * vw, hipMemcpyDeviceToHost));
@@ -1978,6 +2319,66 @@ lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_s
                                  static_cast<const uint64_t*>(d_value_offsets), 0,
                                  static_cast<const uint64_t*>(d_row_offsets) + n, capacity_rows, capacity_bytes,
                                  static_cast<uint8_t*>(d_data), st));
+    return LC_OK;
+    });
+}
+
+// LiquidPrimitiveArray::squeeze with an ExtractDate32 hint (primitive_array.rs:389-420 -> SqueezedDate32Array::
+// from_liquid_date32 / from_liquid_timestamp): the entries are replaced IN HBM by the bit-packed component (e.g. years
+// 1992..1998: 3 bits per row instead of 12).  Everything runs on the device: decode, component, min / max, pack.
+lc_status lc_squeeze_date(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, int32_t field) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
+    if (field < LC_DATE_YEAR || field > LC_DATE_DAY_OF_WEEK) return fail(LC_ERR_INVALID, "unknown date field");
+    if (n == 0) return LC_OK;
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    lc_scan* scan = nullptr;
+    lc_status rc = scan_create_impl(ctx, n, entry_ids, &scan, false);
+    if (rc != LC_OK) return rc;
+    std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
+    const int64_t tpd = scan->is_str ? -1 : date_ticks_per_day(scan->meta[0]);
+    if (tpd < 0) return fail(LC_UNSUPPORTED, "ExtractDate32 squeezing applies to Date32 / Timestamp entries");
+    for (const Entry& e : scan->meta)
+        if (date_ticks_per_day(e) != tpd) return fail(LC_ERR_INVALID, "entries of different types in one squeeze call");
+    const uint64_t rows = scan->total_rows;
+    const size_t vw = scan->meta[0].fd.value_width;
+    uint8_t* d_vals = static_cast<uint8_t*>(pool_alloc(ctx, std::max<uint64_t>(rows, 1) * vw + 64));
+    int32_t* d_comp = static_cast<int32_t*>(pool_alloc(ctx, std::max<uint64_t>(rows, 1) * 4 + 64));
+    uint64_t* d_offs = static_cast<uint64_t*>(pool_alloc(ctx, (n + 1) * 8));
+    struct Bufs {
+        lc_ctx* c; void* a; void* b; void* d;
+        ~Bufs() { (void)hipDeviceSynchronize(); pool_release(c, a); pool_release(c, b); pool_release(c, d); }
+    } bufs{ctx, d_vals, d_comp, d_offs};
+    if (!d_vals || !d_comp || !d_offs) return fail(LC_ERR_OOM, "hipMalloc (squeeze scratch)");
+    rc = lc_scan_gather_fixed(ctx, scan, nullptr, d_vals, rows * vw, d_offs, nullptr);   // decode every row, in order
+    if (rc != LC_OK) return rc;
+    LC_HIP(launch_date_component(d_vals, rows, int(vw), field, tpd, d_comp, nullptr));
+    std::vector<DevEncodeItem> items(n);
+    uint64_t row0 = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const Entry& e = scan->meta[i];
+        DevEncodeItem& it = items[i];
+        it.id = entry_ids[i];
+        it.phys = e.phys;   // the original Arrow type stays the entry's type (original_data_type)
+        it.vw = 4;          // components are i32 on u32 lanes (BitPackedArray<UInt32Type>)
+        it.is_signed = true;
+        it.n = e.len;
+        it.has_validity = e.fd.validity != nullptr;
+        it.d_values = reinterpret_cast<const uint8_t*>(d_comp + row0);
+        it.d_validity = e.fd.validity;
+        it.squeezed_field = field;
+        it.force_all_null = e.all_null;
+        row0 += e.len;
+    }
+    rc = device_encode_and_register(ctx, items);
+    if (rc != LC_OK) return rc;
+    // all-null entries keep their nullability (they carry no validity buffer in either form)
+    std::unique_lock<std::shared_mutex> g(ctx->mu);
+    for (uint64_t i = 0; i < n; i++) {
+        auto it = ctx->entries.find(entry_ids[i]);
+        if (it != ctx->entries.end()) it->second.nullable = scan->meta[i].nullable;
+    }
     return LC_OK;
     });
 }

@@ -538,3 +538,132 @@ def test_fused_count_total(gpu_cache, oracle):
         totals, c = _eval_count(scan, gpu_cache, lc.LiquidExpr.try_new(op, pat, pa.string(), hint), repeat=2)
         assert totals == [want] * 2 and int(c.sum()) == want, (op, pat)
     scan.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# on-device transcoder (integers): byte-identical to the host transcoder
+# ------------------------------------------------------------------------------------------------------------------
+def test_device_transcoder_is_byte_identical_to_the_host_transcoder(gpu_cache, oracle):
+    lo = oracle
+    rng = np.random.default_rng(33)
+    types = [("int8", np.int8, pa.int8()), ("uint8", np.uint8, pa.uint8()), ("int16", np.int16, pa.int16()),
+             ("uint16", np.uint16, pa.uint16()), ("int32", np.int32, pa.int32()), ("uint32", np.uint32, pa.uint32()),
+             ("int64", np.int64, pa.int64()), ("uint64", np.uint64, pa.uint64()), ("date32", np.int32, pa.date32()),
+             ("date64", np.int64, pa.date64()), ("timestamp[us]", np.int64, pa.timestamp("us"))]
+    ids, arrays = [], []
+    eid = 0
+    for name, np_dtype, dtype in types:
+        info = np.iinfo(np_dtype)
+        bits = np.dtype(np_dtype).itemsize * 8
+        for W in sorted({1, 3, bits // 2 + 1, bits - 1, bits}):
+            for n in (8192, 1000, 1, 2048 + 65, 0):
+                span = min((1 << W) - 1, int(info.max) - int(info.min))
+                base = int(info.min) if W >= bits - 1 else int(rng.integers(int(info.min) // 2, int(info.max) // 2 - span))
+                v = np.array((rng.integers(0, span, size=n, endpoint=True, dtype=np.uint64).astype(object) + base).tolist(),
+                             dtype=np_dtype)
+                mode = int(rng.integers(4))
+                mask = None if mode == 0 else (rng.random(n) < (0.2 if mode == 1 else 1.0 if mode == 2 else 0.0))
+                arr = pa.array(v, type=dtype, mask=mask) if mask is not None else pa.array(v, type=dtype)
+                if mode == 3 and n > 10:
+                    arr = arr.slice(3, n - 7)  # non-zero offset: values and validity are re-based
+                eid += 1
+                ids.append(lc.ParquetArrayID.new(20, eid >> 12, 1, eid & 0xFFF))
+                arrays.append(arr)
+    gpu_cache.insert_device(ids, arrays)
+    for e, arr in zip(ids, arrays):
+        want = gpu_cache.transcode(arr)                      # host transcoder (byte-identical to the oracle's encoder)
+        got = gpu_cache.entry_bytes(e)
+        assert got == want, (str(arr.type), len(arr), arr.null_count)
+    # and the entries behave: predicates / get on a sample
+    for k in rng.choice(len(ids), 40, replace=False):
+        e, arr = ids[int(k)], arrays[int(k)]
+        if len(arr) == 0:
+            continue
+        got = gpu_cache.get(e).read()
+        assert got.to_pylist() == arr.to_pylist()
+    # re-serialised bytes of a HOST-staged entry are the staged bytes
+    a = pa.array(rng.integers(-1000, 1000, size=5000), mask=rng.random(5000) < 0.1)
+    gpu_cache.insert(999_999, a)
+    assert gpu_cache.entry_bytes(999_999) == gpu_cache.transcode(a)
+    f = pa.array(np.round(rng.normal(0, 100, size=4096), 2))
+    gpu_cache.insert(999_998, f)
+    assert gpu_cache.entry_bytes(999_998) == gpu_cache.transcode(f)
+    with pytest.raises(lc.LiquidCacheError) as ex:
+        gpu_cache.insert_device([1], [pa.array(["a", "b"])])
+    assert ex.value.status == N.LC_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# squeezed date storage form: the entry holds ONE component, bit-packed
+# ------------------------------------------------------------------------------------------------------------------
+def test_squeezed_date_component_storage(gpu_cache, oracle):
+    lo = oracle
+    rng = np.random.default_rng(44)
+    import datetime
+    epoch = datetime.date(1970, 1, 1)
+    d_lo, d_hi = (datetime.date(1992, 1, 2) - epoch).days, (datetime.date(1998, 12, 1) - epoch).days
+    n = 8192
+    cases = []
+    for k, (dtype, unit) in enumerate(((pa.date32(), None), (pa.timestamp("s"), 86400), (pa.timestamp("us"), 86_400_000_000),
+                                       (pa.timestamp("ns"), 86_400_000_000_000), (pa.date32(), None))):
+        days = rng.integers(d_lo, d_hi + 1, size=n - 37 * k)
+        if k == 4:
+            days = rng.integers(-800_000, 800_000, size=3000)            # far past / future, negative days
+        mask = rng.random(len(days)) < 0.15 if k % 2 else None
+        if unit is None:
+            vals = days.astype(np.int32)
+        else:
+            vals = days.astype(np.int64) * unit + rng.integers(0, unit, size=len(days))   # some time of day
+        arr = pa.array(vals, type=dtype, mask=mask)
+        cases.append((lc.ParquetArrayID.new(30, 0, k, 0), arr, days, mask))
+    # known answers of the reference (squeezed_date32_array.rs:520-618): YEAR of {-1, 0, 1971-07-15} = {1969, 1970, 1971}
+    ka = pa.array(np.array([-1, 0, 560], np.int32), type=pa.date32())
+    cases.append((lc.ParquetArrayID.new(30, 0, 9, 0), ka, np.array([-1, 0, 560]), None))
+    for field in range(4):
+        for eid, arr, days, mask in cases:
+            gpu_cache.insert(eid, arr)
+        ids = [c[0] for c in cases]
+        before = [gpu_cache.get(e).with_expression_hint(lc.CacheExpression.extract_date32(field)).read() for e in ids]
+        full_bytes = [gpu_cache.entry_bytes(e) for e in ids]
+        bytes_before = [gpu_cache.entry_info(e).device_bytes for e in ids]
+        # Date32 and Timestamp entries are squeezed in separate calls (one type per call)
+        gpu_cache.squeeze_date([ids[0], ids[4], ids[5]], field)
+        for k in (1, 2, 3):
+            gpu_cache.squeeze_date([ids[k]], field)
+        for (eid, arr, days, mask), b4, nb, fb in zip(cases, before, bytes_before, full_bytes):
+            info = gpu_cache.entry_info(eid)
+            assert info.squeezed_date_field == field
+            comps = np.array([lo.date_component(field, int(d)) for d in days])
+            valid = np.ones(len(days), bool) if mask is None else ~mask
+            want_w = lo.get_bit_width(int(comps[valid].max() - comps[valid].min())) if valid.any() else 0
+            assert info.bit_width == want_w, (field, info.bit_width, want_w)
+            if len(days) > 2000:
+                assert info.device_bytes < nb
+            sel = rng.random(len(days)) < 0.3
+            for s in (None, sel):
+                g = gpu_cache.get(eid).with_expression_hint(lc.CacheExpression.extract_date32(field))
+                got = (g.with_selection(s) if s is not None else g).read()
+                assert got.type == arr.type
+                want = b4 if s is None else b4.filter(pa.array(s))
+                assert got.equals(want), (field, str(arr.type))
+            # every other read needs the backing bytes
+            for call in (lambda: gpu_cache.get(eid).read(),
+                         lambda: gpu_cache.get(eid).with_expression_hint(lc.CacheExpression.extract_date32((field + 1) % 4)).read(),
+                         lambda: gpu_cache.eval_predicate(eid, lc.LiquidExpr.try_new(">", 0, pa.int64())).read(),
+                         lambda: gpu_cache.scan([eid])):
+                with pytest.raises(lc.LiquidCacheError) as ex:
+                    call()
+                assert ex.value.status == N.LC_NEEDS_BACKING
+            # the bytes taken before the squeeze restore the full entry (the reference reads them back from disk)
+            gpu_cache.stage([eid], [fb], data_types=[arr.type])
+            assert gpu_cache.entry_info(eid).squeezed_date_field == -1
+            assert gpu_cache.get(eid).read().equals(arr)
+    got = gpu_cache.get(cases[5][0]).read()
+    assert got.to_pylist() == ka.to_pylist()
+    gpu_cache.squeeze_date([cases[5][0]], "year")
+    y = gpu_cache.get(cases[5][0]).with_expression_hint(lc.CacheExpression.extract_date32("year")).read()
+    assert [d.year for d in y.to_pylist()] == [1969, 1970, 1971]
+    with pytest.raises(lc.LiquidCacheError) as ex:      # not a date column
+        gpu_cache.insert(77, pa.array([1, 2, 3]))
+        gpu_cache.squeeze_date([77], "year")
+    assert ex.value.status == N.LC_UNSUPPORTED
