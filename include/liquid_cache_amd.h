@@ -104,7 +104,7 @@ typedef struct {
     uint64_t device_bytes;  /* HBM bytes held by the entry */
     uint64_t algorithmic_pred_bytes; /* SURVEY §8(d) bytes one predicate evaluation reads+writes */
     int32_t squeezed_date_field;     /* LC_DATE_* if the entry is a squeezed date component (lc_squeeze_date), else -1 */
-    int32_t reserved;
+    int32_t clamped_from_bit_width;  /* original W if the entry is clamp-squeezed (lc_squeeze_clamp), else 0 */
 } lc_entry_info;
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html), declared here so the
@@ -251,6 +251,17 @@ LC_API lc_status lc_get_date_part_with_selection(lc_ctx* ctx, uint64_t entry_id,
  * keeps the full bytes on its disk tier (lc_entry_to_liquid_bytes BEFORE squeezing gives them) exactly like the
  * reference's `read_backing()`.  Decode, component extraction, min / max and packing run on the device. */
 LC_API lc_status lc_squeeze_date(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, int32_t field);
+
+/* Squeeze integer entries to half their bit width with the Clamp policy (LiquidPrimitiveArray::squeeze,
+ * primitive_array.rs:589-660 -> LiquidPrimitiveClampedArray, hybrid_primitive_array.rs:73-160): offsets at or above the
+ * sentinel 2^(W/2) - 1 are stored as the sentinel.  Entries under 8 bits, all-null entries and other encodings are left
+ * alone; *out_squeezed (optional) counts the entries that were squeezed.  Afterwards a predicate is answered from HBM
+ * whenever the reference's try_eval_predicate_inner can decide it — always, unless a valid selected row holds the
+ * sentinel AND the literal lies at or above reference + sentinel (:199-222) — and a read whenever no selected valid row
+ * holds the sentinel (to_arrow_known_only); otherwise the call answers LC_NEEDS_BACKING (per entry in
+ * lc_eval_predicate_batch's `statuses`) and the caller reads the full array from its disk tier.  Calls on scans that
+ * contain clamped entries synchronise the stream (the sentinel check).  The Quantize policy is not implemented. */
+LC_API lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed);
 
 /* boolean_buffer_and_then(left, right) (src/datafusion/src/utils.rs:62-83): `left` has left_bits bits of which
  * right_bits are set; out (ceil(left_bits/8) bytes) keeps the set bits of `left` whose `right` bit is 1. */

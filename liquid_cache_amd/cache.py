@@ -409,6 +409,14 @@ class LiquidCache:
         ids = (C.c_uint64 * len(entry_ids))(*[int(e) for e in entry_ids])
         N.check(self._lib.lc_squeeze_date(self._ctx, len(entry_ids), ids, f), self._ctx)
 
+    def squeeze_clamp(self, entry_ids: Sequence[int]) -> int:
+        """Squeeze integer entries to half their bit width with the Clamp policy (lc_squeeze_clamp); returns how many
+        qualified.  Reads / predicates that need the clamped-away bits raise LiquidCacheError(LC_NEEDS_BACKING)."""
+        ids = (C.c_uint64 * len(entry_ids))(*[int(e) for e in entry_ids])
+        k = C.c_uint64()
+        N.check(self._lib.lc_squeeze_clamp(self._ctx, len(entry_ids), ids, C.byref(k)), self._ctx)
+        return int(k.value)
+
     def evict(self, entry_ids: Iterable[int]):
         ids = [int(e) for e in entry_ids]
         arr = (C.c_uint64 * len(ids))(*ids)

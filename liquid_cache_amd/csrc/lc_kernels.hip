@@ -287,6 +287,11 @@ __device__ __forceinline__ PackedRange<U> packed_range(const FixedDesc& d, const
     int mode = pred.lit_class;  // -1: literal below every value, +1: above
     uint64_t dlit = 0;
     const uint64_t umax = d.W >= 64 ? ~uint64_t(0) : ((uint64_t(1) << d.W) - 1);
+    if (op == LC_OP_INTERNAL_SENTINEL) {  // rows whose packed value is the clamp sentinel (all ones)
+        r.lo = U(umax);
+        r.span = 0;
+        return r;
+    }
     if (mode == 0) {
         const bool below = d.is_signed ? (int64_t(pred.lit) < int64_t(d.reference)) : (pred.lit < d.reference);
         if (below) mode = -1;
@@ -2563,7 +2568,9 @@ __global__ __launch_bounds__(256) void k_fl_pack(const EncodeDesc* __restrict__ 
         const uint32_t idx = blk * 1024u + fl_order(r >> 3) * 16u + (r & 7u) * 128u + l;
         // every slot is packed, null slots included (they hold whatever the Arrow buffer holds, like the host path);
         // slots past the end are zero (bit_pack_array.rs:97-113)
-        const U v = idx < d.n ? U(U(load_native_any(d, idx)) - U(d.reference)) & mask : U(0);
+        U v = idx < d.n ? U(U(load_native_any(d, idx)) - U(d.reference)) : U(0);
+        if (d.clamp_max && v > U(d.clamp_max)) v = U(d.clamp_max);  // values >= sentinel become the sentinel (:433-437)
+        v &= mask;
         acc = U(acc | U(v << bit));
         uint32_t nb = bit + W;
         if (nb >= TB) {

@@ -100,6 +100,7 @@ struct EncodeDesc {
     uint8_t* packed;           // output of the pack phase (ceil(n/1024) blocks of 128*W bytes)
     uint64_t* validity_out;    // pack phase: the validity words are copied here (or null)
     uint64_t reference;        // pack phase: frame of reference (sign-extended for signed types)
+    uint64_t clamp_max;        // pack phase: offsets are clamped to this value first (clamp squeeze); 0: no clamp
     uint32_t n;
     uint8_t W;                 // pack phase: bit width (0: nothing to pack)
     uint8_t value_log2;        // 0..3: bytes per value = 1 << value_log2
@@ -111,6 +112,10 @@ struct EncodeMinMax {
     uint32_t n_valid;
     uint32_t pad;
 };
+
+// Internal operator: "packed value == all ones" — the sentinel rows of a clamp-squeezed entry
+// (LiquidPrimitiveClampedArray, hybrid_primitive_array.rs:129-146, :194-196).
+#define LC_OP_INTERNAL_SENTINEL 100
 
 // Integer-domain predicate after host normalisation of the literal.
 struct FixedPred {

@@ -82,6 +82,10 @@ struct Entry {
     // SqueezedDate32Array form (squeezed_date32_array.rs:46-53): the entry holds ONE calendar component of a Date32 /
     // Timestamp column, FoR + bit-packed on u32 lanes; `phys` keeps the original type.  -1: not squeezed.
     int squeezed_field = -1;
+    // LiquidPrimitiveClampedArray form (hybrid_primitive_array.rs:73-80): packed at half the original width, offsets at or
+    // above the sentinel 2^W - 1 are stored as the sentinel; orig_W is the width before the squeeze.
+    bool clamped = false;
+    int orig_W = 0;
 };
 
 }  // namespace
@@ -122,6 +126,8 @@ struct lc_scan {
     int lane_log2 = 0;
     uint32_t n = 0, bpe = 0;
     uint32_t max_w = 0;  // widest entry (fixed width): <= 32 selects the register-resident predicate kernel
+    bool has_clamped = false;              // some entry is clamp-squeezed: evaluations first look for unresolved sentinels
+    std::vector<uint32_t> needs_backing;   // entries (scan order) whose last evaluation needs the full array
     std::vector<uint64_t> seg_offsets;  // n+1 word offsets
     uint64_t total_rows = 0;
     void* d_descs = nullptr;
@@ -847,6 +853,7 @@ lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out) 
     out->has_fingerprints = e.has_fp;
     out->device_bytes = e.device_bytes;
     out->squeezed_date_field = e.squeezed_field;
+    out->clamped_from_bit_width = e.clamped ? e.orig_W : 0;
     out->algorithmic_pred_bytes = e.is_str ? 0 : fixed_alg_bytes(e, false);
     return LC_OK;
     });
@@ -920,6 +927,11 @@ struct DevEncodeItem {
     const uint64_t* d_validity = nullptr;
     int squeezed_field = -1;                // >= 0: the values are date components of an entry of type `phys`
     bool force_all_null = false;            // the source entry is all null (it carries no validity buffer to tell)
+    // clamp squeeze: the values are the packed-domain offsets of an existing entry; width and reference are given
+    bool forced = false;
+    int forced_W = 0, orig_W = 0;
+    uint64_t entry_reference = 0, clamp_max = 0;
+    bool entry_signed = false;
     // results
     bool all_null = false;
     int W = 0;
@@ -959,10 +971,19 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
     size_t total = 0;
     for (size_t i = 0; i < n; i++) {
         DevEncodeItem& it = items[i];
-        it.all_null = mm[i].n_valid == 0 || it.force_all_null;  // also empty arrays (primitive_array.rs:160-170)
+        it.all_null = (!it.forced && mm[i].n_valid == 0) || it.force_all_null;  // also empty arrays (primitive_array.rs:160-170)
         it.blob_begin = align_up(total, kSectionAlign);
         size_t cur = it.blob_begin;
-        if (!it.all_null) {
+        if (!it.all_null && it.forced) {
+            it.W = it.forced_W;
+            it.reference = 0;  // the values already are offsets from the entry's reference
+            it.out_packed = cur;
+            cur = align_up(cur + packed_bytes(it.W, it.n) + 128, kSectionAlign);
+            if (it.has_validity) {
+                it.out_validity = cur;
+                cur = align_up(cur + ((size_t(it.n) + 63) / 64) * 8, kSectionAlign);
+            }
+        } else if (!it.all_null) {
             uint64_t range;
             if (it.is_signed) range = uint64_t(int64_t(mm[i].mx)) - uint64_t(int64_t(mm[i].mn));
             else range = mm[i].mx - mm[i].mn;
@@ -992,6 +1013,7 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         EncodeDesc& d = descs[i];
         d.W = uint8_t(it.all_null ? 0 : it.W);
         d.reference = it.reference;
+        d.clamp_max = it.clamp_max;
         d.packed = it.all_null ? nullptr : dbase + it.out_packed;
         d.validity_out = it.out_validity == size_t(-1) ? nullptr : reinterpret_cast<uint64_t*>(dbase + it.out_validity);
     }
@@ -1030,6 +1052,8 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         e.slab = slab;
         e.device_bytes = it.blob_bytes;
         e.squeezed_field = it.squeezed_field;
+        e.clamped = it.forced;
+        e.orig_W = it.orig_W;
         FixedDesc& d = e.fd;
         d = FixedDesc{};
         d.len = it.n;
@@ -1037,8 +1061,8 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         d.lane_log2 = uint8_t(it.vw == 1 ? 3 : it.vw == 2 ? 4 : it.vw == 4 ? 5 : 6);
         d.value_width = uint8_t(it.vw);
         d.kind = kKindInt;
-        d.is_signed = it.is_signed ? 1 : 0;
-        d.reference = it.all_null ? 0 : it.reference;  // already sign-extended by k_col_minmax for signed types
+        d.is_signed = (it.forced ? it.entry_signed : it.is_signed) ? 1 : 0;
+        d.reference = it.all_null ? 0 : (it.forced ? it.entry_reference : it.reference);  // sign-extended for signed types
         d.packed = it.all_null ? nullptr : dbase + it.out_packed;
         d.validity = it.out_validity == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + it.out_validity);
         auto old = ctx->entries.find(it.id);
@@ -1142,6 +1166,7 @@ lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out
     }
     if (e.is_str) return fail(LC_UNSUPPORTED, "byte-view entries are re-serialised by the host (their bytes are what was staged)");
     if (e.squeezed_field >= 0) return fail(LC_NEEDS_BACKING, "a squeezed entry holds one date component only");
+    if (e.clamped) return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry holds half of its bits");
     std::vector<uint8_t> out(16, 0);
     write_ipc_header(out.data(), e.logical, e.phys);
     const FixedDesc& d = e.fd;
@@ -1242,6 +1267,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             s->total_rows += e.len;
             max_len = std::max(max_len, e.len);
             if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
+            s->has_clamped |= e.clamped;
             s->meta.push_back(e);
         }
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
@@ -1313,9 +1339,65 @@ uint64_t lc_scan_rows(const lc_scan* s) { return s ? s->total_rows : 0; }
 uint64_t lc_scan_entries(const lc_scan* s) { return s ? s->n : 0; }
 const uint64_t* lc_scan_segment_offsets(const lc_scan* s) { return s ? s->seg_offsets.data() : nullptr; }
 
+// LiquidPrimitiveClampedArray::try_eval_predicate_inner (hybrid_primitive_array.rs:199-222): can `op literal` be decided
+// on rows that hold the sentinel (their real value is only known to be >= reference + sentinel)?
+static bool clamp_resolves(const Entry& e, const FixedPred& fp) {
+    const uint64_t sentinel = e.W >= 64 ? ~uint64_t(0) : ((uint64_t(1) << e.W) - 1);
+    const bool strict = fp.op == LC_OP_EQ || fp.op == LC_OP_NE || fp.op == LC_OP_GT || fp.op == LC_OP_LE;
+    if (fp.lit_class < 0) return true;    // literal below every value of the type
+    if (fp.lit_class > 0) return false;   // above every value
+    if (e.fd.is_signed) {
+        const int64_t sent_abs = int64_t(e.fd.reference) + int64_t(sentinel);
+        const int64_t k = int64_t(fp.lit);
+        return strict ? k < sent_abs : k <= sent_abs;
+    }
+    const uint64_t sent_abs = e.fd.reference + sentinel;
+    return strict ? fp.lit < sent_abs : fp.lit <= sent_abs;
+}
+
+// Which clamp-squeezed entries of the scan hold a valid, selected sentinel row that `preds` cannot decide?  (`preds`
+// null: any sentinel row counts — reads need every selected value, to_arrow_known_only :129-146.)  Synchronises.
+static lc_status clamp_unresolved_entries(lc_ctx* ctx, lc_scan* s, const FixedPred* preds, int n_preds,
+                                          const void* d_selection, hipStream_t stream, std::vector<uint32_t>* out) {
+    out->clear();
+    std::vector<uint32_t> suspects;
+    for (uint32_t i = 0; i < s->n; i++) {
+        const Entry& e = s->meta[i];
+        if (!e.clamped || e.all_null) continue;
+        bool resolves = preds != nullptr;
+        for (int k = 0; k < n_preds && resolves; k++) resolves = clamp_resolves(e, preds[k]);
+        if (!resolves) suspects.push_back(i);
+    }
+    if (suspects.empty()) return LC_OK;
+    const uint64_t words = std::max<uint64_t>(s->seg_offsets.back(), 1);
+    uint64_t* d_tmp = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
+    uint32_t* d_cnt = static_cast<uint32_t*>(pool_alloc(ctx, size_t(s->n) * 4));
+    struct Bufs {
+        lc_ctx* c; void* a; void* b; hipStream_t st;
+        ~Bufs() { (void)hipStreamSynchronize(st); pool_release(c, a); pool_release(c, b); }
+    } bufs{ctx, d_tmp, d_cnt, stream};
+    if (!d_tmp || !d_cnt) return fail(LC_ERR_OOM, "hipMalloc (sentinel pass)");
+    ScanLaunch L{};
+    L.n_entries = s->n;
+    L.blocks_per_entry = s->bpe;
+    L.d_selection = static_cast<const uint64_t*>(d_selection);
+    L.d_hit = d_tmp;
+    L.d_counts = d_cnt;
+    FixedPred sp{};
+    sp.op = LC_OP_INTERNAL_SENTINEL;
+    LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, sp, nullptr, s->max_w, L, stream));
+    std::vector<uint32_t> cnt(s->n, 0);
+    LC_HIP(hipMemcpyAsync(cnt.data(), d_cnt, size_t(s->n) * 4, hipMemcpyDeviceToHost, stream));
+    LC_HIP(hipStreamSynchronize(stream));
+    for (uint32_t i : suspects)
+        if (cnt[i] > 0) out->push_back(i);
+    return LC_OK;
+}
+
 static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pred, const void* d_selection,
                                 void* d_mask_out, void* d_valid_out, void* d_counts_out, void* d_cand_bytes,
-                                hipStream_t stream, const lc_predicate* pred2 = nullptr, void* d_total_out = nullptr) {
+                                hipStream_t stream, const lc_predicate* pred2 = nullptr, void* d_total_out = nullptr,
+                                bool tolerate_backing = false) {
     return guarded([&]() -> lc_status {
     if (!ctx || !s || !pred || !d_mask_out) return fail(LC_ERR_INVALID, "null argument");
     if (s->n == 0) {
@@ -1361,6 +1443,16 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
                 return fail(LC_UNSUPPORTED, "fused conjuncts must be Eq / Lt / LtEq / Gt / GtEq");
             st = make_fixed_pred(s->meta[0], pred2, &fp2);
             if (st != LC_OK) return st;
+        }
+        if (s->has_clamped) {
+            // clamp-squeezed entries: a sentinel row the predicate cannot decide sends the caller to its disk tier
+            // (Err(NeedsBacking), hybrid_primitive_array.rs:226-229); everything else evaluates on the clamped data as is
+            const FixedPred both[2] = {fp, fp2};
+            std::lock_guard<std::mutex> g(s->mu);
+            st = clamp_unresolved_entries(ctx, s, both, pred2 ? 2 : 1, d_selection, stream, &s->needs_backing);
+            if (st != LC_OK) return st;
+            if (!s->needs_backing.empty() && !tolerate_backing)
+                return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry holds sentinel rows this predicate cannot decide");
         }
         LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, pred2 ? &fp2 : nullptr,
                                  s->max_w, L, stream));
@@ -1818,8 +1910,11 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     }
     if (oom) { cleanup(); return fail(LC_ERR_OOM, "hipMalloc (predicate scratch)"); }
     if (any_sel) LC_HIP_C(hipMemcpy(d_sel, h_sel, words * 8, hipMemcpyHostToDevice));
-    rc = scan_eval_impl(ctx, scan, pred, d_sel, d_hit, d_valid, nullptr, nullptr, nullptr);
+    rc = scan_eval_impl(ctx, scan, pred, d_sel, d_hit, d_valid, nullptr, nullptr, nullptr, nullptr, nullptr, true);
     if (rc != LC_OK) { cleanup(); return rc; }
+    std::vector<uint8_t> backing(m, 0);
+    for (uint32_t k : scan->needs_backing) backing[k] = 1;
+    if (!scan->needs_backing.empty() && !statuses) { cleanup(); return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry needs its backing bytes"); }
     if (any_sel) {
         // the reference returns a BooleanArray of popcount(selection) rows: compress hit/valid by the selection
         LC_HIP_C(launch_mask_compress(d_hit, d_sel, scan->d_seg_offsets, m, d_chit, d_bits, nullptr));
@@ -1837,6 +1932,11 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     for (uint32_t k = 0; k < m; k++) {
         const uint64_t i = present_idx[k];
         const Entry& e = scan->meta[k];
+        if (backing[k]) {  // this entry's answer needs the full array (the others are complete)
+            statuses[i] = LC_NEEDS_BACKING;
+            out_lens[i] = 0;
+            continue;
+        }
         const size_t nb = bitmap_bytes(h_bits[k]);
         out_lens[i] = h_bits[k];
         if (out_values[i]) std::memcpy(out_values[i], h_hit + scan->seg_offsets[k], nb);
@@ -2115,6 +2215,14 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
         priv->buffers[0] = vb;
     }
     int64_t n_buffers = 2;
+    if (!e.is_str && scan->has_clamped) {
+        std::vector<uint32_t> needs;
+        const lc_status cs = clamp_unresolved_entries(ctx, scan, nullptr, 0, d_sel, nullptr, &needs);
+        if (cs != LC_OK || !needs.empty()) {
+            dfree();
+            return cs != LC_OK ? cs : fail(LC_NEEDS_BACKING, "a selected row of the clamp-squeezed entry is at or above the sentinel");
+        }
+    }
     if (!e.is_str) {
         ScanLaunch L{};
         L.n_entries = 1;
@@ -2195,6 +2303,12 @@ lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selecti
     const uint64_t capacity_rows = values_capacity_bytes / vw;
     hipStream_t st = static_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> g(scan->mu);
+    if (scan->has_clamped) {  // a selected sentinel row has no value in HBM (to_arrow_known_only -> None -> hydrate from disk)
+        const lc_status cs = clamp_unresolved_entries(ctx, scan, nullptr, 0, d_selection, st, &scan->needs_backing);
+        if (cs != LC_OK) return cs;
+        if (!scan->needs_backing.empty())
+            return fail(LC_NEEDS_BACKING, "a selected row of a clamp-squeezed entry is at or above the clamp sentinel");
+    }
     const size_t nblk = size_t(scan->n) * scan->bpe;
     const size_t need = nblk * 4 + fixed_gather_offsets_len(nblk) * 8 + 64;
     if (need > scan->needle_cap) {  // reuse the scan's scratch allocation
@@ -2378,6 +2492,86 @@ lc_status lc_squeeze_date(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, in
     for (uint64_t i = 0; i < n; i++) {
         auto it = ctx->entries.find(entry_ids[i]);
         if (it != ctx->entries.end()) it->second.nullable = scan->meta[i].nullable;
+    }
+    return LC_OK;
+    });
+}
+
+// LiquidPrimitiveArray::squeeze with IntegerSqueezePolicy::Clamp (primitive_array.rs:589-660): integer entries of at
+// least 8 bits per value are re-packed IN HBM at half their width; offsets at or above the sentinel 2^(W/2) - 1 are
+// stored as the sentinel.  Entries that do not qualify (narrower, all null, floats / decimals, already squeezed) are
+// left as they are.  *out_squeezed (optional) receives how many entries were squeezed.
+lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
+    if (out_squeezed) *out_squeezed = 0;
+    if (n == 0) return LC_OK;
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    // entries that qualify, grouped by lane width (a scan covers one lane type)
+    std::map<int, std::vector<uint64_t>> by_lane;
+    {
+        std::shared_lock<std::shared_mutex> g(ctx->mu);
+        for (uint64_t i = 0; i < n; i++) {
+            auto it = ctx->entries.find(entry_ids[i]);
+            if (it == ctx->entries.end()) return fail(LC_NOT_STAGED, "entry is not staged");
+            const Entry& e = it->second;
+            if (e.is_str || e.fd.kind != kKindInt || e.all_null || e.W < 8 || e.clamped || e.squeezed_field >= 0) continue;
+            by_lane[e.fd.lane_log2].push_back(entry_ids[i]);
+        }
+    }
+    for (auto& kv : by_lane) {
+        const std::vector<uint64_t>& ids = kv.second;
+        lc_scan* scan = nullptr;
+        lc_status rc = scan_create_impl(ctx, ids.size(), ids.data(), &scan, false);
+        if (rc != LC_OK) return rc;
+        std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
+        const uint64_t rows = scan->total_rows, m = scan->n;
+        const size_t vw = scan->meta[0].fd.value_width;
+        const size_t nblk = size_t(m) * scan->bpe;
+        // descriptors with reference 0: the gather then yields the packed-domain offsets themselves
+        std::vector<FixedDesc> zero_ref(m);
+        for (uint64_t i = 0; i < m; i++) { zero_ref[i] = scan->meta[i].fd; zero_ref[i].reference = 0; }
+        FixedDesc* d_descs0 = static_cast<FixedDesc*>(pool_alloc(ctx, m * sizeof(FixedDesc)));
+        uint8_t* d_vals = static_cast<uint8_t*>(pool_alloc(ctx, std::max<uint64_t>(rows, 1) * vw + 64));
+        uint8_t* d_scr = static_cast<uint8_t*>(pool_alloc(ctx, nblk * 4 + fixed_gather_offsets_len(nblk) * 8 + (m + 1) * 8 + 64));
+        struct Bufs {
+            lc_ctx* c; void* a; void* b; void* d;
+            ~Bufs() { (void)hipDeviceSynchronize(); pool_release(c, a); pool_release(c, b); pool_release(c, d); }
+        } bufs{ctx, d_descs0, d_vals, d_scr};
+        if (!d_descs0 || !d_vals || !d_scr) return fail(LC_ERR_OOM, "hipMalloc (clamp squeeze scratch)");
+        LC_HIP(hipMemcpy(d_descs0, zero_ref.data(), m * sizeof(FixedDesc), hipMemcpyHostToDevice));
+        uint64_t* d_bo = reinterpret_cast<uint64_t*>(d_scr);
+        uint64_t* d_eo = d_bo + fixed_gather_offsets_len(nblk);
+        uint32_t* d_bc = reinterpret_cast<uint32_t*>(d_eo + m + 1);
+        ScanLaunch L{};
+        L.n_entries = uint32_t(m);
+        L.blocks_per_entry = scan->bpe;
+        LC_HIP(launch_fixed_gather(d_descs0, scan->lane_log2, L, d_bc, d_bo, d_eo, d_vals, std::max<uint64_t>(rows, 1), nullptr));
+        std::vector<DevEncodeItem> items(m);
+        uint64_t row0 = 0;
+        for (uint64_t i = 0; i < m; i++) {
+            const Entry& e = scan->meta[i];
+            DevEncodeItem& it = items[i];
+            it.id = ids[i];
+            it.phys = e.phys;
+            it.vw = int(vw);
+            it.is_signed = false;  // the gathered values are unsigned offsets
+            it.entry_signed = e.fd.is_signed != 0;
+            it.n = e.len;
+            it.has_validity = e.fd.validity != nullptr;
+            it.d_values = d_vals + row0 * vw;
+            it.d_validity = e.fd.validity;
+            it.forced = true;
+            it.orig_W = e.W;
+            it.forced_W = std::max(e.W / 2, 1);   // "new squeezed bit width is half of the original" (:612)
+            it.clamp_max = (uint64_t(1) << it.forced_W) - 1;
+            it.entry_reference = e.fd.reference;
+            row0 += e.len;
+        }
+        rc = device_encode_and_register(ctx, items);
+        if (rc != LC_OK) return rc;
+        if (out_squeezed) *out_squeezed += m;
     }
     return LC_OK;
     });

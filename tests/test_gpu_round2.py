@@ -667,3 +667,91 @@ def test_squeezed_date_component_storage(gpu_cache, oracle):
         gpu_cache.insert(77, pa.array([1, 2, 3]))
         gpu_cache.squeeze_date([77], "year")
     assert ex.value.status == N.LC_UNSUPPORTED
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# clamp-squeezed integers: LiquidPrimitiveClampedArray, hybrid_primitive_array.rs
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,np_dtype,dtype,base", [("int32", np.int32, pa.int32(), -1_000_000),
+                                                       ("uint32", np.uint32, pa.uint32(), 1_000_000),
+                                                       ("int64", np.int64, pa.int64(), -(1 << 40)),
+                                                       ("int16", np.int16, pa.int16(), -20_000)])
+def test_clamp_squeeze_resolvable_and_unresolvable(gpu_cache, oracle, name, np_dtype, dtype, base):
+    """The structure of the reference's clamp_predicate_eval_*_resolvable_and_unresolvable tests
+    (hybrid_primitive_array.rs:935-1140): boundary = min + (2^(W/2) - 1); constants below it are decided from the
+    squeezed data alone and equal the full evaluation, constants at / above it need the backing bytes — unless no
+    selected valid row is clamped."""
+    lo = oracle
+    rng = np.random.default_rng(0x5173)
+    n = 5000
+    span = 1 << (14 if name == "int16" else 16)
+    vals = (rng.integers(0, span, size=n).astype(np.int64) + base).astype(np_dtype)
+    vals[:4] = [base, base + span - 1, base + 3, base + 200]
+    valid = rng.random(n) > 0.2
+    valid[:4] = True
+    arr = pa.array(vals, mask=~valid)
+    eid = lc.ParquetArrayID.new(40, 0, 1, 0)
+    gpu_cache.insert(eid, arr)
+    full = gpu_cache.entry_bytes(eid)                       # what the reference writes to disk before squeezing
+    W = gpu_cache.entry_info(eid).bit_width
+    assert W >= 8
+    assert gpu_cache.squeeze_clamp([eid]) == 1
+    info = gpu_cache.entry_info(eid)
+    assert info.bit_width == W // 2 and info.clamped_from_bit_width == W
+    boundary = int(vals[valid].min()) + (1 << (W // 2)) - 1
+    sel = rng.random(n) < 0.5
+    liquid = full
+
+    def check(op, k, selection):
+        expr = lc.LiquidExpr.try_new(op, int(k), dtype)
+        b = gpu_cache.eval_predicate(eid, expr)
+        got = (b.with_selection(selection) if selection is not None else b).read()
+        want = lo.eval_predicate(liquid, lo.OP_NAMES[op], int(k), selection)
+        gv = np.asarray(got.to_numpy(zero_copy_only=False), dtype=object)
+        gm = ~np.asarray(got.is_null().to_numpy(zero_copy_only=False), dtype=bool)
+        assert gm.tolist() == want.validity.tolist()
+        assert [bool(x) for x, m in zip(gv, gm) if m] == [bool(x) for x, m in zip(want.values, want.validity) if m], (op, k)
+
+    for op, k in (("eq", boundary - 1), ("ne", boundary - 1), ("lt", boundary), ("le", boundary - 1),
+                  ("gt", boundary - 1), ("ge", boundary), ("eq", base + 3), ("gt", base - 5)):
+        check(op, k, sel)
+        check(op, k, None)
+    for op, k in (("eq", boundary), ("ne", boundary), ("lt", boundary + 1), ("le", boundary), ("gt", boundary + 1),
+                  ("ge", boundary + 1)):
+        with pytest.raises(lc.LiquidCacheError) as ex:
+            gpu_cache.eval_predicate(eid, lc.LiquidExpr.try_new(op, int(k), dtype)).with_selection(sel).read()
+        assert ex.value.status == N.LC_NEEDS_BACKING, (op, k)
+    # a selection without clamped rows is decided whatever the constant; reads of such rows are served too
+    low = valid & (vals.astype(np.int64) < boundary)
+    assert low.sum() > 3
+    check("ge", boundary + 7, low)
+    check("eq", boundary, low)
+    got = gpu_cache.get(eid).with_selection(low).read()
+    assert got.equals(arr.filter(pa.array(low)))
+    with pytest.raises(lc.LiquidCacheError) as ex:
+        gpu_cache.get(eid).read()
+    assert ex.value.status == N.LC_NEEDS_BACKING
+    with pytest.raises(lc.LiquidCacheError) as ex:
+        gpu_cache.entry_bytes(eid)
+    assert ex.value.status == N.LC_NEEDS_BACKING
+    # the batch call reports the entry that needs its backing and still answers the others
+    eid2 = lc.ParquetArrayID.new(40, 0, 1, 1)
+    gpu_cache.insert(eid2, arr)
+    lib, ctx = gpu_cache._lib, gpu_cache.handle
+    ids = (C.c_uint64 * 2)(int(eid), int(eid2))
+    pred = lc.LiquidExpr.try_new("eq", int(boundary), dtype).as_predicate()
+    outs = [np.zeros(n // 8 + 16, np.uint8) for _ in range(4)]
+    ov = (C.c_void_p * 2)(outs[0].ctypes.data, outs[1].ctypes.data)
+    om = (C.c_void_p * 2)(outs[2].ctypes.data, outs[3].ctypes.data)
+    lens, nullable, statuses = (C.c_uint32 * 2)(), (C.c_int32 * 2)(), (C.c_int32 * 2)()
+    rc = lib.lc_eval_predicate_batch(ctx, 2, ids, C.byref(pred), None, ov, om, lens, nullable, statuses)
+    assert rc == N.LC_OK and list(statuses) == [N.LC_NEEDS_BACKING, N.LC_OK] and lens[1] == n
+    want = lo.eval_predicate(liquid, lo.EQ, int(boundary), None)
+    assert np.unpackbits(outs[1], bitorder="little")[:n].astype(bool)[want.validity].tolist() == want.values[want.validity].tolist()
+    # restoring the backing bytes brings the full entry back
+    gpu_cache.stage([eid], [full], data_types=[dtype])
+    assert gpu_cache.entry_info(eid).clamped_from_bit_width == 0 and gpu_cache.get(eid).read().equals(arr)
+    # narrow / non-integer entries are left alone
+    gpu_cache.insert(7, pa.array(rng.integers(0, 100, size=1000)))
+    gpu_cache.insert(8, pa.array(rng.normal(size=1000)))
+    assert gpu_cache.squeeze_clamp([7, 8]) == 0
