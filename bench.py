@@ -635,8 +635,9 @@ def main():
     if args.rows_total:
         # strong scaling: contiguous, batch-aligned row ranges per rank (liquid_cache_amd.sharding.assign_row_ranges
         # over equally weighted batches gives exactly this split)
+        from liquid_cache_amd.sharding import contiguous_batch_range
         total_batches = (args.rows_total + args.batch_size - 1) // args.batch_size
-        b0, b1 = total_batches * rank // world, total_batches * (rank + 1) // world
+        b0, b1 = contiguous_batch_range(total_batches, rank, world)
         args.rows = min(args.rows_total, b1 * args.batch_size) - b0 * args.batch_size
         scaling = "strong"
 

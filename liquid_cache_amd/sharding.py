@@ -47,6 +47,14 @@ def assign_row_ranges(entry_ids: Sequence[int], world_size: int,
     return shards
 
 
+def contiguous_batch_range(total_batches: int, rank: int, world_size: int):
+    """[first, last) batch of `rank` when a table of `total_batches` equally weighted batches is split into contiguous,
+    batch-aligned row ranges (what assign_row_ranges gives for equal weights) — bench.py's strong-scaling split."""
+    if not 0 <= rank < world_size:
+        raise ValueError("rank out of range")
+    return total_batches * rank // world_size, total_batches * (rank + 1) // world_size
+
+
 def rank_of_entry(entry_id: int, shards: Sequence[Sequence[int]]) -> int:
     key = row_range_key(entry_id)
     for r, s in enumerate(shards):

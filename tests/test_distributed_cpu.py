@@ -122,3 +122,90 @@ def test_pipelined_count_all_reduce(tmp_path, world):
     last, before = map(int, open(out).read().split(","))
     ranks = sum(r + 1 for r in range(world))
     assert last == 1000 * 6 * world + ranks and before == 1000 * 5 * world + ranks
+
+
+def test_strong_scaling_split_covers_the_table_once():
+    """bench.py --rows-total: contiguous batch-aligned ranges per rank, together exactly the table; the same split
+    assign_row_ranges produces for equally weighted batches."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import liquid_cache_amd as lc
+    from liquid_cache_amd import sharding as sh
+    for total in (1, 7, 8, 12_207, 73_247):
+        for world in (1, 2, 3, 8):
+            ranges = [sh.contiguous_batch_range(total, r, world) for r in range(world)]
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+            assert all(ranges[i][1] == ranges[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in ranges]
+            assert max(sizes) - min(sizes) <= 1
+    ids = [lc.ParquetArrayID.new(0, b // 54, 10, b % 54) for b in range(1000)]
+    shards = sh.assign_row_ranges(ids, 8)
+    assert [len(s) for s in shards] == [b - a for a, b in (sh.contiguous_batch_range(1000, r, 8) for r in range(8))]
+
+
+def _q6_worker(rank, world, port, out_path):
+    """Config 4 sharded: lineitem-shaped columns l_shipdate / l_discount / l_quantity, row-range shards, the five Q6
+    conjuncts chained per owned batch (oracle masks stand in for lc_scan_eval), COUNT(*) all-reduced and the final
+    masks all-gathered."""
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import liquid_oracle as lo
+    import liquid_cache_amd as lc
+    from liquid_cache_amd import sharding as sh
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ship, disc, qty = _make_lineitem()
+    nb = len(ship)
+    ids = [lc.ParquetArrayID.new(0, b // 4, col, b % 4) for b in range(nb) for col in (10, 6, 4)]
+    mine = set(sh.assign_row_ranges(ids, world)[rank])
+    count, words = 0, []
+    for b in range(nb):
+        owned = [int(lc.ParquetArrayID.new(0, b // 4, col, b % 4)) in mine for col in (10, 6, 4)]
+        assert all(owned) or not any(owned)       # the three columns of a row range live on one rank
+        if not owned[0]:
+            continue
+        l_ship = lo.encode_primitive(lo.PHYS["date32"], ship[b])
+        l_disc = lo.encode_decimal([int(x) for x in disc[b]], precision=15, scale=2)
+        l_qty = lo.encode_decimal([int(x) for x in qty[b]], precision=15, scale=2)
+        sel = np.ones(len(ship[b]), bool)
+        for liquid, op, lit in ((l_ship, lo.GE, 8766), (l_ship, lo.LT, 9131), (l_disc, lo.GE, 5), (l_disc, lo.LE, 7),
+                                (l_qty, lo.LT, 2400)):
+            r = lo.eval_predicate(liquid, op, lit, sel)          # BooleanArray of popcount(sel) rows ...
+            sel = lo.and_then(sel, r.filter_mask())              # ... re-expanded: boolean_buffer_and_then
+        count += int(sel.sum())
+        seg = np.zeros(((len(sel) + 63) // 64) * 8, np.uint8)
+        packed = np.packbits(sel, bitorder="little")
+        seg[: len(packed)] = packed
+        words.append(seg.view(np.int64))
+    total = sh.all_reduce_count(torch.tensor([count], dtype=torch.int64))
+    gathered = sh.all_gather_mask_segments(torch.from_numpy(np.concatenate(words)) if words else torch.zeros(0, dtype=torch.int64))
+    if rank == 0:
+        np.save(out_path, np.concatenate([g.numpy() for g in gathered]))
+        with open(out_path + ".count", "w") as f:
+            f.write(str(int(total.item())))
+    dist.destroy_process_group()
+
+
+def _make_lineitem(n_batches=9, rows=900, seed=11):
+    rng = np.random.default_rng(seed)
+    lens = [rows if b < n_batches - 1 else rows // 2 for b in range(n_batches)]
+    ship = [rng.integers(8036, 10561, size=n, dtype=np.int32) for n in lens]       # 1992-01-02 .. 1998-12-01
+    disc = [rng.integers(0, 11, size=n, dtype=np.int64) for n in lens]
+    qty = [rng.integers(1, 51, size=n, dtype=np.int64) * 100 for n in lens]
+    return ship, disc, qty
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_tpch_q6_sharded_by_row_range(tmp_path, world):
+    out = str(tmp_path / "q6.npy")
+    mp.spawn(_q6_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    ship, disc, qty = _make_lineitem()
+    want_count, segs = 0, []
+    for b in range(len(ship)):
+        m = (ship[b] >= 8766) & (ship[b] < 9131) & (disc[b] >= 5) & (disc[b] <= 7) & (qty[b] < 2400)
+        want_count += int(m.sum())
+        seg = np.zeros(((len(m) + 63) // 64) * 8, np.uint8)
+        p = np.packbits(m, bitorder="little")
+        seg[: len(p)] = p
+        segs.append(seg.view(np.int64))
+    assert int(open(out + ".count").read()) == want_count > 0
+    assert np.load(out).tolist() == np.concatenate(segs).tolist()
