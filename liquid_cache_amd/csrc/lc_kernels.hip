@@ -568,13 +568,13 @@ __device__ __forceinline__ uint64_t range_ballot(uint32_t t, uint32_t lo_t, uint
     else return __ballot(t <= bound_t);
 }
 
-// u32 lanes: one step = row R of blocks A (lanes 0..31) and B (lanes 32..63)
-template <int W, bool kTwoSided, uint32_t R, int NW>
+// u32 lanes: one step = row R of blocks A (lanes 0..31) and B (lanes 32..63) of block pair P (words parked in lanes 32 P ..)
+template <int W, bool kTwoSided, uint32_t P, uint32_t R, int NW>
 __device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t bound_t, uint32_t& X, uint32_t& Y) {
     const uint64_t b = range_ballot<kTwoSided>(field_top<W, R, NW>(w), lo_t, bound_t);
     const uint32_t blo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b))));
     const uint32_t bhi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32))));
-    constexpr uint32_t word = 2u * (R & 7u) + ((R >> 3) & 1u);
+    constexpr uint32_t word = 32u * P + 2u * (R & 7u) + ((R >> 3) & 1u);
     if constexpr ((R >> 4) == 0) {
         X = writelane_c<word>(blo, X);
         X = writelane_c<16u + word>(bhi, X);
@@ -583,10 +583,10 @@ __device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_
         Y = writelane_c<16u + word>(bhi, Y);
     }
 }
-template <int W, bool kTwoSided, int NW, uint32_t... RS>
+template <int W, bool kTwoSided, uint32_t P, int NW, uint32_t... RS>
 __device__ __forceinline__ void reg_steps32(std::integer_sequence<uint32_t, RS...>, const uint32_t (&w)[NW], uint32_t lo_t,
                                             uint32_t bound_t, uint32_t& X, uint32_t& Y) {
-    (reg_step32<W, kTwoSided, RS, NW>(w, lo_t, bound_t, X, Y), ...);
+    (reg_step32<W, kTwoSided, P, RS, NW>(w, lo_t, bound_t, X, Y), ...);
 }
 // u16 / u64 lanes: one step = one whole 64-row word of block B of the pass (its words are parked in lanes 16*B ..)
 template <int W, bool kTwoSided, uint32_t B, uint32_t R, int NW>
@@ -683,12 +683,16 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     const uint32_t nblocks = (len + 1023u) >> 10;
     const uint32_t lo_t = lo << (32 - W);
     const uint32_t bound_t = (bound << (32 - W)) | (W == 32 ? 0u : ((1u << ((32 - W) & 31)) - 1u));
+    // A pass covers kPairs pairs of blocks: very narrow widths (<= 6 bits, few registers per block) take four blocks at a
+    // time — all 64 lanes own a mask word, the loads of both pairs are in flight before the first compare, and the
+    // per-pass bookkeeping is paid half as often; wider ones keep to one pair (register budget).
+    constexpr uint32_t kPairs = W <= 6 ? 2u : 1u;
     uint32_t count = 0;
-    for (uint32_t blk0 = 0; blk0 < nblocks; blk0 += 2u) {
-        // selection & validity: lane i (< 32) owns mask word 16*blk0 + i of the entry
+    for (uint32_t blk0 = 0; blk0 < nblocks; blk0 += 2u * kPairs) {
+        // selection & validity: lane i (< 32 kPairs) owns mask word 16*blk0 + i of the entry
         const uint32_t widx = blk0 * 16u + uint32_t(lane);
         uint64_t act = 0;
-        const bool own = uint32_t(lane) < 32u && widx < nwords_entry;
+        const bool own = uint32_t(lane) < 32u * kPairs && widx < nwords_entry;
         if (own) {
             uint64_t tail = ~uint64_t(0);
             if (widx == nwords_entry - 1 && (len & 63u)) tail = (uint64_t(1) << (len & 63u)) - 1;
@@ -697,28 +701,61 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
             act = all_null ? 0 : (selw & vw & tail);  // all-null entries carry no validity buffer: no row is valid
         }
         uint64_t result = 0;
-        if (__ballot(act != 0) != 0) {  // passes without a selected valid row do not touch their packed data
+        const uint64_t am = __ballot(act != 0);
+        if (am != 0) {  // block pairs without a selected valid row do not touch their packed data
             if (constant >= 0) {
                 result = constant ? act : 0;
             } else {
-                // (an entry with an odd number of blocks has no block B in its last pass: block A is read again, its mask
-                // words lie outside the entry and are never stored)
-                const uint32_t b_off = (blk0 + 1u < nblocks) ? 128u * uint32_t(W) : 0u;
-                const uint8_t* base = packed + uint64_t(blk0) * 128u * uint32_t(W);
+                const bool go0 = uint32_t(am) != 0, go1 = kPairs > 1 && uint32_t(am >> 32) != 0;
+                // (a pair whose second block lies past the entry reads its first block again: those mask words are
+                // outside the entry and are never stored)
+                const uint8_t* base0 = packed + uint64_t(blk0) * 128u * uint32_t(W);
+                const uint8_t* base1 = packed + uint64_t(blk0 + 2u) * 128u * uint32_t(W);
+                const uint32_t off0 = (blk0 + 1u < nblocks) ? 128u * uint32_t(W) : 0u;
+                const uint32_t off1 = (blk0 + 3u < nblocks) ? 128u * uint32_t(W) : 0u;
                 uint32_t X = 0, Y = 0;
                 if constexpr (TB == 32) {
-                    // word k of FastLanes lane l of block A|B: one 128-byte line per block and k
-                    uint32_t w[NW];
-                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base + (uint32_t(lane) >> 5) * b_off) + (uint32_t(lane) & 31u);
+                    // word k of FastLanes lane l of block A|B of a pair: one 128-byte line per block and k
+                    uint32_t w0[NW], w1[NW];
+                    const uint32_t half = uint32_t(lane) >> 5, l = uint32_t(lane) & 31u;
+                    if (go0) {
+                        const uint32_t* p = reinterpret_cast<const uint32_t*>(base0 + half * off0) + l;
 #pragma unroll
-                    for (int k = 0; k < NW; k++) w[k] = as_global(p)[k * 32];
-                    reg_steps32<W, kTwoSided, NW>(std::make_integer_sequence<uint32_t, 32>{}, w, lo_t, bound_t, X, Y);
+                        for (int k = 0; k < NW; k++) w0[k] = as_global(p)[k * 32];
+                    }
+                    if constexpr (kPairs > 1) {
+                        if (go1) {
+                            const uint32_t* p = reinterpret_cast<const uint32_t*>(base1 + half * off1) + l;
+#pragma unroll
+                            for (int k = 0; k < NW; k++) w1[k] = as_global(p)[k * 32];
+                        }
+                    }
+                    if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, w0, lo_t, bound_t, X, Y);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the second pair's steps from being hoisted (register pressure)
+                    if constexpr (kPairs > 1)
+                        if (go1) reg_steps32<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 32>{}, w1, lo_t, bound_t, X, Y);
                 } else {
-                    uint32_t wa[NW], wb[NW];  // both blocks' loads are in flight before the first compare
-                    load_stream16<U, W, NW>(base, lane, wa);
-                    load_stream16<U, W, NW>(base + b_off, lane, wb);
-                    reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, wa, lo_t, bound_t, X, Y);
-                    reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, wb, lo_t, bound_t, X, Y);
+                    uint32_t wa[NW], wb[NW], wc[NW], wd[NW];  // every block's loads are in flight before the first compare
+                    if (go0) {
+                        load_stream16<U, W, NW>(base0, lane, wa);
+                        load_stream16<U, W, NW>(base0 + off0, lane, wb);
+                    }
+                    if constexpr (kPairs > 1) {
+                        if (go1) {
+                            load_stream16<U, W, NW>(base1, lane, wc);
+                            load_stream16<U, W, NW>(base1 + off1, lane, wd);
+                        }
+                    }
+                    if (go0) {
+                        reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, wa, lo_t, bound_t, X, Y);
+                        reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, wb, lo_t, bound_t, X, Y);
+                    }
+                    if constexpr (kPairs > 1) {
+                        if (go1) {
+                            reg_steps16<W, kTwoSided, 2, NW>(std::make_integer_sequence<uint32_t, 16>{}, wc, lo_t, bound_t, X, Y);
+                            reg_steps16<W, kTwoSided, 3, NW>(std::make_integer_sequence<uint32_t, 16>{}, wd, lo_t, bound_t, X, Y);
+                        }
+                    }
                 }
                 result = ((uint64_t(X) | (uint64_t(Y) << 32)) ^ flip) & act;
             }
