@@ -732,6 +732,8 @@ def main():
     hits = int(reducer.last().item())
     # the fused total must be the sum of the per-entry counts of the same predicate (separate launch, plain reduction)
     scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
+    if os.environ.get("LC_DUMP_COUNTS"):  # kernel-instrumentation aid (profiling builds: make TIMING=1 / ABLATION=1)
+        np.save(os.environ["LC_DUMP_COUNTS"], counts.cpu().numpy())
     local_hits = int(counts.sum(dtype=torch.int64).item())
     lh = torch.tensor([local_hits], dtype=torch.int64, device="cuda")
     if world > 1:

@@ -1323,7 +1323,7 @@ __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) 
 // kInstr: the byte-accounting pass of lc_scan_traffic_model (per-entry candidate / kernel bytes).  A separate
 // instantiation, so that the accounting costs the shipped kernel nothing and a kernel trace keeps the two apart.
 template <bool kBytes, bool kSub, bool kMany, bool kInstr>
-__global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
+__global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred(const StrDesc* __restrict__ descs,
                                                            const DevSymtab* __restrict__ symtabs, StrPred pred,
                                                            ScanLaunch L, uint32_t dres_bytes, uint32_t cmask_bytes) {
     // dynamic LDS: [automaton (u16 row addresses)][role table]   (kSub with a short needle only)
