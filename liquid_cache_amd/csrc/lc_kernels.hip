@@ -1151,7 +1151,12 @@ __device__ __forceinline__ bool like_walk_global(const uint8_t* __restrict__ fss
 // LC_DEBUG_FLAGS bits 16..19 and reported in place of the per-entry counts (scripts/abl.sh).
 #ifdef LC_KERNEL_TIMING
 #define LC_TM_DECL uint64_t tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
-#define LC_TM(i, dep) tm[i] = __builtin_readcyclecounter() + ((dep) & 0)
+#define LC_TM(i, dep)                                                   \
+    do {                                                                \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        tm[i] = __builtin_readcyclecounter();                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              \
+    } while (0)
 #else
 #define LC_TM_DECL
 #define LC_TM(i, dep)
@@ -1323,7 +1328,7 @@ __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) 
 // kInstr: the byte-accounting pass of lc_scan_traffic_model (per-entry candidate / kernel bytes).  A separate
 // instantiation, so that the accounting costs the shipped kernel nothing and a kernel trace keeps the two apart.
 template <bool kBytes, bool kSub, bool kMany, bool kInstr>
-__global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred(const StrDesc* __restrict__ descs,
+__global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
                                                            const DevSymtab* __restrict__ symtabs, StrPred pred,
                                                            ScanLaunch L, uint32_t dres_bytes, uint32_t cmask_bytes) {
     // dynamic LDS: [automaton (u16 row addresses)][role table]   (kSub with a short needle only)
@@ -1332,6 +1337,9 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
 #ifdef LC_ABLATION
     const uint64_t rt_kernel = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef LC_KERNEL_TIMING
+    const uint64_t tm_kernel = __builtin_readcyclecounter();
 #endif
 
     const int lane = lane_id();
@@ -1361,22 +1369,33 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
     // This workgroup's entries: a precomputed range of at most four entries that share one symbol table (so the LDS
     // automaton serves all of them), or — persistent / very large launches — an even split over the counter groups.
     const uint32_t wg_group = blockIdx.x % L.work_groups;
-    uint32_t group_begin, group_end;
-    if (L.d_wg_ranges) {
-        group_begin = L.d_wg_ranges[2u * wg_group];
-        group_end = L.d_wg_ranges[2u * wg_group + 1u];
+    uint32_t group_begin, group_end, slot0;
+    // A record holds at most one entry per wave: wave w takes entry w of the range, and its descriptor comes from the
+    // record (address known from blockIdx: fetched together with the range header).  The draw (a returning far atomic,
+    // ~1-2 us before the wave can even load its descriptor) is only paid by launches without records.
+    const bool static_draw = L.d_wg_ranges != nullptr;
+    const StrWgRecord* rec = L.d_wg_ranges + (static_draw ? wg_group : 0u);
+    StrDesc d_rec;
+    if (static_draw) {
+        group_begin = rec->begin;
+        group_end = rec->end;
+        slot0 = rec->symtab_slot;
+        d_rec = rec->d[wave];
     } else {
+        d_rec = StrDesc{};
         const uint32_t per_group = (L.n_entries + L.work_groups - 1u) / L.work_groups;
         group_begin = wg_group * per_group;
         group_end = min(L.n_entries, group_begin + per_group);
+        slot0 = L.uniform_slot >= 0 ? uint32_t(L.uniform_slot) : descs[min(group_begin, L.n_entries - 1)].symtab_slot;
     }
-    const uint32_t slot0 = L.uniform_slot >= 0 ? uint32_t(L.uniform_slot)
-                                               : descs[min(group_begin, L.n_entries - 1)].symtab_slot;
     if (lds_tbl) {
-        // verbatim copy of the image k_str_automata built for this symbol table
-        const GlobalPtr<u32x4> src = reinterpret_cast<GlobalPtr<u32x4>>(
-            as_global(pred.automata) + size_t(slot0) * pred.automaton_stride + automaton_u8_bytes(nl));
-        for (uint32_t i = tid; i < tbl_bytes / 16u; i += kThreads) reinterpret_cast<u32x4*>(smem)[i] = src[i];
+        // Verbatim copy of the image k_str_automata built for this symbol table, global -> LDS DMA (1 KB per wave
+        // and step; the image is a whole number of KB).  Nothing waits for it here: the table is first needed by the
+        // candidate walk, and the barrier that publishes it sits there (tbl_synced), so the copy's latency overlaps
+        // the entry's descriptor and signature loads.
+        const uint8_t* src = pred.automata + size_t(slot0) * pred.automaton_stride + automaton_u8_bytes(nl);
+        for (uint32_t c = wave * 1024u; c < tbl_bytes; c += kWavesPerBlock * 1024u)
+            async_copy16(src + c + uint32_t(lane) * 16u, smem + c);
     }
     // needle bytes: kernel argument (short needles) or the device copy; staged in LDS when they fit
     const bool needle_in_lds = !kSub && nl <= kNeedleLds;
@@ -1384,7 +1403,8 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
         for (uint32_t i = tid; i < nl; i += kThreads)
             needle_lds[i] = nl <= uint32_t(kInlineNeedle) ? pred.needle_inline[i] : pred.needle[i];
     const uint8_t* np = needle_in_lds ? needle_lds : pred.needle;
-    __syncthreads();
+    bool tbl_synced = !kSub;  // wave uniform: this wave has passed the barrier that publishes the LDS automaton
+    if (!kSub) __syncthreads();
 
     // Persistent waves: the workgroup's setup above is paid once; every wave then draws entries on its own (entries
     // differ in cost, a static split leaves a long tail).  One hot counter would serialise ~16K far atomics (measured:
@@ -1393,10 +1413,6 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
     // zeroes the group's counters for the next launch.
     uint32_t* work = L.d_work + wg_group * 16u;
     uint64_t wave_hits = 0;  // fused COUNT(*): hits of the entries this wave evaluated (lane 0)
-    // A precomputed range holds at most one entry per wave: wave w simply takes entry w of the range.  The draw (a
-    // returning far atomic, ~1-2 us before the wave can even load its descriptor) is only paid by launches that hand a
-    // workgroup more entries than it has waves.
-    const bool static_draw = L.d_wg_ranges != nullptr && group_end - group_begin <= uint32_t(kWavesPerBlock);
     for (uint32_t draw = 0;; draw++) {
         uint32_t entry = 0;
         if (static_draw) {
@@ -1411,8 +1427,14 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
     const uint64_t rt_start = __builtin_amdgcn_s_memrealtime();
 #endif
     LC_TM_DECL;
+#ifdef LC_KERNEL_TIMING
+    uint32_t tm_words = 0, tm_cands = 0;
+#endif
     LC_TM(0, 0);
-    const StrDesc d = descs[entry];
+    StrDesc d_sel;
+    if (static_draw) d_sel = d_rec;
+    else d_sel = descs[entry];
+    const StrDesc& d = d_sel;
     const DevSymtab& st = symtabs[d.symtab_slot];
     // shared LDS copy of the automaton when this entry uses the workgroup's symbol table, else the global one
     const bool tbl_in_lds = lds_tbl && d.symtab_slot == slot0;
@@ -1620,6 +1642,11 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
 
         // ---- phase B: walk the candidate list ----
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (kSub && !tbl_synced) {  // every wave of the workgroup passes exactly one of these (here or after the loop)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the DMA has landed in LDS
+            __syncthreads();
+            tbl_synced = true;
+        }
         LC_TM(2, 0);
         const uint32_t n_walk = LC_ABL(pred.debug_flags & 1) ? 0u : n_cand;
         for (uint32_t jb = 0; jb < n_walk; jb += kWave) {
@@ -1666,6 +1693,10 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
                 const uint32_t off = incl - words;
                 const uint32_t total = read_lane(incl, kWave - 1);
                 hitflag[lane] = 0;
+#ifdef LC_KERNEL_TIMING
+                tm_words += total;
+                tm_cands += min(n_walk - jb, uint32_t(kWave));
+#endif
                 uint32_t carry_state = row0;
                 for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
                     // owner of task t = t0 + lane: the last candidate whose first word is at or before t
@@ -1686,9 +1717,9 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
                     const uint32_t p = o_start + 8u * k;
                     const uint32_t rem = live && p < o_stop ? o_stop - p : 0u;
                     uint64_t w = 0;
+                    LC_TM(4, rem);
                     if (rem) w = load_unaligned<uint64_t>(d.fsst + p);
                     const uint32_t lo = uint32_t(w), hi = uint32_t(w >> 32);
-                    LC_TM(4, lo);
                     const bool first = k == 0;  // first word of its value (a value continuing from the previous pass
                                                 // has k > 0 in lane 0 and takes the carried state)
                     uint32_t x[8];
@@ -1843,6 +1874,9 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
         for (int i = 1; i <= 8; i++)
             if (tsel == uint32_t(i)) c = tm[i] > tm[i - 1] && tm[i - 1] ? tm[i] - tm[i - 1] : 0;
         if (tsel == 9) c = tm[8] - tm[0];
+        if (tsel == 10) c = tm[0] - tm_kernel;  // workgroup prologue (first entry of the wave)
+        if (tsel == 11) c = tm_words;           // 8-byte words walked
+        if (tsel == 12) c = tm_cands;           // candidates walked
 #endif
         if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(c);
     }
@@ -1867,6 +1901,11 @@ __global__ __launch_bounds__(kThreads, (kMany || !kSub) ? 4 : 6) void k_str_pred
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }  // entries
+    if (kSub && !tbl_synced) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ^ the barrier the other waves of the workgroup pass before their walk
     if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, gridDim.x * kWavesPerBlock, wave_hits);
     if (lane == 0 && !static_draw) {
         // workgroups of this group: blockIdx = wg_group, wg_group + work_groups, ...

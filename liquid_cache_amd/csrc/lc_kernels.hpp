@@ -75,6 +75,17 @@ struct alignas(16) StrDesc {
 };
 static_assert(sizeof(StrDesc) == 112, "StrDesc layout");
 
+// What one workgroup of k_str_pred works on: a run of at most four consecutive entries that share a symbol table (one
+// per wave), with a COPY of their descriptors.  The record's address follows from blockIdx alone, so a wave fetches the
+// range header and its own descriptor in one round trip instead of range -> descriptor one after the other.
+struct alignas(16) StrWgRecord {
+    uint32_t begin, end;   // entry range [begin, end), end - begin <= 4
+    uint32_t symtab_slot;  // of all its entries
+    uint32_t pad;
+    StrDesc d[4];          // descriptors of entries begin .. end-1 (zero filled beyond)
+};
+static_assert(sizeof(StrWgRecord) == 464, "StrWgRecord layout");
+
 // Bigram Bloom signature (device-side acceleration index, built at staging for entries that carry fingerprints):
 // bit h(a,b) of a 128-bit set for every pair of adjacent bytes of the dictionary value.  A value can only contain
 // `needle` if it has every needle bigram — a necessary condition exactly like the reference's 32-bucket byte
@@ -163,7 +174,7 @@ struct ScanLaunch {
                              // launches (self-resetting)
     uint32_t work_groups;    // byte views: number of counter groups used by this launch (set by the launcher)
     uint32_t n_wg_ranges;    // byte views: entries of d_wg_ranges (0: entries are split evenly over the groups)
-    const uint32_t* d_wg_ranges;  // byte views: {begin, end} entry range per workgroup; a range never mixes symbol tables
+    const StrWgRecord* d_wg_ranges;  // byte views: one record per workgroup; a range never mixes symbol tables
     uint32_t many_candidates;     // byte views: some entry has no bigram signature index (LIKE walks whole dictionaries)
     // Fused COUNT(*) of the launch (optional): every wave adds the hits of its entries to a sharded accumulator and the
     // wave that arrives last writes the total to *d_total_out — no separate reduction kernel, no memset between launches.

@@ -140,7 +140,7 @@ struct lc_scan {
     size_t automata_symtabs = 0;           // ... over this many symbol tables (0: nothing cached)
     uint8_t* d_needle = nullptr;
     size_t needle_cap = 0;
-    uint32_t* d_wg_ranges = nullptr;  // byte views: {begin, end} per workgroup (<= 4 entries, one symbol table each)
+    StrWgRecord* d_wg_ranges = nullptr;  // byte views: one record per workgroup (<= 4 entries of one symbol table)
     uint32_t n_wg_ranges = 0;
     uint8_t* d_gather = nullptr;  // scratch of lc_scan_gather_bytes_async (grow only)
     size_t gather_cap = 0;
@@ -1475,20 +1475,25 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
                                             "reference requires %needle% on SubstringSearch columns)");
     std::lock_guard<std::mutex> g(s->mu);
     if (!s->d_wg_ranges) {
-        // workgroup ranges: consecutive entries, at most four, never across a symbol-table change (row-group boundary)
-        std::vector<uint32_t> r;
+        // workgroup records: consecutive entries, at most four, never across a symbol-table change (row-group boundary)
+        std::vector<StrWgRecord> r;
         uint32_t begin = 0;
         for (uint32_t i = 1; i <= s->n; i++) {
             if (i == s->n || i - begin == 4 || s->meta[i].sd.symtab_slot != s->meta[begin].sd.symtab_slot) {
-                r.push_back(begin);
-                r.push_back(i);
+                StrWgRecord rec;
+                std::memset(&rec, 0, sizeof(rec));
+                rec.begin = begin;
+                rec.end = i;
+                rec.symtab_slot = s->meta[begin].sd.symtab_slot;
+                for (uint32_t k = begin; k < i; k++) rec.d[k - begin] = s->meta[k].sd;
+                r.push_back(rec);
                 begin = i;
             }
         }
-        s->n_wg_ranges = uint32_t(r.size() / 2);
-        s->d_wg_ranges = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(r.size(), 2) * 4));
-        if (!s->d_wg_ranges) return fail(LC_ERR_OOM, "hipMalloc (scan workgroup ranges)");
-        LC_HIP(hipMemcpyAsync(s->d_wg_ranges, r.data(), r.size() * 4, hipMemcpyHostToDevice, stream));
+        s->n_wg_ranges = uint32_t(r.size());
+        s->d_wg_ranges = static_cast<StrWgRecord*>(pool_alloc(ctx, std::max<size_t>(r.size(), 1) * sizeof(StrWgRecord)));
+        if (!s->d_wg_ranges) return fail(LC_ERR_OOM, "hipMalloc (scan workgroup records)");
+        LC_HIP(hipMemcpyAsync(s->d_wg_ranges, r.data(), r.size() * sizeof(StrWgRecord), hipMemcpyHostToDevice, stream));
         LC_HIP(hipStreamSynchronize(stream));  // `r` is a local
     }
     L.d_wg_ranges = s->d_wg_ranges;
