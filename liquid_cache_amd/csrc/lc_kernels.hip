@@ -960,7 +960,8 @@ __device__ __forceinline__ T load_unaligned(const uint8_t* p) {
     return v;
 }
 
-__device__ __forceinline__ uint32_t str_offset(const StrDesc& d, uint32_t i) {
+template <typename D>
+__device__ __forceinline__ uint32_t str_offset(const D& d, uint32_t i) {
     int32_t r;
     if (d.offset_bytes == 1) r = reinterpret_cast<const int8_t*>(d.residuals)[i];
     else if (d.offset_bytes == 2) r = reinterpret_cast<const int16_t*>(d.residuals)[i];
@@ -970,7 +971,8 @@ __device__ __forceinline__ uint32_t str_offset(const StrDesc& d, uint32_t i) {
 
 // offsets of dictionary entries i and i+1 with ONE (unaligned, 8-byte) load: the residual width only selects shifts,
 // so there is no branch between the load and its use (sections are padded, reading a few bytes past is safe)
-__device__ __forceinline__ void str_offset_pair(const StrDesc& d, uint32_t i, uint32_t& start, uint32_t& stop) {
+template <typename D>
+__device__ __forceinline__ void str_offset_pair(const D& d, uint32_t i, uint32_t& start, uint32_t& stop) {
     const uint32_t ob = d.offset_bytes;  // 1, 2 or 4
     const uint64_t v = load_unaligned<uint64_t>(d.residuals + size_t(i) * ob);
     const uint32_t sh = 32u - 8u * ob;
@@ -980,7 +982,6 @@ __device__ __forceinline__ void str_offset_pair(const StrDesc& d, uint32_t i, ui
     stop = uint32_t(d.slope) * (i + 1u) + uint32_t(d.intercept) + uint32_t(r1);
 }
 
-__device__ const uint64_t kAllOnesWord = ~uint64_t(0);
 
 // byte stream over global memory with aligned 4-byte loads
 struct ByteReader {
@@ -1184,6 +1185,14 @@ constexpr uint32_t kMaxByteTable = 4096;  // dictionary results as one byte per 
 //      (absorbing state) is recorded and not propagated.
 // An entry's ~9 candidates x ~6 words fit one pass of the wave: the chain is ~16-24 lookups instead of ~90 per value.
 // ------------------------------------------------------------------------------------------------------------------
+// compressed bytes per lane and pass of the lane-parallel walk.  An entry's ~9 candidates are ~80 8-byte words, so
+// 16-byte tasks would make one pass the usual case — measured: no gain (the kernel is bound by instruction issue, not by
+// the extra round trip), and the second word's registers cost a wave of occupancy (35 -> 42 us).
+#ifndef LC_WALK_TASK_WORDS
+#define LC_WALK_TASK_WORDS 1
+#endif
+constexpr int kTaskWords = LC_WALK_TASK_WORDS;
+constexpr uint32_t kTaskBytes = 8u * kTaskWords;
 __device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], uint32_t rem) {
     const uint32_t s1 = lds_u16(sb + x[0]);
     const uint32_t s2 = lds_u16(s1 + x[1]);
@@ -1327,6 +1336,7 @@ __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) 
 // kSub:   LIKE / NOT LIKE '%needle%';  else Eq / Ne / ordering / constant.
 // kInstr: the byte-accounting pass of lc_scan_traffic_model (per-entry candidate / kernel bytes).  A separate
 // instantiation, so that the accounting costs the shipped kernel nothing and a kernel trace keeps the two apart.
+using ConstDescPtr = const __attribute__((address_space(4))) StrDesc*;
 template <bool kBytes, bool kSub, bool kMany, bool kInstr>
 __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
                                                            const DevSymtab* __restrict__ symtabs, StrPred pred,
@@ -1368,21 +1378,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
 
     // This workgroup's entries: a precomputed range of at most four entries that share one symbol table (so the LDS
     // automaton serves all of them), or — persistent / very large launches — an even split over the counter groups.
-    const uint32_t wg_group = blockIdx.x % L.work_groups;
+    const uint32_t wg_group = blockIdx.x < L.work_groups ? blockIdx.x : blockIdx.x % L.work_groups;
     uint32_t group_begin, group_end, slot0;
     // A record holds at most one entry per wave: wave w takes entry w of the range, and its descriptor comes from the
     // record (address known from blockIdx: fetched together with the range header).  The draw (a returning far atomic,
     // ~1-2 us before the wave can even load its descriptor) is only paid by launches without records.
     const bool static_draw = L.d_wg_ranges != nullptr;
     const StrWgRecord* rec = L.d_wg_ranges + (static_draw ? wg_group : 0u);
-    StrDesc d_rec;
     if (static_draw) {
         group_begin = rec->begin;
         group_end = rec->end;
         slot0 = rec->symtab_slot;
-        d_rec = rec->d[wave];
     } else {
-        d_rec = StrDesc{};
         const uint32_t per_group = (L.n_entries + L.work_groups - 1u) / L.work_groups;
         group_begin = wg_group * per_group;
         group_end = min(L.n_entries, group_begin + per_group);
@@ -1431,24 +1438,33 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint32_t tm_words = 0, tm_cands = 0;
 #endif
     LC_TM(0, 0);
-    StrDesc d_sel;
-    if (static_draw) d_sel = d_rec;
-    else d_sel = descs[entry];
-    const StrDesc& d = d_sel;
-    const DevSymtab& st = symtabs[d.symtab_slot];
+    // The descriptor stays in memory (scalar loads through the constant cache where a field is used) and the pointer is
+    // laundered between the phases (LC_FORGET_DESC): a phase keeps only its own fields in SGPRs.  Held as one 28-dword
+    // value across the whole entry it pushes the kernel far beyond its SGPR budget (~200 v_writelane / v_readlane
+    // spill instructions in a kernel that is bound by instruction issue).
+    ConstDescPtr dp;
+    if (static_draw) dp = reinterpret_cast<ConstDescPtr>(reinterpret_cast<uintptr_t>(&rec->d[wave]));
+    else dp = reinterpret_cast<ConstDescPtr>(reinterpret_cast<uintptr_t>(descs + entry));
+#define LC_FORGET_DESC                                                                        \
+    do {                                                                                      \
+        uint64_t dp_bits = uniform_u64(uint64_t(reinterpret_cast<uintptr_t>(dp)));            \
+        asm volatile("" : "+s"(dp_bits));                                                     \
+        dp = reinterpret_cast<ConstDescPtr>(uintptr_t(dp_bits));                              \
+    } while (0)
+    const DevSymtab& st = symtabs[dp->symtab_slot];
     // shared LDS copy of the automaton when this entry uses the workgroup's symbol table, else the global one
-    const bool tbl_in_lds = lds_tbl && d.symtab_slot == slot0;
-    const uint8_t* tbl_global = kSub ? pred.automata + size_t(d.symtab_slot) * pred.automaton_stride : nullptr;
-    const uint32_t nwords = (d.n + 63u) >> 6;
+    const bool tbl_in_lds = lds_tbl && dp->symtab_slot == slot0;
+    const uint8_t* tbl_global = kSub ? pred.automata + size_t(dp->symtab_slot) * pred.automaton_stride : nullptr;
+    const uint32_t nwords = (dp->n + 63u) >> 6;
 
     // early out: nothing selected in this entry
     if (L.d_selection) {
         uint32_t any = 0;
-        for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) any |= L.d_selection[d.mask_word_off + w] != 0;
+        for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) any |= L.d_selection[dp->mask_word_off + w] != 0;
         if (__ballot(any != 0) == 0) {
             for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
-                L.d_hit[d.mask_word_off + w] = 0;
-                if (L.d_valid) L.d_valid[d.mask_word_off + w] = 0;
+                L.d_hit[dp->mask_word_off + w] = 0;
+                if (L.d_valid) L.d_valid[dp->mask_word_off + w] = 0;
             }
             if (lane == 0) {
                 if (L.d_counts) L.d_counts[entry] = 0;
@@ -1460,7 +1476,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     }
 
     // ---- shared-prefix short circuits (comparisons.rs:24-26 for Eq, :469-501 for ordering) ----
-    const uint32_t spl = d.shared_prefix_len;
+    const uint32_t spl = dp->shared_prefix_len;
     int uniform_result = -1;  // -1: evaluate per entry; 0/1: every dictionary entry gets this result
     const int op = pred.op;
     const bool is_eq = (op == LC_OP_EQ || op == LC_OP_NE);
@@ -1471,7 +1487,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             const uint32_t m = min(nl, spl);
             int c = 0;
             for (uint32_t i = 0; i < m && c == 0; i++) {
-                const uint32_t a = d.shared_prefix[i], b = np[i];
+                const uint32_t a = dp->shared_prefix[i], b = np[i];
                 c = a < b ? -1 : (a > b ? 1 : 0);
             }
             if (is_eq) {
@@ -1493,9 +1509,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     if (!kSub && uniform_result < 0)
         for (uint32_t i = 0; i < 7 && i < nsl; i++) nsuf7 |= uint64_t(np[spl + i]) << (8 * i);
     const uint32_t needle_fp = pred.needle_fp;
-    const bool prune = kSub && pred.use_fingerprints && d.fingerprints != nullptr;
+    const bool prune = kSub && pred.use_fingerprints && dp->fingerprints != nullptr;
     // bigram signature probe (needles of >= 2 bytes): AND of the needle's bit slices = candidate bitmap
-    const bool use_sig = prune && d.signatures != nullptr && pred.n_sig_bits > 0 && !LC_ABL(pred.debug_flags & 8);
+    const bool use_sig = prune && dp->signatures != nullptr && pred.n_sig_bits > 0 && !LC_ABL(pred.debug_flags & 8);
     // with signatures the (weaker) fingerprint only matters for the NOT LIKE candidate-count rule and for the
     // algorithmic-byte instrumentation: its 4*D bytes are skipped otherwise
     const bool need_fp = prune && (!use_sig || op == LC_OP_NOT_LIKE || (kInstr && L.d_cand_bytes != nullptr));
@@ -1507,16 +1523,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     bool table_cleared = !kSub;  // wave uniform: the dictionary result table holds zeros + the matches set so far
     __builtin_amdgcn_wave_barrier();
 
-    const uint32_t nw = (d.d + 63u) >> 6;  // u64 words of a dictionary bitmap
+    const uint32_t nw = (dp->d + 63u) >> 6;  // u64 words of a dictionary bitmap
     if (kSub && use_sig) {
         for (uint32_t w = uint32_t(lane); w < nw; w += kWave) {
             uint64_t sv[kMaxSigProbe];  // sig_bits is padded with repeats: all loads are issued before the first use
 #pragma unroll
-            for (int k = 0; k < kMaxSigProbe; k++) sv[k] = as_global(d.signatures)[size_t(pred.sig_bits[k]) * nw + w];
+            for (int k = 0; k < kMaxSigProbe; k++) sv[k] = as_global(dp->signatures)[size_t(pred.sig_bits[k]) * nw + w];
             uint64_t m = sv[0];
 #pragma unroll
             for (int k = 1; k < kMaxSigProbe; k++) m &= sv[k];
-            if (w == nw - 1 && (d.d & 63u)) m &= (uint64_t(1) << (d.d & 63u)) - 1;
+            if (w == nw - 1 && (dp->d & 63u)) m &= (uint64_t(1) << (dp->d & 63u)) - 1;
             cmask[w] = m;
         }
     }
@@ -1528,7 +1544,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     // usual handful of candidates, runs once per entry.
     constexpr int KH = 8;
     const bool sig_only = kSub && use_sig && !need_fp;  // the candidates ARE the set bits of the bitmap
-    const uint32_t d_eval = uniform_result < 0 ? d.d : 0u;
+    const uint32_t d_eval = uniform_result < 0 ? dp->d : 0u;
     uint32_t pos = 0;              // next dictionary entry to look at (multiple of 64)
     uint32_t n_cand = 0;           // wave uniform
     uint32_t round_words = kWave;  // bitmap words per signature round (drops to 16 if 64 words overflow an empty list)
@@ -1563,14 +1579,14 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             if (kSub) {
 #pragma unroll
                 for (int k = 0; k < KH; k++) {
-                    const uint32_t ii = min(base + uint32_t(k) * kWave + uint32_t(lane), d.d - 1);
-                    fpv[k] = need_fp ? as_global(d.fingerprints)[ii] : 0xFFFFFFFFu;
+                    const uint32_t ii = min(base + uint32_t(k) * kWave + uint32_t(lane), dp->d - 1);
+                    fpv[k] = need_fp ? as_global(dp->fingerprints)[ii] : 0xFFFFFFFFu;
                 }
             } else {
 #pragma unroll
                 for (int k = 0; k < KH; k++) {
-                    const uint32_t ii = min(base + uint32_t(k) * kWave + uint32_t(lane), d.d - 1);
-                    pkv[k] = reinterpret_cast<GlobalPtr<uint64_t>>(as_global(d.prefix_keys))[ii];
+                    const uint32_t ii = min(base + uint32_t(k) * kWave + uint32_t(lane), dp->d - 1);
+                    pkv[k] = reinterpret_cast<GlobalPtr<uint64_t>>(as_global(dp->prefix_keys))[ii];
                 }
             }
 #pragma unroll
@@ -1578,7 +1594,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 const uint32_t g0 = base + uint32_t(k) * kWave;
                 if (g0 >= d_eval) break;  // uniform
                 const uint32_t i = g0 + uint32_t(lane);
-                const bool in = i < d.d;
+                const bool in = i < dp->d;
                 bool is_cand = false, decided_true = false;
                 if (kSub) {
                     // reference prefilter (fingerprint.rs:33-35): its candidates define the algorithmic bytes
@@ -1587,7 +1603,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     // the stronger bigram signature decides whether the value is walked at all
                     if (use_sig) is_cand = fp_ok && ((cmask[g0 >> 6] >> uint32_t(lane)) & 1);
                     if (need_fp) {
-                        if (kInstr && L.d_cand_bytes && fp_ok) cand_bytes += str_offset(d, i + 1) - str_offset(d, i);
+                        if (kInstr && L.d_cand_bytes && fp_ok) cand_bytes += str_offset(*dp, i + 1) - str_offset(*dp, i);
                         fp_cand += uint32_t(__popcll(__ballot(fp_ok)));
                     }
                 } else if (pred.mode == 3) {
@@ -1641,6 +1657,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         if (took) continue;
 
         // ---- phase B: walk the candidate list ----
+        LC_FORGET_DESC;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (kSub && !tbl_synced) {  // every wave of the workgroup passes exactly one of these (here or after the loop)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the DMA has landed in LDS
@@ -1659,11 +1676,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     table_cleared = true;
                 }
                 WalkManyArgs wa;
-                wa.fsst = d.fsst;
-                wa.residuals = d.residuals;
-                wa.slope = uint32_t(d.slope);
-                wa.intercept = uint32_t(d.intercept);
-                wa.offset_bytes = d.offset_bytes;
+                wa.fsst = dp->fsst;
+                wa.residuals = dp->residuals;
+                wa.slope = uint32_t(dp->slope);
+                wa.intercept = uint32_t(dp->intercept);
+                wa.offset_bytes = dp->offset_bytes;
                 wa.cand_lds = uint32_t(reinterpret_cast<uintptr_t>(cand));
                 wa.n_walk = n_walk;
                 wa.row0 = row0;
@@ -1673,22 +1690,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 const WalkManyResult wr = like_walk_many(wa);
                 any_true |= __ballot(wr.found != 0);
                 if (kInstr && L.d_cand_bytes && !prune) cand_bytes += wr.bytes;
-                if (kInstr && L.d_own_bytes) own_bytes += wr.bytes + 2u * d.offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
+                if (kInstr && L.d_own_bytes) own_bytes += wr.bytes + 2u * dp->offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
                 break;
             }
             const uint32_t j = jb + uint32_t(lane);
             const bool cl = j < n_walk;
             const uint32_t id = cl ? cand[j] : 0u;
             uint32_t start = 0, stop = 0;
-            if (cl) str_offset_pair(d, id, start, stop);
+            if (cl) str_offset_pair(*dp, id, start, stop);
             if (kInstr && L.d_cand_bytes && !prune) cand_bytes += stop - start;
-            if (kInstr && L.d_own_bytes && cl) own_bytes += (stop - start) + 2u * d.offset_bytes;
+            if (kInstr && L.d_own_bytes && cl) own_bytes += (stop - start) + 2u * dp->offset_bytes;
             LC_TM(3, start);
             bool res = false;
             if (false) {
             } else if (kSub && tbl_in_lds) {
                 // lane-parallel walk: one lane per 8-byte word of every candidate (see above)
-                const uint32_t words = cl ? max(1u, (stop - start + 7u) >> 3) : 0u;
+                const uint32_t words = cl ? max(1u, (stop - start + kTaskBytes - 1u) / kTaskBytes) : 0u;
                 const uint32_t incl = wave_inclusive_sum(words);
                 const uint32_t off = incl - words;
                 const uint32_t total = read_lane(incl, kWave - 1);
@@ -1713,22 +1730,35 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     const uint32_t o_off = __shfl(off, int(r), kWave);
                     const uint32_t o_start = __shfl(start, int(r), kWave);
                     const uint32_t o_stop = __shfl(stop, int(r), kWave);
-                    const uint32_t k = t0 + uint32_t(lane) - o_off;  // word index within the value
-                    const uint32_t p = o_start + 8u * k;
+                    const uint32_t k = t0 + uint32_t(lane) - o_off;  // task index within the value
+                    const uint32_t p = o_start + kTaskBytes * k;
                     const uint32_t rem = live && p < o_stop ? o_stop - p : 0u;
-                    uint64_t w = 0;
+                    uint64_t w[kTaskWords];
                     LC_TM(4, rem);
-                    if (rem) w = load_unaligned<uint64_t>(d.fsst + p);
-                    const uint32_t lo = uint32_t(w), hi = uint32_t(w >> 32);
-                    const bool first = k == 0;  // first word of its value (a value continuing from the previous pass
-                                                // has k > 0 in lane 0 and takes the carried state)
-                    uint32_t x[8];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) x[q] = (((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu) << 1;
-                    LC_TM(5, x[0]);
-                    // states (the escape position is part of the state: nothing else crosses word boundaries)
+                    for (int h = 0; h < kTaskWords; h++) {
+                        w[h] = 0;
+                        if (rem > 8u * uint32_t(h)) w[h] = load_unaligned<uint64_t>(dp->fsst + p + 8u * uint32_t(h));
+                    }
+                    const bool first = k == 0;  // first task of its value (a value continuing from the previous pass
+                                                // has k > 0 in lane 0 and takes the carried state)
+                    LC_TM(5, w[0]);
+                    // states (the escape position is part of the state: nothing else crosses task boundaries).  The
+                    // table offsets are extracted from the words at every step (one v_bfe more than keeping 8 offsets
+                    // per word in registers, which would cost this kernel a wave of occupancy)
+                    auto walk_task = [&](uint32_t s) {
+#pragma unroll
+                        for (int h = 0; h < kTaskWords; h++) {
+                            uint32_t x[8];
+                            const uint32_t lo = uint32_t(w[h]), hi = uint32_t(w[h] >> 32);
+#pragma unroll
+                            for (int q = 0; q < 8; q++) x[q] = (((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu) << 1;
+                            s = walk8(s, x, rem > 8u * uint32_t(h) ? rem - 8u * uint32_t(h) : 0u);
+                        }
+                        return s;
+                    };
                     uint32_t s_in = row0;
-                    uint32_t e = walk8(s_in, x, rem);
+                    uint32_t e = walk_task(s_in);
                     bool hit = e == hitrow;
                     for (;;) {
                         uint32_t prev = lane_shift_up1(e, carry_state);
@@ -1737,7 +1767,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                         if (__ballot(changed) == 0) break;
                         if (changed) {
                             s_in = prev;
-                            e = walk8(s_in, x, rem);
+                            e = walk_task(s_in);
                             hit |= e == hitrow;
                         }
                     }
@@ -1749,11 +1779,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 res = cl && hitflag[lane] != 0;
             } else if (kSub) {
-                if (cl) res = like_walk_global(d.fsst, start, stop, tbl_global, nl);
+                if (cl) res = like_walk_global(dp->fsst, start, stop, tbl_global, nl);
             } else if (pred.mode == 3) {
-                if (cl) res = like_generic(st, d.fsst, start, stop, np, nl);
+                if (cl) res = like_generic(st, dp->fsst, start, stop, np, nl);
             } else if (cl) {
-                const int o = decode_compare(st, d.fsst, start, stop, np, nl);
+                const int o = decode_compare(st, dp->fsst, start, stop, np, nl);
                 res = is_eq ? o == 0
                             : (op == LC_OP_LT ? o < 0 : op == LC_OP_LE ? o <= 0 : op == LC_OP_GT ? o > 0 : o >= 0);
             }
@@ -1775,6 +1805,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     }
 
     LC_TM(7, 0);
+    LC_FORGET_DESC;
     // dictionary-level negation:
     //   NotContains inverts the dictionary results only when at least one fingerprint candidate existed
     //   (comparisons.rs:167-180, :644-648 — bit-exact with the reference); Ne inverts row values (:85-90).
@@ -1792,8 +1823,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     // one ds_read_b64 each, combines them with the selection / validity words it loaded itself and stores them
     // (coalesced).  The candidate list is dead by now and provides the staging space.
     const bool all_false = any_true == 0;
+    const bool need_vw = !all_false || invert || L.d_valid != nullptr;
     const uint32_t xor8 = invert ? 0xFFu : 0u;
-    const uint32_t n_rows = LC_ABL(pred.debug_flags & 2) ? 0u : d.n;
+    const uint32_t n_rows = LC_ABL(pred.debug_flags & 2) ? 0u : dp->n;
     const uint32_t key_max = dres_bytes * 8u - 1u;  // bitmap: keys under null slots may be garbage (clamped)
     uint32_t hit_count = 0;
     constexpr int KC = 8;
@@ -1806,20 +1838,21 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             for (int k = 0; k < KC; k++) {
                 const uint32_t r0 = pass + uint32_t(k) * kWave * 8 + uint32_t(lane) * 8;
                 // rows past the end re-read the last 8-row group (never stored)
-                kv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(d.keys) + min(r0, (n_rows - 1u) & ~7u));
+                kv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(dp->keys) + min(r0, (n_rows - 1u) & ~7u));
             }
         }
         uint64_t vw[KC * 8 / kWave];
 #pragma unroll
         for (int h = 0; h < KC * 8 / kWave; h++) {
             const uint32_t widx = (pass >> 6) + uint32_t(h) * kWave + uint32_t(lane);
-            // both words are always loaded (a constant all-ones word stands in for an absent bitmap), so the two
-            // loads are in flight together with the key loads above
+            // wave-uniform branches: the loads that exist are in flight together with the key loads above; an entry
+            // whose hit words are all zero anyway (no dictionary value matched, nothing inverted, no validity output)
+            // loads nothing at all
             const uint32_t wc = min(widx, nwords - 1u);
-            const uint64_t* sp = L.d_selection ? L.d_selection + d.mask_word_off + wc : &kAllOnesWord;
-            const uint64_t* vp = d.validity ? d.validity + wc : &kAllOnesWord;
-            const uint64_t sv = *as_global(sp), vv = *as_global(vp);
-            const uint32_t rows_left = d.n - (wc << 6);
+            uint64_t sv = ~uint64_t(0), vv = ~uint64_t(0);
+            if (need_vw && L.d_selection) sv = *as_global(L.d_selection + dp->mask_word_off + wc);
+            if (need_vw && dp->validity) vv = *as_global(dp->validity + wc);
+            const uint32_t rows_left = dp->n - (wc << 6);
             const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
             vw[h] = widx < nwords ? (sv & vv & tail) : 0;
         }
@@ -1852,8 +1885,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 const uint64_t rw = all_false ? (invert ? ~uint64_t(0) : uint64_t(0))
                                               : reinterpret_cast<const uint64_t*>(stage)[wl];
                 const uint64_t hitw = rw & vw[h];
-                L.d_hit[d.mask_word_off + widx] = hitw;
-                if (L.d_valid) L.d_valid[d.mask_word_off + widx] = vw[h];
+                L.d_hit[dp->mask_word_off + widx] = hitw;
+                if (L.d_valid) L.d_valid[dp->mask_word_off + widx] = vw[h];
                 hit_count += uint32_t(__popcll(hitw));
             }
         }
@@ -1892,15 +1925,16 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         if (kSub) u += use_sig ? pred.n_sig_bits * nw * 8u : 0u;
         // (the instrumented pass itself reads the fingerprints to count the reference's candidates; a normal pass only
         // reads them when there is no signature index or for the NOT LIKE candidate rule)
-        if (kSub) u += (prune && (!use_sig || op == LC_OP_NOT_LIKE)) ? 4u * d.d : 0u;
-        if (!kSub && pred.mode == 0 && uniform_result < 0) u += 8u * d.d;
-        if (!all_false) u += 2u * d.n;
-        u += nwords * 8u * ((L.d_selection ? 1u : 0u) + (d.validity ? 1u : 0u) + 1u + (L.d_valid ? 1u : 0u));
+        if (kSub) u += (prune && (!use_sig || op == LC_OP_NOT_LIKE)) ? 4u * dp->d : 0u;
+        if (!kSub && pred.mode == 0 && uniform_result < 0) u += 8u * dp->d;
+        if (!all_false) u += 2u * dp->n;
+        u += nwords * 8u * ((L.d_selection ? 1u : 0u) + (dp->validity ? 1u : 0u) + 1u + (L.d_valid ? 1u : 0u));
         const uint64_t c = wave_sum_u64(uint64_t(own_bytes));
         if (lane == 0) L.d_own_bytes[entry] = uint32_t(c) + u;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }  // entries
+#undef LC_FORGET_DESC
     if (kSub && !tbl_synced) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
