@@ -1337,7 +1337,10 @@ __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) 
 // kInstr: the byte-accounting pass of lc_scan_traffic_model (per-entry candidate / kernel bytes).  A separate
 // instantiation, so that the accounting costs the shipped kernel nothing and a kernel trace keeps the two apart.
 using ConstDescPtr = const __attribute__((address_space(4))) StrDesc*;
-template <bool kBytes, bool kSub, bool kMany, bool kInstr>
+// kSigOnly: `LIKE '%needle%'` over a scan whose entries ALL carry the bigram signature index (the launcher checks):
+// the candidates are exactly the set bits of the signature AND, so the fingerprint / prefix-key round of phase A, the
+// NOT LIKE candidate rule and the dictionary inversion are compiled out of the headline kernel.
+template <bool kBytes, bool kSub, bool kMany, bool kInstr, bool kSigOnly = false>
 __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
                                                            const DevSymtab* __restrict__ symtabs, StrPred pred,
                                                            ScanLaunch L, uint32_t dres_bytes, uint32_t cmask_bytes) {
@@ -1509,12 +1512,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     if (!kSub && uniform_result < 0)
         for (uint32_t i = 0; i < 7 && i < nsl; i++) nsuf7 |= uint64_t(np[spl + i]) << (8 * i);
     const uint32_t needle_fp = pred.needle_fp;
-    const bool prune = kSub && pred.use_fingerprints && dp->fingerprints != nullptr;
+    const bool prune = kSigOnly || (kSub && pred.use_fingerprints && dp->fingerprints != nullptr);
     // bigram signature probe (needles of >= 2 bytes): AND of the needle's bit slices = candidate bitmap
-    const bool use_sig = prune && dp->signatures != nullptr && pred.n_sig_bits > 0 && !LC_ABL(pred.debug_flags & 8);
+    const bool use_sig = kSigOnly || (prune && dp->signatures != nullptr && pred.n_sig_bits > 0 && !LC_ABL(pred.debug_flags & 8));
     // with signatures the (weaker) fingerprint only matters for the NOT LIKE candidate-count rule and for the
     // algorithmic-byte instrumentation: its 4*D bytes are skipped otherwise
-    const bool need_fp = prune && (!use_sig || op == LC_OP_NOT_LIKE || (kInstr && L.d_cand_bytes != nullptr));
+    const bool need_fp = !kSigOnly && prune && (!use_sig || op == LC_OP_NOT_LIKE || (kInstr && L.d_cand_bytes != nullptr));
 
     uint32_t fp_cand = 0;     // wave uniform: fingerprint candidates seen (NOT LIKE rule)
     uint32_t cand_bytes = 0;  // per lane, summed at the end (instrumented pass only)
@@ -1543,7 +1546,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     // round might not fit, the list is walked first.  One loop, so phase B has exactly one call site and, for the
     // usual handful of candidates, runs once per entry.
     constexpr int KH = 8;
-    const bool sig_only = kSub && use_sig && !need_fp;  // the candidates ARE the set bits of the bitmap
+    const bool sig_only = kSigOnly || (kSub && use_sig && !need_fp);  // the candidates ARE the set bits of the bitmap
     const uint32_t d_eval = uniform_result < 0 ? dp->d : 0u;
     uint32_t pos = 0;              // next dictionary entry to look at (multiple of 64)
     uint32_t n_cand = 0;           // wave uniform
@@ -1571,7 +1574,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 round_words = 16;  // 16 words hold at most 1024 candidates: always fits an empty list
                 took = true;
             }
-        } else if (pos < d_eval && n_cand + KH * kWave <= kCandCap) {
+        } else if (!kSigOnly && pos < d_eval && n_cand + KH * kWave <= kCandCap) {
             // phase A (per entry): fingerprints for LIKE, prefix keys for Eq / ordering
             const uint32_t base = pos;
             uint32_t fpv[KH];
@@ -1810,7 +1813,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     //   NotContains inverts the dictionary results only when at least one fingerprint candidate existed
     //   (comparisons.rs:167-180, :644-648 — bit-exact with the reference); Ne inverts row values (:85-90).
     bool invert = false;
-    if (kSub && op == LC_OP_NOT_LIKE) invert = prune ? (fp_cand > 0) : true;
+    if (!kSigOnly && kSub && op == LC_OP_NOT_LIKE) invert = prune ? (fp_cand > 0) : true;
     if (!kSub && pred.mode == 0 && op == LC_OP_NE) invert = true;
     if (!kSub && pred.mode == 3 && op == LC_OP_NOT_LIKE) invert = true;  // Arrow `nlike` on the rows
     if (uniform_result == 1) invert = !invert;  // all-true dictionary == all-false inverted
@@ -2969,6 +2972,10 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
          {{k_str_pred<true, true, false, false>, k_str_pred<true, true, false, true>},
           {k_str_pred<true, true, true, false>, k_str_pred<true, true, true, true>}}}};
     Kern kern = table[bytes ? 1 : 0][sub ? 1 : 0][many ? 1 : 0][instr ? 1 : 0];
+    // the headline case: LIKE, every entry carries signatures, needle automaton in LDS
+    if (sub && !many && !instr && lds_tbl && pred.use_fingerprints && pred.n_sig_bits > 0 && pred.op == LC_OP_LIKE)
+        kern = bytes ? static_cast<Kern>(k_str_pred<true, true, false, false, true>)
+                     : static_cast<Kern>(k_str_pred<false, true, false, false, true>);
     if (dyn_lds > 64 * 1024) {
         // large dictionaries: gfx950 has 160 KB of LDS per CU, a workgroup may use more than the default 64 KB
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
