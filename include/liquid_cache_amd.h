@@ -105,6 +105,9 @@ typedef struct {
     uint64_t algorithmic_pred_bytes; /* SURVEY §8(d) bytes one predicate evaluation reads+writes */
     int32_t squeezed_date_field;     /* LC_DATE_* if the entry is a squeezed date component (lc_squeeze_date), else -1 */
     int32_t clamped_from_bit_width;  /* original W if the entry is clamp-squeezed (lc_squeeze_clamp), else 0 */
+    int32_t quantized_from_bit_width; /* original W if the entry is quantize-squeezed (lc_squeeze_quantize), else 0 */
+    int32_t reserved0;
+    uint64_t quantized_bucket_width; /* offsets per bucket of a quantize-squeezed entry, else 0 */
 } lc_entry_info;
 
 /* Arrow C Data Interface (https://arrow.apache.org/docs/format/CDataInterface.html), declared here so the
@@ -260,8 +263,18 @@ LC_API lc_status lc_squeeze_date(lc_ctx* ctx, uint64_t n, const uint64_t* entry_
  * sentinel AND the literal lies at or above reference + sentinel (:199-222) — and a read whenever no selected valid row
  * holds the sentinel (to_arrow_known_only); otherwise the call answers LC_NEEDS_BACKING (per entry in
  * lc_eval_predicate_batch's `statuses`) and the caller reads the full array from its disk tier.  Calls on scans that
- * contain clamped entries synchronise the stream (the sentinel check).  The Quantize policy is not implemented. */
+ * contain clamped entries synchronise the stream (the sentinel check). */
 LC_API lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed);
+
+/* The same with the Quantize policy (IntegerSqueezePolicy::Quantize, the reference's default; primitive_array.rs:455-498
+ * -> LiquidPrimitiveQuantizedArray, hybrid_primitive_array.rs:427-665): a row keeps the bucket
+ * (value - reference) / bucket_width at half the bit width, bucket_width = ceil((max offset + 1) / 2^(W/2)).  A
+ * comparison with literal k is answered from HBM unless a valid selected row lies in k's own bucket and that bucket
+ * does not decide it: `< k` and `>= k` are decided there when k is the first value of its bucket, `<= k` and `> k` when
+ * it is the last, `=` / `<>` never (:575-618); a literal below the reference decides everything (:535-547).  Otherwise
+ * LC_NEEDS_BACKING.  Every read of a quantized entry answers LC_NEEDS_BACKING (its to_arrow_array hydrates from disk,
+ * :688-690).  The division, clamp to the last bucket and packing run on the device. */
+LC_API lc_status lc_squeeze_quantize(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed);
 
 /* boolean_buffer_and_then(left, right) (src/datafusion/src/utils.rs:62-83): `left` has left_bits bits of which
  * right_bits are set; out (ceil(left_bits/8) bytes) keeps the set bits of `left` whose `right` bit is 1. */

@@ -417,6 +417,15 @@ class LiquidCache:
         N.check(self._lib.lc_squeeze_clamp(self._ctx, len(entry_ids), ids, C.byref(k)), self._ctx)
         return int(k.value)
 
+    def squeeze_quantize(self, entry_ids: Sequence[int]) -> int:
+        """Squeeze integer entries to half their bit width with the Quantize policy (lc_squeeze_quantize, the
+        reference's default IntegerSqueezePolicy); returns how many qualified.  Predicates the literal's bucket cannot
+        decide, and every read, raise LiquidCacheError(LC_NEEDS_BACKING)."""
+        ids = (C.c_uint64 * len(entry_ids))(*[int(e) for e in entry_ids])
+        k = C.c_uint64()
+        N.check(self._lib.lc_squeeze_quantize(self._ctx, len(entry_ids), ids, C.byref(k)), self._ctx)
+        return int(k.value)
+
     def evict(self, entry_ids: Iterable[int]):
         ids = [int(e) for e in entry_ids]
         arr = (C.c_uint64 * len(ids))(*ids)

@@ -280,6 +280,73 @@ struct PackedRange {
     int constant;  // -1: evaluate; 0/1: every row gives this result
 };
 
+// Quantize-squeezed entries (LiquidPrimitiveQuantizedArray::try_eval_predicate_inner, hybrid_primitive_array.rs:487-665):
+// a row holds the bucket b = (value - reference) / bucket_width.  With rel = literal - reference, q = rel / width,
+// r = rel % width: b < q and b > q decide every comparison; b == q decides only `< k` / `>= k` at r == 0 and `<= k` /
+// `> k` at r == width - 1.  This returns the range for the rows that ARE decided (rows of bucket q that are not give
+// the value the table below assigns them, but the host never lets such a result out: it first counts them with
+// op == LC_OP_INTERNAL_SENTINEL / inner_op, and any such valid selected row means Err(NeedsBacking), :633-655).
+template <typename U>
+__device__ __noinline__ PackedRange<U> packed_range_quantized(const FixedDesc& d, const FixedPred& pred, uint64_t umax) {
+    PackedRange<U> r{0, 0, false, -1};
+    const bool probe = pred.op == LC_OP_INTERNAL_SENTINEL;
+    const int op = probe ? pred.inner_op : pred.op;
+    int mode = pred.lit_class;
+    uint64_t q = 0, rem = 0;
+    const uint64_t bw = quant_bucket_width(d);
+    if (mode == 0) {
+        const bool below = d.is_signed ? (int64_t(pred.lit) < int64_t(d.reference)) : (pred.lit < d.reference);
+        if (below) mode = -1;
+        else {
+            const uint64_t rel = pred.lit - d.reference;
+            q = rel / bw;
+            rem = rel - q * bw;
+            if (q > umax) mode = 1;  // beyond the last bucket: every row is on the `less` side
+        }
+    }
+    if (mode != 0) {
+        if (probe) { r.constant = 0; return r; }  // nothing is undecidable
+        const bool gt_like = (op == LC_OP_GT) || (op == LC_OP_GE) || (op == LC_OP_NE);
+        // a representable literal beyond the last bucket puts every row on the `less` side, where a quantized decimal
+        // also answers true to `=` (see LC_OP_EQ below); a literal outside the type (lit_class) never reaches the
+        // bucket rule in the reference (literal_to_u64 -> None -> evaluated on the hydrated array)
+        const bool lt_like = (op == LC_OP_LT) || (op == LC_OP_LE) || (op == LC_OP_NE) ||
+                             (op == LC_OP_EQ && d.quantized == 2 && pred.lit_class == 0);
+        r.constant = (mode < 0 ? gt_like : lt_like) ? 1 : 0;
+        return r;
+    }
+    const bool first = rem == 0, last = rem + 1 == bw;
+    if (probe) {
+        const bool decided = (op == LC_OP_LT || op == LC_OP_GE) ? first : (op == LC_OP_LE || op == LC_OP_GT) ? last : false;
+        if (decided) r.constant = 0;
+        else { r.lo = U(q); r.span = 0; }
+        return r;
+    }
+    switch (op) {
+        case LC_OP_EQ:
+            // integers: rows outside k's bucket are not equal (:575-581).  Decimals (quantized == 2): the reference's
+            // `less_side` lists Eq (decimal_array.rs:462-465), so buckets below q answer TRUE — reproduced bit for bit
+            if (d.quantized == 2 && q > 0) { r.lo = 0; r.span = U(q - 1); }
+            else r.constant = 0;
+            break;
+        case LC_OP_NE: r.constant = 1; break;
+        case LC_OP_LT: if (q == 0) r.constant = 0; else { r.lo = 0; r.span = U(q - 1); } break;
+        case LC_OP_LE:
+            if (last) { r.lo = 0; r.span = U(q); }
+            else if (q == 0) r.constant = 0;
+            else { r.lo = 0; r.span = U(q - 1); }
+            break;
+        case LC_OP_GE:
+            if (first) { r.lo = U(q); r.span = U(umax - q); break; }
+            [[fallthrough]];
+        default:  // GT, and GE inside a bucket: b > q
+            if (q == umax) r.constant = 0;
+            else { r.lo = U(q + 1); r.span = U(umax - (q + 1)); }
+            break;
+    }
+    return r;
+}
+
 template <typename U>
 __device__ __forceinline__ PackedRange<U> packed_range(const FixedDesc& d, const FixedPred& pred) {
     PackedRange<U> r{0, 0, false, -1};
@@ -287,6 +354,7 @@ __device__ __forceinline__ PackedRange<U> packed_range(const FixedDesc& d, const
     int mode = pred.lit_class;  // -1: literal below every value, +1: above
     uint64_t dlit = 0;
     const uint64_t umax = d.W >= 64 ? ~uint64_t(0) : ((uint64_t(1) << d.W) - 1);
+    if (d.quantized) return packed_range_quantized<U>(d, pred, umax);
     if (op == LC_OP_INTERNAL_SENTINEL) {  // rows whose packed value is the clamp sentinel (all ones)
         r.lo = U(umax);
         r.span = 0;
@@ -2682,6 +2750,7 @@ __global__ __launch_bounds__(256) void k_fl_pack(const EncodeDesc* __restrict__ 
         // every slot is packed, null slots included (they hold whatever the Arrow buffer holds, like the host path);
         // slots past the end are zero (bit_pack_array.rs:97-113)
         U v = idx < d.n ? U(U(load_native_any(d, idx)) - U(d.reference)) : U(0);
+        if (d.quant_width > 1) v = U(uint64_t(v) / d.quant_width);  // bucket index (primitive_array.rs:472-481)
         if (d.clamp_max && v > U(d.clamp_max)) v = U(d.clamp_max);  // values >= sentinel become the sentinel (:433-437)
         v &= mask;
         acc = U(acc | U(v << bit));

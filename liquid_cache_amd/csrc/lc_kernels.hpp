@@ -52,9 +52,11 @@ struct alignas(16) FixedDesc {
     uint8_t kind;              // FixedKind
     uint8_t alp_e, alp_f;
     uint8_t value_width;       // bytes of a decoded Arrow value
-    uint8_t pad;
+    uint8_t quantized;         // 1: the packed values are bucket indices (LiquidPrimitiveQuantizedArray); the bucket
+                               // width (u64) lives in the bits of `patch_idx`, which integer entries do not use
 };
 static_assert(sizeof(FixedDesc) == 64, "FixedDesc layout");
+__host__ __device__ inline uint64_t quant_bucket_width(const FixedDesc& d) { return uint64_t(reinterpret_cast<uintptr_t>(d.patch_idx)); }
 
 struct alignas(16) StrDesc {
     const uint16_t* keys;
@@ -112,6 +114,7 @@ struct EncodeDesc {
     uint64_t* validity_out;    // pack phase: the validity words are copied here (or null)
     uint64_t reference;        // pack phase: frame of reference (sign-extended for signed types)
     uint64_t clamp_max;        // pack phase: offsets are clamped to this value first (clamp squeeze); 0: no clamp
+    uint64_t quant_width;      // pack phase: offsets are divided by this bucket width first (quantize squeeze); 0/1: no
     uint32_t n;
     uint8_t W;                 // pack phase: bit width (0: nothing to pack)
     uint8_t value_log2;        // 0..3: bytes per value = 1 << value_log2
@@ -134,7 +137,8 @@ struct FixedPred {
     int32_t lit_class;    // -1: literal below every representable value, +1: above, 0: `lit` is exact
     uint64_t lit;         // int64 bits (signed logical types) or uint64
     uint32_t lit_f32;     // float predicates: raw IEEE bits of the literal
-    uint32_t pad;
+    int32_t inner_op;     // op == LC_OP_INTERNAL_SENTINEL over quantized entries: the comparison whose undecidable
+                          // rows (bucket of the literal) are looked for
     uint64_t lit_f64;
 };
 

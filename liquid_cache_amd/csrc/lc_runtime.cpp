@@ -86,6 +86,10 @@ struct Entry {
     // above the sentinel 2^W - 1 are stored as the sentinel; orig_W is the width before the squeeze.
     bool clamped = false;
     int orig_W = 0;
+    // LiquidPrimitiveQuantizedArray form (hybrid_primitive_array.rs:427-436): packed at half the original width, a row
+    // holds the bucket (value - reference) / bucket_width.  Predicates only; every read needs the backing bytes.
+    bool quantized = false;
+    uint64_t bucket_width = 0;
 };
 
 }  // namespace
@@ -854,6 +858,8 @@ lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out) 
     out->device_bytes = e.device_bytes;
     out->squeezed_date_field = e.squeezed_field;
     out->clamped_from_bit_width = e.clamped ? e.orig_W : 0;
+    out->quantized_from_bit_width = e.quantized ? e.orig_W : 0;
+    out->quantized_bucket_width = e.quantized ? e.bucket_width : 0;
     out->algorithmic_pred_bytes = e.is_str ? 0 : fixed_alg_bytes(e, false);
     return LC_OK;
     });
@@ -932,6 +938,10 @@ struct DevEncodeItem {
     int forced_W = 0, orig_W = 0;
     uint64_t entry_reference = 0, clamp_max = 0;
     bool entry_signed = false;
+    bool quantize = false;                  // with `forced`: bucket indices instead of clamped offsets
+    uint64_t quant_width = 0;               // result: the bucket width
+    int logical = kInteger;                 // kDecimal: a quantized decimal entry (u64 offsets of the unscaled values)
+    int dec_precision = 0, dec_scale = 0, dec_is256 = 0, entry_value_width = 0;
     // results
     bool all_null = false;
     int W = 0;
@@ -974,6 +984,13 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         it.all_null = (!it.forced && mm[i].n_valid == 0) || it.force_all_null;  // also empty arrays (primitive_array.rs:160-170)
         it.blob_begin = align_up(total, kSectionAlign);
         size_t cur = it.blob_begin;
+        if (!it.all_null && it.forced && it.quantize) {
+            // bucket width = ceil((max offset + 1) / 2^W') (primitive_array.rs:466-470); the last bucket absorbs the rest
+            const uint64_t count = uint64_t(1) << it.forced_W;
+            const uint64_t range_size = mm[i].mx == ~uint64_t(0) ? mm[i].mx : mm[i].mx + 1;  // saturating_add(1)
+            it.quant_width = std::max<uint64_t>(range_size / count + (range_size % count ? 1 : 0), 1);
+            it.clamp_max = count - 1;
+        }
         if (!it.all_null && it.forced) {
             it.W = it.forced_W;
             it.reference = 0;  // the values already are offsets from the entry's reference
@@ -1014,6 +1031,7 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         d.W = uint8_t(it.all_null ? 0 : it.W);
         d.reference = it.reference;
         d.clamp_max = it.clamp_max;
+        d.quant_width = it.quantize ? it.quant_width : 0;
         d.packed = it.all_null ? nullptr : dbase + it.out_packed;
         d.validity_out = it.out_validity == size_t(-1) ? nullptr : reinterpret_cast<uint64_t*>(dbase + it.out_validity);
     }
@@ -1043,7 +1061,10 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         const DevEncodeItem& it = items[i];
         Entry e;
         e.is_str = false;
-        e.logical = kInteger;
+        e.logical = it.logical;
+        e.dec_precision = it.dec_precision;
+        e.dec_scale = it.dec_scale;
+        e.dec_is256 = it.dec_is256;
         e.phys = it.phys;
         e.len = it.n;
         e.all_null = it.all_null;
@@ -1052,7 +1073,9 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         e.slab = slab;
         e.device_bytes = it.blob_bytes;
         e.squeezed_field = it.squeezed_field;
-        e.clamped = it.forced;
+        e.clamped = it.forced && !it.quantize;
+        e.quantized = it.forced && it.quantize && !it.all_null;
+        e.bucket_width = it.quant_width;
         e.orig_W = it.orig_W;
         FixedDesc& d = e.fd;
         d = FixedDesc{};
@@ -1065,6 +1088,14 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         d.reference = it.all_null ? 0 : (it.forced ? it.entry_reference : it.reference);  // sign-extended for signed types
         d.packed = it.all_null ? nullptr : dbase + it.out_packed;
         d.validity = it.out_validity == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + it.out_validity);
+        if (e.quantized) {
+            d.quantized = it.logical == kDecimal ? 2 : 1;
+            d.patch_idx = reinterpret_cast<const uint64_t*>(uintptr_t(it.quant_width));  // see quant_bucket_width()
+        }
+        if (it.logical == kDecimal) {
+            d.kind = kKindDecimal;
+            d.value_width = uint8_t(it.entry_value_width);
+        }
         auto old = ctx->entries.find(it.id);
         if (old != ctx->entries.end()) {
             ctx->entry_bytes -= old->second.device_bytes;
@@ -1167,6 +1198,7 @@ lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out
     if (e.is_str) return fail(LC_UNSUPPORTED, "byte-view entries are re-serialised by the host (their bytes are what was staged)");
     if (e.squeezed_field >= 0) return fail(LC_NEEDS_BACKING, "a squeezed entry holds one date component only");
     if (e.clamped) return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry holds half of its bits");
+    if (e.quantized) return fail(LC_NEEDS_BACKING, "a quantize-squeezed entry holds bucket indices only");
     std::vector<uint8_t> out(16, 0);
     write_ipc_header(out.data(), e.logical, e.phys);
     const FixedDesc& d = e.fd;
@@ -1267,7 +1299,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             s->total_rows += e.len;
             max_len = std::max(max_len, e.len);
             if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
-            s->has_clamped |= e.clamped;
+            s->has_clamped |= e.clamped || e.quantized;
             s->meta.push_back(e);
         }
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
@@ -1355,15 +1387,24 @@ static bool clamp_resolves(const Entry& e, const FixedPred& fp) {
     return strict ? fp.lit < sent_abs : fp.lit <= sent_abs;
 }
 
-// Which clamp-squeezed entries of the scan hold a valid, selected sentinel row that `preds` cannot decide?  (`preds`
-// null: any sentinel row counts — reads need every selected value, to_arrow_known_only :129-146.)  Synchronises.
+// Which squeezed entries of the scan hold a valid, selected row that `preds` cannot decide: the sentinel rows of a
+// clamp-squeezed entry, the rows in the literal's bucket of a quantize-squeezed one (the kernel knows which comparisons
+// a bucket decides: packed_range_quantized).  `preds` null: a read — any sentinel row counts (to_arrow_known_only
+// :129-146), and a quantized entry has no values at all (to_arrow_array hydrates, :688-690).  Synchronises.
 static lc_status clamp_unresolved_entries(lc_ctx* ctx, lc_scan* s, const FixedPred* preds, int n_preds,
                                           const void* d_selection, hipStream_t stream, std::vector<uint32_t>* out) {
     out->clear();
     std::vector<uint32_t> suspects;
+    bool any_quantized = false;
     for (uint32_t i = 0; i < s->n; i++) {
         const Entry& e = s->meta[i];
-        if (!e.clamped || e.all_null) continue;
+        if (e.all_null) continue;
+        if (e.quantized) {
+            if (!preds) out->push_back(i);
+            else { suspects.push_back(i); any_quantized = true; }
+            continue;
+        }
+        if (!e.clamped) continue;
         bool resolves = preds != nullptr;
         for (int k = 0; k < n_preds && resolves; k++) resolves = clamp_resolves(e, preds[k]);
         if (!resolves) suspects.push_back(i);
@@ -1383,14 +1424,23 @@ static lc_status clamp_unresolved_entries(lc_ctx* ctx, lc_scan* s, const FixedPr
     L.d_selection = static_cast<const uint64_t*>(d_selection);
     L.d_hit = d_tmp;
     L.d_counts = d_cnt;
-    FixedPred sp{};
-    sp.op = LC_OP_INTERNAL_SENTINEL;
-    LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, sp, nullptr, s->max_w, L, stream));
-    std::vector<uint32_t> cnt(s->n, 0);
-    LC_HIP(hipMemcpyAsync(cnt.data(), d_cnt, size_t(s->n) * 4, hipMemcpyDeviceToHost, stream));
-    LC_HIP(hipStreamSynchronize(stream));
+    // one probe pass per predicate when quantized entries are involved (their undecidable bucket depends on it); the
+    // sentinel rows of clamped entries are the same in every pass
+    std::vector<uint32_t> cnt(s->n, 0), total(s->n, 0);
+    const int passes = any_quantized ? n_preds : 1;
+    for (int k = 0; k < passes; k++) {
+        FixedPred sp{};
+        if (preds) sp = preds[k];
+        sp.inner_op = sp.op;
+        sp.op = LC_OP_INTERNAL_SENTINEL;
+        LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, sp, nullptr, s->max_w, L, stream));
+        LC_HIP(hipMemcpyAsync(cnt.data(), d_cnt, size_t(s->n) * 4, hipMemcpyDeviceToHost, stream));
+        LC_HIP(hipStreamSynchronize(stream));
+        for (uint32_t i : suspects) total[i] += cnt[i];
+    }
     for (uint32_t i : suspects)
-        if (cnt[i] > 0) out->push_back(i);
+        if (total[i] > 0) out->push_back(i);
+    std::sort(out->begin(), out->end());
     return LC_OK;
 }
 
@@ -2506,7 +2556,7 @@ lc_status lc_squeeze_date(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, in
 // least 8 bits per value are re-packed IN HBM at half their width; offsets at or above the sentinel 2^(W/2) - 1 are
 // stored as the sentinel.  Entries that do not qualify (narrower, all null, floats / decimals, already squeezed) are
 // left as they are.  *out_squeezed (optional) receives how many entries were squeezed.
-lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed) {
+static lc_status squeeze_half_width(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed, bool quantize) {
     return guarded([&]() -> lc_status {
     if (!ctx || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
     if (out_squeezed) *out_squeezed = 0;
@@ -2521,7 +2571,9 @@ lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, u
             auto it = ctx->entries.find(entry_ids[i]);
             if (it == ctx->entries.end()) return fail(LC_NOT_STAGED, "entry is not staged");
             const Entry& e = it->second;
-            if (e.is_str || e.fd.kind != kKindInt || e.all_null || e.W < 8 || e.clamped || e.squeezed_field >= 0) continue;
+            // integers (both policies) and decimals (LiquidDecimalArray::squeeze always quantizes, decimal_array.rs:300-345)
+            const bool kind_ok = e.fd.kind == kKindInt || (quantize && e.fd.kind == kKindDecimal);
+            if (e.is_str || !kind_ok || e.all_null || e.W < 8 || e.clamped || e.quantized || e.squeezed_field >= 0) continue;
             by_lane[e.fd.lane_log2].push_back(entry_ids[i]);
         }
     }
@@ -2532,11 +2584,16 @@ lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, u
         if (rc != LC_OK) return rc;
         std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
         const uint64_t rows = scan->total_rows, m = scan->n;
-        const size_t vw = scan->meta[0].fd.value_width;
+        const bool decimal = scan->meta[0].fd.kind == kKindDecimal;
+        const size_t vw = decimal ? 8 : scan->meta[0].fd.value_width;   // decimals: the u64 offsets, not i128 values
         const size_t nblk = size_t(m) * scan->bpe;
         // descriptors with reference 0: the gather then yields the packed-domain offsets themselves
         std::vector<FixedDesc> zero_ref(m);
-        for (uint64_t i = 0; i < m; i++) { zero_ref[i] = scan->meta[i].fd; zero_ref[i].reference = 0; }
+        for (uint64_t i = 0; i < m; i++) {
+            zero_ref[i] = scan->meta[i].fd;
+            zero_ref[i].reference = 0;
+            if (decimal) { zero_ref[i].kind = kKindInt; zero_ref[i].value_width = 8; zero_ref[i].is_signed = 0; }
+        }
         FixedDesc* d_descs0 = static_cast<FixedDesc*>(pool_alloc(ctx, m * sizeof(FixedDesc)));
         uint8_t* d_vals = static_cast<uint8_t*>(pool_alloc(ctx, std::max<uint64_t>(rows, 1) * vw + 64));
         uint8_t* d_scr = static_cast<uint8_t*>(pool_alloc(ctx, nblk * 4 + fixed_gather_offsets_len(nblk) * 8 + (m + 1) * 8 + 64));
@@ -2571,6 +2628,12 @@ lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, u
             it.orig_W = e.W;
             it.forced_W = std::max(e.W / 2, 1);   // "new squeezed bit width is half of the original" (:612)
             it.clamp_max = (uint64_t(1) << it.forced_W) - 1;
+            it.quantize = quantize;
+            it.logical = e.logical;
+            it.dec_precision = e.dec_precision;
+            it.dec_scale = e.dec_scale;
+            it.dec_is256 = e.dec_is256;
+            it.entry_value_width = e.fd.value_width;
             it.entry_reference = e.fd.reference;
             row0 += e.len;
         }
@@ -2580,6 +2643,13 @@ lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, u
     }
     return LC_OK;
     });
+}
+
+lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed) {
+    return squeeze_half_width(ctx, n, entry_ids, out_squeezed, false);
+}
+lc_status lc_squeeze_quantize(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed) {
+    return squeeze_half_width(ctx, n, entry_ids, out_squeezed, true);
 }
 
 lc_status lc_scan_date_part(lc_ctx* ctx, lc_scan* scan, void* d_values, uint64_t n_values, int32_t field, void* stream) {

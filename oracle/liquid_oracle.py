@@ -518,3 +518,78 @@ def like_match(s: bytes, pattern: bytes) -> bool:
 def fingerprint(s: bytes) -> int:
     a = _u8(s) if len(s) else np.zeros(1, np.uint8)
     return lib().lo_fingerprint(_ptr(a), len(s))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Quantize squeeze (test infrastructure like everything in this directory)
+#   squeeze:   LiquidPrimitiveArray::squeeze, IntegerSqueezePolicy::Quantize    primitive_array.rs:455-498
+#   predicate: LiquidPrimitiveQuantizedArray::try_eval_predicate_inner          hybrid_primitive_array.rs:487-665
+#   selection: try_eval_predicate filters first, then evaluates                 hybrid_primitive_array.rs:700-760
+# ------------------------------------------------------------------------------------------------------------------
+class NeedsBacking(Exception):
+    """SqueezeResult::Err(NeedsBacking): the squeezed data cannot decide, the caller reads the full bytes."""
+
+
+def quantize_squeeze(values, validity, signed: bool):
+    """(buckets, reference, bucket_width, new_bit_width) of the Quantize policy, or None when the array is not
+    squeezable (original width < 8, primitive_array.rs:600-611).  `values`: python ints / numpy; `validity`: bools."""
+    vals = [int(v) for v in values]
+    valid = [True] * len(vals) if validity is None else [bool(b) for b in validity]
+    present = [v for v, ok in zip(vals, valid) if ok]
+    if not present:
+        return None
+    reference = min(present)
+    offsets = [(v - reference) if ok else 0 for v, ok in zip(vals, valid)]
+    orig_bw = get_bit_width(max(offsets))
+    if orig_bw < 8:
+        return None
+    new_bw = max(orig_bw // 2, 1)
+    count = 1 << new_bw
+    range_size = min(max(offsets) + 1, (1 << 64) - 1)
+    width = max(-(-range_size // count), 1)
+    buckets = [min(o // width, count - 1) for o in offsets]
+    return buckets, reference, width, new_bw
+
+
+def quantized_eval(buckets, validity, reference: int, width: int, op: int, k: int, selection=None,
+                   decimal: bool = False) -> BoolResult:
+    """Result over the selected rows, or raises NeedsBacking on the first valid selected row in k's bucket that the
+    bucket does not decide.  decimal=True: LiquidDecimalQuantizedArray (decimal_array.rs:416-512), the same rule except
+    that its `less_side` also lists Eq (:462-465) — rows of lower buckets answer true to `= k`."""
+    n = len(buckets)
+    valid = [True] * n if validity is None else [bool(b) for b in validity]
+    rows = [i for i in range(n) if selection is None or selection[i]]
+    below_const = {EQ: False, NE: True, LT: False, LE: False, GT: True, GE: True}[op]
+    out = []
+    if k < reference:
+        out = [valid[i] and below_const for i in rows]
+    else:
+        rel = k - reference
+        q, r = divmod(rel, width)
+        less_side = {EQ: decimal, NE: True, LT: True, LE: True, GT: False, GE: False}[op]
+        greater_side = {EQ: False, NE: True, LT: False, LE: False, GT: True, GE: True}[op]
+        if op == LT:
+            equal = False if r == 0 else None
+        elif op == LE:
+            equal = True if r + 1 == width else None
+        elif op == GT:
+            equal = False if r + 1 == width else None
+        elif op == GE:
+            equal = True if r == 0 else None
+        else:
+            equal = None
+        for i in rows:
+            if not valid[i]:
+                out.append(False)
+                continue
+            b = buckets[i]
+            if b < q:
+                out.append(less_side)
+            elif b > q:
+                out.append(greater_side)
+            elif equal is None:
+                raise NeedsBacking()
+            else:
+                out.append(equal)
+    has_nulls = validity is not None
+    return BoolResult(np.array(out, dtype=bool), np.array([valid[i] for i in rows], dtype=bool) if has_nulls else None)

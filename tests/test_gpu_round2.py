@@ -755,3 +755,186 @@ def test_clamp_squeeze_resolvable_and_unresolvable(gpu_cache, oracle, name, np_d
     gpu_cache.insert(7, pa.array(rng.integers(0, 100, size=1000)))
     gpu_cache.insert(8, pa.array(rng.normal(size=1000)))
     assert gpu_cache.squeeze_clamp([7, 8]) == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# quantize-squeezed integers: LiquidPrimitiveQuantizedArray, hybrid_primitive_array.rs:427-665
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,np_dtype,dtype,base,bits", [("uint32", np.uint32, pa.uint32(), 1_000_000, 16),
+                                                            ("int32", np.int32, pa.int32(), -1_000_000, 16),
+                                                            ("int64", np.int64, pa.int64(), -(1 << 40), 37),
+                                                            ("int16", np.int16, pa.int16(), -20_000, 14),
+                                                            ("uint64", np.uint64, pa.uint64(), 1 << 50, 24)])
+def test_quantize_squeeze_resolvable_and_unresolvable(gpu_cache, oracle, name, np_dtype, dtype, base, bits):
+    """The structure of the reference's quantize_predicate_eval_*_resolvable_and_unresolvable tests
+    (hybrid_primitive_array.rs:1111-1275) on the device form: literals below the minimum are decided for every
+    operator, `=` on a present value needs the backing bytes; beyond that every (operator, literal) around bucket
+    boundaries is compared with the oracle's restatement of try_eval_predicate_inner, and — where it decides — with
+    the evaluation of the full array."""
+    lo = oracle
+    rng = np.random.default_rng(0x5184)
+    n = 6000
+    vals = (rng.integers(0, 1 << bits, size=n).astype(object) + base)
+    vals[:3] = [base, base + (1 << bits) - 1, base + 5]
+    vals = np.array([int(v) for v in vals], dtype=np_dtype)
+    valid = rng.random(n) > 0.2
+    valid[:3] = True
+    arr = pa.array(vals, mask=~valid)
+    eid = lc.ParquetArrayID.new(41, 0, 1, 0)
+    gpu_cache.insert(eid, arr)
+    full = gpu_cache.entry_bytes(eid)
+    W = gpu_cache.entry_info(eid).bit_width
+    assert W >= 8
+    buckets, reference, width, new_bw = lo.quantize_squeeze([int(v) for v in vals], valid, np.issubdtype(np_dtype, np.signedinteger))
+    assert gpu_cache.squeeze_quantize([eid]) == 1
+    info = gpu_cache.entry_info(eid)
+    assert info.bit_width == new_bw == W // 2 and info.quantized_from_bit_width == W and info.clamped_from_bit_width == 0
+    assert info.quantized_bucket_width == width
+    sel = rng.random(n) < 0.5
+    mn = int(vals[valid].min())
+    assert mn == reference
+
+    def run(op, k, selection):
+        expr = lc.LiquidExpr.try_new(op, int(k), dtype)
+        b = gpu_cache.eval_predicate(eid, expr)
+        return (b.with_selection(selection) if selection is not None else b).read()
+
+    def check(op, k, selection):
+        try:
+            want = lo.quantized_eval(buckets, valid, reference, width, lo.OP_NAMES[op], int(k), selection)
+        except lo.NeedsBacking:
+            with pytest.raises(lc.LiquidCacheError) as ex:
+                run(op, k, selection)
+            assert ex.value.status == N.LC_NEEDS_BACKING, (op, k)
+            return False
+        got = run(op, k, selection)
+        gv = np.asarray(got.to_numpy(zero_copy_only=False), dtype=object)
+        gm = ~np.asarray(got.is_null().to_numpy(zero_copy_only=False), dtype=bool)
+        assert gm.tolist() == want.validity.tolist(), (op, k)
+        assert [bool(x) for x, m in zip(gv, gm) if m] == [bool(x) for x, m in zip(want.values, want.validity) if m], (op, k)
+        # a decided result IS the result on the full array
+        ref = lo.eval_predicate(full, lo.OP_NAMES[op], int(k), selection)
+        assert [bool(x) for x, m in zip(gv, gm) if m] == [bool(x) for x, m in zip(ref.values, ref.validity) if m], (op, k)
+        return True
+
+    # the reference test's resolvable cases (no IO) ...
+    for op, k, const in (("eq", mn - 1, False), ("ne", mn - 1, True), ("lt", mn, False), ("le", mn - 1, False),
+                         ("gt", mn - 1, True), ("ge", mn, True)):
+        assert check(op, k, None)
+        got = run(op, k, None)
+        assert all(bool(x) == const for x in got.to_pylist() if x is not None)
+    # ... and its unresolvable one: `=` on a present value
+    k_present = int(vals[valid][0])
+    assert not check("eq", k_present, None)
+    # bucket boundaries: first / last / interior value of a populated bucket, the last bucket, beyond the maximum
+    qs = sorted({buckets[i] for i in range(n) if valid[i]})
+    decided = 0
+    for q in (qs[1], qs[len(qs) // 2], qs[-1]):
+        for k in (reference + q * width, reference + q * width + width - 1, reference + q * width + width // 2):
+            for op in ("eq", "ne", "lt", "le", "gt", "ge"):
+                decided += check(op, k, sel)
+                decided += check(op, k, None)
+    assert decided >= 12
+    top = reference + ((1 << new_bw)) * width
+    if top + 5 <= np.iinfo(np_dtype).max:
+        for op in ("eq", "ne", "lt", "le", "gt", "ge"):
+            assert check(op, top + 5, sel)
+    # a selection that avoids the literal's bucket is decided whatever the operator
+    q = qs[len(qs) // 2]
+    away = valid & (np.array(buckets) != q)
+    for op in ("eq", "ne", "lt", "le", "gt", "ge"):
+        assert check(op, reference + q * width + 1, away)
+    # reads always need the backing bytes (to_arrow_array hydrates, :688-690)
+    for call in (lambda: gpu_cache.get(eid).read(), lambda: gpu_cache.get(eid).with_selection(sel).read(),
+                 lambda: gpu_cache.entry_bytes(eid)):
+        with pytest.raises(lc.LiquidCacheError) as ex:
+            call()
+        assert ex.value.status == N.LC_NEEDS_BACKING
+    # fused pair of range conjuncts on a scan of quantized + plain entries
+    eid2 = lc.ParquetArrayID.new(41, 0, 1, 1)
+    gpu_cache.insert(eid2, arr)
+    scan = gpu_cache.scan([eid, eid2])
+    lo_k, hi_k = reference + qs[1] * width, reference + qs[-2] * width + width - 1   # first of a bucket, last of a bucket
+    e1, e2 = lc.LiquidExpr.try_new("ge", int(lo_k), dtype), lc.LiquidExpr.try_new("le", int(hi_k), dtype)
+    words = int(scan.mask_words)
+    lib, ctx = gpu_cache._lib, gpu_cache.handle
+    d_mask, d_cnt = C.c_void_p(), C.c_void_p()
+    N.check(lib.lc_device_alloc(ctx, words * 8, C.byref(d_mask)), ctx)
+    N.check(lib.lc_device_alloc(ctx, 8, C.byref(d_cnt)), ctx)
+    try:
+        assert scan.eval_and([e1, e2], d_mask.value, 0, d_cnt.value)
+        cnt = np.zeros(2, np.uint32)
+        N.check(lib.lc_device_to_host(ctx, cnt.ctypes.data_as(C.c_void_p), d_cnt, 8, None), ctx)
+        want = int((valid & (vals.astype(object) >= lo_k) & (vals.astype(object) <= hi_k)).sum())
+        assert cnt.tolist() == [want, want]
+        # the same pair moved inside its buckets cannot be decided for the quantized entry
+        e3 = lc.LiquidExpr.try_new("ge", int(lo_k + 1), dtype)
+        with pytest.raises(lc.LiquidCacheError) as ex:
+            scan.eval_and([e3, e2], d_mask.value, 0, d_cnt.value)
+        assert ex.value.status == N.LC_NEEDS_BACKING
+    finally:
+        lib.lc_device_free(ctx, d_mask)
+        lib.lc_device_free(ctx, d_cnt)
+    del scan
+    # restoring the backing bytes brings the full entry back
+    gpu_cache.stage([eid], [full], data_types=[dtype])
+    assert gpu_cache.entry_info(eid).quantized_from_bit_width == 0 and gpu_cache.get(eid).read().equals(arr)
+    gpu_cache.insert(7, pa.array(rng.integers(0, 100, size=1000)))
+    assert gpu_cache.squeeze_quantize([7]) == 0
+
+
+def test_quantize_squeeze_decimal(gpu_cache, oracle):
+    """LiquidDecimalArray::squeeze -> LiquidDecimalQuantizedArray (decimal_array.rs:300-512): the u64 offsets of the
+    unscaled values are bucketed at half the width; the predicate rule is the integer one except for the reference's
+    `= k` on lower buckets (answers true, :462-465), which the device reproduces."""
+    import decimal
+    lo = oracle
+    rng = np.random.default_rng(0x5187)
+    n = 5000
+    unscaled = [int(x) for x in rng.integers(10_000, 10_000 + (1 << 20), size=n)]
+    valid = rng.random(n) > 0.15
+    valid[:2] = True
+    unscaled[0], unscaled[1] = 10_000, 10_000 + (1 << 20) - 1
+    col = [u if v else None for u, v in zip(unscaled, valid)]
+    liquid = lo.encode_decimal(col, precision=15, scale=2)
+    eid = lc.ParquetArrayID.new(42, 0, 1, 0)
+    gpu_cache.stage([eid], [liquid])
+    W = gpu_cache.entry_info(eid).bit_width
+    buckets, reference, width, new_bw = lo.quantize_squeeze(unscaled, valid, False)
+    assert gpu_cache.squeeze_quantize([eid]) == 1
+    info = gpu_cache.entry_info(eid)
+    assert (info.bit_width, info.quantized_from_bit_width, info.quantized_bucket_width) == (new_bw, W, width)
+    assert info.logical_type == 6
+    dtype = pa.decimal128(15, 2)
+    sel = rng.random(n) < 0.5
+    qs = sorted({buckets[i] for i in range(n) if valid[i]})
+    decided = 0
+    for k in (reference - 3, reference + qs[2] * width, reference + qs[2] * width + width - 1,
+              reference + qs[len(qs) // 2] * width + 1, reference + (1 << new_bw) * width + 11):
+        for op in ("eq", "ne", "lt", "le", "gt", "ge"):
+            for selection in (None, sel):
+                expr = lc.LiquidExpr.try_new(op, decimal.Decimal(k).scaleb(-2), dtype)
+                b = gpu_cache.eval_predicate(eid, expr)
+                b = b.with_selection(selection) if selection is not None else b
+                try:
+                    want = lo.quantized_eval(buckets, valid, reference, width, lo.OP_NAMES[op], k, selection, decimal=True)
+                except lo.NeedsBacking:
+                    with pytest.raises(lc.LiquidCacheError) as ex:
+                        b.read()
+                    assert ex.value.status == N.LC_NEEDS_BACKING, (op, k)
+                    continue
+                got = b.read()
+                gv = np.asarray(got.to_numpy(zero_copy_only=False), dtype=object)
+                gm = ~np.asarray(got.is_null().to_numpy(zero_copy_only=False), dtype=bool)
+                assert gm.tolist() == want.validity.tolist(), (op, k)
+                assert [bool(x) for x, m in zip(gv, gm) if m] == [bool(x) for x, m in zip(want.values, want.validity) if m], (op, k)
+                decided += 1
+                if op != "eq" and k >= reference:   # decided results are the full array's, except the reference's `=` quirk
+                    ref = lo.eval_predicate(liquid, lo.OP_NAMES[op], k, selection)
+                    assert [bool(x) for x, m in zip(gv, gm) if m] == [bool(x) for x, m in zip(ref.values, ref.validity) if m], (op, k)
+    assert decided >= 20
+    with pytest.raises(lc.LiquidCacheError) as ex:
+        gpu_cache.get(eid).read()
+    assert ex.value.status == N.LC_NEEDS_BACKING
+    gpu_cache.stage([eid], [liquid])
+    assert gpu_cache.entry_info(eid).quantized_from_bit_width == 0
