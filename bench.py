@@ -55,7 +55,9 @@ def parse_args(argv=None):
     p.add_argument("--needle", default="google")
     p.add_argument("--needle-ppm", type=int, default=159,
                    help="distinct URLs per million that contain the needle (ClickBench hits: 15,911 of 99,997,497 rows match)")
-    p.add_argument("--workload", default="url_like", choices=["url_like", "int64_gt"])
+    p.add_argument("--workload", default="url_like", choices=["url_like", "int64_gt", "tpch_q6"],
+                   help="tpch_q6: BASELINE.json config 4 (l_shipdate range + l_discount range + l_quantity, row-range "
+                        "sharded; --rows-total defaults to SF100's 600,037,902 lineitem rows)")
     p.add_argument("--int-bits", type=int, default=62, help="int64_gt: FoR bit width of every batch (WatchID ~62)")
     p.add_argument("--int-kind", default="int64", choices=["int64", "int16", "date32", "decimal"],
                    help="int64_gt: Arrow type the integers are staged as (int16 / date32 / decimal128(15,2) for the narrow-"
@@ -379,49 +381,85 @@ def secondary_int_columns(cache, lc, N, args, rows, threads, torch, stream, iter
     return out
 
 
-def secondary_tpch_q6(cache, lc, N, args, rows, threads, torch, stream, iters):
-    """TPC-H Q6-shaped pushdown (SURVEY §8d config 4): l_shipdate >= d1 AND l_shipdate < d2 AND l_discount >= 0.05 AND
-    l_discount <= 0.07 AND l_quantity < 24, every mask the selection of the next predicate; `fused` evaluates the two
-    range pairs in one pass each (lc_scan_eval_and).  COUNT(*) per batch is checked against numpy, exactly."""
-    import pyarrow as pa
-    DEC = pa.decimal128(15, 2)
+def q6_literals():
     epoch = datetime.date(1970, 1, 1)
-    d_lo = (datetime.date(1992, 1, 2) - epoch).days
-    d1, d2 = (datetime.date(1994, 1, 1) - epoch).days, (datetime.date(1995, 1, 1) - epoch).days
+    return ((datetime.date(1992, 1, 2) - epoch).days, (datetime.date(1994, 1, 1) - epoch).days,
+            (datetime.date(1995, 1, 1) - epoch).days)
+
+
+def q6_synth_batch(L, seed, global_batch, n, bufs):
+    """Synthetic lineitem columns of one batch, keyed by the GLOBAL batch index.  ship: 2^12 days from 1992-01-02 (W=12;
+    the SF100 column spans 2,526 days); discount 0..15 hundredths (W=4, TPC-H has 0..10); quantity 1..64, x100 as the
+    unscaled Decimal(15,2) (W=13, TPC-H has 1..50)."""
+    ship, disc, qty = bufs
+    L.lc_synth_int64_batch(seed + 101, global_batch, n, 12, q6_literals()[0], ship.ctypes.data)
+    L.lc_synth_int64_batch(seed + 102, global_batch, n, 4, 0, disc.ctypes.data)
+    L.lc_synth_int64_batch(seed + 103, global_batch, n, 6, 1, qty.ctypes.data)
+    return ship[:n], disc[:n], qty[:n] * 100
+
+
+def q6_expected_count(sh, di, qt):
+    _, d1, d2 = q6_literals()
+    return int(((sh >= d1) & (sh < d2) & (di >= 5) & (di <= 7) & (qt < 2400)).sum())
+
+
+def stage_q6_columns(cache, lc, N, args, rows, threads, batch0=0):
+    """l_shipdate (Date32), l_discount and l_quantity (Decimal128(15,2)) for `rows` rows starting at global batch
+    `batch0` (the synthetic generator is keyed by the GLOBAL batch index, so a shard holds the same bytes whatever the
+    number of ranks).  Returns (ids per column, expected COUNT(*) per batch from numpy)."""
+    import pyarrow as pa
     bs = args.batch_size
     n_batches = (rows + bs - 1) // bs
     L = N.load()
-    ids = {c: [lc.ParquetArrayID.new(2, b // args.row_group_batches, c, b % args.row_group_batches)
+    ids = {c: [lc.ParquetArrayID.new(2, (b + batch0) // args.row_group_batches, c, (b + batch0) % args.row_group_batches)
                for b in range(n_batches)] for c in (10, 6, 4)}
     expected = np.zeros(n_batches, np.int64)
 
     def stage(chunk):
-        # ship: 2^12 days from 1992-01-02 (W=12; the SF100 column spans 2,526 days); discount 0..15 hundredths (W=4, TPC-H
-        # has 0..10); quantity 1..64 (W=13 after the x100 scale, TPC-H has 1..50)
-        ship, disc, qty = np.zeros(bs, np.int64), np.zeros(bs, np.int64), np.zeros(bs, np.int64)
+        bufs = [np.zeros(bs, np.int64) for _ in range(3)]
         for b in range(chunk, n_batches, threads):
             n = min(bs, rows - b * bs)
-            L.lc_synth_int64_batch(args.seed + 101, b, n, 12, d_lo, ship.ctypes.data)
-            L.lc_synth_int64_batch(args.seed + 102, b, n, 4, 0, disc.ctypes.data)
-            L.lc_synth_int64_batch(args.seed + 103, b, n, 6, 1, qty.ctypes.data)
-            sh, di, qt = ship[:n], disc[:n], qty[:n] * 100
-            expected[b] = int(((sh >= d1) & (sh < d2) & (di >= 5) & (di <= 7) & (qt < 2400)).sum())
+            sh, di, qt = q6_synth_batch(L, args.seed, b + batch0, n, bufs)
+            expected[b] = q6_expected_count(sh, di, qt)
             cache.insert(ids[10][b], pa.array(sh.astype(np.int32), type=pa.date32()))
             cache.insert(ids[6][b], _dec_array(pa, di))
             cache.insert(ids[4][b], _dec_array(pa, qt))
 
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(stage, range(threads)))
-    ids_ship, ids_disc, ids_qty = ids[10], ids[6], ids[4]
-    s_ship, s_disc, s_qty = cache.scan(ids_ship), cache.scan(ids_disc), cache.scan(ids_qty)
-    words = int(s_ship.mask_words)
-    masks = [torch.zeros(words, dtype=torch.int64, device="cuda") for _ in range(2)]
-    counts = torch.zeros(s_ship.entries, dtype=torch.int32, device="cuda")
+    return ids, expected
+
+
+def q6_conjuncts(lc, s_ship, s_disc, s_qty):
+    import pyarrow as pa
+    DEC = pa.decimal128(15, 2)
     E = lc.LiquidExpr.try_new
     conj = [(s_ship, E(">=", datetime.date(1994, 1, 1), pa.date32())), (s_ship, E("<", datetime.date(1995, 1, 1), pa.date32())),
             (s_disc, E(">=", decimal.Decimal("0.05"), DEC)), (s_disc, E("<=", decimal.Decimal("0.07"), DEC)),
             (s_qty, E("<", decimal.Decimal("24.00"), DEC))]
     fused = [(s_ship, [conj[0][1], conj[1][1]]), (s_disc, [conj[2][1], conj[3][1]]), (s_qty, [conj[4][1]])]
+    return conj, fused
+
+
+Q6_WIDTHS = {"ship": 12, "disc": 4, "qty": 13}
+
+
+def q6_algorithmic_bytes(rows, passes):
+    # SURVEY §8d: n*W/8 + selection n/8 (all but the first pass) + n/8 out
+    return sum(rows * Q6_WIDTHS[c] // 8 + (rows // 8 if has_sel else 0) + rows // 8 for c, has_sel in passes)
+
+
+def secondary_tpch_q6(cache, lc, N, args, rows, threads, torch, stream, iters):
+    """TPC-H Q6-shaped pushdown (SURVEY §8d config 4): l_shipdate >= d1 AND l_shipdate < d2 AND l_discount >= 0.05 AND
+    l_discount <= 0.07 AND l_quantity < 24, every mask the selection of the next predicate; `fused` evaluates the two
+    range pairs in one pass each (lc_scan_eval_and).  COUNT(*) per batch is checked against numpy, exactly."""
+    ids, expected = stage_q6_columns(cache, lc, N, args, rows, threads)
+    ids_ship, ids_disc, ids_qty = ids[10], ids[6], ids[4]
+    s_ship, s_disc, s_qty = cache.scan(ids_ship), cache.scan(ids_disc), cache.scan(ids_qty)
+    words = int(s_ship.mask_words)
+    masks = [torch.zeros(words, dtype=torch.int64, device="cuda") for _ in range(2)]
+    counts = torch.zeros(s_ship.entries, dtype=torch.int32, device="cuda")
+    conj, fused = q6_conjuncts(lc, s_ship, s_disc, s_qty)
 
     def run_chain():
         sel = 0
@@ -439,7 +477,6 @@ def secondary_tpch_q6(cache, lc, N, args, rows, threads, torch, stream, iters):
             sel = out.data_ptr()
 
     res = {"rows": int(rows), "conjuncts": 5, "count": int(expected.sum())}
-    widths = {"ship": 12, "disc": 4, "qty": 13}
     for tag, fn, passes in (("chained_5_passes", run_chain, [("ship", 0), ("ship", 1), ("disc", 1), ("disc", 1), ("qty", 1)]),
                             ("fused_3_passes", run_fused, [("ship", 0), ("disc", 1), ("qty", 1)])):
         for _ in range(2):
@@ -454,8 +491,7 @@ def secondary_tpch_q6(cache, lc, N, args, rows, threads, torch, stream, iters):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
-        # algorithmic bytes of the passes that are run (n*W/8 + selection n/8 (all but the first) + n/8 out)
-        alg = sum(rows * widths[c] // 8 + (rows // 8 if has_sel else 0) + rows // 8 for c, has_sel in passes)
+        alg = q6_algorithmic_bytes(rows, passes)
         res[tag] = {"ms": ms, "rows_per_s": rows / (ms * 1e-3), "algorithmic_bytes": int(alg),
                     "achieved_gbs": alg / (ms * 1e-3) / 1e9, "frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
     # the chain is worth the 5-pass algorithmic bytes to the query whichever way it is run
@@ -624,6 +660,106 @@ def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal, base):
 
 
 # ---------------------------------------------------------------------------------------------------------- main
+def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch, dist):
+    """BASELINE.json config 4 as a bench workload: the Q6-shaped chain over this rank's contiguous row range of a
+    --rows-total table (strong scaling; the shards hold the same bytes whatever the world size, so COUNT(*) is the same
+    number for every N and equals numpy's).  A step = the three fused passes (ship-date pair, discount pair, quantity),
+    every mask the selection of the next, COUNT(*) produced by the last kernel and summed over ranks by an 8-byte
+    all-reduce that overlaps the next step."""
+    from liquid_cache_amd.sharding import PipelinedCountAllReduce
+    t_stage = time.perf_counter()
+    ids, expected = stage_q6_columns(cache, lc, N, args, args.rows, threads, batch0)
+    t_stage = time.perf_counter() - t_stage
+    s_ship, s_disc, s_qty = cache.scan(ids[10]), cache.scan(ids[6]), cache.scan(ids[4])
+    words = int(s_ship.mask_words)
+    masks = [torch.zeros(max(words, 1), dtype=torch.int64, device="cuda") for _ in range(2)]
+    counts = torch.zeros(max(s_ship.entries, 1), dtype=torch.int32, device="cuda")
+    _, fused = q6_conjuncts(lc, s_ship, s_disc, s_qty)
+    reducer = PipelinedCountAllReduce(lambda: torch.zeros((), dtype=torch.int64, device="cuda"), world)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def chain(total_ptr, counts_ptr):
+        sel = 0
+        for i, (scan, exprs) in enumerate(fused):
+            out = masks[i & 1]
+            if i + 1 < len(fused):
+                assert scan.eval_and(exprs, out.data_ptr(), sel, 0, stream)
+            else:
+                scan.eval_count(exprs, out.data_ptr(), total_ptr, sel, counts_ptr, stream)
+            sel = out.data_ptr()
+
+    def step():
+        total = reducer.acquire()
+        chain(total.data_ptr(), 0)
+        reducer.submit()
+
+    for _ in range(args.warmup):
+        step()
+    reducer.drain()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    reducer.drain()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    hits = int(reducer.last().item())
+    # per-batch counts of the last pass == numpy's per batch; their sum over ranks == the fused COUNT(*)
+    scratch = torch.zeros((), dtype=torch.int64, device="cuda")
+    chain(scratch.data_ptr(), counts.data_ptr())
+    torch.cuda.synchronize()
+    got = counts.cpu().numpy().astype(np.int64)[: len(expected)]
+    assert got.tolist() == expected.tolist(), "device COUNT(*) per batch differs from numpy"
+    sums = torch.tensor([int(expected.sum()), int(s_ship.rows)], dtype=torch.int64, device="cuda")
+    if world > 1:
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    assert int(sums[0].item()) == hits, "fused COUNT(*) %d != numpy %d" % (hits, int(sums[0].item()))
+    rows_all = int(sums[1].item())
+    # kernel time of one chain on this rank (HIP events on the launch stream)
+    iters = max(5, args.steps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        chain(scratch.data_ptr(), 0)
+    e1.record()
+    torch.cuda.synchronize()
+    chain_ms = e0.elapsed_time(e1) / iters
+    if rank != 0:
+        return
+    rows = int(s_ship.rows)
+    alg3 = q6_algorithmic_bytes(rows, [("ship", 0), ("disc", 1), ("qty", 1)])
+    alg5 = q6_algorithmic_bytes(rows, [("ship", 0), ("ship", 1), ("disc", 1), ("disc", 1), ("qty", 1)])
+    out = {
+        "metric": "filtered rows/s (+ GB/s scanned), TPC-H Q6-shaped pushdown chain (BASELINE.json config 4)",
+        "value": rows_all / elapsed * args.steps, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "vs_baseline": None, "dtype": "date32+decimal128", "data": "synthetic",
+        "config": {"workload": "tpch_q6_shipdate_discount_quantity_chain", "rows_per_gpu": rows, "rows_all_gpus": rows_all,
+                   "batch_rows": args.batch_size, "batches_per_gpu": int(s_ship.entries), "first_global_batch": batch0,
+                   "parallelism": "contiguous row-range shards x%d (assign_row_ranges over equal batches), 8-byte "
+                                  "COUNT(*) all-reduce per step" % world,
+                   "predicate": "l_shipdate >= 1994-01-01 AND l_shipdate < 1995-01-01 AND l_discount BETWEEN 0.05 AND "
+                                "0.07 AND l_quantity < 24", "hits": hits, "hits_match_numpy": True,
+                   "stage_seconds": round(t_stage, 2)},
+        "gb_per_s_scanned": alg5 * world / (elapsed / args.steps) / 1e9,
+        "roofline": {"bound": "hbm", "kernel": "k_fixed_pred_reg (3 fused passes: u32 W=12, u64 W=4, u64 W=13)",
+                     "achieved": alg3 / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": alg3 / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": chain_ms,
+                     "algorithmic_bytes": int(alg3), "effective_gbs_vs_5_pass_bytes": alg5 / (chain_ms * 1e-3) / 1e9},
+    }
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -632,6 +768,9 @@ def main():
     if world != args.gpus and world != 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     scaling = "weak"
+    if args.workload == "tpch_q6" and not args.rows_total:
+        args.rows_total = 600_037_902  # TPC-H SF100 lineitem
+    batch0 = 0
     if args.rows_total:
         # strong scaling: contiguous, batch-aligned row ranges per rank (liquid_cache_amd.sharding.assign_row_ranges
         # over equally weighted batches gives exactly this split)
@@ -639,6 +778,7 @@ def main():
         total_batches = (args.rows_total + args.batch_size - 1) // args.batch_size
         b0, b1 = contiguous_batch_range(total_batches, rank, world)
         args.rows = min(args.rows_total, b1 * args.batch_size) - b0 * args.batch_size
+        batch0 = b0
         scaling = "strong"
 
     import torch
@@ -662,6 +802,9 @@ def main():
     cache = lc.LiquidCacheBuilder.new().with_device(local_rank).with_batch_size(args.batch_size).build()
     n_batches = (args.rows + args.batch_size - 1) // args.batch_size
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, min(world, 8))))
+
+    if args.workload == "tpch_q6":
+        return run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch, dist)
 
     t_stage = time.perf_counter()
     if args.workload == "url_like":

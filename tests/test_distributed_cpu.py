@@ -209,3 +209,35 @@ def test_tpch_q6_sharded_by_row_range(tmp_path, world):
         segs.append(seg.view(np.int64))
     assert int(open(out + ".count").read()) == want_count > 0
     assert np.load(out).tolist() == np.concatenate(segs).tolist()
+
+
+def test_bench_q6_shards_hold_the_same_bytes_for_every_world_size():
+    """bench.py --workload tpch_q6 (config 4): the synthetic lineitem batches are keyed by the GLOBAL batch index and the
+    ranks own contiguous batch ranges, so the per-batch COUNT(*) the ranks check against — and their sum, the number
+    every world size must report — do not depend on the number of ranks."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from liquid_cache_amd import _native as N
+    from liquid_cache_amd import sharding as sh
+    L = N.load()
+    total_rows, bs = 200_000, 8192
+    total_batches = (total_rows + bs - 1) // bs
+    bufs = [np.zeros(bs, np.int64) for _ in range(3)]
+
+    def counts_of(world):
+        out = {}
+        for rank in range(world):
+            b0, b1 = sh.contiguous_batch_range(total_batches, rank, world)
+            rows = min(total_rows, b1 * bs) - b0 * bs
+            for b in range((rows + bs - 1) // bs):
+                n = min(bs, rows - b * bs)
+                sh_, di, qt = bench.q6_synth_batch(L, 42, b + b0, n, bufs)
+                assert (b + b0) not in out
+                out[b + b0] = (n, bench.q6_expected_count(sh_, di, qt))
+        return out
+
+    one = counts_of(1)
+    assert sum(n for n, _ in one.values()) == total_rows and sum(c for _, c in one.values()) > 0
+    for world in (2, 3, 8):
+        assert counts_of(world) == one
