@@ -246,6 +246,24 @@ LC_API lc_status lc_get_date_part_with_selection(lc_ctx* ctx, uint64_t entry_id,
                                                  int32_t field, struct ArrowArray* out_array,
                                                  struct ArrowSchema* out_schema);
 
+/* Partial aggregation under a selection — the step after the path: what DataFusion's AggregateExec
+ * (mode: Partial, the url_prefix_filtering snapshot under datafusion-local/src/tests/snapshots) computes from the rows that
+ * get().with_selection() returns, without returning them.  COUNT, SUM, MIN and MAX of the valid rows of a fixed-width
+ * scan (integers, dates, timestamps, decimals as their unscaled integers) that d_selection selects (null: every row;
+ * usually the hit mask of the last conjunct), one pass over the packed data, result left on the device: the caller
+ * combines the partials of its row ranges / ranks (sum of counts and sums, min of mins, ...).  The sum is exact
+ * (128-bit two's complement: lo, hi); min / max are the value's 64-bit pattern (signed or unsigned as the column) and
+ * only meaningful when count > 0.  Asynchronous on `stream`.  LC_UNSUPPORTED for floats and byte views,
+ * LC_NEEDS_BACKING when a selected row of a squeezed entry has no value in HBM. */
+typedef struct {
+    uint64_t count;
+    uint64_t sum_lo, sum_hi;
+    uint64_t min, max;
+    uint64_t reserved;
+} lc_aggregate;
+LC_API lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_out /* lc_aggregate */,
+                                   void* stream);
+
 /* Squeeze Date32 / Timestamp entries to ONE calendar component (LiquidPrimitiveArray::squeeze with the hint
  * CacheExpression::extract_date32(field), primitive_array.rs:389-420 -> SqueezedDate32Array, squeezed_date32_array.rs:
  * 46-221): the entry is replaced in HBM by the component, frame-of-reference + bit-packed on u32 lanes (TPC-H ship dates

@@ -600,6 +600,32 @@ class Scan:
         N.check(st, self._cache.handle)
         return True
 
+    def aggregate(self, out_ptr: int, selection_ptr: int = 0, stream: int = 0):
+        """COUNT / SUM / MIN / MAX of the valid selected rows (lc_scan_aggregate): six u64 at `out_ptr` on the device,
+        {count, sum lo, sum hi, min, max, 0}.  Asynchronous."""
+        N.check(self._lib.lc_scan_aggregate(self._cache.handle, self._h, C.c_void_p(selection_ptr or None),
+                                            C.c_void_p(out_ptr), C.c_void_p(stream or None)), self._cache.handle)
+
+    def aggregate_to_host(self, selection_ptr: int = 0, signed: bool = True) -> dict:
+        """Convenience: run `aggregate` and return {count, sum, min, max} as Python ints (None when count == 0)."""
+        lib, ctx = self._lib, self._cache.handle
+        buf = C.c_void_p()
+        N.check(lib.lc_device_alloc(ctx, 48, C.byref(buf)), ctx)
+        try:
+            self.aggregate(buf.value, selection_ptr)
+            host = (C.c_uint64 * 6)()
+            N.check(lib.lc_device_to_host(ctx, C.cast(host, C.c_void_p), buf, 48, None), ctx)
+        finally:
+            lib.lc_device_free(ctx, buf)
+        count, lo, hi, mn, mx = (int(host[i]) for i in range(5))
+        total = (hi << 64) | lo
+        if total >= 1 << 127:
+            total -= 1 << 128
+        if signed:
+            mn = mn - (1 << 64) if mn >= 1 << 63 else mn
+            mx = mx - (1 << 64) if mx >= 1 << 63 else mx
+        return {"count": count, "sum": total if count else None, "min": mn if count else None, "max": mx if count else None}
+
     def eval_count(self, exprs, mask_out_ptr: int, total_out_ptr: int, selection_ptr: int = 0, counts_ptr: int = 0,
                    stream: int = 0):
         """Predicate pass (one predicate or a fusable pair) whose kernel also produces the COUNT(*) of the launch in

@@ -3082,6 +3082,176 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------
+// Partial aggregation under a selection (the step after the path: what DataFusion's AggregateExec
+// does with the rows `get().with_selection()` returns — here without returning them):
+//   k_fixed_agg       per entry COUNT / SUM / MIN / MAX of the packed-domain offsets of the valid selected rows
+//   k_agg_finalize    offsets -> values (reference per entry, exact in 128 bits), entries -> one result
+// Integers, dates, timestamps and decimals (value = reference + offset, primitive_array.rs:357, decimal_array.rs:189).
+// ------------------------------------------------------------------------------------------------------------------
+struct AggPartial {
+    uint64_t count;
+    uint64_t sum_lo, sum_hi;  // sum of the offsets, 128 bits
+    uint64_t min_u, max_u;    // of the offsets (count > 0)
+    uint64_t pad;
+};
+
+template <typename U>
+__global__ __launch_bounds__(kThreads) void k_fixed_agg(const FixedDesc* __restrict__ descs, ScanLaunch L,
+                                                         AggPartial* __restrict__ partials) {
+    constexpr uint32_t TB = LaneTraits<U>::kBits;
+    constexpr uint32_t kBlockBytesMax = 128u * TB;
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][kBlockBytesMax + 128];
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave); entry < L.n_entries; entry += total_waves) {
+        const FixedDesc d = descs[entry];
+        uint64_t cnt = 0, slo = 0, shi = 0, mn = ~uint64_t(0), mx = 0;  // per lane
+        const uint32_t W = d.W;
+        const U mask = (W >= TB) ? U(~U(0)) : U((U(1) << (W & (TB - 1))) - 1);
+        for (uint32_t blk = 0, row0 = 0; W != 0 && row0 < d.len; blk++, row0 += 1024u) {
+            const uint32_t rows = min(1024u, d.len - row0);
+            const uint32_t nwords = (rows + 63u) >> 6;
+            const uint64_t word_base = d.mask_word_off + uint64_t(blk) * 16u;
+            uint64_t act = 0;
+            if (uint32_t(lane) < nwords) {
+                uint64_t tail = ~uint64_t(0);
+                if (uint32_t(lane) == nwords - 1 && (rows & 63u)) tail = (uint64_t(1) << (rows & 63u)) - 1;
+                act = (L.d_selection ? L.d_selection[word_base + lane] : ~uint64_t(0)) & tail;
+                if (d.validity) act &= d.validity[uint64_t(blk) * 16u + lane];  // aggregates skip nulls
+            }
+            const uint32_t blk_count = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(wave_sum_u64(uint64_t(__popcll(act)))))));
+            if (blk_count == 0) continue;
+            uint8_t* buf = lds[wave];
+            const uint8_t* gblk = d.packed + uint64_t(blk) * 128u * W;
+            const bool sparse = blk_count <= 16u;
+            if (!sparse) {
+                const uint32_t nchunks = 8u * W;
+                const uint4* src = reinterpret_cast<const uint4*>(gblk);
+                constexpr int kSteps = int(kBlockBytesMax / 1024u) > 0 ? int(kBlockBytesMax / 1024u) : 1;
+#pragma unroll
+                for (int st = 0; st < kSteps; st++) {
+                    if (uint32_t(st) * 64u < nchunks) {
+                        const uint32_t c = uint32_t(st) * 64u + uint32_t(lane);
+                        if (c < nchunks) async_copy16(src + c, buf + st * 1024);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            }
+            for (uint32_t it = 0; it < nwords; it++) {
+                const uint32_t alo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act)), int(it)));
+                const uint32_t ahi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act >> 32)), int(it)));
+                const uint64_t aw = uint64_t(alo) | (uint64_t(ahi) << 32);
+                if (aw == 0) continue;
+                if ((aw >> lane) & 1) {
+                    uint32_t row, fl;
+                    fl_row_lane<U>(it * 64u + uint32_t(lane), &row, &fl);
+                    const uint64_t u = uint64_t(sparse ? extract_packed<U>(gblk, row, fl, W, mask)
+                                                       : extract_packed<U>(buf, row, fl, W, mask));
+                    cnt++;
+                    slo += u;
+                    shi += slo < u ? 1u : 0u;
+                    mn = min(mn, u);
+                    mx = max(mx, u);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the staging buffer is reused by the next block
+        }
+        // wave reduction: the 128-bit sums limb by limb (64 lanes x 2^32 fits a u64), min / max by butterflies
+        const uint64_t c = wave_sum_u64(cnt);
+        const uint64_t l0 = wave_sum_u64(slo & 0xFFFFFFFFu), l1 = wave_sum_u64(slo >> 32);
+        const uint64_t l2 = wave_sum_u64(shi & 0xFFFFFFFFu), l3 = wave_sum_u64(shi >> 32);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            mn = min(mn, uint64_t(__shfl_xor((unsigned long long)mn, o, kWave)));
+            mx = max(mx, uint64_t(__shfl_xor((unsigned long long)mx, o, kWave)));
+        }
+        if (lane == 0) {
+            unsigned __int128 t = (unsigned __int128)l0 + ((unsigned __int128)l1 << 32) + ((unsigned __int128)l2 << 64) +
+                                  ((unsigned __int128)l3 << 96);
+            AggPartial p;
+            p.count = c;
+            p.sum_lo = uint64_t(t);
+            p.sum_hi = uint64_t(t >> 64);
+            p.min_u = mn;
+            p.max_u = mx;
+            p.pad = 0;
+            partials[entry] = p;
+        }
+    }
+}
+
+// one workgroup: entries -> {count, sum (i128 as lo / hi), min, max} in the value domain
+__global__ __launch_bounds__(1024) void k_agg_finalize(const FixedDesc* __restrict__ descs, const AggPartial* __restrict__ partials,
+                                                        uint32_t n_entries, uint64_t* __restrict__ out /* [6] */) {
+    __shared__ uint64_t sh_cnt[16];
+    __shared__ __int128 sh_sum[16], sh_min[16], sh_max[16];
+    const __int128 kBig = (__int128)1 << 100;
+    uint64_t cnt = 0;
+    __int128 sum = 0, mn = kBig, mx = -kBig;
+    for (uint32_t e = threadIdx.x; e < n_entries; e += blockDim.x) {
+        const AggPartial p = partials[e];
+        if (p.count == 0) continue;
+        const FixedDesc& d = descs[e];
+        const __int128 ref = d.is_signed ? (__int128)int64_t(d.reference) : (__int128)d.reference;
+        const unsigned __int128 su = ((unsigned __int128)p.sum_hi << 64) | p.sum_lo;
+        cnt += p.count;
+        sum += ref * (__int128)p.count + (__int128)su;
+        mn = min(mn, ref + (__int128)p.min_u);
+        mx = max(mx, ref + (__int128)p.max_u);
+    }
+    // 128-bit values cross lanes as two 64-bit halves
+    auto shfl128 = [](__int128 v, int o) {
+        const uint64_t lo = uint64_t(__shfl_xor((unsigned long long)uint64_t(v), o, kWave));
+        const uint64_t hi = uint64_t(__shfl_xor((unsigned long long)uint64_t((unsigned __int128)v >> 64), o, kWave));
+        return (__int128)(((unsigned __int128)hi << 64) | lo);
+    };
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        cnt += uint64_t(__shfl_xor((unsigned long long)cnt, o, kWave));
+        sum += shfl128(sum, o);
+        mn = min(mn, shfl128(mn, o));
+        mx = max(mx, shfl128(mx, o));
+    }
+    const int wave = wave_id(), lane = lane_id();
+    if (lane == 0) { sh_cnt[wave] = cnt; sh_sum[wave] = sum; sh_min[wave] = mn; sh_max[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < int(blockDim.x / kWave); w++) {
+            cnt += sh_cnt[w];
+            sum += sh_sum[w];
+            mn = min(mn, sh_min[w]);
+            mx = max(mx, sh_max[w]);
+        }
+        out[0] = cnt;
+        out[1] = uint64_t((unsigned __int128)sum);
+        out[2] = uint64_t((unsigned __int128)sum >> 64);
+        out[3] = cnt ? uint64_t((unsigned __int128)mn) : 0;
+        out[4] = cnt ? uint64_t((unsigned __int128)mx) : 0;
+        out[5] = 0;
+    }
+}
+
+hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, void* d_partials, uint64_t* d_out,
+                            hipStream_t stream) {
+    if (L.n_entries == 0) return hipMemsetAsync(d_out, 0, 48, stream);
+    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 block(kThreads);
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * (lane_log2 == 6 ? 4 : 8))));
+    AggPartial* p = static_cast<AggPartial*>(d_partials);
+    switch (lane_log2) {
+        case 3: hipLaunchKernelGGL(k_fixed_agg<uint8_t>, grid, block, 0, stream, d_descs, L, p); break;
+        case 4: hipLaunchKernelGGL(k_fixed_agg<uint16_t>, grid, block, 0, stream, d_descs, L, p); break;
+        case 5: hipLaunchKernelGGL(k_fixed_agg<uint32_t>, grid, block, 0, stream, d_descs, L, p); break;
+        case 6: hipLaunchKernelGGL(k_fixed_agg<uint64_t>, grid, block, 0, stream, d_descs, L, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k_agg_finalize, dim3(1), dim3(1024), 0, stream, d_descs, p, L.n_entries, d_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
                                uint64_t capacity_rows, hipStream_t stream) {

@@ -154,6 +154,7 @@ struct lc_scan {
     // generation is never freed while the context lives, so launches need no lock against concurrent staging
     const DevSymtab* d_symtabs = nullptr;
     size_t n_symtabs = 0;
+    void* d_agg_partials = nullptr;  // lc_scan_aggregate: per-entry partials (allocated once)
     uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
     size_t or_tmp_words = 0;
     unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
@@ -1355,6 +1356,7 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_wg_ranges);
     pool_release(s->ctx, s->d_total_acc);
     pool_release(s->ctx, s->d_or_tmp);
+    pool_release(s->ctx, s->d_agg_partials);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
     if (s->pinned) {
@@ -1615,6 +1617,39 @@ lc_status lc_scan_eval_count(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pre
     if (!d_total_out) return fail(LC_ERR_INVALID, "d_total_out is null");
     return scan_eval_impl(ctx, scan, &preds[0], d_selection, d_mask_out, nullptr, d_counts_out, nullptr,
                           static_cast<hipStream_t>(stream), n_preds == 2 ? &preds[1] : nullptr, d_total_out);
+}
+
+lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_out, void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !scan || !d_out) return fail(LC_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (scan->n == 0) {
+        LC_HIP(hipMemsetAsync(d_out, 0, sizeof(lc_aggregate), st));
+        return LC_OK;
+    }
+    if (scan->is_str) return fail(LC_UNSUPPORTED, "aggregates apply to integer, date, timestamp and decimal columns");
+    for (const Entry& e : scan->meta)
+        if (e.fd.kind != kKindInt && e.fd.kind != kKindDecimal)
+            return fail(LC_UNSUPPORTED, "aggregates apply to integer, date, timestamp and decimal columns");
+    std::lock_guard<std::mutex> g(scan->mu);
+    if (scan->has_clamped) {  // a selected row without its value in HBM (clamp sentinel, any quantized row)
+        const lc_status cs = clamp_unresolved_entries(ctx, scan, nullptr, 0, d_selection, st, &scan->needs_backing);
+        if (cs != LC_OK) return cs;
+        if (!scan->needs_backing.empty())
+            return fail(LC_NEEDS_BACKING, "a selected row of a squeezed entry has no value in HBM");
+    }
+    if (!scan->d_agg_partials) {
+        scan->d_agg_partials = pool_alloc(ctx, size_t(scan->n) * kAggPartialBytes);
+        if (!scan->d_agg_partials) return fail(LC_ERR_OOM, "hipMalloc (aggregate partials)");
+    }
+    ScanLaunch L{};
+    L.n_entries = scan->n;
+    L.blocks_per_entry = scan->bpe;
+    L.d_selection = static_cast<const uint64_t*>(d_selection);
+    LC_HIP(launch_fixed_agg(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, scan->d_agg_partials,
+                            static_cast<uint64_t*>(d_out), st));
+    return LC_OK;
+    });
 }
 
 // Multi-column OR (CachedRowGroup::evaluate_selection_with_predicate, src/datafusion/src/cache/mod.rs:111-150): every

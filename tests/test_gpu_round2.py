@@ -938,3 +938,108 @@ def test_quantize_squeeze_decimal(gpu_cache, oracle):
     assert ex.value.status == N.LC_NEEDS_BACKING
     gpu_cache.stage([eid], [liquid])
     assert gpu_cache.entry_info(eid).quantized_from_bit_width == 0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# partial aggregation under a selection: lc_scan_aggregate
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name,dtype,lo_v,hi_v", [("int8", pa.int8(), -128, 127), ("uint16", pa.uint16(), 0, 65535),
+                                                   ("int32", pa.int32(), -(1 << 31), (1 << 31) - 1),
+                                                   ("int64", pa.int64(), -(1 << 63), (1 << 63) - 1),
+                                                   ("uint64", pa.uint64(), 0, (1 << 64) - 1),
+                                                   ("date32", pa.date32(), 8000, 11000),
+                                                   ("narrow", pa.int64(), 1_000_000, 1_000_013)])
+def test_scan_aggregate_matches_python_integers(gpu_cache, name, dtype, lo_v, hi_v):
+    """COUNT / SUM / MIN / MAX of the valid selected rows over several batches (ragged tail, an all-null batch, a
+    constant batch), exact in 128 bits — checked against Python integers, with and without a selection."""
+    rng = np.random.default_rng(abs(hash(name)) % (1 << 32))
+    lens = [8192, 8192, 5000, 8192, 77]
+    ids, vals_all, valid_all = [], [], []
+    for b, n in enumerate(lens):
+        if pa.types.is_unsigned_integer(dtype) and hi_v > (1 << 63):
+            v = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n, dtype=np.uint64)
+        else:
+            v = rng.integers(lo_v, hi_v, size=n, dtype=np.int64, endpoint=True)
+        if b == 3:
+            v[:] = v[0]                         # constant batch (W = 0 after the frame of reference)
+        valid = rng.random(n) > (1.0 if b == 2 else 0.1)   # batch 2 is all null
+        np_t = dtype.to_pandas_dtype() if not pa.types.is_date32(dtype) else np.int32
+        arr = pa.array(v.astype(np_t), mask=~valid)
+        if pa.types.is_date32(dtype):
+            arr = arr.cast(pa.date32())
+        eid = lc.ParquetArrayID.new(50, 0, 3, b)
+        gpu_cache.insert(eid, arr)
+        ids.append(eid)
+        vals_all.append([int(x) for x in v])
+        valid_all.append(valid)
+    scan = gpu_cache.scan(ids)
+    signed = not pa.types.is_unsigned_integer(dtype)
+    lib, ctx = gpu_cache._lib, gpu_cache.handle
+
+    def expect(select):
+        xs = [x for vs, va, se in zip(vals_all, valid_all, select) for x, ok, s in zip(vs, va, se) if ok and s]
+        return {"count": len(xs), "sum": sum(xs) if xs else None, "min": min(xs) if xs else None, "max": max(xs) if xs else None}
+
+    assert scan.aggregate_to_host(0, signed) == expect([np.ones(n, bool) for n in lens])
+    for frac in (0.5, 0.002, 0.0):
+        select = [rng.random(n) < frac for n in lens]
+        words = np.zeros(int(scan.mask_words), np.uint64)
+        offs = scan.segment_offsets
+        for b, se in enumerate(select):
+            packed = np.packbits(se, bitorder="little")
+            seg = np.zeros(((len(se) + 63) // 64) * 8, np.uint8)
+            seg[: len(packed)] = packed
+            words[int(offs[b]): int(offs[b]) + len(seg) // 8] = seg.view(np.uint64)
+        d_sel = C.c_void_p()
+        N.check(lib.lc_device_alloc(ctx, max(words.size, 1) * 8, C.byref(d_sel)), ctx)
+        try:
+            N.check(lib.lc_host_to_device(ctx, d_sel, words.ctypes.data_as(C.c_void_p), words.size * 8, None), ctx)
+            assert scan.aggregate_to_host(d_sel.value, signed) == expect(select), frac
+        finally:
+            lib.lc_device_free(ctx, d_sel)
+
+
+def test_scan_aggregate_decimal_after_predicate_chain_and_rejections(gpu_cache, oracle):
+    """SUM(l_extendedprice) WHERE l_discount BETWEEN .. — the aggregate reads the hit mask of the chain on the device;
+    floats and byte views are rejected, quantized entries need their backing."""
+    import decimal
+    lo = oracle
+    rng = np.random.default_rng(77)
+    n_b, n = 6, 8192
+    DEC = pa.decimal128(15, 2)
+    price, disc, ids_p, ids_d = [], [], [], []
+    for b in range(n_b):
+        p = rng.integers(90_000, 10_500_000, size=n)
+        d = rng.integers(0, 11, size=n)
+        valid = rng.random(n) > 0.05
+        price.append((p, valid))
+        disc.append(d)
+        ip, idd = lc.ParquetArrayID.new(51, 0, 5, b), lc.ParquetArrayID.new(51, 0, 6, b)
+        gpu_cache.stage([ip], [lo.encode_decimal([int(x) if ok else None for x, ok in zip(p, valid)], precision=15, scale=2)])
+        gpu_cache.stage([idd], [lo.encode_decimal([int(x) for x in d], precision=15, scale=2)])
+        ids_p.append(ip)
+        ids_d.append(idd)
+    s_p, s_d = gpu_cache.scan(ids_p), gpu_cache.scan(ids_d)
+    lib, ctx = gpu_cache._lib, gpu_cache.handle
+    d_mask = C.c_void_p()
+    N.check(lib.lc_device_alloc(ctx, int(s_d.mask_words) * 8, C.byref(d_mask)), ctx)
+    try:
+        e1 = lc.LiquidExpr.try_new(">=", decimal.Decimal("0.05"), DEC)
+        e2 = lc.LiquidExpr.try_new("<=", decimal.Decimal("0.07"), DEC)
+        assert s_d.eval_and([e1, e2], d_mask.value)
+        got = s_p.aggregate_to_host(d_mask.value, signed=False)
+        xs = [int(x) for (p, valid), d in zip(price, disc) for x, ok, dd in zip(p, valid, d) if ok and 5 <= dd <= 7]
+        assert got == {"count": len(xs), "sum": sum(xs), "min": min(xs), "max": max(xs)}
+    finally:
+        lib.lc_device_free(ctx, d_mask)
+    fid, sid = lc.ParquetArrayID.new(51, 0, 7, 0), lc.ParquetArrayID.new(51, 0, 8, 0)
+    gpu_cache.insert(fid, pa.array(rng.normal(size=100)))
+    gpu_cache.insert(sid, pa.array(["a", "b"] * 50))
+    for bad in (fid, sid):
+        with pytest.raises(lc.LiquidCacheError) as ex:
+            gpu_cache.scan([bad]).aggregate_to_host()
+        assert ex.value.status == N.LC_UNSUPPORTED
+    assert gpu_cache.squeeze_quantize([ids_p[0]]) == 1
+    with pytest.raises(lc.LiquidCacheError) as ex:
+        gpu_cache.scan(ids_p).aggregate_to_host()
+    assert ex.value.status == N.LC_NEEDS_BACKING
