@@ -25,6 +25,10 @@ run_one() {  # name, env prefix, args
   done
 }
 for wl in url_like url_like_no_fingerprints int64_gt_w62 date32_gt_w12 int16_gt_w12 decimal_gt_w4; do run_one $wl "LC_X=0" "${WL[$wl]}"; done
+# BASELINE.json config 4 at its full size: the Q6-shaped chain over 600,037,902 rows (kernel trace only)
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tpch_q6_trace -- python $R/bench.py --workload tpch_q6 --steps 10 --warmup 2 > $O/tpch_q6_trace.log 2>&1
+f=$(find $O/tpch_q6_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/tpch_q6_kernel_stats.csv
+grep -h '^{"metric"' $O/tpch_q6_trace.log > $O/tpch_q6_bench_line.json
 # the same LIKE scan with the reference's own prefilter only (no bigram signature index staged)
 run_one url_like_no_signatures "LC_NO_SIGNATURES=1" "--workload url_like"
 # FETCH_SIZE calibration on known byte counts
