@@ -287,7 +287,7 @@ struct PackedRange {
 // the value the table below assigns them, but the host never lets such a result out: it first counts them with
 // op == LC_OP_INTERNAL_SENTINEL / inner_op, and any such valid selected row means Err(NeedsBacking), :633-655).
 template <typename U>
-__device__ __noinline__ PackedRange<U> packed_range_quantized(const FixedDesc& d, const FixedPred& pred, uint64_t umax) {
+__device__ __forceinline__ PackedRange<U> packed_range_quantized(const FixedDesc& d, const FixedPred& pred, uint64_t umax) {
     PackedRange<U> r{0, 0, false, -1};
     const bool probe = pred.op == LC_OP_INTERNAL_SENTINEL;
     const int op = probe ? pred.inner_op : pred.op;

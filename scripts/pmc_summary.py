@@ -49,10 +49,15 @@ for d in sorted(glob.glob(os.path.join(root, "*_FETCH_SIZE"))):
             continue
         factor = factors.get(SHAPE[fam]) or 2.0
         wkb = write.get(k, 0.0)
-        out.setdefault(wl, {})[k[:60]] = {"FETCH_SIZE_KB": kb, "WRITE_SIZE_KB": wkb, "launches": n[k],
-                                          "fetch_shape": SHAPE[fam], "fetch_factor": factor,
-                                          "traffic_bytes": int(kb * 1024 * factor + wkb * 1024),
-                                          "traffic_bytes_raw_counter": int(kb * 1024 + wkb * 1024)}
-        out[wl]["traffic_bytes"] = max(out[wl].get("traffic_bytes", 0), int(kb * 1024 * factor + wkb * 1024))
+        short = k.split("(lc::")[0].replace("void lc::(anonymous namespace)::", "")  # kernel + template arguments
+        out.setdefault(wl, {})[short] = {"FETCH_SIZE_KB": kb, "WRITE_SIZE_KB": wkb, "launches": n[k],
+                                         "fetch_shape": SHAPE[fam], "fetch_factor": factor,
+                                         "traffic_bytes": int(kb * 1024 * factor + wkb * 1024),
+                                         "traffic_bytes_raw_counter": int(kb * 1024 + wkb * 1024)}
+        # the workload's figure is that of the kernel the timed loop launches (the one with the most launches; the
+        # byte-accounting instantiation of k_str_pred runs once per process and also reads the fingerprints)
+        if n[k] >= out[wl].get("_launches", 0):
+            out[wl]["_launches"] = n[k]
+            out[wl]["traffic_bytes"] = int(kb * 1024 * factor + wkb * 1024)
 json.dump(out, open(os.path.join(root, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
