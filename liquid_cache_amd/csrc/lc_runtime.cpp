@@ -155,6 +155,10 @@ struct lc_scan {
     const DevSymtab* d_symtabs = nullptr;
     size_t n_symtabs = 0;
     void* d_agg_partials = nullptr;  // lc_scan_aggregate: per-entry partials (allocated once)
+    // facts about the entries, gathered once at creation
+    uint32_t max_dict_len = 0;
+    bool any_without_signatures = false, any_patch = false, any_fingerprints = false, any_float = false;
+    int32_t uniform_slot = -1;             // byte views: the symbol-table slot when every entry shares one, else -1
     uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
     size_t or_tmp_words = 0;
     unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
@@ -1301,6 +1305,16 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             max_len = std::max(max_len, e.len);
             if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
             s->has_clamped |= e.clamped || e.quantized;
+            s->max_dict_len = std::max(s->max_dict_len, e.dict_len);
+            s->any_fingerprints |= e.has_fp;
+            if (e.is_str) {
+                s->any_without_signatures |= e.sd.signatures == nullptr;
+                if (i == 0) s->uniform_slot = int32_t(e.sd.symtab_slot);
+                else if (int32_t(e.sd.symtab_slot) != s->uniform_slot) s->uniform_slot = -1;
+            } else {
+                s->any_patch |= (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) && e.fd.patch_len > 0;
+                s->any_float |= e.fd.kind == kKindF32 || e.fd.kind == kKindF64;
+            }
             s->meta.push_back(e);
         }
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
@@ -1477,12 +1491,12 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     L.d_own_bytes = d_cand_bytes ? static_cast<uint32_t*>(d_cand_bytes) + s->n : nullptr;
     L.uniform_slot = -1;
     L.d_work = s->d_work;
-    for (const Entry& e : s->meta) L.max_dict_len = std::max(L.max_dict_len, e.dict_len);
+    // per-scan facts gathered once at lc_scan_create (walking the entries of a 600 M-row scan per evaluation cost more
+    // host time than the kernel ran: ~150 us gaps between the passes of a predicate chain)
+    L.max_dict_len = s->max_dict_len;
     if (s->is_str && !s->meta.empty()) {
-        for (const Entry& e : s->meta) L.many_candidates |= e.sd.signatures == nullptr ? 1u : 0u;
-        L.uniform_slot = int32_t(s->meta[0].sd.symtab_slot);
-        for (const Entry& e : s->meta)
-            if (e.sd.symtab_slot != s->meta[0].sd.symtab_slot) L.uniform_slot = -1;
+        L.many_candidates = s->any_without_signatures ? 1u : 0u;
+        L.uniform_slot = s->uniform_slot;
     }
     if (!s->is_str) {
         FixedPred fp, fp2;
@@ -1508,9 +1522,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         }
         LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, pred2 ? &fp2 : nullptr,
                                  s->max_w, L, stream));
-        bool any_patch = false;
-        for (const Entry& e : s->meta) any_patch |= (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) && e.fd.patch_len > 0;
-        if (any_patch) {
+        if (s->any_patch) {
             LC_HIP(launch_alp_patch_fix(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, pred2 ? &fp2 : nullptr, L,
                                         stream));
         }
@@ -1521,8 +1533,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     const lc_status st = make_str_pred(pred, &sp);
     if (st != LC_OK) return st;
     if (sp.p.mode == 3)
-        for (const Entry& e : s->meta)
-            if (e.has_fp)
+        if (s->any_fingerprints)
                 return fail(LC_UNSUPPORTED, "general LIKE patterns apply to byte views without fingerprints (the "
                                             "reference requires %needle% on SubstringSearch columns)");
     std::lock_guard<std::mutex> g(s->mu);
@@ -1628,9 +1639,7 @@ lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection,
         return LC_OK;
     }
     if (scan->is_str) return fail(LC_UNSUPPORTED, "aggregates apply to integer, date, timestamp and decimal columns");
-    for (const Entry& e : scan->meta)
-        if (e.fd.kind != kKindInt && e.fd.kind != kKindDecimal)
-            return fail(LC_UNSUPPORTED, "aggregates apply to integer, date, timestamp and decimal columns");
+    if (scan->any_float) return fail(LC_UNSUPPORTED, "aggregates apply to integer, date, timestamp and decimal columns");
     std::lock_guard<std::mutex> g(scan->mu);
     if (scan->has_clamped) {  // a selected row without its value in HBM (clamp sentinel, any quantized row)
         const lc_status cs = clamp_unresolved_entries(ctx, scan, nullptr, 0, d_selection, st, &scan->needs_backing);
