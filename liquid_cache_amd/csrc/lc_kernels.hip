@@ -2296,6 +2296,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
     constexpr uint32_t TB = LaneTraits<U>::kBits;
     constexpr uint32_t kBlockBytesMax = 128u * TB;
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][kBlockBytesMax + 128];
+    __shared__ uint16_t sel_list[kWavesPerBlock][512];
     const int lane = lane_id(), wave = wave_id();
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
     // persistent grid, one wave per ENTRY (descriptor read once, blocks in turn, running output row)
@@ -2340,19 +2341,38 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
     const U mask = (W >= TB) ? U(~U(0)) : U((U(1) << (W & (TB - 1))) - 1);
-    for (uint32_t it = 0; it < nwords; it++) {
-        const uint32_t alo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act)), int(it)));
-        const uint32_t ahi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act >> 32)), int(it)));
-        const uint64_t aw = uint64_t(alo) | (uint64_t(ahi) << 32);
-        if (aw == 0) continue;
-        if (((aw >> lane) & 1) && out_row + lanes_below(aw) < capacity_rows) {
+    // Selected rows are first listed, then decoded densely: 512 rows (eight selection words) at a time, lane l expands
+    // byte l&7 of word l>>3 into row indices at the position a prefix sum of the popcounts assigns it — the list is in row
+    // order.  The decode loop then runs with consecutive lanes on consecutive OUTPUT rows (coalesced stores, every lane
+    // busy) instead of once per 64-row word with only the selected lanes active (at 10 % selectivity: 2 dense steps per
+    // block instead of 16 steps at 6 lanes each).
+    uint16_t* list = sel_list[wave];
+    for (uint32_t g8 = 0; g8 < nwords; g8 += 8) {
+        const uint32_t wsel = g8 + (uint32_t(lane) >> 3);
+        const uint64_t wv = uint64_t(__shfl((unsigned long long)act, int(wsel & 63u), kWave));
+        uint32_t byte = wsel < nwords ? uint32_t(wv >> (8u * (uint32_t(lane) & 7u))) & 0xFFu : 0u;
+        const uint32_t cnt = uint32_t(__popc(byte));
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        const uint32_t total = read_lane(incl, kWave - 1);
+        if (total == 0) continue;
+        uint32_t o = incl - cnt;
+        const uint32_t row_base = wsel * 64u + 8u * (uint32_t(lane) & 7u);
+        while (byte) {
+            const uint32_t bit = uint32_t(__ffs(int(byte))) - 1u;
+            list[o++] = uint16_t(row_base + bit);
+            byte &= byte - 1u;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t j = uint32_t(lane); j < total; j += kWave) {
+            const uint64_t o_row = out_row + j;
+            if (o_row >= capacity_rows) continue;
             U u = 0;
             if (W != 0) {  // all-null entries decode to zeros (PrimitiveArray::new_null)
                 uint32_t row, fl;
-                fl_row_lane<U>(it * 64u + uint32_t(lane), &row, &fl);
+                fl_row_lane<U>(uint32_t(list[j]), &row, &fl);
                 u = sparse ? extract_packed<U>(gblk, row, fl, W, mask) : extract_packed<U>(buf, row, fl, W, mask);
             }
-            const uint64_t o = out_row + lanes_below(aw);
+            const uint64_t o = o_row;
             if (d.kind == kKindInt) {
                 const U v = W != 0 ? U(u + U(d.reference)) : U(0);  // add_wrapping (primitive_array.rs:357)
                 reinterpret_cast<U*>(out)[o] = v;
@@ -2376,7 +2396,8 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
                 }
             }
         }
-        out_row += uint32_t(__popcll(aw));
+        out_row += total;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list is rewritten by the next group
     }
     // ALP patches overwrite the decoded value (float_array.rs:306-310); patch indices are ascending
     if ((d.kind == kKindF32 || d.kind == kKindF64) && d.patch_len) {
