@@ -3110,10 +3110,10 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
 //   k_agg_finalize    offsets -> values (reference per entry, exact in 128 bits), entries -> one result
 // Integers, dates, timestamps and decimals (value = reference + offset, primitive_array.rs:357, decimal_array.rs:189).
 // ------------------------------------------------------------------------------------------------------------------
-struct AggPartial {
+struct AggPartial {            // one per workgroup of k_fixed_agg, in the value domain
     uint64_t count;
-    uint64_t sum_lo, sum_hi;  // sum of the offsets, 128 bits
-    uint64_t min_u, max_u;    // of the offsets (count > 0)
+    uint64_t sum_lo, sum_hi;  // two's complement i128
+    uint64_t min_u, max_u;    // 64-bit pattern of the value (count > 0)
     uint64_t pad;
 };
 
@@ -3125,6 +3125,10 @@ __global__ __launch_bounds__(kThreads) void k_fixed_agg(const FixedDesc* __restr
     __shared__ __attribute__((aligned(16))) uint8_t lds[kWavesPerBlock][kBlockBytesMax + 128];
     const int lane = lane_id(), wave = wave_id();
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    // this wave's entries, in the value domain (lane 0): value = reference + offset, exact in 128 bits
+    const __int128 kBig = (__int128)1 << 100;
+    uint64_t w_cnt = 0;
+    __int128 w_sum = 0, w_min = kBig, w_max = -kBig;
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave); entry < L.n_entries; entry += total_waves) {
         const FixedDesc d = descs[entry];
         uint64_t cnt = 0, slo = 0, shi = 0, mn = ~uint64_t(0), mx = 0;  // per lane
@@ -3189,39 +3193,54 @@ __global__ __launch_bounds__(kThreads) void k_fixed_agg(const FixedDesc* __restr
             mn = min(mn, uint64_t(__shfl_xor((unsigned long long)mn, o, kWave)));
             mx = max(mx, uint64_t(__shfl_xor((unsigned long long)mx, o, kWave)));
         }
-        if (lane == 0) {
-            unsigned __int128 t = (unsigned __int128)l0 + ((unsigned __int128)l1 << 32) + ((unsigned __int128)l2 << 64) +
-                                  ((unsigned __int128)l3 << 96);
-            AggPartial p;
-            p.count = c;
-            p.sum_lo = uint64_t(t);
-            p.sum_hi = uint64_t(t >> 64);
-            p.min_u = mn;
-            p.max_u = mx;
-            p.pad = 0;
-            partials[entry] = p;
+        if (lane == 0 && c != 0) {
+            const unsigned __int128 t = (unsigned __int128)l0 + ((unsigned __int128)l1 << 32) +
+                                        ((unsigned __int128)l2 << 64) + ((unsigned __int128)l3 << 96);
+            const __int128 ref = d.is_signed ? (__int128)int64_t(d.reference) : (__int128)d.reference;
+            w_cnt += c;
+            w_sum += ref * (__int128)c + (__int128)t;
+            w_min = min(w_min, ref + (__int128)mn);
+            w_max = max(w_max, ref + (__int128)mx);
         }
+    }
+    // one record per workgroup (k_agg_finalize then reduces at most a few thousand of them)
+    __shared__ uint64_t sh_cnt[kWavesPerBlock];
+    __shared__ __int128 sh_sum[kWavesPerBlock], sh_min[kWavesPerBlock], sh_max[kWavesPerBlock];
+    if (lane == 0) { sh_cnt[wave] = w_cnt; sh_sum[wave] = w_sum; sh_min[wave] = w_min; sh_max[wave] = w_max; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; w++) {
+            w_cnt += sh_cnt[w];
+            w_sum += sh_sum[w];
+            w_min = min(w_min, sh_min[w]);
+            w_max = max(w_max, sh_max[w]);
+        }
+        AggPartial p;
+        p.count = w_cnt;
+        p.sum_lo = uint64_t((unsigned __int128)w_sum);
+        p.sum_hi = uint64_t((unsigned __int128)w_sum >> 64);
+        p.min_u = uint64_t((unsigned __int128)w_min);  // 64-bit pattern of the value (signed or unsigned as the column)
+        p.max_u = uint64_t((unsigned __int128)w_max);
+        p.pad = 0;
+        partials[blockIdx.x] = p;
     }
 }
 
-// one workgroup: entries -> {count, sum (i128 as lo / hi), min, max} in the value domain
-__global__ __launch_bounds__(1024) void k_agg_finalize(const FixedDesc* __restrict__ descs, const AggPartial* __restrict__ partials,
-                                                        uint32_t n_entries, uint64_t* __restrict__ out /* [6] */) {
+// one workgroup: the workgroup records -> {count, sum (i128 as lo / hi), min, max}
+__global__ __launch_bounds__(1024) void k_agg_finalize(const AggPartial* __restrict__ partials, uint32_t n_partials,
+                                                        int is_signed, uint64_t* __restrict__ out /* [6] */) {
     __shared__ uint64_t sh_cnt[16];
     __shared__ __int128 sh_sum[16], sh_min[16], sh_max[16];
     const __int128 kBig = (__int128)1 << 100;
     uint64_t cnt = 0;
     __int128 sum = 0, mn = kBig, mx = -kBig;
-    for (uint32_t e = threadIdx.x; e < n_entries; e += blockDim.x) {
+    for (uint32_t e = threadIdx.x; e < n_partials; e += blockDim.x) {
         const AggPartial p = partials[e];
         if (p.count == 0) continue;
-        const FixedDesc& d = descs[e];
-        const __int128 ref = d.is_signed ? (__int128)int64_t(d.reference) : (__int128)d.reference;
-        const unsigned __int128 su = ((unsigned __int128)p.sum_hi << 64) | p.sum_lo;
         cnt += p.count;
-        sum += ref * (__int128)p.count + (__int128)su;
-        mn = min(mn, ref + (__int128)p.min_u);
-        mx = max(mx, ref + (__int128)p.max_u);
+        sum += (__int128)(((unsigned __int128)p.sum_hi << 64) | p.sum_lo);
+        mn = min(mn, is_signed ? (__int128)int64_t(p.min_u) : (__int128)p.min_u);
+        mx = max(mx, is_signed ? (__int128)int64_t(p.max_u) : (__int128)p.max_u);
     }
     // 128-bit values cross lanes as two 64-bit halves
     auto shfl128 = [](__int128 v, int o) {
@@ -3255,12 +3274,16 @@ __global__ __launch_bounds__(1024) void k_agg_finalize(const FixedDesc* __restri
     }
 }
 
-hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, void* d_partials, uint64_t* d_out,
-                            hipStream_t stream) {
+uint32_t fixed_agg_workgroups(uint32_t n_entries, int lane_log2) {
+    const uint64_t wgs_needed = (uint64_t(n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    return uint32_t(std::min<uint64_t>(std::max<uint64_t>(wgs_needed, 1), uint64_t(device_cus()) * (lane_log2 == 6 ? 4 : 8)));
+}
+
+hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, int is_signed, const ScanLaunch& L, void* d_partials,
+                            uint64_t* d_out, hipStream_t stream) {
     if (L.n_entries == 0) return hipMemsetAsync(d_out, 0, 48, stream);
-    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
     const dim3 block(kThreads);
-    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * (lane_log2 == 6 ? 4 : 8))));
+    const dim3 grid(fixed_agg_workgroups(L.n_entries, lane_log2));
     AggPartial* p = static_cast<AggPartial*>(d_partials);
     switch (lane_log2) {
         case 3: hipLaunchKernelGGL(k_fixed_agg<uint8_t>, grid, block, 0, stream, d_descs, L, p); break;
@@ -3269,7 +3292,7 @@ hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, const ScanL
         case 6: hipLaunchKernelGGL(k_fixed_agg<uint64_t>, grid, block, 0, stream, d_descs, L, p); break;
         default: return hipErrorInvalidValue;
     }
-    hipLaunchKernelGGL(k_agg_finalize, dim3(1), dim3(1024), 0, stream, d_descs, p, L.n_entries, d_out);
+    hipLaunchKernelGGL(k_agg_finalize, dim3(1), dim3(1024), 0, stream, p, grid.x, is_signed, d_out);
     return hipGetLastError();
 }
 

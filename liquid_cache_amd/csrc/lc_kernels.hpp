@@ -215,11 +215,12 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
 // d_block_counts: n_entries*blocks_per_entry u32; d_block_offsets: that + 1 u64; d_entry_row_offsets: n_entries + 1 u64
 // u64 elements the caller provides for d_block_offsets: n_blocks + 1 offsets followed by the scan's tile sums
 inline size_t fixed_gather_offsets_len(size_t n_blocks) { return n_blocks + 1 + (n_blocks + 1023) / 1024 + 1; }
-// COUNT / SUM / MIN / MAX of the valid selected rows of a fixed-width scan; d_partials: 48 bytes per entry of scratch;
-// d_out: six u64 {count, sum lo, sum hi (two's complement i128), min, max, 0}
+// COUNT / SUM / MIN / MAX of the valid selected rows of a fixed-width scan; d_partials: 48 bytes of scratch per workgroup
+// (fixed_agg_workgroups); d_out: six u64 {count, sum lo, sum hi (two's complement i128), min, max, 0}
 constexpr size_t kAggPartialBytes = 48;
-hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, void* d_partials, uint64_t* d_out,
-                            hipStream_t stream);
+uint32_t fixed_agg_workgroups(uint32_t n_entries, int lane_log2);
+hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, int is_signed, const ScanLaunch& L, void* d_partials,
+                            uint64_t* d_out, hipStream_t stream);
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
                                uint64_t capacity_rows, hipStream_t stream);

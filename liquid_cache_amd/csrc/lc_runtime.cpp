@@ -1648,15 +1648,15 @@ lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection,
             return fail(LC_NEEDS_BACKING, "a selected row of a squeezed entry has no value in HBM");
     }
     if (!scan->d_agg_partials) {
-        scan->d_agg_partials = pool_alloc(ctx, size_t(scan->n) * kAggPartialBytes);
+        scan->d_agg_partials = pool_alloc(ctx, size_t(fixed_agg_workgroups(scan->n, scan->lane_log2)) * kAggPartialBytes);
         if (!scan->d_agg_partials) return fail(LC_ERR_OOM, "hipMalloc (aggregate partials)");
     }
     ScanLaunch L{};
     L.n_entries = scan->n;
     L.blocks_per_entry = scan->bpe;
     L.d_selection = static_cast<const uint64_t*>(d_selection);
-    LC_HIP(launch_fixed_agg(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, scan->d_agg_partials,
-                            static_cast<uint64_t*>(d_out), st));
+    LC_HIP(launch_fixed_agg(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, scan->meta[0].fd.is_signed, L,
+                            scan->d_agg_partials, static_cast<uint64_t*>(d_out), st));
     return LC_OK;
     });
 }
