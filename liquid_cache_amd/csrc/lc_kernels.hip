@@ -554,7 +554,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
                 constexpr int kSteps = int(kBlockBytesMax / 1024u) > 0 ? int(kBlockBytesMax / 1024u) : 1;
 #pragma unroll
                 for (int s = 0; s < kSteps; s++) {
-                    if (uint32_t(s) * 64u < nchunks && !LC_ABL(pred.pad & 2)) {
+                    if (uint32_t(s) * 64u < nchunks && !LC_ABL(pred.debug_flags & 2)) {
                         const uint32_t c = uint32_t(s) * 64u + uint32_t(lane);
                         if (c < nchunks) async_copy16(src + c, buf + s * 1024);
                     }
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (!LC_ABL(pred.pad & 1))
+                if (!LC_ABL(pred.debug_flags & 1))
                 {
                     const uint32_t fo0 = fl[0] * uint32_t(sizeof(U)), fo1 = fl[1] * uint32_t(sizeof(U));
                     // dense groups (no selection / everything selected): no per-group branch, so the compiler can

@@ -94,10 +94,17 @@ static_assert(sizeof(StrWgRecord) == 464, "StrWgRecord layout");
 // fingerprint (byte_view_array/fingerprint.rs:33-35), only far more selective.  The signatures are stored BIT-SLICED:
 // slice b is a bitmap over the dictionary entries (ceil(D/64) u64 words) telling which values have bit b, so a query
 // ANDs only the slices of the needle's bigrams (<= 8 x D/8 bytes) instead of reading 16 bytes per entry.
-constexpr int kSigBits = 128;
+// Measured with 256 / 512 bits (-DLC_SIG_BITS): 9 -> ~4 / ~1.5 candidates per entry and 5-7 % fewer bytes to move, but the
+// headline scan got SLOWER (33 -> 43 us): the index grows from 36 to 72 / 144 KB per entry, the column from 1.5 to 2.0 /
+// 3.3 GB, and the five slices a query reads sit up to 140 KB apart — the kernel's dependent loads pay for the larger
+// footprint (TLB reach, Infinity Cache residency) more than the walk saves.
+#ifndef LC_SIG_BITS
+#define LC_SIG_BITS 128
+#endif
+constexpr int kSigBits = LC_SIG_BITS;
 constexpr int kMaxSigProbe = 8;
 __host__ __device__ inline uint32_t bigram_bit(uint32_t a, uint32_t b) {
-    return ((((a << 8) | b) * 40503u) >> 7) & 127u;
+    return ((((a << 8) | b) * 40503u) >> 7) & uint32_t(kSigBits - 1);
 }
 
 // Symbol table as the kernels see it.
@@ -140,6 +147,8 @@ struct FixedPred {
     int32_t inner_op;     // op == LC_OP_INTERNAL_SENTINEL over quantized entries: the comparison whose undecidable
                           // rows (bucket of the literal) are looked for
     uint64_t lit_f64;
+    uint32_t debug_flags; // profiling builds (-DLC_ABLATION) only: LC_DEBUG_FLAGS
+    uint32_t pad;
 };
 
 constexpr int kInlineNeedle = 64;
@@ -157,7 +166,7 @@ struct StrPred {
     int32_t debug_flags;       // -DLC_ABLATION builds only (env LC_DEBUG_FLAGS): 1 skip phase B, 2 skip phase C, 8 no signatures
     uint32_t needle_fp;        // LIKE: 32-bucket fingerprint of the needle (fingerprint.rs:33-35)
     uint32_t n_sig_bits;       // LIKE: distinct bigram-signature bits of the needle that are probed (<= kMaxSigProbe)
-    uint8_t sig_bits[kMaxSigProbe];
+    uint16_t sig_bits[kMaxSigProbe];
     uint8_t needle_inline[kInlineNeedle];
 };
 

@@ -535,7 +535,7 @@ lc_status make_fixed_pred(const Entry& e, const lc_predicate* p, FixedPred* out)
     *out = FixedPred{};
     out->op = p->op;
 #ifdef LC_ABLATION
-    if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->pad = uint32_t(std::atoi(dbg));  // profiling builds only
+    if (const char* dbg = std::getenv("LC_DEBUG_FLAGS")) out->debug_flags = uint32_t(std::atoi(dbg));  // profiling builds only
 #endif
     if (!p->lit) return fail(LC_ERR_INVALID, "literal is null");
     if (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) {
@@ -620,7 +620,7 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
         out->needle.assign(inner, inner + il);
         for (size_t k = 0; k < il; k++) out->p.needle_fp |= 1u << (inner[k] & 31);
         for (size_t k = 0; k + 1 < il && out->p.n_sig_bits < uint32_t(kMaxSigProbe); k++) {
-            const uint8_t bit = uint8_t(bigram_bit(inner[k], inner[k + 1]));
+            const uint16_t bit = uint16_t(bigram_bit(inner[k], inner[k + 1]));
             bool dup = false;
             for (uint32_t q = 0; q < out->p.n_sig_bits; q++) dup |= out->p.sig_bits[q] == bit;
             if (!dup) out->p.sig_bits[out->p.n_sig_bits++] = bit;
