@@ -1491,6 +1491,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     // zeroes the group's counters for the next launch.
     uint32_t* work = L.d_work + wg_group * 16u;
     uint64_t wave_hits = 0;  // fused COUNT(*): hits of the entries this wave evaluated (lane 0)
+    // kSigOnly: the row phase is shared by the workgroup (see "cooperative row phase" below); what a wave found for its
+    // own entry: 0 = nothing left to write (no entry, or the early-out wrote it), 1 = no dictionary value matched,
+    // 2 = the dictionary result table of this wave holds matches
+    constexpr bool kCoop = kSigOnly;
+    uint32_t coop_state = 0;
     for (uint32_t draw = 0;; draw++) {
         uint32_t entry = 0;
         if (static_draw) {
@@ -1876,6 +1881,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     }
 
     LC_TM(7, 0);
+    if (kCoop) {
+        coop_state = any_true != 0 ? 2u : 1u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        continue;  // static draw: this was the wave's only entry
+    }
     LC_FORGET_DESC;
     // dictionary-level negation:
     //   NotContains inverts the dictionary results only when at least one fingerprint candidate existed
@@ -2009,6 +2019,105 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     if (kSub && !tbl_synced) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
+    if (kCoop) {
+        // ---- cooperative row phase ----
+        // 30 % of the entries of a selective LIKE have a matching dictionary value and must map 8192 keys to rows, the
+        // others only write zeros: with one wave per entry the workgroup waits for its slowest wave (three of four
+        // workgroups hold at least one such entry).  Instead every wave publishes its result table (it lives in LDS
+        // anyway) and ALL four waves map a quarter of the rows (2048 keys = one 16-byte load x 4 per lane) of each
+        // entry that has matches; entries without matches are zero-filled by their own wave.
+        uint32_t* my_flags = reinterpret_cast<uint32_t*>(hitflag + 72);  // {state, hits} in the spare bytes of the flag area
+        if (lane == 0) { my_flags[0] = coop_state; my_flags[1] = 0; }
+        __syncthreads();
+        const uint32_t n_in_range = group_end - group_begin;
+        uint32_t hit_count = 0;
+        for (uint32_t e = 0; e < n_in_range; e++) {
+            uint8_t* wbase_e = smem + tbl_bytes + kNeedleLds + e * per_wave;
+            uint32_t* flags_e = reinterpret_cast<uint32_t*>(wbase_e + dres_bytes + cmask_bytes + kCandCap * 2u + 72);
+            const uint32_t st_e = uint32_t(__builtin_amdgcn_readfirstlane(int(flags_e[0])));
+            if (st_e == 0) continue;
+            ConstDescPtr de = reinterpret_cast<ConstDescPtr>(reinterpret_cast<uintptr_t>(&rec->d[e]));
+            const uint32_t n_rows = de->n;
+            const uint32_t nwords_e = (n_rows + 63u) >> 6;
+            const uint64_t word_off = de->mask_word_off;
+            const bool need_vw = st_e == 2 || L.d_valid != nullptr;
+            if (st_e == 1) {
+                if (e != wave) continue;  // the entry's own wave writes its zeros
+                for (uint32_t w = uint32_t(lane); w < nwords_e; w += kWave) {
+                    L.d_hit[word_off + w] = 0;
+                    if (L.d_valid) {
+                        uint64_t sv = ~uint64_t(0), vv = ~uint64_t(0);
+                        if (L.d_selection) sv = *as_global(L.d_selection + word_off + w);
+                        if (de->validity) vv = *as_global(de->validity + w);
+                        const uint32_t rows_left = n_rows - (w << 6);
+                        const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
+                        L.d_valid[word_off + w] = sv & vv & tail;
+                    }
+                }
+                continue;
+            }
+            // matches: this wave's quarter of every 8192 rows (entries hold up to 65,536 rows)
+            const uint32_t dres_addr_e = uint32_t(reinterpret_cast<uintptr_t>(wbase_e));
+            const uint32_t* dres_e = reinterpret_cast<const uint32_t*>(wbase_e);
+            const uint32_t key_max = dres_bytes * 8u - 1u;
+            uint8_t* stage = reinterpret_cast<uint8_t*>(cand);  // this wave's own candidate list is dead by now
+            uint32_t hits_e = 0;
+            for (uint32_t pass = wave * 2048u; pass < n_rows; pass += kWavesPerBlock * 2048u) {
+            constexpr int KQ = 4;
+            u32x4 kv[KQ];
+#pragma unroll
+            for (int k = 0; k < KQ; k++) {
+                const uint32_t r0 = pass + uint32_t(k) * kWave * 8 + uint32_t(lane) * 8;
+                kv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(de->keys) + min(r0, (n_rows - 1u) & ~7u));
+            }
+            const uint32_t widx = (pass >> 6) + uint32_t(lane);  // lanes 0..31 own the quarter's 32 mask words
+            uint64_t vwv = 0;
+            if (need_vw && lane < 32 && widx < nwords_e) {
+                uint64_t sv = ~uint64_t(0), vv = ~uint64_t(0);
+                if (L.d_selection) sv = *as_global(L.d_selection + word_off + widx);
+                if (de->validity) vv = *as_global(de->validity + widx);
+                const uint32_t rows_left = n_rows - (widx << 6);
+                const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
+                vwv = sv & vv & tail;
+            }
+#pragma unroll
+            for (int k = 0; k < KQ; k++) {
+                uint32_t bits = 0;
+                const uint32_t kw[4] = {kv[k].x, kv[k].y, kv[k].z, kv[k].w};
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const uint32_t key = (q & 1) ? kw[q >> 1] >> 16 : kw[q >> 1] & 0xFFFFu;
+                    uint32_t hit;
+                    if (kBytes) {
+                        hit = lds_u8(dres_addr_e + key);  // garbage keys under nulls read other LDS bytes: masked below
+                    } else {
+                        const uint32_t kc = min(key, key_max);
+                        hit = (dres_e[kc >> 5] >> (kc & 31)) & 1u;
+                    }
+                    bits |= hit << q;
+                }
+                stage[uint32_t(k) * kWave + uint32_t(lane)] = uint8_t(bits);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t c = 0;
+            if (lane < 32 && widx < nwords_e) {
+                const uint64_t hitw = reinterpret_cast<const uint64_t*>(stage)[lane] & vwv;
+                L.d_hit[word_off + widx] = hitw;
+                if (L.d_valid) L.d_valid[word_off + widx] = vwv;
+                c = uint32_t(__popcll(hitw));
+            }
+            hits_e += uint32_t(wave_sum_u64(uint64_t(c)));
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the staging bytes are rewritten by the next pass
+            }
+            hit_count += hits_e;
+            if (lane == 0 && hits_e) atomicAdd(&flags_e[1], hits_e);
+        }
+        wave_hits += hit_count;  // already a wave total (lane 0 contributes it below)
+        if (L.d_counts) {
+            __syncthreads();
+            if (lane == 0 && group_begin + wave < group_end) L.d_counts[group_begin + wave] = my_flags[1];
+        }
     }
     // ^ the barrier the other waves of the workgroup pass before their walk
     if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, gridDim.x * kWavesPerBlock, wave_hits);
@@ -3032,6 +3141,11 @@ hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, c
     return hipGetLastError();
 }
 
+static bool persistent_env() {
+    static const bool v = std::getenv("LC_STR_PERSISTENT") != nullptr;
+    return v;
+}
+
 hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, const StrPred& pred,
                            const ScanLaunch& L, hipStream_t stream) {
     if (L.n_entries == 0) return hipSuccess;
@@ -3063,7 +3177,8 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
           {k_str_pred<true, true, true, false>, k_str_pred<true, true, true, true>}}}};
     Kern kern = table[bytes ? 1 : 0][sub ? 1 : 0][many ? 1 : 0][instr ? 1 : 0];
     // the headline case: LIKE, every entry carries signatures, needle automaton in LDS
-    if (sub && !many && !instr && lds_tbl && pred.use_fingerprints && pred.n_sig_bits > 0 && pred.op == LC_OP_LIKE)
+    const bool records = !persistent_env() && L.d_wg_ranges && L.n_wg_ranges <= kWorkGroupsMax;  // one wave per entry
+    if (records && sub && !many && !instr && lds_tbl && pred.use_fingerprints && pred.n_sig_bits > 0 && pred.op == LC_OP_LIKE)
         kern = bytes ? static_cast<Kern>(k_str_pred<true, true, false, false, true>)
                      : static_cast<Kern>(k_str_pred<false, true, false, false, true>);
     if (dyn_lds > 64 * 1024) {
@@ -3075,7 +3190,7 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     // Measured (100M-row URL scan): one workgroup per four entries under the hardware dispatcher takes 48 us, a
     // persistent grid 68 us: with every slot always occupied the waves run in phase and the kernel, which is bound by
     // dependent LDS / cross-lane chains rather than by issue or bandwidth, loses the overlap between phases.
-    static const bool persistent = std::getenv("LC_STR_PERSISTENT") != nullptr;  // tuning aid
+    const bool persistent = persistent_env();  // tuning aid
     uint32_t grid = wgs_needed;
     if (persistent) {
         int wgs_per_cu = 0;
