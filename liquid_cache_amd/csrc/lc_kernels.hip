@@ -754,7 +754,10 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     // A pass covers kPairs pairs of blocks: very narrow widths (<= 6 bits, few registers per block) take four blocks at a
     // time — all 64 lanes own a mask word, the loads of both pairs are in flight before the first compare, and the
     // per-pass bookkeeping is paid half as often; wider ones keep to one pair (register budget).
-    constexpr uint32_t kPairs = W <= 6 ? 2u : 1u;
+#ifndef LC_X_PAIRW
+#define LC_X_PAIRW 6
+#endif
+    constexpr uint32_t kPairs = W <= LC_X_PAIRW ? 2u : 1u;
     uint32_t count = 0;
     for (uint32_t blk0 = 0; blk0 < nblocks; blk0 += 2u * kPairs) {
         // selection & validity: lane i (< 32 kPairs) owns mask word 16*blk0 + i of the entry
