@@ -1043,3 +1043,40 @@ def test_scan_aggregate_decimal_after_predicate_chain_and_rejections(gpu_cache, 
     with pytest.raises(lc.LiquidCacheError) as ex:
         gpu_cache.scan(ids_p).aggregate_to_host()
     assert ex.value.status == N.LC_NEEDS_BACKING
+
+
+def test_string_gather_escape_runs_wave_and_lane_paths(gpu_cache, oracle):
+    """The wave-per-value decoder decides "escaped literal or code" from the parity of the run of 255s in front of a
+    byte.  Binary values full of bytes the symbol table does not know (every such byte is an escape pair, a literal 0xFF
+    becomes 255 255) and of 0xFF runs of every length around the 64-byte chunk boundary, compressed with a table trained
+    on other data; sparse selections take the wave path, dense ones the lane-per-row path, both must return the bytes."""
+    lo = oracle
+    rng = np.random.default_rng(0xFF)
+    train = ["http://example.com/%d/index.html?q=%d" % (i % 37, i) for i in range(2000)]
+    offs, data, _ = lo.strings_to_arrow(train)
+    st = lo.fsst_train(offs, data)
+    vals = []
+    for run in list(range(0, 12)) + [31, 32, 33, 63, 64, 65, 127, 128, 129]:
+        for lead in (0, 1, 2, 29, 30, 31, 61, 62, 63):
+            vals.append(b"a" * lead + b"\xff" * run + b"z")
+            vals.append(bytes(rng.integers(128, 256, size=lead, dtype=np.uint8)) + b"\xff" * run)
+    vals += [b"", b"\xff", b"\xff\xff", bytes([255, 254, 255, 255, 1, 255]), b"http://example.com/1/index.html?q=" + b"\xff" * 70]
+    n = 8192
+    keys = rng.integers(0, len(vals), size=n)
+    rows = [vals[k] for k in keys]
+    for i in rng.choice(n, size=100, replace=False):
+        rows[int(i)] = None
+    liquid, _ = lo.encode_byte_view(rows, st=st, arrow_type=lo.BT_BINARY)
+    path, eid = 4242, lc.ParquetArrayID.new(60, 0, 2, 0)
+    gpu_cache.set_symbol_table(path, lo.symtab_bytes(st))
+    gpu_cache.stage([eid], [liquid], [path])
+    scan = gpu_cache.scan([eid])
+    for p_sel in (0.0005, 0.004, 0.3, 1.0):
+        keep = rng.random(n) < p_sel
+        keep[:3] = True
+        words = np.zeros(int(scan.mask_words), np.uint64)
+        packed = np.packbits(keep, bitorder="little")
+        words.view(np.uint8)[: len(packed)] = packed
+        got = scan.gather_bytes_to_host(selection=words)
+        assert got == [r for r, kp in zip(rows, keep) if kp], p_sel
+    scan.close()
