@@ -1285,7 +1285,7 @@ __device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], u
 // fingerprints at all: every dictionary value is walked).  Every lane owns two independent chains; chain c of lane l walks
 // candidates l + 64 c, l + 64 c + 128, ... ONE AFTER THE OTHER without waiting for its neighbours, so the wave stays
 // busy until the list runs out (values differ 10x in length: walking 64 of them in lock step idles most lanes most of
-// the time).  A chain fetches 32 compressed bytes at a time (one memory round trip per 32 table lookups) and the offsets
+// the time).  A chain fetches 64 or 128 compressed bytes at a time (one memory round trip per value, mostly) and the offsets
 // of its next value while it walks the current one.  Per compressed byte: extract, address, one ds_read_u16, and the
 // guard that keeps bytes past the end of a value from moving the state.
 // Only instantiated in the kMany variants of k_str_pred (scans whose entries carry no signature index): its ~60 registers
@@ -1315,8 +1315,11 @@ __device__ __forceinline__ void walk_offsets(const WalkManyArgs& a, uint32_t i, 
     stop = a.slope * (i + 1u) + a.intercept + uint32_t(r1);
 }
 
+// NC chains per lane, CH 8-byte words per fetch.  Measured (100 M-row URL column): 2 x 32 B 543 / 839 us (fingerprint
+// candidates / every value), 2 x 64 B 510 / 773, 1 x 128 B 470 / 814: sparse candidates gain from fetching a whole value
+// in one round trip (their lines are evicted between the pieces otherwise), dense ones from two chains in flight.
+template <int NC, int CH>
 __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) {
-    constexpr int NC = 2, CH = 4;  // chains per lane, 8-byte words per fetch
     constexpr uint32_t kStride = uint32_t(kWave) * NC;
     const int lane = lane_id();
     typedef const __attribute__((address_space(3))) uint16_t* LdsList;
@@ -1766,7 +1769,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 wa.hitrow = hitrow;
                 wa.dres_lds = dres_addr;
                 wa.bytes_mode = kBytes ? 1u : 0u;
-                const WalkManyResult wr = like_walk_many(wa);
+                const WalkManyResult wr = prune ? like_walk_many<1, 16>(wa) : like_walk_many<2, 8>(wa);
                 any_true |= __ballot(wr.found != 0);
                 if (kInstr && L.d_cand_bytes && !prune) cand_bytes += wr.bytes;
                 if (kInstr && L.d_own_bytes) own_bytes += wr.bytes + 2u * dp->offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
