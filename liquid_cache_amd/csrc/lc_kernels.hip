@@ -1023,6 +1023,9 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
 //   phase C  rows: 8 u16 keys per 16-byte load, bitmap lookup in LDS, 8 lanes x 8 bits shuffled into mask words
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kCandCap = 1024;  // candidate list capacity per wave (u16 entries)
+// the signature-only variant sees a handful of candidates per entry: a quarter of the list leaves room for two more
+// workgroups per CU (LDS is what limits its occupancy)
+constexpr uint32_t kCandCapSigOnly = 256;
 
 template <typename T>
 __device__ __forceinline__ T load_unaligned(const uint8_t* p) {
@@ -1440,14 +1443,15 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const uint32_t tbl_bytes = lds_tbl ? automaton_image_bytes(nl) : 0u;
     constexpr uint32_t kNeedleLds = 256;
     constexpr uint32_t kFlagBytes = 80;
-    const uint32_t per_wave = dres_bytes + cmask_bytes + kCandCap * 2u + kFlagBytes;
+    constexpr uint32_t kCap = kSigOnly ? kCandCapSigOnly : kCandCap;
+    const uint32_t per_wave = dres_bytes + cmask_bytes + kCap * 2u + kFlagBytes;
     uint8_t* needle_lds = smem + tbl_bytes;
     uint8_t* wbase = smem + tbl_bytes + kNeedleLds + wave * per_wave;
     uint32_t* dres = reinterpret_cast<uint32_t*>(wbase);  // bitmap words or bytes
     uint8_t* dresb = wbase;
     uint64_t* cmask = reinterpret_cast<uint64_t*>(wbase + dres_bytes);
     uint16_t* cand = reinterpret_cast<uint16_t*>(wbase + dres_bytes + cmask_bytes);
-    uint8_t* hitflag = wbase + dres_bytes + cmask_bytes + kCandCap * 2u;
+    uint8_t* hitflag = wbase + dres_bytes + cmask_bytes + kCap * 2u;
     uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
     const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
     const uint32_t hitrow = row0 + nl * 512u;  // LDS address of the absorbing (matched) state's row
@@ -1639,7 +1643,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             const uint32_t cnt = uint32_t(__popcll(m));
             const uint32_t incl = wave_inclusive_sum(cnt);
             const uint32_t total = read_lane(incl, kWave - 1);
-            if (n_cand + total <= kCandCap) {
+            if (n_cand + total <= kCap) {
                 uint32_t o = n_cand + incl - cnt;
                 while (m) {
                     const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
@@ -1650,10 +1654,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 pos += round_words * 64u;
                 took = true;
             } else if (n_cand == 0) {
-                round_words = 16;  // 16 words hold at most 1024 candidates: always fits an empty list
+                round_words = kCap / 64u;  // that many words hold at most kCap candidates: always fits an empty list
                 took = true;
             }
-        } else if (!kSigOnly && pos < d_eval && n_cand + KH * kWave <= kCandCap) {
+        } else if (!kSigOnly && pos < d_eval && n_cand + KH * kWave <= kCap) {
             // phase A (per entry): fingerprints for LIKE, prefix keys for Eq / ordering
             const uint32_t base = pos;
             uint32_t fpv[KH];
@@ -1917,7 +1921,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint32_t hit_count = 0;
     constexpr int KC = 8;
     uint8_t* stage = reinterpret_cast<uint8_t*>(cand);
-    static_assert(kCandCap * 2 >= KC * kWave, "phase C staging must fit in the candidate list");
+    static_assert(kCap * 2 >= KC * kWave, "phase C staging must fit in the candidate list");
     for (uint32_t pass = 0; pass < n_rows; pass += KC * kWave * 8) {
         u32x4 kv[KC];
         if (!all_false) {
@@ -2040,7 +2044,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         uint32_t hit_count = 0;
         for (uint32_t e = 0; e < n_in_range; e++) {
             uint8_t* wbase_e = smem + tbl_bytes + kNeedleLds + e * per_wave;
-            uint32_t* flags_e = reinterpret_cast<uint32_t*>(wbase_e + dres_bytes + cmask_bytes + kCandCap * 2u + 72);
+            uint32_t* flags_e = reinterpret_cast<uint32_t*>(wbase_e + dres_bytes + cmask_bytes + kCap * 2u + 72);
             const uint32_t st_e = uint32_t(__builtin_amdgcn_readfirstlane(int(flags_e[0])));
             if (st_e == 0) continue;
             ConstDescPtr de = reinterpret_cast<ConstDescPtr>(reinterpret_cast<uintptr_t>(&rec->d[e]));
@@ -3241,13 +3245,18 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     const bool lds_tbl = sub && pred.needle_len <= kMaxLdsNeedle;
     const size_t tbl_bytes = lds_tbl ? automaton_image_bytes(pred.needle_len) : 0;
     static const char* env_pad = std::getenv("LC_STR_LDS_PAD");  // tuning aid: extra LDS per workgroup lowers occupancy
-    const size_t dyn_lds = tbl_bytes + 256 + size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + kCandCap * 2 + 80) +
-                           (env_pad ? size_t(std::atoi(env_pad)) : 0);
-    // persistent launch: as many workgroups as fit on the device at once; the waves draw entries dynamically
-    const uint32_t wgs_needed = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
     // kMany: LIKE over entries without the signature index (hundreds to thousands of candidates per entry)
     const bool many = sub && L.many_candidates;
     const bool instr = L.d_cand_bytes != nullptr || L.d_own_bytes != nullptr;
+    // the headline case: LIKE, every entry carries signatures, needle automaton in LDS, one wave per entry (records)
+    const bool records = !persistent_env() && L.d_wg_ranges && L.n_wg_ranges <= kWorkGroupsMax;
+    const bool sig_only = records && sub && !many && !instr && lds_tbl && pred.use_fingerprints && pred.n_sig_bits > 0 &&
+                          pred.op == LC_OP_LIKE;
+    const size_t cand_cap = sig_only ? kCandCapSigOnly : kCandCap;
+    const size_t dyn_lds = tbl_bytes + 256 + size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + cand_cap * 2 + 80) +
+                           (env_pad ? size_t(std::atoi(env_pad)) : 0);
+    // persistent launch: as many workgroups as fit on the device at once; the waves draw entries dynamically
+    const uint32_t wgs_needed = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
     typedef void (*Kern)(const StrDesc*, const DevSymtab*, StrPred, ScanLaunch, uint32_t, uint32_t);
     static const Kern table[2][2][2][2] = {  // [bytes][sub][many][instr]
         {{{k_str_pred<false, false, false, false>, k_str_pred<false, false, false, true>},
@@ -3260,8 +3269,7 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
           {k_str_pred<true, true, true, false>, k_str_pred<true, true, true, true>}}}};
     Kern kern = table[bytes ? 1 : 0][sub ? 1 : 0][many ? 1 : 0][instr ? 1 : 0];
     // the headline case: LIKE, every entry carries signatures, needle automaton in LDS
-    const bool records = !persistent_env() && L.d_wg_ranges && L.n_wg_ranges <= kWorkGroupsMax;  // one wave per entry
-    if (records && sub && !many && !instr && lds_tbl && pred.use_fingerprints && pred.n_sig_bits > 0 && pred.op == LC_OP_LIKE)
+    if (sig_only)
         kern = bytes ? static_cast<Kern>(k_str_pred<true, true, false, false, true>)
                      : static_cast<Kern>(k_str_pred<false, true, false, false, true>);
     if (dyn_lds > 64 * 1024) {

@@ -6,6 +6,7 @@ import ctypes as C
 import datetime
 import decimal
 import os
+import sys
 
 import numpy as np
 import pyarrow as pa
@@ -1079,4 +1080,50 @@ def test_string_gather_escape_runs_wave_and_lane_paths(gpu_cache, oracle):
         words.view(np.uint8)[: len(packed)] = packed
         got = scan.gather_bytes_to_host(selection=words)
         assert got == [r for r, kp in zip(rows, keep) if kp], p_sel
+    scan.close()
+
+
+def test_like_signature_only_variant_with_many_candidates(gpu_cache, oracle):
+    """The signature-only instantiation keeps a 256-entry candidate list: two-byte needles (one bigram) make most of a
+    2,000-value dictionary a candidate, so the list is filled and walked in several rounds; results as the oracle's, with
+    and without a selection, over entries of different lengths in one scan (cooperative row phase: quarters of 8192 rows,
+    a 20,000-row entry, a 77-row entry)."""
+    lo = oracle
+    rng = np.random.default_rng(256)
+    hint = lc.CacheExpression.SUBSTRING_SEARCH
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _make_strings
+    lens = [8192, 20000, 77, 8192, 4096]
+    ids, blobs = [], []
+    st = None
+    for b, n in enumerate(lens):
+        strs = _make_strings(rng, n, 2000, True)
+        liquid, st = lo.encode_byte_view(strs, st=st, fingerprints=True)
+        eid = lc.ParquetArrayID.new(61, 0, 3, b)
+        if b == 0:
+            gpu_cache.set_symbol_table(6161, lo.symtab_bytes(st))
+        gpu_cache.stage([eid], [liquid], [6161])
+        ids.append(eid)
+        blobs.append(liquid)
+    scan = gpu_cache.scan(ids)
+    offs = scan.segment_offsets
+    for pat in (b"%go%", b"%google%", b"%le.g%", b"%://%", b"%zz%", b"%x1%"):
+        expr = lc.LiquidExpr.try_new("like", pat, pa.string(), hint)
+        for with_sel in (False, True):
+            sels = [rng.random(n) < 0.5 if with_sel else None for n in lens]
+            words = None
+            if with_sel:
+                words = np.zeros(int(scan.mask_words), np.uint64)
+                for b, se in enumerate(sels):
+                    packed = np.packbits(se, bitorder="little")
+                    words[int(offs[b]): int(offs[b + 1])].view(np.uint8)[: len(packed)] = packed
+            mask, counts = scan.eval_to_host(expr, selection=words)
+            for b, n in enumerate(lens):
+                want = lo.eval_predicate(blobs[b], lo.LIKE, pat, None, symtab=st)
+                hit = want.values & (want.validity if want.validity is not None else True)
+                if with_sel:
+                    hit = hit & sels[b]
+                got = np.unpackbits(mask[int(offs[b]): int(offs[b + 1])].view(np.uint8), bitorder="little")[:n].astype(bool)
+                assert got.tolist() == hit.tolist(), (pat, b, with_sel)
+                assert int(counts[b]) == int(hit.sum())
     scan.close()
