@@ -2902,6 +2902,7 @@ __device__ __forceinline__ uint64_t load_native(const uint8_t* p, uint32_t i, bo
     return uint64_t(int64_t(S(v)));
 }
 __device__ __forceinline__ uint64_t load_native_any(const EncodeDesc& d, uint32_t i) {
+    if (d.stride_log2) return *reinterpret_cast<const uint64_t*>(d.values + (size_t(i) << d.stride_log2));
     switch (d.value_log2) {
         case 0: return load_native<uint8_t>(d.values, i, d.is_signed);
         case 1: return load_native<uint16_t>(d.values, i, d.is_signed);
@@ -2918,10 +2919,16 @@ __global__ __launch_bounds__(256) void k_col_minmax(const EncodeDesc* __restrict
     // comparison serves both
     const uint64_t bias = d.is_signed ? (uint64_t(1) << 63) : 0;
     uint64_t mn = ~uint64_t(0), mx = 0;
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, wide = 0;
     for (uint32_t i = threadIdx.x; i < d.n; i += 256) {
         const bool valid = d.validity ? ((d.validity[i >> 6] >> (i & 63u)) & 1) != 0 : true;
         if (!valid) continue;
+        if (d.stride_log2) {  // decimal: the bytes above the low u64 must be zero
+            const uint64_t* p = reinterpret_cast<const uint64_t*>(d.values + (size_t(i) << d.stride_log2));
+            uint64_t hi = p[1];
+            if (d.stride_log2 == 5) hi |= p[2] | p[3];
+            wide += hi != 0;
+        }
         const uint64_t v = load_native_any(d, i) ^ bias;
         mn = v < mn ? v : mn;
         mx = v > mx ? v : mx;
@@ -2934,18 +2941,22 @@ __global__ __launch_bounds__(256) void k_col_minmax(const EncodeDesc* __restrict
         mn = a < mn ? a : mn;
         mx = b > mx ? b : mx;
         cnt += c;
+        wide += __shfl_down(wide, o, kWave);
     }
-    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_cnt[wave_id()] = cnt; }
+    __shared__ uint32_t s_wide[4];
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; s_cnt[wave_id()] = cnt; s_wide[wave_id()] = wide; }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; w++) {
             mn = s_mn[w] < mn ? s_mn[w] : mn;
             mx = s_mx[w] > mx ? s_mx[w] : mx;
             cnt += s_cnt[w];
+            wide += s_wide[w];
         }
         out[blockIdx.x].mn = mn ^ bias;
         out[blockIdx.x].mx = mx ^ bias;
         out[blockIdx.x].n_valid = cnt;
+        out[blockIdx.x].n_wide = wide;
     }
 }
 
@@ -2967,6 +2978,11 @@ __global__ __launch_bounds__(256) void k_fl_pack(const EncodeDesc* __restrict__ 
         // every slot is packed, null slots included (they hold whatever the Arrow buffer holds, like the host path);
         // slots past the end are zero (bit_pack_array.rs:97-113)
         U v = idx < d.n ? U(U(load_native_any(d, idx)) - U(d.reference)) : U(0);
+        if (d.stride_log2) {  // decimal_array.rs:150-166: null slots are 0, then saturating_sub(reference)
+            const bool valid = idx < d.n && (d.validity ? ((d.validity[idx >> 6] >> (idx & 63u)) & 1) != 0 : true);
+            const uint64_t raw = valid ? load_native_any(d, idx) : 0;
+            v = U(raw >= d.reference ? raw - d.reference : 0);
+        }
         if (d.quant_width > 1) v = U(uint64_t(v) / d.quant_width);  // bucket index (primitive_array.rs:472-481)
         if (d.clamp_max && v > U(d.clamp_max)) v = U(d.clamp_max);  // values >= sentinel become the sentinel (:433-437)
         v &= mask;

@@ -126,12 +126,13 @@ struct EncodeDesc {
     uint8_t W;                 // pack phase: bit width (0: nothing to pack)
     uint8_t value_log2;        // 0..3: bytes per value = 1 << value_log2
     uint8_t is_signed;
-    uint8_t pad;
+    uint8_t stride_log2;       // 0: values are dense; 4 / 5: Decimal128 / Decimal256 values, the low u64 of every 16 / 32
+                               // bytes is the value (fits_u64, decimal_array.rs:120-125), null slots pack 0
 };
 struct EncodeMinMax {
     uint64_t mn, mx;  // as int64 bits for signed types
     uint32_t n_valid;
-    uint32_t pad;
+    uint32_t n_wide;  // decimals: valid values that do not fit a u64 (negative or wider): the array stays on the CPU path
 };
 
 // Internal operator: "packed value == all ones" — the sentinel rows of a clamp-squeezed entry

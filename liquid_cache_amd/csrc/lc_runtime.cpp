@@ -945,7 +945,8 @@ struct DevEncodeItem {
     bool entry_signed = false;
     bool quantize = false;                  // with `forced`: bucket indices instead of clamped offsets
     uint64_t quant_width = 0;               // result: the bucket width
-    int logical = kInteger;                 // kDecimal: a quantized decimal entry (u64 offsets of the unscaled values)
+    int in_stride = 0;                      // decimals from Arrow: bytes per value in the staging buffer (16 / 32)
+    int logical = kInteger;                 // kDecimal: a decimal entry (u64 offsets of the unscaled values)
     int dec_precision = 0, dec_scale = 0, dec_is256 = 0, entry_value_width = 0;
     // results
     bool all_null = false;
@@ -969,6 +970,7 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         d.n = it.n;
         d.value_log2 = uint8_t(it.vw == 1 ? 0 : it.vw == 2 ? 1 : it.vw == 4 ? 2 : 3);
         d.is_signed = it.is_signed ? 1 : 0;
+        d.stride_log2 = uint8_t(it.in_stride == 16 ? 4 : it.in_stride == 32 ? 5 : 0);
         max_rows = std::max(max_rows, it.n);
     }
     EncodeDesc* d_descs = static_cast<EncodeDesc*>(pool_alloc(ctx, n * sizeof(EncodeDesc)));
@@ -982,6 +984,9 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
     LC_HIP(launch_col_minmax(d_descs, uint32_t(n), d_mm, nullptr));
     std::vector<EncodeMinMax> mm(n);
     LC_HIP(hipMemcpy(mm.data(), d_mm, n * sizeof(EncodeMinMax), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++)
+        if (items[i].in_stride && mm[i].n_wide)
+            return fail(LC_UNSUPPORTED, "decimal values that do not fit a u64 stay on the reference's CPU path (fits_u64)");
     // layout of the batch's blob: per entry [packed + 128 slack][validity words]
     size_t total = 0;
     for (size_t i = 0; i < n; i++) {
@@ -1126,18 +1131,31 @@ lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_
         const struct ArrowArray* a = arrays[i];
         const struct ArrowSchema* s = schemas[i];
         if (!a || !s) return fail(LC_ERR_INVALID, "null array");
-        const int phys = int_phys_of_format(s->format);
-        if (phys < 0 || s->dictionary || a->length > int64_t(UINT32_MAX))
-            return fail(LC_UNSUPPORTED, "the on-device transcoder takes integer / date / timestamp arrays (use lc_insert_arrow)");
+        int phys = int_phys_of_format(s->format);
+        int dec_p = 0, dec_s = 0, dec_bits = 128;
+        const bool is_decimal = s->format && s->format[0] == 'd' && s->format[1] == ':' &&
+                                std::sscanf(s->format, "d:%d,%d,%d", &dec_p, &dec_s, &dec_bits) >= 2 &&
+                                (dec_bits == 128 || dec_bits == 256);
+        if ((phys < 0 && !is_decimal) || s->dictionary || a->length > int64_t(UINT32_MAX))
+            return fail(LC_UNSUPPORTED, "the on-device transcoder takes integer / date / timestamp / decimal arrays (use lc_insert_arrow)");
         DevEncodeItem& it = items[i];
         it.id = entry_ids[i];
+        if (is_decimal) {  // LiquidDecimalArray: u64 offsets of the unscaled values (decimal_array.rs:127-177)
+            phys = kU64;
+            it.logical = kDecimal;
+            it.dec_precision = dec_p;
+            it.dec_scale = dec_s;
+            it.dec_is256 = dec_bits == 256;
+            it.entry_value_width = dec_bits / 8;
+            it.in_stride = dec_bits / 8;
+        }
         it.phys = phys;
         it.vw = phys_width(phys);
         it.is_signed = !phys_unsigned(phys);
         it.n = uint32_t(a->length);
         it.has_validity = a->n_buffers >= 1 && a->buffers[0] != nullptr;
         it.in_values = align_up(stage_bytes, 16);
-        stage_bytes = it.in_values + size_t(it.n) * size_t(it.vw) + 16;
+        stage_bytes = it.in_values + size_t(it.n) * size_t(it.in_stride ? it.in_stride : it.vw) + 32;
         if (it.has_validity) {
             it.in_validity = align_up(stage_bytes, 16);
             stage_bytes = it.in_validity + ((size_t(it.n) + 63) / 64) * 8;
@@ -1156,8 +1174,9 @@ lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_
         const DevEncodeItem& it = items[i];
         const struct ArrowArray* a = arrays[i];
         const uint8_t* v = static_cast<const uint8_t*>(a->buffers[1]);
-        if (v) std::memcpy(h + it.in_values, v + size_t(a->offset) * size_t(it.vw), size_t(it.n) * size_t(it.vw));
-        else std::memset(h + it.in_values, 0, size_t(it.n) * size_t(it.vw));
+        const size_t vstride = size_t(it.in_stride ? it.in_stride : it.vw);
+        if (v) std::memcpy(h + it.in_values, v + size_t(a->offset) * vstride, size_t(it.n) * vstride);
+        else std::memset(h + it.in_values, 0, size_t(it.n) * vstride);
         if (it.has_validity) {
             const size_t words = (size_t(it.n) + 63) / 64;
             std::memset(h + it.in_validity, 0, words * 8);

@@ -1127,3 +1127,50 @@ def test_like_signature_only_variant_with_many_candidates(gpu_cache, oracle):
                 assert got.tolist() == hit.tolist(), (pat, b, with_sel)
                 assert int(counts[b]) == int(hit.sum())
     scan.close()
+
+
+def test_device_transcoder_decimals_byte_identical(gpu_cache):
+    """Decimal128 / Decimal256 arrays through lc_insert_arrow_device: the low u64 of every value, frame of reference, null
+    slots packed as 0 — byte-identical to the host transcoder (LiquidDecimalArray::from_decimal_array,
+    decimal_array.rs:127-177); values that do not fit a u64 (negative, wide) are refused like the reference's fits_u64."""
+    import decimal
+    rng = np.random.default_rng(128)
+    ids, arrays = [], []
+    k = 0
+    for dtype in (pa.decimal128(15, 2), pa.decimal128(38, 0), pa.decimal256(40, 3)):
+        for hi in (10, 1 << 13, 1 << 40, (1 << 64) - 1):
+            if hi >= 10 ** (dtype.precision - 1):
+                continue
+            for n in (8192, 1000, 1, 2048 + 65, 0):
+                base = int(rng.integers(0, max(1, min(hi, 1 << 62) // 2)))
+                vals = [base + int(x) for x in rng.integers(0, max(1, min(hi, (1 << 63) - 1) - base), size=n)]
+                if hi == (1 << 64) - 1 and n:
+                    vals[0] = (1 << 64) - 1
+                mode = int(rng.integers(3))
+                mask = None if mode == 0 else rng.random(n) < (0.2 if mode == 1 else 1.0)
+                scale = dtype.scale
+                decs = [decimal.Decimal(v).scaleb(-scale) for v in vals]
+                if mask is not None:
+                    decs = [None if m else d for d, m in zip(decs, mask)]
+                with decimal.localcontext() as ctx:
+                    ctx.prec = 80
+                    arr = pa.array(decs, type=dtype)
+                if mode == 1 and n > 10:
+                    arr = arr.slice(2, n - 5)
+                k += 1
+                ids.append(lc.ParquetArrayID.new(21, k >> 12, 1, k & 0xFFF))
+                arrays.append(arr)
+    gpu_cache.insert_device(ids, arrays)
+    for e, arr in zip(ids, arrays):
+        assert gpu_cache.entry_bytes(e) == gpu_cache.transcode(arr), (str(arr.type), len(arr), arr.null_count)
+        info = gpu_cache.entry_info(e)
+        assert info.logical_type == 6
+    for kk in rng.choice(len(ids), 20, replace=False):
+        e, arr = ids[int(kk)], arrays[int(kk)]
+        if len(arr):
+            assert gpu_cache.get(e).read().equals(arr), (str(arr.type), len(arr))
+    for bad in (pa.array([decimal.Decimal("-1.00"), decimal.Decimal("2.00")], type=pa.decimal128(15, 2)),
+                pa.array([decimal.Decimal(1 << 70)], type=pa.decimal128(38, 0))):
+        with pytest.raises(lc.LiquidCacheError) as ex:
+            gpu_cache.insert_device([lc.ParquetArrayID.new(21, 99, 1, 0)], [bad])
+        assert ex.value.status == N.LC_UNSUPPORTED
