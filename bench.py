@@ -528,6 +528,46 @@ def secondary_tpch_q6(cache, lc, N, args, rows, threads, torch, stream, iters):
     return res
 
 
+def secondary_transcode_rate(cache, lc, N, args, rows, threads):
+    """Arrow -> Liquid staging rate: the host transcoder (`cache.insert`, one thread per batch stripe —
+    what the reference's background transcode threads do) against the on-device one (`lc_insert_arrow_device`: the raw
+    values cross PCIe once, min / max and FastLanes packing are kernels), same Int64 W=62 and Date32 W=12 batches; the
+    entries of both paths are byte-identical (tests), so only the time is reported."""
+    import pyarrow as pa
+    bs = args.batch_size
+    n_batches = max(1, min(rows, 16_777_216) // bs)
+    L = N.load()
+    res = {"rows": n_batches * bs, "batches": n_batches}
+    for tag, bits, base, to_arrow in (("int64_w62", 62, int_base(62), lambda v: pa.array(v)),
+                                      ("date32_w12", 12, 8036, lambda v: pa.array(v.astype(np.int32), type=pa.date32()))):
+        buf = np.zeros(bs, np.int64)
+        arrays = []
+        for b in range(n_batches):
+            L.lc_synth_int64_batch(args.seed + 7, b, bs, bits, base, buf.ctypes.data)
+            arrays.append(to_arrow(buf.copy()))
+        ids_h = [lc.ParquetArrayID.new(8, b // args.row_group_batches, 1, b % args.row_group_batches) for b in range(n_batches)]
+        ids_d = [lc.ParquetArrayID.new(8, b // args.row_group_batches, 2, b % args.row_group_batches) for b in range(n_batches)]
+
+        def host_stripe(c):
+            for b in range(c, n_batches, threads):
+                cache.insert(ids_h[b], arrays[b])
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(host_stripe, range(threads)))
+        t_host = time.perf_counter() - t0
+        chunk = 256  # arrays per device call
+        t0 = time.perf_counter()
+        for c in range(0, n_batches, chunk):
+            cache.insert_device(ids_d[c:c + chunk], arrays[c:c + chunk])
+        t_dev = time.perf_counter() - t0
+        res[tag] = {"host_threads": threads, "host_rows_per_s": n_batches * bs / t_host, "host_seconds": t_host,
+                    "device_rows_per_s": n_batches * bs / t_dev, "device_seconds": t_dev,
+                    "device_calls": (n_batches + chunk - 1) // chunk}
+        cache.evict(ids_h + ids_d)
+    return res
+
+
 def secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream, iters, pattern):
     """The LIKE scan in the reference-algorithm regimes: the reference's fingerprint prefilter only (no bigram signature
     index staged), and a column staged without the SubstringSearch hint (no fingerprints: every dictionary value walked)."""
@@ -984,6 +1024,10 @@ def main():
                                                                           max(3, iters // 2))
         except Exception as e:  # noqa: BLE001
             sec["clickbench_pushdown_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            sec["arrow_to_liquid_staging"] = secondary_transcode_rate(cache, lc, N, args, sec_rows, threads)
+        except Exception as e:  # noqa: BLE001
+            sec["arrow_to_liquid_staging"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if args.workload == "url_like" and not args.no_fingerprints:
             sec.update(secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream, iters, pattern))
         out["secondary"] = sec
