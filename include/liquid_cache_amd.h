@@ -248,6 +248,27 @@ LC_API lc_status lc_get_date_part_with_selection(lc_ctx* ctx, uint64_t entry_id,
                                                  int32_t field, struct ArrowArray* out_array,
                                                  struct ArrowSchema* out_schema);
 
+/* A whole pushed-down filter in ONE call: the steps of the reference's LiquidRowFilter in evaluation order
+ * (build_row_filter / get_priority, src/datafusion/src/reader/plantime/row_filter.rs:428-515), as LiquidCacheReader runs
+ * them per batch (liquid_cache_reader.rs:297-339) — here over whole scans: every step's hit mask is the selection of
+ * the next (boolean_buffer_and_then), nothing returns to the host in between.  A step is one predicate or a fusable pair
+ * of range predicates on one column (LC_STEP_AND; an unfusable pair is chained as two passes), or a Kleene OR over
+ * n_terms (scan, predicate) pairs (LC_STEP_OR, cache/mod.rs:111-150).  d_mask_a / d_mask_b: two device buffers of
+ * lc_scan_mask_words u64 used alternately; *d_final_mask receives the one that holds the filter's result (d_selection
+ * itself when n_steps == 0).  d_counts_out (optional): per-entry hits of the last pass; d_total_out (optional): COUNT(*)
+ * of the filter, written by the last predicate kernel (the last step must be LC_STEP_AND).  Asynchronous on `stream`. */
+#define LC_STEP_AND 0
+#define LC_STEP_OR 1
+typedef struct {
+    int32_t kind;               /* LC_STEP_AND / LC_STEP_OR */
+    uint32_t n_terms;           /* AND: 1 or 2 predicates on scans[0]; OR: number of disjuncts */
+    lc_scan* const* scans;      /* AND: scans[0]; OR: n_terms scans (the same scan may repeat: IN lists) */
+    const lc_predicate* preds;  /* n_terms predicates */
+} lc_filter_step;
+LC_API lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_step* steps, const void* d_selection,
+                                     void* d_mask_a, void* d_mask_b, void* d_counts_out, void* d_total_out,
+                                     void** d_final_mask, void* stream);
+
 /* Partial aggregation under a selection — the step after the path: what DataFusion's AggregateExec
  * (mode: Partial, the url_prefix_filtering snapshot under datafusion-local/src/tests/snapshots) computes from the rows that
  * get().with_selection() returns, without returning them.  COUNT, SUM, MIN and MAX of the valid rows of a fixed-width

@@ -1733,6 +1733,57 @@ lc_status lc_scan_eval_or(lc_ctx* ctx, uint32_t n, lc_scan* const* scans, const 
     });
 }
 
+// A whole pushed-down filter in one call: the steps of LiquidRowFilter in evaluation order (row_filter.rs:481-515), every
+// result the selection of the next step (boolean_buffer_and_then), masks alternating between two caller buffers.
+lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_step* steps, const void* d_selection,
+                              void* d_mask_a, void* d_mask_b, void* d_counts_out, void* d_total_out, void** d_final_mask,
+                              void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || (n_steps && !steps) || !d_mask_a || !d_mask_b || d_mask_a == d_mask_b)
+        return fail(LC_ERR_INVALID, "null argument (two distinct mask buffers are needed)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const void* sel = d_selection;
+    void* bufs[2] = {d_mask_a, d_mask_b};
+    int next = 0;
+    auto take = [&]() -> void* {  // an output buffer that is not the current selection
+        void* o = bufs[next];
+        if (o == sel) o = bufs[next ^ 1];
+        next = (o == bufs[0]) ? 1 : 0;
+        return o;
+    };
+    for (uint32_t k = 0; k < n_steps; k++) {
+        const lc_filter_step& sp = steps[k];
+        if (!sp.scans || !sp.preds || sp.n_terms == 0) return fail(LC_ERR_INVALID, "empty filter step");
+        const bool last = k + 1 == n_steps;
+        void* total = last ? d_total_out : nullptr;
+        if (sp.kind == LC_STEP_OR) {
+            void* out = take();
+            const lc_status rc = scan_eval_or_impl(ctx, sp.n_terms, sp.scans, sp.preds, sel, out, nullptr, d_counts_out, st);
+            if (rc != LC_OK) return rc;
+            if (total) return fail(LC_UNSUPPORTED, "the fused COUNT(*) is produced by predicate steps, not by an OR step");
+            sel = out;
+            continue;
+        }
+        if (sp.kind != LC_STEP_AND || sp.n_terms > 2 || !sp.scans[0]) return fail(LC_ERR_INVALID, "bad filter step");
+        void* out = take();
+        lc_status rc = scan_eval_impl(ctx, sp.scans[0], &sp.preds[0], sel, out, nullptr, d_counts_out, nullptr, st,
+                                      sp.n_terms == 2 ? &sp.preds[1] : nullptr, total);
+        if (rc == LC_UNSUPPORTED && sp.n_terms == 2) {
+            // not fusable after all (byte views, Ne): the two predicates as two chained passes
+            rc = scan_eval_impl(ctx, sp.scans[0], &sp.preds[0], sel, out, nullptr, d_counts_out, nullptr, st);
+            if (rc != LC_OK) return rc;
+            sel = out;
+            out = take();
+            rc = scan_eval_impl(ctx, sp.scans[0], &sp.preds[1], sel, out, nullptr, d_counts_out, nullptr, st, nullptr, total);
+        }
+        if (rc != LC_OK) return rc;
+        sel = out;
+    }
+    if (d_final_mask) *d_final_mask = const_cast<void*>(sel);
+    return LC_OK;
+    });
+}
+
 int32_t lc_calibrate_read(void* ctx_, uint64_t bytes, int32_t shape, int32_t iters) {
     lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
     return guarded([&]() -> lc_status {

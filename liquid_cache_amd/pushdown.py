@@ -130,6 +130,11 @@ class PushdownExecutor:
             i += len(group)
         return steps
 
+    def compile(self, row_filter: LiquidRowFilter) -> "CompiledFilter":
+        """Marshal the plan once: `CompiledFilter.run` is then ONE call into the library (lc_scan_eval_filter) per
+        evaluation — what a Rust caller pays, instead of Python rebuilding expressions and ctypes structs per pass."""
+        return CompiledFilter(self, self.plan(row_filter))
+
     def evaluate(self, row_filter: LiquidRowFilter, mask_ptrs: Sequence[int], counts_ptr: int = 0,
                  selection_ptr: int = 0, stream: int = 0) -> int:
         """Asynchronous.  `mask_ptrs`: two device buffers of `mask_words` u64 used alternately; returns the pointer that
@@ -185,3 +190,34 @@ class PushdownExecutor:
                 if b.value:
                     lib.lc_device_free(ctx, b)
         return mask[: int(scan.mask_words)], counts[: scan.entries]
+
+
+class CompiledFilter:
+    """The steps of a LiquidRowFilter as the C ABI takes them (lc_filter_step[]); keeps the ctypes objects alive."""
+
+    def __init__(self, executor: PushdownExecutor, steps: List[_Step]):
+        any_col = next(iter(executor.columns.values()))
+        self._lib, self._ctx = any_col.scan._lib, any_col.scan._cache.handle
+        self.steps = steps
+        self._keep = []
+        arr = (N.FilterStep * max(len(steps), 1))()
+        for k, st in enumerate(steps):
+            preds = (N.Predicate * len(st.exprs))(*[e.as_predicate() for e in st.exprs])
+            scans = (C.c_void_p * len(st.scans))(*[s._h for s in st.scans])
+            self._keep += [preds, scans, st.exprs]
+            arr[k].kind = 1 if st.kind == "or" else 0
+            arr[k].n_terms = len(st.exprs)
+            arr[k].scans = C.cast(scans, C.POINTER(C.c_void_p))
+            arr[k].preds = C.cast(preds, C.c_void_p)
+        self._arr = arr
+        self._n = len(steps)
+        self._final = C.c_void_p()
+
+    def run(self, mask_a_ptr: int, mask_b_ptr: int, counts_ptr: int = 0, selection_ptr: int = 0, total_ptr: int = 0,
+            stream: int = 0) -> int:
+        """Asynchronous.  Returns the device pointer that holds the filter's hit mask."""
+        N.check(self._lib.lc_scan_eval_filter(self._ctx, self._n, self._arr, C.c_void_p(selection_ptr or None),
+                                              C.c_void_p(mask_a_ptr), C.c_void_p(mask_b_ptr),
+                                              C.c_void_p(counts_ptr or None), C.c_void_p(total_ptr or None),
+                                              C.byref(self._final), C.c_void_p(stream or None)), self._ctx)
+        return int(self._final.value or 0)

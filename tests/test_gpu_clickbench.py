@@ -157,3 +157,51 @@ def test_multi_column_or_is_kleene(gpu_cache, oracle):
             assert gm.tolist() == want_m.tolist(), (cols, sel is None)
             assert [bool(x) for x, m in zip(gv, gm) if m] == [bool(x) for x, m in zip(want_v, want_m) if m]
     assert gpu_cache.eval_predicate_or([ids[0], 999], exprs[:2]) is None       # an uncached column -> None
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_compiled_filter_is_one_call_and_gives_the_same_masks(hits, fuse):
+    """lc_scan_eval_filter (the whole LiquidRowFilter in one C call) against the step-by-step executor for every query,
+    with and without an input selection; the fused COUNT(*) of the last predicate kernel equals the popcount."""
+    import ctypes as C
+    from liquid_cache_amd import _native as N
+    cache, columns, ids, arrays, liquids, symtabs, lo = hits
+    ex = PushdownExecutor(columns, fuse_ranges=fuse)
+    scan = columns["IsRefresh"].scan
+    lib, ctx = scan._lib, scan._cache.handle
+    words = int(scan.mask_words)
+    rng = np.random.default_rng(5)
+    sel = rng.integers(0, 1 << 63, size=words, dtype=np.uint64) | (rng.integers(0, 2, size=words, dtype=np.uint64) << np.uint64(63))
+    bufs = [C.c_void_p() for _ in range(5)]
+    try:
+        for b in bufs[:3]:
+            N.check(lib.lc_device_alloc(ctx, words * 8, C.byref(b)), ctx)
+        N.check(lib.lc_device_alloc(ctx, scan.entries * 4, C.byref(bufs[3])), ctx)
+        N.check(lib.lc_device_alloc(ctx, 8, C.byref(bufs[4])), ctx)
+        N.check(lib.lc_host_to_device(ctx, bufs[2], sel.ctypes.data_as(C.c_void_p), words * 8, None), ctx)
+        for q, conj in cb.QUERIES.items():
+            rf = LiquidRowFilter(conj)
+            cf = ex.compile(rf)
+            for use_sel in (False, True):
+                want_mask, want_counts = ex.evaluate_to_host(rf, selection=sel if use_sel else None)
+                last_is_pred = cf.steps[-1].kind != "or"
+                final = cf.run(bufs[0].value, bufs[1].value, bufs[3].value, bufs[2].value if use_sel else 0,
+                               bufs[4].value if last_is_pred else 0)
+                assert final in (bufs[0].value, bufs[1].value)
+                got = np.zeros(words, np.uint64)
+                cnt = np.zeros(scan.entries, np.uint32)
+                tot = np.zeros(1, np.uint64)
+                N.check(lib.lc_device_to_host(ctx, got.ctypes.data_as(C.c_void_p), C.c_void_p(final), words * 8, None), ctx)
+                N.check(lib.lc_device_to_host(ctx, cnt.ctypes.data_as(C.c_void_p), bufs[3], scan.entries * 4, None), ctx)
+                assert np.array_equal(got, want_mask), (q, use_sel)
+                assert np.array_equal(cnt, want_counts), (q, use_sel)
+                if last_is_pred:
+                    N.check(lib.lc_device_to_host(ctx, tot.ctypes.data_as(C.c_void_p), bufs[4], 8, None), ctx)
+                    assert int(tot[0]) == int(want_counts.sum()), (q, use_sel)
+        # no steps: the selection itself is the result
+        empty = ex.compile(LiquidRowFilter([]))
+        assert empty.run(bufs[0].value, bufs[1].value, 0, bufs[2].value) == bufs[2].value
+    finally:
+        for b in bufs:
+            if b.value:
+                lib.lc_device_free(ctx, b)
