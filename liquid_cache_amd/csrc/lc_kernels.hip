@@ -2422,6 +2422,82 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave); entry < L.n_entries; entry += total_waves) {
     const FixedDesc d = descs[entry];
     uint64_t entry_out_row = entry_offsets[entry];
+    const uint32_t vw = d.value_width;
+    const uint32_t W = d.W;
+    // decode one packed offset and store it as output row o
+    auto emit = [&](U u, uint64_t o) {
+        if (d.kind == kKindInt) {
+            const U v = W != 0 ? U(u + U(d.reference)) : U(0);  // add_wrapping (primitive_array.rs:357)
+            reinterpret_cast<U*>(out)[o] = v;
+        } else if (d.kind == kKindDecimal) {
+            if constexpr (TB == 64) {
+                const uint64_t v = W != 0 ? uint64_t(u) + d.reference : 0;  // decimal_array.rs:189, :285
+                uint64_t* p = reinterpret_cast<uint64_t*>(out + o * vw);
+                p[0] = v;
+                p[1] = 0;
+                if (vw == 32) { p[2] = 0; p[3] = 0; }
+            }
+        } else if (d.kind == kKindF32) {
+            if constexpr (TB == 32) {
+                const int32_t iv = int32_t(uint32_t(u) + uint32_t(d.reference));
+                reinterpret_cast<float*>(out)[o] = W != 0 ? alp_decode(iv, d.alp_e, d.alp_f) : 0.0f;
+            }
+        } else {
+            if constexpr (TB == 64) {
+                const int64_t iv = int64_t(uint64_t(u) + d.reference);
+                reinterpret_cast<double*>(out)[o] = W != 0 ? alp_decode(iv, d.alp_e, d.alp_f) : 0.0;
+            }
+        }
+    };
+    // Sparse ENTRIES (what a selective filter leaves: a few rows in 8192): the selection words of the whole entry are
+    // read at once, its selected rows listed, and their packed words fetched straight from HBM in one dense step — two
+    // dependent round trips per entry instead of two per 1024-row block.
+    const uint32_t ewords = (d.len + 63u) >> 6;
+    if (L.d_selection && ewords <= 2u * kWave && d.patch_len == 0) {
+        uint64_t sw[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t w = uint32_t(h) * kWave + uint32_t(lane);
+            sw[h] = 0;
+            if (w < ewords) {
+                sw[h] = L.d_selection[d.mask_word_off + w];
+                if (w == ewords - 1 && (d.len & 63u)) sw[h] &= (uint64_t(1) << (d.len & 63u)) - 1;
+            }
+        }
+        const uint32_t c0 = uint32_t(__popcll(sw[0])), c1 = uint32_t(__popcll(sw[1]));
+        const uint32_t i0 = wave_inclusive_sum(c0), i1 = wave_inclusive_sum(c1);
+        const uint32_t t0 = read_lane(i0, kWave - 1), total = t0 + read_lane(i1, kWave - 1);
+        if (total == 0) continue;
+        if (total <= 512u) {
+            uint16_t* list = sel_list[wave];
+            uint32_t pos[2] = {i0 - c0, t0 + i1 - c1};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint64_t m = sw[h];
+                const uint32_t base = (uint32_t(h) * kWave + uint32_t(lane)) * 64u;
+                while (m) {
+                    list[pos[h]++] = uint16_t(base + uint32_t(__ffsll((long long)m)) - 1u);
+                    m &= m - 1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const U mask_e = (W >= TB) ? U(~U(0)) : U((U(1) << (W & (TB - 1))) - 1);
+            for (uint32_t j = uint32_t(lane); j < total; j += kWave) {
+                const uint64_t o_row = entry_out_row + j;
+                if (o_row >= capacity_rows) continue;
+                U u = 0;
+                if (W != 0) {
+                    const uint32_t r = list[j];
+                    uint32_t row, fl;
+                    fl_row_lane<U>(r & 1023u, &row, &fl);
+                    u = extract_packed<U>(d.packed + uint64_t(r >> 10) * 128u * W, row, fl, W, mask_e);
+                }
+                emit(u, o_row);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            continue;
+        }
+    }
     for (uint32_t blk = 0, row0 = 0; row0 < d.len; blk++, row0 += 1024u) {
     const uint32_t rows = min(1024u, d.len - row0);
     const uint32_t nwords = (rows + 63u) >> 6;
@@ -2436,10 +2512,8 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
     if (blk_count == 0) continue;
     const uint64_t blk_out_row = entry_out_row;
     entry_out_row += blk_count;
-    const uint32_t vw = d.value_width;
     uint64_t out_row = blk_out_row;
     uint8_t* buf = lds[wave];
-    const uint32_t W = d.W;
     // Sparse blocks (the usual case after a selective filter): fetch only the one or two packed words of each selected
     // row straight from HBM instead of staging the whole 128*W-byte block (break-even ~30 rows of two 128-byte lines).
     const uint8_t* gblk = d.packed + uint64_t(blk) * 128u * W;
@@ -2491,29 +2565,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
                 fl_row_lane<U>(uint32_t(list[j]), &row, &fl);
                 u = sparse ? extract_packed<U>(gblk, row, fl, W, mask) : extract_packed<U>(buf, row, fl, W, mask);
             }
-            const uint64_t o = o_row;
-            if (d.kind == kKindInt) {
-                const U v = W != 0 ? U(u + U(d.reference)) : U(0);  // add_wrapping (primitive_array.rs:357)
-                reinterpret_cast<U*>(out)[o] = v;
-            } else if (d.kind == kKindDecimal) {
-                if constexpr (TB == 64) {
-                    const uint64_t v = W != 0 ? uint64_t(u) + d.reference : 0;  // decimal_array.rs:189, :285
-                    uint64_t* p = reinterpret_cast<uint64_t*>(out + o * vw);
-                    p[0] = v;
-                    p[1] = 0;
-                    if (vw == 32) { p[2] = 0; p[3] = 0; }
-                }
-            } else if (d.kind == kKindF32) {
-                if constexpr (TB == 32) {
-                    const int32_t iv = int32_t(uint32_t(u) + uint32_t(d.reference));
-                    reinterpret_cast<float*>(out)[o] = W != 0 ? alp_decode(iv, d.alp_e, d.alp_f) : 0.0f;
-                }
-            } else {
-                if constexpr (TB == 64) {
-                    const int64_t iv = int64_t(uint64_t(u) + d.reference);
-                    reinterpret_cast<double*>(out)[o] = W != 0 ? alp_decode(iv, d.alp_e, d.alp_f) : 0.0;
-                }
-            }
+            emit(u, o_row);
         }
         out_row += total;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the list is rewritten by the next group
@@ -3356,7 +3408,55 @@ __global__ __launch_bounds__(kThreads) void k_fixed_agg(const FixedDesc* __restr
         uint64_t cnt = 0, slo = 0, shi = 0, mn = ~uint64_t(0), mx = 0;  // per lane
         const uint32_t W = d.W;
         const U mask = (W >= TB) ? U(~U(0)) : U((U(1) << (W & (TB - 1))) - 1);
-        for (uint32_t blk = 0, row0 = 0; W != 0 && row0 < d.len; blk++, row0 += 1024u) {
+        // sparse entries: the whole entry's selected valid rows in one dense step (see k_fixed_gather)
+        const uint32_t ewords = (d.len + 63u) >> 6;
+        bool entry_done = false;
+        if (W != 0 && L.d_selection && ewords <= 2u * kWave) {
+            uint64_t sw[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t w = uint32_t(h) * kWave + uint32_t(lane);
+                sw[h] = 0;
+                if (w < ewords) {
+                    sw[h] = L.d_selection[d.mask_word_off + w];
+                    if (d.validity) sw[h] &= d.validity[w];
+                    if (w == ewords - 1 && (d.len & 63u)) sw[h] &= (uint64_t(1) << (d.len & 63u)) - 1;
+                }
+            }
+            const uint32_t c0 = uint32_t(__popcll(sw[0])), c1 = uint32_t(__popcll(sw[1]));
+            const uint32_t i0 = wave_inclusive_sum(c0), i1 = wave_inclusive_sum(c1);
+            const uint32_t t0 = read_lane(i0, kWave - 1), total = t0 + read_lane(i1, kWave - 1);
+            if (total <= 512u) {
+                entry_done = true;
+                if (total != 0) {
+                    uint16_t* list = reinterpret_cast<uint16_t*>(lds[wave]);  // the block staging area is unused here
+                    uint32_t pos[2] = {i0 - c0, t0 + i1 - c1};
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        uint64_t m = sw[h];
+                        const uint32_t base = (uint32_t(h) * kWave + uint32_t(lane)) * 64u;
+                        while (m) {
+                            list[pos[h]++] = uint16_t(base + uint32_t(__ffsll((long long)m)) - 1u);
+                            m &= m - 1;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    for (uint32_t j = uint32_t(lane); j < total; j += kWave) {
+                        const uint32_t r = list[j];
+                        uint32_t row, fl;
+                        fl_row_lane<U>(r & 1023u, &row, &fl);
+                        const uint64_t u = uint64_t(extract_packed<U>(d.packed + uint64_t(r >> 10) * 128u * W, row, fl, W, mask));
+                        cnt++;
+                        slo += u;
+                        shi += slo < u ? 1u : 0u;
+                        mn = min(mn, u);
+                        mx = max(mx, u);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                }
+            }
+        }
+        for (uint32_t blk = 0, row0 = 0; !entry_done && W != 0 && row0 < d.len; blk++, row0 += 1024u) {
             const uint32_t rows = min(1024u, d.len - row0);
             const uint32_t nwords = (rows + 63u) >> 6;
             const uint64_t word_base = d.mask_word_off + uint64_t(blk) * 16u;
