@@ -183,13 +183,15 @@ LC_API lc_status lc_transcode_arrow(lc_ctx* ctx, const struct ArrowArray* array,
 /* cache.insert(entry_id, array) with eager transcoding (benchmark/README.md:42 `liquid_eager_transcode`). */
 LC_API lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArray* array,
                                  const struct ArrowSchema* schema, int32_t hint, uint64_t path_id);
-/* Arrow -> Liquid transcoding ON THE DEVICE for integer-like arrays (Int8..UInt64, Date32/64, Timestamp without zone)
- * and Decimal128 / Decimal256 arrays: the raw values cross PCIe once and min / max (frame of reference, bit width) and
+/* Arrow -> Liquid transcoding ON THE DEVICE for integer-like arrays (Int8..UInt64, Date32/64, Timestamp without zone),
+ * Decimal128 / Decimal256 arrays and Float32 / Float64 arrays: the raw values cross PCIe once; min / max (frame of
+ * reference, bit width), the ALP exponent search on the reference's sample, encoding, exception (patch) extraction and
  * the FastLanes packing run as kernels (LiquidPrimitiveArray::from_arrow_array, primitive_array.rs:159-206;
- * LiquidDecimalArray::from_decimal_array, decimal_array.rs:127-177; BitPackedArray::from_primitive,
- * bit_pack_array.rs:71-124).  The staged entries are byte-identical to what lc_insert_arrow stages (checked through
- * lc_entry_to_liquid_bytes).  LC_UNSUPPORTED for other array types and for decimal arrays with a value that does not
- * fit a u64 (the reference's fits_u64, decimal_array.rs:120-125): use lc_insert_arrow. */
+ * LiquidDecimalArray::from_decimal_array, decimal_array.rs:127-177; LiquidFloatArray::from_arrow_array,
+ * float_array.rs:590-740; BitPackedArray::from_primitive, bit_pack_array.rs:71-124).  The staged entries are
+ * byte-identical to what lc_insert_arrow stages (checked through lc_entry_to_liquid_bytes).  LC_UNSUPPORTED for other
+ * array types (byte views: the dictionary / FSST encoder stays on the host) and for decimal arrays with a value that
+ * does not fit a u64 (the reference's fits_u64, decimal_array.rs:120-125): use lc_insert_arrow. */
 LC_API lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids,
                                         const struct ArrowArray* const* arrays, const struct ArrowSchema* const* schemas);
 /* LiquidArray::to_bytes() of a staged fixed-width entry, rebuilt from HBM (malloc'ed; release with lc_free): what the

@@ -3134,6 +3134,254 @@ __global__ __launch_bounds__(256) void k_calib_read_scattered8(const uint8_t* __
 // ------------------------------------------------------------------------------------------------ launchers
 static int device_cus();
 
+// ------------------------------------------------------------------------------------------------
+// On-device ALP encoder for Float32 / Float64 arrays (LiquidFloatArray::from_arrow_array, float_array.rs:590-740):
+//   k_alp_search   exponent pair (e, f): the reference tries every f < e < max on a sample of <= ~2K values and keeps the
+//                  pair with the smallest estimated size (packed bits + exceptions), first pair wins ties (:715-740)
+//   k_alp_encode   encode every slot, find the exceptions (decode != value), fill their slots with the first clean
+//                  encoding (:652-668), min / max of the result; exceptions compacted in index order
+// then the integer packer (k_fl_pack) on (encoded - min).  Same arithmetic as the host transcoder: (v * 10^e) * 10^-f,
+// round by adding and subtracting the "sweet" constant, Rust `as` saturation; no FMA contraction (-ffp-contract=off).
+// ------------------------------------------------------------------------------------------------
+template <typename F> struct AlpDev;
+template <> struct AlpDev<float> {
+    typedef int32_t I;
+    typedef uint32_t U;
+    static constexpr int kMaxExp = 10;
+    static __device__ __forceinline__ float f10(int i) { return kF10f[i]; }
+    static __device__ __forceinline__ float if10(int i) { return kIF10f[i]; }
+    static __device__ __forceinline__ float sweet() { return 8388608.0f + 4194304.0f; }
+    static __device__ __forceinline__ int32_t imax() { return 2147483647; }
+    static __device__ __forceinline__ int32_t imin() { return -2147483647 - 1; }
+};
+template <> struct AlpDev<double> {
+    typedef int64_t I;
+    typedef uint64_t U;
+    static constexpr int kMaxExp = 18;
+    static __device__ __forceinline__ double f10(int i) { return kF10d[i]; }
+    static __device__ __forceinline__ double if10(int i) { return kIF10d[i]; }
+    static __device__ __forceinline__ double sweet() { return 4503599627370496.0 + 2251799813685248.0; }
+    static __device__ __forceinline__ int64_t imax() { return 9223372036854775807ll; }
+    static __device__ __forceinline__ int64_t imin() { return -9223372036854775807ll - 1; }
+};
+template <typename F>
+__device__ __forceinline__ typename AlpDev<F>::I alp_encode_dev(F v, int e, int f) {
+    typedef typename AlpDev<F>::I I;
+    F t = v * AlpDev<F>::f10(e);
+    t = t * AlpDev<F>::if10(f);
+    F r = t + AlpDev<F>::sweet();
+    asm volatile("" : "+v"(r));  // the add and the subtract must both happen (this IS the rounding)
+    r = r - AlpDev<F>::sweet();
+    if (r != r) return 0;  // Rust `as`: NaN -> 0, saturating
+    if (r >= F(AlpDev<F>::imax())) return AlpDev<F>::imax();
+    if (r <= F(AlpDev<F>::imin())) return AlpDev<F>::imin();
+    return I(r);
+}
+template <typename F>
+__device__ __forceinline__ F alp_decode_dev(typename AlpDev<F>::I i, int e, int f) {
+    F t = F(i);
+    t = t * AlpDev<F>::f10(f);
+    t = t * AlpDev<F>::if10(e);
+    return t;
+}
+__device__ __forceinline__ int dev_bit_width(uint64_t v) { return v == 0 ? 0 : 64 - __clzll((long long)v); }
+
+struct AlpStats {  // one per array
+    uint32_t e, f;          // k_alp_search
+    uint32_t n_exc;         // k_alp_encode
+    uint32_t pad;
+    int64_t mn, mx;         // of the final encoded values (exception slots filled)
+};
+
+template <typename F>
+__global__ __launch_bounds__(256) void k_alp_search(const EncodeDesc* __restrict__ descs, AlpStats* __restrict__ out) {
+    typedef typename AlpDev<F>::I I;
+    typedef typename AlpDev<F>::U U;
+    __shared__ F sample[2048];
+    __shared__ uint32_t s_n;
+    __shared__ int64_t red[5][4];
+    const EncodeDesc d = descs[blockIdx.x];
+    const F* v = reinterpret_cast<const F*>(d.values);
+    // the sample: every value when n <= 1024 (null slots included), else every (n / 1024)-th VALID value
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (d.n <= 1024u) {
+        for (uint32_t i = threadIdx.x; i < d.n; i += 256) sample[i] = v[i];
+        if (threadIdx.x == 0) s_n = d.n;
+    } else {
+        const uint32_t step = d.n / 1024u;
+        for (uint32_t k = threadIdx.x; k * step < d.n; k += 256) {
+            const uint32_t i = k * step;
+            const bool valid = d.validity ? ((d.validity[i >> 6] >> (i & 63u)) & 1) != 0 : true;
+            if (valid) sample[atomicAdd(&s_n, 1u)] = v[i];  // order is irrelevant to the statistics
+        }
+    }
+    __syncthreads();
+    const uint32_t sn = s_n;
+    uint32_t be = 0, bf = 0;
+    uint64_t best = ~uint64_t(0);
+    for (int e = 0; e < AlpDev<F>::kMaxExp && sn; e++) {
+        for (int f = 0; f < e; f++) {
+            int64_t exc = 0, mn_c = INT64_MAX, mx_c = INT64_MIN, mn_a = INT64_MAX, mx_a = INT64_MIN;
+            for (uint32_t j = threadIdx.x; j < sn; j += 256) {
+                const F x = sample[j];
+                const I en = alp_encode_dev<F>(x, e, f);
+                const bool bad = !(alp_decode_dev<F>(en, e, f) == x);
+                exc += bad;
+                mn_a = min(mn_a, int64_t(en));
+                mx_a = max(mx_a, int64_t(en));
+                if (!bad) { mn_c = min(mn_c, int64_t(en)); mx_c = max(mx_c, int64_t(en)); }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                exc += __shfl_down(exc, o, kWave);
+                mn_c = min(mn_c, int64_t(__shfl_down(mn_c, o, kWave)));
+                mx_c = max(mx_c, int64_t(__shfl_down(mx_c, o, kWave)));
+                mn_a = min(mn_a, int64_t(__shfl_down(mn_a, o, kWave)));
+                mx_a = max(mx_a, int64_t(__shfl_down(mx_a, o, kWave)));
+            }
+            if (lane_id() == 0) {
+                red[0][wave_id()] = exc; red[1][wave_id()] = mn_c; red[2][wave_id()] = mx_c;
+                red[3][wave_id()] = mn_a; red[4][wave_id()] = mx_a;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                for (int w = 1; w < 4; w++) {
+                    exc += red[0][w];
+                    mn_c = min(mn_c, red[1][w]); mx_c = max(mx_c, red[2][w]);
+                    mn_a = min(mn_a, red[3][w]); mx_a = max(mx_a, red[4][w]);
+                }
+                // exception slots take a clean encoding when there is one: min / max are those of the clean values
+                const bool use_clean = exc > 0 && uint64_t(exc) < sn;
+                const I mn = I(use_clean ? mn_c : mn_a), mx = I(use_clean ? mx_c : mx_a);
+                const int W = dev_bit_width(uint64_t(U(U(mx) - U(mn))));
+                const uint64_t est = uint64_t((sn + 1023u) / 1024u) * 128u * uint64_t(W) + uint64_t(exc) * (8u + sizeof(F));
+                if (est < best) { best = est; be = uint32_t(e); bf = uint32_t(f); }
+            }
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) { out[blockIdx.x].e = be; out[blockIdx.x].f = bf; }
+}
+
+// enc: n encoded values per array (scratch, stride = max rows), exc_idx / exc_val: compacted exceptions in index order
+template <typename F>
+__global__ __launch_bounds__(1024) void k_alp_encode(const EncodeDesc* __restrict__ descs, AlpStats* __restrict__ stats,
+                                                      uint32_t stride, typename AlpDev<F>::I* __restrict__ enc_all,
+                                                      uint64_t* __restrict__ exc_idx_all, F* __restrict__ exc_val_all) {
+    typedef typename AlpDev<F>::I I;
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint32_t s_first_clean;
+    __shared__ int64_t s_mn[16], s_mx[16];
+    const EncodeDesc d = descs[blockIdx.x];
+    const F* v = reinterpret_cast<const F*>(d.values);
+    I* enc = enc_all + size_t(blockIdx.x) * stride;
+    uint64_t* exc_idx = exc_idx_all + size_t(blockIdx.x) * stride;
+    F* exc_val = exc_val_all + size_t(blockIdx.x) * stride;
+    const int e = int(stats[blockIdx.x].e), f = int(stats[blockIdx.x].f);
+    if (threadIdx.x == 0) s_first_clean = 0xFFFFFFFFu;
+    __syncthreads();
+    uint64_t n_exc = 0;  // running, block uniform
+    for (uint32_t base = 0; base < d.n; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        bool bad = false;
+        F x = 0;
+        if (i < d.n) {
+            x = v[i];
+            const I en = alp_encode_dev<F>(x, e, f);
+            enc[i] = en;
+            bad = !(alp_decode_dev<F>(en, e, f) == x);
+            if (!bad) atomicMin(&s_first_clean, i);
+        }
+        uint64_t total;
+        const uint64_t incl = block_inclusive_scan_1024(bad ? 1u : 0u, wave_tot, &total);
+        if (bad) {
+            exc_idx[n_exc + incl - 1] = i;
+            exc_val[n_exc + incl - 1] = x;
+        }
+        n_exc += total;
+    }
+    __syncthreads();
+    // fill the exception slots (only when some slot is clean), then min / max of the final values
+    const uint32_t first_clean = s_first_clean;
+    const bool fill = n_exc > 0 && n_exc < d.n && first_clean != 0xFFFFFFFFu;
+    const I fill_v = fill ? enc[first_clean] : I(0);
+    __syncthreads();
+    if (fill)
+        for (uint64_t k = threadIdx.x; k < n_exc; k += 1024) enc[exc_idx[k]] = fill_v;
+    __syncthreads();
+    int64_t mn = INT64_MAX, mx = INT64_MIN;
+    for (uint32_t i = threadIdx.x; i < d.n; i += 1024) {
+        const int64_t en = int64_t(enc[i]);
+        mn = min(mn, en);
+        mx = max(mx, en);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = min(mn, int64_t(__shfl_down(mn, o, kWave)));
+        mx = max(mx, int64_t(__shfl_down(mx, o, kWave)));
+    }
+    if (lane_id() == 0) { s_mn[wave_id()] = mn; s_mx[wave_id()] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; w++) { mn = min(mn, s_mn[w]); mx = max(mx, s_mx[w]); }
+        if (d.n == 0) mn = mx = 0;
+        stats[blockIdx.x].n_exc = uint32_t(n_exc);
+        stats[blockIdx.x].mn = mn;
+        stats[blockIdx.x].mx = mx;
+    }
+}
+
+// the compacted exceptions of every array to their place in the entry blobs
+template <typename F>
+__global__ __launch_bounds__(256) void k_alp_copy_patches(const AlpStats* __restrict__ stats, uint32_t stride,
+                                                          const uint64_t* __restrict__ exc_idx_all,
+                                                          const F* __restrict__ exc_val_all,
+                                                          uint64_t* const* __restrict__ dst_idx, F* const* __restrict__ dst_val) {
+    const uint32_t a = blockIdx.y;
+    const uint32_t n = stats[a].n_exc;
+    for (uint32_t k = blockIdx.x * 256u + threadIdx.x; k < n; k += gridDim.x * 256u) {
+        dst_idx[a][k] = exc_idx_all[size_t(a) * stride + k];
+        dst_val[a][k] = exc_val_all[size_t(a) * stride + k];
+    }
+}
+
+hipError_t launch_alp_search(const EncodeDesc* d_descs, uint32_t n_arrays, int value_log2, void* d_stats, hipStream_t stream) {
+    if (n_arrays == 0) return hipSuccess;
+    AlpStats* st = static_cast<AlpStats*>(d_stats);
+    if (value_log2 == 2) hipLaunchKernelGGL(k_alp_search<float>, dim3(n_arrays), dim3(256), 0, stream, d_descs, st);
+    else hipLaunchKernelGGL(k_alp_search<double>, dim3(n_arrays), dim3(256), 0, stream, d_descs, st);
+    return hipGetLastError();
+}
+hipError_t launch_alp_encode(const EncodeDesc* d_descs, uint32_t n_arrays, int value_log2, void* d_stats, uint32_t stride,
+                             void* d_enc, uint64_t* d_exc_idx, void* d_exc_val, hipStream_t stream) {
+    if (n_arrays == 0) return hipSuccess;
+    AlpStats* st = static_cast<AlpStats*>(d_stats);
+    if (value_log2 == 2)
+        hipLaunchKernelGGL(k_alp_encode<float>, dim3(n_arrays), dim3(1024), 0, stream, d_descs, st, stride,
+                           static_cast<int32_t*>(d_enc), d_exc_idx, static_cast<float*>(d_exc_val));
+    else
+        hipLaunchKernelGGL(k_alp_encode<double>, dim3(n_arrays), dim3(1024), 0, stream, d_descs, st, stride,
+                           static_cast<int64_t*>(d_enc), d_exc_idx, static_cast<double*>(d_exc_val));
+    return hipGetLastError();
+}
+hipError_t launch_alp_copy_patches(const void* d_stats, uint32_t n_arrays, int value_log2, uint32_t stride,
+                                   const uint64_t* d_exc_idx, const void* d_exc_val, void* const* d_dst_idx,
+                                   void* const* d_dst_val, uint32_t max_exc, hipStream_t stream) {
+    if (n_arrays == 0 || max_exc == 0) return hipSuccess;
+    const dim3 grid((max_exc + 255u) / 256u, n_arrays), block(256);
+    const AlpStats* st = static_cast<const AlpStats*>(d_stats);
+    if (value_log2 == 2)
+        hipLaunchKernelGGL(k_alp_copy_patches<float>, grid, block, 0, stream, st, stride, d_exc_idx,
+                           static_cast<const float*>(d_exc_val), reinterpret_cast<uint64_t* const*>(d_dst_idx),
+                           reinterpret_cast<float* const*>(d_dst_val));
+    else
+        hipLaunchKernelGGL(k_alp_copy_patches<double>, grid, block, 0, stream, st, stride, d_exc_idx,
+                           static_cast<const double*>(d_exc_val), reinterpret_cast<uint64_t* const*>(d_dst_idx),
+                           reinterpret_cast<double* const*>(d_dst_val));
+    return hipGetLastError();
+}
+
 hipError_t launch_col_minmax(const EncodeDesc* d_descs, uint32_t n_entries, EncodeMinMax* d_out, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
     hipLaunchKernelGGL(k_col_minmax, dim3(n_entries), dim3(256), 0, stream, d_descs, d_out);

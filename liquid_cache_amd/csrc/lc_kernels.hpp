@@ -241,6 +241,17 @@ hipError_t launch_mask_or_kleene(uint64_t* d_hit, uint64_t* d_valid, const uint6
 // per-entry popcounts of the mask passed as L.d_selection
 hipError_t launch_mask_entry_counts(const void* d_descs, bool is_str, const ScanLaunch& L, uint32_t* d_entry_counts,
                                     hipStream_t stream);
+// On-device ALP encoder (floats): exponent search, encode + exceptions, patch placement.  d_stats: one AlpStatsHost per array.
+struct AlpStatsHost {
+    uint32_t e, f, n_exc, pad;
+    int64_t mn, mx;
+};
+hipError_t launch_alp_search(const EncodeDesc* d_descs, uint32_t n_arrays, int value_log2, void* d_stats, hipStream_t stream);
+hipError_t launch_alp_encode(const EncodeDesc* d_descs, uint32_t n_arrays, int value_log2, void* d_stats, uint32_t stride,
+                             void* d_enc, uint64_t* d_exc_idx, void* d_exc_val, hipStream_t stream);
+hipError_t launch_alp_copy_patches(const void* d_stats, uint32_t n_arrays, int value_log2, uint32_t stride,
+                                   const uint64_t* d_exc_idx, const void* d_exc_val, void* const* d_dst_idx,
+                                   void* const* d_dst_val, uint32_t max_exc, hipStream_t stream);
 hipError_t launch_col_minmax(const EncodeDesc* d_descs, uint32_t n_entries, EncodeMinMax* d_out, hipStream_t stream);
 hipError_t launch_fl_pack(const EncodeDesc* d_descs, uint32_t n_entries, uint32_t max_rows, int lane_log2, hipStream_t stream);
 // date / timestamp values -> one calendar component (i32), and its lossy reconstruction in the original Arrow type

@@ -945,6 +945,8 @@ struct DevEncodeItem {
     bool entry_signed = false;
     bool quantize = false;                  // with `forced`: bucket indices instead of clamped offsets
     uint64_t quant_width = 0;               // result: the bucket width
+    bool is_float = false;                  // Float32 / Float64: the ALP path (device_encode_floats)
+    uint32_t n_valid = 0;                   // floats: valid rows, counted on the host (all-null arrays skip the encoder)
     int in_stride = 0;                      // decimals from Arrow: bytes per value in the staging buffer (16 / 32)
     int logical = kInteger;                 // kDecimal: a decimal entry (u64 offsets of the unscaled values)
     int dec_precision = 0, dec_scale = 0, dec_is256 = 0, entry_value_width = 0;
@@ -1117,6 +1119,152 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
     }
     return LC_OK;
 }
+// Floats: ALP on the device (k_alp_search -> k_alp_encode -> k_fl_pack + k_alp_copy_patches), then the entries are
+// registered exactly as lc_stage registers a LiquidFloatArray (build_fixed).
+lc_status device_encode_floats(lc_ctx* ctx, std::vector<DevEncodeItem>& items) {
+    if (items.empty()) return LC_OK;
+    for (int vlog = 2; vlog <= 3; vlog++) {  // one pass per float width (the kernels are templated on it)
+        std::vector<size_t> sel;
+        for (size_t i = 0; i < items.size(); i++)
+            if ((items[i].vw == 4) == (vlog == 2)) sel.push_back(i);
+        if (sel.empty()) continue;
+        const size_t m = sel.size();
+        const size_t fw = size_t(1) << vlog;
+        uint32_t stride = 1;
+        for (size_t k : sel) stride = std::max(stride, items[k].n);
+        std::vector<EncodeDesc> descs(m);
+        for (size_t j = 0; j < m; j++) {
+            const DevEncodeItem& it = items[sel[j]];
+            EncodeDesc& d = descs[j];
+            d = EncodeDesc{};
+            d.values = it.d_values;
+            d.validity = it.has_validity ? it.d_validity : nullptr;
+            d.n = it.n_valid == 0 ? 0 : it.n;  // all-null arrays carry no encoded values (float_array.rs:620-631)
+            d.value_log2 = uint8_t(vlog);
+            d.is_signed = 1;
+        }
+        EncodeDesc* d_descs = static_cast<EncodeDesc*>(pool_alloc(ctx, m * sizeof(EncodeDesc)));
+        AlpStatsHost* d_stats = static_cast<AlpStatsHost*>(pool_alloc(ctx, m * sizeof(AlpStatsHost)));
+        uint8_t* d_enc = static_cast<uint8_t*>(pool_alloc(ctx, m * size_t(stride) * fw + 64));
+        uint64_t* d_xi = static_cast<uint64_t*>(pool_alloc(ctx, m * size_t(stride) * 8 + 64));
+        uint8_t* d_xv = static_cast<uint8_t*>(pool_alloc(ctx, m * size_t(stride) * fw + 64));
+        void** d_ptrs = static_cast<void**>(pool_alloc(ctx, 2 * m * sizeof(void*)));
+        struct Scratch {
+            lc_ctx* c; void* p[6];
+            ~Scratch() { (void)hipDeviceSynchronize(); for (void* q : p) pool_release(c, q); }
+        } scratch{ctx, {d_descs, d_stats, d_enc, d_xi, d_xv, d_ptrs}};
+        if (!d_descs || !d_stats || !d_enc || !d_xi || !d_xv || !d_ptrs) return fail(LC_ERR_OOM, "hipMalloc (ALP encoder scratch)");
+        LC_HIP(hipMemcpy(d_descs, descs.data(), m * sizeof(EncodeDesc), hipMemcpyHostToDevice));
+        LC_HIP(hipMemsetAsync(d_stats, 0, m * sizeof(AlpStatsHost), nullptr));
+        LC_HIP(launch_alp_search(d_descs, uint32_t(m), vlog, d_stats, nullptr));
+        LC_HIP(launch_alp_encode(d_descs, uint32_t(m), vlog, d_stats, stride, d_enc, d_xi, d_xv, nullptr));
+        std::vector<AlpStatsHost> stv(m);
+        LC_HIP(hipMemcpy(stv.data(), d_stats, m * sizeof(AlpStatsHost), hipMemcpyDeviceToHost));
+        // blob layout per entry: [packed + 128 slack][validity words][patch indices u64][patch values]
+        struct Lay { size_t begin, packed, valid, pidx, pval, bytes; int W; bool all_null; };
+        std::vector<Lay> lay(m);
+        size_t total = 0;
+        uint32_t max_exc = 0;
+        for (size_t j = 0; j < m; j++) {
+            const DevEncodeItem& it = items[sel[j]];
+            Lay& L = lay[j];
+            L.all_null = it.n_valid == 0;
+            L.begin = align_up(total, kSectionAlign);
+            L.packed = L.valid = L.pidx = L.pval = size_t(-1);
+            size_t cur = L.begin;
+            L.W = 0;
+            if (!L.all_null) {
+                const uint64_t range = vlog == 2 ? uint64_t(uint32_t(uint32_t(stv[j].mx) - uint32_t(stv[j].mn)))
+                                                 : uint64_t(stv[j].mx) - uint64_t(stv[j].mn);
+                L.W = bit_width_of(range);
+                L.packed = cur;
+                cur = align_up(cur + packed_bytes(L.W, it.n) + 128, kSectionAlign);
+                if (it.has_validity) {
+                    L.valid = cur;
+                    cur = align_up(cur + ((size_t(it.n) + 63) / 64) * 8, kSectionAlign);
+                }
+                if (stv[j].n_exc) {
+                    L.pidx = cur;
+                    cur = align_up(cur + size_t(stv[j].n_exc) * 8, kSectionAlign);
+                    L.pval = cur;
+                    cur = align_up(cur + size_t(stv[j].n_exc) * fw, kSectionAlign);
+                    max_exc = std::max(max_exc, stv[j].n_exc);
+                }
+            }
+            L.bytes = cur - L.begin;
+            total = cur;
+        }
+        total = align_up(total, kSectionAlign) + 256;
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        uint8_t* dbase = nullptr;
+        int slab = -1;
+        lc_status st = arena_alloc(ctx, total, &dbase, &slab);
+        if (st != LC_OK) return st;
+        ctx->slabs[size_t(slab)].live += int64_t(m) - 1;
+        LC_HIP(hipMemsetAsync(dbase, 0, total, nullptr));
+        std::vector<void*> ptrs(2 * m, nullptr);
+        for (size_t j = 0; j < m; j++) {
+            const DevEncodeItem& it = items[sel[j]];
+            const Lay& L = lay[j];
+            EncodeDesc& d = descs[j];
+            d.values = d_enc + j * size_t(stride) * fw;  // the encoded integers
+            d.n = L.all_null ? 0 : it.n;
+            d.W = uint8_t(L.W);
+            d.reference = uint64_t(stv[j].mn);
+            d.packed = L.all_null ? nullptr : dbase + L.packed;
+            d.validity_out = L.valid == size_t(-1) ? nullptr : reinterpret_cast<uint64_t*>(dbase + L.valid);
+            if (L.all_null) d.validity = nullptr;
+            ptrs[j] = L.pidx == size_t(-1) ? nullptr : dbase + L.pidx;
+            ptrs[m + j] = L.pval == size_t(-1) ? nullptr : dbase + L.pval;
+        }
+        LC_HIP(hipMemcpy(d_descs, descs.data(), m * sizeof(EncodeDesc), hipMemcpyHostToDevice));
+        LC_HIP(hipMemcpy(d_ptrs, ptrs.data(), 2 * m * sizeof(void*), hipMemcpyHostToDevice));
+        LC_HIP(launch_fl_pack(d_descs, uint32_t(m), stride, vlog + 3, nullptr));
+        LC_HIP(launch_alp_copy_patches(d_stats, uint32_t(m), vlog, stride, d_xi, d_xv, d_ptrs, d_ptrs + m, max_exc, nullptr));
+        LC_HIP(hipDeviceSynchronize());
+        for (size_t j = 0; j < m; j++) {
+            const DevEncodeItem& it = items[sel[j]];
+            const Lay& L = lay[j];
+            Entry e;
+            e.is_str = false;
+            e.logical = kFloat;
+            e.phys = it.phys;
+            e.len = it.n;
+            e.all_null = L.all_null;
+            e.nullable = it.has_validity || L.all_null;
+            e.W = L.all_null ? 0 : L.W;
+            e.slab = slab;
+            e.device_bytes = L.bytes;
+            FixedDesc& d = e.fd;
+            d = FixedDesc{};
+            d.len = it.n;
+            d.W = uint8_t(e.W);
+            d.lane_log2 = uint8_t(vlog + 3);
+            d.value_width = uint8_t(fw);
+            d.kind = vlog == 2 ? kKindF32 : kKindF64;
+            d.is_signed = 1;
+            if (!L.all_null) {
+                d.reference = uint64_t(stv[j].mn);  // int64 bits, sign-extended for f32 by the kernel's int64 minimum
+                d.alp_e = uint8_t(stv[j].e);
+                d.alp_f = uint8_t(stv[j].f);
+                d.patch_len = stv[j].n_exc;
+                d.packed = dbase + L.packed;
+                d.validity = L.valid == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + L.valid);
+                d.patch_idx = L.pidx == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + L.pidx);
+                d.patch_val = L.pval == size_t(-1) ? nullptr : dbase + L.pval;
+            }
+            auto old = ctx->entries.find(it.id);
+            if (old != ctx->entries.end()) {
+                ctx->entry_bytes -= old->second.device_bytes;
+                arena_release(ctx, old->second.slab);
+                ctx->entries.erase(old);
+            }
+            ctx->entry_bytes += e.device_bytes;
+            ctx->entries.emplace(it.id, std::move(e));
+        }
+    }
+    return LC_OK;
+}
 }  // namespace
 
 lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const struct ArrowArray* const* arrays,
@@ -1132,12 +1280,14 @@ lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_
         const struct ArrowSchema* s = schemas[i];
         if (!a || !s) return fail(LC_ERR_INVALID, "null array");
         int phys = int_phys_of_format(s->format);
+        if (phys < 0 && s->format && (std::string(s->format) == "f" || std::string(s->format) == "g"))
+            phys = s->format[0] == 'f' ? kF32 : kF64;
         int dec_p = 0, dec_s = 0, dec_bits = 128;
         const bool is_decimal = s->format && s->format[0] == 'd' && s->format[1] == ':' &&
                                 std::sscanf(s->format, "d:%d,%d,%d", &dec_p, &dec_s, &dec_bits) >= 2 &&
                                 (dec_bits == 128 || dec_bits == 256);
         if ((phys < 0 && !is_decimal) || s->dictionary || a->length > int64_t(UINT32_MAX))
-            return fail(LC_UNSUPPORTED, "the on-device transcoder takes integer / date / timestamp / decimal arrays (use lc_insert_arrow)");
+            return fail(LC_UNSUPPORTED, "the on-device transcoder takes integer / date / timestamp / decimal / float arrays (use lc_insert_arrow)");
         DevEncodeItem& it = items[i];
         it.id = entry_ids[i];
         if (is_decimal) {  // LiquidDecimalArray: u64 offsets of the unscaled values (decimal_array.rs:127-177)
@@ -1152,6 +1302,8 @@ lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_
         it.phys = phys;
         it.vw = phys_width(phys);
         it.is_signed = !phys_unsigned(phys);
+        it.is_float = phys == kF32 || phys == kF64;
+        if (it.is_float) { it.logical = kFloat; it.is_signed = true; }
         it.n = uint32_t(a->length);
         it.has_validity = a->n_buffers >= 1 && a->buffers[0] != nullptr;
         it.in_values = align_up(stage_bytes, 16);
@@ -1193,14 +1345,21 @@ lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_
                 return out;
             }();
             std::memcpy(h + it.in_validity, bm.data(), bitmap_bytes(it.n));
+            items[i].n_valid = uint32_t(count_bits(bm.data(), it.n));
+        } else {
+            items[i].n_valid = it.n;
         }
     }
     LC_HIP(hipMemcpy(d_in, h, stage_bytes, hipMemcpyHostToDevice));
+    std::vector<DevEncodeItem> ints, floats;
     for (DevEncodeItem& it : items) {
         it.d_values = d_in + it.in_values;
         it.d_validity = reinterpret_cast<const uint64_t*>(d_in + it.in_validity);
+        (it.is_float ? floats : ints).push_back(it);
     }
-    return device_encode_and_register(ctx, items);
+    lc_status rc = device_encode_and_register(ctx, ints);
+    if (rc != LC_OK) return rc;
+    return device_encode_floats(ctx, floats);
     });
 }
 

@@ -1174,3 +1174,61 @@ def test_device_transcoder_decimals_byte_identical(gpu_cache):
         with pytest.raises(lc.LiquidCacheError) as ex:
             gpu_cache.insert_device([lc.ParquetArrayID.new(21, 99, 1, 0)], [bad])
         assert ex.value.status == N.LC_UNSUPPORTED
+
+
+def test_device_transcoder_floats_alp_byte_identical(gpu_cache):
+    """Float32 / Float64 arrays through lc_insert_arrow_device: exponent search on the sample, encoding, exceptions
+    (patches), fill of the exception slots and FastLanes packing all on the device — byte-identical to the host transcoder
+    (LiquidFloatArray::from_arrow_array, float_array.rs:590-740), for decimal-looking data, integers, noisy data that is
+    mostly exceptions, NaN / inf / -0.0, nulls, slices, short, empty and all-null arrays."""
+    rng = np.random.default_rng(715)
+    ids, arrays = [], []
+    k = 0
+    for np_t, pa_t in ((np.float32, pa.float32()), (np.float64, pa.float64())):
+        for n in (8192, 5000, 1024, 1025, 2047, 100, 1, 0):
+            gens = {
+                "cents": lambda: np.round(rng.normal(100, 50, size=n), 2),
+                "tenths": lambda: np.round(rng.uniform(-1000, 1000, size=n), 1),
+                "ints": lambda: rng.integers(-50_000, 50_000, size=n).astype(np.float64),
+                "noise": lambda: rng.normal(size=n),
+                "mixed": lambda: np.where(rng.random(n) < 0.1, rng.normal(size=n), np.round(rng.uniform(0, 10, size=n), 3)),
+                "special": lambda: np.where(rng.random(n) < 0.05, rng.choice([np.nan, np.inf, -np.inf, -0.0, 1e300, 1e-300], size=n),
+                                            np.round(rng.uniform(0, 99, size=n), 2)),
+                "const": lambda: np.full(n, 3.25),
+            }
+            for name, g in gens.items():
+                with np.errstate(over="ignore"):
+                    v = g().astype(np_t)
+                mode = int(rng.integers(4))
+                mask = None if mode == 0 else rng.random(n) < (0.2 if mode in (1, 3) else 1.0)
+                arr = pa.array(v, type=pa_t, mask=mask) if mask is not None else pa.array(v, type=pa_t)
+                if mode == 3 and n > 10:
+                    arr = arr.slice(3, n - 7)
+                k += 1
+                ids.append(lc.ParquetArrayID.new(22, k >> 12, 1, k & 0xFFF))
+                arrays.append(arr)
+    gpu_cache.insert_device(ids, arrays)
+    for e, arr in zip(ids, arrays):
+        want = gpu_cache.transcode(arr)
+        got = gpu_cache.entry_bytes(e)
+        assert got == want, (str(arr.type), len(arr), arr.null_count)
+    for kk in rng.choice(len(ids), 40, replace=False):
+        e, arr = ids[int(kk)], arrays[int(kk)]
+        if len(arr) == 0:
+            continue
+        got = gpu_cache.get(e).read()
+        a = np.asarray(arr.to_numpy(zero_copy_only=False), dtype=np.float64)
+        b = np.asarray(got.to_numpy(zero_copy_only=False), dtype=np.float64)
+        assert got.null_count == arr.null_count
+        valid = ~np.asarray(arr.is_null().to_numpy(zero_copy_only=False), dtype=bool)
+        # ALP maps -0.0 to +0.0 (DESIGN.md §4): compare as the host-staged entry decodes
+        assert np.array_equal(a[valid] + 0.0, b[valid] + 0.0, equal_nan=True), (str(arr.type), len(arr))
+    # mixed batch: integers, decimals and floats in one call
+    import decimal
+    mixed = [pa.array(rng.integers(0, 1000, size=3000)), pa.array(np.round(rng.normal(size=3000), 2)),
+             pa.array([decimal.Decimal("1.25"), None, decimal.Decimal("7.00")], type=pa.decimal128(15, 2)),
+             pa.array(np.round(rng.normal(size=100), 1).astype(np.float32))]
+    mids = [lc.ParquetArrayID.new(23, 0, 1, i) for i in range(4)]
+    gpu_cache.insert_device(mids, mixed)
+    for e, arr in zip(mids, mixed):
+        assert gpu_cache.entry_bytes(e) == gpu_cache.transcode(arr), str(arr.type)
