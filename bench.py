@@ -725,6 +725,27 @@ def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal, base):
     return rows_total / dt, rows_total, int(hits), dt, all_cores
 
 
+def cpu_baseline_q6(cache, lc, args, ids, expected, n_sample):
+    """The five Q6 conjuncts chained per batch by the CPU oracle (eval_predicate over the selection of the previous
+    conjunct, boolean_buffer_and_then in between) on the Liquid bytes of the first n_sample batches — the bytes the GPU
+    scanned, read back from HBM.  Single thread; COUNT(*) per batch checked against numpy."""
+    from oracle import liquid_oracle as lo
+    _, d1, d2 = q6_literals()
+    blobs = [(cache.entry_bytes(ids[10][b]), cache.entry_bytes(ids[6][b]), cache.entry_bytes(ids[4][b])) for b in range(n_sample)]
+    rows = 0
+    t0 = time.perf_counter()
+    for b, (l_ship, l_disc, l_qty) in enumerate(blobs):
+        n = lo.array_info(l_ship).len
+        sel = np.ones(n, bool)
+        for liquid, op, lit in ((l_ship, lo.GE, d1), (l_ship, lo.LT, d2), (l_disc, lo.GE, 5), (l_disc, lo.LE, 7), (l_qty, lo.LT, 2400)):
+            sel = lo.and_then(sel, lo.eval_predicate(liquid, op, lit, sel).filter_mask())
+        assert int(sel.sum()) == int(expected[b]), "CPU oracle COUNT(*) of batch %d differs from numpy" % b
+        rows += n
+    dt = time.perf_counter() - t0
+    return {"value": rows / dt, "unit": "rows/s", "cores": 1, "kind": "port", "hits": int(expected[:n_sample].sum()),
+            "sample": "first %d batches (%d rows) of the same three columns, 5 chained conjuncts, %.1f s" % (n_sample, rows, dt)}
+
+
 # ---------------------------------------------------------------------------------------------------------- main
 def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch, dist):
     """BASELINE.json config 4 as a bench workload: the Q6-shaped chain over this rank's contiguous row range of a
@@ -821,6 +842,8 @@ def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch
                      "frac": alg3 / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": chain_ms,
                      "algorithmic_bytes": int(alg3), "effective_gbs_vs_5_pass_bytes": alg5 / (chain_ms * 1e-3) / 1e9},
     }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_q6(cache, lc, args, ids, expected, min(len(expected), args.cpu_batches or 1500))
     print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
