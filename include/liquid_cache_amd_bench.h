@@ -48,6 +48,11 @@ LC_BENCH_API void lc_synth_int64_batch(uint64_t seed, uint64_t batch_index, uint
  * unit is only documented for 16-byte coalesced reads).  `ctx` is an lc_ctx*. */
 LC_BENCH_API int32_t lc_calibrate_read(void* ctx, uint64_t bytes, int32_t shape, int32_t iters);
 
+/* Test aid: copy of the bigram signature slices of a staged byte-view entry (kSigBits x ceil(D/64) u64 words, slice
+ * major), so that the device-built index can be compared with the host-built one (LC_HOST_SIGNATURES=1).  Returns the
+ * number of bytes written (0: the entry carries no index, or `cap` is too small).  `ctx` is an lc_ctx*. */
+LC_BENCH_API size_t lc_debug_entry_signatures(void* ctx, uint64_t entry_id, uint8_t* out, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

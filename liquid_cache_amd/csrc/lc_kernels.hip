@@ -3382,6 +3382,90 @@ hipError_t launch_alp_copy_patches(const void* d_stats, uint32_t n_arrays, int v
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Bigram signature index of freshly staged byte-view entries, built ON THE DEVICE (the host used to decode every dictionary
+// value and set its bits: 0.8 ms of a 2.3 ms insert, and 36 KB of index per entry over PCIe).  One workgroup per entry;
+// a wave takes 64 consecutive dictionary values (= one 64-bit word column of every slice): lane l decodes value
+// 64 c + l through the symbol table and ORs bit l of LDS word [h(a,b)] for every pair of adjacent decoded bytes; the
+// 128 (kSigBits) words are then stored to the entry's slices.  Same bits as the host builder (lc_runtime.cpp build_str).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_str_build_signatures(const StrDesc* __restrict__ descs,
+                                                                   const DevSymtab* __restrict__ symtabs) {
+    static_assert(kSigBits % 64 == 0, "a lane keeps its value's signature in kSigBits / 64 registers");
+    constexpr int kSigWords = kSigBits / 64;
+    __shared__ uint64_t s_sym[256];
+    __shared__ uint8_t s_len[256];
+    const StrDesc d = descs[blockIdx.y];
+    const uint32_t nw = (d.d + 63u) >> 6;
+    // grid.x workgroups share an entry: workgroup x takes word columns 4x .. 4x+3, x + gridDim.x, ... (a single
+    // workgroup per entry made the latency of a one-entry lc_stage call 0.6 ms)
+    if (!d.signatures || d.d == 0 || blockIdx.x * kWavesPerBlock >= nw) return;
+    const DevSymtab& st = symtabs[d.symtab_slot];
+    s_sym[threadIdx.x] = st.sym[threadIdx.x];  // kThreads == 256
+    s_len[threadIdx.x] = st.len[threadIdx.x];
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    uint64_t* sig = const_cast<uint64_t*>(d.signatures);
+    for (uint32_t c = blockIdx.x * kWavesPerBlock + uint32_t(wave); c < nw; c += gridDim.x * kWavesPerBlock) {
+        // the lane's value as a bit set in registers (no atomics: 64 lanes hammering the few words of the common bigrams
+        // of a URL column made an LDS-atomic version 20x slower), transposed to slice words by ballots afterwards
+        uint64_t mine[kSigWords];
+#pragma unroll
+        for (int r = 0; r < kSigWords; r++) mine[r] = 0;
+        const uint32_t i = c * 64u + uint32_t(lane);
+        if (i < d.d) {
+            uint32_t start, stop;
+            str_offset_pair(d, i, start, stop);
+            int prev = -1;
+            bool escaped = false;  // the next compressed byte is the literal of an escape marker
+            // eight compressed bytes per load, the next word requested before the current one is walked
+            uint64_t w = start < stop ? load_unaligned<uint64_t>(d.fsst + start) : 0;
+            for (uint32_t p = start; p < stop; p += 8u) {
+                const uint64_t cur_w = w;
+                if (p + 8u < stop) w = load_unaligned<uint64_t>(d.fsst + p + 8u);
+                const uint32_t nb = min(8u, stop - p);
+                for (uint32_t k = 0; k < nb; k++) {
+                    const uint32_t code = uint32_t(cur_w >> (8u * k)) & 0xFFu;
+                    uint64_t sym;
+                    uint32_t len;
+                    if (escaped) { sym = code; len = 1; escaped = false; }
+                    else if (code == 255u) { escaped = true; continue; }
+                    else { sym = s_sym[code]; len = s_len[code]; }
+                    for (uint32_t q = 0; q < len; q++) {
+                        const int cur = int((sym >> (8u * q)) & 0xFFu);
+                        if (prev >= 0) {
+                            const uint32_t bit = bigram_bit(uint32_t(prev), uint32_t(cur));
+#pragma unroll
+                            for (int r = 0; r < kSigWords; r++)
+                                if (int(bit >> 6) == r) mine[r] |= uint64_t(1) << (bit & 63u);
+                        }
+                        prev = cur;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kSigWords; r++) {
+            uint64_t keep = 0;  // lane b ends up with the word of slice 64 r + b
+            for (int b = 0; b < 64; b++) {
+                const uint64_t wv = __ballot((mine[r] >> b) & 1);
+                if (lane == b) keep = wv;
+            }
+            sig[size_t(64 * r + lane) * nw + c] = keep;
+        }
+    }
+}
+
+hipError_t launch_str_build_signatures(const StrDesc* d_descs, uint32_t n_entries, uint32_t max_dict_len,
+                                       const DevSymtab* d_symtabs, hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    const uint32_t nw = (std::max(max_dict_len, 1u) + 63u) / 64u;
+    // few entries: one workgroup per four word columns; many entries: the entries themselves fill the device
+    const uint32_t per_entry = n_entries >= 1024u ? 1u : std::min<uint32_t>((nw + kWavesPerBlock - 1) / kWavesPerBlock, 64u);
+    hipLaunchKernelGGL(k_str_build_signatures, dim3(per_entry, n_entries), dim3(kThreads), 0, stream, d_descs, d_symtabs);
+    return hipGetLastError();
+}
+
 hipError_t launch_col_minmax(const EncodeDesc* d_descs, uint32_t n_entries, EncodeMinMax* d_out, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
     hipLaunchKernelGGL(k_col_minmax, dim3(n_entries), dim3(256), 0, stream, d_descs, d_out);

@@ -241,6 +241,9 @@ hipError_t launch_mask_or_kleene(uint64_t* d_hit, uint64_t* d_valid, const uint6
 // per-entry popcounts of the mask passed as L.d_selection
 hipError_t launch_mask_entry_counts(const void* d_descs, bool is_str, const ScanLaunch& L, uint32_t* d_entry_counts,
                                     hipStream_t stream);
+// bigram signature slices of freshly staged byte-view entries (descs[i].signatures: zeroed kSigBits x ceil(D/64) words)
+hipError_t launch_str_build_signatures(const StrDesc* d_descs, uint32_t n_entries, uint32_t max_dict_len,
+                                       const DevSymtab* d_symtabs, hipStream_t stream);
 // On-device ALP encoder (floats): exponent search, encode + exceptions, patch placement.  d_stats: one AlpStatsHost per array.
 struct AlpStatsHost {
     uint32_t e, f, n_exc, pad;

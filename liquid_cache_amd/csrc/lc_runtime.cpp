@@ -90,6 +90,7 @@ struct Entry {
     // holds the bucket (value - reference) / bucket_width.  Predicates only; every read needs the backing bytes.
     bool quantized = false;
     uint64_t bucket_width = 0;
+    bool sig_on_device = false;  // staging: the signature slices are still to be built by k_str_build_signatures
 };
 
 }  // namespace
@@ -108,6 +109,7 @@ struct lc_ctx {
     std::unordered_map<uint64_t, uint32_t> symtab_slot;
     std::vector<std::unique_ptr<SymbolTable>> symtabs;
     bool build_signatures = true;  // LC_NO_SIGNATURES=1 disables the bigram index (plain reference layout only)
+    bool signatures_on_host = false;  // LC_HOST_SIGNATURES=1: build the index on the host (the device builder's oracle)
     DevSymtab* d_symtabs = nullptr;
     size_t d_symtabs_cap = 0;
     size_t d_symtabs_uploaded = 0;
@@ -506,8 +508,15 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
     offs[4] = blob->add(v.residuals, size_t(v.residual_count) * size_t(v.offset_bytes), kSectionAlign, 8);
     offs[5] = blob->add(v.fsst, v.fsst_len, kSectionAlign, 16);
     offs[6] = blob->add(v.shared_prefix, v.shared_prefix_len, kSectionAlign, 8);
-    if (v.fingerprints && ctx->build_signatures) {
-        // substring-search columns: bit-sliced 128-bit bigram signatures of the dictionary values (lc_kernels.hpp)
+    if (v.fingerprints && ctx->build_signatures && !ctx->signatures_on_host) {
+        // substring-search columns: room for the bit-sliced bigram signatures (lc_kernels.hpp); k_str_build_signatures
+        // fills it once the blob is in HBM, before the entry becomes visible
+        const size_t nw = (size_t(v.d) + 63) / 64;
+        offs[7] = blob->add(nullptr, 0);
+        blob->bytes.resize(offs[7] + size_t(kSigBits) * std::max<size_t>(nw, 1) * 8, 0);
+        e->sig_on_device = true;
+    } else if (v.fingerprints && ctx->build_signatures) {
+        // LC_HOST_SIGNATURES=1 (tests): the same index built by the host
         const size_t nw = (size_t(v.d) + 63) / 64;
         std::vector<uint64_t> sig(size_t(kSigBits) * std::max<size_t>(nw, 1), 0);
         std::vector<uint8_t> tmp;
@@ -678,6 +687,7 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     LC_HIP(hipGetDeviceProperties(&ctx->props, dev));
     ctx->max_hbm = max_hbm_bytes;
     if (const char* ns = std::getenv("LC_NO_SIGNATURES")) ctx->build_signatures = std::atoi(ns) == 0;
+    if (const char* hs = std::getenv("LC_HOST_SIGNATURES")) ctx->signatures_on_host = std::atoi(hs) != 0;
     *out = ctx.release();
     return LC_OK;
     });
@@ -783,6 +793,10 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
             pend.push_back(std::move(p));
             i++;
         }
+        {
+            const lc_status ss = sync_symtabs(ctx);  // the signature builder reads the device copies
+            if (ss != LC_OK) return ss;
+        }
         std::unique_lock<std::shared_mutex> g(ctx->mu);
         uint8_t* dbase = nullptr;
         int slab = -1;
@@ -792,6 +806,7 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
         if (st != LC_OK) return st;
         ctx->slabs[size_t(slab)].live += int64_t(pend.size()) - 1;
         LC_HIP(hipMemcpy(dbase, blob.bytes.data(), total, hipMemcpyHostToDevice));
+        std::vector<StrDesc> sig_descs;
         for (Pending& p : pend) {
             auto ptr = [&](size_t off) -> uint8_t* { return off == size_t(-1) ? nullptr : dbase + off; };
             p.e.slab = slab;
@@ -805,6 +820,7 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
                 d.fsst = ptr(p.off[5]);
                 d.shared_prefix = ptr(p.off[6]);
                 d.signatures = reinterpret_cast<const uint64_t*>(ptr(p.off[7]));
+                if (p.e.sig_on_device) sig_descs.push_back(d);
             } else {
                 FixedDesc& d = p.e.fd;
                 d.packed = ptr(p.off[0]);
@@ -812,6 +828,25 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
                 d.patch_idx = reinterpret_cast<const uint64_t*>(ptr(p.off[2]));
                 d.patch_val = ptr(p.off[3]);
             }
+        }
+        if (!sig_descs.empty()) {
+            // the signature slices are built before any entry of this chunk becomes visible to evaluations
+            const DevSymtab* d_st;
+            {
+                std::lock_guard<std::mutex> sg(ctx->st_mu);
+                d_st = ctx->d_symtabs;  // uploaded by the sync_symtabs above; retired arrays are never freed
+            }
+            StrDesc* d_sd = static_cast<StrDesc*>(pool_alloc(ctx, sig_descs.size() * sizeof(StrDesc)));
+            if (!d_sd) return fail(LC_ERR_OOM, "hipMalloc (signature builder descriptors)");
+            const hipError_t e1 = hipMemcpy(d_sd, sig_descs.data(), sig_descs.size() * sizeof(StrDesc), hipMemcpyHostToDevice);
+            uint32_t max_d = 1;
+            for (const StrDesc& sd : sig_descs) max_d = std::max(max_d, sd.d);
+            const hipError_t e2 = e1 == hipSuccess ? launch_str_build_signatures(d_sd, uint32_t(sig_descs.size()), max_d, d_st, nullptr) : e1;
+            const hipError_t e3 = hipDeviceSynchronize();
+            pool_release(ctx, d_sd);
+            if (e2 != hipSuccess || e3 != hipSuccess) return fail(LC_ERR_DEVICE, "k_str_build_signatures failed");
+        }
+        for (Pending& p : pend) {
             auto old = ctx->entries.find(p.id);
             if (old != ctx->entries.end()) {
                 ctx->entry_bytes -= old->second.device_bytes;
@@ -1941,6 +1976,24 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
     if (d_final_mask) *d_final_mask = const_cast<void*>(sel);
     return LC_OK;
     });
+}
+
+size_t lc_debug_entry_signatures(void* ctx_, uint64_t entry_id, uint8_t* out, size_t cap) {
+    lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
+    if (!ctx || !out || ctx->device < 0) return 0;
+    const uint64_t* src = nullptr;
+    size_t bytes = 0;
+    {
+        std::shared_lock<std::shared_mutex> g(ctx->mu);
+        auto it = ctx->entries.find(entry_id);
+        if (it == ctx->entries.end() || !it->second.is_str || !it->second.sd.signatures) return 0;
+        src = it->second.sd.signatures;
+        bytes = size_t(kSigBits) * ((size_t(it->second.sd.d) + 63) / 64) * 8;
+    }
+    if (bytes == 0 || bytes > cap) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
+    if (hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return bytes;
 }
 
 int32_t lc_calibrate_read(void* ctx_, uint64_t bytes, int32_t shape, int32_t iters) {

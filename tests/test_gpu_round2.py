@@ -1232,3 +1232,46 @@ def test_device_transcoder_floats_alp_byte_identical(gpu_cache):
     gpu_cache.insert_device(mids, mixed)
     for e, arr in zip(mids, mixed):
         assert gpu_cache.entry_bytes(e) == gpu_cache.transcode(arr), str(arr.type)
+
+
+def test_device_built_signature_index_equals_the_host_built_one(product_lib, oracle, monkeypatch):
+    """k_str_build_signatures (default) against the host builder (LC_HOST_SIGNATURES=1) on the same staged bytes: the
+    slices must be bit-identical — plain URLs, values full of escapes (bytes the table does not know, 0xFF runs), empty
+    values, a shared prefix, dictionaries that are not a multiple of 64."""
+    lo = oracle
+    rng = np.random.default_rng(97)
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _make_strings
+    cases = []
+    urls = _make_strings(rng, 8192, 2200, True)
+    cases.append((urls, None))
+    cases.append((["http://same.prefix.example/" + s for s in _make_strings(rng, 3000, 777, False)], None))
+    train = ["abcabcabc%d" % i for i in range(500)]
+    offs, data, _ = lo.strings_to_arrow(train)
+    st_other = lo.fsst_train(offs, data)
+    weird = [bytes(rng.integers(0, 256, size=int(rng.integers(0, 90)), dtype=np.uint8)) for _ in range(900)]
+    weird += [b"", b"\\xff", b"\\xff\\xff\\xff", b"a", b"ab"]
+    cases.append(([weird[int(k)] for k in rng.integers(0, len(weird), size=5000)], st_other))
+    blobs = []
+    for strs, st in cases:
+        kw = dict(arrow_type=lo.BT_BINARY) if isinstance(strs[0], bytes) or any(isinstance(x, bytes) for x in strs if x is not None) else {}
+        liquid, st2 = lo.encode_byte_view(strs, st=st, fingerprints=True, **kw)
+        blobs.append((liquid, lo.symtab_bytes(st2)))
+    sigs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LC_HOST_SIGNATURES", mode)
+        cache = lc.LiquidCacheBuilder.new().with_device(0).build()
+        got = []
+        for k, (liquid, stb) in enumerate(blobs):
+            cache.set_symbol_table(900 + k, stb)
+            eid = lc.ParquetArrayID.new(70, 0, 1, k)
+            cache.stage([eid], [liquid], [900 + k])
+            d = cache.entry_info(eid).dict_len
+            buf = np.zeros(128 * ((d + 63) // 64) * 8, np.uint8)
+            nb = cache._lib.lc_debug_entry_signatures(cache.handle, int(eid), buf.ctypes.data_as(C.c_void_p), buf.size)
+            assert nb == buf.size and buf.any()
+            got.append(buf)
+        sigs[mode] = got
+        cache.close()
+    for a, b in zip(sigs["0"], sigs["1"]):
+        assert np.array_equal(a, b)
