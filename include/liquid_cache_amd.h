@@ -194,8 +194,11 @@ LC_API lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct Ar
  * does not fit a u64 (the reference's fits_u64, decimal_array.rs:120-125): use lc_insert_arrow. */
 LC_API lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids,
                                         const struct ArrowArray* const* arrays, const struct ArrowSchema* const* schemas);
-/* LiquidArray::to_bytes() of a staged fixed-width entry, rebuilt from HBM (malloc'ed; release with lc_free): what the
- * reference writes to its disk tier when an entry is squeezed or evicted (core.rs:246, :314). */
+/* LiquidArray::to_bytes() of a staged entry, rebuilt from HBM (malloc'ed; release with lc_free): what the reference
+ * writes to its disk tier when an entry is squeezed or evicted (core.rs:246, :314).  Fixed-width entries
+ * (primitive_array.rs:603-679, decimal_array.rs:197-220, float_array.rs:397-519) and byte views
+ * (byte_view_array/serialization.rs:122-220: keys at 16 bits, raw FSST buffer, compact offsets, prefix keys, shared
+ * prefix, fingerprints).  LC_NEEDS_BACKING for squeezed entries (they no longer hold the full array). */
 LC_API lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out_bytes, size_t* out_len);
 LC_API void lc_free(void* p);
 /* Export the registered symbol table of `path_id` in save_symbol_table format (malloc'ed). */

@@ -91,6 +91,7 @@ struct Entry {
     bool quantized = false;
     uint64_t bucket_width = 0;
     bool sig_on_device = false;  // staging: the signature slices are still to be built by k_str_build_signatures
+    uint64_t raw_bytes = 0;      // byte views: uncompressed size of the dictionary (RawFsstBuffer header)
 };
 
 }  // namespace
@@ -482,6 +483,7 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
     e->has_fp = v.fingerprints != nullptr;
     e->offsets_bytes = v.residual_count * uint32_t(v.offset_bytes);
     e->fsst_len = v.fsst_len;
+    e->raw_bytes = v.uncompressed_bytes;
     StrDesc& d = e->sd;
     d = StrDesc{};
     d.n = v.n;
@@ -1413,7 +1415,64 @@ lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out
         if (it == ctx->entries.end()) return LC_NOT_STAGED;
         e = it->second;
     }
-    if (e.is_str) return fail(LC_UNSUPPORTED, "byte-view entries are re-serialised by the host (their bytes are what was staged)");
+    if (e.is_str) {
+        // LiquidByteViewArray::to_bytes (byte_view_array/serialization.rs:122-220): header, raw FSST buffer, keys as a
+        // BitPackedArray<u16> at 16 bits, compact offsets, prefix keys, shared prefix, fingerprints — read back from HBM
+        const StrDesc& d = e.sd;
+        auto fetch = [&](const void* src, size_t n, std::vector<uint8_t>& dst) -> bool {
+            dst.assign(n, 0);
+            return n == 0 || hipMemcpy(dst.data(), src, n, hipMemcpyDeviceToHost) == hipSuccess;
+        };
+        std::vector<uint8_t> keys_b, valid_b, pk_b, fp_b, res_b, fsst_b, sp_b;
+        if (!fetch(d.keys, size_t(d.n) * 2, keys_b) || !fetch(d.prefix_keys, size_t(d.d) * 8, pk_b) ||
+            !fetch(d.residuals, e.offsets_bytes, res_b) || !fetch(d.fsst, d.fsst_len, fsst_b) ||
+            !fetch(d.shared_prefix, d.shared_prefix_len, sp_b) ||
+            !fetch(d.validity, d.validity ? ((size_t(d.n) + 63) / 64) * 8 : 0, valid_b) ||
+            !fetch(d.fingerprints, d.fingerprints ? size_t(d.d) * 4 : 0, fp_b))
+            return fail(LC_ERR_DEVICE, "hipMemcpy (entry sections)");
+        std::vector<uint8_t> out(40, 0);
+        auto pad8 = [&]() { while (out.size() & 7) out.push_back(0); };
+        const size_t fsst_start = out.size();
+        out.resize(fsst_start + 12 + fsst_b.size());
+        wr<uint64_t>(out.data() + fsst_start, e.raw_bytes);
+        wr<uint32_t>(out.data() + fsst_start + 8, d.fsst_len);
+        if (!fsst_b.empty()) std::memcpy(out.data() + fsst_start + 12, fsst_b.data(), fsst_b.size());
+        const uint32_t fsst_raw_size = uint32_t(out.size() - fsst_start);
+        pad8();
+        const size_t keys_start = out.size();
+        // the reference always writes the keys at 16 bits (serialization.rs:141-150), all-null arrays included
+        append_bitpacked<uint16_t>(out, 16, reinterpret_cast<const uint16_t*>(keys_b.data()),
+                                   d.validity ? valid_b.data() : nullptr, d.n);
+        const uint32_t keys_size = uint32_t(out.size() - keys_start);
+        pad8();
+        const size_t co_start = out.size();
+        if (e.offsets_bytes) {
+            out.resize(co_start + 9 + res_b.size());
+            wr<int32_t>(out.data() + co_start, d.slope);
+            wr<int32_t>(out.data() + co_start + 4, d.intercept);
+            out[co_start + 8] = d.offset_bytes;
+            std::memcpy(out.data() + co_start + 9, res_b.data(), res_b.size());
+        }
+        const uint32_t co_size = uint32_t(out.size() - co_start);
+        pad8();
+        out.insert(out.end(), pk_b.begin(), pk_b.end());
+        pad8();
+        out.insert(out.end(), sp_b.begin(), sp_b.end());
+        pad8();
+        out.insert(out.end(), fp_b.begin(), fp_b.end());
+        write_ipc_header(out.data(), kByteView, e.phys);
+        wr<uint32_t>(out.data() + 16, keys_size);
+        wr<uint32_t>(out.data() + 20, co_size);
+        wr<uint32_t>(out.data() + 24, d.shared_prefix_len);
+        wr<uint32_t>(out.data() + 28, fsst_raw_size);
+        wr<uint32_t>(out.data() + 32, uint32_t(fp_b.size()));
+        uint8_t* buf = static_cast<uint8_t*>(std::malloc(std::max<size_t>(out.size(), 1)));
+        if (!buf) return fail(LC_ERR_OOM, "malloc");
+        std::memcpy(buf, out.data(), out.size());
+        *out_bytes = buf;
+        *out_len = out.size();
+        return LC_OK;
+    }
     if (e.squeezed_field >= 0) return fail(LC_NEEDS_BACKING, "a squeezed entry holds one date component only");
     if (e.clamped) return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry holds half of its bits");
     if (e.quantized) return fail(LC_NEEDS_BACKING, "a quantize-squeezed entry holds bucket indices only");

@@ -1275,3 +1275,44 @@ def test_device_built_signature_index_equals_the_host_built_one(product_lib, ora
         cache.close()
     for a, b in zip(sigs["0"], sigs["1"]):
         assert np.array_equal(a, b)
+
+
+def test_byte_view_entry_bytes_are_the_staged_bytes(gpu_cache, oracle):
+    """LiquidByteViewArray::to_bytes() rebuilt from HBM (lc_entry_to_liquid_bytes): for entries staged from the host
+    transcoder's output and from the oracle's encoder the re-serialised bytes are the staged bytes — strings and
+    binary, nulls, fingerprints on and off, a shared prefix, empty strings, one row, all-null and empty arrays; and the
+    bytes stage again (evict -> stage -> same reads): what the disk tier of the reference does with a string column."""
+    lo = oracle
+    rng = np.random.default_rng(220)
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _make_strings
+    hint = lc.CacheExpression.SUBSTRING_SEARCH
+    cases = [
+        (pa.array(_make_strings(rng, 8192, 2000, True)), hint),
+        (pa.array(_make_strings(rng, 5000, 700, False)), None),
+        (pa.array([None if s is None else "http://shared/prefix/" + s for s in _make_strings(rng, 3000, 500, True)]), hint),
+        (pa.array(["", "", "a", None, ""]), None),
+        (pa.array(["only"]), hint),
+        (pa.array([None, None, None], type=pa.string()), None),
+        (pa.array([], type=pa.string()), None),
+        (pa.array([bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8)) for _ in range(2000)], type=pa.binary()), None),
+        (pa.array(_make_strings(rng, 4000, 900, True), type=pa.string_view()), hint),
+    ]
+    for k, (arr, h) in enumerate(cases):
+        eid = lc.ParquetArrayID.new(80, 0, 1 + k, 0)   # a column (= symbol table path) per case
+        gpu_cache.insert(eid, arr, h)
+        want = gpu_cache.transcode(arr, h, path_id=lc.ParquetArrayID.column_access_path(eid))
+        got = gpu_cache.entry_bytes(eid)
+        assert got == want, (k, str(arr.type), len(arr))
+        if len(arr):
+            before = gpu_cache.get(eid).read()
+            gpu_cache.evict([eid])
+            gpu_cache.stage([eid], [got], data_types=[arr.type])
+            assert gpu_cache.get(eid).read().equals(before) and gpu_cache.entry_bytes(eid) == got
+    # entries staged from the oracle's encoder (the reference's own layout writer restated)
+    strs = _make_strings(rng, 6000, 1500, True)
+    liquid, st = lo.encode_byte_view(strs, fingerprints=True)
+    eid = lc.ParquetArrayID.new(81, 0, 1, 0)
+    gpu_cache.set_symbol_table(8181, lo.symtab_bytes(st))
+    gpu_cache.stage([eid], [liquid], [8181])
+    assert gpu_cache.entry_bytes(eid) == liquid
