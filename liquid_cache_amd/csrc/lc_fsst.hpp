@@ -78,6 +78,24 @@ public:
     // out must have room for 2*len bytes (all bytes escaped).
     size_t compress(const uint8_t* in, size_t len, uint8_t* out) const {
         size_t o = 0, pos = 0;
+        // eight or more bytes left: one unconditional 8-byte load per position, the matcher inlined (same decisions as
+        // match(): longest symbol of >= 3 bytes first, then the 2- / 1-byte table)
+        while (pos + 8 <= len) {
+            uint64_t w;
+            std::memcpy(&w, in + pos, 8);
+            const uint32_t h = hash3(uint32_t(w) & 0xFFFFFF);
+            int code = -1, l = 0;
+            for (uint32_t i = bucket_[h], e = bucket_[h + 1]; i < e; i++) {
+                const Long& s = longs_[i];
+                if (((w ^ s.sym) & s.mask) == 0) { code = s.code; l = s.len; break; }
+            }
+            if (code < 0) {
+                const uint16_t e2 = short2_[uint16_t(w)];
+                if (e2 != kNone) { code = e2 & 0xFF; l = e2 >> 8; }
+            }
+            if (code >= 0) { out[o++] = uint8_t(code); pos += size_t(l); }
+            else { out[o++] = kFsstEscape; out[o++] = in[pos++]; }
+        }
         while (pos < len) {
             int l;
             const int c = match(in + pos, len - pos, &l);
