@@ -408,6 +408,12 @@ def q6_expected_qty_sum(sh, di, qt):
     return int(qt[(sh >= d1) & (sh < d2) & (di >= 5) & (di <= 7) & (qt < 2400)].sum())
 
 
+def q6_expected_qty_disc_product(sh, di, qt):
+    _, d1, d2 = q6_literals()
+    m = (sh >= d1) & (sh < d2) & (di >= 5) & (di <= 7) & (qt < 2400)
+    return int((qt[m].astype(np.int64) * di[m].astype(np.int64)).sum())
+
+
 def stage_q6_columns(cache, lc, N, args, rows, threads, batch0=0):
     """l_shipdate (Date32), l_discount and l_quantity (Decimal128(15,2)) for `rows` rows starting at global batch
     `batch0` (the synthetic generator is keyed by the GLOBAL batch index, so a shard holds the same bytes whatever the
@@ -420,6 +426,7 @@ def stage_q6_columns(cache, lc, N, args, rows, threads, batch0=0):
                for b in range(n_batches)] for c in (10, 6, 4)}
     expected = np.zeros(n_batches, np.int64)
     expected_qty = np.zeros(n_batches, np.int64)
+    expected_qd = np.zeros(n_batches, np.int64)
 
     def stage(chunk):
         bufs = [np.zeros(bs, np.int64) for _ in range(3)]
@@ -428,6 +435,7 @@ def stage_q6_columns(cache, lc, N, args, rows, threads, batch0=0):
             sh, di, qt = q6_synth_batch(L, args.seed, b + batch0, n, bufs)
             expected[b] = q6_expected_count(sh, di, qt)
             expected_qty[b] = q6_expected_qty_sum(sh, di, qt)
+            expected_qd[b] = q6_expected_qty_disc_product(sh, di, qt)
             cache.insert(ids[10][b], pa.array(sh.astype(np.int32), type=pa.date32()))
             cache.insert(ids[6][b], _dec_array(pa, di))
             cache.insert(ids[4][b], _dec_array(pa, qt))
@@ -435,6 +443,7 @@ def stage_q6_columns(cache, lc, N, args, rows, threads, batch0=0):
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(stage, range(threads)))
     stage_q6_columns.last_expected_qty_sum = int(expected_qty.sum())
+    stage_q6_columns.last_expected_qty_disc = int(expected_qd.sum())
     return ids, expected
 
 
@@ -519,6 +528,21 @@ def secondary_tpch_q6(cache, lc, N, args, rows, threads, torch, stream, iters):
     torch.cuda.synchronize()
     res["aggregate_sum_min_max_quantity"] = {"ms": e0.elapsed_time(e1) / iters, "selected_rows": a[0],
                                              "sum_unscaled": a[1], "matches_numpy": True}
+    # Q6's aggregate is a SUM over a product of two decimal columns (sum(l_extendedprice * l_discount)); with the columns
+    # staged here: SUM(l_quantity * l_discount) under the mask, exact, on the device (lc_scan_sum_product)
+    s_qty.sum_product(s_disc, agg_out.data_ptr(), final_mask.data_ptr(), stream)
+    torch.cuda.synchronize()
+    a = [int(x) for x in agg_out.cpu().numpy().astype(np.int64)]
+    assert a[0] == int(expected.sum()) and a[1] == stage_q6_columns.last_expected_qty_disc and a[2] == 0, \
+        "device SUM(l_quantity * l_discount) under the Q6 mask differs from numpy"
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        s_qty.sum_product(s_disc, agg_out.data_ptr(), final_mask.data_ptr(), stream)
+    e1.record()
+    torch.cuda.synchronize()
+    res["aggregate_sum_quantity_times_discount"] = {"ms": e0.elapsed_time(e1) / iters, "selected_rows": a[0],
+                                                    "sum_unscaled": a[1], "matches_numpy": True}
     # the chain is worth the 5-pass algorithmic bytes to the query whichever way it is run
     alg5 = res["chained_5_passes"]["algorithmic_bytes"]
     res["fused_3_passes"]["effective_gbs_vs_5_pass_bytes"] = alg5 / (res["fused_3_passes"]["ms"] * 1e-3) / 1e9

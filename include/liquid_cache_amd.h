@@ -291,6 +291,12 @@ typedef struct {
 } lc_aggregate;
 LC_API lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_out /* lc_aggregate */,
                                    void* stream);
+/* SUM(a * b) — TPC-H Q6's sum(l_extendedprice * l_discount) — over the rows that d_selection selects and that are valid
+ * in BOTH columns: two scans over the same row ranges with the same lane width (two decimal columns, two Int64 columns,
+ * ...).  count and the exact product sum (two's-complement i128, valid while the true sum stays below 2^127) are
+ * written to *d_out; min / max are 0.  Decimals multiply as their unscaled integers: the result has scale sa + sb. */
+LC_API lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, const void* d_selection,
+                                     void* d_out /* lc_aggregate */, void* stream);
 
 /* Squeeze Date32 / Timestamp entries to ONE calendar component (LiquidPrimitiveArray::squeeze with the hint
  * CacheExpression::extract_date32(field), primitive_array.rs:389-420 -> SqueezedDate32Array, squeezed_date32_array.rs:

@@ -69,7 +69,7 @@ EXPORTED_SYMBOLS = [
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
-    "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold", "lc_scan_eval_or", "lc_eval_predicate_or", "lc_insert_arrow_device", "lc_entry_to_liquid_bytes", "lc_squeeze_date", "lc_squeeze_clamp", "lc_squeeze_quantize", "lc_scan_aggregate", "lc_scan_eval_filter",
+    "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold", "lc_scan_eval_or", "lc_eval_predicate_or", "lc_insert_arrow_device", "lc_entry_to_liquid_bytes", "lc_squeeze_date", "lc_squeeze_clamp", "lc_squeeze_quantize", "lc_scan_aggregate", "lc_scan_sum_product", "lc_scan_eval_filter",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
     # include/liquid_cache_amd_bench.h
@@ -107,6 +107,7 @@ def load():
     L.lc_entry_to_liquid_bytes.restype = i32; L.lc_entry_to_liquid_bytes.argtypes = [vp, u64, P(vp), P(sz)]
     L.lc_squeeze_clamp.restype = i32; L.lc_squeeze_clamp.argtypes = [vp, u64, P(u64), P(u64)]
     L.lc_scan_eval_filter.restype = i32; L.lc_scan_eval_filter.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, P(vp), vp]
+    L.lc_scan_sum_product.restype = i32; L.lc_scan_sum_product.argtypes = [vp, vp, vp, vp, vp, vp]
     L.lc_scan_aggregate.restype = i32; L.lc_scan_aggregate.argtypes = [vp, vp, vp, vp, vp]
     L.lc_squeeze_quantize.restype = i32; L.lc_squeeze_quantize.argtypes = [vp, u64, P(u64), P(u64)]
     L.lc_squeeze_date.restype = i32; L.lc_squeeze_date.argtypes = [vp, u64, P(u64), i32]

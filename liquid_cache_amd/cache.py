@@ -606,6 +606,27 @@ class Scan:
         N.check(self._lib.lc_scan_aggregate(self._cache.handle, self._h, C.c_void_p(selection_ptr or None),
                                             C.c_void_p(out_ptr), C.c_void_p(stream or None)), self._cache.handle)
 
+    def sum_product(self, other: "Scan", out_ptr: int, selection_ptr: int = 0, stream: int = 0):
+        """SUM(self * other) over the selected rows valid in both columns (lc_scan_sum_product): {count, sum lo, sum hi,
+        0, 0, 0} as six u64 at `out_ptr`.  Asynchronous."""
+        N.check(self._lib.lc_scan_sum_product(self._cache.handle, self._h, other._h, C.c_void_p(selection_ptr or None),
+                                              C.c_void_p(out_ptr), C.c_void_p(stream or None)), self._cache.handle)
+
+    def sum_product_to_host(self, other: "Scan", selection_ptr: int = 0) -> dict:
+        lib, ctx = self._lib, self._cache.handle
+        buf = C.c_void_p()
+        N.check(lib.lc_device_alloc(ctx, 48, C.byref(buf)), ctx)
+        try:
+            self.sum_product(other, buf.value, selection_ptr)
+            host = (C.c_uint64 * 6)()
+            N.check(lib.lc_device_to_host(ctx, C.cast(host, C.c_void_p), buf, 48, None), ctx)
+        finally:
+            lib.lc_device_free(ctx, buf)
+        total = (int(host[2]) << 64) | int(host[1])
+        if total >= 1 << 127:
+            total -= 1 << 128
+        return {"count": int(host[0]), "sum": total}
+
     def aggregate_to_host(self, selection_ptr: int = 0, signed: bool = True) -> dict:
         """Convenience: run `aggregate` and return {count, sum, min, max} as Python ints (None when count == 0)."""
         lib, ctx = self._lib, self._cache.handle

@@ -3928,9 +3928,113 @@ __global__ __launch_bounds__(1024) void k_agg_finalize(const AggPartial* __restr
     }
 }
 
+// SUM(a * b) over the rows that are selected and valid in BOTH columns (TPC-H Q6: sum(l_extendedprice * l_discount)):
+// two scans over the same row ranges with the same lane type.  value = reference + offset on both sides, so per entry
+//   sum = n ra rb + ra sum(ub) + rb sum(ua) + sum(ua ub)
+// with the three sums accumulated per lane in 128 bits (exact while the true sum stays below 2^127).  The packed words
+// of the selected rows are fetched straight from HBM (the masks that reach an aggregate are selective).
+template <typename U>
+__global__ __launch_bounds__(kThreads) void k_fixed_sum_product(const FixedDesc* __restrict__ descs_a,
+                                                                 const FixedDesc* __restrict__ descs_b, ScanLaunch L,
+                                                                 AggPartial* __restrict__ partials) {
+    constexpr uint32_t TB = LaneTraits<U>::kBits;
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    uint64_t w_cnt = 0;
+    __int128 w_sum = 0;
+    auto wave_sum_u128 = [](unsigned __int128 v) -> unsigned __int128 {
+        const uint64_t lo = uint64_t(v), hi = uint64_t(v >> 64);
+        const uint64_t l0 = wave_sum_u64(lo & 0xFFFFFFFFu), l1 = wave_sum_u64(lo >> 32);
+        const uint64_t l2 = wave_sum_u64(hi & 0xFFFFFFFFu), l3 = wave_sum_u64(hi >> 32);
+        return (unsigned __int128)l0 + ((unsigned __int128)l1 << 32) + ((unsigned __int128)l2 << 64) + ((unsigned __int128)l3 << 96);
+    };
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave); entry < L.n_entries; entry += total_waves) {
+        const FixedDesc a = descs_a[entry], b = descs_b[entry];
+        const uint32_t Wa = a.W, Wb = b.W;
+        if (Wa == 0 || Wb == 0) continue;  // W == 0 <=> the entry is all null (a constant column packs at 1 bit)
+        const U mask_a = (Wa >= TB) ? U(~U(0)) : U((U(1) << (Wa & (TB - 1))) - 1);
+        const U mask_b = (Wb >= TB) ? U(~U(0)) : U((U(1) << (Wb & (TB - 1))) - 1);
+        uint64_t cnt = 0;
+        unsigned __int128 sa = 0, sb = 0, sab = 0;  // per lane
+        const uint32_t nwords = (a.len + 63u) >> 6;
+        for (uint32_t wb = 0; wb < nwords; wb += kWave) {
+            const uint32_t w = wb + uint32_t(lane);
+            uint64_t act = 0;
+            if (w < nwords) {
+                act = L.d_selection ? L.d_selection[a.mask_word_off + w] : ~uint64_t(0);
+                if (a.validity) act &= a.validity[w];
+                if (b.validity) act &= b.validity[w];
+                if (w == nwords - 1 && (a.len & 63u)) act &= (uint64_t(1) << (a.len & 63u)) - 1;
+            }
+            uint64_t busy = __ballot(act != 0);
+            while (busy) {
+                const int src = __ffsll((long long)busy) - 1;
+                busy &= busy - 1;
+                const uint32_t alo = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act)), src));
+                const uint32_t ahi = uint32_t(__builtin_amdgcn_readlane(int(uint32_t(act >> 32)), src));
+                const uint64_t aw = uint64_t(alo) | (uint64_t(ahi) << 32);
+                if ((aw >> lane) & 1) {
+                    const uint32_t r = (wb + uint32_t(src)) * 64u + uint32_t(lane);  // row within the entry
+                    uint32_t row, fl;
+                    fl_row_lane<U>(r & 1023u, &row, &fl);
+                    const uint64_t ua = uint64_t(extract_packed<U>(a.packed + uint64_t(r >> 10) * 128u * Wa, row, fl, Wa, mask_a));
+                    const uint64_t ub = uint64_t(extract_packed<U>(b.packed + uint64_t(r >> 10) * 128u * Wb, row, fl, Wb, mask_b));
+                    cnt++;
+                    sa += ua;
+                    sb += ub;
+                    sab += (unsigned __int128)ua * ub;
+                }
+            }
+        }
+        const uint64_t c = wave_sum_u64(cnt);
+        const unsigned __int128 ta = wave_sum_u128(sa), tb = wave_sum_u128(sb), tab = wave_sum_u128(sab);
+        if (lane == 0 && c != 0) {
+            const __int128 ra = a.is_signed ? (__int128)int64_t(a.reference) : (__int128)a.reference;
+            const __int128 rb = b.is_signed ? (__int128)int64_t(b.reference) : (__int128)b.reference;
+            w_cnt += c;
+            w_sum += ra * rb * (__int128)c + ra * (__int128)tb + rb * (__int128)ta + (__int128)tab;
+        }
+    }
+    __shared__ uint64_t sh_cnt[kWavesPerBlock];
+    __shared__ __int128 sh_sum[kWavesPerBlock];
+    if (lane == 0) { sh_cnt[wave] = w_cnt; sh_sum[wave] = w_sum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kWavesPerBlock; w++) { w_cnt += sh_cnt[w]; w_sum += sh_sum[w]; }
+        AggPartial p;
+        p.count = w_cnt;
+        p.sum_lo = uint64_t((unsigned __int128)w_sum);
+        p.sum_hi = uint64_t((unsigned __int128)w_sum >> 64);
+        p.min_u = 0;
+        p.max_u = 0;
+        p.pad = 0;
+        partials[blockIdx.x] = p;
+    }
+}
+
+hipError_t launch_fixed_sum_product(const FixedDesc* d_descs_a, const FixedDesc* d_descs_b, int lane_log2, const ScanLaunch& L,
+                                    void* d_partials, uint64_t* d_out, hipStream_t stream);
+
 uint32_t fixed_agg_workgroups(uint32_t n_entries, int lane_log2) {
     const uint64_t wgs_needed = (uint64_t(n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
     return uint32_t(std::min<uint64_t>(std::max<uint64_t>(wgs_needed, 1), uint64_t(device_cus()) * (lane_log2 == 6 ? 4 : 8)));
+}
+
+hipError_t launch_fixed_sum_product(const FixedDesc* d_descs_a, const FixedDesc* d_descs_b, int lane_log2, const ScanLaunch& L,
+                                    void* d_partials, uint64_t* d_out, hipStream_t stream) {
+    if (L.n_entries == 0) return hipMemsetAsync(d_out, 0, 48, stream);
+    const dim3 block(kThreads);
+    const dim3 grid(fixed_agg_workgroups(L.n_entries, lane_log2));
+    AggPartial* p = static_cast<AggPartial*>(d_partials);
+    switch (lane_log2) {
+        case 3: hipLaunchKernelGGL(k_fixed_sum_product<uint8_t>, grid, block, 0, stream, d_descs_a, d_descs_b, L, p); break;
+        case 4: hipLaunchKernelGGL(k_fixed_sum_product<uint16_t>, grid, block, 0, stream, d_descs_a, d_descs_b, L, p); break;
+        case 5: hipLaunchKernelGGL(k_fixed_sum_product<uint32_t>, grid, block, 0, stream, d_descs_a, d_descs_b, L, p); break;
+        case 6: hipLaunchKernelGGL(k_fixed_sum_product<uint64_t>, grid, block, 0, stream, d_descs_a, d_descs_b, L, p); break;
+        default: return hipErrorInvalidValue;
+    }
+    hipLaunchKernelGGL(k_agg_finalize, dim3(1), dim3(1024), 0, stream, p, grid.x, 1, d_out);
+    return hipGetLastError();
 }
 
 hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, int is_signed, const ScanLaunch& L, void* d_partials,

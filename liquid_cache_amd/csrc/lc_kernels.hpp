@@ -229,6 +229,9 @@ inline size_t fixed_gather_offsets_len(size_t n_blocks) { return n_blocks + 1 + 
 // (fixed_agg_workgroups); d_out: six u64 {count, sum lo, sum hi (two's complement i128), min, max, 0}
 constexpr size_t kAggPartialBytes = 48;
 uint32_t fixed_agg_workgroups(uint32_t n_entries, int lane_log2);
+// SUM(a * b) over rows selected and valid in both columns (same lane type); d_out as launch_fixed_agg (min / max are 0)
+hipError_t launch_fixed_sum_product(const FixedDesc* d_descs_a, const FixedDesc* d_descs_b, int lane_log2, const ScanLaunch& L,
+                                    void* d_partials, uint64_t* d_out, hipStream_t stream);
 hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, int is_signed, const ScanLaunch& L, void* d_partials,
                             uint64_t* d_out, hipStream_t stream);
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,

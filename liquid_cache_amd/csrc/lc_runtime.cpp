@@ -1933,6 +1933,45 @@ lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection,
     });
 }
 
+lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, const void* d_selection, void* d_out,
+                              void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !scan_a || !scan_b || !d_out) return fail(LC_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (scan_a->ctx != scan_b->ctx || scan_a->seg_offsets != scan_b->seg_offsets)
+        return fail(LC_ERR_INVALID, "the two scans must cover the same row ranges (same entry lengths)");
+    if (scan_a->n == 0) {
+        LC_HIP(hipMemsetAsync(d_out, 0, sizeof(lc_aggregate), st));
+        return LC_OK;
+    }
+    if (scan_a->is_str || scan_b->is_str || scan_a->any_float || scan_b->any_float)
+        return fail(LC_UNSUPPORTED, "aggregates apply to integer, date, timestamp and decimal columns");
+    if (scan_a->lane_log2 != scan_b->lane_log2)
+        return fail(LC_UNSUPPORTED, "SUM(a * b) takes two columns of the same lane width");
+    lc_scan* both[2] = {scan_a, scan_b};
+    for (lc_scan* s : both) {
+        std::lock_guard<std::mutex> g(s->mu);
+        if (s->has_clamped) {
+            const lc_status cs = clamp_unresolved_entries(ctx, s, nullptr, 0, d_selection, st, &s->needs_backing);
+            if (cs != LC_OK) return cs;
+            if (!s->needs_backing.empty()) return fail(LC_NEEDS_BACKING, "a selected row of a squeezed entry has no value in HBM");
+        }
+    }
+    std::lock_guard<std::mutex> g(scan_a->mu);
+    if (!scan_a->d_agg_partials) {
+        scan_a->d_agg_partials = pool_alloc(ctx, size_t(fixed_agg_workgroups(scan_a->n, scan_a->lane_log2)) * kAggPartialBytes);
+        if (!scan_a->d_agg_partials) return fail(LC_ERR_OOM, "hipMalloc (aggregate partials)");
+    }
+    ScanLaunch L{};
+    L.n_entries = scan_a->n;
+    L.blocks_per_entry = scan_a->bpe;
+    L.d_selection = static_cast<const uint64_t*>(d_selection);
+    LC_HIP(launch_fixed_sum_product(static_cast<const FixedDesc*>(scan_a->d_descs), static_cast<const FixedDesc*>(scan_b->d_descs),
+                                    scan_a->lane_log2, L, scan_a->d_agg_partials, static_cast<uint64_t*>(d_out), st));
+    return LC_OK;
+    });
+}
+
 // Multi-column OR (CachedRowGroup::evaluate_selection_with_predicate, src/datafusion/src/cache/mod.rs:111-150): every
 // (column scan, predicate) pair is evaluated over the SAME selection and the results are combined with Kleene OR.
 static lc_status scan_eval_or_impl(lc_ctx* ctx, uint32_t n, lc_scan* const* scans, const lc_predicate* preds,
