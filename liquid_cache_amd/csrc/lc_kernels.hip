@@ -852,6 +852,36 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_dispatch(std::integer_seque
 
 // kMaxW: widest entry the instantiation handles (16 or 32).  The register allocation of a kernel is the maximum over the
 // per-width functions it can call, so scans of narrow columns get the instantiation with the smaller footprint.
+// one entry of one column: the predicate range of the entry, then the per-width function; returns the lane's hit count
+template <typename U, int kMaxW>
+__device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2,
+                                                          const uint64_t* selection, uint64_t* hit, uint64_t* valid_out,
+                                                          int lane) {
+    const PackedRange<U> pr = entry_range<U>(d, pred, pred2, lane);
+    const uint32_t W = max(uint32_t(d.W), 1u);
+    const uint32_t umax = W >= 32 ? ~0u : ((1u << W) - 1u);
+    const uint32_t lo = uint32_t(pr.lo), span = uint32_t(pr.span);
+    RegEntryArgs a;
+    a.packed = d.packed;
+    a.validity = d.validity;
+    a.selection = selection;
+    a.hit = hit;
+    a.valid_out = valid_out;
+    a.len = d.len;
+    a.constant = d.W == 0 ? 0 : pr.constant;
+    a.all_null = d.W == 0 ? 1u : 0u;
+    bool two_sided = false;
+    if (lo == 0) {                    // u <= span
+        a.lo = 0; a.bound = span; a.flip = pr.negate ? 1u : 0u;
+    } else if (lo + span == umax) {   // u >= lo  ==  not (u <= lo - 1)
+        a.lo = 0; a.bound = lo - 1u; a.flip = pr.negate ? 0u : 1u;
+    } else {
+        two_sided = true;
+        a.lo = lo; a.bound = span; a.flip = pr.negate ? 1u : 0u;
+    }
+    return fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, W, two_sided, a);
+}
+
 template <typename U, int kMaxW>
 __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __restrict__ descs, FixedPred pred,
                                                               FixedPred pred2, ScanLaunch L) {
@@ -861,34 +891,58 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __
     uint64_t wave_hits = 0;
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
         const FixedDesc d = descs[entry];
-        const PackedRange<U> pr = entry_range<U>(d, pred, pred2, lane);
-        const uint32_t W = max(uint32_t(d.W), 1u);
-        const uint32_t umax = W >= 32 ? ~0u : ((1u << W) - 1u);
-        const uint32_t lo = uint32_t(pr.lo), span = uint32_t(pr.span);
-        RegEntryArgs a;
-        a.packed = d.packed;
-        a.validity = d.validity;
-        a.selection = L.d_selection ? L.d_selection + d.mask_word_off : nullptr;
-        a.hit = L.d_hit + d.mask_word_off;
-        a.valid_out = L.d_valid ? L.d_valid + d.mask_word_off : nullptr;
-        a.len = d.len;
-        a.constant = d.W == 0 ? 0 : pr.constant;
-        a.all_null = d.W == 0 ? 1u : 0u;
-        bool two_sided = false;
-        if (lo == 0) {                    // u <= span
-            a.lo = 0; a.bound = span; a.flip = pr.negate ? 1u : 0u;
-        } else if (lo + span == umax) {   // u >= lo  ==  not (u <= lo - 1)
-            a.lo = 0; a.bound = lo - 1u; a.flip = pr.negate ? 0u : 1u;
-        } else {
-            two_sided = true;
-            a.lo = lo; a.bound = span; a.flip = pr.negate ? 1u : 0u;
-        }
-        const uint32_t c = fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, W, two_sided, a);
+        const uint32_t c = fixed_pred_entry_step<U, kMaxW>(d, pred, pred2,
+                                                           L.d_selection ? L.d_selection + d.mask_word_off : nullptr,
+                                                           L.d_hit + d.mask_word_off,
+                                                           L.d_valid ? L.d_valid + d.mask_word_off : nullptr, lane);
         if (L.d_counts || L.d_total_out) {
             const uint64_t t = wave_sum_u64(uint64_t(c));
             if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(t);
             wave_hits += t;
         }
+    }
+    if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, total_waves, wave_hits);
+}
+
+// A conjunction over several fixed-width COLUMNS in one launch (LiquidRowFilter's conjuncts, row_filter.rs:481-515; TPC-H Q6:
+// ship-date range, discount range, quantity).  Selection chaining is per entry — conjunct k + 1 of entry e only needs the
+// hits of conjunct k of entry e — so a wave takes an entry through ALL steps: step k writes its hit words to the entry's
+// mask segment and step k + 1 reads them back as its selection (same wave, the lines are in L2), in place.  No
+// intermediate mask crosses a launch boundary, an entry with no survivor skips the remaining columns, and the chain
+// costs one launch ramp instead of one per conjunct.  Steps may differ in lane type (Date32 on u32, decimals on u64,
+// Int16 on u16); every step is the register-resident per-width function of k_fixed_pred_reg.
+template <int kMaxW>
+__global__ __launch_bounds__(kThreads) void k_fixed_chain(FixedChainArgs C, ScanLaunch L) {
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    uint64_t wave_hits = 0;
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
+        const uint64_t word_off = C.step[0].descs[entry].mask_word_off;  // the columns cover the same rows
+        const uint64_t* sel = L.d_selection ? L.d_selection + word_off : nullptr;
+        uint64_t* hit = L.d_hit + word_off;
+        uint64_t t = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < uint32_t(kMaxChainSteps); k++) {  // unrolled: the steps are read from the kernel arguments
+            if (k >= C.n_steps) break;                              // with constant offsets (no private copy of C)
+            const FixedChainStep& sp = C.step[k];
+            const FixedDesc d = sp.descs[entry];
+            uint32_t c;
+            if (sp.lane_log2 == 4) c = fixed_pred_entry_step<uint16_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane);
+            else if (sp.lane_log2 == 5) c = fixed_pred_entry_step<uint32_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane);
+            else c = fixed_pred_entry_step<uint64_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane);
+            t = uniform_u64(wave_sum_u64(uint64_t(c)));  // lane 0 holds the total: broadcast, the branch below is uniform
+            if (t == 0) break;  // nothing survives: the hit words are zero, later columns cannot change that
+            if (k + 1 < C.n_steps) {
+                // the next step reads what this one stored: same wave, same CU — workgroup scope orders the stores before
+                // the loads (an agent-scope release writes back the XCD's whole L2: measured 10x slower than three launches)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                sel = hit;
+            }
+        }
+        if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(t);
+        wave_hits += t;
     }
     if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, total_waves, wave_hits);
 }
@@ -3601,6 +3655,16 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
         case 6: hipLaunchKernelGGL(k_fixed_pred<uint64_t>, grid, block, 0, stream, d_descs, pred, p2, L); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_fixed_chain(const FixedChainArgs& chain, uint32_t max_width, const ScanLaunch& L, hipStream_t stream) {
+    if (L.n_entries == 0 || chain.n_steps == 0) return hipSuccess;
+    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint64_t wgs_resident = uint64_t(device_cus()) * 8;
+    const dim3 grid(uint32_t(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), block(kThreads);
+    if (max_width <= 16) hipLaunchKernelGGL(k_fixed_chain<16>, grid, block, 0, stream, chain, L);
+    else hipLaunchKernelGGL(k_fixed_chain<32>, grid, block, 0, stream, chain, L);
     return hipGetLastError();
 }
 

@@ -152,6 +152,20 @@ struct FixedPred {
     uint32_t pad;
 };
 
+// a conjunction over several fixed-width columns in one launch (k_fixed_chain)
+constexpr int kMaxChainSteps = 6;
+struct FixedChainStep {
+    const FixedDesc* descs;  // the column's descriptors, same entry order and row ranges for every step
+    FixedPred pred, pred2;   // pred2.op < 0: absent
+    int32_t lane_log2;       // 4..6
+    int32_t pad;
+};
+struct FixedChainArgs {
+    FixedChainStep step[kMaxChainSteps];
+    uint32_t n_steps;
+    uint32_t pad;
+};
+
 constexpr int kInlineNeedle = 64;
 
 struct StrPred {
@@ -234,6 +248,7 @@ hipError_t launch_fixed_sum_product(const FixedDesc* d_descs_a, const FixedDesc*
                                     void* d_partials, uint64_t* d_out, hipStream_t stream);
 hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, int is_signed, const ScanLaunch& L, void* d_partials,
                             uint64_t* d_out, hipStream_t stream);
+hipError_t launch_fixed_chain(const FixedChainArgs& chain, uint32_t max_width, const ScanLaunch& L, hipStream_t stream);
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
                                uint64_t capacity_rows, hipStream_t stream);

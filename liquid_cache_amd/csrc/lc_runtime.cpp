@@ -2043,9 +2043,72 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
         next = (o == bufs[0]) ? 1 : 0;
         return o;
     };
+    // a step that the fused chain kernel can take: a predicate (or fusable pair) on a fixed-width column of u16 / u32 / u64
+    // lanes at <= 32 bits, no floats (their exception rows need a second kernel), no squeezed entries (probe passes)
+    auto chainable = [&](const lc_filter_step& sp, const lc_scan* first) -> bool {
+        if (sp.kind != LC_STEP_AND || !sp.scans || !sp.preds || sp.n_terms == 0 || sp.n_terms > 2) return false;
+        const lc_scan* s = sp.scans[0];
+        if (!s || s->n == 0 || s->is_str || s->lane_log2 < 4 || s->max_w > 32 || s->has_clamped || s->any_float) return false;
+        if (first && (s->ctx != first->ctx || s->seg_offsets != first->seg_offsets)) return false;
+        for (uint32_t t = 0; t < sp.n_terms; t++) {
+            const int op = sp.preds[t].op;
+            if (op < LC_OP_EQ || op > LC_OP_GE || !sp.preds[t].lit) return false;
+            if (sp.n_terms == 2 && op == LC_OP_NE) return false;
+        }
+        return true;
+    };
     for (uint32_t k = 0; k < n_steps; k++) {
         const lc_filter_step& sp = steps[k];
         if (!sp.scans || !sp.preds || sp.n_terms == 0) return fail(LC_ERR_INVALID, "empty filter step");
+        // consecutive chainable steps run as ONE launch (k_fixed_chain): every wave takes its entry through all of them
+        if (chainable(sp, nullptr)) {
+            uint32_t run = 1;
+            while (k + run < n_steps && run < uint32_t(kMaxChainSteps) && chainable(steps[k + run], sp.scans[0])) run++;
+            if (run >= 2) {
+                FixedChainArgs chain{};
+                uint32_t max_w = 1;
+                for (uint32_t j = 0; j < run; j++) {
+                    const lc_filter_step& cj = steps[k + j];
+                    lc_scan* s = cj.scans[0];
+                    FixedChainStep& cs = chain.step[j];
+                    cs.descs = static_cast<const FixedDesc*>(s->d_descs);
+                    cs.lane_log2 = s->lane_log2;
+                    lc_status rc = make_fixed_pred(s->meta[0], &cj.preds[0], &cs.pred);
+                    if (rc != LC_OK) return rc;
+                    cs.pred2 = FixedPred{};
+                    cs.pred2.op = -1;
+                    if (cj.n_terms == 2) {
+                        rc = make_fixed_pred(s->meta[0], &cj.preds[1], &cs.pred2);
+                        if (rc != LC_OK) return rc;
+                    }
+                    max_w = std::max(max_w, s->max_w);
+                }
+                chain.n_steps = run;
+                lc_scan* s_last = steps[k + run - 1].scans[0];
+                const bool run_is_last = k + run == n_steps;
+                ScanLaunch L{};
+                L.n_entries = s_last->n;
+                L.blocks_per_entry = s_last->bpe;
+                L.d_selection = static_cast<const uint64_t*>(sel);
+                void* out = take();
+                L.d_hit = static_cast<uint64_t*>(out);
+                L.d_counts = static_cast<uint32_t*>(d_counts_out);
+                if (run_is_last && d_total_out) {
+                    std::lock_guard<std::mutex> g(s_last->mu);
+                    if (!s_last->d_total_acc) {
+                        s_last->d_total_acc = static_cast<unsigned long long*>(pool_alloc(ctx, size_t(kTotalWords) * 8));
+                        if (!s_last->d_total_acc) return fail(LC_ERR_OOM, "hipMalloc (count accumulator)");
+                        LC_HIP(hipMemsetAsync(s_last->d_total_acc, 0, size_t(kTotalWords) * 8, st));
+                    }
+                    L.d_total_acc = s_last->d_total_acc;
+                    L.d_total_out = static_cast<uint64_t*>(d_total_out);
+                }
+                LC_HIP(launch_fixed_chain(chain, max_w, L, st));
+                sel = out;
+                k += run - 1;
+                continue;
+            }
+        }
         const bool last = k + 1 == n_steps;
         void* total = last ? d_total_out : nullptr;
         if (sp.kind == LC_STEP_OR) {

@@ -195,9 +195,9 @@ class PushdownExecutor:
 class CompiledFilter:
     """The steps of a LiquidRowFilter as the C ABI takes them (lc_filter_step[]); keeps the ctypes objects alive."""
 
-    def __init__(self, executor: PushdownExecutor, steps: List[_Step]):
-        any_col = next(iter(executor.columns.values()))
-        self._lib, self._ctx = any_col.scan._lib, any_col.scan._cache.handle
+    def __init__(self, executor: Optional[PushdownExecutor], steps: List[_Step]):
+        any_scan = next(iter(executor.columns.values())).scan if executor is not None else steps[0].scans[0]
+        self._lib, self._ctx = any_scan._lib, any_scan._cache.handle
         self.steps = steps
         self._keep = []
         arr = (N.FilterStep * max(len(steps), 1))()
@@ -212,6 +212,11 @@ class CompiledFilter:
         self._arr = arr
         self._n = len(steps)
         self._final = C.c_void_p()
+
+    @classmethod
+    def from_conjunction(cls, scan_exprs: Sequence) -> "CompiledFilter":
+        """[(scan, [expr] or [expr, expr]), ...]: predicates (or fusable pairs) on the given column scans, in order."""
+        return cls(None, [_Step("and", [scan], list(exprs)) for scan, exprs in scan_exprs])
 
     def run(self, mask_a_ptr: int, mask_b_ptr: int, counts_ptr: int = 0, selection_ptr: int = 0, total_ptr: int = 0,
             stream: int = 0) -> int:
