@@ -125,6 +125,9 @@ struct lc_ctx {
     // same for pinned host staging (pageable hipMemcpy runs at a fraction of the PCIe rate)
     std::unordered_map<void*, size_t> hpool_live;
     std::unordered_map<size_t, std::vector<void*>> hpool_free;
+    // side streams for staging work (signature builder): concurrent lc_stage calls of different host threads do not wait
+    // for each other's kernels the way they would on the null stream with a device-wide synchronise
+    std::vector<hipStream_t> stream_pool;
 };
 
 struct lc_scan {
@@ -173,6 +176,25 @@ namespace {
 
 // ------------------------------------------------------------------ scratch pool
 constexpr size_t kPoolMinClass = 4096, kPoolMaxClass = size_t(64) << 20, kPoolKeepPerClass = 16;
+
+hipStream_t stream_acquire(lc_ctx* ctx) {
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        if (!ctx->stream_pool.empty()) {
+            hipStream_t s = ctx->stream_pool.back();
+            ctx->stream_pool.pop_back();
+            return s;
+        }
+    }
+    hipStream_t s = nullptr;
+    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;  // null stream as a fallback
+    return s;
+}
+void stream_release(lc_ctx* ctx, hipStream_t s) {
+    if (!s) return;
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    ctx->stream_pool.push_back(s);
+}
 
 void* pool_alloc(lc_ctx* ctx, size_t bytes) {
     size_t cls = kPoolMinClass;
@@ -704,6 +726,7 @@ void lc_ctx_destroy(lc_ctx* ctx) {
     for (Slab& s : ctx->slabs)
         if (s.base) (void)hipFree(s.base);
     pool_destroy(ctx);
+    for (hipStream_t st : ctx->stream_pool) (void)hipStreamDestroy(st);
     if (ctx->d_symtabs) (void)hipFree(ctx->d_symtabs);
     for (DevSymtab* p : ctx->d_symtabs_retired) (void)hipFree(p);
     delete ctx;
@@ -799,14 +822,18 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
             const lc_status ss = sync_symtabs(ctx);  // the signature builder reads the device copies
             if (ss != LC_OK) return ss;
         }
-        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        // The cache lock is held only to reserve the blob and, later, to publish the entries: the copy and the signature
+        // kernel of concurrent lc_stage calls (one host thread per column chunk is the usual staging pattern) overlap.
         uint8_t* dbase = nullptr;
         int slab = -1;
         const size_t total = align_up(blob.bytes.size(), kSectionAlign) + 256;
         blob.bytes.resize(total, 0);
-        lc_status st = arena_alloc(ctx, total, &dbase, &slab);
-        if (st != LC_OK) return st;
-        ctx->slabs[size_t(slab)].live += int64_t(pend.size()) - 1;
+        {
+            std::unique_lock<std::shared_mutex> g(ctx->mu);
+            lc_status st = arena_alloc(ctx, total, &dbase, &slab);
+            if (st != LC_OK) return st;
+            ctx->slabs[size_t(slab)].live += int64_t(pend.size()) - 1;  // keeps the slab alive until the entries exist
+        }
         LC_HIP(hipMemcpy(dbase, blob.bytes.data(), total, hipMemcpyHostToDevice));
         std::vector<StrDesc> sig_descs;
         for (Pending& p : pend) {
@@ -840,14 +867,17 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
             }
             StrDesc* d_sd = static_cast<StrDesc*>(pool_alloc(ctx, sig_descs.size() * sizeof(StrDesc)));
             if (!d_sd) return fail(LC_ERR_OOM, "hipMalloc (signature builder descriptors)");
-            const hipError_t e1 = hipMemcpy(d_sd, sig_descs.data(), sig_descs.size() * sizeof(StrDesc), hipMemcpyHostToDevice);
+            hipStream_t side = stream_acquire(ctx);  // (the blob copy above was a synchronous hipMemcpy: it has landed)
+            const hipError_t e1 = hipMemcpyAsync(d_sd, sig_descs.data(), sig_descs.size() * sizeof(StrDesc), hipMemcpyHostToDevice, side);
             uint32_t max_d = 1;
             for (const StrDesc& sd : sig_descs) max_d = std::max(max_d, sd.d);
-            const hipError_t e2 = e1 == hipSuccess ? launch_str_build_signatures(d_sd, uint32_t(sig_descs.size()), max_d, d_st, nullptr) : e1;
-            const hipError_t e3 = hipDeviceSynchronize();
+            const hipError_t e2 = e1 == hipSuccess ? launch_str_build_signatures(d_sd, uint32_t(sig_descs.size()), max_d, d_st, side) : e1;
+            const hipError_t e3 = hipStreamSynchronize(side);
+            stream_release(ctx, side);
             pool_release(ctx, d_sd);
             if (e2 != hipSuccess || e3 != hipSuccess) return fail(LC_ERR_DEVICE, "k_str_build_signatures failed");
         }
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
         for (Pending& p : pend) {
             auto old = ctx->entries.find(p.id);
             if (old != ctx->entries.end()) {
