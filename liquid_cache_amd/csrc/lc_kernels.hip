@@ -3692,8 +3692,18 @@ hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, c
     return hipGetLastError();
 }
 
+// Launch-shape tuning aids (results never depend on them); like every environment hook they exist only in profiling
+// builds (make ABLATION=1 / TIMING=1): the shipped library reads no tuning variable.
+static const char* tuning_env(const char* name) {
+#ifdef LC_ABLATION
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 static bool persistent_env() {
-    static const bool v = std::getenv("LC_STR_PERSISTENT") != nullptr;
+    static const bool v = tuning_env("LC_STR_PERSISTENT") != nullptr;
     return v;
 }
 
@@ -3708,7 +3718,7 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     const uint32_t cmask_bytes = sub ? (((dmax + 63u) / 64u) * 8u + 15u) & ~15u : 0u;
     const bool lds_tbl = sub && pred.needle_len <= kMaxLdsNeedle;
     const size_t tbl_bytes = lds_tbl ? automaton_image_bytes(pred.needle_len) : 0;
-    static const char* env_pad = std::getenv("LC_STR_LDS_PAD");  // tuning aid: extra LDS per workgroup lowers occupancy
+    static const char* env_pad = tuning_env("LC_STR_LDS_PAD");  // tuning aid: extra LDS per workgroup lowers occupancy
     // kMany: LIKE over entries without the signature index (hundreds to thousands of candidates per entry)
     const bool many = sub && L.many_candidates;
     const bool instr = L.d_cand_bytes != nullptr || L.d_own_bytes != nullptr;
@@ -3752,12 +3762,12 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&wgs_per_cu, reinterpret_cast<const void*>(kern), kThreads,
                                                          dyn_lds) != hipSuccess || wgs_per_cu <= 0)
             wgs_per_cu = 2;
-        static const char* env_k = std::getenv("LC_STR_WGS_PER_CU");
+        static const char* env_k = tuning_env("LC_STR_WGS_PER_CU");
         if (env_k && std::atoi(env_k) > 0) wgs_per_cu = std::atoi(env_k);
         grid = std::min<uint32_t>(wgs_needed, uint32_t(device_cus()) * uint32_t(wgs_per_cu));
     }
     ScanLaunch Lw = L;
-    static const char* env_g = std::getenv("LC_STR_WGS_PER_GROUP");  // tuning aid
+    static const char* env_g = tuning_env("LC_STR_WGS_PER_GROUP");  // tuning aid
     const uint32_t wgs_per_group = env_g && std::atoi(env_g) > 0 ? uint32_t(std::atoi(env_g)) : (persistent ? 4u : 1u);
     Lw.work_groups = std::max<uint32_t>(1u, std::min<uint32_t>(kWorkGroupsMax, grid / wgs_per_group));
     if (!persistent && L.d_wg_ranges && L.n_wg_ranges <= kWorkGroupsMax) {
