@@ -75,6 +75,8 @@ def parse_args(argv=None):
     p.add_argument("--no-cold", action="store_true",
                    help="skip the L3-cold timing (rocprofv3 --stats runs: the kernel average then only holds hot launches)")
     p.add_argument("--secondary-rows", type=int, default=0, help="rows of the secondary workloads (0 = --rows)")
+    p.add_argument("--secondary-set", default="all",
+                   help="comma list of the secondary groups to run: q21,int,q6,sweep,staging,like (kernel A/B runs)")
     p.add_argument("--sweep-rows", type=int, default=33_554_432, help="rows of the ClickBench pushdown sweep (config 5)")
     p.add_argument("--seed", type=int, default=42)
     return p.parse_args(argv)
@@ -1068,27 +1070,33 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary:
         sec = {}
         sec_rows = args.secondary_rows or args.rows
-        if args.workload == "url_like" and not args.no_q21:
+        groups = set(args.secondary_set.split(","))
+        want = lambda g: "all" in groups or g in groups  # noqa: E731
+        if args.workload == "url_like" and not args.no_q21 and want("q21"):
             try:
                 sec["q21_pipeline"] = q21_pipeline(cache, lc, N, args, rank, n_batches, threads, scan, expr, torch, stream)
             except Exception as e:  # noqa: BLE001
                 sec["q21_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        sec.update(secondary_int_columns(cache, lc, N, args, sec_rows, threads, torch, stream, iters))
+        if want("int"):
+            sec.update(secondary_int_columns(cache, lc, N, args, sec_rows, threads, torch, stream, iters))
         try:
-            sec["tpch_q6_pushdown"] = secondary_tpch_q6(cache, lc, N, args, sec_rows, threads, torch, stream, iters)
+            if want("q6"):
+                sec["tpch_q6_pushdown"] = secondary_tpch_q6(cache, lc, N, args, sec_rows, threads, torch, stream, iters)
         except Exception as e:  # noqa: BLE001
             sec["tpch_q6_pushdown"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             sweep_rows = min(sec_rows, args.sweep_rows)
-            sec["clickbench_pushdown_sweep"] = secondary_clickbench_sweep(cache, lc, args, sweep_rows, threads, torch, stream,
+            if want("sweep"):
+                sec["clickbench_pushdown_sweep"] = secondary_clickbench_sweep(cache, lc, args, sweep_rows, threads, torch, stream,
                                                                           max(3, iters // 2))
         except Exception as e:  # noqa: BLE001
             sec["clickbench_pushdown_sweep"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
-            sec["arrow_to_liquid_staging"] = secondary_transcode_rate(cache, lc, N, args, sec_rows, threads)
+            if want("staging"):
+                sec["arrow_to_liquid_staging"] = secondary_transcode_rate(cache, lc, N, args, sec_rows, threads)
         except Exception as e:  # noqa: BLE001
             sec["arrow_to_liquid_staging"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if args.workload == "url_like" and not args.no_fingerprints:
+        if args.workload == "url_like" and not args.no_fingerprints and want("like"):
             sec.update(secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream, iters, pattern))
         out["secondary"] = sec
     if rank == 0:

@@ -106,6 +106,12 @@ template <typename T>
 using GlobalPtr = const __attribute__((address_space(1))) T*;
 template <typename T>
 __device__ __forceinline__ GlobalPtr<T> as_global(const T* p) { return (GlobalPtr<T>)p; }
+// stores through a pointer the compiler cannot prove global would be FLAT stores: besides the slower path, a pending flat
+// access makes the compiler wait for ALL outstanding loads (vmcnt(0)) at the next use of any loaded value
+template <typename T>
+using GlobalMutPtr = __attribute__((address_space(1))) T*;
+template <typename T>
+__device__ __forceinline__ GlobalMutPtr<T> as_global_mut(T* p) { return (GlobalMutPtr<T>)p; }
 
 // Fused COUNT(*): called by ONE lane of every wave of the launch (`unit` = its index, `n_units` = how many there are)
 // with the hits of the entries that wave evaluated.  Two levels of {arrivals : 24 | hits : 40} words: the last arrival
@@ -757,87 +763,219 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
 #ifndef LC_X_PAIRW
 #define LC_X_PAIRW 6
 #endif
+#ifndef LC_X_PIPE
+#define LC_X_PIPE 1
+#endif
+#ifndef LC_X_PIPE_REGS
+#define LC_X_PIPE_REGS 16
+#endif
+#ifndef LC_X_PIPE_ALL
+#define LC_X_PIPE_ALL 0
+#endif
     constexpr uint32_t kPairs = W <= LC_X_PAIRW ? 2u : 1u;
-    uint32_t count = 0;
-    for (uint32_t blk0 = 0; blk0 < nblocks; blk0 += 2u * kPairs) {
-        // selection & validity: lane i (< 32 kPairs) owns mask word 16*blk0 + i of the entry
-        const uint32_t widx = blk0 * 16u + uint32_t(lane);
-        uint64_t act = 0;
-        const bool own = uint32_t(lane) < 32u * kPairs && widx < nwords_entry;
-        if (own) {
-            uint64_t tail = ~uint64_t(0);
-            if (widx == nwords_entry - 1 && (len & 63u)) tail = (uint64_t(1) << (len & 63u)) - 1;
-            const uint64_t selw = selection ? as_global(selection)[widx] : ~uint64_t(0);
-            const uint64_t vw = validity ? as_global(validity)[widx] : ~uint64_t(0);
-            act = all_null ? 0 : (selw & vw & tail);  // all-null entries carry no validity buffer: no row is valid
-        }
-        uint64_t result = 0;
-        const uint64_t am = __ballot(act != 0);
-        if (am != 0) {  // block pairs without a selected valid row do not touch their packed data
-            if (constant >= 0) {
-                result = constant ? act : 0;
+    constexpr uint32_t kPassBlocks = 2u * kPairs;
+    constexpr uint32_t kPassWords = 16u * kPassBlocks;     // mask words of a pass: lanes 0 .. kPassWords-1 own one each
+    constexpr int kSets = (TB == 32 ? 1 : 2) * int(kPairs);  // register sets of a pass (u32: both blocks of a pair in one set)
+    // Software pipeline over the passes of an entry (u32 lanes, widths whose two register sets fit the kernel's budget).
+    // Unpipelined, an entry is 8 dependent round trips (per pass: selection / validity words, then the packed words) with
+    // ~175 instructions between them; pipelined, three stages are in flight: the selection / validity words of pass p + 2,
+    // the packed words of pass p + 1 and the compares of pass p (two register sets, ping-pong).  The loads of a pass are
+    // unconditional — a wave-uniform branch around them would make the compiler wait for ALL outstanding loads at the
+    // join — so a pass without a selected valid row reads block 0 of the entry (cached) instead of its own blocks.
+    constexpr bool kPipe = LC_X_PIPE != 0 && (TB == 32 || LC_X_PIPE_ALL != 0) && kSets * NW <= LC_X_PIPE_REGS;
+    if constexpr (kPipe) {
+        struct PassWords { uint32_t w[kSets][NW]; };
+        auto load_pass = [&](PassWords& pw, uint32_t blk0, uint64_t am) {
+            const bool go0 = uint32_t(am) != 0 || (kPairs == 1 && am != 0), go1 = kPairs > 1 && uint32_t(am >> 32) != 0;
+            // (a pair whose second block lies past the entry reads its first block again: those mask words are outside the
+            // entry and are never stored)
+            const uint8_t* base0 = go0 ? packed + uint64_t(blk0) * 128u * uint32_t(W) : packed;
+            const uint8_t* base1 = go1 ? packed + uint64_t(blk0 + 2u) * 128u * uint32_t(W) : packed;
+            const uint32_t off0 = (go0 && blk0 + 1u < nblocks) ? 128u * uint32_t(W) : 0u;
+            const uint32_t off1 = (go1 && blk0 + 3u < nblocks) ? 128u * uint32_t(W) : 0u;
+            if constexpr (TB == 32) {
+                // word k of FastLanes lane l of block A|B of a pair: one 128-byte line per block and k
+                const uint32_t half = uint32_t(lane) >> 5, l = uint32_t(lane) & 31u;
+                {
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base0 + half * off0) + l;
+    #pragma unroll
+                    for (int k = 0; k < NW; k++) pw.w[0][k] = as_global(p)[k * 32];
+                }
+                if constexpr (kPairs > 1) {
+                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base1 + half * off1) + l;
+    #pragma unroll
+                    for (int k = 0; k < NW; k++) pw.w[1][k] = as_global(p)[k * 32];
+                }
             } else {
-                const bool go0 = uint32_t(am) != 0, go1 = kPairs > 1 && uint32_t(am >> 32) != 0;
-                // (a pair whose second block lies past the entry reads its first block again: those mask words are
-                // outside the entry and are never stored)
-                const uint8_t* base0 = packed + uint64_t(blk0) * 128u * uint32_t(W);
-                const uint8_t* base1 = packed + uint64_t(blk0 + 2u) * 128u * uint32_t(W);
-                const uint32_t off0 = (blk0 + 1u < nblocks) ? 128u * uint32_t(W) : 0u;
-                const uint32_t off1 = (blk0 + 3u < nblocks) ? 128u * uint32_t(W) : 0u;
-                uint32_t X = 0, Y = 0;
-                if constexpr (TB == 32) {
-                    // word k of FastLanes lane l of block A|B of a pair: one 128-byte line per block and k
-                    uint32_t w0[NW], w1[NW];
-                    const uint32_t half = uint32_t(lane) >> 5, l = uint32_t(lane) & 31u;
-                    if (go0) {
-                        const uint32_t* p = reinterpret_cast<const uint32_t*>(base0 + half * off0) + l;
-#pragma unroll
-                        for (int k = 0; k < NW; k++) w0[k] = as_global(p)[k * 32];
-                    }
-                    if constexpr (kPairs > 1) {
-                        if (go1) {
-                            const uint32_t* p = reinterpret_cast<const uint32_t*>(base1 + half * off1) + l;
-#pragma unroll
-                            for (int k = 0; k < NW; k++) w1[k] = as_global(p)[k * 32];
-                        }
-                    }
-                    if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, w0, lo_t, bound_t, X, Y);
+                load_stream16<U, W, NW>(base0, lane, pw.w[0]);
+                load_stream16<U, W, NW>(base0 + off0, lane, pw.w[1]);
+                if constexpr (kPairs > 1) {
+                    load_stream16<U, W, NW>(base1, lane, pw.w[2]);
+                    load_stream16<U, W, NW>(base1 + off1, lane, pw.w[3]);
+                }
+            }
+        };
+        auto compute_pass = [&](const PassWords& pw, uint64_t am) -> uint64_t {
+            const bool go0 = uint32_t(am) != 0 || (kPairs == 1 && am != 0), go1 = kPairs > 1 && uint32_t(am >> 32) != 0;
+            uint32_t X = 0, Y = 0;
+            if constexpr (TB == 32) {
+                if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, pw.w[0], lo_t, bound_t, X, Y);
+                if constexpr (kPairs > 1) {
                     __builtin_amdgcn_sched_barrier(0);  // keep the second pair's steps from being hoisted (register pressure)
-                    if constexpr (kPairs > 1)
-                        if (go1) reg_steps32<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 32>{}, w1, lo_t, bound_t, X, Y);
-                } else {
-                    uint32_t wa[NW], wb[NW], wc[NW], wd[NW];  // every block's loads are in flight before the first compare
-                    if (go0) {
-                        load_stream16<U, W, NW>(base0, lane, wa);
-                        load_stream16<U, W, NW>(base0 + off0, lane, wb);
-                    }
-                    if constexpr (kPairs > 1) {
-                        if (go1) {
-                            load_stream16<U, W, NW>(base1, lane, wc);
-                            load_stream16<U, W, NW>(base1 + off1, lane, wd);
-                        }
-                    }
-                    if (go0) {
-                        reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, wa, lo_t, bound_t, X, Y);
-                        reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, wb, lo_t, bound_t, X, Y);
-                    }
-                    if constexpr (kPairs > 1) {
-                        if (go1) {
-                            reg_steps16<W, kTwoSided, 2, NW>(std::make_integer_sequence<uint32_t, 16>{}, wc, lo_t, bound_t, X, Y);
-                            reg_steps16<W, kTwoSided, 3, NW>(std::make_integer_sequence<uint32_t, 16>{}, wd, lo_t, bound_t, X, Y);
-                        }
+                    if (go1) reg_steps32<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 32>{}, pw.w[1], lo_t, bound_t, X, Y);
+                }
+            } else {
+                if (go0) {
+                    reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[0], lo_t, bound_t, X, Y);
+                    reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[1], lo_t, bound_t, X, Y);
+                }
+                if constexpr (kPairs > 1) {
+                    if (go1) {
+                        reg_steps16<W, kTwoSided, 2, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[2], lo_t, bound_t, X, Y);
+                        reg_steps16<W, kTwoSided, 3, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[3], lo_t, bound_t, X, Y);
                     }
                 }
-                result = ((uint64_t(X) | (uint64_t(Y) << 32)) ^ flip) & act;
             }
+            return uint64_t(X) | (uint64_t(Y) << 32);
+        };
+        // lane's selection & validity word of pass p: lane i (< kPassWords) owns mask word p kPassWords + i (0 past the entry)
+        auto load_act = [&](uint32_t p) -> uint64_t {
+            const uint32_t widx = p * kPassWords + uint32_t(lane);
+            const bool own = uint32_t(lane) < kPassWords && widx < nwords_entry;
+            const uint32_t wc = min(widx, nwords_entry - 1u);  // every lane loads (no divergent region around the loads)
+            uint64_t tail = ~uint64_t(0);
+            if (widx == nwords_entry - 1 && (len & 63u)) tail = (uint64_t(1) << (len & 63u)) - 1;
+            const uint64_t selw = selection ? as_global(selection)[wc] : ~uint64_t(0);
+            const uint64_t vw = validity ? as_global(validity)[wc] : ~uint64_t(0);
+            return own ? (selw & vw & tail) : uint64_t(0);
+        };
+        auto store_pass = [&](uint32_t p, uint64_t result, uint64_t act) {
+            const uint32_t widx = p * kPassWords + uint32_t(lane);
+            if (uint32_t(lane) < kPassWords && widx < nwords_entry) {
+                as_global_mut(hit)[widx] = result;
+                if (valid_out) as_global_mut(valid_out)[widx] = act;
+            }
+        };
+        const uint32_t npass = (nblocks + kPassBlocks - 1u) / kPassBlocks;
+        uint32_t count = 0;
+        if (npass == 0) return 0;
+        if (constant >= 0 || all_null) {  // constant outcome (literal outside the entry's range, all-null entry): no packed data
+            for (uint32_t p = 0; p < npass; p++) {
+                const uint64_t act = all_null ? 0 : load_act(p);  // all-null entries carry no validity buffer: no row is valid
+                const uint64_t result = constant > 0 ? act : 0;
+                store_pass(p, result, act);
+                count += uint32_t(__popcll(result));
+            }
+            return count;
         }
-        if (own) {
-            hit[widx] = result;
-            if (valid_out) valid_out[widx] = act;
+        // three stages in flight: selection / validity words of pass p + 2, packed words of pass p + 1, compares of pass p
+        uint64_t act0 = load_act(0), act1 = load_act(1);
+        uint64_t am0 = __ballot(act0 != 0);
+        PassWords bufA, bufB;
+        load_pass(bufA, 0, am0);
+        auto step = [&](uint32_t p, const PassWords& cur, PassWords& nxt) {
+            const uint64_t act2 = load_act(p + 2u);
+            const uint64_t am1 = __ballot(act1 != 0);
+            load_pass(nxt, (p + 1u) * kPassBlocks, am1);
+            __builtin_amdgcn_sched_barrier(0);  // the next pass's loads are issued before this pass's compares
+            uint64_t result = 0;
+            if (am0 != 0) result = (compute_pass(cur, am0) ^ flip) & act0;
+            store_pass(p, result, act0);
+            count += uint32_t(__popcll(result));
+            act0 = act1;
+            am0 = am1;
+            act1 = act2;
+        };
+#pragma unroll 1
+        for (uint32_t p = 0; p < npass; p += 2u) {  // two passes per iteration: the two register sets swap roles, no moves
+            step(p, bufA, bufB);
+            if (p + 1u >= npass) break;
+            step(p + 1u, bufB, bufA);
         }
-        count += uint32_t(__popcll(result));
+        return count;
+    } else {
+        uint32_t count = 0;
+        for (uint32_t blk0 = 0; blk0 < nblocks; blk0 += 2u * kPairs) {
+            // selection & validity: lane i (< 32 kPairs) owns mask word 16*blk0 + i of the entry
+            const uint32_t widx = blk0 * 16u + uint32_t(lane);
+            uint64_t act = 0;
+            const bool own = uint32_t(lane) < 32u * kPairs && widx < nwords_entry;
+            if (own) {
+                uint64_t tail = ~uint64_t(0);
+                if (widx == nwords_entry - 1 && (len & 63u)) tail = (uint64_t(1) << (len & 63u)) - 1;
+                const uint64_t selw = selection ? as_global(selection)[widx] : ~uint64_t(0);
+                const uint64_t vw = validity ? as_global(validity)[widx] : ~uint64_t(0);
+                act = all_null ? 0 : (selw & vw & tail);  // all-null entries carry no validity buffer: no row is valid
+            }
+            uint64_t result = 0;
+            const uint64_t am = __ballot(act != 0);
+            if (am != 0) {  // block pairs without a selected valid row do not touch their packed data
+                if (constant >= 0) {
+                    result = constant ? act : 0;
+                } else {
+                    const bool go0 = uint32_t(am) != 0, go1 = kPairs > 1 && uint32_t(am >> 32) != 0;
+                    // (a pair whose second block lies past the entry reads its first block again: those mask words are
+                    // outside the entry and are never stored)
+                    const uint8_t* base0 = packed + uint64_t(blk0) * 128u * uint32_t(W);
+                    const uint8_t* base1 = packed + uint64_t(blk0 + 2u) * 128u * uint32_t(W);
+                    const uint32_t off0 = (blk0 + 1u < nblocks) ? 128u * uint32_t(W) : 0u;
+                    const uint32_t off1 = (blk0 + 3u < nblocks) ? 128u * uint32_t(W) : 0u;
+                    uint32_t X = 0, Y = 0;
+                    if constexpr (TB == 32) {
+                        // word k of FastLanes lane l of block A|B of a pair: one 128-byte line per block and k
+                        uint32_t w0[NW], w1[NW];
+                        const uint32_t half = uint32_t(lane) >> 5, l = uint32_t(lane) & 31u;
+                        if (go0) {
+                            const uint32_t* p = reinterpret_cast<const uint32_t*>(base0 + half * off0) + l;
+    #pragma unroll
+                            for (int k = 0; k < NW; k++) w0[k] = as_global(p)[k * 32];
+                        }
+                        if constexpr (kPairs > 1) {
+                            if (go1) {
+                                const uint32_t* p = reinterpret_cast<const uint32_t*>(base1 + half * off1) + l;
+    #pragma unroll
+                                for (int k = 0; k < NW; k++) w1[k] = as_global(p)[k * 32];
+                            }
+                        }
+                        if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, w0, lo_t, bound_t, X, Y);
+                        __builtin_amdgcn_sched_barrier(0);  // keep the second pair's steps from being hoisted (register pressure)
+                        if constexpr (kPairs > 1)
+                            if (go1) reg_steps32<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 32>{}, w1, lo_t, bound_t, X, Y);
+                    } else {
+                        uint32_t wa[NW], wb[NW], wc[NW], wd[NW];  // every block's loads are in flight before the first compare
+                        if (go0) {
+                            load_stream16<U, W, NW>(base0, lane, wa);
+                            load_stream16<U, W, NW>(base0 + off0, lane, wb);
+                        }
+                        if constexpr (kPairs > 1) {
+                            if (go1) {
+                                load_stream16<U, W, NW>(base1, lane, wc);
+                                load_stream16<U, W, NW>(base1 + off1, lane, wd);
+                            }
+                        }
+                        if (go0) {
+                            reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, wa, lo_t, bound_t, X, Y);
+                            reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, wb, lo_t, bound_t, X, Y);
+                        }
+                        if constexpr (kPairs > 1) {
+                            if (go1) {
+                                reg_steps16<W, kTwoSided, 2, NW>(std::make_integer_sequence<uint32_t, 16>{}, wc, lo_t, bound_t, X, Y);
+                                reg_steps16<W, kTwoSided, 3, NW>(std::make_integer_sequence<uint32_t, 16>{}, wd, lo_t, bound_t, X, Y);
+                            }
+                        }
+                    }
+                    result = ((uint64_t(X) | (uint64_t(Y) << 32)) ^ flip) & act;
+                }
+            }
+            if (own) {
+                as_global_mut(hit)[widx] = result;
+                if (valid_out) as_global_mut(valid_out)[widx] = act;
+            }
+            count += uint32_t(__popcll(result));
+        }
+
+        return count;
     }
-    return count;
 }
 
 template <typename U, int... WS>
@@ -1080,6 +1218,9 @@ constexpr uint32_t kCandCap = 1024;  // candidate list capacity per wave (u16 en
 // the signature-only variant sees a handful of candidates per entry: a quarter of the list leaves room for two more
 // workgroups per CU (LDS is what limits its occupancy)
 constexpr uint32_t kCandCapSigOnly = 256;
+#ifndef LC_X_POSTINGS
+#define LC_X_POSTINGS 1
+#endif
 
 template <typename T>
 __device__ __forceinline__ T load_unaligned(const uint8_t* p) {
@@ -1498,7 +1639,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     constexpr uint32_t kNeedleLds = 256;
     constexpr uint32_t kFlagBytes = 80;
     constexpr uint32_t kCap = kSigOnly ? kCandCapSigOnly : kCandCap;
-    const uint32_t per_wave = dres_bytes + cmask_bytes + kCap * 2u + kFlagBytes;
+    // (kSigOnly: + the mask words and the matched keys of the inverted-list row phase)
+    const uint32_t per_wave = dres_bytes + cmask_bytes + kCap * 2u + kFlagBytes + (kSigOnly ? kPostLdsBytes : 0u);
     uint8_t* needle_lds = smem + tbl_bytes;
     uint8_t* wbase = smem + tbl_bytes + kNeedleLds + wave * per_wave;
     uint32_t* dres = reinterpret_cast<uint32_t*>(wbase);  // bitmap words or bytes
@@ -1507,6 +1649,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint16_t* cand = reinterpret_cast<uint16_t*>(wbase + dres_bytes + cmask_bytes);
     uint8_t* hitflag = wbase + dres_bytes + cmask_bytes + kCap * 2u;
     uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
+    uint64_t* pmask = reinterpret_cast<uint64_t*>(hitflag + kFlagBytes);            // kSigOnly only
+    uint16_t* mlist = reinterpret_cast<uint16_t*>(hitflag + kFlagBytes + kPostMaxRows / 8u);
     const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
     const uint32_t hitrow = row0 + nl * 512u;  // LDS address of the absorbing (matched) state's row
     const uint32_t dres_addr = uint32_t(reinterpret_cast<uintptr_t>(wbase));
@@ -1556,10 +1700,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint32_t* work = L.d_work + wg_group * 16u;
     uint64_t wave_hits = 0;  // fused COUNT(*): hits of the entries this wave evaluated (lane 0)
     // kSigOnly: the row phase is shared by the workgroup (see "cooperative row phase" below); what a wave found for its
-    // own entry: 0 = nothing left to write (no entry, or the early-out wrote it), 1 = no dictionary value matched,
-    // 2 = the dictionary result table of this wave holds matches
+    // own entry: 0 = nothing left to write (no entry, the early-out wrote it, or no dictionary value matched and the wave
+    // wrote its zeros), 2 = the dictionary result table of this wave holds matches
+    // 3 = matches, rows already written by this wave from the entry's inverted row lists
     constexpr bool kCoop = kSigOnly;
     uint32_t coop_state = 0;
+    uint32_t post_hits = 0;  // state 3: the entry's hit count (wave uniform)
     for (uint32_t draw = 0;; draw++) {
         uint32_t entry = 0;
         if (static_draw) {
@@ -1660,6 +1806,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint32_t cand_bytes = 0;  // per lane, summed at the end (instrumented pass only)
     uint32_t own_bytes = 0;   // per lane (instrumented pass only): bytes this kernel itself moves for the entry
     uint64_t any_true = 0;    // wave uniform: some dictionary entry evaluated true
+    uint32_t n_match = 0;     // wave uniform (kSigOnly): dictionary values that matched; the first kPostMaxMatches in mlist
     bool table_cleared = !kSub;  // wave uniform: the dictionary result table holds zeros + the matches set so far
     __builtin_amdgcn_wave_barrier();
 
@@ -1939,6 +2086,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 if (kBytes) dresb[id] = 1;
                 else atomicOr(&dres[id >> 5], 1u << (id & 31));
             }
+            if (kSigOnly) {
+                if (res) {
+                    const uint32_t slot = n_match + lanes_below(res_mask);
+                    if (slot < kPostMaxMatches) mlist[slot] = uint16_t(id);
+                }
+                n_match += uint32_t(__popcll(res_mask));
+            }
         }
         n_cand = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1946,8 +2100,67 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
 
     LC_TM(7, 0);
     if (kCoop) {
-        coop_state = any_true != 0 ? 2u : 1u;
+        coop_state = any_true != 0 ? 2u : 0u;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (any_true == 0) {
+            // no dictionary value matched (70 % of the entries of the headline scan): the wave writes its zeros right
+            // away instead of carrying them into the cooperative phase behind the workgroup barrier
+            const uint64_t word_off = dp->mask_word_off;
+            for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
+                L.d_hit[word_off + w] = 0;
+                if (L.d_valid) {
+                    uint64_t sv = ~uint64_t(0), vv = ~uint64_t(0);
+                    if (L.d_selection) sv = *as_global(L.d_selection + word_off + w);
+                    if (dp->validity) vv = *as_global(dp->validity + w);
+                    const uint32_t rows_left = dp->n - (w << 6);
+                    const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
+                    L.d_valid[word_off + w] = sv & vv & tail;
+                }
+            }
+        }
+        if (LC_X_POSTINGS && any_true != 0 && dp->postings != nullptr && n_match <= kPostMaxMatches && nwords <= kPostMaxRows / 64u) {
+            // ---- inverted-list row phase: the rows of the (one or two) matching dictionary values are read from the
+            // entry's row lists and set in an LDS copy of the mask words; no key is read.  Two dependent round trips
+            // (list bounds of every match, then the rows), a few dozen bytes instead of 2 n.
+            const uint16_t* post = dp->postings;
+            const uint16_t* prow = post + dp->d + 1u;
+            uint32_t o0 = 0, o1 = 0;
+            if (uint32_t(lane) < n_match) {
+                const uint32_t mid = mlist[lane];
+                o0 = as_global(post)[mid];
+                o1 = as_global(post)[mid + 1u];
+            }
+            for (uint32_t w = uint32_t(lane); w < kPostMaxRows / 64u; w += kWave) pmask[w] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t m = 0; m < n_match; m++) {
+                const uint32_t b = read_lane(o0, m), e1 = read_lane(o1, m);
+                for (uint32_t r = b + uint32_t(lane); r < e1; r += kWave) {
+                    const uint32_t row = as_global(prow)[r];
+                    atomicOr(reinterpret_cast<unsigned long long*>(&pmask[row >> 6]), 1ull << (row & 63u));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint64_t word_off = dp->mask_word_off;
+            uint32_t c = 0;
+            for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
+                uint64_t sv = ~uint64_t(0);
+                if (L.d_selection) sv = *as_global(L.d_selection + word_off + w);
+                const uint64_t hitw = pmask[w] & sv;  // the lists hold valid rows of the entry only
+                L.d_hit[word_off + w] = hitw;
+                if (L.d_valid) {
+                    uint64_t vv = ~uint64_t(0);
+                    if (dp->validity) vv = *as_global(dp->validity + w);
+                    const uint32_t rows_left = dp->n - (w << 6);
+                    const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
+                    L.d_valid[word_off + w] = sv & vv & tail;
+                }
+                c += uint32_t(__popcll(hitw));
+            }
+            post_hits = uint32_t(uniform_u64(wave_sum_u64(uint64_t(c))));
+            wave_hits += post_hits;
+            coop_state = 3u;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         continue;  // static draw: this was the wave's only entry
     }
     LC_FORGET_DESC;
@@ -2072,7 +2285,22 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         // reads them when there is no signature index or for the NOT LIKE candidate rule)
         if (kSub) u += (prune && (!use_sig || op == LC_OP_NOT_LIKE)) ? 4u * dp->d : 0u;
         if (!kSub && pred.mode == 0 && uniform_result < 0) u += 8u * dp->d;
-        if (!all_false) u += 2u * dp->n;
+        if (!all_false) {
+            // rows: the keys, or — when the launch this pass accounts for reads the inverted lists — the list bounds and
+            // the rows of the matching values
+            uint32_t nm = 0, pr = 0;
+            const bool lists = L.acct_postings && dp->postings != nullptr && nwords <= kPostMaxRows / 64u;
+            if (lists) {
+                uint32_t my_m = 0, my_r = 0;
+                for (uint32_t i = uint32_t(lane); i < dp->d; i += kWave) {
+                    const bool hit = kBytes ? dresb[i] != 0 : ((dres[i >> 5] >> (i & 31)) & 1u) != 0;
+                    if (hit) { my_m++; my_r += uint32_t(dp->postings[i + 1u]) - uint32_t(dp->postings[i]); }
+                }
+                nm = uint32_t(uniform_u64(wave_sum_u64(uint64_t(my_m))));
+                pr = uint32_t(uniform_u64(wave_sum_u64(uint64_t(my_r))));
+            }
+            u += (lists && nm <= kPostMaxMatches) ? 4u * nm + 2u * pr : 2u * dp->n;
+        }
         u += nwords * 8u * ((L.d_selection ? 1u : 0u) + (dp->validity ? 1u : 0u) + 1u + (L.d_valid ? 1u : 0u));
         const uint64_t c = wave_sum_u64(uint64_t(own_bytes));
         if (lane == 0) L.d_own_bytes[entry] = uint32_t(c) + u;
@@ -2092,7 +2320,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         // anyway) and ALL four waves map a quarter of the rows (2048 keys = one 16-byte load x 4 per lane) of each
         // entry that has matches; entries without matches are zero-filled by their own wave.
         uint32_t* my_flags = reinterpret_cast<uint32_t*>(hitflag + 72);  // {state, hits} in the spare bytes of the flag area
-        if (lane == 0) { my_flags[0] = coop_state; my_flags[1] = 0; }
+        if (lane == 0) { my_flags[0] = coop_state; my_flags[1] = coop_state == 3u ? post_hits : 0u; }
         __syncthreads();
         const uint32_t n_in_range = group_end - group_begin;
         uint32_t hit_count = 0;
@@ -2100,27 +2328,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             uint8_t* wbase_e = smem + tbl_bytes + kNeedleLds + e * per_wave;
             uint32_t* flags_e = reinterpret_cast<uint32_t*>(wbase_e + dres_bytes + cmask_bytes + kCap * 2u + 72);
             const uint32_t st_e = uint32_t(__builtin_amdgcn_readfirstlane(int(flags_e[0])));
-            if (st_e == 0) continue;
+            if (st_e != 2u) continue;
             ConstDescPtr de = reinterpret_cast<ConstDescPtr>(reinterpret_cast<uintptr_t>(&rec->d[e]));
             const uint32_t n_rows = de->n;
             const uint32_t nwords_e = (n_rows + 63u) >> 6;
             const uint64_t word_off = de->mask_word_off;
-            const bool need_vw = st_e == 2 || L.d_valid != nullptr;
-            if (st_e == 1) {
-                if (e != wave) continue;  // the entry's own wave writes its zeros
-                for (uint32_t w = uint32_t(lane); w < nwords_e; w += kWave) {
-                    L.d_hit[word_off + w] = 0;
-                    if (L.d_valid) {
-                        uint64_t sv = ~uint64_t(0), vv = ~uint64_t(0);
-                        if (L.d_selection) sv = *as_global(L.d_selection + word_off + w);
-                        if (de->validity) vv = *as_global(de->validity + w);
-                        const uint32_t rows_left = n_rows - (w << 6);
-                        const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
-                        L.d_valid[word_off + w] = sv & vv & tail;
-                    }
-                }
-                continue;
-            }
+            const bool need_vw = true;
             // matches: this wave's quarter of every 8192 rows (entries hold up to 65,536 rows)
             const uint32_t dres_addr_e = uint32_t(reinterpret_cast<uintptr_t>(wbase_e));
             const uint32_t* dres_e = reinterpret_cast<const uint32_t*>(wbase_e);
@@ -2461,6 +2674,9 @@ __global__ __launch_bounds__(1024) void k_scan_apply(const uint32_t* __restrict_
 }
 
 
+#ifndef LC_X_GATHER_SW
+#define LC_X_GATHER_SW 1
+#endif
 template <typename U>
 __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __restrict__ descs, ScanLaunch L,
                                                             const uint64_t* __restrict__ entry_offsets,
@@ -2507,17 +2723,21 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
     // read at once, its selected rows listed, and their packed words fetched straight from HBM in one dense step — two
     // dependent round trips per entry instead of two per 1024-row block.
     const uint32_t ewords = (d.len + 63u) >> 6;
-    if (L.d_selection && ewords <= 2u * kWave && d.patch_len == 0) {
-        uint64_t sw[2];
+    // the entry's selection words (entries of up to 8192 rows: lane l holds words l and 64 + l), read once: the block
+    // loop below takes its 16 words per block from these registers instead of one more dependent load per block
+    uint64_t sw[2] = {0, 0};
+    const bool have_sw = LC_X_GATHER_SW != 0 && L.d_selection && ewords <= 2u * kWave;
+    if (have_sw) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t w = uint32_t(h) * kWave + uint32_t(lane);
-            sw[h] = 0;
             if (w < ewords) {
                 sw[h] = L.d_selection[d.mask_word_off + w];
                 if (w == ewords - 1 && (d.len & 63u)) sw[h] &= (uint64_t(1) << (d.len & 63u)) - 1;
             }
         }
+    }
+    if (have_sw && d.patch_len == 0) {
         const uint32_t c0 = uint32_t(__popcll(sw[0])), c1 = uint32_t(__popcll(sw[1]));
         const uint32_t i0 = wave_inclusive_sum(c0), i1 = wave_inclusive_sum(c1);
         const uint32_t t0 = read_lane(i0, kWave - 1), total = t0 + read_lane(i1, kWave - 1);
@@ -2557,7 +2777,12 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
     const uint32_t nwords = (rows + 63u) >> 6;
     const uint64_t word_base = d.mask_word_off + uint64_t(blk) * 16u;
     uint64_t act = 0;
-    if (uint32_t(lane) < nwords) {
+    if (have_sw) {
+        // word 16 blk + lane of the entry sits in lane (16 blk + lane) & 63 of sw[blk >> 2] (tail bits already cleared)
+        const uint64_t src = blk < 4u ? sw[0] : sw[1];
+        const uint64_t got = uint64_t(__shfl((unsigned long long)src, int(((blk & 3u) << 4) + (uint32_t(lane) & 15u)), kWave));
+        act = uint32_t(lane) < nwords ? got : uint64_t(0);
+    } else if (uint32_t(lane) < nwords) {
         uint64_t tail = ~uint64_t(0);
         if (uint32_t(lane) == nwords - 1 && (rows & 63u)) tail = (uint64_t(1) << (rows & 63u)) - 1;
         act = (L.d_selection ? L.d_selection[word_base + lane] : ~uint64_t(0)) & tail;
@@ -3727,7 +3952,8 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     const bool sig_only = records && sub && !many && !instr && lds_tbl && pred.use_fingerprints && pred.n_sig_bits > 0 &&
                           pred.op == LC_OP_LIKE;
     const size_t cand_cap = sig_only ? kCandCapSigOnly : kCandCap;
-    const size_t dyn_lds = tbl_bytes + 256 + size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + cand_cap * 2 + 80) +
+    const size_t dyn_lds = tbl_bytes + 256 +
+                           size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + cand_cap * 2 + 80 + (sig_only ? kPostLdsBytes : 0u)) +
                            (env_pad ? size_t(std::atoi(env_pad)) : 0);
     // persistent launch: as many workgroups as fit on the device at once; the waves draw entries dynamically
     const uint32_t wgs_needed = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -3767,6 +3993,9 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
         grid = std::min<uint32_t>(wgs_needed, uint32_t(device_cus()) * uint32_t(wgs_per_cu));
     }
     ScanLaunch Lw = L;
+    // the byte-accounting pass describes the launch the same predicate gets without it
+    Lw.acct_postings = (instr && LC_X_POSTINGS && records && sub && !many && lds_tbl && pred.use_fingerprints &&
+                        pred.n_sig_bits > 0 && pred.op == LC_OP_LIKE) ? 1u : 0u;
     static const char* env_g = tuning_env("LC_STR_WGS_PER_GROUP");  // tuning aid
     const uint32_t wgs_per_group = env_g && std::atoi(env_g) > 0 ? uint32_t(std::atoi(env_g)) : (persistent ? 4u : 1u);
     Lw.work_groups = std::max<uint32_t>(1u, std::min<uint32_t>(kWorkGroupsMax, grid / wgs_per_group));

@@ -73,9 +73,19 @@ struct alignas(16) StrDesc {
     uint32_t fsst_len, shared_prefix_len;
     uint32_t symtab_slot;
     uint8_t offset_bytes;
-    uint8_t pad[11];
+    uint8_t pad[3];
+    const uint16_t* postings;      // inverted row lists (see below), or nullptr
 };
 static_assert(sizeof(StrDesc) == 112, "StrDesc layout");
+
+// Inverted row lists of a byte-view entry (device-side acceleration index like the signatures; entries of up to 8192 rows
+// on substring-search columns): u16 offsets[D + 1], then the VALID rows grouped by dictionary key (u16 row numbers,
+// rows[offsets[k] .. offsets[k + 1]) reference key k).  A selective predicate matches one or two dictionary values per
+// entry; their rows are then read from these lists (a few bytes) instead of mapping all 8192 keys (16 KB) to results —
+// what map_dictionary_results_to_array_results (comparisons.rs:325-347) computes, for the matching values only.
+constexpr uint32_t kPostMaxRows = 8192;     // entries with more rows carry no lists
+constexpr uint32_t kPostMaxMatches = 32;    // more matching dictionary values than this: the keys are mapped instead
+constexpr uint32_t kPostLdsBytes = kPostMaxRows / 8 + kPostMaxMatches * 2;  // per wave: mask words + matched keys
 
 // What one workgroup of k_str_pred works on: a run of at most four consecutive entries that share a symbol table (one
 // per wave), with a COPY of their descriptors.  The record's address follows from blockIdx alone, so a wave fetches the
@@ -204,6 +214,7 @@ struct ScanLaunch {
     uint32_t n_wg_ranges;    // byte views: entries of d_wg_ranges (0: entries are split evenly over the groups)
     const StrWgRecord* d_wg_ranges;  // byte views: one record per workgroup; a range never mixes symbol tables
     uint32_t many_candidates;     // byte views: some entry has no bigram signature index (LIKE walks whole dictionaries)
+    uint32_t acct_postings;       // byte-accounting pass: the launch it accounts for reads rows through the inverted lists
     // Fused COUNT(*) of the launch (optional): every wave adds the hits of its entries to a sharded accumulator and the
     // wave that arrives last writes the total to *d_total_out — no separate reduction kernel, no memset between launches.
     unsigned long long* d_total_acc;  // kTotalWords u64 owned by the scan, zero between launches (self-resetting)

@@ -111,6 +111,7 @@ struct lc_ctx {
     std::vector<std::unique_ptr<SymbolTable>> symtabs;
     bool build_signatures = true;  // LC_NO_SIGNATURES=1 disables the bigram index (plain reference layout only)
     bool signatures_on_host = false;  // LC_HOST_SIGNATURES=1: build the index on the host (the device builder's oracle)
+    bool build_postings = true;       // LC_NO_POSTINGS=1: no inverted row lists (rows always mapped through the keys)
     DevSymtab* d_symtabs = nullptr;
     size_t d_symtabs_cap = 0;
     size_t d_symtabs_uploaded = 0;
@@ -470,7 +471,7 @@ lc_status build_fixed(const uint8_t* bytes, size_t len, Entry* e, Blob* blob, si
 }
 
 lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path_id, Entry* e, Blob* blob,
-                    size_t offs[8]) {
+                    size_t offs[9]) {
     ByteViewParsed v;
     if (!parse_byte_view(bytes, len, &v)) return fail(LC_ERR_CORRUPT, "malformed Liquid byte-view array");
     // the row lists and mask utilities of the byte-view kernels address rows of an entry with 16 bits (the reference's
@@ -516,7 +517,7 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
     d.fsst_len = v.fsst_len;
     d.shared_prefix_len = v.shared_prefix_len;
     d.symtab_slot = slot;
-    for (int i = 0; i < 8; i++) offs[i] = size_t(-1);
+    for (int i = 0; i < 9; i++) offs[i] = size_t(-1);
     // keys padded to a multiple of 8 (16-byte loads)
     offs[0] = blob->add(v.keys.data(), size_t(v.n) * 2, kSectionAlign, 16);
     if (v.nullable) {
@@ -552,6 +553,20 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
                 sig[size_t(bigram_bit(tmp[k], tmp[k + 1])) * nw + (i >> 6)] |= uint64_t(1) << (i & 63);
         }
         offs[7] = blob->add(sig.data(), sig.size() * 8);
+    }
+    if (v.fingerprints && ctx->build_signatures && ctx->build_postings && v.n <= kPostMaxRows && v.d > 0 && !v.all_null) {
+        // inverted row lists (lc_kernels.hpp): counting sort of the valid rows by dictionary key
+        std::vector<uint16_t> post(size_t(v.d) + 1 + size_t(v.n) + 32, 0);
+        uint16_t* off = post.data();
+        uint16_t* rows = post.data() + v.d + 1;
+        auto valid = [&](uint32_t r) { return !v.nullable || ((v.key_validity[r >> 3] >> (r & 7)) & 1); };
+        for (uint32_t r = 0; r < v.n; r++)
+            if (valid(r) && v.keys[r] < v.d) off[size_t(v.keys[r]) + 1]++;
+        for (uint32_t k = 0; k < v.d; k++) off[k + 1] = uint16_t(off[k + 1] + off[k]);
+        std::vector<uint16_t> cursor(off, off + v.d);
+        for (uint32_t r = 0; r < v.n; r++)
+            if (valid(r) && v.keys[r] < v.d) rows[cursor[v.keys[r]]++] = uint16_t(r);
+        offs[8] = blob->add(post.data(), post.size() * 2, kSectionAlign, 16);
     }
     return LC_OK;
 }
@@ -712,6 +727,7 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     ctx->max_hbm = max_hbm_bytes;
     if (const char* ns = std::getenv("LC_NO_SIGNATURES")) ctx->build_signatures = std::atoi(ns) == 0;
     if (const char* hs = std::getenv("LC_HOST_SIGNATURES")) ctx->signatures_on_host = std::atoi(hs) != 0;
+    if (const char* np = std::getenv("LC_NO_POSTINGS")) ctx->build_postings = std::atoi(np) == 0;
     *out = ctx.release();
     return LC_OK;
     });
@@ -792,7 +808,7 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
         struct Pending {
             uint64_t id;
             Entry e;
-            size_t off[8];
+            size_t off[9];
             size_t blob_begin;
         };
         std::vector<Pending> pend;
@@ -849,6 +865,7 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
                 d.fsst = ptr(p.off[5]);
                 d.shared_prefix = ptr(p.off[6]);
                 d.signatures = reinterpret_cast<const uint64_t*>(ptr(p.off[7]));
+                d.postings = reinterpret_cast<const uint16_t*>(ptr(p.off[8]));
                 if (p.e.sig_on_device) sig_descs.push_back(d);
             } else {
                 FixedDesc& d = p.e.fd;
@@ -1610,7 +1627,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             s->max_dict_len = std::max(s->max_dict_len, e.dict_len);
             s->any_fingerprints |= e.has_fp;
             if (e.is_str) {
-                s->any_without_signatures |= e.sd.signatures == nullptr;
+                s->any_without_signatures |= e.sd.signatures == nullptr && e.sd.d > 0;  // (an all-null entry has no dictionary)
                 if (i == 0) s->uniform_slot = int32_t(e.sd.symtab_slot);
                 else if (int32_t(e.sd.symtab_slot) != s->uniform_slot) s->uniform_slot = -1;
             } else {

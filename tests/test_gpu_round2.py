@@ -1379,3 +1379,73 @@ def test_scan_sum_product_matches_python_integers(gpu_cache, oracle, kind):
     with pytest.raises(lc.LiquidCacheError) as ex:
         sa.sum_product_to_host(gpu_cache.scan(ids_b[:2]))
     assert ex.value.status == N.LC_ERR_INVALID
+
+
+@pytest.mark.gpu
+def test_inverted_row_lists_give_the_masks_of_the_key_mapping(product_lib, oracle, monkeypatch):
+    """LIKE over entries that carry the inverted row lists (default) against the same entries staged without them
+    (LC_NO_POSTINGS=1: every matching entry maps its keys) and against the oracle: needles matching no dictionary value,
+    one or two, a few dozen and most of them (more than the list path takes: key mapping again); nulls, a selection,
+    validity output through eval_predicate, entries of 8192 / 8191 / 65 / 1 rows and one of 9000 rows (no lists)."""
+    lo = oracle
+    rng = np.random.default_rng(4242)
+    hint = lc.CacheExpression.SUBSTRING_SEARCH
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _make_strings
+    lens = [8192, 8191, 65, 1, 9000, 8192]
+    blobs, st = [], None
+    for b, n in enumerate(lens):
+        strs = _make_strings(rng, n, 1500, b != 5)
+        if n > 100:
+            strs[7] = "http://needle-once.example/only" + str(b)      # exactly one value, one row
+            strs[11] = strs[13] = "http://twice.example/needle-two"   # one value, two rows
+        liquid, st = lo.encode_byte_view(strs, st=st, fingerprints=True)
+        blobs.append(liquid)
+    pats = (b"%needle-once%", b"%needle%", b"%nomatchatall%", b"%google%", b"%http%", b"%x1%", b"%9%")
+    results = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LC_NO_POSTINGS", mode)
+        cache = lc.LiquidCacheBuilder.new().with_device(0).build()
+        cache.set_symbol_table(7171, lo.symtab_bytes(st))
+        ids = [lc.ParquetArrayID.new(71, 0, 2, b) for b in range(len(lens))]
+        cache.stage(ids, blobs, [7171] * len(ids))
+        scan = cache.scan(ids)
+        offs = scan.segment_offsets
+        got = {}
+        for pat in pats:
+            expr = lc.LiquidExpr.try_new("like", pat, pa.string(), hint)
+            for with_sel in (False, True):
+                sel_rng = np.random.default_rng(99)
+                sels = [sel_rng.random(n) < 0.4 for n in lens]
+                words = None
+                if with_sel:
+                    words = np.zeros(int(scan.mask_words), np.uint64)
+                    for b, se in enumerate(sels):
+                        packed = np.packbits(se, bitorder="little")
+                        words[int(offs[b]): int(offs[b + 1])].view(np.uint8)[: len(packed)] = packed
+                mask, counts = scan.eval_to_host(expr, selection=words)
+                got[(pat, with_sel)] = (mask.copy(), counts.copy())
+                if mode == "0":
+                    for b, n in enumerate(lens):
+                        want = lo.eval_predicate(blobs[b], lo.LIKE, pat, None, symtab=st)
+                        hit = want.values & (want.validity if want.validity is not None else True)
+                        if with_sel:
+                            hit = hit & sels[b]
+                        bits = np.unpackbits(mask[int(offs[b]): int(offs[b + 1])].view(np.uint8), bitorder="little")[:n]
+                        assert bits.astype(bool).tolist() == hit.tolist(), (pat, b, with_sel)
+                        assert int(counts[b]) == int(hit.sum())
+            # per-entry call: values + validity of the selected rows (the reference's BooleanArray)
+            if mode == "0":
+                from test_gpu_parity import _check_pred
+                for b in (0, 1, 2):
+                    sel = (np.random.default_rng(5 + b).random(lens[b]) < 0.5).tolist()
+                    _check_pred(cache, lo, ids[b], blobs[b], "like", pat, pa.string(), sel, symtab=st, hint=hint)
+        alg, own = scan.traffic_model(lc.LiquidExpr.try_new("like", b"%needle-once%", pa.string(), hint))
+        results[mode] = (got, own)
+        scan.close()
+        cache.close()
+    for k in results["0"][0]:
+        assert np.array_equal(results["0"][0][k][0], results["1"][0][k][0]), k
+        assert np.array_equal(results["0"][0][k][1], results["1"][0][k][1]), k
+    # with the lists, the four matching entries of <= 8192 rows read a few bytes instead of their keys
+    assert results["0"][1] < results["1"][1] - 3 * 2 * 8000
