@@ -1437,7 +1437,10 @@ typedef const __attribute__((address_space(3))) uint16_t* LdsU16Ptr;
 __device__ __forceinline__ uint32_t lds_u16(uint32_t addr) { return *reinterpret_cast<LdsU16Ptr>(addr); }
 __device__ __forceinline__ uint32_t lds_u8(uint32_t addr) { return *reinterpret_cast<LdsBytePtr>(addr); }
 
-constexpr uint32_t kMaxByteTable = 4096;  // dictionary results as one byte per entry up to this dictionary size
+#ifndef LC_X_MAXBYTETABLE
+#define LC_X_MAXBYTETABLE 4096
+#endif
+constexpr uint32_t kMaxByteTable = LC_X_MAXBYTETABLE;  // dictionary results as one byte per entry up to this dictionary size
 
 // ---- the lane-parallel LIKE walker -------------------------------------------------------------------------------
 // The kernel is bound by instruction issue and by the length of dependent chains (a wave instruction costs four

@@ -24,15 +24,21 @@ run_one() {  # name, env prefix, args
     env $envp timeout 240 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_str_pred|k_fixed_pred" --output-format csv -d $O/${wl}_$c -- $B $a --no-cpu-baseline --steps 3 --warmup 1 > $O/${wl}_$c.log 2>&1
   done
 }
-for wl in url_like url_like_no_fingerprints int64_gt_w62 date32_gt_w12 int16_gt_w12 decimal_gt_w4; do run_one $wl "LC_X=0" "${WL[$wl]}"; done
+# WORKLOADS="url_like date32_gt_w12" scripts/profile_round.sh <tag>: only these (a partial refresh after a kernel change)
+ALL="url_like url_like_no_fingerprints int64_gt_w62 date32_gt_w12 int16_gt_w12 decimal_gt_w4 tpch_q6 url_like_no_signatures calib"
+WORKLOADS=${WORKLOADS:-$ALL}
+has() { [[ " $WORKLOADS " == *" $1 "* ]]; }
+for wl in url_like url_like_no_fingerprints int64_gt_w62 date32_gt_w12 int16_gt_w12 decimal_gt_w4; do has $wl && run_one $wl "LC_X=0" "${WL[$wl]}"; done
 # BASELINE.json config 4 at its full size: the Q6-shaped chain over 600,037,902 rows (kernel trace only)
+if has tpch_q6; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/tpch_q6_trace -- python $R/bench.py --workload tpch_q6 --steps 10 --warmup 2 > $O/tpch_q6_trace.log 2>&1
 f=$(find $O/tpch_q6_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/tpch_q6_kernel_stats.csv
 grep -h '^{"metric"' $O/tpch_q6_trace.log > $O/tpch_q6_bench_line.json
+fi
 # the same LIKE scan with the reference's own prefilter only (no bigram signature index staged)
-run_one url_like_no_signatures "LC_NO_SIGNATURES=1" "--workload url_like"
+has url_like_no_signatures && run_one url_like_no_signatures "LC_NO_SIGNATURES=1" "--workload url_like"
 # FETCH_SIZE calibration on known byte counts
-timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "k_calib" --output-format csv -d $O/calib_FETCH_SIZE -- python $R/scripts/pmc_calibrate.py > $O/calib.log 2>&1
+has calib && timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "k_calib" --output-format csv -d $O/calib_FETCH_SIZE -- python $R/scripts/pmc_calibrate.py > $O/calib.log 2>&1
 python $R/scripts/pmc_summary.py $O > $O/pmc_summary.txt 2>&1
-for wl in url_like url_like_no_signatures url_like_no_fingerprints int64_gt_w62 date32_gt_w12 int16_gt_w12 decimal_gt_w4; do echo "== $wl"; head -3 $O/${wl}_kernel_stats.csv; done
+for wl in url_like url_like_no_signatures url_like_no_fingerprints int64_gt_w62 date32_gt_w12 int16_gt_w12 decimal_gt_w4; do has $wl && { echo "== $wl"; head -3 $O/${wl}_kernel_stats.csv; }; done
 tail -40 $O/pmc_summary.txt
