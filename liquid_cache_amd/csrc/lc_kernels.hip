@@ -2413,313 +2413,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_str_like_pool: `LIKE '%needle%'` over entries that all carry the bigram signature index, EIGHT entries per workgroup
-// with their work POOLED (k_str_pred gives every entry its own wave: 35 of 64 lanes busy in the signature phase, ~15
-// candidates = 1.2 half-empty walk passes per entry, and ~1,100 instructions along five dependent round trips per wave).
-//   phase A  the 256 threads AND the needle's slices of ALL the record's dictionary bitmap words (two words per thread:
-//            16 loads in flight per lane) and append the set bits to ONE candidate list in LDS ((entry << 16) | key)
-//   phase B  the waves take the list 64 candidates at a time whatever entry they belong to — the lane-parallel walk of
-//            k_str_pred with the owner's FSST buffer — and set the matching keys in per-entry result bitmaps (LDS)
-//   phase C  per entry (waves take entries in turn): no match: zeros; a few matches and inverted row lists: the rows of
-//            the matching keys; else the keys are mapped through the result bitmap
-// A round covers 512 bitmap words; when its candidates exceed the list (needles of one bigram), it is processed in sixteen
-// sub-rounds of 32 words (at most 2,048 candidates each).  Results are identical to k_str_pred's (parity tests).
-// ------------------------------------------------------------------------------------------------
-constexpr uint32_t kPoolCandCap = 2048;
-constexpr uint32_t kPoolRoundWords = 2u * kThreads;
-constexpr uint32_t kPoolMaxDictWords = 128;  // dictionaries of up to 8192 values (larger ones: k_str_pred)
-__host__ __device__ inline uint32_t pool_lds_bytes(uint32_t tbl_bytes, uint32_t dict_words) {
-    // [automaton image][candidates][result bitmaps][per wave: 80 flag bytes + mask words + matched keys][counters]
-    return tbl_bytes + kPoolCandCap * 4u + kPoolEntries * dict_words * 8u + kWavesPerBlock * (80u + kPostLdsBytes) + 64u;
-}
-
-__global__ __launch_bounds__(kThreads, 4) void k_str_like_pool(StrPred pred, ScanLaunch L, const StrWgRecord8* __restrict__ recs,
-                                                              uint32_t dict_words) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int lane = lane_id();
-    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
-    const uint32_t tid = threadIdx.x;
-    const uint32_t nl = pred.needle_len;
-    const uint32_t tbl_bytes = automaton_image_bytes(nl);
-    uint32_t* cand = reinterpret_cast<uint32_t*>(smem + tbl_bytes);
-    uint64_t* dres = reinterpret_cast<uint64_t*>(smem + tbl_bytes + kPoolCandCap * 4u);
-    uint8_t* wbase = smem + tbl_bytes + kPoolCandCap * 4u + kPoolEntries * dict_words * 8u + wave * (80u + kPostLdsBytes);
-    uint8_t* hitflag = wbase;
-    uint64_t* headmask = reinterpret_cast<uint64_t*>(wbase + 64);
-    uint64_t* pmask = reinterpret_cast<uint64_t*>(wbase + 80);
-    uint16_t* mlist = reinterpret_cast<uint16_t*>(wbase + 80 + kPostMaxRows / 8u);
-    uint32_t* ctr = reinterpret_cast<uint32_t*>(smem + tbl_bytes + kPoolCandCap * 4u + kPoolEntries * dict_words * 8u +
-                                                kWavesPerBlock * (80u + kPostLdsBytes));
-    // ctr[0] candidates in the list, ctr[1] candidates of the round, ctr[2] matched keys listed (phase C), ctr[8 + e] matches of entry e
-    const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));  // 0: the image holds absolute LDS addresses
-    const uint32_t hitrow = row0 + nl * 512u;
-
-    const StrWgRecord8* rec = recs + blockIdx.x;
-    const uint32_t n_e = rec->end - rec->begin;
-    {   // automaton image of the record's symbol table: global -> LDS DMA, published by the first barrier of phase A
-        const uint8_t* src = pred.automata + size_t(rec->symtab_slot) * pred.automaton_stride + automaton_u8_bytes(nl);
-        for (uint32_t c = wave * 1024u; c < tbl_bytes; c += kWavesPerBlock * 1024u)
-            async_copy16(src + c + uint32_t(lane) * 16u, smem + c);
-    }
-    // bitmap words of the entries, as a running sum (wave uniform: scalar loads from the record)
-    uint32_t woff[kPoolEntries + 1];
-    woff[0] = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < kPoolEntries; k++) woff[k + 1] = woff[k] + (k < n_e ? (rec->d[k].d + 63u) >> 6 : 0u);
-    const uint32_t total_words = woff[kPoolEntries];
-    for (uint32_t i = tid; i < kPoolEntries * dict_words; i += kThreads) dres[i] = 0;
-    if (tid < 16) ctr[tid] = 0;
-    __syncthreads();
-    bool first_barrier = true;
-
-    for (uint32_t round = 0; round < total_words; round += kPoolRoundWords) {
-        // ---- phase A: candidate bits of this thread's two words
-        uint64_t m[2] = {0, 0};
-        uint32_t ew[2] = {0, 0};  // (entry << 16) | word of the entry
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const uint32_t t = round + uint32_t(h) * kThreads + tid;
-            if (t < total_words) {
-                uint32_t e = 0;
-#pragma unroll
-                for (uint32_t k = 1; k < kPoolEntries; k++) e += t >= woff[k] ? 1u : 0u;
-                uint32_t wb = 0;
-#pragma unroll
-                for (uint32_t k = 1; k < kPoolEntries; k++) wb = e == k ? woff[k] : wb;
-                const uint32_t w = t - wb;
-                const StrDesc* de = &rec->d[e];
-                const uint32_t nw = (de->d + 63u) >> 6;
-                const uint64_t* sig = de->signatures;
-                uint64_t sv[kMaxSigProbe];
-#pragma unroll
-                for (int k = 0; k < kMaxSigProbe; k++) sv[k] = as_global(sig)[size_t(pred.sig_bits[k]) * nw + w];
-                uint64_t mm = sv[0];
-#pragma unroll
-                for (int k = 1; k < kMaxSigProbe; k++) mm &= sv[k];
-                if (w == nw - 1 && (de->d & 63u)) mm &= (uint64_t(1) << (de->d & 63u)) - 1;
-                m[h] = mm;
-                ew[h] = (e << 16) | w;
-            }
-        }
-        const uint32_t cnt_all = uint32_t(__popcll(m[0])) + uint32_t(__popcll(m[1]));
-        const uint32_t wt = uint32_t(uniform_u64(wave_sum_u64(uint64_t(cnt_all))));
-        if (lane == 0 && wt) atomicAdd(&ctr[1], wt);
-        if (first_barrier) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the table DMA has landed
-        first_barrier = false;
-        __syncthreads();
-        const uint32_t round_total = ctr[1];
-        const uint32_t nsub = round_total <= kPoolCandCap ? 1u : kPoolRoundWords / 32u;
-        for (uint32_t sub = 0; sub < nsub; sub++) {
-            uint32_t c = 0;
-            bool act[2];
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                act[h] = m[h] != 0 && (nsub == 1u || ((uint32_t(h) * kThreads + tid) >> 5) == sub);
-                c += act[h] ? uint32_t(__popcll(m[h])) : 0u;
-            }
-            const uint32_t incl = wave_inclusive_sum(c);
-            const uint32_t wave_total = read_lane(incl, kWave - 1);
-            uint32_t base = 0;
-            if (lane == 0 && wave_total) base = atomicAdd(&ctr[0], wave_total);
-            base = uint32_t(__builtin_amdgcn_readfirstlane(int(base)));
-            uint32_t o = base + incl - c;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                uint64_t mm = act[h] ? m[h] : 0;
-                const uint32_t hi = ew[h] & 0xFFFF0000u, wl = (ew[h] & 0xFFFFu) * 64u;
-                while (mm) {
-                    const uint32_t bit = uint32_t(__ffsll((long long)mm)) - 1u;
-                    cand[o++] = hi | (wl + bit);
-                    mm &= mm - 1;
-                }
-            }
-            __syncthreads();
-            const uint32_t n_cand = ctr[0];
-            // ---- phase B: 64 candidates per wave and step, one lane per 8-byte word of their compressed bytes
-            for (uint32_t c0 = wave * kWave; c0 < n_cand; c0 += kThreads) {
-                const uint32_t j = c0 + uint32_t(lane);
-                const bool cl = j < n_cand;
-                const uint32_t cd = cl ? cand[j] : 0u;
-                const uint32_t e = cd >> 16, id = cd & 0xFFFFu;
-                const StrDesc* de = &rec->d[e];
-                const uint8_t* fsst = de->fsst;
-                uint32_t start = 0, stop = 0;
-                if (cl) str_offset_pair(*de, id, start, stop);
-                const uint32_t words = cl ? max(1u, (stop - start + 7u) / 8u) : 0u;
-                const uint32_t incl_w = wave_inclusive_sum(words);
-                const uint32_t off = incl_w - words;
-                const uint32_t total = read_lane(incl_w, kWave - 1);
-                hitflag[lane] = 0;
-                uint32_t carry_state = row0;
-                const uint32_t fs_lo = uint32_t(reinterpret_cast<uintptr_t>(fsst)), fs_hi = uint32_t(reinterpret_cast<uintptr_t>(fsst) >> 32);
-                for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
-                    if (lane == 0) *headmask = 0;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const bool head = cl && off >= t0 && off < t0 + kWave;
-                    if (head) atomicOr(reinterpret_cast<unsigned long long*>(headmask), 1ull << (off - t0));
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    const uint64_t hm = *headmask;
-                    const uint32_t before = uint32_t(__popcll(__ballot(cl && off < t0)));
-                    const uint64_t upto = lane == 63 ? ~uint64_t(0) : ((uint64_t(2) << lane) - 1);
-                    const uint32_t r = before + uint32_t(__popcll(hm & upto)) - 1u;  // owner lane
-                    const bool live = t0 + uint32_t(lane) < total;
-                    const uint32_t o_off = __shfl(off, int(r), kWave);
-                    const uint32_t o_start = __shfl(start, int(r), kWave);
-                    const uint32_t o_stop = __shfl(stop, int(r), kWave);
-                    const uint32_t o_lo = __shfl(fs_lo, int(r), kWave), o_hi = __shfl(fs_hi, int(r), kWave);
-                    const uint8_t* o_fsst = reinterpret_cast<const uint8_t*>(uintptr_t(uint64_t(o_lo) | (uint64_t(o_hi) << 32)));
-                    const uint32_t k = t0 + uint32_t(lane) - o_off;
-                    const uint32_t p = o_start + 8u * k;
-                    const uint32_t rem = live && p < o_stop ? o_stop - p : 0u;
-                    uint64_t w8 = 0;
-                    if (rem) w8 = load_unaligned<uint64_t>(o_fsst + p);
-                    const bool first = k == 0;
-                    uint32_t x[8];
-                    {
-                        const uint32_t lo = uint32_t(w8), hi = uint32_t(w8 >> 32);
-#pragma unroll
-                        for (int q = 0; q < 8; q++) x[q] = (((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu) << 1;
-                    }
-                    uint32_t s_in = row0;
-                    uint32_t e_st = walk8(s_in, x, rem);
-                    bool hit = e_st == hitrow;
-                    for (;;) {
-                        uint32_t prev = lane_shift_up1(e_st, carry_state);
-                        if (first || prev == hitrow) prev = row0;
-                        const bool changed = prev != s_in;
-                        if (__ballot(changed) == 0) break;
-                        if (changed) {
-                            s_in = prev;
-                            e_st = walk8(s_in, x, rem);
-                            hit |= e_st == hitrow;
-                        }
-                    }
-                    carry_state = read_lane(e_st, kWave - 1);
-                    if (carry_state == hitrow) carry_state = row0;
-                    if (hit && live) hitflag[r] = 1;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (cl && hitflag[lane] != 0) {
-                    atomicOr(reinterpret_cast<unsigned long long*>(&dres[e * dict_words + (id >> 6)]), 1ull << (id & 63u));
-                    atomicAdd(&ctr[8 + e], 1u);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
-            __syncthreads();
-            if (tid == 0) { ctr[0] = 0; ctr[1] = 0; }
-            __syncthreads();
-        }
-    }
-    if (first_barrier) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (records of empty dictionaries only)
-    __syncthreads();
-
-    // ---- phase C: rows, one entry per wave and turn
-    uint64_t wave_hits = 0;
-    for (uint32_t e = wave; e < n_e; e += kWavesPerBlock) {
-        const StrDesc* de = &rec->d[e];
-        const uint32_t n_rows = de->n;
-        const uint32_t nwords = (n_rows + 63u) >> 6;
-        const uint64_t word_off = de->mask_word_off;
-        const uint32_t mc = uint32_t(__builtin_amdgcn_readfirstlane(int(ctr[8 + e])));
-        const uint64_t* dres_e = dres + e * dict_words;
-        uint32_t hits_e = 0;
-        auto active_word = [&](uint32_t w) -> uint64_t {  // selected & valid rows of mask word w
-            uint64_t sv = ~uint64_t(0), vv = ~uint64_t(0);
-            if (L.d_selection) sv = *as_global(L.d_selection + word_off + w);
-            if (de->validity) vv = *as_global(de->validity + w);
-            const uint32_t rows_left = n_rows - (w << 6);
-            const uint64_t tail = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
-            return sv & vv & tail;
-        };
-        if (mc == 0) {
-            for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
-                L.d_hit[word_off + w] = 0;
-                if (L.d_valid) L.d_valid[word_off + w] = active_word(w);
-            }
-        } else if (mc <= kPostMaxMatches && de->postings != nullptr && nwords <= kPostMaxRows / 64u) {
-            // the matching keys out of the result bitmap, then their rows out of the inverted lists
-            const uint32_t nw = (de->d + 63u) >> 6;
-            uint32_t listed = 0;
-            for (uint32_t w0 = 0; w0 < nw; w0 += kWave) {
-                const uint32_t w = w0 + uint32_t(lane);
-                uint64_t mm = w < nw ? dres_e[w] : 0;
-                const uint32_t c = uint32_t(__popcll(mm));
-                const uint32_t incl = wave_inclusive_sum(c);
-                uint32_t o = listed + incl - c;
-                while (mm) {
-                    const uint32_t bit = uint32_t(__ffsll((long long)mm)) - 1u;
-                    if (o < kPostMaxMatches) mlist[o] = uint16_t(w * 64u + bit);
-                    o++;
-                    mm &= mm - 1;
-                }
-                listed += read_lane(incl, kWave - 1);
-            }
-            for (uint32_t w = uint32_t(lane); w < kPostMaxRows / 64u; w += kWave) pmask[w] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint16_t* post = de->postings;
-            const uint16_t* prow = post + de->d + 1u;
-            uint32_t o0 = 0, o1 = 0;
-            if (uint32_t(lane) < listed) {
-                const uint32_t mid = mlist[lane];
-                o0 = as_global(post)[mid];
-                o1 = as_global(post)[mid + 1u];
-            }
-            for (uint32_t q = 0; q < listed; q++) {
-                const uint32_t b = read_lane(o0, int(q)), e1 = read_lane(o1, int(q));
-                for (uint32_t r = b + uint32_t(lane); r < e1; r += kWave) {
-                    const uint32_t row = as_global(prow)[r];
-                    atomicOr(reinterpret_cast<unsigned long long*>(&pmask[row >> 6]), 1ull << (row & 63u));
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
-                uint64_t sv = ~uint64_t(0);
-                if (L.d_selection) sv = *as_global(L.d_selection + word_off + w);
-                const uint64_t hitw = pmask[w] & sv;  // the lists hold valid rows of the entry only
-                L.d_hit[word_off + w] = hitw;
-                if (L.d_valid) L.d_valid[word_off + w] = active_word(w);
-                hits_e += uint32_t(__popcll(hitw));
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        } else {
-            // many matching values (or no lists): every key looked up in the result bitmap, 512 rows per step
-            const uint32_t key_max = dict_words * 64u - 1u;  // keys under null slots may be garbage
-            const uint32_t* dres32 = reinterpret_cast<const uint32_t*>(dres_e);
-            uint8_t* stage = reinterpret_cast<uint8_t*>(pmask);
-            for (uint32_t pass = 0; pass < n_rows; pass += kWave * 8u) {
-                const uint32_t r0 = pass + uint32_t(lane) * 8u;
-                const u32x4 kv = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(de->keys) + min(r0, (n_rows - 1u) & ~7u));
-                const uint32_t kw[4] = {kv.x, kv.y, kv.z, kv.w};
-                uint32_t bits = 0;
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint32_t key = (q & 1) ? kw[q >> 1] >> 16 : kw[q >> 1] & 0xFFFFu;
-                    const uint32_t kc = min(key, key_max);
-                    bits |= ((dres32[kc >> 5] >> (kc & 31u)) & 1u) << q;
-                }
-                stage[lane] = uint8_t(bits);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                const uint32_t w = (pass >> 6) + uint32_t(lane);
-                if (lane < 8 && w < nwords) {
-                    const uint64_t act = active_word(w);
-                    const uint64_t hitw = reinterpret_cast<const uint64_t*>(stage)[lane] & act;
-                    L.d_hit[word_off + w] = hitw;
-                    if (L.d_valid) L.d_valid[word_off + w] = act;
-                    hits_e += uint32_t(__popcll(hitw));
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            }
-        }
-        if (L.d_counts || L.d_total_out) {
-            const uint64_t tot = mc == 0 ? 0 : uniform_u64(wave_sum_u64(uint64_t(hits_e)));
-            if (lane == 0 && L.d_counts) L.d_counts[rec->begin + e] = uint32_t(tot);
-            wave_hits += tot;
-        }
-    }
-    if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, gridDim.x * kWavesPerBlock, wave_hits);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Date-part truncation (SqueezedDate32Array, squeezed_date32_array.rs): values decoded by k_fixed_gather are replaced
 // in place by the lossy reconstruction of ONE component — what the reference serves for an ExtractDate32 hint:
 //   days (Date32) or value.div_euclid(ticks_per_day) (Timestamp, :406-414) -> civil date (:364-397)
@@ -4282,15 +3975,6 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     if (sig_only)
         kern = bytes ? static_cast<Kern>(k_str_pred<true, true, false, false, true>)
                      : static_cast<Kern>(k_str_pred<false, true, false, false, true>);
-    // Pooled variant of the headline case (eight entries per workgroup): selected by LC_LIKE_POOL in profiling builds
-    // until its measurements are in (results identical, parity-tested).
-    static const bool pool_on = tuning_env("LC_LIKE_POOL") != nullptr;
-    if (sig_only && pool_on && L.d_wg8 && L.n_wg8 && dmax <= kPoolMaxDictWords * 64u) {
-        const uint32_t dw = (dmax + 63u) / 64u;
-        hipLaunchKernelGGL(k_str_like_pool, dim3(L.n_wg8), dim3(kThreads), pool_lds_bytes(uint32_t(tbl_bytes), dw), stream,
-                           pred, L, L.d_wg8, dw);
-        return hipGetLastError();
-    }
     if (dyn_lds > 64 * 1024) {
         // large dictionaries: gfx950 has 160 KB of LDS per CU, a workgroup may use more than the default 64 KB
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

@@ -98,16 +98,6 @@ struct alignas(16) StrWgRecord {
 };
 static_assert(sizeof(StrWgRecord) == 464, "StrWgRecord layout");
 
-// the same for k_str_like_pool: eight entries whose work the workgroup pools
-constexpr uint32_t kPoolEntries = 8;
-struct alignas(16) StrWgRecord8 {
-    uint32_t begin, end;
-    uint32_t symtab_slot;
-    uint32_t pad;
-    StrDesc d[kPoolEntries];
-};
-static_assert(sizeof(StrWgRecord8) == 16 + 8 * 112, "StrWgRecord8 layout");
-
 // Bigram Bloom signature (device-side acceleration index, built at staging for entries that carry fingerprints):
 // bit h(a,b) of a 128-bit set for every pair of adjacent bytes of the dictionary value.  A value can only contain
 // `needle` if it has every needle bigram — a necessary condition exactly like the reference's 32-bucket byte
@@ -223,8 +213,6 @@ struct ScanLaunch {
     uint32_t work_groups;    // byte views: number of counter groups used by this launch (set by the launcher)
     uint32_t n_wg_ranges;    // byte views: entries of d_wg_ranges (0: entries are split evenly over the groups)
     const StrWgRecord* d_wg_ranges;  // byte views: one record per workgroup; a range never mixes symbol tables
-    const StrWgRecord8* d_wg8;       // byte views: the same in runs of eight entries (k_str_like_pool), or null
-    uint32_t n_wg8;
     uint32_t many_candidates;     // byte views: some entry has no bigram signature index (LIKE walks whole dictionaries)
     uint32_t acct_postings;       // byte-accounting pass: the launch it accounts for reads rows through the inverted lists
     // Fused COUNT(*) of the launch (optional): every wave adds the hits of its entries to a sharded accumulator and the

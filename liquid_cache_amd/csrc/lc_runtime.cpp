@@ -153,8 +153,6 @@ struct lc_scan {
     size_t needle_cap = 0;
     StrWgRecord* d_wg_ranges = nullptr;  // byte views: one record per workgroup (<= 4 entries of one symbol table)
     uint32_t n_wg_ranges = 0;
-    StrWgRecord8* d_wg8 = nullptr;       // the same in runs of eight (k_str_like_pool)
-    uint32_t n_wg8 = 0;
     uint8_t* d_gather = nullptr;  // scratch of lc_scan_gather_bytes_async (grow only)
     size_t gather_cap = 0;
     uint32_t* d_work = nullptr;  // kWorkGroupsMax x {next entry, finished waves} (64-byte stride): dynamic entry
@@ -1689,7 +1687,6 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_work);
     pool_release(s->ctx, s->d_gather);
     pool_release(s->ctx, s->d_wg_ranges);
-    pool_release(s->ctx, s->d_wg8);
     pool_release(s->ctx, s->d_total_acc);
     pool_release(s->ctx, s->d_or_tmp);
     pool_release(s->ctx, s->d_agg_partials);
@@ -1879,30 +1876,10 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         s->d_wg_ranges = static_cast<StrWgRecord*>(pool_alloc(ctx, std::max<size_t>(r.size(), 1) * sizeof(StrWgRecord)));
         if (!s->d_wg_ranges) return fail(LC_ERR_OOM, "hipMalloc (scan workgroup records)");
         LC_HIP(hipMemcpyAsync(s->d_wg_ranges, r.data(), r.size() * sizeof(StrWgRecord), hipMemcpyHostToDevice, stream));
-        std::vector<StrWgRecord8> r8;
-        begin = 0;
-        for (uint32_t i = 1; i <= s->n; i++) {
-            if (i == s->n || i - begin == kPoolEntries || s->meta[i].sd.symtab_slot != s->meta[begin].sd.symtab_slot) {
-                StrWgRecord8 rec;
-                std::memset(&rec, 0, sizeof(rec));
-                rec.begin = begin;
-                rec.end = i;
-                rec.symtab_slot = s->meta[begin].sd.symtab_slot;
-                for (uint32_t k = begin; k < i; k++) rec.d[k - begin] = s->meta[k].sd;
-                r8.push_back(rec);
-                begin = i;
-            }
-        }
-        s->n_wg8 = uint32_t(r8.size());
-        s->d_wg8 = static_cast<StrWgRecord8*>(pool_alloc(ctx, std::max<size_t>(r8.size(), 1) * sizeof(StrWgRecord8)));
-        if (!s->d_wg8) return fail(LC_ERR_OOM, "hipMalloc (scan workgroup records)");
-        LC_HIP(hipMemcpyAsync(s->d_wg8, r8.data(), r8.size() * sizeof(StrWgRecord8), hipMemcpyHostToDevice, stream));
-        LC_HIP(hipStreamSynchronize(stream));  // `r`, `r8` are locals
+        LC_HIP(hipStreamSynchronize(stream));  // `r` is a local
     }
     L.d_wg_ranges = s->d_wg_ranges;
     L.n_wg_ranges = s->n_wg_ranges;
-    L.d_wg8 = s->d_wg8;
-    L.n_wg8 = s->n_wg8;
     if (!s->d_work) {  // entry-draw counters of k_str_pred: zero once, the kernel leaves them zero
         // one 64-byte counter line per workgroup of the largest launch this scan can make
         const size_t groups = std::min<size_t>(kWorkGroupsMax, std::max<size_t>({s->n_wg_ranges, (size_t(s->n) + 3) / 4, 1}));
