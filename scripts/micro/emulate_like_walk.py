@@ -12,7 +12,7 @@ from oracle import liquid_oracle as lo
 L = N.load()
 cache = lc.LiquidCacheBuilder.new().with_host_only().build()
 bs=8192; seed=42; uniques=2200; ppm=159
-needle=b"mail"; m=len(needle)
+needle=sys.argv[1].encode() if len(sys.argv)>1 else b"mail"; m=len(needle)
 class BV(C.Structure):
     _fields_=[("arrow_type",C.c_int32),("n",C.c_uint32),("d",C.c_uint32),("nullable",C.c_int32),("all_null",C.c_int32),
               ("keys",C.POINTER(C.c_uint16)),("key_validity",C.POINTER(C.c_uint8)),("fsst",C.POINTER(C.c_uint8)),("fsst_len",C.c_uint32),
@@ -101,5 +101,10 @@ def run(b, gpu_extra):
     print('batch',b,'emulated overcount rows',over,'observed',gpu_extra,'fixed-mismatch values',over_fix, fp_vals[:2])
 # rows the GPU counted beyond the ground truth (round 2, before the fix); batch 1566 trains the row group's symbol table
 OBSERVED = {1566: 6, 1567: 5, 1569: 18, 1578: 132}
-for b, extra in OBSERVED.items():
-    run(b, extra)
+if len(sys.argv) > 2:   # broad check of the new rule: python emulate_like_walk.py <needle> <first row group> <row groups>
+    for rg in range(int(sys.argv[2]), int(sys.argv[2]) + int(sys.argv[3])):
+        run(rg * 54, -1)
+        run(rg * 54 + 1 + rg % 53, -1)
+else:
+    for b, extra in OBSERVED.items():
+        run(b, extra)
