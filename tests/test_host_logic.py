@@ -250,3 +250,36 @@ def test_headers_are_plain_c(tmp_path):
                        check=True)
     if shutil.which("g++"):
         subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-I", inc, "-fsyntax-only", "-x", "c++", str(src)], check=True)
+
+
+def test_bench_cpu_baseline_counts_are_the_substring_truth():
+    """bench.py's checker leg: the C oracle's COUNT(*) over regenerated + transcoded batches of the bench column — for the
+    headline needle and for the extra parity needles — equals a plain substring test on the raw strings.  Batches of row
+    group 29 (symbol table trained on its first batch, as in the bench): the table on which `mail` exposed the GPU walker's
+    speculative matches; the oracle must not share such a defect with the kernel it checks."""
+    import bench
+    args = bench.parse_args([])
+    first = 29 * args.row_group_batches
+    cache = lc.LiquidCacheBuilder.new().with_host_only().build()
+    L = N.load()
+    bs = args.batch_size
+    needles = ("google",) + bench.EXTRA_PARITY_NEEDLES
+    got = {n: 0 for n in needles}
+    want = {n: 0 for n in needles}
+    from oracle import liquid_oracle as lo
+    offs = np.zeros(bs + 1, np.int32)
+    data = np.zeros(bs * 512, np.uint8)
+    for b in (first, first + 3, first + 12):
+        n = L.lc_synth_url_batch(args.seed, b, bs, args.uniques, args.needle_ppm, offs.ctypes.data, data.ctypes.data, data.size)
+        raw = data[:n].tobytes()
+        strs = [raw[offs[i]: offs[i + 1]] for i in range(bs)]
+        arr = pa.StringArray.from_buffers(bs, pa.py_buffer(offs.copy()), pa.py_buffer(data[:n].copy()))
+        eid = lc.ParquetArrayID.new(0, b // args.row_group_batches, 13, b % args.row_group_batches)
+        path = lc.ParquetArrayID.column_access_path(eid)
+        blob = cache.transcode(arr, lc.CacheExpression.SUBSTRING_SEARCH, path)
+        st = lo.symtab_load(cache.symbol_table(path))
+        for nd in needles:
+            got[nd] += int(lo.bench_eval_batches([blob], [st], lo.LIKE, ("%" + nd + "%").encode(), 1))
+            want[nd] += sum(nd.encode() in s for s in strs)
+    cache.close()
+    assert got == want and want["mail"] > 0 and want["ru/"] > want["mail"]
