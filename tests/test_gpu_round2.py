@@ -1489,3 +1489,97 @@ def test_like_matches_of_speculative_walks_are_not_matches(gpu_cache):
             assert int(counts[k]) == int(want.sum()), (needle, k, int(counts[k]), int(want.sum()))
             assert got.astype(bool).tolist() == want.tolist(), (needle, k)
     scan.close()
+
+
+def _adversarial_symtab(lo):
+    """A symbol table in which the codes of bytes that NO symbol covers (so they are always escaped in a stream: marker 255,
+    then the literal) hold symbols made of needle pieces: reading such a literal as a code 'decodes' text the value does
+    not contain."""
+    traps = {ord("#"): b"mail", ord("_"): b"ail.", ord("?"): b"gmai", ord("&"): b"l.ru", ord("="): b"email",
+             ord("%"): b"mai", ord("+"): b"ilbox"}
+    covered = b"abcdefghijklmnopqrstuvwxyz0123456789/:.-"
+    extra = [b"ht", b"tp", b"://", b"ru/", b".com", b"www.", b"ya", b"go", b"le"]
+    syms = {}
+    free = iter(c for c in range(255) if c not in traps)
+    for ch in covered:
+        syms[next(free)] = bytes([ch])
+    for e in extra:
+        syms[next(free)] = e
+    syms.update(traps)
+    n = max(syms) + 1
+    st = lo.SymTab()
+    st.n = n
+    for c in range(n):
+        b = syms.get(c, b"\x01")  # unused codes: a byte the data never holds
+        st.len[c] = len(b)
+        st.sym[c] = int.from_bytes(b, "little")
+    return lo.symtab_load(lo.symtab_bytes(st))
+
+
+def _adversarial_strings(rng, n):
+    alpha, traps = b"abcdefghijklmnopqrstuvwxyz0123456789/:.-", b"#_?&=%+"
+    pieces = [b"ma", b"ai", b"il", b"gm", b"em", b"l.", b".r", b"ru", b"bo", b"ox", b"lb"]   # every needle bigram, rarely a needle
+    rare = [b"mail", b"gmail", b"email", b"mailbox", b"ail.ru"]
+    out = []
+    for _ in range(n):
+        length, s = int(rng.integers(3, 100)), bytearray()
+        while len(s) < length:
+            r = rng.random()
+            if r < 0.18:
+                s.append(traps[int(rng.integers(len(traps)))])
+            elif r < 0.40:
+                s += pieces[int(rng.integers(len(pieces)))]
+            elif r < 0.405:
+                s += rare[int(rng.integers(len(rare)))]
+            else:
+                s.append(alpha[int(rng.integers(len(alpha)))])
+        out.append(bytes(s).decode())
+    return out
+
+
+@pytest.mark.gpu
+def test_like_on_an_adversarial_symbol_table(gpu_cache, oracle):
+    """LIKE / NOT LIKE over values full of escaped bytes whose CODES are symbols made of needle pieces, so that every
+    speculative walk of a word that follows an escape marker "sees" needle text: a CPU model of the lane-parallel walk
+    with the pre-fix rule (a match of any walk counts) reports 317 false matches among 1,758 signature candidates of
+    `%mail%` on this data, the fixpoint rule none.  Results as the oracle's, per entry (with / without selection, the
+    compacted BooleanArray) and through a scan; the oracle itself is compared with a plain substring test here."""
+    lo = oracle
+    rng = np.random.default_rng(7)
+    hint = lc.CacheExpression.SUBSTRING_SEARCH
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _check_pred
+    st = _adversarial_symtab(lo)
+    ids, blobs, all_strs = [], [], []
+    gpu_cache.set_symbol_table(8181, lo.symtab_bytes(st))
+    for k, (n, d, nulls) in enumerate(((8192, 4000, False), (8192, 900, True), (3000, 3000, False))):
+        pool = _adversarial_strings(rng, d)
+        strs = [pool[int(i)] for i in rng.integers(0, d, size=n)]
+        if nulls:
+            for i in rng.choice(n, size=n // 25, replace=False):
+                strs[int(i)] = None
+        liquid, _ = lo.encode_byte_view(strs, st=st, fingerprints=True)
+        eid = lc.ParquetArrayID.new(81, 0, 4, k)
+        gpu_cache.stage([eid], [liquid], [8181])
+        ids.append(eid)
+        blobs.append(liquid)
+        all_strs.append(strs)
+    needles = (b"mail", b"gmail", b"email", b"ail.r", b"mailbox", b"l.ru", b"ma")
+    for k, eid in enumerate(ids):
+        for nd in needles:
+            want = lo.eval_predicate(blobs[k], lo.LIKE, b"%" + nd + b"%", None, symtab=st)
+            truth = [s is not None and nd.decode() in s for s in all_strs[k]]
+            assert (want.values & (want.validity if want.validity is not None else True)).tolist() == truth   # the checker
+            for op in ("like", "not_like"):
+                sel = (rng.random(len(all_strs[k])) < 0.4).tolist() if rng.integers(2) else None
+                _check_pred(gpu_cache, lo, eid, blobs[k], op, b"%" + nd + b"%", pa.string(), sel, symtab=st, hint=hint)
+    scan = gpu_cache.scan(ids)
+    offs = scan.segment_offsets
+    for nd in needles:
+        mask, counts = scan.eval_to_host(lc.LiquidExpr.try_new("like", b"%" + nd + b"%", pa.string(), hint))
+        for k, strs in enumerate(all_strs):
+            truth = np.array([s is not None and nd.decode() in s for s in strs])
+            got = np.unpackbits(mask[int(offs[k]): int(offs[k + 1])].view(np.uint8), bitorder="little")[: len(strs)]
+            assert got.astype(bool).tolist() == truth.tolist(), (nd, k)
+            assert int(counts[k]) == int(truth.sum())
+    scan.close()
