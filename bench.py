@@ -231,6 +231,8 @@ def roofline(kernel, kernel_ms, alg_bytes, kernel_bytes, cold_ms=None, traffic=N
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
            "traffic": traffic, "traffic_source": traffic_src,
            "traffic_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+           # the same fraction by MEASURED HBM bytes (PMC): what the memory system actually delivered for this kernel
+           "frac_by_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
            "kernel": kernel, "kernel_ms": kernel_ms, "kernel_bytes_per_launch": int(kernel_bytes),
            "algorithmic_bytes_per_launch": int(alg_bytes), "effective_gbs": alg_bytes / (kernel_ms * 1e-3) / 1e9}
     if cold_ms is not None:
