@@ -15,6 +15,8 @@ r = d['roofline']
 print('primary %-18s ms %.4f frac %.3f | cold ms %.4f frac %.3f | kernel MB %.1f alg MB %.1f eff GB/s %.0f' % (
     r['kernel'], r['kernel_ms'], r['frac'], r.get('kernel_ms_l3_cold', 0), r.get('frac_l3_cold', 0),
     r['kernel_bytes_per_launch'] / 1e6, r['algorithmic_bytes_per_launch'] / 1e6, r['effective_gbs']))
+if r.get('frac_by_traffic'):
+    print('   by measured HBM traffic: %.1f MB per launch, frac %.3f' % (r['traffic'] / 1e6, r['frac_by_traffic']))
 if 'cpu_baseline' in d:
     print('cpu 1 core %.3e rows/s; all cores (%d) %.3e' % (d['cpu_baseline']['value'], d['cpu_baseline_all_cores']['cores'],
                                                          d['cpu_baseline_all_cores']['value']))
