@@ -53,6 +53,13 @@ LC_BENCH_API int32_t lc_calibrate_read(void* ctx, uint64_t bytes, int32_t shape,
  * number of bytes written (0: the entry carries no index, or `cap` is too small).  `ctx` is an lc_ctx*. */
 LC_BENCH_API size_t lc_debug_entry_signatures(void* ctx, uint64_t entry_id, uint8_t* out, size_t cap);
 
+/* Test aid (host only, no context): the inverted row lists lc_stage attaches to byte-view entries of substring-search
+ * columns — u16 offsets[d + 1], then the valid rows grouped by dictionary key — for `n` (<= 8192) keys, an optional
+ * LSB-first validity bitmap and a dictionary of `d` values.  Returns the number of u16 written to `out` (d + 1 + n + 32;
+ * 0: bad arguments or `cap` too small). */
+LC_BENCH_API size_t lc_debug_row_lists(const uint16_t* keys, const uint8_t* validity, uint32_t n, uint32_t d, uint16_t* out,
+                                       size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

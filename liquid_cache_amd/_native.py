@@ -73,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
     # include/liquid_cache_amd_bench.h
-    "lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch", "lc_calibrate_read", "lc_debug_entry_signatures",
+    "lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch", "lc_calibrate_read", "lc_debug_entry_signatures", "lc_debug_row_lists",
 ]
 
 _lib = None
@@ -157,6 +157,8 @@ def load():
     L.lc_calibrate_read.restype = i32; L.lc_calibrate_read.argtypes = [vp, u64, i32, i32]
     L.lc_debug_entry_signatures.restype = sz
     L.lc_debug_entry_signatures.argtypes = [vp, u64, vp, sz]
+    L.lc_debug_row_lists.restype = sz
+    L.lc_debug_row_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, sz]
     L.lc_synth_title_batch.restype = sz
     L.lc_synth_title_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
     L.lc_synth_phrase_batch.restype = sz

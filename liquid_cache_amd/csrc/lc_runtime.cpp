@@ -470,6 +470,23 @@ lc_status build_fixed(const uint8_t* bytes, size_t len, Entry* e, Blob* blob, si
     return LC_OK;
 }
 
+// Inverted row lists of a byte-view entry (lc_kernels.hpp): u16 offsets[D + 1], then the VALID rows grouped by key — a
+// counting sort.  Keys of null slots may be garbage (the reference allows it) and keys >= D cannot be listed: both are
+// skipped, as map_dictionary_results_to_array_results never yields a hit for them.  32 spare entries behind the rows.
+std::vector<uint16_t> build_row_lists(const uint16_t* keys, const uint8_t* validity, uint32_t n, uint32_t d) {
+    std::vector<uint16_t> post(size_t(d) + 1 + size_t(n) + 32, 0);
+    uint16_t* off = post.data();
+    uint16_t* rows = post.data() + d + 1;
+    auto valid = [&](uint32_t r) { return !validity || ((validity[r >> 3] >> (r & 7)) & 1); };
+    for (uint32_t r = 0; r < n; r++)
+        if (valid(r) && keys[r] < d) off[size_t(keys[r]) + 1]++;
+    for (uint32_t k = 0; k < d; k++) off[k + 1] = uint16_t(off[k + 1] + off[k]);
+    std::vector<uint16_t> cursor(off, off + d);
+    for (uint32_t r = 0; r < n; r++)
+        if (valid(r) && keys[r] < d) rows[cursor[keys[r]]++] = uint16_t(r);
+    return post;
+}
+
 lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path_id, Entry* e, Blob* blob,
                     size_t offs[9]) {
     ByteViewParsed v;
@@ -555,17 +572,7 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
         offs[7] = blob->add(sig.data(), sig.size() * 8);
     }
     if (v.fingerprints && ctx->build_signatures && ctx->build_postings && v.n <= kPostMaxRows && v.d > 0 && !v.all_null) {
-        // inverted row lists (lc_kernels.hpp): counting sort of the valid rows by dictionary key
-        std::vector<uint16_t> post(size_t(v.d) + 1 + size_t(v.n) + 32, 0);
-        uint16_t* off = post.data();
-        uint16_t* rows = post.data() + v.d + 1;
-        auto valid = [&](uint32_t r) { return !v.nullable || ((v.key_validity[r >> 3] >> (r & 7)) & 1); };
-        for (uint32_t r = 0; r < v.n; r++)
-            if (valid(r) && v.keys[r] < v.d) off[size_t(v.keys[r]) + 1]++;
-        for (uint32_t k = 0; k < v.d; k++) off[k + 1] = uint16_t(off[k + 1] + off[k]);
-        std::vector<uint16_t> cursor(off, off + v.d);
-        for (uint32_t r = 0; r < v.n; r++)
-            if (valid(r) && v.keys[r] < v.d) rows[cursor[v.keys[r]]++] = uint16_t(r);
+        const std::vector<uint16_t> post = build_row_lists(v.keys.data(), v.nullable ? v.key_validity : nullptr, v.n, v.d);
         offs[8] = blob->add(post.data(), post.size() * 2, kSectionAlign, 16);
     }
     return LC_OK;
@@ -2184,6 +2191,14 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
     if (d_final_mask) *d_final_mask = const_cast<void*>(sel);
     return LC_OK;
     });
+}
+
+size_t lc_debug_row_lists(const uint16_t* keys, const uint8_t* validity, uint32_t n, uint32_t d, uint16_t* out, size_t cap) {
+    if (!keys || !out || n > kPostMaxRows || d == 0) return 0;
+    const std::vector<uint16_t> post = build_row_lists(keys, validity, n, d);
+    if (post.size() > cap) return 0;
+    std::memcpy(out, post.data(), post.size() * 2);
+    return post.size();
 }
 
 size_t lc_debug_entry_signatures(void* ctx_, uint64_t entry_id, uint8_t* out, size_t cap) {

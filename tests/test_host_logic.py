@@ -283,3 +283,29 @@ def test_bench_cpu_baseline_counts_are_the_substring_truth():
             want[nd] += sum(nd.encode() in s for s in strs)
     cache.close()
     assert got == want and want["mail"] > 0 and want["ru/"] > want["mail"]
+
+
+def test_inverted_row_lists_layout(product_lib):
+    """The row lists lc_stage attaches to byte-view entries: offsets[d + 1] is a running sum, the rows of key k
+    are exactly the VALID rows whose key is k (any order within a key), rows under nulls and keys >= d are not listed."""
+    rng = np.random.default_rng(12)
+    for n, d, p_null in ((8192, 2200, 0.05), (8192, 1, 0.0), (77, 500, 0.5), (1, 1, 0.0), (8192, 8192, 0.0)):
+        keys = rng.integers(0, d, size=n).astype(np.uint16)
+        valid = rng.random(n) >= p_null
+        keys[~valid] = rng.integers(0, 65536, size=int((~valid).sum())).astype(np.uint16)   # garbage under nulls
+        bitmap = np.packbits(valid, bitorder="little")
+        out = np.zeros(d + 1 + n + 32, np.uint16)
+        got = product_lib.lc_debug_row_lists(keys.ctypes.data, bitmap.ctypes.data if p_null else None, n, d,
+                                            out.ctypes.data, out.size)
+        assert got == out.size
+        off, rows = out[: d + 1].astype(np.int64), out[d + 1: d + 1 + n]
+        assert off[0] == 0 and (np.diff(off) >= 0).all() and off[d] == int(valid.sum())
+        for k in set(rng.integers(0, d, size=min(d, 200)).tolist()) | {0, d - 1}:
+            want = np.nonzero(valid & (keys == k))[0]
+            assert sorted(rows[off[k]: off[k + 1]].tolist()) == want.tolist(), (n, d, k)
+    # out of contract: more rows than an entry with lists may have, no dictionary, a short buffer
+    big = np.zeros(9000, np.uint16)
+    out = np.zeros(20000, np.uint16)
+    assert product_lib.lc_debug_row_lists(big.ctypes.data, None, 9000, 10, out.ctypes.data, out.size) == 0
+    assert product_lib.lc_debug_row_lists(big.ctypes.data, None, 100, 0, out.ctypes.data, out.size) == 0
+    assert product_lib.lc_debug_row_lists(big.ctypes.data, None, 100, 10, out.ctypes.data, 50) == 0
