@@ -70,6 +70,10 @@ def parse_args(argv=None):
     p.add_argument("--no-fingerprints", action="store_true",
                    help="url_like: stage the column without the SubstringSearch hint (no fingerprints, no signature index: "
                         "every dictionary value is walked)")
+    p.add_argument("--no-signatures", action="store_true",
+                   help="url_like: stage without the bigram signature index (reference layout only: the reference's "
+                        "fingerprint prefilter decides the candidates)")
+    p.add_argument("--no-row-lists", action="store_true", help="url_like: stage without the inverted row lists")
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
     p.add_argument("--no-secondary", action="store_true", help="skip every secondary workload (profiling runs)")
     p.add_argument("--no-cold", action="store_true",
@@ -99,7 +103,7 @@ def stage_url_column(cache, lc, N, args, rank, n_batches, threads, file_id=None)
         first = rg * args.row_group_batches
         for b in range(first, min(first + args.row_group_batches, n_batches)):
             rows = min(bs, rows_total - b * bs)
-            n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
+            n = N.load_bench().lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
                                      offs.ctypes.data, data.ctypes.data, data.size)
             arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
             cache.insert(ids[b], arr, None if args.no_fingerprints else lc.CacheExpression.SUBSTRING_SEARCH)
@@ -125,7 +129,7 @@ def stage_phrase_column(cache, lc, N, args, rank, n_batches, threads):
         first = rg * args.row_group_batches
         for b in range(first, min(first + args.row_group_batches, n_batches)):
             rows = min(bs, args.rows - b * bs)
-            n = L.lc_synth_phrase_batch(args.seed + rank * 1_000_003, b, rows, 600, 870, offs.ctypes.data,
+            n = N.load_bench().lc_synth_phrase_batch(args.seed + rank * 1_000_003, b, rows, 600, 870, offs.ctypes.data,
                                         data.ctypes.data, data.size)
             arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:max(n, 1)]))
             cache.insert(ids[b], arr)
@@ -164,7 +168,7 @@ def stage_int_column(cache, lc, N, args, rank, rows_total, threads, bits=None, b
         buf = np.zeros(bs, np.int64)
         for b in range(c, n_batches, threads):
             rows = min(bs, rows_total - b * bs)
-            L.lc_synth_int64_batch(args.seed + rank * 1_000_003 + col * 7919, b, rows, bits, base, buf.ctypes.data)
+            N.load_bench().lc_synth_int64_batch(args.seed + rank * 1_000_003 + col * 7919, b, rows, bits, base, buf.ctypes.data)
             v = buf[:rows]
             if on_batch is not None:
                 on_batch(b, v)
@@ -392,13 +396,14 @@ def q6_literals():
 
 
 def q6_synth_batch(L, seed, global_batch, n, bufs):
+    from liquid_cache_amd import _native as N
     """Synthetic lineitem columns of one batch, keyed by the GLOBAL batch index.  ship: 2^12 days from 1992-01-02 (W=12;
     the SF100 column spans 2,526 days); discount 0..15 hundredths (W=4, TPC-H has 0..10); quantity 1..64, x100 as the
     unscaled Decimal(15,2) (W=13, TPC-H has 1..50)."""
     ship, disc, qty = bufs
-    L.lc_synth_int64_batch(seed + 101, global_batch, n, 12, q6_literals()[0], ship.ctypes.data)
-    L.lc_synth_int64_batch(seed + 102, global_batch, n, 4, 0, disc.ctypes.data)
-    L.lc_synth_int64_batch(seed + 103, global_batch, n, 6, 1, qty.ctypes.data)
+    N.load_bench().lc_synth_int64_batch(seed + 101, global_batch, n, 12, q6_literals()[0], ship.ctypes.data)
+    N.load_bench().lc_synth_int64_batch(seed + 102, global_batch, n, 4, 0, disc.ctypes.data)
+    N.load_bench().lc_synth_int64_batch(seed + 103, global_batch, n, 6, 1, qty.ctypes.data)
     return ship[:n], disc[:n], qty[:n] * 100
 
 
@@ -586,7 +591,7 @@ def secondary_transcode_rate(cache, lc, N, args, rows, threads):
         buf = np.zeros(bs, np.int64)
         arrays = []
         for b in range(n_batches):
-            L.lc_synth_int64_batch(args.seed + 7, b, bs, bits, base, buf.ctypes.data)
+            N.load_bench().lc_synth_int64_batch(args.seed + 7, b, bs, bits, base, buf.ctypes.data)
             arrays.append(to_arrow(buf.copy()))
         ids_h = [lc.ParquetArrayID.new(8, b // args.row_group_batches, 1, b % args.row_group_batches) for b in range(n_batches)]
         ids_d = [lc.ParquetArrayID.new(8, b // args.row_group_batches, 2, b % args.row_group_batches) for b in range(n_batches)]
@@ -617,19 +622,11 @@ def secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream
     import copy
     import pyarrow as pa
     out = {}
-    for name, env, nofp in (("url_like_no_signatures", {"LC_NO_SIGNATURES": "1"}, False),
-                            ("url_like_no_fingerprints", {}, True)):
+    for name, sig, nofp in (("url_like_no_signatures", False, False),
+                            ("url_like_no_fingerprints", True, True)):
         try:
-            old = {k: os.environ.get(k) for k in env}
-            os.environ.update(env)
-            try:
-                cache2 = lc.LiquidCacheBuilder.new().with_device(torch.cuda.current_device()).build()
-            finally:
-                for k, v in old.items():
-                    if v is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = v
+            cache2 = (lc.LiquidCacheBuilder.new().with_device(torch.cuda.current_device())
+                      .with_index_options(signatures=sig).build())
             a2 = copy.copy(args)
             a2.no_fingerprints = nofp
             ids = stage_url_column(cache2, lc, N, a2, rank, n_batches, threads)
@@ -711,7 +708,7 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads, extra
         data = np.zeros(bs * 512, np.uint8)
         for b in range(c, n_sample, threads):
             rows = min(bs, args.rows - b * bs)
-            n = L.lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
+            n = N.load_bench().lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
                                      offs.ctypes.data, data.ctypes.data, data.size)
             arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
             eid = lc.ParquetArrayID.new(rank, b // args.row_group_batches, 13, b % args.row_group_batches)
@@ -752,7 +749,7 @@ def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal, base):
     rows_total = 0
     for b in range(n_sample):
         rows = min(bs, args.rows - b * bs)
-        L.lc_synth_int64_batch(args.seed + rank * 1_000_003, b, rows, args.int_bits, base, buf.ctypes.data)
+        N.load_bench().lc_synth_int64_batch(args.seed + rank * 1_000_003, b, rows, args.int_bits, base, buf.ctypes.data)
         v = buf[:rows]
         if args.int_kind == "int16":
             arr = pa.array(v.astype(np.int16))
@@ -936,7 +933,8 @@ def main():
     from liquid_cache_amd import _native as N
     import pyarrow as pa
 
-    cache = lc.LiquidCacheBuilder.new().with_device(local_rank).with_batch_size(args.batch_size).build()
+    cache = (lc.LiquidCacheBuilder.new().with_device(local_rank).with_batch_size(args.batch_size)
+             .with_index_options(signatures=not args.no_signatures, row_lists=not args.no_row_lists).build())
     n_batches = (args.rows + args.batch_size - 1) // args.batch_size
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, min(world, 8))))
 
@@ -1033,7 +1031,7 @@ def main():
     if rank == 0:
         if args.workload == "url_like":
             tkey = "url_like_no_fingerprints" if args.no_fingerprints else (
-                "url_like_no_signatures" if os.environ.get("LC_NO_SIGNATURES", "0") not in ("", "0") else "url_like")
+                "url_like_no_signatures" if args.no_signatures else "url_like")
         else:
             tkey = "%s_gt_w%d" % (args.int_kind, args.int_bits)
         traffic, traffic_src = measured_traffic(tkey)

@@ -148,6 +148,19 @@ struct ArrowArray {
  * (reference default max_memory_bytes is 1 GiB; HBM has 288 GB, the arena grows in slabs). */
 LC_API lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t max_hbm_bytes, lc_ctx** out);
 LC_API void lc_ctx_destroy(lc_ctx* ctx);
+/* Staging options of a context (set them before staging; entries already staged keep what they were staged with).  The
+ * library reads NO environment variable: nothing outside these calls changes what is staged or how it is evaluated.
+ * Results are identical under every combination (tested); only HBM use and speed differ.
+ *   LC_OPT_SIGNATURE_INDEX  (default 1) byte views of substring-search columns get the bit-sliced bigram signature index
+ *                           (+ ~25 % HBM per entry); 0 = the reference layout only: LIKE runs the reference's
+ *                           fingerprint filter (byte_view_array/fingerprint.rs) and walks its candidates
+ *   LC_OPT_ROW_LISTS        (default 1) such entries also get inverted row lists (+ ~12 %)
+ *   LC_OPT_HOST_BUILT_INDEX (default 0) 1 = the signature index is built by the host while staging instead of by the
+ *                           device kernel (bit-identical; kept as the device builder's cross-check) */
+#define LC_OPT_SIGNATURE_INDEX 1
+#define LC_OPT_ROW_LISTS 2
+#define LC_OPT_HOST_BUILT_INDEX 3
+LC_API lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value);
 LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
 LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);
 LC_API const char* lc_version(void);
@@ -200,6 +213,17 @@ LC_API lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t*
  * (byte_view_array/serialization.rs:122-220: keys at 16 bits, raw FSST buffer, compact offsets, prefix keys, shared
  * prefix, fingerprints).  LC_NEEDS_BACKING for squeezed entries (they no longer hold the full array). */
 LC_API lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out_bytes, size_t* out_len);
+/* The device-side acceleration index of a byte-view entry (bigram signature slices + inverted row lists: DESIGN.md §2;
+ * not part of the reference format) as one opaque, versioned blob (malloc'ed; release with lc_free; *out_len == 0 when
+ * the entry carries none).  A disk tier that keeps it beside the Liquid bytes hands it back to lc_stage_indexed and the
+ * entry becomes visible without the index being rebuilt (80 us of device time and a counting sort per entry). */
+LC_API lc_status lc_entry_index_to_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out_bytes, size_t* out_len);
+/* lc_stage with prebuilt indexes: index_bytes[i] (may be NULL) is what lc_entry_index_to_bytes returned for the same
+ * Liquid bytes.  A blob that does not describe exactly this entry (dictionary size, rows, signature width, section sizes,
+ * list bounds) is ignored and the index is rebuilt: a stale or foreign blob can cost time, never a result. */
+LC_API lc_status lc_stage_indexed(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes,
+                                  const size_t* lens, const uint64_t* path_ids, const uint8_t* const* index_bytes,
+                                  const size_t* index_lens);
 LC_API void lc_free(void* p);
 /* Export the registered symbol table of `path_id` in save_symbol_table format (malloc'ed). */
 LC_API lc_status lc_symtab_get(lc_ctx* ctx, uint64_t path_id, uint8_t** out_bytes, size_t* out_len);

@@ -1,4 +1,5 @@
 /*
+ * Bench / test aids, built into libliquid_cache_amd_bench.so (never into the product library).
  * Synthetic ClickBench-shaped column generators used by bench.py and the full-size tests.
  * They only produce Arrow-layout host buffers; everything downstream goes through the public API in
  * liquid_cache_amd.h (lc_insert_arrow / lc_scan_*).  There is no dataset access on the benchmark machines
@@ -47,11 +48,6 @@ LC_BENCH_API void lc_synth_int64_batch(uint64_t seed, uint64_t batch_index, uint
  * sector — so that rocprofv3's FETCH_SIZE can be calibrated on the access patterns of the scan kernels (the counter's
  * unit is only documented for 16-byte coalesced reads).  `ctx` is an lc_ctx*. */
 LC_BENCH_API int32_t lc_calibrate_read(void* ctx, uint64_t bytes, int32_t shape, int32_t iters);
-
-/* Test aid: copy of the bigram signature slices of a staged byte-view entry (kSigBits x ceil(D/64) u64 words, slice
- * major), so that the device-built index can be compared with the host-built one (LC_HOST_SIGNATURES=1).  Returns the
- * number of bytes written (0: the entry carries no index, or `cap` is too small).  `ctx` is an lc_ctx*. */
-LC_BENCH_API size_t lc_debug_entry_signatures(void* ctx, uint64_t entry_id, uint8_t* out, size_t cap);
 
 /* Test aid (host only, no context): the inverted row lists lc_stage attaches to byte-view entries of substring-search
  * columns — u16 offsets[d + 1], then the valid rows grouped by dictionary key — for `n` (<= 8192) keys, an optional

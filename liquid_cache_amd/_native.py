@@ -17,6 +17,7 @@ LC_ERR_INVALID, LC_ERR_CORRUPT, LC_ERR_DEVICE, LC_ERR_OOM, LC_ERR_NO_SYMTAB = -1
 OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_LIKE, OP_NOT_LIKE = range(8)
 LIT_I64, LIT_U64, LIT_F32, LIT_F64, LIT_BYTES, LIT_I128, LIT_BOOL = range(7)
 HINT_NONE, HINT_SUBSTRING_SEARCH, HINT_PREDICATE_COLUMN = 0, 1, 2
+OPT_SIGNATURE_INDEX, OPT_ROW_LISTS, OPT_HOST_BUILT_INDEX = 1, 2, 3
 
 
 class LiquidCacheError(RuntimeError):
@@ -65,18 +66,44 @@ ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offse
 
 # every symbol include/liquid_cache_amd.h declares (tests check that the built library exports all of them)
 EXPORTED_SYMBOLS = [
-    "lc_ctx_create", "lc_ctx_destroy", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
+    "lc_ctx_create", "lc_ctx_destroy", "lc_ctx_set_option", "lc_entry_index_to_bytes", "lc_stage_indexed", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
     "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold", "lc_scan_eval_or", "lc_eval_predicate_or", "lc_insert_arrow_device", "lc_entry_to_liquid_bytes", "lc_squeeze_date", "lc_squeeze_clamp", "lc_squeeze_quantize", "lc_scan_aggregate", "lc_scan_sum_product", "lc_scan_eval_filter",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
-    # include/liquid_cache_amd_bench.h
-    "lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch", "lc_calibrate_read", "lc_debug_entry_signatures", "lc_debug_row_lists",
 ]
+# include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
+BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
+                 "lc_calibrate_read", "lc_debug_row_lists"]
 
 _lib = None
+_bench = None
+BENCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libliquid_cache_amd_bench.so")
+
+
+def load_bench():
+    """The bench / test aid library (synthetic ClickBench-shaped column generators, PMC calibration kernels)."""
+    global _bench
+    if _bench is not None:
+        return _bench
+    load()  # the aid library links the product library
+    if not os.path.exists(BENCH_LIB_PATH):
+        raise ImportError(f"{BENCH_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+    B = C.CDLL(BENCH_LIB_PATH)
+    vp, u64, i32, sz = C.c_void_p, C.c_uint64, C.c_int32, C.c_size_t
+    for name in ("lc_synth_url_batch", "lc_synth_title_batch", "lc_synth_phrase_batch"):
+        getattr(B, name).restype = sz
+        getattr(B, name).argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
+    B.lc_synth_int64_batch.restype = None
+    B.lc_synth_int64_batch.argtypes = [u64, u64, C.c_uint32, i32, C.c_int64, vp]
+    B.lc_calibrate_read.restype = i32
+    B.lc_calibrate_read.argtypes = [vp, u64, i32, i32]
+    B.lc_debug_row_lists.restype = sz
+    B.lc_debug_row_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, sz]
+    _bench = B
+    return B
 
 
 def load():
@@ -88,17 +115,20 @@ def load():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). liquid_cache_amd has no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
     vp, u64, i32, sz = C.c_void_p, C.c_uint64, C.c_int32, C.c_size_t
     P = C.POINTER
     L.lc_version.restype = C.c_char_p
     L.lc_last_error.restype = C.c_char_p; L.lc_last_error.argtypes = [vp]
     L.lc_ctx_create.restype = i32; L.lc_ctx_create.argtypes = [P(C.c_int32), i32, u64, P(vp)]
     L.lc_ctx_destroy.restype = None; L.lc_ctx_destroy.argtypes = [vp]
+    L.lc_ctx_set_option.restype = i32; L.lc_ctx_set_option.argtypes = [vp, i32, C.c_int64]
     L.lc_device_info_get.restype = i32; L.lc_device_info_get.argtypes = [vp, P(DeviceInfo)]
     L.lc_symtab_set.restype = i32; L.lc_symtab_set.argtypes = [vp, u64, vp, sz]
     L.lc_symtab_get.restype = i32; L.lc_symtab_get.argtypes = [vp, u64, P(vp), P(sz)]
     L.lc_stage.restype = i32; L.lc_stage.argtypes = [vp, u64, P(u64), P(vp), P(sz), P(u64)]
+    L.lc_stage_indexed.restype = i32; L.lc_stage_indexed.argtypes = [vp, u64, P(u64), P(vp), P(sz), P(u64), P(vp), P(sz)]
+    L.lc_entry_index_to_bytes.restype = i32; L.lc_entry_index_to_bytes.argtypes = [vp, u64, P(vp), P(sz)]
     L.lc_evict.restype = i32; L.lc_evict.argtypes = [vp, u64, P(u64)]
     L.lc_entry_info_get.restype = i32; L.lc_entry_info_get.argtypes = [vp, u64, P(EntryInfo)]
     L.lc_transcode_arrow.restype = i32; L.lc_transcode_arrow.argtypes = [vp, vp, vp, i32, u64, P(vp), P(sz)]
@@ -152,19 +182,6 @@ def load():
     L.lc_device_to_host.restype = i32; L.lc_device_to_host.argtypes = [vp, vp, vp, u64, vp]
     L.lc_host_to_device.restype = i32; L.lc_host_to_device.argtypes = [vp, vp, vp, u64, vp]
     L.lc_stream_synchronize.restype = i32; L.lc_stream_synchronize.argtypes = [vp, vp]
-    L.lc_synth_url_batch.restype = sz
-    L.lc_synth_url_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
-    L.lc_calibrate_read.restype = i32; L.lc_calibrate_read.argtypes = [vp, u64, i32, i32]
-    L.lc_debug_entry_signatures.restype = sz
-    L.lc_debug_entry_signatures.argtypes = [vp, u64, vp, sz]
-    L.lc_debug_row_lists.restype = sz
-    L.lc_debug_row_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, sz]
-    L.lc_synth_title_batch.restype = sz
-    L.lc_synth_title_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
-    L.lc_synth_phrase_batch.restype = sz
-    L.lc_synth_phrase_batch.argtypes = [u64, u64, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, sz]
-    L.lc_synth_int64_batch.restype = None
-    L.lc_synth_int64_batch.argtypes = [u64, u64, C.c_uint32, i32, C.c_int64, vp]
     _lib = L
     return L
 

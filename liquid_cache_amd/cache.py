@@ -200,6 +200,7 @@ class LiquidCacheBuilder:
         self.max_memory_bytes = 0  # 0: bounded by HBM only (the reference default is 1 GiB of host RAM)
         self.device: Optional[int] = None
         self.host_only = False
+        self.options = {}  # lc_ctx_set_option(option, value) pairs applied right after the context is created
 
     @staticmethod
     def new() -> "LiquidCacheBuilder":
@@ -220,6 +221,18 @@ class LiquidCacheBuilder:
     def with_host_only(self) -> "LiquidCacheBuilder":
         """Transcoding / symbol tables only (no GPU): every staging or evaluation call raises."""
         self.host_only = True
+        return self
+
+    def with_index_options(self, signatures: Optional[bool] = None, row_lists: Optional[bool] = None,
+                           host_built: Optional[bool] = None) -> "LiquidCacheBuilder":
+        """The device-side acceleration structures of substring-search byte views (include/liquid_cache_amd.h,
+        lc_ctx_set_option): bigram signature index, inverted row lists, host-built index.  Results never depend on them."""
+        if signatures is not None:
+            self.options[N.OPT_SIGNATURE_INDEX] = int(bool(signatures))
+        if row_lists is not None:
+            self.options[N.OPT_ROW_LISTS] = int(bool(row_lists))
+        if host_built is not None:
+            self.options[N.OPT_HOST_BUILT_INDEX] = int(bool(host_built))
         return self
 
     def build(self) -> "LiquidCache":
@@ -271,6 +284,8 @@ class LiquidCache:
         N.check(st, None)
         self._ctx = ctx
         self._types = {}
+        for opt, val in builder.options.items():
+            N.check(self._lib.lc_ctx_set_option(self._ctx, opt, val), self._ctx)
 
     # -- lifecycle ---------------------------------------------------------------------------------
     def close(self):
@@ -319,9 +334,12 @@ class LiquidCache:
         return data
 
     def stage(self, entry_ids: Sequence[int], liquid_bytes: Sequence[bytes], path_ids: Optional[Sequence[int]] = None,
-              data_types: Optional[Sequence[pa.DataType]] = None):
-        """Stage serialized LiquidArrays (`LiquidArray::to_bytes()` output) in HBM."""
+              data_types: Optional[Sequence[pa.DataType]] = None, index_bytes: Optional[Sequence[Optional[bytes]]] = None):
+        """Stage serialized LiquidArrays (`LiquidArray::to_bytes()` output) in HBM; `index_bytes[i]` (optional) is the
+        acceleration index `entry_index_bytes` returned for the same bytes (lc_stage_indexed)."""
         n = len(entry_ids)
+        if index_bytes is not None:
+            return self._stage_indexed(entry_ids, liquid_bytes, path_ids, data_types, index_bytes)
         ids = (C.c_uint64 * n)(*[int(e) for e in entry_ids])
         keep = [(C.c_uint8 * len(b)).from_buffer_copy(b) for b in liquid_bytes]
         ptrs = (C.c_void_p * n)(*[C.cast(k, C.c_void_p) for k in keep])
@@ -333,6 +351,35 @@ class LiquidCache:
         if data_types is not None:
             for e, t in zip(entry_ids, data_types):
                 self._types[int(e)] = t
+
+    def _stage_indexed(self, entry_ids, liquid_bytes, path_ids, data_types, index_bytes):
+        n = len(entry_ids)
+        ids = (C.c_uint64 * n)(*[int(e) for e in entry_ids])
+        keep = [(C.c_uint8 * len(b)).from_buffer_copy(b) for b in liquid_bytes]
+        ptrs = (C.c_void_p * n)(*[C.cast(k, C.c_void_p) for k in keep])
+        lens = (C.c_size_t * n)(*[len(b) for b in liquid_bytes])
+        if path_ids is None:
+            path_ids = [ParquetArrayID.column_access_path(e) for e in entry_ids]
+        pids = (C.c_uint64 * n)(*[int(p) for p in path_ids])
+        ikeep = [None if b is None else (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0") for b in index_bytes]
+        iptrs = (C.c_void_p * n)(*[None if k is None else C.cast(k, C.c_void_p) for k in ikeep])
+        ilens = (C.c_size_t * n)(*[0 if b is None else len(b) for b in index_bytes])
+        N.check(self._lib.lc_stage_indexed(self._ctx, n, ids, ptrs, lens, pids, iptrs, ilens), self._ctx)
+        if data_types is not None:
+            for e, t in zip(entry_ids, data_types):
+                self._types[int(e)] = t
+
+    def entry_index_bytes(self, entry_id: int) -> Optional[bytes]:
+        """The entry's device-side acceleration index as an opaque blob (lc_entry_index_to_bytes); b"" if it has none."""
+        out, ln = C.c_void_p(), C.c_size_t()
+        st = self._lib.lc_entry_index_to_bytes(self._ctx, int(entry_id), C.byref(out), C.byref(ln))
+        if st == N.LC_NOT_STAGED:
+            return None
+        N.check(st, self._ctx)
+        data = C.string_at(out, ln.value) if ln.value else b""
+        if out.value:
+            self._lib.lc_free(out)
+        return data
 
     def transcode(self, array: pa.Array, squeeze_hint: Optional[int] = None, path_id: int = 0) -> Optional[bytes]:
         """Arrow -> Liquid bytes (transcode_liquid_inner_with_hint); None for types that stay Arrow."""

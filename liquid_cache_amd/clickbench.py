@@ -95,9 +95,9 @@ def synth_batch(name: str, seed: int, b: int, rows: int, scratch=None) -> pa.Arr
         data = np.zeros(rows * 512, np.uint8) if scratch is None else scratch
         s = seed * 131 + cid
         if name == "URL":
-            n = L.lc_synth_url_batch(s, b, rows, min(2200, rows), 159, offs.ctypes.data, data.ctypes.data, data.size)
+            n = N.load_bench().lc_synth_url_batch(s, b, rows, min(2200, rows), 159, offs.ctypes.data, data.ctypes.data, data.size)
         elif name == "Referer":  # URL shaped; about one row in five has no referer
-            n = L.lc_synth_url_batch(s, b, rows, min(1500, rows), 400, offs.ctypes.data, data.ctypes.data, data.size)
+            n = N.load_bench().lc_synth_url_batch(s, b, rows, min(1500, rows), 400, offs.ctypes.data, data.ctypes.data, data.size)
             blank = np.random.default_rng([seed, cid, b]).random(rows) < 0.2
             lens = np.diff(offs)
             kept = data[:n][np.repeat(~blank, lens)]
@@ -105,11 +105,11 @@ def synth_batch(name: str, seed: int, b: int, rows: int, scratch=None) -> pa.Arr
             data[: kept.size] = kept
             n = int(kept.size)
         elif name == "Title":
-            n = L.lc_synth_title_batch(s, b, rows, min(1750, rows), 900, offs.ctypes.data, data.ctypes.data, data.size)
+            n = N.load_bench().lc_synth_title_batch(s, b, rows, min(1750, rows), 900, offs.ctypes.data, data.ctypes.data, data.size)
         elif name == "MobilePhoneModel":
-            n = L.lc_synth_phrase_batch(s, b, rows, 160, 940, offs.ctypes.data, data.ctypes.data, data.size)
+            n = N.load_bench().lc_synth_phrase_batch(s, b, rows, 160, 940, offs.ctypes.data, data.ctypes.data, data.size)
         else:
-            n = L.lc_synth_phrase_batch(s, b, rows, 600, 870, offs.ctypes.data, data.ctypes.data, data.size)
+            n = N.load_bench().lc_synth_phrase_batch(s, b, rows, 600, 870, offs.ctypes.data, data.ctypes.data, data.size)
         return pa.StringArray.from_buffers(rows, pa.py_buffer(offs), pa.py_buffer(data[:max(n, 1)].copy()))
     rng = np.random.default_rng([seed, cid, b])
     if name == "EventDate":       # July 2013 with a little June / August

@@ -1,0 +1,93 @@
+// Bench / profiling / test aids (include/liquid_cache_amd_bench.h).  Built into libliquid_cache_amd_bench.so, NOT into the
+// product library: the synthetic column generators (lc_synth.cpp), the PMC counter calibration kernels and the host-side
+// row-list builder aid live here and reach the product only through its public C ABI.
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/liquid_cache_amd.h"
+#include "../../include/liquid_cache_amd_bench.h"
+#include "lc_host.hpp"
+#include "lc_kernels.hpp"
+
+namespace {
+
+template <typename T>
+__device__ __forceinline__ T load_unaligned(const uint8_t* p) {
+    T v;
+    __builtin_memcpy(&v, (const __attribute__((address_space(1))) uint8_t*)p, sizeof(T));
+    return v;
+}
+
+
+// Counter calibration (scripts/pmc_calibrate.py): read a KNOWN number of bytes with a given access shape, so that
+// rocprofv3's FETCH_SIZE can be converted into bytes for that shape instead of assuming the factor of another one.
+//   k_calib_read<W>          every lane reads W consecutive bytes, lanes adjacent (coalesced): W = 4, 8, 16
+//   k_calib_read_scattered8  every lane reads 8 unaligned bytes out of its own 64-byte sector (the FSST word loads and
+//                            offset-pair loads of k_str_pred look like this): 64 useful... 8 useful bytes per sector
+template <int W>
+__global__ __launch_bounds__(256) void k_calib_read(const uint8_t* __restrict__ src, uint64_t bytes, uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    const uint64_t n = bytes / W;
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
+        if constexpr (W == 4) acc ^= reinterpret_cast<const uint32_t*>(src)[i];
+        else if constexpr (W == 8) { const uint2 v = reinterpret_cast<const uint2*>(src)[i]; acc ^= v.x ^ v.y; }
+        else { const uint4 v = reinterpret_cast<const uint4*>(src)[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    }
+    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_calib_read_scattered8(const uint8_t* __restrict__ src, uint64_t bytes,
+                                                                uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    const uint64_t n = bytes / 64;  // one access per 64-byte sector
+    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
+        const uint64_t v = load_unaligned<uint64_t>(src + i * 64 + 3 + (i % 7) * 7);
+        acc ^= uint32_t(v) ^ uint32_t(v >> 32);
+    }
+    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+int32_t lc_calibrate_read(void* ctx_, uint64_t bytes, int32_t shape, int32_t iters) {
+    lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
+    if (!ctx || bytes < 4096 || iters <= 0) return LC_ERR_INVALID;
+    lc_device_info info;
+    if (lc_device_info_get(ctx, &info) != LC_OK || info.device_id < 0) return LC_ERR_DEVICE;
+    if (hipSetDevice(info.device_id) != hipSuccess) return LC_ERR_DEVICE;
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes + 8192) != hipSuccess) return LC_ERR_OOM;
+    int32_t rc = LC_OK;
+    if (hipMemset(d, 1, bytes + 8192) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = LC_ERR_DEVICE;
+    const uint8_t* p = static_cast<const uint8_t*>(d);
+    uint32_t* sink = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d) + bytes);
+    const dim3 grid(2048), block(256);
+    for (int i = 0; i < iters && rc == LC_OK; i++) {
+        switch (shape) {
+            case 4: hipLaunchKernelGGL(k_calib_read<4>, grid, block, 0, nullptr, p, bytes, sink); break;
+            case 8: hipLaunchKernelGGL(k_calib_read<8>, grid, block, 0, nullptr, p, bytes, sink); break;
+            case 16: hipLaunchKernelGGL(k_calib_read<16>, grid, block, 0, nullptr, p, bytes, sink); break;
+            case 1008: hipLaunchKernelGGL(k_calib_read_scattered8, grid, block, 0, nullptr, p, bytes, sink); break;
+            default: rc = LC_ERR_INVALID;  // unknown access shape (4, 8, 16 or 1008)
+        }
+        if (rc == LC_OK && hipGetLastError() != hipSuccess) rc = LC_ERR_DEVICE;
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipFree(d);
+    return rc;
+}
+
+size_t lc_debug_row_lists(const uint16_t* keys, const uint8_t* validity, uint32_t n, uint32_t d, uint16_t* out, size_t cap) {
+    if (!keys || !out || n > lc::kPostMaxRows || d == 0) return 0;
+    const std::vector<uint16_t> post = lc::build_row_lists(keys, validity, n, d);
+    if (post.size() > cap) return 0;
+    std::memcpy(out, post.data(), post.size() * 2);
+    return post.size();
+}
+
+}  // extern "C"

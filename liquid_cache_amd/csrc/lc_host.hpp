@@ -407,4 +407,22 @@ inline bool substring_pattern(const uint8_t* p, size_t pl, const uint8_t** inner
     return true;
 }
 
+// Inverted row lists of a byte-view entry (lc_kernels.hpp): u16 offsets[D + 1], then the VALID rows grouped by key — a
+// counting sort.  Keys of null slots may be garbage (the reference allows it) and keys >= D cannot be listed: both are
+// skipped, as map_dictionary_results_to_array_results never yields a hit for them.  32 spare entries behind the rows.
+inline std::vector<uint16_t> build_row_lists(const uint16_t* keys, const uint8_t* validity, uint32_t n, uint32_t d) {
+    std::vector<uint16_t> post(size_t(d) + 1 + size_t(n) + 32, 0);
+    uint16_t* off = post.data();
+    uint16_t* rows = post.data() + d + 1;
+    auto valid = [&](uint32_t r) { return !validity || ((validity[r >> 3] >> (r & 7)) & 1); };
+    for (uint32_t r = 0; r < n; r++)
+        if (valid(r) && keys[r] < d) off[size_t(keys[r]) + 1]++;
+    for (uint32_t k = 0; k < d; k++) off[k + 1] = uint16_t(off[k + 1] + off[k]);
+    std::vector<uint16_t> cursor(off, off + d);
+    for (uint32_t r = 0; r < n; r++)
+        if (valid(r) && keys[r] < d) rows[cursor[keys[r]]++] = uint16_t(r);
+    return post;
+}
+
+
 }  // namespace lc

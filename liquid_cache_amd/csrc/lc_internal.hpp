@@ -1,0 +1,198 @@
+// Internals shared by the translation units behind the C ABI (lc_runtime.cpp, lc_like_pipeline.hip, lc_comm.cpp): the
+// context / scan objects, the entry metadata, error plumbing and the device scratch pool.  Not installed, not part of
+// the ABI.
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "lc_host.hpp"
+#include "lc_kernels.hpp"
+#include "lc_transcode.hpp"
+
+namespace lc {
+
+// Message of the last failing call on this thread (a fixed buffer: recording an error can never throw).
+lc_status fail(lc_status st, const char* msg) noexcept;
+inline lc_status fail(lc_status st, const std::string& msg) noexcept { return fail(st, msg.c_str()); }
+
+// Nothing may unwind across the C ABI (include/liquid_cache_amd.h): every entry point runs its body through this.
+template <typename F>
+lc_status guarded(F&& body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(LC_ERR_OOM, "host allocation failed");
+    } catch (const std::exception& e) {
+        return fail(LC_ERR_INVALID, e.what());
+    } catch (...) {
+        return fail(LC_ERR_INVALID, "unexpected exception");
+    }
+}
+
+#define LC_HIP(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return lc::fail(LC_ERR_DEVICE, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
+    } while (0)
+
+constexpr size_t kSlabBytes = size_t(256) << 20;
+constexpr size_t kSectionAlign = 128;
+
+struct Slab {
+    uint8_t* base = nullptr;
+    size_t size = 0, used = 0;
+    int64_t live = 0;
+};
+
+struct Entry {
+    bool is_str = false;
+    int logical = 0, phys = 0;
+    uint32_t len = 0;
+    bool nullable = false, all_null = false;
+    int W = 0;
+    FixedDesc fd{};
+    StrDesc sd{};
+    uint64_t path_id = 0;
+    uint32_t dict_len = 0;
+    bool has_fp = false;
+    int dec_precision = 0, dec_scale = 0, dec_is256 = 0;
+    size_t device_bytes = 0;
+    int slab = -1;
+    uint32_t offsets_bytes = 0;  // compact offset residual bytes (byte views)
+    uint32_t fsst_len = 0;
+    // SqueezedDate32Array form (squeezed_date32_array.rs:46-53): the entry holds ONE calendar component of a Date32 /
+    // Timestamp column, FoR + bit-packed on u32 lanes; `phys` keeps the original type.  -1: not squeezed.
+    int squeezed_field = -1;
+    // LiquidPrimitiveClampedArray form (hybrid_primitive_array.rs:73-80): packed at half the original width, offsets at or
+    // above the sentinel 2^W - 1 are stored as the sentinel; orig_W is the width before the squeeze.
+    bool clamped = false;
+    int orig_W = 0;
+    // LiquidPrimitiveQuantizedArray form (hybrid_primitive_array.rs:427-436): packed at half the original width, a row
+    // holds the bucket (value - reference) / bucket_width.  Predicates only; every read needs the backing bytes.
+    bool quantized = false;
+    uint64_t bucket_width = 0;
+    bool sig_on_device = false;  // staging: the signature slices are still to be built by k_str_build_signatures
+    uint64_t raw_bytes = 0;      // byte views: uncompressed size of the dictionary (RawFsstBuffer header)
+};
+
+struct LikePipeline;  // lc_like_pipeline.hip: scan-level index + scratch of the selective-LIKE pipeline
+
+}  // namespace lc
+
+struct lc_ctx {
+    int device = 0;
+    hipDeviceProp_t props{};
+    std::shared_mutex mu;
+    std::unordered_map<uint64_t, lc::Entry> entries;
+    std::vector<lc::Slab> slabs;
+    uint64_t max_hbm = 0;
+    uint64_t staged_bytes = 0;  // slab capacity reserved on the device (what max_hbm bounds)
+    uint64_t entry_bytes = 0;   // sum of the staged entries' blobs (what lc_device_info reports)
+    // symbol tables
+    std::mutex st_mu;
+    std::unordered_map<uint64_t, uint32_t> symtab_slot;
+    std::vector<std::unique_ptr<lc::SymbolTable>> symtabs;
+    bool build_signatures = true;  // LC_OPT_SIGNATURE_INDEX = 0 disables the bigram index (plain reference layout only)
+    bool signatures_on_host = false;  // LC_OPT_HOST_BUILT_INDEX = 1: build the index on the host (the device builder's oracle)
+    bool build_postings = true;       // LC_OPT_ROW_LISTS = 0: no inverted row lists (rows always mapped through the keys)
+    lc::DevSymtab* d_symtabs = nullptr;
+    size_t d_symtabs_cap = 0;
+    size_t d_symtabs_uploaded = 0;
+    // earlier (smaller) generations of the device array: launches that captured them may still be in flight on some
+    // stream, so they are kept until the context goes away (a few hundred KB per doubling)
+    std::vector<lc::DevSymtab*> d_symtabs_retired;
+    // Recycled device scratch for the per-call drop-in API (descriptor arrays, masks, gather buffers): hipMalloc /
+    // hipFree cost 0.1-1 ms each and hipFree synchronises the device, which would dominate an 8192-row call.
+    std::mutex pool_mu;
+    std::unordered_map<void*, size_t> pool_live;                // pointer -> size class (bytes)
+    std::unordered_map<size_t, std::vector<void*>> pool_free;   // size class -> cached blocks
+    // same for pinned host staging (pageable hipMemcpy runs at a fraction of the PCIe rate)
+    std::unordered_map<void*, size_t> hpool_live;
+    std::unordered_map<size_t, std::vector<void*>> hpool_free;
+    // side streams for staging work (signature builder): concurrent lc_stage calls of different host threads do not wait
+    // for each other's kernels the way they would on the null stream with a device-wide synchronise
+    std::vector<hipStream_t> stream_pool;
+};
+
+struct lc_scan {
+    lc_ctx* ctx = nullptr;
+    bool is_str = false;
+    int lane_log2 = 0;
+    uint32_t n = 0, bpe = 0;
+    uint32_t max_w = 0;  // widest entry (fixed width): <= 32 selects the register-resident predicate kernel
+    bool has_clamped = false;              // some entry is clamp-squeezed: evaluations first look for unresolved sentinels
+    std::vector<uint32_t> needs_backing;   // entries (scan order) whose last evaluation needs the full array
+    std::vector<uint64_t> seg_offsets;  // n+1 word offsets
+    std::vector<uint32_t> lens;         // rows per entry: two scans cover the same row ranges iff these are equal
+    uint64_t total_rows = 0;
+    void* d_descs = nullptr;
+    uint64_t* d_seg_offsets = nullptr;
+    std::vector<lc::Entry> meta;  // copies of the entries' metadata (descs have mask_word_off filled in)
+    // LIKE scratch
+    uint8_t* d_automata = nullptr;
+    size_t automata_cap = 0;
+    std::vector<uint8_t> automata_needle;  // the automata in d_automata were built for this needle ...
+    size_t automata_symtabs = 0;           // ... over this many symbol tables (0: nothing cached)
+    uint8_t* d_needle = nullptr;
+    size_t needle_cap = 0;
+    lc::StrWgRecord* d_wg_ranges = nullptr;  // byte views: one record per workgroup (<= 4 entries of one symbol table)
+    uint32_t n_wg_ranges = 0;
+    uint8_t* d_gather = nullptr;  // scratch of lc_scan_gather_bytes_async (grow only)
+    size_t gather_cap = 0;
+    uint32_t* d_work = nullptr;  // kWorkGroupsMax x {next entry, finished waves} (64-byte stride): dynamic entry
+                                 // assignment of the persistent byte-view scan kernel
+    // device symbol tables as of scan creation: every entry of the scan references a slot below n_symtabs, and an array
+    // generation is never freed while the context lives, so launches need no lock against concurrent staging
+    const lc::DevSymtab* d_symtabs = nullptr;
+    size_t n_symtabs = 0;
+    void* d_agg_partials = nullptr;  // lc_scan_aggregate: per-entry partials (allocated once)
+    // facts about the entries, gathered once at creation
+    uint32_t max_dict_len = 0;
+    bool any_without_signatures = false, any_patch = false, any_fingerprints = false, any_float = false;
+    int32_t uniform_slot = -1;             // byte views: the symbol-table slot when every entry shares one, else -1
+    uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
+    size_t or_tmp_words = 0;
+    unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
+    bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
+    // The scan's scratch (automata, work counters, COUNT(*) accumulator, OR / aggregate temporaries) is used by
+    // asynchronous launches after `mu` is released.  Calls on one scan are ordered on one stream; when a call arrives on
+    // another stream, the previous one is drained first (scan_enter_stream) so the scratch is never shared in flight.
+    hipStream_t last_stream = nullptr;
+    bool used = false;
+    std::mutex mu;
+};
+
+
+namespace lc {
+
+hipStream_t stream_acquire(lc_ctx* ctx);
+void stream_release(lc_ctx* ctx, hipStream_t s);
+void* pool_alloc(lc_ctx* ctx, size_t bytes);
+void pool_release(lc_ctx* ctx, void* p);  // the caller guarantees that nothing in flight still uses `p`
+void* host_pool_alloc(lc_ctx* ctx, size_t bytes);
+void host_pool_release(lc_ctx* ctx, void* p);
+void arena_pin(lc_ctx* ctx, int slab_idx);
+void arena_release(lc_ctx* ctx, int slab_idx);  // caller holds ctx->mu exclusively
+lc_status sync_symtabs(lc_ctx* ctx);
+void scan_enter_stream(lc_scan* s, hipStream_t stream);  // caller holds s->mu
+
+struct StrPredHost {
+    StrPred p{};
+    std::vector<uint8_t> needle;
+};
+lc_status make_str_pred(const lc_predicate* p, StrPredHost* out);
+
+}  // namespace lc

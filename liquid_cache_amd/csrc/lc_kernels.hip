@@ -3390,33 +3390,6 @@ __global__ __launch_bounds__(256) void k_component_lossy(const int32_t* __restri
     }
 }
 
-// Counter calibration (scripts/pmc_calibrate.py): read a KNOWN number of bytes with a given access shape, so that
-// rocprofv3's FETCH_SIZE can be converted into bytes for that shape instead of assuming the factor of another one.
-//   k_calib_read<W>          every lane reads W consecutive bytes, lanes adjacent (coalesced): W = 4, 8, 16
-//   k_calib_read_scattered8  every lane reads 8 unaligned bytes out of its own 64-byte sector (the FSST word loads and
-//                            offset-pair loads of k_str_pred look like this): 64 useful... 8 useful bytes per sector
-template <int W>
-__global__ __launch_bounds__(256) void k_calib_read(const uint8_t* __restrict__ src, uint64_t bytes, uint32_t* __restrict__ sink) {
-    uint32_t acc = 0;
-    const uint64_t n = bytes / W;
-    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
-        if constexpr (W == 4) acc ^= reinterpret_cast<const uint32_t*>(src)[i];
-        else if constexpr (W == 8) { const uint2 v = reinterpret_cast<const uint2*>(src)[i]; acc ^= v.x ^ v.y; }
-        else { const uint4 v = reinterpret_cast<const uint4*>(src)[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
-    }
-    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
-}
-__global__ __launch_bounds__(256) void k_calib_read_scattered8(const uint8_t* __restrict__ src, uint64_t bytes,
-                                                                uint32_t* __restrict__ sink) {
-    uint32_t acc = 0;
-    const uint64_t n = bytes / 64;  // one access per 64-byte sector
-    for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256) {
-        const uint64_t v = load_unaligned<uint64_t>(src + i * 64 + 3 + (i % 7) * 7);
-        acc ^= uint32_t(v) ^ uint32_t(v >> 32);
-    }
-    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -3798,20 +3771,6 @@ hipError_t launch_component_lossy(const int32_t* d_comps, uint64_t n, int value_
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }
-
-hipError_t launch_calib_read(const void* d_buf, uint64_t bytes, int shape, uint32_t* d_sink, hipStream_t stream) {
-    const uint8_t* p = static_cast<const uint8_t*>(d_buf);
-    const dim3 grid(2048), block(256);
-    switch (shape) {
-        case 4: hipLaunchKernelGGL(k_calib_read<4>, grid, block, 0, stream, p, bytes, d_sink); break;
-        case 8: hipLaunchKernelGGL(k_calib_read<8>, grid, block, 0, stream, p, bytes, d_sink); break;
-        case 16: hipLaunchKernelGGL(k_calib_read<16>, grid, block, 0, stream, p, bytes, d_sink); break;
-        case 1008: hipLaunchKernelGGL(k_calib_read_scattered8, grid, block, 0, stream, p, bytes, d_sink); break;
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
 
 hipError_t launch_mask_or_kleene(uint64_t* d_hit, uint64_t* d_valid, const uint64_t* d_hit_b, const uint64_t* d_valid_b,
                                  uint64_t n_words, hipStream_t stream) {

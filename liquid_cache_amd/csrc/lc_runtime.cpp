@@ -15,165 +15,29 @@
 
 #include <hip/hip_runtime.h>
 
-#include "../../include/liquid_cache_amd_bench.h"
-#include "lc_host.hpp"
-#include "lc_kernels.hpp"
-#include "lc_transcode.hpp"
+#include "lc_internal.hpp"
 
 using namespace lc;
 
-namespace {
+namespace lc {
 
-// Message of the last failing call on this thread.  A fixed buffer: recording an error can never throw.
 thread_local char g_last_error[512] = {0};
 
 lc_status fail(lc_status st, const char* msg) noexcept {
     std::snprintf(g_last_error, sizeof(g_last_error), "%s", msg ? msg : "");
     return st;
 }
-lc_status fail(lc_status st, const std::string& msg) noexcept { return fail(st, msg.c_str()); }
 
-// Nothing may unwind across the C ABI (include/liquid_cache_amd.h): every entry point runs its body through this.
-template <typename F>
-lc_status guarded(F&& body) noexcept {
-    try {
-        return body();
-    } catch (const std::bad_alloc&) {
-        return fail(LC_ERR_OOM, "host allocation failed");
-    } catch (const std::exception& e) {
-        return fail(LC_ERR_INVALID, e.what());
-    } catch (...) {
-        return fail(LC_ERR_INVALID, "unexpected exception");
-    }
+// Caller holds s->mu.  See lc_scan::last_stream.
+void scan_enter_stream(lc_scan* s, hipStream_t stream) {
+    if (s->used && s->last_stream != stream) (void)hipStreamSynchronize(s->last_stream);
+    s->last_stream = stream;
+    s->used = true;
 }
 
-#define LC_HIP(expr)                                                                              \
-    do {                                                                                          \
-        hipError_t _e = (expr);                                                                   \
-        if (_e != hipSuccess)                                                                     \
-            return fail(LC_ERR_DEVICE, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
-    } while (0)
+}  // namespace lc
 
-constexpr size_t kSlabBytes = size_t(256) << 20;
-constexpr size_t kSectionAlign = 128;
-
-struct Slab {
-    uint8_t* base = nullptr;
-    size_t size = 0, used = 0;
-    int64_t live = 0;
-};
-
-struct Entry {
-    bool is_str = false;
-    int logical = 0, phys = 0;
-    uint32_t len = 0;
-    bool nullable = false, all_null = false;
-    int W = 0;
-    FixedDesc fd{};
-    StrDesc sd{};
-    uint64_t path_id = 0;
-    uint32_t dict_len = 0;
-    bool has_fp = false;
-    int dec_precision = 0, dec_scale = 0, dec_is256 = 0;
-    size_t device_bytes = 0;
-    int slab = -1;
-    uint32_t offsets_bytes = 0;  // compact offset residual bytes (byte views)
-    uint32_t fsst_len = 0;
-    // SqueezedDate32Array form (squeezed_date32_array.rs:46-53): the entry holds ONE calendar component of a Date32 /
-    // Timestamp column, FoR + bit-packed on u32 lanes; `phys` keeps the original type.  -1: not squeezed.
-    int squeezed_field = -1;
-    // LiquidPrimitiveClampedArray form (hybrid_primitive_array.rs:73-80): packed at half the original width, offsets at or
-    // above the sentinel 2^W - 1 are stored as the sentinel; orig_W is the width before the squeeze.
-    bool clamped = false;
-    int orig_W = 0;
-    // LiquidPrimitiveQuantizedArray form (hybrid_primitive_array.rs:427-436): packed at half the original width, a row
-    // holds the bucket (value - reference) / bucket_width.  Predicates only; every read needs the backing bytes.
-    bool quantized = false;
-    uint64_t bucket_width = 0;
-    bool sig_on_device = false;  // staging: the signature slices are still to be built by k_str_build_signatures
-    uint64_t raw_bytes = 0;      // byte views: uncompressed size of the dictionary (RawFsstBuffer header)
-};
-
-}  // namespace
-
-struct lc_ctx {
-    int device = 0;
-    hipDeviceProp_t props{};
-    std::shared_mutex mu;
-    std::unordered_map<uint64_t, Entry> entries;
-    std::vector<Slab> slabs;
-    uint64_t max_hbm = 0;
-    uint64_t staged_bytes = 0;  // slab capacity reserved on the device (what max_hbm bounds)
-    uint64_t entry_bytes = 0;   // sum of the staged entries' blobs (what lc_device_info reports)
-    // symbol tables
-    std::mutex st_mu;
-    std::unordered_map<uint64_t, uint32_t> symtab_slot;
-    std::vector<std::unique_ptr<SymbolTable>> symtabs;
-    bool build_signatures = true;  // LC_NO_SIGNATURES=1 disables the bigram index (plain reference layout only)
-    bool signatures_on_host = false;  // LC_HOST_SIGNATURES=1: build the index on the host (the device builder's oracle)
-    bool build_postings = true;       // LC_NO_POSTINGS=1: no inverted row lists (rows always mapped through the keys)
-    DevSymtab* d_symtabs = nullptr;
-    size_t d_symtabs_cap = 0;
-    size_t d_symtabs_uploaded = 0;
-    // earlier (smaller) generations of the device array: launches that captured them may still be in flight on some
-    // stream, so they are kept until the context goes away (a few hundred KB per doubling)
-    std::vector<DevSymtab*> d_symtabs_retired;
-    // Recycled device scratch for the per-call drop-in API (descriptor arrays, masks, gather buffers): hipMalloc /
-    // hipFree cost 0.1-1 ms each and hipFree synchronises the device, which would dominate an 8192-row call.
-    std::mutex pool_mu;
-    std::unordered_map<void*, size_t> pool_live;                // pointer -> size class (bytes)
-    std::unordered_map<size_t, std::vector<void*>> pool_free;   // size class -> cached blocks
-    // same for pinned host staging (pageable hipMemcpy runs at a fraction of the PCIe rate)
-    std::unordered_map<void*, size_t> hpool_live;
-    std::unordered_map<size_t, std::vector<void*>> hpool_free;
-    // side streams for staging work (signature builder): concurrent lc_stage calls of different host threads do not wait
-    // for each other's kernels the way they would on the null stream with a device-wide synchronise
-    std::vector<hipStream_t> stream_pool;
-};
-
-struct lc_scan {
-    lc_ctx* ctx = nullptr;
-    bool is_str = false;
-    int lane_log2 = 0;
-    uint32_t n = 0, bpe = 0;
-    uint32_t max_w = 0;  // widest entry (fixed width): <= 32 selects the register-resident predicate kernel
-    bool has_clamped = false;              // some entry is clamp-squeezed: evaluations first look for unresolved sentinels
-    std::vector<uint32_t> needs_backing;   // entries (scan order) whose last evaluation needs the full array
-    std::vector<uint64_t> seg_offsets;  // n+1 word offsets
-    uint64_t total_rows = 0;
-    void* d_descs = nullptr;
-    uint64_t* d_seg_offsets = nullptr;
-    std::vector<Entry> meta;  // copies of the entries' metadata (descs have mask_word_off filled in)
-    // LIKE scratch
-    uint8_t* d_automata = nullptr;
-    size_t automata_cap = 0;
-    std::vector<uint8_t> automata_needle;  // the automata in d_automata were built for this needle ...
-    size_t automata_symtabs = 0;           // ... over this many symbol tables (0: nothing cached)
-    uint8_t* d_needle = nullptr;
-    size_t needle_cap = 0;
-    StrWgRecord* d_wg_ranges = nullptr;  // byte views: one record per workgroup (<= 4 entries of one symbol table)
-    uint32_t n_wg_ranges = 0;
-    uint8_t* d_gather = nullptr;  // scratch of lc_scan_gather_bytes_async (grow only)
-    size_t gather_cap = 0;
-    uint32_t* d_work = nullptr;  // kWorkGroupsMax x {next entry, finished waves} (64-byte stride): dynamic entry
-                                 // assignment of the persistent byte-view scan kernel
-    // device symbol tables as of scan creation: every entry of the scan references a slot below n_symtabs, and an array
-    // generation is never freed while the context lives, so launches need no lock against concurrent staging
-    const DevSymtab* d_symtabs = nullptr;
-    size_t n_symtabs = 0;
-    void* d_agg_partials = nullptr;  // lc_scan_aggregate: per-entry partials (allocated once)
-    // facts about the entries, gathered once at creation
-    uint32_t max_dict_len = 0;
-    bool any_without_signatures = false, any_patch = false, any_fingerprints = false, any_float = false;
-    int32_t uniform_slot = -1;             // byte views: the symbol-table slot when every entry shares one, else -1
-    uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
-    size_t or_tmp_words = 0;
-    unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
-    bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
-    std::mutex mu;
-};
-
-namespace {
+namespace lc {
 
 // ------------------------------------------------------------------ scratch pool
 constexpr size_t kPoolMinClass = 4096, kPoolMaxClass = size_t(64) << 20, kPoolKeepPerClass = 16;
@@ -341,6 +205,53 @@ void arena_release(lc_ctx* ctx, int slab_idx) {
     }
 }
 
+// Live counts reserved for entries that are not published yet (lc_stage, the device encoders): if the call fails between
+// the reservation and the publication the counts are given back, so the slab can still drain.  Declare it BEFORE any
+// lock on ctx->mu that the function holds while it may fail (the destructor takes the lock itself).
+struct ArenaReservation {
+    lc_ctx* ctx;
+    int slab = -1;
+    int64_t count = 0;
+    explicit ArenaReservation(lc_ctx* c) : ctx(c) {}
+    void arm(int slab_idx, int64_t n) { slab = slab_idx; count = n; }
+    void disarm() { count = 0; }
+    ~ArenaReservation() {
+        if (count <= 0) return;
+        (void)hipDeviceSynchronize();  // nothing may still write into the blob when the slab is returned
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        for (int64_t i = 0; i < count; i++) arena_release(ctx, slab);
+    }
+    ArenaReservation(const ArenaReservation&) = delete;
+    ArenaReservation& operator=(const ArenaReservation&) = delete;
+};
+
+// Keeps the slab of an entry alive while a call reads the entry's blob outside the cache lock (read-backs, squeezes).
+struct SlabPin {
+    lc_ctx* ctx;
+    int slab;
+    SlabPin(lc_ctx* c, int s) : ctx(c), slab(s) {}  // the caller holds ctx->mu (shared is enough for the lookup, the pin
+                                                      // itself is taken under the unique lock: see pin_entry)
+    ~SlabPin() {
+        if (slab < 0) return;
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        arena_release(ctx, slab);
+    }
+    SlabPin(const SlabPin&) = delete;
+    SlabPin& operator=(const SlabPin&) = delete;
+};
+
+// Copy of a staged entry with its slab pinned (unique lock: `live` is a plain counter).  slab = -1 in `*pin_slab` when
+// the entry is absent.
+bool pin_entry(lc_ctx* ctx, uint64_t entry_id, Entry* out, int* pin_slab) {
+    std::unique_lock<std::shared_mutex> g(ctx->mu);
+    auto it = ctx->entries.find(entry_id);
+    if (it == ctx->entries.end()) { *pin_slab = -1; return false; }
+    *out = it->second;
+    arena_pin(ctx, out->slab);
+    *pin_slab = out->slab;
+    return true;
+}
+
 // ------------------------------------------------------------------ symbol tables
 struct CtxSymtabs : SymtabProvider {
     lc_ctx* ctx;
@@ -470,25 +381,18 @@ lc_status build_fixed(const uint8_t* bytes, size_t len, Entry* e, Blob* blob, si
     return LC_OK;
 }
 
-// Inverted row lists of a byte-view entry (lc_kernels.hpp): u16 offsets[D + 1], then the VALID rows grouped by key — a
-// counting sort.  Keys of null slots may be garbage (the reference allows it) and keys >= D cannot be listed: both are
-// skipped, as map_dictionary_results_to_array_results never yields a hit for them.  32 spare entries behind the rows.
-std::vector<uint16_t> build_row_lists(const uint16_t* keys, const uint8_t* validity, uint32_t n, uint32_t d) {
-    std::vector<uint16_t> post(size_t(d) + 1 + size_t(n) + 32, 0);
-    uint16_t* off = post.data();
-    uint16_t* rows = post.data() + d + 1;
-    auto valid = [&](uint32_t r) { return !validity || ((validity[r >> 3] >> (r & 7)) & 1); };
-    for (uint32_t r = 0; r < n; r++)
-        if (valid(r) && keys[r] < d) off[size_t(keys[r]) + 1]++;
-    for (uint32_t k = 0; k < d; k++) off[k + 1] = uint16_t(off[k + 1] + off[k]);
-    std::vector<uint16_t> cursor(off, off + d);
-    for (uint32_t r = 0; r < n; r++)
-        if (valid(r) && keys[r] < d) rows[cursor[keys[r]]++] = uint16_t(r);
-    return post;
-}
+// Serialised acceleration index of a byte-view entry ("LCIX", lc_entry_index_to_bytes): what lc_stage builds for
+// substring-search columns — the bit-sliced bigram signatures and the inverted row lists — so that the disk tier can keep
+// it beside the Liquid bytes and a re-stage does not rebuild it.
+struct IndexHeader {
+    uint32_t magic, version, d, n, sig_bits, flags;  // flags: 1 = signatures present, 2 = row lists present
+    uint64_t sig_bytes, post_bytes;
+};
+constexpr uint32_t kIndexMagic = 0x5849434Cu;  // "LCIX"
+static_assert(sizeof(IndexHeader) == 40, "IndexHeader layout");
 
 lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path_id, Entry* e, Blob* blob,
-                    size_t offs[9]) {
+                    size_t offs[9], const uint8_t* index = nullptr, size_t index_len = 0) {
     ByteViewParsed v;
     if (!parse_byte_view(bytes, len, &v)) return fail(LC_ERR_CORRUPT, "malformed Liquid byte-view array");
     // the row lists and mask utilities of the byte-view kernels address rows of an entry with 16 bits (the reference's
@@ -550,7 +454,33 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
     offs[4] = blob->add(v.residuals, size_t(v.residual_count) * size_t(v.offset_bytes), kSectionAlign, 8);
     offs[5] = blob->add(v.fsst, v.fsst_len, kSectionAlign, 16);
     offs[6] = blob->add(v.shared_prefix, v.shared_prefix_len, kSectionAlign, 8);
-    if (v.fingerprints && ctx->build_signatures && !ctx->signatures_on_host) {
+    // a prebuilt index is used when it describes exactly this entry (dictionary size, rows, signature width, section
+    // sizes); anything else is ignored and the index is rebuilt
+    const uint8_t* pre_sig = nullptr;
+    const uint8_t* pre_post = nullptr;
+    size_t pre_post_bytes = 0;
+    if (index && index_len >= sizeof(IndexHeader)) {
+        IndexHeader h;
+        std::memcpy(&h, index, sizeof(h));
+        const size_t nw = std::max<size_t>((size_t(v.d) + 63) / 64, 1);
+        const bool head_ok = h.magic == kIndexMagic && h.version == 1 && h.d == v.d && h.n == v.n && h.sig_bits == uint32_t(kSigBits) &&
+                             index_len == sizeof(h) + h.sig_bytes + h.post_bytes;
+        if (head_ok && (h.flags & 1u) && h.sig_bytes == size_t(kSigBits) * nw * 8) pre_sig = index + sizeof(h);
+        if (head_ok && (h.flags & 2u) && h.post_bytes == (size_t(v.d) + 1 + size_t(v.n) + 32) * 2) {
+            pre_post = index + sizeof(h) + h.sig_bytes;
+            pre_post_bytes = h.post_bytes;
+            // the list bounds must be a monotone partition of at most n rows, the rows below n (the kernels index with them)
+            const uint16_t* po = reinterpret_cast<const uint16_t*>(pre_post);
+            bool ok = po[0] == 0 && po[v.d] <= v.n;
+            for (uint32_t k = 0; k < v.d && ok; k++) ok = po[k] <= po[k + 1];
+            for (uint32_t r = 0; ok && r < po[v.d]; r++) ok = po[v.d + 1 + r] < v.n;
+            if (!ok) { pre_post = nullptr; pre_post_bytes = 0; }
+        }
+    }
+    if (v.fingerprints && ctx->build_signatures && pre_sig) {
+        const size_t nw = std::max<size_t>((size_t(v.d) + 63) / 64, 1);
+        offs[7] = blob->add(pre_sig, size_t(kSigBits) * nw * 8);
+    } else if (v.fingerprints && ctx->build_signatures && !ctx->signatures_on_host) {
         // substring-search columns: room for the bit-sliced bigram signatures (lc_kernels.hpp); k_str_build_signatures
         // fills it once the blob is in HBM, before the entry becomes visible
         const size_t nw = (size_t(v.d) + 63) / 64;
@@ -558,7 +488,7 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
         blob->bytes.resize(offs[7] + size_t(kSigBits) * std::max<size_t>(nw, 1) * 8, 0);
         e->sig_on_device = true;
     } else if (v.fingerprints && ctx->build_signatures) {
-        // LC_HOST_SIGNATURES=1 (tests): the same index built by the host
+        // LC_OPT_HOST_BUILT_INDEX (tests): the same index built by the host
         const size_t nw = (size_t(v.d) + 63) / 64;
         std::vector<uint64_t> sig(size_t(kSigBits) * std::max<size_t>(nw, 1), 0);
         std::vector<uint8_t> tmp;
@@ -571,7 +501,9 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
         }
         offs[7] = blob->add(sig.data(), sig.size() * 8);
     }
-    if (v.fingerprints && ctx->build_signatures && ctx->build_postings && v.n <= kPostMaxRows && v.d > 0 && !v.all_null) {
+    if (v.fingerprints && ctx->build_signatures && ctx->build_postings && v.n <= kPostMaxRows && v.d > 0 && !v.all_null && pre_post) {
+        offs[8] = blob->add(pre_post, pre_post_bytes, kSectionAlign, 16);
+    } else if (v.fingerprints && ctx->build_signatures && ctx->build_postings && v.n <= kPostMaxRows && v.d > 0 && !v.all_null) {
         const std::vector<uint16_t> post = build_row_lists(v.keys.data(), v.nullable ? v.key_validity : nullptr, v.n, v.d);
         offs[8] = blob->add(post.data(), post.size() * 2, kSectionAlign, 16);
     }
@@ -630,11 +562,6 @@ lc_status make_fixed_pred(const Entry& e, const lc_predicate* p, FixedPred* out)
     }
     return LC_OK;
 }
-
-struct StrPredHost {
-    StrPred p{};
-    std::vector<uint8_t> needle;
-};
 
 lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
     out->p = StrPred{};
@@ -732,11 +659,23 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     ctx->device = dev;
     LC_HIP(hipGetDeviceProperties(&ctx->props, dev));
     ctx->max_hbm = max_hbm_bytes;
-    if (const char* ns = std::getenv("LC_NO_SIGNATURES")) ctx->build_signatures = std::atoi(ns) == 0;
-    if (const char* hs = std::getenv("LC_HOST_SIGNATURES")) ctx->signatures_on_host = std::atoi(hs) != 0;
-    if (const char* np = std::getenv("LC_NO_POSTINGS")) ctx->build_postings = std::atoi(np) == 0;
+    // (no environment variable is read here: what the library stages and how it evaluates is decided by the caller
+    // through lc_ctx_set_option, never by the process environment)
     *out = ctx.release();
     return LC_OK;
+    });
+}
+
+lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
+    return guarded([&]() -> lc_status {
+    if (!ctx) return fail(LC_ERR_INVALID, "null argument");
+    std::unique_lock<std::shared_mutex> g(ctx->mu);
+    switch (option) {
+        case LC_OPT_SIGNATURE_INDEX: ctx->build_signatures = value != 0; return LC_OK;
+        case LC_OPT_ROW_LISTS: ctx->build_postings = value != 0; return LC_OK;
+        case LC_OPT_HOST_BUILT_INDEX: ctx->signatures_on_host = value != 0; return LC_OK;
+        default: return fail(LC_ERR_INVALID, "unknown context option");
+    }
     });
 }
 
@@ -802,8 +741,22 @@ lc_status lc_symtab_get(lc_ctx* ctx, uint64_t path_id, uint8_t** out_bytes, size
 
 void lc_free(void* p) { std::free(p); }
 
+static lc_status stage_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes, const size_t* lens,
+                            const uint64_t* path_ids, const uint8_t* const* index_bytes, const size_t* index_lens);
+
 lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes,
                    const size_t* lens, const uint64_t* path_ids) {
+    return stage_impl(ctx, n, entry_ids, bytes, lens, path_ids, nullptr, nullptr);
+}
+
+lc_status lc_stage_indexed(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes, const size_t* lens,
+                           const uint64_t* path_ids, const uint8_t* const* index_bytes, const size_t* index_lens) {
+    if (index_bytes && !index_lens) return fail(LC_ERR_INVALID, "index_lens is null");
+    return stage_impl(ctx, n, entry_ids, bytes, lens, path_ids, index_bytes, index_lens);
+}
+
+static lc_status stage_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uint8_t* const* bytes, const size_t* lens,
+                            const uint64_t* path_ids, const uint8_t* const* index_bytes, const size_t* index_lens) {
     return guarded([&]() -> lc_status {
     if (!ctx || (n && (!entry_ids || !bytes || !lens))) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
@@ -830,7 +783,8 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
             for (auto& o : p.off) o = size_t(-1);
             lc_status st;
             if (logical == kByteView) {
-                st = build_str(ctx, bytes[i], lens[i], path_ids ? path_ids[i] : 0, &p.e, &blob, p.off);
+                st = build_str(ctx, bytes[i], lens[i], path_ids ? path_ids[i] : 0, &p.e, &blob, p.off,
+                               index_bytes ? index_bytes[i] : nullptr, index_bytes && index_bytes[i] ? index_lens[i] : 0);
             } else if (logical == kInteger || logical == kDecimal || logical == kFloat) {
                 st = build_fixed(bytes[i], lens[i], &p.e, &blob, &p.off[0], &p.off[1], &p.off[2], &p.off[3]);
             } else {
@@ -851,11 +805,13 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
         int slab = -1;
         const size_t total = align_up(blob.bytes.size(), kSectionAlign) + 256;
         blob.bytes.resize(total, 0);
+        ArenaReservation reserved(ctx);  // gives the counts back if anything below fails before the entries are published
         {
             std::unique_lock<std::shared_mutex> g(ctx->mu);
             lc_status st = arena_alloc(ctx, total, &dbase, &slab);
             if (st != LC_OK) return st;
             ctx->slabs[size_t(slab)].live += int64_t(pend.size()) - 1;  // keeps the slab alive until the entries exist
+            reserved.arm(slab, int64_t(pend.size()));
         }
         LC_HIP(hipMemcpy(dbase, blob.bytes.data(), total, hipMemcpyHostToDevice));
         std::vector<StrDesc> sig_descs;
@@ -912,6 +868,7 @@ lc_status lc_stage(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const uin
             ctx->entry_bytes += p.e.device_bytes;
             ctx->entries.emplace(p.id, std::move(p.e));
         }
+        reserved.disarm();
     }
     return sync_symtabs(ctx);
     });
@@ -1121,12 +1078,14 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         total = cur;
     }
     total = align_up(total, kSectionAlign) + 256;
+    ArenaReservation reserved(ctx);  // declared before the lock: its destructor locks on its own (failure paths only)
     std::unique_lock<std::shared_mutex> g(ctx->mu);
     uint8_t* dbase = nullptr;
     int slab = -1;
     lc_status st = arena_alloc(ctx, total, &dbase, &slab);
     if (st != LC_OK) return st;
     ctx->slabs[size_t(slab)].live += int64_t(n) - 1;
+    reserved.arm(slab, int64_t(n));
     LC_HIP(hipMemsetAsync(dbase, 0, total, nullptr));  // slack behind packed sections and tail words must be zero
     for (size_t i = 0; i < n; i++) {
         const DevEncodeItem& it = items[i];
@@ -1208,6 +1167,7 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
         ctx->entry_bytes += e.device_bytes;
         ctx->entries.emplace(it.id, std::move(e));
     }
+    reserved.disarm();
     return LC_OK;
 }
 // Floats: ALP on the device (k_alp_search -> k_alp_encode -> k_fl_pack + k_alp_copy_patches), then the entries are
@@ -1286,12 +1246,14 @@ lc_status device_encode_floats(lc_ctx* ctx, std::vector<DevEncodeItem>& items) {
             total = cur;
         }
         total = align_up(total, kSectionAlign) + 256;
+        ArenaReservation reserved(ctx);  // before the lock: see device_encode_and_register
         std::unique_lock<std::shared_mutex> g(ctx->mu);
         uint8_t* dbase = nullptr;
         int slab = -1;
         lc_status st = arena_alloc(ctx, total, &dbase, &slab);
         if (st != LC_OK) return st;
         ctx->slabs[size_t(slab)].live += int64_t(m) - 1;
+        reserved.arm(slab, int64_t(m));
         LC_HIP(hipMemsetAsync(dbase, 0, total, nullptr));
         std::vector<void*> ptrs(2 * m, nullptr);
         for (size_t j = 0; j < m; j++) {
@@ -1353,6 +1315,7 @@ lc_status device_encode_floats(lc_ctx* ctx, std::vector<DevEncodeItem>& items) {
             ctx->entry_bytes += e.device_bytes;
             ctx->entries.emplace(it.id, std::move(e));
         }
+        reserved.disarm();
     }
     return LC_OK;
 }
@@ -1457,18 +1420,52 @@ lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_
 // LiquidArray::to_bytes() of a staged fixed-width entry (primitive_array.rs:603-679, decimal_array.rs:197-220,
 // float_array.rs:397-519, bit_pack_array.rs:181-256): what the reference writes to its disk tier when it squeezes or
 // evicts an entry, rebuilt from the HBM-resident form.
+lc_status lc_entry_index_to_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out_bytes, size_t* out_len) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !out_bytes || !out_len) return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    *out_bytes = nullptr;
+    *out_len = 0;
+    Entry e;
+    int pinned_slab = -1;
+    if (!pin_entry(ctx, entry_id, &e, &pinned_slab)) return LC_NOT_STAGED;
+    SlabPin pin(ctx, pinned_slab);
+    if (!e.is_str || (!e.sd.signatures && !e.sd.postings)) return LC_OK;  // nothing to keep: *out_len == 0
+    IndexHeader h{};
+    h.magic = kIndexMagic;
+    h.version = 1;
+    h.d = e.sd.d;
+    h.n = e.sd.n;
+    h.sig_bits = uint32_t(kSigBits);
+    const size_t nw = std::max<size_t>((size_t(e.sd.d) + 63) / 64, 1);
+    if (e.sd.signatures) { h.flags |= 1u; h.sig_bytes = size_t(kSigBits) * nw * 8; }
+    if (e.sd.postings) { h.flags |= 2u; h.post_bytes = (size_t(e.sd.d) + 1 + size_t(e.sd.n) + 32) * 2; }
+    const size_t total = sizeof(h) + h.sig_bytes + h.post_bytes;
+    uint8_t* buf = static_cast<uint8_t*>(std::malloc(total));
+    if (!buf) return fail(LC_ERR_OOM, "malloc");
+    std::memcpy(buf, &h, sizeof(h));
+    hipError_t e1 = hipSuccess, e2 = hipSuccess;
+    if (h.sig_bytes) e1 = hipMemcpy(buf + sizeof(h), e.sd.signatures, h.sig_bytes, hipMemcpyDeviceToHost);
+    if (h.post_bytes) e2 = hipMemcpy(buf + sizeof(h) + h.sig_bytes, e.sd.postings, h.post_bytes, hipMemcpyDeviceToHost);
+    if (e1 != hipSuccess || e2 != hipSuccess) { std::free(buf); return fail(LC_ERR_DEVICE, "hipMemcpy (entry index)"); }
+    *out_bytes = buf;
+    *out_len = total;
+    return LC_OK;
+    });
+}
+
 lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out_bytes, size_t* out_len) {
     return guarded([&]() -> lc_status {
     if (!ctx || !out_bytes || !out_len) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
+    // This is the evict-to-disk path, so an lc_evict / re-stage of the same entry on another thread is expected: the slab is
+    // pinned for the duration of the read-back (a concurrent eviction then only drops the entry, not the bytes under us).
     Entry e;
-    {
-        std::shared_lock<std::shared_mutex> g(ctx->mu);
-        auto it = ctx->entries.find(entry_id);
-        if (it == ctx->entries.end()) return LC_NOT_STAGED;
-        e = it->second;
-    }
+    int pinned_slab = -1;
+    if (!pin_entry(ctx, entry_id, &e, &pinned_slab)) return LC_NOT_STAGED;
+    SlabPin pin(ctx, pinned_slab);
     if (e.is_str) {
         // LiquidByteViewArray::to_bytes (byte_view_array/serialization.rs:122-220): header, raw FSST buffer, keys as a
         // BitPackedArray<u16> at 16 bits, compact offsets, prefix keys, shared prefix, fingerprints — read back from HBM
@@ -1589,6 +1586,7 @@ lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out
 }
 
 // ------------------------------------------------------------------ scans
+
 static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed);
 
 lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out) {
@@ -1608,7 +1606,10 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     s->seg_offsets.assign(n + 1, 0);
     s->meta.reserve(n);
     {
-        std::shared_lock<std::shared_mutex> g(ctx->mu);
+        // ONE critical section captures the entries and pins their slabs: between a capture under one lock and a pin
+        // under another an lc_evict / re-stage could drain the slab and the scan would keep dangling device pointers.
+        // The pins are taken after every entry has validated, so the error returns below leave nothing pinned.
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
         uint32_t max_len = 0;
         for (uint64_t i = 0; i < n; i++) {
             auto it = ctx->entries.find(entry_ids[i]);
@@ -1627,6 +1628,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             if (e.is_str) e.sd.mask_word_off = off;
             else e.fd.mask_word_off = off;
             s->seg_offsets[i + 1] = off + (uint64_t(e.len) + 63) / 64;
+            s->lens.push_back(e.len);
             s->total_rows += e.len;
             max_len = std::max(max_len, e.len);
             if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
@@ -1644,11 +1646,8 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             s->meta.push_back(e);
         }
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
-    }
-    {
         // pin the slabs of the scan's entries: evicting or re-staging an entry under a live scan is then safe (the scan
         // keeps the blob it captured; lc_scan_destroy drops the pins)
-        std::unique_lock<std::shared_mutex> g(ctx->mu);
         for (const Entry& e : s->meta) arena_pin(ctx, e.slab);
         s->pinned = true;
     }
@@ -1795,6 +1794,10 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     if (s->n == 0) {
         if (d_total_out) LC_HIP(hipMemsetAsync(d_total_out, 0, 8, stream));
         return LC_OK;
+    }
+    {
+        std::lock_guard<std::mutex> g(s->mu);
+        scan_enter_stream(s, stream);
     }
     ScanLaunch L{};
     if (d_total_out) {
@@ -1967,6 +1970,7 @@ lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection,
     if (scan->is_str) return fail(LC_UNSUPPORTED, "aggregates apply to integer, date, timestamp and decimal columns");
     if (scan->any_float) return fail(LC_UNSUPPORTED, "aggregates apply to integer, date, timestamp and decimal columns");
     std::lock_guard<std::mutex> g(scan->mu);
+    scan_enter_stream(scan, st);
     if (scan->has_clamped) {  // a selected row without its value in HBM (clamp sentinel, any quantized row)
         const lc_status cs = clamp_unresolved_entries(ctx, scan, nullptr, 0, d_selection, st, &scan->needs_backing);
         if (cs != LC_OK) return cs;
@@ -1992,7 +1996,8 @@ lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, con
     return guarded([&]() -> lc_status {
     if (!ctx || !scan_a || !scan_b || !d_out) return fail(LC_ERR_INVALID, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (scan_a->ctx != scan_b->ctx || scan_a->seg_offsets != scan_b->seg_offsets)
+    // entry LENGTHS, not word counts: entries of 60 and 64 rows share a mask layout but not a tail mask
+    if (scan_a->ctx != scan_b->ctx || scan_a->lens != scan_b->lens)
         return fail(LC_ERR_INVALID, "the two scans must cover the same row ranges (same entry lengths)");
     if (scan_a->n == 0) {
         LC_HIP(hipMemsetAsync(d_out, 0, sizeof(lc_aggregate), st));
@@ -2005,6 +2010,7 @@ lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, con
     lc_scan* both[2] = {scan_a, scan_b};
     for (lc_scan* s : both) {
         std::lock_guard<std::mutex> g(s->mu);
+        if (s == scan_a) scan_enter_stream(s, st);
         if (s->has_clamped) {
             const lc_status cs = clamp_unresolved_entries(ctx, s, nullptr, 0, d_selection, st, &s->needs_backing);
             if (cs != LC_OK) return cs;
@@ -2035,7 +2041,7 @@ static lc_status scan_eval_or_impl(lc_ctx* ctx, uint32_t n, lc_scan* const* scan
     lc_scan* s0 = scans[0];
     if (!s0) return fail(LC_ERR_INVALID, "null scan");
     for (uint32_t i = 1; i < n; i++) {
-        if (!scans[i] || scans[i]->ctx != s0->ctx || scans[i]->seg_offsets != s0->seg_offsets)
+        if (!scans[i] || scans[i]->ctx != s0->ctx || scans[i]->lens != s0->lens)
             return fail(LC_ERR_INVALID, "the scans of a multi-column OR must cover the same row ranges (same entry lengths)");
     }
     const uint64_t words = s0->seg_offsets.back();
@@ -2043,6 +2049,7 @@ static lc_status scan_eval_or_impl(lc_ctx* ctx, uint32_t n, lc_scan* const* scan
     uint64_t* tmp = nullptr;
     {
         std::lock_guard<std::mutex> g(s0->mu);
+        scan_enter_stream(s0, stream);
         if (s0->or_tmp_words < 3 * words) {
             LC_HIP(hipStreamSynchronize(stream));  // earlier launches may still use the smaller scratch
             pool_release(ctx, s0->d_or_tmp);
@@ -2103,7 +2110,7 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
         if (sp.kind != LC_STEP_AND || !sp.scans || !sp.preds || sp.n_terms == 0 || sp.n_terms > 2) return false;
         const lc_scan* s = sp.scans[0];
         if (!s || s->n == 0 || s->is_str || s->lane_log2 < 4 || s->max_w > 32 || s->has_clamped || s->any_float) return false;
-        if (first && (s->ctx != first->ctx || s->seg_offsets != first->seg_offsets)) return false;
+        if (first && (s->ctx != first->ctx || s->lens != first->lens)) return false;
         for (uint32_t t = 0; t < sp.n_terms; t++) {
             const int op = sp.preds[t].op;
             if (op < LC_OP_EQ || op > LC_OP_GE || !sp.preds[t].lit) return false;
@@ -2190,51 +2197,6 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
     }
     if (d_final_mask) *d_final_mask = const_cast<void*>(sel);
     return LC_OK;
-    });
-}
-
-size_t lc_debug_row_lists(const uint16_t* keys, const uint8_t* validity, uint32_t n, uint32_t d, uint16_t* out, size_t cap) {
-    if (!keys || !out || n > kPostMaxRows || d == 0) return 0;
-    const std::vector<uint16_t> post = build_row_lists(keys, validity, n, d);
-    if (post.size() > cap) return 0;
-    std::memcpy(out, post.data(), post.size() * 2);
-    return post.size();
-}
-
-size_t lc_debug_entry_signatures(void* ctx_, uint64_t entry_id, uint8_t* out, size_t cap) {
-    lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
-    if (!ctx || !out || ctx->device < 0) return 0;
-    const uint64_t* src = nullptr;
-    size_t bytes = 0;
-    {
-        std::shared_lock<std::shared_mutex> g(ctx->mu);
-        auto it = ctx->entries.find(entry_id);
-        if (it == ctx->entries.end() || !it->second.is_str || !it->second.sd.signatures) return 0;
-        src = it->second.sd.signatures;
-        bytes = size_t(kSigBits) * ((size_t(it->second.sd.d) + 63) / 64) * 8;
-    }
-    if (bytes == 0 || bytes > cap) return 0;
-    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
-    if (hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-    return bytes;
-}
-
-int32_t lc_calibrate_read(void* ctx_, uint64_t bytes, int32_t shape, int32_t iters) {
-    lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
-    return guarded([&]() -> lc_status {
-    if (!ctx || bytes < 4096 || iters <= 0) return fail(LC_ERR_INVALID, "bad argument");
-    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
-    LC_HIP(hipSetDevice(ctx->device));
-    void* d = nullptr;
-    LC_HIP(hipMalloc(&d, bytes + 8192));
-    lc_status rc = LC_OK;
-    if (hipMemset(d, 1, bytes + 8192) != hipSuccess || hipDeviceSynchronize() != hipSuccess) rc = fail(LC_ERR_DEVICE, "memset");
-    for (int i = 0; i < iters && rc == LC_OK; i++)
-        if (launch_calib_read(d, bytes, shape, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d) + bytes), nullptr) != hipSuccess)
-            rc = fail(LC_ERR_INVALID, "unknown access shape (4, 8, 16 or 1008)");
-    (void)hipDeviceSynchronize();
-    (void)hipFree(d);
-    return rc;
     });
 }
 
@@ -3123,6 +3085,9 @@ static lc_status squeeze_half_width(lc_ctx* ctx, uint64_t n, const uint64_t* ent
             // integers (both policies) and decimals (LiquidDecimalArray::squeeze always quantizes, decimal_array.rs:300-345)
             const bool kind_ok = e.fd.kind == kKindInt || (quantize && e.fd.kind == kKindDecimal);
             if (e.is_str || !kind_ok || e.all_null || e.W < 8 || e.clamped || e.quantized || e.squeezed_field >= 0) continue;
+            // Date32 / Timestamp arrays are never half-width squeezed by the reference: their squeeze() only knows the
+            // date-component form and returns None without such a hint (primitive_array.rs:398-411)
+            if (date_ticks_per_day(e) >= 0) continue;
             by_lane[e.fd.lane_log2].push_back(entry_ids[i]);
         }
     }

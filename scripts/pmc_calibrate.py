@@ -14,6 +14,6 @@ BYTES = 1 << 30
 cache = lc.LiquidCacheBuilder.new().build()
 L = N.load()
 for shape in (4, 8, 16, 1008):
-    N.check(L.lc_calibrate_read(cache.handle, BYTES, shape, 5), cache.handle)
+    N.check(N.load_bench().lc_calibrate_read(cache.handle, BYTES, shape, 5), cache.handle)
 print("calibration launches done: %d bytes per launch" % BYTES)
 cache.close()

@@ -36,7 +36,7 @@ f=$(find $O/tpch_q6_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && c
 grep -h '^{"metric"' $O/tpch_q6_trace.log > $O/tpch_q6_bench_line.json
 fi
 # the same LIKE scan with the reference's own prefilter only (no bigram signature index staged)
-has url_like_no_signatures && run_one url_like_no_signatures "LC_NO_SIGNATURES=1" "--workload url_like"
+has url_like_no_signatures && run_one url_like_no_signatures "LC_X=0" "--workload url_like --no-signatures"
 # FETCH_SIZE calibration on known byte counts
 has calib && timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex "k_calib" --output-format csv -d $O/calib_FETCH_SIZE -- python $R/scripts/pmc_calibrate.py > $O/calib.log 2>&1
 python $R/scripts/pmc_summary.py $O > $O/pmc_summary.txt 2>&1

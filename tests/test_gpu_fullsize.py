@@ -66,7 +66,7 @@ def test_int64_scan_full_size(product_lib, bench_mod):
         buf = np.zeros(BS, np.int64)
         for b in [0, n_batches - 1] + [int(x) for x in rng.integers(1, n_batches - 1, size=40)]:
             rows = min(BS, ROWS - b * BS)
-            L.lc_synth_int64_batch(args.seed, b, rows, args.int_bits, base, buf.ctypes.data)
+            N.load_bench().lc_synth_int64_batch(args.seed, b, rows, args.int_bits, base, buf.ctypes.data)
             want = buf[:rows] > lit
             assert int(c_gt[b]) == int(want.sum()), b
             assert _entry_bits(m_gt, scan, b, rows).tolist() == want.tolist(), b
@@ -114,7 +114,7 @@ def test_url_like_scan_full_size(product_lib, bench_mod):
         sample += [int(b) for b in np.nonzero(c)[0][:10]]           # and batches that do have matches
         for b in sample:
             rows = min(BS, ROWS - b * BS)
-            n = L.lc_synth_url_batch(args.seed, b, rows, min(args.uniques, rows), args.needle_ppm, offs.ctypes.data, data.ctypes.data,
+            n = N.load_bench().lc_synth_url_batch(args.seed, b, rows, min(args.uniques, rows), args.needle_ppm, offs.ctypes.data, data.ctypes.data,
                                      data.size)
             raw = data[:n].tobytes()
             want = np.array([b"google" in raw[offs[i]:offs[i + 1]] for i in range(rows)])
@@ -129,7 +129,7 @@ def test_url_like_scan_full_size(product_lib, bench_mod):
         for rg in range((n_batches + rgb - 1) // rgb):
             b = min(rg * rgb + rg % rgb, n_batches - 1)
             rows = min(BS, ROWS - b * BS)
-            n = L.lc_synth_url_batch(args.seed, b, rows, min(args.uniques, rows), args.needle_ppm, offs.ctypes.data, data.ctypes.data,
+            n = N.load_bench().lc_synth_url_batch(args.seed, b, rows, min(args.uniques, rows), args.needle_ppm, offs.ctypes.data, data.ctypes.data,
                                      data.size)
             raw = data[:n].tobytes()
             strs = [raw[offs[i]:offs[i + 1]] for i in range(rows)]
@@ -195,8 +195,8 @@ def test_q21_pipeline_contents_full_size(product_lib, bench_mod, oracle):
         for b in sample:
             rows = min(BS, ROWS - b * BS)
             liquids = []
-            for col, synth, extra, eid, h in ((13, L.lc_synth_url_batch, (min(args.uniques, rows), args.needle_ppm), url_ids[b], hint),
-                                              (39, L.lc_synth_phrase_batch, (600, 870), sp_ids[b], None)):
+            for col, synth, extra, eid, h in ((13, N.load_bench().lc_synth_url_batch, (min(args.uniques, rows), args.needle_ppm), url_ids[b], hint),
+                                              (39, N.load_bench().lc_synth_phrase_batch, (600, 870), sp_ids[b], None)):
                 n = synth(args.seed, b, rows, *extra, offs.ctypes.data, data.ctypes.data, data.size)
                 arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1].copy()), pa.py_buffer(data[:max(n, 1)].copy()))
                 path = lc.ParquetArrayID.column_access_path(eid)

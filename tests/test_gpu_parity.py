@@ -181,10 +181,9 @@ def _make_strings(rng, n, n_unique, with_nulls):
 
 @pytest.fixture()
 def gpu_cache_no_signatures(product_lib, monkeypatch):
-    """A context that stages byte views WITHOUT the bigram signature index (LC_NO_SIGNATURES is read when the context
-    is created): the kernel then runs the reference's fingerprint filter."""
-    monkeypatch.setenv("LC_NO_SIGNATURES", "1")
-    cache = lc.LiquidCacheBuilder.new().build()
+    """A context that stages byte views WITHOUT the bigram signature index (lc_ctx_set_option LC_OPT_SIGNATURE_INDEX = 0):
+    the kernel then runs the reference's fingerprint filter."""
+    cache = lc.LiquidCacheBuilder.new().with_index_options(signatures=False).build()
     yield cache
     cache.close()
 

@@ -1235,7 +1235,7 @@ def test_device_transcoder_floats_alp_byte_identical(gpu_cache):
 
 
 def test_device_built_signature_index_equals_the_host_built_one(product_lib, oracle, monkeypatch):
-    """k_str_build_signatures (default) against the host builder (LC_HOST_SIGNATURES=1) on the same staged bytes: the
+    """k_str_build_signatures (default) against the host builder (LC_OPT_HOST_BUILT_INDEX) on the same staged bytes: the
     slices must be bit-identical — plain URLs, values full of escapes (bytes the table does not know, 0xFF runs), empty
     values, a shared prefix, dictionaries that are not a multiple of 64."""
     lo = oracle
@@ -1259,17 +1259,17 @@ def test_device_built_signature_index_equals_the_host_built_one(product_lib, ora
         blobs.append((liquid, lo.symtab_bytes(st2)))
     sigs = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("LC_HOST_SIGNATURES", mode)
-        cache = lc.LiquidCacheBuilder.new().with_device(0).build()
+        cache = lc.LiquidCacheBuilder.new().with_device(0).with_index_options(host_built=(mode == "1")).build()
         got = []
         for k, (liquid, stb) in enumerate(blobs):
             cache.set_symbol_table(900 + k, stb)
             eid = lc.ParquetArrayID.new(70, 0, 1, k)
             cache.stage([eid], [liquid], [900 + k])
             d = cache.entry_info(eid).dict_len
-            buf = np.zeros(128 * ((d + 63) // 64) * 8, np.uint8)
-            nb = cache._lib.lc_debug_entry_signatures(cache.handle, int(eid), buf.ctypes.data_as(C.c_void_p), buf.size)
-            assert nb == buf.size and buf.any()
+            blob = cache.entry_index_bytes(eid)  # 40-byte header, the signature slices, the row lists
+            sig_bytes = 128 * max((d + 63) // 64, 1) * 8
+            buf = np.frombuffer(blob, np.uint8)[40: 40 + sig_bytes]
+            assert len(buf) == sig_bytes and buf.any()
             got.append(buf)
         sigs[mode] = got
         cache.close()
@@ -1384,7 +1384,7 @@ def test_scan_sum_product_matches_python_integers(gpu_cache, oracle, kind):
 @pytest.mark.gpu
 def test_inverted_row_lists_give_the_masks_of_the_key_mapping(product_lib, oracle, monkeypatch):
     """LIKE over entries that carry the inverted row lists (default) against the same entries staged without them
-    (LC_NO_POSTINGS=1: every matching entry maps its keys) and against the oracle: needles matching no dictionary value,
+    (LC_OPT_ROW_LISTS = 0: every matching entry maps its keys) and against the oracle: needles matching no dictionary value,
     one or two, a few dozen and most of them (more than the list path takes: key mapping again); nulls, a selection,
     validity output through eval_predicate, entries of 8192 / 8191 / 65 / 1 rows and one of 9000 rows (no lists)."""
     lo = oracle
@@ -1404,8 +1404,7 @@ def test_inverted_row_lists_give_the_masks_of_the_key_mapping(product_lib, oracl
     pats = (b"%needle-once%", b"%needle%", b"%nomatchatall%", b"%google%", b"%http%", b"%x1%", b"%9%")
     results = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("LC_NO_POSTINGS", mode)
-        cache = lc.LiquidCacheBuilder.new().with_device(0).build()
+        cache = lc.LiquidCacheBuilder.new().with_device(0).with_index_options(row_lists=(mode == "0")).build()
         cache.set_symbol_table(7171, lo.symtab_bytes(st))
         ids = [lc.ParquetArrayID.new(71, 0, 2, b) for b in range(len(lens))]
         cache.stage(ids, blobs, [7171] * len(ids))
@@ -1456,7 +1455,7 @@ def _synth_url_batch(b, rows=8192):
     L = N.load()
     offs = np.zeros(rows + 1, np.int32)
     data = np.zeros(rows * 512, np.uint8)
-    n = L.lc_synth_url_batch(42, b, rows, 2200, 159, offs.ctypes.data, data.ctypes.data, data.size)
+    n = N.load_bench().lc_synth_url_batch(42, b, rows, 2200, 159, offs.ctypes.data, data.ctypes.data, data.size)
     raw = data[:n].tobytes()
     arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs.copy()), pa.py_buffer(data[:n].copy()))
     return arr, [raw[offs[i]: offs[i + 1]] for i in range(rows)]

@@ -19,20 +19,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    return set(re.findall(r"\b(lc_[a-z0-9_]+)\s*\(", text)) - {"lc_status"}
+
+
+def _exported(path):
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+    return {line.split()[-1] for line in out.splitlines() if " T " in line}
+
+
 def test_library_exports_every_declared_symbol(product_lib):
-    declared = set()
-    for h in ("liquid_cache_amd.h", "liquid_cache_amd_bench.h"):
-        text = open(os.path.join(ROOT, "include", h)).read()
-        declared |= set(re.findall(r"\b(lc_[a-z0-9_]+)\s*\(", text))
-    declared -= {"lc_status"}
+    declared = _declared("liquid_cache_amd.h")
     assert declared == set(N.EXPORTED_SYMBOLS)
-    out = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True, check=True).stdout
-    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    exported = _exported(N.LIB_PATH)
     missing = declared - exported
-    assert not missing, f"symbols declared in include/*.h but not exported: {sorted(missing)}"
+    assert not missing, f"symbols declared in include/liquid_cache_amd.h but not exported: {sorted(missing)}"
     for name in declared:
         assert hasattr(product_lib, name)
     assert b"gfx950" in product_lib.lc_version()
+
+
+def test_bench_aids_live_in_their_own_library(product_lib):
+    """Data generators and profiling aids (include/liquid_cache_amd_bench.h) are NOT part of the product library."""
+    declared = _declared("liquid_cache_amd_bench.h")
+    assert declared == set(N.BENCH_SYMBOLS)
+    assert not (declared & _exported(N.LIB_PATH)), "bench aids leaked into the product library"
+    assert declared <= _exported(N.BENCH_LIB_PATH)
+    B = N.load_bench()
+    for name in declared:
+        assert hasattr(B, name)
+    # and nothing in the product library's exports is undeclared
+    assert _exported(N.LIB_PATH) <= _declared("liquid_cache_amd.h"), sorted(_exported(N.LIB_PATH) - _declared("liquid_cache_amd.h"))
 
 
 def test_library_embeds_gfx950_code_object():
@@ -270,7 +288,7 @@ def test_bench_cpu_baseline_counts_are_the_substring_truth():
     offs = np.zeros(bs + 1, np.int32)
     data = np.zeros(bs * 512, np.uint8)
     for b in (first, first + 3, first + 12):
-        n = L.lc_synth_url_batch(args.seed, b, bs, args.uniques, args.needle_ppm, offs.ctypes.data, data.ctypes.data, data.size)
+        n = N.load_bench().lc_synth_url_batch(args.seed, b, bs, args.uniques, args.needle_ppm, offs.ctypes.data, data.ctypes.data, data.size)
         raw = data[:n].tobytes()
         strs = [raw[offs[i]: offs[i + 1]] for i in range(bs)]
         arr = pa.StringArray.from_buffers(bs, pa.py_buffer(offs.copy()), pa.py_buffer(data[:n].copy()))
@@ -295,7 +313,7 @@ def test_inverted_row_lists_layout(product_lib):
         keys[~valid] = rng.integers(0, 65536, size=int((~valid).sum())).astype(np.uint16)   # garbage under nulls
         bitmap = np.packbits(valid, bitorder="little")
         out = np.zeros(d + 1 + n + 32, np.uint16)
-        got = product_lib.lc_debug_row_lists(keys.ctypes.data, bitmap.ctypes.data if p_null else None, n, d,
+        got = N.load_bench().lc_debug_row_lists(keys.ctypes.data, bitmap.ctypes.data if p_null else None, n, d,
                                             out.ctypes.data, out.size)
         assert got == out.size
         off, rows = out[: d + 1].astype(np.int64), out[d + 1: d + 1 + n]
@@ -306,6 +324,6 @@ def test_inverted_row_lists_layout(product_lib):
     # out of contract: more rows than an entry with lists may have, no dictionary, a short buffer
     big = np.zeros(9000, np.uint16)
     out = np.zeros(20000, np.uint16)
-    assert product_lib.lc_debug_row_lists(big.ctypes.data, None, 9000, 10, out.ctypes.data, out.size) == 0
-    assert product_lib.lc_debug_row_lists(big.ctypes.data, None, 100, 0, out.ctypes.data, out.size) == 0
-    assert product_lib.lc_debug_row_lists(big.ctypes.data, None, 100, 10, out.ctypes.data, 50) == 0
+    assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 9000, 10, out.ctypes.data, out.size) == 0
+    assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 100, 0, out.ctypes.data, out.size) == 0
+    assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 100, 10, out.ctypes.data, 50) == 0
