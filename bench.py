@@ -734,8 +734,15 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads, extra
     dt_mt = time.perf_counter() - t1
     all_cores = {"value": rows_total / dt_mt, "unit": "rows/s", "cores": cores, "kind": "port",
                  "sample": "same batches, one batch per OpenMP task, %.2f s" % dt_mt, "hits": int(hits_mt)}
-    if extra_patterns:
-        all_cores["extra_hits"] = {p.decode(): int(lo.bench_eval_batches(bl, sts, lo.LIKE, p, cores)) for p in extra_patterns}
+    # checker leg (untimed): the oracle's hit MASK and per-batch counts for the headline pattern and the extra needles, in
+    # scan layout, for a bit-for-bit comparison with the GPU's over the whole sample
+    seg = np.zeros(n_sample + 1, np.uint64)
+    for b in range(n_sample):
+        seg[b + 1] = seg[b] + (min(bs, args.rows - b * bs) + 63) // 64
+    checks = {}
+    for p in (pattern,) + tuple(extra_patterns):
+        checks[p.decode() if isinstance(p, bytes) else p] = lo.bench_eval_batches_masks(bl, sts, lo.LIKE, p, seg, cores)
+    all_cores["_checks"] = checks
     return rows_total / dt, rows_total, int(hits), dt, all_cores
 
 
@@ -1076,18 +1083,33 @@ def main():
             # the CPU restatement of the reference algorithm and the GPU scan saw the same bytes: same COUNT(*)
             assert hits_s == hits == all_cores["hits"], "GPU hits %d != CPU oracle hits %d" % (hits, hits_s)
             out["config"]["hits_match_cpu_oracle"] = True
-            if all_cores.get("extra_hits"):
-                try:  # the same comparison for the other needles (reported, never fatal to the bench line)
-                    import pyarrow as pa
-                    par = {}
-                    for pat, cpu_h in all_cores.pop("extra_hits").items():
-                        e2 = lc.LiquidExpr.try_new("like", pat.encode(), pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
-                        scan.eval(e2, mask.data_ptr(), 0, counts.data_ptr(), stream)
-                        gpu_h = int(counts.sum(dtype=torch.int64).item())
-                        par[pat] = {"gpu_hits": gpu_h, "cpu_oracle_hits": cpu_h, "match": gpu_h == cpu_h}
-                    out["config"]["other_needles_match_cpu_oracle"] = par
-                except Exception as e:  # noqa: BLE001
-                    out["config"]["other_needles_match_cpu_oracle"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            checks = all_cores.pop("_checks", None)
+            if checks:
+                # bit-for-bit: the GPU's hit mask and per-entry counts against the oracle's, over the WHOLE column, for
+                # the headline needle and the extra ones (scalars only, so that they survive into the driver's record)
+                import pyarrow as pa
+                n_ok = n_bad = 0
+                worst = None
+                for pat, (cpu_total, cpu_mask, cpu_counts) in checks.items():
+                    e2 = lc.LiquidExpr.try_new("like", pat.encode(), pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
+                    mask.zero_()
+                    scan.eval(e2, mask.data_ptr(), 0, counts.data_ptr(), stream)
+                    torch.cuda.synchronize()
+                    g_mask = mask.cpu().numpy().view(np.uint64)[: cpu_mask.size]
+                    g_counts = counts.cpu().numpy().view(np.uint32)[: cpu_counts.size]
+                    ok = bool(np.array_equal(g_mask, cpu_mask)) and bool(np.array_equal(g_counts, cpu_counts))
+                    n_ok += ok
+                    n_bad += not ok
+                    if not ok and worst is None:
+                        worst = "%s: gpu %d cpu %d, %d entries differ" % (pat, int(g_counts.sum()), cpu_total,
+                                                                          int((g_counts != cpu_counts).sum()))
+                out["config"]["needles_checked"] = n_ok + n_bad
+                out["config"]["needle_masks_all_match_cpu_oracle"] = n_bad == 0
+                out["config"]["needle_entry_counts_all_match_cpu_oracle"] = n_bad == 0
+                if worst:
+                    out["config"]["needle_first_mismatch"] = worst
+                assert n_bad == 0, "GPU mask differs from the CPU oracle's: " + str(worst)
+        all_cores.pop("_checks", None)
 
     if rank == 0 and world == 1 and not args.no_secondary:
         sec = {}

@@ -29,112 +29,11 @@
 #include <type_traits>
 #include <utility>
 
-extern "C" __device__ int __llvm_amdgcn_writelane_i32(int, int, int) __asm("llvm.amdgcn.writelane.i32");
+#include "lc_device.hpp"
 
 namespace lc {
 
 namespace {
-
-constexpr int kWave = 64;
-constexpr int kWavesPerBlock = 4;
-constexpr int kThreads = kWave * kWavesPerBlock;
-
-__device__ __forceinline__ int lane_id() { return int(threadIdx.x) & (kWave - 1); }
-__device__ __forceinline__ int wave_id() { return int(threadIdx.x) >> 6; }
-
-// number of set bits of `mask` strictly below this lane
-__device__ __forceinline__ uint32_t lanes_below(uint64_t mask) {
-    return __builtin_amdgcn_mbcnt_hi(uint32_t(mask >> 32), __builtin_amdgcn_mbcnt_lo(uint32_t(mask), 0u));
-}
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, kWave);
-    return v;  // lane 0 holds the total
-}
-
-// Cross-lane steps on the VALU's DPP path (a few cycles) instead of ds_bpermute (an LDS round trip, ~100 cycles):
-// the byte-view kernel is bound by the length of its dependent chains.
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
-    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kCtrl, kRowMask, 0xF, false));
-}
-// inclusive prefix sum over the 64 lanes (gfx9 DPP: row_shr within rows of 16, then row_bcast15 / row_bcast31)
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
-    v += dpp_or_zero<0x111, 0xF>(v);  // row_shr:1
-    v += dpp_or_zero<0x112, 0xF>(v);  // row_shr:2
-    v += dpp_or_zero<0x114, 0xF>(v);  // row_shr:4
-    v += dpp_or_zero<0x118, 0xF>(v);  // row_shr:8
-    v += dpp_or_zero<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
-    v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
-    return v;
-}
-// value of the previous lane (lane 0 gets `first`)
-__device__ __forceinline__ uint32_t lane_shift_up1(uint32_t v, uint32_t first) {
-    return uint32_t(__builtin_amdgcn_update_dpp(int(first), int(v), 0x138, 0xF, 0xF, false));  // wave_shr:1
-}
-__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
-    const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
-    const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))));
-    return uint64_t(lo) | (uint64_t(hi) << 32);
-}
-__device__ __forceinline__ uint32_t read_lane(uint32_t v, int lane) { return uint32_t(__builtin_amdgcn_readlane(int(v), lane)); }
-
-// global -> LDS DMA of 16 bytes per active lane: lane l writes lds_base + l*16 (lds_base must be wave-uniform)
-__device__ __forceinline__ void async_copy16(const void* gsrc_lane, void* lds_base) {
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
-                                         reinterpret_cast<uintptr_t>(gsrc_lane)),
-                                     reinterpret_cast<__attribute__((address_space(3))) void*>(
-                                         uint32_t(reinterpret_cast<uintptr_t>(lds_base))),
-                                     16, 0, 0);
-}
-
-// v_writelane_b32 with a compile-time lane.  The LLVM intrinsic, not inline assembly: gfx950 needs two wait states
-// between a VALU instruction that writes an SGPR / VCC (v_cmp) and a v_writelane that reads it.  The compiler's hazard
-// recognizer provides them (s_nop, or independent work scheduled in between) for its own instructions only; a
-// hand-written v_writelane placed right behind the v_cmp reads the PREVIOUS mask (found the hard way: counts stayed
-// plausible, bits did not).
-template <uint32_t LANE>
-__device__ __forceinline__ uint32_t writelane_c(uint32_t sval, uint32_t old) {
-    return uint32_t(__llvm_amdgcn_writelane_i32(int(sval), int(LANE), int(old)));
-}
-
-// Pointers read out of descriptors are generic to the compiler; these casts make the accesses global_load (own
-// vmcnt counter, no coupling with LDS waits) instead of flat_load.
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-template <typename T>
-using GlobalPtr = const __attribute__((address_space(1))) T*;
-template <typename T>
-__device__ __forceinline__ GlobalPtr<T> as_global(const T* p) { return (GlobalPtr<T>)p; }
-// stores through a pointer the compiler cannot prove global would be FLAT stores: besides the slower path, a pending flat
-// access makes the compiler wait for ALL outstanding loads (vmcnt(0)) at the next use of any loaded value
-template <typename T>
-using GlobalMutPtr = __attribute__((address_space(1))) T*;
-template <typename T>
-__device__ __forceinline__ GlobalMutPtr<T> as_global_mut(T* p) { return (GlobalMutPtr<T>)p; }
-
-// Fused COUNT(*): called by ONE lane of every wave of the launch (`unit` = its index, `n_units` = how many there are)
-// with the hits of the entries that wave evaluated.  Two levels of {arrivals : 24 | hits : 40} words: the last arrival
-// of a shard forwards the shard's sum to the top word, the last shard writes the total and leaves every word zero
-// for the next launch.  One returning far atomic per wave, nothing spins.
-__device__ __forceinline__ void total_contribute(const ScanLaunch& L, uint32_t unit, uint32_t n_units, uint64_t hits) {
-    constexpr unsigned long long kOne = 1ull << 40, kMask = kOne - 1;
-    const uint32_t n_shards = n_units < kTotalShards ? n_units : kTotalShards;
-    const uint32_t shard = unit % n_shards;
-    const uint32_t in_shard = (n_units - shard + n_shards - 1) / n_shards;
-    unsigned long long* sw = L.d_total_acc + 8u * (shard + 1u);
-    const unsigned long long inc = kOne | (hits & kMask);
-    const unsigned long long old = atomicAdd(sw, inc);
-    if ((old >> 40) + 1ull != in_shard) return;
-    const unsigned long long shard_hits = (old + inc) & kMask;
-    atomicExch(sw, 0ull);
-    const unsigned long long tinc = kOne | shard_hits;
-    const unsigned long long told = atomicAdd(L.d_total_acc, tinc);
-    if ((told >> 40) + 1ull != n_shards) return;
-    atomicExch(L.d_total_acc, 0ull);
-    // an atomic store: the value must land in memory, not in this XCD's L2 behind a later k_alp_patch_fix adjustment
-    atomicExch(reinterpret_cast<unsigned long long*>(L.d_total_out), (told + tinc) & kMask);
-}
 
 // FL_ORDER[x] = 3-bit reversal, stored as nibbles
 __device__ __forceinline__ uint32_t fl_order(uint32_t x) { return (0x73516240u >> (4 * x)) & 7u; }
@@ -1222,13 +1121,6 @@ constexpr uint32_t kCandCapSigOnly = 256;
 #define LC_X_POSTINGS 1
 #endif
 
-template <typename T>
-__device__ __forceinline__ T load_unaligned(const uint8_t* p) {
-    T v;
-    __builtin_memcpy(&v, (const __attribute__((address_space(1))) uint8_t*)p, sizeof(T));
-    return v;
-}
-
 template <typename D>
 __device__ __forceinline__ uint32_t str_offset(const D& d, uint32_t i) {
     int32_t r;
@@ -1432,11 +1324,6 @@ __device__ __forceinline__ bool like_walk_global(const uint8_t* __restrict__ fss
 #define LC_TM(i, dep)
 #endif
 
-typedef const __attribute__((address_space(3))) uint8_t* LdsBytePtr;
-typedef const __attribute__((address_space(3))) uint16_t* LdsU16Ptr;
-__device__ __forceinline__ uint32_t lds_u16(uint32_t addr) { return *reinterpret_cast<LdsU16Ptr>(addr); }
-__device__ __forceinline__ uint32_t lds_u8(uint32_t addr) { return *reinterpret_cast<LdsBytePtr>(addr); }
-
 #ifndef LC_X_MAXBYTETABLE
 #define LC_X_MAXBYTETABLE 4096
 #endif
@@ -1457,31 +1344,6 @@ constexpr uint32_t kMaxByteTable = LC_X_MAXBYTETABLE;  // dictionary results as 
 //      (absorbing state) is recorded and not propagated.
 // An entry's ~9 candidates x ~6 words fit one pass of the wave: the chain is ~16-24 lookups instead of ~90 per value.
 // ------------------------------------------------------------------------------------------------------------------
-// compressed bytes per lane and pass of the lane-parallel walk.  An entry's ~9 candidates are ~80 8-byte words, so
-// 16-byte tasks would make one pass the usual case — measured: no gain (the kernel is bound by instruction issue, not by
-// the extra round trip), and the second word's registers cost a wave of occupancy (35 -> 42 us).
-#ifndef LC_WALK_TASK_WORDS
-#define LC_WALK_TASK_WORDS 1
-#endif
-constexpr int kTaskWords = LC_WALK_TASK_WORDS;
-constexpr uint32_t kTaskBytes = 8u * kTaskWords;
-__device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], uint32_t rem) {
-    const uint32_t s1 = lds_u16(sb + x[0]);
-    const uint32_t s2 = lds_u16(s1 + x[1]);
-    const uint32_t s3 = lds_u16(s2 + x[2]);
-    const uint32_t s4 = lds_u16(s3 + x[3]);
-    const uint32_t s5 = lds_u16(s4 + x[4]);
-    const uint32_t s6 = lds_u16(s5 + x[5]);
-    const uint32_t s7 = lds_u16(s6 + x[6]);
-    const uint32_t s8 = lds_u16(s7 + x[7]);
-    // state after the first min(rem, 8) bytes
-    const uint32_t r = min(rem, 8u) - 1u;
-    const uint32_t a0 = (r & 1u) ? s2 : s1, a1 = (r & 1u) ? s4 : s3, a2 = (r & 1u) ? s6 : s5, a3 = (r & 1u) ? s8 : s7;
-    const uint32_t b0 = (r & 2u) ? a1 : a0, b1 = (r & 2u) ? a3 : a2;
-    const uint32_t sel = (r & 4u) ? b1 : b0;
-    return rem == 0 ? sb : sel;
-}
-
 // Sequential walker over the same LDS image for entries with at least a wave of candidates (no signature index, or no
 // fingerprints at all: every dictionary value is walked).  Every lane owns two independent chains; chain c of lane l walks
 // candidates l + 64 c, l + 64 c + 128, ... ONE AFTER THE OTHER without waiting for its neighbours, so the wave stays

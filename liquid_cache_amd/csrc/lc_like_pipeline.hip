@@ -1,0 +1,559 @@
+// Scan-level pipeline for SELECTIVE `LIKE '%needle%'` over byte-view columns that carry the bigram signature index and
+// the inverted row lists (the headline scan: ClickBench q20 / "Q21", URL LIKE '%google%').
+//
+// What it replaces: k_str_pred puts ONE WAVE on every entry and takes it through five dependent round trips (descriptor
+// -> signature slices -> candidate offsets -> compressed bytes -> row lists) with ~1,300 instructions, most of which run
+// once per entry whatever the entry holds; measured (round 2) it is bound by that chain, not by bandwidth.  Here the
+// same work is cut into two throughput-shaped kernels over the WHOLE scan:
+//
+//   k_like_probe   one lane per 64 dictionary values of the scan (a flat index over all entries, built once per scan):
+//                  AND of the needle's signature slices (coalesced 8-byte loads), candidates compacted into ONE list for
+//                  the scan, written at positions known from the plan (no atomics; the list is ordered by entry, hence
+//                  grouped by symbol table).  The same kernel zero-fills the hit mask and the per-entry counts.
+//   k_like_walk    one wave per 64 candidates of ONE symbol table, whatever entries they belong to: the needle's
+//                  automaton folded over the table's FSST symbols sits in LDS (k_str_automata's image), the candidates'
+//                  compressed bytes are cut into 8-byte words and walked one lane per word (the walker of k_str_pred,
+//                  exact at its fixpoint); the rows of a matching dictionary value are read from the entry's inverted
+//                  row list and OR-ed into the mask with far atomics (a selective needle matches a few thousand rows
+//                  of 100 M), hits are added to the per-entry counts and to the fused COUNT(*).
+//
+// Reference counterpart: LiquidByteViewArray::compare_like_substring — fingerprint filter, decode + memmem of the
+// candidates, map_dictionary_results_to_array_results (byte_view_array/comparisons.rs:159-183, 325-347, 598-651).
+// Results are identical (the candidates of the signature AND are a superset of the matches, the walk is exact).
+//
+// The PLAN (once per scan and needle, cached): the probe runs in count mode, the per-wave candidate counts come back to
+// the host (the one synchronisation), their prefix sums become the write positions and the chunk schedule of the walk;
+// then one trial run counts the hits.  Entries are immutable while a scan pins them, so the counts are a property of
+// (scan, needle) and every later evaluation runs without a host round trip.  Needles that are not selective (many
+// candidates or many hit rows: the atomics would dominate) keep k_str_pred, as do scans with entries that lack the
+// index, NOT LIKE, validity outputs and the byte-accounting pass.
+#include "lc_device.hpp"
+#include "lc_internal.hpp"
+
+namespace lc {
+
+struct alignas(16) LikeK1Ref {
+    const uint64_t* sig;  // bit-sliced signatures of the entry: slice b at sig + b * nw
+    uint32_t woff;        // first flat word of the entry
+    uint32_t nw;          // ceil(d / 64)
+    uint32_t d;
+    uint32_t slot;        // symbol-table slot
+    uint32_t pad[2];
+};
+static_assert(sizeof(LikeK1Ref) == 32, "LikeK1Ref layout");
+
+struct alignas(16) LikeK2Ref {
+    const uint8_t* fsst;
+    const uint8_t* residuals;
+    const uint16_t* postings;
+    uint64_t mask_word_off;
+    int32_t slope, intercept;
+    uint32_t offset_bytes, d;
+};
+static_assert(sizeof(LikeK2Ref) == 48, "LikeK2Ref layout");
+
+struct LikeChunk {
+    uint32_t first, count;  // candidates [first, first + count) of the scan's list, all of one symbol table
+    uint32_t slot;          // that table
+    uint32_t pad;
+};
+
+constexpr uint32_t kProbeThreads = 256;
+constexpr uint32_t kWalkWaves = 2;                       // waves per workgroup of the walk (they share the LDS automaton)
+constexpr uint32_t kWalkChunk = kWalkWaves * 64;         // candidates per workgroup
+constexpr uint32_t kMaxPlans = 8;
+// a needle is "selective" (worth the pipeline) up to this many signature candidates per entry on average and this many
+// hit rows per 1024 rows of the scan; beyond, k_str_pred's per-entry key mapping is the better algorithm
+constexpr uint32_t kMaxCandPerEntry = 48;
+constexpr uint32_t kMaxHitsPer1024 = 16;
+
+struct LikePlan {
+    std::vector<uint8_t> needle;
+    bool use_pipeline = false;
+    uint32_t n_cand = 0, n_chunks = 0;
+    uint64_t hits = 0;
+    uint32_t* d_wave_off = nullptr;  // write position of every probe wave (n_k1_waves)
+    LikeChunk* d_chunks = nullptr;
+    uint64_t* d_cand = nullptr;      // (entry << 16 | dictionary key) x n_cand
+    uint64_t last_use = 0;
+};
+
+struct LikePipeline {
+    bool built = false, eligible = false;
+    uint32_t n_flat = 0;         // flat words incl. the padding that keeps a probe wave inside one symbol table
+    uint32_t n_k1_waves = 0;
+    uint32_t* d_word_entry = nullptr;
+    LikeK1Ref* d_k1 = nullptr;
+    LikeK2Ref* d_k2 = nullptr;
+    std::vector<uint32_t> wave_slot;  // host: symbol-table slot of every probe wave
+    unsigned long long* d_total_acc = nullptr;
+    std::vector<LikePlan> plans;
+    uint64_t tick = 0;
+};
+
+namespace {
+
+struct ProbeArgs {
+    const uint32_t* word_entry;
+    const LikeK1Ref* refs;
+    uint32_t n_flat;
+    uint32_t n_entries;
+    uint16_t sig_bits[kMaxSigProbe];
+    uint32_t* wave_count;      // count mode
+    const uint32_t* wave_off;  // fill mode
+    uint64_t* cand;
+    uint64_t* mask;            // fill mode: zero-filled here
+    uint64_t mask_words;
+    uint32_t* counts;          // optional, zero-filled here
+    uint64_t* total_zero;      // optional: COUNT(*) word to clear (scans without a single candidate)
+};
+
+// N = distinct signature bits of the needle (1..8): every slice load is issued before the first use, none is repeated
+template <int N, bool kCount>
+__global__ __launch_bounds__(kProbeThreads) void k_like_probe(ProbeArgs a) {
+    const uint32_t gtid = blockIdx.x * kProbeThreads + threadIdx.x;
+    if (!kCount) {
+        // the hit mask starts all clear (the walk ORs the hit rows in); 16-byte coalesced stores over the whole grid
+        const uint32_t nthreads = gridDim.x * kProbeThreads;
+        GlobalMutPtr<u32x4> m4 = reinterpret_cast<GlobalMutPtr<u32x4>>(as_global_mut(a.mask));
+        const uint64_t n16 = a.mask_words >> 1;
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (uint64_t i = gtid; i < n16; i += nthreads) m4[i] = z;
+        if ((a.mask_words & 1u) && gtid == 0) as_global_mut(a.mask)[a.mask_words - 1] = 0;
+        if (a.counts)
+            for (uint32_t i = gtid; i < a.n_entries; i += nthreads) as_global_mut(a.counts)[i] = 0;
+        if (a.total_zero && gtid == 0) as_global_mut(a.total_zero)[0] = 0;
+    }
+    if (gtid >= a.n_flat) return;  // n_flat is a multiple of 64: whole waves leave
+    const int lane = lane_id();
+    const uint32_t e = as_global(a.word_entry)[gtid];
+    uint64_t m = 0;
+    uint32_t w = 0;
+    if (e != 0xFFFFFFFFu) {
+        const u32x4 r0 = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.refs + e));
+        const u32x4 r1 = *(reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.refs + e)) + 1);
+        const uint64_t* sig = reinterpret_cast<const uint64_t*>(uint64_t(r0.x) | (uint64_t(r0.y) << 32));
+        const uint32_t woff = r0.z, nw = r0.w, d = r1.x;
+        w = gtid - woff;
+        uint64_t sv[N];
+#pragma unroll
+        for (int k = 0; k < N; k++) sv[k] = as_global(sig)[size_t(a.sig_bits[k]) * nw + w];
+        m = sv[0];
+#pragma unroll
+        for (int k = 1; k < N; k++) m &= sv[k];
+        if (w == nw - 1u && (d & 63u)) m &= (uint64_t(1) << (d & 63u)) - 1;
+    }
+    const uint32_t cnt = uint32_t(__popcll(m));
+    const uint32_t incl = wave_inclusive_sum(cnt);
+    const uint32_t wv = gtid >> 6;
+    if (kCount) {
+        if (lane == kWave - 1) as_global_mut(a.wave_count)[wv] = incl;
+        return;
+    }
+    uint32_t o = as_global(a.wave_off)[wv] + incl - cnt;
+    while (m) {
+        const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+        as_global_mut(a.cand)[o++] = (uint64_t(e) << 16) | uint64_t(w * 64u + bit);
+        m &= m - 1;
+    }
+}
+
+struct WalkArgs {
+    const LikeChunk* chunks;
+    const uint64_t* cand;
+    const LikeK2Ref* refs;
+    const uint8_t* automata;
+    uint32_t automaton_stride;
+    uint32_t nl;
+    const uint64_t* selection;
+    uint64_t* mask;
+    uint32_t* counts;
+    ScanLaunch total;  // d_total_acc / d_total_out only
+};
+
+__device__ __forceinline__ uint64_t shfl_u64(uint64_t v, int src) {
+    const uint32_t lo = uint32_t(__shfl(int(uint32_t(v)), src, kWave));
+    const uint32_t hi = uint32_t(__shfl(int(uint32_t(v >> 32)), src, kWave));
+    return uint64_t(lo) | (uint64_t(hi) << 32);
+}
+
+__global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
+    // dynamic LDS: [automaton image (u16 row addresses, built for LDS address 0)][per wave: 64 hit flags + head mask]
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t nl = a.nl;
+    const uint32_t tbl_bytes = automaton_image_bytes(nl);
+    const LikeChunk ch = a.chunks[blockIdx.x];
+    {
+        const uint8_t* src = a.automata + size_t(ch.slot) * a.automaton_stride + automaton_u8_bytes(nl);
+        for (uint32_t c = wave * 1024u; c < tbl_bytes; c += kWalkWaves * 1024u)
+            async_copy16(src + c + uint32_t(lane) * 16u, smem + c);
+    }
+    uint8_t* hitflag = smem + tbl_bytes + wave * 80u;
+    uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
+    const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
+    const uint32_t hitrow = row0 + nl * 512u;
+
+    // this lane's candidate
+    const uint32_t idx = wave * 64u + uint32_t(lane);
+    const bool cl = idx < ch.count;
+    uint64_t c64 = 0;
+    if (cl) c64 = as_global(a.cand)[ch.first + idx];
+    const uint32_t e = uint32_t(c64 >> 16), key = uint32_t(c64) & 0xFFFFu;
+    uint64_t abs_start = 0;  // address of the candidate's first compressed byte
+    uint32_t len = 0;
+    uint64_t post_bits = 0, mask_off = 0;
+    uint32_t dlen = 0;
+    if (cl) {
+        GlobalPtr<u32x4> rp = reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.refs + e));
+        const u32x4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
+        const uint64_t fsst = uint64_t(r0.x) | (uint64_t(r0.y) << 32);
+        const uint8_t* residuals = reinterpret_cast<const uint8_t*>(uint64_t(r0.z) | (uint64_t(r0.w) << 32));
+        post_bits = uint64_t(r1.x) | (uint64_t(r1.y) << 32);
+        mask_off = uint64_t(r1.z) | (uint64_t(r1.w) << 32);
+        const uint32_t slope = r2.x, intercept = r2.y, ob = r2.z;
+        dlen = r2.w;
+        const uint64_t v = load_unaligned<uint64_t>(residuals + size_t(key) * ob);
+        const uint32_t sh = 32u - 8u * ob;
+        const int32_t q0 = int32_t(uint32_t(v) << sh) >> sh;
+        const int32_t q1 = int32_t(uint32_t(v >> (8u * ob)) << sh) >> sh;
+        const uint32_t start = slope * key + intercept + uint32_t(q0);
+        const uint32_t stop = slope * (key + 1u) + intercept + uint32_t(q1);
+        abs_start = fsst + start;
+        len = stop - start;
+    }
+    // ---- lane-parallel walk: one lane per 8-byte word of every candidate (see "the lane-parallel LIKE walker" in
+    // lc_kernels.hip: byte roles and automaton states are corrected across neighbouring lanes to a fixpoint, and a match
+    // counts only there)
+    const uint32_t words = cl ? max(1u, (len + 7u) >> 3) : 0u;
+    const uint32_t incl = wave_inclusive_sum(words);
+    const uint32_t off = incl - words;
+    const uint32_t total = read_lane(incl, kWave - 1);
+    hitflag[lane] = 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the image DMA has landed
+    __syncthreads();
+    uint32_t carry_state = row0;
+    for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
+        if (lane == 0) *headmask = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const bool head = cl && off >= t0 && off < t0 + kWave;
+        if (head) atomicOr(reinterpret_cast<unsigned long long*>(headmask), 1ull << (off - t0));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint64_t hm = *headmask;
+        const uint32_t before = uint32_t(__popcll(__ballot(cl && off < t0)));
+        const uint64_t upto = lane == 63 ? ~uint64_t(0) : ((uint64_t(2) << lane) - 1);
+        const uint32_t r = before + uint32_t(__popcll(hm & upto)) - 1u;  // owner lane of task t0 + lane
+        const bool live = t0 + uint32_t(lane) < total;
+        const uint32_t o_off = uint32_t(__shfl(int(off), int(r), kWave));
+        const uint32_t o_len = uint32_t(__shfl(int(len), int(r), kWave));
+        const uint64_t o_abs = shfl_u64(abs_start, int(r));
+        const uint32_t k = t0 + uint32_t(lane) - o_off;  // word index within the value
+        const uint32_t p = 8u * k;
+        const uint32_t rem = live && p < o_len ? o_len - p : 0u;
+        uint64_t wd = 0;
+        if (rem) wd = load_unaligned<uint64_t>(reinterpret_cast<const uint8_t*>(o_abs + p));
+        const bool first = k == 0;
+        auto walk_task = [&](uint32_t s) {
+            uint32_t x[8];
+            const uint32_t lo = uint32_t(wd), hi = uint32_t(wd >> 32);
+#pragma unroll
+            for (int q = 0; q < 8; q++) x[q] = (((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu) << 1;
+            return walk8(s, x, rem);
+        };
+        uint32_t s_in = row0;
+        uint32_t en = walk_task(s_in);
+        for (;;) {
+            uint32_t prev = lane_shift_up1(en, carry_state);
+            if (first || prev == hitrow) prev = row0;
+            const bool changed = prev != s_in;
+            if (__ballot(changed) == 0) break;
+            if (changed) {
+                s_in = prev;
+                en = walk_task(s_in);
+            }
+        }
+        const bool hit = en == hitrow;
+        carry_state = read_lane(en, kWave - 1);
+        if (carry_state == hitrow) carry_state = row0;
+        if (hit && live) hitflag[r] = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const bool res = cl && hitflag[lane] != 0;
+    uint64_t matched = __ballot(res);
+    uint64_t wave_hits = 0;
+    if (matched) {
+        // ---- rows of the matching dictionary values, from the entries' inverted row lists
+        uint32_t o0 = 0, o1 = 0;
+        if (res) {
+            const uint32_t v = load_unaligned<uint32_t>(reinterpret_cast<const uint8_t*>(post_bits) + 2u * size_t(key));
+            o0 = v & 0xFFFFu;
+            o1 = v >> 16;
+        }
+        while (matched) {
+            const int ml = int(__ffsll((long long)matched)) - 1;
+            matched &= matched - 1;
+            const uint32_t b = read_lane(o0, ml), e1 = read_lane(o1, ml);
+            const uint64_t pb = uniform_u64(shfl_u64(post_bits, ml));
+            const uint64_t moff = uniform_u64(shfl_u64(mask_off, ml));
+            const uint32_t dd = read_lane(dlen, ml);
+            const uint16_t* prow = reinterpret_cast<const uint16_t*>(pb) + dd + 1u;
+            uint32_t c = 0;
+            for (uint32_t rr = b + uint32_t(lane); rr < e1; rr += kWave) {
+                const uint32_t row = as_global(prow)[rr];
+                const uint64_t bit = uint64_t(1) << (row & 63u);
+                bool on = true;
+                if (a.selection) on = (as_global(a.selection)[moff + (row >> 6)] & bit) != 0;
+                if (on) {
+                    atomicOr(reinterpret_cast<unsigned long long*>(a.mask + moff + (row >> 6)), (unsigned long long)bit);
+                    c++;
+                }
+            }
+            const uint64_t ct = uniform_u64(wave_sum_u64(uint64_t(c)));
+            if (a.counts && lane == 0 && ct) atomicAdd(a.counts + read_lane(e, ml), uint32_t(ct));
+            wave_hits += ct;
+        }
+    }
+    if (a.total.d_total_out && lane == 0)
+        total_contribute(a.total, blockIdx.x * kWalkWaves + wave, gridDim.x * kWalkWaves, wave_hits);
+}
+
+template <bool kCount>
+hipError_t launch_probe(int n_sig, const ProbeArgs& a, hipStream_t stream) {
+    const uint32_t grid = (a.n_flat + kProbeThreads - 1) / kProbeThreads;
+    if (grid == 0) return hipSuccess;
+    typedef void (*Kern)(ProbeArgs);
+    static const Kern table[kMaxSigProbe] = {k_like_probe<1, kCount>, k_like_probe<2, kCount>, k_like_probe<3, kCount>,
+                                             k_like_probe<4, kCount>, k_like_probe<5, kCount>, k_like_probe<6, kCount>,
+                                             k_like_probe<7, kCount>, k_like_probe<8, kCount>};
+    hipLaunchKernelGGL(table[n_sig - 1], dim3(grid), dim3(kProbeThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_walk(const WalkArgs& a, uint32_t n_chunks, hipStream_t stream) {
+    if (n_chunks == 0) return hipSuccess;
+    const size_t lds = automaton_image_bytes(a.nl) + kWalkWaves * 80u;
+    hipLaunchKernelGGL(k_like_walk, dim3(n_chunks), dim3(kWalkWaves * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+void free_plan(lc_ctx* ctx, LikePlan& p) {
+    pool_release(ctx, p.d_wave_off);
+    pool_release(ctx, p.d_chunks);
+    pool_release(ctx, p.d_cand);
+    p.d_wave_off = nullptr;
+    p.d_chunks = nullptr;
+    p.d_cand = nullptr;
+}
+
+// flat index over the scan's dictionaries, built once per scan
+lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
+    lp->built = true;
+    lp->eligible = false;
+    if (!s->is_str || s->n == 0) return LC_OK;
+    for (const Entry& e : s->meta) {
+        if (e.sd.d == 0) continue;  // an all-null entry has no dictionary: no candidates, its mask words stay zero
+        if (!e.sd.signatures || !e.sd.postings || e.sd.n > kPostMaxRows) return LC_OK;
+    }
+    std::vector<uint32_t> word_entry;
+    std::vector<LikeK1Ref> k1(s->n);
+    std::vector<LikeK2Ref> k2(s->n);
+    uint32_t prev_slot = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i < s->n; i++) {
+        const StrDesc& d = s->meta[i].sd;
+        const uint32_t nw = (d.d + 63u) / 64u;
+        if (nw && d.symtab_slot != prev_slot) {
+            // a probe wave (64 flat words) never spans two symbol tables: the candidate list is then grouped by table
+            while (word_entry.size() % 64) word_entry.push_back(0xFFFFFFFFu);
+            prev_slot = d.symtab_slot;
+        }
+        if (uint64_t(word_entry.size()) + nw + 64 > 0xFFFFFFF0ull) return LC_OK;
+        k1[i] = LikeK1Ref{d.signatures, uint32_t(word_entry.size()), nw, d.d, d.symtab_slot, {0, 0}};
+        k2[i] = LikeK2Ref{d.fsst, d.residuals, d.postings, d.mask_word_off, d.slope, d.intercept, d.offset_bytes, d.d};
+        for (uint32_t w = 0; w < nw; w++) word_entry.push_back(i);
+    }
+    while (word_entry.size() % 64) word_entry.push_back(0xFFFFFFFFu);
+    lp->n_flat = uint32_t(word_entry.size());
+    lp->n_k1_waves = lp->n_flat / 64;
+    lp->wave_slot.assign(lp->n_k1_waves, 0);
+    for (uint32_t wv = 0; wv < lp->n_k1_waves; wv++) {
+        const uint32_t e = word_entry[size_t(wv) * 64];  // the padding sits at the END of a table's range
+        lp->wave_slot[wv] = e == 0xFFFFFFFFu ? 0u : s->meta[e].sd.symtab_slot;
+    }
+    lp->d_word_entry = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(word_entry.size(), 1) * 4));
+    lp->d_k1 = static_cast<LikeK1Ref*>(pool_alloc(ctx, size_t(s->n) * sizeof(LikeK1Ref)));
+    lp->d_k2 = static_cast<LikeK2Ref*>(pool_alloc(ctx, size_t(s->n) * sizeof(LikeK2Ref)));
+    lp->d_total_acc = static_cast<unsigned long long*>(pool_alloc(ctx, size_t(kTotalWords) * 8));
+    if (!lp->d_word_entry || !lp->d_k1 || !lp->d_k2 || !lp->d_total_acc) return fail(LC_ERR_OOM, "hipMalloc (LIKE pipeline index)");
+    LC_HIP(hipMemcpyAsync(lp->d_word_entry, word_entry.data(), word_entry.size() * 4, hipMemcpyHostToDevice, stream));
+    LC_HIP(hipMemcpyAsync(lp->d_k1, k1.data(), k1.size() * sizeof(LikeK1Ref), hipMemcpyHostToDevice, stream));
+    LC_HIP(hipMemcpyAsync(lp->d_k2, k2.data(), k2.size() * sizeof(LikeK2Ref), hipMemcpyHostToDevice, stream));
+    LC_HIP(hipMemsetAsync(lp->d_total_acc, 0, size_t(kTotalWords) * 8, stream));  // once: launches leave it zero
+    LC_HIP(hipStreamSynchronize(stream));  // the host vectors are locals
+    lp->eligible = true;
+    return LC_OK;
+}
+
+void fill_probe_args(const lc_scan* s, const LikePipeline* lp, const StrPred& p, ProbeArgs* a) {
+    *a = ProbeArgs{};
+    a->word_entry = lp->d_word_entry;
+    a->refs = lp->d_k1;
+    a->n_flat = lp->n_flat;
+    a->n_entries = s->n;
+    for (int k = 0; k < kMaxSigProbe; k++) a->sig_bits[k] = p.sig_bits[k];
+}
+
+lc_status run(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred& p, const ScanLaunch& L, hipStream_t stream) {
+    ProbeArgs pa;
+    fill_probe_args(s, lp, p, &pa);
+    pa.wave_off = plan.d_wave_off;
+    pa.cand = plan.d_cand;
+    pa.mask = L.d_hit;
+    pa.mask_words = s->seg_offsets.back();
+    pa.counts = L.d_counts;
+    pa.total_zero = plan.n_chunks == 0 ? L.d_total_out : nullptr;
+    LC_HIP(launch_probe<false>(int(p.n_sig_bits), pa, stream));
+    WalkArgs wa{};
+    wa.chunks = plan.d_chunks;
+    wa.cand = plan.d_cand;
+    wa.refs = lp->d_k2;
+    wa.automata = p.automata;
+    wa.automaton_stride = p.automaton_stride;
+    wa.nl = p.needle_len;
+    wa.selection = L.d_selection;
+    wa.mask = L.d_hit;
+    wa.counts = L.d_counts;
+    wa.total.d_total_acc = lp->d_total_acc;
+    wa.total.d_total_out = L.d_total_out;
+    LC_HIP(launch_walk(wa, plan.n_chunks, stream));
+    return LC_OK;
+}
+
+lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost& sp, hipStream_t stream, LikePlan* plan) {
+    plan->needle = sp.needle;
+    plan->use_pipeline = false;
+    uint32_t* d_wave_count = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(lp->n_k1_waves, 1) * 4));
+    if (!d_wave_count) return fail(LC_ERR_OOM, "hipMalloc (LIKE plan)");
+    struct Tmp {
+        lc_ctx* c; void* p; hipStream_t st;
+        ~Tmp() { (void)hipStreamSynchronize(st); pool_release(c, p); }
+    } tmp{ctx, d_wave_count, stream};
+    ProbeArgs pa;
+    fill_probe_args(s, lp, sp.p, &pa);
+    pa.wave_count = d_wave_count;
+    LC_HIP(launch_probe<true>(int(sp.p.n_sig_bits), pa, stream));
+    std::vector<uint32_t> wc(lp->n_k1_waves, 0);
+    LC_HIP(hipMemcpyAsync(wc.data(), d_wave_count, size_t(lp->n_k1_waves) * 4, hipMemcpyDeviceToHost, stream));
+    LC_HIP(hipStreamSynchronize(stream));
+    // write positions (exclusive prefix sums) and the chunk schedule: consecutive candidates of ONE symbol table
+    std::vector<uint32_t> woff(lp->n_k1_waves, 0);
+    std::vector<LikeChunk> chunks;
+    uint64_t total = 0;
+    uint32_t run_begin = 0;  // first candidate of the current table
+    auto close_table = [&](uint32_t slot, uint32_t end) {
+        for (uint32_t f = run_begin; f < end; f += kWalkChunk)
+            chunks.push_back(LikeChunk{f, std::min(kWalkChunk, end - f), slot, 0});
+        run_begin = end;
+    };
+    for (uint32_t wv = 0; wv < lp->n_k1_waves; wv++) {
+        if (wv > 0 && lp->wave_slot[wv] != lp->wave_slot[wv - 1]) close_table(lp->wave_slot[wv - 1], uint32_t(total));
+        woff[wv] = uint32_t(total);
+        total += wc[wv];
+        if (total > uint64_t(kMaxCandPerEntry) * s->n + 4096) return LC_OK;  // not selective: k_str_pred keeps it
+    }
+    if (lp->n_k1_waves) close_table(lp->wave_slot[lp->n_k1_waves - 1], uint32_t(total));
+    plan->n_cand = uint32_t(total);
+    plan->n_chunks = uint32_t(chunks.size());
+    plan->d_wave_off = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(woff.size(), 1) * 4));
+    plan->d_chunks = static_cast<LikeChunk*>(pool_alloc(ctx, std::max<size_t>(chunks.size(), 1) * sizeof(LikeChunk)));
+    plan->d_cand = static_cast<uint64_t*>(pool_alloc(ctx, std::max<uint64_t>(total, 1) * 8));
+    if (!plan->d_wave_off || !plan->d_chunks || !plan->d_cand) {
+        free_plan(ctx, *plan);
+        return fail(LC_ERR_OOM, "hipMalloc (LIKE plan)");
+    }
+    LC_HIP(hipMemcpyAsync(plan->d_wave_off, woff.data(), woff.size() * 4, hipMemcpyHostToDevice, stream));
+    LC_HIP(hipMemcpyAsync(plan->d_chunks, chunks.data(), chunks.size() * sizeof(LikeChunk), hipMemcpyHostToDevice, stream));
+    // trial run into scratch: how many rows does the needle hit?
+    const uint64_t words = std::max<uint64_t>(s->seg_offsets.back(), 1);
+    uint64_t* d_scratch = static_cast<uint64_t*>(pool_alloc(ctx, words * 8 + 8));
+    if (!d_scratch) {
+        free_plan(ctx, *plan);
+        return fail(LC_ERR_OOM, "hipMalloc (LIKE plan)");
+    }
+    struct Tmp2 {
+        lc_ctx* c; void* p; hipStream_t st;
+        ~Tmp2() { (void)hipStreamSynchronize(st); pool_release(c, p); }
+    } tmp2{ctx, d_scratch, stream};
+    ScanLaunch L{};
+    L.d_hit = d_scratch;
+    L.d_total_out = d_scratch + words;
+    StrPred p = sp.p;
+    lc_status rc = run(s, lp, *plan, p, L, stream);
+    uint64_t hits = 0;
+    if (rc == LC_OK && hipMemcpyAsync(&hits, d_scratch + words, 8, hipMemcpyDeviceToHost, stream) != hipSuccess)
+        rc = fail(LC_ERR_DEVICE, "hipMemcpy (LIKE plan)");
+    if (rc == LC_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(LC_ERR_DEVICE, "stream (LIKE plan)");
+    if (rc != LC_OK) {
+        free_plan(ctx, *plan);
+        return rc;
+    }
+    plan->hits = hits;
+    plan->use_pipeline = hits * 1024u <= uint64_t(kMaxHitsPer1024) * std::max<uint64_t>(s->total_rows, 1024);
+    if (!plan->use_pipeline) free_plan(ctx, *plan);
+    return LC_OK;
+}
+
+}  // namespace
+
+void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
+    if (!lp) return;
+    for (LikePlan& p : lp->plans) free_plan(ctx, p);
+    pool_release(ctx, lp->d_word_entry);
+    pool_release(ctx, lp->d_k1);
+    pool_release(ctx, lp->d_k2);
+    pool_release(ctx, lp->d_total_acc);
+    delete lp;
+}
+
+// Caller holds s->mu and has built the automata of `sp` (sp.p.automata).  *handled = true: the evaluation was launched.
+lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
+                             bool* handled) {
+    *handled = false;
+    const StrPred& p = sp.p;
+    if (p.mode != 1 || p.op != LC_OP_LIKE || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
+        automaton_image_bytes(p.needle_len) == 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
+        return LC_OK;
+    if (!s->like) s->like = new LikePipeline();
+    LikePipeline* lp = s->like;
+    if (!lp->built) {
+        const lc_status st = build_index(ctx, s, lp, stream);
+        if (st != LC_OK) return st;
+    }
+    if (!lp->eligible) return LC_OK;
+    LikePlan* plan = nullptr;
+    for (LikePlan& q : lp->plans)
+        if (q.needle == sp.needle) plan = &q;
+    if (!plan) {
+        if (lp->plans.size() >= kMaxPlans) {
+            // evict the least recently used plan (launches that read its buffers are on this scan's one stream)
+            size_t victim = 0;
+            for (size_t i = 1; i < lp->plans.size(); i++)
+                if (lp->plans[i].last_use < lp->plans[victim].last_use) victim = i;
+            (void)hipStreamSynchronize(stream);
+            free_plan(ctx, lp->plans[victim]);
+            lp->plans.erase(lp->plans.begin() + long(victim));
+        }
+        LikePlan fresh;
+        const lc_status st = make_plan(ctx, s, lp, sp, stream, &fresh);
+        if (st != LC_OK) return st;
+        lp->plans.push_back(std::move(fresh));
+        plan = &lp->plans.back();
+    }
+    plan->last_use = ++lp->tick;
+    if (!plan->use_pipeline) return LC_OK;
+    const lc_status st = run(s, lp, *plan, p, L, stream);
+    if (st == LC_OK) *handled = true;
+    return st;
+}
+
+}  // namespace lc

@@ -444,6 +444,32 @@ def bench_eval_batches(blobs, symtabs, op: int, literal, threads: int = 1) -> in
     return int(r)
 
 
+def bench_eval_batches_masks(blobs, symtabs, op: int, literal, seg_offsets: np.ndarray, threads: int = 1):
+    """bench_eval_batches that also returns the hit mask in scan layout (u64 words, batch i at seg_offsets[i]) and the
+    per-batch hit counts: (total, mask words, counts).  Used by bench.py's checker leg and the full-size tests."""
+    n = len(blobs)
+    arrs = [_u8(b) for b in blobs]
+    ptrs = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    lens = (C.c_size_t * n)(*[a.size for a in arrs])
+    is_str = symtabs is not None and any(s is not None for s in symtabs)
+    st_ptrs = (C.c_void_p * n)(*[C.addressof(s) if s is not None else None for s in symtabs]) if is_str else None
+    lg = logical_type(blobs[0])
+    info = None if lg == LOGICAL_BYTE_VIEW else array_info(blobs[0])
+    tag, buf, ln = _literal(lg, 0 if info is None else info.phys, literal)
+    so = np.ascontiguousarray(seg_offsets, np.uint64)
+    assert so.size == n + 1
+    mask = np.zeros(max(int(so[-1]), 1), np.uint64)
+    counts = np.zeros(max(n, 1), np.uint32)
+    fn = lib().lo_bench_eval_batches_masks
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int,
+                   C.c_void_p, C.c_void_p, C.c_void_p]
+    r = fn(n, ptrs, lens, st_ptrs, op, tag, _ptr(buf), ln, threads, so.ctypes.data, mask.ctypes.data, counts.ctypes.data)
+    if r < 0:
+        raise RuntimeError("lo_bench_eval_batches_masks failed")
+    return int(r), mask[: int(so[-1])], counts[:n]
+
+
 def byte_view_len(liquid: bytes) -> int:
     a = _u8(liquid)
     # header(16) + view header(20) -> fsst at 40; keys section follows (serialization.rs:223-252)

@@ -24,9 +24,29 @@ static int64_t popcount_and(const uint8_t* a, const uint8_t* b, int64_t bits, in
 
 /* blobs[i]: Liquid bytes of batch i; symtabs[i]: its FSST symbol table (NULL for fixed-width batches).
  * threads <= 1: plain loop.  Returns the number of rows whose predicate value is true (and valid), or <0 on error. */
+static int64_t eval_batches(size_t n, const uint8_t* const* blobs, const size_t* lens, const lo_symtab* const* symtabs, int op,
+                            int lit_tag, const void* lit, size_t lit_len, int threads, const uint64_t* seg_offsets,
+                            uint64_t* mask_out, uint32_t* counts_out);
+
 LO_EXPORT int64_t lo_bench_eval_batches(size_t n, const uint8_t* const* blobs, const size_t* lens,
                                         const lo_symtab* const* symtabs, int op, int lit_tag, const void* lit,
                                         size_t lit_len, int threads) {
+    return eval_batches(n, blobs, lens, symtabs, op, lit_tag, lit, lit_len, threads, NULL, NULL, NULL);
+}
+
+/* The same, also returning what a device scan returns: the hit mask (pred AND valid) in scan layout — batch i's bits start
+ * at u64 word seg_offsets[i], bits past the batch's last row are zero — and the per-batch hit counts.  bench.py compares
+ * both with the GPU's on the whole column (not only the COUNT(*) total). */
+LO_EXPORT int64_t lo_bench_eval_batches_masks(size_t n, const uint8_t* const* blobs, const size_t* lens,
+                                              const lo_symtab* const* symtabs, int op, int lit_tag, const void* lit,
+                                              size_t lit_len, int threads, const uint64_t* seg_offsets, uint64_t* mask_out,
+                                              uint32_t* counts_out) {
+    return eval_batches(n, blobs, lens, symtabs, op, lit_tag, lit, lit_len, threads, seg_offsets, mask_out, counts_out);
+}
+
+static int64_t eval_batches(size_t n, const uint8_t* const* blobs, const size_t* lens, const lo_symtab* const* symtabs, int op,
+                            int lit_tag, const void* lit, size_t lit_len, int threads, const uint64_t* seg_offsets,
+                            uint64_t* mask_out, uint32_t* counts_out) {
     int64_t total = 0;
     int failed = 0;
     if (threads < 1) threads = 1;
@@ -50,7 +70,21 @@ LO_EXPORT int64_t lo_bench_eval_batches(size_t n, const uint8_t* const* blobs, c
                 failed = 1;
                 continue;
             }
-            total += popcount_and(ov, ovalid, k, nullable);
+            const int64_t c = popcount_and(ov, ovalid, k, nullable);
+            total += c;
+            if (counts_out) counts_out[i] = (uint32_t)c;
+            if (mask_out && seg_offsets) {
+                /* no selection: k == rows of the batch; ov / ovalid are zero beyond bit k */
+                const size_t words = (size_t)(seg_offsets[i + 1] - seg_offsets[i]);
+                for (size_t w = 0; w < words; w++) {
+                    uint64_t a, b = ~(uint64_t)0;
+                    memcpy(&a, ov + 8 * w, 8);
+                    if (nullable) memcpy(&b, ovalid + 8 * w, 8);
+                    const int64_t left = k - (int64_t)(64 * w);
+                    const uint64_t tail = left >= 64 ? ~(uint64_t)0 : (left <= 0 ? 0 : (((uint64_t)1 << left) - 1));
+                    mask_out[seg_offsets[i] + w] = a & b & tail;
+                }
+            }
         }
         free(ov);
         free(ovalid);
