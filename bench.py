@@ -23,6 +23,7 @@ of the per-rank hit-mask segments into the single Arrow BooleanArray north_star 
 from __future__ import annotations
 
 import argparse
+import copy
 import datetime
 import decimal
 import json
@@ -74,6 +75,11 @@ def parse_args(argv=None):
                    help="url_like: stage without the bigram signature index (reference layout only: the reference's "
                         "fingerprint prefilter decides the candidates)")
     p.add_argument("--no-row-lists", action="store_true", help="url_like: stage without the inverted row lists")
+    p.add_argument("--no-like-pipeline", action="store_true",
+                   help="url_like: evaluate LIKE with the one-wave-per-entry kernel only (A/B of the scan-level pipeline)")
+    p.add_argument("--rotate", type=int, default=0,
+                   help="columns the timed loop rotates through (one per step, all resident in HBM) so that a step never "
+                        "finds its data in the 256 MiB Infinity Cache; 0 = as many as make the cycle move >= 768 MB (1..8)")
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
     p.add_argument("--no-secondary", action="store_true", help="skip every secondary workload (profiling runs)")
     p.add_argument("--no-cold", action="store_true",
@@ -229,19 +235,25 @@ def measured_traffic(key):
 
 def roofline(kernel, kernel_ms, alg_bytes, kernel_bytes, cold_ms=None, traffic=None, traffic_src=None):
     """`achieved` = bytes the kernel itself has to move (lc_scan_traffic_model) / kernel time: a true fraction of the
-    HBM peak.  `effective_gbs` = the reference algorithm's bytes / the same time: what the scan is worth
-    to the query; it exceeds `achieved` wherever the kernel's index structures spare it bytes."""
-    ach = kernel_bytes / (kernel_ms * 1e-3) / 1e9
+    HBM peak.  The time is the L3-COLD one when it was measured (Infinity Cache flushed before every launch: a hot-cache
+    query over a 100-column table never finds a 100 MB column in the 256 MiB memory-side cache); the back-to-back figure
+    is kept as `*_hot`.  `effective_gbs` = the reference algorithm's bytes / the same time: what the scan is
+    worth to the query; it exceeds `achieved` wherever the kernel's index structures spare it bytes."""
+    t_ms = cold_ms if cold_ms is not None else kernel_ms
+    ach = kernel_bytes / (t_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+           "timing": "l3_cold" if cold_ms is not None else "back_to_back",
            "traffic": traffic, "traffic_source": traffic_src,
-           "traffic_gbs": (traffic / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+           "traffic_gbs": (traffic / (t_ms * 1e-3) / 1e9) if traffic else None,
            # the same fraction by MEASURED HBM bytes (PMC): what the memory system actually delivered for this kernel
-           "frac_by_traffic": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-           "kernel": kernel, "kernel_ms": kernel_ms, "kernel_bytes_per_launch": int(kernel_bytes),
-           "algorithmic_bytes_per_launch": int(alg_bytes), "effective_gbs": alg_bytes / (kernel_ms * 1e-3) / 1e9}
+           "frac_by_traffic": (traffic / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+           "kernel": kernel, "kernel_ms": t_ms, "kernel_bytes_per_launch": int(kernel_bytes),
+           "algorithmic_bytes_per_launch": int(alg_bytes), "effective_gbs": alg_bytes / (t_ms * 1e-3) / 1e9}
     if cold_ms is not None:
-        out.update({"kernel_ms_l3_cold": cold_ms, "achieved_l3_cold": kernel_bytes / (cold_ms * 1e-3) / 1e9,
-                    "frac_l3_cold": kernel_bytes / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS})
+        out.update({"kernel_ms_hot": kernel_ms, "achieved_hot": kernel_bytes / (kernel_ms * 1e-3) / 1e9,
+                    "frac_hot": kernel_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    # (names of earlier rounds, same numbers)
+                    "kernel_ms_l3_cold": cold_ms, "frac_l3_cold": ach / HBM_PEAK_GBS})
     return out
 
 
@@ -258,7 +270,7 @@ def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=Tr
     alg, own = scan.traffic_model(expr, False)
     r = roofline(kernel, ms, alg, own, cold)
     r["hits"] = int(counts.sum(dtype=torch.int64).item())
-    r["rows_per_s"] = scan.rows / (ms * 1e-3)
+    r["rows_per_s"] = scan.rows / (r["kernel_ms"] * 1e-3)
     return r, mask, counts
 
 
@@ -692,6 +704,20 @@ def secondary_clickbench_sweep(cache, lc, args, rows, threads, torch, stream, it
 # (all cores, untimed).  `mail` is the needle that exposed the speculative-walk false positives of round 2 (3,112 rows in the
 # 4 of 226 row groups whose symbol table holds "mail" under the code of a frequently escaped byte).
 EXTRA_PARITY_NEEDLES = ("mail", "file", "ru/")
+# The needle classes of the LIKE path (secondary.like_needle_classes): every one is timed (hot and L3-cold) and its hit
+# mask compared bit for bit with the CPU oracle's over the whole column.  (label, operator, needle)
+NEEDLE_CLASSES = (
+    ("1_byte", "like", "q"),                                   # no bigram: the reference's fingerprint filter decides
+    ("selective_6", "like", "google"),                         # the headline
+    ("selective_4", "like", "file"),
+    ("mid_3", "like", "ru/"),
+    ("non_selective_4", "like", "mail"),                       # ~19 % of the rows
+    ("selective_16", "like", "yandex.ru/search"),              # > 15 bytes: the LDS automaton image grows to 17 KB
+    ("selective_24", "like", "market.yandex.ru/catalog"),
+    ("long_34", "like", "images.yandex.ru/search/catalog/it"),  # > 31 bytes: automaton table walked in global memory
+    ("not_like_6", "not_like", "google"),
+    ("not_like_absent", "not_like", "zzzzqqq"),
+)
 
 
 def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads, extra_patterns=()):
@@ -740,8 +766,10 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads, extra
     for b in range(n_sample):
         seg[b + 1] = seg[b] + (min(bs, args.rows - b * bs) + 63) // 64
     checks = {}
-    for p in (pattern,) + tuple(extra_patterns):
-        checks[p.decode() if isinstance(p, bytes) else p] = lo.bench_eval_batches_masks(bl, sts, lo.LIKE, p, seg, cores)
+    for op, p in (("like", pattern),) + tuple(extra_patterns):
+        t1 = time.perf_counter()
+        r = lo.bench_eval_batches_masks(bl, sts, lo.OP_NAMES[op], p, seg, cores)
+        checks[(op, p.decode())] = r + (time.perf_counter() - t1,)
     all_cores["_checks"] = checks
     return rows_total / dt, rows_total, int(hits), dt, all_cores
 
@@ -941,7 +969,8 @@ def main():
     import pyarrow as pa
 
     cache = (lc.LiquidCacheBuilder.new().with_device(local_rank).with_batch_size(args.batch_size)
-             .with_index_options(signatures=not args.no_signatures, row_lists=not args.no_row_lists).build())
+             .with_index_options(signatures=not args.no_signatures, row_lists=not args.no_row_lists,
+                                 like_pipeline_min_entries=-1 if args.no_like_pipeline else None).build())
     n_batches = (args.rows + args.batch_size - 1) // args.batch_size
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, min(world, 8))))
 
@@ -974,16 +1003,35 @@ def main():
     words = int(scan.mask_words)
     mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
     counts = torch.zeros(max(scan.entries, 1), dtype=torch.int32, device="cuda")
+    # The timed loop ROTATES through several resident columns of the same shape (other seeds), one per step: a hot-cache
+    # query never finds its column in the 256 MiB memory-side Infinity Cache, and back-to-back passes over ONE 40-160 MB
+    # column would (round 2: 27.9 us hot vs 35.9 us cold).  The cycle is sized to move >= 768 MB.
+    _, own0 = scan.traffic_model(expr, False)
+    n_rot = args.rotate if args.rotate > 0 else max(1, min(8, -(-(768 << 20) // max(int(own0), 1))))
+    t_rot = time.perf_counter()
+    scans = [scan]
+    for r in range(1, n_rot):
+        a2 = copy.copy(args)
+        a2.seed = args.seed + 7919 * r
+        if args.workload == "url_like":
+            ids_r = stage_url_column(cache, lc, N, a2, rank, n_batches, threads, file_id=1000 + 16 * r + rank)
+        else:
+            ids_r = stage_int_column(cache, lc, N, a2, rank, args.rows, threads, base=base, kind=args.int_kind, col=200 + r)
+        scans.append(cache.scan(ids_r))
+    t_stage += time.perf_counter() - t_rot
     # COUNT(*) partials: written by the predicate kernel itself (lc_scan_eval_count); two buffers so that the all-reduce
     # of step i (RCCL's own stream) overlaps the scan of step i+1
     from liquid_cache_amd.sharding import PipelinedCountAllReduce, all_gather_mask_segments
     reducer = PipelinedCountAllReduce(lambda: torch.zeros((), dtype=torch.int64, device="cuda"), world)
     stream = torch.cuda.current_stream().cuda_stream
     gathered = [None]
+    step_no = [0]
 
     def step():
         total = reducer.acquire()
-        scan.eval_count(expr, mask.data_ptr(), total.data_ptr(), 0, 0, stream)  # mask + COUNT(*) of this shard, one kernel
+        sc = scans[step_no[0] % n_rot]
+        step_no[0] += 1
+        sc.eval_count(expr, mask.data_ptr(), total.data_ptr(), 0, 0, stream)  # mask + COUNT(*) of this shard, one kernel
         reducer.submit()  # exchange step of COUNT(*) queries: the partial counts -> global count (8 bytes)
         if args.exchange == "mask" and world > 1:
             # exchange step of mask consumers: the per-rank segments -> one BooleanArray (row-range shards concatenate)
@@ -991,9 +1039,10 @@ def main():
 
     drain = reducer.drain
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, n_rot)):  # every column is scanned once before the clock starts (plans, automata)
         step()
     drain()
+    step_no[0] = 0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -1014,6 +1063,10 @@ def main():
     if world > 1:
         dist.all_reduce(rows_t, op=dist.ReduceOp.SUM)
     rows_all = int(rows_t.item())
+    step_no[0] = 0  # COUNT(*) of column 0 (the one the CPU oracle checks), through the same step
+    step()
+    drain()
+    torch.cuda.synchronize()
     hits = int(reducer.last().item())
     # the fused total must be the sum of the per-entry counts of the same predicate (separate launch, plain reduction)
     scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
@@ -1062,15 +1115,19 @@ def main():
                            world, "8-byte COUNT(*) all-reduce (overlapped with the next scan)" if args.exchange == "count"
                            else "COUNT(*) all-reduce + all-gather of the hit-mask segments"),
                        "predicate": ("URL LIKE '%%%s%%'" % args.needle) if args.workload == "url_like" else "col > literal",
-                       "hits": hits, "stage_seconds": round(t_stage, 2)},
+                       "hits": hits, "stage_seconds": round(t_stage, 2), "rotating_columns": n_rot,
+                       "timed_loop": "step i scans resident column i %% %d (L3-cold by construction)" % n_rot},
             # what the scan is worth to the query: the reference algorithm's bytes per second of wall clock
             "gb_per_s_scanned": alg_bytes * world / (elapsed / args.steps) / 1e9,
             "roofline": roofline(kernel, kernel_ms, alg_bytes, own_bytes, cold_ms, traffic, traffic_src),
         }
+        out["config"]["evaluation_path"] = scan.explain(expr)
+        if "like_pipeline" in out["config"]["evaluation_path"]:
+            out["roofline"]["kernel"] = "k_like_probe + k_like_walk"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_sample = args.cpu_batches or n_batches  # ~4 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
         if args.workload == "url_like":
-            extra = tuple(("%" + n + "%").encode() for n in EXTRA_PARITY_NEEDLES if n != args.needle) \
+            extra = tuple((op, ("%" + n + "%").encode()) for _, op, n in NEEDLE_CLASSES if (op, n) != ("like", args.needle)) \
                 if n_sample == n_batches and not args.no_fingerprints else ()
             v, rows_s, hits_s, dt, all_cores = cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads, extra)
         else:
@@ -1090,8 +1147,11 @@ def main():
                 import pyarrow as pa
                 n_ok = n_bad = 0
                 worst = None
-                for pat, (cpu_total, cpu_mask, cpu_counts) in checks.items():
-                    e2 = lc.LiquidExpr.try_new("like", pat.encode(), pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
+                classes = {}
+                labels = {(op, "%" + n + "%"): lab for lab, op, n in NEEDLE_CLASSES}
+                hint = lc.CacheExpression.SUBSTRING_SEARCH
+                for (op, pat), (cpu_total, cpu_mask, cpu_counts, cpu_s) in checks.items():
+                    e2 = lc.LiquidExpr.try_new(op, pat.encode(), pa.string(), hint)
                     mask.zero_()
                     scan.eval(e2, mask.data_ptr(), 0, counts.data_ptr(), stream)
                     torch.cuda.synchronize()
@@ -1101,13 +1161,28 @@ def main():
                     n_ok += ok
                     n_bad += not ok
                     if not ok and worst is None:
-                        worst = "%s: gpu %d cpu %d, %d entries differ" % (pat, int(g_counts.sum()), cpu_total,
-                                                                          int((g_counts != cpu_counts).sum()))
+                        worst = "%s %s: gpu %d cpu %d, %d entries differ" % (op, pat, int(g_counts.sum()), cpu_total,
+                                                                             int((g_counts != cpu_counts).sum()))
+                    lab = labels.get((op, pat))
+                    if lab and not args.no_secondary:
+                        it = max(3, iters // 4)
+                        hot = scan.eval_timed(e2, mask.data_ptr(), it, 0, counts.data_ptr(), stream)
+                        cold = None if args.no_cold else scan.eval_timed_cold(e2, mask.data_ptr(), 3, FLUSH_BYTES, 0,
+                                                                              counts.data_ptr(), stream)
+                        classes[lab] = {"predicate": "URL %s '%s'" % ("LIKE" if op == "like" else "NOT LIKE", pat),
+                                        "needle_bytes": len(pat) - 2, "hits": int(g_counts.sum()),
+                                        "hit_fraction": float(g_counts.sum()) / max(int(scan.rows), 1),
+                                        "mask_equals_cpu_oracle": ok, "kernel_us_hot": round(hot * 1e3, 2),
+                                        "kernel_us_l3_cold": None if cold is None else round(cold * 1e3, 2),
+                                        "rows_per_s_l3_cold": None if cold is None else scan.rows / (cold * 1e-3),
+                                        "cpu_oracle_all_cores_s": round(cpu_s, 3), "path": scan.explain(e2)}
                 out["config"]["needles_checked"] = n_ok + n_bad
                 out["config"]["needle_masks_all_match_cpu_oracle"] = n_bad == 0
                 out["config"]["needle_entry_counts_all_match_cpu_oracle"] = n_bad == 0
                 if worst:
                     out["config"]["needle_first_mismatch"] = worst
+                if classes:
+                    out["like_needle_classes"] = classes
                 assert n_bad == 0, "GPU mask differs from the CPU oracle's: " + str(worst)
         all_cores.pop("_checks", None)
 

@@ -156,10 +156,15 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
  *                           fingerprint filter (byte_view_array/fingerprint.rs) and walks its candidates
  *   LC_OPT_ROW_LISTS        (default 1) such entries also get inverted row lists (+ ~12 %)
  *   LC_OPT_HOST_BUILT_INDEX (default 0) 1 = the signature index is built by the host while staging instead of by the
- *                           device kernel (bit-identical; kept as the device builder's cross-check) */
+ *                           device kernel (bit-identical; kept as the device builder's cross-check)
+ * Evaluation option (may be changed at any time):
+ *   LC_OPT_LIKE_PIPELINE_MIN_ENTRIES (default 32) scans of at least this many entries evaluate a selective
+ *                           LIKE '%needle%' with the scan-level pipeline (probe + walk, planned once per scan and needle)
+ *                           instead of the one-wave-per-entry kernel; negative = never */
 #define LC_OPT_SIGNATURE_INDEX 1
 #define LC_OPT_ROW_LISTS 2
 #define LC_OPT_HOST_BUILT_INDEX 3
+#define LC_OPT_LIKE_PIPELINE_MIN_ENTRIES 4
 LC_API lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value);
 LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
 LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);
@@ -382,6 +387,10 @@ LC_API uint64_t lc_scan_entries(const lc_scan* scan);
 LC_API lc_status lc_scan_traffic_model(lc_scan* scan, const lc_predicate* pred, int32_t with_selection,
                                        uint64_t* out_algorithmic, uint64_t* out_kernel_bytes);
 LC_API uint64_t lc_scan_algorithmic_bytes(lc_scan* scan, const lc_predicate* pred, int32_t with_selection);
+/* One line on how `pred` is evaluated over this scan (which kernels; for LIKE whether the scan-level pipeline planned the
+ * needle and with how many candidates) — the EXPLAIN of this library, for logs and benchmarks.  `out` receives a
+ * NUL-terminated string of at most cap - 1 characters. */
+LC_API lc_status lc_scan_explain(lc_scan* scan, const lc_predicate* pred, char* out, size_t cap);
 /* word offset of entry i's segment inside the mask (n+1 values, host memory owned by the scan) */
 LC_API const uint64_t* lc_scan_segment_offsets(const lc_scan* scan);
 

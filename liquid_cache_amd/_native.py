@@ -17,7 +17,7 @@ LC_ERR_INVALID, LC_ERR_CORRUPT, LC_ERR_DEVICE, LC_ERR_OOM, LC_ERR_NO_SYMTAB = -1
 OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_LIKE, OP_NOT_LIKE = range(8)
 LIT_I64, LIT_U64, LIT_F32, LIT_F64, LIT_BYTES, LIT_I128, LIT_BOOL = range(7)
 HINT_NONE, HINT_SUBSTRING_SEARCH, HINT_PREDICATE_COLUMN = 0, 1, 2
-OPT_SIGNATURE_INDEX, OPT_ROW_LISTS, OPT_HOST_BUILT_INDEX = 1, 2, 3
+OPT_SIGNATURE_INDEX, OPT_ROW_LISTS, OPT_HOST_BUILT_INDEX, OPT_LIKE_PIPELINE_MIN_ENTRIES = 1, 2, 3, 4
 
 
 class LiquidCacheError(RuntimeError):
@@ -66,7 +66,7 @@ ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offse
 
 # every symbol include/liquid_cache_amd.h declares (tests check that the built library exports all of them)
 EXPORTED_SYMBOLS = [
-    "lc_ctx_create", "lc_ctx_destroy", "lc_ctx_set_option", "lc_entry_index_to_bytes", "lc_stage_indexed", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
+    "lc_ctx_create", "lc_ctx_destroy", "lc_ctx_set_option", "lc_entry_index_to_bytes", "lc_stage_indexed", "lc_scan_explain", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
@@ -163,6 +163,7 @@ def load():
         getattr(L, name).restype = u64; getattr(L, name).argtypes = [vp]
     L.lc_scan_algorithmic_bytes.restype = u64; L.lc_scan_algorithmic_bytes.argtypes = [vp, P(Predicate), i32]
     L.lc_scan_traffic_model.restype = i32; L.lc_scan_traffic_model.argtypes = [vp, P(Predicate), i32, P(u64), P(u64)]
+    L.lc_scan_explain.restype = i32; L.lc_scan_explain.argtypes = [vp, P(Predicate), C.c_char_p, sz]
     L.lc_scan_segment_offsets.restype = P(u64); L.lc_scan_segment_offsets.argtypes = [vp]
     L.lc_scan_eval.restype = i32; L.lc_scan_eval.argtypes = [vp, vp, P(Predicate), vp, vp, vp, vp]
     L.lc_scan_eval_and.restype = i32; L.lc_scan_eval_and.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, vp, vp]

@@ -224,7 +224,8 @@ class LiquidCacheBuilder:
         return self
 
     def with_index_options(self, signatures: Optional[bool] = None, row_lists: Optional[bool] = None,
-                           host_built: Optional[bool] = None) -> "LiquidCacheBuilder":
+                           host_built: Optional[bool] = None, like_pipeline_min_entries: Optional[int] = None
+                           ) -> "LiquidCacheBuilder":
         """The device-side acceleration structures of substring-search byte views (include/liquid_cache_amd.h,
         lc_ctx_set_option): bigram signature index, inverted row lists, host-built index.  Results never depend on them."""
         if signatures is not None:
@@ -233,6 +234,8 @@ class LiquidCacheBuilder:
             self.options[N.OPT_ROW_LISTS] = int(bool(row_lists))
         if host_built is not None:
             self.options[N.OPT_HOST_BUILT_INDEX] = int(bool(host_built))
+        if like_pipeline_min_entries is not None:
+            self.options[N.OPT_LIKE_PIPELINE_MIN_ENTRIES] = int(like_pipeline_min_entries)
         return self
 
     def build(self) -> "LiquidCache":
@@ -617,6 +620,13 @@ class Scan:
     def algorithmic_bytes(self, expr: LiquidExpr, with_selection: bool = False) -> int:
         pred = expr.as_predicate()
         return self._lib.lc_scan_algorithmic_bytes(self._h, C.byref(pred), int(with_selection))
+
+    def explain(self, expr: LiquidExpr) -> str:
+        """Which kernels evaluate `expr` over this scan (lc_scan_explain)."""
+        buf = C.create_string_buffer(512)
+        pred = expr.as_predicate()
+        N.check(self._lib.lc_scan_explain(self._h, C.byref(pred), buf, 512), self._cache.handle)
+        return buf.value.decode()
 
     def traffic_model(self, expr: LiquidExpr, with_selection: bool = False):
         """(algorithmic bytes of the reference algorithm, bytes this kernel itself moves) for one evaluation."""

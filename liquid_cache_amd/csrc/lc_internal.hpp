@@ -107,6 +107,7 @@ struct lc_ctx {
     std::vector<std::unique_ptr<lc::SymbolTable>> symtabs;
     bool build_signatures = true;  // LC_OPT_SIGNATURE_INDEX = 0 disables the bigram index (plain reference layout only)
     bool signatures_on_host = false;  // LC_OPT_HOST_BUILT_INDEX = 1: build the index on the host (the device builder's oracle)
+    uint32_t like_pipeline_min_entries = 32;  // LC_OPT_LIKE_PIPELINE_MIN_ENTRIES: scans below it evaluate LIKE with k_str_pred
     bool build_postings = true;       // LC_OPT_ROW_LISTS = 0: no inverted row lists (rows always mapped through the keys)
     lc::DevSymtab* d_symtabs = nullptr;
     size_t d_symtabs_cap = 0;
@@ -166,6 +167,7 @@ struct lc_scan {
     uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
     size_t or_tmp_words = 0;
     unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
+    lc::LikePipeline* like = nullptr;  // scan-level index + plans of the selective-LIKE pipeline (lc_like_pipeline.hip)
     bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
     // The scan's scratch (automata, work counters, COUNT(*) accumulator, OR / aggregate temporaries) is used by
     // asynchronous launches after `mu` is released.  Calls on one scan are ordered on one stream; when a call arrives on
@@ -194,5 +196,13 @@ struct StrPredHost {
     std::vector<uint8_t> needle;
 };
 lc_status make_str_pred(const lc_predicate* p, StrPredHost* out);
+
+// lc_like_pipeline.hip.  Caller holds s->mu and has built the automata of `sp`.  *handled: the evaluation was launched
+// by the pipeline; otherwise the caller launches k_str_pred.
+lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
+                             bool* handled);
+void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp);
+std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp);           // caller holds s->mu
+uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts);  // caller holds s->mu
 
 }  // namespace lc

@@ -24,7 +24,8 @@
 namespace lc {
 
 constexpr int kMaxNeedleAutomaton = 63;  // KMP automaton states must fit a u8 table
-constexpr uint32_t kMaxLdsNeedle = 15;   // needles up to this length also get an LDS image of the automaton
+constexpr uint32_t kMaxLdsNeedle = 31;   // needles up to this length also get an LDS image of the automaton (32 KB at 31:
+                                         // u16 row addresses reach 64 KB)
 // Per symbol table, k_str_automata emits: the u8 next-state table ((m+1) x 512 bytes) and, for short needles, the
 // image the scan kernel copies verbatim to LDS address 0: 2 (m+1) rows x 256 u16 entries holding the LDS byte address
 // of the next state's row (rows 0..m: next byte is a code; rows m+1..2m+1: next byte is an escaped literal).

@@ -72,6 +72,8 @@ struct LikePlan {
     bool use_pipeline = false;
     uint32_t n_cand = 0, n_chunks = 0;
     uint64_t hits = 0;
+    uint64_t cand_bytes = 0;         // compressed bytes of the candidates (byte accounting)
+    uint64_t matches = 0;            // dictionary values that matched
     uint32_t* d_wave_off = nullptr;  // write position of every probe wave (n_k1_waves)
     LikeChunk* d_chunks = nullptr;
     uint64_t* d_cand = nullptr;      // (entry << 16 | dictionary key) x n_cand
@@ -168,6 +170,7 @@ struct WalkArgs {
     const uint64_t* selection;
     uint64_t* mask;
     uint32_t* counts;
+    unsigned long long* stats;  // plan run only: {compressed bytes of the candidates, matching dictionary values}
     ScanLaunch total;  // d_total_acc / d_total_out only
 };
 
@@ -192,7 +195,10 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
     }
     uint8_t* hitflag = smem + tbl_bytes + wave * 80u;
     uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
+    // the image holds absolute LDS addresses computed for a table at LDS address 0: this kernel has no static LDS, so its
+    // dynamic segment starts there (a toolchain that placed it elsewhere would make every lookup wrong: stop loudly)
     const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
+    if (row0 != 0u) __builtin_trap();
     const uint32_t hitrow = row0 + nl * 512u;
 
     // this lane's candidate
@@ -282,6 +288,13 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
     const bool res = cl && hitflag[lane] != 0;
     uint64_t matched = __ballot(res);
     uint64_t wave_hits = 0;
+    if (a.stats) {
+        const uint64_t lb = wave_sum_u64(uint64_t(len));
+        if (lane == 0) {
+            atomicAdd(a.stats, (unsigned long long)lb);
+            atomicAdd(a.stats + 1, (unsigned long long)__popcll(matched));
+        }
+    }
     if (matched) {
         // ---- rows of the matching dictionary values, from the entries' inverted row lists
         uint32_t o0 = 0, o1 = 0;
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
             o1 = v >> 16;
         }
         while (matched) {
-            const int ml = int(__ffsll((long long)matched)) - 1;
+            const int ml = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)matched)) - 1);
             matched &= matched - 1;
             const uint32_t b = read_lane(o0, ml), e1 = read_lane(o1, ml);
             const uint64_t pb = uniform_u64(shfl_u64(post_bits, ml));
@@ -320,8 +333,9 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
 
 template <bool kCount>
 hipError_t launch_probe(int n_sig, const ProbeArgs& a, hipStream_t stream) {
-    const uint32_t grid = (a.n_flat + kProbeThreads - 1) / kProbeThreads;
-    if (grid == 0) return hipSuccess;
+    uint32_t grid = (a.n_flat + kProbeThreads - 1) / kProbeThreads;
+    if (grid == 0 && kCount) return hipSuccess;
+    if (grid == 0) grid = 1;  // fill mode still clears the mask and the counts
     typedef void (*Kern)(ProbeArgs);
     static const Kern table[kMaxSigProbe] = {k_like_probe<1, kCount>, k_like_probe<2, kCount>, k_like_probe<3, kCount>,
                                              k_like_probe<4, kCount>, k_like_probe<5, kCount>, k_like_probe<6, kCount>,
@@ -403,7 +417,8 @@ void fill_probe_args(const lc_scan* s, const LikePipeline* lp, const StrPred& p,
     for (int k = 0; k < kMaxSigProbe; k++) a->sig_bits[k] = p.sig_bits[k];
 }
 
-lc_status run(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred& p, const ScanLaunch& L, hipStream_t stream) {
+lc_status run(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred& p, const ScanLaunch& L, hipStream_t stream,
+              unsigned long long* d_stats = nullptr) {
     ProbeArgs pa;
     fill_probe_args(s, lp, p, &pa);
     pa.wave_off = plan.d_wave_off;
@@ -423,6 +438,7 @@ lc_status run(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred&
     wa.selection = L.d_selection;
     wa.mask = L.d_hit;
     wa.counts = L.d_counts;
+    wa.stats = d_stats;
     wa.total.d_total_acc = lp->d_total_acc;
     wa.total.d_total_out = L.d_total_out;
     LC_HIP(launch_walk(wa, plan.n_chunks, stream));
@@ -475,7 +491,7 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
     LC_HIP(hipMemcpyAsync(plan->d_chunks, chunks.data(), chunks.size() * sizeof(LikeChunk), hipMemcpyHostToDevice, stream));
     // trial run into scratch: how many rows does the needle hit?
     const uint64_t words = std::max<uint64_t>(s->seg_offsets.back(), 1);
-    uint64_t* d_scratch = static_cast<uint64_t*>(pool_alloc(ctx, words * 8 + 8));
+    uint64_t* d_scratch = static_cast<uint64_t*>(pool_alloc(ctx, words * 8 + 24));
     if (!d_scratch) {
         free_plan(ctx, *plan);
         return fail(LC_ERR_OOM, "hipMalloc (LIKE plan)");
@@ -488,16 +504,20 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
     L.d_hit = d_scratch;
     L.d_total_out = d_scratch + words;
     StrPred p = sp.p;
-    lc_status rc = run(s, lp, *plan, p, L, stream);
-    uint64_t hits = 0;
-    if (rc == LC_OK && hipMemcpyAsync(&hits, d_scratch + words, 8, hipMemcpyDeviceToHost, stream) != hipSuccess)
+    lc_status rc = hipMemsetAsync(d_scratch + words, 0, 24, stream) == hipSuccess ? LC_OK : fail(LC_ERR_DEVICE, "memset (LIKE plan)");
+    if (rc == LC_OK) rc = run(s, lp, *plan, p, L, stream, reinterpret_cast<unsigned long long*>(d_scratch + words + 1));
+    uint64_t res3[3] = {0, 0, 0};
+    if (rc == LC_OK && hipMemcpyAsync(res3, d_scratch + words, 24, hipMemcpyDeviceToHost, stream) != hipSuccess)
         rc = fail(LC_ERR_DEVICE, "hipMemcpy (LIKE plan)");
     if (rc == LC_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(LC_ERR_DEVICE, "stream (LIKE plan)");
     if (rc != LC_OK) {
         free_plan(ctx, *plan);
         return rc;
     }
+    const uint64_t hits = res3[0];
     plan->hits = hits;
+    plan->cand_bytes = res3[1];
+    plan->matches = res3[2];
     plan->use_pipeline = hits * 1024u <= uint64_t(kMaxHitsPer1024) * std::max<uint64_t>(s->total_rows, 1024);
     if (!plan->use_pipeline) free_plan(ctx, *plan);
     return LC_OK;
@@ -515,6 +535,47 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     delete lp;
 }
 
+// One line on how `LIKE '%needle%'` was / would be evaluated on this scan (lc_scan_explain).  Caller holds s->mu.
+std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
+    const LikePipeline* lp = s->like;
+    if (!lp || !lp->built) return "k_str_pred (no pipeline index on this scan yet)";
+    if (!lp->eligible) return "k_str_pred (entries without signature index / row lists)";
+    for (const LikePlan& q : lp->plans)
+        if (q.needle == sp.needle) {
+            char buf[256];
+            if (q.use_pipeline)
+                std::snprintf(buf, sizeof(buf), "like_pipeline: k_like_probe + k_like_walk, %u candidates in %u chunks, %llu hit rows, %u flat words",
+                              q.n_cand, q.n_chunks, (unsigned long long)q.hits, lp->n_flat);
+            else
+                std::snprintf(buf, sizeof(buf), "k_str_pred (needle not selective: %u+ candidates, %llu hit rows at plan time)", q.n_cand,
+                              (unsigned long long)q.hits);
+            return buf;
+        }
+    return "k_str_pred (needle not planned)";
+}
+
+// Bytes the two kernels themselves have to move for one evaluation (the numerator of an honest HBM-roofline fraction, like
+// lc_scan_traffic_model's figure for k_str_pred): probe = entry map + the needle's slices + mask / count clears + the
+// candidate list; walk = chunk records + candidates + one 48-byte reference per entry that has candidates + offset pairs +
+// compressed bytes of the candidates + list bounds and rows of the matches + one 8-byte read-modify-write per hit row.
+// 0 when the pipeline does not take this needle.  Caller holds s->mu.
+uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts) {
+    const LikePipeline* lp = s->like;
+    if (!lp || !lp->eligible) return 0;
+    for (const LikePlan& q : lp->plans)
+        if (q.needle == sp.needle && q.use_pipeline) {
+            uint64_t flat_valid = 0;
+            for (const Entry& e : s->meta) flat_valid += (e.sd.d + 63u) / 64u;
+            uint64_t b = uint64_t(lp->n_flat) * 4 + flat_valid * 8 * sp.p.n_sig_bits + uint64_t(s->n) * 32 +
+                         s->seg_offsets.back() * 8 + (with_counts ? uint64_t(s->n) * 4 : 0) + uint64_t(lp->n_k1_waves) * 4 +
+                         uint64_t(q.n_cand) * 8;
+            b += uint64_t(q.n_chunks) * 16 + uint64_t(q.n_cand) * (8 + 8) + std::min<uint64_t>(q.n_cand, s->n) * 48 + q.cand_bytes +
+                 q.matches * 4 + q.hits * (2 + 16);
+            return b;
+        }
+    return 0;
+}
+
 // Caller holds s->mu and has built the automata of `sp` (sp.p.automata).  *handled = true: the evaluation was launched.
 lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
                              bool* handled) {
@@ -523,6 +584,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     if (p.mode != 1 || p.op != LC_OP_LIKE || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
         automaton_image_bytes(p.needle_len) == 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
         return LC_OK;
+    if (s->n < ctx->like_pipeline_min_entries) return LC_OK;  // small scans are launch bound either way: one kernel
     if (!s->like) s->like = new LikePipeline();
     LikePipeline* lp = s->like;
     if (!lp->built) {

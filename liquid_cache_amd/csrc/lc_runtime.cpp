@@ -674,6 +674,9 @@ lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
         case LC_OPT_SIGNATURE_INDEX: ctx->build_signatures = value != 0; return LC_OK;
         case LC_OPT_ROW_LISTS: ctx->build_postings = value != 0; return LC_OK;
         case LC_OPT_HOST_BUILT_INDEX: ctx->signatures_on_host = value != 0; return LC_OK;
+        case LC_OPT_LIKE_PIPELINE_MIN_ENTRIES:
+            ctx->like_pipeline_min_entries = value < 0 ? 0xFFFFFFFFu : uint32_t(std::min<int64_t>(value, 0xFFFFFFFFll));
+            return LC_OK;
         default: return fail(LC_ERR_INVALID, "unknown context option");
     }
     });
@@ -1696,6 +1699,7 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_total_acc);
     pool_release(s->ctx, s->d_or_tmp);
     pool_release(s->ctx, s->d_agg_partials);
+    like_pipeline_destroy(s->ctx, s->like);
     if (s->d_automata) (void)hipFree(s->d_automata);
     if (s->d_needle) (void)hipFree(s->d_needle);
     if (s->pinned) {
@@ -1929,6 +1933,13 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         }
         LC_HIP(hipMemcpy(s->d_needle, sp.needle.data(), sp.needle.size(), hipMemcpyHostToDevice));
         sp.p.needle = s->d_needle;
+    }
+    if (sp.p.mode == 1) {
+        // selective LIKE over an indexed column: the scan-level pipeline (probe + walk); everything else: k_str_pred
+        bool handled = false;
+        const lc_status ps = like_pipeline_eval(ctx, s, sp, L, stream, &handled);
+        if (ps != LC_OK) return ps;
+        if (handled) return LC_OK;
     }
     LC_HIP(launch_str_pred(static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, sp.p, L, stream));
     return LC_OK;
@@ -2317,6 +2328,10 @@ lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t wi
     std::vector<uint32_t> cand(size_t(s->n) * 2, 0);
     lc_status rc = (!d_cand || !d_mask) ? fail(LC_ERR_OOM, "hipMalloc (traffic model scratch)") : LC_OK;
     if (rc == LC_OK && hipMemset(d_cand, 0, size_t(s->n) * 8) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipMemset");
+    const bool like = pred->op == LC_OP_LIKE || pred->op == LC_OP_NOT_LIKE;
+    // a plain evaluation first: the path the predicate really takes (scan-level LIKE pipeline or k_str_pred) is then
+    // planned, and the kernel bytes reported below describe THAT path
+    if (rc == LC_OK && like) rc = scan_eval_impl(ctx, s, pred, nullptr, d_mask, nullptr, nullptr, nullptr, nullptr);
     if (rc == LC_OK) rc = scan_eval_impl(ctx, s, pred, nullptr, d_mask, nullptr, nullptr, d_cand, nullptr);
     if (rc == LC_OK && (hipDeviceSynchronize() != hipSuccess ||
                         hipMemcpy(cand.data(), d_cand, size_t(s->n) * 8, hipMemcpyDeviceToHost) != hipSuccess))
@@ -2325,7 +2340,6 @@ lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t wi
     pool_release(ctx, d_cand);
     pool_release(ctx, d_mask);
     if (rc != LC_OK) return rc;
-    const bool like = pred->op == LC_OP_LIKE || pred->op == LC_OP_NOT_LIKE;
     for (uint32_t i = 0; i < s->n; i++) {
         const Entry& e = s->meta[i];
         const uint64_t n = e.len, m = (n + 7) / 8;
@@ -2334,8 +2348,37 @@ lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t wi
         else if (pred->lit_tag == LC_LIT_BYTES) alg += 8ull * e.dict_len + (cand[i] ? e.offsets_bytes : 0);
         own += cand[size_t(s->n) + i];
     }
+    if (like) {
+        StrPredHost sp;
+        if (make_str_pred(pred, &sp) == LC_OK && sp.p.mode == 1) {
+            std::lock_guard<std::mutex> g(s->mu);
+            const uint64_t pb = like_pipeline_bytes(s, sp, false);
+            if (pb) own = pb;  // the pipeline takes this needle: its two kernels' bytes, not k_str_pred's
+        }
+    }
     *out_algorithmic = alg;
     *out_kernel_bytes = own;
+    return LC_OK;
+    });
+}
+
+lc_status lc_scan_explain(lc_scan* s, const lc_predicate* pred, char* out, size_t cap) {
+    return guarded([&]() -> lc_status {
+    if (!s || !pred || !out || cap == 0) return fail(LC_ERR_INVALID, "null argument");
+    std::string text;
+    if (!s->is_str) {
+        text = s->max_w <= 32 && s->lane_log2 >= 4 ? "k_fixed_pred_reg (register resident, thread = FastLanes lane)"
+                                                   : "k_fixed_pred (LDS staged)";
+        if (s->any_patch) text += " + k_alp_patch_fix";
+    } else {
+        StrPredHost sp;
+        const lc_status st = make_str_pred(pred, &sp);
+        if (st != LC_OK) return st;
+        std::lock_guard<std::mutex> g(s->mu);
+        if (sp.p.mode == 1 && pred->op == LC_OP_LIKE) text = like_pipeline_explain(s, sp);
+        else text = "k_str_pred";
+    }
+    std::snprintf(out, cap, "%s", text.c_str());
     return LC_OK;
     });
 }
