@@ -466,6 +466,32 @@ LC_API lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const vo
 LC_API lc_status lc_scan_date_part(lc_ctx* ctx, lc_scan* scan, void* d_values, uint64_t n_values, int32_t field,
                                    void* stream);
 
+/* ------------------------------------------------------------------ multi-GPU exchange (one process per GPU)
+ *
+ * Entries are sharded by ROW RANGE (file, row group, batch): every column of a batch lives on the same rank, so
+ * conjunctions chain their selections on one device and the data path needs no collective.  What is
+ * left are the two exchange steps of a sharded scan, here directly on RCCL over xGMI (librccl.so is opened lazily: a
+ * single-GPU process never loads it).  One lc_comm per lc_ctx; rank 0 creates the unique id and the host distributes
+ * its LC_COMM_ID_BYTES bytes to the other ranks by whatever means it has (a file, a socket, MPI ...).
+ * For a HOST-ONLY context (lc_ctx_create with n_devices == 0) the same calls run over a shared-memory file of the node and
+ * the "device" pointers are host pointers: this exists so that the multi-rank logic runs in CPU test suites. */
+#define LC_COMM_ID_BYTES 128
+typedef struct lc_comm lc_comm;
+LC_API lc_status lc_comm_unique_id(lc_ctx* ctx, uint8_t* out_id /* LC_COMM_ID_BYTES */);
+LC_API lc_status lc_comm_init(lc_ctx* ctx, int32_t rank, int32_t world, const uint8_t* id, lc_comm** out);
+LC_API void lc_comm_destroy(lc_comm* comm);
+LC_API int32_t lc_comm_rank(const lc_comm* comm);
+LC_API int32_t lc_comm_world(const lc_comm* comm);
+/* COUNT(*) of a sharded scan: *d_total (one u64 on the device, e.g. what lc_scan_eval_count wrote) becomes the sum over
+ * all ranks, in place.  Asynchronous on `stream` (ordered after the kernel that produced the partial count). */
+LC_API lc_status lc_comm_allreduce_count(lc_comm* comm, void* d_total, void* stream);
+/* The hit mask of the whole table from the per-rank masks: rank r contributes words_per_rank[r] u64 words (its
+ * lc_scan_mask_words; host array of `world` values, the same on every rank) and every rank receives the concatenation
+ * in rank order in d_mask_all — per-entry segments are word aligned, so row-range shards concatenate without bit
+ * shifting into the single Arrow BooleanArray.  Asynchronous on `stream`. */
+LC_API lc_status lc_comm_allgather_mask(lc_comm* comm, const void* d_mask_local, uint64_t local_words, void* d_mask_all,
+                                        const uint64_t* words_per_rank, void* stream);
+
 /* Convenience for hosts without their own HIP runtime binding. */
 LC_API lc_status lc_device_alloc(lc_ctx* ctx, uint64_t bytes, void** out_dptr);
 LC_API lc_status lc_device_free(lc_ctx* ctx, void* dptr);

@@ -32,17 +32,16 @@
 
 namespace lc {
 
-struct alignas(16) LikeK1Ref {
-    const uint64_t* sig;  // bit-sliced signatures of the entry: slice b at sig + b * nw
-    uint32_t woff;        // first flat word of the entry
-    uint32_t nw;          // ceil(d / 64)
-    uint32_t d;
-    uint32_t slot;        // symbol-table slot
-    uint32_t pad[2];
+// one record per flat word (64 dictionary values of one entry): everything the probe needs in ONE coalesced 16-byte load
+struct alignas(16) FlatRec {
+    uint64_t sig_addr;  // address of this word in slice 0 of the entry's signatures; slice b is nw words further per b
+    uint32_t entry;     // scan index of the entry, 0xFFFFFFFF: padding (keeps a probe wave inside one symbol table)
+    uint16_t nw;        // ceil(d / 64)
+    uint16_t w;         // index of this word inside the entry
 };
-static_assert(sizeof(LikeK1Ref) == 32, "LikeK1Ref layout");
+static_assert(sizeof(FlatRec) == 16, "FlatRec layout");
 
-struct alignas(16) LikeK2Ref {
+struct alignas(16) LikeEntryRef {
     const uint8_t* fsst;
     const uint8_t* residuals;
     const uint16_t* postings;
@@ -50,17 +49,24 @@ struct alignas(16) LikeK2Ref {
     int32_t slope, intercept;
     uint32_t offset_bytes, d;
 };
-static_assert(sizeof(LikeK2Ref) == 48, "LikeK2Ref layout");
+static_assert(sizeof(LikeEntryRef) == 48, "LikeEntryRef layout");
+
+// a candidate as the walk wants it: where its compressed bytes are — no descriptor, no offset load left to do
+struct alignas(16) CandRec {
+    uint64_t abs_start;  // address of the first compressed byte
+    uint32_t len;        // compressed bytes
+    uint32_t key;        // dictionary key inside its entry
+};
+static_assert(sizeof(CandRec) == 16, "CandRec layout");
 
 struct LikeChunk {
-    uint32_t first, count;  // candidates [first, first + count) of the scan's list, all of one symbol table
-    uint32_t slot;          // that table
-    uint32_t pad;
+    uint32_t first, count;  // candidates [first, first + count) of the scan's list: one wave, one symbol table, and (unless
+                            // a single value is longer) at most 64 eight-byte words = ONE pass of the lane-parallel walk
 };
 
 constexpr uint32_t kProbeThreads = 256;
-constexpr uint32_t kWalkWaves = 2;                       // waves per workgroup of the walk (they share the LDS automaton)
-constexpr uint32_t kWalkChunk = kWalkWaves * 64;         // candidates per workgroup
+constexpr uint32_t kProbeRound = 128;                    // candidates a probe wave redistributes through LDS at a time
+constexpr uint32_t kWalkWaves = 4;                       // waves (= chunks) per workgroup of the walk; they share the LDS automaton
 constexpr uint32_t kMaxPlans = 8;
 // a needle is "selective" (worth the pipeline) up to this many signature candidates per entry on average and this many
 // hit rows per 1024 rows of the scan; beyond, k_str_pred's per-entry key mapping is the better algorithm
@@ -70,13 +76,15 @@ constexpr uint32_t kMaxHitsPer1024 = 16;
 struct LikePlan {
     std::vector<uint8_t> needle;
     bool use_pipeline = false;
-    uint32_t n_cand = 0, n_chunks = 0;
+    uint32_t n_cand = 0, n_chunks = 0, n_wgs = 0;
     uint64_t hits = 0;
     uint64_t cand_bytes = 0;         // compressed bytes of the candidates (byte accounting)
     uint64_t matches = 0;            // dictionary values that matched
     uint32_t* d_wave_off = nullptr;  // write position of every probe wave (n_k1_waves)
-    LikeChunk* d_chunks = nullptr;
-    uint64_t* d_cand = nullptr;      // (entry << 16 | dictionary key) x n_cand
+    LikeChunk* d_chunks = nullptr;   // kWalkWaves per workgroup (padded with empty chunks where the table changes)
+    uint32_t* d_wg_slot = nullptr;   // symbol-table slot of every walk workgroup
+    CandRec* d_cand = nullptr;
+    uint32_t* d_cand_entry = nullptr;
     uint64_t last_use = 0;
 };
 
@@ -84,10 +92,8 @@ struct LikePipeline {
     bool built = false, eligible = false;
     uint32_t n_flat = 0;         // flat words incl. the padding that keeps a probe wave inside one symbol table
     uint32_t n_k1_waves = 0;
-    uint32_t* d_word_entry = nullptr;
-    LikeK1Ref* d_k1 = nullptr;
-    LikeK2Ref* d_k2 = nullptr;
-    std::vector<uint32_t> wave_slot;  // host: symbol-table slot of every probe wave
+    FlatRec* d_flat = nullptr;
+    LikeEntryRef* d_refs = nullptr;
     unsigned long long* d_total_acc = nullptr;
     std::vector<LikePlan> plans;
     uint64_t tick = 0;
@@ -96,14 +102,15 @@ struct LikePipeline {
 namespace {
 
 struct ProbeArgs {
-    const uint32_t* word_entry;
-    const LikeK1Ref* refs;
+    const FlatRec* flat;
+    const LikeEntryRef* refs;
     uint32_t n_flat;
     uint32_t n_entries;
     uint16_t sig_bits[kMaxSigProbe];
     uint32_t* wave_count;      // count mode
     const uint32_t* wave_off;  // fill mode
-    uint64_t* cand;
+    CandRec* cand;
+    uint32_t* cand_entry;
     uint64_t* mask;            // fill mode: zero-filled here
     uint64_t mask_words;
     uint32_t* counts;          // optional, zero-filled here
@@ -113,6 +120,8 @@ struct ProbeArgs {
 // N = distinct signature bits of the needle (1..8): every slice load is issued before the first use, none is repeated
 template <int N, bool kCount>
 __global__ __launch_bounds__(kProbeThreads) void k_like_probe(ProbeArgs a) {
+    __shared__ uint32_t lds_entry[kProbeThreads / 64][kProbeRound];
+    __shared__ uint16_t lds_key[kProbeThreads / 64][kProbeRound];
     const uint32_t gtid = blockIdx.x * kProbeThreads + threadIdx.x;
     if (!kCount) {
         // the hit mask starts all clear (the walk ORs the hit rows in); 16-byte coalesced stores over the whole grid
@@ -128,42 +137,75 @@ __global__ __launch_bounds__(kProbeThreads) void k_like_probe(ProbeArgs a) {
     }
     if (gtid >= a.n_flat) return;  // n_flat is a multiple of 64: whole waves leave
     const int lane = lane_id();
-    const uint32_t e = as_global(a.word_entry)[gtid];
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const u32x4 fr = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.flat + gtid));
+    const uint32_t e = fr.z, nw = fr.w & 0xFFFFu, w = fr.w >> 16;
     uint64_t m = 0;
-    uint32_t w = 0;
     if (e != 0xFFFFFFFFu) {
-        const u32x4 r0 = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.refs + e));
-        const u32x4 r1 = *(reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.refs + e)) + 1);
-        const uint64_t* sig = reinterpret_cast<const uint64_t*>(uint64_t(r0.x) | (uint64_t(r0.y) << 32));
-        const uint32_t woff = r0.z, nw = r0.w, d = r1.x;
-        w = gtid - woff;
+        const uint64_t* sig = reinterpret_cast<const uint64_t*>(uint64_t(fr.x) | (uint64_t(fr.y) << 32));
         uint64_t sv[N];
 #pragma unroll
-        for (int k = 0; k < N; k++) sv[k] = as_global(sig)[size_t(a.sig_bits[k]) * nw + w];
+        for (int k = 0; k < N; k++) sv[k] = as_global(sig)[size_t(a.sig_bits[k]) * nw];
         m = sv[0];
 #pragma unroll
         for (int k = 1; k < N; k++) m &= sv[k];
-        if (w == nw - 1u && (d & 63u)) m &= (uint64_t(1) << (d & 63u)) - 1;
+        // (no bit beyond the dictionary can be set: the index builders only set bits of real values and lc_stage_indexed
+        // rejects blobs that do otherwise)
     }
     const uint32_t cnt = uint32_t(__popcll(m));
     const uint32_t incl = wave_inclusive_sum(cnt);
+    const uint32_t total = read_lane(incl, kWave - 1);
     const uint32_t wv = gtid >> 6;
     if (kCount) {
-        if (lane == kWave - 1) as_global_mut(a.wave_count)[wv] = incl;
+        if (lane == 0) as_global_mut(a.wave_count)[wv] = total;
         return;
     }
-    uint32_t o = as_global(a.wave_off)[wv] + incl - cnt;
-    while (m) {
-        const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
-        as_global_mut(a.cand)[o++] = (uint64_t(e) << 16) | uint64_t(w * 64u + bit);
-        m &= m - 1;
+    if (total == 0) return;
+    const uint32_t base = uint32_t(__builtin_amdgcn_readfirstlane(int(as_global(a.wave_off)[wv])));
+    // The wave's candidates are spread over its lanes first (LDS), so that the two dependent loads every candidate needs —
+    // its entry's reference and its offset pair — are issued by 64 lanes at once instead of inside a divergent loop.
+    for (uint32_t r0 = 0; r0 < total; r0 += kProbeRound) {
+        uint32_t o = incl - cnt;
+        uint64_t mm = m;
+        while (mm) {
+            const uint32_t bit = uint32_t(__ffsll((long long)mm)) - 1u;
+            mm &= mm - 1;
+            const uint32_t pos = o++;
+            if (pos >= r0 && pos < r0 + kProbeRound) {
+                lds_entry[wave][pos - r0] = e;
+                lds_key[wave][pos - r0] = uint16_t(w * 64u + bit);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const uint32_t n_round = min(kProbeRound, total - r0);
+        for (uint32_t j = uint32_t(lane); j < n_round; j += kWave) {
+            const uint32_t ce = lds_entry[wave][j], key = lds_key[wave][j];
+            GlobalPtr<u32x4> rp = reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.refs + ce));
+            const u32x4 r0v = rp[0], r2v = rp[2];
+            const uint64_t fsst = uint64_t(r0v.x) | (uint64_t(r0v.y) << 32);
+            const uint8_t* residuals = reinterpret_cast<const uint8_t*>(uint64_t(r0v.z) | (uint64_t(r0v.w) << 32));
+            const uint32_t slope = r2v.x, intercept = r2v.y, ob = r2v.z;
+            const uint64_t v = load_unaligned<uint64_t>(residuals + size_t(key) * ob);
+            const uint32_t sh = 32u - 8u * ob;
+            const int32_t q0 = int32_t(uint32_t(v) << sh) >> sh;
+            const int32_t q1 = int32_t(uint32_t(v >> (8u * ob)) << sh) >> sh;
+            const uint32_t start = slope * key + intercept + uint32_t(q0);
+            const uint32_t stop = slope * (key + 1u) + intercept + uint32_t(q1);
+            const uint64_t abs_start = fsst + start;
+            const u32x4 out = {uint32_t(abs_start), uint32_t(abs_start >> 32), stop - start, key};
+            *reinterpret_cast<GlobalMutPtr<u32x4>>(as_global_mut(a.cand + base + r0 + j)) = out;
+            as_global_mut(a.cand_entry)[base + r0 + j] = ce;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 }
 
 struct WalkArgs {
     const LikeChunk* chunks;
-    const uint64_t* cand;
-    const LikeK2Ref* refs;
+    const uint32_t* wg_slot;
+    const CandRec* cand;
+    const uint32_t* cand_entry;
+    const LikeEntryRef* refs;
     const uint8_t* automata;
     uint32_t automaton_stride;
     uint32_t nl;
@@ -187,12 +229,13 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     const uint32_t nl = a.nl;
     const uint32_t tbl_bytes = automaton_image_bytes(nl);
-    const LikeChunk ch = a.chunks[blockIdx.x];
+    const uint32_t slot = a.wg_slot[blockIdx.x];
     {
-        const uint8_t* src = a.automata + size_t(ch.slot) * a.automaton_stride + automaton_u8_bytes(nl);
+        const uint8_t* src = a.automata + size_t(slot) * a.automaton_stride + automaton_u8_bytes(nl);
         for (uint32_t c = wave * 1024u; c < tbl_bytes; c += kWalkWaves * 1024u)
             async_copy16(src + c + uint32_t(lane) * 16u, smem + c);
     }
+    const LikeChunk ch = a.chunks[blockIdx.x * kWalkWaves + wave];
     uint8_t* hitflag = smem + tbl_bytes + wave * 80u;
     uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
     // the image holds absolute LDS addresses computed for a table at LDS address 0: this kernel has no static LDS, so its
@@ -201,37 +244,20 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
     if (row0 != 0u) __builtin_trap();
     const uint32_t hitrow = row0 + nl * 512u;
 
-    // this lane's candidate
-    const uint32_t idx = wave * 64u + uint32_t(lane);
-    const bool cl = idx < ch.count;
-    uint64_t c64 = 0;
-    if (cl) c64 = as_global(a.cand)[ch.first + idx];
-    const uint32_t e = uint32_t(c64 >> 16), key = uint32_t(c64) & 0xFFFFu;
-    uint64_t abs_start = 0;  // address of the candidate's first compressed byte
-    uint32_t len = 0;
-    uint64_t post_bits = 0, mask_off = 0;
-    uint32_t dlen = 0;
+    // this lane's candidate: one 16-byte record says where its compressed bytes are
+    const bool cl = uint32_t(lane) < ch.count;
+    uint64_t abs_start = 0;
+    uint32_t len = 0, key = 0, e = 0;
     if (cl) {
-        GlobalPtr<u32x4> rp = reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.refs + e));
-        const u32x4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
-        const uint64_t fsst = uint64_t(r0.x) | (uint64_t(r0.y) << 32);
-        const uint8_t* residuals = reinterpret_cast<const uint8_t*>(uint64_t(r0.z) | (uint64_t(r0.w) << 32));
-        post_bits = uint64_t(r1.x) | (uint64_t(r1.y) << 32);
-        mask_off = uint64_t(r1.z) | (uint64_t(r1.w) << 32);
-        const uint32_t slope = r2.x, intercept = r2.y, ob = r2.z;
-        dlen = r2.w;
-        const uint64_t v = load_unaligned<uint64_t>(residuals + size_t(key) * ob);
-        const uint32_t sh = 32u - 8u * ob;
-        const int32_t q0 = int32_t(uint32_t(v) << sh) >> sh;
-        const int32_t q1 = int32_t(uint32_t(v >> (8u * ob)) << sh) >> sh;
-        const uint32_t start = slope * key + intercept + uint32_t(q0);
-        const uint32_t stop = slope * (key + 1u) + intercept + uint32_t(q1);
-        abs_start = fsst + start;
-        len = stop - start;
+        const u32x4 c = *reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.cand + ch.first + uint32_t(lane)));
+        abs_start = uint64_t(c.x) | (uint64_t(c.y) << 32);
+        len = c.z;
+        key = c.w;
+        e = as_global(a.cand_entry)[ch.first + uint32_t(lane)];
     }
     // ---- lane-parallel walk: one lane per 8-byte word of every candidate (see "the lane-parallel LIKE walker" in
-    // lc_kernels.hip: byte roles and automaton states are corrected across neighbouring lanes to a fixpoint, and a match
-    // counts only there)
+    // lc_kernels.hip: automaton states are corrected across neighbouring lanes to a fixpoint, and a match counts only
+    // there).  The plan cut the chunks so that this loop runs once unless a single value is longer than 512 bytes.
     const uint32_t words = cl ? max(1u, (len + 7u) >> 3) : 0u;
     const uint32_t incl = wave_inclusive_sum(words);
     const uint32_t off = incl - words;
@@ -296,9 +322,16 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
         }
     }
     if (matched) {
-        // ---- rows of the matching dictionary values, from the entries' inverted row lists
-        uint32_t o0 = 0, o1 = 0;
+        // ---- rows of the matching dictionary values, from the entries' inverted row lists (matches are rare: the
+        // entry's reference is only fetched now, by the matching lanes)
+        uint32_t o0 = 0, o1 = 0, dlen = 0;
+        uint64_t post_bits = 0, mask_off = 0;
         if (res) {
+            GlobalPtr<u32x4> rp = reinterpret_cast<GlobalPtr<u32x4>>(as_global(a.refs + e));
+            const u32x4 r1 = rp[1], r2 = rp[2];
+            post_bits = uint64_t(r1.x) | (uint64_t(r1.y) << 32);
+            mask_off = uint64_t(r1.z) | (uint64_t(r1.w) << 32);
+            dlen = r2.w;
             const uint32_t v = load_unaligned<uint32_t>(reinterpret_cast<const uint8_t*>(post_bits) + 2u * size_t(key));
             o0 = v & 0xFFFFu;
             o1 = v >> 16;
@@ -344,20 +377,24 @@ hipError_t launch_probe(int n_sig, const ProbeArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_walk(const WalkArgs& a, uint32_t n_chunks, hipStream_t stream) {
-    if (n_chunks == 0) return hipSuccess;
+hipError_t launch_walk(const WalkArgs& a, uint32_t n_wgs, hipStream_t stream) {
+    if (n_wgs == 0) return hipSuccess;
     const size_t lds = automaton_image_bytes(a.nl) + kWalkWaves * 80u;
-    hipLaunchKernelGGL(k_like_walk, dim3(n_chunks), dim3(kWalkWaves * 64), lds, stream, a);
+    hipLaunchKernelGGL(k_like_walk, dim3(n_wgs), dim3(kWalkWaves * 64), lds, stream, a);
     return hipGetLastError();
 }
 
 void free_plan(lc_ctx* ctx, LikePlan& p) {
     pool_release(ctx, p.d_wave_off);
     pool_release(ctx, p.d_chunks);
+    pool_release(ctx, p.d_wg_slot);
     pool_release(ctx, p.d_cand);
+    pool_release(ctx, p.d_cand_entry);
     p.d_wave_off = nullptr;
     p.d_chunks = nullptr;
+    p.d_wg_slot = nullptr;
     p.d_cand = nullptr;
+    p.d_cand_entry = nullptr;
 }
 
 // flat index over the scan's dictionaries, built once per scan
@@ -369,39 +406,32 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
         if (e.sd.d == 0) continue;  // an all-null entry has no dictionary: no candidates, its mask words stay zero
         if (!e.sd.signatures || !e.sd.postings || e.sd.n > kPostMaxRows) return LC_OK;
     }
-    std::vector<uint32_t> word_entry;
-    std::vector<LikeK1Ref> k1(s->n);
-    std::vector<LikeK2Ref> k2(s->n);
+    std::vector<FlatRec> flat;
+    std::vector<LikeEntryRef> refs(s->n);
+    const FlatRec pad{0, 0xFFFFFFFFu, 0, 0};
     uint32_t prev_slot = 0xFFFFFFFFu;
     for (uint32_t i = 0; i < s->n; i++) {
         const StrDesc& d = s->meta[i].sd;
         const uint32_t nw = (d.d + 63u) / 64u;
         if (nw && d.symtab_slot != prev_slot) {
             // a probe wave (64 flat words) never spans two symbol tables: the candidate list is then grouped by table
-            while (word_entry.size() % 64) word_entry.push_back(0xFFFFFFFFu);
+            while (flat.size() % 64) flat.push_back(pad);
             prev_slot = d.symtab_slot;
         }
-        if (uint64_t(word_entry.size()) + nw + 64 > 0xFFFFFFF0ull) return LC_OK;
-        k1[i] = LikeK1Ref{d.signatures, uint32_t(word_entry.size()), nw, d.d, d.symtab_slot, {0, 0}};
-        k2[i] = LikeK2Ref{d.fsst, d.residuals, d.postings, d.mask_word_off, d.slope, d.intercept, d.offset_bytes, d.d};
-        for (uint32_t w = 0; w < nw; w++) word_entry.push_back(i);
+        if (uint64_t(flat.size()) + nw + 64 > 0xFFFFFFF0ull) return LC_OK;
+        refs[i] = LikeEntryRef{d.fsst, d.residuals, d.postings, d.mask_word_off, d.slope, d.intercept, d.offset_bytes, d.d};
+        for (uint32_t w = 0; w < nw; w++)
+            flat.push_back(FlatRec{uint64_t(reinterpret_cast<uintptr_t>(d.signatures + w)), i, uint16_t(nw), uint16_t(w)});
     }
-    while (word_entry.size() % 64) word_entry.push_back(0xFFFFFFFFu);
-    lp->n_flat = uint32_t(word_entry.size());
+    while (flat.size() % 64) flat.push_back(pad);
+    lp->n_flat = uint32_t(flat.size());
     lp->n_k1_waves = lp->n_flat / 64;
-    lp->wave_slot.assign(lp->n_k1_waves, 0);
-    for (uint32_t wv = 0; wv < lp->n_k1_waves; wv++) {
-        const uint32_t e = word_entry[size_t(wv) * 64];  // the padding sits at the END of a table's range
-        lp->wave_slot[wv] = e == 0xFFFFFFFFu ? 0u : s->meta[e].sd.symtab_slot;
-    }
-    lp->d_word_entry = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(word_entry.size(), 1) * 4));
-    lp->d_k1 = static_cast<LikeK1Ref*>(pool_alloc(ctx, size_t(s->n) * sizeof(LikeK1Ref)));
-    lp->d_k2 = static_cast<LikeK2Ref*>(pool_alloc(ctx, size_t(s->n) * sizeof(LikeK2Ref)));
+    lp->d_flat = static_cast<FlatRec*>(pool_alloc(ctx, std::max<size_t>(flat.size(), 1) * sizeof(FlatRec)));
+    lp->d_refs = static_cast<LikeEntryRef*>(pool_alloc(ctx, size_t(s->n) * sizeof(LikeEntryRef)));
     lp->d_total_acc = static_cast<unsigned long long*>(pool_alloc(ctx, size_t(kTotalWords) * 8));
-    if (!lp->d_word_entry || !lp->d_k1 || !lp->d_k2 || !lp->d_total_acc) return fail(LC_ERR_OOM, "hipMalloc (LIKE pipeline index)");
-    LC_HIP(hipMemcpyAsync(lp->d_word_entry, word_entry.data(), word_entry.size() * 4, hipMemcpyHostToDevice, stream));
-    LC_HIP(hipMemcpyAsync(lp->d_k1, k1.data(), k1.size() * sizeof(LikeK1Ref), hipMemcpyHostToDevice, stream));
-    LC_HIP(hipMemcpyAsync(lp->d_k2, k2.data(), k2.size() * sizeof(LikeK2Ref), hipMemcpyHostToDevice, stream));
+    if (!lp->d_flat || !lp->d_refs || !lp->d_total_acc) return fail(LC_ERR_OOM, "hipMalloc (LIKE pipeline index)");
+    LC_HIP(hipMemcpyAsync(lp->d_flat, flat.data(), flat.size() * sizeof(FlatRec), hipMemcpyHostToDevice, stream));
+    LC_HIP(hipMemcpyAsync(lp->d_refs, refs.data(), refs.size() * sizeof(LikeEntryRef), hipMemcpyHostToDevice, stream));
     LC_HIP(hipMemsetAsync(lp->d_total_acc, 0, size_t(kTotalWords) * 8, stream));  // once: launches leave it zero
     LC_HIP(hipStreamSynchronize(stream));  // the host vectors are locals
     lp->eligible = true;
@@ -410,28 +440,37 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
 
 void fill_probe_args(const lc_scan* s, const LikePipeline* lp, const StrPred& p, ProbeArgs* a) {
     *a = ProbeArgs{};
-    a->word_entry = lp->d_word_entry;
-    a->refs = lp->d_k1;
+    a->flat = lp->d_flat;
+    a->refs = lp->d_refs;
     a->n_flat = lp->n_flat;
     a->n_entries = s->n;
     for (int k = 0; k < kMaxSigProbe; k++) a->sig_bits[k] = p.sig_bits[k];
 }
 
-lc_status run(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred& p, const ScanLaunch& L, hipStream_t stream,
-              unsigned long long* d_stats = nullptr) {
+lc_status run_probe(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred& p, const ScanLaunch& L, hipStream_t stream) {
     ProbeArgs pa;
     fill_probe_args(s, lp, p, &pa);
     pa.wave_off = plan.d_wave_off;
     pa.cand = plan.d_cand;
+    pa.cand_entry = plan.d_cand_entry;
     pa.mask = L.d_hit;
     pa.mask_words = s->seg_offsets.back();
     pa.counts = L.d_counts;
-    pa.total_zero = plan.n_chunks == 0 ? L.d_total_out : nullptr;
+    pa.total_zero = plan.n_wgs == 0 ? L.d_total_out : nullptr;
     LC_HIP(launch_probe<false>(int(p.n_sig_bits), pa, stream));
+    return LC_OK;
+}
+
+lc_status run(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred& p, const ScanLaunch& L, hipStream_t stream,
+              unsigned long long* d_stats = nullptr) {
+    const lc_status ps = run_probe(s, lp, plan, p, L, stream);
+    if (ps != LC_OK) return ps;
     WalkArgs wa{};
     wa.chunks = plan.d_chunks;
+    wa.wg_slot = plan.d_wg_slot;
     wa.cand = plan.d_cand;
-    wa.refs = lp->d_k2;
+    wa.cand_entry = plan.d_cand_entry;
+    wa.refs = lp->d_refs;
     wa.automata = p.automata;
     wa.automaton_stride = p.automaton_stride;
     wa.nl = p.needle_len;
@@ -441,19 +480,23 @@ lc_status run(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred&
     wa.stats = d_stats;
     wa.total.d_total_acc = lp->d_total_acc;
     wa.total.d_total_out = L.d_total_out;
-    LC_HIP(launch_walk(wa, plan.n_chunks, stream));
+    LC_HIP(launch_walk(wa, plan.n_wgs, stream));
     return LC_OK;
 }
 
 lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost& sp, hipStream_t stream, LikePlan* plan) {
     plan->needle = sp.needle;
     plan->use_pipeline = false;
+    const uint64_t words = std::max<uint64_t>(s->seg_offsets.back(), 1);
+    // scratch: per-wave counts | trial mask | {COUNT(*), candidate bytes, matches}
     uint32_t* d_wave_count = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(lp->n_k1_waves, 1) * 4));
-    if (!d_wave_count) return fail(LC_ERR_OOM, "hipMalloc (LIKE plan)");
+    uint64_t* d_scratch = static_cast<uint64_t*>(pool_alloc(ctx, words * 8 + 24));
     struct Tmp {
-        lc_ctx* c; void* p; hipStream_t st;
-        ~Tmp() { (void)hipStreamSynchronize(st); pool_release(c, p); }
-    } tmp{ctx, d_wave_count, stream};
+        lc_ctx* c; void* p; void* q; hipStream_t st;
+        ~Tmp() { (void)hipStreamSynchronize(st); pool_release(c, p); pool_release(c, q); }
+    } tmp{ctx, d_wave_count, d_scratch, stream};
+    if (!d_wave_count || !d_scratch) return fail(LC_ERR_OOM, "hipMalloc (LIKE plan)");
+    // 1. count: candidates of every probe wave -> write positions
     ProbeArgs pa;
     fill_probe_args(s, lp, sp.p, &pa);
     pa.wave_count = d_wave_count;
@@ -461,64 +504,85 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
     std::vector<uint32_t> wc(lp->n_k1_waves, 0);
     LC_HIP(hipMemcpyAsync(wc.data(), d_wave_count, size_t(lp->n_k1_waves) * 4, hipMemcpyDeviceToHost, stream));
     LC_HIP(hipStreamSynchronize(stream));
-    // write positions (exclusive prefix sums) and the chunk schedule: consecutive candidates of ONE symbol table
     std::vector<uint32_t> woff(lp->n_k1_waves, 0);
-    std::vector<LikeChunk> chunks;
     uint64_t total = 0;
-    uint32_t run_begin = 0;  // first candidate of the current table
-    auto close_table = [&](uint32_t slot, uint32_t end) {
-        for (uint32_t f = run_begin; f < end; f += kWalkChunk)
-            chunks.push_back(LikeChunk{f, std::min(kWalkChunk, end - f), slot, 0});
-        run_begin = end;
-    };
     for (uint32_t wv = 0; wv < lp->n_k1_waves; wv++) {
-        if (wv > 0 && lp->wave_slot[wv] != lp->wave_slot[wv - 1]) close_table(lp->wave_slot[wv - 1], uint32_t(total));
         woff[wv] = uint32_t(total);
         total += wc[wv];
-        if (total > uint64_t(kMaxCandPerEntry) * s->n + 4096) return LC_OK;  // not selective: k_str_pred keeps it
+        if (total > uint64_t(kMaxCandPerEntry) * s->n + 4096) {
+            plan->n_cand = uint32_t(total);
+            return LC_OK;  // not selective: k_str_pred keeps it
+        }
     }
-    if (lp->n_k1_waves) close_table(lp->wave_slot[lp->n_k1_waves - 1], uint32_t(total));
     plan->n_cand = uint32_t(total);
-    plan->n_chunks = uint32_t(chunks.size());
     plan->d_wave_off = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(woff.size(), 1) * 4));
-    plan->d_chunks = static_cast<LikeChunk*>(pool_alloc(ctx, std::max<size_t>(chunks.size(), 1) * sizeof(LikeChunk)));
-    plan->d_cand = static_cast<uint64_t*>(pool_alloc(ctx, std::max<uint64_t>(total, 1) * 8));
-    if (!plan->d_wave_off || !plan->d_chunks || !plan->d_cand) {
-        free_plan(ctx, *plan);
-        return fail(LC_ERR_OOM, "hipMalloc (LIKE plan)");
-    }
-    LC_HIP(hipMemcpyAsync(plan->d_wave_off, woff.data(), woff.size() * 4, hipMemcpyHostToDevice, stream));
-    LC_HIP(hipMemcpyAsync(plan->d_chunks, chunks.data(), chunks.size() * sizeof(LikeChunk), hipMemcpyHostToDevice, stream));
-    // trial run into scratch: how many rows does the needle hit?
-    const uint64_t words = std::max<uint64_t>(s->seg_offsets.back(), 1);
-    uint64_t* d_scratch = static_cast<uint64_t*>(pool_alloc(ctx, words * 8 + 24));
-    if (!d_scratch) {
-        free_plan(ctx, *plan);
-        return fail(LC_ERR_OOM, "hipMalloc (LIKE plan)");
-    }
-    struct Tmp2 {
-        lc_ctx* c; void* p; hipStream_t st;
-        ~Tmp2() { (void)hipStreamSynchronize(st); pool_release(c, p); }
-    } tmp2{ctx, d_scratch, stream};
+    plan->d_cand = static_cast<CandRec*>(pool_alloc(ctx, std::max<uint64_t>(total, 1) * sizeof(CandRec)));
+    plan->d_cand_entry = static_cast<uint32_t*>(pool_alloc(ctx, std::max<uint64_t>(total, 1) * 4));
+    auto bail = [&](lc_status st) { free_plan(ctx, *plan); return st; };
+    if (!plan->d_wave_off || !plan->d_cand || !plan->d_cand_entry) return bail(fail(LC_ERR_OOM, "hipMalloc (LIKE plan)"));
+    if (hipMemcpyAsync(plan->d_wave_off, woff.data(), woff.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess)
+        return bail(fail(LC_ERR_DEVICE, "hipMemcpy (LIKE plan)"));
+    // 2. emit the candidate records once and cut them into chunks: consecutive candidates of ONE symbol table with at most
+    //    64 eight-byte words in all (one pass of the walk), four chunks per workgroup
     ScanLaunch L{};
     L.d_hit = d_scratch;
     L.d_total_out = d_scratch + words;
-    StrPred p = sp.p;
-    lc_status rc = hipMemsetAsync(d_scratch + words, 0, 24, stream) == hipSuccess ? LC_OK : fail(LC_ERR_DEVICE, "memset (LIKE plan)");
-    if (rc == LC_OK) rc = run(s, lp, *plan, p, L, stream, reinterpret_cast<unsigned long long*>(d_scratch + words + 1));
+    plan->n_wgs = 1;  // (keeps the probe from clearing the total word: the trial below owns it)
+    lc_status rc = run_probe(s, lp, *plan, sp.p, L, stream);
+    if (rc != LC_OK) return bail(rc);
+    std::vector<CandRec> recs(total);
+    std::vector<uint32_t> ents(total);
+    if ((total && (hipMemcpyAsync(recs.data(), plan->d_cand, total * sizeof(CandRec), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                   hipMemcpyAsync(ents.data(), plan->d_cand_entry, total * 4, hipMemcpyDeviceToHost, stream) != hipSuccess)) ||
+        hipStreamSynchronize(stream) != hipSuccess)
+        return bail(fail(LC_ERR_DEVICE, "hipMemcpy (LIKE plan)"));
+    std::vector<LikeChunk> chunks;
+    std::vector<uint32_t> wg_slot;
+    uint32_t cur_first = 0, cur_count = 0, cur_words = 0, cur_slot = 0xFFFFFFFFu;
+    auto close_chunk = [&]() {
+        if (cur_count == 0) return;
+        if (chunks.size() % kWalkWaves == 0) wg_slot.push_back(cur_slot);
+        chunks.push_back(LikeChunk{cur_first, cur_count});
+        cur_count = cur_words = 0;
+    };
+    auto close_table = [&]() {
+        close_chunk();
+        while (chunks.size() % kWalkWaves) chunks.push_back(LikeChunk{0, 0});
+    };
+    for (uint64_t i = 0; i < total; i++) {
+        if (ents[i] >= s->n) return bail(fail(LC_ERR_DEVICE, "LIKE plan: candidate list is corrupt"));
+        const uint32_t slot = s->meta[ents[i]].sd.symtab_slot;
+        const uint32_t wds = std::max<uint32_t>(1u, (recs[i].len + 7u) / 8u);
+        if (slot != cur_slot) {
+            close_table();
+            cur_slot = slot;
+        }
+        if (cur_count && (cur_words + wds > 64u || cur_count == 64u)) close_chunk();
+        if (cur_count == 0) cur_first = uint32_t(i);
+        cur_count++;
+        cur_words += wds;
+    }
+    close_table();
+    plan->n_chunks = uint32_t(chunks.size());
+    plan->n_wgs = uint32_t(chunks.size() / kWalkWaves);
+    plan->d_chunks = static_cast<LikeChunk*>(pool_alloc(ctx, std::max<size_t>(chunks.size(), 1) * sizeof(LikeChunk)));
+    plan->d_wg_slot = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(wg_slot.size(), 1) * 4));
+    if (!plan->d_chunks || !plan->d_wg_slot) return bail(fail(LC_ERR_OOM, "hipMalloc (LIKE plan)"));
+    if (hipMemcpyAsync(plan->d_chunks, chunks.data(), chunks.size() * sizeof(LikeChunk), hipMemcpyHostToDevice, stream) != hipSuccess ||
+        hipMemcpyAsync(plan->d_wg_slot, wg_slot.data(), wg_slot.size() * 4, hipMemcpyHostToDevice, stream) != hipSuccess)
+        return bail(fail(LC_ERR_DEVICE, "hipMemcpy (LIKE plan)"));
+    // 3. trial run into scratch: how many rows does the needle hit?
+    rc = hipMemsetAsync(d_scratch + words, 0, 24, stream) == hipSuccess ? LC_OK : fail(LC_ERR_DEVICE, "memset (LIKE plan)");
+    if (rc == LC_OK) rc = run(s, lp, *plan, sp.p, L, stream, reinterpret_cast<unsigned long long*>(d_scratch + words + 1));
     uint64_t res3[3] = {0, 0, 0};
     if (rc == LC_OK && hipMemcpyAsync(res3, d_scratch + words, 24, hipMemcpyDeviceToHost, stream) != hipSuccess)
         rc = fail(LC_ERR_DEVICE, "hipMemcpy (LIKE plan)");
     if (rc == LC_OK && hipStreamSynchronize(stream) != hipSuccess) rc = fail(LC_ERR_DEVICE, "stream (LIKE plan)");
-    if (rc != LC_OK) {
-        free_plan(ctx, *plan);
-        return rc;
-    }
-    const uint64_t hits = res3[0];
-    plan->hits = hits;
+    if (rc != LC_OK) return bail(rc);
+    plan->hits = res3[0];
     plan->cand_bytes = res3[1];
     plan->matches = res3[2];
-    plan->use_pipeline = hits * 1024u <= uint64_t(kMaxHitsPer1024) * std::max<uint64_t>(s->total_rows, 1024);
+    plan->use_pipeline = plan->hits * 1024u <= uint64_t(kMaxHitsPer1024) * std::max<uint64_t>(s->total_rows, 1024);
     if (!plan->use_pipeline) free_plan(ctx, *plan);
     return LC_OK;
 }
@@ -528,9 +592,8 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
 void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     if (!lp) return;
     for (LikePlan& p : lp->plans) free_plan(ctx, p);
-    pool_release(ctx, lp->d_word_entry);
-    pool_release(ctx, lp->d_k1);
-    pool_release(ctx, lp->d_k2);
+    pool_release(ctx, lp->d_flat);
+    pool_release(ctx, lp->d_refs);
     pool_release(ctx, lp->d_total_acc);
     delete lp;
 }
@@ -564,13 +627,17 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
     if (!lp || !lp->eligible) return 0;
     for (const LikePlan& q : lp->plans)
         if (q.needle == sp.needle && q.use_pipeline) {
+            // probe: 16 B per flat word + the needle's slices + mask / count clears + write positions + per candidate the
+            // offset pair (8) and the 16 + 4 bytes of its record; one 48-byte reference per entry that has candidates
             uint64_t flat_valid = 0;
             for (const Entry& e : s->meta) flat_valid += (e.sd.d + 63u) / 64u;
-            uint64_t b = uint64_t(lp->n_flat) * 4 + flat_valid * 8 * sp.p.n_sig_bits + uint64_t(s->n) * 32 +
-                         s->seg_offsets.back() * 8 + (with_counts ? uint64_t(s->n) * 4 : 0) + uint64_t(lp->n_k1_waves) * 4 +
-                         uint64_t(q.n_cand) * 8;
-            b += uint64_t(q.n_chunks) * 16 + uint64_t(q.n_cand) * (8 + 8) + std::min<uint64_t>(q.n_cand, s->n) * 48 + q.cand_bytes +
-                 q.matches * 4 + q.hits * (2 + 16);
+            uint64_t b = uint64_t(lp->n_flat) * 16 + flat_valid * 8 * sp.p.n_sig_bits + s->seg_offsets.back() * 8 +
+                         (with_counts ? uint64_t(s->n) * 4 : 0) + uint64_t(lp->n_k1_waves) * 4 + uint64_t(q.n_cand) * (8 + 20) +
+                         std::min<uint64_t>(q.n_cand, s->n) * 48;
+            // walk: chunk records + workgroup slots + candidate records + compressed bytes + per match its entry's
+            // reference (48), list bounds (4) and rows (2 each) + one 8-byte read-modify-write per hit row
+            b += uint64_t(q.n_chunks) * 8 + uint64_t(q.n_wgs) * 4 + uint64_t(q.n_cand) * 20 + q.cand_bytes + q.matches * (48 + 4) +
+                 q.hits * (2 + 16);
             return b;
         }
     return 0;

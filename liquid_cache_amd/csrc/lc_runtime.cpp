@@ -465,7 +465,19 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
         const size_t nw = std::max<size_t>((size_t(v.d) + 63) / 64, 1);
         const bool head_ok = h.magic == kIndexMagic && h.version == 1 && h.d == v.d && h.n == v.n && h.sig_bits == uint32_t(kSigBits) &&
                              index_len == sizeof(h) + h.sig_bytes + h.post_bytes;
-        if (head_ok && (h.flags & 1u) && h.sig_bytes == size_t(kSigBits) * nw * 8) pre_sig = index + sizeof(h);
+        if (head_ok && (h.flags & 1u) && h.sig_bytes == size_t(kSigBits) * nw * 8) {
+            pre_sig = index + sizeof(h);
+            // no slice may have a bit beyond the dictionary: the kernels turn set bits into dictionary keys
+            if (v.d & 63u) {
+                const uint64_t beyond = ~((uint64_t(1) << (v.d & 63u)) - 1);
+                for (int b = 0; b < kSigBits && pre_sig; b++) {
+                    uint64_t last;
+                    std::memcpy(&last, pre_sig + (size_t(b) * nw + (nw - 1)) * 8, 8);
+                    if (last & beyond) pre_sig = nullptr;
+                }
+            }
+            if (v.d == 0) pre_sig = nullptr;
+        }
         if (head_ok && (h.flags & 2u) && h.post_bytes == (size_t(v.d) + 1 + size_t(v.n) + 32) * 2) {
             pre_post = index + sizeof(h) + h.sig_bytes;
             pre_post_bytes = h.post_bytes;
