@@ -77,6 +77,8 @@ def parse_args(argv=None):
     p.add_argument("--no-row-lists", action="store_true", help="url_like: stage without the inverted row lists")
     p.add_argument("--no-like-pipeline", action="store_true",
                    help="url_like: evaluate LIKE with the one-wave-per-entry kernel only (A/B of the scan-level pipeline)")
+    p.add_argument("--no-needle-classes", action="store_true", help="skip the timing of the LIKE needle classes")
+    p.add_argument("--like-path", type=int, default=0, help="LC_OPT_LIKE_PATH (A/B aid): 0 auto, 1 k_str_pred, 2 two-kernel, 3 lean")
     p.add_argument("--rotate", type=int, default=0,
                    help="columns the timed loop rotates through (one per step, all resident in HBM) so that a step never "
                         "finds its data in the 256 MiB Infinity Cache; 0 = as many as make the cycle move >= 768 MB (1..8)")
@@ -970,7 +972,8 @@ def main():
 
     cache = (lc.LiquidCacheBuilder.new().with_device(local_rank).with_batch_size(args.batch_size)
              .with_index_options(signatures=not args.no_signatures, row_lists=not args.no_row_lists,
-                                 like_pipeline_min_entries=-1 if args.no_like_pipeline else None).build())
+                                 like_pipeline_min_entries=-1 if args.no_like_pipeline else None,
+                                 like_path=args.like_path or None).build())
     n_batches = (args.rows + args.batch_size - 1) // args.batch_size
     threads = max(1, min(32, (os.cpu_count() or 8) // max(1, min(world, 8))))
 
@@ -1122,8 +1125,8 @@ def main():
             "roofline": roofline(kernel, kernel_ms, alg_bytes, own_bytes, cold_ms, traffic, traffic_src),
         }
         out["config"]["evaluation_path"] = scan.explain(expr)
-        if "like_pipeline" in out["config"]["evaluation_path"]:
-            out["roofline"]["kernel"] = "k_like_probe + k_like_walk"
+        if out["config"]["evaluation_path"].startswith("k_like_"):
+            out["roofline"]["kernel"] = out["config"]["evaluation_path"].split(":")[0].split(" (")[0]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_sample = args.cpu_batches or n_batches  # ~4 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
         if args.workload == "url_like":
@@ -1164,7 +1167,7 @@ def main():
                         worst = "%s %s: gpu %d cpu %d, %d entries differ" % (op, pat, int(g_counts.sum()), cpu_total,
                                                                              int((g_counts != cpu_counts).sum()))
                     lab = labels.get((op, pat))
-                    if lab and not args.no_secondary:
+                    if lab and not args.no_needle_classes:
                         it = max(3, iters // 4)
                         hot = scan.eval_timed(e2, mask.data_ptr(), it, 0, counts.data_ptr(), stream)
                         cold = None if args.no_cold else scan.eval_timed_cold(e2, mask.data_ptr(), 3, FLUSH_BYTES, 0,

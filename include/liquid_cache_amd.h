@@ -165,6 +165,8 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
 #define LC_OPT_ROW_LISTS 2
 #define LC_OPT_HOST_BUILT_INDEX 3
 #define LC_OPT_LIKE_PIPELINE_MIN_ENTRIES 4
+#define LC_OPT_LIKE_PATH 5 /* tuning / A-B aid: 0 automatic (default), 1 k_str_pred only, 2 the two-kernel pipeline, 3 the
+                            * lean kernel for every needle.  Results are identical under every value. */
 LC_API lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value);
 LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
 LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);

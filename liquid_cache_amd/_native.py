@@ -17,7 +17,7 @@ LC_ERR_INVALID, LC_ERR_CORRUPT, LC_ERR_DEVICE, LC_ERR_OOM, LC_ERR_NO_SYMTAB = -1
 OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE, OP_LIKE, OP_NOT_LIKE = range(8)
 LIT_I64, LIT_U64, LIT_F32, LIT_F64, LIT_BYTES, LIT_I128, LIT_BOOL = range(7)
 HINT_NONE, HINT_SUBSTRING_SEARCH, HINT_PREDICATE_COLUMN = 0, 1, 2
-OPT_SIGNATURE_INDEX, OPT_ROW_LISTS, OPT_HOST_BUILT_INDEX, OPT_LIKE_PIPELINE_MIN_ENTRIES = 1, 2, 3, 4
+OPT_SIGNATURE_INDEX, OPT_ROW_LISTS, OPT_HOST_BUILT_INDEX, OPT_LIKE_PIPELINE_MIN_ENTRIES, OPT_LIKE_PATH = 1, 2, 3, 4, 5
 
 
 class LiquidCacheError(RuntimeError):
@@ -81,7 +81,7 @@ BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_
 
 _lib = None
 _bench = None
-BENCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libliquid_cache_amd_bench.so")
+BENCH_LIB_PATH = os.path.join(_HERE, "libliquid_cache_amd_bench.so")
 
 
 def load_bench():

@@ -224,8 +224,8 @@ class LiquidCacheBuilder:
         return self
 
     def with_index_options(self, signatures: Optional[bool] = None, row_lists: Optional[bool] = None,
-                           host_built: Optional[bool] = None, like_pipeline_min_entries: Optional[int] = None
-                           ) -> "LiquidCacheBuilder":
+                           host_built: Optional[bool] = None, like_pipeline_min_entries: Optional[int] = None,
+                           like_path: Optional[int] = None) -> "LiquidCacheBuilder":
         """The device-side acceleration structures of substring-search byte views (include/liquid_cache_amd.h,
         lc_ctx_set_option): bigram signature index, inverted row lists, host-built index.  Results never depend on them."""
         if signatures is not None:
@@ -236,6 +236,8 @@ class LiquidCacheBuilder:
             self.options[N.OPT_HOST_BUILT_INDEX] = int(bool(host_built))
         if like_pipeline_min_entries is not None:
             self.options[N.OPT_LIKE_PIPELINE_MIN_ENTRIES] = int(like_pipeline_min_entries)
+        if like_path is not None:
+            self.options[N.OPT_LIKE_PATH] = int(like_path)
         return self
 
     def build(self) -> "LiquidCache":

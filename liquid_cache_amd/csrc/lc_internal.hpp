@@ -107,6 +107,7 @@ struct lc_ctx {
     std::vector<std::unique_ptr<lc::SymbolTable>> symtabs;
     bool build_signatures = true;  // LC_OPT_SIGNATURE_INDEX = 0 disables the bigram index (plain reference layout only)
     bool signatures_on_host = false;  // LC_OPT_HOST_BUILT_INDEX = 1: build the index on the host (the device builder's oracle)
+    int like_path = 0;  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred only, 2 two-kernel pipeline, 3 lean kernel for every needle
     uint32_t like_pipeline_min_entries = 32;  // LC_OPT_LIKE_PIPELINE_MIN_ENTRIES: scans below it evaluate LIKE with k_str_pred
     bool build_postings = true;       // LC_OPT_ROW_LISTS = 0: no inverted row lists (rows always mapped through the keys)
     lc::DevSymtab* d_symtabs = nullptr;

@@ -64,6 +64,38 @@ struct LikeChunk {
                             // a single value is longer) at most 64 eight-byte words = ONE pass of the lane-parallel walk
 };
 
+// ---- the lean one-kernel form (k_like_lean): what a workgroup of four waves needs for its (at most four) entries of ONE
+// symbol table, fetched with scalar loads from an address that follows from blockIdx alone
+struct alignas(16) LeanEntry {
+    const uint64_t* sig;
+    const uint8_t* residuals;
+    const uint8_t* fsst;
+    const uint16_t* postings;
+    uint64_t mask_word_off;
+    int32_t slope, intercept;
+    uint32_t d, n;
+    uint32_t offset_bytes, nw;
+};
+static_assert(sizeof(LeanEntry) == 64, "LeanEntry layout");
+struct alignas(16) LeanRec {
+    uint32_t begin, end;  // entries [begin, end) of the scan, end - begin <= 4: wave w takes entry begin + w
+    uint32_t slot;        // their symbol table
+    uint32_t pad;
+    LeanEntry e[4];
+};
+static_assert(sizeof(LeanRec) == 272, "LeanRec layout");
+constexpr uint32_t kLeanCap = 512;  // candidate keys a wave lists in LDS before it walks them
+#ifndef LC_LEAN_WAVES
+#define LC_LEAN_WAVES 4
+#endif
+constexpr uint32_t kLeanWaves = LC_LEAN_WAVES;  // waves (= entries) per workgroup of k_like_lean: they share the LDS automaton
+static_assert(kLeanWaves >= 1 && kLeanWaves <= 4, "a LeanRec holds four entries");
+// -DLC_LEAN_STOP=n (variant builds only, results are WRONG): leave the kernel after phase n — 1 probe, 2 offset pairs,
+// 3 compressed words — to measure where the time goes
+#ifndef LC_LEAN_STOP
+#define LC_LEAN_STOP 0
+#endif
+
 constexpr uint32_t kProbeThreads = 256;
 constexpr uint32_t kProbeRound = 128;                    // candidates a probe wave redistributes through LDS at a time
 constexpr uint32_t kWalkWaves = 4;                       // waves (= chunks) per workgroup of the walk; they share the LDS automaton
@@ -94,6 +126,8 @@ struct LikePipeline {
     uint32_t n_k1_waves = 0;
     FlatRec* d_flat = nullptr;
     LikeEntryRef* d_refs = nullptr;
+    LeanRec* d_lean = nullptr;   // one record per workgroup of k_like_lean
+    uint32_t n_lean = 0;
     unsigned long long* d_total_acc = nullptr;
     std::vector<LikePlan> plans;
     uint64_t tick = 0;
@@ -364,6 +398,241 @@ __global__ __launch_bounds__(kWalkWaves * 64) void k_like_walk(WalkArgs a) {
         total_contribute(a.total, blockIdx.x * kWalkWaves + wave, gridDim.x * kWalkWaves, wave_hits);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// k_like_lean: the same evaluation in ONE kernel, one wave per entry — k_str_pred's kSigOnly variant reduced to what a
+// selective LIKE over indexed entries needs (~350 instructions per entry instead of ~1,300: k_str_pred is bound by
+// instruction issue, 12,207 waves x 1,300 instructions x 4 cycles / 1,024 SIMDs = 26 us at 2.4 GHz).  No plan, no host
+// round trip; correct for every needle (candidates beyond the LDS list are walked in further rounds), fastest for
+// selective ones.  Chain of a wave: record (scalar) -> signature slices -> offset pairs -> compressed words -> walk ->
+// list bounds -> rows -> mask words.
+struct LeanArgs {
+    const LeanRec* recs;
+    const uint8_t* automata;
+    uint32_t automaton_stride;
+    uint32_t nl;
+    uint16_t sig_bits[kMaxSigProbe];
+    const uint64_t* selection;
+    uint64_t* mask;
+    uint32_t* counts;
+    ScanLaunch total;  // d_total_acc / d_total_out only
+};
+using ConstLeanPtr = const __attribute__((address_space(4))) LeanEntry*;
+
+template <int N>
+__global__ __launch_bounds__(kLeanWaves * 64, 32 / kLeanWaves) void k_like_lean(LeanArgs a) {
+    // dynamic LDS: [automaton image][per wave: 128 mask words | kLeanCap u16 candidate keys | 64 hit flags + head mask]
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t kPerWave = kPostMaxRows / 8u + kLeanCap * 2u + 80u;
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t nl = a.nl;
+    const uint32_t tbl_bytes = automaton_image_bytes(nl);
+    const LeanRec* rec = a.recs + blockIdx.x;
+    const uint32_t begin = rec->begin, end = rec->end;
+    {
+        const uint8_t* src = a.automata + size_t(rec->slot) * a.automaton_stride + automaton_u8_bytes(nl);
+        for (uint32_t c = wave * 1024u; c < tbl_bytes; c += kLeanWaves * 1024u) async_copy16(src + c + uint32_t(lane) * 16u, smem + c);
+    }
+    const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
+    if (row0 != 0u) __builtin_trap();  // the image holds absolute LDS addresses computed for address 0
+    const uint32_t hitrow = row0 + nl * 512u;
+    uint8_t* wbase = smem + tbl_bytes + wave * kPerWave;
+    uint64_t* pmask = reinterpret_cast<uint64_t*>(wbase);
+    uint16_t* list = reinterpret_cast<uint16_t*>(wbase + kPostMaxRows / 8u);
+    uint8_t* hitflag = wbase + kPostMaxRows / 8u + kLeanCap * 2u;
+    uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
+    const uint32_t entry = begin + wave;
+    uint64_t wave_hits = 0;
+    if (entry >= end) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (a.total.d_total_out && lane == 0) total_contribute(a.total, blockIdx.x * kLeanWaves + wave, gridDim.x * kLeanWaves, 0);
+        return;
+    }
+    ConstLeanPtr E = reinterpret_cast<ConstLeanPtr>(reinterpret_cast<uintptr_t>(&rec->e[wave]));
+    const uint32_t nw = E->nw, n_rows = E->n;
+    const uint32_t nwords = (n_rows + 63u) >> 6;
+    // mask words of the entry start clear in LDS (16 bytes per lane = 1 KB)
+    reinterpret_cast<uint4*>(pmask)[lane] = make_uint4(0, 0, 0, 0);
+    bool synced = false;
+    uint32_t n_list = 0;
+
+    // walk candidates list[0 .. count): 64 per batch, one lane per 8-byte word; rows of the matches go into pmask
+    auto walk_list = [&](uint32_t count) {
+        for (uint32_t b0 = 0; b0 < count; b0 += kWave) {
+            const uint32_t j = b0 + uint32_t(lane);
+            const bool cl = j < count;
+            const uint32_t key = cl ? uint32_t(list[j]) : 0u;
+            uint32_t start = 0, len = 0;
+            if (cl) {
+                const uint32_t ob = E->offset_bytes;
+                const uint64_t v = load_unaligned<uint64_t>(E->residuals + size_t(key) * ob);
+                const uint32_t sh = 32u - 8u * ob;
+                const int32_t q0 = int32_t(uint32_t(v) << sh) >> sh;
+                const int32_t q1 = int32_t(uint32_t(v >> (8u * ob)) << sh) >> sh;
+                start = uint32_t(E->slope) * key + uint32_t(E->intercept) + uint32_t(q0);
+                len = uint32_t(E->slope) * (key + 1u) + uint32_t(E->intercept) + uint32_t(q1) - start;
+            }
+            const uint32_t words = cl ? max(1u, (len + 7u) >> 3) : 0u;
+            const uint32_t incl = wave_inclusive_sum(words);
+            const uint32_t off = incl - words;
+            const uint32_t total = read_lane(incl, kWave - 1);
+            hitflag[lane] = 0;
+            if (LC_LEAN_STOP == 2) { if (total == 0x7FFFFFFFu) list[0] = 1; continue; }
+            uint32_t carry_state = row0;
+            for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
+                if (lane == 0) *headmask = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const bool head = cl && off >= t0 && off < t0 + kWave;
+                if (head) atomicOr(reinterpret_cast<unsigned long long*>(headmask), 1ull << (off - t0));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint64_t hm = *headmask;
+                const uint32_t before = uint32_t(__popcll(__ballot(cl && off < t0)));
+                const uint64_t upto = lane == 63 ? ~uint64_t(0) : ((uint64_t(2) << lane) - 1);
+                const uint32_t r = before + uint32_t(__popcll(hm & upto)) - 1u;  // owner lane of task t0 + lane
+                const bool live = t0 + uint32_t(lane) < total;
+                const uint32_t o_off = uint32_t(__shfl(int(off), int(r), kWave));
+                const uint32_t o_start = uint32_t(__shfl(int(start), int(r), kWave));
+                const uint32_t o_len = uint32_t(__shfl(int(len), int(r), kWave));
+                const uint32_t k = t0 + uint32_t(lane) - o_off;
+                const uint32_t p = 8u * k;
+                const uint32_t rem = live && p < o_len ? o_len - p : 0u;
+                uint64_t wd = 0;
+                if (rem) wd = load_unaligned<uint64_t>(E->fsst + o_start + p);
+                if (LC_LEAN_STOP == 3) { if (wd == 0x123456789ull) list[0] = 1; continue; }
+                const bool first = k == 0;
+                auto walk_task = [&](uint32_t st) {
+                    uint32_t x[8];
+                    const uint32_t lo = uint32_t(wd), hi = uint32_t(wd >> 32);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) x[q] = (((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu) << 1;
+                    return walk8(st, x, rem);
+                };
+                if (!synced) {  // the LDS automaton: every wave of the workgroup passes this barrier exactly once
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    synced = true;
+                }
+                uint32_t s_in = row0;
+                uint32_t en = walk_task(s_in);
+                for (;;) {
+                    uint32_t prev = lane_shift_up1(en, carry_state);
+                    if (first || prev == hitrow) prev = row0;
+                    const bool changed = prev != s_in;
+                    if (__ballot(changed) == 0) break;
+                    if (changed) {
+                        s_in = prev;
+                        en = walk_task(s_in);
+                    }
+                }
+                const bool hit = en == hitrow;  // a match counts only at the fixpoint (see k_str_pred)
+                carry_state = read_lane(en, kWave - 1);
+                if (carry_state == hitrow) carry_state = row0;
+                if (hit && live) hitflag[r] = 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool res = cl && hitflag[lane] != 0;
+            uint64_t matched = __ballot(res);
+            if (matched) {
+                // rows of the matching dictionary values from the entry's inverted row lists, into the LDS mask words
+                uint32_t o0 = 0, o1 = 0;
+                if (res) {
+                    const uint32_t v = load_unaligned<uint32_t>(reinterpret_cast<const uint8_t*>(E->postings) + 2u * size_t(key));
+                    o0 = v & 0xFFFFu;
+                    o1 = v >> 16;
+                }
+                const uint16_t* prow = E->postings + E->d + 1u;
+                while (matched) {
+                    const int ml = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)matched)) - 1);
+                    matched &= matched - 1;
+                    const uint32_t b = read_lane(o0, ml), e1 = read_lane(o1, ml);
+                    for (uint32_t rr = b + uint32_t(lane); rr < e1; rr += kWave) {
+                        const uint32_t row = as_global(prow)[rr];
+                        atomicOr(reinterpret_cast<unsigned long long*>(&pmask[row >> 6]), 1ull << (row & 63u));
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    };
+
+    // ---- probe: AND of the needle's signature slices, 64 words (4,096 dictionary values) per round
+    for (uint32_t w0 = 0; w0 < nw; w0 += kWave) {
+        const uint32_t w = w0 + uint32_t(lane);
+        uint64_t m = 0;
+        if (w < nw) {
+            uint64_t sv[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) sv[k] = as_global(E->sig)[size_t(a.sig_bits[k]) * nw + w];
+            m = sv[0];
+#pragma unroll
+            for (int k = 1; k < N; k++) m &= sv[k];
+        }
+        const uint32_t cnt = uint32_t(__popcll(m));
+        const uint32_t incl = wave_inclusive_sum(cnt);
+        const uint32_t tot = read_lane(incl, kWave - 1);
+        if (tot > kLeanCap) {
+            // a round with more candidates than the list holds (the needle is not selective here): the lanes' words are
+            // taken one after the other, each word's values (<= 64) as one batch
+            walk_list(n_list);
+            n_list = 0;
+            for (int sl = 0; sl < kWave; sl++) {
+                const uint64_t ms = uniform_u64(uint64_t(uint32_t(__shfl(int(uint32_t(m)), sl, kWave))) |
+                                                (uint64_t(uint32_t(__shfl(int(uint32_t(m >> 32)), sl, kWave))) << 32));
+                if (ms == 0) continue;
+                if ((ms >> lane) & 1u) list[lanes_below(ms)] = uint16_t((w0 + uint32_t(sl)) * 64u + uint32_t(lane));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                walk_list(uint32_t(__popcll(ms)));
+            }
+            continue;
+        }
+        if (n_list + tot > kLeanCap) {
+            walk_list(n_list);
+            n_list = 0;
+        }
+        uint32_t o = n_list + incl - cnt;
+        while (m) {
+            const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+            m &= m - 1;
+            list[o++] = uint16_t(w * 64u + bit);
+        }
+        n_list += tot;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if (LC_LEAN_STOP == 1) n_list = n_list == 0x7FFFFFFFu ? 1u : 0u;
+    walk_list(n_list);
+    if (!synced) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    // ---- the entry's mask words: rows of the lists are valid rows, the selection is applied here
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint64_t moff = E->mask_word_off;
+    uint32_t c = 0;
+    for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
+        uint64_t hitw = pmask[w];
+        if (a.selection && hitw) hitw &= as_global(a.selection)[moff + w];
+        as_global_mut(a.mask)[moff + w] = hitw;
+        c += uint32_t(__popcll(hitw));
+    }
+    if (a.counts || a.total.d_total_out) {
+        const uint32_t ct = read_lane(wave_inclusive_sum(c), kWave - 1);
+        if (lane == 0 && a.counts) as_global_mut(a.counts)[entry] = ct;
+        wave_hits = ct;
+    }
+    if (a.total.d_total_out && lane == 0) total_contribute(a.total, blockIdx.x * kLeanWaves + wave, gridDim.x * kLeanWaves, wave_hits);
+}
+
+hipError_t launch_lean(int n_sig, const LeanArgs& a, uint32_t n_recs, hipStream_t stream) {
+    if (n_recs == 0) return hipSuccess;
+    typedef void (*Kern)(LeanArgs);
+    static const Kern table[kMaxSigProbe] = {k_like_lean<1>, k_like_lean<2>, k_like_lean<3>, k_like_lean<4>,
+                                             k_like_lean<5>, k_like_lean<6>, k_like_lean<7>, k_like_lean<8>};
+    const size_t lds = automaton_image_bytes(a.nl) + kLeanWaves * (kPostMaxRows / 8u + kLeanCap * 2u + 80u);
+    hipLaunchKernelGGL(table[n_sig - 1], dim3(n_recs), dim3(kLeanWaves * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
 template <bool kCount>
 hipError_t launch_probe(int n_sig, const ProbeArgs& a, hipStream_t stream) {
     uint32_t grid = (a.n_flat + kProbeThreads - 1) / kProbeThreads;
@@ -426,6 +695,28 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
     while (flat.size() % 64) flat.push_back(pad);
     lp->n_flat = uint32_t(flat.size());
     lp->n_k1_waves = lp->n_flat / 64;
+    // k_like_lean: one record per workgroup — consecutive entries, at most four, never across a symbol-table change
+    std::vector<LeanRec> lean;
+    for (uint32_t b = 0, i = 1; i <= s->n; i++) {
+        if (i == s->n || i - b == kLeanWaves || s->meta[i].sd.symtab_slot != s->meta[b].sd.symtab_slot) {
+            LeanRec r;
+            std::memset(&r, 0, sizeof(r));
+            r.begin = b;
+            r.end = i;
+            r.slot = s->meta[b].sd.symtab_slot;
+            for (uint32_t k = b; k < i; k++) {
+                const StrDesc& d = s->meta[k].sd;
+                r.e[k - b] = LeanEntry{d.signatures, d.residuals, d.fsst, d.postings, d.mask_word_off, d.slope, d.intercept,
+                                       d.d, d.n, d.offset_bytes, (d.d + 63u) / 64u};
+            }
+            lean.push_back(r);
+            b = i;
+        }
+    }
+    lp->n_lean = uint32_t(lean.size());
+    lp->d_lean = static_cast<LeanRec*>(pool_alloc(ctx, std::max<size_t>(lean.size(), 1) * sizeof(LeanRec)));
+    if (!lp->d_lean) return fail(LC_ERR_OOM, "hipMalloc (LIKE pipeline index)");
+    LC_HIP(hipMemcpyAsync(lp->d_lean, lean.data(), lean.size() * sizeof(LeanRec), hipMemcpyHostToDevice, stream));
     lp->d_flat = static_cast<FlatRec*>(pool_alloc(ctx, std::max<size_t>(flat.size(), 1) * sizeof(FlatRec)));
     lp->d_refs = static_cast<LikeEntryRef*>(pool_alloc(ctx, size_t(s->n) * sizeof(LikeEntryRef)));
     lp->d_total_acc = static_cast<unsigned long long*>(pool_alloc(ctx, size_t(kTotalWords) * 8));
@@ -481,6 +772,22 @@ lc_status run(lc_scan* s, LikePipeline* lp, const LikePlan& plan, const StrPred&
     wa.total.d_total_acc = lp->d_total_acc;
     wa.total.d_total_out = L.d_total_out;
     LC_HIP(launch_walk(wa, plan.n_wgs, stream));
+    return LC_OK;
+}
+
+lc_status run_lean(LikePipeline* lp, const StrPred& p, const ScanLaunch& L, hipStream_t stream) {
+    LeanArgs la{};
+    la.recs = lp->d_lean;
+    la.automata = p.automata;
+    la.automaton_stride = p.automaton_stride;
+    la.nl = p.needle_len;
+    for (int k = 0; k < kMaxSigProbe; k++) la.sig_bits[k] = p.sig_bits[k];
+    la.selection = L.d_selection;
+    la.mask = L.d_hit;
+    la.counts = L.d_counts;
+    la.total.d_total_acc = lp->d_total_acc;
+    la.total.d_total_out = L.d_total_out;
+    LC_HIP(launch_lean(int(p.n_sig_bits), la, lp->n_lean, stream));
     return LC_OK;
 }
 
@@ -594,6 +901,7 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     for (LikePlan& p : lp->plans) free_plan(ctx, p);
     pool_release(ctx, lp->d_flat);
     pool_release(ctx, lp->d_refs);
+    pool_release(ctx, lp->d_lean);
     pool_release(ctx, lp->d_total_acc);
     delete lp;
 }
@@ -601,14 +909,20 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
 // One line on how `LIKE '%needle%'` was / would be evaluated on this scan (lc_scan_explain).  Caller holds s->mu.
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
     const LikePipeline* lp = s->like;
-    if (!lp || !lp->built) return "k_str_pred (no pipeline index on this scan yet)";
+    const int path = s->ctx->like_path;
+    if (path == 1 || s->n < s->ctx->like_pipeline_min_entries) return "k_str_pred";
+    if (!lp || !lp->built) return "k_str_pred (no scan-level index on this scan yet)";
     if (!lp->eligible) return "k_str_pred (entries without signature index / row lists)";
+    if (path == 3) return "k_like_lean (forced for every needle)";
     for (const LikePlan& q : lp->plans)
         if (q.needle == sp.needle) {
             char buf[256];
-            if (q.use_pipeline)
-                std::snprintf(buf, sizeof(buf), "like_pipeline: k_like_probe + k_like_walk, %u candidates in %u chunks, %llu hit rows, %u flat words",
+            if (q.use_pipeline && path == 2)
+                std::snprintf(buf, sizeof(buf), "k_like_probe + k_like_walk: %u candidates in %u chunks, %llu hit rows, %u flat words",
                               q.n_cand, q.n_chunks, (unsigned long long)q.hits, lp->n_flat);
+            else if (q.use_pipeline)
+                std::snprintf(buf, sizeof(buf), "k_like_lean: %u candidates at plan time (%.1f per entry), %llu hit rows", q.n_cand,
+                              double(q.n_cand) / double(std::max<uint32_t>(s->n, 1)), (unsigned long long)q.hits);
             else
                 std::snprintf(buf, sizeof(buf), "k_str_pred (needle not selective: %u+ candidates, %llu hit rows at plan time)", q.n_cand,
                               (unsigned long long)q.hits);
@@ -651,7 +965,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     if (p.mode != 1 || p.op != LC_OP_LIKE || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
         automaton_image_bytes(p.needle_len) == 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
         return LC_OK;
-    if (s->n < ctx->like_pipeline_min_entries) return LC_OK;  // small scans are launch bound either way: one kernel
+    if (s->n < ctx->like_pipeline_min_entries || ctx->like_path == 1) return LC_OK;
     if (!s->like) s->like = new LikePipeline();
     LikePipeline* lp = s->like;
     if (!lp->built) {
@@ -659,6 +973,11 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         if (st != LC_OK) return st;
     }
     if (!lp->eligible) return LC_OK;
+    if (ctx->like_path == 3) {  // forced: the lean kernel for every needle (it is correct for all of them)
+        const lc_status st = run_lean(lp, p, L, stream);
+        if (st == LC_OK) *handled = true;
+        return st;
+    }
     LikePlan* plan = nullptr;
     for (LikePlan& q : lp->plans)
         if (q.needle == sp.needle) plan = &q;
@@ -680,7 +999,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     }
     plan->last_use = ++lp->tick;
     if (!plan->use_pipeline) return LC_OK;
-    const lc_status st = run(s, lp, *plan, p, L, stream);
+    const lc_status st = ctx->like_path == 2 ? run(s, lp, *plan, p, L, stream) : run_lean(lp, p, L, stream);
     if (st == LC_OK) *handled = true;
     return st;
 }

@@ -686,6 +686,10 @@ lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
         case LC_OPT_SIGNATURE_INDEX: ctx->build_signatures = value != 0; return LC_OK;
         case LC_OPT_ROW_LISTS: ctx->build_postings = value != 0; return LC_OK;
         case LC_OPT_HOST_BUILT_INDEX: ctx->signatures_on_host = value != 0; return LC_OK;
+        case LC_OPT_LIKE_PATH:
+            if (value < 0 || value > 3) return fail(LC_ERR_INVALID, "LC_OPT_LIKE_PATH takes 0..3");
+            ctx->like_path = int(value);
+            return LC_OK;
         case LC_OPT_LIKE_PIPELINE_MIN_ENTRIES:
             ctx->like_pipeline_min_entries = value < 0 ? 0xFFFFFFFFu : uint32_t(std::min<int64_t>(value, 0xFFFFFFFFll));
             return LC_OK;
