@@ -78,7 +78,7 @@ def parse_args(argv=None):
     p.add_argument("--no-like-pipeline", action="store_true",
                    help="url_like: evaluate LIKE with the one-wave-per-entry kernel only (A/B of the scan-level pipeline)")
     p.add_argument("--no-needle-classes", action="store_true", help="skip the timing of the LIKE needle classes")
-    p.add_argument("--like-path", type=int, default=0, help="LC_OPT_LIKE_PATH (A/B aid): 0 auto, 1 k_str_pred, 2 two-kernel, 3 lean")
+    p.add_argument("--like-path", type=int, default=0, help="LC_OPT_LIKE_PATH (A/B aid): 0 auto, 1 k_str_pred, 3 k_like_lean for every needle")
     p.add_argument("--rotate", type=int, default=0,
                    help="columns the timed loop rotates through (one per step, all resident in HBM) so that a step never "
                         "finds its data in the 256 MiB Infinity Cache; 0 = as many as make the cycle move >= 768 MB (1..8)")

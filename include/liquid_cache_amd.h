@@ -157,16 +157,17 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
  *   LC_OPT_ROW_LISTS        (default 1) such entries also get inverted row lists (+ ~12 %)
  *   LC_OPT_HOST_BUILT_INDEX (default 0) 1 = the signature index is built by the host while staging instead of by the
  *                           device kernel (bit-identical; kept as the device builder's cross-check)
- * Evaluation option (may be changed at any time):
- *   LC_OPT_LIKE_PIPELINE_MIN_ENTRIES (default 32) scans of at least this many entries evaluate a selective
- *                           LIKE '%needle%' with the scan-level pipeline (probe + walk, planned once per scan and needle)
- *                           instead of the one-wave-per-entry kernel; negative = never */
+ * Evaluation options (may be changed at any time):
+ *   LC_OPT_LIKE_PIPELINE_MIN_ENTRIES (default 32) on scans of at least this many entries a LIKE '%needle%' is PLANNED once
+ *                           per scan and needle (one trial evaluation counts the hit rows; the one host round trip) and
+ *                           selective needles then run the lean kernel (k_like_lean) instead of the general one
+ *                           (k_str_pred); negative = never
+ *   LC_OPT_LIKE_PATH        tuning / A-B aid: 0 automatic (default), 1 k_str_pred only, 3 k_like_lean for every needle */
 #define LC_OPT_SIGNATURE_INDEX 1
 #define LC_OPT_ROW_LISTS 2
 #define LC_OPT_HOST_BUILT_INDEX 3
 #define LC_OPT_LIKE_PIPELINE_MIN_ENTRIES 4
-#define LC_OPT_LIKE_PATH 5 /* tuning / A-B aid: 0 automatic (default), 1 k_str_pred only, 2 the two-kernel pipeline, 3 the
-                            * lean kernel for every needle.  Results are identical under every value. */
+#define LC_OPT_LIKE_PATH 5
 LC_API lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value);
 LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
 LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);

@@ -88,7 +88,7 @@ struct Entry {
     uint64_t raw_bytes = 0;      // byte views: uncompressed size of the dictionary (RawFsstBuffer header)
 };
 
-struct LikePipeline;  // lc_like_pipeline.hip: scan-level index + scratch of the selective-LIKE pipeline
+struct LikePipeline;  // lc_like_pipeline.hip: workgroup records + cached plans of k_like_lean
 
 }  // namespace lc
 
@@ -107,8 +107,8 @@ struct lc_ctx {
     std::vector<std::unique_ptr<lc::SymbolTable>> symtabs;
     bool build_signatures = true;  // LC_OPT_SIGNATURE_INDEX = 0 disables the bigram index (plain reference layout only)
     bool signatures_on_host = false;  // LC_OPT_HOST_BUILT_INDEX = 1: build the index on the host (the device builder's oracle)
-    int like_path = 0;  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred only, 2 two-kernel pipeline, 3 lean kernel for every needle
-    uint32_t like_pipeline_min_entries = 32;  // LC_OPT_LIKE_PIPELINE_MIN_ENTRIES: scans below it evaluate LIKE with k_str_pred
+    int like_path = 0;  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred only, 3 k_like_lean for every needle
+    uint32_t like_pipeline_min_entries = 32;  // LC_OPT_LIKE_PIPELINE_MIN_ENTRIES: smaller scans are not planned (k_str_pred)
     bool build_postings = true;       // LC_OPT_ROW_LISTS = 0: no inverted row lists (rows always mapped through the keys)
     lc::DevSymtab* d_symtabs = nullptr;
     size_t d_symtabs_cap = 0;
@@ -168,7 +168,7 @@ struct lc_scan {
     uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
     size_t or_tmp_words = 0;
     unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
-    lc::LikePipeline* like = nullptr;  // scan-level index + plans of the selective-LIKE pipeline (lc_like_pipeline.hip)
+    lc::LikePipeline* like = nullptr;  // workgroup records + plans of k_like_lean (lc_like_pipeline.hip)
     bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
     // The scan's scratch (automata, work counters, COUNT(*) accumulator, OR / aggregate temporaries) is used by
     // asynchronous launches after `mu` is released.  Calls on one scan are ordered on one stream; when a call arrives on

@@ -35,7 +35,6 @@ VARIANTS = {"default": {}, "no_signatures": dict(signatures=False), "no_row_list
             "host_built_index": dict(host_built=True),
             # selective LIKE through the scan-level pipeline even for the smallest scans / never
             "pipeline_always": dict(like_pipeline_min_entries=1), "pipeline_never": dict(like_pipeline_min_entries=-1),
-            "two_kernel": dict(like_pipeline_min_entries=1, like_path=2),
             "lean_every_needle": dict(like_pipeline_min_entries=1, like_path=3)}
 
 
@@ -162,7 +161,7 @@ def fuzz_cases(oracle):
     return cases
 
 
-@pytest.mark.parametrize("variant", ["default", "pipeline_never", "two_kernel", "lean_every_needle", "no_signatures",
+@pytest.mark.parametrize("variant", ["default", "pipeline_never", "lean_every_needle", "no_signatures",
                                      "no_row_lists"])
 def test_fuzz_like_over_many_symbol_tables(product_lib, oracle, fuzz_cases, variant):
     """One scan over 60 entries with 60 different symbol tables (every workgroup record, every K2 chunk of the scan-level
