@@ -24,7 +24,7 @@
 namespace lc {
 
 constexpr int kMaxNeedleAutomaton = 63;  // KMP automaton states must fit a u8 table
-constexpr uint32_t kMaxLdsNeedle = 31;   // needles up to this length also get an LDS image of the automaton (32 KB at 31:
+constexpr uint32_t kMaxLdsNeedle = 47;   // needles up to this length also get an LDS image of the automaton (48 KB at 47:
                                          // u16 row addresses reach 64 KB)
 // Per symbol table, k_str_automata emits: the u8 next-state table ((m+1) x 512 bytes) and, for short needles, the
 // image the scan kernel copies verbatim to LDS address 0: 2 (m+1) rows x 256 u16 entries holding the LDS byte address
@@ -113,7 +113,9 @@ static_assert(sizeof(StrWgRecord) == 464, "StrWgRecord layout");
 #define LC_SIG_BITS 128
 #endif
 constexpr int kSigBits = LC_SIG_BITS;
-constexpr int kMaxSigProbe = 8;
+constexpr int kMaxSigProbe = 8;      // slices k_str_pred ANDs (always this many: short needles repeat theirs)
+constexpr int kMaxSigProbeWide = 16; // slices k_like_lean ANDs at most (long needles: every further bigram is another factor
+                                     // fewer candidates to walk, and a slice is a few hundred bytes per entry)
 __host__ __device__ inline uint32_t bigram_bit(uint32_t a, uint32_t b) {
     return ((((a << 8) | b) * 40503u) >> 7) & uint32_t(kSigBits - 1);
 }
@@ -193,6 +195,12 @@ struct StrPred {
     uint32_t needle_fp;        // LIKE: 32-bucket fingerprint of the needle (fingerprint.rs:33-35)
     uint32_t n_sig_bits;       // LIKE: distinct bigram-signature bits of the needle that are probed (<= kMaxSigProbe)
     uint16_t sig_bits[kMaxSigProbe];
+    // the same list continued (k_like_lean): n_sig_wide >= n_sig_bits distinct bits, the first n_sig_bits are sig_bits.
+    // The bigrams are taken in an order that spreads them over the whole needle (ends first, then midpoints), so that
+    // whatever prefix of the list a kernel uses covers the needle evenly ('%yandex.ru/search%': its first 8 bigrams only
+    // say "yandex.ru", which 45 % of the values of a URL column contain).
+    uint32_t n_sig_wide;
+    uint16_t sig_wide[kMaxSigProbeWide];
     uint8_t needle_inline[kInlineNeedle];
 };
 

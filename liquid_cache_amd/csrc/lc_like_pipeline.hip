@@ -37,8 +37,10 @@ struct alignas(16) LeanEntry {
     int32_t slope, intercept;
     uint32_t d, n;
     uint32_t offset_bytes, nw;
+    const uint64_t* validity;      // NOT LIKE only (LIKE hits come from the row lists, which hold valid rows)
+    const uint32_t* fingerprints;  // NOT LIKE only: the reference's candidate rule (comparisons.rs:167-180)
 };
-static_assert(sizeof(LeanEntry) == 64, "LeanEntry layout");
+static_assert(sizeof(LeanEntry) == 80, "LeanEntry layout");
 #ifndef LC_LEAN_E
 #define LC_LEAN_E 1
 #endif
@@ -54,7 +56,7 @@ struct alignas(16) LeanRec {
     uint32_t pad;
     LeanEntry e[8 + 1];   // (+ 1: the second-entry pointer of the last wave stays inside the record)
 };
-static_assert(sizeof(LeanRec) == 16 + 9 * 64, "LeanRec layout");
+static_assert(sizeof(LeanRec) == 16 + 9 * 80, "LeanRec layout");
 constexpr uint32_t kLeanCap = 512;  // candidate keys a wave lists in LDS before it walks them
 #ifndef LC_LEAN_WAVES
 #define LC_LEAN_WAVES 4
@@ -94,7 +96,9 @@ struct LeanArgs {
     const uint8_t* automata;
     uint32_t automaton_stride;
     uint32_t nl;
-    uint16_t sig_bits[kMaxSigProbe];
+    uint32_t n_extra;                       // signature bits beyond the N the kernel is instantiated for
+    uint32_t needle_fp;                     // NOT LIKE: 32-bucket fingerprint of the needle (fingerprint.rs:33-35)
+    uint16_t sig_bits[kMaxSigProbeWide];
     const uint64_t* selection;
     uint64_t* mask;
     uint32_t* counts;
@@ -109,7 +113,11 @@ __device__ __forceinline__ T pick(bool second, T a, T b) {
     return kLeanE == 2 && second ? b : a;
 }
 
-template <int N>
+// kNot: NOT LIKE.  The reference inverts the dictionary results only when at least one dictionary value passes the 32-bucket
+// fingerprint filter of the needle (comparisons.rs:167-180, :644-648) — an entry without such a value answers all false.
+// A value that matches passes the filter, so the fingerprints are only consulted for entries without a match, and there the
+// first 64 values almost always hold a candidate (one 256-byte load, requested together with the signature slices).
+template <int N, bool kNot>
 __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(LeanArgs a) {
     // dynamic LDS: [automaton image][per wave: kLeanE x 128 mask words | kLeanCap candidates (slot << 16 | key) |
     //                                          64 hit flags + head mask]
@@ -163,6 +171,16 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
     for (uint32_t q = 0; q < kLeanE; q++) reinterpret_cast<uint4*>(pmask)[q * 64u + uint32_t(lane)] = make_uint4(0, 0, 0, 0);
     bool synced = false;
     uint32_t n_list = 0;
+    uint32_t fp0[kLeanE];  // NOT LIKE: fingerprints of the first 64 values of each entry, in flight with the slices
+    if (kNot) {
+#pragma unroll
+        for (uint32_t q = 0; q < kLeanE; q++) {
+            ConstLeanPtr E = q ? EB : EA;
+            fp0[q] = 0;
+            if ((q == 0 || hasB) && uint32_t(lane) < E->d) fp0[q] = as_global(E->fingerprints)[lane];
+        }
+    }
+    uint64_t any_match[kLeanE] = {};  // NOT LIKE: the entry has a matching dictionary value (wave uniform)
 
     // walk candidates list[0 .. count): 64 per batch, one lane per 8-byte word; rows of the matches go into pmask
     auto walk_list = [&](uint32_t count) {
@@ -255,6 +273,11 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
                     atomicAdd(a.stats + 2, (unsigned long long)__popcll(matched));
                 }
             }
+            if (kNot) {
+                const uint64_t msb = kLeanE == 2 ? __ballot(res && sb) : 0;
+                any_match[0] |= matched & ~msb;
+                if (kLeanE == 2) any_match[kLeanE - 1] |= msb;
+            }
             if (matched) {
                 // rows of the matching dictionary values from the entry's inverted row lists, into the LDS mask words
                 uint32_t o0 = 0, o1 = 0;
@@ -298,6 +321,16 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
             m = sv[0];
 #pragma unroll
             for (int k = 1; k < N; k++) m &= sv[k];
+            if (N == kMaxSigProbe && a.n_extra) {
+                // long needles: the further bigrams, four slices in flight at a time
+                for (uint32_t k0 = 0; k0 < a.n_extra; k0 += 4) {
+                    uint64_t xv[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4; k++)
+                        xv[k] = as_global(sig)[size_t(a.sig_bits[kMaxSigProbe + min(k0 + k, a.n_extra - 1u)]) * nw + w];
+                    m &= xv[0] & xv[1] & xv[2] & xv[3];
+                }
+            }
         }
         const uint32_t tag = sb ? 0x10000u : 0u;
         const uint32_t cnt = uint32_t(__popcll(m));
@@ -350,9 +383,26 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
         const uint64_t moff = E->mask_word_off;
         const uint32_t nwords = (E->n + 63u) >> 6;
         uint32_t c = 0;
+        bool invert = false;  // wave uniform
+        if (kNot) {
+            invert = any_match[q] != 0 || __ballot((fp0[q] & a.needle_fp) == a.needle_fp && uint32_t(lane) < E->d) != 0;
+            for (uint32_t i0 = kWave; !invert && i0 < E->d; i0 += kWave) {  // rare: no candidate among the first 64 values
+                const uint32_t i = i0 + uint32_t(lane);
+                const uint32_t fp = i < E->d ? as_global(E->fingerprints)[i] : 0u;
+                invert = __ballot((fp & a.needle_fp) == a.needle_fp && i < E->d) != 0;
+            }
+        }
         for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
             uint64_t hitw = pmask[q * (kMaskBytes / 8u) + w];
-            if (a.selection && hitw) hitw &= as_global(a.selection)[moff + w];
+            if (kNot) {
+                const uint32_t rows_left = E->n - (w << 6);
+                uint64_t keep = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
+                if (E->validity) keep &= as_global(E->validity)[w];
+                hitw = invert ? ~hitw & keep : 0;
+                if (a.selection) hitw &= as_global(a.selection)[moff + w];
+            } else if (a.selection && hitw) {
+                hitw &= as_global(a.selection)[moff + w];
+            }
             as_global_mut(a.mask)[moff + w] = hitw;
             c += uint32_t(__popcll(hitw));
         }
@@ -365,13 +415,16 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
     if (a.total.d_total_out && lane == 0) total_contribute(a.total, blockIdx.x * kLeanWaves + wave, gridDim.x * kLeanWaves, wave_hits);
 }
 
-hipError_t launch_lean(int n_sig, const LeanArgs& a, uint32_t n_recs, hipStream_t stream) {
+hipError_t launch_lean(int n_sig, bool negated, const LeanArgs& a, uint32_t n_recs, hipStream_t stream) {
     if (n_recs == 0) return hipSuccess;
     typedef void (*Kern)(LeanArgs);
-    static const Kern table[kMaxSigProbe] = {k_like_lean<1>, k_like_lean<2>, k_like_lean<3>, k_like_lean<4>,
-                                             k_like_lean<5>, k_like_lean<6>, k_like_lean<7>, k_like_lean<8>};
+    static const Kern table[2][kMaxSigProbe] = {
+        {k_like_lean<1, false>, k_like_lean<2, false>, k_like_lean<3, false>, k_like_lean<4, false>, k_like_lean<5, false>,
+         k_like_lean<6, false>, k_like_lean<7, false>, k_like_lean<8, false>},
+        {k_like_lean<1, true>, k_like_lean<2, true>, k_like_lean<3, true>, k_like_lean<4, true>, k_like_lean<5, true>,
+         k_like_lean<6, true>, k_like_lean<7, true>, k_like_lean<8, true>}};
     const size_t lds = automaton_image_bytes(a.nl) + kLeanWaves * (kLeanE * (kPostMaxRows / 8u) + kLeanCap * 4u + 80u);
-    hipLaunchKernelGGL(table[n_sig - 1], dim3(n_recs), dim3(kLeanWaves * 64), lds, stream, a);
+    hipLaunchKernelGGL(table[negated ? 1 : 0][n_sig - 1], dim3(n_recs), dim3(kLeanWaves * 64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -382,7 +435,7 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
     if (!s->is_str || s->n == 0) return LC_OK;
     for (const Entry& e : s->meta) {
         if (e.sd.d == 0) continue;  // an all-null entry has no dictionary: no candidates, its mask words are zero
-        if (!e.sd.signatures || !e.sd.postings || e.sd.n > kPostMaxRows) return LC_OK;
+        if (!e.sd.signatures || !e.sd.postings || !e.sd.fingerprints || e.sd.n > kPostMaxRows) return LC_OK;
     }
     // consecutive entries, at most kLeanWaves * kLeanE, never across a symbol-table change
     std::vector<LeanRec> lean;
@@ -396,7 +449,7 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
             for (uint32_t k = b; k < i; k++) {
                 const StrDesc& d = s->meta[k].sd;
                 r.e[k - b] = LeanEntry{d.signatures, d.residuals, d.fsst, d.postings, d.mask_word_off, d.slope, d.intercept,
-                                       d.d, d.n, d.offset_bytes, (d.d + 63u) / 64u};
+                                       d.d, d.n, d.offset_bytes, (d.d + 63u) / 64u, d.validity, d.fingerprints};
             }
             lean.push_back(r);
             b = i;
@@ -414,20 +467,23 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
 }
 
 lc_status run_lean(LikePipeline* lp, const StrPred& p, const ScanLaunch& L, hipStream_t stream,
-                   unsigned long long* d_stats = nullptr) {
+                   unsigned long long* d_stats = nullptr, bool force_like = false) {
     LeanArgs la{};
     la.recs = lp->d_lean;
     la.automata = p.automata;
     la.automaton_stride = p.automaton_stride;
     la.nl = p.needle_len;
-    for (int k = 0; k < kMaxSigProbe; k++) la.sig_bits[k] = p.sig_bits[k];
+    for (int k = 0; k < kMaxSigProbeWide; k++) la.sig_bits[k] = p.sig_wide[k < int(p.n_sig_wide) ? k : 0];
+    la.n_extra = p.n_sig_wide > uint32_t(kMaxSigProbe) ? p.n_sig_wide - uint32_t(kMaxSigProbe) : 0u;
+    la.needle_fp = p.needle_fp;
     la.selection = L.d_selection;
     la.mask = L.d_hit;
     la.counts = L.d_counts;
     la.stats = d_stats;
     la.total.d_total_acc = lp->d_total_acc;
     la.total.d_total_out = L.d_total_out;
-    LC_HIP(launch_lean(int(p.n_sig_bits), la, lp->n_lean, stream));
+    LC_HIP(launch_lean(int(std::min<uint32_t>(p.n_sig_wide, uint32_t(kMaxSigProbe))), p.op == LC_OP_NOT_LIKE && !force_like, la,
+                       lp->n_lean, stream));
     return LC_OK;
 }
 
@@ -446,7 +502,8 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
     L.d_hit = d_scratch;
     L.d_total_out = d_scratch + words;
     LC_HIP(hipMemsetAsync(d_scratch + words, 0, 32, stream));
-    const lc_status rc = run_lean(lp, sp.p, L, stream, reinterpret_cast<unsigned long long*>(d_scratch + words + 1));
+    // (always as LIKE: the plan belongs to the needle, NOT LIKE is selective exactly when LIKE is)
+    const lc_status rc = run_lean(lp, sp.p, L, stream, reinterpret_cast<unsigned long long*>(d_scratch + words + 1), true);
     if (rc != LC_OK) return rc;
     uint64_t res[4] = {0, 0, 0, 0};
     LC_HIP(hipMemcpyAsync(res, d_scratch + words, 32, hipMemcpyDeviceToHost, stream));
@@ -499,7 +556,7 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
     for (const LikePlan& q : lp->plans)
         if (q.needle == sp.needle && (q.use_lean || s->ctx->like_path == 3)) {
             uint64_t b = uint64_t(lp->n_lean) * 16 + uint64_t(s->n) * 64 + s->seg_offsets.back() * 8 + (with_counts ? uint64_t(s->n) * 4 : 0);
-            for (const Entry& e : s->meta) b += uint64_t((e.sd.d + 63u) / 64u) * 8 * sp.p.n_sig_bits;
+            for (const Entry& e : s->meta) b += uint64_t((e.sd.d + 63u) / 64u) * 8 * sp.p.n_sig_wide;
             b += q.n_cand * 8 + q.cand_bytes + q.matches * 4 + q.hits * 2;
             return b;
         }
@@ -511,7 +568,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
                              bool* handled) {
     *handled = false;
     const StrPred& p = sp.p;
-    if (p.mode != 1 || p.op != LC_OP_LIKE || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
+    if (p.mode != 1 || (p.op != LC_OP_LIKE && p.op != LC_OP_NOT_LIKE) || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
         automaton_image_bytes(p.needle_len) == 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
         return LC_OK;
     if (s->n < ctx->like_pipeline_min_entries || ctx->like_path == 1) return LC_OK;

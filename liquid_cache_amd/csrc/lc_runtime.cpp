@@ -613,13 +613,36 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
         out->p.use_fingerprints = 1;
         out->needle.assign(inner, inner + il);
         for (size_t k = 0; k < il; k++) out->p.needle_fp |= 1u << (inner[k] & 31);
-        for (size_t k = 0; k + 1 < il && out->p.n_sig_bits < uint32_t(kMaxSigProbe); k++) {
+        // bigram positions in an order that covers the needle evenly at every prefix: both ends, then midpoints of the
+        // remaining gaps, breadth first
+        std::vector<size_t> order;
+        if (il >= 2) {
+            const size_t last = il - 2;
+            std::vector<uint8_t> seen(last + 1, 0);
+            std::vector<std::pair<size_t, size_t>> gaps;
+            auto take = [&](size_t k) { if (!seen[k]) { seen[k] = 1; order.push_back(k); } };
+            take(0);
+            take(last);
+            gaps.push_back({0, last});
+            for (size_t g = 0; g < gaps.size(); g++) {
+                const size_t lo = gaps[g].first, hi = gaps[g].second;
+                if (hi - lo < 2) continue;
+                const size_t mid = lo + (hi - lo) / 2;
+                take(mid);
+                gaps.push_back({lo, mid});
+                gaps.push_back({mid, hi});
+            }
+        }
+        for (size_t k : order) {
+            if (out->p.n_sig_wide >= uint32_t(kMaxSigProbeWide)) break;
             const uint16_t bit = uint16_t(bigram_bit(inner[k], inner[k + 1]));
             bool dup = false;
-            for (uint32_t q = 0; q < out->p.n_sig_bits; q++) dup |= out->p.sig_bits[q] == bit;
-            if (!dup) out->p.sig_bits[out->p.n_sig_bits++] = bit;
+            for (uint32_t q = 0; q < out->p.n_sig_wide; q++) dup |= out->p.sig_wide[q] == bit;
+            if (!dup) out->p.sig_wide[out->p.n_sig_wide++] = bit;
         }
-        // the kernel always ANDs kMaxSigProbe slices (all loads in flight together): pad with repeats
+        out->p.n_sig_bits = std::min<uint32_t>(out->p.n_sig_wide, uint32_t(kMaxSigProbe));
+        for (uint32_t q = 0; q < out->p.n_sig_bits; q++) out->p.sig_bits[q] = out->p.sig_wide[q];
+        // k_str_pred always ANDs kMaxSigProbe slices (all loads in flight together): pad with repeats
         for (uint32_t q = out->p.n_sig_bits; q < uint32_t(kMaxSigProbe) && out->p.n_sig_bits > 0; q++)
             out->p.sig_bits[q] = out->p.sig_bits[q % out->p.n_sig_bits];
     } else {
@@ -2391,7 +2414,7 @@ lc_status lc_scan_explain(lc_scan* s, const lc_predicate* pred, char* out, size_
         const lc_status st = make_str_pred(pred, &sp);
         if (st != LC_OK) return st;
         std::lock_guard<std::mutex> g(s->mu);
-        if (sp.p.mode == 1 && pred->op == LC_OP_LIKE) text = like_pipeline_explain(s, sp);
+        if (sp.p.mode == 1) text = like_pipeline_explain(s, sp);
         else text = "k_str_pred";
     }
     std::snprintf(out, cap, "%s", text.c_str());
