@@ -66,6 +66,9 @@ def parse_args(argv=None):
     p.add_argument("--int-base", type=int, default=None, help="int64_gt: smallest value (default: a large id-like base)")
     p.add_argument("--exchange", default="count", choices=["count", "mask"],
                    help="multi-GPU exchange step per scan: COUNT(*) all-reduce or all-gather of the hit-mask segments")
+    p.add_argument("--comm", default="torch", choices=["torch", "abi"],
+                   help="who runs the exchange step: torch.distributed (RCCL through PyTorch) or the library's own C ABI "
+                        "(lc_comm_*: RCCL directly, what a Rust host would bind); the unique id travels over torch's store")
     p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = whole column)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-fingerprints", action="store_true",
@@ -1024,11 +1027,30 @@ def main():
     t_stage += time.perf_counter() - t_rot
     # COUNT(*) partials: written by the predicate kernel itself (lc_scan_eval_count); two buffers so that the all-reduce
     # of step i (RCCL's own stream) overlaps the scan of step i+1
-    from liquid_cache_amd.sharding import PipelinedCountAllReduce, all_gather_mask_segments
-    reducer = PipelinedCountAllReduce(lambda: torch.zeros((), dtype=torch.int64, device="cuda"), world)
+    from liquid_cache_amd.sharding import (Communicator, PipelinedAbiCountAllReduce, PipelinedCountAllReduce,
+                                           all_gather_mask_segments)
+    comm = None
+    comm_used = "torch.distributed"
+    if args.comm == "abi" and world > 1:
+        try:  # the library's own communicator; its 128-byte id is broadcast by the launcher's process group
+            uid = [Communicator.unique_id(cache) if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            comm = Communicator(cache, rank, world, uid[0])
+            comm_used = "lc_comm (RCCL through the C ABI)"
+        except Exception as e:  # noqa: BLE001 — never lose the scaling run to the optional path
+            comm = None
+            comm_used = "torch.distributed (lc_comm failed: %s)" % e
+    make_total = lambda: torch.zeros((), dtype=torch.int64, device="cuda")  # noqa: E731
+    reducer = PipelinedAbiCountAllReduce(make_total, comm, torch) if comm else PipelinedCountAllReduce(make_total, world)
     stream = torch.cuda.current_stream().cuda_stream
     gathered = [None]
     step_no = [0]
+    words_per_rank = None
+    if comm and args.exchange == "mask":
+        wl = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(world)]
+        dist.all_gather(wl, torch.tensor([words], dtype=torch.int64, device="cuda"))
+        words_per_rank = [int(x.item()) for x in wl]
+        gathered[0] = torch.zeros(max(sum(words_per_rank), 1), dtype=torch.int64, device="cuda")
 
     def step():
         total = reducer.acquire()
@@ -1038,7 +1060,10 @@ def main():
         reducer.submit()  # exchange step of COUNT(*) queries: the partial counts -> global count (8 bytes)
         if args.exchange == "mask" and world > 1:
             # exchange step of mask consumers: the per-rank segments -> one BooleanArray (row-range shards concatenate)
-            gathered[0] = all_gather_mask_segments(mask)
+            if comm:
+                comm.allgather_mask(mask.data_ptr(), words, gathered[0].data_ptr(), words_per_rank, stream)
+            else:
+                gathered[0] = all_gather_mask_segments(mask)
 
     drain = reducer.drain
 
@@ -1081,7 +1106,7 @@ def main():
         dist.all_reduce(lh, op=dist.ReduceOp.SUM)
     assert int(lh.item()) == hits, "fused COUNT(*) %d != sum of per-entry counts %d" % (hits, int(lh.item()))
     if args.exchange == "mask" and world > 1:
-        assert sum(int(x.numel()) for x in gathered[0]) * 64 >= rows_all
+        assert (int(gathered[0].numel()) if comm else sum(int(x.numel()) for x in gathered[0])) * 64 >= rows_all
 
     # roofline of the dominant kernel: HIP events on the launch stream, same launches as the timed region
     alg_bytes, own_bytes = scan.traffic_model(expr, False)
@@ -1118,6 +1143,7 @@ def main():
                            world, "8-byte COUNT(*) all-reduce (overlapped with the next scan)" if args.exchange == "count"
                            else "COUNT(*) all-reduce + all-gather of the hit-mask segments"),
                        "predicate": ("URL LIKE '%%%s%%'" % args.needle) if args.workload == "url_like" else "col > literal",
+                       "exchange_by": comm_used,
                        "hits": hits, "stage_seconds": round(t_stage, 2), "rotating_columns": n_rot,
                        "timed_loop": "step i scans resident column i %% %d (L3-cold by construction)" % n_rot},
             # what the scan is worth to the query: the reference algorithm's bytes per second of wall clock

@@ -129,3 +129,94 @@ class PipelinedCountAllReduce:
     def last(self):
         """The (globally reduced, after drain()) count of the most recent step."""
         return self.buffers[(self.steps - 1) & 1]
+
+
+class Communicator:
+    """The exchange steps behind the C ABI (lc_comm_*): RCCL over xGMI for device contexts, a shared-memory file for
+    host-only contexts (CPU tests).  Rank 0 creates the unique id (`Communicator.unique_id(cache)`), the host distributes
+    its 128 bytes (here: whatever the caller has — a file, torch.distributed's store, MPI) and every rank calls
+    `Communicator(cache, rank, world, id)`."""
+
+    def __init__(self, cache, rank: int, world: int, unique_id: bytes):
+        import ctypes as C
+        from . import _native as N
+        self._lib, self._cache, self._C, self._N = cache._lib, cache, C, N
+        if len(unique_id) != 128:
+            raise ValueError("the communicator id is 128 bytes")
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        N.check(self._lib.lc_comm_init(cache.handle, rank, world, buf, C.byref(h)), cache.handle)
+        self._h = h
+        self.rank, self.world = rank, world
+
+    @staticmethod
+    def unique_id(cache) -> bytes:
+        import ctypes as C
+        from . import _native as N
+        buf = (C.c_uint8 * 128)()
+        N.check(cache._lib.lc_comm_unique_id(cache.handle, buf), cache.handle)
+        return bytes(buf)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.lc_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allreduce_count(self, total_ptr: int, stream: int = 0):
+        """In-place sum over the ranks of the u64 at `total_ptr` (device pointer; host pointer for host-only contexts)."""
+        self._N.check(self._lib.lc_comm_allreduce_count(self._h, total_ptr, stream or None), self._cache.handle)
+
+    def allgather_mask(self, local_ptr: int, local_words: int, all_ptr: int, words_per_rank, stream: int = 0):
+        C = self._C
+        wpr = (C.c_uint64 * self.world)(*[int(w) for w in words_per_rank])
+        self._N.check(self._lib.lc_comm_allgather_mask(self._h, local_ptr or None, int(local_words), all_ptr, wpr,
+                                                        stream or None), self._cache.handle)
+
+
+class PipelinedAbiCountAllReduce:
+    """PipelinedCountAllReduce on the C ABI (lc_comm_allreduce_count, RCCL directly, no torch.distributed collective):
+    the all-reduce of step i runs on a side HIP stream behind an event recorded after step i's scan, so it overlaps the
+    scan of step i + 1; step i + 2 makes the scan stream wait for it before the buffer is overwritten."""
+
+    def __init__(self, make_buffer, comm: "Communicator", torch):
+        self.torch = torch
+        self.comm = comm
+        self.buffers = [make_buffer(), make_buffer()]
+        self.side = torch.cuda.Stream()
+        self.done = [None, None]
+        self.steps = 0
+
+    def acquire(self):
+        b = self.steps & 1
+        self.steps += 1
+        if self.done[b] is not None:
+            self.torch.cuda.current_stream().wait_event(self.done[b])
+            self.done[b] = None
+        self._current = b
+        return self.buffers[b]
+
+    def submit(self):
+        if self.comm.world > 1:
+            torch = self.torch
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            self.side.wait_event(ready)
+            self.comm.allreduce_count(self.buffers[self._current].data_ptr(), self.side.cuda_stream)
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            self.done[self._current] = ev
+
+    def drain(self):
+        for b in range(2):
+            if self.done[b] is not None:
+                self.done[b].synchronize()
+                self.done[b] = None
+
+    def last(self):
+        return self.buffers[(self.steps - 1) & 1]

@@ -241,3 +241,60 @@ def test_bench_q6_shards_hold_the_same_bytes_for_every_world_size():
     assert sum(n for n, _ in one.values()) == total_rows and sum(c for _, c in one.values()) > 0
     for world in (2, 3, 8):
         assert counts_of(world) == one
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the exchange steps behind the C ABI (lc_comm_*), shared-memory backend of host-only contexts: what a Rust host binds
+# ------------------------------------------------------------------------------------------------------------------
+def _abi_worker(rank, world, id_path, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    import liquid_cache_amd as lc
+    from liquid_cache_amd import sharding as sh
+    cache = lc.LiquidCacheBuilder.new().with_host_only().build()
+    if rank == 0:
+        uid = sh.Communicator.unique_id(cache)
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(id_path + ".tmp", id_path)  # the host's own distribution channel: here a file
+    else:
+        import time
+        for _ in range(2000):
+            if os.path.exists(id_path):
+                break
+            time.sleep(0.005)
+        uid = open(id_path, "rb").read()
+    comm = sh.Communicator(cache, rank, world, uid)
+    rng = np.random.default_rng(100 + rank)
+    results = []
+    for rnd in range(5):
+        # COUNT(*): per-rank partial counts -> the global count on every rank
+        part = np.array([int(rng.integers(0, 1 << 40)) + rank], np.uint64)
+        mine = int(part[0])
+        comm.allreduce_count(part.ctypes.data)
+        # mask: per-rank segments of different lengths (incl. an empty one) -> the concatenation on every rank
+        wpr = [((r * 7 + rnd * 3) % 5) * 11 for r in range(world)]
+        local = rng.integers(0, 1 << 62, size=wpr[rank], dtype=np.int64).view(np.uint64)
+        out = np.zeros(max(sum(wpr), 1), np.uint64)
+        comm.allgather_mask(local.ctypes.data if local.size else 0, local.size, out.ctypes.data, wpr)
+        results.append((mine, int(part[0]), local.tolist(), out[: sum(wpr)].tolist(), wpr))
+    comm.close()
+    cache.close()
+    np.save(out_path % rank, np.array([repr(results)]))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_c_abi_exchange_steps_over_shared_memory(product_lib, tmp_path, world):
+    id_path = str(tmp_path / "comm_id")
+    out = str(tmp_path / "res_%d.npy")
+    mp.spawn(_abi_worker, args=(world, id_path, out), nprocs=world, join=True)
+    res = [eval(str(np.load(out % r)[0])) for r in range(world)]  # noqa: S307 (our own repr)
+    for rnd in range(5):
+        total = sum(res[r][rnd][0] for r in range(world)) % (1 << 64)
+        concat = []
+        for r in range(world):
+            concat += res[r][rnd][2]
+        for r in range(world):
+            assert res[r][rnd][1] == total, (rnd, r)
+            assert res[r][rnd][3] == concat, (rnd, r)
+            assert res[r][rnd][4] == res[0][rnd][4]

@@ -287,3 +287,38 @@ def test_index_blob_round_trip(product_lib, oracle, fuzz_cases):
                 assert [None if w is None else bool(g) for g, w in zip(got, want)] == want
     finally:
         cache.close()
+
+
+def test_c_abi_exchange_on_rccl_world_of_one(product_lib):
+    """lc_comm_* on the device backend: librccl is opened lazily, a one-rank communicator reduces and gathers in place
+    (the multi-rank arithmetic is covered by the shared-memory backend in tests/test_distributed_cpu.py; an 8-GPU node is
+    what exercises RCCL across ranks)."""
+    import ctypes as C
+    from liquid_cache_amd import _native as N
+    from liquid_cache_amd import sharding as sh
+    cache = lc.LiquidCacheBuilder.new().build()
+    try:
+        uid = sh.Communicator.unique_id(cache)
+        assert len(uid) == 128 and any(uid)
+        comm = sh.Communicator(cache, 0, 1, uid)
+        lib, ctx = cache._lib, cache.handle
+        d_total, d_a, d_b = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        N.check(lib.lc_device_alloc(ctx, 8, C.byref(d_total)), ctx)
+        N.check(lib.lc_device_alloc(ctx, 8 * 100, C.byref(d_a)), ctx)
+        N.check(lib.lc_device_alloc(ctx, 8 * 100, C.byref(d_b)), ctx)
+        v = np.array([123456789012], np.uint64)
+        N.check(lib.lc_host_to_device(ctx, d_total, v.ctypes.data_as(C.c_void_p), 8, None), ctx)
+        comm.allreduce_count(d_total.value)
+        words = np.arange(100, dtype=np.uint64) * 0x0101010101
+        N.check(lib.lc_host_to_device(ctx, d_a, words.ctypes.data_as(C.c_void_p), 800, None), ctx)
+        comm.allgather_mask(d_a.value, 100, d_b.value, [100])
+        N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+        back, got = np.zeros(1, np.uint64), np.zeros(100, np.uint64)
+        N.check(lib.lc_device_to_host(ctx, back.ctypes.data_as(C.c_void_p), d_total, 8, None), ctx)
+        N.check(lib.lc_device_to_host(ctx, got.ctypes.data_as(C.c_void_p), d_b, 800, None), ctx)
+        assert int(back[0]) == 123456789012 and got.tolist() == words.tolist()
+        comm.close()
+        for p in (d_total, d_a, d_b):
+            lib.lc_device_free(ctx, p)
+    finally:
+        cache.close()
