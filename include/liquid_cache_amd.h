@@ -168,6 +168,7 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
 #define LC_OPT_HOST_BUILT_INDEX 3
 #define LC_OPT_LIKE_PIPELINE_MIN_ENTRIES 4
 #define LC_OPT_LIKE_PATH 5
+#define LC_OPT_LIKE_MANY_HINT 6 /* A/B aid (default 1): needles the plan found unselective run k_str_pred's sequential walker */
 LC_API lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value);
 LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
 LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);

@@ -107,6 +107,7 @@ struct lc_ctx {
     std::vector<std::unique_ptr<lc::SymbolTable>> symtabs;
     bool build_signatures = true;  // LC_OPT_SIGNATURE_INDEX = 0 disables the bigram index (plain reference layout only)
     bool signatures_on_host = false;  // LC_OPT_HOST_BUILT_INDEX = 1: build the index on the host (the device builder's oracle)
+    bool like_many_hint = true;  // LC_OPT_LIKE_MANY_HINT (A/B aid): unselective planned needles take k_str_pred's sequential walker
     int like_path = 0;  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred only, 3 k_like_lean for every needle
     uint32_t like_pipeline_min_entries = 32;  // LC_OPT_LIKE_PIPELINE_MIN_ENTRIES: smaller scans are not planned (k_str_pred)
     bool build_postings = true;       // LC_OPT_ROW_LISTS = 0: no inverted row lists (rows always mapped through the keys)
@@ -201,7 +202,7 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out);
 // lc_like_pipeline.hip.  Caller holds s->mu and has built the automata of `sp`.  *handled: the evaluation was launched
 // by the pipeline; otherwise the caller launches k_str_pred.
 lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
-                             bool* handled);
+                             bool* handled, bool* many_candidates);
 void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp);
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp);           // caller holds s->mu
 uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts);  // caller holds s->mu

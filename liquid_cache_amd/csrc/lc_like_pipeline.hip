@@ -565,8 +565,9 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
 
 // Caller holds s->mu and has built the automata of `sp` (sp.p.automata).  *handled = true: the evaluation was launched.
 lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
-                             bool* handled) {
+                             bool* handled, bool* many_candidates) {
     *handled = false;
+    *many_candidates = false;
     const StrPred& p = sp.p;
     if (p.mode != 1 || (p.op != LC_OP_LIKE && p.op != LC_OP_NOT_LIKE) || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
         automaton_image_bytes(p.needle_len) == 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
@@ -596,6 +597,9 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         plan = &lp->plans.back();
     }
     plan->last_use = ++lp->tick;
+    // a needle the plan found unselective: k_str_pred takes it, and with at least a wave of candidates per entry its
+    // sequential walker (every lane works through its own share of the list) beats the lane-parallel one
+    if (!plan->use_lean) *many_candidates = plan->n_cand >= uint64_t(kWave) * s->n;
     if (!plan->use_lean && ctx->like_path != 3) return LC_OK;
     const lc_status st = run_lean(lp, p, L, stream);
     if (st == LC_OK) *handled = true;

@@ -709,6 +709,7 @@ lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
         case LC_OPT_SIGNATURE_INDEX: ctx->build_signatures = value != 0; return LC_OK;
         case LC_OPT_ROW_LISTS: ctx->build_postings = value != 0; return LC_OK;
         case LC_OPT_HOST_BUILT_INDEX: ctx->signatures_on_host = value != 0; return LC_OK;
+        case LC_OPT_LIKE_MANY_HINT: ctx->like_many_hint = value != 0; return LC_OK;
         case LC_OPT_LIKE_PATH:
             if (value != 0 && value != 1 && value != 3) return fail(LC_ERR_INVALID, "LC_OPT_LIKE_PATH takes 0, 1 or 3");
             ctx->like_path = int(value);
@@ -1975,10 +1976,11 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     }
     if (sp.p.mode == 1) {
         // selective LIKE over an indexed column: k_like_lean (planned once per scan and needle); everything else: k_str_pred
-        bool handled = false;
-        const lc_status ps = like_pipeline_eval(ctx, s, sp, L, stream, &handled);
+        bool handled = false, many = false;
+        const lc_status ps = like_pipeline_eval(ctx, s, sp, L, stream, &handled, &many);
         if (ps != LC_OK) return ps;
         if (handled) return LC_OK;
+        if (many && ctx->like_many_hint) L.many_candidates = 1;
     }
     LC_HIP(launch_str_pred(static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, sp.p, L, stream));
     return LC_OK;
