@@ -358,7 +358,15 @@ LC_API lc_status lc_squeeze_clamp(lc_ctx* ctx, uint64_t n, const uint64_t* entry
  * does not decide it: `< k` and `>= k` are decided there when k is the first value of its bucket, `<= k` and `> k` when
  * it is the last, `=` / `<>` never (:575-618); a literal below the reference decides everything (:535-547).  Otherwise
  * LC_NEEDS_BACKING.  Every read of a quantized entry answers LC_NEEDS_BACKING (its to_arrow_array hydrates from disk,
- * :688-690).  The division, clamp to the last bucket and packing run on the device. */
+ * :688-690).  The division, clamp to the last bucket and packing run on the device.
+ * Float32 / Float64 entries take the float form (FloatSqueezePolicy::Quantize, the only float policy; float_array.rs:338-395
+ * -> LiquidFloatQuantizedArray :742-953): a row keeps (encoded >> shift) - (reference >> shift) of its ALP-encoded value at
+ * half the bit width, shift = W - W / 2; validity and the ALP exceptions stay.  A comparison is decided per row from the
+ * decoded bounds of its bucket exactly as the reference computes them (plain IEEE operators; exception rows by their
+ * values); any valid selected unpatched row left undecided -> LC_NEEDS_BACKING.  LC_UNSUPPORTED for a selection over an
+ * entry WITH exceptions (the reference filters the buckets but not the patch indices, :772-792: there is no defined
+ * result to be identical to).  Entries in which a bucket would need one bit more than the halved width (the reference
+ * packs such a value with whatever its packer does) are left unsqueezed. */
 LC_API lc_status lc_squeeze_quantize(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed);
 
 /* boolean_buffer_and_then(left, right) (src/datafusion/src/utils.rs:62-83): `left` has left_bits bits of which

@@ -84,6 +84,9 @@ struct Entry {
     // holds the bucket (value - reference) / bucket_width.  Predicates only; every read needs the backing bytes.
     bool quantized = false;
     uint64_t bucket_width = 0;
+    // LiquidFloatQuantizedArray form (float_array.rs:742-953): ALP-encoded values cut to half the bit width by a right shift
+    // of the ABSOLUTE encoded value; fq_shift > 0 marks it (then `quantized` is set as well: every read needs the backing)
+    int fq_shift = 0;
     bool sig_on_device = false;  // staging: the signature slices are still to be built by k_str_build_signatures
     uint64_t raw_bytes = 0;      // byte views: uncompressed size of the dictionary (RawFsstBuffer header)
 };
@@ -137,6 +140,8 @@ struct lc_scan {
     uint32_t n = 0, bpe = 0;
     uint32_t max_w = 0;  // widest entry (fixed width): <= 32 selects the register-resident predicate kernel
     bool has_clamped = false;              // some entry is clamp-squeezed: evaluations first look for unresolved sentinels
+    bool has_fquant = false;               // some entry is a float-quantized hybrid (k_float_quant_pred evaluates those)
+    bool fquant_patches = false;           // ... and carries ALP exceptions: no selection can be applied (see lc_squeeze_quantize)
     std::vector<uint32_t> needs_backing;   // entries (scan order) whose last evaluation needs the full array
     std::vector<uint64_t> seg_offsets;  // n+1 word offsets
     std::vector<uint32_t> lens;         // rows per entry: two scans cover the same row ranges iff these are equal

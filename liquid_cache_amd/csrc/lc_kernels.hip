@@ -342,6 +342,8 @@ __device__ __forceinline__ PackedRange<U> intersect_ranges(const PackedRange<U>&
 template <typename U>
 __device__ __forceinline__ PackedRange<U> entry_range(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2, int lane) {
     const bool alp = d.kind == kKindF32 || d.kind == kKindF64;
+    // float-quantized entries are evaluated by k_float_quant_pred: here their mask words are written as zeros
+    if (d.quantized & 0x80u) return PackedRange<U>{0, 0, false, 0};
     PackedRange<U> pr = alp ? packed_range_alp<U>(d, pred, lane) : packed_range<U>(d, pred);
     if (pred2.op >= 0) {
         const PackedRange<U> pr2 = alp ? packed_range_alp<U>(d, pred2, lane) : packed_range<U>(d, pred2);
@@ -1008,7 +1010,7 @@ __global__ __launch_bounds__(kThreads) void k_alp_patch_fix(const FixedDesc* __r
     const I litkey2 = FloatBits<F>::key(FloatBits<F>::from_bits(pred2.lit));
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < L.n_entries; entry += total_waves) {
         const FixedDesc d = descs[entry];
-        if (d.patch_len == 0 || d.W == 0) continue;
+        if (d.patch_len == 0 || d.W == 0 || (d.quantized & 0x80u)) continue;
         int delta = 0;
         for (uint32_t k = uint32_t(lane); k < d.patch_len; k += kWave) {
             const uint64_t row = d.patch_idx[k];
@@ -1034,6 +1036,117 @@ __global__ __launch_bounds__(kThreads) void k_alp_patch_fix(const FixedDesc* __r
                 if (L.d_counts) L.d_counts[entry] = uint32_t(int64_t(L.d_counts[entry]) + t);
                 if (L.d_total_out) atomicAdd(reinterpret_cast<unsigned long long*>(L.d_total_out), (unsigned long long)t);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LiquidFloatQuantizedArray::try_eval_predicate_inner (float_array.rs:825-953): a row holds the bucket of its ALP-encoded
+// value, (encoded >> shift) - (reference >> shift).  Per row the reference decodes the bucket's bounds
+//   lo = decode((bucket << shift) + reference),  hi = decode(((bucket + 1) << shift) + reference)
+// (as written there: the reference is added AFTER the shift) and decides the comparison from them with plain IEEE
+// operators (handle_eq .. handle_gteq, :797-868); a valid row whose bounds do not decide it makes the whole call
+// Err(NeedsBacking).  Rows stored as ALP exceptions are decided by their patch value, again with IEEE operators
+// (:935-946), and are never "undecided".  One wave per entry, 1024 rows per round: the patches of the round are marked in
+// an LDS bitmap first (the patch indices are sorted).  This is the memory-pressure regime: not a tuned kernel.
+template <typename F>
+__device__ __forceinline__ int fq_decide(int op, F lo, F hi, F k) {  // 1 / 0: decided true / false, -1: undecided
+    switch (op) {
+        case LC_OP_EQ: return (k < lo || k > hi) ? 0 : -1;
+        case LC_OP_NE: return (k < lo || k > hi) ? 1 : -1;
+        case LC_OP_LT: return k <= lo ? 0 : (hi < k ? 1 : -1);
+        case LC_OP_LE: return k < lo ? 0 : (hi <= k ? 1 : -1);
+        case LC_OP_GT: return k < lo ? 1 : (hi <= k ? 0 : -1);
+        default: return k <= lo ? 1 : (hi < k ? 0 : -1);  // GE
+    }
+}
+template <typename F>
+__device__ __forceinline__ bool fq_compare(int op, F v, F k) {
+    switch (op) {
+        case LC_OP_EQ: return v == k;
+        case LC_OP_NE: return v != k;
+        case LC_OP_LT: return v < k;
+        case LC_OP_LE: return v <= k;
+        case LC_OP_GT: return v > k;
+        default: return v >= k;
+    }
+}
+
+template <typename U, typename F>
+__global__ __launch_bounds__(kThreads) void k_float_quant_pred(const FixedDesc* __restrict__ descs, FixedPred pred, ScanLaunch L,
+                                                                uint32_t* __restrict__ undecided) {
+    typedef typename FloatBits<F>::I I;
+    __shared__ uint64_t patch_bits[kWavesPerBlock][16];
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    const F k = FloatBits<F>::from_bits(pred.lit);
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
+        const FixedDesc d = descs[entry];
+        if (!(d.quantized & 0x80u) || d.W == 0) continue;
+        const uint32_t shift = d.quantized & 0x7Fu, W = d.W;
+        const U mask = U((U(1) << W) - 1);
+        uint32_t pcur = 0, hits = 0, und = 0;
+        for (uint32_t row0 = 0, blk = 0; row0 < d.len; row0 += 1024u, blk++) {
+            const uint32_t rows = min(1024u, d.len - row0);
+            if (lane < 16) patch_bits[wave][lane] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // patches of this round: indices are ascending, the ones below row0 + 1024 form a prefix of what is left
+            for (;;) {
+                const uint32_t kk = pcur + uint32_t(lane);
+                const uint64_t idx = kk < d.patch_len ? d.patch_idx[kk] : ~uint64_t(0);
+                const bool in = idx < uint64_t(row0) + 1024u;
+                if (in && idx >= row0)
+                    atomicOr(reinterpret_cast<unsigned long long*>(&patch_bits[wave][(idx - row0) >> 6]), 1ull << ((idx - row0) & 63u));
+                const uint32_t n_in = uint32_t(__popcll(__ballot(in)));
+                pcur += n_in;
+                if (n_in < uint32_t(kWave)) break;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint8_t* block = d.packed + size_t(blk) * 128u * W;
+            for (uint32_t it = 0; it * 64u < rows; it++) {
+                const uint32_t i = it * 64u + uint32_t(lane);
+                const uint64_t widx = d.mask_word_off + uint64_t(blk) * 16u + it;
+                uint64_t act = ~uint64_t(0);
+                if (rows - it * 64u < 64u) act = (uint64_t(1) << (rows - it * 64u)) - 1;
+                if (d.validity) act &= d.validity[uint64_t(blk) * 16u + it];
+                if (L.d_selection) act &= L.d_selection[widx];
+                const uint64_t pw = patch_bits[wave][it];
+                uint32_t r, fl;
+                fl_row_lane<U>(i, &r, &fl);
+                const U b = i < rows ? extract_packed<U>(block, r, fl, W, mask) : U(0);
+                const I val = I(b);
+                const I lo_i = I(U(U(val) << shift) + U(d.reference));            // wrapping, like the reference's add_wrapping
+                const I hi_i = I(U(U(val + I(1)) << shift) + U(d.reference));
+                const int dec = fq_decide<F>(pred.op, alp_decode(lo_i, d.alp_e, d.alp_f), alp_decode(hi_i, d.alp_e, d.alp_f), k);
+                const uint64_t t_mask = __ballot(dec == 1), u_mask = __ballot(dec < 0);
+                const uint64_t hitw = t_mask & act & ~pw;
+                und |= uint32_t((u_mask & act & ~pw) != 0);
+                L.d_hit[widx] = hitw;
+                if (L.d_valid) L.d_valid[widx] = act;
+                hits += uint32_t(__popcll(hitw));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // patch rows: decided by value
+        int delta = 0;
+        for (uint32_t kk = uint32_t(lane); kk < d.patch_len; kk += kWave) {
+            const uint64_t row = d.patch_idx[kk];
+            if (row >= d.len) continue;
+            const uint64_t word = d.mask_word_off + (row >> 6), bit = uint64_t(1) << (row & 63);
+            bool active = d.validity ? ((d.validity[row >> 6] >> (row & 63)) & 1) != 0 : true;
+            if (L.d_selection) active = active && (L.d_selection[word] & bit) != 0;
+            if (active && fq_compare<F>(pred.op, reinterpret_cast<const F*>(d.patch_val)[kk], k)) {
+                atomicOr(reinterpret_cast<unsigned long long*>(&L.d_hit[word]), (unsigned long long)bit);
+                delta++;
+            }
+        }
+        const uint32_t dsum = uint32_t(uniform_u64(wave_sum_u64(uint64_t(delta))));
+        if (lane == 0) {
+            const uint32_t total = hits + dsum;  // `hits` is wave uniform (popcounts of ballots)
+            if (L.d_counts) L.d_counts[entry] = total;
+            if (L.d_total_out && total) atomicAdd(reinterpret_cast<unsigned long long*>(L.d_total_out), (unsigned long long)total);
+            undecided[entry] = und;
         }
     }
 }
@@ -3185,6 +3298,11 @@ __global__ __launch_bounds__(256) void k_fl_pack(const EncodeDesc* __restrict__ 
             const uint64_t raw = valid ? load_native_any(d, idx) : 0;
             v = U(raw >= d.reference ? raw - d.reference : 0);
         }
+        if (d.fq_shift) {  // float Quantize squeeze: bucket of the absolute encoded value (float_array.rs:363-368)
+            typedef typename std::make_signed<U>::type S;
+            const S ref = S(U(d.fq_ref));
+            v = U(S(S(U(U(ref) + v)) >> d.fq_shift) - S(ref >> d.fq_shift));
+        }
         if (d.quant_width > 1) v = U(uint64_t(v) / d.quant_width);  // bucket index (primitive_array.rs:472-481)
         if (d.clamp_max && v > U(d.clamp_max)) v = U(d.clamp_max);  // values >= sentinel become the sentinel (:433-437)
         v &= mask;
@@ -3733,6 +3851,17 @@ hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const F
     const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8))), block(kThreads);
     if (lane_log2 == 5) hipLaunchKernelGGL(k_alp_patch_fix<float>, grid, block, 0, stream, d_descs, pred, p2, L);
     else if (lane_log2 == 6) hipLaunchKernelGGL(k_alp_patch_fix<double>, grid, block, 0, stream, d_descs, pred, p2, L);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+hipError_t launch_float_quant_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
+                                   uint32_t* d_undecided, hipStream_t stream) {
+    if (L.n_entries == 0) return hipSuccess;
+    const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8))), block(kThreads);
+    if (lane_log2 == 5) hipLaunchKernelGGL((k_float_quant_pred<uint32_t, float>), grid, block, 0, stream, d_descs, pred, L, d_undecided);
+    else if (lane_log2 == 6) hipLaunchKernelGGL((k_float_quant_pred<uint64_t, double>), grid, block, 0, stream, d_descs, pred, L, d_undecided);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

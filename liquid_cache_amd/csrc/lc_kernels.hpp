@@ -53,8 +53,9 @@ struct alignas(16) FixedDesc {
     uint8_t kind;              // FixedKind
     uint8_t alp_e, alp_f;
     uint8_t value_width;       // bytes of a decoded Arrow value
-    uint8_t quantized;         // 1: the packed values are bucket indices (LiquidPrimitiveQuantizedArray); the bucket
-                               // width (u64) lives in the bits of `patch_idx`, which integer entries do not use
+    uint8_t quantized;         // 1 / 2: the packed values are bucket indices (LiquidPrimitiveQuantizedArray / decimal); the bucket
+                               // width (u64) lives in the bits of `patch_idx`, which integer entries do not use.
+                               // 0x80 | shift: LiquidFloatQuantizedArray (float_array.rs:742-953), bucket = encoded >> shift
 };
 static_assert(sizeof(FixedDesc) == 64, "FixedDesc layout");
 __host__ __device__ inline uint64_t quant_bucket_width(const FixedDesc& d) { return uint64_t(reinterpret_cast<uintptr_t>(d.patch_idx)); }
@@ -141,6 +142,11 @@ struct EncodeDesc {
     uint8_t is_signed;
     uint8_t stride_log2;       // 0: values are dense; 4 / 5: Decimal128 / Decimal256 values, the low u64 of every 16 / 32
                                // bytes is the value (fits_u64, decimal_array.rs:120-125), null slots pack 0
+    uint8_t fq_shift;          // pack phase, float Quantize squeeze (float_array.rs:357-369): the values are packed-domain offsets
+                               // of an ALP array; what is packed is ((fq_ref + v) >> fq_shift) - (fq_ref >> fq_shift), signed
+                               // arithmetic in the lane width; 0: no such transform
+    uint8_t pad[3];
+    uint64_t fq_ref;           // the array's reference (sign-extended)
 };
 struct EncodeMinMax {
     uint64_t mn, mx;  // as int64 bits for signed types
@@ -240,6 +246,11 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
                              uint32_t max_width, const ScanLaunch& L, hipStream_t stream);
 hipError_t launch_alp_patch_fix(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const FixedPred* pred2,
                                 const ScanLaunch& L, hipStream_t stream);
+// float-quantized entries of a scan (FixedDesc::quantized & 0x80; the other kernels leave their mask words zero): the
+// reference's bucket-bound decision per row, patches by value; d_undecided[entry] != 0: some valid selected unpatched row
+// could not be decided (Err(NeedsBacking)).  Adds the entries' hits to d_counts / *d_total_out.
+hipError_t launch_float_quant_pred(const FixedDesc* d_descs, int lane_log2, const FixedPred& pred, const ScanLaunch& L,
+                                   uint32_t* d_undecided, hipStream_t stream);
 hipError_t launch_str_entry_offsets(const StrDesc* d_descs, const ScanLaunch& L, uint32_t* d_entry_counts, uint64_t* d_tiles,
                                     uint64_t* d_entry_row_offsets, hipStream_t stream);
 hipError_t launch_str_sel_rows(const StrDesc* d_descs, const DevSymtab* d_symtabs, const ScanLaunch& L,

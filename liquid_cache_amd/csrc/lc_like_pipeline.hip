@@ -69,6 +69,9 @@ static_assert(kLeanWaves >= 1 && kLeanWaves <= 4, "a LeanRec holds eight entries
 #ifndef LC_LEAN_STOP
 #define LC_LEAN_STOP 0
 #endif
+#ifndef LC_LEAN_XCD
+#define LC_LEAN_XCD 1
+#endif
 constexpr uint32_t kMaxPlans = 8;
 // a needle is "selective" (worth this kernel) up to this many hit rows per 1024 rows of the scan
 constexpr uint32_t kMaxHitsPer1024 = 16;
@@ -93,6 +96,7 @@ namespace {
 
 struct LeanArgs {
     const LeanRec* recs;
+    uint32_t n_recs;
     const uint8_t* automata;
     uint32_t automaton_stride;
     uint32_t nl;
@@ -129,7 +133,21 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
     if (LC_LEAN_STOP == -1) return;  // launch floor
     const uint32_t nl = a.nl;
     const uint32_t tbl_bytes = automaton_image_bytes(nl);
-    const LeanRec* rec = a.recs + blockIdx.x;
+    // XCD-aware record order: the hardware deals consecutive workgroups round-robin to the 8 XCDs (each with its own L2), and
+    // ~13 consecutive records share a symbol table — dealt by blockIdx every XCD would fetch every table's automaton image
+    // (PMC: 15 MB per launch).  Workgroup b takes record (b % 8) * ceil(G / 8) + b / 8: an XCD works through one contiguous
+    // eighth of the scan, a table's image is fetched by one or two L2s.
+#if LC_LEAN_XCD
+    const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
+    const uint32_t rec_idx = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    if (rec_idx >= a.n_recs) {  // (the grid is rounded up to a multiple of 8; every wave of it reports to the COUNT(*))
+        if (a.total.d_total_out && lane == 0) total_contribute(a.total, blockIdx.x * kLeanWaves + wave, gridDim.x * kLeanWaves, 0);
+        return;
+    }
+#else
+    const uint32_t rec_idx = blockIdx.x;
+#endif
+    const LeanRec* rec = a.recs + rec_idx;
     // the wave's entries: begin + kLeanE * wave (+ 1); their fields come with the record header in one round of scalar loads
     ConstLeanPtr EA = reinterpret_cast<ConstLeanPtr>(reinterpret_cast<uintptr_t>(&rec->e[kLeanE * wave]));
     ConstLeanPtr EB = reinterpret_cast<ConstLeanPtr>(reinterpret_cast<uintptr_t>(&rec->e[kLeanE * wave + (kLeanE - 1u)]));
@@ -424,7 +442,8 @@ hipError_t launch_lean(int n_sig, bool negated, const LeanArgs& a, uint32_t n_re
         {k_like_lean<1, true>, k_like_lean<2, true>, k_like_lean<3, true>, k_like_lean<4, true>, k_like_lean<5, true>,
          k_like_lean<6, true>, k_like_lean<7, true>, k_like_lean<8, true>}};
     const size_t lds = automaton_image_bytes(a.nl) + kLeanWaves * (kLeanE * (kPostMaxRows / 8u) + kLeanCap * 4u + 80u);
-    hipLaunchKernelGGL(table[negated ? 1 : 0][n_sig - 1], dim3(n_recs), dim3(kLeanWaves * 64), lds, stream, a);
+    const uint32_t grid = LC_LEAN_XCD ? (n_recs + 7u) / 8u * 8u : n_recs;
+    hipLaunchKernelGGL(table[negated ? 1 : 0][n_sig - 1], dim3(grid), dim3(kLeanWaves * 64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -470,6 +489,7 @@ lc_status run_lean(LikePipeline* lp, const StrPred& p, const ScanLaunch& L, hipS
                    unsigned long long* d_stats = nullptr, bool force_like = false) {
     LeanArgs la{};
     la.recs = lp->d_lean;
+    la.n_recs = lp->n_lean;
     la.automata = p.automata;
     la.automaton_stride = p.automaton_stride;
     la.nl = p.needle_len;

@@ -955,7 +955,7 @@ lc_status lc_entry_info_get(lc_ctx* ctx, uint64_t entry_id, lc_entry_info* out) 
     out->squeezed_date_field = e.squeezed_field;
     out->clamped_from_bit_width = e.clamped ? e.orig_W : 0;
     out->quantized_from_bit_width = e.quantized ? e.orig_W : 0;
-    out->quantized_bucket_width = e.quantized ? e.bucket_width : 0;
+    out->quantized_bucket_width = e.quantized ? (e.fq_shift > 0 ? (uint64_t(1) << e.fq_shift) : e.bucket_width) : 0;
     out->algorithmic_pred_bytes = e.is_str ? 0 : fixed_alg_bytes(e, false);
     return LC_OK;
     });
@@ -1676,6 +1676,8 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             max_len = std::max(max_len, e.len);
             if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
             s->has_clamped |= e.clamped || e.quantized;
+            s->has_fquant |= e.fq_shift > 0;
+            s->fquant_patches |= e.fq_shift > 0 && e.fd.patch_len > 0;
             s->max_dict_len = std::max(s->max_dict_len, e.dict_len);
             s->any_fingerprints |= e.has_fp;
             if (e.is_str) {
@@ -1784,6 +1786,10 @@ static lc_status clamp_unresolved_entries(lc_ctx* ctx, lc_scan* s, const FixedPr
     for (uint32_t i = 0; i < s->n; i++) {
         const Entry& e = s->meta[i];
         if (e.all_null) continue;
+        if (e.fq_shift > 0) {  // float-quantized: reads need the backing, predicates are decided by k_float_quant_pred
+            if (!preds) out->push_back(i);
+            continue;
+        }
         if (e.quantized) {
             if (!preds) out->push_back(i);
             else { suspects.push_back(i); any_quantized = true; }
@@ -1898,6 +1904,31 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         if (s->any_patch) {
             LC_HIP(launch_alp_patch_fix(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, pred2 ? &fp2 : nullptr, L,
                                         stream));
+        }
+        if (s->has_fquant) {
+            // float-quantized hybrids (the kernels above wrote zeros for them): the reference's bucket-bound decision;
+            // an entry with an undecidable valid selected row answers Err(NeedsBacking) (float_array.rs:924-929)
+            if (pred2) return fail(LC_UNSUPPORTED, "fused conjuncts are not evaluated on float-quantized entries");
+            if (d_selection && s->fquant_patches)
+                return fail(LC_UNSUPPORTED, "a selection over a float-quantized entry with ALP exceptions has no defined result in "
+                                            "the reference (its patch indices are not re-based, float_array.rs:772-792)");
+            uint32_t* d_und = static_cast<uint32_t*>(pool_alloc(ctx, size_t(s->n) * 4));
+            if (!d_und) return fail(LC_ERR_OOM, "hipMalloc (float quantize flags)");
+            struct Tmp {
+                lc_ctx* c; void* p; hipStream_t st;
+                ~Tmp() { (void)hipStreamSynchronize(st); pool_release(c, p); }
+            } tmp{ctx, d_und, stream};
+            LC_HIP(hipMemsetAsync(d_und, 0, size_t(s->n) * 4, stream));
+            LC_HIP(launch_float_quant_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, L, d_und, stream));
+            std::vector<uint32_t> und(s->n, 0);
+            LC_HIP(hipMemcpyAsync(und.data(), d_und, size_t(s->n) * 4, hipMemcpyDeviceToHost, stream));
+            LC_HIP(hipStreamSynchronize(stream));
+            std::lock_guard<std::mutex> g(s->mu);
+            for (uint32_t i = 0; i < s->n; i++)
+                if (und[i]) s->needs_backing.push_back(i);
+            std::sort(s->needs_backing.begin(), s->needs_backing.end());
+            if (!s->needs_backing.empty() && !tolerate_backing)
+                return fail(LC_NEEDS_BACKING, "a float-quantized entry holds a row whose bucket does not decide this predicate");
         }
         return LC_OK;
     }
@@ -3151,6 +3182,174 @@ lc_status lc_squeeze_date(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, in
 // least 8 bits per value are re-packed IN HBM at half their width; offsets at or above the sentinel 2^(W/2) - 1 are
 // stored as the sentinel.  Entries that do not qualify (narrower, all null, floats / decimals, already squeezed) are
 // left as they are.  *out_squeezed (optional) receives how many entries were squeezed.
+// LiquidFloatArray::squeeze, FloatSqueezePolicy::Quantize (float_array.rs:338-395): new width = W / 2, shift = W - W / 2, a row
+// keeps ((reference + offset) >> shift) - (reference >> shift).  That bucket can be 2^(W/2) — one more than the new width
+// holds — whenever (reference mod 2^shift) + max offset carries into bit W; what the reference's packer makes of such a
+// value is the business of the fastlanes crate (not in the tree), so those entries are left unsqueezed here: results stay
+// exact and nothing is claimed about undefined behaviour.  Gather of the offsets, bucket arithmetic and packing run on the
+// device; validity and the ALP exceptions move to the new blob unchanged.
+static lc_status squeeze_float_quantize(lc_ctx* ctx, const std::vector<uint64_t>& all_ids, uint64_t* out_done) {
+    std::map<int, std::vector<uint64_t>> by_lane;
+    {
+        std::shared_lock<std::shared_mutex> g(ctx->mu);
+        for (uint64_t id : all_ids) {
+            auto it = ctx->entries.find(id);
+            if (it != ctx->entries.end()) by_lane[it->second.fd.lane_log2].push_back(id);
+        }
+    }
+    for (auto& kv : by_lane) {
+        const std::vector<uint64_t>& ids = kv.second;
+        lc_scan* scan = nullptr;
+        lc_status rc = scan_create_impl(ctx, ids.size(), ids.data(), &scan, false);
+        if (rc != LC_OK) return rc;
+        std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
+        const uint64_t rows = scan->total_rows, m = scan->n;
+        const size_t vw = size_t(1) << (scan->lane_log2 - 3);
+        const size_t nblk = size_t(m) * scan->bpe;
+        std::vector<FixedDesc> zero_ref(m);
+        for (uint64_t i = 0; i < m; i++) {  // plain unsigned offsets: no reference, no ALP decode, no patches
+            zero_ref[i] = scan->meta[i].fd;
+            zero_ref[i].reference = 0;
+            zero_ref[i].kind = kKindInt;
+            zero_ref[i].is_signed = 0;
+            zero_ref[i].patch_len = 0;
+            zero_ref[i].patch_idx = nullptr;
+            zero_ref[i].patch_val = nullptr;
+            zero_ref[i].value_width = uint8_t(vw);
+        }
+        FixedDesc* d_descs0 = static_cast<FixedDesc*>(pool_alloc(ctx, m * sizeof(FixedDesc)));
+        uint8_t* d_vals = static_cast<uint8_t*>(pool_alloc(ctx, std::max<uint64_t>(rows, 1) * vw + 64));
+        uint8_t* d_scr = static_cast<uint8_t*>(pool_alloc(ctx, nblk * 4 + fixed_gather_offsets_len(nblk) * 8 + (m + 1) * 8 + 64));
+        EncodeDesc* d_enc = static_cast<EncodeDesc*>(pool_alloc(ctx, m * sizeof(EncodeDesc)));
+        EncodeMinMax* d_mm = static_cast<EncodeMinMax*>(pool_alloc(ctx, m * sizeof(EncodeMinMax)));
+        struct Bufs {
+            lc_ctx* c; void* p[5];
+            ~Bufs() { (void)hipDeviceSynchronize(); for (void* q : p) pool_release(c, q); }
+        } bufs{ctx, {d_descs0, d_vals, d_scr, d_enc, d_mm}};
+        if (!d_descs0 || !d_vals || !d_scr || !d_enc || !d_mm) return fail(LC_ERR_OOM, "hipMalloc (float quantize scratch)");
+        LC_HIP(hipMemcpy(d_descs0, zero_ref.data(), m * sizeof(FixedDesc), hipMemcpyHostToDevice));
+        uint64_t* d_bo = reinterpret_cast<uint64_t*>(d_scr);
+        uint64_t* d_eo = d_bo + fixed_gather_offsets_len(nblk);
+        uint32_t* d_bc = reinterpret_cast<uint32_t*>(d_eo + m + 1);
+        ScanLaunch L{};
+        L.n_entries = uint32_t(m);
+        L.blocks_per_entry = scan->bpe;
+        LC_HIP(launch_fixed_gather(d_descs0, scan->lane_log2, L, d_bc, d_bo, d_eo, d_vals, std::max<uint64_t>(rows, 1), nullptr));
+        // largest offset of every entry -> largest bucket
+        std::vector<EncodeDesc> enc(m);
+        uint64_t row0 = 0;
+        for (uint64_t i = 0; i < m; i++) {
+            const Entry& e = scan->meta[i];
+            enc[i] = EncodeDesc{};
+            enc[i].values = d_vals + row0 * vw;
+            enc[i].validity = nullptr;  // null slots hold whatever offset the packer stored: they are bucketed like the rest
+            enc[i].n = e.len;
+            enc[i].value_log2 = uint8_t(scan->lane_log2 - 3);
+            row0 += e.len;
+        }
+        LC_HIP(hipMemcpy(d_enc, enc.data(), m * sizeof(EncodeDesc), hipMemcpyHostToDevice));
+        LC_HIP(launch_col_minmax(d_enc, uint32_t(m), d_mm, nullptr));
+        std::vector<EncodeMinMax> mm(m);
+        LC_HIP(hipMemcpy(mm.data(), d_mm, m * sizeof(EncodeMinMax), hipMemcpyDeviceToHost));
+        struct Lay { bool take; int new_w, shift; size_t begin, packed, valid, pidx, pval, bytes; };
+        std::vector<Lay> lay(m);
+        size_t total = 0;
+        uint32_t max_rows = 0;
+        for (uint64_t i = 0; i < m; i++) {
+            const Entry& e = scan->meta[i];
+            Lay& y = lay[i];
+            y = Lay{};
+            y.new_w = e.W / 2;
+            y.shift = e.W - y.new_w;
+            const int lane_bits = int(vw) * 8;
+            // signed arithmetic in the lane width, as the reference's
+            auto sx = [&](uint64_t v) { return lane_bits == 32 ? int64_t(int32_t(uint32_t(v))) : int64_t(v); };
+            const int64_t ref = sx(e.fd.reference);
+            const int64_t top = lane_bits == 32 ? int64_t(int32_t(uint32_t(uint64_t(ref) + mm[i].mx))) : int64_t(uint64_t(ref) + mm[i].mx);
+            const uint64_t max_bucket = uint64_t((top >> y.shift) - (ref >> y.shift));
+            y.take = max_bucket < (uint64_t(1) << y.new_w);
+            if (!y.take) continue;
+            y.begin = align_up(total, kSectionAlign);
+            size_t cur = y.begin;
+            y.packed = cur;
+            cur = align_up(cur + packed_bytes(y.new_w, e.len) + 128, kSectionAlign);
+            y.valid = y.pidx = y.pval = size_t(-1);
+            if (e.fd.validity) { y.valid = cur; cur = align_up(cur + ((size_t(e.len) + 63) / 64) * 8, kSectionAlign); }
+            if (e.fd.patch_len) {
+                y.pidx = cur;
+                cur = align_up(cur + size_t(e.fd.patch_len) * 8, kSectionAlign);
+                y.pval = cur;
+                cur = align_up(cur + size_t(e.fd.patch_len) * vw, kSectionAlign);
+            }
+            y.bytes = cur - y.begin;
+            total = cur;
+            max_rows = std::max(max_rows, e.len);
+        }
+        uint64_t n_take = 0;
+        for (const Lay& y : lay) n_take += y.take;
+        if (n_take == 0) continue;
+        total = align_up(total, kSectionAlign) + 256;
+        ArenaReservation reserved(ctx);
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        uint8_t* dbase = nullptr;
+        int slab = -1;
+        rc = arena_alloc(ctx, total, &dbase, &slab);
+        if (rc != LC_OK) return rc;
+        ctx->slabs[size_t(slab)].live += int64_t(n_take) - 1;
+        reserved.arm(slab, int64_t(n_take));
+        LC_HIP(hipMemsetAsync(dbase, 0, total, nullptr));
+        std::vector<EncodeDesc> pack;
+        for (uint64_t i = 0; i < m; i++) {
+            if (!lay[i].take) continue;
+            const Entry& e = scan->meta[i];
+            EncodeDesc d = enc[i];
+            d.W = uint8_t(lay[i].new_w);
+            d.reference = 0;
+            d.packed = dbase + lay[i].packed;
+            d.fq_shift = uint8_t(lay[i].shift);
+            d.fq_ref = e.fd.reference;
+            pack.push_back(d);
+            if (e.fd.validity)
+                LC_HIP(hipMemcpyAsync(dbase + lay[i].valid, e.fd.validity, ((size_t(e.len) + 63) / 64) * 8, hipMemcpyDeviceToDevice, nullptr));
+            if (e.fd.patch_len) {
+                LC_HIP(hipMemcpyAsync(dbase + lay[i].pidx, e.fd.patch_idx, size_t(e.fd.patch_len) * 8, hipMemcpyDeviceToDevice, nullptr));
+                LC_HIP(hipMemcpyAsync(dbase + lay[i].pval, e.fd.patch_val, size_t(e.fd.patch_len) * vw, hipMemcpyDeviceToDevice, nullptr));
+            }
+        }
+        LC_HIP(hipMemcpy(d_enc, pack.data(), pack.size() * sizeof(EncodeDesc), hipMemcpyHostToDevice));
+        LC_HIP(launch_fl_pack(d_enc, uint32_t(pack.size()), max_rows, scan->lane_log2, nullptr));
+        LC_HIP(hipDeviceSynchronize());
+        for (uint64_t i = 0; i < m; i++) {
+            if (!lay[i].take) continue;
+            Entry e = scan->meta[i];  // type, length, ALP exponents, reference stay
+            e.fd.mask_word_off = 0;
+            e.orig_W = e.W;
+            e.W = lay[i].new_w;
+            e.fd.W = uint8_t(lay[i].new_w);
+            e.fd.quantized = uint8_t(0x80u | uint32_t(lay[i].shift));
+            e.quantized = true;
+            e.fq_shift = lay[i].shift;
+            e.slab = slab;
+            e.device_bytes = lay[i].bytes;
+            e.fd.packed = dbase + lay[i].packed;
+            e.fd.validity = lay[i].valid == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + lay[i].valid);
+            e.fd.patch_idx = lay[i].pidx == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + lay[i].pidx);
+            e.fd.patch_val = lay[i].pval == size_t(-1) ? nullptr : dbase + lay[i].pval;
+            auto old = ctx->entries.find(ids[i]);
+            if (old != ctx->entries.end()) {
+                ctx->entry_bytes -= old->second.device_bytes;
+                arena_release(ctx, old->second.slab);  // the scan above still pins the old blob until it is destroyed
+                ctx->entries.erase(old);
+            }
+            ctx->entry_bytes += e.device_bytes;
+            ctx->entries.emplace(ids[i], std::move(e));
+        }
+        reserved.disarm();
+        if (out_done) *out_done += n_take;
+    }
+    return LC_OK;
+}
+
 static lc_status squeeze_half_width(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, uint64_t* out_squeezed, bool quantize) {
     return guarded([&]() -> lc_status {
     if (!ctx || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
@@ -3160,6 +3359,7 @@ static lc_status squeeze_half_width(lc_ctx* ctx, uint64_t n, const uint64_t* ent
     LC_HIP(hipSetDevice(ctx->device));
     // entries that qualify, grouped by lane width (a scan covers one lane type)
     std::map<int, std::vector<uint64_t>> by_lane;
+    std::vector<uint64_t> float_ids;
     {
         std::shared_lock<std::shared_mutex> g(ctx->mu);
         for (uint64_t i = 0; i < n; i++) {
@@ -3167,6 +3367,11 @@ static lc_status squeeze_half_width(lc_ctx* ctx, uint64_t n, const uint64_t* ent
             if (it == ctx->entries.end()) return fail(LC_NOT_STAGED, "entry is not staged");
             const Entry& e = it->second;
             // integers (both policies) and decimals (LiquidDecimalArray::squeeze always quantizes, decimal_array.rs:300-345)
+            const bool is_float = e.fd.kind == kKindF32 || e.fd.kind == kKindF64;
+            if (quantize && is_float && !e.is_str && !e.all_null && e.W >= 8 && !e.quantized) {
+                float_ids.push_back(entry_ids[i]);  // FloatSqueezePolicy::Quantize, the only float policy (float_array.rs:61-65)
+                continue;
+            }
             const bool kind_ok = e.fd.kind == kKindInt || (quantize && e.fd.kind == kKindDecimal);
             if (e.is_str || !kind_ok || e.all_null || e.W < 8 || e.clamped || e.quantized || e.squeezed_field >= 0) continue;
             // Date32 / Timestamp arrays are never half-width squeezed by the reference: their squeeze() only knows the
@@ -3238,6 +3443,12 @@ static lc_status squeeze_half_width(lc_ctx* ctx, uint64_t n, const uint64_t* ent
         rc = device_encode_and_register(ctx, items);
         if (rc != LC_OK) return rc;
         if (out_squeezed) *out_squeezed += m;
+    }
+    if (!float_ids.empty()) {
+        uint64_t done = 0;
+        const lc_status rc = squeeze_float_quantize(ctx, float_ids, &done);
+        if (rc != LC_OK) return rc;
+        if (out_squeezed) *out_squeezed += done;
     }
     return LC_OK;
     });

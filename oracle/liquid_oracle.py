@@ -619,3 +619,125 @@ def quantized_eval(buckets, validity, reference: int, width: int, op: int, k: in
                 out.append(equal)
     has_nulls = validity is not None
     return BoolResult(np.array(out, dtype=bool), np.array([valid[i] for i in rows], dtype=bool) if has_nulls else None)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Float Quantize squeeze (test infrastructure)
+#   squeeze:   LiquidFloatArray::squeeze, FloatSqueezePolicy::Quantize            float_array.rs:338-395
+#   predicate: LiquidFloatQuantizedArray::try_eval_predicate_inner                float_array.rs:825-953
+#   selection: try_eval_predicate filters the buckets first (filter_inner :786-792) but keeps the UNFILTERED patch indices
+#              (new_from_filtered :772-784), so with patches a selection has no well-defined result: not restated.
+# Restated as written, including that the bucket bounds are computed as (bucket << shift) + reference (:919-922) although
+# the buckets were cut at multiples of 2^shift of the ABSOLUTE encoded value (:363-368) — the bounds sit
+# reference mod 2^shift too high.
+# ------------------------------------------------------------------------------------------------------------------
+_F10_32 = [np.float32(x) for x in (1.0, 10.0, 100.0, 1000.0, 10000.0, 100000.0, 1000000.0, 10000000.0, 100000000.0,
+                                   1000000000.0, 10000000000.0)]
+_IF10_32 = [np.float32(x) for x in (1.0, 0.1, 0.01, 0.001, 0.0001, 0.00001, 0.000001, 0.0000001, 0.00000001,
+                                    0.000000001, 0.0000000001)]
+
+
+def _wrap(v: int, bits: int) -> int:
+    v &= (1 << bits) - 1
+    return v - (1 << bits) if v >> (bits - 1) else v
+
+
+def _alp_decode(i: int, e: int, f: int, bits: int):
+    """LiquidFloatType::decode_single (float_array.rs:109-125): (i as F) * F10[f] * IF10[e], no fused multiply-add."""
+    if bits == 32:
+        return np.float32(np.float32(np.float32(i) * _F10_32[f]) * _IF10_32[e])
+    return np.float64(np.float64(i) * _F10_64[f]) * _IF10_64[e]
+
+
+_F10_64 = [np.float64(float("1e%d" % k)) for k in range(24)]
+_IF10_64 = [np.float64(float("1e-%d" % k)) for k in range(24)]
+
+
+def float_parts(liquid: bytes):
+    """(info, packed-domain offsets as python ints, validity bools | None, patch indices, patch values) of a LiquidFloatArray."""
+    info = array_info(liquid)
+    assert info.logical == LOGICAL_FLOAT
+    a = _u8(liquid)
+    n = info.len
+    sec = int(info.bitpacked_off)
+    has_nulls = int(a[sec + 5])
+    nulls_len = int(np.frombuffer(a[sec + 6: sec + 10].tobytes(), np.uint32)[0])
+    values_len = int(np.frombuffer(a[sec + 10: sec + 14].tobytes(), np.uint32)[0])
+    voff = sec + ((16 + nulls_len + 7) // 8) * 8
+    udt = np.uint32 if info.phys == 8 else np.uint64
+    if info.all_null or info.bit_width == 0:
+        offs = [0] * n
+    else:
+        offs = [int(x) for x in bitunpack(a[voff: voff + values_len], info.bit_width, n, udt)]
+    valid = unpack_bits(a[sec + 16: sec + 16 + nulls_len], n).tolist() if has_nulls else None
+    pl = int(info.patch_len)
+    pidx = np.frombuffer(a[int(info.patch_indices_off): int(info.patch_indices_off) + 8 * pl].tobytes(), np.uint64).tolist()
+    fdt = np.float32 if info.phys == 8 else np.float64
+    w = 4 if info.phys == 8 else 8
+    pval = np.frombuffer(a[int(info.patch_values_off): int(info.patch_values_off) + w * pl].tobytes(), fdt).copy()
+    return info, offs, valid, pidx, pval
+
+
+def float_quantize_squeeze(liquid: bytes):
+    """dict(buckets, shift, new_bw, reference, e, f, bits, validity, patch_idx, patch_val, overflow) or None when the
+    array is not squeezable (no bit width or < 8 bits, float_array.rs:343-346)."""
+    info, offs, valid, pidx, pval = float_parts(liquid)
+    if info.all_null or info.bit_width < 8:
+        return None
+    bits = 32 if info.phys == 8 else 64
+    ref = _wrap(int(info.reference), bits)
+    new_bw = info.bit_width // 2
+    shift = info.bit_width - new_bw
+    qmin = ref >> shift
+    buckets = [(_wrap(_wrap(ref + o, bits) >> shift, bits) - qmin) & ((1 << bits) - 1) for o in offs]
+    return dict(buckets=buckets, shift=shift, new_bw=new_bw, reference=ref, e=info.alp_e, f=info.alp_f, bits=bits,
+                validity=valid, patch_idx=[int(i) for i in pidx], patch_val=pval,
+                overflow=any(b >= (1 << new_bw) for b in buckets))
+
+
+def float_quantized_eval(q, op: int, k, selection=None) -> BoolResult:
+    """try_eval_predicate (filter_inner, then try_eval_predicate_inner): BoolResult over the selected rows, or raises
+    NeedsBacking when a valid, unpatched, selected row's bucket bounds do not decide the comparison.  A selection over an
+    array WITH patches is not restated (see the header of this section)."""
+    if selection is not None:
+        if q["patch_idx"]:
+            raise ValueError("selection over a float-quantized array with patches: undefined in the reference")
+        keep = [i for i, s_ in enumerate(selection) if s_]
+        q = dict(q, buckets=[q["buckets"][i] for i in keep],
+                 validity=None if q["validity"] is None else [q["validity"][i] for i in keep])
+    bits = q["bits"]
+    ft = np.float32 if bits == 32 else np.float64
+    k = ft(k)
+    n = len(q["buckets"])
+    valid = [True] * n if q["validity"] is None else q["validity"]
+    patched = set(q["patch_idx"])
+    out = [False] * n
+
+    def decide(lo, hi):
+        if op == EQ:
+            return False if (k < lo or k > hi) else None
+        if op == NE:
+            return True if (k < lo or k > hi) else None
+        if op == LT:
+            return False if k <= lo else (True if hi < k else None)
+        if op == LE:
+            return False if k < lo else (True if hi <= k else None)
+        if op == GT:
+            return True if k < lo else (False if hi <= k else None)
+        return True if k <= lo else (False if hi < k else None)
+
+    with np.errstate(all="ignore"):
+        for i, b in enumerate(q["buckets"]):
+            if not valid[i] or i in patched:
+                continue
+            lo_i = _wrap((b << q["shift"]) + q["reference"], bits)
+            hi_i = _wrap(((b + 1) << q["shift"]) + q["reference"], bits)
+            d = decide(_alp_decode(lo_i, q["e"], q["f"], bits), _alp_decode(hi_i, q["e"], q["f"], bits))
+            if d is None:
+                raise NeedsBacking()
+            out[i] = bool(d)
+        for i, pv in zip(q["patch_idx"], q["patch_val"]):
+            pv = ft(pv)
+            out[i] = bool({EQ: pv == k, NE: pv != k, LT: pv < k, LE: pv <= k, GT: pv > k, GE: pv >= k}[op])
+    vals = np.array(out, bool)
+    return BoolResult(vals, None if q["validity"] is None else np.array(valid, bool))

@@ -35,7 +35,8 @@ for k, kb in calib.items():
     factors[shape] = CALIB_BYTES / (kb * 1024.0) if kb else None
 out["fetch_size_calibration"] = {"bytes_per_launch": CALIB_BYTES, "real_bytes_per_reported_byte": factors}
 # dominant access shape of each kernel family
-SHAPE = {"k_str_pred": "coalesced8", "k_fixed_pred_reg": "coalesced4", "k_fixed_pred": "coalesced16"}
+SHAPE = {"k_str_pred": "coalesced8", "k_like_lean": "coalesced8", "k_fixed_pred_reg": "coalesced4", "k_fixed_pred": "coalesced16",
+         "k_fixed_chain": "coalesced4"}
 for d in sorted(glob.glob(os.path.join(root, "*_FETCH_SIZE"))):
     wl = os.path.basename(d)[: -len("_FETCH_SIZE")]
     if wl == "calib":
@@ -43,8 +44,7 @@ for d in sorted(glob.glob(os.path.join(root, "*_FETCH_SIZE"))):
     fetch, n = medians(wl + "_FETCH_SIZE")
     write, _ = medians(wl + "_WRITE_SIZE")
     for k, kb in fetch.items():
-        fam = "k_fixed_pred_reg" if "k_fixed_pred_reg" in k else ("k_fixed_pred" if "k_fixed_pred" in k else
-                                                                  ("k_str_pred" if "k_str_pred" in k else None))
+        fam = next((f for f in ("k_fixed_pred_reg", "k_fixed_pred", "k_fixed_chain", "k_str_pred", "k_like_lean") if f in k), None)
         if fam is None:
             continue
         factor = factors.get(SHAPE[fam]) or 2.0
