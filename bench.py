@@ -329,6 +329,33 @@ def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_ex
     res = {"query": "q21.sql pushdown: SearchPhrase <> '' -> URL LIKE '%%%s%%' -> get(URL), get(SearchPhrase)" % args.needle,
            "ms": ms, "rows_per_s": url_scan.rows / (ms * 1e-3), "rows_after_searchphrase": n_ne,
            "rows_out": out["rows_out"], "url_bytes_out": out["url_bytes"], "phrase_bytes_out": out["phrase_bytes"]}
+    # the step after the path: GROUP BY "SearchPhrase" with MIN("URL") and COUNT(*) as per-entry partials on the device
+    # (lc_scan_group_partials) instead of handing the selected strings to a host-side partial aggregate
+    try:
+        pcap = max(k_out, 1) + 64
+        partials = torch.zeros((pcap, 4), dtype=torch.int32, device="cuda")
+        n_part = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+        def run_partials():
+            sp_scan.eval(ne_expr, m1.data_ptr(), 0, c1.data_ptr(), stream)
+            url_scan.eval(like_expr, m2.data_ptr(), m1.data_ptr(), counts.data_ptr(), stream)
+            sp_scan.group_partials(url_scan, partials.data_ptr(), pcap, n_part.data_ptr(), m2.data_ptr(), False, stream)
+
+        for _ in range(2):
+            run_partials()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run_partials()
+        torch.cuda.synchronize()
+        res["ms_with_group_partials"] = (time.perf_counter() - t0) / iters * 1e3
+        npart = int(n_part.item())
+        p = partials[:npart].cpu().numpy().view(np.uint32)
+        res["group_partials"] = npart
+        res["group_partials_rows_covered"] = int(p[:, 2].sum())  # == rows_out: every selected row is in exactly one partial
+        assert res["group_partials_rows_covered"] == k_out and npart <= k_out
+    except Exception as e:  # noqa: BLE001
+        res["group_partials_error"] = "%s: %s" % (type(e).__name__, e)
     sp_scan.close()
     return res
 

@@ -331,6 +331,30 @@ LC_API lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_sel
 LC_API lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, const void* d_selection,
                                      void* d_out /* lc_aggregate */, void* stream);
 
+/* Partial GROUP BY over a byte-view column with COUNT(*) and MIN / MAX of a second byte-view column — the step after the
+ * path for ClickBench q21.sql (`SELECT "SearchPhrase", MIN("URL"), COUNT(*) ... WHERE <pushed-down filter> GROUP BY
+ * "SearchPhrase"`): what DataFusion's AggregateExec(mode = Partial) computes from the rows get().with_selection() returns,
+ * without returning them.  group_scan and value_scan (NULL: COUNT only) cover the same row ranges.  For the rows that
+ * d_selection selects (NULL: all) every entry is grouped by the group column's dictionary key (inside a batch equal keys
+ * are equal strings) and one lc_group_partial per (entry, group) is appended to d_partials:
+ *   entry       scan index of the entry
+ *   group_row   the first selected row of the group in that entry (its group value — NULL for the group of null rows —
+ *               is what lc_scan_gather_bytes decodes for the row reference (entry << 32 | group_row))
+ *   count       selected rows of the group, null values of the value column included (COUNT(*))
+ *   best_row    the row that holds the smallest (want_max: largest) NON-NULL value of the value column among them, byte-wise
+ *               order as Arrow's min / max of a string array; 0xFFFFFFFF if every value is null (or no value_scan)
+ * *d_n_partials (u64, device; zeroed by the call) receives how many partials the selection produces; records beyond
+ * `capacity` are dropped — compare and retry with a larger buffer.  An entry may emit several partials for one group
+ * (more than 704 distinct groups among its selected rows): partials merge by value like those of different entries.
+ * The final aggregate (merging partials whose group strings are equal) is the caller's, as it is DataFusion's final
+ * AggregateExec's.  Order of the records is unspecified.  Asynchronous on `stream`. */
+typedef struct {
+    uint32_t entry, group_row, count, best_row;
+} lc_group_partial;
+LC_API lc_status lc_scan_group_partials(lc_ctx* ctx, lc_scan* group_scan, lc_scan* value_scan, int32_t want_max,
+                                        const void* d_selection, void* d_partials, uint64_t capacity, void* d_n_partials,
+                                        void* stream);
+
 /* Squeeze Date32 / Timestamp entries to ONE calendar component (LiquidPrimitiveArray::squeeze with the hint
  * CacheExpression::extract_date32(field), primitive_array.rs:389-420 -> SqueezedDate32Array, squeezed_date32_array.rs:
  * 46-221): the entry is replaced in HBM by the component, frame-of-reference + bit-packed on u32 lanes (TPC-H ship dates

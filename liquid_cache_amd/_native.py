@@ -66,7 +66,7 @@ ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offse
 
 # every symbol include/liquid_cache_amd.h declares (tests check that the built library exports all of them)
 EXPORTED_SYMBOLS = [
-    "lc_ctx_create", "lc_ctx_destroy", "lc_ctx_set_option", "lc_entry_index_to_bytes", "lc_stage_indexed", "lc_scan_explain", "lc_comm_unique_id", "lc_comm_init",
+    "lc_ctx_create", "lc_ctx_destroy", "lc_ctx_set_option", "lc_entry_index_to_bytes", "lc_stage_indexed", "lc_scan_explain", "lc_scan_group_partials", "lc_comm_unique_id", "lc_comm_init",
     "lc_comm_destroy", "lc_comm_rank", "lc_comm_world", "lc_comm_allreduce_count", "lc_comm_allgather_mask", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
@@ -171,6 +171,7 @@ def load():
     L.lc_comm_world.restype = i32; L.lc_comm_world.argtypes = [vp]
     L.lc_comm_allreduce_count.restype = i32; L.lc_comm_allreduce_count.argtypes = [vp, vp, vp]
     L.lc_comm_allgather_mask.restype = i32; L.lc_comm_allgather_mask.argtypes = [vp, vp, u64, vp, P(u64), vp]
+    L.lc_scan_group_partials.restype = i32; L.lc_scan_group_partials.argtypes = [vp, vp, vp, i32, vp, vp, u64, vp, vp]
     L.lc_scan_explain.restype = i32; L.lc_scan_explain.argtypes = [vp, P(Predicate), C.c_char_p, sz]
     L.lc_scan_segment_offsets.restype = P(u64); L.lc_scan_segment_offsets.argtypes = [vp]
     L.lc_scan_eval.restype = i32; L.lc_scan_eval.argtypes = [vp, vp, P(Predicate), vp, vp, vp, vp]

@@ -862,6 +862,46 @@ class Scan:
                     lib.lc_device_free(ctx, p)
         return vals[:k], offs
 
+    def group_partials(self, value_scan: Optional["Scan"], partials_ptr: int, capacity: int, n_ptr: int,
+                       selection_ptr: int = 0, want_max: bool = False, stream: int = 0):
+        """Partial GROUP BY this (byte-view) column with COUNT(*) and MIN / MAX of `value_scan` (lc_scan_group_partials)."""
+        N.check(self._lib.lc_scan_group_partials(self._cache.handle, self._h, value_scan._h if value_scan is not None else None,
+                                                 1 if want_max else 0, selection_ptr or None, partials_ptr or None, capacity,
+                                                 n_ptr, stream or None), self._cache.handle)
+
+    def group_partials_to_host(self, value_scan: Optional["Scan"] = None, selection: Optional[np.ndarray] = None,
+                               want_max: bool = False, capacity: int = 1 << 16):
+        """Convenience for tests: ndarray of (entry, group_row, count, best_row) u32 records (retries when `capacity` was
+        too small)."""
+        lib, ctx = self._lib, self._cache.handle
+        d_sel, d_n = C.c_void_p(), C.c_void_p()
+        N.check(lib.lc_device_alloc(ctx, 8, C.byref(d_n)), ctx)
+        try:
+            if selection is not None:
+                sel = np.ascontiguousarray(selection, dtype=np.uint64)
+                N.check(lib.lc_device_alloc(ctx, max(sel.size, 1) * 8, C.byref(d_sel)), ctx)
+                N.check(lib.lc_host_to_device(ctx, d_sel, sel.ctypes.data_as(C.c_void_p), sel.size * 8, None), ctx)
+            while True:
+                d_p = C.c_void_p()
+                N.check(lib.lc_device_alloc(ctx, max(capacity, 1) * 16, C.byref(d_p)), ctx)
+                try:
+                    self.group_partials(value_scan, d_p.value, capacity, d_n.value, d_sel.value or 0, want_max)
+                    n = np.zeros(1, np.uint64)
+                    N.check(lib.lc_device_to_host(ctx, n.ctypes.data_as(C.c_void_p), d_n, 8, None), ctx)
+                    k = int(n[0])
+                    if k <= capacity:
+                        out = np.zeros((max(k, 1), 4), np.uint32)
+                        if k:
+                            N.check(lib.lc_device_to_host(ctx, out.ctypes.data_as(C.c_void_p), d_p, k * 16, None), ctx)
+                        return out[:k]
+                    capacity = k
+                finally:
+                    lib.lc_device_free(ctx, d_p)
+        finally:
+            for p in (d_sel, d_n):
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+
     def eval_to_host(self, expr: LiquidExpr, selection: Optional[np.ndarray] = None):
         """Convenience for tests: runs the scan and returns (mask words as uint64 ndarray, per-entry counts)."""
         lib, ctx = self._lib, self._cache.handle

@@ -153,5 +153,49 @@ __device__ __forceinline__ uint32_t walk8(uint32_t sb, const uint32_t (&x)[8], u
 }
 
 
+// offsets of dictionary entries i and i+1 with ONE (unaligned, 8-byte) load: the residual width only selects shifts,
+// so there is no branch between the load and its use (sections are padded, reading a few bytes past is safe)
+template <typename D>
+__device__ __forceinline__ void str_offset_pair(const D& d, uint32_t i, uint32_t& start, uint32_t& stop) {
+    const uint32_t ob = d.offset_bytes;  // 1, 2 or 4
+    const uint64_t v = load_unaligned<uint64_t>(d.residuals + size_t(i) * ob);
+    const uint32_t sh = 32u - 8u * ob;
+    const int32_t r0 = int32_t(uint32_t(v) << sh) >> sh;
+    const int32_t r1 = int32_t(uint32_t(v >> (8u * ob)) << sh) >> sh;
+    start = uint32_t(d.slope) * i + uint32_t(d.intercept) + uint32_t(r0);
+    stop = uint32_t(d.slope) * (i + 1u) + uint32_t(d.intercept) + uint32_t(r1);
+}
+
+
+
+// Decoding iterator over one FSST-compressed value: position in the code stream + byte index inside the current symbol
+// (raw/fsst_buffer.rs:642-663: code 255 escapes the next byte; a dangling escape marker is ignored).
+struct FsstIter {
+    uint32_t pos, stop;  // next code, end of the value
+    uint64_t sym;        // bytes of the current symbol
+    uint32_t len, k;     // its length, index of the current byte
+    bool at_end;
+};
+__device__ __forceinline__ void fsst_iter_load(FsstIter& it, const DevSymtab& st, const uint8_t* __restrict__ fsst) {
+    while (it.pos < it.stop) {
+        const uint32_t c = fsst[it.pos++];
+        if (c == 255u) {
+            if (it.pos >= it.stop) break;  // dangling escape marker: ignored, like the reference decoder
+            it.sym = fsst[it.pos++];
+            it.len = 1;
+        } else {
+            it.sym = st.sym[c];
+            it.len = st.len[c];
+        }
+        it.k = 0;
+        if (it.len) return;
+    }
+    it.at_end = true;
+}
+__device__ __forceinline__ uint32_t fsst_iter_cur(const FsstIter& it) { return uint32_t(it.sym >> (8u * it.k)) & 0xFFu; }
+__device__ __forceinline__ void fsst_iter_next(FsstIter& it, const DevSymtab& st, const uint8_t* __restrict__ fsst) {
+    if (++it.k == it.len) fsst_iter_load(it, st, fsst);
+}
+
 }  // namespace
 }  // namespace lc

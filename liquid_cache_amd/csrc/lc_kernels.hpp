@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include "../../include/liquid_cache_amd.h"
+
 // Ablation hooks (skip a kernel phase, replace counts by timestamps) are compiled ONLY into profiling builds
 // (`make ABLATION=1`): in the shipped library no environment variable can change a result.
 #ifdef LC_ABLATION
@@ -319,6 +321,10 @@ hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, cons
                                 hipStream_t stream);
 // byte-view get-with-selection of ONE entry: d_dict_len (D u32 scratch), d_offsets (n+1 i32), d_rows (n u32 scratch),
 // d_totals (2 u64: selected rows, data bytes), d_data (>= uncompressed bytes of the referenced values + 8)
+// partial GROUP BY over dictionary keys (lc_groupby.hip)
+hipError_t launch_group_partials(const StrDesc* g_descs, const StrDesc* v_descs, const DevSymtab* symtabs, const uint64_t* selection,
+                                 uint32_t n_entries, int want_max, lc_group_partial* out, uint64_t capacity,
+                                 unsigned long long* n_out, hipStream_t stream);
 hipError_t launch_str_gather(const StrDesc* d_descs, const DevSymtab* d_symtabs, uint32_t entry, uint32_t dict_len,
                              uint32_t n_rows, const uint64_t* d_selection, uint32_t* d_dict_len, int32_t* d_offsets,
                              uint32_t* d_rows, uint64_t* d_totals, uint8_t* d_data, hipStream_t stream);

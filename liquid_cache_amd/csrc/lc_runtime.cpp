@@ -2074,6 +2074,31 @@ lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection,
     });
 }
 
+lc_status lc_scan_group_partials(lc_ctx* ctx, lc_scan* group_scan, lc_scan* value_scan, int32_t want_max, const void* d_selection,
+                                 void* d_partials, uint64_t capacity, void* d_n_partials, void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !group_scan || !d_n_partials || (capacity && !d_partials)) return fail(LC_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LC_HIP(hipMemsetAsync(d_n_partials, 0, 8, st));
+    if (group_scan->n == 0) return LC_OK;
+    if (!group_scan->is_str || (value_scan && !value_scan->is_str))
+        return fail(LC_UNSUPPORTED, "group partials take byte-view (string / binary) columns");
+    if (value_scan && (value_scan->ctx != group_scan->ctx || value_scan->lens != group_scan->lens))
+        return fail(LC_ERR_INVALID, "the two scans must cover the same row ranges (same entry lengths)");
+    for (lc_scan* s : {group_scan, value_scan}) {
+        if (!s) continue;
+        std::lock_guard<std::mutex> g(s->mu);
+        scan_enter_stream(s, st);
+    }
+    LC_HIP(launch_group_partials(static_cast<const StrDesc*>(group_scan->d_descs),
+                                 value_scan ? static_cast<const StrDesc*>(value_scan->d_descs) : nullptr,
+                                 value_scan ? value_scan->d_symtabs : group_scan->d_symtabs, static_cast<const uint64_t*>(d_selection),
+                                 group_scan->n, want_max ? 1 : 0, static_cast<lc_group_partial*>(d_partials), capacity,
+                                 static_cast<unsigned long long*>(d_n_partials), st));
+    return LC_OK;
+    });
+}
+
 lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, const void* d_selection, void* d_out,
                               void* stream) {
     return guarded([&]() -> lc_status {

@@ -404,3 +404,82 @@ def test_float_quantize_hybrid(product_lib, oracle, ftype, dtype):
         assert n_squeezed >= 2 and n_needs > 0 and n_decided > 20, (n_squeezed, n_needs, n_decided)
     finally:
         cache.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# partial GROUP BY with COUNT(*) / MIN / MAX over byte views (the step after the path for q21.sql)
+# ------------------------------------------------------------------------------------------------------------------
+def _expected_partials(groups, values, sel, want_max):
+    """Per entry: {group value: (count, best value | None, first row of the group, earliest row holding the best value)}."""
+    out = {}
+    for r in np.flatnonzero(sel):
+        gv, vv = groups[r], values[r] if values is not None else None
+        cnt, best, first, brow = out.get(gv, (0, None, int(r), None))
+        cnt += 1
+        if vv is not None and (best is None or (vv > best if want_max else vv < best)):
+            best, brow = vv, int(r)
+        out[gv] = (cnt, best, first, brow)
+    return out
+
+
+@pytest.mark.parametrize("want_max", [False, True])
+def test_group_partials_count_min_max(product_lib, oracle, want_max):
+    lo = oracle
+    cache = lc.LiquidCacheBuilder.new().build()
+    try:
+        rng = np.random.default_rng(31 + int(want_max))
+        phrases = ["", "погода", "google maps", "купить авто", "a", "ab", "ab\0", "abcdefg", "abcdefgh", "abcdefgi",
+                   "abcdefg" + "x" * 300, "abcdefg" + "x" * 299 + "y"] + ["phrase %d" % i for i in range(40)]
+        shapes = [(8192, 50, True, 0.002), (8192, 50, True, 0.9), (3000, 2500, False, 1.0), (65, 5, True, 0.5), (8192, 30, False, 0.0)]
+        g_ids, v_ids, data = [], [], []
+        for b, (n, n_groups, nulls, p_sel) in enumerate(shapes):
+            pool = phrases[:n_groups] if n_groups <= len(phrases) else phrases + ["uniq-%05d" % i for i in range(n_groups - len(phrases))]
+            groups = [pool[int(k)] for k in np.minimum(rng.zipf(1.2, size=n) - 1, len(pool) - 1)]
+            if b == 2:  # ~1,750 distinct groups in one entry: more than the kernel's table takes at once
+                groups = [pool[int(k)] for k in rng.integers(0, len(pool), size=n)]
+            urls = fz._pool_urls(rng, 600)
+            # values that agree on the shared prefix + 7 bytes and differ later, shorter / longer twins, empty
+            urls += [b"http://yandex.ru/search?p=1", b"http://yandex.ru/search?p=10", b"http://yandex.ru/searc", b"http://y", b"",
+                     b"http://yandex.ru/search?p=1\xff"]
+            values = [urls[int(k)] for k in rng.integers(0, len(urls), size=n)]
+            if nulls:
+                for i in rng.choice(n, size=n // 20, replace=False):
+                    groups[int(i)] = None
+                for i in rng.choice(n, size=n // 10, replace=False):
+                    values[int(i)] = None
+            ge, ve = lc.ParquetArrayID.new(50, b, 1, 0), lc.ParquetArrayID.new(50, b, 2, 0)
+            cache.insert(ge, pa.array(groups, type=pa.string()))
+            cache.insert(ve, pa.array(values, type=pa.binary()), HINT)
+            g_ids.append(ge)
+            v_ids.append(ve)
+            data.append((groups, values, rng.random(n) < p_sel))
+        gs, vs = cache.scan(g_ids), cache.scan(v_ids)
+        offs = gs.segment_offsets
+        words = np.zeros(int(gs.mask_words), np.uint64)
+        for b, (_, _, se) in enumerate(data):
+            packed = np.packbits(se, bitorder="little")
+            words[int(offs[b]): int(offs[b + 1])].view(np.uint8)[: len(packed)] = packed
+        for use_sel, use_values in ((True, True), (False, True), (True, False)):
+            recs = gs.group_partials_to_host(vs if use_values else None, words if use_sel else None, want_max, capacity=64)
+            got = {}
+            for entry, grow, cnt, brow in recs.tolist():
+                groups, values, se = data[entry]
+                key = (entry, groups[grow])
+                bv = None if brow == 0xFFFFFFFF else values[brow]
+                if key in got:   # an entry may emit several partials for a group (table flush): they merge by value
+                    c0, b0, g0, r0 = got[key]
+                    if bv is not None and (b0 is None or (bv > b0 if want_max else bv < b0) or (bv == b0 and brow < r0)):
+                        b0, r0 = bv, brow
+                    got[key] = (c0 + cnt, b0, min(g0, grow), r0)
+                else:
+                    got[key] = (cnt, bv, grow, None if brow == 0xFFFFFFFF else brow)
+            want = {}
+            for entry, (groups, values, se) in enumerate(data):
+                sel = se if use_sel else np.ones(len(groups), bool)
+                for gv, t in _expected_partials(groups, values if use_values else None, sel, want_max).items():
+                    want[(entry, gv)] = t
+            assert got == want, (want_max, use_sel, use_values, len(got), len(want))
+            if not use_sel:
+                assert len({r[1] for r in recs.tolist() if r[0] == 2}) > 704  # the table was emitted more than once
+    finally:
+        cache.close()
