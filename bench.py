@@ -112,12 +112,15 @@ def stage_url_column(cache, lc, N, args, rank, n_batches, threads, file_id=None)
         offs = np.zeros(bs + 1, np.int32)
         data = np.zeros(bs * 512, np.uint8)
         first = rg * args.row_group_batches
+        arrs, bids = [], []
         for b in range(first, min(first + args.row_group_batches, n_batches)):
             rows = min(bs, rows_total - b * bs)
             n = N.load_bench().lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
                                      offs.ctypes.data, data.ctypes.data, data.size)
-            arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
-            cache.insert(ids[b], arr, None if args.no_fingerprints else lc.CacheExpression.SUBSTRING_SEARCH)
+            arrs.append(pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1].copy()), pa.py_buffer(data[:n].copy())))
+            bids.append(ids[b])
+        # the batches of one row group go in together: one upload and one signature-builder launch per row group
+        cache.insert_batch(bids, arrs, None if args.no_fingerprints else lc.CacheExpression.SUBSTRING_SEARCH)
         return rg
 
     n_rg = (n_batches + args.row_group_batches - 1) // args.row_group_batches

@@ -205,6 +205,13 @@ LC_API lc_status lc_transcode_arrow(lc_ctx* ctx, const struct ArrowArray* array,
 /* cache.insert(entry_id, array) with eager transcoding (benchmark/README.md:42 `liquid_eager_transcode`). */
 LC_API lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArray* array,
                                  const struct ArrowSchema* schema, int32_t hint, uint64_t path_id);
+/* The same for `n` arrays in one call (typically the batches of one row group): the arrays are transcoded one after the
+ * other on the calling thread, then staged together — one upload, ONE launch of the signature builder for all of them, one
+ * publication.  A column inserted entry by entry pays a ~80 us builder launch per entry (12,207 launches for the 100 M-row
+ * URL column); callers that parallelise staging give every thread whole row groups.  hints / path_ids may be NULL. */
+LC_API lc_status lc_insert_arrow_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids,
+                                       const struct ArrowArray* const* arrays, const struct ArrowSchema* const* schemas,
+                                       const int32_t* hints, const uint64_t* path_ids);
 /* Arrow -> Liquid transcoding ON THE DEVICE for integer-like arrays (Int8..UInt64, Date32/64, Timestamp without zone),
  * Decimal128 / Decimal256 arrays and Float32 / Float64 arrays: the raw values cross PCIe once; min / max (frame of
  * reference, bit width), the ALP exponent search on the reference's sample, encoding, exception (patch) extraction and

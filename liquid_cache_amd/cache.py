@@ -419,6 +419,31 @@ class LiquidCache:
         N.check(st, self._ctx)
         self._types[int(entry_id)] = batch_to_cache.type
 
+    def insert_batch(self, entry_ids: Sequence[int], arrays: Sequence[pa.Array], squeeze_hint: Optional[int] = None,
+                     path_ids: Optional[Sequence[int]] = None):
+        """`cache.insert` for the batches of one row group in ONE call (lc_insert_arrow_batch): transcoded one after the
+        other, staged together (one upload, one signature-builder launch)."""
+        n = len(entry_ids)
+        c_arrs = [N.ArrowArray() for _ in range(n)]
+        c_schemas = [N.ArrowSchema() for _ in range(n)]
+        arrays = [a.combine_chunks() if isinstance(a, pa.ChunkedArray) else a for a in arrays]
+        try:
+            for a, ca, cs in zip(arrays, c_arrs, c_schemas):
+                a._export_to_c(C.addressof(ca), C.addressof(cs))
+            ids = (C.c_uint64 * n)(*[int(e) for e in entry_ids])
+            ap = (C.c_void_p * n)(*[C.addressof(x) for x in c_arrs])
+            sp = (C.c_void_p * n)(*[C.addressof(x) for x in c_schemas])
+            hints = (C.c_int32 * n)(*([squeeze_hint or N.HINT_NONE] * n))
+            pids = (C.c_uint64 * n)(*[int(ParquetArrayID.column_access_path(e) if path_ids is None else path_ids[i])
+                                      for i, e in enumerate(entry_ids)])
+            st = self._lib.lc_insert_arrow_batch(self._ctx, n, ids, ap, sp, hints, pids)
+        finally:
+            for ca, cs in zip(c_arrs, c_schemas):
+                _release(ca, cs)
+        N.check(st, self._ctx)
+        for e, a in zip(entry_ids, arrays):
+            self._types[int(e)] = a.type
+
     def insert_device(self, entry_ids: Sequence[int], arrays: Sequence[pa.Array]):
         """`cache.insert` for a batch of integer-like arrays with the transcoding done ON THE DEVICE
         (lc_insert_arrow_device): raw values cross PCIe once, min / max and FastLanes packing run as kernels.  Raises

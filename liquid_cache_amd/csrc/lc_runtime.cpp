@@ -991,6 +991,27 @@ lc_status lc_insert_arrow(lc_ctx* ctx, uint64_t entry_id, const struct ArrowArra
     });
 }
 
+lc_status lc_insert_arrow_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const struct ArrowArray* const* arrays,
+                                const struct ArrowSchema* const* schemas, const int32_t* hints, const uint64_t* path_ids) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || (n && (!entry_ids || !arrays || !schemas))) return fail(LC_ERR_INVALID, "null argument");
+    // transcode every array (host), then ONE lc_stage: one upload, one signature-builder launch, one publication
+    CtxSymtabs st(ctx);
+    std::vector<std::vector<uint8_t>> blobs(n);
+    std::vector<const uint8_t*> ptrs(n);
+    std::vector<size_t> lens(n);
+    std::vector<uint64_t> paths(n, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        paths[i] = path_ids ? path_ids[i] : 0;
+        const lc_status rc = transcode_arrow(arrays[i], schemas[i], hints ? hints[i] : LC_HINT_NONE, st, paths[i], blobs[i]);
+        if (rc != LC_OK) return fail(rc, "array type is not transcoded to a Liquid encoding");
+        ptrs[i] = blobs[i].data();
+        lens[i] = blobs[i].size();
+    }
+    return lc_stage(ctx, n, entry_ids, ptrs.data(), lens.data(), paths.data());
+    });
+}
+
 // ------------------------------------------------------------------ on-device transcoder (fixed-width integers)
 static int int_phys_of_format(const char* f) {
     if (!f) return -1;

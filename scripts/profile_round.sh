@@ -8,7 +8,7 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # one column, back to back (rocprof averages then describe hot launches; the cold figures come from the bench line itself)
-B="python $R/bench.py --no-secondary --no-needle-classes --no-cold --rotate 1 --steps 20 --warmup 3"
+B="python $R/bench.py --no-secondary --no-needle-classes --no-cpu-baseline --no-cold --rotate 1 --steps 20 --warmup 3"
 declare -A WL
 WL[url_like]="--workload url_like"
 WL[url_like_k_str_pred]="--workload url_like --like-path 1"
@@ -23,7 +23,7 @@ run_one() {  # name, env prefix, args
   f=$(find $O/${wl}_trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${wl}_kernel_stats.csv
   grep -h '^{"metric"' $O/${wl}_trace.log > $O/${wl}_bench_line.json
   for c in FETCH_SIZE WRITE_SIZE; do
-    env $envp timeout 240 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_str_pred|k_fixed_pred|k_like_lean|k_fixed_chain" --output-format csv -d $O/${wl}_$c -- $B $a --no-cpu-baseline --steps 3 --warmup 1 > $O/${wl}_$c.log 2>&1
+    env $envp timeout 240 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_str_pred|k_fixed_pred|k_like_lean|k_fixed_chain" --output-format csv -d $O/${wl}_$c -- $B $a --steps 3 --warmup 1 > $O/${wl}_$c.log 2>&1
   done
 }
 # WORKLOADS="url_like date32_gt_w12" scripts/profile_round.sh <tag>: only these (a partial refresh after a kernel change)

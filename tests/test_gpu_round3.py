@@ -483,3 +483,26 @@ def test_group_partials_count_min_max(product_lib, oracle, want_max):
                 assert len({r[1] for r in recs.tolist() if r[0] == 2}) > 704  # the table was emitted more than once
     finally:
         cache.close()
+
+
+def test_insert_batch_equals_single_inserts(product_lib, oracle):
+    """lc_insert_arrow_batch: the batches of a row group staged in one call hold the same bytes (Liquid bytes and the
+    acceleration index) as entries inserted one by one, strings and numbers mixed."""
+    cache = lc.LiquidCacheBuilder.new().build()
+    try:
+        rng = np.random.default_rng(5)
+        arrays = [pa.array([u.decode() for u in fz._pool_urls(rng, 300)] * 3) for _ in range(4)]
+        arrays.append(pa.array(rng.integers(0, 1000, size=900)))
+        single = [lc.ParquetArrayID.new(60, 0, 7, b) for b in range(5)]
+        batch = [lc.ParquetArrayID.new(61, 0, 7, b) for b in range(5)]
+        for e, a in zip(single, arrays):
+            cache.insert(e, a, HINT if pa.types.is_string(a.type) else None, path_id=777)
+        cache.insert_batch(batch, arrays, HINT, path_ids=[777] * 5)
+        for s_, b_ in zip(single, batch):
+            assert cache.entry_bytes(s_) == cache.entry_bytes(b_)
+            assert cache.entry_index_bytes(s_) == cache.entry_index_bytes(b_)
+        expr = lc.LiquidExpr.try_new("like", "%google%", pa.string(), HINT)
+        for s_, b_ in zip(single[:4], batch[:4]):
+            assert cache.eval_predicate(s_, expr).read().equals(cache.eval_predicate(b_, expr).read())
+    finally:
+        cache.close()
