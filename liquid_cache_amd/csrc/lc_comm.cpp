@@ -101,15 +101,27 @@ struct lc_comm {
 
 namespace {
 
-void shm_barrier(lc_comm* c) {
+// false: a rank did not arrive within the time limit (it died: the others must not spin forever)
+constexpr int kShmTimeoutSeconds = 120;
+template <typename Cond>
+bool spin_until(Cond&& done) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t i = 0; !done(); i++) {
+        std::this_thread::yield();
+        if ((i & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(kShmTimeoutSeconds)) return false;
+    }
+    return true;
+}
+
+bool shm_barrier(lc_comm* c) {
     ShmHeader* h = c->shm;
     c->local_sense ^= 1u;
     if (h->barrier_count.fetch_add(1, std::memory_order_acq_rel) + 1 == uint32_t(c->world)) {
         h->barrier_count.store(0, std::memory_order_relaxed);
         h->barrier_sense.store(c->local_sense, std::memory_order_release);
-    } else {
-        while (h->barrier_sense.load(std::memory_order_acquire) != c->local_sense) std::this_thread::yield();
+        return true;
     }
+    return spin_until([&] { return h->barrier_sense.load(std::memory_order_acquire) == c->local_sense; });
 }
 
 }  // namespace
@@ -168,7 +180,10 @@ lc_status lc_comm_init(lc_ctx* ctx, int32_t rank, int32_t world, const uint8_t* 
         c->shm_data = static_cast<uint8_t*>(p) + sizeof(ShmHeader);
         c->shm->world = uint32_t(world);
         c->shm->arrived.fetch_add(1, std::memory_order_acq_rel);
-        while (c->shm->arrived.load(std::memory_order_acquire) < uint32_t(world)) std::this_thread::yield();
+        if (!spin_until([&] { return c->shm->arrived.load(std::memory_order_acquire) >= uint32_t(world); })) {
+            munmap(p, c->shm_bytes);
+            return fail(LC_ERR_DEVICE, "shared-memory communicator: not every rank arrived");
+        }
         *out = c.release();
         return LC_OK;
     }
@@ -189,7 +204,7 @@ void lc_comm_destroy(lc_comm* c) {
     try {
         if (c->rc) (void)rccl().CommDestroy(c->rc);
         if (c->shm) {
-            shm_barrier(c);
+            (void)shm_barrier(c);
             munmap(c->shm, c->shm_bytes);
             if (c->rank == 0) shm_unlink(c->shm_name.c_str());
         }
@@ -208,10 +223,10 @@ lc_status lc_comm_allreduce_count(lc_comm* c, void* d_total, void* stream) {
         uint64_t v;
         std::memcpy(&v, d_total, 8);
         c->shm->slots[c->rank] = v;
-        shm_barrier(c);
+        if (!shm_barrier(c)) return fail(LC_ERR_DEVICE, "shared-memory communicator: a rank did not arrive");
         uint64_t sum = 0;
         for (int r = 0; r < c->world; r++) sum += c->shm->slots[r];
-        shm_barrier(c);  // nobody overwrites a slot before everybody has read it
+        if (!shm_barrier(c)) return fail(LC_ERR_DEVICE, "shared-memory communicator: a rank did not arrive");  // (slots are reused)
         std::memcpy(d_total, &sum, 8);
         return LC_OK;
     }
@@ -235,9 +250,9 @@ lc_status lc_comm_allgather_mask(lc_comm* c, const void* d_mask_local, uint64_t 
     if (c->shm) {
         if (total * 8 > kShmData) return fail(LC_ERR_INVALID, "mask too large for the shared-memory test backend");
         std::memcpy(c->shm_data + my_off * 8, d_mask_local, size_t(local_words) * 8);
-        shm_barrier(c);
+        if (!shm_barrier(c)) return fail(LC_ERR_DEVICE, "shared-memory communicator: a rank did not arrive");
         std::memcpy(d_mask_all, c->shm_data, size_t(total) * 8);
-        shm_barrier(c);
+        if (!shm_barrier(c)) return fail(LC_ERR_DEVICE, "shared-memory communicator: a rank did not arrive");
         return LC_OK;
     }
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(kThreads) void k_float_quant_pred(const FixedDesc* 
                 hits += uint32_t(__popcll(hitw));
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // the words stored above are in memory before the atomics below touch them
         // patch rows: decided by value
         int delta = 0;
         for (uint32_t kk = uint32_t(lane); kk < d.patch_len; kk += kWave) {
