@@ -218,11 +218,21 @@ LC_API lc_status lc_insert_arrow_batch(lc_ctx* ctx, uint64_t n, const uint64_t* 
  * the FastLanes packing run as kernels (LiquidPrimitiveArray::from_arrow_array, primitive_array.rs:159-206;
  * LiquidDecimalArray::from_decimal_array, decimal_array.rs:127-177; LiquidFloatArray::from_arrow_array,
  * float_array.rs:590-740; BitPackedArray::from_primitive, bit_pack_array.rs:71-124).  The staged entries are
- * byte-identical to what lc_insert_arrow stages (checked through lc_entry_to_liquid_bytes).  LC_UNSUPPORTED for other
- * array types (byte views: the dictionary / FSST encoder stays on the host) and for decimal arrays with a value that
- * does not fit a u64 (the reference's fits_u64, decimal_array.rs:120-125): use lc_insert_arrow. */
+ * byte-identical to what lc_insert_arrow stages (checked through lc_entry_to_liquid_bytes).
+ * Utf8 / Binary arrays (i32 offsets, up to 65536 rows) become LiquidByteViewArrays on the device as well
+ * (LiquidByteViewArray::from_string_array, byte_view_array/conversions.rs:260-373): dictionary in first-occurrence order,
+ * FSST compression of the dictionary values with the path's symbol table (trained on the host from the first array of a
+ * path, transcode.rs:16-33 — training is once per column chunk, encoding is per batch), shared prefix, prefix keys,
+ * fingerprints, compact offsets, and the acceleration index (signatures, row lists).  Without hints / path ids
+ * (lc_insert_arrow_device) byte views get no fingerprints and path 0.
+ * LC_UNSUPPORTED for other array types (views, large offsets, dictionaries), for decimal arrays with a value that does not
+ * fit a u64 (the reference's fits_u64, decimal_array.rs:120-125), and for a byte-view array whose offset line fit would
+ * round in f64 (sums above 2^53: gigabyte-sized batches): use lc_insert_arrow.  All-or-nothing per array class. */
 LC_API lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids,
                                         const struct ArrowArray* const* arrays, const struct ArrowSchema* const* schemas);
+LC_API lc_status lc_insert_arrow_batch_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids,
+                                              const struct ArrowArray* const* arrays, const struct ArrowSchema* const* schemas,
+                                              const int32_t* hints, const uint64_t* path_ids);
 /* LiquidArray::to_bytes() of a staged entry, rebuilt from HBM (malloc'ed; release with lc_free): what the reference
  * writes to its disk tier when an entry is squeezed or evicted (core.rs:246, :314).  Fixed-width entries
  * (primitive_array.rs:603-679, decimal_array.rs:197-220, float_array.rs:397-519) and byte views

@@ -66,7 +66,7 @@ ArrowArray._fields_ = [("length", C.c_int64), ("null_count", C.c_int64), ("offse
 
 # every symbol include/liquid_cache_amd.h declares (tests check that the built library exports all of them)
 EXPORTED_SYMBOLS = [
-    "lc_ctx_create", "lc_ctx_destroy", "lc_ctx_set_option", "lc_entry_index_to_bytes", "lc_stage_indexed", "lc_scan_explain", "lc_scan_group_partials", "lc_insert_arrow_batch", "lc_comm_unique_id", "lc_comm_init",
+    "lc_ctx_create", "lc_ctx_destroy", "lc_ctx_set_option", "lc_entry_index_to_bytes", "lc_stage_indexed", "lc_scan_explain", "lc_scan_group_partials", "lc_insert_arrow_batch", "lc_insert_arrow_batch_device", "lc_comm_unique_id", "lc_comm_init",
     "lc_comm_destroy", "lc_comm_rank", "lc_comm_world", "lc_comm_allreduce_count", "lc_comm_allgather_mask", "lc_last_error", "lc_device_info_get", "lc_version", "lc_symtab_set",
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
@@ -136,6 +136,7 @@ def load():
     L.lc_insert_arrow.restype = i32; L.lc_insert_arrow.argtypes = [vp, u64, vp, vp, i32, u64]
     L.lc_insert_arrow_batch.restype = i32; L.lc_insert_arrow_batch.argtypes = [vp, u64, P(u64), P(vp), P(vp), P(i32), P(u64)]
     L.lc_insert_arrow_device.restype = i32; L.lc_insert_arrow_device.argtypes = [vp, u64, P(u64), P(vp), P(vp)]
+    L.lc_insert_arrow_batch_device.restype = i32; L.lc_insert_arrow_batch_device.argtypes = [vp, u64, P(u64), P(vp), P(vp), P(i32), P(u64)]
     L.lc_entry_to_liquid_bytes.restype = i32; L.lc_entry_to_liquid_bytes.argtypes = [vp, u64, P(vp), P(sz)]
     L.lc_squeeze_clamp.restype = i32; L.lc_squeeze_clamp.argtypes = [vp, u64, P(u64), P(u64)]
     L.lc_scan_eval_filter.restype = i32; L.lc_scan_eval_filter.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, P(vp), vp]

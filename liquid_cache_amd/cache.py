@@ -444,9 +444,11 @@ class LiquidCache:
         for e, a in zip(entry_ids, arrays):
             self._types[int(e)] = a.type
 
-    def insert_device(self, entry_ids: Sequence[int], arrays: Sequence[pa.Array]):
-        """`cache.insert` for a batch of integer-like arrays with the transcoding done ON THE DEVICE
-        (lc_insert_arrow_device): raw values cross PCIe once, min / max and FastLanes packing run as kernels.  Raises
+    def insert_device(self, entry_ids: Sequence[int], arrays: Sequence[pa.Array], squeeze_hint: Optional[int] = None,
+                      path_ids: Optional[Sequence[int]] = None):
+        """`cache.insert` for a batch of arrays with the transcoding done ON THE DEVICE (lc_insert_arrow_batch_device):
+        raw values cross PCIe once; min / max, ALP, FastLanes packing and — for Utf8 / Binary arrays — the dictionary,
+        FSST compression, prefix keys, fingerprints and compact offsets run as kernels.  Raises
         LiquidCacheError(LC_UNSUPPORTED) for other types (use `insert`)."""
         n = len(entry_ids)
         c_arrs = [N.ArrowArray() for _ in range(n)]
@@ -459,7 +461,10 @@ class LiquidCache:
             ids = (C.c_uint64 * n)(*[int(e) for e in entry_ids])
             ap = (C.c_void_p * n)(*[C.addressof(x) for x in c_arrs])
             sp = (C.c_void_p * n)(*[C.addressof(x) for x in c_schemas])
-            st = self._lib.lc_insert_arrow_device(self._ctx, n, ids, ap, sp)
+            hints = (C.c_int32 * n)(*([squeeze_hint or N.HINT_NONE] * n))
+            pids = (C.c_uint64 * n)(*[int(ParquetArrayID.column_access_path(e) if path_ids is None else path_ids[i])
+                                      for i, e in enumerate(entry_ids)])
+            st = self._lib.lc_insert_arrow_batch_device(self._ctx, n, ids, ap, sp, hints, pids)
         finally:
             for ca, cs in zip(c_arrs, c_schemas):
                 _release(ca, cs)

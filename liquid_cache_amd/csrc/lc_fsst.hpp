@@ -122,6 +122,26 @@ public:
         return e & 0xFF;
     }
 
+    // the matcher's tables for the device encoder (DevFsstEncoder, lc_kernels.hpp): same candidates in the same order
+    template <class Dev, class Hash2>
+    void export_device(Dev* d, uint32_t short2_slots, Hash2 hash2) const {
+        std::memset(d, 0, sizeof(Dev));
+        for (size_t i = 0; i < longs_.size(); i++) {
+            d->long_sym[i] = longs_[i].sym;
+            d->long_len[i] = longs_[i].len;
+            d->long_code[i] = longs_[i].code;
+        }
+        for (uint32_t h = 0; h <= kBuckets; h++) d->bucket[h] = uint8_t(bucket_[h]);  // <= 255 symbols
+        for (int b = 0; b < 256; b++) d->short1[b] = short1_[b] == kNone ? uint16_t(0xFFFF) : uint16_t(short1_[b] & 0xFF);
+        for (int c = 0; c < st_.n; c++) {
+            if (st_.len[c] != 2) continue;
+            const uint32_t key = uint16_t(st_.sym[c]);
+            uint32_t s = hash2(key);
+            while (d->short2[s] != 0 && ((d->short2[s] >> 8) & 0xFFFFu) != key) s = (s + 1) & (short2_slots - 1);
+            d->short2[s] = (1u << 31) | (key << 8) | uint32_t(c);  // a later code of the same two bytes wins, as in build()
+        }
+    }
+
 private:
     struct Long { uint64_t sym, mask; uint8_t len; uint8_t code; uint32_t h; };
     static constexpr uint16_t kNone = 0xFFFF;

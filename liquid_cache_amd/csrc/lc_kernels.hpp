@@ -329,4 +329,60 @@ hipError_t launch_str_gather(const StrDesc* d_descs, const DevSymtab* d_symtabs,
                              uint32_t n_rows, const uint64_t* d_selection, uint32_t* d_dict_len, int32_t* d_offsets,
                              uint32_t* d_rows, uint64_t* d_totals, uint8_t* d_data, hipStream_t stream);
 
+// ---- on-device byte-view transcoder (lc_bv_encode.hip) ----
+// FsstEncoder (lc_fsst.hpp) as the kernels read it: the symbols of >= 3 bytes in bucket order of their 3-byte-prefix hash
+// (longest first inside a bucket), the 2-byte symbols in a small open-addressing table, the 1-byte symbols by value.
+constexpr uint32_t kDevEncBuckets = 4096;
+constexpr uint32_t kDevEncShort2Slots = 1024;
+__host__ __device__ inline uint32_t dev_enc_short2_hash(uint32_t key16) { return ((key16 * 40503u) >> 4) & (kDevEncShort2Slots - 1); }
+struct DevFsstEncoder {
+    uint64_t long_sym[256];                 // masked to the symbol's length
+    uint32_t short2[kDevEncShort2Slots];    // 0: free, else 1 << 31 | two bytes << 8 | code
+    uint16_t short1[256];                   // 0xFFFF: none, else the code
+    uint8_t long_len[256];
+    uint8_t long_code[256];
+    uint8_t bucket[kDevEncBuckets + 8];     // long symbols of hash h: [bucket[h], bucket[h + 1])
+};
+struct BvEncodeStats {
+    uint64_t raw_bytes;       // sum of the dictionary values' lengths
+    uint32_t d;               // dictionary values
+    uint32_t fsst_len;        // compressed bytes
+    uint32_t shared_prefix_len;
+    int32_t slope, intercept; // compact offsets
+    uint32_t offset_bytes;    // 1 / 2 / 4
+    uint32_t inexact;         // the f64 sums of the reference's line fit would round (> 2^53): host path
+    uint32_t pad;
+};
+struct BvEncodeDesc {  // one Utf8 / Binary array (i32 offsets)
+    const int32_t* offsets;    // n + 1, as in the Arrow buffer (not rebased)
+    const uint8_t* data;       // bytes from offsets[0] on, 16 readable bytes behind the end
+    const uint64_t* validity;  // u64 words, or null
+    uint32_t* table;           // open addressing, table_mask + 1 slots preset to 0xFFFFFFFF
+    uint32_t* row_slot;        // n
+    uint32_t* dict_row;        // n: first row of dictionary value k
+    uint32_t* dict_index;      // n: dictionary index of a first-occurrence row
+    uint32_t* clen;            // n: compressed length of value k
+    uint32_t* offsets_out;     // n + 1: compressed offsets
+    uint32_t* fingerprints;    // n
+    uint16_t* keys;            // n
+    uint8_t* comp;             // 2 * data bytes + 16: value k compressed at twice its input position
+    BvEncodeStats* stats;
+    uint32_t n, table_mask, encoder, pad;
+};
+struct BvPackDesc {  // where k_bv_pack writes the entry (the sections of StrDesc, writable)
+    uint16_t* keys;
+    uint64_t* validity;        // null: not nullable
+    uint8_t* prefix_keys;
+    uint32_t* fingerprints;    // null: none
+    uint8_t* residuals;
+    uint8_t* fsst;
+    uint8_t* shared_prefix;
+    uint16_t* postings;        // null: no row lists
+    uint32_t d, shared_prefix_len, offset_bytes;
+    int32_t slope, intercept;
+    uint32_t pad;
+};
+hipError_t launch_bv_build(const BvEncodeDesc* d_descs, uint32_t n_arrays, const DevFsstEncoder* d_encoders, hipStream_t stream);
+hipError_t launch_bv_pack(const BvEncodeDesc* d_descs, const BvPackDesc* d_packs, uint32_t n_arrays, hipStream_t stream);
+
 }  // namespace lc

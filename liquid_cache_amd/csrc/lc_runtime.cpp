@@ -1385,12 +1385,354 @@ lc_status device_encode_floats(lc_ctx* ctx, std::vector<DevEncodeItem>& items) {
 }
 }  // namespace
 
+// ---- Utf8 / Binary arrays: dictionary, FSST, prefix keys, fingerprints, compact offsets and row lists on the device
+// (lc_bv_encode.hip).  All-or-nothing: nothing is published unless every array of the call could be encoded.
+struct BvItem {
+    uint64_t id = 0;
+    const struct ArrowArray* a = nullptr;
+    int arrow_type = 0;
+    bool want_fp = false;
+    uint64_t path_id = 0;
+    uint32_t slot = 0, encoder = 0;
+    uint32_t n = 0;
+    bool has_validity = false;
+    size_t data_len = 0;
+    uint32_t table_slots = 0;
+    // byte offsets inside the input staging buffer / the device scratch
+    size_t in_offsets = 0, in_data = 0, in_validity = 0;
+    size_t sc_table = 0, sc_row_slot = 0, sc_dict_row = 0, sc_dict_index = 0, sc_clen = 0, sc_offsets = 0, sc_fp = 0, sc_keys = 0, sc_comp = 0;
+};
+
+static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& items) {
+    const size_t m = items.size();
+    if (m == 0) return LC_OK;
+    // symbol tables: train-once-per-path from the first array of the path (transcode.rs:16-33), as lc_insert_arrow does
+    CtxSymtabs symtabs(ctx);
+    std::vector<uint32_t> enc_slots;
+    for (BvItem& it : items) {
+        const int32_t* o = static_cast<const int32_t*>(it.a->buffers[1]) + it.a->offset;
+        const uint8_t* data = static_cast<const uint8_t*>(it.a->buffers[2]);
+        if (!symtabs.find(it.path_id)) {
+            const uint8_t* validity = it.has_validity ? static_cast<const uint8_t*>(it.a->buffers[0]) : nullptr;
+            std::vector<std::pair<const uint8_t*, size_t>> train;
+            train.reserve(it.n);
+            for (uint32_t r = 0; r < it.n; r++) {
+                if (validity && !get_bit(validity, size_t(it.a->offset) + r)) continue;
+                train.emplace_back(data ? data + o[r] : reinterpret_cast<const uint8_t*>(""), size_t(o[r + 1] - o[r]));
+            }
+            symtabs.insert(it.path_id, fsst_train(train));
+        }
+        {
+            std::lock_guard<std::mutex> g(ctx->st_mu);
+            it.slot = ctx->symtab_slot.at(it.path_id);
+        }
+        size_t e = 0;
+        while (e < enc_slots.size() && enc_slots[e] != it.slot) e++;
+        if (e == enc_slots.size()) enc_slots.push_back(it.slot);
+        it.encoder = uint32_t(e);
+    }
+    {
+        const lc_status ss = sync_symtabs(ctx);  // the signature builder reads the device copies
+        if (ss != LC_OK) return ss;
+    }
+    // input staging (pinned) and device scratch layouts
+    size_t in_bytes = align_up(enc_slots.size() * sizeof(DevFsstEncoder), 256);
+    size_t sc_bytes = 0, table_bytes = 0;
+    for (BvItem& it : items) {
+        it.in_offsets = in_bytes;
+        in_bytes = align_up(in_bytes + (size_t(it.n) + 1) * 4, 16);
+        it.in_data = in_bytes;
+        in_bytes = align_up(in_bytes + it.data_len + 16, 16);
+        if (it.has_validity) {
+            it.in_validity = in_bytes;
+            in_bytes = align_up(in_bytes + ((size_t(it.n) + 63) / 64) * 8, 16);
+        }
+        it.table_slots = 64;
+        while (it.table_slots < it.n * 2u + 16u) it.table_slots <<= 1;
+        it.sc_table = table_bytes;  // the tables sit together at the front of the scratch: one memset
+        table_bytes += size_t(it.table_slots) * 4;
+    }
+    sc_bytes = align_up(table_bytes, 256);
+    for (BvItem& it : items) {
+        auto take = [&](size_t bytes) { const size_t at = sc_bytes; sc_bytes = align_up(sc_bytes + bytes, 16); return at; };
+        it.sc_row_slot = take(size_t(it.n) * 4);
+        it.sc_dict_row = take(size_t(it.n) * 4);
+        it.sc_dict_index = take(size_t(it.n) * 4);
+        it.sc_clen = take(size_t(it.n) * 4);
+        it.sc_offsets = take((size_t(it.n) + 1) * 4);
+        it.sc_fp = take(size_t(it.n) * 4);
+        it.sc_keys = take(size_t(it.n) * 2);
+        it.sc_comp = take(2 * it.data_len + 16);
+    }
+    const size_t sc_descs = sc_bytes;
+    sc_bytes = align_up(sc_bytes + m * sizeof(BvEncodeDesc), 256);
+    const size_t sc_packs = sc_bytes;
+    sc_bytes = align_up(sc_bytes + m * sizeof(BvPackDesc), 256);
+    const size_t sc_stats = sc_bytes;
+    sc_bytes = align_up(sc_bytes + m * sizeof(BvEncodeStats), 256);
+    in_bytes = align_up(in_bytes, 256);
+    uint8_t* h_in = static_cast<uint8_t*>(host_pool_alloc(ctx, in_bytes));
+    uint8_t* d_in = static_cast<uint8_t*>(pool_alloc(ctx, in_bytes));
+    uint8_t* d_sc = static_cast<uint8_t*>(pool_alloc(ctx, sc_bytes));
+    struct Bufs {
+        lc_ctx* c; void* h; void* d; void* s;
+        ~Bufs() { (void)hipDeviceSynchronize(); host_pool_release(c, h); pool_release(c, d); pool_release(c, s); }
+    } bufs{ctx, h_in, d_in, d_sc};
+    if (!h_in || !d_in || !d_sc) return fail(LC_ERR_OOM, "staging buffers of the on-device byte-view transcoder");
+    for (size_t e = 0; e < enc_slots.size(); e++) {
+        const SymbolTable* st;
+        {
+            std::lock_guard<std::mutex> g(ctx->st_mu);
+            st = ctx->symtabs[enc_slots[e]].get();  // unique_ptr targets are stable
+        }
+        FsstEncoder enc(*st);
+        enc.export_device(reinterpret_cast<DevFsstEncoder*>(h_in) + e, kDevEncShort2Slots, dev_enc_short2_hash);
+    }
+    for (const BvItem& it : items) {
+        const int32_t* o = static_cast<const int32_t*>(it.a->buffers[1]) + it.a->offset;
+        const uint8_t* data = static_cast<const uint8_t*>(it.a->buffers[2]);
+        std::memcpy(h_in + it.in_offsets, o, (size_t(it.n) + 1) * 4);
+        if (it.data_len) std::memcpy(h_in + it.in_data, data + o[0], it.data_len);
+        std::memset(h_in + it.in_data + it.data_len, 0, 16);
+        if (it.has_validity) {
+            const size_t words = (size_t(it.n) + 63) / 64;
+            std::memset(h_in + it.in_validity, 0, words * 8);
+            const uint8_t* src = static_cast<const uint8_t*>(it.a->buffers[0]);
+            uint8_t* dst = h_in + it.in_validity;
+            for (size_t k = 0; k < it.n; k++)
+                if (get_bit(src, size_t(it.a->offset) + k)) set_bit(dst, k);
+        }
+    }
+    hipStream_t side = stream_acquire(ctx);
+    struct StreamGuard {
+        lc_ctx* c; hipStream_t s;
+        ~StreamGuard() { (void)hipStreamSynchronize(s); stream_release(c, s); }
+    } sguard{ctx, side};
+    LC_HIP(hipMemcpyAsync(d_in, h_in, in_bytes, hipMemcpyHostToDevice, side));
+    LC_HIP(hipMemsetAsync(d_sc, 0xFF, table_bytes, side));
+    std::vector<BvEncodeDesc> descs(m);
+    for (size_t i = 0; i < m; i++) {
+        const BvItem& it = items[i];
+        BvEncodeDesc& d = descs[i];
+        d = BvEncodeDesc{};
+        d.offsets = reinterpret_cast<const int32_t*>(d_in + it.in_offsets);
+        d.data = d_in + it.in_data;
+        d.validity = it.has_validity ? reinterpret_cast<const uint64_t*>(d_in + it.in_validity) : nullptr;
+        d.table = reinterpret_cast<uint32_t*>(d_sc + it.sc_table);
+        d.row_slot = reinterpret_cast<uint32_t*>(d_sc + it.sc_row_slot);
+        d.dict_row = reinterpret_cast<uint32_t*>(d_sc + it.sc_dict_row);
+        d.dict_index = reinterpret_cast<uint32_t*>(d_sc + it.sc_dict_index);
+        d.clen = reinterpret_cast<uint32_t*>(d_sc + it.sc_clen);
+        d.offsets_out = reinterpret_cast<uint32_t*>(d_sc + it.sc_offsets);
+        d.fingerprints = reinterpret_cast<uint32_t*>(d_sc + it.sc_fp);
+        d.keys = reinterpret_cast<uint16_t*>(d_sc + it.sc_keys);
+        d.comp = d_sc + it.sc_comp;
+        d.stats = reinterpret_cast<BvEncodeStats*>(d_sc + sc_stats) + i;
+        d.n = it.n;
+        d.table_mask = it.table_slots - 1;
+        d.encoder = it.encoder;
+    }
+    BvEncodeDesc* d_descs = reinterpret_cast<BvEncodeDesc*>(d_sc + sc_descs);
+    LC_HIP(hipMemcpyAsync(d_descs, descs.data(), m * sizeof(BvEncodeDesc), hipMemcpyHostToDevice, side));
+    LC_HIP(launch_bv_build(d_descs, uint32_t(m), reinterpret_cast<const DevFsstEncoder*>(d_in), side));
+    std::vector<BvEncodeStats> stats(m);
+    LC_HIP(hipMemcpyAsync(stats.data(), d_sc + sc_stats, m * sizeof(BvEncodeStats), hipMemcpyDeviceToHost, side));
+    LC_HIP(hipStreamSynchronize(side));
+    for (size_t i = 0; i < m; i++) {
+        if (stats[i].inexact)
+            return fail(LC_UNSUPPORTED, "compact-offset fit of this array leaves the exact range of f64 sums: use lc_insert_arrow");
+        if (stats[i].d > 65536) return fail(LC_UNSUPPORTED, "more than 65536 distinct values in one array");
+    }
+    // layout of the entries' blob: the sections build_str lays out, in the same order with the same slack
+    struct Sections { size_t off[9]; size_t begin, bytes; };
+    std::vector<Sections> lay(m);
+    size_t total = 0;
+    for (size_t i = 0; i < m; i++) {
+        const BvItem& it = items[i];
+        const BvEncodeStats& st = stats[i];
+        Sections& L = lay[i];
+        for (size_t& o : L.off) o = size_t(-1);
+        L.begin = align_up(total, kSectionAlign);
+        size_t cur = L.begin;
+        auto add = [&](size_t bytes, size_t extra) { const size_t at = align_up(cur, kSectionAlign); cur = at + bytes + extra; return at; };
+        const size_t nw = std::max<size_t>((size_t(st.d) + 63) / 64, 1);
+        L.off[0] = add(size_t(it.n) * 2, 16);
+        if (it.has_validity) L.off[1] = add(((size_t(it.n) + 63) / 64) * 8, 0);
+        L.off[2] = add(size_t(st.d) * 8, 0);
+        const bool has_fp = it.want_fp && st.d > 0;  // an empty fingerprint section reads back as "none" (serialization.rs:209-218)
+        if (has_fp) L.off[3] = add(size_t(st.d) * 4, 0);
+        L.off[4] = add((size_t(st.d) + 1) * st.offset_bytes, 8);
+        L.off[5] = add(st.fsst_len, 16);
+        L.off[6] = add(st.shared_prefix_len, 8);
+        if (has_fp && ctx->build_signatures) {
+            L.off[7] = add(size_t(kSigBits) * nw * 8, 0);
+            if (ctx->build_postings && it.n <= kPostMaxRows && st.d > 0)
+                L.off[8] = add((size_t(st.d) + 1 + size_t(it.n) + 32) * 2, 16);
+        }
+        L.bytes = align_up(cur, kSectionAlign) - L.begin;
+        total = L.begin + L.bytes;
+    }
+    total = align_up(total, kSectionAlign) + 256;
+    uint8_t* dbase = nullptr;
+    int slab = -1;
+    ArenaReservation reserved(ctx);
+    {
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        const lc_status st = arena_alloc(ctx, total, &dbase, &slab);
+        if (st != LC_OK) return st;
+        ctx->slabs[size_t(slab)].live += int64_t(m) - 1;
+        reserved.arm(slab, int64_t(m));
+    }
+    LC_HIP(hipMemsetAsync(dbase, 0, total, side));  // slack behind sections, signature slices, spare list entries
+    std::vector<BvPackDesc> packs(m);
+    std::vector<Entry> entries(m);
+    std::vector<StrDesc> sig_descs;
+    for (size_t i = 0; i < m; i++) {
+        const BvItem& it = items[i];
+        const BvEncodeStats& st = stats[i];
+        const Sections& L = lay[i];
+        auto ptr = [&](int k) -> uint8_t* { return L.off[k] == size_t(-1) ? nullptr : dbase + L.off[k]; };
+        BvPackDesc& p = packs[i];
+        p = BvPackDesc{};
+        p.keys = reinterpret_cast<uint16_t*>(ptr(0));
+        p.validity = reinterpret_cast<uint64_t*>(ptr(1));
+        p.prefix_keys = ptr(2);
+        p.fingerprints = reinterpret_cast<uint32_t*>(ptr(3));
+        p.residuals = ptr(4);
+        p.fsst = ptr(5);
+        p.shared_prefix = ptr(6);
+        p.postings = reinterpret_cast<uint16_t*>(ptr(8));
+        p.d = st.d;
+        p.shared_prefix_len = st.shared_prefix_len;
+        p.offset_bytes = st.offset_bytes;
+        p.slope = st.slope;
+        p.intercept = st.intercept;
+        Entry& e = entries[i];
+        e.is_str = true;
+        e.logical = kByteView;
+        e.phys = it.arrow_type;
+        e.len = it.n;
+        e.nullable = it.has_validity;
+        e.all_null = false;
+        e.W = 16;
+        e.path_id = it.path_id;
+        e.dict_len = st.d;
+        e.has_fp = L.off[3] != size_t(-1);
+        e.offsets_bytes = (st.d + 1) * st.offset_bytes;
+        e.fsst_len = st.fsst_len;
+        e.raw_bytes = st.raw_bytes;
+        e.slab = slab;
+        e.device_bytes = L.bytes;
+        e.sig_on_device = L.off[7] != size_t(-1);
+        StrDesc& d = e.sd;
+        d = StrDesc{};
+        d.n = it.n;
+        d.d = st.d;
+        d.slope = st.slope;
+        d.intercept = st.intercept;
+        d.offset_bytes = uint8_t(st.offset_bytes);
+        d.fsst_len = st.fsst_len;
+        d.shared_prefix_len = st.shared_prefix_len;
+        d.symtab_slot = it.slot;
+        d.keys = p.keys;
+        d.validity = p.validity;
+        d.prefix_keys = p.prefix_keys;
+        d.fingerprints = p.fingerprints;
+        d.residuals = p.residuals;
+        d.fsst = p.fsst;
+        d.shared_prefix = p.shared_prefix;
+        d.signatures = reinterpret_cast<const uint64_t*>(ptr(7));
+        d.postings = p.postings;
+        if (e.sig_on_device) sig_descs.push_back(d);
+    }
+    BvPackDesc* d_packs = reinterpret_cast<BvPackDesc*>(d_sc + sc_packs);
+    LC_HIP(hipMemcpyAsync(d_packs, packs.data(), m * sizeof(BvPackDesc), hipMemcpyHostToDevice, side));
+    LC_HIP(launch_bv_pack(d_descs, d_packs, uint32_t(m), side));
+    if (!sig_descs.empty()) {
+        const DevSymtab* d_st;
+        {
+            std::lock_guard<std::mutex> sg(ctx->st_mu);
+            d_st = ctx->d_symtabs;
+        }
+        // the descriptors of the signature builder reuse the BvEncodeDesc area (k_bv_pack is ordered before it on the stream,
+        // but still reads it): they go behind the stats instead
+        StrDesc* d_sd = static_cast<StrDesc*>(pool_alloc(ctx, sig_descs.size() * sizeof(StrDesc)));
+        if (!d_sd) return fail(LC_ERR_OOM, "hipMalloc (signature builder descriptors)");
+        uint32_t max_d = 1;
+        for (const StrDesc& sd : sig_descs) max_d = std::max(max_d, sd.d);
+        const hipError_t e1 = hipMemcpyAsync(d_sd, sig_descs.data(), sig_descs.size() * sizeof(StrDesc), hipMemcpyHostToDevice, side);
+        const hipError_t e2 = e1 == hipSuccess ? launch_str_build_signatures(d_sd, uint32_t(sig_descs.size()), max_d, d_st, side) : e1;
+        const hipError_t e3 = hipStreamSynchronize(side);
+        pool_release(ctx, d_sd);
+        if (e2 != hipSuccess || e3 != hipSuccess) return fail(LC_ERR_DEVICE, "k_str_build_signatures failed");
+    }
+    LC_HIP(hipStreamSynchronize(side));
+    std::unique_lock<std::shared_mutex> g(ctx->mu);
+    for (size_t i = 0; i < m; i++) {
+        auto old = ctx->entries.find(items[i].id);
+        if (old != ctx->entries.end()) {
+            ctx->entry_bytes -= old->second.device_bytes;
+            arena_release(ctx, old->second.slab);
+            ctx->entries.erase(old);
+        }
+        ctx->entry_bytes += entries[i].device_bytes;
+        ctx->entries.emplace(items[i].id, std::move(entries[i]));
+    }
+    reserved.disarm();
+    return LC_OK;
+}
+
 lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const struct ArrowArray* const* arrays,
                                  const struct ArrowSchema* const* schemas) {
+    return lc_insert_arrow_batch_device(ctx, n, entry_ids, arrays, schemas, nullptr, nullptr);
+}
+
+lc_status lc_insert_arrow_batch_device(lc_ctx* ctx, uint64_t n_all, const uint64_t* ids_all, const struct ArrowArray* const* arrays_all,
+                                       const struct ArrowSchema* const* schemas_all, const int32_t* hints, const uint64_t* path_ids) {
     return guarded([&]() -> lc_status {
-    if (!ctx || (n && (!entry_ids || !arrays || !schemas))) return fail(LC_ERR_INVALID, "null argument");
+    if (!ctx || (n_all && (!ids_all || !arrays_all || !schemas_all))) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
+    // byte views (Utf8 / Binary) take their own encoder; everything else goes through the fixed-width one below
+    std::vector<BvItem> views;
+    std::vector<uint64_t> entry_ids_v;
+    std::vector<const struct ArrowArray*> arrays_v;
+    std::vector<const struct ArrowSchema*> schemas_v;
+    for (uint64_t i = 0; i < n_all; i++) {
+        const struct ArrowArray* a = arrays_all[i];
+        const struct ArrowSchema* s = schemas_all[i];
+        if (!a || !s) return fail(LC_ERR_INVALID, "null array");
+        const std::string fmt = s->format ? s->format : "";
+        if ((fmt == "u" || fmt == "z") && !s->dictionary) {
+            if (a->length > 65536) return fail(LC_UNSUPPORTED, "byte-view entries of more than 65536 rows are not handled on the device");
+            BvItem it;
+            it.id = ids_all[i];
+            it.a = a;
+            it.arrow_type = fmt == "u" ? kUtf8 : kBinary;
+            it.want_fp = hints && hints[i] == LC_HINT_SUBSTRING_SEARCH;
+            it.path_id = path_ids ? path_ids[i] : 0;
+            it.n = uint32_t(a->length);
+            it.has_validity = a->n_buffers >= 1 && a->buffers[0] != nullptr;
+            if (a->n_buffers < 3 || !a->buffers[1]) return fail(LC_ERR_INVALID, "Utf8 / Binary array without an offsets buffer");
+            const int32_t* o = static_cast<const int32_t*>(a->buffers[1]) + a->offset;
+            if (o[it.n] < o[0]) return fail(LC_ERR_INVALID, "Utf8 / Binary offsets decrease");
+            it.data_len = size_t(o[it.n] - o[0]);
+            if (it.data_len && !a->buffers[2]) return fail(LC_ERR_INVALID, "Utf8 / Binary array without a data buffer");
+            views.push_back(it);
+        } else {
+            entry_ids_v.push_back(ids_all[i]);
+            arrays_v.push_back(a);
+            schemas_v.push_back(s);
+        }
+    }
+    {
+        const lc_status rc = device_encode_byte_views(ctx, views);
+        if (rc != LC_OK) return rc;
+    }
+    const uint64_t n = entry_ids_v.size();
+    const uint64_t* entry_ids = entry_ids_v.data();
+    const struct ArrowArray* const* arrays = arrays_v.data();
+    const struct ArrowSchema* const* schemas = schemas_v.data();
     std::vector<DevEncodeItem> items(n);
     size_t stage_bytes = 0;
     for (uint64_t i = 0; i < n; i++) {
@@ -1405,7 +1747,7 @@ lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_
                                 std::sscanf(s->format, "d:%d,%d,%d", &dec_p, &dec_s, &dec_bits) >= 2 &&
                                 (dec_bits == 128 || dec_bits == 256);
         if ((phys < 0 && !is_decimal) || s->dictionary || a->length > int64_t(UINT32_MAX))
-            return fail(LC_UNSUPPORTED, "the on-device transcoder takes integer / date / timestamp / decimal / float arrays (use lc_insert_arrow)");
+            return fail(LC_UNSUPPORTED, "the on-device transcoder takes integer / date / timestamp / decimal / float / Utf8 / Binary arrays (use lc_insert_arrow)");
         DevEncodeItem& it = items[i];
         it.id = entry_ids[i];
         if (is_decimal) {  // LiquidDecimalArray: u64 offsets of the unscaled values (decimal_array.rs:127-177)

@@ -506,3 +506,75 @@ def test_insert_batch_equals_single_inserts(product_lib, oracle):
             assert cache.eval_predicate(s_, expr).read().equals(cache.eval_predicate(b_, expr).read())
     finally:
         cache.close()
+
+
+def _bv_cases():
+    """Arrays for the on-device byte-view transcoder: (name, array, hint).  Duplicates, nulls, slices with an offset, every
+    byte value, values longer than the prefix-key length byte can say, values of one and two bytes (the matcher's tail
+    paths), data the symbol table was not trained on (escapes), one distinct value, no value, no row."""
+    rng = np.random.default_rng(11)
+    cases = []
+    urls = fz._pool_urls(rng, 700)
+    rows = fz._zipf_rows(rng, urls, 8192)
+    cases.append(("urls_8192", pa.array([r.decode() for r in rows]), HINT))
+    with_nulls = [None if rng.random() < 0.2 else r.decode() for r in rows[:5000]]
+    cases.append(("urls_nulls", pa.array(with_nulls, type=pa.string()), HINT))
+    cases.append(("urls_slice", pa.array(with_nulls, type=pa.string()).slice(37, 3001), HINT))
+    cases.append(("urls_no_hint", pa.array([r.decode() for r in rows[:3000]]), None))
+    cases.append(("bytes", pa.array(fz._zipf_rows(rng, fz._pool_bytes(rng, 500), 4000), type=pa.binary()), HINT))
+    cases.append(("bytes_unique", pa.array(list(dict.fromkeys(fz._pool_bytes(rng, 3000))), type=pa.binary()), HINT))
+    cases.append(("small_alphabet", pa.array(fz._zipf_rows(rng, fz._pool_small_alphabet(rng, 300), 2500), type=pa.binary()), HINT))
+    cases.append(("escape_heavy", pa.array(fz._zipf_rows(rng, fz._pool_escape_heavy(rng, 400), 3000), type=pa.binary()), HINT))
+    cases.append(("shared_prefix", pa.array(["https://example.com/a/" + "q" * int(k) + str(int(k) % 7) for k in rng.integers(0, 40, size=2000)]), HINT))
+    cases.append(("one_value", pa.array(["same"] * 1000), HINT))
+    cases.append(("one_row", pa.array(["x"]), HINT))
+    cases.append(("empty_strings", pa.array([""] * 10 + ["a", "", "ab"]), HINT))
+    cases.append(("all_null", pa.array([None] * 77, type=pa.string()), HINT))
+    cases.append(("no_rows", pa.array([], type=pa.string()), HINT))
+    cases.append(("over_8192_rows", pa.array([r.decode() for r in fz._zipf_rows(rng, urls, 20000)]), HINT))  # no row lists
+    cases.append(("many_distinct", pa.array([("v%06d" % i) for i in rng.permutation(9000)]), HINT))
+    return cases
+
+
+def test_device_byte_view_transcoder_equals_host(product_lib, oracle):
+    """lc_insert_arrow_batch_device on Utf8 / Binary arrays: the entry the kernels build (dictionary in first-occurrence
+    order, FSST bytes, compact offsets, prefix keys, shared prefix, fingerprints; signature slices and row lists) holds the
+    same bytes as the one the host transcoder stages — LiquidByteViewArray::to_bytes() rebuilt from HBM and the serialized
+    acceleration index are compared byte for byte — and decodes / filters alike."""
+    cache = lc.LiquidCacheBuilder.new().build()
+    try:
+        cases = _bv_cases()
+        host_ids, dev_ids = [], []
+        for i, (name, arr, hint) in enumerate(cases):
+            h = lc.ParquetArrayID.new(70, 0, i, 0)
+            host_ids.append(h)
+            cache.insert(h, arr, hint, path_id=9000 + i)   # trains the path's symbol table
+        dev_ids = [lc.ParquetArrayID.new(71, 0, i, 0) for i in range(len(cases))]
+        # one call for all string arrays of a hint class (the C ABI takes per-array hints; the Python mirror one per call)
+        for hint in (HINT, None):
+            sel = [i for i, c in enumerate(cases) if c[2] == hint]
+            cache.insert_device([dev_ids[i] for i in sel], [cases[i][1] for i in sel], hint, path_ids=[9000 + i for i in sel])
+        like = lc.LiquidExpr.try_new("like", "%google%", pa.string(), HINT)
+        for (name, arr, hint), h, d in zip(cases, host_ids, dev_ids):
+            hb, db = cache.entry_bytes(h), cache.entry_bytes(d)
+            assert hb is not None and hb == db, (name, len(hb), len(db), next((k for k in range(min(len(hb), len(db))) if hb[k] != db[k]), -1))
+            assert cache.entry_index_bytes(h) == cache.entry_index_bytes(d), name
+            assert cache.get(d).read().equals(arr), name
+            if pa.types.is_string(arr.type) and len(arr):
+                assert cache.eval_predicate(d, like).read().equals(cache.eval_predicate(h, like).read()), name
+        # a fresh path: the device call trains the table (from the first array of the path), the host path then reuses it
+        name, arr, hint = cases[0]
+        d2, h2 = lc.ParquetArrayID.new(72, 0, 0, 0), lc.ParquetArrayID.new(72, 0, 0, 1)
+        cache.insert_device([d2], [arr], hint, path_ids=[9900])
+        cache.insert(h2, arr, hint, path_id=9900)
+        assert cache.entry_bytes(d2) == cache.entry_bytes(h2)
+        # mixed call: numbers and strings together
+        nums = pa.array(np.arange(5000, dtype=np.int64) * 3)
+        m1, m2 = lc.ParquetArrayID.new(73, 0, 0, 0), lc.ParquetArrayID.new(73, 0, 1, 0)
+        cache.insert_device([m1, m2], [nums, cases[0][1]], HINT, path_ids=[0, 9000])
+        assert cache.get(m1).read().equals(nums) and cache.entry_bytes(m2) == cache.entry_bytes(host_ids[0])
+        # views are not taken: the caller uses the host transcoder
+        with pytest.raises(lc.LiquidCacheError):
+            cache.insert_device([lc.ParquetArrayID.new(74, 0, 0, 0)], [pa.array(["a", "b"], type=pa.string_view())], HINT, path_ids=[1])
+    finally:
+        cache.close()
