@@ -660,6 +660,60 @@ def secondary_transcode_rate(cache, lc, N, args, rows, threads):
                     "device_rows_per_s": n_batches * bs / t_dev, "device_seconds": t_dev,
                     "device_calls": (n_batches + chunk - 1) // chunk}
         cache.evict(ids_h + ids_d)
+    # URL-shaped Utf8 batches: dictionary + FSST + prefix keys + fingerprints + compact offsets + the acceleration index.
+    # Symbol tables are trained beforehand (once per column chunk, on the host, for both paths: transcode.rs:16-33), so the
+    # timed part is the per-batch encoding — host threads over row groups against one device call per row group.
+    try:
+        nb = max(1, min(n_batches, 512))
+        rgb = args.row_group_batches
+        offs = np.zeros(bs + 1, np.int32)
+        data = np.zeros(bs * 512, np.uint8)
+        arrays = []
+        for b in range(nb):
+            n = N.load_bench().lc_synth_url_batch(args.seed + 11, b, bs, min(args.uniques, bs), args.needle_ppm,
+                                                  offs.ctypes.data, data.ctypes.data, data.size)
+            arrays.append(pa.StringArray.from_buffers(bs, pa.py_buffer(offs.copy()), pa.py_buffer(data[:n].copy())))
+        hint = lc.CacheExpression.SUBSTRING_SEARCH
+        ids_h = [lc.ParquetArrayID.new(9, b // rgb, 1, b % rgb) for b in range(nb)]
+        ids_d = [lc.ParquetArrayID.new(9, b // rgb, 2, b % rgb) for b in range(nb)]
+        paths = [1_000_000 + b // rgb for b in range(nb)]
+        groups = [list(range(g, min(g + rgb, nb))) for g in range(0, nb, rgb)]
+        warm = [lc.ParquetArrayID.new(9, g[0] // rgb, 3, 0) for g in groups]
+        for g, w in zip(groups, warm):
+            cache.insert(w, arrays[g[0]], hint, path_id=paths[g[0]])  # trains the row group's symbol table
+
+        def host_group(g):
+            cache.insert_batch([ids_h[b] for b in g], [arrays[b] for b in g], hint, path_ids=[paths[b] for b in g])
+
+        def dev_group(g):
+            cache.insert_device([ids_d[b] for b in g], [arrays[b] for b in g], hint, path_ids=[paths[b] for b in g])
+
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(host_group, groups))
+        t_host = time.perf_counter() - t0
+        dev_group(groups[0])  # (first launch of the two kernels)
+        cache.evict([ids_d[b] for b in groups[0]])
+        t0 = time.perf_counter()
+        for g in groups:
+            dev_group(g)
+        t_dev1 = time.perf_counter() - t0
+        cache.evict(ids_d)
+        dev_threads = min(threads, 4)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=dev_threads) as ex:
+            list(ex.map(dev_group, groups))
+        t_dev = time.perf_counter() - t0
+        same = all(cache.entry_bytes(ids_h[b]) == cache.entry_bytes(ids_d[b]) for b in range(0, nb, max(1, nb // 16)))
+        raw_bytes = int(sum(a.nbytes for a in arrays))
+        res["url_utf8"] = {"rows": nb * bs, "arrow_bytes": raw_bytes, "host_threads": threads,
+                           "host_rows_per_s": nb * bs / t_host, "host_seconds": t_host,
+                           "device_rows_per_s_one_thread": nb * bs / t_dev1, "device_seconds_one_thread": t_dev1,
+                           "device_threads": dev_threads, "device_rows_per_s": nb * bs / t_dev, "device_seconds": t_dev,
+                           "device_calls": len(groups), "sampled_entries_byte_identical": bool(same)}
+        cache.evict(ids_h + ids_d + warm)
+    except Exception as e:  # noqa: BLE001
+        res["url_utf8"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return res
 
 

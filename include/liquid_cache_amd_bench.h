@@ -49,6 +49,13 @@ LC_BENCH_API void lc_synth_int64_batch(uint64_t seed, uint64_t batch_index, uint
  * unit is only documented for 16-byte coalesced reads).  `ctx` is an lc_ctx*. */
 LC_BENCH_API int32_t lc_calibrate_read(void* ctx, uint64_t bytes, int32_t shape, int32_t iters);
 
+/* Streaming-read probe: the average time (HIP events, microseconds) of a kernel that only reads `bytes` bytes once with
+ * 16-byte loads on `grid_blocks` workgroups of 256 threads — back to back (hot: sizes below the 256 MiB Infinity Cache stay
+ * resident) and with a 1 GiB flush read before every launch (L3-cold).  The measured ceiling the scan kernels' times are
+ * read against. */
+LC_BENCH_API int32_t lc_probe_stream_read(void* ctx, uint64_t bytes, int32_t iters, int32_t grid_blocks, double* out_hot_us,
+                                          double* out_cold_us);
+
 /* Test aid (host only, no context): the inverted row lists lc_stage attaches to byte-view entries of substring-search
  * columns — u16 offsets[d + 1], then the valid rows grouped by dictionary key — for `n` (<= 8192) keys, an optional
  * LSB-first validity bitmap and a dictionary of `d` values.  Returns the number of u16 written to `out` (d + 1 + n + 32;

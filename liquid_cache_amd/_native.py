@@ -77,7 +77,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
-                 "lc_calibrate_read", "lc_debug_row_lists"]
+                 "lc_calibrate_read", "lc_probe_stream_read", "lc_debug_row_lists"]
 
 _lib = None
 _bench = None
@@ -101,6 +101,8 @@ def load_bench():
     B.lc_synth_int64_batch.argtypes = [u64, u64, C.c_uint32, i32, C.c_int64, vp]
     B.lc_calibrate_read.restype = i32
     B.lc_calibrate_read.argtypes = [vp, u64, i32, i32]
+    B.lc_probe_stream_read.restype = i32
+    B.lc_probe_stream_read.argtypes = [vp, u64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     B.lc_debug_row_lists.restype = sz
     B.lc_debug_row_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, sz]
     _bench = B

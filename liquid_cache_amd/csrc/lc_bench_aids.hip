@@ -49,10 +49,67 @@ __global__ __launch_bounds__(256) void k_calib_read_scattered8(const uint8_t* __
     if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
 }
 
+// Streaming-read probe (lc_probe_stream_read): what a kernel that does nothing but read `bytes` once — 16 bytes per lane,
+// four independent loads in flight per lane, grid sized to fill the chip — achieves on this device, so that the scan
+// kernels' roofline fractions can be read against the MEASURED ceiling for their byte count, hot and L3-cold.
+__global__ __launch_bounds__(256) void k_probe_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
+    uint32_t acc = 0;
+    const uint64_t stride = uint64_t(gridDim.x) * 256;
+    uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
+    }
+    for (; i < n16; i += stride) { const uint4 a = src[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
+}
 
 }  // namespace
 
 extern "C" {
+
+int32_t lc_probe_stream_read(void* ctx_, uint64_t bytes, int32_t iters, int32_t grid_blocks, double* out_hot_us, double* out_cold_us) {
+    lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
+    if (!ctx || bytes < 4096 || iters <= 0 || grid_blocks <= 0 || !out_hot_us || !out_cold_us) return LC_ERR_INVALID;
+    lc_device_info info;
+    if (lc_device_info_get(ctx, &info) != LC_OK || info.device_id < 0) return LC_ERR_DEVICE;
+    if (hipSetDevice(info.device_id) != hipSuccess) return LC_ERR_DEVICE;
+    const uint64_t flush_bytes = uint64_t(1) << 30;  // 4 x the 256 MiB Infinity Cache
+    uint8_t* d = nullptr;
+    uint8_t* f = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), bytes + 65536) != hipSuccess) return LC_ERR_OOM;
+    if (hipMalloc(reinterpret_cast<void**>(&f), flush_bytes + 65536) != hipSuccess) { (void)hipFree(d); return LC_ERR_OOM; }
+    int32_t rc = LC_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipMemset(d, 1, bytes + 65536) != hipSuccess || hipMemset(f, 2, flush_bytes + 65536) != hipSuccess ||
+        hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        rc = LC_ERR_DEVICE;
+    uint32_t* sink = reinterpret_cast<uint32_t*>(d + bytes);
+    uint32_t* fsink = reinterpret_cast<uint32_t*>(f + flush_bytes);
+    const dim3 grid{uint32_t(grid_blocks)}, block(256);
+    double hot = 0, cold = 0;
+    for (int pass = 0; pass < 2 && rc == LC_OK; pass++) {  // 0: hot (back to back), 1: cold (flush before every launch)
+        double sum = 0;
+        for (int i = -2; i < iters && rc == LC_OK; i++) {
+            if (pass == 1) hipLaunchKernelGGL(k_probe_read, dim3(4096), block, 0, nullptr, reinterpret_cast<const uint4*>(f), flush_bytes / 16, fsink);
+            (void)hipEventRecord(e0, nullptr);
+            hipLaunchKernelGGL(k_probe_read, grid, block, 0, nullptr, reinterpret_cast<const uint4*>(d), bytes / 16, sink);
+            (void)hipEventRecord(e1, nullptr);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = LC_ERR_DEVICE; break; }
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (i >= 0) sum += double(ms) * 1000.0;
+        }
+        (pass == 0 ? hot : cold) = sum / iters;
+    }
+    *out_hot_us = hot;
+    *out_cold_us = cold;
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d);
+    (void)hipFree(f);
+    return rc;
+}
 
 int32_t lc_calibrate_read(void* ctx_, uint64_t bytes, int32_t shape, int32_t iters) {
     lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);

@@ -1202,9 +1202,19 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
     const uint32_t code = threadIdx.x;
     const uint64_t sym = st.sym[code];
     const uint32_t sl = st.len[code];  // 0 for unused codes (and for 255, handled as escape by the scanner)
+    // PAD CODE of this (needle, table): a code that never completes a match — no state reaches the matched state on it, and
+    // as a literal byte it is not the needle's last byte — so a walker may fill the bytes behind the end of a value with
+    // it instead of guarding every step: a value that has matched stays matched (absorbing state), one that has not
+    // cannot start to.  Stored in the first entry of the image's last row (the literal row of the matched state, which no
+    // walk can reach); 0xFFFF when the table has no such code.
+    __shared__ uint32_t pad_code;
+    if (threadIdx.x == 0) pad_code = 0xFFFFu;
+    __syncthreads();
+    bool completes = code == 255u || m == 0 || code == uint32_t(needle.bytes[m ? m - 1 : 0]);
     for (uint32_t s = 0; s <= m; s++) {
         uint32_t cur = s;
         for (uint32_t k = 0; k < sl; k++) cur = delta[cur * 256 + uint32_t((sym >> (8 * k)) & 0xFF)];
+        completes |= s < m && cur == m;
         // code 255 is the escape marker: never a transition (0xFF flag in the u8 table)
         t[s * 512 + code] = code == 255u ? uint8_t(0xFF) : uint8_t(cur);
         t[s * 512 + 256 + code] = delta[s * 256 + code];
@@ -1214,6 +1224,9 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
             img[(m + 1u + s) * 256 + code] = uint16_t(uint32_t(delta[s * 256 + code]) * 512u);
         }
     }
+    if (!completes) atomicMin(&pad_code, code);
+    __syncthreads();
+    if (img && threadIdx.x == 0) img[(2u * m + 1u) * 256u] = uint16_t(pad_code);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1227,6 +1240,13 @@ __global__ __launch_bounds__(256) void k_str_automata(const DevSymtab* __restric
 //   phase C  rows: 8 u16 keys per 16-byte load, bitmap lookup in LDS, 8 lanes x 8 bits shuffled into mask words
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kCandCap = 1024;  // candidate list capacity per wave (u16 entries)
+// many-candidate LIKE (A/B aid: -DLC_X_CANDCAP_MANY).  Measured on the 100 M-row URL column, fingerprint candidates / every
+// value walked: 1024 -> 489 / 687 us, 2560 (one pass per batch, 8 instead of 16 waves per CU) -> 519 / 690 us with the
+// streaming walker, 769 / 1163 us with the chained one.
+#ifndef LC_X_CANDCAP_MANY
+#define LC_X_CANDCAP_MANY 1024
+#endif
+constexpr uint32_t kCandCapMany = LC_X_CANDCAP_MANY;
 // the signature-only variant sees a handful of candidates per entry: a quarter of the list leaves room for two more
 // workgroups per CU (LDS is what limits its occupancy)
 constexpr uint32_t kCandCapSigOnly = 256;
@@ -1435,10 +1455,12 @@ struct WalkManyArgs {
     uint32_t row0, hitrow;
     uint32_t dres_lds;   // LDS address of the dictionary result table
     uint32_t bytes_mode; // table is bytes (1) or a bitmap (0)
+    uint32_t dbg;        // ablation builds: phases of like_walk_stream to leave out (LC_DEBUG_FLAGS)
 };
 struct WalkManyResult {
     uint32_t found;   // this lane set at least one dictionary entry
     uint32_t bytes;   // compressed bytes this lane walked
+    uint32_t iters;   // timing builds: loop rounds of the streaming walker
 };
 
 __device__ __forceinline__ void walk_offsets(const WalkManyArgs& a, uint32_t i, uint32_t& start, uint32_t& stop) {
@@ -1535,6 +1557,201 @@ __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) 
     return out;
 }
 
+// Streaming walker for the same situation (at least a wave of candidates), used whenever the automaton image carries a
+// pad code (k_str_automata).  like_walk_many walks CH words per fetch whatever the value's length: on the URL column (values
+// of 10..110 compressed bytes, 44 on average) 37 % (128-byte fetches) to 64 % (64-byte) of its steps move a state.  Here
+// every chain is a little pipeline that never idles on a short value:
+//   cursor   runs kStreamDepth blocks ahead and touches ADDRESSES only: it cuts the chain's current value into 16-byte
+//            blocks, issues the (unconditional) load of the next block, and when a value ends draws the next candidate
+//            from the wave's LDS counter — values go to whichever chain is free, so lanes finish together — with its
+//            start and length read from LDS (an offsets pre-pass fills them: no global load sits between a value and
+//            the next, and the only loads in the loop are the block loads, which the hardware returns in order);
+//   walker   takes the oldest block: bytes behind the end of the value are replaced by the pad code (two masks per block
+//            instead of a compare and a select per byte), 16 dependent lookups, and on a value's last block the state is
+//            recorded and reset.
+// A block costs 16 lookups for 16 bytes unless it is the last of its value: ~92 % of the steps move a state.
+// What it buys (100 M-row URL column, same box, A/B builds): every dictionary value walked (no fingerprints) 801 -> 687 us;
+// fingerprint candidates (46 % of the values) 489 -> 519-544 us, so that case keeps like_walk_many.  Why not more: ablation
+// builds (scripts/occ_many.sh) show the loop without its table lookups at 646 of 674 us and without its block loads at
+// 553 us — the bound is neither LDS nor HBM but the instructions a wave issues per block (cursor + masks ~200 of ~330) and
+// the address unit, which sees 64 different lines per 16-byte-per-lane load.  Halving the waves per CU costs 10 %.
+#ifndef LC_X_STREAM_MODE
+#define LC_X_STREAM_MODE 2  // 0: never, 1: whenever the image has a pad code, 2: only when every dictionary value is walked
+#endif
+constexpr int kStreamDepth = 3;
+constexpr uint32_t kStreamMaxFsst = 1u << 20;  // start (20 bits) and length (12 bits) of a candidate share one LDS word
+struct StreamLds {
+    uint32_t spans;    // LDS address: u32 per candidate, start | min(length, 4095) << 20
+    uint32_t counter;  // LDS address: u32 next candidate to hand out
+};
+
+template <int NC>
+__device__ __forceinline__ WalkManyResult like_walk_stream(const WalkManyArgs& a, const StreamLds& sl, uint32_t pad_code) {
+    constexpr int D = kStreamDepth;
+    const int lane = lane_id();
+    typedef const __attribute__((address_space(3))) uint16_t* LdsList;
+    typedef __attribute__((address_space(3))) uint32_t* LdsU32;
+    typedef __attribute__((address_space(3))) uint8_t* LdsBytes;
+    const LdsList cand = reinterpret_cast<LdsList>(a.cand_lds);
+    const LdsU32 spans = reinterpret_cast<LdsU32>(sl.spans);
+    const LdsU32 counter = reinterpret_cast<LdsU32>(sl.counter);
+    WalkManyResult out{0, 0, 0};
+    // offsets pre-pass: eight residual pairs per lane are in flight before the first is used (written out: left to the
+    // compiler the loop waited for every load in turn, 19 dependent trips to memory for a URL batch)
+    {
+        constexpr int PB = 8;
+        const uint32_t ob = a.offset_bytes, sh = 32u - 8u * ob;
+        for (uint32_t j0 = 0; j0 < a.n_walk; j0 += uint32_t(PB) * kWave) {
+            uint32_t ids[PB];
+            uint64_t rv[PB];
+#pragma unroll
+            for (int k = 0; k < PB; k++) ids[k] = cand[min(j0 + uint32_t(k) * kWave + uint32_t(lane), a.n_walk - 1u)];
+#pragma unroll
+            for (int k = 0; k < PB; k++) rv[k] = load_unaligned<uint64_t>(a.residuals + size_t(ids[k]) * ob);
+#pragma unroll
+            for (int k = 0; k < PB; k++) {
+                const uint32_t j = j0 + uint32_t(k) * kWave + uint32_t(lane);
+                const int32_t r0 = int32_t(uint32_t(rv[k]) << sh) >> sh;
+                const int32_t r1 = int32_t(uint32_t(rv[k] >> (8u * ob)) << sh) >> sh;
+                const uint32_t st = a.slope * ids[k] + a.intercept + uint32_t(r0);
+                const uint32_t sp = a.slope * (ids[k] + 1u) + a.intercept + uint32_t(r1);
+                if (j < a.n_walk) spans[j] = st | (min(sp - st, 0xFFFu) << 20);
+            }
+        }
+    }
+    if (LC_ABL(a.dbg & 512)) return out;
+    if (lane == 0) *counter = uint32_t(kWave) * NC * 2u;  // every chain starts with a current and a reserved candidate
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint64_t zz = uint64_t(pad_code) * 0x0101010101010101ull;
+    // per chain: cursor (current value cj / cpos / crem, reserved next value nj / nspan) and walker (sb) state, D blocks in flight
+    uint32_t cj[NC], cpos[NC], crem[NC], nj[NC], nspan[NC], sb[NC], last_addr[NC];
+    bool cact[NC];
+    uint64_t w0[NC][D], w1[NC][D];
+    uint32_t meta[NC][D];  // valid bytes (0..16) | last block of its value << 5 | candidate index << 16
+    // the reserved candidate becomes the current one; the next reservation is drawn now and read when it is needed — one
+    // value later — so no LDS round trip sits between two values of a chain
+    auto advance = [&](int c) {
+        const uint32_t j = nj[c];
+        cact[c] = j < a.n_walk;
+        if (cact[c]) {
+            cj[c] = j;
+            cpos[c] = nspan[c] & 0xFFFFFu;
+            crem[c] = nspan[c] >> 20;
+            if (crem[c] == 0xFFFu) {  // 4 KB or more of compressed bytes in one value
+                uint32_t st, sp;
+                walk_offsets(a, cand[j], st, sp);
+                crem[c] = sp - st;
+            }
+            out.bytes += crem[c];
+            nj[c] = atomicAdd((uint32_t*)counter, 1u);
+            nspan[c] = spans[min(nj[c], a.n_walk - 1u)];
+        }
+    };
+    auto cursor_step = [&](int c, int d) {
+        uint32_t m = 0, addr = last_addr[c];
+        if (cact[c]) {
+            const uint32_t take = min(crem[c], 16u);
+            const bool last = crem[c] <= 16u;
+            m = take | (last ? 32u : 0u) | (cj[c] << 16);
+            addr = cpos[c];
+            cpos[c] += 16u;
+            crem[c] -= take;
+            if (last) advance(c);
+        }
+        last_addr[c] = addr;
+        meta[c][d] = m;
+        // unconditional: an idle chain re-reads its last block (a cache hit), so that every step issues the same number
+        // of loads and the wait for a block is a count of younger loads, never "all of them"
+        if (LC_ABL(a.dbg & 256)) { w0[c][d] = addr; w1[c][d] = addr; return; }
+        w0[c][d] = load_unaligned<uint64_t>(a.fsst + addr);
+        w1[c][d] = load_unaligned<uint64_t>(a.fsst + addr + 8u);
+    };
+    auto byte_mask = [](uint32_t valid) -> uint64_t {  // low `valid` (0..8) bytes set
+        return valid >= 8u ? ~uint64_t(0) : ((uint64_t(1) << (8u * valid)) - 1u);
+    };
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        sb[c] = a.row0;
+        last_addr[c] = 0;
+        cj[c] = cpos[c] = crem[c] = 0;
+        // static first assignment: chain c of lane l holds candidate l + 64 c, and reserves l + 64 (NC + c)
+        nj[c] = uint32_t(lane) + uint32_t(kWave) * uint32_t(c);
+        nspan[c] = spans[min(nj[c], a.n_walk - 1u)];
+        const uint32_t reserve = uint32_t(lane) + uint32_t(kWave) * uint32_t(NC + c);
+        const uint32_t j = nj[c];
+        cact[c] = j < a.n_walk;
+        if (cact[c]) {
+            cj[c] = j;
+            cpos[c] = nspan[c] & 0xFFFFFu;
+            crem[c] = nspan[c] >> 20;
+            if (crem[c] == 0xFFFu) {
+                uint32_t st, sp;
+                walk_offsets(a, cand[j], st, sp);
+                crem[c] = sp - st;
+            }
+            out.bytes += crem[c];
+        }
+        nj[c] = reserve;
+        nspan[c] = spans[min(reserve, a.n_walk - 1u)];
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) cursor_step(c, d);
+    }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int c = 0; c < NC; c++) any |= cact[c];
+        // nothing left to hand out anywhere: the blocks in flight are the last ones, one more round drains them
+        const bool drain = __ballot(any) == 0;
+#ifdef LC_KERNEL_TIMING
+        out.iters++;
+#endif
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            uint64_t x0[NC], x1[NC];
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const uint32_t valid = meta[c][d] & 31u;
+                const uint64_t m0 = byte_mask(min(valid, 8u)), m1 = byte_mask(valid - min(valid, 8u));
+                x0[c] = (w0[c][d] & m0) | (zz & ~m0);
+                x1[c] = (w1[c][d] & m1) | (zz & ~m1);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+#pragma unroll
+                for (uint32_t q = 0; q < 8; q++) {
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        const uint64_t ww = h ? x1[c] : x0[c];
+                        const uint32_t code = (q < 4 ? uint32_t(ww) >> (8 * q) : uint32_t(ww >> 32) >> (8 * (q - 4))) & 0xFFu;
+                        if (LC_ABL(a.dbg & 128)) sb[c] = a.row0 + ((sb[c] + 2u * code) & 0x1FEu);
+                        else sb[c] = lds_u16(sb[c] + 2u * code);
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const bool last = (meta[c][d] & 32u) != 0;
+                const bool hit = last && sb[c] == a.hitrow;
+                if (__ballot(hit)) {
+                    if (hit) {
+                        const uint32_t id = cand[meta[c][d] >> 16];
+                        out.found = 1;
+                        if (a.bytes_mode) reinterpret_cast<LdsBytes>(a.dres_lds)[id] = 1;
+                        else atomicOr((uint32_t*)(reinterpret_cast<LdsU32>(a.dres_lds) + (id >> 5)), 1u << (id & 31));
+                    }
+                }
+                sb[c] = last ? a.row0 : sb[c];
+                cursor_step(c, d);
+            }
+        }
+        if (drain) break;
+    }
+    return out;
+}
+
 // Byte-view predicate: ONE WAVE per entry (batch), four entries per workgroup, no workgroup barriers after setup.
 //   phase A  candidates of the dictionary: LIKE with the bigram signature index: AND of the needle's bit slices,
 //            set bits scattered into an LDS list;  otherwise per entry (8 x 64 entries per round, all loads issued
@@ -1576,9 +1793,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const uint32_t tbl_bytes = lds_tbl ? automaton_image_bytes(nl) : 0u;
     constexpr uint32_t kNeedleLds = 256;
     constexpr uint32_t kFlagBytes = 80;
-    constexpr uint32_t kCap = kSigOnly ? kCandCapSigOnly : kCandCap;
+    constexpr uint32_t kCap = kSigOnly ? kCandCapSigOnly : (kMany ? kCandCapMany : kCandCap);
     // (kSigOnly: + the mask words and the matched keys of the inverted-list row phase)
-    const uint32_t per_wave = dres_bytes + cmask_bytes + kCap * 2u + kFlagBytes + (kSigOnly ? kPostLdsBytes : 0u);
+    constexpr uint32_t kStreamBytes = kMany ? kCap * 4u + 16u : 0u;  // like_walk_stream: candidate spans, counter
+    const uint32_t per_wave = dres_bytes + cmask_bytes + kCap * 2u + kFlagBytes + (kSigOnly ? kPostLdsBytes : 0u) + kStreamBytes;
     uint8_t* needle_lds = smem + tbl_bytes;
     uint8_t* wbase = smem + tbl_bytes + kNeedleLds + wave * per_wave;
     uint32_t* dres = reinterpret_cast<uint32_t*>(wbase);  // bitmap words or bytes
@@ -1912,8 +2130,24 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 wa.hitrow = hitrow;
                 wa.dres_lds = dres_addr;
                 wa.bytes_mode = kBytes ? 1u : 0u;
-                const WalkManyResult wr = prune ? like_walk_many<1, 16>(wa) : like_walk_many<2, 8>(wa);
+                wa.dbg = pred.debug_flags;
+                // (tbl_synced: the image is in LDS; its last row starts with the pad code)
+                const uint32_t pad_code = lds_u16(row0 + (2u * nl + 1u) * 512u);
+                WalkManyResult wr;
+                if (pad_code != 0xFFFFu && dp->fsst_len < kStreamMaxFsst && !LC_ABL(pred.debug_flags & 64) &&
+                    (LC_X_STREAM_MODE == 1 || (LC_X_STREAM_MODE == 2 && !prune))) {
+                    StreamLds sl;
+                    sl.spans = uint32_t(reinterpret_cast<uintptr_t>(hitflag + kFlagBytes + (kSigOnly ? kPostLdsBytes : 0u)));
+                    sl.counter = sl.spans + kCap * 4u;
+                    wr = like_walk_stream<2>(wa, sl, pad_code);
+                } else {
+                    wr = prune ? like_walk_many<1, 16>(wa) : like_walk_many<2, 8>(wa);
+                }
                 any_true |= __ballot(wr.found != 0);
+#ifdef LC_KERNEL_TIMING
+                tm_words += wr.iters;
+                tm_cands += n_walk;
+#endif
                 if (kInstr && L.d_cand_bytes && !prune) cand_bytes += wr.bytes;
                 if (kInstr && L.d_own_bytes) own_bytes += wr.bytes + 2u * dp->offset_bytes * ((n_walk - uint32_t(lane) + 63u) / 64u);
                 break;
@@ -3855,8 +4089,10 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
                            const ScanLaunch& L, hipStream_t stream) {
     if (L.n_entries == 0) return hipSuccess;
     const uint32_t dmax = std::max<uint32_t>(L.max_dict_len, 1u);
-    const bool bytes = dmax <= kMaxByteTable;
     const bool sub = pred.mode == 1;
+    // (the many-candidate LIKE keeps its dictionary results as a bitmap: its walker is bound by the number of waves a CU
+    // holds, which LDS decides, and matches are rare writes)
+    const bool bytes = dmax <= kMaxByteTable && !(sub && L.many_candidates);
     // per-wave dictionary results: one byte per entry, or a bitmap (+ one spare word pair for the group stores)
     const uint32_t dres_bytes = bytes ? (dmax + 15u) & ~15u : (((dmax + 63u) / 64u) * 8u + 15u) & ~15u;
     const uint32_t cmask_bytes = sub ? (((dmax + 63u) / 64u) * 8u + 15u) & ~15u : 0u;
@@ -3870,9 +4106,10 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     const bool records = !persistent_env() && L.d_wg_ranges && L.n_wg_ranges <= kWorkGroupsMax;
     const bool sig_only = records && sub && !many && !instr && lds_tbl && pred.use_fingerprints && pred.n_sig_bits > 0 &&
                           pred.op == LC_OP_LIKE;
-    const size_t cand_cap = sig_only ? kCandCapSigOnly : kCandCap;
+    const size_t cand_cap = sig_only ? kCandCapSigOnly : (many ? kCandCapMany : kCandCap);
     const size_t dyn_lds = tbl_bytes + 256 +
-                           size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + cand_cap * 2 + 80 + (sig_only ? kPostLdsBytes : 0u)) +
+                           size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + cand_cap * 2 + 80 + (sig_only ? kPostLdsBytes : 0u) +
+                                                     (many ? cand_cap * 4 + 16 : 0)) +
                            (env_pad ? size_t(std::atoi(env_pad)) : 0);
     // persistent launch: as many workgroups as fit on the device at once; the waves draw entries dynamically
     const uint32_t wgs_needed = (L.n_entries + kWavesPerBlock - 1) / kWavesPerBlock;

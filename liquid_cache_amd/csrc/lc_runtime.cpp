@@ -1476,7 +1476,9 @@ static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& item
     uint8_t* d_sc = static_cast<uint8_t*>(pool_alloc(ctx, sc_bytes));
     struct Bufs {
         lc_ctx* c; void* h; void* d; void* s;
-        ~Bufs() { (void)hipDeviceSynchronize(); host_pool_release(c, h); pool_release(c, d); pool_release(c, s); }
+        // (all device work of this call runs on `side`, which StreamGuard below has synchronised by the time this runs:
+        // no device-wide synchronise, so concurrent calls of other host threads overlap)
+        ~Bufs() { host_pool_release(c, h); pool_release(c, d); pool_release(c, s); }
     } bufs{ctx, h_in, d_in, d_sc};
     if (!h_in || !d_in || !d_sc) return fail(LC_ERR_OOM, "staging buffers of the on-device byte-view transcoder");
     for (size_t e = 0; e < enc_slots.size(); e++) {
