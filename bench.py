@@ -265,7 +265,35 @@ def roofline(kernel, kernel_ms, alg_bytes, kernel_bytes, cold_ms=None, traffic=N
     return out
 
 
-def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=True):
+def add_read_probe(r, cache, N):
+    """The MEASURED ceiling next to the nominal one: time of a kernel that only reads the same number of bytes once
+    (lc_probe_stream_read: 16-byte loads, best of three grid sizes), hot and L3-cold.  `frac_of_read_probe` = probe time /
+    kernel time: 1.0 means the scan kernel moves its bytes as fast as this device streams that many bytes at all."""
+    import ctypes as C
+    try:
+        B = N.load_bench()
+        best = None
+        for grid in (1024, 2048, 8192):
+            hot, cold = C.c_double(), C.c_double()
+            if B.lc_probe_stream_read(cache._ctx, max(int(r["kernel_bytes_per_launch"]), 65536), 10, grid, C.byref(hot), C.byref(cold)) != 0:
+                return r
+            if best is None or cold.value < best[1]:
+                best = (hot.value, cold.value, grid)
+        probe = {"bytes": int(r["kernel_bytes_per_launch"]), "hot_us": best[0], "cold_us": best[1], "grid": best[2],
+                 "cold_gbs": r["kernel_bytes_per_launch"] / best[1] / 1e3, "hot_gbs": r["kernel_bytes_per_launch"] / best[0] / 1e3}
+        r["read_probe"] = probe
+        if r.get("timing") == "l3_cold":
+            r["frac_of_read_probe"] = best[1] / (r["kernel_ms"] * 1e3)
+            if r.get("kernel_ms_hot"):
+                r["frac_of_read_probe_hot"] = best[0] / (r["kernel_ms_hot"] * 1e3)
+        else:
+            r["frac_of_read_probe"] = best[0] / (r["kernel_ms"] * 1e3)
+    except Exception as e:  # noqa: BLE001
+        r["read_probe"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return r
+
+
+def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=True, probe=None):
     """HIP-event kernel time (hot, and with the Infinity Cache flushed before every launch) + byte model of one predicate."""
     words = int(scan.mask_words) if words is None else words
     mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
@@ -277,6 +305,8 @@ def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=Tr
         if with_cold else None
     alg, own = scan.traffic_model(expr, False)
     r = roofline(kernel, ms, alg, own, cold)
+    if probe is not None:
+        add_read_probe(r, *probe)
     r["hits"] = int(counts.sum(dtype=torch.int64).item())
     r["rows_per_s"] = scan.rows / (r["kernel_ms"] * 1e-3)
     return r, mask, counts
@@ -424,7 +454,7 @@ def secondary_int_columns(cache, lc, N, args, rows, threads, torch, stream, iter
                 lit_v = datetime.date(1970, 1, 1) + datetime.timedelta(days=lit)
             else:
                 lit_v = lit
-            r, _, counts = time_pred(scan, lc.LiquidExpr.try_new(">", lit_v, dtype), torch, stream, iters, kernel)
+            r, _, counts = time_pred(scan, lc.LiquidExpr.try_new(">", lit_v, dtype), torch, stream, iters, kernel, probe=(cache, N))
             r["rows"] = int(scan.rows)
             if name == "int64_gt_w62":
                 r["get_with_selection"] = measure_get_with_selection(scan, lc, bits, base_v, counts, torch, stream, iters)
@@ -734,7 +764,7 @@ def secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream
             scan = cache2.scan(ids)
             hint = lc.CacheExpression.SUBSTRING_SEARCH
             expr = lc.LiquidExpr.try_new("like", pattern, pa.string(), hint)
-            r, _, _ = time_pred(scan, expr, torch, stream, max(3, iters // 2), "k_str_pred", with_cold=True)
+            r, _, _ = time_pred(scan, expr, torch, stream, max(3, iters // 2), "k_str_pred", with_cold=True, probe=(cache2, N))
             out[name] = r
             scan.close()
             cache2.close()
@@ -1234,6 +1264,8 @@ def main():
             "gb_per_s_scanned": alg_bytes * world / (elapsed / args.steps) / 1e9,
             "roofline": roofline(kernel, kernel_ms, alg_bytes, own_bytes, cold_ms, traffic, traffic_src),
         }
+        if world == 1 and not args.no_secondary:
+            add_read_probe(out["roofline"], cache, N)  # (skipped in the profiling runs: their traces hold the scan kernels only)
         out["config"]["evaluation_path"] = scan.explain(expr)
         if out["config"]["evaluation_path"].startswith("k_like_"):
             out["roofline"]["kernel"] = out["config"]["evaluation_path"].split(":")[0].split(" (")[0]
