@@ -1575,10 +1575,18 @@ __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) 
 // builds (scripts/occ_many.sh) show the loop without its table lookups at 646 of 674 us and without its block loads at
 // 553 us — the bound is neither LDS nor HBM but the instructions a wave issues per block (cursor + masks ~200 of ~330) and
 // the address unit, which sees 64 different lines per 16-byte-per-lane load.  Halving the waves per CU costs 10 %.
+// Also measured: a static hand-out of the candidates (no LDS counter) 746 us (the lanes no longer finish together), two
+// blocks in flight instead of three 673 us (-3 %, the default).
 #ifndef LC_X_STREAM_MODE
 #define LC_X_STREAM_MODE 2  // 0: never, 1: whenever the image has a pad code, 2: only when every dictionary value is walked
 #endif
-constexpr int kStreamDepth = 3;
+#ifndef LC_X_STREAM_STATIC
+#define LC_X_STREAM_STATIC 0
+#endif
+#ifndef LC_X_STREAM_DEPTH
+#define LC_X_STREAM_DEPTH 2
+#endif
+constexpr int kStreamDepth = LC_X_STREAM_DEPTH;
 constexpr uint32_t kStreamMaxFsst = 1u << 20;  // start (20 bits) and length (12 bits) of a candidate share one LDS word
 struct StreamLds {
     uint32_t spans;    // LDS address: u32 per candidate, start | min(length, 4095) << 20
@@ -1643,7 +1651,11 @@ __device__ __forceinline__ WalkManyResult like_walk_stream(const WalkManyArgs& a
                 crem[c] = sp - st;
             }
             out.bytes += crem[c];
+#if LC_X_STREAM_STATIC
+            nj[c] = nj[c] + uint32_t(kWave) * NC;  // (A/B aid: static hand-out, chain c of lane l walks l + 64 c + 128 k)
+#else
             nj[c] = atomicAdd((uint32_t*)counter, 1u);
+#endif
             nspan[c] = spans[min(nj[c], a.n_walk - 1u)];
         }
     };
