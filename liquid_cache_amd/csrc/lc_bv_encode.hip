@@ -65,30 +65,6 @@ __device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, 
     return i == len || load_tail(a + i, len - i) == load_tail(b + i, len - i);
 }
 
-// FsstEncoder::match (lc_fsst.hpp): the longest symbol of >= 3 bytes that fits, else the 2-byte symbol, else the 1-byte one
-__device__ __forceinline__ int enc_match(const EncLds& e, uint64_t w, uint32_t avail, uint32_t* out_len) {
-    if (avail >= 3) {
-        const uint32_t h = ((uint32_t(w) & 0xFFFFFFu) * 2654435761u) >> 20;
-        for (uint32_t i = e.bucket[h], end = e.bucket[h + 1]; i < end; i++) {
-            const uint32_t l = e.long_len[i];
-            const uint64_t mask = l >= 8 ? ~uint64_t(0) : ((uint64_t(1) << (8u * l)) - 1);
-            if (l <= avail && ((w ^ e.long_sym[i]) & mask) == 0) { *out_len = l; return e.long_code[i]; }
-        }
-    }
-    if (avail >= 2) {
-        const uint32_t key = uint32_t(w) & 0xFFFFu;
-        for (uint32_t s = dev_enc_short2_hash(key);; s = (s + 1) & (kDevEncShort2Slots - 1)) {
-            const uint32_t v = e.short2[s];
-            if (v == 0) break;
-            if (((v >> 8) & 0xFFFFu) == key) { *out_len = 2; return int(v & 0xFFu); }
-        }
-    }
-    const uint16_t s1 = e.short1[uint32_t(w) & 0xFFu];
-    if (s1 == 0xFFFFu) return -1;
-    *out_len = 1;
-    return int(s1 & 0xFFu);
-}
-
 // block-wide exclusive prefix sum of one value per thread (1024 threads = 16 waves); returns the exclusive sum and the total
 __device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t* wave_tot /* 16 */, uint32_t* total) {
     const uint32_t inc = wave_inclusive_sum(v);
@@ -192,22 +168,10 @@ __global__ __launch_bounds__(kBvThreads) void k_bv_build(const BvEncodeDesc* __r
             while (c < m && p[c] == p0[c]) c++;
             sp = c;
             uint8_t* out = a.comp + 2 * size_t(start);
-            uint32_t o = 0, pos = 0, fp = 0;
-            while (pos < len) {
-                const uint32_t avail = len - pos;
-                const uint64_t w = avail >= 8 ? load_unaligned<uint64_t>(p + pos) : load_tail(p + pos, avail);
-                uint32_t l = 1;
-                const int code = enc_match(enc, w, min(avail, 8u), &l);
-                if (code >= 0) {
-                    out[o++] = uint8_t(code);
-                } else {
-                    out[o++] = 255;
-                    out[o++] = uint8_t(w);
-                    l = 1;
-                }
-                for (uint32_t b = 0; b < l; b++) fp |= 1u << (uint32_t(w >> (8u * b)) & 31u);
-                pos += l;
-            }
+            uint32_t fp = 0;
+            const uint32_t o = dev_enc_compress(enc, [p](uint32_t pos, uint32_t avail) {
+                return avail >= 8 ? load_unaligned<uint64_t>(p + pos) : load_tail(p + pos, avail);
+            }, len, out, &fp);
             a.clen[k] = o;
             a.fingerprints[k] = fp;
         }

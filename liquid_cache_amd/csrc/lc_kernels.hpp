@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/liquid_cache_amd.h"
+#include "lc_fsst_device.hpp"
 
 // Ablation hooks (skip a kernel phase, replace counts by timestamps) are compiled ONLY into profiling builds
 // (`make ABLATION=1`): in the shipped library no environment variable can change a result.
@@ -330,19 +331,7 @@ hipError_t launch_str_gather(const StrDesc* d_descs, const DevSymtab* d_symtabs,
                              uint32_t* d_rows, uint64_t* d_totals, uint8_t* d_data, hipStream_t stream);
 
 // ---- on-device byte-view transcoder (lc_bv_encode.hip) ----
-// FsstEncoder (lc_fsst.hpp) as the kernels read it: the symbols of >= 3 bytes in bucket order of their 3-byte-prefix hash
-// (longest first inside a bucket), the 2-byte symbols in a small open-addressing table, the 1-byte symbols by value.
-constexpr uint32_t kDevEncBuckets = 4096;
-constexpr uint32_t kDevEncShort2Slots = 1024;
-__host__ __device__ inline uint32_t dev_enc_short2_hash(uint32_t key16) { return ((key16 * 40503u) >> 4) & (kDevEncShort2Slots - 1); }
-struct DevFsstEncoder {
-    uint64_t long_sym[256];                 // masked to the symbol's length
-    uint32_t short2[kDevEncShort2Slots];    // 0: free, else 1 << 31 | two bytes << 8 | code
-    uint16_t short1[256];                   // 0xFFFF: none, else the code
-    uint8_t long_len[256];
-    uint8_t long_code[256];
-    uint8_t bucket[kDevEncBuckets + 8];     // long symbols of hash h: [bucket[h], bucket[h + 1])
-};
+// (DevFsstEncoder, its matcher and the per-value compression loop: lc_fsst_device.hpp, shared with the CPU model test)
 struct BvEncodeStats {
     uint64_t raw_bytes;       // sum of the dictionary values' lengths
     uint32_t d;               // dictionary values

@@ -27,3 +27,16 @@ def test_c_program_runs_the_readme_vector(tmp_path, product_lib):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "c abi ok" in r.stdout
+
+
+def test_device_fsst_encoder_model_equals_host_encoder(tmp_path):
+    """The encoder k_bv_build runs per dictionary value (lc_fsst_device.hpp: table layout, matcher, compression loop — the
+    same source the kernel compiles) executed on the CPU: its code stream equals FsstEncoder::compress for 19,200 values
+    over 12 trained tables (URLs, all byte values, four-letter alphabets, escape-heavy text; own and foreign data)."""
+    csrc = os.path.join(ROOT, "liquid_cache_amd", "csrc")
+    exe = str(tmp_path / "fsst_device_encoder_model")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", os.path.join(ROOT, "tests", "c_abi", "fsst_device_encoder_model.cpp"),
+                    os.path.join(csrc, "lc_fsst.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "device encoder model ok" in r.stdout
