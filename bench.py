@@ -85,6 +85,8 @@ def parse_args(argv=None):
     p.add_argument("--rotate", type=int, default=0,
                    help="columns the timed loop rotates through (one per step, all resident in HBM) so that a step never "
                         "finds its data in the 256 MiB Infinity Cache; 0 = as many as make the cycle move >= 768 MB (1..8)")
+    p.add_argument("--stage-on-device", action="store_true",
+                   help="url_like: transcode the URL batches on the device (lc_insert_arrow_batch_device) instead of the host")
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
     p.add_argument("--no-secondary", action="store_true", help="skip every secondary workload (profiling runs)")
     p.add_argument("--no-cold", action="store_true",
@@ -120,7 +122,11 @@ def stage_url_column(cache, lc, N, args, rank, n_batches, threads, file_id=None)
             arrs.append(pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1].copy()), pa.py_buffer(data[:n].copy())))
             bids.append(ids[b])
         # the batches of one row group go in together: one upload and one signature-builder launch per row group
-        cache.insert_batch(bids, arrs, None if args.no_fingerprints else lc.CacheExpression.SUBSTRING_SEARCH)
+        hint = None if args.no_fingerprints else lc.CacheExpression.SUBSTRING_SEARCH
+        if args.stage_on_device:
+            cache.insert_device(bids, arrs, hint)  # dictionary + FSST + index on the device (byte-identical entries)
+        else:
+            cache.insert_batch(bids, arrs, hint)
         return rg
 
     n_rg = (n_batches + args.row_group_batches - 1) // args.row_group_batches

@@ -4010,7 +4010,12 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
     const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
     // widths up to 32 bits on u16 / u32 / u64 lanes: register-resident kernel (no LDS: 8 workgroups per CU)
     const bool reg = max_width <= 32 && lane_log2 >= 4;
-    const uint64_t wgs_resident = uint64_t(n_cus) * ((lane_log2 == 6 && !reg) ? 4 : 8);
+    // (A/B aid.  12,207 entries over 8,192 resident waves is 1.49 entries per wave; one workgroup per four entries under the
+    // hardware dispatcher instead — factor 2 / 4 — changed nothing: Date32 W=12 35.5-37.9 us cold, Int64 W=17 58.0-58.6.)
+#ifndef LC_X_REG_GRID_FACTOR
+#define LC_X_REG_GRID_FACTOR 1
+#endif
+    const uint64_t wgs_resident = uint64_t(n_cus) * ((lane_log2 == 6 && !reg) ? 4 : 8) * (reg ? LC_X_REG_GRID_FACTOR : 1);
     const dim3 grid(uint32_t(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), block(kThreads);
     if (reg) {
         const bool narrow = max_width <= 16;
