@@ -1578,7 +1578,10 @@ __device__ __forceinline__ WalkManyResult like_walk_many(const WalkManyArgs& a) 
 // Also measured: a static hand-out of the candidates (no LDS counter) 746 us (the lanes no longer finish together), two
 // blocks in flight instead of three 673 us (-3 %, the default).
 #ifndef LC_X_STREAM_MODE
-#define LC_X_STREAM_MODE 2  // 0: never, 1: whenever the image has a pad code, 2: only when every dictionary value is walked
+#define LC_X_STREAM_MODE 2  // 0: never, 1: whenever the image has a pad code, 2: for dense candidate lists only
+#endif
+#ifndef LC_X_STREAM_DENSITY
+#define LC_X_STREAM_DENSITY 70  // percent of the values a pass looked at that are candidates, from which on the list streams
 #endif
 #ifndef LC_X_STREAM_STATIC
 #define LC_X_STREAM_STATIC 0
@@ -2001,6 +2004,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     const bool sig_only = kSigOnly || (kSub && use_sig && !need_fp);  // the candidates ARE the set bits of the bitmap
     const uint32_t d_eval = uniform_result < 0 ? dp->d : 0u;
     uint32_t pos = 0;              // next dictionary entry to look at (multiple of 64)
+    uint32_t pass_begin = 0;       // first dictionary entry the current candidate list was drawn from
     uint32_t n_cand = 0;           // wave uniform
     uint32_t round_words = kWave;  // bitmap words per signature round (drops to 16 if 64 words overflow an empty list)
     while (pos < d_eval || n_cand > 0) {
@@ -2146,8 +2150,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 // (tbl_synced: the image is in LDS; its last row starts with the pad code)
                 const uint32_t pad_code = lds_u16(row0 + (2u * nl + 1u) * 512u);
                 WalkManyResult wr;
+                // dense lists (most of the values the pass looked at are candidates: no prefilter, or a needle it cannot
+                // prune — '%ru/%' is in 89 % of the URLs) stream; sparse ones keep the chained walker (measured crossover)
+                const uint32_t looked_at = min(pos, dp->d) - min(pass_begin, dp->d);
+                const bool dense = n_walk * 100u >= looked_at * uint32_t(LC_X_STREAM_DENSITY);
                 if (pad_code != 0xFFFFu && dp->fsst_len < kStreamMaxFsst && !LC_ABL(pred.debug_flags & 64) &&
-                    (LC_X_STREAM_MODE == 1 || (LC_X_STREAM_MODE == 2 && !prune))) {
+                    (LC_X_STREAM_MODE == 1 || (LC_X_STREAM_MODE == 2 && dense))) {
                     StreamLds sl;
                     sl.spans = uint32_t(reinterpret_cast<uintptr_t>(hitflag + kFlagBytes + (kSigOnly ? kPostLdsBytes : 0u)));
                     sl.counter = sl.spans + kCap * 4u;
@@ -2285,6 +2293,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             }
         }
         n_cand = 0;
+        pass_begin = pos;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 

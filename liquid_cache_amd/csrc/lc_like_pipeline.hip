@@ -549,6 +549,7 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
     const LikePipeline* lp = s->like;
     const int path = s->ctx->like_path;
+    if (sp.p.mode == 1 && sp.p.needle_len == 1) return "k_str_pred (1-byte needle: no bigram, every fingerprint candidate walked by the many-candidate walkers)";
     if (path == 1 || s->n < s->ctx->like_pipeline_min_entries) return "k_str_pred";
     if (!lp || !lp->built) return "k_str_pred (scan not evaluated yet)";
     if (!lp->eligible) return "k_str_pred (entries without signature index / row lists)";
@@ -589,6 +590,10 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     *handled = false;
     *many_candidates = false;
     const StrPred& p = sp.p;
+    // a 1-byte needle has no bigram: its candidates are whatever the 32-bucket fingerprint lets through, which for a byte
+    // that occurs in the column is most of every dictionary (the many-candidate kernel falls back to the lane-parallel
+    // walk by itself for an entry with less than a wave of candidates)
+    if (p.mode == 1 && p.needle_len == 1 && (p.op == LC_OP_LIKE || p.op == LC_OP_NOT_LIKE)) *many_candidates = true;
     if (p.mode != 1 || (p.op != LC_OP_LIKE && p.op != LC_OP_NOT_LIKE) || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
         automaton_image_bytes(p.needle_len) == 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
         return LC_OK;
