@@ -21,6 +21,7 @@ import pyarrow.parquet as pq
 import pytest
 
 import liquid_cache_amd as lc
+from liquid_cache_amd import _native as N
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import fuzz_data as fz  # noqa: E402
@@ -35,7 +36,9 @@ VARIANTS = {"default": {}, "no_signatures": dict(signatures=False), "no_row_list
             "host_built_index": dict(host_built=True),
             # selective LIKE through the scan-level pipeline even for the smallest scans / never
             "pipeline_always": dict(like_pipeline_min_entries=1), "pipeline_never": dict(like_pipeline_min_entries=-1),
-            "lean_every_needle": dict(like_pipeline_min_entries=1, like_path=3)}
+            "lean_every_needle": dict(like_pipeline_min_entries=1, like_path=3),
+            # every batch transcoded ON THE DEVICE (lc_insert_arrow_batch_device: dictionary, FSST, ALP, packing as kernels)
+            "device_transcoder": {}}
 
 
 def _digest(bools):
@@ -69,6 +72,8 @@ def _literal(p, t):
 @pytest.mark.parametrize("variant", list(VARIANTS))
 def test_reference_samples_through_the_hip_path(product_lib, variant):
     cache = lc.LiquidCacheBuilder.new().with_index_options(**VARIANTS[variant]).build()
+    on_device = variant == "device_transcoder"
+    n_device = 0
     try:
         tables = {"nano_hits": (pq.read_table(os.path.join(GOLD, "nano_hits_cols.parquet")), (24576, 10), 1),
                   "lineitem": (pq.read_table(os.path.join(GOLD, "lineitem_sf0001.parquet")), None, 2)}
@@ -85,7 +90,17 @@ def test_reference_samples_through_the_hip_path(product_lib, variant):
             for rg, b, arr in _batches(table[col], rgs):
                 eid = lc.ParquetArrayID.new(file_id, rg, ci, b)
                 is_str = pa.types.is_string(arr.type)
-                cache.insert(eid, arr, HINT if (is_str and hinted) else None)
+                hint = HINT if (is_str and hinted) else None
+                if on_device:
+                    try:
+                        cache.insert_device([eid], [arr], hint)
+                        nonlocal n_device
+                        n_device += 1
+                    except lc.LiquidCacheError as e:   # types the device encoders do not take stay on the host path
+                        assert e.status == N.LC_UNSUPPORTED, e
+                        cache.insert(eid, arr, hint)
+                else:
+                    cache.insert(eid, arr, hint)
                 ids.append(eid)
                 lens.append(len(arr))
             scans[key] = (cache.scan(ids), ids, lens, table[col].type)
@@ -114,6 +129,7 @@ def test_reference_samples_through_the_hip_path(product_lib, variant):
                 assert _digest(np.concatenate(parts)) == p["digest"], (variant, "per-entry", p)
             checked += 1
         assert checked == len(EXP["predicates"]) >= 200
+        assert not on_device or n_device >= 10  # (the sample columns are strings, integers, dates, decimals: all taken)
         # the SQL-level answers pinned by the reference's datafusion-local snapshots
         scan, ids, lens, t = column("nano_hits", "URL")
         _, c = scan.eval_to_host(lc.LiquidExpr.try_new("like", "%tours%", t, HINT))
