@@ -219,13 +219,15 @@ LC_API lc_status lc_insert_arrow_batch(lc_ctx* ctx, uint64_t n, const uint64_t* 
  * LiquidDecimalArray::from_decimal_array, decimal_array.rs:127-177; LiquidFloatArray::from_arrow_array,
  * float_array.rs:590-740; BitPackedArray::from_primitive, bit_pack_array.rs:71-124).  The staged entries are
  * byte-identical to what lc_insert_arrow stages (checked through lc_entry_to_liquid_bytes).
- * Utf8 / Binary arrays (i32 offsets, up to 65536 rows) become LiquidByteViewArrays on the device as well
+ * Utf8 / Binary arrays (i32 offsets) and Utf8View / BinaryView arrays (what DataFusion's Parquet reader produces; their rows
+ * are laid out as offsets + bytes by the same host pass that copies them into pinned memory), up to 65536 rows, become
+ * LiquidByteViewArrays on the device as well
  * (LiquidByteViewArray::from_string_array, byte_view_array/conversions.rs:260-373): dictionary in first-occurrence order,
  * FSST compression of the dictionary values with the path's symbol table (trained on the host from the first array of a
  * path, transcode.rs:16-33 — training is once per column chunk, encoding is per batch), shared prefix, prefix keys,
  * fingerprints, compact offsets, and the acceleration index (signatures, row lists).  Without hints / path ids
  * (lc_insert_arrow_device) byte views get no fingerprints and path 0.
- * LC_UNSUPPORTED for other array types (views, large offsets, dictionaries), for decimal arrays with a value that does not
+ * LC_UNSUPPORTED for other array types (64-bit offsets, dictionaries), for decimal arrays with a value that does not
  * fit a u64 (the reference's fits_u64, decimal_array.rs:120-125), and for a byte-view array whose offset line fit would
  * round in f64 (sums above 2^53: gigabyte-sized batches): use lc_insert_arrow.  All-or-nothing per array class. */
 LC_API lc_status lc_insert_arrow_device(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids,

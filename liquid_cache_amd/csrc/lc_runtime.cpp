@@ -1396,8 +1396,23 @@ struct BvItem {
     uint32_t slot = 0, encoder = 0;
     uint32_t n = 0;
     bool has_validity = false;
+    bool views = false;  // Utf8View / BinaryView: the rows are gathered into offsets + bytes while they are staged
     size_t data_len = 0;
     uint32_t table_slots = 0;
+    // row r of the array (no validity check)
+    std::pair<const uint8_t*, size_t> row(uint32_t r) const {
+        const size_t i = size_t(a->offset) + r;
+        if (!views) {
+            const int32_t* o = static_cast<const int32_t*>(a->buffers[1]);
+            const uint8_t* d = static_cast<const uint8_t*>(a->buffers[2]);
+            return {d ? d + o[i] : reinterpret_cast<const uint8_t*>(""), size_t(o[i + 1] - o[i])};
+        }
+        const uint8_t* view = static_cast<const uint8_t*>(a->buffers[1]) + 16 * i;
+        const uint32_t len = rd<uint32_t>(view);
+        if (len <= 12) return {view + 4, len};
+        const int32_t buf = rd<int32_t>(view + 8), off = rd<int32_t>(view + 12);
+        return {static_cast<const uint8_t*>(a->buffers[2 + buf]) + off, len};
+    }
     // byte offsets inside the input staging buffer / the device scratch
     size_t in_offsets = 0, in_data = 0, in_validity = 0;
     size_t sc_table = 0, sc_row_slot = 0, sc_dict_row = 0, sc_dict_index = 0, sc_clen = 0, sc_offsets = 0, sc_fp = 0, sc_keys = 0, sc_comp = 0;
@@ -1410,15 +1425,13 @@ static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& item
     CtxSymtabs symtabs(ctx);
     std::vector<uint32_t> enc_slots;
     for (BvItem& it : items) {
-        const int32_t* o = static_cast<const int32_t*>(it.a->buffers[1]) + it.a->offset;
-        const uint8_t* data = static_cast<const uint8_t*>(it.a->buffers[2]);
         if (!symtabs.find(it.path_id)) {
             const uint8_t* validity = it.has_validity ? static_cast<const uint8_t*>(it.a->buffers[0]) : nullptr;
             std::vector<std::pair<const uint8_t*, size_t>> train;
             train.reserve(it.n);
             for (uint32_t r = 0; r < it.n; r++) {
                 if (validity && !get_bit(validity, size_t(it.a->offset) + r)) continue;
-                train.emplace_back(data ? data + o[r] : reinterpret_cast<const uint8_t*>(""), size_t(o[r + 1] - o[r]));
+                train.push_back(it.row(r));
             }
             symtabs.insert(it.path_id, fsst_train(train));
         }
@@ -1491,10 +1504,28 @@ static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& item
         enc.export_device(reinterpret_cast<DevFsstEncoder*>(h_in) + e, kDevEncShort2Slots, dev_enc_short2_hash);
     }
     for (const BvItem& it : items) {
-        const int32_t* o = static_cast<const int32_t*>(it.a->buffers[1]) + it.a->offset;
-        const uint8_t* data = static_cast<const uint8_t*>(it.a->buffers[2]);
-        std::memcpy(h_in + it.in_offsets, o, (size_t(it.n) + 1) * 4);
-        if (it.data_len) std::memcpy(h_in + it.in_data, data + o[0], it.data_len);
+        if (!it.views && !it.a->buffers[1]) {  // (an empty array may come without an offsets buffer)
+            std::memset(h_in + it.in_offsets, 0, (size_t(it.n) + 1) * 4);
+        } else if (!it.views) {
+            const int32_t* o = static_cast<const int32_t*>(it.a->buffers[1]) + it.a->offset;
+            const uint8_t* data = static_cast<const uint8_t*>(it.a->buffers[2]);
+            std::memcpy(h_in + it.in_offsets, o, (size_t(it.n) + 1) * 4);
+            if (it.data_len) std::memcpy(h_in + it.in_data, data + o[0], it.data_len);
+        } else {
+            // views: the same pass that copies the bytes into pinned memory lays them out as offsets + data
+            int32_t* o = reinterpret_cast<int32_t*>(h_in + it.in_offsets);
+            uint8_t* dst = h_in + it.in_data;
+            const uint8_t* validity = it.has_validity ? static_cast<const uint8_t*>(it.a->buffers[0]) : nullptr;
+            size_t pos = 0;
+            for (uint32_t r = 0; r < it.n; r++) {
+                o[r] = int32_t(pos);
+                if (validity && !get_bit(validity, size_t(it.a->offset) + r)) continue;  // (null slots: no bytes)
+                const auto v = it.row(r);
+                if (v.second) std::memcpy(dst + pos, v.first, v.second);
+                pos += v.second;
+            }
+            o[it.n] = int32_t(pos);
+        }
         std::memset(h_in + it.in_data + it.data_len, 0, 16);
         if (it.has_validity) {
             const size_t words = (size_t(it.n) + 63) / 64;
@@ -1705,21 +1736,42 @@ lc_status lc_insert_arrow_batch_device(lc_ctx* ctx, uint64_t n_all, const uint64
         const struct ArrowSchema* s = schemas_all[i];
         if (!a || !s) return fail(LC_ERR_INVALID, "null array");
         const std::string fmt = s->format ? s->format : "";
-        if ((fmt == "u" || fmt == "z") && !s->dictionary) {
+        if ((fmt == "u" || fmt == "z" || fmt == "vu" || fmt == "vz") && !s->dictionary) {
             if (a->length > 65536) return fail(LC_UNSUPPORTED, "byte-view entries of more than 65536 rows are not handled on the device");
             BvItem it;
             it.id = ids_all[i];
             it.a = a;
-            it.arrow_type = fmt == "u" ? kUtf8 : kBinary;
+            it.views = fmt[0] == 'v';
+            it.arrow_type = fmt == "u" ? kUtf8 : fmt == "z" ? kBinary : fmt == "vu" ? kUtf8View : kBinaryView;
             it.want_fp = hints && hints[i] == LC_HINT_SUBSTRING_SEARCH;
             it.path_id = path_ids ? path_ids[i] : 0;
             it.n = uint32_t(a->length);
             it.has_validity = a->n_buffers >= 1 && a->buffers[0] != nullptr;
-            if (a->n_buffers < 3 || !a->buffers[1]) return fail(LC_ERR_INVALID, "Utf8 / Binary array without an offsets buffer");
-            const int32_t* o = static_cast<const int32_t*>(a->buffers[1]) + a->offset;
-            if (o[it.n] < o[0]) return fail(LC_ERR_INVALID, "Utf8 / Binary offsets decrease");
-            it.data_len = size_t(o[it.n] - o[0]);
-            if (it.data_len && !a->buffers[2]) return fail(LC_ERR_INVALID, "Utf8 / Binary array without a data buffer");
+            if (a->n_buffers < (it.views ? 2 : 3) || (it.n && !a->buffers[1]))
+                return fail(LC_ERR_INVALID, "byte array without its offsets / views buffer");
+            if (!it.views) {
+                static const int32_t zero2[2] = {0, 0};
+                const int32_t* o = a->buffers[1] ? static_cast<const int32_t*>(a->buffers[1]) + a->offset : zero2;
+                if (o[it.n] < o[0]) return fail(LC_ERR_INVALID, "Utf8 / Binary offsets decrease");
+                it.data_len = size_t(o[it.n] - o[0]);
+                if (it.data_len && !a->buffers[2]) return fail(LC_ERR_INVALID, "Utf8 / Binary array without a data buffer");
+            } else {
+                const uint8_t* validity = it.has_validity ? static_cast<const uint8_t*>(a->buffers[0]) : nullptr;
+                size_t total = 0;
+                for (uint32_t r = 0; r < it.n; r++) {
+                    if (validity && !get_bit(validity, size_t(a->offset) + r)) continue;
+                    const uint8_t* view = static_cast<const uint8_t*>(a->buffers[1]) + 16 * (size_t(a->offset) + r);
+                    const uint32_t len = rd<uint32_t>(view);
+                    if (len > 12) {
+                        const int32_t buf = rd<int32_t>(view + 8);
+                        if (buf < 0 || int64_t(buf) + 2 >= a->n_buffers || !a->buffers[2 + buf])
+                            return fail(LC_ERR_INVALID, "view refers to a data buffer the array does not have");
+                    }
+                    total += len;
+                }
+                if (total > size_t(INT32_MAX)) return fail(LC_UNSUPPORTED, "more than 2 GiB of bytes in one batch");
+                it.data_len = total;
+            }
             views.push_back(it);
         } else {
             entry_ids_v.push_back(ids_all[i]);

@@ -590,7 +590,7 @@ def test_device_transcoder_is_byte_identical_to_the_host_transcoder(gpu_cache, o
     gpu_cache.insert(999_998, f)
     assert gpu_cache.entry_bytes(999_998) == gpu_cache.transcode(f)
     with pytest.raises(lc.LiquidCacheError) as ex:
-        gpu_cache.insert_device([1], [pa.array(["a", "b"], type=pa.string_view())])  # (Utf8 / Binary are taken since round 3)
+        gpu_cache.insert_device([1], [pa.array(["a", "b"], type=pa.large_string())])  # (Utf8 / Binary and their views are taken since round 3)
     assert ex.value.status == N.LC_UNSUPPORTED
 
 

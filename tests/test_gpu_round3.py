@@ -549,6 +549,10 @@ def _bv_cases():
     cases.append(("no_rows", pa.array([], type=pa.string()), HINT))
     cases.append(("over_8192_rows", pa.array([r.decode() for r in fz._zipf_rows(rng, urls, 20000)]), HINT))  # no row lists
     cases.append(("many_distinct", pa.array([("v%06d" % i) for i in rng.permutation(9000)]), HINT))
+    # view arrays (what DataFusion's Parquet reader hands over): short values inline, long ones in data buffers, nulls, a slice
+    cases.append(("utf8_view", pa.array(with_nulls, type=pa.string_view()), HINT))
+    cases.append(("utf8_view_slice", pa.array(with_nulls, type=pa.string_view()).slice(11, 2500), HINT))
+    cases.append(("binary_view", pa.array(fz._zipf_rows(rng, fz._pool_bytes(rng, 400), 3000), type=pa.binary_view()), HINT))
     return cases
 
 
@@ -589,8 +593,8 @@ def test_device_byte_view_transcoder_equals_host(product_lib, oracle):
         m1, m2 = lc.ParquetArrayID.new(73, 0, 0, 0), lc.ParquetArrayID.new(73, 0, 1, 0)
         cache.insert_device([m1, m2], [nums, cases[0][1]], HINT, path_ids=[0, 9000])
         assert cache.get(m1).read().equals(nums) and cache.entry_bytes(m2) == cache.entry_bytes(host_ids[0])
-        # views are not taken: the caller uses the host transcoder
+        # 64-bit offsets are not taken: the caller uses the host transcoder
         with pytest.raises(lc.LiquidCacheError):
-            cache.insert_device([lc.ParquetArrayID.new(74, 0, 0, 0)], [pa.array(["a", "b"], type=pa.string_view())], HINT, path_ids=[1])
+            cache.insert_device([lc.ParquetArrayID.new(74, 0, 0, 0)], [pa.array(["a", "b"], type=pa.large_string())], HINT, path_ids=[1])
     finally:
         cache.close()
