@@ -47,6 +47,9 @@ static_assert(sizeof(LeanEntry) == 80, "LeanEntry layout");
 // entries a wave takes AT ONCE (their candidates share the wave's lanes).  Two were tried because 12,207 one-entry waves need
 // 1.5 generations of the 8,192 wave slots and 6,104 two-entry waves one: parity green, but 24.9 us against 20.5 — the second
 // probe round and the second walk pass lengthen every wave's dependent chain by more than the saved generation is worth.
+// A second attempt requested the slices of both entries in ONE round and the words of the second walk pass before the first
+// pass is walked (79 VGPRs, 6,104 waves on 6,144 slots: one generation): 24.3 us — the chain of a two-entry wave is ~21 us
+// against ~9 us for one entry (the walks' fixpoint iterations and the row phases add up, they do not overlap).
 constexpr uint32_t kLeanE = LC_LEAN_E;
 static_assert(kLeanE == 1 || kLeanE == 2, "a wave takes one or two entries");
 struct alignas(16) LeanRec {
