@@ -1752,7 +1752,9 @@ lc_status lc_insert_arrow_batch_device(lc_ctx* ctx, uint64_t n_all, const uint64
             if (!it.views) {
                 static const int32_t zero2[2] = {0, 0};
                 const int32_t* o = a->buffers[1] ? static_cast<const int32_t*>(a->buffers[1]) + a->offset : zero2;
-                if (o[it.n] < o[0]) return fail(LC_ERR_INVALID, "Utf8 / Binary offsets decrease");
+                // (the kernels take lengths as offset differences: a decreasing pair would send them out of the buffer)
+                for (uint32_t r = 0; r < it.n; r++)
+                    if (o[r + 1] < o[r] || o[r] < 0) return fail(LC_ERR_INVALID, "Utf8 / Binary offsets decrease");
                 it.data_len = size_t(o[it.n] - o[0]);
                 if (it.data_len && !a->buffers[2]) return fail(LC_ERR_INVALID, "Utf8 / Binary array without a data buffer");
             } else {
