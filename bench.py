@@ -1049,6 +1049,10 @@ def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch
                      "frac": alg3 / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": chain_ms,
                      "algorithmic_bytes": int(alg3), "effective_gbs_vs_5_pass_bytes": alg5 / (chain_ms * 1e-3) / 1e9},
     }
+    if world == 1 and not args.no_secondary:
+        out["roofline"]["kernel_bytes_per_launch"] = int(alg3)
+        out["roofline"]["timing"] = "back_to_back"  # (2.25 GB per pass: far beyond the Infinity Cache, hot = cold)
+        add_read_probe(out["roofline"], cache, N)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_q6(cache, lc, args, ids, expected, min(len(expected), args.cpu_batches or 1500))
     print(json.dumps(out), flush=True)
