@@ -66,10 +66,42 @@ def main():
                             print("MISMATCH variant %s op %s needle %r rep %d: gpu %d truth %d" % (name, op, nd, rep, bits.sum(), want.sum()))
                             sys.exit(1)
                         checked += 1
+            # comparisons against literals cut from the data (whole values, prefixes, a value plus a byte), and LIKE under a
+            # random selection: the result is the selection AND the predicate
+            import operator
+            cmp_ops = {"==": operator.eq, "!=": operator.ne, "<": operator.lt, "<=": operator.le, ">": operator.gt, ">=": operator.ge}
+            lits = []
+            for _ in range(8):
+                v = flat[int(rng.integers(len(flat)))]
+                lits += [v, v[: max(1, len(v) // 2)], v + b"0"]
+            lits += [b"", b"http://", b"https://zzzz"]
+            for lit in lits:
+                for opn, fn in cmp_ops.items():
+                    expr = lc.LiquidExpr.try_new(opn, lit, pa.binary() if False else pa.string(), HINT)
+                    mask, counts = scan.eval_to_host(expr)
+                    bits = np.unpackbits(mask.view(np.uint8), bitorder="little")[: len(flat)].astype(np.bool_)
+                    want = np.fromiter((fn(v, lit) for v in flat), dtype=np.bool_, count=len(flat))
+                    if not np.array_equal(bits, want):
+                        print("MISMATCH variant %s op %s literal %r: gpu %d truth %d" % (name, opn, lit, bits.sum(), want.sum()))
+                        sys.exit(1)
+                    checked += 1
+            sel_bits = rng.random(len(flat)) < 0.3
+            sel_words = np.packbits(sel_bits, bitorder="little").view(np.uint64)
+            for nd in needles[:20]:
+                for op in ("like", "not_like"):
+                    expr = lc.LiquidExpr.try_new(op, b"%" + nd + b"%", pa.string(), HINT)
+                    mask, counts = scan.eval_to_host(expr, sel_words)
+                    bits = np.unpackbits(mask.view(np.uint8), bitorder="little")[: len(flat)].astype(np.bool_)
+                    want = (truth[nd] if op == "like" else ~truth[nd]) & sel_bits
+                    if not np.array_equal(bits, want):
+                        print("MISMATCH under selection: variant %s op %s needle %r" % (name, op, nd))
+                        sys.exit(1)
+                    checked += 1
             scan.close()
         finally:
             cache.close()
-    print("soak ok: %d evaluations (%d needles x 2 operators x 2 x %d variants) over %d rows" % (checked, len(needles), len(VARIANTS), len(flat)))
+    print("soak ok: %d evaluations (%d needles x 2 operators x 2 + 27 literals x 6 comparisons + 40 under a selection, x %d variants) over %d rows" % (
+        checked, len(needles), len(VARIANTS), len(flat)))
 
 
 if __name__ == "__main__":
