@@ -2241,7 +2241,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                     for (;;) {
                         uint32_t prev = lane_shift_up1(e, carry_state);
                         if (first || prev == hitrow) prev = row0;
-                        const bool changed = prev != s_in;
+                        // (only lanes that hold a task: idle lanes behind the last one would hand a state from lane to
+                        // lane for up to 63 more rounds of the loop)
+                        const bool changed = live && prev != s_in;
                         if (__ballot(changed) == 0) break;
                         if (changed) {
                             s_in = prev;

@@ -86,10 +86,20 @@ struct LikePlan {
     uint64_t last_use = 0;
 };
 
+struct FlatGroup;
 struct LikePipeline {
     bool built = false, eligible = false;
     LeanRec* d_lean = nullptr;  // one record per workgroup
     uint32_t n_lean = 0;
+    // the scan-level wide signature index of k_like_flat (see below): kFlatBits slices over the dictionary words of ALL
+    // entries of the scan, slice-major; null when the scan is not eligible for it (or it did not fit)
+    bool flat = false, flat_tried = false;
+    uint64_t* d_slices = nullptr;
+    FlatGroup* d_groups = nullptr;
+    uint32_t n_groups = 0, n_group_slots = 0;  // groups with entries / records incl. the padding of workgroup batches
+    uint32_t group_words = 0;                  // signature words of a group inside a slice (even, <= kFlatGroupWords)
+    uint64_t slices_bytes = 0;
+    double flat_build_ms = 0;
     unsigned long long* d_total_acc = nullptr;
     std::vector<LikePlan> plans;
     uint64_t tick = 0;
@@ -271,7 +281,8 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
                 for (;;) {
                     uint32_t prev = lane_shift_up1(en, carry_state);
                     if (first || prev == hitrow) prev = row0;
-                    const bool changed = prev != s_in;
+                    // (idle lanes behind the last task would hand a state from lane to lane for up to 63 more rounds)
+                    const bool changed = live && prev != s_in;
                     if (__ballot(changed) == 0) break;
                     if (changed) {
                         s_in = prev;
@@ -450,6 +461,609 @@ hipError_t launch_lean(int n_sig, bool negated, const LeanArgs& a, uint32_t n_re
     return hipGetLastError();
 }
 
+}  // namespace
+
+// ================================================================================================================
+// k_like_flat — the same evaluation over a SCAN-LEVEL signature index: 512-bit bigram signatures, stored slice-major
+// across all entries of the scan.
+//
+// Why (round 4): k_like_lean walks 9.4 candidates per entry for 0.34 matching values — everything behind its probe is
+// paid per candidate (offset pair, compressed words, walk: half its time and 37 of its 80 MB).  512 signature bits leave
+// the matches and next to nothing else (URL LIKE '%google%': 0.40 candidates per entry = the matching values), but
+// per-entry storage of that many slices lost in round 2: the five slices a query reads sat up to 140 KB apart.  Here
+// slice b of ALL entries is one dense array, so a query streams N arrays (N = distinct needle bigrams, <= 16) of 8 bytes
+// per 64 dictionary values whatever the number of bits, fully coalesced: a wave owns a GROUP of up to four consecutive
+// entries whose dictionaries fit 128 signature words (URL batches: three, 35 words each) and reads 16 bytes per lane and
+// slice at an address that follows from its index alone — no descriptor round trip in front of the probe.  The group's
+// record (one 64-byte line of scalar loads + 64 bytes per entry copied to LDS) is in flight beside the slices.
+// Behind the probe the chain is the one of k_like_lean with the list bounds of the inverted row lists requested together
+// with the offset pairs: [slices | record | automaton image] -> [offset pair | list bounds] -> words -> walk -> rows -> store.
+//
+// The index is derived data like the bigram slices of the entries (a necessary condition of the same kind as the
+// reference's fingerprint, byte_view_array/fingerprint.rs:33-35; comparisons.rs:598-615), built on the device from the
+// dictionary values the first time a LIKE runs on the scan (k_flat_build), 64 bytes per dictionary value.
+constexpr int kFlatBits = 512;
+constexpr uint32_t kFlatGroupWords = 128;  // signature words of a group: 16 bytes per lane and slice
+constexpr uint32_t kFlatMaxE = 4;          // entries of a group (LDS: 1 KB of mask words each)
+constexpr uint32_t kFlatCap = 256;         // candidates a wave lists before it walks them
+#ifndef LC_FLAT_WAVES
+#define LC_FLAT_WAVES 4
+#endif
+// -DLC_FLAT_STOP=n (variant builds only, results are WRONG): -1 leave at once, 1 probe + zero stores only, 2 up to the offset
+// pairs (12: without loading them), 3 up to the walk (no rows)
+#ifndef LC_FLAT_STOP
+#define LC_FLAT_STOP 0
+#endif
+constexpr uint32_t kFlatWaves = LC_FLAT_WAVES;  // waves (= groups) per workgroup; > 1: they share the LDS automaton image
+static_assert(kFlatWaves == 1 || kFlatWaves == 2 || kFlatWaves == 4, "waves per workgroup");
+__host__ __device__ inline uint32_t flat_bigram_bit(uint32_t a, uint32_t b) {
+    return ((((a << 8) | b) * 40503u) >> 7) & uint32_t(kFlatBits - 1);
+}
+
+struct alignas(16) FlatEntry {  // what the walk needs of an entry, copied to LDS
+    const uint8_t* residuals;
+    const uint8_t* fsst;
+    const uint16_t* postings;
+    const uint64_t* validity;      // NOT LIKE only
+    const uint32_t* fingerprints;  // NOT LIKE only
+    int32_t slope, intercept;
+    uint32_t d, offset_bytes;
+    uint32_t pad[2];
+};
+static_assert(sizeof(FlatEntry) == 64, "FlatEntry layout");
+struct alignas(64) FlatGroup {
+    // one line, scalar loads
+    uint32_t first_entry, n_entries;  // entries [first_entry, first_entry + n_entries) of the scan; 0 entries: padding
+    uint32_t slot;                    // their symbol table
+    uint32_t n_words;                 // signature words in use (<= kFlatGroupWords)
+    uint32_t word_off[kFlatMaxE];     // first signature word of entry j (0xFFFFFFFF beyond n_entries)
+    uint64_t mask_word_off;           // of entry 0; the segments of a scan's consecutive entries are consecutive
+    uint32_t n_rows[kFlatMaxE];
+    uint32_t pad[2];
+    FlatEntry e[kFlatMaxE];
+};
+constexpr uint32_t kFlatHotBytes = 64;
+static_assert(sizeof(FlatGroup) == kFlatHotBytes + 64 * kFlatMaxE, "FlatGroup layout");
+
+namespace {
+
+struct FlatArgs {
+    const FlatGroup* groups;
+    uint32_t n_slots;                       // records (groups + padding)
+    const uint64_t* slices;
+    uint64_t slice_words;                   // u64 words of one slice (= n_slots * group_words)
+    uint32_t group_words;                   // words of a group inside a slice: the largest group of the scan, even
+    const uint8_t* automata;
+    uint32_t automaton_stride;
+    uint32_t nl;
+    uint32_t n_extra;                       // signature bits beyond the N the kernel is instantiated for
+    uint32_t needle_fp;
+    uint16_t sig_bits[kMaxSigProbeWide];
+    const uint64_t* selection;
+    uint64_t* mask;
+    uint32_t* counts;
+    unsigned long long* stats;
+    ScanLaunch total;
+};
+using ConstFlatPtr = const __attribute__((address_space(4))) FlatGroup*;
+
+template <int N, bool kNot>
+__global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
+    // dynamic LDS: [automaton image][per wave: kFlatMaxE x 128 mask words | kFlatMaxE x FlatEntry | kFlatCap candidates
+    //                                          (entry << 16 | key) | 64 hit flags + head mask]
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    constexpr uint32_t kMaskBytes = kPostMaxRows / 8u;
+    constexpr uint32_t kPerWave = kFlatMaxE * kMaskBytes + kFlatMaxE * 64u + kFlatCap * 4u + 80u;
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    if (LC_FLAT_STOP == -1) return;
+    const uint32_t nl = a.nl;
+    const uint32_t tbl_bytes = automaton_image_bytes(nl);
+    // XCD-aware order (see k_like_lean): workgroup b takes batch (b % 8) * ceil(G / 8) + b / 8
+    const uint32_t per_xcd = (gridDim.x + 7u) / 8u;
+    const uint32_t wg = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const uint32_t gi = wg * kFlatWaves + wave;
+    const uint32_t unit = blockIdx.x * kFlatWaves + wave, n_units = gridDim.x * kFlatWaves;
+    if (wg * kFlatWaves >= a.n_slots) {  // (the grid is rounded up to a multiple of 8: a whole workgroup without records)
+        if (a.total.d_total_out && lane == 0) total_contribute(a.total, unit, n_units, 0);
+        return;
+    }
+    const bool live = gi < a.n_slots;
+    // ---- the probe's loads: 16 bytes per lane and slice, addresses from the wave's index alone
+    u32x4 sv[N];
+    u32x4 xv[kMaxSigProbeWide - kMaxSigProbe];
+#pragma unroll
+    for (int k = 0; k < N; k++) sv[k] = u32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < kMaxSigProbeWide - kMaxSigProbe; k++) xv[k] = u32x4{~0u, ~0u, ~0u, ~0u};
+    if (live && 2u * uint32_t(lane) < a.group_words) {
+        const uint64_t* base = a.slices + size_t(gi) * a.group_words + size_t(lane) * 2u;
+#pragma unroll
+        for (int k = 0; k < N; k++)
+            sv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(reinterpret_cast<uintptr_t>(base + size_t(a.sig_bits[k]) * a.slice_words));
+        if (N == kMaxSigProbe && a.n_extra) {
+#pragma unroll
+            for (int k = 0; k < kMaxSigProbeWide - kMaxSigProbe; k++)
+                xv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(reinterpret_cast<uintptr_t>(
+                    base + size_t(a.sig_bits[kMaxSigProbe + min(uint32_t(k), a.n_extra - 1u)]) * a.slice_words));
+        }
+    }
+    ConstFlatPtr G = reinterpret_cast<ConstFlatPtr>(reinterpret_cast<uintptr_t>(a.groups + (live ? gi : wg * kFlatWaves)));
+    const uint32_t n_entries = live ? G->n_entries : 0u;
+    const uint32_t first_entry = G->first_entry;
+    const uint32_t wo1 = G->word_off[1], wo2 = G->word_off[2], wo3 = G->word_off[3];
+    const uint64_t moff0 = G->mask_word_off;
+    const uint32_t nr0 = G->n_rows[0], nr1 = G->n_rows[1], nr2 = G->n_rows[2], nr3 = G->n_rows[3];
+    uint8_t* wbase = smem + tbl_bytes + wave * kPerWave;
+    uint64_t* pmask = reinterpret_cast<uint64_t*>(wbase);
+    const FlatEntry* cold = reinterpret_cast<const FlatEntry*>(wbase + kFlatMaxE * kMaskBytes);
+    uint32_t* list = reinterpret_cast<uint32_t*>(wbase + kFlatMaxE * kMaskBytes + kFlatMaxE * 64u);
+    uint8_t* hitflag = reinterpret_cast<uint8_t*>(list) + kFlatCap * 4u;
+    uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
+    // the entries' walk fields -> LDS (16 lanes x 16 bytes), in flight with the slices
+    if (lane < int(kFlatMaxE * 4u))
+        async_copy16(reinterpret_cast<const uint8_t*>(a.groups + (live ? gi : wg * kFlatWaves)) + kFlatHotBytes + uint32_t(lane) * 16u,
+                     wbase + kFlatMaxE * kMaskBytes);
+    auto load_image = [&]() {
+        const uint8_t* src = a.automata + size_t(G->slot) * a.automaton_stride + automaton_u8_bytes(nl);
+        for (uint32_t c = wave * 1024u; c < tbl_bytes; c += kFlatWaves * 1024u) async_copy16(src + c + uint32_t(lane) * 16u, smem + c);
+    };
+    if (kFlatWaves > 1) load_image();  // shared by the workgroup: every wave brings its share, one barrier below
+    const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
+    if (row0 != 0u) __builtin_trap();  // the image holds absolute LDS addresses computed for address 0
+    const uint32_t hitrow = row0 + nl * 512u;
+    // mask words of the entries start clear in LDS (16 bytes per lane and entry)
+#pragma unroll
+    for (uint32_t q = 0; q < kFlatMaxE; q++) reinterpret_cast<uint4*>(pmask)[q * 64u + uint32_t(lane)] = make_uint4(0, 0, 0, 0);
+
+    // ---- AND of the needle's slices: 128 dictionary values per lane
+    uint64_t m0, m1;
+    {
+        u32x4 m = sv[0];
+#pragma unroll
+        for (int k = 1; k < N; k++) m &= sv[k];
+        if (N == kMaxSigProbe && a.n_extra) {
+#pragma unroll
+            for (int k = 0; k < kMaxSigProbeWide - kMaxSigProbe; k++) m &= xv[k];
+        }
+        m0 = uint64_t(m.x) | (uint64_t(m.y) << 32);
+        m1 = uint64_t(m.z) | (uint64_t(m.w) << 32);
+    }
+    const uint32_t cnt = uint32_t(__popcll(m0)) + uint32_t(__popcll(m1));
+    const uint32_t incl = wave_inclusive_sum(cnt);
+    const uint32_t tot = read_lane(incl, kWave - 1);
+    bool image_ready = false;
+    auto sync_image = [&]() {  // every wave of the workgroup passes this exactly once
+        if (image_ready) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kFlatWaves > 1) __syncthreads();
+        image_ready = true;
+    };
+    uint32_t any_match = 0;  // NOT LIKE: bit j: entry j has a matching dictionary value (wave uniform)
+    uint64_t wave_hits = 0;
+
+    if ((!kNot && tot == 0) || LC_FLAT_STOP == 1) {
+        // no dictionary value of the group can contain the needle: zeros, straight from registers
+        uint64_t moff = moff0;
+        for (uint32_t j = 0; j < n_entries; j++) {
+            const uint32_t nr = j == 0 ? nr0 : j == 1 ? nr1 : j == 2 ? nr2 : nr3;
+            const uint32_t nwords = (nr + 63u) >> 6;
+            for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) as_global_mut(a.mask)[moff + w] = 0;
+            if (a.counts && lane == 0) as_global_mut(a.counts)[first_entry + j] = 0;
+            moff += nwords;
+        }
+        if (kFlatWaves > 1) sync_image();
+        if (a.total.d_total_out && lane == 0) total_contribute(a.total, unit, n_units, 0);
+        return;
+    }
+    if (kFlatWaves == 1 && tot != 0) load_image();
+
+    // walk candidates list[0 .. count): 64 per batch, one lane per 8-byte word; rows of the matches go into pmask
+    auto walk_list = [&](uint32_t count) {
+        for (uint32_t b0 = 0; b0 < count; b0 += kWave) {
+            const uint32_t j = b0 + uint32_t(lane);
+            const bool cl = j < count;
+            const uint32_t c32 = cl ? list[j] : 0u;
+            const uint32_t key = c32 & 0xFFFFu;
+            const uint32_t ej = c32 >> 16;
+            uint64_t abs_start = 0;
+            uint32_t len = 0, o0 = 0, o1 = 0;
+            const uint16_t* prow = nullptr;
+            if (cl && LC_FLAT_STOP != 12) {
+                const FlatEntry& E = cold[ej];
+                const uint32_t ob = E.offset_bytes;
+                const uint64_t v = load_unaligned<uint64_t>(E.residuals + size_t(key) * ob);
+                const uint32_t pb = load_unaligned<uint32_t>(reinterpret_cast<const uint8_t*>(E.postings) + 2u * size_t(key));
+                const uint32_t slope = uint32_t(E.slope), intercept = uint32_t(E.intercept);
+                const uint32_t sh = 32u - 8u * ob;
+                const int32_t q0 = int32_t(uint32_t(v) << sh) >> sh;
+                const int32_t q1 = int32_t(uint32_t(v >> (8u * ob)) << sh) >> sh;
+                const uint32_t start = slope * key + intercept + uint32_t(q0);
+                len = slope * (key + 1u) + intercept + uint32_t(q1) - start;
+                abs_start = uint64_t(reinterpret_cast<uintptr_t>(E.fsst)) + start;
+                o0 = pb & 0xFFFFu;
+                o1 = pb >> 16;
+                prow = E.postings + E.d + 1u;
+            }
+            // the first four rows of every candidate's list, requested with its compressed words (at 512 signature bits
+            // nearly every candidate is a match, and a URL value occurs in ~4 rows of its batch): no round trip behind the walk
+            uint64_t rows4 = 0;
+            if (cl && o1 > o0) rows4 = load_unaligned<uint64_t>(reinterpret_cast<const uint8_t*>(prow + o0));
+            const uint32_t words = cl ? max(1u, (len + 7u) >> 3) : 0u;
+            const uint32_t wincl = wave_inclusive_sum(words);
+            const uint32_t off = wincl - words;
+            const uint32_t total = read_lane(wincl, kWave - 1);
+            hitflag[lane] = 0;
+            if (LC_FLAT_STOP == 2 || LC_FLAT_STOP == 12) { if (total == 0x7FFFFFFFu) list[0] = 1; continue; }
+            uint32_t carry_state = row0;
+            for (uint32_t t0 = 0; t0 < total; t0 += kWave) {
+                if (lane == 0) *headmask = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const bool head = cl && off >= t0 && off < t0 + kWave;
+                if (head) atomicOr(reinterpret_cast<unsigned long long*>(headmask), 1ull << (off - t0));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint64_t hm = *headmask;
+                const uint32_t before = uint32_t(__popcll(__ballot(cl && off < t0)));
+                const uint64_t upto = lane == 63 ? ~uint64_t(0) : ((uint64_t(2) << lane) - 1);
+                const uint32_t r = before + uint32_t(__popcll(hm & upto)) - 1u;  // owner lane of task t0 + lane
+                const bool tlive = t0 + uint32_t(lane) < total;
+                const uint32_t o_off = uint32_t(__shfl(int(off), int(r), kWave));
+                const uint32_t o_len = uint32_t(__shfl(int(len), int(r), kWave));
+                const uint32_t o_lo = uint32_t(__shfl(int(uint32_t(abs_start)), int(r), kWave));
+                const uint32_t o_hi = uint32_t(__shfl(int(uint32_t(abs_start >> 32)), int(r), kWave));
+                const uint32_t k = t0 + uint32_t(lane) - o_off;
+                const uint32_t p = 8u * k;
+                const uint32_t rem = tlive && p < o_len ? o_len - p : 0u;
+                uint64_t wd = 0;
+                if (rem) wd = load_unaligned<uint64_t>(reinterpret_cast<const uint8_t*>((uint64_t(o_hi) << 32 | o_lo) + p));
+                const bool first = k == 0;
+                auto walk_task = [&](uint32_t st) {
+                    uint32_t x[8];
+                    const uint32_t lo = uint32_t(wd), hi = uint32_t(wd >> 32);
+#pragma unroll
+                    for (int q = 0; q < 8; q++) x[q] = (((q < 4 ? lo : hi) >> (8 * (q & 3))) & 0xFFu) << 1;
+                    return walk8(st, x, rem);
+                };
+                sync_image();
+                uint32_t s_in = row0;
+                uint32_t en = walk_task(s_in);
+                for (;;) {
+                    uint32_t prev = lane_shift_up1(en, carry_state);
+                    if (first || prev == hitrow) prev = row0;
+                    const bool changed = tlive && prev != s_in;
+                    if (__ballot(changed) == 0) break;
+                    if (changed) {
+                        s_in = prev;
+                        en = walk_task(s_in);
+                    }
+                }
+                const bool hit = en == hitrow;  // a match counts only at the fixpoint (see k_str_pred)
+                carry_state = read_lane(en, kWave - 1);
+                if (carry_state == hitrow) carry_state = row0;
+                if (hit && tlive) hitflag[r] = 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const bool res = cl && hitflag[lane] != 0;
+            uint64_t matched = __ballot(res);
+            if (a.stats) {
+                const uint64_t lb = wave_sum_u64(uint64_t(len));
+                if (lane == 0) {
+                    atomicAdd(a.stats, (unsigned long long)min(count - b0, uint32_t(kWave)));
+                    atomicAdd(a.stats + 1, (unsigned long long)lb);
+                    atomicAdd(a.stats + 2, (unsigned long long)__popcll(matched));
+                }
+            }
+            // rows of the matching dictionary values from the entries' inverted row lists, into the LDS mask words
+            if (LC_FLAT_STOP == 3) matched = matched == 0x123456789ull ? 1 : 0;
+            if (kNot && matched) {
+#pragma unroll
+                for (uint32_t q = 0; q < kFlatMaxE; q++)
+                    if (__ballot(res && ej == q)) any_match |= 1u << q;
+            }
+            if (LC_FLAT_STOP != 3 && res) {
+                uint64_t* pm = pmask + ej * (kMaskBytes / 8u);
+                const uint32_t nr4 = min(o1 - o0, 4u);
+                for (uint32_t q = 0; q < nr4; q++) {
+                    const uint32_t row = uint32_t(rows4 >> (16u * q)) & 0xFFFFu;
+                    atomicOr(reinterpret_cast<unsigned long long*>(&pm[row >> 6]), 1ull << (row & 63u));
+                }
+            }
+            matched = LC_FLAT_STOP == 3 ? 0 : __ballot(res && o1 - o0 > 4u);  // longer lists: the rest, a value at a time
+            while (matched) {
+                const int ml = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)matched)) - 1);
+                matched &= matched - 1;
+                const uint32_t b = read_lane(o0, ml) + 4u, e1 = read_lane(o1, ml);
+                const uint32_t uj = read_lane(ej, ml);  // wave uniform
+                const FlatEntry& E = cold[uj];
+                const uint16_t* pr = E.postings + E.d + 1u;
+                uint64_t* pm = pmask + uj * (kMaskBytes / 8u);
+                for (uint32_t rr = b + uint32_t(lane); rr < e1; rr += kWave) {
+                    const uint32_t row = as_global(pr)[rr];
+                    atomicOr(reinterpret_cast<unsigned long long*>(&pm[row >> 6]), 1ull << (row & 63u));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    };
+
+    // ---- the candidates: (entry of the group << 16) | dictionary key
+    auto entry_of = [&](uint32_t w) { return uint32_t(w >= wo1) + uint32_t(w >= wo2) + uint32_t(w >= wo3); };
+    auto word_base = [&](uint32_t ej) { return ej == 0 ? 0u : ej == 1 ? wo1 : ej == 2 ? wo2 : wo3; };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the entries' fields are in LDS)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (tot <= kFlatCap) {
+        uint32_t o = incl - cnt;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            uint64_t m = h ? m1 : m0;
+            const uint32_t w = 2u * uint32_t(lane) + uint32_t(h);
+            const uint32_t ej = entry_of(w);
+            const uint32_t kb = (w - word_base(ej)) * 64u;
+            while (m) {
+                const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+                m &= m - 1;
+                list[o++] = (ej << 16) | (kb + bit);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        walk_list(tot);
+    } else {
+        // more candidates than the list holds (the needle is not selective here): the signature words are taken one after
+        // the other, each word's values (<= 64) as one batch
+        for (int sl = 0; sl < kWave; sl++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint64_t mm = h ? m1 : m0;
+                const uint64_t ms = uniform_u64(uint64_t(uint32_t(__shfl(int(uint32_t(mm)), sl, kWave))) |
+                                                (uint64_t(uint32_t(__shfl(int(uint32_t(mm >> 32)), sl, kWave))) << 32));
+                if (ms == 0) continue;
+                const uint32_t w = 2u * uint32_t(sl) + uint32_t(h);
+                const uint32_t ej = entry_of(w);
+                if ((ms >> lane) & 1u) list[lanes_below(ms)] = (ej << 16) | ((w - word_base(ej)) * 64u + uint32_t(lane));
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                walk_list(uint32_t(__popcll(ms)));
+            }
+        }
+    }
+    sync_image();
+    // ---- the entries' mask words: rows of the lists are valid rows, the selection is applied here
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    uint64_t moff = moff0;
+    for (uint32_t j = 0; j < n_entries; j++) {
+        const uint32_t nr = j == 0 ? nr0 : j == 1 ? nr1 : j == 2 ? nr2 : nr3;
+        const uint32_t nwords = (nr + 63u) >> 6;
+        uint32_t c = 0;
+        bool invert = false;  // wave uniform
+        const uint64_t* validity = nullptr;
+        if (kNot) {
+            // the reference inverts the dictionary results only when some dictionary value passes the 32-bucket fingerprint
+            // filter of the needle (comparisons.rs:167-180, :644-648); a matching value passes it
+            const FlatEntry& E = cold[j];
+            validity = E.validity;
+            invert = ((any_match >> j) & 1u) != 0;
+            for (uint32_t i0 = 0; !invert && i0 < E.d; i0 += kWave) {
+                const uint32_t i = i0 + uint32_t(lane);
+                const uint32_t fp = i < E.d ? as_global(E.fingerprints)[i] : 0u;
+                invert = __ballot((fp & a.needle_fp) == a.needle_fp && i < E.d) != 0;
+            }
+        }
+        for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
+            uint64_t hitw = pmask[j * (kMaskBytes / 8u) + w];
+            if (kNot) {
+                const uint32_t rows_left = nr - (w << 6);
+                uint64_t keep = rows_left >= 64 ? ~uint64_t(0) : ((uint64_t(1) << rows_left) - 1);
+                if (validity) keep &= as_global(validity)[w];
+                hitw = invert ? ~hitw & keep : 0;
+                if (a.selection) hitw &= as_global(a.selection)[moff + w];
+            } else if (a.selection && hitw) {
+                hitw &= as_global(a.selection)[moff + w];
+            }
+            as_global_mut(a.mask)[moff + w] = hitw;
+            c += uint32_t(__popcll(hitw));
+        }
+        if (a.counts || a.total.d_total_out) {
+            const uint32_t ct = read_lane(wave_inclusive_sum(c), kWave - 1);
+            if (lane == 0 && a.counts) as_global_mut(a.counts)[first_entry + j] = ct;
+            wave_hits += ct;
+        }
+        moff += nwords;
+    }
+    if (a.total.d_total_out && lane == 0) total_contribute(a.total, unit, n_units, wave_hits);
+}
+
+hipError_t launch_flat(int n_sig, bool negated, const FlatArgs& a, hipStream_t stream) {
+    if (a.n_slots == 0) return hipSuccess;
+    typedef void (*Kern)(FlatArgs);
+    static const Kern table[2][kMaxSigProbe] = {
+        {k_like_flat<1, false>, k_like_flat<2, false>, k_like_flat<3, false>, k_like_flat<4, false>, k_like_flat<5, false>,
+         k_like_flat<6, false>, k_like_flat<7, false>, k_like_flat<8, false>},
+        {k_like_flat<1, true>, k_like_flat<2, true>, k_like_flat<3, true>, k_like_flat<4, true>, k_like_flat<5, true>,
+         k_like_flat<6, true>, k_like_flat<7, true>, k_like_flat<8, true>}};
+    const size_t lds = automaton_image_bytes(a.nl) + kFlatWaves * (kFlatMaxE * (kPostMaxRows / 8u) + kFlatMaxE * 64u + kFlatCap * 4u + 80u);
+    const uint32_t wgs = (a.n_slots + kFlatWaves - 1u) / kFlatWaves;
+    const uint32_t grid = (wgs + 7u) / 8u * 8u;
+    hipLaunchKernelGGL(table[negated ? 1 : 0][n_sig - 1], dim3(grid), dim3(kFlatWaves * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+// Builder of the scan-level slices: workgroup (x, e) takes eight signature words (512 dictionary values) of entry e — a
+// lane decodes one value through the symbol table into kFlatBits bits in registers (as k_str_build_signatures), ballots
+// transpose 64 values to slice words staged in LDS, and the workgroup stores eight consecutive words of every slice.
+struct FlatBuildArgs {
+    const StrDesc* descs;
+    const DevSymtab* symtabs;
+    const uint32_t* dst_word;  // per entry: its first word inside a slice
+    uint64_t* slices;
+    uint64_t slice_words;
+};
+__global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
+    constexpr int kSigWords = kFlatBits / 64;
+    __shared__ uint64_t s_sym[256];
+    __shared__ uint8_t s_len[256];
+    __shared__ uint64_t stage[kFlatBits][8];
+    const StrDesc d = a.descs[blockIdx.y];
+    const uint32_t nw = (d.d + 63u) >> 6;
+    if (d.d == 0 || blockIdx.x * 8u >= nw) return;
+    const DevSymtab& st = a.symtabs[d.symtab_slot];
+    s_sym[threadIdx.x] = st.sym[threadIdx.x];
+    s_len[threadIdx.x] = st.len[threadIdx.x];
+    __syncthreads();
+    const int lane = lane_id(), wave = wave_id();
+    for (uint32_t q = 0; q < 2; q++) {
+        const uint32_t cc = uint32_t(wave) * 2u + q;  // column of the stage
+        const uint32_t c = blockIdx.x * 8u + cc;
+        uint64_t mine[kSigWords];
+#pragma unroll
+        for (int r = 0; r < kSigWords; r++) mine[r] = 0;
+        const uint32_t i = c * 64u + uint32_t(lane);
+        if (c < nw && i < d.d) {
+            uint32_t start, stop;
+            str_offset_pair(d, i, start, stop);
+            int prev = -1;
+            bool escaped = false;
+            uint64_t w = start < stop ? load_unaligned<uint64_t>(d.fsst + start) : 0;
+            for (uint32_t p = start; p < stop; p += 8u) {
+                const uint64_t cur_w = w;
+                if (p + 8u < stop) w = load_unaligned<uint64_t>(d.fsst + p + 8u);
+                const uint32_t nb = min(8u, stop - p);
+                for (uint32_t k = 0; k < nb; k++) {
+                    const uint32_t code = uint32_t(cur_w >> (8u * k)) & 0xFFu;
+                    uint64_t sym;
+                    uint32_t len;
+                    if (escaped) { sym = code; len = 1; escaped = false; }
+                    else if (code == 255u) { escaped = true; continue; }
+                    else { sym = s_sym[code]; len = s_len[code]; }
+                    for (uint32_t t = 0; t < len; t++) {
+                        const int cur = int((sym >> (8u * t)) & 0xFFu);
+                        if (prev >= 0) {
+                            const uint32_t bit = flat_bigram_bit(uint32_t(prev), uint32_t(cur));
+#pragma unroll
+                            for (int r = 0; r < kSigWords; r++)
+                                if (int(bit >> 6) == r) mine[r] |= uint64_t(1) << (bit & 63u);
+                        }
+                        prev = cur;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kSigWords; r++) {
+            uint64_t keep = 0;  // lane b ends up with the word of slice 64 r + b
+            for (int b = 0; b < 64; b++) {
+                const uint64_t wv = __ballot((mine[r] >> b) & 1);
+                if (lane == b) keep = wv;
+            }
+            stage[64 * r + lane][cc] = keep;
+        }
+    }
+    __syncthreads();
+    const uint32_t cols = min(8u, nw - blockIdx.x * 8u);
+    const size_t dst = size_t(a.dst_word[blockIdx.y]) + size_t(blockIdx.x) * 8u;
+    for (uint32_t s = threadIdx.x; s < uint32_t(kFlatBits); s += 256u)
+        for (uint32_t cc = 0; cc < cols; cc++) a.slices[size_t(s) * a.slice_words + dst + cc] = stage[s][cc];
+}
+
+// The scan-level index of k_like_flat: groups of consecutive entries (one symbol table, <= kFlatMaxE entries, <= 128
+// signature words), their records, and the kFlatBits slices built from the dictionary values.  A scan whose index does not
+// fit (more than half of the free device memory) keeps k_like_lean.
+lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
+    lp->flat = false;
+    lp->flat_tried = true;
+    std::vector<FlatGroup> groups;
+    std::vector<uint32_t> dst_word(s->n, 0);
+    uint32_t n_groups = 0;
+    auto pad_batch = [&]() {  // a workgroup's groups share a symbol table: close the batch with empty records
+        while (groups.size() % kFlatWaves) {
+            FlatGroup g;
+            std::memset(&g, 0, sizeof(g));
+            g.slot = groups.back().slot;
+            g.first_entry = groups.back().first_entry + groups.back().n_entries;
+            g.mask_word_off = s->seg_offsets[g.first_entry];
+            for (uint32_t k = 0; k < kFlatMaxE; k++) g.word_off[k] = 0xFFFFFFFFu;
+            groups.push_back(g);
+        }
+    };
+    for (uint32_t b = 0; b < s->n;) {
+        FlatGroup g;
+        std::memset(&g, 0, sizeof(g));
+        for (uint32_t k = 0; k < kFlatMaxE; k++) g.word_off[k] = 0xFFFFFFFFu;
+        g.first_entry = b;
+        g.slot = s->meta[b].sd.symtab_slot;
+        g.mask_word_off = s->seg_offsets[b];
+        uint32_t words = 0, i = b;
+        while (i < s->n && i - b < kFlatMaxE && s->meta[i].sd.symtab_slot == g.slot) {
+            const StrDesc& d = s->meta[i].sd;
+            const uint32_t nw = (d.d + 63u) / 64u;
+            if (words + nw > kFlatGroupWords) break;
+            // (consecutive entries of a scan have consecutive mask segments: the kernel derives them from the first)
+            if (i > b && d.mask_word_off != s->seg_offsets[i]) return fail(LC_ERR_INVALID, "scan mask segments are not consecutive");
+            const uint32_t j = i - b;
+            g.word_off[j] = words;
+            g.n_rows[j] = d.n;
+            g.e[j] = FlatEntry{d.residuals, d.fsst, d.postings, d.validity, d.fingerprints, d.slope, d.intercept, d.d,
+                               uint32_t(d.offset_bytes), {0, 0}};
+            words += nw;
+            i++;
+        }
+        if (i == b) return LC_OK;  // (a dictionary of more than 8192 values: not eligible, k_like_lean stays)
+        g.word_off[0] = 0;
+        g.n_entries = i - b;
+        g.n_words = words;
+        if (!groups.empty() && groups.back().slot != g.slot) pad_batch();
+        groups.push_back(g);
+        n_groups++;
+        b = i;
+    }
+    if (groups.empty()) return LC_OK;
+    pad_batch();
+    // every group takes the same number of words inside a slice (the wave's address follows from its index): the largest
+    // group of the scan, even (16-byte loads)
+    uint32_t gw = 2;
+    for (const FlatGroup& g : groups) gw = std::max(gw, (g.n_words + 1u) & ~1u);
+    for (size_t gi = 0; gi < groups.size(); gi++)
+        for (uint32_t j = 0; j < groups[gi].n_entries; j++)
+            dst_word[groups[gi].first_entry + j] = uint32_t(gi) * gw + groups[gi].word_off[j];
+    if (uint64_t(groups.size()) * gw > 0xFFFFFFFFull) return LC_OK;
+    const uint64_t slice_words = uint64_t(groups.size()) * gw;
+    const uint64_t bytes = slice_words * 8u * uint64_t(kFlatBits);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    (void)hipEventCreate(&ev0);
+    (void)hipEventCreate(&ev1);
+    uint32_t* d_dst = static_cast<uint32_t*>(pool_alloc(ctx, size_t(s->n) * 4));
+    struct Tmp {
+        lc_ctx* c; void* p; hipStream_t st; hipEvent_t a, b;
+        ~Tmp() { (void)hipStreamSynchronize(st); pool_release(c, p); if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } tmp{ctx, d_dst, stream, ev0, ev1};
+    if (!d_dst) return fail(LC_ERR_OOM, "hipMalloc (flat index build)");
+    if (hipMalloc(reinterpret_cast<void**>(&lp->d_slices), bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        lp->d_slices = nullptr;
+        return LC_OK;  // no room: the entry-level index serves
+    }
+    lp->d_groups = static_cast<FlatGroup*>(pool_alloc(ctx, groups.size() * sizeof(FlatGroup)));
+    if (!lp->d_groups) return fail(LC_ERR_OOM, "hipMalloc (flat group records)");
+    if (ev0) LC_HIP(hipEventRecord(ev0, stream));
+    LC_HIP(hipMemsetAsync(lp->d_slices, 0, bytes, stream));
+    LC_HIP(hipMemcpyAsync(lp->d_groups, groups.data(), groups.size() * sizeof(FlatGroup), hipMemcpyHostToDevice, stream));
+    LC_HIP(hipMemcpyAsync(d_dst, dst_word.data(), size_t(s->n) * 4, hipMemcpyHostToDevice, stream));
+    FlatBuildArgs ba{static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, d_dst, lp->d_slices, slice_words};
+    const uint32_t max_nw = (std::max(s->max_dict_len, 1u) + 63u) / 64u;
+    hipLaunchKernelGGL(k_flat_build, dim3((max_nw + 7u) / 8u, s->n), dim3(256), 0, stream, ba);
+    LC_HIP(hipGetLastError());
+    if (ev1) LC_HIP(hipEventRecord(ev1, stream));
+    LC_HIP(hipStreamSynchronize(stream));  // the vectors are locals
+    float ms = 0;
+    if (ev0 && ev1 && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) lp->flat_build_ms = ms;
+    lp->n_groups = n_groups;
+    lp->n_group_slots = uint32_t(groups.size());
+    lp->group_words = gw;
+    lp->slices_bytes = bytes;
+    lp->flat = true;
+    return LC_OK;
+}
+
 // per-workgroup records, built once per scan
 lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
     lp->built = true;
@@ -510,6 +1124,64 @@ lc_status run_lean(LikePipeline* lp, const StrPred& p, const ScanLaunch& L, hipS
     return LC_OK;
 }
 
+// the needle's bigrams as bits of the scan-level signatures, in the order make_str_pred takes them (both ends, then the
+// midpoints of the remaining gaps: every prefix of the list covers the needle evenly)
+uint32_t flat_needle_bits(const std::vector<uint8_t>& needle, uint16_t (&bits)[kMaxSigProbeWide]) {
+    uint32_t n = 0;
+    const size_t il = needle.size();
+    if (il < 2) return 0;
+    std::vector<size_t> order;
+    const size_t last = il - 2;
+    std::vector<uint8_t> seen(last + 1, 0);
+    std::vector<std::pair<size_t, size_t>> gaps;
+    auto take = [&](size_t k) { if (!seen[k]) { seen[k] = 1; order.push_back(k); } };
+    take(0);
+    take(last);
+    gaps.push_back({0, last});
+    for (size_t g = 0; g < gaps.size(); g++) {
+        const size_t lo = gaps[g].first, hi = gaps[g].second;
+        if (hi - lo < 2) continue;
+        const size_t mid = lo + (hi - lo) / 2;
+        take(mid);
+        gaps.push_back({lo, mid});
+        gaps.push_back({mid, hi});
+    }
+    for (size_t k : order) {
+        if (n >= uint32_t(kMaxSigProbeWide)) break;
+        const uint16_t bit = uint16_t(flat_bigram_bit(needle[k], needle[k + 1]));
+        bool dup = false;
+        for (uint32_t q = 0; q < n; q++) dup |= bits[q] == bit;
+        if (!dup) bits[n++] = bit;
+    }
+    for (uint32_t q = n; q < uint32_t(kMaxSigProbeWide); q++) bits[q] = bits[0];
+    return n;
+}
+
+lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
+                   unsigned long long* d_stats = nullptr, bool force_like = false) {
+    const StrPred& p = sp.p;
+    FlatArgs fa{};
+    fa.groups = lp->d_groups;
+    fa.n_slots = lp->n_group_slots;
+    fa.slices = lp->d_slices;
+    fa.slice_words = uint64_t(lp->n_group_slots) * lp->group_words;
+    fa.group_words = lp->group_words;
+    fa.automata = p.automata;
+    fa.automaton_stride = p.automaton_stride;
+    fa.nl = p.needle_len;
+    const uint32_t nb = flat_needle_bits(sp.needle, fa.sig_bits);
+    fa.n_extra = nb > uint32_t(kMaxSigProbe) ? nb - uint32_t(kMaxSigProbe) : 0u;
+    fa.needle_fp = p.needle_fp;
+    fa.selection = L.d_selection;
+    fa.mask = L.d_hit;
+    fa.counts = L.d_counts;
+    fa.stats = d_stats;
+    fa.total.d_total_acc = lp->d_total_acc;
+    fa.total.d_total_out = L.d_total_out;
+    LC_HIP(launch_flat(int(std::min<uint32_t>(nb, uint32_t(kMaxSigProbe))), p.op == LC_OP_NOT_LIKE && !force_like, fa, stream));
+    return LC_OK;
+}
+
 // one trial evaluation into scratch: how many rows does the needle hit?
 lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost& sp, hipStream_t stream, LikePlan* plan) {
     plan->needle = sp.needle;
@@ -526,7 +1198,9 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
     L.d_total_out = d_scratch + words;
     LC_HIP(hipMemsetAsync(d_scratch + words, 0, 32, stream));
     // (always as LIKE: the plan belongs to the needle, NOT LIKE is selective exactly when LIKE is)
-    const lc_status rc = run_lean(lp, sp.p, L, stream, reinterpret_cast<unsigned long long*>(d_scratch + words + 1), true);
+    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(d_scratch + words + 1);
+    const bool use_flat = lp->flat && (ctx->like_path == 0 || ctx->like_path == 4);
+    const lc_status rc = use_flat ? run_flat(lp, sp, L, stream, d_stats, true) : run_lean(lp, sp.p, L, stream, d_stats, true);
     if (rc != LC_OK) return rc;
     uint64_t res[4] = {0, 0, 0, 0};
     LC_HIP(hipMemcpyAsync(res, d_scratch + words, 32, hipMemcpyDeviceToHost, stream));
@@ -545,6 +1219,8 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     if (!lp) return;
     pool_release(ctx, lp->d_lean);
     pool_release(ctx, lp->d_total_acc);
+    pool_release(ctx, lp->d_groups);
+    if (lp->d_slices) (void)hipFree(lp->d_slices);
     delete lp;
 }
 
@@ -557,11 +1233,14 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
     if (!lp || !lp->built) return "k_str_pred (scan not evaluated yet)";
     if (!lp->eligible) return "k_str_pred (entries without signature index / row lists)";
     if (path == 3) return "k_like_lean (forced for every needle)";
+    const bool use_flat = lp->flat && (path == 0 || path == 4);
+    if (path == 4 && use_flat) return "k_like_flat (forced for every needle)";
+    if (path == 4) return "k_like_lean (forced for every needle; no scan-level index)";
     for (const LikePlan& q : lp->plans)
         if (q.needle == sp.needle) {
             char buf[256];
-            std::snprintf(buf, sizeof(buf), "%s: %llu candidates (%.1f per entry), %llu matching values, %llu hit rows at plan time",
-                          q.use_lean ? "k_like_lean" : "k_str_pred (needle not selective)", (unsigned long long)q.n_cand,
+            std::snprintf(buf, sizeof(buf), "%s: %llu candidates (%.2f per entry), %llu matching values, %llu hit rows at plan time",
+                          q.use_lean ? (use_flat ? "k_like_flat" : "k_like_lean") : "k_str_pred (needle not selective)", (unsigned long long)q.n_cand,
                           double(q.n_cand) / double(std::max<uint32_t>(s->n, 1)), (unsigned long long)q.matches,
                           (unsigned long long)q.hits);
             return buf;
@@ -578,7 +1257,18 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
     const LikePipeline* lp = s->like;
     if (!lp || !lp->eligible || s->ctx->like_path == 1) return 0;
     for (const LikePlan& q : lp->plans)
-        if (q.needle == sp.needle && (q.use_lean || s->ctx->like_path == 3)) {
+        if (q.needle == sp.needle && (q.use_lean || s->ctx->like_path == 3 || s->ctx->like_path == 4)) {
+            if (lp->flat && (s->ctx->like_path == 0 || s->ctx->like_path == 4)) {
+                // k_like_flat: per group its record line and 1 KB of every probed slice; per group with a candidate the
+                // entries' walk fields; per candidate its offset pair (8), list bounds (4) and compressed bytes; 2 bytes
+                // per hit row; the mask words out
+                uint16_t bits[kMaxSigProbeWide];
+                const uint64_t nb = flat_needle_bits(sp.needle, bits);
+                uint64_t b = uint64_t(lp->n_group_slots) * (kFlatHotBytes + nb * lp->group_words * 8) + s->seg_offsets.back() * 8 +
+                             (with_counts ? uint64_t(s->n) * 4 : 0);
+                b += std::min<uint64_t>(q.n_cand, lp->n_groups) * 64 * kFlatMaxE + q.n_cand * 12 + q.cand_bytes + q.hits * 2;
+                return b;
+            }
             uint64_t b = uint64_t(lp->n_lean) * 16 + uint64_t(s->n) * 64 + s->seg_offsets.back() * 8 + (with_counts ? uint64_t(s->n) * 4 : 0);
             for (const Entry& e : s->meta) b += uint64_t((e.sd.d + 63u) / 64u) * 8 * sp.p.n_sig_wide;
             b += q.n_cand * 8 + q.cand_bytes + q.matches * 4 + q.hits * 2;
@@ -608,6 +1298,12 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         if (st != LC_OK) return st;
     }
     if (!lp->eligible) return LC_OK;
+    const bool want_flat = ctx->like_path == 0 || ctx->like_path == 4;
+    if (want_flat && !lp->flat_tried) {
+        const lc_status st = build_flat(ctx, s, lp, stream);
+        if (st != LC_OK) return st;
+    }
+    const bool use_flat = want_flat && lp->flat;
     LikePlan* plan = nullptr;
     for (LikePlan& q : lp->plans)
         if (q.needle == sp.needle) plan = &q;
@@ -628,8 +1324,8 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     // a needle the plan found unselective: k_str_pred takes it, and with at least a wave of candidates per entry its
     // sequential walker (every lane works through its own share of the list) beats the lane-parallel one
     if (!plan->use_lean) *many_candidates = plan->n_cand >= uint64_t(kWave) * s->n;
-    if (!plan->use_lean && ctx->like_path != 3) return LC_OK;
-    const lc_status st = run_lean(lp, p, L, stream);
+    if (!plan->use_lean && ctx->like_path != 3 && ctx->like_path != 4) return LC_OK;
+    const lc_status st = use_flat ? run_flat(lp, sp, L, stream) : run_lean(lp, p, L, stream);
     if (st == LC_OK) *handled = true;
     return st;
 }

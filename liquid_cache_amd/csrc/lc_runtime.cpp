@@ -711,7 +711,7 @@ lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
         case LC_OPT_HOST_BUILT_INDEX: ctx->signatures_on_host = value != 0; return LC_OK;
         case LC_OPT_LIKE_MANY_HINT: ctx->like_many_hint = value != 0; return LC_OK;
         case LC_OPT_LIKE_PATH:
-            if (value != 0 && value != 1 && value != 3) return fail(LC_ERR_INVALID, "LC_OPT_LIKE_PATH takes 0, 1 or 3");
+            if (value < 0 || value > 4) return fail(LC_ERR_INVALID, "LC_OPT_LIKE_PATH takes 0 .. 4");
             ctx->like_path = int(value);
             return LC_OK;
         case LC_OPT_LIKE_PIPELINE_MIN_ENTRIES:
