@@ -22,6 +22,9 @@
 // Reference counterpart: LiquidByteViewArray::compare_like_substring — fingerprint filter, decode + memmem of the
 // candidates, map_dictionary_results_to_array_results (byte_view_array/comparisons.rs:159-183, 325-347, 598-651).
 // Results are identical (the candidates of the signature AND are a superset of the matches, the walk is exact).
+#include <chrono>
+#include <cstring>
+
 #include "lc_device.hpp"
 #include "lc_internal.hpp"
 
@@ -84,6 +87,8 @@ struct LikePlan {
     bool use_lean = false;
     uint64_t hits = 0, n_cand = 0, cand_bytes = 0, matches = 0;  // of the trial run (byte accounting, EXPLAIN)
     uint64_t last_use = 0;
+    uint32_t n_probe = 0;   // k_like_flat: slices probed (a long needle has more bigrams than are worth reading, see make_plan)
+    float plan_ms = 0;      // what planning cost (trial launches + the host round trip)
 };
 
 struct FlatGroup;
@@ -1158,7 +1163,7 @@ uint32_t flat_needle_bits(const std::vector<uint8_t>& needle, uint16_t (&bits)[k
 }
 
 lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
-                   unsigned long long* d_stats = nullptr, bool force_like = false) {
+                   unsigned long long* d_stats = nullptr, bool force_like = false, uint32_t max_probe = kMaxSigProbeWide) {
     const StrPred& p = sp.p;
     FlatArgs fa{};
     fa.groups = lp->d_groups;
@@ -1169,7 +1174,8 @@ lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L,
     fa.automata = p.automata;
     fa.automaton_stride = p.automaton_stride;
     fa.nl = p.needle_len;
-    const uint32_t nb = flat_needle_bits(sp.needle, fa.sig_bits);
+    const uint32_t nb = std::min(flat_needle_bits(sp.needle, fa.sig_bits), std::max(max_probe, 1u));
+    for (uint32_t q = nb; q < uint32_t(kMaxSigProbeWide); q++) fa.sig_bits[q] = fa.sig_bits[0];
     fa.n_extra = nb > uint32_t(kMaxSigProbe) ? nb - uint32_t(kMaxSigProbe) : 0u;
     fa.needle_fp = p.needle_fp;
     fa.selection = L.d_selection;
@@ -1200,15 +1206,42 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
     // (always as LIKE: the plan belongs to the needle, NOT LIKE is selective exactly when LIKE is)
     unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(d_scratch + words + 1);
     const bool use_flat = lp->flat && (ctx->like_path == 0 || ctx->like_path == 4);
-    const lc_status rc = use_flat ? run_flat(lp, sp, L, stream, d_stats, true) : run_lean(lp, sp.p, L, stream, d_stats, true);
-    if (rc != LC_OK) return rc;
+    const auto t_begin = std::chrono::steady_clock::now();
     uint64_t res[4] = {0, 0, 0, 0};
-    LC_HIP(hipMemcpyAsync(res, d_scratch + words, 32, hipMemcpyDeviceToHost, stream));
-    LC_HIP(hipStreamSynchronize(stream));
+    auto trial = [&](uint32_t n_probe) -> lc_status {
+        LC_HIP(hipMemsetAsync(d_scratch + words, 0, 32, stream));
+        const lc_status rc = use_flat ? run_flat(lp, sp, L, stream, d_stats, true, n_probe) : run_lean(lp, sp.p, L, stream, d_stats, true);
+        if (rc != LC_OK) return rc;
+        LC_HIP(hipMemcpyAsync(res, d_scratch + words, 32, hipMemcpyDeviceToHost, stream));
+        LC_HIP(hipStreamSynchronize(stream));
+        return LC_OK;
+    };
+    uint16_t bits[kMaxSigProbeWide];
+    const uint32_t nb = use_flat ? flat_needle_bits(sp.needle, bits) : 0u;
+    plan->n_probe = std::min<uint32_t>(nb, uint32_t(kMaxSigProbe));
+    lc_status rc = trial(use_flat ? plan->n_probe : 0u);
+    if (rc != LC_OK) return rc;
+    if (use_flat && nb > uint32_t(kMaxSigProbe)) {
+        // A long needle has more bigrams than the eight a wave reads in its first round.  Every further slice costs the scan
+        // 8 bytes per 64 dictionary values and removes candidates; what is cheaper depends on the data ('%yandex.ru/search%':
+        // 74 -> 37 candidates per entry with all 15 — worth it; a 34-byte needle that hits nothing: 1.1 -> 0 — not worth
+        // 27 MB more).  Priced with the measured constants of this kernel: ~0.75 us per slice and 12,207 entries against
+        // ~0.2 ns per candidate walked.
+        const uint64_t cand8 = res[1];
+        uint64_t keep[4];
+        std::memcpy(keep, res, sizeof(keep));
+        rc = trial(nb);
+        if (rc != LC_OK) return rc;
+        const double slice_ns = 750.0 * double(lp->n_group_slots) / 4096.0, cand_ns = 0.2;
+        const double cost8 = double(cand8) * cand_ns, cost_all = double(res[1]) * cand_ns + double(nb - kMaxSigProbe) * slice_ns;
+        if (cost_all < cost8) plan->n_probe = nb;
+        else std::memcpy(res, keep, sizeof(keep));
+    }
     plan->hits = res[0];
     plan->n_cand = res[1];
     plan->cand_bytes = res[2];
     plan->matches = res[3];
+    plan->plan_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     plan->use_lean = plan->hits * 1024u <= uint64_t(kMaxHitsPer1024) * std::max<uint64_t>(s->total_rows, 1024);
     return LC_OK;
 }
@@ -1238,11 +1271,14 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
     if (path == 4) return "k_like_lean (forced for every needle; no scan-level index)";
     for (const LikePlan& q : lp->plans)
         if (q.needle == sp.needle) {
-            char buf[256];
-            std::snprintf(buf, sizeof(buf), "%s: %llu candidates (%.2f per entry), %llu matching values, %llu hit rows at plan time",
-                          q.use_lean ? (use_flat ? "k_like_flat" : "k_like_lean") : "k_str_pred (needle not selective)", (unsigned long long)q.n_cand,
-                          double(q.n_cand) / double(std::max<uint32_t>(s->n, 1)), (unsigned long long)q.matches,
-                          (unsigned long long)q.hits);
+            char buf[384];
+            int k = std::snprintf(buf, sizeof(buf), "%s: %llu candidates (%.2f per entry), %llu matching values, %llu hit rows at plan time",
+                                  q.use_lean ? (use_flat ? "k_like_flat" : "k_like_lean") : "k_str_pred (needle not selective)",
+                                  (unsigned long long)q.n_cand, double(q.n_cand) / double(std::max<uint32_t>(s->n, 1)),
+                                  (unsigned long long)q.matches, (unsigned long long)q.hits);
+            if (use_flat && k > 0 && size_t(k) < sizeof(buf))
+                std::snprintf(buf + k, sizeof(buf) - size_t(k), "; %u slices probed, planned in %.2f ms; scan-level index %.2f GB built in %.1f ms",
+                              q.n_probe, double(q.plan_ms), double(lp->slices_bytes) / 1e9, lp->flat_build_ms);
             return buf;
         }
     return "k_str_pred (needle not planned)";
@@ -1263,7 +1299,7 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
                 // entries' walk fields; per candidate its offset pair (8), list bounds (4) and compressed bytes; 2 bytes
                 // per hit row; the mask words out
                 uint16_t bits[kMaxSigProbeWide];
-                const uint64_t nb = flat_needle_bits(sp.needle, bits);
+                const uint64_t nb = std::min<uint64_t>(flat_needle_bits(sp.needle, bits), q.n_probe ? q.n_probe : kMaxSigProbeWide);
                 uint64_t b = uint64_t(lp->n_group_slots) * (kFlatHotBytes + nb * lp->group_words * 8) + s->seg_offsets.back() * 8 +
                              (with_counts ? uint64_t(s->n) * 4 : 0);
                 b += std::min<uint64_t>(q.n_cand, lp->n_groups) * 64 * kFlatMaxE + q.n_cand * 12 + q.cand_bytes + q.hits * 2;
@@ -1325,7 +1361,8 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     // sequential walker (every lane works through its own share of the list) beats the lane-parallel one
     if (!plan->use_lean) *many_candidates = plan->n_cand >= uint64_t(kWave) * s->n;
     if (!plan->use_lean && ctx->like_path != 3 && ctx->like_path != 4) return LC_OK;
-    const lc_status st = use_flat ? run_flat(lp, sp, L, stream) : run_lean(lp, p, L, stream);
+    const lc_status st = use_flat ? run_flat(lp, sp, L, stream, nullptr, false, plan->n_probe ? plan->n_probe : kMaxSigProbeWide)
+                                  : run_lean(lp, p, L, stream);
     if (st == LC_OK) *handled = true;
     return st;
 }
