@@ -6,7 +6,7 @@ included: `URL LIKE '%google%'` (benchmark/clickbench/queries/q20.sql / q21.sql 
 synthetic 100 M-row ClickBench-shaped URL column that is fully transcoded (dictionary + FSST + fingerprints) and
 resident in HBM before the timed region starts.  Reported on ONE JSON line: filtered rows/s (value), the roofline
 object of the dominant kernel (live HIP-event timing on the launch stream; `achieved` counts the bytes the kernel itself
-has to move, `effective_gbs` the reference algorithm's bytes of SURVEY §8d; hot and L3-cold), a CPU baseline (the C oracle
+has to move, `reference_algorithm_equivalent_gbs` the reference algorithm's bytes of SURVEY §8d; hot and L3-cold), a CPU baseline (the C oracle
 restating the reference's algorithm on the same bytes, whose hit count must equal the GPU's), and — at N=1 — the
 secondary workloads of BASELINE.json's other configs (Int64 `>`, narrow integer / date / decimal columns, the TPC-H Q6
 chain, get-with-selection, the q21.sql pushdown pipeline, LIKE without the signature index / without fingerprints).
@@ -50,6 +50,9 @@ def parse_args(argv=None):
     p.add_argument("--rows", type=int, default=99_997_497, help="rows per GPU (ClickBench hits = 99,997,497)")
     p.add_argument("--rows-total", type=int, default=0,
                    help="strong scaling: rows of the whole table, split evenly over the ranks (overrides --rows)")
+    p.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                   help="--gpus N > 1: 'strong' (default) splits ONE --rows table (ClickBench hits: 99,997,497 rows) by contiguous "
+                        "row ranges, the metric's '1/2/4/8 GPU' line; 'weak' stages --rows rows on every rank")
     p.add_argument("--batch-size", type=int, default=8192)
     p.add_argument("--uniques", type=int, default=2200, help="distinct URLs per batch (nano_hits: ~2,150-2,250)")
     p.add_argument("--row-group-batches", type=int, default=54, help="batches sharing one FSST symbol table")
@@ -100,24 +103,34 @@ def parse_args(argv=None):
 
 
 # ---------------------------------------------------------------------------------------------------------- staging
+def url_seed(args, rank):
+    """Generator seed of the URL column: rank-free when the ranks hold row ranges of ONE table (strong scaling)."""
+    return args.seed + (0 if getattr(args, "batch0", None) is not None else rank * 1_000_003)
+
+
 def stage_url_column(cache, lc, N, args, rank, n_batches, threads, file_id=None):
-    """Generate + transcode + stage the URL column through the public API; returns entry ids."""
+    """Generate + transcode + stage the URL column through the public API; returns entry ids.  Under strong scaling
+    (args.batch0 = this rank's first GLOBAL batch) the batches are generated by their global index from a rank-free seed and
+    carry their global ids: the union of the shards is the table a single GPU stages."""
     L = N.load()
     import pyarrow as pa
     rows_total = args.rows
     bs = args.batch_size
-    fid = rank if file_id is None else file_id
-    ids = [lc.ParquetArrayID.new(fid, b // args.row_group_batches, 13, b % args.row_group_batches)
-           for b in range(n_batches)]
+    strong = getattr(args, "batch0", None) is not None
+    b0 = args.batch0 if strong else 0
+    fid = (0 if strong else rank) if file_id is None else file_id
+    rgb = args.row_group_batches
+    ids = [lc.ParquetArrayID.new(fid, (b + b0) // rgb, 13, (b + b0) % rgb) for b in range(n_batches)]
+    seed = url_seed(args, rank)
 
     def do_row_group(rg):
         offs = np.zeros(bs + 1, np.int32)
         data = np.zeros(bs * 512, np.uint8)
-        first = rg * args.row_group_batches
         arrs, bids = [], []
-        for b in range(first, min(first + args.row_group_batches, n_batches)):
+        for gb in range(max(rg * rgb, b0), min((rg + 1) * rgb, b0 + n_batches)):
+            b = gb - b0
             rows = min(bs, rows_total - b * bs)
-            n = N.load_bench().lc_synth_url_batch(args.seed + rank * 1_000_003, b, rows, min(args.uniques, rows), args.needle_ppm,
+            n = N.load_bench().lc_synth_url_batch(seed, gb, rows, min(args.uniques, rows), args.needle_ppm,
                                      offs.ctypes.data, data.ctypes.data, data.size)
             arrs.append(pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1].copy()), pa.py_buffer(data[:n].copy())))
             bids.append(ids[b])
@@ -129,9 +142,9 @@ def stage_url_column(cache, lc, N, args, rank, n_batches, threads, file_id=None)
             cache.insert_batch(bids, arrs, hint)
         return rg
 
-    n_rg = (n_batches + args.row_group_batches - 1) // args.row_group_batches
-    with ThreadPoolExecutor(max_workers=threads) as ex:
-        list(ex.map(do_row_group, range(n_rg)))
+    if n_batches > 0:
+        with ThreadPoolExecutor(max_workers=threads) as ex:
+            list(ex.map(do_row_group, range(b0 // rgb, (b0 + n_batches - 1) // rgb + 1)))
     return ids
 
 
@@ -181,14 +194,17 @@ def stage_int_column(cache, lc, N, args, rank, rows_total, threads, bits=None, b
     bits = args.int_bits if bits is None else bits
     base = int_base(bits) if base is None else base
     n_batches = (rows_total + bs - 1) // bs
-    ids = [lc.ParquetArrayID.new(rank, b // args.row_group_batches, col, b % args.row_group_batches)
+    strong = getattr(args, "batch0", None) is not None  # row ranges of ONE table: global batch index, rank-free seed
+    b0 = args.batch0 if strong else 0
+    ids = [lc.ParquetArrayID.new(0 if strong else rank, (b + b0) // args.row_group_batches, col, (b + b0) % args.row_group_batches)
            for b in range(n_batches)]
+    seed = args.seed + (0 if strong else rank * 1_000_003) + col * 7919
 
     def do_chunk(c):
         buf = np.zeros(bs, np.int64)
         for b in range(c, n_batches, threads):
             rows = min(bs, rows_total - b * bs)
-            N.load_bench().lc_synth_int64_batch(args.seed + rank * 1_000_003 + col * 7919, b, rows, bits, base, buf.ctypes.data)
+            N.load_bench().lc_synth_int64_batch(seed, b + b0, rows, bits, base, buf.ctypes.data)
             v = buf[:rows]
             if on_batch is not None:
                 on_batch(b, v)
@@ -231,19 +247,26 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def measured_traffic(key):
+def measured_traffic(key, kernel=None):
     """HBM bytes per launch of the dominant kernel, from the rocprofv3 --pmc passes of the newest profiled round
     (profiles/<round>/hbm_traffic.json, produced by scripts/profile_round.sh + scripts/pmc_summary.py: FETCH_SIZE scaled
     by the factor calibrated on known byte counts, plus WRITE_SIZE; counters cannot be read from inside the process).
-    None when this workload has not been profiled."""
+    `kernel`: the figure is only taken from a profile of THAT kernel (a round that replaced the kernel must not inherit the
+    old one's bytes).  None when this workload has not been profiled."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "hbm_traffic.json")), reverse=True):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if key in d and "traffic_bytes" in d[key]:
-            return int(d[key]["traffic_bytes"]), os.path.relpath(f, ROOT)
+        e = d.get(key)
+        if not isinstance(e, dict) or "traffic_bytes" not in e:
+            continue
+        fam = (kernel or "").split("<")[0].split(" ")[0]
+        if fam and not any(isinstance(v, dict) and k.startswith(fam) and v.get("traffic_bytes") == e["traffic_bytes"]
+                           for k, v in e.items()):
+            return None, None  # the newest profile of this workload is of another kernel: unmeasured, not inherited
+        return int(e["traffic_bytes"]), os.path.relpath(f, ROOT)
     return None, None
 
 
@@ -251,8 +274,9 @@ def roofline(kernel, kernel_ms, alg_bytes, kernel_bytes, cold_ms=None, traffic=N
     """`achieved` = bytes the kernel itself has to move (lc_scan_traffic_model) / kernel time: a true fraction of the
     HBM peak.  The time is the L3-COLD one when it was measured (Infinity Cache flushed before every launch: a hot-cache
     query over a 100-column table never finds a 100 MB column in the 256 MiB memory-side cache); the back-to-back figure
-    is kept as `*_hot`.  `effective_gbs` = the reference algorithm's bytes / the same time: what the scan is
-    worth to the query; it exceeds `achieved` wherever the kernel's index structures spare it bytes."""
+    is kept as `*_hot`.  `reference_algorithm_equivalent_gbs` = the reference algorithm's bytes / the same
+    time: what the scan is worth to the query.  It is NOT a bandwidth — it exceeds `achieved` (and the HBM peak) wherever
+    the kernel's index structures spare it bytes."""
     t_ms = cold_ms if cold_ms is not None else kernel_ms
     ach = kernel_bytes / (t_ms * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -262,7 +286,8 @@ def roofline(kernel, kernel_ms, alg_bytes, kernel_bytes, cold_ms=None, traffic=N
            # the same fraction by MEASURED HBM bytes (PMC): what the memory system actually delivered for this kernel
            "frac_by_traffic": (traffic / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
            "kernel": kernel, "kernel_ms": t_ms, "kernel_bytes_per_launch": int(kernel_bytes),
-           "algorithmic_bytes_per_launch": int(alg_bytes), "effective_gbs": alg_bytes / (t_ms * 1e-3) / 1e9}
+           "algorithmic_bytes_per_launch": int(alg_bytes),
+           "reference_algorithm_equivalent_gbs": alg_bytes / (t_ms * 1e-3) / 1e9}
     if cold_ms is not None:
         out.update({"kernel_ms_hot": kernel_ms, "achieved_hot": kernel_bytes / (kernel_ms * 1e-3) / 1e9,
                     "frac_hot": kernel_bytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -434,7 +459,7 @@ def measure_get_with_selection(scan, lc, bits, base, counts, torch, stream, iter
                          "selected_rows": k_sel, "ms": g_ms, "necessary_bytes": int(necessary),
                          "achieved_gbs": necessary / (g_ms * 1e-3) / 1e9,
                          "frac": necessary / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes": int(alg), "effective_gbs": alg / (g_ms * 1e-3) / 1e9,
+                         "algorithmic_bytes": int(alg), "reference_algorithm_equivalent_gbs": alg / (g_ms * 1e-3) / 1e9,
                          "rows_per_s": scan.rows / (g_ms * 1e-3)}
     return res
 
@@ -901,6 +926,42 @@ def cpu_baseline_url(cache, lc, N, args, rank, n_sample, pattern, threads, extra
     return rows_total / dt, rows_total, int(hits), dt, all_cores
 
 
+def oracle_url_sample_counts(cache, lc, N, args, rank, file_id, batches, pattern, threads):
+    """Checker leg: the oracle's per-batch COUNT(*) of `pattern` for the given batches of a staged URL column
+    (regenerated from its seed and transcoded with the column's own symbol tables: the bytes the GPU holds)."""
+    from oracle import liquid_oracle as lo
+    import pyarrow as pa
+    bs = args.batch_size
+    blobs = [None] * len(batches)
+    seed = url_seed(args, rank)
+
+    def prep(c):
+        offs = np.zeros(bs + 1, np.int32)
+        data = np.zeros(bs * 512, np.uint8)
+        for k in range(c, len(batches), threads):
+            b = batches[k]
+            rows = min(bs, args.rows - b * bs)
+            n = N.load_bench().lc_synth_url_batch(seed, b, rows, min(args.uniques, rows), args.needle_ppm,
+                                                  offs.ctypes.data, data.ctypes.data, data.size)
+            arr = pa.StringArray.from_buffers(rows, pa.py_buffer(offs[: rows + 1]), pa.py_buffer(data[:n]))
+            eid = lc.ParquetArrayID.new(file_id, b // args.row_group_batches, 13, b % args.row_group_batches)
+            path = lc.ParquetArrayID.column_access_path(eid)
+            blobs[k] = (cache.transcode(arr, lc.CacheExpression.SUBSTRING_SEARCH, path), path)
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(prep, range(threads)))
+    symtabs = {}
+    for _, path in blobs:
+        if path not in symtabs:
+            symtabs[path] = lo.symtab_load(cache.symbol_table(path))
+    seg = np.zeros(len(batches) + 1, np.uint64)
+    for k, b in enumerate(batches):
+        seg[k + 1] = seg[k] + (min(bs, args.rows - b * bs) + 63) // 64
+    _, _, cpu_counts, = lo.bench_eval_batches_masks([bl for bl, _ in blobs], [symtabs[pth] for _, pth in blobs], lo.LIKE,
+                                                    pattern, seg, usable_cores())
+    return np.asarray(cpu_counts).astype(np.int64)
+
+
 def cpu_baseline_int(cache, lc, N, args, rank, n_sample, literal, base):
     from oracle import liquid_oracle as lo
     import pyarrow as pa
@@ -1070,25 +1131,42 @@ def main():
     scaling = "weak"
     if args.workload == "tpch_q6" and not args.rows_total:
         args.rows_total = 600_037_902  # TPC-H SF100 lineitem
+    if world > 1 and not args.rows_total and args.scaling != "weak":
+        # the metric's "1/2/4/8 GPU" line: ONE table of --rows rows (ClickBench hits: 99,997,497) split by contiguous row
+        # ranges (ParquetArrayID keeps file / row group / batch of a row range together, datafusion/src/cache/id.rs:15-21)
+        args.rows_total = args.rows
+    if args.scaling == "strong" and not args.rows_total:
+        args.rows_total = args.rows
     batch0 = 0
+    args.batch0 = None
     if args.rows_total:
         # strong scaling: contiguous, batch-aligned row ranges per rank (liquid_cache_amd.sharding.assign_row_ranges
         # over equally weighted batches gives exactly this split)
         from liquid_cache_amd.sharding import contiguous_batch_range
         total_batches = (args.rows_total + args.batch_size - 1) // args.batch_size
         b0, b1 = contiguous_batch_range(total_batches, rank, world)
-        args.rows = min(args.rows_total, b1 * args.batch_size) - b0 * args.batch_size
+        args.rows = max(0, min(args.rows_total, b1 * args.batch_size) - b0 * args.batch_size)
         batch0 = b0
         scaling = "strong"
+        if world > 1:
+            args.batch0 = b0  # generators and ids take GLOBAL batch indices: the shards' union is the one-GPU table
 
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: liquid_cache_amd has no CPU fallback")
+    # LC_BENCH_TEST_BACKEND=gloo: dry run of the multi-rank code path on a box with ONE GPU (every rank on device 0, the
+    # collectives through gloo) — a test aid for the launcher / sharding / reporting logic, never a measurement
+    test_backend = os.environ.get("LC_BENCH_TEST_BACKEND")
+    if test_backend:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if test_backend:
+            dist.init_process_group(backend=test_backend)
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as g
     if rank == 0:
@@ -1135,6 +1213,14 @@ def main():
     words = int(scan.mask_words)
     mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
     counts = torch.zeros(max(scan.entries, 1), dtype=torch.int32, device="cuda")
+    # what the FIRST evaluation of this predicate on a fresh scan costs (host wall clock, device drained before and after):
+    # the scan's records, the scan-level index of k_like_flat, the folded automata and the plan's trial launch — a query's
+    # first run pays it, the steady state of the timed loop does not
+    torch.cuda.synchronize()
+    t_first = time.perf_counter()
+    scan.eval(expr, mask.data_ptr(), 0, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    first_eval_us = (time.perf_counter() - t_first) * 1e6
     # The timed loop ROTATES through several resident columns of the same shape (other seeds), one per step: a hot-cache
     # query never finds its column in the 256 MiB memory-side Infinity Cache, and back-to-back passes over ONE 40-160 MB
     # column would (round 2: 27.9 us hot vs 35.9 us cold).  The cycle is sized to move >= 768 MB.
@@ -1146,7 +1232,8 @@ def main():
         a2 = copy.copy(args)
         a2.seed = args.seed + 7919 * r
         if args.workload == "url_like":
-            ids_r = stage_url_column(cache, lc, N, a2, rank, n_batches, threads, file_id=1000 + 16 * r + rank)
+            ids_r = stage_url_column(cache, lc, N, a2, rank, n_batches, threads,
+                                     file_id=1000 + 16 * r + (0 if args.batch0 is not None else rank))
         else:
             ids_r = stage_int_column(cache, lc, N, a2, rank, args.rows, threads, base=base, kind=args.int_kind, col=200 + r)
         scans.append(cache.scan(ids_r))
@@ -1193,9 +1280,19 @@ def main():
 
     drain = reducer.drain
 
-    for _ in range(max(args.warmup, n_rot)):  # every column is scanned once before the clock starts (plans, automata)
+    warm_steps = max(args.warmup, n_rot)
+    for _ in range(warm_steps):  # every column is scanned once before the clock starts (plans, automata)
         step()
     drain()
+    new_needle_us = None
+    if args.workload == "url_like" and rank == 0:
+        # ... and a needle this scan has not seen (its index exists): automata + plan + one evaluation
+        e_new = lc.LiquidExpr.try_new("like", b"%yahoo%", pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
+        torch.cuda.synchronize()
+        t_new = time.perf_counter()
+        scan.eval(e_new, mask.data_ptr(), 0, 0, stream)
+        torch.cuda.synchronize()
+        new_needle_us = (time.perf_counter() - t_new) * 1e6
     step_no[0] = 0
     if world > 1:
         dist.barrier()
@@ -1231,6 +1328,20 @@ def main():
     if world > 1:
         dist.all_reduce(lh, op=dist.ReduceOp.SUM)
     assert int(lh.item()) == hits, "fused COUNT(*) %d != sum of per-entry counts %d" % (hits, int(lh.item()))
+    # the same for every column of the rotation (the timed loop scans them all): fused COUNT(*) == sum of per-entry counts
+    rot_hits, rot_counts = [hits], [counts.cpu().numpy().astype(np.int64)]
+    for r in range(1, n_rot):
+        tot_r = torch.zeros((), dtype=torch.int64, device="cuda")
+        scans[r].eval_count(expr, mask.data_ptr(), tot_r.data_ptr(), 0, 0, stream)
+        scans[r].eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
+        torch.cuda.synchronize()
+        c_r = counts.cpu().numpy().astype(np.int64)[: scans[r].entries]
+        assert int(tot_r.item()) == int(c_r.sum()), "rotating column %d: fused COUNT(*) %d != per-entry sum %d" % (
+            r, int(tot_r.item()), int(c_r.sum()))
+        rot_hits.append(int(tot_r.item()))
+        rot_counts.append(c_r)
+    scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)  # (the mask / counts buffers hold column 0 again)
+    torch.cuda.synchronize()
     if args.exchange == "mask" and world > 1:
         assert (int(gathered[0].numel()) if comm else sum(int(x.numel()) for x in gathered[0])) * 64 >= rows_all
 
@@ -1241,6 +1352,22 @@ def main():
     cold_ms = None if args.no_cold else scan.eval_timed_cold(expr, mask.data_ptr(), max(3, iters // 4), FLUSH_BYTES, 0,
                                                              counts.data_ptr(), stream)
 
+    # multi-GPU: what bounds a step — this rank's kernel against the exchange (8-byte all-reduce, overlapped with the next
+    # scan by the pipelined reducer): kernel time of the slowest / fastest rank and the bare collective, measured here
+    kt = torch.tensor([kernel_ms, -kernel_ms], dtype=torch.float64, device="cuda")
+    exchange_us = None
+    if world > 1:
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+        xbuf = torch.zeros((), dtype=torch.int64, device="cuda")
+        for _ in range(5):
+            dist.all_reduce(xbuf)
+        torch.cuda.synchronize()
+        tx = time.perf_counter()
+        for _ in range(50):
+            dist.all_reduce(xbuf)
+        torch.cuda.synchronize()
+        exchange_us = (time.perf_counter() - tx) / 50 * 1e6
+
     out = None
     if rank == 0:
         if args.workload == "url_like":
@@ -1248,7 +1375,11 @@ def main():
                 "url_like_no_signatures" if args.no_signatures else "url_like")
         else:
             tkey = "%s_gt_w%d" % (args.int_kind, args.int_bits)
-        traffic, traffic_src = measured_traffic(tkey)
+        path = scan.explain(expr)
+        if path.startswith("k_like_"):
+            kernel = path.split(":")[0].split(" (")[0]
+        traffic, traffic_src = measured_traffic(tkey, kernel)
+        step_s = elapsed / args.steps
         out = {
             "metric": "filtered rows/s (+ GB/s scanned), ClickBench Q21 hot cache",
             "value": rows_all / elapsed * args.steps,
@@ -1257,6 +1388,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "timed_region_s": elapsed,
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -1265,22 +1397,39 @@ def main():
             "config": {"workload": workload, "rows_per_gpu": int(scan.rows), "rows_all_gpus": rows_all,
                        "batch_rows": args.batch_size, "batches_per_gpu": int(scan.entries),
                        "distinct_per_batch": args.uniques,
-                       "parallelism": "row-range shards x%d, %s per step" % (
-                           world, "8-byte COUNT(*) all-reduce (overlapped with the next scan)" if args.exchange == "count"
+                       "parallelism": "%s x%d, %s per step" % (
+                           ("ONE %d-row table split into contiguous row-range shards (strong scaling)" % rows_all)
+                           if scaling == "strong" else "a %d-row table per GPU (weak scaling)" % int(scan.rows), world,
+                           "8-byte COUNT(*) all-reduce (overlapped with the next scan)" if args.exchange == "count"
                            else "COUNT(*) all-reduce + all-gather of the hit-mask segments"),
                        "predicate": ("URL LIKE '%%%s%%'" % args.needle) if args.workload == "url_like" else "col > literal",
                        "exchange_by": comm_used,
                        "hits": hits, "stage_seconds": round(t_stage, 2), "rotating_columns": n_rot,
+                       "rotating_columns_hits": rot_hits,
+                       "rotating_columns_count_equals_entry_counts": True,
+                       "warmup_steps_run": warm_steps,
                        "timed_loop": "step i scans resident column i %% %d (L3-cold by construction)" % n_rot},
-            # what the scan is worth to the query: the reference algorithm's bytes per second of wall clock
-            "gb_per_s_scanned": alg_bytes * world / (elapsed / args.steps) / 1e9,
+            # the bytes THIS implementation moves per second of wall clock (lc_scan_traffic_model's own-bytes figure) ...
+            "gb_per_s_scanned": own_bytes * world / step_s / 1e9,
+            # ... and what the scan is worth to the query: the reference algorithm's bytes per second of wall
+            # clock — an equivalence, not a bandwidth (it exceeds the HBM peak where the index spares the kernel bytes)
+            "reference_algorithm_equivalent_gbs": alg_bytes * world / step_s / 1e9,
+            "first_evaluation_us": round(first_eval_us, 1),
+            "new_needle_first_evaluation_us": None if new_needle_us is None else round(new_needle_us, 1),
             "roofline": roofline(kernel, kernel_ms, alg_bytes, own_bytes, cold_ms, traffic, traffic_src),
         }
+        if world > 1:
+            out["scaling_model"] = {
+                "kernel_us_slowest_rank": float(kt[0].item()) * 1e3, "kernel_us_fastest_rank": -float(kt[1].item()) * 1e3,
+                "exchange_us": exchange_us,
+                "step_us": ms_per_step * 1e3,
+                "note": "kernel = HIP events on rank-local launches (hot); exchange = one 8-byte all-reduce alone; the "
+                        "pipelined reducer overlaps the exchange of step i with the scan of step i+1, so a step costs "
+                        "max(kernel, exchange) plus launch gaps; below ~1,000 entries per GPU the kernel sits on its "
+                        "launch floor (~5 us) and the curve flattens"}
         if world == 1 and not args.no_secondary:
             add_read_probe(out["roofline"], cache, N)  # (skipped in the profiling runs: their traces hold the scan kernels only)
-        out["config"]["evaluation_path"] = scan.explain(expr)
-        if out["config"]["evaluation_path"].startswith("k_like_"):
-            out["roofline"]["kernel"] = out["config"]["evaluation_path"].split(":")[0].split(" (")[0]
+        out["config"]["evaluation_path"] = path
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_sample = args.cpu_batches or n_batches  # ~4 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
         if args.workload == "url_like":
@@ -1342,6 +1491,22 @@ def main():
                     out["like_needle_classes"] = classes
                 assert n_bad == 0, "GPU mask differs from the CPU oracle's: " + str(worst)
         all_cores.pop("_checks", None)
+        if args.workload == "url_like" and n_rot > 1 and not args.no_fingerprints:
+            # the other columns of the rotation (timed, too): per-entry counts of a spread sample of their batches against
+            # the oracle's over the same bytes
+            sample = sorted(set(range(0, n_batches, max(1, n_batches // 96))) | {n_batches - 1})
+            ok_cols = 0
+            for r in range(1, n_rot):
+                a2 = copy.copy(args)
+                a2.seed = args.seed + 7919 * r
+                want = oracle_url_sample_counts(cache, lc, N, a2, rank, 1000 + 16 * r + rank, sample, pattern, threads)
+                got = rot_counts[r][sample]
+                assert np.array_equal(got, want), "rotating column %d: per-entry counts differ from the oracle's on %d of %d " \
+                    "sampled batches" % (r, int((got != want).sum()), len(sample))
+                ok_cols += 1
+            out["config"]["rotating_columns_checked_against_oracle"] = ok_cols
+            out["config"]["rotating_columns_oracle_sample"] = "%d batches of each (every %dth + the last)" % (
+                len(sample), max(1, n_batches // 96))
 
     if rank == 0 and world == 1 and not args.no_secondary:
         sec = {}

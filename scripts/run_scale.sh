@@ -1,9 +1,11 @@
 #!/bin/bash
 # The 1/2/4/8-GPU curve of BASELINE.json in one command (run on an 8-GPU MI355X node):
 #   scripts/run_scale.sh [out-dir]
-# For N in 1 2 4 8: weak scaling (every rank scans its own 99,997,497-row column) with both exchange steps (COUNT(*)
-# all-reduce, hit-mask all-gather) through torch.distributed and through the library's own C ABI (lc_comm_*), and the
-# strong-scaling split of BASELINE config 4 (TPC-H Q6 shape, 600,037,902 rows over the ranks).  One JSON line per run.
+# For N in 1 2 4 8: the metric's line — STRONG scaling of the 99,997,497-row ClickBench table (bench.py's default for
+# N > 1: contiguous row-range shards of one table) with both exchange steps (COUNT(*) all-reduce, hit-mask all-gather) through
+# torch.distributed and through the library's own C ABI (lc_comm_*); the weak-scaling curve (every rank scans its own
+# 99,997,497-row column) as the secondary; and the strong split of BASELINE config 4 (TPC-H Q6 shape, 600,037,902 rows).
+# One JSON line per run.
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=${1:-$R/gpurun_out/scale}
 mkdir -p "$O"
@@ -31,8 +33,9 @@ PY
 for n in 1 2 4 8; do
   for comm in torch abi; do
     for ex in count mask; do
-      run $n "url_like_${ex}_${comm}" --steps 40 --warmup 8 --no-secondary --no-cpu-baseline --exchange $ex --comm $comm
+      run $n "url_like_strong_${ex}_${comm}" --steps 40 --warmup 8 --no-secondary --no-cpu-baseline --exchange $ex --comm $comm
     done
   done
+  run $n url_like_weak_count_torch --scaling weak --steps 40 --warmup 8 --no-secondary --no-cpu-baseline
   run $n tpch_q6_strong --workload tpch_q6 --steps 20 --warmup 4
 done

@@ -298,3 +298,97 @@ def test_c_abi_exchange_steps_over_shared_memory(product_lib, tmp_path, world):
             assert res[r][rnd][1] == total, (rnd, r)
             assert res[r][rnd][3] == concat, (rnd, r)
             assert res[r][rnd][4] == res[0][rnd][4]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# bench.py --gpus N (default for N > 1): STRONG scaling of the URL workload — one table split by contiguous row ranges —
+# end to end on CPU: bench.py's own shard arithmetic and generator keys, the oracle in place of lc_scan_eval, the exchange
+# steps through lc_comm_* (shared-memory backend)
+# ------------------------------------------------------------------------------------------------------------------
+_URL_TOTAL_ROWS, _URL_BS = 8192 * 5 + 1234, 8192
+
+
+def _url_batch(seed, gb, rows):
+    from liquid_cache_amd import _native as N
+    offs = np.zeros(_URL_BS + 1, np.int32)
+    data = np.zeros(_URL_BS * 512, np.uint8)
+    n = N.load_bench().lc_synth_url_batch(seed, gb, rows, min(300, rows), 20000, offs.ctypes.data, data.ctypes.data, data.size)
+    raw = bytes(data[:n])
+    return [raw[offs[i]: offs[i + 1]] for i in range(rows)]
+
+
+def _url_strong_worker(rank, world, id_path, out_path):
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import liquid_oracle as lo
+    import liquid_cache_amd as lc
+    from liquid_cache_amd import sharding as sh
+    # the shard bench.py main() gives this rank: --rows <table>, world > 1 -> rows_total = rows, batch-aligned contiguous range
+    args = bench.parse_args(["--gpus", str(world), "--rows", str(_URL_TOTAL_ROWS)])
+    assert args.scaling == "auto"
+    total_batches = (_URL_TOTAL_ROWS + _URL_BS - 1) // _URL_BS
+    b0, b1 = sh.contiguous_batch_range(total_batches, rank, world)
+    args.batch0 = b0
+    assert bench.url_seed(args, rank) == args.seed          # rank-free: the union of the shards is the one-GPU table
+    rows_mine = max(0, min(_URL_TOTAL_ROWS, b1 * _URL_BS) - b0 * _URL_BS)
+    count, segs = 0, []
+    for gb in range(b0, b1):
+        rows = min(_URL_BS, rows_mine - (gb - b0) * _URL_BS)
+        vals = _url_batch(bench.url_seed(args, rank), gb, rows)
+        liquid, st = lo.encode_byte_view(vals, fingerprints=True)
+        m = lo.eval_predicate(liquid, lo.LIKE, b"%google%", None, symtab=st).filter_mask()
+        count += int(m.sum())
+        seg = np.zeros(((len(m) + 63) // 64) * 8, np.uint8)
+        p = np.packbits(m, bitorder="little")
+        seg[: len(p)] = p
+        segs.append(seg.view(np.uint64))
+    cache = lc.LiquidCacheBuilder.new().with_host_only().build()
+    if rank == 0:
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(sh.Communicator.unique_id(cache))
+        os.replace(id_path + ".tmp", id_path)
+    else:
+        import time
+        for _ in range(4000):
+            if os.path.exists(id_path):
+                break
+            time.sleep(0.005)
+    comm = sh.Communicator(cache, rank, world, open(id_path, "rb").read())
+    part = np.array([count], np.uint64)
+    comm.allreduce_count(part.ctypes.data)
+    local = np.concatenate(segs) if segs else np.zeros(0, np.uint64)
+    wpr = []
+    for r in range(world):
+        a, b = sh.contiguous_batch_range(total_batches, r, world)
+        wpr.append(sum((min(_URL_BS, _URL_TOTAL_ROWS - gb * _URL_BS) + 63) // 64 for gb in range(a, b)))
+    assert wpr[rank] == local.size
+    out = np.zeros(max(sum(wpr), 1), np.uint64)
+    comm.allgather_mask(local.ctypes.data if local.size else 0, local.size, out.ctypes.data, wpr)
+    comm.close()
+    cache.close()
+    if rank == world - 1:
+        np.save(out_path, out[: sum(wpr)])
+        with open(out_path + ".count", "w") as f:
+            f.write(str(int(part[0])))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_url_strong_split_through_lc_comm(product_lib, tmp_path, world):
+    out = str(tmp_path / "url_mask.npy")
+    mp.spawn(_url_strong_worker, args=(world, str(tmp_path / "comm_id"), out), nprocs=world, join=True)
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seed = bench.parse_args([]).seed
+    want_count, segs = 0, []
+    for gb in range((_URL_TOTAL_ROWS + _URL_BS - 1) // _URL_BS):
+        rows = min(_URL_BS, _URL_TOTAL_ROWS - gb * _URL_BS)
+        m = np.array([b"google" in v for v in _url_batch(seed, gb, rows)])
+        want_count += int(m.sum())
+        seg = np.zeros(((len(m) + 63) // 64) * 8, np.uint8)
+        p = np.packbits(m, bitorder="little")
+        seg[: len(p)] = p
+        segs.append(seg.view(np.uint64))
+    assert int(open(out + ".count").read()) == want_count > 0
+    assert np.load(out).tolist() == np.concatenate(segs).tolist()
