@@ -554,6 +554,11 @@ LC_API lc_status lc_device_memset(lc_ctx* ctx, void* dptr, int value, uint64_t b
 LC_API lc_status lc_device_to_host(lc_ctx* ctx, void* host_dst, const void* dptr, uint64_t bytes, void* stream);
 LC_API lc_status lc_host_to_device(lc_ctx* ctx, void* dptr, const void* host_src, uint64_t bytes, void* stream);
 LC_API lc_status lc_stream_synchronize(lc_ctx* ctx, void* stream);
+/* A stream of the caller's own (non-blocking: it does not synchronise with the default stream) — one per worker thread
+ * is the intended use: the reference's read path runs on `target_partitions` tokio workers concurrently
+ * (datafusion/src/reader/runtime/liquid_cache_reader.rs:297-391) and no call of this library synchronises the device. */
+LC_API lc_status lc_stream_create(lc_ctx* ctx, void** out_stream);
+LC_API lc_status lc_stream_destroy(lc_ctx* ctx, void* stream);
 
 /* Time `iters` back-to-back lc_scan_eval launches with HIP events recorded on `stream` (the stream the kernels
  * run on); returns the average milliseconds per launch.  Used by bench.py for the roofline figure. */

@@ -74,6 +74,7 @@ EXPORTED_SYMBOLS = [
     "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold", "lc_scan_eval_or", "lc_eval_predicate_or", "lc_insert_arrow_device", "lc_entry_to_liquid_bytes", "lc_squeeze_date", "lc_squeeze_clamp", "lc_squeeze_quantize", "lc_scan_aggregate", "lc_scan_sum_product", "lc_scan_eval_filter",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
+    "lc_stream_create", "lc_stream_destroy",
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
@@ -196,6 +197,8 @@ def load():
     L.lc_device_to_host.restype = i32; L.lc_device_to_host.argtypes = [vp, vp, vp, u64, vp]
     L.lc_host_to_device.restype = i32; L.lc_host_to_device.argtypes = [vp, vp, vp, u64, vp]
     L.lc_stream_synchronize.restype = i32; L.lc_stream_synchronize.argtypes = [vp, vp]
+    L.lc_stream_create.restype = i32; L.lc_stream_create.argtypes = [vp, P(vp)]
+    L.lc_stream_destroy.restype = i32; L.lc_stream_destroy.argtypes = [vp, vp]
     _lib = L
     return L
 

@@ -89,6 +89,7 @@ struct Entry {
     int fq_shift = 0;
     bool sig_on_device = false;  // staging: the signature slices are still to be built by k_str_build_signatures
     uint64_t raw_bytes = 0;      // byte views: uncompressed size of the dictionary (RawFsstBuffer header)
+    uint64_t uid = 0;            // unique per publication (publish_entry): a cached scan knows its entry was replaced
 };
 
 struct LikePipeline;  // lc_like_pipeline.hip: workgroup records + cached plans of k_like_lean
@@ -131,6 +132,21 @@ struct lc_ctx {
     // side streams for staging work (signature builder): concurrent lc_stage calls of different host threads do not wait
     // for each other's kernels the way they would on the null stream with a device-wide synchronise
     std::vector<hipStream_t> stream_pool;
+    // Every host thread that calls into the context keeps ONE stream of its own for its calls (stream_acquire binds it on the
+    // thread's first call; creating a stream costs ~10 ms, so a pool that hands streams around still created them inside
+    // the callers' hot loops whenever more threads overlapped than before).  all_streams owns them: destroyed with the
+    // context, whatever thread holds them.
+    uint64_t uid = 0;                      // unique among the contexts of the process (thread-local bindings refer to it)
+    std::vector<hipStream_t> all_streams;  // guarded by pool_mu
+    // Idle ONE-ENTRY scans of the per-entry drop-in calls (lc_eval_predicate, lc_get_with_selection, ...), by entry id: a
+    // partition thread evaluates the batches of its row range one entry at a time, and building a scan (descriptor upload,
+    // pins, scratch) per call cost more than the kernel.  A call checks a scan out (exclusive use) and back in; scans of
+    // evicted / replaced entries move to the graveyard under ctx->mu and are destroyed outside it (scan_cache_reap).
+    std::atomic<uint64_t> next_uid{0};
+    std::mutex scan_cache_mu;
+    std::unordered_map<uint64_t, std::vector<lc_scan*>> scan_cache;
+    size_t scan_cache_size = 0;
+    std::vector<lc_scan*> scan_graveyard;
 };
 
 struct lc_scan {
@@ -181,6 +197,8 @@ struct lc_scan {
     // another stream, the previous one is drained first (scan_enter_stream) so the scratch is never shared in flight.
     hipStream_t last_stream = nullptr;
     bool used = false;
+    std::vector<hipStream_t> streams_used;  // every stream a launch over this scan went to: lc_scan_destroy drains these
+                                            // (not the device: other threads' calls keep running)
     std::mutex mu;
 };
 
@@ -197,6 +215,7 @@ void arena_pin(lc_ctx* ctx, int slab_idx);
 void arena_release(lc_ctx* ctx, int slab_idx);  // caller holds ctx->mu exclusively
 lc_status sync_symtabs(lc_ctx* ctx);
 void scan_enter_stream(lc_scan* s, hipStream_t stream);  // caller holds s->mu
+void scan_note_stream(lc_scan* s, hipStream_t stream);   // read-only use of the scan's descriptors on `stream`
 
 struct StrPredHost {
     StrPred p{};

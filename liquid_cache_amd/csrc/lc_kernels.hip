@@ -3408,6 +3408,13 @@ __global__ __launch_bounds__(256) void k_mask_or_kleene(uint64_t* __restrict__ h
 
 // Reads `n16` 16-byte words and keeps one word per workgroup: replaces whatever the memory-side cache held by CLEAN lines
 // of a scratch buffer (a memset would leave 256 MiB of dirty lines whose write-back the next kernel pays for).
+// Small results of the per-entry calls go to PINNED HOST memory straight from a kernel (8-byte words, either pointer may be
+// host memory): no SDMA / blit copy per call — eight host threads issuing four small copies per call serialised on the copy
+// engines (measured: 36 us per lc_eval_predicate alone, 350 us with eight concurrent callers).
+__global__ __launch_bounds__(256) void k_copy_words(uint64_t* __restrict__ dst, const uint64_t* __restrict__ src, uint64_t n) {
+    for (uint64_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += uint64_t(gridDim.x) * 256ull) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void k_flush_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
     uint32_t acc = 0;
     for (uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x; i < n16; i += uint64_t(gridDim.x) * 256) {
@@ -3990,6 +3997,13 @@ hipError_t launch_mask_entry_counts(const void* d_descs, bool is_str, const Scan
     else
         hipLaunchKernelGGL(k_sel_entry_counts<FixedDesc>, grid, dim3(kThreads), 0, stream,
                            static_cast<const FixedDesc*>(d_descs), L, d_entry_counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_words(void* dst, const void* src, uint64_t n_words, hipStream_t stream) {
+    if (n_words == 0) return hipSuccess;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((n_words + 255) / 256, 1024));
+    hipLaunchKernelGGL(k_copy_words, dim3(grid), dim3(256), 0, stream, static_cast<uint64_t*>(dst), static_cast<const uint64_t*>(src), n_words);
     return hipGetLastError();
 }
 

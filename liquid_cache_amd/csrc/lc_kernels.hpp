@@ -314,6 +314,8 @@ hipError_t launch_date_component(const void* d_values, uint64_t n, int value_wid
                                  int32_t* d_out, hipStream_t stream);
 hipError_t launch_component_lossy(const int32_t* d_comps, uint64_t n, int value_width, int field, int64_t ticks_per_day,
                                   void* d_out, hipStream_t stream);
+// dst[i] = src[i] for n_words u64 words; either side may be pinned host memory (results of the per-entry calls)
+hipError_t launch_copy_words(void* dst, const void* src, uint64_t n_words, hipStream_t stream);
 // cache flush for cold timings: streams `bytes` of d_buf through the memory-side cache (d_sink: >= 2048 u32)
 hipError_t launch_flush_read(const void* d_buf, uint64_t bytes, uint32_t* d_sink, hipStream_t stream);
 hipError_t launch_mask_compress(const uint64_t* d_src, const uint64_t* d_sel, const uint64_t* d_seg_offsets,

@@ -33,6 +33,11 @@ void scan_enter_stream(lc_scan* s, hipStream_t stream) {
     if (s->used && s->last_stream != stream) (void)hipStreamSynchronize(s->last_stream);
     s->last_stream = stream;
     s->used = true;
+    if (std::find(s->streams_used.begin(), s->streams_used.end(), stream) == s->streams_used.end()) s->streams_used.push_back(stream);
+}
+void scan_note_stream(lc_scan* s, hipStream_t stream) {
+    std::lock_guard<std::mutex> g(s->mu);
+    if (std::find(s->streams_used.begin(), s->streams_used.end(), stream) == s->streams_used.end()) s->streams_used.push_back(stream);
 }
 
 }  // namespace lc
@@ -40,26 +45,63 @@ void scan_enter_stream(lc_scan* s, hipStream_t stream) {
 namespace lc {
 
 // ------------------------------------------------------------------ scratch pool
-constexpr size_t kPoolMinClass = 4096, kPoolMaxClass = size_t(64) << 20, kPoolKeepPerClass = 16;
+constexpr size_t kPoolMinClass = 4096, kPoolMaxClass = size_t(64) << 20, kPoolKeepPerClass = 64;
 
+// ---- per-thread streams
+void ctx_register(lc_ctx* ctx);
+void ctx_unregister(lc_ctx* ctx);
+namespace {
+std::mutex g_ctx_registry_mu;
+std::unordered_map<uint64_t, lc_ctx*> g_ctx_registry;  // live contexts by uid
+std::atomic<uint64_t> g_next_ctx_uid{0};
+struct ThreadStreams {
+    std::vector<std::pair<uint64_t, hipStream_t>> bound;  // (context uid, this thread's stream for it)
+    ~ThreadStreams() {
+        // the thread ends: its streams go back to their contexts' pools (a context that is gone destroyed them already)
+        std::lock_guard<std::mutex> g(g_ctx_registry_mu);
+        for (auto& b : bound) {
+            auto it = g_ctx_registry.find(b.first);
+            if (it == g_ctx_registry.end()) continue;
+            std::lock_guard<std::mutex> g2(it->second->pool_mu);
+            it->second->stream_pool.push_back(b.second);
+        }
+    }
+};
+thread_local ThreadStreams t_streams;
+}  // namespace
+
+void ctx_register(lc_ctx* ctx) {
+    ctx->uid = ++g_next_ctx_uid;
+    std::lock_guard<std::mutex> g(g_ctx_registry_mu);
+    g_ctx_registry[ctx->uid] = ctx;
+}
+void ctx_unregister(lc_ctx* ctx) {
+    std::lock_guard<std::mutex> g(g_ctx_registry_mu);
+    g_ctx_registry.erase(ctx->uid);
+}
+
+// The calling thread's stream for this context (bound on its first call: from the pool of streams finished threads left
+// behind, else created).  Never the null stream unless stream creation fails.
 hipStream_t stream_acquire(lc_ctx* ctx) {
+    for (auto& b : t_streams.bound)
+        if (b.first == ctx->uid) return b.second;
+    hipStream_t s = nullptr;
     {
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         if (!ctx->stream_pool.empty()) {
-            hipStream_t s = ctx->stream_pool.back();
+            s = ctx->stream_pool.back();
             ctx->stream_pool.pop_back();
-            return s;
         }
     }
-    hipStream_t s = nullptr;
-    if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;  // null stream as a fallback
+    if (!s) {
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;  // null stream as a fallback
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        ctx->all_streams.push_back(s);
+    }
+    t_streams.bound.emplace_back(ctx->uid, s);
     return s;
 }
-void stream_release(lc_ctx* ctx, hipStream_t s) {
-    if (!s) return;
-    std::lock_guard<std::mutex> g(ctx->pool_mu);
-    ctx->stream_pool.push_back(s);
-}
+void stream_release(lc_ctx*, hipStream_t) {}  // (the stream stays bound to the thread)
 
 void* pool_alloc(lc_ctx* ctx, size_t bytes) {
     size_t cls = kPoolMinClass;
@@ -224,6 +266,41 @@ struct ArenaReservation {
     ArenaReservation(const ArenaReservation&) = delete;
     ArenaReservation& operator=(const ArenaReservation&) = delete;
 };
+
+// ---- idle one-entry scans of the per-entry drop-in calls (lc_ctx::scan_cache)
+// Caller holds ctx->mu exclusively: the entry `id` is being replaced or evicted — its idle scans (which pin the old blob)
+// move to the graveyard; they are destroyed outside the lock (scan_cache_reap).
+static void scan_cache_invalidate_locked(lc_ctx* ctx, uint64_t id) {
+    std::lock_guard<std::mutex> g(ctx->scan_cache_mu);
+    auto it = ctx->scan_cache.find(id);
+    if (it == ctx->scan_cache.end()) return;
+    for (lc_scan* s : it->second) ctx->scan_graveyard.push_back(s);
+    ctx->scan_cache_size -= it->second.size();
+    ctx->scan_cache.erase(it);
+}
+// Caller holds NO lock of the context.
+static void scan_cache_reap(lc_ctx* ctx) {
+    std::vector<lc_scan*> dead;
+    {
+        std::lock_guard<std::mutex> g(ctx->scan_cache_mu);
+        dead.swap(ctx->scan_graveyard);
+    }
+    for (lc_scan* s : dead) lc_scan_destroy(s);
+}
+// Caller holds ctx->mu exclusively.  Publishes `e` under `id` (replacing what was there: scans that pinned the old blob
+// keep it alive) with a fresh uid.
+static void publish_entry(lc_ctx* ctx, uint64_t id, Entry&& e) {
+    auto old = ctx->entries.find(id);
+    if (old != ctx->entries.end()) {
+        ctx->entry_bytes -= old->second.device_bytes;
+        arena_release(ctx, old->second.slab);
+        ctx->entries.erase(old);
+        scan_cache_invalidate_locked(ctx, id);
+    }
+    e.uid = ++ctx->next_uid;
+    ctx->entry_bytes += e.device_bytes;
+    ctx->entries.emplace(id, std::move(e));
+}
 
 // Keeps the slab of an entry alive while a call reads the entry's blob outside the cache lock (read-backs, squeezes).
 struct SlabPin {
@@ -676,6 +753,7 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
         // host-only context: Arrow->Liquid transcoding and symbol tables only; every device call fails loudly
         std::unique_ptr<lc_ctx> host(new lc_ctx());
         host->device = -1;
+        ctx_register(host.get());
         *out = host.release();
         return LC_OK;
     }
@@ -696,6 +774,7 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     ctx->max_hbm = max_hbm_bytes;
     // (no environment variable is read here: what the library stages and how it evaluates is decided by the caller
     // through lc_ctx_set_option, never by the process environment)
+    ctx_register(ctx.get());
     *out = ctx.release();
     return LC_OK;
     });
@@ -725,13 +804,27 @@ lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
 void lc_ctx_destroy(lc_ctx* ctx) {
     if (!ctx) return;
     try {
-    if (ctx->device < 0) { delete ctx; return; }
+    if (ctx->device < 0) { ctx_unregister(ctx); delete ctx; return; }
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
+    {
+        std::vector<lc_scan*> idle;
+        {
+            std::lock_guard<std::mutex> g(ctx->scan_cache_mu);
+            for (auto& kv : ctx->scan_cache)
+                for (lc_scan* sc : kv.second) idle.push_back(sc);
+            ctx->scan_cache.clear();
+            ctx->scan_cache_size = 0;
+            for (lc_scan* sc : ctx->scan_graveyard) idle.push_back(sc);
+            ctx->scan_graveyard.clear();
+        }
+        for (lc_scan* sc : idle) lc_scan_destroy(sc);
+    }
     for (Slab& s : ctx->slabs)
         if (s.base) (void)hipFree(s.base);
     pool_destroy(ctx);
-    for (hipStream_t st : ctx->stream_pool) (void)hipStreamDestroy(st);
+    ctx_unregister(ctx);
+    for (hipStream_t st : ctx->all_streams) (void)hipStreamDestroy(st);
     if (ctx->d_symtabs) (void)hipFree(ctx->d_symtabs);
     for (DevSymtab* p : ctx->d_symtabs_retired) (void)hipFree(p);
     delete ctx;
@@ -902,14 +995,7 @@ static lc_status stage_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, 
         }
         std::unique_lock<std::shared_mutex> g(ctx->mu);
         for (Pending& p : pend) {
-            auto old = ctx->entries.find(p.id);
-            if (old != ctx->entries.end()) {
-                ctx->entry_bytes -= old->second.device_bytes;
-                arena_release(ctx, old->second.slab);  // scans that pinned it keep the old blob alive
-                ctx->entries.erase(old);
-            }
-            ctx->entry_bytes += p.e.device_bytes;
-            ctx->entries.emplace(p.id, std::move(p.e));
+            publish_entry(ctx, p.id, std::move(p.e));
         }
         reserved.disarm();
     }
@@ -922,15 +1008,20 @@ lc_status lc_evict(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids) {
     if (!ctx || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
-    LC_HIP(hipDeviceSynchronize());  // in-flight scans may still read the blobs
-    std::unique_lock<std::shared_mutex> g(ctx->mu);
-    for (uint64_t i = 0; i < n; i++) {
-        auto it = ctx->entries.find(entry_ids[i]);
-        if (it == ctx->entries.end()) continue;
-        ctx->entry_bytes -= it->second.device_bytes;
-        arena_release(ctx, it->second.slab);
-        ctx->entries.erase(it);
+    // No device-wide synchronise: whatever still reads a blob holds a pin on its slab (scans, SlabPin), and a slab is only
+    // returned to the driver when its last pin goes.  Other threads' evaluations keep running.
+    {
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        for (uint64_t i = 0; i < n; i++) {
+            auto it = ctx->entries.find(entry_ids[i]);
+            if (it == ctx->entries.end()) continue;
+            ctx->entry_bytes -= it->second.device_bytes;
+            arena_release(ctx, it->second.slab);
+            ctx->entries.erase(it);
+            scan_cache_invalidate_locked(ctx, entry_ids[i]);
+        }
     }
+    scan_cache_reap(ctx);  // idle one-entry scans of the evicted entries drop their pins now
     return LC_OK;
     });
 }
@@ -1091,7 +1182,7 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
     EncodeMinMax* d_mm = static_cast<EncodeMinMax*>(pool_alloc(ctx, n * sizeof(EncodeMinMax)));
     struct Scratch {
         lc_ctx* c; void* a; void* b;
-        ~Scratch() { (void)hipDeviceSynchronize(); pool_release(c, a); pool_release(c, b); }
+        ~Scratch() { (void)hipStreamSynchronize(nullptr); pool_release(c, a); pool_release(c, b); }
     } scratch{ctx, d_descs, d_mm};
     if (!d_descs || !d_mm) return fail(LC_ERR_OOM, "hipMalloc (encoder scratch)");
     LC_HIP(hipMemcpy(d_descs, descs.data(), n * sizeof(EncodeDesc), hipMemcpyHostToDevice));
@@ -1177,12 +1268,12 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
             if (!d_sub) return fail(LC_ERR_OOM, "hipMalloc (encoder scratch)");
             const hipError_t e1 = hipMemcpy(d_sub, sub.data(), sub.size() * sizeof(EncodeDesc), hipMemcpyHostToDevice);
             const hipError_t e2 = e1 == hipSuccess ? launch_fl_pack(d_sub, uint32_t(sub.size()), sub_rows, ll + 3, nullptr) : e1;
-            (void)hipDeviceSynchronize();
+            (void)hipStreamSynchronize(nullptr);
             pool_release(ctx, d_sub);
             if (e2 != hipSuccess) return fail(LC_ERR_DEVICE, "k_fl_pack launch failed");
         }
     }
-    LC_HIP(hipDeviceSynchronize());
+    LC_HIP(hipStreamSynchronize(nullptr));
     for (size_t i = 0; i < n; i++) {
         const DevEncodeItem& it = items[i];
         Entry e;
@@ -1222,14 +1313,7 @@ lc_status device_encode_and_register(lc_ctx* ctx, std::vector<DevEncodeItem>& it
             d.kind = kKindDecimal;
             d.value_width = uint8_t(it.entry_value_width);
         }
-        auto old = ctx->entries.find(it.id);
-        if (old != ctx->entries.end()) {
-            ctx->entry_bytes -= old->second.device_bytes;
-            arena_release(ctx, old->second.slab);
-            ctx->entries.erase(old);
-        }
-        ctx->entry_bytes += e.device_bytes;
-        ctx->entries.emplace(it.id, std::move(e));
+        publish_entry(ctx, it.id, std::move(e));
     }
     reserved.disarm();
     return LC_OK;
@@ -1266,7 +1350,7 @@ lc_status device_encode_floats(lc_ctx* ctx, std::vector<DevEncodeItem>& items) {
         void** d_ptrs = static_cast<void**>(pool_alloc(ctx, 2 * m * sizeof(void*)));
         struct Scratch {
             lc_ctx* c; void* p[6];
-            ~Scratch() { (void)hipDeviceSynchronize(); for (void* q : p) pool_release(c, q); }
+            ~Scratch() { (void)hipStreamSynchronize(nullptr); for (void* q : p) pool_release(c, q); }
         } scratch{ctx, {d_descs, d_stats, d_enc, d_xi, d_xv, d_ptrs}};
         if (!d_descs || !d_stats || !d_enc || !d_xi || !d_xv || !d_ptrs) return fail(LC_ERR_OOM, "hipMalloc (ALP encoder scratch)");
         LC_HIP(hipMemcpy(d_descs, descs.data(), m * sizeof(EncodeDesc), hipMemcpyHostToDevice));
@@ -1338,7 +1422,7 @@ lc_status device_encode_floats(lc_ctx* ctx, std::vector<DevEncodeItem>& items) {
         LC_HIP(hipMemcpy(d_ptrs, ptrs.data(), 2 * m * sizeof(void*), hipMemcpyHostToDevice));
         LC_HIP(launch_fl_pack(d_descs, uint32_t(m), stride, vlog + 3, nullptr));
         LC_HIP(launch_alp_copy_patches(d_stats, uint32_t(m), vlog, stride, d_xi, d_xv, d_ptrs, d_ptrs + m, max_exc, nullptr));
-        LC_HIP(hipDeviceSynchronize());
+        LC_HIP(hipStreamSynchronize(nullptr));
         for (size_t j = 0; j < m; j++) {
             const DevEncodeItem& it = items[sel[j]];
             const Lay& L = lay[j];
@@ -1370,14 +1454,7 @@ lc_status device_encode_floats(lc_ctx* ctx, std::vector<DevEncodeItem>& items) {
                 d.patch_idx = L.pidx == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + L.pidx);
                 d.patch_val = L.pval == size_t(-1) ? nullptr : dbase + L.pval;
             }
-            auto old = ctx->entries.find(it.id);
-            if (old != ctx->entries.end()) {
-                ctx->entry_bytes -= old->second.device_bytes;
-                arena_release(ctx, old->second.slab);
-                ctx->entries.erase(old);
-            }
-            ctx->entry_bytes += e.device_bytes;
-            ctx->entries.emplace(it.id, std::move(e));
+            publish_entry(ctx, it.id, std::move(e));
         }
         reserved.disarm();
     }
@@ -1702,14 +1779,7 @@ static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& item
     LC_HIP(hipStreamSynchronize(side));
     std::unique_lock<std::shared_mutex> g(ctx->mu);
     for (size_t i = 0; i < m; i++) {
-        auto old = ctx->entries.find(items[i].id);
-        if (old != ctx->entries.end()) {
-            ctx->entry_bytes -= old->second.device_bytes;
-            arena_release(ctx, old->second.slab);
-            ctx->entries.erase(old);
-        }
-        ctx->entry_bytes += entries[i].device_bytes;
-        ctx->entries.emplace(items[i].id, std::move(entries[i]));
+        publish_entry(ctx, items[i].id, std::move(entries[i]));
     }
     reserved.disarm();
     return LC_OK;
@@ -1835,7 +1905,7 @@ lc_status lc_insert_arrow_batch_device(lc_ctx* ctx, uint64_t n_all, const uint64
     uint8_t* d_in = static_cast<uint8_t*>(pool_alloc(ctx, stage_bytes));
     struct Bufs {
         lc_ctx* c; void* h; void* d;
-        ~Bufs() { (void)hipDeviceSynchronize(); host_pool_release(c, h); pool_release(c, d); }
+        ~Bufs() { (void)hipStreamSynchronize(nullptr); host_pool_release(c, h); pool_release(c, d); }
     } bufs{ctx, h, d_in};
     if (!h || !d_in) return fail(LC_ERR_OOM, "staging buffers of the on-device transcoder");
     for (uint64_t i = 0; i < n; i++) {
@@ -2049,19 +2119,38 @@ lc_status lc_entry_to_liquid_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out
 
 // ------------------------------------------------------------------ scans
 
-static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed);
+#ifdef LC_CALL_PROFILE
+#include <chrono>
+static std::atomic<uint64_t> g_prof_ns[16];
+static std::atomic<uint64_t> g_prof_calls{0};
+struct ProfDump { ~ProfDump() {
+    const char* names[16] = {"checkout", "alloc", "eval launch", "compress/copy launch", "sync", "unpack", "release", "-",
+                             "create:lock", "create:alloc", "create:copy+sync", "create:symtabs", "destroy", "stream_acquire", "-", "-"};
+    std::fprintf(stderr, "lc_eval_predicate_batch profile over %llu calls:", (unsigned long long)g_prof_calls.load());
+    for (int i = 0; i < 14; i++) std::fprintf(stderr, " %s %.1f us;", names[i], double(g_prof_ns[i].load()) / 1e3 / double(std::max<uint64_t>(g_prof_calls.load(), 1)));
+    std::fprintf(stderr, "\n"); } } g_prof_dump;
+#define LC_PROF_T0 auto _pt = std::chrono::steady_clock::now()
+#define LC_PROF(i) do { auto _n = std::chrono::steady_clock::now(); g_prof_ns[i] += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(_n - _pt).count()); _pt = _n; } while (0)
+#else
+#define LC_PROF_T0
+#define LC_PROF(i)
+#endif
+static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed,
+                                  hipStream_t st = nullptr);
 
 lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out) {
     return scan_create_impl(ctx, n, entry_ids, out, false);
 }
 
-static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed) {
+static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed,
+                                  hipStream_t stream) {
     return guarded([&]() -> lc_status {
     if (!ctx || !out || (n && !entry_ids)) return fail(LC_ERR_INVALID, "null argument");
     *out = nullptr;
     if (n > 0xFFFFFFFFull) return fail(LC_ERR_INVALID, "too many entries in one scan");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
+    LC_PROF_T0;
     std::unique_ptr<lc_scan> s(new lc_scan());
     s->ctx = ctx;
     s->n = uint32_t(n);
@@ -2115,21 +2204,36 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         for (const Entry& e : s->meta) arena_pin(ctx, e.slab);
         s->pinned = true;
     }
+    LC_PROF(8);
     const size_t desc_size = s->is_str ? sizeof(StrDesc) : sizeof(FixedDesc);
-    std::vector<uint8_t> host(desc_size * std::max<uint64_t>(n, 1));
-    for (uint64_t i = 0; i < n; i++) {
-        if (s->is_str) std::memcpy(host.data() + i * desc_size, &s->meta[i].sd, desc_size);
-        else std::memcpy(host.data() + i * desc_size, &s->meta[i].fd, desc_size);
+    // pinned staging: an asynchronous copy from pageable memory makes the runtime pin the pages for the duration of the
+    // call — a process-wide lock that eight concurrent callers queue on (measured: 20 us alone, 1.2 ms with eight)
+    const size_t desc_bytes = desc_size * std::max<uint64_t>(n, 1), seg_bytes = (n + 1) * 8;
+    struct Pinned {
+        lc_ctx* c; uint8_t* p;
+        ~Pinned() { host_pool_release(c, p); }
+    } host{ctx, static_cast<uint8_t*>(host_pool_alloc(ctx, desc_bytes + seg_bytes))};
+    for (uint64_t i = 0; i < n && host.p; i++) {
+        if (s->is_str) std::memcpy(host.p + i * desc_size, &s->meta[i].sd, desc_size);
+        else std::memcpy(host.p + i * desc_size, &s->meta[i].fd, desc_size);
     }
-    s->d_descs = pool_alloc(ctx, host.size());
-    s->d_seg_offsets = static_cast<uint64_t*>(pool_alloc(ctx, (n + 1) * 8));
-    lc_status st = (!s->d_descs || !s->d_seg_offsets) ? fail(LC_ERR_OOM, "hipMalloc (scan descriptors)") : LC_OK;
-    if (st == LC_OK && hipMemcpy(s->d_descs, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess)
+    if (host.p) std::memcpy(host.p + desc_bytes, s->seg_offsets.data(), seg_bytes);
+    s->d_descs = pool_alloc(ctx, desc_bytes);
+    s->d_seg_offsets = static_cast<uint64_t*>(pool_alloc(ctx, seg_bytes));
+    lc_status st = (!s->d_descs || !s->d_seg_offsets || !host.p) ? fail(LC_ERR_OOM, "hipMalloc (scan descriptors)") : LC_OK;
+    // on the caller's stream (a pooled one for the per-entry calls): the null stream would order this call behind the
+    // null-stream work of every other host thread
+    LC_PROF(9);
+    if (st == LC_OK && hipMemcpyAsync(s->d_descs, host.p, desc_bytes, hipMemcpyHostToDevice, stream) != hipSuccess)
         st = fail(LC_ERR_DEVICE, "hipMemcpy (scan descriptors)");
     if (st == LC_OK &&
-        hipMemcpy(s->d_seg_offsets, s->seg_offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice) != hipSuccess)
+        hipMemcpyAsync(s->d_seg_offsets, host.p + desc_bytes, seg_bytes, hipMemcpyHostToDevice, stream) != hipSuccess)
         st = fail(LC_ERR_DEVICE, "hipMemcpy (scan offsets)");
+    if (st == LC_OK && hipStreamSynchronize(stream) != hipSuccess) st = fail(LC_ERR_DEVICE, "hipStreamSynchronize (scan descriptors)");
+    if (st == LC_OK) s->streams_used.push_back(stream);
+    LC_PROF(10);
     if (st == LC_OK) st = sync_symtabs(ctx);
+    LC_PROF(11);
     if (st == LC_OK) {
         std::lock_guard<std::mutex> g(ctx->st_mu);
         s->d_symtabs = ctx->d_symtabs;
@@ -2149,9 +2253,13 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
 
 void lc_scan_destroy(lc_scan* s) {
     if (!s) return;
+    LC_PROF_T0;
     try {
     (void)hipSetDevice(s->ctx->device);
-    (void)hipDeviceSynchronize();  // nothing in flight may still read the scan's buffers when they are recycled
+    // nothing in flight may still read the scan's buffers when they are recycled: drain the streams its launches went to
+    // (not the device — the calls of other host threads keep running)
+    for (hipStream_t st : s->streams_used) (void)hipStreamSynchronize(st);
+    if (s->streams_used.empty()) (void)hipStreamSynchronize(nullptr);
     pool_release(s->ctx, s->d_descs);
     pool_release(s->ctx, s->d_seg_offsets);
     pool_release(s->ctx, s->d_work);
@@ -2161,8 +2269,8 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_or_tmp);
     pool_release(s->ctx, s->d_agg_partials);
     like_pipeline_destroy(s->ctx, s->like);
-    if (s->d_automata) (void)hipFree(s->d_automata);
-    if (s->d_needle) (void)hipFree(s->d_needle);
+    pool_release(s->ctx, s->d_automata);
+    pool_release(s->ctx, s->d_needle);
     if (s->pinned) {
         std::unique_lock<std::shared_mutex> g(s->ctx->mu);
         for (const Entry& e : s->meta) arena_release(s->ctx, e.slab);
@@ -2170,6 +2278,7 @@ void lc_scan_destroy(lc_scan* s) {
     delete s;
     } catch (...) {
     }
+    LC_PROF(12);
 }
 
 uint64_t lc_scan_mask_words(const lc_scan* s) { return s ? s->seg_offsets.back() : 0; }
@@ -2379,8 +2488,15 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         s->n_wg_ranges = uint32_t(r.size());
         s->d_wg_ranges = static_cast<StrWgRecord*>(pool_alloc(ctx, std::max<size_t>(r.size(), 1) * sizeof(StrWgRecord)));
         if (!s->d_wg_ranges) return fail(LC_ERR_OOM, "hipMalloc (scan workgroup records)");
-        LC_HIP(hipMemcpyAsync(s->d_wg_ranges, r.data(), r.size() * sizeof(StrWgRecord), hipMemcpyHostToDevice, stream));
-        LC_HIP(hipStreamSynchronize(stream));  // `r` is a local
+        // (through pinned staging: see scan_create_impl)
+        void* h_r = host_pool_alloc(ctx, std::max<size_t>(r.size(), 1) * sizeof(StrWgRecord));
+        if (!h_r) return fail(LC_ERR_OOM, "hipHostMalloc (scan workgroup records)");
+        std::memcpy(h_r, r.data(), r.size() * sizeof(StrWgRecord));
+        const hipError_t ec = hipMemcpyAsync(s->d_wg_ranges, h_r, r.size() * sizeof(StrWgRecord), hipMemcpyHostToDevice, stream);
+        const hipError_t es = hipStreamSynchronize(stream);
+        host_pool_release(ctx, h_r);
+        LC_HIP(ec);
+        LC_HIP(es);
     }
     L.d_wg_ranges = s->d_wg_ranges;
     L.n_wg_ranges = s->n_wg_ranges;
@@ -2398,8 +2514,9 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         const size_t need = size_t(stride) * std::max<size_t>(nst, 1);
         if (need > s->automata_cap) {
             LC_HIP(hipStreamSynchronize(stream));
-            if (s->d_automata) LC_HIP(hipFree(s->d_automata));
-            LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_automata), need));
+            pool_release(ctx, s->d_automata);  // (hipFree would synchronise the whole device)
+            s->d_automata = static_cast<uint8_t*>(pool_alloc(ctx, need));
+            if (!s->d_automata) { s->automata_cap = 0; return fail(LC_ERR_OOM, "hipMalloc (LIKE automata)"); }
             s->automata_cap = need;
             s->automata_symtabs = 0;
         }
@@ -2417,11 +2534,13 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         const size_t need = sp.needle.size() + 16;
         LC_HIP(hipStreamSynchronize(stream));  // previous evaluation may still read the old needle
         if (need > s->needle_cap) {
-            if (s->d_needle) LC_HIP(hipFree(s->d_needle));
-            LC_HIP(hipMalloc(reinterpret_cast<void**>(&s->d_needle), need));
+            pool_release(ctx, s->d_needle);
+            s->d_needle = static_cast<uint8_t*>(pool_alloc(ctx, need));
+            if (!s->d_needle) { s->needle_cap = 0; return fail(LC_ERR_OOM, "hipMalloc (needle)"); }
             s->needle_cap = need;
         }
-        LC_HIP(hipMemcpy(s->d_needle, sp.needle.data(), sp.needle.size(), hipMemcpyHostToDevice));
+        LC_HIP(hipMemcpyAsync(s->d_needle, sp.needle.data(), sp.needle.size(), hipMemcpyHostToDevice, stream));
+        LC_HIP(hipStreamSynchronize(stream));  // (`sp` is a local)
         sp.p.needle = s->d_needle;
     }
     if (sp.p.mode == 1) {
@@ -2952,7 +3071,115 @@ lc_status lc_stream_synchronize(lc_ctx* ctx, void* stream) {
     });
 }
 
+lc_status lc_stream_create(lc_ctx* ctx, void** out_stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !out_stream) return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = nullptr;
+    LC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out_stream = s;
+    return LC_OK;
+    });
+}
+
+lc_status lc_stream_destroy(lc_ctx* ctx, void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx) return fail(LC_ERR_INVALID, "null argument");
+    if (stream) LC_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return LC_OK;
+    });
+}
+
 // ------------------------------------------------------------------ per-entry drop-in calls
+// One per-entry drop-in call: a stream from the context's pool and the call's scratch.  Everything the call launches or
+// copies goes to that stream; the ONE host wait is on that stream (never the device: the reference's read path is driven
+// from `target_partitions` worker threads at once, liquid_cache_reader.rs:297-391), and the scratch returns to the pools
+// once the stream has drained.
+struct CallStream {
+    lc_ctx* ctx;
+    hipStream_t st;
+    std::vector<void*> dev, host;
+    explicit CallStream(lc_ctx* c) : ctx(c), st(stream_acquire(c)) {}
+    void* dalloc(size_t bytes) {
+        void* p = pool_alloc(ctx, bytes ? bytes : 8);
+        if (p) dev.push_back(p);
+        return p;
+    }
+    void* halloc(size_t bytes) {  // pinned
+        void* p = host_pool_alloc(ctx, bytes ? bytes : 8);
+        if (p) host.push_back(p);
+        return p;
+    }
+    hipError_t sync() { return hipStreamSynchronize(st); }
+    ~CallStream() {
+        (void)hipStreamSynchronize(st);
+        for (void* p : dev) pool_release(ctx, p);
+        for (void* p : host) host_pool_release(ctx, p);
+        stream_release(ctx, st);
+    }
+    CallStream(const CallStream&) = delete;
+    CallStream& operator=(const CallStream&) = delete;
+};
+
+constexpr size_t kScanCacheMax = 8192, kScanCachePerEntry = 2;
+// results of a per-entry call up to this size reach the host through pinned memory written by a kernel (no copy engine)
+constexpr size_t kPinnedResultMax = size_t(1) << 20;
+
+// An idle one-entry scan of `id` (exclusive use until scan_checkin), or a new one.  A cached scan is only handed out when
+// the entry it captured is still the published one (uid).
+static lc_status scan_checkout(lc_ctx* ctx, uint64_t id, bool allow_squeezed, hipStream_t st, lc_scan** out) {
+    *out = nullptr;
+    scan_cache_reap(ctx);
+    lc_scan* cached = nullptr;
+    {
+        std::lock_guard<std::mutex> g(ctx->scan_cache_mu);
+        auto it = ctx->scan_cache.find(id);
+        if (it != ctx->scan_cache.end() && !it->second.empty()) {
+            cached = it->second.back();
+            it->second.pop_back();
+            ctx->scan_cache_size--;
+            if (it->second.empty()) ctx->scan_cache.erase(it);
+        }
+    }
+    if (cached) {
+        bool fresh = false, squeezed = false;
+        {
+            std::shared_lock<std::shared_mutex> g(ctx->mu);
+            auto it = ctx->entries.find(id);
+            fresh = it != ctx->entries.end() && it->second.uid == cached->meta[0].uid;
+            squeezed = fresh && it->second.squeezed_field >= 0;
+        }
+        if (fresh && (!squeezed || allow_squeezed)) {
+            *out = cached;
+            return LC_OK;
+        }
+        lc_scan_destroy(cached);
+    }
+    return scan_create_impl(ctx, 1, &id, out, allow_squeezed, st);
+}
+static void scan_checkin(lc_ctx* ctx, uint64_t id, lc_scan* s) {
+    if (!s) return;
+    bool keep = false;
+    {
+        std::shared_lock<std::shared_mutex> g(ctx->mu);  // (an entry replaced meanwhile: its scan is not worth keeping)
+        auto it = ctx->entries.find(id);
+        keep = it != ctx->entries.end() && it->second.uid == s->meta[0].uid;
+        if (keep) {
+            std::lock_guard<std::mutex> g2(ctx->scan_cache_mu);
+            std::vector<lc_scan*>& v = ctx->scan_cache[id];
+            keep = v.size() < kScanCachePerEntry && ctx->scan_cache_size < kScanCacheMax;
+            if (keep) { v.push_back(s); ctx->scan_cache_size++; }
+            else if (v.empty()) ctx->scan_cache.erase(id);
+        }
+    }
+    if (!keep) lc_scan_destroy(s);
+}
+struct ScanLease {  // check-in (or destruction) of a call's scan on every path out
+    lc_ctx* ctx; uint64_t id; lc_scan* s; bool cached;
+    ~ScanLease() { if (cached) scan_checkin(ctx, id, s); else if (s) lc_scan_destroy(s); }
+};
+
 lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, const lc_predicate* pred,
                                   const uint8_t* const* selections, uint8_t* const* out_values,
                                   uint8_t* const* out_validity, uint32_t* out_lens, int32_t* out_nullable,
@@ -2975,24 +3202,29 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         }
     }
     if (present_ids.empty()) return LC_OK;
+    const bool one = present_ids.size() == 1;
+    LC_PROF_T0;
+    ScanLease lease{ctx, present_ids[0], nullptr, one};
+    CallStream cs(ctx);  // (declared after the lease: the stream is drained before the scan is checked in / destroyed)
+    LC_PROF(13);
     lc_scan* scan = nullptr;
-    lc_status rc = lc_scan_create(ctx, present_ids.size(), present_ids.data(), &scan);
+    lc_status rc = one ? scan_checkout(ctx, present_ids[0], false, cs.st, &scan)
+                       : scan_create_impl(ctx, present_ids.size(), present_ids.data(), &scan, false, cs.st);
+    if (rc == LC_NOT_STAGED && statuses) {  // (evicted between the check above and the scan)
+        for (uint64_t i : present_idx) statuses[i] = LC_NOT_STAGED;
+        return LC_OK;
+    }
     if (rc != LC_OK) return rc;
-    std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
+    lease.s = scan;
+    LC_PROF(0);
     const uint64_t words = std::max<uint64_t>(scan->seg_offsets.back(), 1);
     const uint32_t m = scan->n;
     bool any_sel = false;
     if (selections)
         for (uint64_t i : present_idx) any_sel |= selections[i] != nullptr;
-    // host selection in scan layout (entries without a selection get all ones)
-    // pinned staging: [selection | hit | valid] words + per-entry bit counts
-    uint64_t* h_stage = static_cast<uint64_t*>(host_pool_alloc(ctx, words * 8 * 3 + size_t(m) * 4 + 64));
+    // pinned staging: [selection | hit | valid] words + per-entry bit counts (entries without a selection get all ones)
+    uint64_t* h_stage = static_cast<uint64_t*>(cs.halloc(words * 8 * 3 + size_t(m) * 4 + 64));
     if (!h_stage) return fail(LC_ERR_OOM, "hipHostMalloc (predicate staging)");
-    struct HostStage {
-        lc_ctx* c;
-        void* p;
-        ~HostStage() { host_pool_release(c, p); }
-    } stage_guard{ctx, h_stage};
     uint64_t* h_sel = h_stage;
     uint64_t* h_hit = h_stage + words;
     uint64_t* h_valid = h_stage + 2 * words;
@@ -3009,51 +3241,39 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             if (e.len & 7) dst[nb - 1] &= uint8_t((1u << (e.len & 7)) - 1);
         }
     }
-    uint64_t *d_sel = nullptr, *d_hit = nullptr, *d_valid = nullptr, *d_chit = nullptr, *d_cvalid = nullptr;
-    uint32_t* d_bits = nullptr;
-    auto cleanup = [&]() {
-        for (void* p : {(void*)d_sel, (void*)d_hit, (void*)d_valid, (void*)d_chit, (void*)d_cvalid, (void*)d_bits})
-            pool_release(ctx, p);  // every use below is followed by a blocking copy
-    };
-#define LC_HIP_C(expr)                                                                          \
-    do {                                                                                        \
-        hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess) {                                                                 \
-            cleanup();                                                                          \
-            return fail(LC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
-        }                                                                                       \
-    } while (0)
-    d_hit = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
-    d_valid = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
-    bool oom = !d_hit || !d_valid;
-    if (any_sel) {
-        d_sel = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
-        d_chit = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
-        d_cvalid = static_cast<uint64_t*>(pool_alloc(ctx, words * 8));
-        d_bits = static_cast<uint32_t*>(pool_alloc(ctx, size_t(m) * 4));
-        oom = oom || !d_sel || !d_chit || !d_cvalid || !d_bits;
-    }
-    if (oom) { cleanup(); return fail(LC_ERR_OOM, "hipMalloc (predicate scratch)"); }
-    if (any_sel) LC_HIP_C(hipMemcpy(d_sel, h_sel, words * 8, hipMemcpyHostToDevice));
-    rc = scan_eval_impl(ctx, scan, pred, d_sel, d_hit, d_valid, nullptr, nullptr, nullptr, nullptr, nullptr, true);
-    if (rc != LC_OK) { cleanup(); return rc; }
+    // device scratch in two blocks, so that the results leave in ONE copy: [hit | valid] and (under a selection)
+    // [selection | compacted hit | compacted valid | bit counts] — the host block [hit | valid | bits] mirrors the tail
+    uint64_t* d_hv = static_cast<uint64_t*>(cs.dalloc(words * 8 * 2));
+    uint64_t* d_cmp = any_sel ? static_cast<uint64_t*>(cs.dalloc(words * 8 * 3 + size_t(m) * 4 + 64)) : nullptr;
+    if (!d_hv || (any_sel && !d_cmp)) return fail(LC_ERR_OOM, "hipMalloc (predicate scratch)");
+    uint64_t *d_hit = d_hv, *d_valid = d_hv + words;
+    uint64_t *d_sel = any_sel ? d_cmp : nullptr, *d_chit = any_sel ? d_cmp + words : nullptr,
+             *d_cvalid = any_sel ? d_cmp + 2 * words : nullptr;
+    uint32_t* d_bits = any_sel ? reinterpret_cast<uint32_t*>(d_cmp + 3 * words) : nullptr;
+    LC_PROF(1);
+    if (any_sel) LC_HIP(hipMemcpyAsync(d_sel, h_sel, words * 8, hipMemcpyHostToDevice, cs.st));
+    rc = scan_eval_impl(ctx, scan, pred, d_sel, d_hit, d_valid, nullptr, nullptr, cs.st, nullptr, nullptr, true);
+    if (rc != LC_OK) return rc;
+    LC_PROF(2);
     std::vector<uint8_t> backing(m, 0);
     for (uint32_t k : scan->needs_backing) backing[k] = 1;
-    if (!scan->needs_backing.empty() && !statuses) { cleanup(); return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry needs its backing bytes"); }
+    if (!scan->needs_backing.empty() && !statuses) return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry needs its backing bytes");
     if (any_sel) {
         // the reference returns a BooleanArray of popcount(selection) rows: compress hit/valid by the selection
-        LC_HIP_C(launch_mask_compress(d_hit, d_sel, scan->d_seg_offsets, m, d_chit, d_bits, nullptr));
-        LC_HIP_C(launch_mask_compress(d_valid, d_sel, scan->d_seg_offsets, m, d_cvalid, nullptr, nullptr));
-        LC_HIP_C(hipMemcpy(h_hit, d_chit, words * 8, hipMemcpyDeviceToHost));
-        LC_HIP_C(hipMemcpy(h_valid, d_cvalid, words * 8, hipMemcpyDeviceToHost));
-        LC_HIP_C(hipMemcpy(h_bits, d_bits, size_t(m) * 4, hipMemcpyDeviceToHost));
+        LC_HIP(launch_mask_compress(d_hit, d_sel, scan->d_seg_offsets, m, d_chit, d_bits, cs.st));
+        LC_HIP(launch_mask_compress(d_valid, d_sel, scan->d_seg_offsets, m, d_cvalid, nullptr, cs.st));
+        LC_HIP(hipMemcpyAsync(h_hit, d_chit, words * 8 * 2 + size_t(m) * 4, hipMemcpyDeviceToHost, cs.st));
     } else {
-        LC_HIP_C(hipMemcpy(h_hit, d_hit, words * 8, hipMemcpyDeviceToHost));
-        LC_HIP_C(hipMemcpy(h_valid, d_valid, words * 8, hipMemcpyDeviceToHost));
-        for (uint32_t k = 0; k < m; k++) h_bits[k] = scan->meta[k].len;
+        LC_HIP(hipMemcpyAsync(h_hit, d_hv, words * 8 * 2, hipMemcpyDeviceToHost, cs.st));
     }
-    cleanup();
-#undef LC_HIP_C
+    LC_PROF(3);
+    LC_HIP(cs.sync());  // the call's one wait
+    LC_PROF(4);
+#ifdef LC_CALL_PROFILE
+    g_prof_calls++;
+#endif
+    if (!any_sel)
+        for (uint32_t k = 0; k < m; k++) h_bits[k] = scan->meta[k].len;
     for (uint32_t k = 0; k < m; k++) {
         const uint64_t i = present_idx[k];
         const Entry& e = scan->meta[k];
@@ -3096,24 +3316,21 @@ lc_status lc_eval_predicate_or(lc_ctx* ctx, uint32_t n, const uint64_t* entry_id
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
     std::vector<lc_scan*> scans(n, nullptr);
-    struct Guard {
-        std::vector<lc_scan*>& v;
-        ~Guard() { for (lc_scan* s : v) lc_scan_destroy(s); }
-    } guard{scans};
+    struct Guard {  // (declared before the stream: it is drained before the scans are checked in)
+        lc_ctx* c; const uint64_t* ids; std::vector<lc_scan*>& v;
+        ~Guard() { for (size_t k = 0; k < v.size(); k++) scan_checkin(c, ids[k], v[k]); }
+    } guard{ctx, entry_ids, scans};
+    CallStream cs(ctx);
     for (uint32_t i = 0; i < n; i++) {
-        const lc_status rc = lc_scan_create(ctx, 1, &entry_ids[i], &scans[i]);
+        const lc_status rc = scan_checkout(ctx, entry_ids[i], false, cs.st, &scans[i]);
         if (rc != LC_OK) return rc;  // LC_NOT_STAGED == the reference's early `None` (try_read_liquid, mod.rs:128-134)
     }
     const uint32_t len = scans[0]->meta[0].len;
     for (uint32_t i = 1; i < n; i++)
         if (scans[i]->meta[0].len != len) return fail(LC_ERR_INVALID, "the columns of a multi-column OR have different lengths");
     const uint64_t words = std::max<uint64_t>((uint64_t(len) + 63) / 64, 1);
-    uint64_t* d_buf = static_cast<uint64_t*>(pool_alloc(ctx, words * 8 * 5 + 64));
-    uint64_t* h_buf = static_cast<uint64_t*>(host_pool_alloc(ctx, words * 8 * 3 + 64));
-    struct Bufs {
-        lc_ctx* c; void* d; void* h;
-        ~Bufs() { (void)hipDeviceSynchronize(); pool_release(c, d); host_pool_release(c, h); }
-    } bufs{ctx, d_buf, h_buf};
+    uint64_t* d_buf = static_cast<uint64_t*>(cs.dalloc(words * 8 * 5 + 64));
+    uint64_t* h_buf = static_cast<uint64_t*>(cs.halloc(words * 8 * 3 + 64));
     if (!d_buf || !h_buf) return fail(LC_ERR_OOM, "hipMalloc (OR scratch)");
     uint64_t *d_sel = d_buf, *d_hit = d_buf + words, *d_valid = d_buf + 2 * words, *d_chit = d_buf + 3 * words,
              *d_cvalid = d_buf + 4 * words;
@@ -3124,15 +3341,17 @@ lc_status lc_eval_predicate_or(lc_ctx* ctx, uint32_t n, const uint64_t* entry_id
     if (selection) std::memcpy(h_buf, selection, nb);
     else std::memset(h_buf, 0xFF, nb);
     if (len & 7) reinterpret_cast<uint8_t*>(h_buf)[nb - 1] &= uint8_t((1u << (len & 7)) - 1);
-    LC_HIP(hipMemcpy(d_sel, h_buf, words * 8, hipMemcpyHostToDevice));
-    lc_status rc = scan_eval_or_impl(ctx, n, scans.data(), preds, d_sel, d_hit, d_valid, nullptr, nullptr);
+    LC_HIP(hipMemcpyAsync(d_sel, h_buf, words * 8, hipMemcpyHostToDevice, cs.st));
+    lc_status rc = scan_eval_or_impl(ctx, n, scans.data(), preds, d_sel, d_hit, d_valid, nullptr, cs.st);
     if (rc != LC_OK) return rc;
-    LC_HIP(launch_mask_compress(d_hit, d_sel, scans[0]->d_seg_offsets, 1, d_chit, d_bits, nullptr));
-    LC_HIP(launch_mask_compress(d_valid, d_sel, scans[0]->d_seg_offsets, 1, d_cvalid, nullptr, nullptr));
-    uint32_t bits = 0;
-    LC_HIP(hipMemcpy(h_buf, d_chit, words * 8, hipMemcpyDeviceToHost));
-    LC_HIP(hipMemcpy(h_buf + words, d_cvalid, words * 8, hipMemcpyDeviceToHost));
-    LC_HIP(hipMemcpy(&bits, d_bits, 4, hipMemcpyDeviceToHost));
+    LC_HIP(launch_mask_compress(d_hit, d_sel, scans[0]->d_seg_offsets, 1, d_chit, d_bits, cs.st));
+    LC_HIP(launch_mask_compress(d_valid, d_sel, scans[0]->d_seg_offsets, 1, d_cvalid, nullptr, cs.st));
+    uint32_t* h_bits = reinterpret_cast<uint32_t*>(h_buf + 2 * words);
+    LC_HIP(hipMemcpyAsync(h_buf, d_chit, words * 8, hipMemcpyDeviceToHost, cs.st));
+    LC_HIP(hipMemcpyAsync(h_buf + words, d_cvalid, words * 8, hipMemcpyDeviceToHost, cs.st));
+    LC_HIP(hipMemcpyAsync(h_bits, d_bits, 4, hipMemcpyDeviceToHost, cs.st));
+    LC_HIP(cs.sync());
+    const uint32_t bits = *h_bits;
     std::memcpy(out_values, h_buf, bitmap_bytes(bits));
     std::memcpy(out_validity, h_buf + words, bitmap_bytes(bits));
     *out_len = bits;
@@ -3154,26 +3373,22 @@ lc_status lc_mask_and_then(lc_ctx* ctx, const uint8_t* left, uint64_t left_bits,
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
     const uint64_t lw = (left_bits + 63) / 64, rw = (right_bits + 63) / 64 + 1;
-    std::vector<uint64_t> hl(lw, 0), hr(rw, 0);
-    std::memcpy(hl.data(), left, bitmap_bytes(left_bits));
+    CallStream cs(ctx);
+    uint64_t* h = static_cast<uint64_t*>(cs.halloc((2 * lw + rw) * 8));
+    uint64_t* d = static_cast<uint64_t*>(cs.dalloc((2 * lw + rw) * 8));
+    if (!h || !d) return fail(LC_ERR_OOM, "hipMalloc");
+    uint64_t *hl = h, *hr = h + lw, *ho = h + lw + rw;
+    uint64_t *dl = d, *dr = d + lw, *dout = d + lw + rw;
+    std::memset(h, 0, (lw + rw) * 8);
+    std::memcpy(hl, left, bitmap_bytes(left_bits));
     if (left_bits & 63) hl[lw - 1] &= (uint64_t(1) << (left_bits & 63)) - 1;
-    if (right_bits) std::memcpy(hr.data(), right, bitmap_bytes(right_bits));
-    uint64_t *dl = nullptr, *dr = nullptr, *dout = nullptr;
-    lc_status rc = LC_OK;
-    dl = static_cast<uint64_t*>(pool_alloc(ctx, lw * 8));
-    dr = static_cast<uint64_t*>(pool_alloc(ctx, rw * 8));
-    dout = static_cast<uint64_t*>(pool_alloc(ctx, lw * 8));
-    if (!dl || !dr || !dout) rc = fail(LC_ERR_OOM, "hipMalloc");
-    if (rc == LC_OK && (hipMemcpy(dl, hl.data(), lw * 8, hipMemcpyHostToDevice) != hipSuccess ||
-                        hipMemcpy(dr, hr.data(), rw * 8, hipMemcpyHostToDevice) != hipSuccess ||
-                        launch_mask_and_then(dl, left_bits, dr, dout, nullptr) != hipSuccess ||
-                        hipMemcpy(hl.data(), dout, lw * 8, hipMemcpyDeviceToHost) != hipSuccess))
-        rc = fail(LC_ERR_DEVICE, "and_then device pass failed");
-    pool_release(ctx, dl);
-    pool_release(ctx, dr);
-    pool_release(ctx, dout);
-    if (rc == LC_OK) std::memcpy(out, hl.data(), bitmap_bytes(left_bits));
-    return rc;
+    if (right_bits) std::memcpy(hr, right, bitmap_bytes(right_bits));
+    LC_HIP(hipMemcpyAsync(d, h, (lw + rw) * 8, hipMemcpyHostToDevice, cs.st));
+    LC_HIP(launch_mask_and_then(dl, left_bits, dr, dout, cs.st));
+    LC_HIP(hipMemcpyAsync(ho, dout, lw * 8, hipMemcpyDeviceToHost, cs.st));
+    LC_HIP(cs.sync());
+    std::memcpy(out, ho, bitmap_bytes(left_bits));
+    return LC_OK;
     });
 }
 
@@ -3262,10 +3477,13 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
     if (!ctx || !out_array || !out_schema) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
+    ScanLease lease{ctx, entry_id, nullptr, true};
+    CallStream cs(ctx);  // (after the lease: the stream is drained before the scan is checked in)
     lc_scan* scan = nullptr;
-    lc_status rc = scan_create_impl(ctx, 1, &entry_id, &scan, date_field >= 0);
+    lc_status rc = scan_checkout(ctx, entry_id, date_field >= 0, cs.st, &scan);
     if (rc != LC_OK) return rc;
-    std::unique_ptr<lc_scan, void (*)(lc_scan*)> guard(scan, lc_scan_destroy);
+    lease.s = scan;
+    scan_note_stream(scan, cs.st);
     const Entry& e = scan->meta[0];
     if (date_field >= 0 && date_ticks_per_day(e) < 0)
         return fail(LC_UNSUPPORTED, "ExtractDate32 applies to Date32 / Timestamp entries");
@@ -3273,57 +3491,47 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
         return fail(LC_NEEDS_BACKING, "entry is squeezed to another date component");
     const bool squeezed = e.squeezed_field >= 0;
     const uint64_t words = std::max<uint64_t>((uint64_t(e.len) + 63) / 64, 1);
-    std::vector<void*> dev;
-    auto dalloc = [&](size_t bytes) -> void* {
-        void* p = pool_alloc(ctx, bytes ? bytes : 8);
-        if (p) dev.push_back(p);
-        return p;
-    };
-    // every device buffer of this call is last used by a blocking copy or followed by the synchronize below
-    auto dfree = [&]() { (void)hipDeviceSynchronize(); for (void* p : dev) pool_release(ctx, p); dev.clear(); };
-#define LC_HIP_G(expr)                                                                          \
-    do {                                                                                        \
-        hipError_t _e = (expr);                                                                 \
-        if (_e != hipSuccess) {                                                                 \
-            dfree();                                                                            \
-            return fail(LC_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));      \
-        }                                                                                       \
-    } while (0)
-    uint64_t* d_sel = nullptr;
-    std::vector<uint64_t> h_sel(words, 0);
+    // every launch and copy of this call goes to the call's stream; its scratch returns to the pools when `cs` goes
+    auto dalloc = [&](size_t bytes) -> void* { return cs.dalloc(bytes); };
+    auto dfree = [&]() {};
+    hipStream_t st = cs.st;
+#define LC_HIP_G(expr) LC_HIP(expr)
+    // One pinned block [selection | compacted validity | bit count, totals] and its device mirror: every transfer of the call
+    // is a copy between pinned and device memory on the call's stream.  (Measured and rejected: kernels reading the
+    // selection from / writing the results to the pinned block in place — a kernel that touches host memory ends with a
+    // system-scope release, ~80 us per launch.)
+    uint64_t* h_pin = static_cast<uint64_t*>(cs.halloc(words * 8 * 2 + 64));
+    uint64_t* d_pin = static_cast<uint64_t*>(dalloc(words * 8 * 3 + 64));
+    if (!h_pin || !d_pin) return fail(LC_ERR_OOM, "hipHostMalloc (get staging)");
+    uint64_t* h_sel = h_pin;
+    uint64_t* h_valid = h_pin + words;
+    uint64_t* h_small = h_pin + 2 * words;  // [0]: k bits (u32), [2..3]: string totals
+    uint64_t *d_selc = d_pin, *d_vout = d_pin + words, *d_small = d_pin + 2 * words, *d_vsrc = d_pin + 2 * words + 8;
+    h_small[0] = 0;
+    const uint64_t* d_sel = nullptr;  // (what the gather kernels take: null = every row)
+    // the selection the compaction uses: the caller's, or "all rows" with the tail masked
     if (selection) {
-        std::memcpy(h_sel.data(), selection, bitmap_bytes(e.len));
+        std::memset(h_sel, 0, words * 8);
+        std::memcpy(h_sel, selection, bitmap_bytes(e.len));
         if (e.len & 63) h_sel[words - 1] &= (uint64_t(1) << (e.len & 63)) - 1;
-        d_sel = static_cast<uint64_t*>(dalloc(words * 8));
-        if (!d_sel) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
-        LC_HIP_G(hipMemcpy(d_sel, h_sel.data(), words * 8, hipMemcpyHostToDevice));
+        d_sel = d_selc;
+    } else {
+        for (uint64_t w = 0; w < words; w++) h_sel[w] = ~uint64_t(0);
+        if (e.len & 63) h_sel[words - 1] = (uint64_t(1) << (e.len & 63)) - 1;
+        if (e.len == 0) h_sel[0] = 0;
     }
     // compacted validity (k bits)
-    std::vector<uint64_t> h_valid(words, 0);
     uint32_t k_bits = 0;
     {
-        uint64_t* d_vsrc = static_cast<uint64_t*>(dalloc(words * 8));
-        uint64_t* d_vout = static_cast<uint64_t*>(dalloc(words * 8));
-        uint32_t* d_bits = static_cast<uint32_t*>(dalloc(4));
-        if (!d_vsrc || !d_vout || !d_bits) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
         const uint64_t* vptr = e.is_str ? e.sd.validity : e.fd.validity;
-        if (e.all_null) LC_HIP_G(hipMemset(d_vsrc, 0, words * 8));
-        else if (vptr) LC_HIP_G(hipMemcpy(d_vsrc, vptr, ((uint64_t(e.len) + 63) / 64) * 8, hipMemcpyDeviceToDevice));
-        else LC_HIP_G(hipMemset(d_vsrc, 0xFF, words * 8));
-        std::vector<uint64_t> sel_all;
-        const uint64_t* d_selc = d_sel;
-        if (!d_selc) {  // no selection: "all rows", with the tail masked
-            sel_all.assign(words, ~uint64_t(0));
-            if (e.len & 63) sel_all[words - 1] = (uint64_t(1) << (e.len & 63)) - 1;
-            if (e.len == 0) sel_all[0] = 0;
-            uint64_t* d_all = static_cast<uint64_t*>(dalloc(words * 8));
-            if (!d_all) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
-            LC_HIP_G(hipMemcpy(d_all, sel_all.data(), words * 8, hipMemcpyHostToDevice));
-            d_selc = d_all;
-        }
-        LC_HIP_G(launch_mask_compress(d_vsrc, d_selc, scan->d_seg_offsets, 1, d_vout, d_bits, nullptr));
-        LC_HIP_G(hipMemcpy(h_valid.data(), d_vout, words * 8, hipMemcpyDeviceToHost));
-        LC_HIP_G(hipMemcpy(&k_bits, d_bits, 4, hipMemcpyDeviceToHost));
+        const uint64_t* vsrc = vptr;
+        if (e.all_null) { LC_HIP_G(hipMemsetAsync(d_vsrc, 0, words * 8, st)); vsrc = d_vsrc; }
+        else if (!vptr) { LC_HIP_G(hipMemsetAsync(d_vsrc, 0xFF, words * 8, st)); vsrc = d_vsrc; }
+        LC_HIP_G(hipMemcpyAsync(d_selc, h_sel, words * 8, hipMemcpyHostToDevice, st));
+        LC_HIP_G(launch_mask_compress(vsrc, d_selc, scan->d_seg_offsets, 1, d_vout, reinterpret_cast<uint32_t*>(d_small), st));
+        LC_HIP_G(hipMemcpyAsync(h_valid, d_vout, words * 8 + 8, hipMemcpyDeviceToHost, st));  // (+ the bit count behind it)
+        LC_HIP_G(hipStreamSynchronize(st));  // (k sizes the output)
+        k_bits = *reinterpret_cast<const uint32_t*>(h_small);
     }
     const uint64_t k = k_bits;
     std::unique_ptr<ExportPriv> priv(new ExportPriv());
@@ -3335,14 +3543,14 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
     int64_t null_count = 0;
     if (e.nullable) {
         uint8_t* vb = host_alloc(bitmap_bytes(k));
-        std::memcpy(vb, h_valid.data(), bitmap_bytes(k));
+        std::memcpy(vb, h_valid, bitmap_bytes(k));
         null_count = int64_t(k) - int64_t(count_bits(vb, k));
         priv->buffers[0] = vb;
     }
     int64_t n_buffers = 2;
     if (!e.is_str && scan->has_clamped) {
         std::vector<uint32_t> needs;
-        const lc_status cs = clamp_unresolved_entries(ctx, scan, nullptr, 0, d_sel, nullptr, &needs);
+        const lc_status cs = clamp_unresolved_entries(ctx, scan, nullptr, 0, d_sel, st, &needs);
         if (cs != LC_OK || !needs.empty()) {
             dfree();
             return cs != LC_OK ? cs : fail(LC_NEEDS_BACKING, "a selected row of the clamp-squeezed entry is at or above the sentinel");
@@ -3362,17 +3570,26 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
         uint8_t* d_vals = static_cast<uint8_t*>(dalloc(std::max<size_t>(k, 1) * vw + 64));
         uint8_t* d_comp = squeezed ? static_cast<uint8_t*>(dalloc(std::max<size_t>(k, 1) * gw + 64)) : d_vals;
         if (!d_bc || !d_bo || !d_eo || !d_vals || !d_comp) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
-        LC_HIP_G(hipMemset(d_vals, 0, std::max<size_t>(k, 1) * vw + 64));
-        if (squeezed) LC_HIP_G(hipMemset(d_comp, 0, std::max<size_t>(k, 1) * gw + 64));
+        LC_HIP_G(hipMemsetAsync(d_vals, 0, std::max<size_t>(k, 1) * vw + 64, st));
+        if (squeezed) LC_HIP_G(hipMemsetAsync(d_comp, 0, std::max<size_t>(k, 1) * gw + 64, st));
         LC_HIP_G(launch_fixed_gather(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, L, d_bc, d_bo, d_eo,
-                                     d_comp, std::max<uint64_t>(k, 1), nullptr));
+                                     d_comp, std::max<uint64_t>(k, 1), st));
         if (squeezed)  // SqueezedDate32Array::to_component_array (squeezed_date32_array.rs:267-359)
             LC_HIP_G(launch_component_lossy(reinterpret_cast<const int32_t*>(d_comp), k, int(vw), date_field,
-                                            std::max<int64_t>(date_ticks_per_day(e), 1), d_vals, nullptr));
+                                            std::max<int64_t>(date_ticks_per_day(e), 1), d_vals, st));
         else if (date_field >= 0)
-            LC_HIP_G(launch_date_lossy(d_vals, k, int(vw), date_field, date_ticks_per_day(e), nullptr));
+            LC_HIP_G(launch_date_lossy(d_vals, k, int(vw), date_field, date_ticks_per_day(e), st));
         uint8_t* vals = host_alloc(std::max<size_t>(k, 1) * vw);
-        LC_HIP_G(hipMemcpy(vals, d_vals, k * vw, hipMemcpyDeviceToHost));
+        const size_t out_words = (k * vw + 7) / 8;  // (d_vals carries 64 zeroed bytes of slack)
+        uint8_t* h_out = out_words * 8 <= kPinnedResultMax ? static_cast<uint8_t*>(cs.halloc(out_words * 8 + 8)) : nullptr;
+        if (h_out) {
+            LC_HIP_G(hipMemcpyAsync(h_out, d_vals, out_words * 8, hipMemcpyDeviceToHost, st));
+            LC_HIP_G(hipStreamSynchronize(st));
+            std::memcpy(vals, h_out, k * vw);
+        } else {
+            LC_HIP_G(hipMemcpyAsync(vals, d_vals, k * vw, hipMemcpyDeviceToHost, st));
+            LC_HIP_G(hipStreamSynchronize(st));
+        }
         priv->buffers[1] = vals;
     } else {
         n_buffers = 3;
@@ -3384,18 +3601,30 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
         const StrDesc* descs = static_cast<const StrDesc*>(scan->d_descs);
         // passes 1+2 size the output, pass 3 decodes (two launches of the same helper keep the code in one place)
         LC_HIP_G(launch_str_gather(descs, scan->d_symtabs, 0, e.dict_len, 0, d_sel, d_dlen, d_offs, d_rows, d_tot, nullptr,
-                                   nullptr));
-        uint64_t tot[2] = {0, 0};
-        LC_HIP_G(hipMemcpy(tot, d_tot, 16, hipMemcpyDeviceToHost));
+                                   st));
+        LC_HIP_G(hipMemcpyAsync(h_small + 2, d_tot, 16, hipMemcpyDeviceToHost, st));
+        LC_HIP_G(hipStreamSynchronize(st));
+        const uint64_t tot[2] = {h_small[2], h_small[3]};
         if (tot[1] > uint64_t(INT32_MAX)) { dfree(); return fail(LC_UNSUPPORTED, "selected strings exceed 2 GiB (i32 offsets)"); }
         uint8_t* d_data = static_cast<uint8_t*>(dalloc(tot[1] + 64));
         if (!d_data) { dfree(); return fail(LC_ERR_OOM, "hipMalloc"); }
         LC_HIP_G(launch_str_gather(descs, scan->d_symtabs, 0, e.dict_len, uint32_t(tot[0]), d_sel, d_dlen, d_offs, d_rows,
-                                   d_tot, d_data, nullptr));
+                                   d_tot, d_data, st));
         int32_t* offs = reinterpret_cast<int32_t*>(host_alloc((k + 1) * 4));
         uint8_t* data = host_alloc(tot[1]);
-        LC_HIP_G(hipMemcpy(offs, d_offs, (k + 1) * 4, hipMemcpyDeviceToHost));
-        LC_HIP_G(hipMemcpy(data, d_data, tot[1], hipMemcpyDeviceToHost));
+        const size_t ow = ((k + 1) * 4 + 7) / 8, dw = (tot[1] + 7) / 8;  // (both device buffers are padded beyond that)
+        uint64_t* h_out = (ow + dw) * 8 <= kPinnedResultMax ? static_cast<uint64_t*>(cs.halloc((ow + dw) * 8 + 8)) : nullptr;
+        if (h_out) {
+            LC_HIP_G(hipMemcpyAsync(h_out, d_offs, ow * 8, hipMemcpyDeviceToHost, st));
+            LC_HIP_G(hipMemcpyAsync(h_out + ow, d_data, dw * 8, hipMemcpyDeviceToHost, st));
+            LC_HIP_G(hipStreamSynchronize(st));
+            std::memcpy(offs, h_out, (k + 1) * 4);
+            std::memcpy(data, h_out + ow, tot[1]);
+        } else {
+            LC_HIP_G(hipMemcpyAsync(offs, d_offs, (k + 1) * 4, hipMemcpyDeviceToHost, st));
+            LC_HIP_G(hipMemcpyAsync(data, d_data, tot[1], hipMemcpyDeviceToHost, st));
+            LC_HIP_G(hipStreamSynchronize(st));
+        }
         priv->buffers[1] = offs;
         priv->buffers[2] = data;
     }
@@ -3420,6 +3649,7 @@ lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selecti
     if (!ctx || !scan || !d_values_out || !d_row_offsets) return fail(LC_ERR_INVALID, "null argument");
     if (scan->is_str) return fail(LC_UNSUPPORTED, "scan-wide gather covers fixed-width columns");
     if (scan->n == 0) return LC_OK;
+    scan_note_stream(scan, static_cast<hipStream_t>(stream));
     const uint64_t vw = scan->meta[0].fd.value_width;
     if (values_capacity_bytes < scan->total_rows * vw && !d_selection)
         return fail(LC_ERR_INVALID, "values buffer too small for an unselected gather");
@@ -3464,8 +3694,10 @@ lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const void* d_se
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
     *out_rows = 0;
     *out_bytes = 0;
+    scan_note_stream(scan, static_cast<hipStream_t>(stream));
     if (scan->n == 0) return LC_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    scan_note_stream(scan, st);
     const uint64_t n = scan->n;
     const uint64_t tiles_len = std::max<uint64_t>(n, capacity_rows) / 1024 + 4;
     uint32_t* d_counts = static_cast<uint32_t*>(pool_alloc(ctx, n * 4));
@@ -3512,6 +3744,7 @@ lc_status lc_scan_gather_bytes(lc_ctx* ctx, lc_scan* scan, const void* d_row_ref
     return guarded([&]() -> lc_status {
     if (!ctx || !scan || (rows && (!d_row_refs || !d_value_offsets || !d_data))) return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
+    scan_note_stream(scan, static_cast<hipStream_t>(stream));
     LC_HIP(launch_str_decode_sel(static_cast<const StrDesc*>(scan->d_descs), scan->d_symtabs,
                                  static_cast<const uint64_t*>(d_row_refs), static_cast<const uint64_t*>(d_value_offsets), rows,
                                  nullptr, rows, ~uint64_t(0), static_cast<uint8_t*>(d_data), static_cast<hipStream_t>(stream)));
@@ -3528,6 +3761,7 @@ lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_s
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
     if (scan->n == 0) return LC_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    scan_note_stream(scan, st);
     const uint64_t n = scan->n;
     // scratch owned by the scan (grow only): [entry counts u32 x n | row lengths u32 x capacity | tile sums u64]
     const uint64_t tiles_len = std::max<uint64_t>(n, capacity_rows) / 1024 + 4;
@@ -3587,7 +3821,7 @@ lc_status lc_squeeze_date(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, in
     uint64_t* d_offs = static_cast<uint64_t*>(pool_alloc(ctx, (n + 1) * 8));
     struct Bufs {
         lc_ctx* c; void* a; void* b; void* d;
-        ~Bufs() { (void)hipDeviceSynchronize(); pool_release(c, a); pool_release(c, b); pool_release(c, d); }
+        ~Bufs() { (void)hipStreamSynchronize(nullptr); pool_release(c, a); pool_release(c, b); pool_release(c, d); }
     } bufs{ctx, d_vals, d_comp, d_offs};
     if (!d_vals || !d_comp || !d_offs) return fail(LC_ERR_OOM, "hipMalloc (squeeze scratch)");
     rc = lc_scan_gather_fixed(ctx, scan, nullptr, d_vals, rows * vw, d_offs, nullptr);   // decode every row, in order
@@ -3668,7 +3902,7 @@ static lc_status squeeze_float_quantize(lc_ctx* ctx, const std::vector<uint64_t>
         EncodeMinMax* d_mm = static_cast<EncodeMinMax*>(pool_alloc(ctx, m * sizeof(EncodeMinMax)));
         struct Bufs {
             lc_ctx* c; void* p[5];
-            ~Bufs() { (void)hipDeviceSynchronize(); for (void* q : p) pool_release(c, q); }
+            ~Bufs() { (void)hipStreamSynchronize(nullptr); for (void* q : p) pool_release(c, q); }
         } bufs{ctx, {d_descs0, d_vals, d_scr, d_enc, d_mm}};
         if (!d_descs0 || !d_vals || !d_scr || !d_enc || !d_mm) return fail(LC_ERR_OOM, "hipMalloc (float quantize scratch)");
         LC_HIP(hipMemcpy(d_descs0, zero_ref.data(), m * sizeof(FixedDesc), hipMemcpyHostToDevice));
@@ -3762,7 +3996,7 @@ static lc_status squeeze_float_quantize(lc_ctx* ctx, const std::vector<uint64_t>
         }
         LC_HIP(hipMemcpy(d_enc, pack.data(), pack.size() * sizeof(EncodeDesc), hipMemcpyHostToDevice));
         LC_HIP(launch_fl_pack(d_enc, uint32_t(pack.size()), max_rows, scan->lane_log2, nullptr));
-        LC_HIP(hipDeviceSynchronize());
+        LC_HIP(hipStreamSynchronize(nullptr));
         for (uint64_t i = 0; i < m; i++) {
             if (!lay[i].take) continue;
             Entry e = scan->meta[i];  // type, length, ALP exponents, reference stay
@@ -3779,14 +4013,7 @@ static lc_status squeeze_float_quantize(lc_ctx* ctx, const std::vector<uint64_t>
             e.fd.validity = lay[i].valid == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + lay[i].valid);
             e.fd.patch_idx = lay[i].pidx == size_t(-1) ? nullptr : reinterpret_cast<const uint64_t*>(dbase + lay[i].pidx);
             e.fd.patch_val = lay[i].pval == size_t(-1) ? nullptr : dbase + lay[i].pval;
-            auto old = ctx->entries.find(ids[i]);
-            if (old != ctx->entries.end()) {
-                ctx->entry_bytes -= old->second.device_bytes;
-                arena_release(ctx, old->second.slab);  // the scan above still pins the old blob until it is destroyed
-                ctx->entries.erase(old);
-            }
-            ctx->entry_bytes += e.device_bytes;
-            ctx->entries.emplace(ids[i], std::move(e));
+            publish_entry(ctx, ids[i], std::move(e));
         }
         reserved.disarm();
         if (out_done) *out_done += n_take;
@@ -3846,7 +4073,7 @@ static lc_status squeeze_half_width(lc_ctx* ctx, uint64_t n, const uint64_t* ent
         uint8_t* d_scr = static_cast<uint8_t*>(pool_alloc(ctx, nblk * 4 + fixed_gather_offsets_len(nblk) * 8 + (m + 1) * 8 + 64));
         struct Bufs {
             lc_ctx* c; void* a; void* b; void* d;
-            ~Bufs() { (void)hipDeviceSynchronize(); pool_release(c, a); pool_release(c, b); pool_release(c, d); }
+            ~Bufs() { (void)hipStreamSynchronize(nullptr); pool_release(c, a); pool_release(c, b); pool_release(c, d); }
         } bufs{ctx, d_descs0, d_vals, d_scr};
         if (!d_descs0 || !d_vals || !d_scr) return fail(LC_ERR_OOM, "hipMalloc (clamp squeeze scratch)");
         LC_HIP(hipMemcpy(d_descs0, zero_ref.data(), m * sizeof(FixedDesc), hipMemcpyHostToDevice));

@@ -40,3 +40,12 @@ def test_device_fsst_encoder_model_equals_host_encoder(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "device encoder model ok" in r.stdout
+
+
+def test_concurrent_callers_program_compiles_and_links(tmp_path, product_lib):
+    exe = str(tmp_path / "concurrent_callers")
+    libdir = os.path.join(ROOT, "liquid_cache_amd")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi", "concurrent_callers.c"), "-o", exe,
+                    "-L", libdir, "-l:libliquid_cache_amd.so", "-Wl,-rpath," + libdir], check=True)
+    assert os.path.exists(exe)

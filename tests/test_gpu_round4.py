@@ -133,3 +133,30 @@ def test_flat_index_groups_against_oracle(product_lib, oracle, grouped_cases, li
         scan.close()
     finally:
         cache.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# concurrent callers at the boundary (tests/c_abi/concurrent_callers.c: pthreads, no Python in the measured region)
+# ------------------------------------------------------------------------------------------------------------------
+def _build_concurrent(tmp_path):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "concurrent_callers")
+    libdir = os.path.join(root, "liquid_cache_amd")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-pthread", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", "concurrent_callers.c"), "-o", exe,
+                    "-L", libdir, "-l:libliquid_cache_amd.so", "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_eight_threads_with_their_own_streams_while_a_ninth_stages_and_evicts(product_lib, tmp_path):
+    """Eight host threads x distinct streams loop over lc_eval_predicate / lc_eval_predicate_batch / lc_scan_eval /
+    lc_get_with_selection on different columns while a ninth thread stages, re-stages and evicts: every answer equals the
+    single-threaded one and the eight together take less than twice one alone (no device-wide synchronise in any call;
+    reference: liquid_cache_reader.rs:297-391, cache/index.rs:30-34)."""
+    import subprocess
+    exe = _build_concurrent(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "concurrent callers ok" in r.stdout
