@@ -231,6 +231,7 @@ lc_status lc_comm_allreduce_count(lc_comm* c, void* d_total, void* stream) {
         return LC_OK;
     }
     if (c->world == 1) return LC_OK;
+    LC_HIP(hipSetDevice(c->ctx->device));  // (the collective launches on the thread's current device)
     const int e = rccl().AllReduce(d_total, d_total, 1, kRcclUint64, kRcclSum, c->rc, static_cast<hipStream_t>(stream));
     if (e != 0) return rccl_fail("ncclAllReduce", e);
     return LC_OK;
@@ -257,6 +258,7 @@ lc_status lc_comm_allgather_mask(lc_comm* c, const void* d_mask_local, uint64_t 
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     uint64_t* all = static_cast<uint64_t*>(d_mask_all);
+    LC_HIP(hipSetDevice(c->ctx->device));
     if (c->world == 1) {
         if (local_words && d_mask_all != d_mask_local)
             LC_HIP(hipMemcpyAsync(all, d_mask_local, size_t(local_words) * 8, hipMemcpyDeviceToDevice, st));

@@ -89,6 +89,8 @@ struct Entry {
     int fq_shift = 0;
     bool sig_on_device = false;  // staging: the signature slices are still to be built by k_str_build_signatures
     uint64_t raw_bytes = 0;      // byte views: uncompressed size of the dictionary (RawFsstBuffer header)
+    uint64_t index_hash = 0;     // byte views: hash of what the acceleration index was derived from (keys, validity, offsets,
+                                 // FSST bytes, symbol table) — an "LCIX" blob is only taken back for exactly these bytes
     uint64_t uid = 0;            // unique per publication (publish_entry): a cached scan knows its entry was replaced
 };
 

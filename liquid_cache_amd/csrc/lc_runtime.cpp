@@ -464,9 +464,37 @@ lc_status build_fixed(const uint8_t* bytes, size_t len, Entry* e, Blob* blob, si
 struct IndexHeader {
     uint32_t magic, version, d, n, sig_bits, flags;  // flags: 1 = signatures present, 2 = row lists present
     uint64_t sig_bytes, post_bytes;
+    uint64_t content_hash;  // of the Liquid bytes the index was derived from (index_content_hash): a blob kept for another
+                            // version of the entry — same dictionary size and row count, other strings — is not taken
 };
 constexpr uint32_t kIndexMagic = 0x5849434Cu;  // "LCIX"
-static_assert(sizeof(IndexHeader) == 40, "IndexHeader layout");
+constexpr uint32_t kIndexVersion = 2;
+static_assert(sizeof(IndexHeader) == 48, "IndexHeader layout");
+
+// FNV-1a over the sections an index depends on: the dictionary keys of the rows and their validity words (row lists), the
+// offset residuals + line parameters and the FSST bytes (which dictionary value is which string) and the symbol table
+// (what the FSST bytes decode to).
+static uint64_t fnv1a(uint64_t h, const void* p, size_t n) {
+    const uint8_t* b = static_cast<const uint8_t*>(p);
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+static uint64_t index_content_hash(const void* keys, size_t key_bytes, const void* validity_words, size_t validity_bytes,
+                                   const void* residuals, size_t residual_bytes, const void* fsst, size_t fsst_bytes,
+                                   int32_t slope, int32_t intercept, const SymbolTable& st) {
+    uint64_t h = 1469598103934665603ull;
+    h = fnv1a(h, keys, key_bytes);
+    h = fnv1a(h, &validity_bytes, sizeof(validity_bytes));
+    if (validity_bytes) h = fnv1a(h, validity_words, validity_bytes);
+    h = fnv1a(h, residuals, residual_bytes);
+    h = fnv1a(h, &slope, 4);
+    h = fnv1a(h, &intercept, 4);
+    h = fnv1a(h, fsst, fsst_bytes);
+    h = fnv1a(h, &st.n, sizeof(st.n));
+    h = fnv1a(h, st.len, sizeof(st.len));
+    h = fnv1a(h, st.sym, sizeof(st.sym));
+    return h ? h : 1;  // (0 = "not computed")
+}
 
 lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path_id, Entry* e, Blob* blob,
                     size_t offs[9], const uint8_t* index = nullptr, size_t index_len = 0) {
@@ -531,8 +559,14 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
     offs[4] = blob->add(v.residuals, size_t(v.residual_count) * size_t(v.offset_bytes), kSectionAlign, 8);
     offs[5] = blob->add(v.fsst, v.fsst_len, kSectionAlign, 16);
     offs[6] = blob->add(v.shared_prefix, v.shared_prefix_len, kSectionAlign, 8);
-    // a prebuilt index is used when it describes exactly this entry (dictionary size, rows, signature width, section
-    // sizes); anything else is ignored and the index is rebuilt
+    e->index_hash = index_content_hash(blob->bytes.data() + offs[0], size_t(v.n) * 2,
+                                       offs[1] == size_t(-1) ? nullptr : blob->bytes.data() + offs[1],
+                                       offs[1] == size_t(-1) ? 0 : ((size_t(v.n) + 63) / 64) * 8,
+                                       blob->bytes.data() + offs[4], size_t(v.residual_count) * size_t(v.offset_bytes),
+                                       blob->bytes.data() + offs[5], v.fsst_len, v.slope, v.intercept, *host_st);
+    // a prebuilt index is used when it describes exactly this entry — dictionary size, rows, signature width, section
+    // sizes AND the hash of the bytes it was derived from; anything else is ignored and the index is rebuilt: a stale or
+    // foreign blob can cost time, never a result
     const uint8_t* pre_sig = nullptr;
     const uint8_t* pre_post = nullptr;
     size_t pre_post_bytes = 0;
@@ -540,8 +574,12 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
         IndexHeader h;
         std::memcpy(&h, index, sizeof(h));
         const size_t nw = std::max<size_t>((size_t(v.d) + 63) / 64, 1);
-        const bool head_ok = h.magic == kIndexMagic && h.version == 1 && h.d == v.d && h.n == v.n && h.sig_bits == uint32_t(kSigBits) &&
-                             index_len == sizeof(h) + h.sig_bytes + h.post_bytes;
+        // (section sizes checked one by one: their sum may wrap)
+        const size_t body = index_len - sizeof(h);
+        const bool sizes_ok = h.sig_bytes <= body && h.post_bytes == body - h.sig_bytes &&
+                              ((h.flags & 1u) || h.sig_bytes == 0) && ((h.flags & 2u) || h.post_bytes == 0) && (h.flags & ~3u) == 0;
+        const bool head_ok = h.magic == kIndexMagic && h.version == kIndexVersion && h.d == v.d && h.n == v.n &&
+                             h.sig_bits == uint32_t(kSigBits) && sizes_ok && h.content_hash == e->index_hash;
         if (head_ok && (h.flags & 1u) && h.sig_bytes == size_t(kSigBits) * nw * 8) {
             pre_sig = index + sizeof(h);
             // no slice may have a bit beyond the dictionary: the kernels turn set bits into dictionary keys
@@ -1835,9 +1873,15 @@ lc_status lc_insert_arrow_batch_device(lc_ctx* ctx, uint64_t n_all, const uint64
                     const uint8_t* view = static_cast<const uint8_t*>(a->buffers[1]) + 16 * (size_t(a->offset) + r);
                     const uint32_t len = rd<uint32_t>(view);
                     if (len > 12) {
+                        // C Data Interface: buffers = [validity, views, data 0 .. data k-1, variadic sizes (i64 x k)] — the
+                        // LAST buffer holds the data buffers' sizes and is not a data buffer itself
                         const int32_t buf = rd<int32_t>(view + 8);
-                        if (buf < 0 || int64_t(buf) + 2 >= a->n_buffers || !a->buffers[2 + buf])
+                        const int32_t off = rd<int32_t>(view + 12);
+                        if (buf < 0 || int64_t(buf) + 2 >= a->n_buffers - 1 || !a->buffers[2 + buf] || !a->buffers[a->n_buffers - 1])
                             return fail(LC_ERR_INVALID, "view refers to a data buffer the array does not have");
+                        const int64_t size = static_cast<const int64_t*>(a->buffers[a->n_buffers - 1])[buf];
+                        if (off < 0 || int64_t(off) + int64_t(len) > size)
+                            return fail(LC_ERR_INVALID, "view reaches beyond its data buffer");
                     }
                     total += len;
                 }
@@ -1966,10 +2010,29 @@ lc_status lc_entry_index_to_bytes(lc_ctx* ctx, uint64_t entry_id, uint8_t** out_
     if (!e.is_str || (!e.sd.signatures && !e.sd.postings)) return LC_OK;  // nothing to keep: *out_len == 0
     IndexHeader h{};
     h.magic = kIndexMagic;
-    h.version = 1;
+    h.version = kIndexVersion;
     h.d = e.sd.d;
     h.n = e.sd.n;
     h.sig_bits = uint32_t(kSigBits);
+    h.content_hash = e.index_hash;
+    if (h.content_hash == 0) {
+        // an entry encoded on the device (no host bytes at staging): hash the same sections read back from its blob
+        const size_t kb = size_t(e.sd.n) * 2, vb = e.sd.validity ? ((size_t(e.sd.n) + 63) / 64) * 8 : 0;
+        std::vector<uint8_t> tmp(kb + vb + e.offsets_bytes + e.fsst_len + 8);
+        uint8_t* pk = tmp.data(), *pv = pk + kb, *pr = pv + vb, *pf = pr + e.offsets_bytes;
+        const SymbolTable* st = nullptr;
+        {
+            std::lock_guard<std::mutex> g(ctx->st_mu);
+            if (e.sd.symtab_slot < ctx->symtabs.size()) st = ctx->symtabs[e.sd.symtab_slot].get();
+        }
+        if (!st) return fail(LC_ERR_NO_SYMTAB, "entry refers to an unknown symbol table");
+        if ((kb && hipMemcpy(pk, e.sd.keys, kb, hipMemcpyDeviceToHost) != hipSuccess) ||
+            (vb && hipMemcpy(pv, e.sd.validity, vb, hipMemcpyDeviceToHost) != hipSuccess) ||
+            (e.offsets_bytes && hipMemcpy(pr, e.sd.residuals, e.offsets_bytes, hipMemcpyDeviceToHost) != hipSuccess) ||
+            (e.fsst_len && hipMemcpy(pf, e.sd.fsst, e.fsst_len, hipMemcpyDeviceToHost) != hipSuccess))
+            return fail(LC_ERR_DEVICE, "hipMemcpy (entry index hash)");
+        h.content_hash = index_content_hash(pk, kb, pv, vb, pr, e.offsets_bytes, pf, e.fsst_len, e.sd.slope, e.sd.intercept, *st);
+    }
     const size_t nw = std::max<size_t>((size_t(e.sd.d) + 63) / 64, 1);
     if (e.sd.signatures) { h.flags |= 1u; h.sig_bytes = size_t(kSigBits) * nw * 8; }
     if (e.sd.postings) { h.flags |= 2u; h.post_bytes = (size_t(e.sd.d) + 1 + size_t(e.sd.n) + 32) * 2; }
