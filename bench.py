@@ -96,8 +96,9 @@ def parse_args(argv=None):
                    help="skip the L3-cold timing (rocprofv3 --stats runs: the kernel average then only holds hot launches)")
     p.add_argument("--secondary-rows", type=int, default=0, help="rows of the secondary workloads (0 = --rows)")
     p.add_argument("--secondary-set", default="all",
-                   help="comma list of the secondary groups to run: q21,int,q6,sweep,staging,like (kernel A/B runs)")
-    p.add_argument("--sweep-rows", type=int, default=33_554_432, help="rows of the ClickBench pushdown sweep (config 5)")
+                   help="comma list of the secondary groups to run: q21,int,micro,q6,sweep,staging,like (kernel A/B runs)")
+    p.add_argument("--sweep-rows", type=int, default=0,
+                   help="rows of the ClickBench pushdown sweep (config 5); 0 = the whole table (--rows)")
     p.add_argument("--seed", type=int, default=42)
     return p.parse_args(argv)
 
@@ -214,6 +215,12 @@ def stage_int_column(cache, lc, N, args, rank, rows_total, threads, bits=None, b
                 arr = pa.array(v.astype(np.int16))
             elif kind == "date32":
                 arr = pa.array(v.astype(np.int32), type=pa.date32())
+            elif kind == "uint32":
+                arr = pa.array(v.astype(np.uint32))
+            elif kind == "int32":
+                arr = pa.array(v.astype(np.int32))
+            elif kind == "float64":
+                arr = pa.array(v.astype(np.float64) / 100.0)  # two decimals: ALP exponent 2, packed like the integers
             else:
                 arr = _dec_array(pa, v)
             cache.insert(ids[b], arr)
@@ -263,8 +270,9 @@ def measured_traffic(key, kernel=None):
         if not isinstance(e, dict) or "traffic_bytes" not in e:
             continue
         fam = (kernel or "").split("<")[0].split(" ")[0]
-        if fam and not any(isinstance(v, dict) and k.startswith(fam) and v.get("traffic_bytes") == e["traffic_bytes"]
-                           for k, v in e.items()):
+        kernels = {k: v for k, v in e.items() if isinstance(v, dict)}
+        summed = not any(v.get("traffic_bytes") == e["traffic_bytes"] for v in kernels.values())  # (a multi-kernel workload)
+        if fam and not any(k.startswith(fam) and (summed or v.get("traffic_bytes") == e["traffic_bytes"]) for k, v in kernels.items()):
             return None, None  # the newest profile of this workload is of another kernel: unmeasured, not inherited
         return int(e["traffic_bytes"]), os.path.relpath(f, ROOT)
     return None, None
@@ -324,8 +332,9 @@ def add_read_probe(r, cache, N):
     return r
 
 
-def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=True, probe=None):
-    """HIP-event kernel time (hot, and with the Infinity Cache flushed before every launch) + byte model of one predicate."""
+def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=True, probe=None, tkey=None):
+    """HIP-event kernel time (hot, and with the Infinity Cache flushed before every launch) + byte model of one predicate.
+    `tkey`: the workload's key in profiles/<round>/hbm_traffic.json (PMC traffic of the same kernel, when profiled)."""
     words = int(scan.mask_words) if words is None else words
     mask = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
     counts = torch.zeros(max(scan.entries, 1), dtype=torch.int32, device="cuda")
@@ -335,7 +344,8 @@ def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=Tr
     cold = scan.eval_timed_cold(expr, mask.data_ptr(), max(3, iters // 4), FLUSH_BYTES, 0, counts.data_ptr(), stream) \
         if with_cold else None
     alg, own = scan.traffic_model(expr, False)
-    r = roofline(kernel, ms, alg, own, cold)
+    traffic, traffic_src = measured_traffic(tkey, kernel) if tkey else (None, None)
+    r = roofline(kernel, ms, alg, own, cold, traffic, traffic_src)
     if probe is not None:
         add_read_probe(r, *probe)
     r["hits"] = int(counts.sum(dtype=torch.int64).item())
@@ -455,7 +465,9 @@ def measure_get_with_selection(scan, lc, bits, base, counts, torch, stream, iter
         dense = per_block > 16
         necessary = scan.rows // 8 + int(dense.sum()) * 128 * bits + int(per_block[~dense].sum()) * 16 + k_sel * 8
         alg = scan.rows * bits // 8 + scan.rows // 8 + k_sel * 8   # n*W/8 + n/8 read, k*sizeof(T) written
+        g_traffic = measured_traffic("gather_10pct", "k_fixed_gather")[0] if sel_name == "10pct" and scan.rows == 99_997_497 else None
         res[sel_name] = {"kernels": "k_sel_entry_counts + k_scan_{tile_sums,tiles,apply} + k_fixed_gather<u64>",
+                         "traffic": g_traffic,
                          "selected_rows": k_sel, "ms": g_ms, "necessary_bytes": int(necessary),
                          "achieved_gbs": necessary / (g_ms * 1e-3) / 1e9,
                          "frac": necessary / (g_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -485,7 +497,8 @@ def secondary_int_columns(cache, lc, N, args, rows, threads, torch, stream, iter
                 lit_v = datetime.date(1970, 1, 1) + datetime.timedelta(days=lit)
             else:
                 lit_v = lit
-            r, _, counts = time_pred(scan, lc.LiquidExpr.try_new(">", lit_v, dtype), torch, stream, iters, kernel, probe=(cache, N))
+            r, _, counts = time_pred(scan, lc.LiquidExpr.try_new(">", lit_v, dtype), torch, stream, iters, kernel, probe=(cache, N),
+                                     tkey=name)
             r["rows"] = int(scan.rows)
             if name == "int64_gt_w62":
                 r["get_with_selection"] = measure_get_with_selection(scan, lc, bits, base_v, counts, torch, stream, iters)
@@ -494,6 +507,103 @@ def secondary_int_columns(cache, lc, N, args, rows, threads, torch, stream, iter
             cache.evict(ids)
         except Exception as e:  # noqa: BLE001 - a secondary measurement must never cost the headline line
             out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url_scan=None):
+    """The reference's own micro-benchmark shapes and the hot-path kernels earlier rounds never timed, each
+    with a roofline object (own bytes / HIP-event time, hot and L3-cold):
+      * u32 bit widths {1,3,7,11,19,27} (core/bench/bitpacking.rs:12-13), `>` at 50 %, and W=11 at selectivity
+        {0.01,0.1,0.3,0.7,0.9} (bitpacking.rs:62-75);
+      * Int32 `= 500` over uniform [0,1024) at batch 16384 (datafusion/bench/filter_pushdown.rs:23-31,115-119);
+      * config 2 at selectivity {0.01 %, 1 %, 50 %} (Int64 W=62 / W=17, Date32 W=12);
+      * ALP float predicate (float_array.rs:294-316), string Eq / ordering through the prefix keys
+        (byte_view_array/comparisons.rs:21-151, 351-405), date-part extraction over decoded values."""
+    import pyarrow as pa
+    out = {}
+
+    def run(name, kind, bits, base, dtype, kernel, col, lits, a=None, op=">"):
+        try:
+            ids = stage_int_column(cache, lc, N, a or args, 1, rows, threads, bits=bits, base=base, col=col, kind=kind)
+            scan = cache.scan(ids)
+            for tag, lit in lits:
+                if kind == "date32":
+                    lit_v = datetime.date(1970, 1, 1) + datetime.timedelta(days=int(lit))
+                elif kind == "float64":
+                    lit_v = float(lit) / 100.0
+                else:
+                    lit_v = int(lit)
+                r, _, _ = time_pred(scan, lc.LiquidExpr.try_new(op, lit_v, dtype), torch, stream, iters, kernel)
+                r["rows"] = int(scan.rows)
+                r["selectivity"] = r["hits"] / max(int(scan.rows), 1)
+                out[name + tag] = r
+            scan.close()
+            cache.evict(ids)
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    frac = lambda bits, base, s: base + int((1 << bits) * (1.0 - s))  # noqa: E731  (`>` literal for selectivity s)
+    for w in (1, 3, 7, 11, 19, 27):
+        lits = [("", (1 << (w - 1)) - (1 if w == 1 else 0))]
+        if w == 11:
+            lits += [("_sel%g" % sv, frac(w, 0, sv)) for sv in (0.01, 0.1, 0.3, 0.7, 0.9)]
+        run("uint32_gt_w%d" % w, "uint32", w, 0, pa.uint32(), "k_fixed_pred_reg<u32>", 60 + w, lits)
+    a16 = copy.copy(args)
+    a16.batch_size = 16384
+    run("int32_eq_500_batch16384", "int32", 10, 0, pa.int32(), "k_fixed_pred_reg<u32>", 95, [("", 500)], a=a16, op="=")
+    sels = (("_sel0.01pct", 1e-4), ("_sel1pct", 1e-2), ("_sel50pct", 0.5))
+    b62 = int_base(62)
+    run("int64_gt_w62", "int64", 62, b62, pa.int64(), "k_fixed_pred<u64> (LDS staged)", 96, [(t, frac(62, b62, sv)) for t, sv in sels])
+    run("int64_gt_w17", "int64", 17, 1000, pa.int64(), "k_fixed_pred_reg<u64>", 97, [(t, frac(17, 1000, sv)) for t, sv in sels])
+    run("date32_gt_w12", "date32", 12, 8036, pa.date32(), "k_fixed_pred_reg<u32>", 98, [(t, frac(12, 8036, sv)) for t, sv in sels])
+    run("float64_alp_gt_w17", "float64", 17, 0, pa.float64(), "k_fixed_pred_reg<u64> (ALP, packed-domain range)", 99,
+        [("", frac(17, 0, 0.5))])
+    if url_scan is not None:
+        try:  # string Eq / ordering: prefix keys decide almost every dictionary value, the row lists / keys give the rows
+            offs = np.zeros(args.batch_size + 1, np.int32)
+            data = np.zeros(args.batch_size * 512, np.uint8)
+            nb = N.load_bench().lc_synth_url_batch(url_seed(args, 0), 0, args.batch_size, min(args.uniques, args.batch_size),
+                                                   args.needle_ppm, offs.ctypes.data, data.ctypes.data, data.size)
+            v0 = bytes(data[:nb][offs[0]: offs[1]])
+            for tag, op, lit in (("string_eq_existing_value", "=", v0), ("string_lt", "<", b"http://m"), ("string_ge", ">=", b"http://m")):
+                r, _, _ = time_pred(url_scan, lc.LiquidExpr.try_new(op, lit, pa.string()), torch, stream, max(3, iters // 2), "k_str_pred")
+                r["rows"] = int(url_scan.rows)
+                r["predicate"] = "URL %s %r" % (op, lit[:40])
+                out[tag] = r
+        except Exception as e:  # noqa: BLE001
+            out["string_eq_ordering"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:  # date-part extraction over decoded Date32 values, in place (k_date_component / lossy reconstruction)
+        ids = stage_int_column(cache, lc, N, args, 1, min(rows, 33_554_432), threads, bits=12, base=8036, col=94, kind="date32")
+        scan = cache.scan(ids)
+        n = int(scan.rows)
+        vals = torch.randint(8036, 8036 + 4096, (n,), dtype=torch.int32, device="cuda")
+        scan.date_part(vals.data_ptr(), n, lc.Date32Field.YEAR, stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            scan.date_part(vals.data_ptr(), n, lc.Date32Field.YEAR, stream)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        out["date_part_year_in_place"] = {"bound": "hbm", "kernel": "k_date_lossy<i32>", "kernel_ms": ms, "rows": n,
+                                          "kernel_bytes_per_launch": 8 * n, "achieved": 8 * n / (ms * 1e-3) / 1e9,
+                                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 8 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "timing": "back_to_back", "traffic": None}
+        scan.close()
+        cache.evict(ids)
+    except Exception as e:  # noqa: BLE001
+        out["date_part_year_in_place"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:  # boolean_buffer_and_then through the host API: a per-call latency (8192-bit masks), not a bandwidth
+        left = np.random.default_rng(5).random(8192) < 0.5
+        right = np.random.default_rng(6).random(int(left.sum())) < 0.5
+        lc.boolean_buffer_and_then(cache, left, right)
+        t0 = time.perf_counter()
+        for _ in range(200):
+            lc.boolean_buffer_and_then(cache, left, right)
+        out["mask_and_then_host_call"] = {"unit": "us per call (8192-bit left, host buffers in and out)",
+                                          "value": (time.perf_counter() - t0) / 200 * 1e6}
+    except Exception as e:  # noqa: BLE001
+        out["mask_and_then_host_call"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -797,7 +907,8 @@ def secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream
             scan = cache2.scan(ids)
             hint = lc.CacheExpression.SUBSTRING_SEARCH
             expr = lc.LiquidExpr.try_new("like", pattern, pa.string(), hint)
-            r, _, _ = time_pred(scan, expr, torch, stream, max(3, iters // 2), "k_str_pred", with_cold=True, probe=(cache2, N))
+            r, _, _ = time_pred(scan, expr, torch, stream, max(3, iters // 2), "k_str_pred", with_cold=True, probe=(cache2, N),
+                                tkey=name)
             out[name] = r
             scan.close()
             cache2.close()
@@ -841,9 +952,23 @@ def secondary_clickbench_sweep(cache, lc, args, rows, threads, torch, stream, it
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / iters
         total_ms += ms
-        out["queries"]["q%d" % q] = {"passes": len(ex.plan(rf)), "conjuncts": sum(len(s.exprs) for s in ex.plan(rf)),
+        # bytes of the query's passes by the library's own byte model (lc_scan_traffic_model per conjunct; passes behind the
+        # first are priced WITH their selection words but as if no entry were skipped — the kernels do skip entries whose
+        # selection is empty, so for multi-conjunct queries this is an upper bound and `frac` with it)
+        steps = ex.plan(rf)
+        own = alg = 0
+        for k, stp in enumerate(steps):
+            for sc, ex_ in zip(stp.scans if stp.kind == "or" else stp.scans * len(stp.exprs), stp.exprs):
+                a_b, o_b = sc.traffic_model(ex_, k > 0)
+                own += int(o_b)
+                alg += int(a_b)
+        out["queries"]["q%d" % q] = {"passes": len(steps), "conjuncts": sum(len(s.exprs) for s in steps),
                                      "ms": ms, "rows_per_s": rows / (ms * 1e-3),
-                                     "rows_out": int(counts.sum(dtype=torch.int64).item())}
+                                     "rows_out": int(counts.sum(dtype=torch.int64).item()),
+                                     "own_bytes_model": own, "algorithmic_bytes": alg,
+                                     "achieved_gbs": own / (ms * 1e-3) / 1e9,
+                                     "frac": own / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                     "filter": " AND ".join(s.text for s in steps)[:160]}
     out["total_ms_all_queries"] = total_ms
     for c in columns.values():
         c.scan.close()
@@ -1107,7 +1232,9 @@ def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch
         "gb_per_s_scanned": alg5 * world / (elapsed / args.steps) / 1e9,
         "roofline": {"bound": "hbm", "kernel": "k_fixed_chain (one launch over 3 columns: u32 W=12, u64 W=4, u64 W=13)",
                      "achieved": alg3 / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": alg3 / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None, "kernel_ms": chain_ms,
+                     "frac": alg3 / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "traffic": measured_traffic("tpch_q6", "k_fixed_chain")[0] if rows_all == 600_037_902 and world == 1 else None,
+                     "kernel_ms": chain_ms,
                      "algorithmic_bytes": int(alg3), "effective_gbs_vs_5_pass_bytes": alg5 / (chain_ms * 1e-3) / 1e9},
     }
     if world == 1 and not args.no_secondary:
@@ -1520,13 +1647,19 @@ def main():
                 sec["q21_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if want("int"):
             sec.update(secondary_int_columns(cache, lc, N, args, sec_rows, threads, torch, stream, iters))
+        if want("micro"):
+            try:
+                sec["micro"] = secondary_micro(cache, lc, N, args, sec_rows, threads, torch, stream, max(5, iters // 2),
+                                               url_scan=scan if args.workload == "url_like" else None)
+            except Exception as e:  # noqa: BLE001
+                sec["micro"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
             if want("q6"):
                 sec["tpch_q6_pushdown"] = secondary_tpch_q6(cache, lc, N, args, sec_rows, threads, torch, stream, iters)
         except Exception as e:  # noqa: BLE001
             sec["tpch_q6_pushdown"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:
-            sweep_rows = min(sec_rows, args.sweep_rows)
+            sweep_rows = min(sec_rows, args.sweep_rows) if args.sweep_rows else sec_rows
             if want("sweep"):
                 sec["clickbench_pushdown_sweep"] = secondary_clickbench_sweep(cache, lc, args, sweep_rows, threads, torch, stream,
                                                                           max(3, iters // 2))

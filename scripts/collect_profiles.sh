@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: scripts/collect_profiles.sh <round-tag>
 # Copies the summaries scripts/profile_round.sh left under gpurun_out/<tag>/ into profiles/<tag>/ (tracked).
-tag=${1:-r3}
+tag=${1:-r4}
 R=$(cd "$(dirname "$0")/.." && pwd)
 S=$R/gpurun_out/$tag
 D=$R/profiles/$tag
