@@ -560,18 +560,6 @@ LC_API lc_status lc_stream_synchronize(lc_ctx* ctx, void* stream);
 LC_API lc_status lc_stream_create(lc_ctx* ctx, void** out_stream);
 LC_API lc_status lc_stream_destroy(lc_ctx* ctx, void* stream);
 
-/* Time `iters` back-to-back lc_scan_eval launches with HIP events recorded on `stream` (the stream the kernels
- * run on); returns the average milliseconds per launch.  Used by bench.py for the roofline figure. */
-LC_API lc_status lc_scan_eval_timed(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
-                                    void* d_mask_out, void* d_counts_out, void* stream, int32_t iters,
-                                    float* out_avg_ms);
-
-/* The same with the memory-side cache flushed before every launch (`flush_bytes` of scratch are streamed through it
- * by a read-only kernel between launches, so no dirty lines are left to write back; >= 512 MiB defeats the 256 MiB
- * Infinity Cache): the cold-L3 kernel time of one evaluation. */
-LC_API lc_status lc_scan_eval_timed_cold(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
-                                         void* d_mask_out, void* d_counts_out, void* stream, int32_t iters,
-                                         uint64_t flush_bytes, float* out_avg_ms);
 
 #ifdef __cplusplus
 }

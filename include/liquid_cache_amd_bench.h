@@ -56,6 +56,15 @@ LC_BENCH_API int32_t lc_calibrate_read(void* ctx, uint64_t bytes, int32_t shape,
 LC_BENCH_API int32_t lc_probe_stream_read(void* ctx, uint64_t bytes, int32_t iters, int32_t grid_blocks, double* out_hot_us,
                                           double* out_cold_us);
 
+/* Kernel time of lc_scan_eval over a scan (`scan`: lc_scan*, `pred`: const lc_predicate*), HIP events recorded on `stream`
+ * (the stream the kernels run on); the average milliseconds per evaluation over `iters` launches.  flush_bytes == 0: back
+ * to back (hot: a column below the 256 MiB Infinity Cache stays resident); > 0: that many bytes of scratch are streamed
+ * through the memory-side cache by a read-only kernel before every launch (>= 512 MiB defeats the Infinity Cache) — the
+ * L3-cold kernel time of one evaluation.  Uses the public scan API only; the roofline figures of bench.py come from here. */
+LC_BENCH_API int32_t lc_bench_eval_timed(void* ctx, void* scan, const void* pred, const void* d_selection, void* d_mask_out,
+                                         void* d_counts_out, void* stream, int32_t iters, uint64_t flush_bytes,
+                                         float* out_avg_ms);
+
 /* Test aid (host only, no context): the inverted row lists lc_stage attaches to byte-view entries of substring-search
  * columns — u16 offsets[d + 1], then the valid rows grouped by dictionary key — for `n` (<= 8192) keys, an optional
  * LSB-first validity bitmap and a dictionary of `d` values.  Returns the number of u16 written to `out` (d + 1 + n + 32;

@@ -71,14 +71,14 @@ EXPORTED_SYMBOLS = [
     "lc_stage", "lc_evict", "lc_entry_info_get", "lc_transcode_arrow", "lc_insert_arrow", "lc_free", "lc_symtab_get",
     "lc_eval_predicate", "lc_eval_predicate_batch", "lc_get_with_selection", "lc_get_date_part_with_selection", "lc_scan_date_part", "lc_scan_gather_bytes_plan", "lc_scan_gather_bytes", "lc_scan_gather_bytes_async", "lc_mask_and_then", "lc_scan_create",
     "lc_scan_destroy", "lc_scan_mask_words", "lc_scan_rows", "lc_scan_entries", "lc_scan_algorithmic_bytes",
-    "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_timed_cold", "lc_scan_eval_or", "lc_eval_predicate_or", "lc_insert_arrow_device", "lc_entry_to_liquid_bytes", "lc_squeeze_date", "lc_squeeze_clamp", "lc_squeeze_quantize", "lc_scan_aggregate", "lc_scan_sum_product", "lc_scan_eval_filter",
+    "lc_scan_traffic_model", "lc_scan_eval_and", "lc_scan_eval_count", "lc_scan_eval_or", "lc_eval_predicate_or", "lc_insert_arrow_device", "lc_entry_to_liquid_bytes", "lc_squeeze_date", "lc_squeeze_clamp", "lc_squeeze_quantize", "lc_scan_aggregate", "lc_scan_sum_product", "lc_scan_eval_filter",
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
-    "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize", "lc_scan_eval_timed",
+    "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize",
     "lc_stream_create", "lc_stream_destroy",
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
-                 "lc_calibrate_read", "lc_probe_stream_read", "lc_debug_row_lists"]
+                 "lc_calibrate_read", "lc_probe_stream_read", "lc_debug_row_lists", "lc_bench_eval_timed"]
 
 _lib = None
 _bench = None
@@ -106,6 +106,8 @@ def load_bench():
     B.lc_probe_stream_read.argtypes = [vp, u64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     B.lc_debug_row_lists.restype = sz
     B.lc_debug_row_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, sz]
+    B.lc_bench_eval_timed.restype = i32
+    B.lc_bench_eval_timed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, u64, C.POINTER(C.c_float)]
     _bench = B
     return B
 
@@ -186,10 +188,6 @@ def load():
     L.lc_eval_predicate_or.argtypes = [vp, C.c_uint32, P(u64), P(Predicate), vp, vp, vp, P(C.c_uint32), P(C.c_int32)]
     L.lc_scan_eval_count.restype = i32
     L.lc_scan_eval_count.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, vp, vp, vp]
-    L.lc_scan_eval_timed_cold.restype = i32
-    L.lc_scan_eval_timed_cold.argtypes = [vp, vp, P(Predicate), vp, vp, vp, vp, i32, u64, P(C.c_float)]
-    L.lc_scan_eval_timed.restype = i32
-    L.lc_scan_eval_timed.argtypes = [vp, vp, P(Predicate), vp, vp, vp, vp, i32, P(C.c_float)]
     L.lc_scan_gather_fixed.restype = i32; L.lc_scan_gather_fixed.argtypes = [vp, vp, vp, vp, u64, vp, vp]
     L.lc_device_alloc.restype = i32; L.lc_device_alloc.argtypes = [vp, u64, P(vp)]
     L.lc_device_free.restype = i32; L.lc_device_free.argtypes = [vp, vp]

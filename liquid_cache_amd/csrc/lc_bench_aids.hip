@@ -111,6 +111,63 @@ int32_t lc_probe_stream_read(void* ctx_, uint64_t bytes, int32_t iters, int32_t 
     return rc;
 }
 
+// Kernel time of lc_scan_eval over a scan, HIP events on the stream the kernels run on — back to back (hot), or with the
+// memory-side Infinity Cache flushed before every launch (two read passes of k_probe_read over `flush_bytes` of scratch:
+// the cache ends up holding clean scratch lines only).  Through the PUBLIC scan API only: bench infrastructure, not part of
+// the product library.
+int32_t lc_bench_eval_timed(void* ctx_, void* scan_, const void* pred_, const void* d_selection, void* d_mask_out,
+                            void* d_counts_out, void* stream, int32_t iters, uint64_t flush_bytes, float* out_avg_ms) {
+    lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
+    lc_scan* scan = static_cast<lc_scan*>(scan_);
+    const lc_predicate* pred = static_cast<const lc_predicate*>(pred_);
+    if (!ctx || !scan || !pred || !out_avg_ms || iters <= 0) return LC_ERR_INVALID;
+    lc_device_info info;
+    if (lc_device_info_get(ctx, &info) != LC_OK || info.device_id < 0) return LC_ERR_DEVICE;
+    if (hipSetDevice(info.device_id) != hipSuccess) return LC_ERR_DEVICE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint8_t* d_flush = nullptr;
+    if (flush_bytes) {
+        flush_bytes = std::max<uint64_t>(flush_bytes, 1 << 20);
+        if (hipMalloc(reinterpret_cast<void**>(&d_flush), flush_bytes + 65536) != hipSuccess) return LC_ERR_OOM;
+        if (hipMemset(d_flush, 1, flush_bytes + 65536) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+            (void)hipFree(d_flush);
+            return LC_ERR_DEVICE;
+        }
+    }
+    hipEvent_t a = nullptr, b = nullptr;
+    int32_t rc = LC_OK;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) rc = LC_ERR_DEVICE;
+    double total = 0;
+    if (rc == LC_OK && !d_flush) {
+        // back to back: one pair of events around all launches
+        if (hipEventRecord(a, st) != hipSuccess) rc = LC_ERR_DEVICE;
+        for (int i = 0; i < iters && rc == LC_OK; i++) rc = lc_scan_eval(ctx, scan, pred, d_selection, d_mask_out, d_counts_out, st);
+        float ms = 0;
+        if (rc == LC_OK && (hipEventRecord(b, st) != hipSuccess || hipEventSynchronize(b) != hipSuccess ||
+                            hipEventElapsedTime(&ms, a, b) != hipSuccess))
+            rc = LC_ERR_DEVICE;
+        total = ms;
+    }
+    for (int i = 0; i < iters && rc == LC_OK && d_flush; i++) {
+        for (int pass = 0; pass < 2; pass++)
+            hipLaunchKernelGGL(k_probe_read, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_flush), flush_bytes / 16,
+                               reinterpret_cast<uint32_t*>(d_flush + flush_bytes));
+        if (hipGetLastError() != hipSuccess || hipEventRecord(a, st) != hipSuccess) { rc = LC_ERR_DEVICE; break; }
+        rc = lc_scan_eval(ctx, scan, pred, d_selection, d_mask_out, d_counts_out, st);
+        float ms = 0;
+        if (rc == LC_OK && (hipEventRecord(b, st) != hipSuccess || hipEventSynchronize(b) != hipSuccess ||
+                            hipEventElapsedTime(&ms, a, b) != hipSuccess))
+            rc = LC_ERR_DEVICE;
+        total += ms;
+    }
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+    (void)hipStreamSynchronize(st);
+    if (d_flush) (void)hipFree(d_flush);
+    if (rc == LC_OK) *out_avg_ms = float(total / iters);
+    return rc;
+}
+
 int32_t lc_calibrate_read(void* ctx_, uint64_t bytes, int32_t shape, int32_t iters) {
     lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
     if (!ctx || bytes < 4096 || iters <= 0) return LC_ERR_INVALID;

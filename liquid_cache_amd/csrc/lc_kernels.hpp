@@ -316,8 +316,6 @@ hipError_t launch_component_lossy(const int32_t* d_comps, uint64_t n, int value_
                                   void* d_out, hipStream_t stream);
 // dst[i] = src[i] for n_words u64 words; either side may be pinned host memory (results of the per-entry calls)
 hipError_t launch_copy_words(void* dst, const void* src, uint64_t n_words, hipStream_t stream);
-// cache flush for cold timings: streams `bytes` of d_buf through the memory-side cache (d_sink: >= 2048 u32)
-hipError_t launch_flush_read(const void* d_buf, uint64_t bytes, uint32_t* d_sink, hipStream_t stream);
 hipError_t launch_mask_compress(const uint64_t* d_src, const uint64_t* d_sel, const uint64_t* d_seg_offsets,
                                 uint32_t n_entries, uint64_t* d_out, uint32_t* d_out_bits, hipStream_t stream);
 hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, const uint64_t* d_right, uint64_t* d_out,

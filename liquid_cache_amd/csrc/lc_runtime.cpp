@@ -2912,72 +2912,6 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
 // Kernel time of ONE evaluation with the memory-side cache flushed before every launch: `flush_bytes` of scratch are
 // READ between launches (the 256 MiB Infinity Cache of MI355X keeps a 150 MB working set resident across
 // back-to-back identical passes, which a hot-cache QUERY over a 100-column table never enjoys).
-lc_status lc_scan_eval_timed_cold(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
-                                  void* d_mask_out, void* d_counts_out, void* stream, int32_t iters, uint64_t flush_bytes,
-                                  float* out_avg_ms) {
-    return guarded([&]() -> lc_status {
-    if (!ctx || !scan || !out_avg_ms || iters <= 0) return fail(LC_ERR_INVALID, "bad iters/out");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    void* d_flush = nullptr;
-    if (flush_bytes) {
-        flush_bytes = std::max<uint64_t>(flush_bytes, 1 << 20);
-        LC_HIP(hipMalloc(&d_flush, flush_bytes + 8192));
-        if (hipMemset(d_flush, 1, flush_bytes + 8192) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-            (void)hipFree(d_flush);
-            return fail(LC_ERR_DEVICE, "flush buffer initialisation failed");
-        }
-    }
-    hipEvent_t a, b;
-    lc_status rc = LC_OK;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipEventCreate");
-    double total = 0;
-    for (int i = 0; i < iters && rc == LC_OK; i++) {
-        // two read passes over the scratch: the memory-side cache ends up holding clean scratch lines only
-        for (int pass = 0; pass < 2 && d_flush && rc == LC_OK; pass++)
-            if (launch_flush_read(d_flush, flush_bytes, reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(d_flush) + flush_bytes),
-                                  st) != hipSuccess)
-                rc = fail(LC_ERR_DEVICE, "flush");
-        if (rc == LC_OK && hipEventRecord(a, st) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipEventRecord");
-        if (rc == LC_OK) rc = scan_eval_impl(ctx, scan, pred, d_selection, d_mask_out, nullptr, d_counts_out, nullptr, st);
-        if (rc == LC_OK && (hipEventRecord(b, st) != hipSuccess || hipEventSynchronize(b) != hipSuccess))
-            rc = fail(LC_ERR_DEVICE, "hipEventRecord/Synchronize");
-        float ms = 0;
-        if (rc == LC_OK && hipEventElapsedTime(&ms, a, b) != hipSuccess) rc = fail(LC_ERR_DEVICE, "hipEventElapsedTime");
-        total += ms;
-    }
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    (void)hipStreamSynchronize(st);
-    if (d_flush) (void)hipFree(d_flush);
-    if (rc == LC_OK) *out_avg_ms = float(total / iters);
-    return rc;
-    });
-}
-
-lc_status lc_scan_eval_timed(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_selection,
-                             void* d_mask_out, void* d_counts_out, void* stream, int32_t iters, float* out_avg_ms) {
-    return guarded([&]() -> lc_status {
-    if (!out_avg_ms || iters <= 0) return fail(LC_ERR_INVALID, "bad iters/out");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipEvent_t a, b;
-    LC_HIP(hipEventCreate(&a));
-    LC_HIP(hipEventCreate(&b));
-    LC_HIP(hipEventRecord(a, st));
-    for (int i = 0; i < iters; i++) {
-        const lc_status rc = scan_eval_impl(ctx, scan, pred, d_selection, d_mask_out, nullptr, d_counts_out, nullptr, st);
-        if (rc != LC_OK) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); return rc; }
-    }
-    LC_HIP(hipEventRecord(b, st));
-    LC_HIP(hipEventSynchronize(b));
-    float ms = 0;
-    LC_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    *out_avg_ms = ms / float(iters);
-    return LC_OK;
-    });
-}
-
 // Host-side form of packed_range()'s constant test for integer / decimal entries: an entry whose FoR range excludes the
 // literal is answered from its metadata and its packed data is never read.
 static bool fixed_entry_is_constant(const Entry& e, const FixedPred& fp) {
