@@ -78,7 +78,10 @@ struct alignas(16) StrDesc {
     uint32_t fsst_len, shared_prefix_len;
     uint32_t symtab_slot;
     uint8_t offset_bytes;
-    uint8_t pad[3];
+    uint8_t multi_empty;           // the dictionary holds MORE than one empty value (values are distinct in the reference's
+                                   // dictionaries, so at most one; staged bytes from elsewhere may differ): k_like_scanall's
+                                   // end-rank -> value arithmetic needs that, such scans keep k_str_pred
+    uint8_t pad[2];
     const uint16_t* postings;      // inverted row lists (see below), or nullptr
 };
 static_assert(sizeof(StrDesc) == 112, "StrDesc layout");
@@ -269,6 +272,10 @@ hipError_t launch_str_automata(const DevSymtab* d_symtabs, uint32_t n_symtabs, c
                                uint32_t needle_len, uint8_t* d_automata, hipStream_t stream);
 hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, const StrPred& pred,
                            const ScanLaunch& L, hipStream_t stream);
+// [NOT] LIKE '%needle%' with many candidates: the whole FSST buffer of every entry streamed once, lane per 8-byte word
+// (lc_like_scanall.hip); d_recs: the scan's workgroup records (<= 4 entries of one symbol table each)
+hipError_t launch_like_scanall(const StrWgRecord* d_recs, uint32_t n_recs, const StrPred& pred, const ScanLaunch& L,
+                               unsigned long long* d_total_acc, hipStream_t stream);
 // per-block selected-row counts -> exclusive offsets, then compaction of decoded values
 // d_block_counts: n_entries*blocks_per_entry u32; d_block_offsets: that + 1 u64; d_entry_row_offsets: n_entries + 1 u64
 // u64 elements the caller provides for d_block_offsets: n_blocks + 1 offsets followed by the scan's tile sums

@@ -1262,7 +1262,7 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
     const LikePipeline* lp = s->like;
     const int path = s->ctx->like_path;
     if (sp.p.mode == 1 && sp.p.needle_len == 1) return "k_str_pred (1-byte needle: no bigram, every fingerprint candidate walked by the many-candidate walkers)";
-    if (path == 1 || s->n < s->ctx->like_pipeline_min_entries) return "k_str_pred";
+    if (path == 1 || path == 5 || s->n < s->ctx->like_pipeline_min_entries) return "k_str_pred";
     if (!lp || !lp->built) return "k_str_pred (scan not evaluated yet)";
     if (!lp->eligible) return "k_str_pred (entries without signature index / row lists)";
     if (path == 3) return "k_like_lean (forced for every needle)";
@@ -1326,7 +1326,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     if (p.mode != 1 || (p.op != LC_OP_LIKE && p.op != LC_OP_NOT_LIKE) || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
         automaton_image_bytes(p.needle_len) == 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
         return LC_OK;
-    if (s->n < ctx->like_pipeline_min_entries || ctx->like_path == 1) return LC_OK;
+    if (s->n < ctx->like_pipeline_min_entries || ctx->like_path == 1 || ctx->like_path == 5) return LC_OK;
     if (!s->like) s->like = new LikePipeline();
     LikePipeline* lp = s->like;
     if (!lp->built) {

@@ -40,6 +40,8 @@ VARIANTS = {"default": {}, "no_signatures": dict(signatures=False), "no_row_list
             # the scan-level 512-bit signature index (k_like_flat) for every needle / never (entry-level index only)
             "flat_every_needle": dict(like_pipeline_min_entries=1, like_path=4),
             "lean_auto": dict(like_pipeline_min_entries=1, like_path=2),
+            # every [NOT] LIKE through the word-streaming many-candidate kernel (k_like_scanall)
+            "scanall_every_needle": dict(like_pipeline_min_entries=1, like_path=5),
             # every batch transcoded ON THE DEVICE (lc_insert_arrow_batch_device: dictionary, FSST, ALP, packing as kernels)
             "device_transcoder": {}}
 
@@ -181,7 +183,7 @@ def fuzz_cases(oracle):
 
 
 @pytest.mark.parametrize("variant", ["default", "pipeline_never", "lean_every_needle", "flat_every_needle", "pipeline_always",
-                                     "no_signatures", "no_row_lists"])
+                                     "scanall_every_needle", "no_signatures", "no_row_lists"])
 def test_fuzz_like_over_many_symbol_tables(product_lib, oracle, fuzz_cases, variant):
     """One scan over 60 entries with 60 different symbol tables (every workgroup record, every K2 chunk of the scan-level
     pipeline sees a different table): LIKE / NOT LIKE with needles cut from the data and from the symbols, with and

@@ -77,7 +77,7 @@ def grouped_cases(oracle):
     return runs
 
 
-@pytest.mark.parametrize("like_path", [4, 0, 3])
+@pytest.mark.parametrize("like_path", [4, 0, 3, 5])
 def test_flat_index_groups_against_oracle(product_lib, oracle, grouped_cases, like_path):
     lo = oracle
     cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1, like_path=like_path or None).build()
@@ -130,6 +130,8 @@ def test_flat_index_groups_against_oracle(product_lib, oracle, grouped_cases, li
             assert how.startswith("k_like_flat"), how
         if like_path == 3:
             assert how.startswith("k_like_lean"), how
+        if like_path == 5:
+            assert how.startswith("k_like_scanall"), how
         scan.close()
     finally:
         cache.close()
