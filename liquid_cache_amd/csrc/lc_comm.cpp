@@ -97,6 +97,8 @@ struct lc_comm {
     size_t shm_bytes = 0;
     std::string shm_name;
     uint32_t local_sense = 0;
+    bool poisoned = false;       // a rank did not arrive in time: the barrier state is no longer consistent — every later
+                                 // collective fails fast instead of hanging or answering from half-written slots
 };
 
 namespace {
@@ -114,6 +116,7 @@ bool spin_until(Cond&& done) {
 }
 
 bool shm_barrier(lc_comm* c) {
+    if (c->poisoned) return false;
     ShmHeader* h = c->shm;
     c->local_sense ^= 1u;
     if (h->barrier_count.fetch_add(1, std::memory_order_acq_rel) + 1 == uint32_t(c->world)) {
@@ -121,7 +124,9 @@ bool shm_barrier(lc_comm* c) {
         h->barrier_sense.store(c->local_sense, std::memory_order_release);
         return true;
     }
-    return spin_until([&] { return h->barrier_sense.load(std::memory_order_acquire) == c->local_sense; });
+    if (spin_until([&] { return h->barrier_sense.load(std::memory_order_acquire) == c->local_sense; })) return true;
+    c->poisoned = true;
+    return false;
 }
 
 }  // namespace
@@ -182,6 +187,7 @@ lc_status lc_comm_init(lc_ctx* ctx, int32_t rank, int32_t world, const uint8_t* 
         c->shm->arrived.fetch_add(1, std::memory_order_acq_rel);
         if (!spin_until([&] { return c->shm->arrived.load(std::memory_order_acquire) >= uint32_t(world); })) {
             munmap(p, c->shm_bytes);
+            shm_unlink(name);  // (whoever gives up removes the name: the ranks that did arrive hold their own mappings)
             return fail(LC_ERR_DEVICE, "shared-memory communicator: not every rank arrived");
         }
         *out = c.release();
@@ -204,9 +210,9 @@ void lc_comm_destroy(lc_comm* c) {
     try {
         if (c->rc) (void)rccl().CommDestroy(c->rc);
         if (c->shm) {
-            (void)shm_barrier(c);
+            const bool clean = shm_barrier(c);  // (fails at once on a poisoned communicator: no 120 s wait for a dead peer)
             munmap(c->shm, c->shm_bytes);
-            if (c->rank == 0) shm_unlink(c->shm_name.c_str());
+            if (c->rank == 0 || !clean) shm_unlink(c->shm_name.c_str());
         }
         delete c;
     } catch (...) {

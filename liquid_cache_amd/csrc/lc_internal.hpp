@@ -111,12 +111,14 @@ struct lc_ctx {
     std::mutex st_mu;
     std::unordered_map<uint64_t, uint32_t> symtab_slot;
     std::vector<std::unique_ptr<lc::SymbolTable>> symtabs;
-    bool build_signatures = true;  // LC_OPT_SIGNATURE_INDEX = 0 disables the bigram index (plain reference layout only)
-    bool signatures_on_host = false;  // LC_OPT_HOST_BUILT_INDEX = 1: build the index on the host (the device builder's oracle)
-    bool like_many_hint = true;  // LC_OPT_LIKE_MANY_HINT (A/B aid): unselective planned needles take k_str_pred's sequential walker
-    int like_path = 0;  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred only, 3 k_like_lean for every needle
-    uint32_t like_pipeline_min_entries = 32;  // LC_OPT_LIKE_PIPELINE_MIN_ENTRIES: smaller scans are not planned (k_str_pred)
-    bool build_postings = true;       // LC_OPT_ROW_LISTS = 0: no inverted row lists (rows always mapped through the keys)
+    // options (lc_ctx_set_option): written under `mu`, read by evaluations and staging calls of other threads without it
+    std::atomic<bool> build_signatures{true};   // LC_OPT_SIGNATURE_INDEX = 0 disables the bigram index (plain reference layout only)
+    std::atomic<bool> signatures_on_host{false};  // LC_OPT_HOST_BUILT_INDEX = 1: build the index on the host (the device builder's oracle)
+    std::atomic<bool> like_many_hint{true};  // LC_OPT_LIKE_MANY_HINT (A/B aid): unselective planned needles take k_str_pred's sequential walker
+    std::atomic<int> like_path{0};  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred, 2 auto without the scan-level index, 3 / 4 / 5 k_like_lean /
+                                    // k_like_flat / k_like_scanall for every needle
+    std::atomic<uint32_t> like_pipeline_min_entries{32};  // LC_OPT_LIKE_PIPELINE_MIN_ENTRIES: smaller scans are not planned (k_str_pred)
+    std::atomic<bool> build_postings{true};       // LC_OPT_ROW_LISTS = 0: no inverted row lists (rows always mapped through the keys)
     lc::DevSymtab* d_symtabs = nullptr;
     size_t d_symtabs_cap = 0;
     size_t d_symtabs_uploaded = 0;

@@ -2126,7 +2126,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         LC_TM(2, 0);
         const uint32_t n_walk = LC_ABL(pred.debug_flags & 1) ? 0u : n_cand;
         for (uint32_t jb = 0; jb < n_walk; jb += kWave) {
-            if (kMany && kSub && tbl_in_lds && n_walk >= uint32_t(kWave)) {
+#ifndef LC_X_MANY_MIN
+#define LC_X_MANY_MIN kWave  // (A/B aid: candidates per pass from which on the sequential walkers take over)
+#endif
+            if (kMany && kSub && tbl_in_lds && n_walk >= uint32_t(LC_X_MANY_MIN)) {
                 // at least a wave of candidates: sequential chains, every lane works through its own share of the list
                 if (!table_cleared) {  // the result table is cleared lazily (LIKE): do it before the first match is set
                     for (uint32_t i = uint32_t(lane); i < dres_bytes / 16u; i += kWave)

@@ -1766,7 +1766,7 @@ static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& item
         e.phys = it.arrow_type;
         e.len = it.n;
         e.nullable = it.has_validity;
-        e.all_null = false;
+        e.all_null = st.d == 0 && it.n > 0;  // (as build_str: an array of nulls only has no dictionary)
         e.W = 16;
         e.path_id = it.path_id;
         e.dict_len = st.d;
@@ -1900,10 +1900,6 @@ lc_status lc_insert_arrow_batch_device(lc_ctx* ctx, uint64_t n_all, const uint64
             schemas_v.push_back(s);
         }
     }
-    {
-        const lc_status rc = device_encode_byte_views(ctx, views);
-        if (rc != LC_OK) return rc;
-    }
     const uint64_t n = entry_ids_v.size();
     const uint64_t* entry_ids = entry_ids_v.data();
     const struct ArrowArray* const* arrays = arrays_v.data();
@@ -1947,6 +1943,12 @@ lc_status lc_insert_arrow_batch_device(lc_ctx* ctx, uint64_t n_all, const uint64
             it.in_validity = align_up(stage_bytes, 16);
             stage_bytes = it.in_validity + ((size_t(it.n) + 63) / 64) * 8;
         }
+    }
+    {
+        // every array of the call has been classified and validated by now: a call that is going to answer LC_UNSUPPORTED /
+        // LC_ERR_INVALID for one of its arrays has published nothing (round-3 advisor finding)
+        const lc_status rc = device_encode_byte_views(ctx, views);
+        if (rc != LC_OK) return rc;
     }
     if (n == 0) return LC_OK;
     stage_bytes = align_up(stage_bytes, 256);
@@ -4019,13 +4021,17 @@ static lc_status squeeze_float_quantize(lc_ctx* ctx, const std::vector<uint64_t>
         if (n_take == 0) continue;
         total = align_up(total, kSectionAlign) + 256;
         ArenaReservation reserved(ctx);
-        std::unique_lock<std::shared_mutex> g(ctx->mu);
         uint8_t* dbase = nullptr;
         int slab = -1;
-        rc = arena_alloc(ctx, total, &dbase, &slab);
-        if (rc != LC_OK) return rc;
-        ctx->slabs[size_t(slab)].live += int64_t(n_take) - 1;
-        reserved.arm(slab, int64_t(n_take));
+        {
+            // the cache lock is held for the allocation and (below) for the publication only — not across the copies, the
+            // pack kernel and the wait for them, which would stall every concurrent scan creation, stage and evict
+            std::unique_lock<std::shared_mutex> g(ctx->mu);
+            rc = arena_alloc(ctx, total, &dbase, &slab);
+            if (rc != LC_OK) return rc;
+            ctx->slabs[size_t(slab)].live += int64_t(n_take) - 1;
+            reserved.arm(slab, int64_t(n_take));
+        }
         LC_HIP(hipMemsetAsync(dbase, 0, total, nullptr));
         std::vector<EncodeDesc> pack;
         for (uint64_t i = 0; i < m; i++) {
@@ -4048,8 +4054,20 @@ static lc_status squeeze_float_quantize(lc_ctx* ctx, const std::vector<uint64_t>
         LC_HIP(hipMemcpy(d_enc, pack.data(), pack.size() * sizeof(EncodeDesc), hipMemcpyHostToDevice));
         LC_HIP(launch_fl_pack(d_enc, uint32_t(pack.size()), max_rows, scan->lane_log2, nullptr));
         LC_HIP(hipStreamSynchronize(nullptr));
+        std::unique_lock<std::shared_mutex> g(ctx->mu);
+        uint64_t n_published = 0;
         for (uint64_t i = 0; i < m; i++) {
             if (!lay[i].take) continue;
+            {
+                // an id that was re-staged or evicted since the scan captured it keeps what is there now: the quantized form
+                // was built from the captured entry (its share of the slab reservation is given back)
+                auto cur = ctx->entries.find(ids[i]);
+                if (cur == ctx->entries.end() || cur->second.uid != scan->meta[i].uid) {
+                    arena_release(ctx, slab);
+                    continue;
+                }
+            }
+            n_published++;
             Entry e = scan->meta[i];  // type, length, ALP exponents, reference stay
             e.fd.mask_word_off = 0;
             e.orig_W = e.W;
@@ -4067,7 +4085,7 @@ static lc_status squeeze_float_quantize(lc_ctx* ctx, const std::vector<uint64_t>
             publish_entry(ctx, ids[i], std::move(e));
         }
         reserved.disarm();
-        if (out_done) *out_done += n_take;
+        if (out_done) *out_done += n_published;
     }
     return LC_OK;
 }
