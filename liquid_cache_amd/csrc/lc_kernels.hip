@@ -519,7 +519,8 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
 //   u32 lanes (32 per block): thread = (block A|B of a pair, lane); step r gives bits [32*(r>>4), +32) of word
 //                             2*(r&7) + ((r>>3)&1) of block A in the low half of the ballot and of block B in the high half
 //   u16 lanes (64 per block): thread = lane; step r gives word 2*(r&7) + (r>>3) whole
-//   u64 lanes (16 per block): thread = (q, lane); q owns rows 16*{0,2,1,3}[q] .. +15; step r' gives word 2*(r'&7) + (r'>>3)
+//   u64 lanes (16 per block): thread = (block A|B, h, lane), h owns rows 32 h .. +31 of its lane, read as whole u64 words;
+//                             the ballots follow the u32 rule (load_stream64)
 // 4-5 issue slots per 64 rows.  A pass covers two blocks; their 32 mask words are parked in lanes 0..31 and combined with
 // selection & validity once per pass.  Constant outcomes (literal outside the entry's FoR range) still skip the packed data.
 // ------------------------------------------------------------------------------------------------
@@ -563,7 +564,7 @@ __device__ __forceinline__ void reg_steps32(std::integer_sequence<uint32_t, RS..
                                             uint32_t bound_t, uint32_t& X, uint32_t& Y) {
     (reg_step32<W, kTwoSided, P, RS, NW>(w, lo_t, bound_t, X, Y), ...);
 }
-// u16 / u64 lanes: one step = one whole 64-row word of block B of the pass (its words are parked in lanes 16*B ..)
+// u16 lanes: one step = one whole 64-row word of block B of the pass (its words are parked in lanes 16*B ..)
 template <int W, bool kTwoSided, uint32_t B, uint32_t R, int NW>
 __device__ __forceinline__ void reg_step16(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t bound_t, uint32_t& X, uint32_t& Y) {
     const uint64_t b = range_ballot<kTwoSided>(field_top<W, R, NW>(w), lo_t, bound_t);
@@ -577,39 +578,43 @@ __device__ __forceinline__ void reg_steps16(std::integer_sequence<uint32_t, RS..
     (reg_step16<W, kTwoSided, B, RS, NW>(w, lo_t, bound_t, X, Y), ...);
 }
 
-// the thread's 16-row bit stream of one block on u16 / u64 lanes
+// the thread's 16-row bit stream of one block on u16 lanes: u16 word j of lane l at j*128 + 2l; two of them make one dword
 template <typename U, int W, int NW>
 __device__ __forceinline__ void load_stream16(const uint8_t* base, int lane, uint32_t (&w)[NW]) {
-    if constexpr (LaneTraits<U>::kBits == 16) {
-        // u16 word j of lane l at j*128 + 2l; two of them make one dword of the stream
-        const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + uint32_t(lane);
+    static_assert(LaneTraits<U>::kBits == 16, "u16 lanes");
+    const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + uint32_t(lane);
 #pragma unroll
-        for (int k = 0; k < NW; k++) {
-            const uint32_t x = as_global(p)[(2 * k) * 64];
-            const uint32_t y = (2 * k + 1 < W) ? uint32_t(as_global(p)[(2 * k + 1) * 64]) : 0u;
-            w[k] = x | (y << 16);
-        }
-    } else {
-        // u64 lanes: thread (q, l) owns rows 16*g .. 16*g+15 of lane l, g = {0,2,1,3}[q]: bits [16*g*W, +16*W) of the
-        // lane's stream of u64 words (word j at j*128 + 8l), read as dwords
-        const uint32_t q = uint32_t(lane) >> 4, l = uint32_t(lane) & 15u;
-        const uint32_t g = ((q & 1u) << 1) | (q >> 1);
-        const uint32_t bit0 = 16u * g * uint32_t(W);
-        const uint32_t d0 = bit0 >> 5;  // first dword of the thread's stream; dword i of a lane's stream is half (i & 1)
-                                        // of u64 word i >> 1, i.e. at byte (i >> 1) * 128 + (i & 1) * 4
-        // two per-thread bases so that every load has a compile-time offset whatever the parity of d0:
-        //   d0 even: dword d0+k at base + (k>>1)*128 + (k&1)*4;   d0 odd: the same + 4 (k even) or + 124 (k odd)
-        const uint8_t* b0 = base + l * 8u + (d0 >> 1) * 128u + (d0 & 1u) * 4u;
-        const uint32_t* pe = reinterpret_cast<const uint32_t*>(b0);
-        const uint32_t* po = reinterpret_cast<const uint32_t*>(b0 + (d0 & 1u) * 120u);
+    for (int k = 0; k < NW; k++) {
+        const uint32_t x = as_global(p)[(2 * k) * 64];
+        const uint32_t y = (2 * k + 1 < W) ? uint32_t(as_global(p)[(2 * k + 1) * 64]) : 0u;
+        w[k] = x | (y << 16);
+    }
+}
+
+// u64 lanes (16 per block, 64 rows per lane) evaluated in the shape of u32 lanes: thread = (block A|B of a pair, h, lane),
+// h owns rows 32 h .. 32 h + 31 of its lane's stream — dwords [h W, h W + W) of the lane's W u64 words (word j of lane l at
+// j * 128 + 8 l).  Read as whole u64 words: 16 lanes x 8 bytes are one 128-byte line, so a load instruction touches four
+// lines once each (as dwords every line was requested by two instructions and the L3-cold scan of a W = 17 column took
+// 57 us instead of 47).  For odd W the upper half starts on the high dword of a word: one select per dword.
+// With lane = 32 block + 16 h + l the ballot of step r holds bits [32 (r >> 4), +32) of mask word 2 (r & 7) + ((r >> 3) & 1)
+// of block A in its low half and of block B in its high half — the u32-lane rule (reg_step32), because the FastLanes order
+// puts the rows 16 g .. 16 g + 15 of every lane at bits 16 {0,2,1,3}[g] of the word.
+template <int W, int NW>
+__device__ __forceinline__ void load_stream64(const uint8_t* base, uint32_t lane32, uint32_t (&w)[NW]) {
+    static_assert(NW == W + (W & 1), "odd widths carry one more dword (the upper half starts on the high dword of a word)");
+    const uint32_t h = lane32 >> 4, l = lane32 & 15u;
+    const uint64_t* p = reinterpret_cast<const uint64_t*>(base + l * 8u + h * uint32_t(W / 2) * 128u);
 #pragma unroll
-        for (int k = 0; k < NW; k++) w[k] = (k & 1) ? as_global(po)[(k >> 1) * 32 + 1] : as_global(pe)[(k >> 1) * 32];
-        if constexpr (W & 1) {  // odd widths: the 16-row groups start on a 16-bit boundary
-            const uint32_t bo = bit0 & 31u;
+    for (int m = 0; m < NW / 2; m++) {
+        const uint64_t v = as_global(p)[m * 16];
+        w[2 * m] = uint32_t(v);
+        w[2 * m + 1] = uint32_t(v >> 32);
+    }
+    if constexpr (W & 1) {
+        // in place, and a bit select (not `h ? w[k + 1] : w[k]`, which the compiler turns into w[k + h]: an array in scratch)
+        const uint32_t up = 0u - h;
 #pragma unroll
-            for (int k = 0; k + 1 < NW; k++) w[k] = __builtin_amdgcn_alignbit(w[k + 1], w[k], bo);
-            w[NW - 1] >>= bo;  // its last 16 stream bits
-        }
+        for (int k = 0; k < W; k++) asm("v_bfi_b32 %0, %1, %2, %0" : "+v"(w[k]) : "v"(up), "v"(w[k + 1]));
     }
 }
 
@@ -639,8 +644,9 @@ __device__ __forceinline__ const uint8_t* uniform_ptr(const void* p) {
 template <typename U, int W, bool kTwoSided>
 __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     constexpr uint32_t TB = LaneTraits<U>::kBits;
-    // dwords of the thread's stream: u32 lanes hold all 32 rows of their lane, u16 / u64 threads hold 16 rows
-    constexpr int NW = TB == 32 ? W : (16 * W + 31) / 32;
+    // dwords of the thread's stream: u32 / u64 threads hold 32 rows of their lane, u16 threads 16
+    constexpr bool k32 = TB != 16;  // u32 lanes, and u64 lanes in their shape (load_stream64)
+    constexpr int NW = TB == 64 ? W + (W & 1) : (TB == 32 ? W : (16 * W + 31) / 32);
     const int lane = lane_id();
     // arguments arrive in vector registers; they are wave uniform
     const uint8_t* packed = uniform_ptr(a.packed);
@@ -676,14 +682,20 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     constexpr uint32_t kPairs = W <= LC_X_PAIRW ? 2u : 1u;
     constexpr uint32_t kPassBlocks = 2u * kPairs;
     constexpr uint32_t kPassWords = 16u * kPassBlocks;     // mask words of a pass: lanes 0 .. kPassWords-1 own one each
-    constexpr int kSets = (TB == 32 ? 1 : 2) * int(kPairs);  // register sets of a pass (u32: both blocks of a pair in one set)
+    constexpr int kSets = (k32 ? 1 : 2) * int(kPairs);  // register sets of a pass (u32 / u64: both blocks of a pair in one set)
     // Software pipeline over the passes of an entry (u32 lanes, widths whose two register sets fit the kernel's budget).
     // Unpipelined, an entry is 8 dependent round trips (per pass: selection / validity words, then the packed words) with
     // ~175 instructions between them; pipelined, three stages are in flight: the selection / validity words of pass p + 2,
     // the packed words of pass p + 1 and the compares of pass p (two register sets, ping-pong).  The loads of a pass are
     // unconditional — a wave-uniform branch around them would make the compiler wait for ALL outstanding loads at the
     // join — so a pass without a selected valid row reads block 0 of the entry (cached) instead of its own blocks.
-    constexpr bool kPipe = LC_X_PIPE != 0 && (TB == 32 || LC_X_PIPE_ALL != 0) && kSets * NW <= LC_X_PIPE_REGS;
+    // (u64 lanes in the same shape: measured with 12 / 18 / 32 registers per pass pipelined — Int64 W = 17 52.1-56.0 us cold
+    // against 52.4 without, Decimal W = 4 25.6 against 25.4 — so they stay unpipelined)
+#ifndef LC_X_PIPE_REGS64
+#define LC_X_PIPE_REGS64 0
+#endif
+    constexpr bool kPipe = LC_X_PIPE != 0 && (k32 || LC_X_PIPE_ALL != 0) &&
+                           kSets * NW <= (TB == 64 ? LC_X_PIPE_REGS64 : LC_X_PIPE_REGS);
     if constexpr (kPipe) {
         struct PassWords { uint32_t w[kSets][NW]; };
         auto load_pass = [&](PassWords& pw, uint32_t blk0, uint64_t am) {
@@ -694,7 +706,11 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
             const uint8_t* base1 = go1 ? packed + uint64_t(blk0 + 2u) * 128u * uint32_t(W) : packed;
             const uint32_t off0 = (go0 && blk0 + 1u < nblocks) ? 128u * uint32_t(W) : 0u;
             const uint32_t off1 = (go1 && blk0 + 3u < nblocks) ? 128u * uint32_t(W) : 0u;
-            if constexpr (TB == 32) {
+            if constexpr (TB == 64) {
+                const uint32_t half = uint32_t(lane) >> 5, l = uint32_t(lane) & 31u;
+                load_stream64<W, NW>(base0 + half * off0, l, pw.w[0]);
+                if constexpr (kPairs > 1) load_stream64<W, NW>(base1 + half * off1, l, pw.w[1]);
+            } else if constexpr (TB == 32) {
                 // word k of FastLanes lane l of block A|B of a pair: one 128-byte line per block and k
                 const uint32_t half = uint32_t(lane) >> 5, l = uint32_t(lane) & 31u;
                 {
@@ -719,7 +735,7 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
         auto compute_pass = [&](const PassWords& pw, uint64_t am) -> uint64_t {
             const bool go0 = uint32_t(am) != 0 || (kPairs == 1 && am != 0), go1 = kPairs > 1 && uint32_t(am >> 32) != 0;
             uint32_t X = 0, Y = 0;
-            if constexpr (TB == 32) {
+            if constexpr (k32) {
                 if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, pw.w[0], lo_t, bound_t, X, Y);
                 if constexpr (kPairs > 1) {
                     __builtin_amdgcn_sched_barrier(0);  // keep the second pair's steps from being hoisted (register pressure)
@@ -822,20 +838,28 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
                     const uint32_t off0 = (blk0 + 1u < nblocks) ? 128u * uint32_t(W) : 0u;
                     const uint32_t off1 = (blk0 + 3u < nblocks) ? 128u * uint32_t(W) : 0u;
                     uint32_t X = 0, Y = 0;
-                    if constexpr (TB == 32) {
+                    if constexpr (k32) {
                         // word k of FastLanes lane l of block A|B of a pair: one 128-byte line per block and k
                         uint32_t w0[NW], w1[NW];
                         const uint32_t half = uint32_t(lane) >> 5, l = uint32_t(lane) & 31u;
                         if (go0) {
-                            const uint32_t* p = reinterpret_cast<const uint32_t*>(base0 + half * off0) + l;
+                            if constexpr (TB == 64) {
+                                load_stream64<W, NW>(base0 + half * off0, l, w0);
+                            } else {
+                                const uint32_t* p = reinterpret_cast<const uint32_t*>(base0 + half * off0) + l;
     #pragma unroll
-                            for (int k = 0; k < NW; k++) w0[k] = as_global(p)[k * 32];
+                                for (int k = 0; k < NW; k++) w0[k] = as_global(p)[k * 32];
+                            }
                         }
                         if constexpr (kPairs > 1) {
                             if (go1) {
-                                const uint32_t* p = reinterpret_cast<const uint32_t*>(base1 + half * off1) + l;
+                                if constexpr (TB == 64) {
+                                    load_stream64<W, NW>(base1 + half * off1, l, w1);
+                                } else {
+                                    const uint32_t* p = reinterpret_cast<const uint32_t*>(base1 + half * off1) + l;
     #pragma unroll
-                                for (int k = 0; k < NW; k++) w1[k] = as_global(p)[k * 32];
+                                    for (int k = 0; k < NW; k++) w1[k] = as_global(p)[k * 32];
+                                }
                             }
                         }
                         if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, w0, lo_t, bound_t, X, Y);
@@ -929,6 +953,9 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
     uint64_t wave_hits = 0;
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
+        // (measured and dropped: the next entry's descriptor fetched ahead — no change — and the whole entry requested at
+        // once through an LDS scratch line so that the passes hit in L2: Date32 W = 12 36 -> 45 us cold, 29 -> 41 hot; the
+        // second trip of every line through the L2 -> CU fabric costs more than the HBM latency it hides)
         const FixedDesc d = descs[entry];
         const uint32_t c = fixed_pred_entry_step<U, kMaxW>(d, pred, pred2,
                                                            L.d_selection ? L.d_selection + d.mask_word_off : nullptr,

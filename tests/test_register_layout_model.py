@@ -64,33 +64,39 @@ def test_u16_lanes(oracle, W):
     _check(vals, threads, lambda l, r: (2 * (r & 7) + (r >> 3), l), 16, W)
 
 
-@pytest.mark.parametrize("W", [1, 2, 3, 4, 5, 12, 13, 15, 16, 20, 22, 29, 31, 32])
+@pytest.mark.parametrize("W", [1, 2, 3, 4, 5, 12, 13, 15, 16, 17, 20, 22, 29, 31, 32])
 def test_u64_lanes(oracle, W):
+    """u64 lanes in the shape of u32 lanes (load_stream64): thread (h, l) of a block owns rows 32 h .. 32 h + 31 of lane l,
+    read as whole u64 words; odd widths select the upper dword for h = 1."""
     rng = np.random.default_rng(200 + W)
     vals = rng.integers(0, 1 << W, size=1024, dtype=np.uint64)
     raw = oracle.bitpack(vals, W)
-    nw = (16 * W + 31) // 32
 
-    def dword_at(byte_off):  # a 4-byte global load
-        assert 0 <= byte_off and byte_off + 4 <= raw.size, "load outside the block"
-        return int(raw[byte_off:byte_off + 4].view(np.uint32)[0])
+    def qword_at(byte_off):  # an 8-byte global load
+        assert 0 <= byte_off and byte_off + 8 <= raw.size, "load outside the block"
+        return int(raw[byte_off:byte_off + 8].view(np.uint64)[0])
 
     threads = {}
-    for lane in range(64):
-        q, l = lane >> 4, lane & 15
-        g = ((q & 1) << 1) | (q >> 1)
-        bit0 = 16 * g * W
-        d0 = bit0 >> 5
-        b0 = l * 8 + (d0 >> 1) * 128 + (d0 & 1) * 4
-        pe, po = b0, b0 + (d0 & 1) * 120
-        w = [dword_at(po + ((k >> 1) * 32 + 1) * 4) if (k & 1) else dword_at(pe + (k >> 1) * 128) for k in range(nw)]
-        if W & 1:
-            bo = bit0 & 31
-            for k in range(nw - 1):
-                w[k] = alignbit(w[k + 1], w[k], bo)
-            w[nw - 1] >>= bo
-        threads[lane] = w
-    _check(vals, threads, lambda t, r: (2 * (r & 7) + (r >> 3), t), 16, W)
+    for lane32 in range(32):  # block A of the pair; block B runs the same code on its own 128*W bytes
+        h, l = lane32 >> 4, lane32 & 15
+        if W % 2 == 0:
+            base = l * 8 + h * (W // 2) * 128
+            d = []
+            for m in range(W // 2):
+                v = qword_at(base + m * 128)
+                d += [v & M32, v >> 32]
+            w = d
+        else:
+            nq = (W + 1) // 2
+            base = l * 8 + h * ((W - 1) // 2) * 128
+            d = []
+            for m in range(nq):
+                v = qword_at(base + m * 128)
+                d += [v & M32, v >> 32]
+            w = [d[k + 1] if h else d[k] for k in range(W)]
+        threads[lane32] = w
+    # the u32-lane rule: step r -> bits [32 (r >> 4), +32) of word 2 (r & 7) + ((r >> 3) & 1); bit = 32 (r >> 4) + 16 h + l
+    _check(vals, threads, lambda t, r: (2 * (r & 7) + ((r >> 3) & 1), 32 * (r >> 4) + t), 32, W)
 
 
 def test_top_aligned_range_compare_is_the_masked_compare():
