@@ -226,6 +226,7 @@ void scan_note_stream(lc_scan* s, hipStream_t stream);   // read-only use of the
 struct StrPredHost {
     StrPred p{};
     std::vector<uint8_t> needle;
+    std::vector<uint8_t> verify;  // p.verify_len != 0: the literal pattern the accepted values are matched against
 };
 lc_status make_str_pred(const lc_predicate* p, StrPredHost* out);
 

@@ -2329,6 +2329,27 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 
+    if (kSub && !kSigOnly && pred.verify_len != 0 && any_true != 0) {
+        // a needle the automaton cannot hold (over 63 bytes): what it accepted contains the needle's first 63 bytes; those
+        // (few) dictionary values are now matched against the whole pattern
+        uint64_t still = 0;
+        for (uint32_t i0 = 0; i0 < dp->d; i0 += kWave) {
+            const uint32_t i = i0 + uint32_t(lane);
+            bool hit = i < dp->d && (kBytes ? dresb[i] != 0 : ((dres[i >> 5] >> (i & 31)) & 1u) != 0);
+            if (hit) {
+                uint32_t start, stop;
+                str_offset_pair(*dp, i, start, stop);
+                hit = like_generic(st, dp->fsst, start, stop, pred.needle, pred.verify_len);
+                if (!hit) {
+                    if (kBytes) dresb[i] = 0;
+                    else atomicAnd(&dres[i >> 5], ~(1u << (i & 31)));
+                }
+            }
+            still |= __ballot(hit);
+        }
+        any_true = still;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
     LC_TM(7, 0);
     if (kCoop) {
         coop_state = any_true != 0 ? 2u : 0u;
@@ -4165,7 +4186,7 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
     // the headline case: LIKE, every entry carries signatures, needle automaton in LDS, one wave per entry (records)
     const bool records = !persistent_env() && L.d_wg_ranges && L.n_wg_ranges <= kWorkGroupsMax;
     const bool sig_only = records && sub && !many && !instr && lds_tbl && pred.use_fingerprints && pred.n_sig_bits > 0 &&
-                          pred.op == LC_OP_LIKE;
+                          pred.op == LC_OP_LIKE && pred.verify_len == 0;
     const size_t cand_cap = sig_only ? kCandCapSigOnly : (many ? kCandCapMany : kCandCap);
     const size_t dyn_lds = tbl_bytes + 256 +
                            size_t(kWavesPerBlock) * (size_t(dres_bytes) + cmask_bytes + cand_cap * 2 + 80 + (sig_only ? kPostLdsBytes : 0u) +

@@ -27,8 +27,10 @@
 namespace lc {
 
 constexpr int kMaxNeedleAutomaton = 63;  // KMP automaton states must fit a u8 table
-constexpr uint32_t kMaxLdsNeedle = 47;   // needles up to this length also get an LDS image of the automaton (48 KB at 47:
-                                         // u16 row addresses reach 64 KB)
+constexpr uint32_t kMaxLdsNeedle = 63;   // every automaton needle gets an LDS image: (m + 1) KB at LDS address 0, u16 row
+                                         // addresses (the last row of a 63-byte needle starts at 65,024); above 47 bytes a
+                                         // workgroup's LDS passes the default 64 KB (launches raise the limit: gfx950 gives
+                                         // a workgroup up to 160 KB)
 // Per symbol table, k_str_automata emits: the u8 next-state table ((m+1) x 512 bytes) and, for short needles, the
 // image the scan kernel copies verbatim to LDS address 0: 2 (m+1) rows x 256 u16 entries holding the LDS byte address
 // of the next state's row (rows 0..m: next byte is a code; rows m+1..2m+1: next byte is an escaped literal).
@@ -213,6 +215,11 @@ struct StrPred {
     // say "yandex.ru", which 45 % of the values of a URL column contain).
     uint32_t n_sig_wide;
     uint16_t sig_wide[kMaxSigProbeWide];
+    // mode 1, needles over kMaxNeedleAutomaton bytes: the automaton runs over the needle's FIRST kMaxNeedleAutomaton bytes
+    // (needle_len says so) — a necessary condition like the prefilters, whose bits come from the whole needle — and the
+    // dictionary values it accepts are then matched exactly against the pattern (`needle`: the literal '%...%', verify_len
+    // bytes, device copy).  0: the automaton's answer is exact.
+    uint32_t verify_len;
     uint8_t needle_inline[kInlineNeedle];
 };
 

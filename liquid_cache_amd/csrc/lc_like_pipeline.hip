@@ -462,6 +462,11 @@ hipError_t launch_lean(int n_sig, bool negated, const LeanArgs& a, uint32_t n_re
          k_like_lean<6, true>, k_like_lean<7, true>, k_like_lean<8, true>}};
     const size_t lds = automaton_image_bytes(a.nl) + kLeanWaves * (kLeanE * (kPostMaxRows / 8u) + kLeanCap * 4u + 80u);
     const uint32_t grid = LC_LEAN_XCD ? (n_recs + 7u) / 8u * 8u : n_recs;
+    if (lds > 64 * 1024) {  // needles of 48-63 bytes: the image alone is 49-64 KB
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(table[negated ? 1 : 0][n_sig - 1]),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(table[negated ? 1 : 0][n_sig - 1], dim3(grid), dim3(kLeanWaves * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -887,6 +892,11 @@ hipError_t launch_flat(int n_sig, bool negated, const FlatArgs& a, hipStream_t s
     const size_t lds = automaton_image_bytes(a.nl) + kFlatWaves * (kFlatMaxE * (kPostMaxRows / 8u) + kFlatMaxE * 64u + kFlatCap * 4u + 80u);
     const uint32_t wgs = (a.n_slots + kFlatWaves - 1u) / kFlatWaves;
     const uint32_t grid = (wgs + 7u) / 8u * 8u;
+    if (lds > 64 * 1024) {  // needles of 48-63 bytes: the image alone is 49-64 KB
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(table[negated ? 1 : 0][n_sig - 1]),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(table[negated ? 1 : 0][n_sig - 1], dim3(grid), dim3(kFlatWaves * 64), lds, stream, a);
     return hipGetLastError();
 }
@@ -1262,6 +1272,7 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
     const LikePipeline* lp = s->like;
     const int path = s->ctx->like_path;
     if (sp.p.mode == 1 && sp.p.needle_len == 1) return "k_str_pred (1-byte needle: no bigram, every fingerprint candidate walked by the many-candidate walkers)";
+    if (sp.p.mode == 1 && sp.p.verify_len != 0) return "k_str_pred (needle over 63 bytes: automaton over its first 63, accepted values matched against the pattern)";
     if (path == 1 || path == 5 || s->n < s->ctx->like_pipeline_min_entries) return "k_str_pred";
     if (!lp || !lp->built) return "k_str_pred (scan not evaluated yet)";
     if (!lp->eligible) return "k_str_pred (entries without signature index / row lists)";
@@ -1291,7 +1302,7 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
 // Caller holds s->mu.
 uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts) {
     const LikePipeline* lp = s->like;
-    if (!lp || !lp->eligible || s->ctx->like_path == 1) return 0;
+    if (!lp || !lp->eligible || s->ctx->like_path == 1 || sp.p.verify_len != 0) return 0;
     for (const LikePlan& q : lp->plans)
         if (q.needle == sp.needle && (q.use_lean || s->ctx->like_path == 3 || s->ctx->like_path == 4)) {
             if (lp->flat && (s->ctx->like_path == 0 || s->ctx->like_path == 4)) {
@@ -1323,8 +1334,9 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     // that occurs in the column is most of every dictionary (the many-candidate kernel falls back to the lane-parallel
     // walk by itself for an entry with less than a wave of candidates)
     if (p.mode == 1 && p.needle_len == 1 && (p.op == LC_OP_LIKE || p.op == LC_OP_NOT_LIKE)) *many_candidates = true;
+    // (needles over 63 bytes: their matches are verified against the whole pattern, which k_str_pred does)
     if (p.mode != 1 || (p.op != LC_OP_LIKE && p.op != LC_OP_NOT_LIKE) || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
-        automaton_image_bytes(p.needle_len) == 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
+        automaton_image_bytes(p.needle_len) == 0 || p.verify_len != 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
         return LC_OK;
     if (s->n < ctx->like_pipeline_min_entries || ctx->like_path == 1 || ctx->like_path == 5) return LC_OK;
     if (!s->like) s->like = new LikePipeline();

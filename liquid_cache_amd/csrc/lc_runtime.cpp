@@ -714,11 +714,11 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
     } else if (p->op == LC_OP_LIKE || p->op == LC_OP_NOT_LIKE) {
         const uint8_t* inner;
         size_t il;
-        if (!substring_pattern(lit, ll, &inner, &il) || il > size_t(kMaxNeedleAutomaton)) {
-            // general pattern (prefix / suffix / `_` / several parts), or a needle too long for the folded automaton:
-            // Arrow `like` on every dictionary value.  The reference only gets here for entries WITHOUT fingerprints
-            // (with them it `expect()`s a %needle% pattern, comparisons.rs:150-166); the caller checks that.
-            if (ll > size_t(kMaxNeedleBytes)) return fail(LC_UNSUPPORTED, "LIKE pattern longer than 4096 bytes");
+        if (ll > size_t(kMaxNeedleBytes)) return fail(LC_UNSUPPORTED, "LIKE pattern longer than 4096 bytes");
+        if (!substring_pattern(lit, ll, &inner, &il)) {
+            // general pattern (prefix / suffix / `_` / several parts): Arrow `like` on every dictionary value.  The reference
+            // only gets here for entries WITHOUT fingerprints (with them it `expect()`s a %needle% pattern,
+            // comparisons.rs:150-166); the caller checks that.
             out->p.mode = 3;
             out->needle.assign(lit, lit + ll);
 #ifdef LC_ABLATION
@@ -731,7 +731,14 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out) {
         }
         out->p.mode = 1;
         out->p.use_fingerprints = 1;
-        out->needle.assign(inner, inner + il);
+        // needles the folded automaton cannot hold: it runs over their first kMaxNeedleAutomaton bytes and the (very few)
+        // dictionary values it accepts are matched exactly against the pattern; fingerprint and bigram bits are those of the
+        // whole needle (comparisons.rs:598-651 computes the same: prefilter, then memmem of the needle)
+        out->needle.assign(inner, inner + std::min(il, size_t(kMaxNeedleAutomaton)));
+        if (il > size_t(kMaxNeedleAutomaton)) {
+            out->verify.assign(lit, lit + ll);
+            out->p.verify_len = uint32_t(ll);
+        }
         for (size_t k = 0; k < il; k++) out->p.needle_fp |= 1u << (inner[k] & 31);
         // bigram positions in an order that covers the needle evenly at every prefix: both ends, then midpoints of the
         // remaining gaps, breadth first
@@ -2601,6 +2608,19 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         }
         sp.p.automata = s->d_automata;
         sp.p.automaton_stride = stride;
+    }
+    if (sp.p.mode == 1 && sp.p.verify_len != 0) {
+        const size_t need = sp.verify.size() + 16;
+        LC_HIP(hipStreamSynchronize(stream));  // previous evaluation may still read the old pattern
+        if (need > s->needle_cap) {
+            pool_release(ctx, s->d_needle);
+            s->d_needle = static_cast<uint8_t*>(pool_alloc(ctx, need));
+            if (!s->d_needle) { s->needle_cap = 0; return fail(LC_ERR_OOM, "hipMalloc (needle)"); }
+            s->needle_cap = need;
+        }
+        LC_HIP(hipMemcpyAsync(s->d_needle, sp.verify.data(), sp.verify.size(), hipMemcpyHostToDevice, stream));
+        LC_HIP(hipStreamSynchronize(stream));  // (`sp` is a local)
+        sp.p.needle = s->d_needle;
     } else if ((sp.p.mode == 0 || sp.p.mode == 3) && sp.needle.size() > size_t(kInlineNeedle)) {
         const size_t need = sp.needle.size() + 16;
         LC_HIP(hipStreamSynchronize(stream));  // previous evaluation may still read the old needle
@@ -2623,7 +2643,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         if (many && ctx->like_many_hint) L.many_candidates = 1;
         // many candidates (no signature index, no fingerprints, a 1-byte or an unselective needle): the whole FSST buffer of
         // every entry streamed once, lane per word (k_like_scanall) instead of a chain per value
-        const bool scanall_ok = (sp.p.op == LC_OP_LIKE || sp.p.op == LC_OP_NOT_LIKE) && sp.p.needle_len >= 1 &&
+        const bool scanall_ok = (sp.p.op == LC_OP_LIKE || sp.p.op == LC_OP_NOT_LIKE) && sp.p.needle_len >= 1 && sp.p.verify_len == 0 &&
                                 automaton_image_bytes(sp.p.needle_len) != 0 && !L.d_cand_bytes && !L.d_own_bytes &&
                                 !s->any_multi_empty && ctx->like_path != 1 && s->n_wg_ranges > 0;
         // Where it is used (measured, 100 M-row URL column): every value walked — columns staged without fingerprints — 582 us
