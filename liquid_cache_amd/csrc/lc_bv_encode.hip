@@ -263,7 +263,7 @@ __global__ __launch_bounds__(kBvThreads) void k_bv_build(const BvEncodeDesc* __r
 
 // ---------------------------------------------------------------------------------------------------------------- pack
 __global__ __launch_bounds__(kBvThreads) void k_bv_pack(const BvEncodeDesc* __restrict__ descs, const BvPackDesc* __restrict__ packs) {
-    __shared__ uint32_t pairs[kPostMaxRows];
+    __shared__ uint32_t pairs[kPostLdsRows];
     const BvEncodeDesc& a = descs[blockIdx.x];
     const BvPackDesc& o = packs[blockIdx.x];
     const uint32_t tid = threadIdx.x, n = a.n, d = o.d;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(kBvThreads) void k_bv_pack(const BvEncodeDesc* __re
     // ---- inverted row lists: (key, row) pairs of the valid rows sorted, invalid rows last
     if (!o.postings) return;
     uint32_t N = 64;
-    while (N < n) N <<= 1;  // n <= kPostMaxRows (the runtime only asks for lists then)
+    while (N < n) N <<= 1;  // n <= kPostLdsRows (the runtime only asks for lists then)
     for (uint32_t i = tid; i < N; i += kBvThreads) {
         uint32_t v = 0xFFFFFFFFu;
         if (i < n && row_valid(a.validity, i)) v = (uint32_t(a.keys[i]) << 16) | i;

@@ -1848,7 +1848,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
     uint8_t* hitflag = wbase + dres_bytes + cmask_bytes + kCap * 2u;
     uint64_t* headmask = reinterpret_cast<uint64_t*>(hitflag + 64);
     uint64_t* pmask = reinterpret_cast<uint64_t*>(hitflag + kFlagBytes);            // kSigOnly only
-    uint16_t* mlist = reinterpret_cast<uint16_t*>(hitflag + kFlagBytes + kPostMaxRows / 8u);
+    uint16_t* mlist = reinterpret_cast<uint16_t*>(hitflag + kFlagBytes + kPostLdsRows / 8u);
     const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
     const uint32_t hitrow = row0 + nl * 512u;  // LDS address of the absorbing (matched) state's row
     const uint32_t dres_addr = uint32_t(reinterpret_cast<uintptr_t>(wbase));
@@ -2370,7 +2370,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 }
             }
         }
-        if (LC_X_POSTINGS && any_true != 0 && dp->postings != nullptr && n_match <= kPostMaxMatches && nwords <= kPostMaxRows / 64u) {
+        if (LC_X_POSTINGS && any_true != 0 && dp->postings != nullptr && n_match <= kPostMaxMatches && nwords <= kPostLdsRows / 64u) {
             // ---- inverted-list row phase: the rows of the (one or two) matching dictionary values are read from the
             // entry's row lists and set in an LDS copy of the mask words; no key is read.  Two dependent round trips
             // (list bounds of every match, then the rows), a few dozen bytes instead of 2 n.
@@ -2382,7 +2382,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
                 o0 = as_global(post)[mid];
                 o1 = as_global(post)[mid + 1u];
             }
-            for (uint32_t w = uint32_t(lane); w < kPostMaxRows / 64u; w += kWave) pmask[w] = 0;
+            for (uint32_t w = uint32_t(lane); w < kPostLdsRows / 64u; w += kWave) pmask[w] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             for (uint32_t m = 0; m < n_match; m++) {
                 const uint32_t b = read_lane(o0, m), e1 = read_lane(o1, m);
@@ -2541,7 +2541,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restr
             // rows: the keys, or — when the launch this pass accounts for reads the inverted lists — the list bounds and
             // the rows of the matching values
             uint32_t nm = 0, pr = 0;
-            const bool lists = L.acct_postings && dp->postings != nullptr && nwords <= kPostMaxRows / 64u;
+            const bool lists = L.acct_postings && dp->postings != nullptr && nwords <= kPostLdsRows / 64u;
             if (lists) {
                 uint32_t my_m = 0, my_r = 0;
                 for (uint32_t i = uint32_t(lane); i < dp->d; i += kWave) {
@@ -3355,7 +3355,7 @@ __global__ __launch_bounds__(kThreads) void k_str_sel_rows(const StrDesc* __rest
                 uint64_t m = sw;
                 while (m) {
                     const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
-                    list[pos++] = uint16_t((w & 1023u) * 64u + bit);  // row within the entry (entries have <= 65536 rows)
+                    list[pos++] = uint16_t(uint32_t(lane) * 64u + bit);  // row within this group of 64 selection words
                     m &= m - 1;
                 }
             }
@@ -3363,7 +3363,7 @@ __global__ __launch_bounds__(kThreads) void k_str_sel_rows(const StrDesc* __rest
             if (group_rows <= 8u) {
                 // a handful of rows (the usual case after a selective filter): the wave measures them one by one
                 for (uint32_t j = 0; j < group_rows; j++) {
-                    const uint32_t row = list[j];
+                    const uint32_t row = wb * 64u + list[j];
                     const uint64_t o = out_row + j;
                     if (o >= capacity) break;
                     const bool valid = d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true;
@@ -3381,7 +3381,7 @@ __global__ __launch_bounds__(kThreads) void k_str_sel_rows(const StrDesc* __rest
                 }
             } else
             for (uint32_t j = uint32_t(lane); j < group_rows; j += kWave) {
-                const uint32_t row = list[j];
+                const uint32_t row = wb * 64u + list[j];
                 const uint64_t o = out_row + j;
                 if (o < capacity) {
                     const bool valid = d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true;

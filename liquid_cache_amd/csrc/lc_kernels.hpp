@@ -88,14 +88,17 @@ struct alignas(16) StrDesc {
 };
 static_assert(sizeof(StrDesc) == 112, "StrDesc layout");
 
-// Inverted row lists of a byte-view entry (device-side acceleration index like the signatures; entries of up to 8192 rows
+// Inverted row lists of a byte-view entry (device-side acceleration index like the signatures; entries of up to 65,535 rows
 // on substring-search columns): u16 offsets[D + 1], then the VALID rows grouped by dictionary key (u16 row numbers,
 // rows[offsets[k] .. offsets[k + 1]) reference key k).  A selective predicate matches one or two dictionary values per
-// entry; their rows are then read from these lists (a few bytes) instead of mapping all 8192 keys (16 KB) to results —
+// entry; their rows are then read from these lists (a few bytes) instead of mapping all keys (2 bytes per row) to results —
 // what map_dictionary_results_to_array_results (comparisons.rs:325-347) computes, for the matching values only.
-constexpr uint32_t kPostMaxRows = 8192;     // entries with more rows carry no lists
+constexpr uint32_t kPostMaxRows = 65535;    // entries with more rows carry no lists (u16 offsets count the valid rows)
+constexpr uint32_t kPostLdsRows = 8192;     // k_str_pred / k_like_lean keep an entry's mask words in 1 KB of LDS: larger
+                                            // entries take the lists only in k_like_flat (mask size per scan); the
+                                            // device transcoder sorts an entry's (key, row) pairs in LDS up to this size
 constexpr uint32_t kPostMaxMatches = 32;    // more matching dictionary values than this: the keys are mapped instead
-constexpr uint32_t kPostLdsBytes = kPostMaxRows / 8 + kPostMaxMatches * 2;  // per wave: mask words + matched keys
+constexpr uint32_t kPostLdsBytes = kPostLdsRows / 8 + kPostMaxMatches * 2;  // per wave: mask words + matched keys
 
 // What one workgroup of k_str_pred works on: a run of at most four consecutive entries that share a symbol table (one
 // per wave), with a COPY of their descriptors.  The record's address follows from blockIdx alone, so a wave fetches the

@@ -98,6 +98,8 @@ struct LikePipeline {
     uint32_t n_lean = 0;
     // the scan-level wide signature index of k_like_flat (see below): kFlatBits slices over the dictionary words of ALL
     // entries of the scan, slice-major; null when the scan is not eligible for it (or it did not fit)
+    bool lean_ok = false;                      // every entry fits k_like_lean's 1 KB of mask words (<= kPostLdsRows rows)
+    uint32_t flat_mask_bytes = 0;              // k_like_flat: LDS bytes of one entry's mask words (the scan's largest entry)
     bool flat = false, flat_tried = false;
     uint64_t* d_slices = nullptr;
     FlatGroup* d_groups = nullptr;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
     // dynamic LDS: [automaton image][per wave: kLeanE x 128 mask words | kLeanCap candidates (slot << 16 | key) |
     //                                          64 hit flags + head mask]
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr uint32_t kMaskBytes = kPostMaxRows / 8u;
+    constexpr uint32_t kMaskBytes = kPostLdsRows / 8u;
     constexpr uint32_t kPerWave = kLeanE * kMaskBytes + kLeanCap * 4u + 80u;
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
@@ -460,7 +462,7 @@ hipError_t launch_lean(int n_sig, bool negated, const LeanArgs& a, uint32_t n_re
          k_like_lean<6, false>, k_like_lean<7, false>, k_like_lean<8, false>},
         {k_like_lean<1, true>, k_like_lean<2, true>, k_like_lean<3, true>, k_like_lean<4, true>, k_like_lean<5, true>,
          k_like_lean<6, true>, k_like_lean<7, true>, k_like_lean<8, true>}};
-    const size_t lds = automaton_image_bytes(a.nl) + kLeanWaves * (kLeanE * (kPostMaxRows / 8u) + kLeanCap * 4u + 80u);
+    const size_t lds = automaton_image_bytes(a.nl) + kLeanWaves * (kLeanE * (kPostLdsRows / 8u) + kLeanCap * 4u + 80u);
     const uint32_t grid = LC_LEAN_XCD ? (n_recs + 7u) / 8u * 8u : n_recs;
     if (lds > 64 * 1024) {  // needles of 48-63 bytes: the image alone is 49-64 KB
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(table[negated ? 1 : 0][n_sig - 1]),
@@ -543,6 +545,7 @@ struct FlatArgs {
     const uint64_t* slices;
     uint64_t slice_words;                   // u64 words of one slice (= n_slots * group_words)
     uint32_t group_words;                   // words of a group inside a slice: the largest group of the scan, even
+    uint32_t mask_bytes;                    // kBig: LDS bytes of one entry's mask words (a multiple of 1 KB)
     const uint8_t* automata;
     uint32_t automaton_stride;
     uint32_t nl;
@@ -557,13 +560,15 @@ struct FlatArgs {
 };
 using ConstFlatPtr = const __attribute__((address_space(4))) FlatGroup*;
 
-template <int N, bool kNot>
+// kBig: scans with entries of more than 8,192 rows (batch sizes of 16,384 .. 65,535): the LDS mask words of an entry take
+// a.mask_bytes instead of 1 KB, and groups hold as many entries as 16 KB of them allow (build_flat).
+template <int N, bool kNot, bool kBig>
 __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
-    // dynamic LDS: [automaton image][per wave: kFlatMaxE x 128 mask words | kFlatMaxE x FlatEntry | kFlatCap candidates
+    // dynamic LDS: [automaton image][per wave: kFlatMaxE x mask words | kFlatMaxE x FlatEntry | kFlatCap candidates
     //                                          (entry << 16 | key) | 64 hit flags + head mask]
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr uint32_t kMaskBytes = kPostMaxRows / 8u;
-    constexpr uint32_t kPerWave = kFlatMaxE * kMaskBytes + kFlatMaxE * 64u + kFlatCap * 4u + 80u;
+    const uint32_t kMaskBytes = kBig ? a.mask_bytes : kPostLdsRows / 8u;
+    const uint32_t kPerWave = kFlatMaxE * kMaskBytes + kFlatMaxE * 64u + kFlatCap * 4u + 80u;
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     if (LC_FLAT_STOP == -1) return;
@@ -623,8 +628,12 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
     if (row0 != 0u) __builtin_trap();  // the image holds absolute LDS addresses computed for address 0
     const uint32_t hitrow = row0 + nl * 512u;
     // mask words of the entries start clear in LDS (16 bytes per lane and entry)
+    if (kBig) {
+        for (uint32_t i = uint32_t(lane); i < kFlatMaxE * kMaskBytes / 16u; i += kWave) reinterpret_cast<uint4*>(pmask)[i] = make_uint4(0, 0, 0, 0);
+    } else {
 #pragma unroll
-    for (uint32_t q = 0; q < kFlatMaxE; q++) reinterpret_cast<uint4*>(pmask)[q * 64u + uint32_t(lane)] = make_uint4(0, 0, 0, 0);
+        for (uint32_t q = 0; q < kFlatMaxE; q++) reinterpret_cast<uint4*>(pmask)[q * 64u + uint32_t(lane)] = make_uint4(0, 0, 0, 0);
+    }
 
     // ---- AND of the needle's slices: 128 dictionary values per lane
     uint64_t m0, m1;
@@ -884,20 +893,24 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
 hipError_t launch_flat(int n_sig, bool negated, const FlatArgs& a, hipStream_t stream) {
     if (a.n_slots == 0) return hipSuccess;
     typedef void (*Kern)(FlatArgs);
-    static const Kern table[2][kMaxSigProbe] = {
-        {k_like_flat<1, false>, k_like_flat<2, false>, k_like_flat<3, false>, k_like_flat<4, false>, k_like_flat<5, false>,
-         k_like_flat<6, false>, k_like_flat<7, false>, k_like_flat<8, false>},
-        {k_like_flat<1, true>, k_like_flat<2, true>, k_like_flat<3, true>, k_like_flat<4, true>, k_like_flat<5, true>,
-         k_like_flat<6, true>, k_like_flat<7, true>, k_like_flat<8, true>}};
-    const size_t lds = automaton_image_bytes(a.nl) + kFlatWaves * (kFlatMaxE * (kPostMaxRows / 8u) + kFlatMaxE * 64u + kFlatCap * 4u + 80u);
+#define LC_FLAT_ROW(NOT, BIG)                                                                                                  \
+    {k_like_flat<1, NOT, BIG>, k_like_flat<2, NOT, BIG>, k_like_flat<3, NOT, BIG>, k_like_flat<4, NOT, BIG>,                  \
+     k_like_flat<5, NOT, BIG>, k_like_flat<6, NOT, BIG>, k_like_flat<7, NOT, BIG>, k_like_flat<8, NOT, BIG>}
+    static const Kern table[2][2][kMaxSigProbe] = {{LC_FLAT_ROW(false, false), LC_FLAT_ROW(true, false)},
+                                                   {LC_FLAT_ROW(false, true), LC_FLAT_ROW(true, true)}};
+#undef LC_FLAT_ROW
+    const bool big = a.mask_bytes > kPostLdsRows / 8u;
+    const Kern kern = table[big ? 1 : 0][negated ? 1 : 0][n_sig - 1];
+    const size_t lds = automaton_image_bytes(a.nl) +
+                       kFlatWaves * (kFlatMaxE * size_t(big ? a.mask_bytes : kPostLdsRows / 8u) + kFlatMaxE * 64u + kFlatCap * 4u + 80u);
     const uint32_t wgs = (a.n_slots + kFlatWaves - 1u) / kFlatWaves;
     const uint32_t grid = (wgs + 7u) / 8u * 8u;
-    if (lds > 64 * 1024) {  // needles of 48-63 bytes: the image alone is 49-64 KB
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(table[negated ? 1 : 0][n_sig - 1]),
-                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+    if (lds > 64 * 1024) {  // needles of 48-63 bytes (the image alone is 49-64 KB), entries of more than 8,192 rows
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 160 * 1024 - 512);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(table[negated ? 1 : 0][n_sig - 1], dim3(grid), dim3(kFlatWaves * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kFlatWaves * 64), lds, stream, a);
     return hipGetLastError();
 }
 
@@ -987,6 +1000,14 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     std::vector<FlatGroup> groups;
     std::vector<uint32_t> dst_word(s->n, 0);
     uint32_t n_groups = 0;
+    // LDS mask words of an entry: 1 KB per 8,192 rows of the scan's largest entry; a group holds as many entries as 16 KB of
+    // them allow (4 x 16 KB per workgroup beside a 64 KB automaton image at most)
+    uint32_t max_rows = 1;
+    for (const Entry& e : s->meta) max_rows = std::max(max_rows, e.sd.n);
+    const uint32_t mask_bytes = (max_rows + kPostLdsRows - 1u) / kPostLdsRows * (kPostLdsRows / 8u);
+    const uint32_t max_e = std::min<uint32_t>(kFlatMaxE, std::max<uint32_t>(1u, 16384u / mask_bytes));
+    if (mask_bytes > 8192u) return LC_OK;
+    lp->flat_mask_bytes = mask_bytes;
     auto pad_batch = [&]() {  // a workgroup's groups share a symbol table: close the batch with empty records
         while (groups.size() % kFlatWaves) {
             FlatGroup g;
@@ -1006,7 +1027,7 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
         g.slot = s->meta[b].sd.symtab_slot;
         g.mask_word_off = s->seg_offsets[b];
         uint32_t words = 0, i = b;
-        while (i < s->n && i - b < kFlatMaxE && s->meta[i].sd.symtab_slot == g.slot) {
+        while (i < s->n && i - b < max_e && s->meta[i].sd.symtab_slot == g.slot) {
             const StrDesc& d = s->meta[i].sd;
             const uint32_t nw = (d.d + 63u) / 64u;
             if (words + nw > kFlatGroupWords) break;
@@ -1088,6 +1109,8 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
         if (e.sd.d == 0) continue;  // an all-null entry has no dictionary: no candidates, its mask words are zero
         if (!e.sd.signatures || !e.sd.postings || !e.sd.fingerprints || e.sd.n > kPostMaxRows) return LC_OK;
     }
+    lp->lean_ok = true;  // (entries of more than 8,192 rows: only k_like_flat, whose LDS mask size is the scan's)
+    for (const Entry& e : s->meta) lp->lean_ok = lp->lean_ok && e.sd.n <= kPostLdsRows;
     // consecutive entries, at most kLeanWaves * kLeanE, never across a symbol-table change
     std::vector<LeanRec> lean;
     for (uint32_t b = 0, i = 1; i <= s->n; i++) {
@@ -1181,6 +1204,7 @@ lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L,
     fa.slices = lp->d_slices;
     fa.slice_words = uint64_t(lp->n_group_slots) * lp->group_words;
     fa.group_words = lp->group_words;
+    fa.mask_bytes = lp->flat_mask_bytes;
     fa.automata = p.automata;
     fa.automaton_stride = p.automaton_stride;
     fa.nl = p.needle_len;
@@ -1276,6 +1300,8 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
     if (path == 1 || path == 5 || s->n < s->ctx->like_pipeline_min_entries) return "k_str_pred";
     if (!lp || !lp->built) return "k_str_pred (scan not evaluated yet)";
     if (!lp->eligible) return "k_str_pred (entries without signature index / row lists)";
+    if (!lp->lean_ok && !(lp->flat && (path == 0 || path == 4)))
+        return "k_str_pred (entries of more than 8192 rows and no scan-level index)";
     if (path == 3) return "k_like_lean (forced for every needle)";
     const bool use_flat = lp->flat && (path == 0 || path == 4);
     if (path == 4 && use_flat) return "k_like_flat (forced for every needle)";
@@ -1352,6 +1378,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         if (st != LC_OK) return st;
     }
     const bool use_flat = want_flat && lp->flat;
+    if (!use_flat && !lp->lean_ok) return LC_OK;  // entries of more than 8,192 rows without the scan-level index: k_str_pred
     LikePlan* plan = nullptr;
     for (LikePlan& q : lp->plans)
         if (q.needle == sp.needle) plan = &q;

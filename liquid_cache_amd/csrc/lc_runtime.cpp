@@ -500,9 +500,9 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
                     size_t offs[9], const uint8_t* index = nullptr, size_t index_len = 0) {
     ByteViewParsed v;
     if (!parse_byte_view(bytes, len, &v)) return fail(LC_ERR_CORRUPT, "malformed Liquid byte-view array");
-    // the row lists and mask utilities of the byte-view kernels address rows of an entry with 16 bits (the reference's
-    // batches are 8192 rows); larger arrays stay on the caller's CPU path
-    if (v.n > 65536) return fail(LC_UNSUPPORTED, "byte-view entries of more than 65536 rows are not handled on the device");
+    // (any number of rows: the dictionary keys are u16, so an entry has at most 65,536 distinct values, but the reference's
+    // batch size is the caller's choice, builders.rs:68-71.  Entries of more than 65,535 rows carry no inverted row lists —
+    // those address rows with 16 bits — and are evaluated by k_str_pred's key mapping.)
     uint32_t slot;
     const SymbolTable* host_st = nullptr;
     {
@@ -1761,7 +1761,9 @@ static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& item
         p.residuals = ptr(4);
         p.fsst = ptr(5);
         p.shared_prefix = ptr(6);
-        p.postings = reinterpret_cast<uint16_t*>(ptr(8));
+        // (k_bv_pack sorts an entry's (key, row) pairs in LDS: up to kPostLdsRows rows; the lists of larger entries are made
+        // on the host from the keys the kernels produced, below)
+        p.postings = it.n <= kPostLdsRows ? reinterpret_cast<uint16_t*>(ptr(8)) : nullptr;
         p.d = st.d;
         p.shared_prefix_len = st.shared_prefix_len;
         p.offset_bytes = st.offset_bytes;
@@ -1802,7 +1804,7 @@ static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& item
         d.fsst = p.fsst;
         d.shared_prefix = p.shared_prefix;
         d.signatures = reinterpret_cast<const uint64_t*>(ptr(7));
-        d.postings = p.postings;
+        d.postings = reinterpret_cast<const uint16_t*>(ptr(8));
         if (e.sig_on_device) sig_descs.push_back(d);
     }
     BvPackDesc* d_packs = reinterpret_cast<BvPackDesc*>(d_sc + sc_packs);
@@ -1827,6 +1829,21 @@ static lc_status device_encode_byte_views(lc_ctx* ctx, std::vector<BvItem>& item
         if (e2 != hipSuccess || e3 != hipSuccess) return fail(LC_ERR_DEVICE, "k_str_build_signatures failed");
     }
     LC_HIP(hipStreamSynchronize(side));
+    for (size_t i = 0; i < m; i++) {
+        // batch sizes over 8,192 rows (rare): the same lists the host transcoder attaches, from the entry's keys
+        const BvItem& it = items[i];
+        if (lay[i].off[8] == size_t(-1) || it.n <= kPostLdsRows) continue;
+        std::vector<uint16_t> keys(it.n);
+        std::vector<uint64_t> valid(it.has_validity ? (size_t(it.n) + 63) / 64 : 0);
+        LC_HIP(hipMemcpyAsync(keys.data(), dbase + lay[i].off[0], size_t(it.n) * 2, hipMemcpyDeviceToHost, side));
+        if (!valid.empty())
+            LC_HIP(hipMemcpyAsync(valid.data(), dbase + lay[i].off[1], valid.size() * 8, hipMemcpyDeviceToHost, side));
+        LC_HIP(hipStreamSynchronize(side));
+        const std::vector<uint16_t> post = build_row_lists(keys.data(), valid.empty() ? nullptr : reinterpret_cast<const uint8_t*>(valid.data()),
+                                                           it.n, stats[i].d);
+        LC_HIP(hipMemcpyAsync(dbase + lay[i].off[8], post.data(), post.size() * 2, hipMemcpyHostToDevice, side));
+        LC_HIP(hipStreamSynchronize(side));  // (`post` is a local)
+    }
     std::unique_lock<std::shared_mutex> g(ctx->mu);
     for (size_t i = 0; i < m; i++) {
         publish_entry(ctx, items[i].id, std::move(entries[i]));

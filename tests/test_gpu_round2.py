@@ -369,15 +369,17 @@ def test_stage_rejects_out_of_contract_entries(gpu_cache, oracle):
     with pytest.raises(lc.LiquidCacheError) as e:
         gpu_cache.stage([1], [bytes(liquid)])
     assert e.value.status == N.LC_ERR_CORRUPT
-    # byte-view entry of more than 65536 rows: not handled on the device -> caller's CPU path
+    # (a byte-view entry of more than 65536 rows used to be refused here; since round 4 it is staged and evaluated by the
+    # general kernels: tests/test_gpu_round4_limits.py)
     strs = ["v%d" % (i % 100) for i in range(65537)]
     host = lc.LiquidCacheBuilder.new().with_host_only().build()
     big = host.transcode(pa.array(strs), None, 77)
     gpu_cache.set_symbol_table(77, host.symbol_table(77))
-    with pytest.raises(lc.LiquidCacheError) as e:
-        gpu_cache.stage([2], [big], path_ids=[77])
-    assert e.value.status == N.LC_UNSUPPORTED
+    gpu_cache.stage([2], [big], path_ids=[77])
     host.close()
+    got = gpu_cache.eval_predicate(2, lc.LiquidExpr.try_new("=", b"v7", pa.string())).read()
+    assert got.to_pylist() == [s == "v7" for s in strs]
+    gpu_cache.evict([2])
     assert gpu_cache.entry_info(1) is None and gpu_cache.entry_info(2) is None
 
 

@@ -4,8 +4,9 @@
   is raised past the default 64 KB), on every LIKE kernel; for longer ones the automaton runs over the first 63 bytes and
   the dictionary values it accepts are matched against the whole pattern (one case: the first 64 bytes of a value followed
   by a byte it does not have) — all equal to the oracle's decode + memmem (byte_view_array/comparisons.rs:598-651);
-* entries of more than 8,192 rows (batch sizes of 16,384 .. 65,536: builders.rs:68-71 takes any) carry inverted row lists
-  and run the scan-level index kernel; entries beyond 65,536 rows are evaluated by the general kernels.
+* entries of more than 8,192 rows (batch sizes of 16,384 .. 65,535: builders.rs:68-71 takes any) carry inverted row lists
+  and run the scan-level index kernel; entries beyond that (100,000 and 150,001 rows here) are evaluated by the general
+  kernels — LIKE, Eq and ordering predicates, per-entry calls and get-with-selection.
 """
 import os
 import sys
@@ -87,12 +88,13 @@ def _check_scan(lo, scan, flat, needles, rng, tag, ops=("like", "not_like")):
                     sels[b] = se
                     packed = np.packbits(se, bitorder="little")
                     words[int(offs[b]): int(offs[b + 1])].view(np.uint8)[: len(packed)] = packed
-            expr = lc.LiquidExpr.try_new(op, b"%" + nd + b"%", pa.binary(), HINT)
+            lit = b"%" + nd + b"%" if "like" in op else nd
+            expr = lc.LiquidExpr.try_new(op, lit, pa.binary(), HINT)
             mask, counts = scan.eval_to_host(expr, selection=words)
             bits = np.unpackbits(mask.view(np.uint8), bitorder="little")
             for b, (rows, liquid, st) in enumerate(flat):
                 got = bits[int(offs[b]) * 64: int(offs[b]) * 64 + lens[b]].astype(bool)
-                want = _want_full(lo, liquid, st, lo.OP_NAMES[op], b"%" + nd + b"%", sels[b], lens[b])
+                want = _want_full(lo, liquid, st, lo.OP_NAMES[op], lit, sels[b], lens[b])
                 assert np.array_equal(got, want), (tag, b, op, len(nd), nd[:20], with_sel, int(got.sum()), int(want.sum()))
                 assert int(counts[b]) == int(want.sum()), (tag, b, op, len(nd))
                 assert not bits[int(offs[b]) * 64 + lens[b]: int(offs[b + 1]) * 64].any()
@@ -129,6 +131,82 @@ def test_needles_of_48_to_63_bytes_and_longer(product_lib, oracle, like_path):
             assert how.startswith("k_like_lean"), how
         if like_path == 5:
             assert how.startswith("k_like_scanall"), how
+        scan.close()
+    finally:
+        cache.close()
+
+
+# (rows, distinct, nulls): batch sizes of 16,384 .. 65,535 rows next to ordinary ones; 65,536 rows carry no row lists (their
+# u16 offsets could not count the valid rows) and keep the whole scan on k_str_pred
+BIG_SPECS = {
+    "16k": [(16384, 3000, False), (16384, 2500, True), (8192, 2000, False), (16384, 90, False)],
+    "40k_65535": [(40000, 6000, True), (65535, 5000, False), (100, 60, False), (65535, 8000, True)],
+    "65536": [(65536, 4000, False), (8192, 2000, True)],
+}
+
+
+@pytest.mark.parametrize("like_path", [0, 4, 1, 5])
+@pytest.mark.parametrize("spec", sorted(BIG_SPECS))
+def test_entries_of_more_than_8192_rows(product_lib, oracle, spec, like_path):
+    lo = oracle
+    rng = np.random.default_rng(len(spec) * 131 + like_path)
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1, like_path=like_path or None).build()
+    try:
+        ids, flat = _stage_entries(cache, lo, BIG_SPECS[spec], rng, 31)
+        scan = cache.scan(ids)
+        values = [v for rows, _, _ in flat for v in rows if v is not None]
+        needles = [b"example.com/catalog", b"yandex.ru/search", b"section-3", b"#77", b"zzzzqqq", b"ref="]
+        for ln in (5, 9, 20):
+            v = values[int(rng.integers(len(values)))]
+            a = int(rng.integers(0, len(v) - ln))
+            needles.append(v[a:a + ln])
+        n = _check_scan(lo, scan, flat, needles, rng, "%s path %d" % (spec, like_path))
+        assert n >= len(flat) * 2 * len(needles)
+        how = scan.explain(lc.LiquidExpr.try_new("like", b"%section-3%", pa.binary(), HINT))
+        if like_path == 4 and spec != "65536":
+            assert how.startswith("k_like_flat"), how
+        if spec == "65536" and like_path in (0, 4):
+            assert how.startswith("k_str_pred"), how
+        # the rows come back the same through get-with-selection (the row lists are not involved, the entry size is)
+        rows, liquid, st = flat[0]
+        sel = rng.random(len(rows)) < 0.001
+        got = cache.get(ids[0]).with_selection(sel).read()
+        want = [rows[int(i)] for i in np.flatnonzero(sel)]
+        assert got.to_pylist() == want
+        scan.close()
+    finally:
+        cache.close()
+
+
+@pytest.mark.parametrize("like_path", [0, 1, 5])
+def test_entries_of_more_than_65536_rows(product_lib, oracle, like_path):
+    lo = oracle
+    rng = np.random.default_rng(65537 + like_path)
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1, like_path=like_path or None).build()
+    try:
+        ids, flat = _stage_entries(cache, lo, [(100000, 7000, True), (8192, 2000, False), (150001, 300, False)], rng, 41)
+        scan = cache.scan(ids)
+        values = [v for rows, _, _ in flat for v in rows if v is not None]
+        needles = [b"example.com/catalog", b"section-3", b"#77", b"zzzzqqq"]
+        v = values[int(rng.integers(len(values)))]
+        needles.append(v[3:14])
+        n = _check_scan(lo, scan, flat, needles, rng, "path %d" % like_path)
+        lits = [values[int(rng.integers(len(values)))] for _ in range(2)] + [b"http://m", b""]
+        n += _check_scan(lo, scan, flat, lits, rng, "path %d cmp" % like_path, ops=("eq", "lt", "ge"))
+        assert n >= len(flat) * (2 * len(needles) + 3 * len(lits))
+        # per-entry drop-in calls on the large entries
+        for b in (0, 2):
+            rows, liquid, st = flat[b]
+            sel = rng.random(len(rows)) < 0.3
+            expr = lc.LiquidExpr.try_new("like", b"%section-3%", pa.binary(), HINT)
+            got = cache.eval_predicate(ids[b], expr).with_selection(sel).read()
+            r = lo.eval_predicate(liquid, lo.OP_NAMES["like"], b"%section-3%", sel, symtab=st)
+            want = pa.array(r.values, mask=None if r.validity is None else ~r.validity)
+            assert got.equals(want), (b, like_path)
+            sel2 = rng.random(len(rows)) < 0.0005
+            sel2[-1] = True
+            back = cache.get(ids[b]).with_selection(sel2).read()
+            assert back.to_pylist() == [rows[int(i)] for i in np.flatnonzero(sel2)]
         scan.close()
     finally:
         cache.close()

@@ -307,7 +307,8 @@ def test_inverted_row_lists_layout(product_lib):
     """The row lists lc_stage attaches to byte-view entries: offsets[d + 1] is a running sum, the rows of key k
     are exactly the VALID rows whose key is k (any order within a key), rows under nulls and keys >= d are not listed."""
     rng = np.random.default_rng(12)
-    for n, d, p_null in ((8192, 2200, 0.05), (8192, 1, 0.0), (77, 500, 0.5), (1, 1, 0.0), (8192, 8192, 0.0)):
+    for n, d, p_null in ((8192, 2200, 0.05), (8192, 1, 0.0), (77, 500, 0.5), (1, 1, 0.0), (8192, 8192, 0.0),
+                         (16384, 3000, 0.1), (65535, 9000, 0.0), (65535, 1, 0.0)):  # batch sizes up to 65,535 rows
         keys = rng.integers(0, d, size=n).astype(np.uint16)
         valid = rng.random(n) >= p_null
         keys[~valid] = rng.integers(0, 65536, size=int((~valid).sum())).astype(np.uint16)   # garbage under nulls
@@ -322,8 +323,8 @@ def test_inverted_row_lists_layout(product_lib):
             want = np.nonzero(valid & (keys == k))[0]
             assert sorted(rows[off[k]: off[k + 1]].tolist()) == want.tolist(), (n, d, k)
     # out of contract: more rows than an entry with lists may have, no dictionary, a short buffer
-    big = np.zeros(9000, np.uint16)
-    out = np.zeros(20000, np.uint16)
-    assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 9000, 10, out.ctypes.data, out.size) == 0
+    big = np.zeros(65536, np.uint16)
+    out = np.zeros(70000, np.uint16)
+    assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 65536, 10, out.ctypes.data, out.size) == 0  # u16 offsets
     assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 100, 0, out.ctypes.data, out.size) == 0
     assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 100, 10, out.ctypes.data, 50) == 0
