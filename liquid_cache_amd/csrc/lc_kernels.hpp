@@ -284,8 +284,10 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
                            const ScanLaunch& L, hipStream_t stream);
 // [NOT] LIKE '%needle%' with many candidates: the whole FSST buffer of every entry streamed once, lane per 8-byte word
 // (lc_like_scanall.hip); d_recs: the scan's workgroup records (<= 4 entries of one symbol table each)
+// (uni_slice / uni_word: a 1-byte needle answered from the scan-level unigram index instead of a walk, see ScanAllArgs)
 hipError_t launch_like_scanall(const StrWgRecord* d_recs, uint32_t n_recs, const StrPred& pred, const ScanLaunch& L,
-                               unsigned long long* d_total_acc, hipStream_t stream);
+                               unsigned long long* d_total_acc, hipStream_t stream, const uint64_t* uni_slice = nullptr,
+                               const uint32_t* uni_word = nullptr);
 // per-block selected-row counts -> exclusive offsets, then compaction of decoded values
 // d_block_counts: n_entries*blocks_per_entry u32; d_block_offsets: that + 1 u64; d_entry_row_offsets: n_entries + 1 u64
 // u64 elements the caller provides for d_block_offsets: n_blocks + 1 offsets followed by the scan's tile sums

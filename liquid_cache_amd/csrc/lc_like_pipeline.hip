@@ -107,6 +107,13 @@ struct LikePipeline {
     uint32_t group_words = 0;                  // signature words of a group inside a slice (even, <= kFlatGroupWords)
     uint64_t slices_bytes = 0;
     double flat_build_ms = 0;
+    // the unigram index (1-byte needles): 256 slices in the layout of the bigram slices — bit i of entry e's words in slice
+    // b: dictionary value i holds byte b.  Built the first time a 1-byte needle runs on the scan.
+    uint32_t* d_dst_word = nullptr;            // per entry: its first word inside a slice
+    uint64_t slice_words = 0;
+    uint64_t* d_uni = nullptr;
+    bool uni_tried = false;
+    double uni_build_ms = 0;
     unsigned long long* d_total_acc = nullptr;
     std::vector<LikePlan> plans;
     uint64_t tick = 0;
@@ -924,11 +931,14 @@ struct FlatBuildArgs {
     uint64_t* slices;
     uint64_t slice_words;
 };
+// kUni: the 256 unigram slices (bit = the byte itself) instead of the kFlatBits bigram slices.
+template <bool kUni>
 __global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
-    constexpr int kSigWords = kFlatBits / 64;
+    constexpr int kBits = kUni ? 256 : kFlatBits;
+    constexpr int kSigWords = kBits / 64;
     __shared__ uint64_t s_sym[256];
     __shared__ uint8_t s_len[256];
-    __shared__ uint64_t stage[kFlatBits][8];
+    __shared__ uint64_t stage[kBits][8];
     const StrDesc d = a.descs[blockIdx.y];
     const uint32_t nw = (d.d + 63u) >> 6;
     if (d.d == 0 || blockIdx.x * 8u >= nw) return;
@@ -963,8 +973,8 @@ __global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
                     else { sym = s_sym[code]; len = s_len[code]; }
                     for (uint32_t t = 0; t < len; t++) {
                         const int cur = int((sym >> (8u * t)) & 0xFFu);
-                        if (prev >= 0) {
-                            const uint32_t bit = flat_bigram_bit(uint32_t(prev), uint32_t(cur));
+                        if (kUni || prev >= 0) {
+                            const uint32_t bit = kUni ? uint32_t(cur) : flat_bigram_bit(uint32_t(prev), uint32_t(cur));
 #pragma unroll
                             for (int r = 0; r < kSigWords; r++)
                                 if (int(bit >> 6) == r) mine[r] |= uint64_t(1) << (bit & 63u);
@@ -987,7 +997,7 @@ __global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
     __syncthreads();
     const uint32_t cols = min(8u, nw - blockIdx.x * 8u);
     const size_t dst = size_t(a.dst_word[blockIdx.y]) + size_t(blockIdx.x) * 8u;
-    for (uint32_t s = threadIdx.x; s < uint32_t(kFlatBits); s += 256u)
+    for (uint32_t s = threadIdx.x; s < uint32_t(kBits); s += 256u)
         for (uint32_t cc = 0; cc < cols; cc++) a.slices[size_t(s) * a.slice_words + dst + cc] = stage[s][cc];
 }
 
@@ -1067,12 +1077,14 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
     (void)hipEventCreate(&ev1);
-    uint32_t* d_dst = static_cast<uint32_t*>(pool_alloc(ctx, size_t(s->n) * 4));
+    uint32_t* d_dst = static_cast<uint32_t*>(pool_alloc(ctx, size_t(s->n) * 4));  // (kept: the unigram index shares the layout)
     struct Tmp {
-        lc_ctx* c; void* p; hipStream_t st; hipEvent_t a, b;
-        ~Tmp() { (void)hipStreamSynchronize(st); pool_release(c, p); if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-    } tmp{ctx, d_dst, stream, ev0, ev1};
+        hipStream_t st; hipEvent_t a, b;
+        ~Tmp() { (void)hipStreamSynchronize(st); if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } tmp{stream, ev0, ev1};
     if (!d_dst) return fail(LC_ERR_OOM, "hipMalloc (flat index build)");
+    lp->d_dst_word = d_dst;
+    lp->slice_words = slice_words;
     if (hipMalloc(reinterpret_cast<void**>(&lp->d_slices), bytes) != hipSuccess) {
         (void)hipGetLastError();
         lp->d_slices = nullptr;
@@ -1086,7 +1098,7 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     LC_HIP(hipMemcpyAsync(d_dst, dst_word.data(), size_t(s->n) * 4, hipMemcpyHostToDevice, stream));
     FlatBuildArgs ba{static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, d_dst, lp->d_slices, slice_words};
     const uint32_t max_nw = (std::max(s->max_dict_len, 1u) + 63u) / 64u;
-    hipLaunchKernelGGL(k_flat_build, dim3((max_nw + 7u) / 8u, s->n), dim3(256), 0, stream, ba);
+    hipLaunchKernelGGL(k_flat_build<false>, dim3((max_nw + 7u) / 8u, s->n), dim3(256), 0, stream, ba);
     LC_HIP(hipGetLastError());
     if (ev1) LC_HIP(hipEventRecord(ev1, stream));
     LC_HIP(hipStreamSynchronize(stream));  // the vectors are locals
@@ -1097,6 +1109,43 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     lp->group_words = gw;
     lp->slices_bytes = bytes;
     lp->flat = true;
+    return LC_OK;
+}
+
+// The unigram index of a scan that has its bigram index (same groups, same word offsets): 256 slices, 32 bytes per
+// dictionary value (0.98 GB and one more pass over the dictionaries for the 100 M-row URL column).  A value holds the byte b
+// exactly when its bit in slice b is set, so a 1-byte LIKE needs no walk: k_like_scanall<kUni> copies the entry's words of
+// ONE slice and maps the rows through the keys.
+lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
+    (void)ctx;
+    lp->uni_tried = true;
+    if (!lp->flat || !lp->d_dst_word || lp->slice_words == 0) return LC_OK;
+    const uint64_t bytes = lp->slice_words * 8u * 256u;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
+    uint64_t* d_uni = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d_uni), bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return LC_OK;  // no room: the walkers serve
+    }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    (void)hipEventCreate(&ev0);
+    (void)hipEventCreate(&ev1);
+    struct Tmp {
+        hipEvent_t a, b;
+        ~Tmp() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } tmp{ev0, ev1};
+    lp->d_uni = d_uni;  // (freed with the pipeline whatever happens below)
+    if (ev0) LC_HIP(hipEventRecord(ev0, stream));
+    LC_HIP(hipMemsetAsync(d_uni, 0, bytes, stream));
+    FlatBuildArgs ba{static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, lp->d_dst_word, d_uni, lp->slice_words};
+    const uint32_t max_nw = (std::max(s->max_dict_len, 1u) + 63u) / 64u;
+    hipLaunchKernelGGL(k_flat_build<true>, dim3((max_nw + 7u) / 8u, s->n), dim3(256), 0, stream, ba);
+    LC_HIP(hipGetLastError());
+    if (ev1) LC_HIP(hipEventRecord(ev1, stream));
+    LC_HIP(hipStreamSynchronize(stream));
+    float ms = 0;
+    if (ev0 && ev1 && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) lp->uni_build_ms = ms;
     return LC_OK;
 }
 
@@ -1287,7 +1336,9 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     pool_release(ctx, lp->d_lean);
     pool_release(ctx, lp->d_total_acc);
     pool_release(ctx, lp->d_groups);
+    pool_release(ctx, lp->d_dst_word);
     if (lp->d_slices) (void)hipFree(lp->d_slices);
+    if (lp->d_uni) (void)hipFree(lp->d_uni);
     delete lp;
 }
 
@@ -1295,7 +1346,15 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
     const LikePipeline* lp = s->like;
     const int path = s->ctx->like_path;
-    if (sp.p.mode == 1 && sp.p.needle_len == 1) return "k_str_pred (1-byte needle: no bigram, every fingerprint candidate walked by the many-candidate walkers)";
+    if (sp.p.mode == 1 && sp.p.needle_len == 1) {
+        if (lp && lp->d_uni && (path == 0 || path == 4) && s->n >= s->ctx->like_pipeline_min_entries) {
+            char buf[256];
+            std::snprintf(buf, sizeof(buf), "k_like_scanall<unigram> (1-byte needle: exact from the scan-level unigram index, no walk; rows "
+                          "through the keys; index %.2f GB built in %.1f ms)", double(lp->slice_words) * 8 * 256 / 1e9, lp->uni_build_ms);
+            return buf;
+        }
+        return "k_str_pred (1-byte needle: no bigram, every fingerprint candidate walked by the many-candidate walkers)";
+    }
     if (sp.p.mode == 1 && sp.p.verify_len != 0) return "k_str_pred (needle over 63 bytes: automaton over its first 63, accepted values matched against the pattern)";
     if (path == 1 || path == 5 || s->n < s->ctx->like_pipeline_min_entries) return "k_str_pred";
     if (!lp || !lp->built) return "k_str_pred (scan not evaluated yet)";
@@ -1329,6 +1388,17 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
 uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts) {
     const LikePipeline* lp = s->like;
     if (!lp || !lp->eligible || s->ctx->like_path == 1 || sp.p.verify_len != 0) return 0;
+    if (sp.p.mode == 1 && sp.p.needle_len == 1) {
+        // k_like_scanall<unigram>: per entry its descriptor, its words of ONE slice, the keys (2 n; an upper bound: entries
+        // without a matching value skip them), validity words of nullable entries, mask words out
+        if (!lp->d_uni || !(s->ctx->like_path == 0 || s->ctx->like_path == 4)) return 0;
+        uint64_t b = with_counts ? uint64_t(s->n) * 4 : 0;
+        for (const Entry& e : s->meta) {
+            const uint64_t words = (uint64_t(e.len) + 63) / 64;
+            b += sizeof(StrDesc) + 4 + uint64_t((e.sd.d + 63u) / 64u) * 8 + 2ull * e.len + words * 8 * (1 + (e.nullable ? 1 : 0));
+        }
+        return b;
+    }
     for (const LikePlan& q : lp->plans)
         if (q.needle == sp.needle && (q.use_lean || s->ctx->like_path == 3 || s->ctx->like_path == 4)) {
             if (lp->flat && (s->ctx->like_path == 0 || s->ctx->like_path == 4)) {
@@ -1359,7 +1429,34 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     // a 1-byte needle has no bigram: its candidates are whatever the 32-bucket fingerprint lets through, which for a byte
     // that occurs in the column is most of every dictionary (the many-candidate kernel falls back to the lane-parallel
     // walk by itself for an entry with less than a wave of candidates)
-    if (p.mode == 1 && p.needle_len == 1 && (p.op == LC_OP_LIKE || p.op == LC_OP_NOT_LIKE)) *many_candidates = true;
+    if (p.mode == 1 && p.needle_len == 1 && (p.op == LC_OP_LIKE || p.op == LC_OP_NOT_LIKE)) {
+        *many_candidates = true;
+        // ... unless the scan has (or can get) the unigram index: the needle byte's slice IS the dictionary result
+        const bool want = (ctx->like_path == 0 || ctx->like_path == 4) && s->n >= ctx->like_pipeline_min_entries &&
+                          s->d_wg_ranges && s->n_wg_ranges > 0 && !L.d_cand_bytes && !L.d_own_bytes && !LC_ABL(p.debug_flags != 0);
+        if (want) {
+            if (!s->like) s->like = new LikePipeline();
+            LikePipeline* lp = s->like;
+            if (!lp->built) {
+                const lc_status st = build_index(ctx, s, lp, stream);
+                if (st != LC_OK) return st;
+            }
+            if (lp->eligible && !lp->flat_tried) {
+                const lc_status st = build_flat(ctx, s, lp, stream);
+                if (st != LC_OK) return st;
+            }
+            if (lp->eligible && lp->flat && !lp->uni_tried) {
+                const lc_status st = build_unigram(ctx, s, lp, stream);
+                if (st != LC_OK) return st;
+            }
+            if (lp->eligible && lp->flat && lp->d_uni) {
+                LC_HIP(launch_like_scanall(s->d_wg_ranges, s->n_wg_ranges, p, L, L.d_total_acc, stream,
+                                           lp->d_uni + uint64_t(sp.needle[0]) * lp->slice_words, lp->d_dst_word));
+                *handled = true;
+                return LC_OK;
+            }
+        }
+    }
     // (needles over 63 bytes: their matches are verified against the whole pattern, which k_str_pred does)
     if (p.mode != 1 || (p.op != LC_OP_LIKE && p.op != LC_OP_NOT_LIKE) || !p.use_fingerprints || p.n_sig_bits == 0 || p.needle_len < 2 ||
         automaton_image_bytes(p.needle_len) == 0 || p.verify_len != 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))

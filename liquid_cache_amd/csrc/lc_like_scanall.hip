@@ -63,24 +63,28 @@ struct ScanAllArgs {
     uint64_t* valid;
     uint32_t* counts;
     ScanLaunch total;
+    // kUni (1-byte needles): the needle byte's slice of the scan-level unigram index — bit i of entry e's words (at
+    // uni_word[e]) says whether dictionary value i holds the byte — is the dictionary result; nothing is walked
+    const uint64_t* uni_slice;
+    const uint32_t* uni_word;
 };
 using ConstRecDesc = const __attribute__((address_space(4))) StrDesc*;
 
-template <bool kNot>
+template <bool kNot, bool kUni>
 __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     const uint32_t nl = a.nl;
-    const uint32_t tbl_bytes = automaton_image_bytes(nl);
+    const uint32_t tbl_bytes = kUni ? 0u : automaton_image_bytes(nl);
     const StrWgRecord* rec = a.recs + blockIdx.x;
     const uint32_t begin = rec->begin, end = rec->end;
-    {   // the workgroup's automaton image (its entries share one symbol table): every wave brings its share
+    if (!kUni) {   // the workgroup's automaton image (its entries share one symbol table): every wave brings its share
         const uint8_t* src = a.automata + size_t(rec->symtab_slot) * a.automaton_stride + automaton_u8_bytes(nl);
         for (uint32_t c = wave * 1024u; c < tbl_bytes; c += kWavesPerBlock * 1024u) async_copy16(src + c + uint32_t(lane) * 16u, smem + c);
     }
     const uint32_t row0 = uint32_t(reinterpret_cast<uintptr_t>(smem));
-    if (row0 != 0u) __builtin_trap();  // the image holds absolute LDS addresses computed for address 0
+    if (!kUni && row0 != 0u) __builtin_trap();  // the image holds absolute LDS addresses computed for address 0
     const uint32_t hitrow = row0 + nl * 512u;
     const uint32_t per_wave = a.dres_bytes + kSaFixedLds;
     uint8_t* wbase = smem + tbl_bytes + wave * per_wave;
@@ -95,8 +99,10 @@ __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
     const uint32_t unit = blockIdx.x * kWavesPerBlock + wave, n_units = gridDim.x * kWavesPerBlock;
     const uint32_t entry = begin + wave;
     // every wave of the workgroup passes the barrier that publishes the image exactly once
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (!kUni) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
     if (entry >= end) {
         if (a.total.d_total_out && lane == 0) total_contribute(a.total, unit, n_units, 0);
         return;
@@ -118,7 +124,19 @@ __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     uint64_t any_true = 0;  // wave uniform
 
-    if (D > 0 && fsst_len > 0) {
+    if (kUni) {
+        // the slice words ARE the dictionary results (bits beyond D are zero in the index)
+        const uint64_t* src = a.uni_slice + a.uni_word[entry];
+        const uint32_t nw = (D + 63u) >> 6;
+        uint64_t acc = 0;
+        for (uint32_t w = uint32_t(lane); w < nw; w += kWave) {
+            const uint64_t v = *as_global(src + w);
+            reinterpret_cast<uint64_t*>(dres)[w] = v;
+            acc |= v;
+        }
+        any_true = __ballot(acc != 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    } else if (D > 0 && fsst_len > 0) {
         const uint8_t* fsst = dp->fsst;
         const uint32_t last_word = (fsst_len - 1u) & ~7u;  // (the section carries 16 bytes of padding)
         uint32_t v_next = 0;        // first dictionary value whose end has not been placed yet (wave uniform)
@@ -370,7 +388,8 @@ __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
 
 // Launcher: one workgroup per record of the scan (<= 4 entries of one symbol table, one per wave).
 hipError_t launch_like_scanall(const StrWgRecord* d_recs, uint32_t n_recs, const StrPred& pred, const ScanLaunch& L,
-                               unsigned long long* d_total_acc, hipStream_t stream) {
+                               unsigned long long* d_total_acc, hipStream_t stream, const uint64_t* uni_slice,
+                               const uint32_t* uni_word) {
     if (n_recs == 0) return hipSuccess;
     ScanAllArgs a{};
     a.recs = d_recs;
@@ -387,9 +406,13 @@ hipError_t launch_like_scanall(const StrWgRecord* d_recs, uint32_t n_recs, const
     a.counts = L.d_counts;
     a.total.d_total_acc = d_total_acc;
     a.total.d_total_out = L.d_total_out;
-    const size_t lds = automaton_image_bytes(pred.needle_len) + size_t(kWavesPerBlock) * (a.dres_bytes + kSaFixedLds);
+    a.uni_slice = uni_slice;
+    a.uni_word = uni_word;
+    const bool uni = uni_slice != nullptr;
+    const size_t lds = (uni ? 0 : automaton_image_bytes(pred.needle_len)) + size_t(kWavesPerBlock) * (a.dres_bytes + kSaFixedLds);
     typedef void (*Kern)(ScanAllArgs);
-    const Kern kern = pred.op == LC_OP_NOT_LIKE ? static_cast<Kern>(k_like_scanall<true>) : static_cast<Kern>(k_like_scanall<false>);
+    const Kern kern = uni ? (pred.op == LC_OP_NOT_LIKE ? static_cast<Kern>(k_like_scanall<true, true>) : static_cast<Kern>(k_like_scanall<false, true>))
+                          : (pred.op == LC_OP_NOT_LIKE ? static_cast<Kern>(k_like_scanall<true, false>) : static_cast<Kern>(k_like_scanall<false, false>));
     if (lds > 64 * 1024) {
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                  160 * 1024 - 512);
