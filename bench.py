@@ -344,6 +344,8 @@ def time_pred(scan, expr, torch, stream, iters, kernel, words=None, with_cold=Tr
     cold = scan.eval_timed_cold(expr, mask.data_ptr(), max(3, iters // 4), FLUSH_BYTES, 0, counts.data_ptr(), stream) \
         if with_cold else None
     alg, own = scan.traffic_model(expr, False)
+    if kernel is None:  # the kernel the library says it ran (lc_scan_explain: "k_like_scanall (...)", "k_like_flat: ...")
+        kernel = scan.explain(expr).split(" ")[0].rstrip(":")
     traffic, traffic_src = measured_traffic(tkey, kernel) if tkey else (None, None)
     r = roofline(kernel, ms, alg, own, cold, traffic, traffic_src)
     if probe is not None:
@@ -907,7 +909,7 @@ def secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream
             scan = cache2.scan(ids)
             hint = lc.CacheExpression.SUBSTRING_SEARCH
             expr = lc.LiquidExpr.try_new("like", pattern, pa.string(), hint)
-            r, _, _ = time_pred(scan, expr, torch, stream, max(3, iters // 2), "k_str_pred", with_cold=True, probe=(cache2, N),
+            r, _, _ = time_pred(scan, expr, torch, stream, max(3, iters // 2), None, with_cold=True, probe=(cache2, N),
                                 tkey=name)
             out[name] = r
             scan.close()

@@ -66,7 +66,7 @@ LC_BENCH_API int32_t lc_bench_eval_timed(void* ctx, void* scan, const void* pred
                                          float* out_avg_ms);
 
 /* Test aid (host only, no context): the inverted row lists lc_stage attaches to byte-view entries of substring-search
- * columns — u16 offsets[d + 1], then the valid rows grouped by dictionary key — for `n` (<= 8192) keys, an optional
+ * columns — u16 offsets[d + 1], then the valid rows grouped by dictionary key — for `n` (<= 65535) keys, an optional
  * LSB-first validity bitmap and a dictionary of `d` values.  Returns the number of u16 written to `out` (d + 1 + n + 32;
  * 0: bad arguments or `cap` too small). */
 LC_BENCH_API size_t lc_debug_row_lists(const uint16_t* keys, const uint8_t* validity, uint32_t n, uint32_t d, uint16_t* out,

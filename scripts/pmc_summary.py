@@ -45,11 +45,11 @@ for k, kb in calib.items():
         factors[shape] = CALIB_BYTES / (kb * 1024.0)
 out["fetch_size_calibration"] = {"bytes_per_launch": CALIB_BYTES, "real_bytes_per_reported_byte": factors}
 # dominant access shape of each kernel family
-SHAPE = {"k_str_pred": "coalesced8", "k_like_lean": "coalesced8", "k_like_flat": "coalesced16", "k_fixed_pred_reg": "coalesced4",
+SHAPE = {"k_str_pred": "coalesced8", "k_like_lean": "coalesced8", "k_like_flat": "coalesced16", "k_like_scanall": "coalesced8", "k_fixed_pred_reg": "coalesced4",
          "k_fixed_pred": "coalesced16", "k_fixed_chain": "coalesced4", "k_fixed_gather": "coalesced16",
          "k_sel_entry_counts": "coalesced8", "k_scan_": "coalesced8"}
 FAMILIES = ("k_fixed_pred_reg", "k_fixed_pred", "k_fixed_chain", "k_fixed_gather", "k_sel_entry_counts", "k_scan_", "k_str_pred",
-            "k_like_lean", "k_like_flat")
+            "k_like_lean", "k_like_flat", "k_like_scanall")
 SUMMED = {"gather_10pct"}  # every kernel of the workload belongs to one evaluation
 for d in sorted(glob.glob(os.path.join(root, "*_FETCH_SIZE"))):
     wl = os.path.basename(d)[: -len("_FETCH_SIZE")]

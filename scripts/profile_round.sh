@@ -11,13 +11,14 @@ mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
 # one column, back to back (rocprof averages then describe hot launches; the cold figures come from the bench line itself)
 B="python $R/bench.py --no-secondary --no-needle-classes --no-cpu-baseline --no-cold --rotate 1 --steps 20 --warmup 3"
-KREGEX="k_str_pred|k_fixed_pred|k_like_lean|k_like_flat|k_fixed_chain|k_fixed_gather|k_sel_entry_counts|k_scan_"
+KREGEX="k_str_pred|k_fixed_pred|k_like_lean|k_like_flat|k_like_scanall|k_fixed_chain|k_fixed_gather|k_sel_entry_counts|k_scan_"
 declare -A WL
 WL[url_like]="$B --workload url_like"
 WL[url_like_k_like_lean]="$B --workload url_like --like-path 3"
 WL[url_like_k_str_pred]="$B --workload url_like --like-path 1"
 WL[url_like_no_signatures]="$B --workload url_like --no-signatures"
 WL[url_like_no_fingerprints]="$B --workload url_like --no-fingerprints"
+WL[url_like_1byte]="$B --workload url_like --needle q --needle-ppm 0"
 WL[int64_gt_w62]="$B --workload int64_gt --int-bits 62"
 WL[int64_gt_w17]="$B --workload int64_gt --int-bits 17 --int-base 1000"
 WL[date32_gt_w12]="$B --workload int64_gt --int-kind date32 --int-bits 12 --int-base 8036"
@@ -25,7 +26,7 @@ WL[int16_gt_w12]="$B --workload int64_gt --int-kind int16 --int-bits 12 --int-ba
 WL[decimal_gt_w4]="$B --workload int64_gt --int-kind decimal --int-bits 4 --int-base 0"
 WL[tpch_q6]="python $R/bench.py --workload tpch_q6 --steps 10 --warmup 2 --no-secondary --no-cpu-baseline"
 WL[gather_10pct]="python $R/scripts/gather_profile.py --frac 0.1"
-ALL="url_like url_like_k_like_lean url_like_k_str_pred url_like_no_signatures url_like_no_fingerprints int64_gt_w62 int64_gt_w17 date32_gt_w12 int16_gt_w12 decimal_gt_w4 tpch_q6 gather_10pct"
+ALL="url_like url_like_k_like_lean url_like_k_str_pred url_like_no_signatures url_like_no_fingerprints url_like_1byte int64_gt_w62 int64_gt_w17 date32_gt_w12 int16_gt_w12 decimal_gt_w4 tpch_q6 gather_10pct"
 WORKLOADS=${WORKLOADS:-$ALL}
 for wl in $WORKLOADS; do
   cmd=${WL[$wl]}
