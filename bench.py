@@ -568,7 +568,7 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                                                    args.needle_ppm, offs.ctypes.data, data.ctypes.data, data.size)
             v0 = bytes(data[:nb][offs[0]: offs[1]])
             for tag, op, lit in (("string_eq_existing_value", "=", v0), ("string_lt", "<", b"http://m"), ("string_ge", ">=", b"http://m")):
-                r, _, _ = time_pred(url_scan, lc.LiquidExpr.try_new(op, lit, pa.string()), torch, stream, max(3, iters // 2), "k_str_pred")
+                r, _, _ = time_pred(url_scan, lc.LiquidExpr.try_new(op, lit, pa.string()), torch, stream, max(3, iters // 2), None)
                 r["rows"] = int(url_scan.rows)
                 r["predicate"] = "URL %s %r" % (op, lit[:40])
                 out[tag] = r

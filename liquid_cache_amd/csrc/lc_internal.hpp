@@ -192,6 +192,7 @@ struct lc_scan {
     bool any_without_signatures = false, any_patch = false, any_fingerprints = false, any_float = false;
     bool any_multi_empty = false;          // byte views: some dictionary holds several empty values (k_like_scanall is not used)
     bool last_like_scanall = false;        // the last [NOT] LIKE evaluation went to k_like_scanall (EXPLAIN, byte model)
+    bool last_eq_flat = false;             // the last `=` / `<>` evaluation went to k_like_flat (EXPLAIN, byte model)
     int32_t uniform_slot = -1;             // byte views: the symbol-table slot when every entry shares one, else -1
     uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
     size_t or_tmp_words = 0;

@@ -223,6 +223,9 @@ struct StrPred {
     // dictionary values it accepts are then matched exactly against the pattern (`needle`: the literal '%...%', verify_len
     // bytes, device copy).  0: the automaton's answer is exact.
     uint32_t verify_len;
+    // mode 1 through k_like_flat only: != 0 makes the evaluation `=` / `<>` on the needle (its length) instead of [NOT] LIKE —
+    // a value equals the needle exactly when it contains it and has its length (lc_runtime.cpp: eq_via_index)
+    uint32_t eq_len;
     uint8_t needle_inline[kInlineNeedle];
 };
 

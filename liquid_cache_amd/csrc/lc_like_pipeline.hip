@@ -101,6 +101,8 @@ struct LikePipeline {
     bool lean_ok = false;                      // every entry fits k_like_lean's 1 KB of mask words (<= kPostLdsRows rows)
     uint32_t flat_mask_bytes = 0;              // k_like_flat: LDS bytes of one entry's mask words (the scan's largest entry)
     bool flat = false, flat_tried = false;
+    bool eq_ok = false;                        // k_like_flat can evaluate `=` / `<>` (prefix keys everywhere)
+    const DevSymtab* d_symtabs = nullptr;      // the scan's
     uint64_t* d_slices = nullptr;
     FlatGroup* d_groups = nullptr;
     uint32_t n_groups = 0, n_group_slots = 0;  // groups with entries / records incl. the padding of workgroup batches
@@ -526,8 +528,9 @@ struct alignas(16) FlatEntry {  // what the walk needs of an entry, copied to LD
     const uint64_t* validity;      // NOT LIKE only
     const uint32_t* fingerprints;  // NOT LIKE only
     int32_t slope, intercept;
-    uint32_t d, offset_bytes;
-    uint32_t pad[2];
+    uint32_t d;
+    uint32_t ob_sp;                // offset_bytes | shared_prefix_len << 8
+    const uint8_t* prefix_keys;    // `=` / `<>` only: byte 7 of a key = length of the value behind the shared prefix (255: >= 255)
 };
 static_assert(sizeof(FlatEntry) == 64, "FlatEntry layout");
 struct alignas(64) FlatGroup {
@@ -553,6 +556,10 @@ struct FlatArgs {
     uint64_t slice_words;                   // u64 words of one slice (= n_slots * group_words)
     uint32_t group_words;                   // words of a group inside a slice: the largest group of the scan, even
     uint32_t mask_bytes;                    // kBig: LDS bytes of one entry's mask words (a multiple of 1 KB)
+    uint32_t eq_len;                        // != 0: `=` / `<>` (kNot) on the needle: a match must also have this length
+    const DevSymtab* symtabs;               // eq_len: lengths of values of 255 bytes and more are counted from their codes
+    const uint8_t* eq_lit;                  // eq_len > kMaxNeedleAutomaton: the whole literal (the automaton ran over its first
+                                            // 63 bytes): values of its length that contain those are compared byte by byte
     const uint8_t* automata;
     uint32_t automaton_stride;
     uint32_t nl;
@@ -697,7 +704,7 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
             const uint16_t* prow = nullptr;
             if (cl && LC_FLAT_STOP != 12) {
                 const FlatEntry& E = cold[ej];
-                const uint32_t ob = E.offset_bytes;
+                const uint32_t ob = E.ob_sp & 0xFFu;
                 const uint64_t v = load_unaligned<uint64_t>(E.residuals + size_t(key) * ob);
                 const uint32_t pb = load_unaligned<uint32_t>(reinterpret_cast<const uint8_t*>(E.postings) + 2u * size_t(key));
                 const uint32_t slope = uint32_t(E.slope), intercept = uint32_t(E.intercept);
@@ -769,7 +776,41 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
                 if (hit && tlive) hitflag[r] = 1;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const bool res = cl && hitflag[lane] != 0;
+            bool res = cl && hitflag[lane] != 0;
+            if (a.eq_len != 0 && res) {
+                // `=`: the value contains the needle; it IS the needle when it is as long.  The prefix key knows the length
+                // behind the entry's shared prefix (raw/fsst_buffer.rs:162-188; 255: that many or more, or unknown — then
+                // the symbol lengths of the value's codes are added up)
+                const FlatEntry& E = cold[ej];
+                const uint32_t rl = uint32_t(as_global(E.prefix_keys)[size_t(key) * 8u + 7u]);
+                uint32_t vlen = (E.ob_sp >> 8) + rl;
+                if (rl == 255u) {
+                    const DevSymtab& st = a.symtabs[G->slot];
+                    const uint8_t* p = reinterpret_cast<const uint8_t*>(abs_start);
+                    vlen = 0;
+                    for (uint32_t i = 0; i < len; i++) {
+                        const uint32_t code = as_global(p)[i];
+                        if (code == 255u) { vlen += 1u; i++; }
+                        else vlen += st.len[code];
+                    }
+                }
+                res = vlen == a.eq_len;
+                if (res && a.eq_len > uint32_t(kMaxNeedleAutomaton)) {
+                    // a literal the automaton could not hold: decode and compare (same length, so every byte is one of both)
+                    const DevSymtab& st = a.symtabs[G->slot];
+                    const uint8_t* p = reinterpret_cast<const uint8_t*>(abs_start);
+                    uint32_t j = 0;
+                    for (uint32_t i = 0; i < len && res; i++) {
+                        const uint32_t code = as_global(p)[i];
+                        uint64_t sym;
+                        uint32_t sl;
+                        if (code == 255u) { i++; sym = i < len ? as_global(p)[i] : 0u; sl = 1; }
+                        else { sym = st.sym[code]; sl = st.len[code]; }
+                        for (uint32_t k = 0; k < sl && res; k++, j++)
+                            res = j < a.eq_len && uint32_t((sym >> (8u * k)) & 0xFFu) == uint32_t(as_global(a.eq_lit)[j]);
+                    }
+                }
+            }
             uint64_t matched = __ballot(res);
             if (a.stats) {
                 const uint64_t lb = wave_sum_u64(uint64_t(len));
@@ -866,7 +907,7 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
             // filter of the needle (comparisons.rs:167-180, :644-648); a matching value passes it
             const FlatEntry& E = cold[j];
             validity = E.validity;
-            invert = ((any_match >> j) & 1u) != 0;
+            invert = ((any_match >> j) & 1u) != 0 || a.eq_len != 0;  // (`<>` is the complement over the valid rows, no candidate rule)
             for (uint32_t i0 = 0; !invert && i0 < E.d; i0 += kWave) {
                 const uint32_t i = i0 + uint32_t(lane);
                 const uint32_t fp = i < E.d ? as_global(E.fingerprints)[i] : 0u;
@@ -1018,6 +1059,7 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     const uint32_t max_e = std::min<uint32_t>(kFlatMaxE, std::max<uint32_t>(1u, 16384u / mask_bytes));
     if (mask_bytes > 8192u) return LC_OK;
     lp->flat_mask_bytes = mask_bytes;
+    bool eq_ok = true;  // `=` / `<>` through the index need every entry's prefix keys and a shared prefix that fits 24 bits
     auto pad_batch = [&]() {  // a workgroup's groups share a symbol table: close the batch with empty records
         while (groups.size() % kFlatWaves) {
             FlatGroup g;
@@ -1047,7 +1089,8 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
             g.word_off[j] = words;
             g.n_rows[j] = d.n;
             g.e[j] = FlatEntry{d.residuals, d.fsst, d.postings, d.validity, d.fingerprints, d.slope, d.intercept, d.d,
-                               uint32_t(d.offset_bytes), {0, 0}};
+                               uint32_t(d.offset_bytes) | (std::min<uint32_t>(d.shared_prefix_len, 0xFFFFFFu) << 8), d.prefix_keys};
+            if (d.shared_prefix_len >= 0xFFFFFFu || !d.prefix_keys) eq_ok = false;
             words += nw;
             i++;
         }
@@ -1109,6 +1152,8 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     lp->group_words = gw;
     lp->slices_bytes = bytes;
     lp->flat = true;
+    lp->eq_ok = eq_ok;
+    lp->d_symtabs = s->d_symtabs;
     return LC_OK;
 }
 
@@ -1254,6 +1299,9 @@ lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L,
     fa.slice_words = uint64_t(lp->n_group_slots) * lp->group_words;
     fa.group_words = lp->group_words;
     fa.mask_bytes = lp->flat_mask_bytes;
+    fa.eq_len = force_like ? 0u : p.eq_len;
+    fa.symtabs = lp->d_symtabs;
+    fa.eq_lit = p.needle;
     fa.automata = p.automata;
     fa.automaton_stride = p.automaton_stride;
     fa.nl = p.needle_len;
@@ -1355,6 +1403,21 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
         }
         return "k_str_pred (1-byte needle: no bigram, every fingerprint candidate walked by the many-candidate walkers)";
     }
+    if (sp.p.mode == 1 && sp.p.eq_len != 0) {
+        const bool flat_eq = lp && lp->built && lp->eligible && lp->flat && lp->eq_ok && (path == 0 || path == 4) &&
+                             s->n >= s->ctx->like_pipeline_min_entries;
+        if (!flat_eq) return "k_str_pred";
+        for (const LikePlan& q : lp->plans)
+            if (q.needle == sp.needle) {
+                if (!q.use_lean && path != 4) return "k_str_pred (the literal's substring candidates are not selective)";
+                char buf[256];
+                std::snprintf(buf, sizeof(buf), "k_like_flat (string equality through the scan-level index: the %llu values that contain "
+                              "the literal (%.2f per entry), then their length)", (unsigned long long)q.n_cand,
+                              double(q.n_cand) / double(std::max<uint32_t>(s->n, 1)));
+                return buf;
+            }
+        return "k_str_pred (literal not planned)";
+    }
     if (sp.p.mode == 1 && sp.p.verify_len != 0) return "k_str_pred (needle over 63 bytes: automaton over its first 63, accepted values matched against the pattern)";
     if (path == 1 || path == 5 || s->n < s->ctx->like_pipeline_min_entries) return "k_str_pred";
     if (!lp || !lp->built) return "k_str_pred (scan not evaluated yet)";
@@ -1410,6 +1473,7 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
                 uint64_t b = uint64_t(lp->n_group_slots) * (kFlatHotBytes + nb * lp->group_words * 8) + s->seg_offsets.back() * 8 +
                              (with_counts ? uint64_t(s->n) * 4 : 0);
                 b += std::min<uint64_t>(q.n_cand, lp->n_groups) * 64 * kFlatMaxE + q.n_cand * 12 + q.cand_bytes + q.hits * 2;
+                if (sp.p.eq_len != 0) b += q.matches * 8;  // `=`: the prefix key of every value that contains the literal
                 return b;
             }
             uint64_t b = uint64_t(lp->n_lean) * 16 + uint64_t(s->n) * 64 + s->seg_offsets.back() * 8 + (with_counts ? uint64_t(s->n) * 4 : 0);
@@ -1476,6 +1540,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     }
     const bool use_flat = want_flat && lp->flat;
     if (!use_flat && !lp->lean_ok) return LC_OK;  // entries of more than 8,192 rows without the scan-level index: k_str_pred
+    if (p.eq_len != 0 && !(use_flat && lp->eq_ok)) return LC_OK;  // `=` / `<>`: the scan-level kernel only
     LikePlan* plan = nullptr;
     for (LikePlan& q : lp->plans)
         if (q.needle == sp.needle) plan = &q;

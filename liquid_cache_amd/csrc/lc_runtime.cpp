@@ -2563,6 +2563,33 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         if (s->any_fingerprints)
                 return fail(LC_UNSUPPORTED, "general LIKE patterns apply to byte views without fingerprints (the "
                                             "reference requires %needle% on SubstringSearch columns)");
+    // `=` / `<>` with a literal of 2..63 bytes on a scan that can have the scan-level signature index: a value equals the
+    // literal exactly when it CONTAINS it and has its length, so the evaluation is the substring search of k_like_flat (a
+    // handful of candidates per entry instead of every prefix key) followed by a length test.  Anything the index path does
+    // not take (unselective literals, entries without the index, validity outputs) falls through to k_str_pred below.
+    StrPredHost sq;
+    bool try_eq = false;
+    if (sp.p.mode == 0 && (sp.p.op == LC_OP_EQ || sp.p.op == LC_OP_NE) && sp.needle.size() >= 2 &&
+        (ctx->like_path == 0 || ctx->like_path == 4) && !d_valid_out &&
+        !d_cand_bytes && s->any_fingerprints && !s->any_without_signatures && !pred2) {
+        std::vector<uint8_t> pat;
+        pat.push_back('%');
+        pat.insert(pat.end(), sp.needle.begin(), sp.needle.end());
+        pat.push_back('%');
+        lc_predicate lp2 = *pred;
+        lp2.op = sp.p.op == LC_OP_EQ ? LC_OP_LIKE : LC_OP_NOT_LIKE;
+        lp2.lit = pat.data();
+        lp2.lit_len = pat.size();
+        // (a literal that holds `%`, `_` or a backslash is no plain substring pattern: make_str_pred says mode 3)
+        // (a literal of more than 63 bytes: the automaton runs over its first 63 and k_like_flat compares the values of the
+        // literal's length that contain those byte by byte — `verify` then carries the literal, not a pattern)
+        if (make_str_pred(&lp2, &sq) == LC_OK && sq.p.mode == 1) {
+            sq.p.eq_len = uint32_t(sp.needle.size());
+            sq.p.verify_len = 0;
+            sq.verify = sp.needle;
+            try_eq = true;
+        }
+    }
     std::lock_guard<std::mutex> g(s->mu);
     if (!s->d_wg_ranges) {
         // workgroup records: consecutive entries, at most four, never across a symbol-table change (row-group boundary)
@@ -2603,8 +2630,8 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         LC_HIP(hipMemsetAsync(s->d_work, 0, groups * 64, stream));
     }
     L.d_work = s->d_work;
-    if (sp.p.mode == 1) {
-        const uint32_t stride = automaton_stride(sp.p.needle_len);
+    auto build_automata = [&](StrPredHost& q) -> lc_status {
+        const uint32_t stride = automaton_stride(q.p.needle_len);
         const size_t nst = s->n_symtabs;
         const size_t need = size_t(stride) * std::max<size_t>(nst, 1);
         if (need > s->automata_cap) {
@@ -2617,14 +2644,42 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         }
         // a query evaluates one pattern over and over: the folded automata are rebuilt only when the needle or the
         // set of symbol tables changed (stream order keeps earlier launches valid)
-        if (s->automata_symtabs != nst || s->automata_needle != sp.needle) {
-            LC_HIP(launch_str_automata(s->d_symtabs, uint32_t(nst), sp.needle.data(), sp.p.needle_len,
-                                       s->d_automata, stream));
-            s->automata_needle = sp.needle;
+        if (s->automata_symtabs != nst || s->automata_needle != q.needle) {
+            LC_HIP(launch_str_automata(s->d_symtabs, uint32_t(nst), q.needle.data(), q.p.needle_len, s->d_automata, stream));
+            s->automata_needle = q.needle;
             s->automata_symtabs = nst;
         }
-        sp.p.automata = s->d_automata;
-        sp.p.automaton_stride = stride;
+        q.p.automata = s->d_automata;
+        q.p.automaton_stride = stride;
+        return LC_OK;
+    };
+    if (try_eq) {
+        const lc_status ba = build_automata(sq);
+        if (ba != LC_OK) return ba;
+        if (sq.p.eq_len > uint32_t(kMaxNeedleAutomaton)) {
+            const size_t need = sq.verify.size() + 16;
+            LC_HIP(hipStreamSynchronize(stream));  // a previous evaluation may still read the old literal
+            if (need > s->needle_cap) {
+                pool_release(ctx, s->d_needle);
+                s->d_needle = static_cast<uint8_t*>(pool_alloc(ctx, need));
+                if (!s->d_needle) { s->needle_cap = 0; return fail(LC_ERR_OOM, "hipMalloc (needle)"); }
+                s->needle_cap = need;
+            }
+            LC_HIP(hipMemcpyAsync(s->d_needle, sq.verify.data(), sq.verify.size(), hipMemcpyHostToDevice, stream));
+            LC_HIP(hipStreamSynchronize(stream));  // (`sq` is a local)
+            sq.p.needle = s->d_needle;
+        }
+        bool handled = false, many = false;
+        const lc_status ps = like_pipeline_eval(ctx, s, sq, L, stream, &handled, &many);
+        if (ps != LC_OK) return ps;
+        s->last_eq_flat = handled;
+        if (handled) { s->last_like_scanall = false; return LC_OK; }
+    } else {
+        s->last_eq_flat = false;
+    }
+    if (sp.p.mode == 1) {
+        const lc_status ba = build_automata(sp);
+        if (ba != LC_OK) return ba;
     }
     if (sp.p.mode == 1 && sp.p.verify_len != 0) {
         const size_t need = sp.verify.size() + 16;
@@ -3075,6 +3130,30 @@ lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t wi
             }
         }
     }
+    if (!like && (pred->op == LC_OP_EQ || pred->op == LC_OP_NE) && pred->lit_tag == LC_LIT_BYTES) {
+        // `=` / `<>` that the plain evaluation sends through the scan-level index: that kernel's bytes (the substring search
+        // of the literal + 8 bytes of prefix key per value that contains it), not k_str_pred's
+        uint64_t* d_m2 = static_cast<uint64_t*>(pool_alloc(ctx, std::max<uint64_t>(s->seg_offsets.back(), 1) * 8));
+        if (d_m2) {
+            const lc_status r2 = scan_eval_impl(ctx, s, pred, nullptr, d_m2, nullptr, nullptr, nullptr, nullptr);
+            (void)hipDeviceSynchronize();
+            pool_release(ctx, d_m2);
+            if (r2 == LC_OK) {
+                std::lock_guard<std::mutex> g(s->mu);
+                if (s->last_eq_flat) {
+                    StrPredHost sq;
+                    sq.needle.assign(static_cast<const uint8_t*>(pred->lit),
+                                     static_cast<const uint8_t*>(pred->lit) + std::min<size_t>(pred->lit_len, size_t(kMaxNeedleAutomaton)));
+                    sq.p.mode = 1;
+                    sq.p.op = LC_OP_LIKE;
+                    sq.p.needle_len = uint32_t(sq.needle.size());
+                    sq.p.eq_len = uint32_t(pred->lit_len);
+                    const uint64_t pb = like_pipeline_bytes(s, sq, false);
+                    if (pb) own = pb;
+                }
+            }
+        }
+    }
     *out_algorithmic = alg;
     *out_kernel_bytes = own;
     return LC_OK;
@@ -3101,6 +3180,15 @@ lc_status lc_scan_explain(lc_scan* s, const lc_predicate* pred, char* out, size_
                 text = "k_like_scanall (every dictionary value walked, lane per 8-byte word)" + text.substr(10);
         } else {
             text = "k_str_pred";
+            if (s->last_eq_flat && sp.p.mode == 0 && (sp.p.op == LC_OP_EQ || sp.p.op == LC_OP_NE)) {
+                // (what the last `=` / `<>` on this scan really launched: the substring search of the literal + a length test)
+                StrPredHost sq;
+                sq.needle.assign(sp.needle.begin(), sp.needle.begin() + long(std::min(sp.needle.size(), size_t(kMaxNeedleAutomaton))));
+                sq.p.mode = 1;
+                sq.p.needle_len = uint32_t(sq.needle.size());
+                sq.p.eq_len = sp.p.needle_len;
+                text = like_pipeline_explain(s, sq);
+            }
         }
     }
     std::snprintf(out, cap, "%s", text.c_str());

@@ -47,11 +47,13 @@ def _long_value_pool(rng, d):
     return out
 
 
-def _stage_entries(cache, lo, specs, rng, file_id):
-    """specs: (rows, distinct, nulls) per entry, ONE symbol table; returns (ids, [(rows, liquid, st)])."""
+def _stage_entries(cache, lo, specs, rng, file_id, extra=()):
+    """specs: (rows, distinct, nulls) per entry, ONE symbol table; returns (ids, [(rows, liquid, st)]).  `extra`: values every
+    entry's dictionary holds besides its own."""
     pools = []
     for n, d, nulls in specs:
-        pool = _long_value_pool(rng, d)
+        pool = list(extra) + _long_value_pool(rng, max(d - len(extra), 1))
+        d = len(pool)
         rows = [pool[i] for i in range(min(d, n))] + [pool[int(k)] for k in rng.integers(0, d, size=max(0, n - d))]
         rows = [rows[int(i)] for i in rng.permutation(len(rows))]
         if nulls:
@@ -207,6 +209,42 @@ def test_entries_of_more_than_65536_rows(product_lib, oracle, like_path):
             sel2[-1] = True
             back = cache.get(ids[b]).with_selection(sel2).read()
             assert back.to_pylist() == [rows[int(i)] for i in np.flatnonzero(sel2)]
+        scan.close()
+    finally:
+        cache.close()
+
+
+@pytest.mark.parametrize("like_path", [0, 4, 1])
+def test_string_equality_through_the_scan_level_index(product_lib, oracle, like_path):
+    """`=` / `<>` with a literal of 2 bytes or more: k_like_flat finds the dictionary values that CONTAIN the literal (its first
+    63 bytes) and keeps those of its length (longer literals: compared byte by byte; byte_view_array/comparisons.rs:21-151
+    compares the decoded value).  Literals that are values, that
+    are proper substrings of values (of values under and over 255 bytes: the prefix key's length byte saturates there), that
+    extend a value, that are absent; with and without a selection; against the oracle."""
+    lo = oracle
+    rng = np.random.default_rng(2163 + like_path)
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1, like_path=like_path or None).build()
+    try:
+        base = b"http://example.org/equal/literal-of-forty-bytes"
+        extra = [base, base + b"/longer", base + b"x" * 300, b"ab", b"abc", b"zab", base[:20]]
+        ids, flat = _stage_entries(cache, lo, [(8192, 1500, False), (5000, 900, True), (8192, 2000, False), (300, 200, True),
+                                               (16384, 2500, False)], rng, 51, extra=extra)
+        scan = cache.scan(ids)
+        values = [v for rows, _, _ in flat for v in rows if v is not None]
+        lits = list(extra) + [base + b"/longe", base[1:], b"bc", b"zzzzqqq", b"example.org/equal"]
+        lits += [values[int(i)] for i in rng.integers(0, len(values), size=8)]  # (most are longer than the 63-byte automaton)
+        longv = max(values, key=len)
+        lits += [longv, longv[:-1] + b"\x01", longv[:70], longv[:63], longv[:64]]
+        lits = [x for x in lits if 2 <= len(x)]
+        n = _check_scan(lo, scan, flat, lits, rng, "path %d" % like_path, ops=("eq", "ne"))
+        assert n >= len(flat) * 2 * len(lits)
+        expr = lc.LiquidExpr.try_new("=", base, pa.binary(), HINT)
+        scan.eval_to_host(expr)  # (the plans of a scan are a small LRU: this literal's is the newest again)
+        how = scan.explain(expr)
+        if like_path in (0, 4):
+            assert how.startswith("k_like_flat (string equality"), how
+        else:
+            assert how.startswith("k_str_pred"), how
         scan.close()
     finally:
         cache.close()
