@@ -976,24 +976,26 @@ struct FlatBuildArgs {
 template <bool kUni>
 __global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
     constexpr int kBits = kUni ? 256 : kFlatBits;
-    constexpr int kSigWords = kBits / 64;
     __shared__ uint64_t s_sym[256];
     __shared__ uint8_t s_len[256];
-    __shared__ uint64_t stage[kBits][8];
+    __shared__ uint64_t stage[kBits][8];  // [slice][column]: bit l of a word = the value lane l of the column's wave decodes
     const StrDesc d = a.descs[blockIdx.y];
     const uint32_t nw = (d.d + 63u) >> 6;
     if (d.d == 0 || blockIdx.x * 8u >= nw) return;
     const DevSymtab& st = a.symtabs[d.symtab_slot];
     s_sym[threadIdx.x] = st.sym[threadIdx.x];
     s_len[threadIdx.x] = st.len[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < uint32_t(kBits) * 8u; i += 256u) (&stage[0][0])[i] = 0;
     __syncthreads();
     const int lane = lane_id(), wave = wave_id();
+    // A lane sets ITS bit of the slice word straight in LDS (the transposition the index needs happens by addressing: until
+    // round 4's end every lane kept a 512-bit set in registers — eight compare / select pairs per decoded byte — and 512
+    // ballots per 64 values turned them over: 17.6 ms for the 100 M-row URL column).  A column belongs to one wave, so
+    // only its own lanes meet in a word: when all active lanes hold the same bit (the common prefixes of a URL column:
+    // same codes, same expansions, in lock step) one lane stores their mask, otherwise an LDS atomic OR per lane.
     for (uint32_t q = 0; q < 2; q++) {
         const uint32_t cc = uint32_t(wave) * 2u + q;  // column of the stage
         const uint32_t c = blockIdx.x * 8u + cc;
-        uint64_t mine[kSigWords];
-#pragma unroll
-        for (int r = 0; r < kSigWords; r++) mine[r] = 0;
         const uint32_t i = c * 64u + uint32_t(lane);
         if (c < nw && i < d.d) {
             uint32_t start, stop;
@@ -1016,23 +1018,18 @@ __global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
                         const int cur = int((sym >> (8u * t)) & 0xFFu);
                         if (kUni || prev >= 0) {
                             const uint32_t bit = kUni ? uint32_t(cur) : flat_bigram_bit(uint32_t(prev), uint32_t(cur));
-#pragma unroll
-                            for (int r = 0; r < kSigWords; r++)
-                                if (int(bit >> 6) == r) mine[r] |= uint64_t(1) << (bit & 63u);
+                            const uint64_t active = __ballot(true);
+                            const uint32_t b0 = uint32_t(__builtin_amdgcn_readfirstlane(int(bit)));
+                            if (__ballot(bit != b0) == 0) {
+                                if (uint32_t(lane) == uint32_t(__ffsll((long long)active)) - 1u) stage[b0][cc] |= active;
+                            } else {
+                                atomicOr(reinterpret_cast<unsigned long long*>(&stage[bit][cc]), 1ull << lane);
+                            }
                         }
                         prev = cur;
                     }
                 }
             }
-        }
-#pragma unroll
-        for (int r = 0; r < kSigWords; r++) {
-            uint64_t keep = 0;  // lane b ends up with the word of slice 64 r + b
-            for (int b = 0; b < 64; b++) {
-                const uint64_t wv = __ballot((mine[r] >> b) & 1);
-                if (lane == b) keep = wv;
-            }
-            stage[64 * r + lane][cc] = keep;
         }
     }
     __syncthreads();

@@ -36,7 +36,7 @@ def main():
     cold = scan.eval_timed_cold(expr, mask.data_ptr(), 5, bench.FLUSH_BYTES, 0, counts.data_ptr(), stream) if a.cold else float("nan")
     print("%-8s path %d  hot %.2f us  cold %.2f us  hits %d  %s" % (
         os.path.basename(os.environ.get("LC_LIB_PATH", "default")).replace("libliquid_cache_amd_", "").replace(".so", ""),
-        a.like_path, hot * 1e3, cold * 1e3, int(counts.sum(dtype=torch.int64).item()), scan.explain(expr)[:60]), flush=True)
+        a.like_path, hot * 1e3, cold * 1e3, int(counts.sum(dtype=torch.int64).item()), scan.explain(expr)[-110:]), flush=True)
     scan.close()
     cache.close()
 
