@@ -16,6 +16,8 @@
 // One wave per entry.  The groups of an entry live in an LDS hash table keyed by the group key (claimed with LDS
 // compare-and-swap by the lanes of a 64-row batch in parallel); an entry whose selected rows hold more distinct groups
 // than the table emits what it has and goes on — duplicate (entry, group) partials are still partials.
+#include <algorithm>
+#include <cstdio>
 #include "lc_device.hpp"
 #include "lc_internal.hpp"
 
@@ -58,6 +60,24 @@ __device__ __noinline__ int dict_compare(const StrDesc& d, const DevSymtab& st, 
     uint32_t sa, ea, sb, eb;
     str_offset_pair(d, ka, sa, ea);
     str_offset_pair(d, kb, sb, eb);
+    // Equal compressed bytes decode to equal bytes: the common compressed prefix is skipped eight codes per load, and only
+    // what follows is decoded (the values of a group are URLs of one site: the decoding iterator costs three dependent
+    // loads per code, 20-40 us for two 76-byte values — the slowest wave's two such compares were most of this kernel).
+    // The skip never stops inside an escape pair (marker 255 + literal): an odd run of 255s before the stop gives one back.
+    {
+        const uint32_t mc = min(ea - sa, eb - sb);
+        uint32_t common = 0;
+        while (common + 8u <= mc) {
+            const uint64_t wa = load_unaligned<uint64_t>(d.fsst + sa + common), wb = load_unaligned<uint64_t>(d.fsst + sb + common);
+            if (wa != wb) { common += uint32_t(__builtin_ctzll(wa ^ wb)) >> 3; break; }
+            common += 8u;
+        }
+        uint32_t run = 0;
+        while (run < common && d.fsst[sa + common - 1u - run] == 255u) run++;
+        common -= run & 1u;
+        sa += common;
+        sb += common;
+    }
     FsstIter ia{sa, ea, 0, 0, 0, false}, ib{sb, eb, 0, 0, 0, false};
     fsst_iter_load(ia, st, d.fsst);
     fsst_iter_load(ib, st, d.fsst);
@@ -70,26 +90,46 @@ __device__ __noinline__ int dict_compare(const StrDesc& d, const DevSymtab& st, 
     return ia.at_end ? (ib.at_end ? 0 : -1) : 1;
 }
 
-__global__ __launch_bounds__(64) void k_group_partials(GroupArgs a) {
-    __shared__ uint32_t t_key[kGroupSlots];
-    __shared__ uint32_t t_row[kGroupSlots];    // a row of the group
-    __shared__ uint32_t t_cnt[kGroupSlots];
-    __shared__ uint32_t t_best[kGroupSlots];   // row holding the MIN / MAX value so far, kNoRow: none yet
-    __shared__ uint32_t n_distinct;
+// One wave per entry, two per workgroup (2 x 16 KB of tables), a persistent grid: the waves stride over the entries.  A
+// selective filter leaves five entries in six without a row (a wave reads their 128 selection words and moves on); an entry
+// that has one is a chain of ~8 dependent round trips (descriptors, selection words, validity and keys of both columns, the
+// returning append to the output), which is what the kernel's time is made of (q21.sql over 100 M rows: 2,153 rows in
+// ~2,000 entries, 80 us; until the end of round 4 one 64-thread workgroup per entry and one load per selection WORD: 98 us).
+constexpr uint32_t kGroupWaves = 2;
+__global__ __launch_bounds__(kGroupWaves * 64) void k_group_partials(GroupArgs a) {
+    __shared__ uint32_t s_key[kGroupWaves][kGroupSlots];
+    __shared__ uint32_t s_row[kGroupWaves][kGroupSlots];    // a row of the group
+    __shared__ uint32_t s_cnt[kGroupWaves][kGroupSlots];
+    __shared__ uint32_t s_best[kGroupWaves][kGroupSlots];   // row holding the MIN / MAX value so far, kNoRow: none yet
+    __shared__ uint32_t s_distinct[kGroupWaves];
     const int lane = lane_id();
-    const uint32_t entry = blockIdx.x;
-    const StrDesc& g = a.g_descs[entry];
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    // (the wave's tables by name, not through pointers: a generic pointer to LDS makes every access a flat one, and a flat
+    // access waits for every outstanding global load as well)
+#define t_key s_key[wave]
+#define t_row s_row[wave]
+#define t_cnt s_cnt[wave]
+#define t_best s_best[wave]
+#define n_distinct s_distinct[wave]
+    for (uint32_t entry = blockIdx.x * kGroupWaves + wave; entry < a.n_entries; entry += gridDim.x * kGroupWaves) {
+    // (by value: through a reference every use of a pointer field is another global load in front of the load it is for —
+    // the stores and atomics in between keep the compiler from holding it in a register)
+    const StrDesc g = a.g_descs[entry];
     const uint32_t nwords = (g.n + 63u) >> 6;
-    // anything selected in this entry?  (a selective filter leaves most entries empty)
-    uint32_t any = 0;
-    for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
-        uint64_t sw = a.selection ? a.selection[g.mask_word_off + w] : ~uint64_t(0);
-        if (w == nwords - 1u && (g.n & 63u)) sw &= (uint64_t(1) << (g.n & 63u)) - 1;
-        any |= sw != 0;
+    {   // anything selected in this entry?
+        uint32_t any = 0;
+        for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) {
+            uint64_t sw = a.selection ? a.selection[g.mask_word_off + w] : ~uint64_t(0);
+            if (w == nwords - 1u && (g.n & 63u)) sw &= (uint64_t(1) << (g.n & 63u)) - 1;
+            any |= sw != 0;
+        }
+        if (__ballot(any != 0) == 0) continue;
     }
-    if (__ballot(any != 0) == 0) return;
-    const StrDesc* v = a.v_descs ? a.v_descs + entry : nullptr;
-    const DevSymtab* vst = v ? a.symtabs + v->symtab_slot : nullptr;
+    const bool has_v = a.v_descs != nullptr;
+    StrDesc vd{};
+    if (has_v) vd = a.v_descs[entry];
+    const StrDesc* v = has_v ? &vd : nullptr;
+    const DevSymtab* vst = has_v ? a.symtabs + vd.symtab_slot : nullptr;
     auto clear_table = [&]() {
         for (uint32_t i = uint32_t(lane); i < kGroupSlots; i += kWave) t_key[i] = kEmptyKey;
         if (lane == 0) n_distinct = 0;
@@ -110,11 +150,23 @@ __global__ __launch_bounds__(64) void k_group_partials(GroupArgs a) {
         }
     };
     clear_table();
-    for (uint32_t w = 0; w < nwords; w++) {
-        uint64_t sw = a.selection ? a.selection[g.mask_word_off + w] : ~uint64_t(0);  // wave-uniform address
-        if (w == nwords - 1u && (g.n & 63u)) sw &= (uint64_t(1) << (g.n & 63u)) - 1;
-        sw = uniform_u64(sw);
-        if (sw == 0) continue;
+    // 64 selection words at a time, one per lane, and only the non-empty ones are visited: a selective filter leaves one
+    // or two words of an entry with a row (one dependent load per WORD of the entry, 128 of them, made this kernel 98 us
+    // for the 2,153 rows of q21.sql over 100 M)
+    for (uint32_t wb = 0; wb < nwords; wb += kWave) {
+      const uint32_t wl = wb + uint32_t(lane);
+      uint64_t sw_l = 0;
+      if (wl < nwords) {
+          sw_l = a.selection ? a.selection[g.mask_word_off + wl] : ~uint64_t(0);
+          if (wl == nwords - 1u && (g.n & 63u)) sw_l &= (uint64_t(1) << (g.n & 63u)) - 1;
+      }
+      uint64_t nz = __ballot(sw_l != 0);
+      while (nz) {
+        const int src = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)nz)) - 1);
+        nz &= nz - 1;
+        const uint32_t w = wb + uint32_t(src);
+        const uint64_t sw = uniform_u64(uint64_t(uint32_t(__shfl(int(uint32_t(sw_l)), src, kWave))) |
+                                        (uint64_t(uint32_t(__shfl(int(uint32_t(sw_l >> 32)), src, kWave))) << 32));
         if (n_distinct >= kGroupFlushAt) {  // (read after the fence of the previous batch: wave uniform)
             emit_table();
             clear_table();
@@ -122,13 +174,15 @@ __global__ __launch_bounds__(64) void k_group_partials(GroupArgs a) {
         const bool active = (sw >> lane) & 1u;
         const uint32_t row = w * 64u + uint32_t(lane);
         uint32_t gk = kNullGroup, vk = kEmptyKey;
-        if (active) {
-            const bool gvalid = g.validity ? ((g.validity[w] >> lane) & 1u) != 0 : true;
-            if (gvalid) gk = g.keys[row];
-            if (v) {
-                const bool vvalid = v->validity ? ((v->validity[w] >> lane) & 1u) != 0 : true;
-                if (vvalid) vk = v->keys[row];
-            }
+        {
+            // the four loads of a row are requested together (validity word and key of both columns): one round trip
+            const uint32_t rc = min(row, g.n - 1u);
+            const uint64_t gvw = g.validity ? g.validity[w] : ~uint64_t(0);
+            const uint32_t gkr = g.keys[rc];
+            const uint64_t vvw = (has_v && vd.validity) ? vd.validity[w] : ~uint64_t(0);
+            const uint32_t vkr = has_v ? uint32_t(vd.keys[rc]) : 0u;
+            if (active && ((gvw >> lane) & 1u)) gk = gkr;
+            if (active && has_v && ((vvw >> lane) & 1u)) vk = vkr;
         }
         if (active) {
             // claim / find the group's slot
@@ -164,8 +218,15 @@ __global__ __launch_bounds__(64) void k_group_partials(GroupArgs a) {
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      }
     }
     emit_table();
+    }
+#undef t_key
+#undef t_row
+#undef t_cnt
+#undef t_best
+#undef n_distinct
 }
 
 }  // namespace
@@ -175,7 +236,12 @@ hipError_t launch_group_partials(const StrDesc* g_descs, const StrDesc* v_descs,
                                  unsigned long long* n_out, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
     GroupArgs a{g_descs, v_descs, symtabs, selection, n_entries, want_max, out, capacity, n_out};
-    hipLaunchKernelGGL(k_group_partials, dim3(n_entries), dim3(64), 0, stream, a);
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    const uint32_t wgs = std::min<uint32_t>((n_entries + kGroupWaves - 1u) / kGroupWaves, uint32_t(cus) * 5u);  // 5 x 32 KB of LDS per CU
+    hipLaunchKernelGGL(k_group_partials, dim3(wgs), dim3(kGroupWaves * 64), 0, stream, a);
     return hipGetLastError();
 }
 
