@@ -2855,7 +2855,9 @@ __global__ __launch_bounds__(kThreads) void k_sel_entry_counts(const Desc* __res
     }
 }
 
-// Exclusive scan of the counts in three small launches (a single workgroup walking ~100 K counts took 150 us):
+// Exclusive scan of the counts in three small launches (a single workgroup walking ~100 K counts took 150 us; round 4 tried
+// one workgroup for up to 16 K counts again — a thread sums 16 consecutive counts, one block scan, 16 offsets written: the
+// 100 M-row gather went from 182 to 207 us at 10 % and from 24 to 29 us at 0.1 %, one CU's latency against three launches):
 //   k_scan_tile_sums   one workgroup per 1024 counts -> tile sum
 //   k_scan_tiles       one workgroup scans the tile sums (exclusive, in place; total appended)
 //   k_scan_apply       every workgroup rescans its tile on top of its tile offset
