@@ -1675,6 +1675,16 @@ def main():
         if args.workload == "url_like" and not args.no_fingerprints and want("like"):
             sec.update(secondary_like_variants(lc, N, args, rank, n_batches, threads, torch, stream, iters, pattern))
         out["secondary"] = sec
+    if args.workload == "url_like" and rank == 0:
+        # a NEW scan over the same entries (a host that creates a scan per query): the scan-level index and the plans of the
+        # scan just destroyed are adopted, so its first evaluation is records + automata + one launch
+        scan.close()
+        scan = cache.scan(ids)
+        torch.cuda.synchronize()
+        t_next = time.perf_counter()
+        scan.eval(expr, mask.data_ptr(), 0, 0, stream)
+        torch.cuda.synchronize()
+        out["next_scan_first_evaluation_us"] = round((time.perf_counter() - t_next) * 1e6, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     scan.close()

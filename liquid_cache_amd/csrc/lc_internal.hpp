@@ -147,6 +147,10 @@ struct lc_ctx {
     // pins, scratch) per call cost more than the kernel.  A call checks a scan out (exclusive use) and back in; scans of
     // evicted / replaced entries move to the graveyard under ctx->mu and are destroyed outside it (scan_cache_reap).
     std::atomic<uint64_t> next_uid{0};
+    // scan-level LIKE indexes of destroyed scans (lc_like_pipeline.hip): a host that creates a scan per query over the same
+    // entries gets the index (and the plans) of the previous one instead of rebuilding 2-3 GB in 13 ms
+    std::mutex like_orphans_mu;
+    std::vector<lc::LikePipeline*> like_orphans;  // most recently orphaned last
     std::mutex scan_cache_mu;
     std::unordered_map<uint64_t, std::vector<lc_scan*>> scan_cache;
     size_t scan_cache_size = 0;
@@ -236,6 +240,10 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out);
 lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
                              bool* handled, bool* many_candidates);
 void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp);
+// lc_scan_destroy: keeps a pipeline that has a scan-level index for the next scan over the same entries (bounded), destroys
+// the others.  like_orphans_clear: context teardown.
+void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp);
+void like_orphans_clear(lc_ctx* ctx);
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp);           // caller holds s->mu
 uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts);  // caller holds s->mu
 

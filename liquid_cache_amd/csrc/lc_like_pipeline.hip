@@ -119,6 +119,7 @@ struct LikePipeline {
     unsigned long long* d_total_acc = nullptr;
     std::vector<LikePlan> plans;
     uint64_t tick = 0;
+    std::vector<uint64_t> uids;  // the publications (Entry::uid) of the scan's entries, in scan order: what the index describes
 };
 
 namespace {
@@ -1195,6 +1196,8 @@ lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t s
 lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
     lp->built = true;
     lp->eligible = false;
+    lp->uids.clear();
+    for (const Entry& e : s->meta) lp->uids.push_back(e.uid);
     if (!s->is_str || s->n == 0) return LC_OK;
     for (const Entry& e : s->meta) {
         if (e.sd.d == 0) continue;  // an all-null entry has no dictionary: no candidates, its mask words are zero
@@ -1376,6 +1379,55 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
 
 }  // namespace
 
+// A destroyed scan's pipeline that carries a scan-level index waits here for the next scan over the same publications of the
+// same entries (same uids in the same order: same blobs, same mask layout — the records hold pointers into the entries,
+// which the adopting scan pins like the scan that built them did).  At most kLikeOrphans of them and a quarter of the
+// device's memory; the oldest goes first.
+constexpr size_t kLikeOrphans = 4;
+static uint64_t pipeline_bytes(const LikePipeline* lp) {
+    return lp->slices_bytes + (lp->d_uni ? lp->slice_words * 8u * 256u : 0u);
+}
+static LikePipeline* like_pipeline_adopt(lc_ctx* ctx, const lc_scan* s) {
+    std::lock_guard<std::mutex> g(ctx->like_orphans_mu);
+    for (size_t i = ctx->like_orphans.size(); i-- > 0;) {
+        LikePipeline* lp = ctx->like_orphans[i];
+        if (lp->uids.size() != s->meta.size()) continue;
+        bool same = true;
+        for (size_t k = 0; same && k < lp->uids.size(); k++) same = lp->uids[k] == s->meta[k].uid;
+        if (!same) continue;
+        ctx->like_orphans.erase(ctx->like_orphans.begin() + long(i));
+        return lp;
+    }
+    return nullptr;
+}
+void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp) {
+    if (!lp) return;
+    if (!lp->built || !lp->flat) { like_pipeline_destroy(ctx, lp); return; }
+    std::vector<LikePipeline*> out;
+    {
+        std::lock_guard<std::mutex> g(ctx->like_orphans_mu);
+        ctx->like_orphans.push_back(lp);
+        size_t total_b = 0, free_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
+        uint64_t held = 0;
+        for (const LikePipeline* q : ctx->like_orphans) held += pipeline_bytes(q);
+        while (!ctx->like_orphans.empty() && (ctx->like_orphans.size() > kLikeOrphans || held > total_b / 4)) {
+            held -= pipeline_bytes(ctx->like_orphans.front());
+            out.push_back(ctx->like_orphans.front());
+            ctx->like_orphans.erase(ctx->like_orphans.begin());
+        }
+    }
+    for (LikePipeline* q : out) like_pipeline_destroy(ctx, q);
+}
+void like_orphans_clear(lc_ctx* ctx) {
+    std::vector<LikePipeline*> out;
+    {
+        std::lock_guard<std::mutex> g(ctx->like_orphans_mu);
+        out.swap(ctx->like_orphans);
+    }
+    for (LikePipeline* q : out) like_pipeline_destroy(ctx, q);
+}
+
 void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     if (!lp) return;
     pool_release(ctx, lp->d_lean);
@@ -1496,6 +1548,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         const bool want = (ctx->like_path == 0 || ctx->like_path == 4) && s->n >= ctx->like_pipeline_min_entries &&
                           s->d_wg_ranges && s->n_wg_ranges > 0 && !L.d_cand_bytes && !L.d_own_bytes && !LC_ABL(p.debug_flags != 0);
         if (want) {
+            if (!s->like) s->like = like_pipeline_adopt(ctx, s);
             if (!s->like) s->like = new LikePipeline();
             LikePipeline* lp = s->like;
             if (!lp->built) {
@@ -1523,6 +1576,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         automaton_image_bytes(p.needle_len) == 0 || p.verify_len != 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
         return LC_OK;
     if (s->n < ctx->like_pipeline_min_entries || ctx->like_path == 1 || ctx->like_path == 5) return LC_OK;
+    if (!s->like) s->like = like_pipeline_adopt(ctx, s);
     if (!s->like) s->like = new LikePipeline();
     LikePipeline* lp = s->like;
     if (!lp->built) {

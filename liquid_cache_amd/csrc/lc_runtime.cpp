@@ -870,6 +870,7 @@ void lc_ctx_destroy(lc_ctx* ctx) {
         }
         for (lc_scan* sc : idle) lc_scan_destroy(sc);
     }
+    like_orphans_clear(ctx);
     for (Slab& s : ctx->slabs)
         if (s.base) (void)hipFree(s.base);
     pool_destroy(ctx);
@@ -2363,7 +2364,7 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_total_acc);
     pool_release(s->ctx, s->d_or_tmp);
     pool_release(s->ctx, s->d_agg_partials);
-    like_pipeline_destroy(s->ctx, s->like);
+    like_pipeline_orphan(s->ctx, s->like);
     pool_release(s->ctx, s->d_automata);
     pool_release(s->ctx, s->d_needle);
     if (s->pinned) {

@@ -362,3 +362,65 @@ def test_reference_known_answers_through_the_hip_path(product_lib):
     finally:
         cache.close()
     assert n_checked >= 85
+
+
+def test_scan_level_index_survives_the_scan(product_lib, oracle, grouped_cases):
+    """A host that creates a scan per query over the same entries (DataFusion builds a reader per query) gets the scan-level
+    index and the plans of the previous scan: same results, no rebuild; a re-staged entry (new publication) is not served
+    from the old index."""
+    import time
+    lo = oracle
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1).build()
+    try:
+        ids, flat = [], []
+        for r_i, (st, entries) in enumerate(grouped_cases):
+            path = 7100 + r_i
+            cache.set_symbol_table(path, lo.symtab_bytes(st))
+            for e_i, (rows, liquid) in enumerate(entries):
+                eid = lc.ParquetArrayID.new(12, r_i, 5, e_i)
+                cache.stage([eid], [liquid], [path])
+                ids.append(eid)
+                flat.append((rows, liquid, st, path))
+        expr = lc.LiquidExpr.try_new("like", b"%google%", pa.binary(), HINT)
+        one = lc.LiquidExpr.try_new("like", b"%a%", pa.binary(), HINT)
+
+        def run(scan):
+            t0 = time.perf_counter()
+            m, c = scan.eval_to_host(expr)
+            dt = time.perf_counter() - t0
+            m1, c1 = scan.eval_to_host(one)
+            return m.copy(), c.copy(), m1.copy(), c1.copy(), dt
+
+        s1 = cache.scan(ids)
+        a = run(s1)
+        how1 = s1.explain(expr)
+        assert "scan-level index" in how1, how1
+        s1.close()
+        s2 = cache.scan(ids)
+        how2 = s2.explain(expr)          # before any evaluation on THIS scan: nothing adopted yet
+        assert how2.startswith("k_str_pred (scan not evaluated yet)"), how2
+        b = run(s2)
+        how2 = s2.explain(expr)
+        s2.close()
+        assert how2 == how1, (how1, how2)  # the same plan and the same index (its build time is part of the text)
+        for x, y in zip(a[:4], b[:4]):
+            assert np.array_equal(x, y)
+        # (the index build shows in the first evaluation of a scan that has to make it)
+        assert b[4] < a[4], (a[4], b[4])
+        # re-stage one entry with other rows: the scan over the new publication answers from ITS data
+        rows, liquid, st, path = flat[2]
+        other = [None if v is None else v + b"~google~" for v in rows]
+        liquid2, _ = lo.encode_byte_view(other, st=st, fingerprints=True, arrow_type=lo.BT_BINARY)
+        cache.stage([ids[2]], [liquid2], [path])
+        s3 = cache.scan(ids)
+        m3, c3 = s3.eval_to_host(expr)
+        offs = s3.segment_offsets
+        bits = np.unpackbits(m3.view(np.uint8), bitorder="little")
+        got = bits[int(offs[2]) * 64: int(offs[2]) * 64 + len(other)].astype(bool)
+        assert np.array_equal(got, np.array([v is not None for v in other]))
+        assert int(c3[2]) == sum(v is not None for v in other)
+        for b_i in (0, 1, 3):
+            assert int(c3[b_i]) == int(a[1][b_i])
+        s3.close()
+    finally:
+        cache.close()
