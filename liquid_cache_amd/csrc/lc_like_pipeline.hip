@@ -1114,7 +1114,11 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     const uint64_t slice_words = uint64_t(groups.size()) * gw;
     const uint64_t bytes = slice_words * 8u * uint64_t(kFlatBits);
     size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return LC_OK;
+    if (bytes > free_b / 2) {  // the indexes kept for scans that may never come make room for one that is needed now
+        like_orphans_clear(ctx);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
     (void)hipEventCreate(&ev1);

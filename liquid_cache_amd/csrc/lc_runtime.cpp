@@ -218,6 +218,12 @@ lc_status arena_alloc(lc_ctx* ctx, size_t bytes, uint8_t** out, int* slab_idx) {
     }
     Slab s;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&s.base), want);
+    if (e != hipSuccess) {
+        // the indexes kept for future scans (like_pipeline_orphan) are a cache: staged data comes first
+        (void)hipGetLastError();
+        like_orphans_clear(ctx);
+        e = hipMalloc(reinterpret_cast<void**>(&s.base), want);
+    }
     if (e != hipSuccess) return fail(LC_ERR_OOM, std::string("hipMalloc slab: ") + hipGetErrorString(e));
     s.size = want;
     s.used = bytes;
