@@ -162,8 +162,10 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
  *                           per scan and needle (one trial evaluation counts the hit rows; the one host round trip) and
  *                           selective needles then run the lean kernel (k_like_lean) instead of the general one
  *                           (k_str_pred); negative = never
- *   LC_OPT_LIKE_PATH        tuning / A-B aid: 0 automatic (default), 1 k_str_pred only, 2 automatic without the scan-level
- *                           signature index, 3 / 4 k_like_lean / k_like_flat for every needle, 5 k_like_scanall for every needle */
+ *   LC_OPT_LIKE_PATH        tuning / A-B aid: 0 automatic (default: selective needles, 1-byte needles and string = / <>
+ *                           through the scan-level bigram / unigram index where the scan has one), 1 k_str_pred only,
+ *                           2 automatic without the scan-level signature index, 3 / 4 k_like_lean / k_like_flat for
+ *                           every needle, 5 k_like_scanall (the walker) for every needle.  Results never depend on it. */
 #define LC_OPT_SIGNATURE_INDEX 1
 #define LC_OPT_ROW_LISTS 2
 #define LC_OPT_HOST_BUILT_INDEX 3
