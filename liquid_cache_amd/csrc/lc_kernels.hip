@@ -4045,6 +4045,35 @@ hipError_t launch_mask_entry_counts(const void* d_descs, bool is_str, const Scan
     return hipGetLastError();
 }
 
+// Workgroup records of a byte-view scan, on the device: the host only says where a record begins (the records are copies of
+// up to four descriptors each — 5.6 MB for the 12,207 entries of a 100 M-row column, which used to be assembled on the
+// host and copied over for the first evaluation of every new scan).
+__global__ __launch_bounds__(256) void k_str_wg_records(const StrDesc* __restrict__ descs, const uint32_t* __restrict__ begins,
+                                                         uint32_t n_recs, StrWgRecord* __restrict__ recs) {
+    // 29 x 16 bytes per record: a thread copies one 16-byte piece
+    constexpr uint32_t kPieces = sizeof(StrWgRecord) / 16u, kDescPieces = sizeof(StrDesc) / 16u;
+    static_assert(sizeof(StrWgRecord) == 16u + 4u * sizeof(StrDesc) && sizeof(StrDesc) % 16u == 0, "record layout");
+    const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    const uint32_t r = uint32_t(t / kPieces), piece = uint32_t(t % kPieces);
+    if (r >= n_recs) return;
+    const uint32_t begin = begins[r], end = begins[r + 1];
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (piece == 0) {
+        v = make_uint4(begin, end, descs[begin].symtab_slot, 0);
+    } else {
+        const uint32_t k = (piece - 1u) / kDescPieces, q = (piece - 1u) % kDescPieces;
+        if (begin + k < end) v = reinterpret_cast<const uint4*>(descs + begin + k)[q];
+    }
+    reinterpret_cast<uint4*>(recs + r)[piece] = v;
+}
+
+hipError_t launch_str_wg_records(const StrDesc* d_descs, const uint32_t* d_begins, uint32_t n_recs, StrWgRecord* d_recs, hipStream_t stream) {
+    if (n_recs == 0) return hipSuccess;
+    const uint64_t threads = uint64_t(n_recs) * (sizeof(StrWgRecord) / 16u);
+    hipLaunchKernelGGL(k_str_wg_records, dim3(uint32_t((threads + 255u) / 256u)), dim3(256), 0, stream, d_descs, d_begins, n_recs, d_recs);
+    return hipGetLastError();
+}
+
 hipError_t launch_copy_words(void* dst, const void* src, uint64_t n_words, hipStream_t stream) {
     if (n_words == 0) return hipSuccess;
     const uint32_t grid = uint32_t(std::min<uint64_t>((n_words + 255) / 256, 1024));

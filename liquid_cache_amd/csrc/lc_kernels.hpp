@@ -287,6 +287,8 @@ hipError_t launch_str_pred(const StrDesc* d_descs, const DevSymtab* d_symtabs, c
                            const ScanLaunch& L, hipStream_t stream);
 // [NOT] LIKE '%needle%' with many candidates: the whole FSST buffer of every entry streamed once, lane per 8-byte word
 // (lc_like_scanall.hip); d_recs: the scan's workgroup records (<= 4 entries of one symbol table each)
+// the workgroup records of a byte-view scan (StrWgRecord) from its descriptors: record r covers entries [begins[r], begins[r + 1])
+hipError_t launch_str_wg_records(const StrDesc* d_descs, const uint32_t* d_begins, uint32_t n_recs, StrWgRecord* d_recs, hipStream_t stream);
 // (uni_slice / uni_word: a 1-byte needle answered from the scan-level unigram index instead of a walk, see ScanAllArgs)
 hipError_t launch_like_scanall(const StrWgRecord* d_recs, uint32_t n_recs, const StrPred& pred, const ScanLaunch& L,
                                unsigned long long* d_total_acc, hipStream_t stream, const uint64_t* uni_slice = nullptr,

@@ -2599,32 +2599,36 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     }
     std::lock_guard<std::mutex> g(s->mu);
     if (!s->d_wg_ranges) {
-        // workgroup records: consecutive entries, at most four, never across a symbol-table change (row-group boundary)
-        std::vector<StrWgRecord> r;
+        // workgroup records: consecutive entries, at most four, never across a symbol-table change (row-group boundary).
+        // The host says where each begins; k_str_wg_records copies the descriptors into them on the device.
+        std::vector<uint32_t> begins;
         uint32_t begin = 0;
         for (uint32_t i = 1; i <= s->n; i++) {
             if (i == s->n || i - begin == 4 || s->meta[i].sd.symtab_slot != s->meta[begin].sd.symtab_slot) {
-                StrWgRecord rec;
-                std::memset(&rec, 0, sizeof(rec));
-                rec.begin = begin;
-                rec.end = i;
-                rec.symtab_slot = s->meta[begin].sd.symtab_slot;
-                for (uint32_t k = begin; k < i; k++) rec.d[k - begin] = s->meta[k].sd;
-                r.push_back(rec);
+                begins.push_back(begin);
                 begin = i;
             }
         }
-        s->n_wg_ranges = uint32_t(r.size());
-        s->d_wg_ranges = static_cast<StrWgRecord*>(pool_alloc(ctx, std::max<size_t>(r.size(), 1) * sizeof(StrWgRecord)));
+        begins.push_back(s->n);
+        const size_t n_recs = begins.size() - 1;
+        s->n_wg_ranges = uint32_t(n_recs);
+        s->d_wg_ranges = static_cast<StrWgRecord*>(pool_alloc(ctx, std::max<size_t>(n_recs, 1) * sizeof(StrWgRecord)));
         if (!s->d_wg_ranges) return fail(LC_ERR_OOM, "hipMalloc (scan workgroup records)");
-        // (through pinned staging: see scan_create_impl)
-        void* h_r = host_pool_alloc(ctx, std::max<size_t>(r.size(), 1) * sizeof(StrWgRecord));
-        if (!h_r) return fail(LC_ERR_OOM, "hipHostMalloc (scan workgroup records)");
-        std::memcpy(h_r, r.data(), r.size() * sizeof(StrWgRecord));
-        const hipError_t ec = hipMemcpyAsync(s->d_wg_ranges, h_r, r.size() * sizeof(StrWgRecord), hipMemcpyHostToDevice, stream);
+        uint32_t* d_begins = static_cast<uint32_t*>(pool_alloc(ctx, begins.size() * 4));
+        void* h_b = host_pool_alloc(ctx, begins.size() * 4);  // (through pinned staging: see scan_create_impl)
+        if (!d_begins || !h_b) {
+            pool_release(ctx, d_begins);
+            host_pool_release(ctx, h_b);
+            return fail(LC_ERR_OOM, "scan workgroup records: staging");
+        }
+        std::memcpy(h_b, begins.data(), begins.size() * 4);
+        const hipError_t ec = hipMemcpyAsync(d_begins, h_b, begins.size() * 4, hipMemcpyHostToDevice, stream);
+        const hipError_t ek = ec == hipSuccess ? launch_str_wg_records(static_cast<const StrDesc*>(s->d_descs), d_begins, uint32_t(n_recs),
+                                                                       s->d_wg_ranges, stream) : ec;
         const hipError_t es = hipStreamSynchronize(stream);
-        host_pool_release(ctx, h_r);
-        LC_HIP(ec);
+        host_pool_release(ctx, h_b);
+        pool_release(ctx, d_begins);
+        LC_HIP(ek);
         LC_HIP(es);
     }
     L.d_wg_ranges = s->d_wg_ranges;
