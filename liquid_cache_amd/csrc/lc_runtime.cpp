@@ -2257,6 +2257,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     s->n = uint32_t(n);
     s->seg_offsets.assign(n + 1, 0);
     s->meta.reserve(n);
+    s->lens.reserve(n);
     {
         // ONE critical section captures the entries and pins their slabs: between a capture under one lock and a pin
         // under another an lc_evict / re-stage could drain the slab and the scan would keep dangling device pointers.
@@ -2266,7 +2267,8 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         for (uint64_t i = 0; i < n; i++) {
             auto it = ctx->entries.find(entry_ids[i]);
             if (it == ctx->entries.end()) return fail(LC_NOT_STAGED, "entry is not staged");
-            Entry e = it->second;
+            s->meta.push_back(it->second);  // (one copy of the ~400-byte entry record, edited in place)
+            Entry& e = s->meta.back();
             if (e.squeezed_field >= 0 && !allow_squeezed)
                 return fail(LC_NEEDS_BACKING, "entry is squeezed to one date component: predicates and plain reads need the "
                                               "full array from the disk tier");
@@ -2298,7 +2300,6 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
                 s->any_patch |= (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) && e.fd.patch_len > 0;
                 s->any_float |= e.fd.kind == kKindF32 || e.fd.kind == kKindF64;
             }
-            s->meta.push_back(e);
         }
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
         // pin the slabs of the scan's entries: evicting or re-staging an entry under a live scan is then safe (the scan
