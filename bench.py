@@ -574,6 +574,49 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                 out[tag] = r
         except Exception as e:  # noqa: BLE001
             out["string_eq_ordering"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:  # get().with_selection() of a byte-view column, device resident (k_sel_entry_counts + scans + k_str_sel_rows +
+            # k_str_decode_sel): 1 % of the rows, and the rows a selective LIKE leaves
+            words = int(url_scan.mask_words)
+            like = lc.LiquidExpr.try_new("like", b"%google%", pa.string(), lc.CacheExpression.SUBSTRING_SEARCH)
+            m_like = torch.zeros(max(words, 1), dtype=torch.int64, device="cuda")
+            url_scan.eval(like, m_like.data_ptr(), 0, 0, stream)
+            g = torch.Generator(device="cuda")
+            g.manual_seed(7)
+            # ~1.5 % of the rows: the AND of six random words has one bit in 64 set
+            m_rand = torch.randint(-(1 << 62), 1 << 62, (6, max(words, 1)), dtype=torch.int64, device="cuda", generator=g)
+            m_1pct = m_rand[0] & m_rand[1] & m_rand[2] & m_rand[3] & m_rand[4] & m_rand[5]
+            cap = 1 << 21
+            row_offs = torch.zeros(url_scan.entries + 1, dtype=torch.int64, device="cuda")
+            refs = torch.zeros(cap, dtype=torch.int64, device="cuda")
+            voffs = torch.zeros(cap + 1, dtype=torch.int64, device="cuda")
+            data = torch.zeros(cap * 128, dtype=torch.uint8, device="cuda")
+            for tag, m in (("byte_view_gather_1.5pct", m_1pct), ("byte_view_gather_after_like", m_like)):
+                def run():
+                    url_scan.gather_bytes_async(row_offs.data_ptr(), refs.data_ptr(), voffs.data_ptr(), cap, data.data_ptr(),
+                                                data.numel(), m.data_ptr(), 0, stream)
+                run()
+                torch.cuda.synchronize()
+                k = int(row_offs[-1].item())
+                nbytes = int(voffs[min(k, cap)].item())
+                assert 0 < k <= cap and nbytes <= data.numel()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                n_it = max(3, iters // 2)
+                e0.record()
+                for _ in range(n_it):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / n_it
+                # what the gather has to move: the selection words twice (counts, rows), per selected row its key (2), the
+                # offset pair (~8), ~44 compressed bytes, reference + length + value offset out (20) and the decoded bytes
+                need = 2 * words * 8 + k * (2 + 8 + 20) + int(nbytes * 0.58) + nbytes
+                out[tag] = {"bound": "hbm", "kernel": "k_sel_entry_counts + k_scan_* + k_str_sel_rows + k_scan_* + k_str_decode_sel",
+                            "kernel_ms": ms, "rows": int(url_scan.rows), "selected_rows": k, "bytes_out": nbytes,
+                            "kernel_bytes_per_launch": int(need), "achieved": need / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": need / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "timing": "back_to_back", "traffic": None,
+                            "rows_out_per_s": k / (ms * 1e-3)}
+        except Exception as e:  # noqa: BLE001
+            out["byte_view_gather"] = {"error": "%s: %s" % (type(e).__name__, e)}
     try:  # date-part extraction over decoded Date32 values, in place (k_date_component / lossy reconstruction)
         ids = stage_int_column(cache, lc, N, args, 1, min(rows, 33_554_432), threads, bits=12, base=8036, col=94, kind="date32")
         scan = cache.scan(ids)

@@ -127,6 +127,11 @@ __device__ __forceinline__ T load_unaligned(const uint8_t* p) {
     return v;
 }
 
+template <typename T>
+__device__ __forceinline__ void store_unaligned(uint8_t* p, T v) {
+    __builtin_memcpy((__attribute__((address_space(1))) uint8_t*)p, &v, sizeof(T));
+}
+
 typedef const __attribute__((address_space(3))) uint8_t* LdsBytePtr;
 typedef const __attribute__((address_space(3))) uint16_t* LdsU16Ptr;
 __device__ __forceinline__ uint32_t lds_u16(uint32_t addr) { return *reinterpret_cast<LdsU16Ptr>(addr); }
