@@ -3433,12 +3433,94 @@ __global__ __launch_bounds__(kThreads) void k_str_decode_sel(const StrDesc* __re
         }
         return;
     }
-    for (uint64_t r = uint64_t(blockIdx.x) * kThreads + threadIdx.x; r < k; r += uint64_t(gridDim.x) * kThreads) {
-        if (value_offsets[r + 1] == value_offsets[r]) continue;  // null or empty
-        if (value_offsets[r + 1] > capacity_bytes) continue;      // does not fit: the caller sees the total and retries
-        const uint64_t ref = row_refs[r];
-        const StrDesc& d = descs[uint32_t(ref >> 32)];
-        const DevSymtab& st = symtabs[d.symtab_slot];
+    // A lane per row, a wave per CONTIGUOUS run of rows: the rows are in (entry, row) order, so a run lies in one or two
+    // entries and its values share a symbol table, which the wave keeps in LDS (2.3 KB) — the symbol and its length are two
+    // LDS reads per code.  (Round 4: with the rows dealt out across the grid and every lane fetching symbols from the
+    // table in global memory, 64 different addresses per load, 1.5 M rows took 0.6 ms of a 0.7 ms gather.)  A batch of 64
+    // rows that spans two tables (a row-group boundary) reads them from global memory.
+    __shared__ uint64_t s_sym[kWavesPerBlock][256];
+    __shared__ uint8_t s_len[kWavesPerBlock][256];
+    // The 64 rows of a batch are neighbours in the output too: their bytes are decoded into LDS (a lane per row, byte
+    // stores) and leave as whole 16-byte pieces, a wave per batch — 8-byte stores straight from the lanes hit 64 different
+    // lines per instruction, every one a partial line for the memory system to merge (0.6 ms for 125 MB).
+    constexpr uint32_t kStage = 6144;
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[kWavesPerBlock][kStage + 16];
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint64_t per_wave = ((k + n_waves - 1) / n_waves + 63u) & ~uint64_t(63);
+    const uint64_t r0 = (uint64_t(blockIdx.x) * kWavesPerBlock + wave) * per_wave, r1 = min(k, r0 + per_wave);
+    uint32_t cached_slot = 0xFFFFFFFFu;  // wave uniform
+    for (uint64_t rb = r0; rb < r1; rb += kWave) {
+        const uint64_t r = rb + uint64_t(lane);
+        bool live = r < r1;
+        if (live && (value_offsets[r + 1] == value_offsets[r] || value_offsets[r + 1] > capacity_bytes)) live = false;  // null / empty / does not fit
+        const uint64_t ref = live ? row_refs[r] : 0;
+        const StrDesc* dp = descs + uint32_t(ref >> 32);
+        const uint32_t slot = live ? dp->symtab_slot : 0u;
+        const uint64_t lm = __ballot(live);
+        if (lm == 0) continue;
+        const uint32_t slot0 = uint32_t(__shfl(int(slot), __ffsll((long long)lm) - 1, kWave));
+        const bool in_lds = __ballot(live && slot != slot0) == 0;  // wave uniform
+        if (in_lds && slot0 != cached_slot) {
+            const DevSymtab& t = symtabs[slot0];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t c = uint32_t(lane); c < 256u; c += kWave) { s_sym[wave][c] = t.sym[c]; s_len[wave][c] = t.len[c]; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            cached_slot = slot0;
+        }
+        // the batch's bytes in the output: [b0, b1) (rows that are null or empty take none)
+        const uint64_t b0 = value_offsets[rb], b1 = value_offsets[min(rb + uint64_t(kWave), r1)];
+        const uint64_t g0 = uint64_t(reinterpret_cast<uintptr_t>(data)) + b0;
+        const uint32_t mis = uint32_t(g0) & 15u;  // the LDS copy has the alignment of its place in memory
+        const bool staged = in_lds && b1 - b0 <= kStage && b1 <= capacity_bytes;  // wave uniform
+        if (staged) {
+            if (live) {
+                const StrDesc& d = *dp;
+                const uint32_t key = d.keys[uint32_t(ref)];
+                uint32_t start, stop;
+                str_offset_pair(d, key, start, stop);
+                uint32_t so = mis + uint32_t(value_offsets[r] - b0);
+                // the compressed bytes sixteen at a time, the next sixteen requested while these are decoded (a 4-byte
+                // load in front of every fourth code — 64 lanes, 64 lines — was most of a batch's time); the section
+                // carries 16 bytes of slack behind its last value
+                const uint8_t* p = d.fsst + start;
+                const uint32_t n = stop - start;
+                uint64_t c0 = load_unaligned<uint64_t>(p), c1 = load_unaligned<uint64_t>(p + 8);
+                uint64_t n0 = 0, n1 = 0;
+                if (n > 16u) { n0 = load_unaligned<uint64_t>(p + 16); n1 = load_unaligned<uint64_t>(p + 24); }
+                bool lit = false;  // the next byte is an escaped literal
+                for (uint32_t pos = 0; pos < n;) {
+                    const uint32_t i = pos & 15u;
+                    const uint32_t c = uint32_t(((i & 8u) ? c1 : c0) >> (8u * (i & 7u))) & 0xFFu;
+                    pos++;
+                    if ((pos & 15u) == 0) {
+                        c0 = n0;
+                        c1 = n1;
+                        if (pos + 16u < n) { n0 = load_unaligned<uint64_t>(p + pos + 16u); n1 = load_unaligned<uint64_t>(p + pos + 24u); }
+                    }
+                    if (lit) { s_out[wave][so++] = uint8_t(c); lit = false; continue; }
+                    if (c == 255u) { lit = true; continue; }
+                    const uint64_t sym = s_sym[wave][c];
+                    const uint32_t sl = s_len[wave][c];
+                    for (uint32_t b = 0; b < sl; b++) s_out[wave][so + b] = uint8_t(sym >> (8u * b));
+                    so += sl;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint64_t gend = g0 + (b1 - b0);
+            const uint64_t ga = min((g0 + 15u) & ~uint64_t(15), gend), gb = max(gend & ~uint64_t(15), ga);
+            for (uint64_t x = g0 + uint64_t(lane); x < ga; x += kWave)
+                *reinterpret_cast<uint8_t*>(uintptr_t(x)) = s_out[wave][uint32_t(x - g0) + mis];
+            for (uint64_t x = ga + uint64_t(lane) * 16u; x < gb; x += uint64_t(kWave) * 16u)
+                *reinterpret_cast<uint4*>(uintptr_t(x)) = *reinterpret_cast<const uint4*>(&s_out[wave][uint32_t(x - g0) + mis]);
+            for (uint64_t x = gb + uint64_t(lane); x < gend; x += kWave)
+                *reinterpret_cast<uint8_t*>(uintptr_t(x)) = s_out[wave][uint32_t(x - g0) + mis];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            continue;
+        }
+        if (!live) continue;
+        const StrDesc& d = *dp;
+        const DevSymtab& st = symtabs[slot];
         const uint32_t key = d.keys[uint32_t(ref)];
         uint32_t start, stop;
         str_offset_pair(d, key, start, stop);
@@ -3454,6 +3536,7 @@ __global__ __launch_bounds__(kThreads) void k_str_decode_sel(const StrDesc* __re
             uint64_t sym;
             uint32_t sl;
             if (c == 255u) { if (!br.more()) break; sym = br.next(); sl = 1; }
+            else if (in_lds) { sym = s_sym[wave][c]; sl = s_len[wave][c]; }
             else { sym = st.sym[c]; sl = st.len[c]; }
             if (sl == 0) continue;
             if (sl < 8u) sym &= (uint64_t(1) << (8u * sl)) - 1;
