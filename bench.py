@@ -40,6 +40,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 FLUSH_BYTES = 1 << 30  # scratch overwritten between cold launches (Infinity Cache: 256 MiB)
+MIN_TRAFFIC_ROUND = "r5"  # oldest profiles/<round>/hbm_traffic.json whose kernels are the ones this tree launches (round 5
+                          # changed the headline kernel's outputs — no mask for COUNT(*) — and the narrow-integer kernels)
 
 
 def parse_args(argv=None):
@@ -86,8 +88,16 @@ def parse_args(argv=None):
     p.add_argument("--no-needle-classes", action="store_true", help="skip the timing of the LIKE needle classes")
     p.add_argument("--like-path", type=int, default=0, help="LC_OPT_LIKE_PATH (A/B aid): 0 auto, 1 k_str_pred, 3 k_like_lean for every needle")
     p.add_argument("--rotate", type=int, default=0,
-                   help="columns the timed loop rotates through (one per step, all resident in HBM) so that a step never "
-                        "finds its data in the 256 MiB Infinity Cache; 0 = as many as make the cycle move >= 768 MB (1..8)")
+                   help="resident tables the timed loop rotates through (one per scan) so that a scan never finds its data in "
+                        "the 256 MiB Infinity Cache; 0 = as many as make the cycle READ >= 2.2 x 256 MiB (1..32)")
+    p.add_argument("--scans-per-step", type=int, default=0,
+                   help="scans (one pass of the predicate over one resident table each) that make up ONE timed step; 0 = 256 "
+                        "(tpch_q6: 16), so that --steps 20 times tens of milliseconds instead of a third of one")
+    p.add_argument("--full-line", action="store_true",
+                   help="print the whole record (every secondary, ~40 KB) as the last stdout line instead of the compact one "
+                        "(A/B scripts); the whole record is written to --detail-path either way")
+    p.add_argument("--detail-path", default=os.path.join(ROOT, "bench_detail.json"),
+                   help="where the whole record (secondaries, needle classes, sweep) goes; the stdout line stays <= 4 KB")
     p.add_argument("--stage-on-device", action="store_true",
                    help="url_like: transcode the URL batches on the device (lc_insert_arrow_batch_device) instead of the host")
     p.add_argument("--no-q21", action="store_true", help="skip the secondary q21.sql pushdown pipeline measurement")
@@ -262,6 +272,8 @@ def measured_traffic(key, kernel=None):
     old one's bytes).  None when this workload has not been profiled."""
     import glob
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "hbm_traffic.json")), reverse=True):
+        if os.path.basename(os.path.dirname(f)) < MIN_TRAFFIC_ROUND:
+            continue  # (profiles of rounds whose kernels have since been replaced: unmeasured, not inherited)
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
@@ -302,6 +314,105 @@ def roofline(kernel, kernel_ms, alg_bytes, kernel_bytes, cold_ms=None, traffic=N
                     # (names of earlier rounds, same numbers)
                     "kernel_ms_l3_cold": cold_ms, "frac_l3_cold": ach / HBM_PEAK_GBS})
     return out
+
+
+def _fracs(node, path=""):
+    """(name, frac) of every roofline-style object below `node` (dicts that carry both "frac" and a kernel / kernels)."""
+    found = []
+    if isinstance(node, dict):
+        if isinstance(node.get("frac"), (int, float)) and ("kernel" in node or "kernels" in node or "achieved_gbs" in node):
+            found.append((path, float(node["frac"])))
+        for k, v in node.items():
+            if isinstance(v, dict):
+                found += _fracs(v, (path + "." if path else "") + str(k))
+    return found
+
+
+def compact_line(out, detail_path):
+    """The record the driver parses: <= 4 KB.  Mirrors the reference's per-iteration record
+    (benchmark/src/inprocess_runner.rs:278-352: query, iteration, time, cache/IO counters): what was run, how long it took,
+    the roofline object of the dominant kernel, the CPU baseline and a handful of scalars that summarise the secondaries;
+    everything else is in `detail` (bench_detail.json)."""
+    g = lambda d, *ks: next((d[k] for k in ks if isinstance(d, dict) and k in d), None)  # noqa: E731
+    cfg, rf = out.get("config", {}), out.get("roofline", {})
+    keep_cfg = ("workload", "rows_per_gpu", "rows_all_gpus", "batches_per_gpu", "predicate", "hits", "cpu_hits",
+                "hits_match_cpu_oracle", "hits_match_numpy", "needles_checked", "needle_masks_all_match_cpu_oracle",
+                "rotating_columns", "rotating_columns_checked_against_oracle", "scans_per_step", "us_per_scan",
+                "cycle_read_bytes", "index_bytes", "first_evaluation_us", "next_scan_first_evaluation_us", "stage_seconds",
+                "exchange_by", "granularity")
+    c = {k: cfg[k] for k in keep_cfg if k in cfg}
+    for k in ("parallelism", "evaluation_path", "step"):
+        if k in cfg:
+            c[k] = str(cfg[k])[:200]
+    own = g(rf, "kernel_bytes_per_launch", "algorithmic_bytes")
+    r = {"bound": rf.get("bound", "hbm"), "kernel": str(rf.get("kernel"))[:80], "kernel_ms": rf.get("kernel_ms"),
+         "timing": rf.get("timing"), "achieved": rf.get("achieved"), "peak": rf.get("peak"), "unit": rf.get("unit"),
+         "frac": rf.get("frac"), "kernel_ms_hot": rf.get("kernel_ms_hot"), "frac_hot": rf.get("frac_hot"),
+         "own_bytes": own, "algorithmic_bytes": g(rf, "algorithmic_bytes_per_launch", "algorithmic_bytes"),
+         "traffic": rf.get("traffic"), "traffic_over_own": (rf["traffic"] / own) if rf.get("traffic") and own else None,
+         "frac_by_traffic": rf.get("frac_by_traffic"), "traffic_source": rf.get("traffic_source")}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "timed_region_s",
+                                    "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = c
+    line["gb_per_s_scanned"] = out.get("gb_per_s_scanned")
+    line["roofline"] = r
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = out["cpu_baseline"]
+        ac = out.get("cpu_baseline_all_cores")
+        if isinstance(ac, dict):
+            line["cpu_baseline_all_cores"] = {k: ac.get(k) for k in ("value", "unit", "cores", "kind")}
+    if "scaling_model" in out:
+        line["scaling_model"] = {k: v for k, v in out["scaling_model"].items() if k != "note"}
+    sec = out.get("secondary")
+    if isinstance(sec, dict):
+        fr = _fracs(sec)
+        sm = {}
+        if fr:
+            worst = min(fr, key=lambda t: t[1])
+            sm["secondary_objects"] = len(fr)
+            sm["worst_secondary_frac"] = round(worst[1], 4)
+            sm["worst_secondary"] = worst[0][:60]
+        for name, keys in (("int64_gt_w62_frac", ("int64_gt_w62", "frac")), ("date32_gt_w12_frac", ("date32_gt_w12", "frac")),
+                           ("decimal_gt_w4_frac", ("decimal_gt_w4", "frac")), ("int64_gt_w17_frac", ("int64_gt_w17", "frac")),
+                           ("tpch_q6_chain_frac", ("tpch_q6_pushdown", "full_size", "frac")),
+                           ("q21_pipeline_ms", ("q21_pipeline", "ms")),
+                           ("byte_view_gather_after_like_ms", ("micro", "byte_view_gather_after_like", "kernel_ms")),
+                           ("url_like_no_signatures_ms", ("url_like_no_signatures", "kernel_ms")),
+                           ("url_like_no_fingerprints_ms", ("url_like_no_fingerprints", "kernel_ms")),
+                           ("clickbench_sweep_ms", ("clickbench_pushdown_sweep", "ms_all_queries")),
+                           ("rowgroup_rows_per_s", ("rowgroup_granularity", "rows_per_s")),
+                           ("eval_predicate_call_us", ("rowgroup_granularity", "eval_predicate_call_us"))):
+            node = sec
+            for k in keys:
+                node = node.get(k) if isinstance(node, dict) else None
+            if isinstance(node, (int, float)):
+                sm[name] = round(float(node), 5)
+        sm["secondary_errors"] = sum(1 for v in sec.values() if isinstance(v, dict) and "error" in v)
+        line["summary"] = sm
+    line["detail"] = os.path.relpath(detail_path, ROOT) if detail_path else None
+    s = json.dumps(line)
+    if len(s) > 4000:  # never let a long string push the line past what the driver keeps
+        for k in ("evaluation_path", "parallelism", "step"):
+            if k in c:
+                c[k] = c[k][:80]
+        line.pop("cpu_baseline_all_cores", None)
+        s = json.dumps(line)
+    return s
+
+
+def emit(out, args):
+    """Whole record -> --detail-path (and gpurun_out/, which travels back from a GPU box); compact record -> stdout."""
+    paths = [args.detail_path]
+    gout = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(gout):
+        paths.append(os.path.join(gout, os.path.basename(args.detail_path)))
+    for p in paths:
+        try:
+            with open(p, "w") as f:
+                json.dump(out, f)
+        except OSError as e:
+            print("warning: could not write %s: %s" % (p, e), file=sys.stderr)
+    print(json.dumps(out) if args.full_line else compact_line(out, args.detail_path), flush=True)
 
 
 def add_read_probe(r, cache, N):
@@ -403,8 +514,44 @@ def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_ex
     out.update(rows_out=k_out, url_bytes=int(voffs[0][k_out].item()), phrase_bytes=int(voffs[1][k_out].item()))
     assert out["url_bytes"] <= data[0].numel() and out["phrase_bytes"] <= data[1].numel()
     res = {"query": "q21.sql pushdown: SearchPhrase <> '' -> URL LIKE '%%%s%%' -> get(URL), get(SearchPhrase)" % args.needle,
-           "ms": ms, "rows_per_s": url_scan.rows / (ms * 1e-3), "rows_after_searchphrase": n_ne,
+           "ms_mask_form": ms, "rows_after_searchphrase": n_ne,
            "rows_out": out["rows_out"], "url_bytes_out": out["url_bytes"], "phrase_bytes_out": out["phrase_bytes"]}
+    # Round 5, the same pipeline with SPARSE results: the LIKE appends its hit rows as a list (no 12.5 MB mask of zeros), both
+    # projections are ONE launch each over that list (Arrow BinaryView records + data buffer).  Same conjunction, evaluated in
+    # the reference's order (NotEq first: row_filter.rs:499-515); the rows out are the same set (checked below).
+    hcap = 1 << 20
+    hits = torch.zeros(hcap, dtype=torch.int64, device="cuda")
+    n_hits = torch.zeros(1, dtype=torch.int64, device="cuda")
+    views = [torch.zeros((hcap, 2), dtype=torch.int64, device="cuda") for _ in range(2)]
+    nbytes = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(2)]
+
+    def run_hits():
+        sp_scan.eval(ne_expr, m1.data_ptr(), 0, 0, stream)
+        url_scan.eval_hits(like_expr, hits.data_ptr(), hcap, n_hits.data_ptr(), m1.data_ptr(), 0, 0, 0, stream)
+        url_scan.gather_bytes_hits(hits.data_ptr(), n_hits.data_ptr(), hcap, views[0].data_ptr(), data[0].data_ptr(),
+                                   min(data[0].numel(), (1 << 31) - 1), nbytes[0].data_ptr(), 0, stream)
+        sp_scan.gather_bytes_hits(hits.data_ptr(), n_hits.data_ptr(), hcap, views[1].data_ptr(), data[1].data_ptr(),
+                                  min(data[1].numel(), (1 << 31) - 1), nbytes[1].data_ptr(), 0, stream)
+
+    for _ in range(2):
+        run_hits()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run_hits()
+    torch.cuda.synchronize()
+    ms_h = (time.perf_counter() - t0) / iters * 1e3
+    k_h = int(n_hits.item())
+    # the list holds exactly the rows of the mask form; the gathered lengths add up to the mask form's bytes
+    hv = hits[:k_h].cpu().numpy().view(np.uint64)
+    want_rows = refs[0][:k_out].cpu().numpy().view(np.uint64)
+    assert k_h == k_out and np.array_equal(np.sort(hv), np.sort(want_rows)), "hit list differs from the mask form's rows"
+    for c in range(2):
+        lens = views[c][:k_h, 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0]
+        assert int(lens.astype(np.int64).sum()) == (out["url_bytes"], out["phrase_bytes"])[c], "gathered bytes differ"
+    res.update(ms=ms_h, rows_per_s=url_scan.rows / (ms_h * 1e-3),
+               kernels="k_str_pred (SearchPhrase <> '') + k_like_flat (hit list) + 2 x k_str_gather_hits",
+               hit_list_equals_mask_form=True)
     # the step after the path: GROUP BY "SearchPhrase" with MIN("URL") and COUNT(*) as per-entry partials on the device
     # (lc_scan_group_partials) instead of handing the selected strings to a host-side partial aggregate
     try:
@@ -610,11 +757,42 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                 # what the gather has to move: the selection words twice (counts, rows), per selected row its key (2), the
                 # offset pair (~8), ~44 compressed bytes, reference + length + value offset out (20) and the decoded bytes
                 need = 2 * words * 8 + k * (2 + 8 + 20) + int(nbytes * 0.58) + nbytes
-                out[tag] = {"bound": "hbm", "kernel": "k_sel_entry_counts + k_scan_* + k_str_sel_rows + k_scan_* + k_str_decode_sel",
+                out[tag + "_mask_form"] = {"bound": "hbm", "kernel": "k_sel_entry_counts + k_scan_* + k_str_sel_rows + k_scan_* + k_str_decode_sel",
                             "kernel_ms": ms, "rows": int(url_scan.rows), "selected_rows": k, "bytes_out": nbytes,
                             "kernel_bytes_per_launch": int(need), "achieved": need / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": need / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "timing": "back_to_back", "traffic": None,
                             "rows_out_per_s": k / (ms * 1e-3)}
+                # round 5: the same rows as a HIT LIST (what lc_scan_eval_hits leaves), gathered by ONE launch into BinaryView
+                # records + a data buffer
+                hits_t = torch.zeros(cap, dtype=torch.int64, device="cuda")
+                n_h = torch.zeros(1, dtype=torch.int64, device="cuda")
+                n_b = torch.zeros(1, dtype=torch.int64, device="cuda")
+                views_t = torch.zeros((cap, 2), dtype=torch.int64, device="cuda")
+                url_scan.mask_to_hits(m.data_ptr(), hits_t.data_ptr(), cap, n_h.data_ptr(), 0, stream)
+
+                def run_h():
+                    url_scan.gather_bytes_hits(hits_t.data_ptr(), n_h.data_ptr(), cap, views_t.data_ptr(), data.data_ptr(),
+                                               min(data.numel(), (1 << 31) - 1), n_b.data_ptr(), 0, stream)
+                run_h()
+                torch.cuda.synchronize()
+                assert int(n_h.item()) == k
+                lens_h = views_t[:k, 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0].astype(np.int64)
+                assert int(lens_h.sum()) == nbytes, "hit-list gather: lengths differ from the mask form's"
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(n_it):
+                    run_h()
+                e1.record()
+                torch.cuda.synchronize()
+                ms_h = e0.elapsed_time(e1) / n_it
+                # what it has to move: per row its record (8), key (2), offset pair (~8), prefix key (8), ~0.58 compressed
+                # bytes per decoded byte, the view (16) and the decoded bytes
+                need_h = k * (8 + 2 + 8 + 8 + 16) + int(nbytes * 0.58) + nbytes
+                out[tag] = {"bound": "hbm", "kernel": "k_str_gather_hits (one launch over the hit list)", "kernel_ms": ms_h,
+                            "rows": int(url_scan.rows), "selected_rows": k, "bytes_out": nbytes,
+                            "kernel_bytes_per_launch": int(need_h), "achieved": need_h / (ms_h * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                            "unit": "GB/s", "frac": need_h / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "timing": "back_to_back",
+                            "traffic": None, "rows_out_per_s": k / (ms_h * 1e-3), "mask_form_ms": ms}
         except Exception as e:  # noqa: BLE001
             out["byte_view_gather"] = {"error": "%s: %s" % (type(e).__name__, e)}
     try:  # date-part extraction over decoded Date32 values, in place (k_date_component / lossy reconstruction)
@@ -1213,10 +1391,13 @@ def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch
         # one call, one kernel: lc_scan_eval_filter runs the three columns as k_fixed_chain, COUNT(*) from the same kernel
         compiled.run(masks[0].data_ptr(), masks[1].data_ptr(), counts_ptr, 0, total_ptr, stream)
 
+    sps = args.scans_per_step if args.scans_per_step > 0 else 16  # chains per timed step (a chain over 600 M rows: ~0.55 ms)
+
     def step():
-        total = reducer.acquire()
-        chain(total.data_ptr(), 0)
-        reducer.submit()
+        for _ in range(sps):
+            total = reducer.acquire()
+            chain(total.data_ptr(), 0)
+            reducer.submit()
 
     for _ in range(args.warmup):
         step()
@@ -1264,8 +1445,9 @@ def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch
     alg5 = q6_algorithmic_bytes(rows, [("ship", 0), ("ship", 1), ("disc", 1), ("disc", 1), ("qty", 1)])
     out = {
         "metric": "filtered rows/s (+ GB/s scanned), TPC-H Q6-shaped pushdown chain (BASELINE.json config 4)",
-        "value": rows_all / elapsed * args.steps, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+        "value": rows_all * sps / elapsed * args.steps, "unit": "rows/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "timed_region_s": elapsed,
+        "higher_is_better": True, "scaling": scaling,
         "vs_baseline": None, "dtype": "date32+decimal128", "data": "synthetic",
         "config": {"workload": "tpch_q6_shipdate_discount_quantity_chain", "rows_per_gpu": rows, "rows_all_gpus": rows_all,
                    "batch_rows": args.batch_size, "batches_per_gpu": int(s_ship.entries), "first_global_batch": batch0,
@@ -1273,8 +1455,10 @@ def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch
                                   "COUNT(*) all-reduce per step" % world,
                    "predicate": "l_shipdate >= 1994-01-01 AND l_shipdate < 1995-01-01 AND l_discount BETWEEN 0.05 AND "
                                 "0.07 AND l_quantity < 24", "hits": hits, "hits_match_numpy": True,
-                   "stage_seconds": round(t_stage, 2)},
-        "gb_per_s_scanned": alg5 * world / (elapsed / args.steps) / 1e9,
+                   "stage_seconds": round(t_stage, 2), "scans_per_step": sps,
+                   "us_per_scan": elapsed / args.steps / sps * 1e6,
+                   "step": "%d chains, each one launch over the rank's row range of the three columns" % sps},
+        "gb_per_s_scanned": alg5 * world / (elapsed / args.steps / sps) / 1e9,
         "roofline": {"bound": "hbm", "kernel": "k_fixed_chain (one launch over 3 columns: u32 W=12, u64 W=4, u64 W=13)",
                      "achieved": alg3 / (chain_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": alg3 / (chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -1288,7 +1472,7 @@ def run_tpch_q6(cache, lc, N, args, rank, world, batch0, threads, scaling, torch
         add_read_probe(out["roofline"], cache, N)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_q6(cache, lc, args, ids, expected, min(len(expected), args.cpu_batches or 1500))
-    print(json.dumps(out), flush=True)
+    emit(out, args)
     if world > 1:
         dist.destroy_process_group()
 
@@ -1393,13 +1577,25 @@ def main():
     scan.eval(expr, mask.data_ptr(), 0, 0, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     first_eval_us = (time.perf_counter() - t_first) * 1e6
-    # The timed loop ROTATES through several resident columns of the same shape (other seeds), one per step: a hot-cache
+    # The timed loop ROTATES through several resident tables of the same shape (other seeds), one per scan: a hot-cache
     # query never finds its column in the 256 MiB memory-side Infinity Cache, and back-to-back passes over ONE 40-160 MB
-    # column would (round 2: 27.9 us hot vs 35.9 us cold).  The cycle is sized to move >= 768 MB.
-    _, own0 = scan.traffic_model(expr, False)
-    n_rot = args.rotate if args.rotate > 0 else max(1, min(8, -(-(768 << 20) // max(int(own0), 1))))
+    # column would (round 2: 27.9 us hot vs 35.9 us cold).  The cycle is sized so that the bytes it READS (the kernel's own
+    # bytes minus the mask words it writes, when it writes them) exceed 2.2 x 256 MiB: when a table comes round again,
+    # more than twice the cache's capacity of other lines has passed through it (round 4's cap of 8 tables stopped
+    # guaranteeing that once the kernel's own bytes fell to 33 MB).
+    sparse_count = world == 1 or args.exchange == "count"  # COUNT(*) consumers take no mask (d_mask_out = NULL)
+    _, own0 = scan.traffic_model(expr, False, no_mask=sparse_count)
+    _, own0_mask = scan.traffic_model(expr, False)
+    # (kernels that cannot skip the mask words are charged for them either way)
+    read0 = max(int(own0) - (int(words) * 8 if int(own0) == int(own0_mask) else 0), 1)
+    n_rot = args.rotate if args.rotate > 0 else max(1, min(32, -(-int(2.2 * (256 << 20)) // read0)))
+    if args.rotate <= 0 and args.workload == "url_like":
+        # every resident URL table takes ~1 GB of Liquid bytes + ~2 GB of scan-level index: leave room for the secondaries
+        free_b, _tot = torch.cuda.mem_get_info()
+        n_rot = max(1, min(n_rot, int(free_b * 0.5) // (3 << 30)))
     t_rot = time.perf_counter()
     scans = [scan]
+    rot_ids = [ids]
     for r in range(1, n_rot):
         a2 = copy.copy(args)
         a2.seed = args.seed + 7919 * r
@@ -1409,6 +1605,7 @@ def main():
         else:
             ids_r = stage_int_column(cache, lc, N, a2, rank, args.rows, threads, base=base, kind=args.int_kind, col=200 + r)
         scans.append(cache.scan(ids_r))
+        rot_ids.append(ids_r)
     t_stage += time.perf_counter() - t_rot
     # COUNT(*) partials: written by the predicate kernel itself (lc_scan_eval_count); two buffers so that the all-reduce
     # of step i (RCCL's own stream) overlaps the scan of step i+1
@@ -1437,23 +1634,37 @@ def main():
         words_per_rank = [int(x.item()) for x in wl]
         gathered[0] = torch.zeros(max(sum(words_per_rank), 1), dtype=torch.int64, device="cuda")
 
-    def step():
+    # ONE STEP = `sps` scans: each scan is one pass of the predicate over ONE resident table (--rows rows per rank), COUNT(*)
+    # included, followed by its exchange step; consecutive scans take consecutive tables of the rotation.  (Round 4 timed 20
+    # single scans = 0.33 ms, where one scheduler hiccup moves the result by tens of percent.)
+    sps = args.scans_per_step if args.scans_per_step > 0 else 256
+    want_mask = args.exchange == "mask" and world > 1
+    mask_ptr = mask.data_ptr() if (want_mask or not sparse_count) else 0
+
+    def one_scan():
         total = reducer.acquire()
         sc = scans[step_no[0] % n_rot]
         step_no[0] += 1
-        sc.eval_count(expr, mask.data_ptr(), total.data_ptr(), 0, 0, stream)  # mask + COUNT(*) of this shard, one kernel
+        # COUNT(*) of this shard from the predicate kernel itself; the hit mask only when the exchange step consumes it
+        sc.eval_count(expr, mask_ptr, total.data_ptr(), 0, 0, stream)
         reducer.submit()  # exchange step of COUNT(*) queries: the partial counts -> global count (8 bytes)
-        if args.exchange == "mask" and world > 1:
+        if want_mask:
             # exchange step of mask consumers: the per-rank segments -> one BooleanArray (row-range shards concatenate)
             if comm:
                 comm.allgather_mask(mask.data_ptr(), words, gathered[0].data_ptr(), words_per_rank, stream)
             else:
                 gathered[0] = all_gather_mask_segments(mask)
 
+    def step():
+        for _ in range(sps):
+            one_scan()
+
     drain = reducer.drain
 
-    warm_steps = max(args.warmup, n_rot)
-    for _ in range(warm_steps):  # every column is scanned once before the clock starts (plans, automata)
+    for _ in range(n_rot):  # every table is scanned once before the clock starts (plans, automata, scan-level index)
+        one_scan()
+    warm_steps = max(args.warmup, 1)
+    for _ in range(warm_steps):
         step()
     drain()
     new_needle_us = None
@@ -1486,8 +1697,8 @@ def main():
     if world > 1:
         dist.all_reduce(rows_t, op=dist.ReduceOp.SUM)
     rows_all = int(rows_t.item())
-    step_no[0] = 0  # COUNT(*) of column 0 (the one the CPU oracle checks), through the same step
-    step()
+    step_no[0] = 0  # COUNT(*) of table 0 (the one the CPU oracle checks), through the same call
+    one_scan()
     drain()
     torch.cuda.synchronize()
     hits = int(reducer.last().item())
@@ -1514,15 +1725,29 @@ def main():
         rot_counts.append(c_r)
     scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)  # (the mask / counts buffers hold column 0 again)
     torch.cuda.synchronize()
+    for r in range(1, n_rot):  # the other tables of the rotation have done their work: their HBM goes to the secondaries
+        scans[r].close()
+        cache.evict(rot_ids[r])
+    del scans[1:]
     if args.exchange == "mask" and world > 1:
         assert (int(gathered[0].numel()) if comm else sum(int(x.numel()) for x in gathered[0])) * 64 >= rows_all
 
     # roofline of the dominant kernel: HIP events on the launch stream, same launches as the timed region
-    alg_bytes, own_bytes = scan.traffic_model(expr, False)
+    # (the same call as the timed loop's: no mask output when the loop asks for none)
+    alg_bytes, own_bytes = scan.traffic_model(expr, False, no_mask=not mask_ptr)
     iters = max(5, args.steps)
-    kernel_ms = scan.eval_timed(expr, mask.data_ptr(), iters, 0, counts.data_ptr(), stream)
-    cold_ms = None if args.no_cold else scan.eval_timed_cold(expr, mask.data_ptr(), max(3, iters // 4), FLUSH_BYTES, 0,
+    kernel_ms = scan.eval_timed(expr, mask_ptr, max(iters, 50), 0, counts.data_ptr(), stream)
+    cold_ms = None if args.no_cold else scan.eval_timed_cold(expr, mask_ptr, max(5, iters // 2), FLUSH_BYTES, 0,
                                                              counts.data_ptr(), stream)
+    with_mask = None
+    if not mask_ptr and not args.no_cold:
+        # the same predicate with the hit MASK written (what a mask consumer — a conjunction's next step — asks for)
+        _, own_m = scan.traffic_model(expr, False)
+        hot_m = scan.eval_timed(expr, mask.data_ptr(), max(iters, 50), 0, counts.data_ptr(), stream)
+        cold_m = scan.eval_timed_cold(expr, mask.data_ptr(), max(5, iters // 2), FLUSH_BYTES, 0, counts.data_ptr(), stream)
+        with_mask = {"kernel_ms_hot": hot_m, "kernel_ms_l3_cold": cold_m, "own_bytes": int(own_m),
+                     "frac_l3_cold": own_m / (cold_m * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "frac_hot": own_m / (hot_m * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
     # multi-GPU: what bounds a step — this rank's kernel against the exchange (8-byte all-reduce, overlapped with the next
     # scan by the pipelined reducer): kernel time of the slowest / fastest rank and the bare collective, measured here
@@ -1551,10 +1776,10 @@ def main():
         if path.startswith("k_like_"):
             kernel = path.split(":")[0].split(" (")[0]
         traffic, traffic_src = measured_traffic(tkey, kernel)
-        step_s = elapsed / args.steps
+        step_s = elapsed / args.steps / sps  # seconds per scan of one table
         out = {
             "metric": "filtered rows/s (+ GB/s scanned), ClickBench Q21 hot cache",
-            "value": rows_all / elapsed * args.steps,
+            "value": rows_all * sps / elapsed * args.steps,
             "unit": "rows/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -1579,8 +1804,12 @@ def main():
                        "hits": hits, "stage_seconds": round(t_stage, 2), "rotating_columns": n_rot,
                        "rotating_columns_hits": rot_hits,
                        "rotating_columns_count_equals_entry_counts": True,
-                       "warmup_steps_run": warm_steps,
-                       "timed_loop": "step i scans resident column i %% %d (L3-cold by construction)" % n_rot},
+                       "warmup_steps_run": warm_steps, "scans_per_step": sps, "us_per_scan": step_s * 1e6,
+                       "cycle_read_bytes": int(read0) * n_rot,
+                       "mask_written_in_timed_loop": bool(mask_ptr),
+                       "step": "%d scans; scan i is one pass of the predicate (+ COUNT(*)) over resident table i %% %d of %d "
+                               "rows: the cycle reads %.0f MB = %.1f x the 256 MiB Infinity Cache (L3-cold)" % (
+                                   sps, n_rot, int(scan.rows), read0 * n_rot / 1e6, read0 * n_rot / (256 << 20))},
             # the bytes THIS implementation moves per second of wall clock (lc_scan_traffic_model's own-bytes figure) ...
             "gb_per_s_scanned": own_bytes * world / step_s / 1e9,
             # ... and what the scan is worth to the query: the reference algorithm's bytes per second of wall
@@ -1590,6 +1819,8 @@ def main():
             "new_needle_first_evaluation_us": None if new_needle_us is None else round(new_needle_us, 1),
             "roofline": roofline(kernel, kernel_ms, alg_bytes, own_bytes, cold_ms, traffic, traffic_src),
         }
+        if with_mask:
+            out["same_predicate_with_mask_output"] = with_mask
         if world > 1:
             out["scaling_model"] = {
                 "kernel_us_slowest_rank": float(kt[0].item()) * 1e3, "kernel_us_fastest_rank": -float(kt[1].item()) * 1e3,
@@ -1602,6 +1833,10 @@ def main():
         if world == 1 and not args.no_secondary:
             add_read_probe(out["roofline"], cache, N)  # (skipped in the profiling runs: their traces hold the scan kernels only)
         out["config"]["evaluation_path"] = path
+        out["config"]["first_evaluation_us"] = out["first_evaluation_us"]
+        import re
+        m_ix = re.search(r"scan-level index ([0-9.]+) GB", path)
+        out["config"]["index_bytes"] = int(float(m_ix.group(1)) * 1e9) if m_ix else 0
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_sample = args.cpu_batches or n_batches  # ~4 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
         if args.workload == "url_like":
@@ -1668,7 +1903,7 @@ def main():
             # the oracle's over the same bytes
             sample = sorted(set(range(0, n_batches, max(1, n_batches // 96))) | {n_batches - 1})
             ok_cols = 0
-            for r in range(1, n_rot):
+            for r in sorted(set(range(1, n_rot, max(1, (n_rot - 1) // 7)))):  # (<= 8 of them: each costs ~0.5 s of CPU)
                 a2 = copy.copy(args)
                 a2.seed = args.seed + 7919 * r
                 want = oracle_url_sample_counts(cache, lc, N, a2, rank, 1000 + 16 * r + rank, sample, pattern, threads)
@@ -1728,8 +1963,9 @@ def main():
         scan.eval(expr, mask.data_ptr(), 0, 0, stream)
         torch.cuda.synchronize()
         out["next_scan_first_evaluation_us"] = round((time.perf_counter() - t_next) * 1e6, 1)
+        out["config"]["next_scan_first_evaluation_us"] = out["next_scan_first_evaluation_us"]
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out, args)
     scan.close()
     cache.close()
     if world > 1:

@@ -441,7 +441,13 @@ LC_API uint64_t lc_scan_entries(const lc_scan* scan);
  *                     fingerprints, walks only the candidates that survive them and reads keys only for entries in
  *                     which some dictionary value matched) — the numerator of an honest HBM-roofline fraction.
  * For byte views both are data dependent and are measured by one instrumented device pass on the default stream
- * (synchronises; same serialisation rule as lc_scan_eval).  lc_scan_algorithmic_bytes returns the first figure. */
+ * (synchronises; same serialisation rule as lc_scan_eval).  lc_scan_algorithmic_bytes returns the first figure.
+ * `with_selection` is a set of flags: LC_TRAFFIC_WITH_SELECTION (1; any odd value of earlier versions), LC_TRAFFIC_NO_MASK
+ * (the evaluation is a COUNT(*) / hit-list call with d_mask_out == NULL: kernels that skip the mask words are not charged
+ * for them), LC_TRAFFIC_HIT_LIST (8 bytes per hit row written). */
+#define LC_TRAFFIC_WITH_SELECTION 1
+#define LC_TRAFFIC_NO_MASK 2
+#define LC_TRAFFIC_HIT_LIST 4
 LC_API lc_status lc_scan_traffic_model(lc_scan* scan, const lc_predicate* pred, int32_t with_selection,
                                        uint64_t* out_algorithmic, uint64_t* out_kernel_bytes);
 LC_API uint64_t lc_scan_algorithmic_bytes(lc_scan* scan, const lc_predicate* pred, int32_t with_selection);
@@ -484,7 +490,9 @@ LC_API lc_status lc_scan_eval_or(lc_ctx* ctx, uint32_t n, lc_scan* const* scans,
 /* lc_scan_eval_and plus the COUNT(*) of the launch: *d_total_out (one u64, device) receives the number of hits of the
  * whole scan, produced by the predicate kernel itself (no reduction pass, no memset between launches) — what a
  * `SELECT COUNT(*) ... WHERE <pushed-down predicate>` consumer (ClickBench q20) or the 8-byte count all-reduce of a
- * sharded scan reads.  d_counts_out (per entry) stays optional. */
+ * sharded scan reads.  d_counts_out (per entry) stays optional.  d_mask_out may be NULL (round 5): a COUNT(*) consumer
+ * needs no mask, and for a selective predicate the mask of zeros is a third of the kernel's traffic — k_like_flat then
+ * writes none; evaluation paths that cannot skip it write to scan-owned scratch. */
 LC_API lc_status lc_scan_eval_count(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
                                     const void* d_selection, void* d_mask_out, void* d_counts_out, void* d_total_out,
                                     void* stream);
@@ -517,6 +525,43 @@ LC_API lc_status lc_scan_gather_bytes(lc_ctx* ctx, lc_scan* scan, const void* d_
 LC_API lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_row_offsets,
                                             void* d_row_refs, void* d_value_offsets, void* d_row_valid,
                                             uint64_t capacity_rows, void* d_data, uint64_t capacity_bytes, void* stream);
+
+/* ---- sparse results: hit lists (round 5) -------------------------------------------------------------------------------
+ * A selective filter leaves a handful of rows per batch (ClickBench q21: 16,635 of 99,997,497).  The reference hands such a
+ * result on as a BooleanBuffer per batch (liquid_cache_reader.rs:297-339) and gathers with it (:342-391,
+ * byte_view_array/helpers.rs:44-64); over whole scans the mask of zeros is most of the traffic and turning it back into
+ * rows costs more launches than the filter.  A HIT LIST is the same result as u64 records (scan index of the entry << 32 |
+ * row): the records of one entry are contiguous and in ascending row order; the order of the entries is unspecified (the
+ * waves append with one atomic each).  The set of records is exactly the set bits of the mask lc_scan_eval would write.
+ *
+ * lc_scan_eval_hits: evaluate preds (1 or 2, as lc_scan_eval_count) over the scan and append the hit rows to d_hits_out
+ *   (`capacity` records).  *d_n_hits (u64, device; zeroed by the call) receives the number of hits, which may EXCEED capacity:
+ *   records beyond it are dropped — compare and retry with a larger buffer (or fall back to the mask form).
+ *   d_hit_first (optional, u32 per entry): for every entry WITH hits the index of its first record (entries without: untouched);
+ *   d_counts_out (optional): hits per entry; d_total_out (optional): COUNT(*).  No mask is written.  Kernels that can emit the
+ *   list themselves (k_like_flat: selective [NOT] LIKE and string = / <>) do; for every other evaluation path the mask goes to
+ *   scan-owned scratch and one more kernel lists it — always correct, fastest where it matters.  Asynchronous on `stream`.
+ * lc_scan_mask_to_hits: the same list from a mask in scan layout (e.g. the result of lc_scan_eval_filter). */
+LC_API lc_status lc_scan_eval_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
+                                   const void* d_selection, void* d_hits_out, uint64_t capacity, void* d_n_hits,
+                                   void* d_hit_first, void* d_counts_out, void* d_total_out, void* stream);
+LC_API lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, void* d_hits_out, uint64_t capacity,
+                                      void* d_n_hits, void* d_hit_first, void* stream);
+/* get().with_selection() for the rows of a hit list, ONE launch, no host round trip.  `scan` is any scan over the same row
+ * ranges as the scan that produced the list (the projection columns of the filtered batches).  Row i of the output is
+ * record i of the list; k = min(*d_n_hits, capacity_rows) rows are produced.
+ *   fixed width: d_values_out receives k decoded values (the column's Arrow value width); d_row_valid (optional) k bytes.
+ *   byte views : d_views receives k Arrow BinaryView / Utf8View records (16 bytes: i32 length; up to 12 bytes the value
+ *                itself, zero padded; else 4-byte prefix, buffer index 0, i32 offset into d_data); nulls have length 0 and
+ *                d_row_valid[i] == 0.  Space in d_data is claimed with an atomic per wave: *d_n_bytes (u64, device; zeroed
+ *                by the call) receives the bytes the values need — a value that would end beyond capacity_bytes is not
+ *                written (its view still carries length and offset): compare and retry.  capacity_bytes < 2 GiB.
+ * LC_UNSUPPORTED for scans that hold squeezed entries (lc_scan_gather_fixed decides their reads). */
+LC_API lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits,
+                                           uint64_t capacity_rows, void* d_values_out, void* d_row_valid, void* stream);
+LC_API lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits,
+                                           uint64_t capacity_rows, void* d_views, void* d_row_valid, void* d_data,
+                                           uint64_t capacity_bytes, void* d_n_bytes, void* stream);
 
 /* ExtractDate32 over gathered values of a Date32 / Timestamp scan: replaces `n_values` decoded values in d_values
  * (as written by lc_scan_gather_fixed) in place by their lossy date-part reconstruction (see
@@ -559,7 +604,9 @@ LC_API lc_status lc_host_to_device(lc_ctx* ctx, void* dptr, const void* host_src
 LC_API lc_status lc_stream_synchronize(lc_ctx* ctx, void* stream);
 /* A stream of the caller's own (non-blocking: it does not synchronise with the default stream) — one per worker thread
  * is the intended use: the reference's read path runs on `target_partitions` tokio workers concurrently
- * (datafusion/src/reader/runtime/liquid_cache_reader.rs:297-391) and no call of this library synchronises the device. */
+ * (datafusion/src/reader/runtime/liquid_cache_reader.rs:297-391) and no call of this library synchronises the device.
+ * A stream must OUTLIVE the scans it was used with: lc_scan_destroy drains the streams its launches went to before it
+ * recycles the scan's descriptors — destroy the scans first, then the stream. */
 LC_API lc_status lc_stream_create(lc_ctx* ctx, void** out_stream);
 LC_API lc_status lc_stream_destroy(lc_ctx* ctx, void* stream);
 

@@ -660,11 +660,13 @@ class Scan:
         N.check(self._lib.lc_scan_explain(self._h, C.byref(pred), buf, 512), self._cache.handle)
         return buf.value.decode()
 
-    def traffic_model(self, expr: LiquidExpr, with_selection: bool = False):
-        """(algorithmic bytes of the reference algorithm, bytes this kernel itself moves) for one evaluation."""
+    def traffic_model(self, expr: LiquidExpr, with_selection: bool = False, no_mask: bool = False, hit_list: bool = False):
+        """(algorithmic bytes of the reference algorithm, bytes this kernel itself moves) for one evaluation.  `no_mask` /
+        `hit_list`: the evaluation is a COUNT(*) / hit-list call without a mask output (LC_TRAFFIC_NO_MASK / _HIT_LIST)."""
         pred = expr.as_predicate()
         alg, own = C.c_uint64(), C.c_uint64()
-        N.check(self._lib.lc_scan_traffic_model(self._h, C.byref(pred), int(with_selection), C.byref(alg),
+        flags = (1 if with_selection else 0) | (2 if no_mask else 0) | (4 if hit_list else 0)
+        N.check(self._lib.lc_scan_traffic_model(self._h, C.byref(pred), flags, C.byref(alg),
                                                 C.byref(own)), self._cache.handle)
         return int(alg.value), int(own.value)
 
@@ -930,6 +932,164 @@ class Scan:
             for p in (d_sel, d_n):
                 if p.value:
                     lib.lc_device_free(ctx, p)
+
+    # ---- sparse results: hit lists (lc_scan_eval_hits / lc_scan_gather_*_hits) -----------------------------------------
+    def eval_hits(self, exprs, hits_ptr: int, capacity: int, n_hits_ptr: int, selection_ptr: int = 0, hit_first_ptr: int = 0,
+                  counts_ptr: int = 0, total_out_ptr: int = 0, stream: int = 0):
+        """The predicate's hit rows as (entry << 32 | row) u64 records instead of a mask (lc_scan_eval_hits).  Asynchronous."""
+        if isinstance(exprs, LiquidExpr):
+            exprs = [exprs]
+        preds = (N.Predicate * len(exprs))(*[e.as_predicate() for e in exprs])
+        N.check(self._lib.lc_scan_eval_hits(self._cache.handle, self._h, preds, len(exprs), C.c_void_p(selection_ptr or None),
+                                            C.c_void_p(hits_ptr), capacity, C.c_void_p(n_hits_ptr),
+                                            C.c_void_p(hit_first_ptr or None), C.c_void_p(counts_ptr or None),
+                                            C.c_void_p(total_out_ptr or None), C.c_void_p(stream or None)), self._cache.handle)
+
+    def mask_to_hits(self, mask_ptr: int, hits_ptr: int, capacity: int, n_hits_ptr: int, hit_first_ptr: int = 0, stream: int = 0):
+        N.check(self._lib.lc_scan_mask_to_hits(self._cache.handle, self._h, C.c_void_p(mask_ptr), C.c_void_p(hits_ptr), capacity,
+                                               C.c_void_p(n_hits_ptr), C.c_void_p(hit_first_ptr or None),
+                                               C.c_void_p(stream or None)), self._cache.handle)
+
+    def gather_fixed_hits(self, hits_ptr: int, n_hits_ptr: int, capacity_rows: int, values_out_ptr: int, row_valid_ptr: int = 0,
+                          stream: int = 0):
+        """get().with_selection() of a fixed-width column for the rows of a hit list, one launch."""
+        N.check(self._lib.lc_scan_gather_fixed_hits(self._cache.handle, self._h, C.c_void_p(hits_ptr), C.c_void_p(n_hits_ptr),
+                                                    capacity_rows, C.c_void_p(values_out_ptr), C.c_void_p(row_valid_ptr or None),
+                                                    C.c_void_p(stream or None)), self._cache.handle)
+
+    def gather_bytes_hits(self, hits_ptr: int, n_hits_ptr: int, capacity_rows: int, views_ptr: int, data_ptr: int,
+                          capacity_bytes: int, n_bytes_ptr: int, row_valid_ptr: int = 0, stream: int = 0):
+        """The same for a byte-view column: Arrow BinaryView records (16 bytes per row) + one data buffer, one launch."""
+        N.check(self._lib.lc_scan_gather_bytes_hits(self._cache.handle, self._h, C.c_void_p(hits_ptr), C.c_void_p(n_hits_ptr),
+                                                    capacity_rows, C.c_void_p(views_ptr), C.c_void_p(row_valid_ptr or None),
+                                                    C.c_void_p(data_ptr or None), capacity_bytes, C.c_void_p(n_bytes_ptr),
+                                                    C.c_void_p(stream or None)), self._cache.handle)
+
+    def _dev(self, nbytes: int) -> C.c_void_p:
+        p = C.c_void_p()
+        N.check(self._lib.lc_device_alloc(self._cache.handle, max(int(nbytes), 8), C.byref(p)), self._cache.handle)
+        return p
+
+    def _to_dev(self, arr: np.ndarray) -> C.c_void_p:
+        p = self._dev(arr.nbytes)
+        if arr.nbytes:
+            N.check(self._lib.lc_host_to_device(self._cache.handle, p, arr.ctypes.data_as(C.c_void_p), arr.nbytes, None),
+                    self._cache.handle)
+        return p
+
+    def _from_dev(self, p: C.c_void_p, dtype, count: int) -> np.ndarray:
+        out = np.zeros(max(int(count), 1), dtype)
+        if count:
+            N.check(self._lib.lc_device_to_host(self._cache.handle, out.ctypes.data_as(C.c_void_p), p,
+                                                int(count) * out.itemsize, None), self._cache.handle)
+        return out[: int(count)]
+
+    def eval_hits_to_host(self, exprs, selection: Optional[np.ndarray] = None, capacity: Optional[int] = None,
+                          from_mask: bool = False):
+        """Convenience for tests: (hit records as they were written, n_hits, per-entry counts, COUNT(*), first-hit index per
+        entry).  `from_mask`: evaluate to a mask and list it with lc_scan_mask_to_hits instead (the two must agree)."""
+        lib, ctx = self._lib, self._cache.handle
+        cap = int(self.rows) if capacity is None else int(capacity)
+        ptrs = []
+        try:
+            d_hits = self._dev(max(cap, 1) * 8); ptrs.append(d_hits)
+            d_n = self._dev(8); ptrs.append(d_n)
+            d_first = self._to_dev(np.full(max(self.entries, 1), 0xFFFFFFFF, np.uint32)); ptrs.append(d_first)
+            d_counts = self._dev(max(self.entries, 1) * 4); ptrs.append(d_counts)
+            d_total = self._to_dev(np.zeros(1, np.uint64)); ptrs.append(d_total)
+            d_sel = None
+            if selection is not None:
+                d_sel = self._to_dev(np.ascontiguousarray(selection, dtype=np.uint64)); ptrs.append(d_sel)
+            if from_mask:
+                d_mask = self._dev(max(int(self.mask_words), 1) * 8); ptrs.append(d_mask)
+                self.eval_count(exprs, d_mask.value, d_total.value, d_sel.value if d_sel else 0, d_counts.value)
+                self.mask_to_hits(d_mask.value, d_hits.value, cap, d_n.value, d_first.value)
+            else:
+                self.eval_hits(exprs, d_hits.value, cap, d_n.value, d_sel.value if d_sel else 0, d_first.value, d_counts.value,
+                               d_total.value)
+            N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+            n = int(self._from_dev(d_n, np.uint64, 1)[0])
+            hits = self._from_dev(d_hits, np.uint64, min(n, cap))
+            counts = self._from_dev(d_counts, np.uint32, self.entries)
+            total = int(self._from_dev(d_total, np.uint64, 1)[0])
+            first = self._from_dev(d_first, np.uint32, self.entries)
+        finally:
+            for p in ptrs:
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+        return hits, n, counts, total, first
+
+    def gather_bytes_hits_to_host(self, hits: np.ndarray, capacity_bytes: Optional[int] = None):
+        """Convenience for tests: list of bytes / None, row i = record i of `hits` — decoded from the BinaryView records."""
+        lib, ctx = self._lib, self._cache.handle
+        hits = np.ascontiguousarray(hits, dtype=np.uint64)
+        k = int(hits.size)
+        ptrs = []
+        try:
+            d_hits = self._to_dev(hits); ptrs.append(d_hits)
+            d_n = self._to_dev(np.array([k], np.uint64)); ptrs.append(d_n)
+            d_views = self._dev(max(k, 1) * 16); ptrs.append(d_views)
+            d_valid = self._dev(max(k, 1)); ptrs.append(d_valid)
+            d_nb = self._dev(8); ptrs.append(d_nb)
+            cap_b = 1 << 16 if capacity_bytes is None else int(capacity_bytes)
+            while True:
+                d_data = self._dev(max(cap_b, 1))
+                try:
+                    self.gather_bytes_hits(d_hits.value, d_n.value, max(k, 1), d_views.value, d_data.value, cap_b, d_nb.value,
+                                           d_valid.value)
+                    N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+                    need = int(self._from_dev(d_nb, np.uint64, 1)[0])
+                    if need <= cap_b:
+                        data = self._from_dev(d_data, np.uint8, need).tobytes()
+                        break
+                    cap_b = need
+                finally:
+                    lib.lc_device_free(ctx, d_data)
+            views = self._from_dev(d_views, np.uint8, k * 16).reshape(-1, 16) if k else np.zeros((0, 16), np.uint8)
+            valid = self._from_dev(d_valid, np.uint8, k)
+        finally:
+            for p in ptrs:
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+        out = []
+        for i in range(k):
+            if not valid[i]:
+                assert not views[i].any(), "a null row's view must be all zero"
+                out.append(None)
+                continue
+            ln = int(views[i, :4].view(np.int32)[0])
+            if ln <= 12:
+                assert not views[i, 4 + ln:].any(), "inline views are zero padded"
+                out.append(views[i, 4: 4 + ln].tobytes())
+            else:
+                buf, off = (int(x) for x in views[i, 8:16].view(np.int32))
+                assert buf == 0
+                v = data[off: off + ln]
+                assert v[:4] == views[i, 4:8].tobytes(), "view prefix differs from the value"
+                out.append(v)
+        return out
+
+    def gather_fixed_hits_to_host(self, hits: np.ndarray, np_dtype):
+        """Convenience for tests: (values, validity) for the records of `hits`."""
+        lib, ctx = self._lib, self._cache.handle
+        hits = np.ascontiguousarray(hits, dtype=np.uint64)
+        k = int(hits.size)
+        width = np.dtype(np_dtype).itemsize
+        ptrs = []
+        try:
+            d_hits = self._to_dev(hits); ptrs.append(d_hits)
+            d_n = self._to_dev(np.array([k], np.uint64)); ptrs.append(d_n)
+            d_vals = self._dev(max(k, 1) * width + 64); ptrs.append(d_vals)
+            d_valid = self._dev(max(k, 1)); ptrs.append(d_valid)
+            self.gather_fixed_hits(d_hits.value, d_n.value, max(k, 1), d_vals.value, d_valid.value)
+            N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+            vals = self._from_dev(d_vals, np_dtype, k)
+            valid = self._from_dev(d_valid, np.uint8, k)
+        finally:
+            for p in ptrs:
+                if p.value:
+                    lib.lc_device_free(ctx, p)
+        return vals, valid.astype(bool)
 
     def eval_to_host(self, expr: LiquidExpr, selection: Optional[np.ndarray] = None):
         """Convenience for tests: runs the scan and returns (mask words as uint64 ndarray, per-entry counts)."""

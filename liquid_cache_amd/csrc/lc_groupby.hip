@@ -236,10 +236,13 @@ hipError_t launch_group_partials(const StrDesc* g_descs, const StrDesc* v_descs,
                                  unsigned long long* n_out, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
     GroupArgs a{g_descs, v_descs, symtabs, selection, n_entries, want_max, out, capacity, n_out};
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
+    static int cus = 0;  // (queried once: hipGetDeviceProperties on every launch cost more host time than the launch)
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                  ? prop.multiProcessorCount : 256;
+    }
     const uint32_t wgs = std::min<uint32_t>((n_entries + kGroupWaves - 1u) / kGroupWaves, uint32_t(cus) * 5u);  // 5 x 32 KB of LDS per CU
     hipLaunchKernelGGL(k_group_partials, dim3(wgs), dim3(kGroupWaves * 64), 0, stream, a);
     return hipGetLastError();

@@ -201,6 +201,9 @@ struct lc_scan {
     uint64_t* d_or_tmp = nullptr;  // lc_scan_eval_or: [hit | valid | valid of the first column] scratch (grow only)
     size_t or_tmp_words = 0;
     unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
+    uint64_t* d_mask_scratch = nullptr;    // mask words of evaluations whose caller wants none (d_mask_out == NULL) but whose
+                                           // kernel cannot skip them (allocated on first need)
+    bool last_native_hits = false;         // the last evaluation's kernel emitted the hit list itself (k_like_flat)
     lc::LikePipeline* like = nullptr;  // workgroup records + plans of k_like_lean (lc_like_pipeline.hip)
     bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
     // The scan's scratch (automata, work counters, COUNT(*) accumulator, OR / aggregate temporaries) is used by
@@ -245,6 +248,6 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp);
 void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp);
 void like_orphans_clear(lc_ctx* ctx);
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp);           // caller holds s->mu
-uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts);  // caller holds s->mu
+uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts, uint32_t sparse_flags = 0);  // caller holds s->mu
 
 }  // namespace lc

@@ -3553,6 +3553,237 @@ __global__ __launch_bounds__(kThreads) void k_str_decode_sel(const StrDesc* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Sparse results (round 5): a selective filter leaves a handful of rows per entry — 16,635 of 99,997,497 for the headline
+// LIKE — and the 12.5 MB mask of zeros that says so was a third of that kernel's traffic, the five launches that turned
+// it back into rows 5x the kernel.  A HIT LIST is the same result as (entry << 32 | row) records: the rows of one entry
+// contiguous and ascending, entries in no particular order (the waves append with one atomic each).
+//   k_mask_to_hits        any mask -> hit list (one wave per entry); predicate kernels that can emit the list themselves
+//                         (k_like_flat) skip the mask altogether
+//   k_fixed_gather_hits   get().with_selection() of a fixed-width column for the rows of a hit list, ONE launch
+//   k_str_gather_hits     the same for byte views: Arrow BinaryView / Utf8View records (16 bytes per row: length, then the
+//                         value itself up to 12 bytes, else 4-byte prefix | buffer 0 | offset) + one data buffer whose
+//                         space the waves claim with an atomic — no counts, no scans, no second pass
+// What the reference does with a BooleanBuffer per batch (liquid_cache_reader.rs:342-391 read_from_cache ->
+// get_arrow_array_with_filter; byte_view_array/helpers.rs:44-64 filter_inner) for the rows a filter left.
+// ------------------------------------------------------------------------------------------------
+template <typename Desc>
+__global__ __launch_bounds__(kThreads) void k_mask_to_hits(const Desc* __restrict__ descs, uint32_t n_entries,
+                                                           const uint64_t* __restrict__ mask, uint64_t* __restrict__ hits,
+                                                           uint64_t cap, unsigned long long* __restrict__ n_hits,
+                                                           uint32_t* __restrict__ hit_first) {
+    const int lane = lane_id();
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < n_entries; entry += total_waves) {
+        const uint32_t len = desc_rows(descs[entry]);
+        const uint64_t base = descs[entry].mask_word_off;
+        const uint32_t nwords = (len + 63u) >> 6;
+        auto word = [&](uint32_t w) -> uint64_t {
+            if (w >= nwords) return 0;
+            uint64_t m = mask[base + w];
+            if (w == nwords - 1 && (len & 63u)) m &= (uint64_t(1) << (len & 63u)) - 1;
+            return m;
+        };
+        uint32_t c = 0;
+        for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) c += uint32_t(__popcll(word(w)));
+        const uint32_t tot = read_lane(wave_inclusive_sum(c), kWave - 1);
+        if (tot == 0) continue;
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(n_hits, (unsigned long long)tot);
+        b = uniform_u64(b);
+        if (hit_first && lane == 0) hit_first[entry] = uint32_t(b);
+        for (uint32_t w0 = 0; w0 < nwords; w0 += kWave) {
+            const uint32_t w = w0 + uint32_t(lane);
+            uint64_t m = word(w);
+            const uint32_t cnt = uint32_t(__popcll(m));
+            const uint32_t incl = wave_inclusive_sum(cnt);
+            uint64_t pos = b + incl - cnt;
+            while (m) {
+                const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+                m &= m - 1;
+                if (pos < cap) hits[pos] = (uint64_t(entry) << 32) | (w * 64u + bit);
+                pos++;
+            }
+            b += read_lane(incl, kWave - 1);
+        }
+    }
+}
+
+template <typename U>
+__global__ __launch_bounds__(kThreads) void k_fixed_gather_hits(const FixedDesc* __restrict__ descs,
+                                                                 const uint64_t* __restrict__ hits,
+                                                                 const unsigned long long* __restrict__ n_hits, uint64_t cap,
+                                                                 uint8_t* __restrict__ out, uint8_t* __restrict__ row_valid) {
+    constexpr uint32_t TB = LaneTraits<U>::kBits;
+    const uint64_t k = min(uint64_t(*n_hits), cap);
+    for (uint64_t i = uint64_t(blockIdx.x) * kThreads + threadIdx.x; i < k; i += uint64_t(gridDim.x) * kThreads) {
+        const uint64_t ref = hits[i];
+        const uint32_t r = uint32_t(ref);
+        const FixedDesc& d = descs[uint32_t(ref >> 32)];
+        const uint32_t W = d.W, vw = d.value_width;
+        const bool valid = W != 0 && r < d.len && (d.validity ? ((d.validity[r >> 6] >> (r & 63u)) & 1) != 0 : true);
+        if (row_valid) row_valid[i] = valid ? 1 : 0;
+        U u = 0;
+        if (W != 0 && r < d.len) {
+            const U mask_e = (W >= TB) ? U(~U(0)) : U((U(1) << (W & (TB - 1))) - 1);
+            uint32_t row, fl;
+            fl_row_lane<U>(r & 1023u, &row, &fl);
+            u = extract_packed<U>(d.packed + uint64_t(r >> 10) * 128u * W, row, fl, W, mask_e);
+        }
+        if (d.kind == kKindInt) {
+            reinterpret_cast<U*>(out)[i] = W != 0 ? U(u + U(d.reference)) : U(0);  // add_wrapping (primitive_array.rs:357)
+        } else if (d.kind == kKindDecimal) {
+            if constexpr (TB == 64) {
+                uint64_t* p = reinterpret_cast<uint64_t*>(out + i * vw);
+                p[0] = W != 0 ? uint64_t(u) + d.reference : 0;  // decimal_array.rs:189, :285
+                p[1] = 0;
+                if (vw == 32) { p[2] = 0; p[3] = 0; }
+            }
+        } else {
+            // ALP: decode, then the patch of this row if it has one (float_array.rs:306-310; ascending patch indices)
+            uint32_t lo = 0, hi = d.patch_len;
+            while (lo < hi) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (d.patch_idx[mid] < uint64_t(r)) lo = mid + 1; else hi = mid;
+            }
+            const bool patched = lo < d.patch_len && d.patch_idx[lo] == uint64_t(r);
+            if (d.kind == kKindF32) {
+                if constexpr (TB == 32) {
+                    const int32_t iv = int32_t(uint32_t(u) + uint32_t(d.reference));
+                    float v = W != 0 ? alp_decode(iv, d.alp_e, d.alp_f) : 0.0f;
+                    if (patched) v = reinterpret_cast<const float*>(d.patch_val)[lo];
+                    reinterpret_cast<float*>(out)[i] = v;
+                }
+            } else {
+                if constexpr (TB == 64) {
+                    const int64_t iv = int64_t(uint64_t(u) + d.reference);
+                    double v = W != 0 ? alp_decode(iv, d.alp_e, d.alp_f) : 0.0;
+                    if (patched) v = reinterpret_cast<const double*>(d.patch_val)[lo];
+                    reinterpret_cast<double*>(out)[i] = v;
+                }
+            }
+        }
+    }
+}
+
+// the first min(len, 4) decoded bytes of a value (the prefix field of a BinaryView), a code at a time
+__device__ __forceinline__ uint32_t str_first4(const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop, const DevSymtab& st) {
+    uint32_t v = 0, have = 0;
+    for (uint32_t p = start; p < stop && have < 4u;) {
+        const uint32_t c = fsst[p++];
+        uint64_t sym;
+        uint32_t sl;
+        if (c == 255u) { if (p >= stop) break; sym = fsst[p++]; sl = 1; }
+        else { sym = st.sym[c]; sl = st.len[c]; }
+        if (sl == 0) continue;
+        if (sl < 8u) sym &= (uint64_t(1) << (8u * sl)) - 1;
+        v |= uint32_t(sym << (8u * have));
+        have += sl;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __restrict__ descs,
+                                                               const DevSymtab* __restrict__ symtabs,
+                                                               const uint64_t* __restrict__ hits,
+                                                               const unsigned long long* __restrict__ n_hits, uint64_t cap_rows,
+                                                               uint32_t* __restrict__ views, uint8_t* __restrict__ row_valid,
+                                                               uint8_t* __restrict__ data, uint64_t cap_bytes,
+                                                               unsigned long long* __restrict__ n_bytes) {
+    const uint64_t k = min(uint64_t(*n_hits), cap_rows);
+    const uint64_t n_waves = uint64_t(gridDim.x) * kWavesPerBlock;
+    const int lane = lane_id();
+    const uint64_t gw = uint64_t(blockIdx.x) * kWavesPerBlock + uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    // rows of a batch: few rows for this grid -> small batches, every value decoded by the whole wave (a lane per compressed
+    // byte: the latency of a selective gather is that of its slowest lane-serial walk otherwise); many rows -> 64 per batch, a
+    // lane per row
+    uint32_t R = 64;
+    if (k < n_waves * 16u) {
+        const uint64_t per = (k + n_waves - 1) / max(n_waves, uint64_t(1));
+        R = 1;
+        while (R < per && R < 64u) R <<= 1;
+    }
+    const bool coop = R < 64u;
+    for (uint64_t rb = gw * R; rb < k; rb += n_waves * R) {
+        const uint64_t i = rb + uint64_t(lane);
+        const bool live = uint32_t(lane) < R && i < k;
+        const uint64_t ref = live ? hits[i] : 0;
+        const uint32_t row = uint32_t(ref);
+        const StrDesc* dp = descs + uint32_t(ref >> 32);
+        bool valid = false;
+        uint32_t len = 0, start = 0, stop = 0, slot = 0;
+        if (live) {
+            const StrDesc& d = *dp;
+            slot = d.symtab_slot;
+            valid = row < d.n && (d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true);
+            if (valid) {
+                const uint32_t key = uint32_t(d.keys[row]);
+                str_offset_pair(d, key, start, stop);
+                len = str_decoded_len(d, symtabs[slot], key);
+            }
+        }
+        // space in the data buffer: values of more than 12 bytes (shorter ones live in their view), one atomic per batch
+        const uint32_t need = len > 12u ? len : 0u;
+        const uint32_t incl = wave_inclusive_sum(need);
+        const uint32_t tot = read_lane(incl, kWave - 1);
+        unsigned long long b = 0;
+        if (tot && lane == 0) b = atomicAdd(n_bytes, (unsigned long long)tot);
+        b = uniform_u64(b);
+        const uint64_t off = b + incl - need;
+        const bool fits = need == 0 || off + need <= cap_bytes;
+        uint32_t* v = views + 4u * i;
+        if (live) {
+            if (row_valid) row_valid[i] = valid ? 1 : 0;
+            if (len > 12u) {
+                const uint4 rec = make_uint4(len, str_first4(dp->fsst, start, stop, symtabs[slot]), 0u, uint32_t(off));
+                *reinterpret_cast<uint4*>(v) = rec;
+            } else {
+                *reinterpret_cast<uint4*>(v) = make_uint4(len, 0u, 0u, 0u);  // (the value's bytes follow below)
+            }
+        }
+        uint8_t* dst = len > 12u ? data + off : reinterpret_cast<uint8_t*>(v) + 4;
+        if (coop) {
+            const uint64_t todo = __ballot(live && len != 0 && fits);
+            for (uint64_t m = todo; m;) {
+                const int j = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)m)) - 1);
+                m &= m - 1;
+                const uint64_t dj = uniform_u64(uint64_t(__shfl((unsigned long long)reinterpret_cast<uintptr_t>(dst), j, kWave)));
+                const uint64_t fj = uniform_u64(uint64_t(__shfl((unsigned long long)reinterpret_cast<uintptr_t>(dp->fsst), j, kWave)));
+                (void)wave_decode_value<true>(reinterpret_cast<const uint8_t*>(uintptr_t(fj)), read_lane(start, j), read_lane(stop, j),
+                                              symtabs[read_lane(slot, j)], reinterpret_cast<uint8_t*>(uintptr_t(dj)));
+            }
+            continue;
+        }
+        if (!live || len == 0 || !fits) continue;
+        const DevSymtab& st = symtabs[slot];
+        ByteReader br;
+        br.init(dp->fsst, start, stop);
+        // decoded bytes are collected in a register and stored eight at a time (see k_str_decode_sel)
+        uint8_t* o = dst;
+        uint64_t buf = 0;
+        uint32_t have = 0;
+        while (br.more()) {
+            const uint32_t c = br.next();
+            uint64_t sym;
+            uint32_t sl;
+            if (c == 255u) { if (!br.more()) break; sym = br.next(); sl = 1; }
+            else { sym = st.sym[c]; sl = st.len[c]; }
+            if (sl == 0) continue;
+            if (sl < 8u) sym &= (uint64_t(1) << (8u * sl)) - 1;
+            buf |= sym << (8u * have);
+            have += sl;
+            if (have >= 8u) {
+                if (len > 12u) store_unaligned<uint64_t>(o, buf);
+                else for (uint32_t q = 0; q < 8u; q++) o[q] = uint8_t(buf >> (8u * q));
+                o += 8;
+                have -= 8u;
+                buf = have ? sym >> (8u * (sl - have)) : 0;
+            }
+        }
+        for (uint32_t q = 0; q < have; q++) o[q] = uint8_t(buf >> (8u * q));
+    }
+}
+
 // Kleene OR of two predicate results in scan-mask form (hit = value AND valid AND selected, valid = valid AND selected),
 // what arrow's or_kleene gives on the two BooleanArrays (cache/mod.rs:111-150): true if either side is true, null if
 // neither is true and one is null, false if both are false.  In place on (hit, valid).
@@ -4844,6 +5075,45 @@ hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, cons
     const uint64_t nwords = (left_bits + 63) / 64;
     if (nwords == 0) return hipSuccess;
     hipLaunchKernelGGL(k_mask_and_then, dim3(1), dim3(kThreads), 0, stream, d_left, nwords, d_right, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_mask_to_hits(const void* d_descs, bool is_str, uint32_t n_entries, const uint64_t* d_mask, uint64_t* d_hits,
+                               uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, hipStream_t stream) {
+    if (n_entries == 0) return hipSuccess;
+    const uint64_t wgs_needed = (uint64_t(n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 16)));
+    if (is_str)
+        hipLaunchKernelGGL(k_mask_to_hits<StrDesc>, grid, dim3(kThreads), 0, stream, static_cast<const StrDesc*>(d_descs), n_entries,
+                           d_mask, d_hits, cap, d_n_hits, d_hit_first);
+    else
+        hipLaunchKernelGGL(k_mask_to_hits<FixedDesc>, grid, dim3(kThreads), 0, stream, static_cast<const FixedDesc*>(d_descs), n_entries,
+                           d_mask, d_hits, cap, d_n_hits, d_hit_first);
+    return hipGetLastError();
+}
+
+hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, const uint64_t* d_hits,
+                                    const unsigned long long* d_n_hits, uint64_t cap, uint8_t* d_values_out, uint8_t* d_row_valid,
+                                    hipStream_t stream) {
+    if (cap == 0) return hipSuccess;
+    const dim3 grid(uint32_t(std::min<uint64_t>((cap + kThreads - 1) / kThreads, uint64_t(device_cus()) * 8))), block(kThreads);
+    switch (lane_log2) {
+        case 3: hipLaunchKernelGGL(k_fixed_gather_hits<uint8_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid); break;
+        case 4: hipLaunchKernelGGL(k_fixed_gather_hits<uint16_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid); break;
+        case 5: hipLaunchKernelGGL(k_fixed_gather_hits<uint32_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid); break;
+        case 6: hipLaunchKernelGGL(k_fixed_gather_hits<uint64_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_hits,
+                                  const unsigned long long* d_n_hits, uint64_t cap_rows, uint32_t* d_views, uint8_t* d_row_valid,
+                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, hipStream_t stream) {
+    if (cap_rows == 0) return hipSuccess;
+    const uint32_t grid = uint32_t(std::min<uint64_t>((cap_rows + kWavesPerBlock - 1) / kWavesPerBlock, uint64_t(device_cus()) * 8));
+    hipLaunchKernelGGL(k_str_gather_hits, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_hits, d_n_hits, cap_rows,
+                       d_views, d_row_valid, d_data, cap_bytes, d_n_bytes);
     return hipGetLastError();
 }
 

@@ -253,6 +253,17 @@ struct ScanLaunch {
     // wave that arrives last writes the total to *d_total_out — no separate reduction kernel, no memset between launches.
     unsigned long long* d_total_acc;  // kTotalWords u64 owned by the scan, zero between launches (self-resetting)
     uint64_t* d_total_out;            // null: no total wanted
+    // Sparse result (optional; lc_scan_eval_hits): every hit row as (entry << 32 | row) appended to d_hits — the rows of one
+    // entry contiguous and ascending, entries in no particular order.  *d_n_hits (zero before the launch) receives the number
+    // of hits, which may exceed hits_cap (records beyond it are dropped).  d_hit_first (optional): per entry WITH hits, the
+    // index of its first record.  Kernels that do not emit the list themselves leave it to k_mask_to_hits.
+    uint64_t* d_hits;
+    uint64_t hits_cap;
+    unsigned long long* d_n_hits;
+    uint32_t* d_hit_first;
+    uint32_t mask_optional;           // d_hit is the scan's own scratch (the caller wants no mask): a kernel that can answer
+                                      // d_counts / d_total_out / d_hits without storing mask words may skip them
+    uint32_t pad_sparse;
 };
 // accumulator layout: word 0 = top level, words 8, 16, ... = shards (one 64-byte line each).  A word packs
 // {arrivals : 24 | hits : 40}, so ONE returning atomic both adds a count and tells the caller whether it was the last.
@@ -350,6 +361,15 @@ hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, cons
 hipError_t launch_group_partials(const StrDesc* g_descs, const StrDesc* v_descs, const DevSymtab* symtabs, const uint64_t* selection,
                                  uint32_t n_entries, int want_max, lc_group_partial* out, uint64_t capacity,
                                  unsigned long long* n_out, hipStream_t stream);
+// hit lists (sparse results): mask -> list, and get-with-selection for the rows of a list in ONE launch each
+hipError_t launch_mask_to_hits(const void* d_descs, bool is_str, uint32_t n_entries, const uint64_t* d_mask, uint64_t* d_hits,
+                               uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, hipStream_t stream);
+hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, const uint64_t* d_hits,
+                                    const unsigned long long* d_n_hits, uint64_t cap, uint8_t* d_values_out, uint8_t* d_row_valid,
+                                    hipStream_t stream);
+hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_hits,
+                                  const unsigned long long* d_n_hits, uint64_t cap_rows, uint32_t* d_views, uint8_t* d_row_valid,
+                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, hipStream_t stream);
 hipError_t launch_str_gather(const StrDesc* d_descs, const DevSymtab* d_symtabs, uint32_t entry, uint32_t dict_len,
                              uint32_t n_rows, const uint64_t* d_selection, uint32_t* d_dict_len, int32_t* d_offsets,
                              uint32_t* d_rows, uint64_t* d_totals, uint8_t* d_data, hipStream_t stream);

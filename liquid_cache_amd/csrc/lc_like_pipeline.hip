@@ -568,9 +568,13 @@ struct FlatArgs {
     uint32_t needle_fp;
     uint16_t sig_bits[kMaxSigProbeWide];
     const uint64_t* selection;
-    uint64_t* mask;
+    uint64_t* mask;                         // null: no mask wanted (COUNT(*) / hit-list consumers): no zero words are written
     uint32_t* counts;
     unsigned long long* stats;
+    uint64_t* hits;                         // sparse result (ScanLaunch::d_hits), or null
+    uint64_t hits_cap;
+    unsigned long long* n_hits;
+    uint32_t* hit_first;
     ScanLaunch total;
 };
 using ConstFlatPtr = const __attribute__((address_space(4))) FlatGroup*;
@@ -682,7 +686,8 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
         for (uint32_t j = 0; j < n_entries; j++) {
             const uint32_t nr = j == 0 ? nr0 : j == 1 ? nr1 : j == 2 ? nr2 : nr3;
             const uint32_t nwords = (nr + 63u) >> 6;
-            for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) as_global_mut(a.mask)[moff + w] = 0;
+            if (a.mask)
+                for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) as_global_mut(a.mask)[moff + w] = 0;
             if (a.counts && lane == 0) as_global_mut(a.counts)[first_entry + j] = 0;
             moff += nwords;
         }
@@ -926,15 +931,43 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
             } else if (a.selection && hitw) {
                 hitw &= as_global(a.selection)[moff + w];
             }
-            as_global_mut(a.mask)[moff + w] = hitw;
+            if (a.mask) as_global_mut(a.mask)[moff + w] = hitw;
+            if (a.hits) pmask[j * (kMaskBytes / 8u) + w] = hitw;  // (the final word: selection and NOT applied)
             c += uint32_t(__popcll(hitw));
         }
-        if (a.counts || a.total.d_total_out) {
+        if (a.counts || a.total.d_total_out || a.hits) {
             const uint32_t ct = read_lane(wave_inclusive_sum(c), kWave - 1);
             if (lane == 0 && a.counts) as_global_mut(a.counts)[first_entry + j] = ct;
             wave_hits += ct;
         }
         moff += nwords;
+    }
+    if (a.hits && wave_hits != 0) {
+        // sparse result: the group's hit rows as (entry << 32 | row), in (entry, row) order, behind ONE atomic of the wave
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned long long b = 0;
+        if (lane == 0) b = atomicAdd(a.n_hits, (unsigned long long)wave_hits);
+        b = uniform_u64(b);
+        for (uint32_t j = 0; j < n_entries; j++) {
+            const uint32_t nr = j == 0 ? nr0 : j == 1 ? nr1 : j == 2 ? nr2 : nr3;
+            const uint32_t nwords = (nr + 63u) >> 6;
+            const unsigned long long eb = b;
+            for (uint32_t w0 = 0; w0 < nwords; w0 += kWave) {
+                const uint32_t w = w0 + uint32_t(lane);
+                uint64_t m = w < nwords ? pmask[j * (kMaskBytes / 8u) + w] : 0;
+                const uint32_t cnt = uint32_t(__popcll(m));
+                const uint32_t incl = wave_inclusive_sum(cnt);
+                unsigned long long pos = b + incl - cnt;
+                while (m) {
+                    const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+                    m &= m - 1;
+                    if (pos < a.hits_cap) as_global_mut(a.hits)[pos] = (uint64_t(first_entry + j) << 32) | (w * 64u + bit);
+                    pos++;
+                }
+                b += read_lane(incl, kWave - 1);
+            }
+            if (a.hit_first && b != eb && lane == 0) as_global_mut(a.hit_first)[first_entry + j] = uint32_t(eb);
+        }
     }
     if (a.total.d_total_out && lane == 0) total_contribute(a.total, unit, n_units, wave_hits);
 }
@@ -1314,9 +1347,13 @@ lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L,
     fa.n_extra = nb > uint32_t(kMaxSigProbe) ? nb - uint32_t(kMaxSigProbe) : 0u;
     fa.needle_fp = p.needle_fp;
     fa.selection = L.d_selection;
-    fa.mask = L.d_hit;
+    fa.mask = L.mask_optional ? nullptr : L.d_hit;
     fa.counts = L.d_counts;
     fa.stats = d_stats;
+    fa.hits = L.d_hits;
+    fa.hits_cap = L.hits_cap;
+    fa.n_hits = L.d_n_hits;
+    fa.hit_first = L.d_hit_first;
     fa.total.d_total_acc = lp->d_total_acc;
     fa.total.d_total_out = L.d_total_out;
     LC_HIP(launch_flat(int(std::min<uint32_t>(nb, uint32_t(kMaxSigProbe))), p.op == LC_OP_NOT_LIKE && !force_like, fa, stream));
@@ -1501,7 +1538,7 @@ std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp) {
 // per candidate its offset pair (8) and its compressed bytes; per matching value its list bounds (4) and 2 bytes per
 // row; the entry's mask words out (+ the selection words of entries with hits).  0 when k_str_pred takes this needle.
 // Caller holds s->mu.
-uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts) {
+uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts, uint32_t sparse_flags) {
     const LikePipeline* lp = s->like;
     if (!lp || !lp->eligible || s->ctx->like_path == 1 || sp.p.verify_len != 0) return 0;
     if (sp.p.mode == 1 && sp.p.needle_len == 1) {
@@ -1523,7 +1560,10 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
                 // per hit row; the mask words out
                 uint16_t bits[kMaxSigProbeWide];
                 const uint64_t nb = std::min<uint64_t>(flat_needle_bits(sp.needle, bits), q.n_probe ? q.n_probe : kMaxSigProbeWide);
-                uint64_t b = uint64_t(lp->n_group_slots) * (kFlatHotBytes + nb * lp->group_words * 8) + s->seg_offsets.back() * 8 +
+                // sparse_flags: 2 = the caller takes no mask (k_like_flat then stores no mask words), 4 = it takes the hit list
+                // (8 bytes per hit row)
+                uint64_t b = uint64_t(lp->n_group_slots) * (kFlatHotBytes + nb * lp->group_words * 8) +
+                             ((sparse_flags & 2u) ? 0 : s->seg_offsets.back() * 8) + ((sparse_flags & 4u) ? q.hits * 8 : 0) +
                              (with_counts ? uint64_t(s->n) * 4 : 0);
                 b += std::min<uint64_t>(q.n_cand, lp->n_groups) * 64 * kFlatMaxE + q.n_cand * 12 + q.cand_bytes + q.hits * 2;
                 if (sp.p.eq_len != 0) b += q.matches * 8;  // `=`: the prefix key of every value that contains the literal
@@ -1619,7 +1659,10 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     if (!plan->use_lean && ctx->like_path != 3 && ctx->like_path != 4) return LC_OK;
     const lc_status st = use_flat ? run_flat(lp, sp, L, stream, nullptr, false, plan->n_probe ? plan->n_probe : kMaxSigProbeWide)
                                   : run_lean(lp, p, L, stream);
-    if (st == LC_OK) *handled = true;
+    if (st == LC_OK) {
+        *handled = true;
+        s->last_native_hits = use_flat && L.d_hits != nullptr;  // (k_like_flat appends the hit list itself)
+    }
     return st;
 }
 

@@ -117,7 +117,13 @@ void* pool_alloc(lc_ctx* ctx, size_t bytes) {
         }
     }
     void* p = nullptr;
-    if (hipMalloc(&p, cls) != hipSuccess) return nullptr;
+    if (hipMalloc(&p, cls) != hipSuccess) {
+        // the scan-level LIKE indexes kept for the NEXT scan over the same entries are a cache, outside the entry accounting:
+        // they go before an allocation fails
+        (void)hipGetLastError();
+        like_orphans_clear(ctx);
+        if (hipMalloc(&p, cls) != hipSuccess) return nullptr;
+    }
     std::lock_guard<std::mutex> g(ctx->pool_mu);
     ctx->pool_live[p] = cls;
     return p;
@@ -525,6 +531,24 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
             if (c == kFsstEscape) { i++; continue; }
             if (c >= st.n) return fail(LC_ERR_CORRUPT, "FSST code outside the registered symbol table");
         }
+        // The gather sizing passes and the `=` length test take a value's length from byte 7 of its prefix key
+        // (PrefixKey::from_parts, raw/fsst_buffer.rs:162-188: the length behind the shared prefix, 255 = that or more) while
+        // the decode writes whatever the codes decode to: a key that disagrees with its value would make the decode overrun the
+        // slot sized for it.  The reference trusts its own serialisation; bytes from anywhere else are checked here, once.
+        for (uint32_t k = 0; k < v.d; k++) {
+            const uint32_t a = v.offset_at(k), b = v.offset_at(k + 1);
+            if (a > b || b > v.fsst_len) return fail(LC_ERR_CORRUPT, "compact offsets outside the FSST buffer");
+            uint64_t dl = 0;
+            for (uint32_t i = a; i < b; i++) {
+                const uint8_t c = v.fsst[i];
+                if (c == kFsstEscape) { if (++i < b) dl++; }  // (a dangling escape marker decodes to nothing)
+                else dl += st.len[c];
+            }
+            if (dl < v.shared_prefix_len) return fail(LC_ERR_CORRUPT, "dictionary value shorter than the shared prefix");
+            const uint64_t rest = dl - v.shared_prefix_len;
+            if (v.prefix_keys[size_t(k) * 8 + 7] != uint8_t(std::min<uint64_t>(rest, 255)))
+                return fail(LC_ERR_CORRUPT, "prefix key length byte disagrees with the FSST-compressed value");
+        }
     }
     e->is_str = true;
     e->logical = kByteView;
@@ -570,11 +594,15 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
     offs[4] = blob->add(v.residuals, size_t(v.residual_count) * size_t(v.offset_bytes), kSectionAlign, 8);
     offs[5] = blob->add(v.fsst, v.fsst_len, kSectionAlign, 16);
     offs[6] = blob->add(v.shared_prefix, v.shared_prefix_len, kSectionAlign, 8);
-    e->index_hash = index_content_hash(blob->bytes.data() + offs[0], size_t(v.n) * 2,
-                                       offs[1] == size_t(-1) ? nullptr : blob->bytes.data() + offs[1],
-                                       offs[1] == size_t(-1) ? 0 : ((size_t(v.n) + 63) / 64) * 8,
-                                       blob->bytes.data() + offs[4], size_t(v.residual_count) * size_t(v.offset_bytes),
-                                       blob->bytes.data() + offs[5], v.fsst_len, v.slope, v.intercept, *host_st);
+    // the content hash validates a prebuilt index blob: computed only when one is supplied (a byte-serial hash over every
+    // staged byte view cost seconds of host time per 100 M-row column); lc_entry_index_to_bytes computes it on demand
+    e->index_hash = 0;
+    if (index && index_len >= sizeof(IndexHeader))
+        e->index_hash = index_content_hash(blob->bytes.data() + offs[0], size_t(v.n) * 2,
+                                           offs[1] == size_t(-1) ? nullptr : blob->bytes.data() + offs[1],
+                                           offs[1] == size_t(-1) ? 0 : ((size_t(v.n) + 63) / 64) * 8,
+                                           blob->bytes.data() + offs[4], size_t(v.residual_count) * size_t(v.offset_bytes),
+                                           blob->bytes.data() + offs[5], v.fsst_len, v.slope, v.intercept, *host_st);
     // a prebuilt index is used when it describes exactly this entry — dictionary size, rows, signature width, section
     // sizes AND the hash of the bytes it was derived from; anything else is ignored and the index is rebuilt: a stale or
     // foreign blob can cost time, never a result
@@ -2369,6 +2397,7 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_gather);
     pool_release(s->ctx, s->d_wg_ranges);
     pool_release(s->ctx, s->d_total_acc);
+    pool_release(s->ctx, s->d_mask_scratch);
     pool_release(s->ctx, s->d_or_tmp);
     pool_release(s->ctx, s->d_agg_partials);
     like_pipeline_orphan(s->ctx, s->like);
@@ -2466,12 +2495,26 @@ static lc_status clamp_unresolved_entries(lc_ctx* ctx, lc_scan* s, const FixedPr
     return LC_OK;
 }
 
+// sparse result of an evaluation (lc_scan_eval_hits)
+struct HitsOut {
+    void* d_hits = nullptr;
+    uint64_t cap = 0;
+    void* d_n_hits = nullptr;
+    void* d_hit_first = nullptr;
+};
+
 static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pred, const void* d_selection,
                                 void* d_mask_out, void* d_valid_out, void* d_counts_out, void* d_cand_bytes,
                                 hipStream_t stream, const lc_predicate* pred2 = nullptr, void* d_total_out = nullptr,
-                                bool tolerate_backing = false) {
+                                bool tolerate_backing = false, const HitsOut* hits = nullptr) {
     return guarded([&]() -> lc_status {
-    if (!ctx || !s || !pred || !d_mask_out) return fail(LC_ERR_INVALID, "null argument");
+    if (!ctx || !s || !pred) return fail(LC_ERR_INVALID, "null argument");
+    // d_mask_out == NULL: the caller consumes COUNT(*), per-entry counts or the hit list and wants no mask
+    if (!d_mask_out && !d_total_out && !d_counts_out && !(hits && hits->d_hits))
+        return fail(LC_ERR_INVALID, "no output: d_mask_out is null and neither a count nor a hit list is asked for");
+    if (!d_mask_out && d_valid_out) return fail(LC_ERR_INVALID, "a validity output needs the mask output");
+    if (hits && hits->d_hits && !hits->d_n_hits) return fail(LC_ERR_INVALID, "d_n_hits is null");
+    if (hits && hits->d_n_hits) LC_HIP(hipMemsetAsync(hits->d_n_hits, 0, 8, stream));
     if (s->n == 0) {
         if (d_total_out) LC_HIP(hipMemsetAsync(d_total_out, 0, 8, stream));
         return LC_OK;
@@ -2479,8 +2522,26 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     {
         std::lock_guard<std::mutex> g(s->mu);
         scan_enter_stream(s, stream);
+        s->last_native_hits = false;
+        if (!d_mask_out && !s->d_mask_scratch) {
+            s->d_mask_scratch = static_cast<uint64_t*>(pool_alloc(ctx, std::max<uint64_t>(s->seg_offsets.back(), 1) * 8));
+            if (!s->d_mask_scratch) return fail(LC_ERR_OOM, "hipMalloc (mask scratch)");
+        }
     }
+    const bool want_hits = hits && hits->d_hits;
     ScanLaunch L{};
+    if (!d_mask_out) {
+        d_mask_out = s->d_mask_scratch;
+        L.mask_optional = 1;
+    }
+    if (want_hits) {
+        L.d_hits = static_cast<uint64_t*>(hits->d_hits);
+        L.hits_cap = hits->cap;
+        L.d_n_hits = static_cast<unsigned long long*>(hits->d_n_hits);
+        L.d_hit_first = static_cast<uint32_t*>(hits->d_hit_first);
+    }
+    // the evaluation proper; kernels that do not append the hit list themselves leave it to k_mask_to_hits below
+    const lc_status est = [&]() -> lc_status {
     if (d_total_out) {
         std::lock_guard<std::mutex> g(s->mu);
         if (!s->d_total_acc) {
@@ -2744,6 +2805,12 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     }
     LC_HIP(launch_str_pred(static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, sp.p, L, stream));
     return LC_OK;
+    }();
+    if (est != LC_OK) return est;
+    if (want_hits && !s->last_native_hits)
+        LC_HIP(launch_mask_to_hits(s->d_descs, s->is_str, s->n, static_cast<const uint64_t*>(d_mask_out), L.d_hits, L.hits_cap,
+                                   L.d_n_hits, L.d_hit_first, stream));
+    return LC_OK;
     });
 }
 
@@ -2847,7 +2914,10 @@ lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, con
     lc_scan* both[2] = {scan_a, scan_b};
     for (lc_scan* s : both) {
         std::lock_guard<std::mutex> g(s->mu);
+        // scan_a's scratch (aggregate partials) is used by the launch; scan_b's descriptors and blobs are read by it: both
+        // must know the stream, or lc_scan_destroy(scan_b) could recycle them under the running kernel
         if (s == scan_a) scan_enter_stream(s, st);
+        else if (std::find(s->streams_used.begin(), s->streams_used.end(), st) == s->streams_used.end()) s->streams_used.push_back(st);
         if (s->has_clamped) {
             const lc_status cs = clamp_unresolved_entries(ctx, s, nullptr, 0, d_selection, st, &s->needs_backing);
             if (cs != LC_OK) return cs;
@@ -2980,6 +3050,9 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
                         if (rc != LC_OK) return rc;
                     }
                     max_w = std::max(max_w, s->max_w);
+                    // the chain kernel reads the descriptors and blobs of EVERY step's scan on `st`: each scan must drain that
+                    // stream before its descriptors are recycled (lc_scan_destroy no longer synchronises the device)
+                    scan_note_stream(s, st);
                 }
                 chain.n_steps = run;
                 lc_scan* s_last = steps[k + run - 1].scans[0];
@@ -3060,6 +3133,8 @@ lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t wi
     if (!s || !pred || !out_algorithmic || !out_kernel_bytes) return fail(LC_ERR_INVALID, "null argument");
     *out_algorithmic = *out_kernel_bytes = 0;
     uint64_t alg = 0, own = 0;
+    const uint32_t sparse_flags = uint32_t(with_selection) & (LC_TRAFFIC_NO_MASK | LC_TRAFFIC_HIT_LIST);
+    with_selection &= LC_TRAFFIC_WITH_SELECTION;
     if (!s->is_str) {
         if (s->n == 0) return LC_OK;
         FixedPred fp;
@@ -3125,7 +3200,7 @@ lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t wi
         StrPredHost sp;
         if (make_str_pred(pred, &sp) == LC_OK && sp.p.mode == 1) {
             std::lock_guard<std::mutex> g(s->mu);
-            const uint64_t pb = like_pipeline_bytes(s, sp, false);
+            const uint64_t pb = like_pipeline_bytes(s, sp, false, sparse_flags);
             if (pb) own = pb;  // the pipeline takes this needle: its two kernels' bytes, not k_str_pred's
             else if (scanall_plain) {
                 // k_like_scanall: per entry its descriptor, the offset residuals, the whole FSST buffer, the keys of entries
@@ -3160,7 +3235,7 @@ lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t wi
                     sq.p.op = LC_OP_LIKE;
                     sq.p.needle_len = uint32_t(sq.needle.size());
                     sq.p.eq_len = uint32_t(pred->lit_len);
-                    const uint64_t pb = like_pipeline_bytes(s, sq, false);
+                    const uint64_t pb = like_pipeline_bytes(s, sq, false, sparse_flags);
                     if (pb) own = pb;
                 }
             }
@@ -3219,7 +3294,11 @@ lc_status lc_device_alloc(lc_ctx* ctx, uint64_t bytes, void** out) {
     if (!ctx || !out) return fail(LC_ERR_INVALID, "null argument");
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
-    LC_HIP(hipMalloc(out, bytes ? bytes : 8));
+    if (hipMalloc(out, bytes ? bytes : 8) != hipSuccess) {
+        (void)hipGetLastError();
+        like_orphans_clear(ctx);  // (cached scan-level indexes of destroyed scans go before an allocation fails)
+        if (hipMalloc(out, bytes ? bytes : 8) != hipSuccess) return fail(LC_ERR_OOM, "hipMalloc");
+    }
     return LC_OK;
     });
 }
@@ -3982,6 +4061,72 @@ lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_s
                                  static_cast<const uint64_t*>(d_value_offsets), 0,
                                  static_cast<const uint64_t*>(d_row_offsets) + n, capacity_rows, capacity_bytes,
                                  static_cast<uint8_t*>(d_data), st));
+    return LC_OK;
+    });
+}
+
+lc_status lc_scan_eval_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds, const void* d_selection,
+                            void* d_hits_out, uint64_t capacity, void* d_n_hits, void* d_hit_first, void* d_counts_out,
+                            void* d_total_out, void* stream) {
+    if (!preds || n_preds == 0 || n_preds > 2) return fail(LC_ERR_INVALID, "lc_scan_eval_hits takes one or two predicates");
+    if (!d_hits_out || !d_n_hits) return fail(LC_ERR_INVALID, "d_hits_out / d_n_hits is null");
+    HitsOut h;
+    h.d_hits = d_hits_out;
+    h.cap = capacity;
+    h.d_n_hits = d_n_hits;
+    h.d_hit_first = d_hit_first;
+    return scan_eval_impl(ctx, scan, &preds[0], d_selection, nullptr, nullptr, d_counts_out, nullptr,
+                          static_cast<hipStream_t>(stream), n_preds == 2 ? &preds[1] : nullptr, d_total_out, false, &h);
+}
+
+lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, void* d_hits_out, uint64_t capacity,
+                               void* d_n_hits, void* d_hit_first, void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !scan || !d_mask || !d_hits_out || !d_n_hits) return fail(LC_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LC_HIP(hipMemsetAsync(d_n_hits, 0, 8, st));
+    if (scan->n == 0) return LC_OK;
+    scan_note_stream(scan, st);
+    LC_HIP(launch_mask_to_hits(scan->d_descs, scan->is_str, scan->n, static_cast<const uint64_t*>(d_mask),
+                               static_cast<uint64_t*>(d_hits_out), capacity, static_cast<unsigned long long*>(d_n_hits),
+                               static_cast<uint32_t*>(d_hit_first), st));
+    return LC_OK;
+    });
+}
+
+lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits, uint64_t capacity_rows,
+                                    void* d_values_out, void* d_row_valid, void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !scan || !d_hits || !d_n_hits || !d_values_out) return fail(LC_ERR_INVALID, "null argument");
+    if (scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_fixed_hits covers fixed-width columns (byte views: lc_scan_gather_bytes_hits)");
+    if (scan->has_clamped || scan->has_fquant)
+        return fail(LC_UNSUPPORTED, "squeezed entries: lc_scan_gather_fixed decides which reads need the backing array");
+    if (scan->n == 0 || capacity_rows == 0) return LC_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    scan_note_stream(scan, st);
+    LC_HIP(launch_fixed_gather_hits(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, static_cast<const uint64_t*>(d_hits),
+                                    static_cast<const unsigned long long*>(d_n_hits), capacity_rows,
+                                    static_cast<uint8_t*>(d_values_out), static_cast<uint8_t*>(d_row_valid), st));
+    return LC_OK;
+    });
+}
+
+lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits, uint64_t capacity_rows,
+                                    void* d_views, void* d_row_valid, void* d_data, uint64_t capacity_bytes, void* d_n_bytes,
+                                    void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !scan || !d_hits || !d_n_hits || !d_views || !d_n_bytes || (capacity_bytes && !d_data))
+        return fail(LC_ERR_INVALID, "null argument");
+    if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes_hits covers byte-view columns");
+    if (capacity_bytes > 0x7FFFFFFFull) return fail(LC_ERR_INVALID, "a BinaryView offset is an i32: capacity_bytes must stay below 2 GiB");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    LC_HIP(hipMemsetAsync(d_n_bytes, 0, 8, st));
+    if (scan->n == 0 || capacity_rows == 0) return LC_OK;
+    scan_note_stream(scan, st);
+    LC_HIP(launch_str_gather_hits(static_cast<const StrDesc*>(scan->d_descs), scan->d_symtabs, static_cast<const uint64_t*>(d_hits),
+                                  static_cast<const unsigned long long*>(d_n_hits), capacity_rows, static_cast<uint32_t*>(d_views),
+                                  static_cast<uint8_t*>(d_row_valid), static_cast<uint8_t*>(d_data), capacity_bytes,
+                                  static_cast<unsigned long long*>(d_n_bytes), st));
     return LC_OK;
     });
 }

@@ -6,7 +6,7 @@ mkdir -p "$out"
 for v in "$@"; do
     name=$(basename "$v" .so)
     if [ "$v" = default ]; then unset LC_LIB_PATH; else export LC_LIB_PATH="$PWD/$v"; fi
-    timeout 300 python bench.py --workload int64_gt --int-kind date32 --int-bits 12 --no-cpu-baseline \
+    timeout 300 python bench.py --full-line --workload int64_gt --int-kind date32 --int-bits 12 --no-cpu-baseline \
         --secondary-set int,q6 > "$out/$name.json" 2> "$out/$name.err"
 done
 unset LC_LIB_PATH

@@ -2,7 +2,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for v in default "$@"; do
   if [ "$v" = default ]; then unset LC_LIB_PATH; else export LC_LIB_PATH=$R/liquid_cache_amd/variants/libliquid_cache_amd_$v.so; fi
-  python $R/bench.py --secondary-set like --no-cpu-baseline --no-needle-classes --steps 5 --warmup 2 2>&1 | tail -1 | python -c "
+  python $R/bench.py --full-line --secondary-set like --no-cpu-baseline --no-needle-classes --steps 5 --warmup 2 2>&1 | tail -1 | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
 for k,v in d['secondary'].items():

@@ -6,7 +6,7 @@ names=$1; shift
 mkdir -p $R/gpurun_out/ab
 for v in $names; do
   if [ "$v" = default ]; then unset LC_LIB_PATH; else export LC_LIB_PATH=$R/liquid_cache_amd/variants/libliquid_cache_amd_$v.so; fi
-  timeout 200 python $R/bench.py --no-secondary --no-cpu-baseline --rotate 1 --steps 20 --warmup 3 "$@" > $R/gpurun_out/ab/$v.json 2> $R/gpurun_out/ab/$v.err
+  timeout 200 python $R/bench.py --full-line --no-secondary --no-cpu-baseline --rotate 1 --steps 20 --warmup 3 "$@" > $R/gpurun_out/ab/$v.json 2> $R/gpurun_out/ab/$v.err
   python - <<PY
 import json
 try:

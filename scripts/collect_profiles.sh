@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 S=$R/gpurun_out/$tag
 D=$R/profiles/$tag
 mkdir -p $D
-cp $S/*_kernel_stats.csv $S/*_bench_line.json $S/full_bench_line.json $D/ 2>/dev/null
+cp $S/*_kernel_stats.csv $S/*_bench_line.json $S/bench_line.json $S/bench_detail.json $D/ 2>/dev/null
 [ -f $S/hbm_traffic.json ] && cp $S/hbm_traffic.json $D/
 [ -f $S/pmc_summary.txt ] && cp $S/pmc_summary.txt $D/hbm_traffic_pmc.txt
 ls -la $D

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export LC_LIB_PATH=$R/liquid_cache_amd/libliquid_cache_amd_timing.so
 for t in ${PHASES:-1 2 3 4 5 6 7 8 9}; do
-  LC_DEBUG_FLAGS=$((t << 16)) LC_DUMP_COUNTS=/tmp/tm_$t.npy python $R/bench.py --no-secondary --no-cpu-baseline --no-cold --steps 3 --warmup 1 "$@" > /tmp/tm_$t.log 2>&1 || tail -3 /tmp/tm_$t.log
+  LC_DEBUG_FLAGS=$((t << 16)) LC_DUMP_COUNTS=/tmp/tm_$t.npy python $R/bench.py --full-line --no-secondary --no-cpu-baseline --no-cold --steps 3 --warmup 1 "$@" > /tmp/tm_$t.log 2>&1 || tail -3 /tmp/tm_$t.log
   python - <<PY
 import numpy as np
 c = np.load("/tmp/tm_$t.npy").astype(np.int64)

@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-secondary --no-cold --no-cpu-baseline --rotate 1 --steps 3 --warmup 1"
+B="python $R/bench.py --full-line --no-secondary --no-cold --no-cpu-baseline --rotate 1 --steps 3 --warmup 1"
 G[1]="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS"
 G[2]="SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH"
 G[3]="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"

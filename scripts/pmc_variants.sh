@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in $names; do
   if [ "$v" = default ]; then unset LC_LIB_PATH; else export LC_LIB_PATH=$R/liquid_cache_amd/variants/libliquid_cache_amd_$v.so; fi
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 200 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_like_lean" --output-format csv -d $O/${v}_$c -- python $R/bench.py --no-secondary --no-cpu-baseline --no-cold --rotate 1 --steps 3 --warmup 1 "$@" > $O/${v}_$c.log 2>&1
+    timeout 200 rocprofv3 --pmc $c --kernel-trace --kernel-include-regex "k_like_lean" --output-format csv -d $O/${v}_$c -- python $R/bench.py --full-line --no-secondary --no-cpu-baseline --no-cold --rotate 1 --steps 3 --warmup 1 "$@" > $O/${v}_$c.log 2>&1
   done
   python - <<PY
 import csv, glob, statistics

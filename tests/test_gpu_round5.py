@@ -1,0 +1,275 @@
+"""Round 5: sparse results — hit lists instead of masks, and get-with-selection from a hit list in one launch.
+
+Reference shape: the per-batch BooleanBuffer a filter leaves and the gathers that consume it
+(datafusion/src/reader/runtime/liquid_cache_reader.rs:297-391, core/src/liquid_array/byte_view_array/helpers.rs:44-64,
+primitive_array.rs:370-374).  A hit list must hold exactly the set bits of the mask the oracle computes; the values gathered
+for its records must be the oracle's get-with-selection of the same rows.
+"""
+import os
+import sys
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import liquid_cache_amd as lc
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_data as fz  # noqa: E402
+from test_gpu_round4 import RUNS, _want_full, grouped_cases  # noqa: E402,F401  (the grouped-entries fixture)
+
+pytestmark = pytest.mark.gpu
+HINT = lc.CacheExpression.SUBSTRING_SEARCH
+
+
+def _stage_grouped(cache, lo, cases):
+    ids, flat = [], []
+    for r_i, (st, entries) in enumerate(cases):
+        path = 7100 + r_i
+        cache.set_symbol_table(path, lo.symtab_bytes(st))
+        for e_i, (rows, liquid) in enumerate(entries):
+            eid = lc.ParquetArrayID.new(12, r_i, 5, e_i)
+            cache.stage([eid], [liquid], [path])
+            ids.append(eid)
+            flat.append((rows, liquid, st))
+    return ids, flat
+
+
+def _hits_to_bits(hits, offs, n_bits):
+    bits = np.zeros(n_bits, bool)
+    e = (hits >> np.uint64(32)).astype(np.int64)
+    r = (hits & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    pos = offs[e].astype(np.int64) * 64 + r
+    assert len(np.unique(pos)) == len(pos), "a row appears twice in the hit list"
+    bits[pos] = True
+    return bits
+
+
+def _check_list_shape(hits, counts, first):
+    """The records of one entry are contiguous and ascending; `first` points at each entry's first record."""
+    if len(hits) == 0:
+        return
+    e = (hits >> np.uint64(32)).astype(np.int64)
+    r = (hits & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    change = np.flatnonzero(np.diff(e) != 0) + 1
+    starts = np.concatenate([[0], change])
+    ents = e[starts]
+    assert len(np.unique(ents)) == len(ents), "the records of an entry are not contiguous"
+    same = np.diff(e) == 0
+    assert (np.diff(r)[same] > 0).all(), "rows of an entry are not ascending"
+    for s, en in zip(starts, ents):
+        assert int(first[en]) == int(s)
+    run_len = np.diff(np.concatenate([starts, [len(hits)]]))
+    assert run_len.tolist() == counts[ents].tolist()
+
+
+@pytest.mark.parametrize("like_path", [0, 4, 3, 1])
+def test_hit_list_equals_oracle_mask(product_lib, oracle, grouped_cases, like_path):
+    lo = oracle
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1, like_path=like_path or None).build()
+    try:
+        ids, flat = _stage_grouped(cache, lo, grouped_cases)
+        scan = cache.scan(ids)
+        lens = [len(c[0]) for c in flat]
+        offs = scan.segment_offsets
+        n_bits = int(scan.mask_words) * 64
+        rng = np.random.default_rng(5)
+        needles = [b"google", b"mail", b"go", b"a", b"zzzzqqq", b"http://", b"index.php?id=1", b"#21", b"//"]
+        for rows, _, st in (flat[1], flat[7]):
+            needles += fz.make_needles(rng, rows, st, 2, for_like=True)
+        checked = 0
+        for qi, nd in enumerate(needles):
+            for op, with_sel in (("like", qi % 2 == 0), ("not_like", qi % 3 == 0), ("like", qi % 2 == 1)):
+                sels, words = [None] * len(flat), None
+                if with_sel:
+                    words = np.zeros(int(scan.mask_words), np.uint64)
+                    for b, n in enumerate(lens):
+                        se = rng.random(n) < [0.02, 0.5, 0.97][b % 3]
+                        sels[b] = se
+                        packed = np.packbits(se, bitorder="little")
+                        words[int(offs[b]): int(offs[b + 1])].view(np.uint8)[: len(packed)] = packed
+                expr = lc.LiquidExpr.try_new(op, b"%" + nd + b"%", pa.binary(), HINT)
+                want = np.zeros(n_bits, bool)
+                want_counts = np.zeros(len(flat), np.int64)
+                for b, (rows, liquid, st) in enumerate(flat):
+                    w = _want_full(lo, liquid, st, lo.OP_NAMES[op], b"%" + nd + b"%", sels[b], lens[b])
+                    want[int(offs[b]) * 64: int(offs[b]) * 64 + lens[b]] = w
+                    want_counts[b] = int(w.sum())
+                for from_mask in (False, True):
+                    hits, n, counts, total, first = scan.eval_hits_to_host(expr, selection=words, from_mask=from_mask)
+                    assert n == len(hits) == int(want.sum()) == total, (nd, op, with_sel, from_mask, n, int(want.sum()), total)
+                    assert counts.astype(np.int64).tolist() == want_counts.tolist()
+                    assert np.array_equal(_hits_to_bits(hits, offs, n_bits), want), (nd, op, with_sel, from_mask)
+                    _check_list_shape(hits, counts, first)
+                # a buffer that is too small: the count is still the full one, what was written are records of the result
+                if int(want.sum()) > 3:
+                    cap = int(want.sum()) // 2
+                    hits, n, _, total, _ = scan.eval_hits_to_host(expr, selection=words, capacity=cap)
+                    assert n == total == int(want.sum()) and len(hits) == cap
+                    assert _hits_to_bits(hits, offs, n_bits)[~want].sum() == 0
+                checked += 1
+        assert checked >= 27
+        scan.close()
+    finally:
+        cache.close()
+
+
+def test_count_without_mask_and_string_equality_hits(product_lib, oracle, grouped_cases):
+    """d_mask_out = NULL is legal for COUNT(*) / per-entry-count consumers on every evaluation path; string = / <> through
+    the scan-level index emits hit lists as well."""
+    import ctypes as C
+    lo = oracle
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1).build()
+    try:
+        ids, flat = _stage_grouped(cache, lo, grouped_cases)
+        scan = cache.scan(ids)
+        offs = scan.segment_offsets
+        n_bits = int(scan.mask_words) * 64
+        lens = [len(c[0]) for c in flat]
+        some_value = next(v for v in flat[0][0] if v is not None and len(v) > 14)
+        exprs = [lc.LiquidExpr.try_new("like", b"%google%", pa.binary(), HINT),
+                 lc.LiquidExpr.try_new("not_like", b"%a%", pa.binary(), HINT),
+                 lc.LiquidExpr.try_new("=", some_value, pa.binary(), HINT),
+                 lc.LiquidExpr.try_new("!=", some_value, pa.binary(), HINT),
+                 lc.LiquidExpr.try_new("<", b"http://m", pa.binary(), HINT)]
+        for expr in exprs:
+            mask, counts = scan.eval_to_host(expr)
+            d_total = scan._to_dev(np.zeros(1, np.uint64))
+            d_counts = scan._dev(max(scan.entries, 1) * 4)
+            try:
+                scan.eval_count(expr, 0, d_total.value, 0, d_counts.value)
+                cache._lib.lc_stream_synchronize(cache.handle, None)
+                total = int(scan._from_dev(d_total, np.uint64, 1)[0])
+                c2 = scan._from_dev(d_counts, np.uint32, scan.entries)
+            finally:
+                cache._lib.lc_device_free(cache.handle, d_total)
+                cache._lib.lc_device_free(cache.handle, d_counts)
+            assert total == int(counts.sum()) and c2.tolist() == counts.tolist()
+            hits, n, c3, t3, first = scan.eval_hits_to_host(expr)
+            bits = np.unpackbits(mask.view(np.uint8), bitorder="little").astype(bool)
+            assert n == t3 == total and np.array_equal(_hits_to_bits(hits, offs, n_bits), bits)
+            _check_list_shape(hits, c3, first)
+        # no output at all is an error, not a silent no-op
+        pred = exprs[0].as_predicate()
+        st = cache._lib.lc_scan_eval(cache.handle, scan._h, C.byref(pred), None, None, None, None)
+        assert st == -1
+        assert sum(lens) == scan.rows
+        scan.close()
+    finally:
+        cache.close()
+
+
+def test_gather_bytes_from_hit_list(product_lib, oracle, grouped_cases):
+    """BinaryView records + data buffer for the rows of a hit list == the oracle's get-with-selection of those rows."""
+    lo = oracle
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1).build()
+    try:
+        ids, flat = _stage_grouped(cache, lo, grouped_cases)
+        scan = cache.scan(ids)
+        lens = [len(c[0]) for c in flat]
+        truth = []  # per entry: the oracle's decode of every row
+        for rows, liquid, st in flat:
+            truth.append(lo.filter_byte_view(liquid, st, None))
+            assert truth[-1] == list(rows)
+        rng = np.random.default_rng(8)
+        # (a) what a selective LIKE leaves: the wave-cooperative decode (few rows per wave)
+        for nd in (b"google", b"#21", b"zzzzqqq"):
+            expr = lc.LiquidExpr.try_new("like", b"%" + nd + b"%", pa.binary(), HINT)
+            hits, n, _, _, _ = scan.eval_hits_to_host(expr)
+            got = scan.gather_bytes_hits_to_host(hits)
+            want = [truth[int(h >> np.uint64(32))][int(h & np.uint64(0xFFFFFFFF))] for h in hits]
+            assert got == want and all(nd in v for v in got)
+        # (b) random rows incl. nulls, in list order (any order is legal input): small and large lists (lane-per-row decode)
+        all_refs = np.concatenate([(np.uint64(e) << np.uint64(32)) | np.arange(n, dtype=np.uint64) for e, n in enumerate(lens)])
+        for k in (1, 7, 63, 64, 65, 900, len(all_refs)):
+            refs = all_refs if k == len(all_refs) else all_refs[rng.choice(len(all_refs), size=k, replace=False)]
+            got = scan.gather_bytes_hits_to_host(refs, capacity_bytes=64)  # (too small at first: retried with *d_n_bytes)
+            want = [truth[int(h >> np.uint64(32))][int(h & np.uint64(0xFFFFFFFF))] for h in refs]
+            assert got == want, k
+        scan.close()
+    finally:
+        cache.close()
+
+
+def test_gather_bytes_hits_length_classes(gpu_cache, oracle):
+    """Values of 0, 1..12 (inline views), 13, 254, 255 (length byte saturates) and 700 bytes, escapes, a shared prefix."""
+    rng = np.random.default_rng(3)
+    lengths = [0, 1, 4, 11, 12, 13, 14, 100, 253, 254, 255, 256, 700]
+    pool = [bytes(rng.integers(32, 127, size=n, dtype=np.uint8)) for n in lengths] + [b"\xff\xfe\x00\xff" * 5, "ÿñ".encode() * 9]
+    for shared in (b"", b"http://www.example.com/"):
+        vals = [shared + p for p in pool]
+        rows = [vals[int(i)] for i in rng.integers(0, len(vals), size=3000)]
+        for i in rng.choice(3000, size=100, replace=False):
+            rows[int(i)] = None
+        ids = []
+        for b in range(3):
+            eid = lc.ParquetArrayID.new(40 + len(shared), 0, 9, b)
+            gpu_cache.insert(eid, pa.array(rows[b * 1000:(b + 1) * 1000], type=pa.binary()), HINT)
+            ids.append(eid)
+        scan = gpu_cache.scan(ids)
+        refs = np.concatenate([(np.uint64(e) << np.uint64(32)) | np.arange(1000, dtype=np.uint64) for e in range(3)])
+        for sub in (refs, refs[rng.permutation(len(refs))[:50]]):
+            got = scan.gather_bytes_hits_to_host(sub)
+            want = [rows[int(h >> np.uint64(32)) * 1000 + int(h & np.uint64(0xFFFFFFFF))] for h in sub]
+            assert got == want
+        scan.close()
+
+
+def test_gather_fixed_from_hit_list(gpu_cache, oracle):
+    """Fixed-width columns: integers of several lane types, dates, decimals, ALP floats with patches; hits of a predicate on
+    ONE column project ANOTHER column of the same row ranges."""
+    import decimal
+    rng = np.random.default_rng(12)
+    n_batches, n = 5, 8192
+    total = n_batches * n - 100
+    cols = {
+        "i64": (rng.integers(-2**40, 2**40, size=total).astype(np.int64), pa.int64(), np.int64),
+        "i16": (rng.integers(-300, 3000, size=total).astype(np.int16), pa.int16(), np.int16),
+        "u8": (rng.integers(0, 200, size=total).astype(np.uint8), pa.uint8(), np.uint8),
+        "d32": (rng.integers(7000, 12000, size=total).astype(np.int32), pa.date32(), np.int32),
+        "f64": ((rng.integers(-10**6, 10**6, size=total) / 100.0).astype(np.float64), pa.float64(), np.float64),
+        "f32": ((rng.integers(-10**4, 10**4, size=total) / 10.0).astype(np.float32), pa.float32(), np.float32),
+    }
+    cols["f64"][0][rng.random(total) < 0.01] = np.pi  # ALP exceptions
+    cols["f32"][0][rng.random(total) < 0.01] = np.float32(np.e)
+    null_mask = rng.random(total) < 0.05
+    scans = {}
+    for ci, (name, (vals, pa_dt, _)) in enumerate(cols.items()):
+        ids = []
+        for k in range(n_batches):
+            eid = lc.ParquetArrayID.new(6, 0, 20 + ci, k)
+            sl = slice(k * n, min((k + 1) * n, total))
+            gpu_cache.insert(eid, pa.array(vals[sl], type=pa_dt, mask=null_mask[sl] if name in ("i16", "f64") else None))
+            ids.append(eid)
+        scans[name] = gpu_cache.scan(ids)
+    dec = [decimal.Decimal(int(x)) / 100 for x in rng.integers(0, 10**7, size=total)]
+    ids = []
+    for k in range(n_batches):
+        eid = lc.ParquetArrayID.new(6, 0, 40, k)
+        gpu_cache.insert(eid, pa.array(dec[k * n: min((k + 1) * n, total)], type=pa.decimal128(15, 2)))
+        ids.append(eid)
+    scans["dec"] = gpu_cache.scan(ids)
+    # the filter: i64 > literal (fixed-width evaluation: the list comes from the mask in scan-owned scratch)
+    lit = int(np.quantile(cols["i64"][0], 0.99))
+    expr = lc.LiquidExpr.try_new(">", lit, pa.int64())
+    hits, n_hits, counts, tot, first = scans["i64"].eval_hits_to_host(expr)
+    keep = cols["i64"][0] > lit
+    assert n_hits == tot == int(keep.sum()) == len(hits)
+    _check_list_shape(hits, counts, first)
+    rows = (hits >> np.uint64(32)).astype(np.int64) * n + (hits & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    assert sorted(rows.tolist()) == np.flatnonzero(keep).tolist()
+    for name, (vals, _, np_dt) in cols.items():
+        got, valid = scans[name].gather_fixed_hits_to_host(hits, np_dt)
+        nulls = null_mask[rows] if name in ("i16", "f64") else np.zeros(len(rows), bool)
+        assert valid.tolist() == (~nulls).tolist()
+        assert got[~nulls].view(np.uint8).tobytes() == vals[rows][~nulls].view(np.uint8).tobytes(), name  # bit-exact
+    got, valid = scans["dec"].gather_fixed_hits_to_host(hits, np.dtype([("lo", np.uint64), ("hi", np.uint64)]))
+    assert valid.all() and got["hi"].tolist() == [0] * len(rows)
+    assert got["lo"].tolist() == [int(dec[r] * 100) for r in rows]
+    # a dense list (every row): same values as the mask-driven gather
+    all_refs = np.concatenate([(np.uint64(e) << np.uint64(32)) | np.arange(min(n, total - e * n), dtype=np.uint64)
+                               for e in range(n_batches)])
+    got, _ = scans["u8"].gather_fixed_hits_to_host(all_refs, np.uint8)
+    assert got.tobytes() == cols["u8"][0].tobytes()
+    for s in scans.values():
+        s.close()
