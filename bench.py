@@ -106,7 +106,7 @@ def parse_args(argv=None):
                    help="skip the L3-cold timing (rocprofv3 --stats runs: the kernel average then only holds hot launches)")
     p.add_argument("--secondary-rows", type=int, default=0, help="rows of the secondary workloads (0 = --rows)")
     p.add_argument("--secondary-set", default="all",
-                   help="comma list of the secondary groups to run: q21,int,micro,q6,sweep,staging,like (kernel A/B runs)")
+                   help="comma list of the secondary groups to run: q21,rowgroup,int,micro,q6,sweep,staging,like (kernel A/B runs)")
     p.add_argument("--sweep-rows", type=int, default=0,
                    help="rows of the ClickBench pushdown sweep (config 5); 0 = the whole table (--rows)")
     p.add_argument("--seed", type=int, default=42)
@@ -827,6 +827,58 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                                           "value": (time.perf_counter() - t0) / 200 * 1e6}
     except Exception as e:  # noqa: BLE001
         out["mask_and_then_host_call"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return out
+
+
+def secondary_rowgroup(cache, lc, N, args, ids, expr, whole_scan_hits, rows):
+    """The number a drop-in gets when it calls at the REFERENCE's granularity: one evaluation per row group (the ~54 batches
+    of one ColumnAccessPath; liquid_stream.rs:358-430, liquid_cache_reader.rs:264-294) from T host threads on their own
+    streams, the row-group scans created once and kept — and per-entry lc_eval_predicate calls.  Driver: C++ over the public
+    ABI (lc_bench_rowgroup_run), so that no Python / GIL time is in the numbers."""
+    import ctypes as C
+    B = N.load_bench()
+    rgb = args.row_group_batches
+    ids_np = np.ascontiguousarray(np.asarray([int(e) for e in ids], dtype=np.uint64))
+    begins = list(range(0, len(ids), rgb)) + [len(ids)]
+    gb = np.ascontiguousarray(np.asarray(begins, dtype=np.uint64))
+    pred = expr.as_predicate()
+    out = {"row_groups": len(begins) - 1, "entries_per_row_group": rgb, "rows": int(rows),
+           "driver": "lc_bench_rowgroup_run: one lc_scan_eval_count per unit and pass, T threads x own stream, scans kept"}
+    runs = {}
+    best = None
+    for label, threads, gps, with_mask in (("t1", 1, 1, 0), ("t4", 4, 1, 0), ("t8", 8, 1, 0), ("t16", 16, 1, 0),
+                                           ("t8_mask", 8, 1, 1), ("t8_x8", 8, 8, 0), ("t1_x226", 1, len(begins) - 1, 0)):
+        st = N.RowGroupStats()
+        rc = B.lc_bench_rowgroup_run(cache._ctx, len(begins) - 1, gb.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                     ids_np.ctypes.data_as(C.POINTER(C.c_uint64)), C.cast(C.byref(pred), C.c_void_p), threads, 5,
+                                     with_mask, gps, C.byref(st))
+        if rc != 0:
+            runs[label] = {"error": "lc_bench_rowgroup_run rc %d" % rc}
+            continue
+        assert int(st.hits) == whole_scan_hits, "row-group calls: COUNT(*) %d != the whole scan's %d" % (st.hits, whole_scan_hits)
+        r = {"threads": threads, "row_groups_per_call": gps, "mask_written": bool(with_mask), "calls_per_pass": int(st.units),
+             "pass_us": st.wall_s / st.passes * 1e6, "rows_per_s": rows * st.passes / st.wall_s,
+             "call_us_host_side": st.call_us_mean, "first_pass_ms": st.first_pass_s * 1e3,
+             "us_per_call_wall": st.wall_s / st.passes / max(int(st.units), 1) * 1e6 * threads}
+        runs[label] = r
+        if gps == 1 and not with_mask and (best is None or r["rows_per_s"] > best["rows_per_s"]):
+            best = r
+    out["runs"] = runs
+    if best:
+        out["rows_per_s"] = best["rows_per_s"]
+        out["best_threads"] = best["threads"]
+        out["hits_equal_whole_scan"] = True
+    # the per-entry drop-in call (host buffers out): what `impl LiquidArray for GpuLiquidArray` pays per batch
+    n_e = min(len(ids), 2048)
+    for threads in (1, 8):
+        us, hits = C.c_double(), C.c_uint64()
+        rc = B.lc_bench_entry_calls(cache._ctx, n_e, ids_np.ctypes.data_as(C.POINTER(C.c_uint64)), C.cast(C.byref(pred), C.c_void_p),
+                                    threads, 2, args.batch_size, C.byref(us), C.byref(hits))
+        if rc == 0:
+            out["eval_predicate_call_us" if threads == 1 else "eval_predicate_call_us_8_callers"] = us.value
+            out["eval_predicate_hits_first_%d_entries" % n_e] = int(hits.value)
+        else:
+            out["eval_predicate_call_error"] = rc
     return out
 
 
@@ -1925,6 +1977,11 @@ def main():
                 sec["q21_pipeline"] = q21_pipeline(cache, lc, N, args, rank, n_batches, threads, scan, expr, torch, stream)
             except Exception as e:  # noqa: BLE001
                 sec["q21_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if args.workload == "url_like" and want("rowgroup"):
+            try:
+                sec["rowgroup_granularity"] = secondary_rowgroup(cache, lc, N, args, ids, expr, hits, int(scan.rows))
+            except Exception as e:  # noqa: BLE001
+                sec["rowgroup_granularity"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if want("int"):
             sec.update(secondary_int_columns(cache, lc, N, args, sec_rows, threads, torch, stream, iters))
         if want("micro"):

@@ -553,9 +553,11 @@ LC_API lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_
  *   fixed width: d_values_out receives k decoded values (the column's Arrow value width); d_row_valid (optional) k bytes.
  *   byte views : d_views receives k Arrow BinaryView / Utf8View records (16 bytes: i32 length; up to 12 bytes the value
  *                itself, zero padded; else 4-byte prefix, buffer index 0, i32 offset into d_data); nulls have length 0 and
- *                d_row_valid[i] == 0.  Space in d_data is claimed with an atomic per wave: *d_n_bytes (u64, device; zeroed
- *                by the call) receives the bytes the values need — a value that would end beyond capacity_bytes is not
- *                written (its view still carries length and offset): compare and retry.  capacity_bytes < 2 GiB.
+ *                d_row_valid[i] == 0.  Space in d_data is claimed with one atomic per batch of rows: *d_n_bytes (u64,
+ *                device; zeroed by the call) receives the bytes claimed — every non-empty value claims its length, also
+ *                the ones of 12 bytes and less that live in their view (a batch's values are then ONE range of the
+ *                buffer, which a wave stores coalesced).  A value that would end beyond capacity_bytes is not written
+ *                (its view carries length and offset only): compare and retry.  capacity_bytes < 2 GiB.
  * LC_UNSUPPORTED for scans that hold squeezed entries (lc_scan_gather_fixed decides their reads). */
 LC_API lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits,
                                            uint64_t capacity_rows, void* d_values_out, void* d_row_valid, void* stream);

@@ -65,6 +65,33 @@ LC_BENCH_API int32_t lc_bench_eval_timed(void* ctx, void* scan, const void* pred
                                          void* d_counts_out, void* stream, int32_t iters, uint64_t flush_bytes,
                                          float* out_avg_ms);
 
+/* Row-group-granular driver: the column is walked the way the reference's reader walks it — one evaluation per ROW GROUP
+ * (the batches that share a ColumnAccessPath: liquid_stream.rs:358-430, liquid_cache_reader.rs:264-294), `threads` host
+ * threads at once, each on a stream of its own (lc_stream_create), the row-group scans created once and kept.
+ *   group_begin: n_groups + 1 indices into entry_ids (row group g = entry_ids[group_begin[g] .. group_begin[g + 1]))
+ *   groups_per_scan: consecutive row groups one scan (one call) covers — 1 is the reference's granularity
+ *   with_mask: 0 = COUNT(*) only (d_mask_out = NULL), 1 = the hit mask of every call is written as well
+ * Every call is lc_scan_eval_count (public ABI); a pass = every unit once; `passes` passes are timed after one untimed pass
+ * (scan creation, scan-level indexes, plans: first_pass_s). */
+typedef struct {
+    double wall_s;        /* the timed passes: slowest thread */
+    double first_pass_s;  /* scan creation + first evaluation of every unit: slowest thread */
+    double total_s;       /* everything, threads started to joined */
+    double call_us_mean;  /* host time inside one lc_scan_eval_count call (launch side), mean over the timed calls */
+    uint64_t calls;       /* timed calls */
+    uint64_t hits;        /* COUNT(*) of ONE pass summed over the units (== the whole-column scan's) */
+    uint64_t units;
+    uint32_t passes, threads;
+} lc_rowgroup_stats;
+LC_BENCH_API int32_t lc_bench_rowgroup_run(void* ctx, uint64_t n_groups, const uint64_t* group_begin, const uint64_t* entry_ids,
+                                           const void* pred, int32_t threads, int32_t passes, int32_t with_mask,
+                                           int32_t groups_per_scan, lc_rowgroup_stats* out);
+/* The per-entry drop-in call (lc_eval_predicate, host buffers out, no selection) over `n` entries, `threads` callers at
+ * once, `rounds` rounds after one warming round: *out_call_us = what one caller waits per call; *out_hits = set bits of
+ * round 0 (== the scan's COUNT(*)). */
+LC_BENCH_API int32_t lc_bench_entry_calls(void* ctx, uint64_t n, const uint64_t* entry_ids, const void* pred, int32_t threads,
+                                          int32_t rounds, uint32_t rows_per_entry, double* out_call_us, uint64_t* out_hits);
+
 /* Test aid (host only, no context): the inverted row lists lc_stage attaches to byte-view entries of substring-search
  * columns — u16 offsets[d + 1], then the valid rows grouped by dictionary key — for `n` (<= 65535) keys, an optional
  * LSB-first validity bitmap and a dictionary of `d` values.  Returns the number of u16 written to `out` (d + 1 + n + 32;

@@ -79,7 +79,14 @@ EXPORTED_SYMBOLS = [
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
-                 "lc_calibrate_read", "lc_probe_stream_read", "lc_debug_row_lists", "lc_bench_eval_timed"]
+                 "lc_calibrate_read", "lc_probe_stream_read", "lc_debug_row_lists", "lc_bench_eval_timed",
+                 "lc_bench_rowgroup_run", "lc_bench_entry_calls"]
+
+
+class RowGroupStats(C.Structure):
+    _fields_ = [("wall_s", C.c_double), ("first_pass_s", C.c_double), ("total_s", C.c_double), ("call_us_mean", C.c_double),
+                ("calls", C.c_uint64), ("hits", C.c_uint64), ("units", C.c_uint64), ("passes", C.c_uint32),
+                ("threads", C.c_uint32)]
 
 _lib = None
 _bench = None
@@ -109,6 +116,10 @@ def load_bench():
     B.lc_debug_row_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, sz]
     B.lc_bench_eval_timed.restype = i32
     B.lc_bench_eval_timed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, u64, C.POINTER(C.c_float)]
+    B.lc_bench_rowgroup_run.restype = i32
+    B.lc_bench_rowgroup_run.argtypes = [vp, u64, C.POINTER(u64), C.POINTER(u64), vp, i32, i32, i32, i32, C.POINTER(RowGroupStats)]
+    B.lc_bench_entry_calls.restype = i32
+    B.lc_bench_entry_calls.argtypes = [vp, u64, C.POINTER(u64), vp, i32, i32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(u64)]
     _bench = B
     return B
 

@@ -48,6 +48,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
     v += dpp_or_zero<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
     return v;
 }
+// OR of `v` over the 64 lanes, in every lane (the same DPP ladder, then a broadcast of lane 63)
+__device__ __forceinline__ uint32_t wave_or_all(uint32_t v) {
+    v |= dpp_or_zero<0x111, 0xF>(v);
+    v |= dpp_or_zero<0x112, 0xF>(v);
+    v |= dpp_or_zero<0x114, 0xF>(v);
+    v |= dpp_or_zero<0x118, 0xF>(v);
+    v |= dpp_or_zero<0x142, 0xA>(v);
+    v |= dpp_or_zero<0x143, 0xC>(v);
+    return uint32_t(__builtin_amdgcn_readlane(int(v), 63));
+}
 // value of the previous lane (lane 0 gets `first`)
 __device__ __forceinline__ uint32_t lane_shift_up1(uint32_t v, uint32_t first) {
     return uint32_t(__builtin_amdgcn_update_dpp(int(first), int(v), 0x138, 0xF, 0xF, false));  // wave_shr:1

@@ -3666,22 +3666,60 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather_hits(const FixedDesc*
     }
 }
 
-// the first min(len, 4) decoded bytes of a value (the prefix field of a BinaryView), a code at a time
-__device__ __forceinline__ uint32_t str_first4(const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop, const DevSymtab& st) {
-    uint32_t v = 0, have = 0;
-    for (uint32_t p = start; p < stop && have < 4u;) {
-        const uint32_t c = fsst[p++];
-        uint64_t sym;
-        uint32_t sl;
-        if (c == 255u) { if (p >= stop) break; sym = fsst[p++]; sl = 1; }
-        else { sym = st.sym[c]; sl = st.len[c]; }
-        if (sl == 0) continue;
-        if (sl < 8u) sym &= (uint64_t(1) << (8u * sl)) - 1;
-        v |= uint32_t(sym << (8u * have));
-        have += sl;
+// One value decoded by the whole wave (wave_decode_value) with the symbol table wherever `st` lives (LDS copy or global),
+// the first chunk's bytes already loaded by the caller (`pre`: byte start + lane, so that the loads of several values are in
+// flight together), and the value's first 12 bytes returned in every lane (`head`: a BinaryView holds values of up to 12
+// bytes itself and the first four of longer ones).  store == false: sizes and head only.
+template <class Tab>
+__device__ __forceinline__ uint32_t wave_decode_head(const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop, const Tab& st,
+                                                     uint8_t* __restrict__ out, bool store, uint32_t pre, uint32_t (&head)[3]) {
+    const int lane = lane_id();
+    uint32_t out_off = 0, h0 = 0, h1 = 0, h2 = 0;
+    bool lit0 = false;
+    for (uint32_t p = start; p < stop; p += kWave) {
+        const uint32_t i = p + uint32_t(lane);
+        const bool in = i < stop;
+        const uint32_t b = p == start ? (in ? pre : 0u) : (in ? uint32_t(fsst[i]) : 0u);
+        const uint64_t m255 = __ballot(in && b == 255u);
+        const uint64_t lower = lane == 0 ? 0 : (~uint64_t(0) >> (64 - lane));
+        const uint64_t not255_below = ~m255 & lower;
+        uint32_t r;
+        if (not255_below != 0) r = uint32_t(lane) - 1u - uint32_t(63 - __clzll((long long)not255_below));
+        else r = lit0 ? (lane == 0 ? 1u : uint32_t(lane) - 1u) : uint32_t(lane);
+        const bool literal = (lane == 0 && lit0) || (r & 1u) != 0;
+        const bool escape = in && b == 255u && !literal;
+        uint32_t len = 0;
+        if (in && !escape) len = literal ? 1u : uint32_t(st.len[b]);
+        const uint32_t incl = wave_inclusive_sum(len);
+        if (len) {
+            const uint32_t o = out_off + incl - len;
+            const uint64_t sym = literal ? uint64_t(b) : uint64_t(st.sym[b]);
+            if (store)
+                for (uint32_t q = 0; q < len; q++) out[o + q] = uint8_t(sym >> (8 * q));
+            if (o < 12u) {
+                for (uint32_t q = 0; q < len && o + q < 12u; q++) {
+                    const uint32_t pos = o + q, byte = uint32_t(sym >> (8 * q)) & 0xFFu;
+                    const uint32_t sh = byte << (8u * (pos & 3u));
+                    if (pos < 4u) h0 |= sh; else if (pos < 8u) h1 |= sh; else h2 |= sh;
+                }
+            }
+        }
+        out_off += read_lane(incl, kWave - 1);
+        lit0 = ((__ballot(escape) >> 63) & 1) != 0;
     }
-    return v;
+    head[0] = wave_or_all(h0);
+    head[1] = wave_or_all(h1);
+    head[2] = wave_or_all(h2);
+    return out_off;
 }
+
+// the symbol table as k_str_gather_hits keeps it in LDS: DevSymtab's layout, copied verbatim by LDS DMA
+struct alignas(16) LdsSymtab {
+    uint64_t sym[256];
+    uint8_t len[256];
+};
+static_assert(sizeof(LdsSymtab) == sizeof(DevSymtab) && sizeof(LdsSymtab) == 2304, "LdsSymtab mirrors DevSymtab");
+constexpr uint32_t kGatherStage = 6144;
 
 __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __restrict__ descs,
                                                                const DevSymtab* __restrict__ symtabs,
@@ -3690,31 +3728,52 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
                                                                uint32_t* __restrict__ views, uint8_t* __restrict__ row_valid,
                                                                uint8_t* __restrict__ data, uint64_t cap_bytes,
                                                                unsigned long long* __restrict__ n_bytes) {
+    __shared__ LdsSymtab s_tab[kWavesPerBlock];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[kWavesPerBlock][kGatherStage + 16];
     const uint64_t k = min(uint64_t(*n_hits), cap_rows);
     const uint64_t n_waves = uint64_t(gridDim.x) * kWavesPerBlock;
     const int lane = lane_id();
-    const uint64_t gw = uint64_t(blockIdx.x) * kWavesPerBlock + uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
-    // rows of a batch: few rows for this grid -> small batches, every value decoded by the whole wave (a lane per compressed
-    // byte: the latency of a selective gather is that of its slowest lane-serial walk otherwise); many rows -> 64 per batch, a
-    // lane per row
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint64_t gw = uint64_t(blockIdx.x) * kWavesPerBlock + wave;
+    // Rows of a batch.  Few rows for this grid (what a selective filter leaves): R = the power of two that gives every wave
+    // one batch; the batch's R rows take the dependent loads hits -> descriptor -> key -> offsets / length -> compressed
+    // bytes side by side (a lane per row, then a load per row with all lanes), and each value is decoded by the whole wave out
+    // of the LDS copy of its symbol table.  Many rows: 64 per batch, a lane per row, decoded into LDS and stored coalesced.
     uint32_t R = 64;
-    if (k < n_waves * 16u) {
-        const uint64_t per = (k + n_waves - 1) / max(n_waves, uint64_t(1));
+    if (k < n_waves * 32u) {
+        const uint64_t per = (k + n_waves - 1) / n_waves;
         R = 1;
-        while (R < per && R < 64u) R <<= 1;
+        while (R < per) R <<= 1;
     }
     const bool coop = R < 64u;
+    uint32_t cached_slot = 0xFFFFFFFFu;  // wave uniform: the table in s_tab[wave]
+    LdsSymtab& tab = s_tab[wave];
     for (uint64_t rb = gw * R; rb < k; rb += n_waves * R) {
         const uint64_t i = rb + uint64_t(lane);
         const bool live = uint32_t(lane) < R && i < k;
         const uint64_t ref = live ? hits[i] : 0;
         const uint32_t row = uint32_t(ref);
         const StrDesc* dp = descs + uint32_t(ref >> 32);
+        const uint32_t slot = live ? dp->symtab_slot : 0u;
+        const uint64_t lm = __ballot(live);
+        const uint32_t slot0 = read_lane(slot, int(__ffsll((long long)lm)) - 1);
+        const bool in_lds = __ballot(live && slot != slot0) == 0;  // wave uniform
+        bool tab_pending = false;
+        if (in_lds && slot0 != cached_slot) {
+            // 2304 bytes by LDS DMA (3 x 64 lanes x 16 bytes, the last issue 16 lanes): in flight beside the loads below
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint8_t* src = reinterpret_cast<const uint8_t*>(symtabs + slot0);
+            uint8_t* dstl = reinterpret_cast<uint8_t*>(&tab);
+            async_copy16(src + uint32_t(lane) * 16u, dstl);
+            async_copy16(src + 1024u + uint32_t(lane) * 16u, dstl + 1024);
+            if (lane < 16) async_copy16(src + 2048u + uint32_t(lane) * 16u, dstl + 2048);
+            cached_slot = slot0;
+            tab_pending = true;
+        }
         bool valid = false;
-        uint32_t len = 0, start = 0, stop = 0, slot = 0;
+        uint32_t len = 0, start = 0, stop = 0;
         if (live) {
             const StrDesc& d = *dp;
-            slot = d.symtab_slot;
             valid = row < d.n && (d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true);
             if (valid) {
                 const uint32_t key = uint32_t(d.keys[row]);
@@ -3722,65 +3781,145 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
                 len = str_decoded_len(d, symtabs[slot], key);
             }
         }
-        // space in the data buffer: values of more than 12 bytes (shorter ones live in their view), one atomic per batch
-        const uint32_t need = len > 12u ? len : 0u;
-        const uint32_t incl = wave_inclusive_sum(need);
+        // space in the data buffer, one atomic per batch; the batch's values are neighbours there
+        const uint32_t incl = wave_inclusive_sum(len);
         const uint32_t tot = read_lane(incl, kWave - 1);
         unsigned long long b = 0;
         if (tot && lane == 0) b = atomicAdd(n_bytes, (unsigned long long)tot);
         b = uniform_u64(b);
-        const uint64_t off = b + incl - need;
-        const bool fits = need == 0 || off + need <= cap_bytes;
+        const uint64_t off = b + incl - len;
+        const bool fits = off + len <= cap_bytes;
         uint32_t* v = views + 4u * i;
         if (live) {
             if (row_valid) row_valid[i] = valid ? 1 : 0;
-            if (len > 12u) {
-                const uint4 rec = make_uint4(len, str_first4(dp->fsst, start, stop, symtabs[slot]), 0u, uint32_t(off));
-                *reinterpret_cast<uint4*>(v) = rec;
-            } else {
-                *reinterpret_cast<uint4*>(v) = make_uint4(len, 0u, 0u, 0u);  // (the value's bytes follow below)
-            }
+            if (len == 0) *reinterpret_cast<uint4*>(v) = make_uint4(0u, 0u, 0u, 0u);          // null or empty
+            else if (!fits) *reinterpret_cast<uint4*>(v) = make_uint4(len, 0u, 0u, uint32_t(off));  // (the caller retries)
         }
-        uint8_t* dst = len > 12u ? data + off : reinterpret_cast<uint8_t*>(v) + 4;
+        const uint64_t todo = __ballot(live && len != 0 && fits);
+        if (todo == 0) {
+            if (tab_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            continue;
+        }
         if (coop) {
-            const uint64_t todo = __ballot(live && len != 0 && fits);
+            // values four at a time: their first 64 compressed bytes requested together, then decoded one after the other
             for (uint64_t m = todo; m;) {
-                const int j = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)m)) - 1);
-                m &= m - 1;
-                const uint64_t dj = uniform_u64(uint64_t(__shfl((unsigned long long)reinterpret_cast<uintptr_t>(dst), j, kWave)));
-                const uint64_t fj = uniform_u64(uint64_t(__shfl((unsigned long long)reinterpret_cast<uintptr_t>(dp->fsst), j, kWave)));
-                (void)wave_decode_value<true>(reinterpret_cast<const uint8_t*>(uintptr_t(fj)), read_lane(start, j), read_lane(stop, j),
-                                              symtabs[read_lane(slot, j)], reinterpret_cast<uint8_t*>(uintptr_t(dj)));
+                int j[4];
+                uint32_t pre[4], st_[4], sp_[4];
+                uint64_t fp[4];
+                int nq = 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    j[q] = -1;
+                    if (m) {
+                        j[q] = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)m)) - 1);
+                        m &= m - 1;
+                        nq = q + 1;
+                        st_[q] = read_lane(start, j[q]);
+                        sp_[q] = read_lane(stop, j[q]);
+                        fp[q] = uniform_u64(uint64_t(__shfl((unsigned long long)reinterpret_cast<uintptr_t>(dp->fsst), j[q], kWave)));
+                        const uint32_t x = st_[q] + uint32_t(lane);
+                        pre[q] = x < sp_[q] ? uint32_t(as_global(reinterpret_cast<const uint8_t*>(uintptr_t(fp[q])))[x]) : 0u;
+                    }
+                }
+                if (tab_pending) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    tab_pending = false;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (q >= nq) break;
+                    const uint32_t lj = read_lane(len, j[q]);
+                    const uint64_t oj = uniform_u64(uint64_t(__shfl((unsigned long long)off, j[q], kWave)));
+                    uint32_t head[3];
+                    const uint8_t* f = reinterpret_cast<const uint8_t*>(uintptr_t(fp[q]));
+                    if (in_lds) (void)wave_decode_head(f, st_[q], sp_[q], tab, data + oj, true, pre[q], head);
+                    else (void)wave_decode_head(f, st_[q], sp_[q], symtabs[read_lane(slot, j[q])], data + oj, true, pre[q], head);
+                    if (lane == 0) {
+                        uint32_t* vj = views + 4u * (rb + uint64_t(j[q]));
+                        *reinterpret_cast<uint4*>(vj) = lj > 12u ? make_uint4(lj, head[0], 0u, uint32_t(oj))
+                                                                : make_uint4(lj, head[0], head[1], head[2]);
+                    }
+                }
             }
             continue;
         }
-        if (!live || len == 0 || !fits) continue;
-        const DevSymtab& st = symtabs[slot];
-        ByteReader br;
-        br.init(dp->fsst, start, stop);
-        // decoded bytes are collected in a register and stored eight at a time (see k_str_decode_sel)
-        uint8_t* o = dst;
-        uint64_t buf = 0;
-        uint32_t have = 0;
-        while (br.more()) {
-            const uint32_t c = br.next();
-            uint64_t sym;
-            uint32_t sl;
-            if (c == 255u) { if (!br.more()) break; sym = br.next(); sl = 1; }
-            else { sym = st.sym[c]; sl = st.len[c]; }
-            if (sl == 0) continue;
-            if (sl < 8u) sym &= (uint64_t(1) << (8u * sl)) - 1;
-            buf |= sym << (8u * have);
-            have += sl;
-            if (have >= 8u) {
-                if (len > 12u) store_unaligned<uint64_t>(o, buf);
-                else for (uint32_t q = 0; q < 8u; q++) o[q] = uint8_t(buf >> (8u * q));
-                o += 8;
-                have -= 8u;
-                buf = have ? sym >> (8u * (sl - have)) : 0;
-            }
+        if (tab_pending) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
-        for (uint32_t q = 0; q < have; q++) o[q] = uint8_t(buf >> (8u * q));
+        // ---- 64 rows, a lane per row.  The batch's bytes are one range [b, b + tot) of the data buffer: decoded into LDS (byte
+        // stores), they leave as whole 16-byte pieces — 8-byte stores straight from the lanes hit 64 different lines per
+        // instruction, each a partial line for the memory system to merge (see k_str_decode_sel).
+        const bool staged = in_lds && tot <= kGatherStage && b + tot <= cap_bytes && todo == __ballot(live && len != 0);
+        const uint64_t g0 = uint64_t(reinterpret_cast<uintptr_t>(data)) + b;
+        const uint32_t mis = uint32_t(g0) & 15u;  // the LDS copy has the alignment of its place in memory
+        uint32_t h0 = 0, h1 = 0, h2 = 0;
+        if (live && len != 0 && fits) {
+            const uint8_t* p = dp->fsst + start;
+            const uint32_t n = stop - start;
+            uint8_t* so = s_out[wave] + mis + uint32_t(off - b);
+            uint8_t* go = data + off;
+            uint32_t vpos = 0;
+            // the compressed bytes sixteen at a time, the next sixteen requested while these are decoded
+            uint64_t c0 = load_unaligned<uint64_t>(p), c1 = load_unaligned<uint64_t>(p + 8);
+            uint64_t n0 = 0, n1 = 0;
+            if (n > 16u) { n0 = load_unaligned<uint64_t>(p + 16); n1 = load_unaligned<uint64_t>(p + 24); }
+            bool lit = false;
+            uint64_t gbuf = 0;   // unstaged: decoded bytes waiting for an 8-byte store
+            uint32_t ghave = 0;
+            for (uint32_t pos = 0; pos < n;) {
+                const uint32_t ci = pos & 15u;
+                const uint32_t c = uint32_t(((ci & 8u) ? c1 : c0) >> (8u * (ci & 7u))) & 0xFFu;
+                pos++;
+                if ((pos & 15u) == 0) {
+                    c0 = n0;
+                    c1 = n1;
+                    if (pos + 16u < n) { n0 = load_unaligned<uint64_t>(p + pos + 16u); n1 = load_unaligned<uint64_t>(p + pos + 24u); }
+                }
+                uint64_t sym;
+                uint32_t sl;
+                if (lit) { sym = c; sl = 1; lit = false; }
+                else if (c == 255u) { lit = true; continue; }
+                else if (in_lds) { sym = tab.sym[c]; sl = tab.len[c]; }
+                else { sym = symtabs[slot].sym[c]; sl = symtabs[slot].len[c]; }
+                if (sl == 0) continue;
+                if (sl < 8u) sym &= (uint64_t(1) << (8u * sl)) - 1;
+                if (vpos < 12u) {
+                    for (uint32_t q = 0; q < sl && vpos + q < 12u; q++) {
+                        const uint32_t ps = vpos + q, sh = (uint32_t(sym >> (8u * q)) & 0xFFu) << (8u * (ps & 3u));
+                        if (ps < 4u) h0 |= sh; else if (ps < 8u) h1 |= sh; else h2 |= sh;
+                    }
+                }
+                if (staged) {
+                    for (uint32_t q = 0; q < sl; q++) so[vpos + q] = uint8_t(sym >> (8u * q));
+                } else {
+                    gbuf |= sym << (8u * ghave);
+                    ghave += sl;
+                    if (ghave >= 8u) {
+                        store_unaligned<uint64_t>(go, gbuf);
+                        go += 8;
+                        ghave -= 8u;
+                        gbuf = ghave ? sym >> (8u * (sl - ghave)) : 0;
+                    }
+                }
+                vpos += sl;
+            }
+            if (!staged) for (uint32_t q = 0; q < ghave; q++) go[q] = uint8_t(gbuf >> (8u * q));
+            *reinterpret_cast<uint4*>(v) = len > 12u ? make_uint4(len, h0, 0u, uint32_t(off)) : make_uint4(len, h0, h1, h2);
+        }
+        if (staged) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint64_t gend = g0 + tot;
+            const uint64_t ga = min((g0 + 15u) & ~uint64_t(15), gend), gb = max(gend & ~uint64_t(15), ga);
+            for (uint64_t x = g0 + uint64_t(lane); x < ga; x += kWave)
+                *reinterpret_cast<uint8_t*>(uintptr_t(x)) = s_out[wave][uint32_t(x - g0) + mis];
+            for (uint64_t x = ga + uint64_t(lane) * 16u; x < gb; x += uint64_t(kWave) * 16u)
+                *reinterpret_cast<uint4*>(uintptr_t(x)) = *reinterpret_cast<const uint4*>(&s_out[wave][uint32_t(x - g0) + mis]);
+            for (uint64_t x = gb + uint64_t(lane); x < gend; x += kWave)
+                *reinterpret_cast<uint8_t*>(uintptr_t(x)) = s_out[wave][uint32_t(x - g0) + mis];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
     }
 }
 
@@ -5111,7 +5250,8 @@ hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_sym
                                   const unsigned long long* d_n_hits, uint64_t cap_rows, uint32_t* d_views, uint8_t* d_row_valid,
                                   uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, hipStream_t stream) {
     if (cap_rows == 0) return hipSuccess;
-    const uint32_t grid = uint32_t(std::min<uint64_t>((cap_rows + kWavesPerBlock - 1) / kWavesPerBlock, uint64_t(device_cus()) * 8));
+    // 34 KB of LDS per workgroup: four of them per CU are resident, and a latency-bound gather wants no second round
+    const uint32_t grid = uint32_t(std::min<uint64_t>((cap_rows + kWavesPerBlock - 1) / kWavesPerBlock, uint64_t(device_cus()) * 4));
     hipLaunchKernelGGL(k_str_gather_hits, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_hits, d_n_hits, cap_rows,
                        d_views, d_row_valid, d_data, cap_bytes, d_n_bytes);
     return hipGetLastError();
