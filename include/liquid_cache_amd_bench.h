@@ -67,11 +67,11 @@ LC_BENCH_API int32_t lc_bench_eval_timed(void* ctx, void* scan, const void* pred
 
 /* Row-group-granular driver: the column is walked the way the reference's reader walks it — one evaluation per ROW GROUP
  * (the batches that share a ColumnAccessPath: liquid_stream.rs:358-430, liquid_cache_reader.rs:264-294), `threads` host
- * threads at once, each on a stream of its own (lc_stream_create), the row-group scans created once and kept.
+ * threads at once, each on a stream of its own (one lc_stream_create each), the row-group scans created once and kept.
  *   group_begin: n_groups + 1 indices into entry_ids (row group g = entry_ids[group_begin[g] .. group_begin[g + 1]))
  *   groups_per_scan: consecutive row groups one scan (one call) covers — 1 is the reference's granularity
  *   with_mask: 0 = COUNT(*) only (d_mask_out = NULL), 1 = the hit mask of every call is written as well
- * Every call is lc_scan_eval_count (public ABI); a pass = every unit once; `passes` passes are timed after one untimed pass
+ * Every call is the public lc_scan_eval_count; a pass = every unit once; `passes` passes are timed after one untimed pass
  * (scan creation, scan-level indexes, plans: first_pass_s). */
 typedef struct {
     double wall_s;        /* the timed passes: slowest thread */

@@ -5,4 +5,4 @@ host-side mirror of the reference's cache interface (`cache.py`).  See DESIGN.md
 """
 from ._native import LiquidCacheError, LIB_PATH, EXPORTED_SYMBOLS  # noqa: F401
 from .cache import (EntryID, ParquetArrayID, CacheExpression, LiquidExpr, LiquidCacheBuilder, LiquidCache, Scan,  # noqa: F401
-                    Date32Field, ExtractDate32, boolean_buffer_and_then)
+                    Date32Field, ExtractDate32, boolean_buffer_and_then, Column, Cast, ToTimestampSeconds)

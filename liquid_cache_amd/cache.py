@@ -101,10 +101,204 @@ def _is_numeric_like(t: pa.DataType) -> bool:
             or (pa.types.is_timestamp(t) and t.tz is None))
 
 
+class Column:
+    """The left-hand side of a predicate as the reference's `is_column_like` sees it (liquid_expr.rs:150-163): the column
+    itself or the column under Cast / CastColumn / TryCast wrappers; `ToTimestampSeconds` is the one scalar function the
+    reference accepts around it (`is_to_timestamp_seconds_column`, :165-174)."""
+
+    def __init__(self):
+        self.inner = None
+
+
+class Cast(Column):
+    """CAST(inner AS to_type) (CastExpr / CastColumnExpr; `try_cast=True`: TryCastExpr)."""
+
+    def __init__(self, inner: Column, to_type: pa.DataType, try_cast: bool = False):
+        self.inner, self.to_type, self.try_cast = inner, to_type, try_cast
+
+
+class ToTimestampSeconds(Column):
+    """to_timestamp_seconds(inner): an Int64 of seconds since the epoch read as Timestamp(Second)."""
+
+    def __init__(self, inner: Column):
+        self.inner = inner
+
+
+_BIG = (1 << 64) - 1  # beyond every signed column type: `col = _BIG` is constant false, `col != _BIG` constant true
+
+
+def _int_range(t: pa.DataType):
+    if pa.types.is_date32(t):
+        return -(1 << 31), (1 << 31) - 1
+    if pa.types.is_date64(t) or pa.types.is_timestamp(t):
+        return -(1 << 63), (1 << 63) - 1
+    if pa.types.is_signed_integer(t):
+        return -(1 << (t.bit_width - 1)), (1 << (t.bit_width - 1)) - 1
+    if pa.types.is_unsigned_integer(t):
+        return 0, (1 << t.bit_width) - 1
+    return None
+
+
+def _as_int_in(v, t: pa.DataType):
+    """The literal as the integer a column of type `t` stores (days, ticks, the integer itself); None: not exact."""
+    if isinstance(v, bool):
+        return None
+    if pa.types.is_date32(t) and isinstance(v, datetime.date) and not isinstance(v, datetime.datetime):
+        return (v - datetime.date(1970, 1, 1)).days
+    if pa.types.is_date64(t) and isinstance(v, datetime.date) and not isinstance(v, datetime.datetime):
+        return (v - datetime.date(1970, 1, 1)).days * 86_400_000
+    if pa.types.is_timestamp(t) and isinstance(v, datetime.datetime):
+        return int(pa.scalar(v, type=t).value)
+    if isinstance(v, (int, np.integer)):
+        return int(v)
+    return None
+
+
+_TICKS = {"s": 1, "ms": 1000, "us": 1_000_000, "ns": 1_000_000_000}
+
+
+def _scaled(code: int, num, k: int):
+    """`x * k OP num` (k > 0, x an integer) as `x OP' lit'`; num: int, Fraction-like float handled by the caller."""
+    import math
+    from fractions import Fraction
+    q = Fraction(num) / k
+    integral = q.denominator == 1
+    if code == N.OP_EQ:
+        return (N.OP_EQ, int(q)) if integral else (N.OP_EQ, None)    # None: constant (false for =, true for !=)
+    if code == N.OP_NE:
+        return (N.OP_NE, int(q)) if integral else (N.OP_NE, None)
+    if code == N.OP_GT:
+        return N.OP_GT, math.floor(q)
+    if code == N.OP_GE:
+        return N.OP_GE, math.ceil(q)
+    if code == N.OP_LT:
+        return N.OP_LT, math.ceil(q)
+    if code == N.OP_LE:
+        return N.OP_LE, math.floor(q)
+    return None
+
+
+def _unwrap_cast(code: int, lit, t_in: pa.DataType, t_out: pa.DataType):
+    """`CAST(x AS t_out) OP lit` as `x OP' lit'` with x of type t_in — only where the two are the same predicate for EVERY x
+    (the reference evaluates the cast itself, eval_predicate_on_array).  Returns (code', lit') or None (unsupported:
+    the caller keeps the reference's CPU path).  lit' is None for a constant outcome."""
+    import math
+    if _is_byte_like(t_in) and _is_byte_like(t_out):
+        return code, lit  # Utf8 / Utf8View / Binary / BinaryView: the same bytes
+    if code > N.OP_GE:
+        return None
+    r_in = _int_range(t_in)
+    if r_in is None:
+        if pa.types.is_float32(t_in) and pa.types.is_float64(t_out) and isinstance(lit, (int, float, np.floating)):
+            # every f32 is an f64: compare against the f32 neighbours of the literal
+            x = float(lit)
+            if math.isnan(x):
+                return None
+            f = np.float32(x)
+            fx = float(f)  # (a literal beyond the f32 range rounds to +-inf: its f32 neighbours are +-max and +-inf)
+            if fx == x:
+                return code, fx
+            lo = fx if fx < x else float(np.nextafter(f, np.float32(-np.inf)))   # largest f32 below x
+            hi = fx if fx > x else float(np.nextafter(f, np.float32(np.inf)))    # smallest f32 above x
+            if code == N.OP_EQ or code == N.OP_NE:
+                return code, None
+            if code in (N.OP_GT, N.OP_GE):
+                return N.OP_GE, hi
+            return N.OP_LE, lo
+        return None
+    lo_in, hi_in = r_in
+    r_out = _int_range(t_out)
+    int_like_in = pa.types.is_integer(t_in)
+    if r_out is not None:
+        # integer-like to integer-like: same stored integer (widening), or the integer times a constant (date / time units)
+        k = None
+        if int_like_in and pa.types.is_integer(t_out):
+            k = 1
+        elif pa.types.is_date32(t_in) and pa.types.is_date64(t_out):
+            k = 86_400_000
+        elif pa.types.is_date32(t_in) and pa.types.is_timestamp(t_out) and t_out.tz is None:
+            k = 86_400 * _TICKS[t_out.unit]
+        elif pa.types.is_date32(t_in) and pa.types.is_integer(t_out):
+            k = 1
+        elif pa.types.is_timestamp(t_in) and pa.types.is_timestamp(t_out) and t_in.tz is None and t_out.tz is None \
+                and _TICKS[t_out.unit] % _TICKS[t_in.unit] == 0:
+            k = _TICKS[t_out.unit] // _TICKS[t_in.unit]
+        elif pa.types.is_integer(t_in) and t_in.bit_width == 64 and pa.types.is_timestamp(t_out) and t_out.tz is None:
+            k = 1  # Int64 reinterpreted as ticks
+        if k is None:
+            return None
+        if k == 1 and not (r_out[0] <= lo_in and hi_in <= r_out[1]):
+            return None  # narrowing: the cast itself can fail / wrap
+        if k != 1 and (lo_in * k < r_out[0] or hi_in * k > r_out[1]):
+            # the product can leave the target type: accepted for dates and timestamps going to s / ms / us (they overflow
+            # beyond +-290,000 years, where the cast itself fails, in the reference as well), never to nanoseconds (year 2262)
+            if not (pa.types.is_date32(t_in) or pa.types.is_timestamp(t_in)) or (pa.types.is_timestamp(t_out) and t_out.unit == "ns"):
+                return None
+        li = _as_int_in(lit, t_out)
+        if li is None:
+            return None
+        return _scaled(code, li, k)
+    if pa.types.is_floating(t_out) and (int_like_in or pa.types.is_date32(t_in)):
+        # every value must convert exactly: |x| < 2^24 for f32, 2^53 for f64
+        exact_bits = 24 if t_out.bit_width == 32 else 53
+        if max(abs(lo_in), abs(hi_in)) > (1 << exact_bits):
+            return None
+        if not isinstance(lit, (int, float, np.floating, np.integer)) or isinstance(lit, bool):
+            return None
+        x = float(np.float32(lit)) if t_out.bit_width == 32 else float(lit)
+        if math.isnan(x):
+            return None
+        if math.isinf(x):
+            return code, (_BIG if x > 0 else -(1 << 63))
+        from fractions import Fraction
+        return _scaled(code, Fraction(x), 1)
+    return None
+
+
+def _normalise_lhs(code: int, literal, column_type: pa.DataType, lhs: Column):
+    """Peel the wrappers of `lhs` off the predicate, outermost first.  Returns (code, literal in the column's own domain,
+    constant) or None.  constant: None, or the outcome for every valid row."""
+    chain = []
+    node = lhs
+    while node is not None and not type(node) is Column:
+        chain.append(node)
+        node = node.inner
+    if node is None:
+        return None
+    # the type every wrapper sees: innermost first
+    t = column_type
+    typed = []
+    for w in reversed(chain):
+        if isinstance(w, ToTimestampSeconds):
+            if not (pa.types.is_integer(t) and t.bit_width == 64):
+                return None
+            t_out = pa.timestamp("s")
+        else:
+            t_out = w.to_type
+        typed.append((t, t_out))
+        t = t_out
+    for t_in, t_out in reversed(typed):  # outermost first
+        r = _unwrap_cast(code, literal, t_in, t_out)
+        if r is None:
+            return None
+        code, literal = r
+        if literal is None:  # constant outcome
+            return code, None, code == N.OP_NE
+    return code, literal, None
+
+
 class LiquidExpr:
     """A predicate validated for evaluation on Liquid data: `column OP literal`, `column [NOT] LIKE pattern`
     or a boolean literal on byte-like columns.  `try_new` returns None where the reference's
-    `LiquidExpr::try_new` returns None (liquid_expr.rs:65-148)."""
+    `LiquidExpr::try_new` returns None (liquid_expr.rs:65-148).
+
+    `lhs` (round 5): the column-like forms the reference also accepts — Cast / CastColumn / TryCast wrappers and
+    `to_timestamp_seconds(col)` (liquid_expr.rs:150-174).  The reference evaluates such a predicate by running the cast on
+    the decoded array (eval_predicate_on_array); here the wrappers are peeled off on the host and the literal is moved
+    into the column's own domain with the exact rounding rule per operator (`CAST(d AS TIMESTAMP) > t` is `d > floor(t /
+    86400 s)`, `CAST(i AS DOUBLE) >= 12.5` is `i >= 13`, `= 12.5` is constant false ...), so that the device kernels
+    evaluate `col OP literal'` on the encoded data.  Forms without an exact rewrite (narrowing casts, Int64 -> Double,
+    time zones) return None: the caller keeps the reference's CPU path, exactly as for an unsupported expression."""
 
     def __init__(self, op: int, lit_tag: int, lit_bytes: bytes):
         self.op, self.lit_tag, self.lit_bytes = op, lit_tag, lit_bytes
@@ -115,7 +309,7 @@ class LiquidExpr:
 
     @staticmethod
     def try_new(op: Union[str, int, None], literal, data_type: pa.DataType,
-                expression_hint: Optional[int] = None) -> Optional["LiquidExpr"]:
+                expression_hint: Optional[int] = None, lhs: Optional[Column] = None) -> Optional["LiquidExpr"]:
         if op is None:  # Literal(Boolean) (liquid_expr.rs:78-80)
             if isinstance(literal, bool) and _is_byte_like(data_type):
                 return LiquidExpr(N.OP_EQ, N.LIT_BOOL, bytes([1 if literal else 0]))
@@ -123,6 +317,23 @@ class LiquidExpr:
         code = _OPS.get(op.lower()) if isinstance(op, str) else op
         if code is None:
             return None
+        if lhs is not None and type(lhs) is not Column:
+            if _is_byte_like(data_type) and isinstance(lhs, ToTimestampSeconds):
+                return None  # (byte-like columns take is_column_like only, liquid_expr.rs:92-94)
+            norm = _normalise_lhs(code, literal, data_type, lhs)
+            if norm is None:
+                return None
+            code, literal, constant = norm
+            if constant is not None:
+                # every valid row answers `constant`: a literal outside the column type's range says exactly that
+                lo_hi = _int_range(data_type)
+                if lo_hi is None:
+                    if not pa.types.is_floating(data_type):
+                        return None
+                    # floats: no value equals NaN under IEEE, but Arrow's total order does — use an interval that is empty
+                    return None
+                code = N.OP_NE if constant else N.OP_EQ
+                literal = -1 if lo_hi[0] == 0 else _BIG
         if _is_byte_like(data_type):
             if isinstance(literal, str):
                 literal = literal.encode("utf-8")

@@ -3567,44 +3567,84 @@ __global__ __launch_bounds__(kThreads) void k_str_decode_sel(const StrDesc* __re
 // What the reference does with a BooleanBuffer per batch (liquid_cache_reader.rs:342-391 read_from_cache ->
 // get_arrow_array_with_filter; byte_view_array/helpers.rs:44-64 filter_inner) for the rows a filter left.
 // ------------------------------------------------------------------------------------------------
+// One returning atomic per WORKGROUP and 16 entries: returning atomics on ONE address complete a few nanoseconds apart
+// whatever the number of waves waiting (measured: one per wave and entry made this kernel 48 us for 12,207 entries, 8,000 of
+// them with a hit), so the four waves of a workgroup count four entries each, add up in LDS and share one base.
+constexpr uint32_t kHitsEntriesPerWave = 4;
 template <typename Desc>
 __global__ __launch_bounds__(kThreads) void k_mask_to_hits(const Desc* __restrict__ descs, uint32_t n_entries,
                                                            const uint64_t* __restrict__ mask, uint64_t* __restrict__ hits,
                                                            uint64_t cap, unsigned long long* __restrict__ n_hits,
                                                            uint32_t* __restrict__ hit_first) {
+    __shared__ unsigned long long s_wave_tot[kWavesPerBlock];
+    __shared__ unsigned long long s_base;
     const int lane = lane_id();
-    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
-    for (uint32_t entry = blockIdx.x * kWavesPerBlock + uint32_t(wave_id()); entry < n_entries; entry += total_waves) {
-        const uint32_t len = desc_rows(descs[entry]);
-        const uint64_t base = descs[entry].mask_word_off;
-        const uint32_t nwords = (len + 63u) >> 6;
-        auto word = [&](uint32_t w) -> uint64_t {
-            if (w >= nwords) return 0;
-            uint64_t m = mask[base + w];
-            if (w == nwords - 1 && (len & 63u)) m &= (uint64_t(1) << (len & 63u)) - 1;
-            return m;
-        };
-        uint32_t c = 0;
-        for (uint32_t w = uint32_t(lane); w < nwords; w += kWave) c += uint32_t(__popcll(word(w)));
-        const uint32_t tot = read_lane(wave_inclusive_sum(c), kWave - 1);
-        if (tot == 0) continue;
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(n_hits, (unsigned long long)tot);
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    constexpr uint32_t kPerWg = kHitsEntriesPerWave * kWavesPerBlock;
+    // (every wave of a workgroup runs the same number of iterations: the barriers below are workgroup wide)
+    for (uint32_t e0 = blockIdx.x * kPerWg; e0 < n_entries; e0 += gridDim.x * kPerWg) {
+        uint32_t len[kHitsEntriesPerWave], tot[kHitsEntriesPerWave];
+        uint64_t base[kHitsEntriesPerWave];
+        uint64_t m0[kHitsEntriesPerWave], m1[kHitsEntriesPerWave];  // entries of up to 8,192 rows: words lane and 64 + lane
+        uint32_t wave_tot = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < kHitsEntriesPerWave; q++) {
+            const uint32_t entry = e0 + wave * kHitsEntriesPerWave + q;
+            len[q] = entry < n_entries ? desc_rows(descs[entry]) : 0u;
+            base[q] = entry < n_entries ? descs[entry].mask_word_off : 0u;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < kHitsEntriesPerWave; q++) {
+            const uint32_t nwords = (len[q] + 63u) >> 6;
+            auto word = [&](uint32_t w) -> uint64_t {
+                if (w >= nwords) return 0;
+                uint64_t m = mask[base[q] + w];
+                if (w == nwords - 1 && (len[q] & 63u)) m &= (uint64_t(1) << (len[q] & 63u)) - 1;
+                return m;
+            };
+            m0[q] = word(uint32_t(lane));
+            m1[q] = word(64u + uint32_t(lane));
+            uint32_t c = uint32_t(__popcll(m0[q])) + uint32_t(__popcll(m1[q]));
+            for (uint32_t w = 128u + uint32_t(lane); w < nwords; w += kWave) c += uint32_t(__popcll(word(w)));
+            tot[q] = read_lane(wave_inclusive_sum(c), kWave - 1);
+            wave_tot += tot[q];
+        }
+        if (lane == 0) s_wave_tot[wave] = wave_tot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (uint32_t w = 0; w < uint32_t(kWavesPerBlock); w++) t += s_wave_tot[w];
+            s_base = t ? atomicAdd(n_hits, t) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long b = s_base;
+        for (uint32_t w = 0; w < wave; w++) b += s_wave_tot[w];
         b = uniform_u64(b);
-        if (hit_first && lane == 0) hit_first[entry] = uint32_t(b);
-        for (uint32_t w0 = 0; w0 < nwords; w0 += kWave) {
-            const uint32_t w = w0 + uint32_t(lane);
-            uint64_t m = word(w);
-            const uint32_t cnt = uint32_t(__popcll(m));
-            const uint32_t incl = wave_inclusive_sum(cnt);
-            uint64_t pos = b + incl - cnt;
-            while (m) {
-                const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
-                m &= m - 1;
-                if (pos < cap) hits[pos] = (uint64_t(entry) << 32) | (w * 64u + bit);
-                pos++;
+        __syncthreads();  // (s_wave_tot / s_base are rewritten by the next iteration)
+#pragma unroll
+        for (uint32_t q = 0; q < kHitsEntriesPerWave; q++) {
+            if (tot[q] == 0) continue;
+            const uint32_t entry = e0 + wave * kHitsEntriesPerWave + q;
+            const uint32_t nwords = (len[q] + 63u) >> 6;
+            if (hit_first && lane == 0) hit_first[entry] = uint32_t(b);
+            for (uint32_t w0 = 0; w0 < nwords; w0 += kWave) {
+                const uint32_t w = w0 + uint32_t(lane);
+                uint64_t m = w0 == 0 ? m0[q] : (w0 == uint32_t(kWave) ? m1[q] : 0);
+                if (w0 >= 2u * kWave && w < nwords) {
+                    m = mask[base[q] + w];
+                    if (w == nwords - 1 && (len[q] & 63u)) m &= (uint64_t(1) << (len[q] & 63u)) - 1;
+                }
+                const uint32_t cnt = uint32_t(__popcll(m));
+                const uint32_t incl = wave_inclusive_sum(cnt);
+                uint64_t pos = b + incl - cnt;
+                while (m) {
+                    const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+                    m &= m - 1;
+                    if (pos < cap) hits[pos] = (uint64_t(entry) << 32) | (w * 64u + bit);
+                    pos++;
+                }
+                b += read_lane(incl, kWave - 1);
             }
-            b += read_lane(incl, kWave - 1);
         }
     }
 }
@@ -3730,15 +3770,16 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
                                                                unsigned long long* __restrict__ n_bytes) {
     __shared__ LdsSymtab s_tab[kWavesPerBlock];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[kWavesPerBlock][kGatherStage + 16];
+    __shared__ unsigned long long s_tot[2][kWavesPerBlock], s_base[2];
     const uint64_t k = min(uint64_t(*n_hits), cap_rows);
     const uint64_t n_waves = uint64_t(gridDim.x) * kWavesPerBlock;
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
-    const uint64_t gw = uint64_t(blockIdx.x) * kWavesPerBlock + wave;
     // Rows of a batch.  Few rows for this grid (what a selective filter leaves): R = the power of two that gives every wave
-    // one batch; the batch's R rows take the dependent loads hits -> descriptor -> key -> offsets / length -> compressed
-    // bytes side by side (a lane per row, then a load per row with all lanes), and each value is decoded by the whole wave out
-    // of the LDS copy of its symbol table.  Many rows: 64 per batch, a lane per row, decoded into LDS and stored coalesced.
+    // one batch; the batch's R rows take the dependent loads hits -> descriptor -> key | validity -> offsets | length ->
+    // compressed bytes side by side (a lane per row, then a load per row with all lanes), and each value is decoded by the
+    // whole wave out of the LDS copy of its symbol table.  Many rows: 64 per batch, a lane per row, decoded into LDS and
+    // stored coalesced.
     uint32_t R = 64;
     if (k < n_waves * 32u) {
         const uint64_t per = (k + n_waves - 1) / n_waves;
@@ -3748,7 +3789,12 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
     const bool coop = R < 64u;
     uint32_t cached_slot = 0xFFFFFFFFu;  // wave uniform: the table in s_tab[wave]
     LdsSymtab& tab = s_tab[wave];
-    for (uint64_t rb = gw * R; rb < k; rb += n_waves * R) {
+    // (every wave of a workgroup runs the same number of iterations: the space in the data buffer is claimed by ONE returning
+    // atomic per workgroup and iteration — returning atomics on one address complete a few nanoseconds apart, 2,000 waves
+    // asking for themselves were most of this kernel's time — behind two workgroup barriers)
+    uint32_t it = 0;
+    for (uint64_t rb0 = uint64_t(blockIdx.x) * kWavesPerBlock * R; rb0 < k; rb0 += n_waves * R, it ^= 1u) {
+        const uint64_t rb = rb0 + uint64_t(wave) * R;
         const uint64_t i = rb + uint64_t(lane);
         const bool live = uint32_t(lane) < R && i < k;
         const uint64_t ref = live ? hits[i] : 0;
@@ -3756,10 +3802,10 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
         const StrDesc* dp = descs + uint32_t(ref >> 32);
         const uint32_t slot = live ? dp->symtab_slot : 0u;
         const uint64_t lm = __ballot(live);
-        const uint32_t slot0 = read_lane(slot, int(__ffsll((long long)lm)) - 1);
+        const uint32_t slot0 = lm ? read_lane(slot, int(__ffsll((long long)lm)) - 1) : 0u;
         const bool in_lds = __ballot(live && slot != slot0) == 0;  // wave uniform
         bool tab_pending = false;
-        if (in_lds && slot0 != cached_slot) {
+        if (lm != 0 && in_lds && slot0 != cached_slot) {
             // 2304 bytes by LDS DMA (3 x 64 lanes x 16 bytes, the last issue 16 lanes): in flight beside the loads below
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             const uint8_t* src = reinterpret_cast<const uint8_t*>(symtabs + slot0);
@@ -3774,18 +3820,46 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
         uint32_t len = 0, start = 0, stop = 0;
         if (live) {
             const StrDesc& d = *dp;
-            valid = row < d.n && (d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true);
+            // key and validity word side by side (the key of a null row is garbage: it is not used)
+            const bool in_rows = row < d.n;
+            const uint32_t kraw = in_rows ? uint32_t(d.keys[row]) : 0u;
+            const uint64_t vw = (in_rows && d.validity) ? d.validity[row >> 6] : ~uint64_t(0);
+            valid = in_rows && ((vw >> (row & 63u)) & 1) != 0;
             if (valid) {
-                const uint32_t key = uint32_t(d.keys[row]);
-                str_offset_pair(d, key, start, stop);
-                len = str_decoded_len(d, symtabs[slot], key);
+                str_offset_pair(d, kraw, start, stop);
+                len = str_decoded_len(d, symtabs[slot], kraw);
             }
         }
-        // space in the data buffer, one atomic per batch; the batch's values are neighbours there
+        // the first 64 compressed bytes of the batch's first four values, requested before the space is claimed
+        const uint64_t todo0 = __ballot(live && len != 0);
+        int j4[4] = {-1, -1, -1, -1};
+        uint32_t pre4[4] = {0, 0, 0, 0};
+        if (coop) {
+            uint64_t m = todo0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (m) {
+                    j4[q] = __builtin_amdgcn_readfirstlane(int(__ffsll((long long)m)) - 1);
+                    m &= m - 1;
+                    const uint64_t f = uniform_u64(uint64_t(__shfl((unsigned long long)reinterpret_cast<uintptr_t>(dp->fsst), j4[q], kWave)));
+                    const uint32_t x = read_lane(start, j4[q]) + uint32_t(lane);
+                    pre4[q] = x < read_lane(stop, j4[q]) ? uint32_t(as_global(reinterpret_cast<const uint8_t*>(uintptr_t(f)))[x]) : 0u;
+                }
+            }
+        }
+        // space in the data buffer: the batch's values are neighbours there
         const uint32_t incl = wave_inclusive_sum(len);
         const uint32_t tot = read_lane(incl, kWave - 1);
-        unsigned long long b = 0;
-        if (tot && lane == 0) b = atomicAdd(n_bytes, (unsigned long long)tot);
+        if (lane == 0) s_tot[it][wave] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (uint32_t w = 0; w < uint32_t(kWavesPerBlock); w++) t += s_tot[it][w];
+            s_base[it] = t ? atomicAdd(n_bytes, t) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long b = s_base[it];
+        for (uint32_t w = 0; w < wave; w++) b += s_tot[it][w];
         b = uniform_u64(b);
         const uint64_t off = b + incl - len;
         const bool fits = off + len <= cap_bytes;
@@ -3796,13 +3870,14 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
             else if (!fits) *reinterpret_cast<uint4*>(v) = make_uint4(len, 0u, 0u, uint32_t(off));  // (the caller retries)
         }
         const uint64_t todo = __ballot(live && len != 0 && fits);
-        if (todo == 0) {
-            if (tab_pending) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            continue;
+        if (tab_pending) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        if (todo == 0) continue;
         if (coop) {
-            // values four at a time: their first 64 compressed bytes requested together, then decoded one after the other
-            for (uint64_t m = todo; m;) {
+            bool first_group = true;
+            for (uint64_t m = todo0; m; first_group = false) {
                 int j[4];
                 uint32_t pre[4], st_[4], sp_[4];
                 uint64_t fp[4];
@@ -3817,18 +3892,18 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
                         st_[q] = read_lane(start, j[q]);
                         sp_[q] = read_lane(stop, j[q]);
                         fp[q] = uniform_u64(uint64_t(__shfl((unsigned long long)reinterpret_cast<uintptr_t>(dp->fsst), j[q], kWave)));
-                        const uint32_t x = st_[q] + uint32_t(lane);
-                        pre[q] = x < sp_[q] ? uint32_t(as_global(reinterpret_cast<const uint8_t*>(uintptr_t(fp[q])))[x]) : 0u;
+                        if (first_group) {
+                            pre[q] = pre4[q];
+                        } else {
+                            const uint32_t x = st_[q] + uint32_t(lane);
+                            pre[q] = x < sp_[q] ? uint32_t(as_global(reinterpret_cast<const uint8_t*>(uintptr_t(fp[q])))[x]) : 0u;
+                        }
                     }
-                }
-                if (tab_pending) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    tab_pending = false;
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     if (q >= nq) break;
+                    if (((todo >> j[q]) & 1u) == 0) continue;  // (does not fit: its view says so)
                     const uint32_t lj = read_lane(len, j[q]);
                     const uint64_t oj = uniform_u64(uint64_t(__shfl((unsigned long long)off, j[q], kWave)));
                     uint32_t head[3];
@@ -3844,14 +3919,10 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
             }
             continue;
         }
-        if (tab_pending) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
         // ---- 64 rows, a lane per row.  The batch's bytes are one range [b, b + tot) of the data buffer: decoded into LDS (byte
         // stores), they leave as whole 16-byte pieces — 8-byte stores straight from the lanes hit 64 different lines per
         // instruction, each a partial line for the memory system to merge (see k_str_decode_sel).
-        const bool staged = in_lds && tot <= kGatherStage && b + tot <= cap_bytes && todo == __ballot(live && len != 0);
+        const bool staged = in_lds && tot <= kGatherStage && b + tot <= cap_bytes && todo == todo0;
         const uint64_t g0 = uint64_t(reinterpret_cast<uintptr_t>(data)) + b;
         const uint32_t mis = uint32_t(g0) & 15u;  // the LDS copy has the alignment of its place in memory
         uint32_t h0 = 0, h1 = 0, h2 = 0;
@@ -5220,8 +5291,9 @@ hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, cons
 hipError_t launch_mask_to_hits(const void* d_descs, bool is_str, uint32_t n_entries, const uint64_t* d_mask, uint64_t* d_hits,
                                uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
-    const uint64_t wgs_needed = (uint64_t(n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
-    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 16)));
+    const uint64_t per_wg = uint64_t(kHitsEntriesPerWave) * kWavesPerBlock;
+    const uint64_t wgs_needed = (uint64_t(n_entries) + per_wg - 1) / per_wg;
+    const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8)));
     if (is_str)
         hipLaunchKernelGGL(k_mask_to_hits<StrDesc>, grid, dim3(kThreads), 0, stream, static_cast<const StrDesc*>(d_descs), n_entries,
                            d_mask, d_hits, cap, d_n_hits, d_hit_first);

@@ -679,6 +679,63 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
     };
     uint32_t any_match = 0;  // NOT LIKE: bit j: entry j has a matching dictionary value (wave uniform)
     uint64_t wave_hits = 0;
+    // The end of every wave that has records: the sparse result (its hit rows as (entry << 32 | row) in (entry, row) order, read
+    // back from the final mask words in LDS) and the fused COUNT(*).  The list position comes from ONE returning atomic per
+    // WORKGROUP: returning atomics on one address complete a few nanoseconds apart however many waves wait for them (2,800
+    // groups with a hit: ~15 us when every wave asked for itself), so the waves add up in LDS and share a base.  Called exactly
+    // once by every wave of a workgroup that has records, after its sync_image() (the barriers are workgroup wide).
+    auto finish = [&](uint64_t wh) {
+        if (a.hits) {
+            unsigned long long b = 0;
+            if (kFlatWaves > 1) {
+                auto slot_of = [&](uint32_t w) {
+                    return reinterpret_cast<unsigned long long*>(smem + tbl_bytes + w * kPerWave + kFlatMaxE * kMaskBytes +
+                                                                 kFlatMaxE * 64u + kFlatCap * 4u + 64u);  // (its headmask)
+                };
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane == 0) *slot_of(wave) = wh;
+                __syncthreads();
+                unsigned long long all = 0, before = 0;
+                for (uint32_t w = 0; w < kFlatWaves; w++) {
+                    const unsigned long long v = *slot_of(w);
+                    all += v;
+                    if (w < wave) before += v;
+                }
+                unsigned long long* bslot = reinterpret_cast<unsigned long long*>(smem + tbl_bytes + kFlatMaxE * kMaskBytes +
+                                                                                  kFlatMaxE * 64u + kFlatCap * 4u);  // wave 0's hit flags
+                __syncthreads();
+                if (wave == 0 && lane == 0) *bslot = all ? atomicAdd(a.n_hits, all) : 0ull;
+                __syncthreads();
+                b = uniform_u64(*bslot + before);
+            } else if (wh) {
+                if (lane == 0) b = atomicAdd(a.n_hits, (unsigned long long)wh);
+                b = uniform_u64(b);
+            }
+            if (wh != 0) {
+                for (uint32_t j = 0; j < n_entries; j++) {
+                    const uint32_t nr = j == 0 ? nr0 : j == 1 ? nr1 : j == 2 ? nr2 : nr3;
+                    const uint32_t nwords = (nr + 63u) >> 6;
+                    const unsigned long long eb = b;
+                    for (uint32_t w0 = 0; w0 < nwords; w0 += kWave) {
+                        const uint32_t w = w0 + uint32_t(lane);
+                        uint64_t m = w < nwords ? pmask[j * (kMaskBytes / 8u) + w] : 0;
+                        const uint32_t cnt = uint32_t(__popcll(m));
+                        const uint32_t incl = wave_inclusive_sum(cnt);
+                        unsigned long long pos = b + incl - cnt;
+                        while (m) {
+                            const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
+                            m &= m - 1;
+                            if (pos < a.hits_cap) as_global_mut(a.hits)[pos] = (uint64_t(first_entry + j) << 32) | (w * 64u + bit);
+                            pos++;
+                        }
+                        b += read_lane(incl, kWave - 1);
+                    }
+                    if (a.hit_first && b != eb && lane == 0) as_global_mut(a.hit_first)[first_entry + j] = uint32_t(eb);
+                }
+            }
+        }
+        if (a.total.d_total_out && lane == 0) total_contribute(a.total, unit, n_units, wh);
+    };
 
     if ((!kNot && tot == 0) || LC_FLAT_STOP == 1) {
         // no dictionary value of the group can contain the needle: zeros, straight from registers
@@ -692,7 +749,7 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
             moff += nwords;
         }
         if (kFlatWaves > 1) sync_image();
-        if (a.total.d_total_out && lane == 0) total_contribute(a.total, unit, n_units, 0);
+        finish(0);
         return;
     }
     if (kFlatWaves == 1 && tot != 0) load_image();
@@ -942,34 +999,7 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
         }
         moff += nwords;
     }
-    if (a.hits && wave_hits != 0) {
-        // sparse result: the group's hit rows as (entry << 32 | row), in (entry, row) order, behind ONE atomic of the wave
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        unsigned long long b = 0;
-        if (lane == 0) b = atomicAdd(a.n_hits, (unsigned long long)wave_hits);
-        b = uniform_u64(b);
-        for (uint32_t j = 0; j < n_entries; j++) {
-            const uint32_t nr = j == 0 ? nr0 : j == 1 ? nr1 : j == 2 ? nr2 : nr3;
-            const uint32_t nwords = (nr + 63u) >> 6;
-            const unsigned long long eb = b;
-            for (uint32_t w0 = 0; w0 < nwords; w0 += kWave) {
-                const uint32_t w = w0 + uint32_t(lane);
-                uint64_t m = w < nwords ? pmask[j * (kMaskBytes / 8u) + w] : 0;
-                const uint32_t cnt = uint32_t(__popcll(m));
-                const uint32_t incl = wave_inclusive_sum(cnt);
-                unsigned long long pos = b + incl - cnt;
-                while (m) {
-                    const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
-                    m &= m - 1;
-                    if (pos < a.hits_cap) as_global_mut(a.hits)[pos] = (uint64_t(first_entry + j) << 32) | (w * 64u + bit);
-                    pos++;
-                }
-                b += read_lane(incl, kWave - 1);
-            }
-            if (a.hit_first && b != eb && lane == 0) as_global_mut(a.hit_first)[first_entry + j] = uint32_t(eb);
-        }
-    }
-    if (a.total.d_total_out && lane == 0) total_contribute(a.total, unit, n_units, wave_hits);
+    finish(wave_hits);
 }
 
 hipError_t launch_flat(int n_sig, bool negated, const FlatArgs& a, hipStream_t stream) {

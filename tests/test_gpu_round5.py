@@ -273,3 +273,57 @@ def test_gather_fixed_from_hit_list(gpu_cache, oracle):
     assert got.tobytes() == cols["u8"][0].tobytes()
     for s in scans.values():
         s.close()
+
+
+def test_cast_wrapped_predicates_on_reference_samples(gpu_cache):
+    """`CAST(col) OP literal` / `to_timestamp_seconds(col) OP literal` (liquid_expr.rs:150-174): the rewritten predicate on the
+    device == pyarrow's cast + compare over the reference's own sample columns (ClickBench's EventTime is an Int64 of seconds,
+    EventDate a UInt16 of days — the queries wrap both)."""
+    import datetime
+    import pyarrow.compute as pc
+    import pyarrow.parquet as pq
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    hits = pq.read_table(os.path.join(gold, "nano_hits_cols.parquet"))
+    line = pq.read_table(os.path.join(gold, "lineitem_sf0001.parquet"))
+    fns = {"=": pc.equal, "!=": pc.not_equal, "<": pc.less, "<=": pc.less_equal, ">": pc.greater, ">=": pc.greater_equal}
+    col = lc.Column()
+    et = hits["EventTime"].combine_chunks()
+    t_mid = datetime.datetime.utcfromtimestamp(int(np.median(et.to_numpy())))
+    cases = [
+        (hits["EventTime"], lc.ToTimestampSeconds(col), lambda a: pc.cast(a, pa.timestamp("s")), pa.timestamp("s"),
+         [t_mid, t_mid + datetime.timedelta(seconds=1), datetime.datetime(2013, 7, 15), datetime.datetime(1970, 1, 1)]),
+        (hits["EventDate"], lc.Cast(col, pa.int32()), lambda a: pc.cast(a, pa.int32()), pa.int32(), [-5, 0, 15901, 15902, 70000]),
+        (hits["ResolutionWidth"], lc.Cast(col, pa.float64()), lambda a: pc.cast(a, pa.float64()), pa.float64(),
+         [1024.0, 1023.5, 1366.25, -1.0, 1e9]),
+        (hits["RegionID"], lc.Cast(col, pa.int64()), lambda a: pc.cast(a, pa.int64()), pa.int64(), [229, 2**35, -2**35]),
+        (line["l_shipdate"], lc.Cast(col, pa.timestamp("us")), lambda a: pc.cast(a, pa.timestamp("us")), pa.timestamp("us"),
+         [datetime.datetime(1994, 1, 1), datetime.datetime(1994, 1, 1, 0, 0, 0, 1), datetime.datetime(1995, 6, 17, 12)]),
+        (hits["URL"], lc.Cast(col, pa.string_view()), lambda a: a, pa.string(), ["", "http://"]),
+    ]
+    eid = 9000
+    checked = 0
+    for chunked, lhs, cast, t_lit, lits in cases:
+        arr = chunked.combine_chunks()
+        ids = []
+        for b in range(0, len(arr), 8192):
+            eid += 1
+            gpu_cache.insert(eid, arr.slice(b, 8192))
+            ids.append(eid)
+        scan = gpu_cache.scan(ids)
+        casted = cast(arr)
+        for op, fn in fns.items():
+            for lit in lits:
+                expr = lc.LiquidExpr.try_new(op, lit, arr.type, None, lhs)
+                assert expr is not None, (str(arr.type), op, lit)
+                want = fn(casted, pa.scalar(lit, type=t_lit)).fill_null(False).to_numpy(zero_copy_only=False)
+                mask, counts = scan.eval_to_host(expr)
+                got = np.zeros(len(arr), bool)
+                bits = np.unpackbits(mask.view(np.uint8), bitorder="little").astype(bool)
+                for k, b in enumerate(range(0, len(arr), 8192)):
+                    n = min(8192, len(arr) - b)
+                    got[b:b + n] = bits[int(scan.segment_offsets[k]) * 64: int(scan.segment_offsets[k]) * 64 + n]
+                assert np.array_equal(got, want), (str(arr.type), op, lit, int(got.sum()), int(want.sum()))
+                assert int(counts.sum()) == int(want.sum())
+                checked += 1
+        scan.close()
+    assert checked >= 100
