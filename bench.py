@@ -1886,9 +1886,9 @@ def main():
             add_read_probe(out["roofline"], cache, N)  # (skipped in the profiling runs: their traces hold the scan kernels only)
         out["config"]["evaluation_path"] = path
         out["config"]["first_evaluation_us"] = out["first_evaluation_us"]
-        import re
-        m_ix = re.search(r"scan-level index ([0-9.]+) GB", path)
-        out["config"]["index_bytes"] = int(float(m_ix.group(1)) * 1e9) if m_ix else 0
+        inf = scan.info()
+        out["config"]["index_bytes"] = int(inf.index_bytes) + int(inf.unigram_index_bytes)
+        out["config"]["index_build_ms"] = round(float(inf.index_build_ms), 3)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_sample = args.cpu_batches or n_batches  # ~4 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
         if args.workload == "url_like":

@@ -432,6 +432,26 @@ LC_API void lc_scan_destroy(lc_scan* scan);
 LC_API uint64_t lc_scan_mask_words(const lc_scan* scan);  /* total u64 words of the mask */
 LC_API uint64_t lc_scan_rows(const lc_scan* scan);
 LC_API uint64_t lc_scan_entries(const lc_scan* scan);
+/* What a scan holds.  index_bytes / unigram_index_bytes: the scan-level LIKE indexes built on this scan's first LIKE (first
+ * 1-byte LIKE) — derived data outside the entries' blobs, 64 + 32 bytes per dictionary value; they count against the
+ * context's max_hbm_bytes when they are built (a scan whose index does not fit the budget evaluates with the entry-level
+ * index instead), stay with the scan, and after lc_scan_destroy are kept (bounded, oldest first) for the next scan over the
+ * same publications of the same entries.  ctx_index_bytes: all such indexes alive in the context, cached ones included. */
+typedef struct {
+    uint64_t entries, rows, mask_words;
+    uint64_t entry_bytes;          /* HBM of the scan's entries (sum of lc_entry_info.device_bytes) */
+    uint64_t index_bytes;          /* scan-level bigram signature index, 0 if not built (yet) */
+    uint64_t unigram_index_bytes;  /* scan-level unigram index, 0 if not built */
+    uint64_t ctx_index_bytes;
+    uint64_t ctx_slab_bytes;       /* slab capacity the context has reserved for entries (what max_hbm_bytes bounds, with the indexes) */
+    double index_build_ms;         /* device time of the builds */
+    uint32_t like_plans;           /* needles planned on this scan */
+    int32_t is_byte_view;
+    int32_t max_bit_width;
+    int32_t reserved;
+} lc_scan_info;
+LC_API lc_status lc_scan_info_get(lc_scan* scan, lc_scan_info* out);
+
 /* Byte accounting of ONE evaluation of `pred` over the scan, for roofline reports:
  *   *out_algorithmic  the reference algorithm's bytes: packed values / keys + selection + validity + output, and for
  *                     byte views the prefilter (4D fingerprints or 8D prefix keys), the offsets and the compressed

@@ -48,6 +48,13 @@ class EntryInfo(C.Structure):
                 ("quantized_from_bit_width", C.c_int32), ("reserved0", C.c_int32), ("quantized_bucket_width", C.c_uint64)]
 
 
+class ScanInfo(C.Structure):
+    _fields_ = [("entries", C.c_uint64), ("rows", C.c_uint64), ("mask_words", C.c_uint64), ("entry_bytes", C.c_uint64),
+                ("index_bytes", C.c_uint64), ("unigram_index_bytes", C.c_uint64), ("ctx_index_bytes", C.c_uint64),
+                ("ctx_slab_bytes", C.c_uint64), ("index_build_ms", C.c_double), ("like_plans", C.c_uint32), ("is_byte_view", C.c_int32),
+                ("max_bit_width", C.c_int32), ("reserved", C.c_int32)]
+
+
 class ArrowSchema(C.Structure):
     pass
 
@@ -75,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "lc_scan_segment_offsets", "lc_scan_eval", "lc_scan_gather_fixed", "lc_device_alloc", "lc_device_free",
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize",
     "lc_stream_create", "lc_stream_destroy",
-    "lc_scan_eval_hits", "lc_scan_mask_to_hits", "lc_scan_gather_fixed_hits", "lc_scan_gather_bytes_hits",
+    "lc_scan_eval_hits", "lc_scan_mask_to_hits", "lc_scan_gather_fixed_hits", "lc_scan_gather_bytes_hits", "lc_scan_info_get",
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
@@ -201,6 +208,7 @@ def load():
     L.lc_scan_eval_count.restype = i32
     L.lc_scan_eval_count.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, vp, vp, vp]
     L.lc_scan_gather_fixed.restype = i32; L.lc_scan_gather_fixed.argtypes = [vp, vp, vp, vp, u64, vp, vp]
+    L.lc_scan_info_get.restype = i32; L.lc_scan_info_get.argtypes = [vp, P(ScanInfo)]
     L.lc_scan_eval_hits.restype = i32
     L.lc_scan_eval_hits.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, u64, vp, vp, vp, vp, vp]
     L.lc_scan_mask_to_hits.restype = i32; L.lc_scan_mask_to_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]

@@ -860,6 +860,12 @@ class Scan:
         except Exception:
             pass
 
+    def info(self) -> N.ScanInfo:
+        """lc_scan_info_get: entries, rows, HBM of the entries and of the scan-level LIKE indexes."""
+        out = N.ScanInfo()
+        N.check(self._lib.lc_scan_info_get(self._h, C.byref(out)), self._cache.handle)
+        return out
+
     def algorithmic_bytes(self, expr: LiquidExpr, with_selection: bool = False) -> int:
         pred = expr.as_predicate()
         return self._lib.lc_scan_algorithmic_bytes(self._h, C.byref(pred), int(with_selection))

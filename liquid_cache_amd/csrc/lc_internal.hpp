@@ -107,6 +107,8 @@ struct lc_ctx {
     uint64_t max_hbm = 0;
     uint64_t staged_bytes = 0;  // slab capacity reserved on the device (what max_hbm bounds)
     uint64_t entry_bytes = 0;   // sum of the staged entries' blobs (what lc_device_info reports)
+    std::atomic<uint64_t> index_bytes{0};  // scan-level LIKE indexes alive (live scans + the ones kept for the next scan): derived
+                                           // data outside the slabs, charged to max_hbm when one is built
     // symbol tables
     std::mutex st_mu;
     std::unordered_map<uint64_t, uint32_t> symtab_slot;
@@ -249,5 +251,7 @@ void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp);
 void like_orphans_clear(lc_ctx* ctx);
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp);           // caller holds s->mu
 uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts, uint32_t sparse_flags = 0);  // caller holds s->mu
+// what the scan's pipeline holds (lc_scan_info_get); caller holds s->mu
+void like_pipeline_info(const lc_scan* s, uint64_t* bigram_bytes, uint64_t* unigram_bytes, double* build_ms, uint32_t* n_plans);
 
 }  // namespace lc

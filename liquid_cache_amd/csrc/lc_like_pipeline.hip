@@ -1042,7 +1042,10 @@ __global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
     constexpr int kBits = kUni ? 256 : kFlatBits;
     __shared__ uint64_t s_sym[256];
     __shared__ uint8_t s_len[256];
-    __shared__ uint64_t stage[kBits][8];  // [slice][column]: bit l of a word = the value lane l of the column's wave decodes
+    // [column][slice]: bit l of a word = the value lane l of the column's wave decodes.  Slice fastest: the 64 lanes of a wave
+    // OR into one column, so their words sit 8 bytes apart — 32 banks — instead of 64 bytes apart (4 bank positions, 16-way
+    // conflicts on every LDS atomic: the layout of round 4)
+    __shared__ uint64_t stage[8][kBits];
     const StrDesc d = a.descs[blockIdx.y];
     const uint32_t nw = (d.d + 63u) >> 6;
     if (d.d == 0 || blockIdx.x * 8u >= nw) return;
@@ -1085,9 +1088,9 @@ __global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
                             const uint64_t active = __ballot(true);
                             const uint32_t b0 = uint32_t(__builtin_amdgcn_readfirstlane(int(bit)));
                             if (__ballot(bit != b0) == 0) {
-                                if (uint32_t(lane) == uint32_t(__ffsll((long long)active)) - 1u) stage[b0][cc] |= active;
+                                if (uint32_t(lane) == uint32_t(__ffsll((long long)active)) - 1u) stage[cc][b0] |= active;
                             } else {
-                                atomicOr(reinterpret_cast<unsigned long long*>(&stage[bit][cc]), 1ull << lane);
+                                atomicOr(reinterpret_cast<unsigned long long*>(&stage[cc][bit]), 1ull << lane);
                             }
                         }
                         prev = cur;
@@ -1100,7 +1103,7 @@ __global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
     const uint32_t cols = min(8u, nw - blockIdx.x * 8u);
     const size_t dst = size_t(a.dst_word[blockIdx.y]) + size_t(blockIdx.x) * 8u;
     for (uint32_t s = threadIdx.x; s < uint32_t(kBits); s += 256u)
-        for (uint32_t cc = 0; cc < cols; cc++) a.slices[size_t(s) * a.slice_words + dst + cc] = stage[s][cc];
+        for (uint32_t cc = 0; cc < cols; cc++) a.slices[size_t(s) * a.slice_words + dst + cc] = stage[cc][s];
 }
 
 // The scan-level index of k_like_flat: groups of consecutive entries (one symbol table, <= kFlatMaxE entries, <= 128
@@ -1182,6 +1185,11 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
         like_orphans_clear(ctx);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
     }
+    // the index is HBM the caller's budget must cover: max_hbm_bytes bounds slabs + indexes (the cached ones go first)
+    if (ctx->max_hbm && ctx->staged_bytes + ctx->index_bytes.load() + bytes > ctx->max_hbm) {
+        like_orphans_clear(ctx);
+        if (ctx->staged_bytes + ctx->index_bytes.load() + bytes > ctx->max_hbm) return LC_OK;  // k_like_lean serves
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
     (void)hipEventCreate(&ev1);
@@ -1216,6 +1224,7 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     lp->n_group_slots = uint32_t(groups.size());
     lp->group_words = gw;
     lp->slices_bytes = bytes;
+    ctx->index_bytes += bytes;
     lp->flat = true;
     lp->eq_ok = eq_ok;
     lp->d_symtabs = s->d_symtabs;
@@ -1227,12 +1236,12 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
 // exactly when its bit in slice b is set, so a 1-byte LIKE needs no walk: k_like_scanall<kUni> copies the entry's words of
 // ONE slice and maps the rows through the keys.
 lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
-    (void)ctx;
     lp->uni_tried = true;
     if (!lp->flat || !lp->d_dst_word || lp->slice_words == 0) return LC_OK;
     const uint64_t bytes = lp->slice_words * 8u * 256u;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
+    if (ctx->max_hbm && ctx->staged_bytes + ctx->index_bytes.load() + bytes > ctx->max_hbm) return LC_OK;  // (the walkers serve)
     uint64_t* d_uni = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&d_uni), bytes) != hipSuccess) {
         (void)hipGetLastError();
@@ -1246,6 +1255,7 @@ lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t s
         ~Tmp() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
     } tmp{ev0, ev1};
     lp->d_uni = d_uni;  // (freed with the pipeline whatever happens below)
+    ctx->index_bytes += bytes;
     if (ev0) LC_HIP(hipEventRecord(ev0, stream));
     LC_HIP(hipMemsetAsync(d_uni, 0, bytes, stream));
     FlatBuildArgs ba{static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, lp->d_dst_word, d_uni, lp->slice_words};
@@ -1505,9 +1515,17 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     pool_release(ctx, lp->d_total_acc);
     pool_release(ctx, lp->d_groups);
     pool_release(ctx, lp->d_dst_word);
-    if (lp->d_slices) (void)hipFree(lp->d_slices);
-    if (lp->d_uni) (void)hipFree(lp->d_uni);
+    if (lp->d_slices) { (void)hipFree(lp->d_slices); ctx->index_bytes -= lp->slices_bytes; }
+    if (lp->d_uni) { (void)hipFree(lp->d_uni); ctx->index_bytes -= lp->slice_words * 8u * 256u; }
     delete lp;
+}
+
+void like_pipeline_info(const lc_scan* s, uint64_t* bigram_bytes, uint64_t* unigram_bytes, double* build_ms, uint32_t* n_plans) {
+    const LikePipeline* lp = s->like;
+    *bigram_bytes = lp && lp->d_slices ? lp->slices_bytes : 0;
+    *unigram_bytes = lp && lp->d_uni ? lp->slice_words * 8u * 256u : 0;
+    *build_ms = lp ? lp->flat_build_ms + lp->uni_build_ms : 0.0;
+    *n_plans = lp ? uint32_t(lp->plans.size()) : 0u;
 }
 
 // One line on how `LIKE '%needle%'` was / would be evaluated on this scan (lc_scan_explain).  Caller holds s->mu.

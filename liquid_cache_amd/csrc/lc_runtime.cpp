@@ -218,7 +218,17 @@ lc_status arena_alloc(lc_ctx* ctx, size_t bytes, uint8_t** out, int* slab_idx) {
     }
     size_t want = std::max(bytes, kSlabBytes);
     if (ctx->max_hbm) {
-        const uint64_t left = ctx->max_hbm > ctx->staged_bytes ? ctx->max_hbm - ctx->staged_bytes : 0;
+        // the budget covers the slabs AND the scan-level LIKE indexes; the indexes kept for future scans are a cache and go
+        // first (live scans keep theirs: staging then fails like the reference's CacheFull)
+        auto left_now = [&]() {
+            const uint64_t used = ctx->staged_bytes + ctx->index_bytes.load();
+            return ctx->max_hbm > used ? ctx->max_hbm - used : uint64_t(0);
+        };
+        uint64_t left = left_now();
+        if (bytes > left) {
+            like_orphans_clear(ctx);
+            left = left_now();
+        }
         if (bytes > left) return fail(LC_ERR_OOM, "HBM budget exhausted (max_hbm_bytes)");
         want = std::max<size_t>(bytes, std::min<uint64_t>(want, left));  // small budgets get small slabs
     }
@@ -2411,6 +2421,29 @@ void lc_scan_destroy(lc_scan* s) {
     } catch (...) {
     }
     LC_PROF(12);
+}
+
+lc_status lc_scan_info_get(lc_scan* s, lc_scan_info* out) {
+    return guarded([&]() -> lc_status {
+    if (!s || !out) return fail(LC_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->entries = s->n;
+    out->rows = s->total_rows;
+    out->mask_words = s->seg_offsets.back();
+    out->is_byte_view = s->is_str ? 1 : 0;
+    out->max_bit_width = s->is_str ? 16 : int32_t(s->max_w);
+    for (const Entry& e : s->meta) out->entry_bytes += e.device_bytes;
+    std::lock_guard<std::mutex> g(s->mu);
+    uint32_t plans = 0;
+    like_pipeline_info(s, &out->index_bytes, &out->unigram_index_bytes, &out->index_build_ms, &plans);
+    out->like_plans = plans;
+    out->ctx_index_bytes = s->ctx->index_bytes.load();
+    {
+        std::shared_lock<std::shared_mutex> gc(s->ctx->mu);
+        out->ctx_slab_bytes = s->ctx->staged_bytes;
+    }
+    return LC_OK;
+    });
 }
 
 uint64_t lc_scan_mask_words(const lc_scan* s) { return s ? s->seg_offsets.back() : 0; }

@@ -327,3 +327,74 @@ def test_cast_wrapped_predicates_on_reference_samples(gpu_cache):
                 checked += 1
         scan.close()
     assert checked >= 100
+
+
+def test_index_budget_and_eviction_mid_stream(product_lib, oracle, grouped_cases):
+    """The scan-level LIKE index is HBM the caller's budget covers (lc_scan_info_get, max_hbm_bytes): a scan whose index does
+    not fit evaluates with the entry-level index (k_like_lean) — same masks — and an index cached for a future scan is
+    dropped when a live query needs the room.  A query stream over three 'columns' under a budget of 1.5 indexes."""
+    lo = oracle
+
+    def stage_cols(cache):
+        cols = []
+        for c in range(3):
+            ids = []
+            for r_i, (st, entries) in enumerate(grouped_cases):
+                path = 7300 + 10 * c + r_i
+                cache.set_symbol_table(path, lo.symtab_bytes(st))
+                for e_i, (rows, liquid) in enumerate(entries):
+                    eid = lc.ParquetArrayID.new(20 + c, r_i, 5, e_i)
+                    cache.stage([eid], [liquid], [path])
+                    ids.append(eid)
+            cols.append(ids)
+        return cols
+
+    needles = [b"google", b"index.php?id=1", b"zzzzqqq"]
+    exprs = [lc.LiquidExpr.try_new("like", b"%" + nd + b"%", pa.binary(), HINT) for nd in needles]
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1).build()
+    try:
+        cols = stage_cols(cache)
+        scan = cache.scan(cols[0])
+        want = [scan.eval_to_host(e) for e in exprs]
+        info = scan.info()
+        index_bytes, slab_bytes = int(info.index_bytes), int(info.ctx_slab_bytes)
+        assert index_bytes > 0 and int(info.ctx_index_bytes) == index_bytes and info.like_plans == len(needles)
+        assert scan.explain(exprs[0]).startswith("k_like_flat")
+        assert int(info.entries) == scan.entries and int(info.rows) == scan.rows and info.is_byte_view == 1
+        scan.close()
+    finally:
+        cache.close()
+    budget = slab_bytes + index_bytes * 3 // 2
+    cache = lc.LiquidCacheBuilder.new().with_max_memory_bytes(budget).with_index_options(like_pipeline_min_entries=1).build()
+    try:
+        cols = stage_cols(cache)
+
+        def query(c, keep=False):
+            s = cache.scan(cols[c])
+            for e, (m, cnt) in zip(exprs, want):
+                gm, gc = s.eval_to_host(e)
+                assert np.array_equal(gm, m) and gc.tolist() == cnt.tolist()
+            inf = s.info()
+            assert int(inf.ctx_index_bytes) + int(inf.ctx_slab_bytes) <= budget
+            path = s.explain(exprs[0]).split(":")[0].split(" ")[0]
+            if not keep:
+                s.close()
+            return path, int(inf.index_bytes), s
+        seen = []
+        for q in range(6):  # a scan per query, the columns round robin: every query finds room (cached indexes are dropped)
+            path, ib, _ = query(q % 3)
+            seen.append(path)
+            assert path == "k_like_flat" and ib == index_bytes
+        # a LIVE scan holds its index: the next column's index does not fit the budget and the entry-level index serves
+        path_a, ib_a, live = query(0, keep=True)
+        assert path_a == "k_like_flat" and ib_a == index_bytes
+        path_b, ib_b, _ = query(1)
+        assert path_b == "k_like_lean" and ib_b == 0, (path_b, ib_b)
+        live.close()
+        path_c, ib_c, _ = query(1)  # the room is back
+        assert path_c == "k_like_flat" and ib_c == index_bytes
+        # staging more data than the budget leaves fails like the reference's CacheFull, the cached index going first
+        extra = lc.ParquetArrayID.new(29, 0, 5, 0)
+        cache.stage([extra], [grouped_cases[0][1][0][1]], [7300])
+    finally:
+        cache.close()
