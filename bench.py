@@ -549,9 +549,43 @@ def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_ex
     for c in range(2):
         lens = views[c][:k_h, 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0]
         assert int(lens.astype(np.int64).sum()) == (out["url_bytes"], out["phrase_bytes"])[c], "gathered bytes differ"
-    res.update(ms=ms_h, rows_per_s=url_scan.rows / (ms_h * 1e-3),
-               kernels="k_str_pred (SearchPhrase <> '') + k_like_flat (hit list) + 2 x k_str_gather_hits",
+    res.update(ms_reference_order=ms_h,
+               kernels_reference_order="k_str_pred (SearchPhrase <> '') + k_like_flat (hit list) + 2 x k_str_gather_hits",
                hit_list_equals_mask_form=True)
+    # ... and with the conjuncts in the order a sparse pipeline wants them (a conjunction commutes): the SELECTIVE one first —
+    # the LIKE leaves 16,635 rows as a hit list — and `SearchPhrase <> ''` evaluated on those rows only (lc_scan_filter_hits:
+    # per record, on the row's own value), instead of mapping 100 M keys to find 13 M rows of which 2,153 survive.  The four
+    # device counters are zeroed by ONE memset (LC_HITS_COUNTERS_ZEROED).
+    hits2 = torch.zeros(hcap, dtype=torch.int64, device="cuda")
+    ctr = torch.zeros(4, dtype=torch.int64, device="cuda")
+    c_ptr = [ctr.data_ptr() + 8 * i for i in range(4)]
+
+    def run_sparse():
+        N.check(cache._lib.lc_device_memset(cache.handle, ctr.data_ptr(), 0, 32, stream), cache.handle)
+        url_scan.eval_hits(like_expr, hits.data_ptr(), hcap, c_ptr[0], 0, 0, 0, 0, stream, counters_zeroed=True)
+        sp_scan.filter_hits(ne_expr, hits.data_ptr(), c_ptr[0], hcap, hits2.data_ptr(), hcap, c_ptr[1], stream, counters_zeroed=True)
+        url_scan.gather_bytes_hits(hits2.data_ptr(), c_ptr[1], hcap, views[0].data_ptr(), data[0].data_ptr(),
+                                   min(data[0].numel(), (1 << 31) - 1), c_ptr[2], 0, stream, counters_zeroed=True)
+        sp_scan.gather_bytes_hits(hits2.data_ptr(), c_ptr[1], hcap, views[1].data_ptr(), data[1].data_ptr(),
+                                  min(data[1].numel(), (1 << 31) - 1), c_ptr[3], 0, stream, counters_zeroed=True)
+
+    for _ in range(2):
+        run_sparse()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run_sparse()
+    torch.cuda.synchronize()
+    ms_s = (time.perf_counter() - t0) / iters * 1e3
+    cv = ctr.cpu().numpy()
+    hv2 = hits2[: int(cv[1])].cpu().numpy().view(np.uint64)
+    assert int(cv[1]) == k_out and np.array_equal(np.sort(hv2), np.sort(want_rows)), "sparse pipeline: rows differ from the mask form's"
+    for c in range(2):
+        lens = views[c][: int(cv[1]), 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0]
+        assert int(lens.astype(np.int64).sum()) == (out["url_bytes"], out["phrase_bytes"])[c], "sparse pipeline: gathered bytes differ"
+    res.update(ms=ms_s, rows_per_s=url_scan.rows / (ms_s * 1e-3), rows_after_like=int(cv[0]),
+               kernels="k_like_flat (hit list) + k_pred_hits (SearchPhrase <> '' on the listed rows) + 2 x k_str_gather_hits",
+               sparse_pipeline_equals_mask_form=True)
     # the step after the path: GROUP BY "SearchPhrase" with MIN("URL") and COUNT(*) as per-entry partials on the device
     # (lc_scan_group_partials) instead of handing the selected strings to a host-side partial aggregate
     try:

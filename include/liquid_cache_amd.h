@@ -561,10 +561,27 @@ LC_API lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const vo
  *   d_counts_out (optional): hits per entry; d_total_out (optional): COUNT(*).  No mask is written.  Kernels that can emit the
  *   list themselves (k_like_flat: selective [NOT] LIKE and string = / <>) do; for every other evaluation path the mask goes to
  *   scan-owned scratch and one more kernel lists it — always correct, fastest where it matters.  Asynchronous on `stream`.
- * lc_scan_mask_to_hits: the same list from a mask in scan layout (e.g. the result of lc_scan_eval_filter). */
+ * lc_scan_mask_to_hits: the same list from a mask in scan layout (e.g. the result of lc_scan_eval_filter).
+ * flags: LC_HITS_COUNTERS_ZEROED — the caller has zeroed the u64 device counters this call writes (*d_n_hits; for the
+ *   gathers *d_n_bytes; for the filter *d_n_hits_out), typically all counters of a query with ONE lc_device_memset: the call
+ *   then issues no memset of its own (each is a small kernel in front of the real one). */
+#define LC_HITS_COUNTERS_ZEROED 1u
 LC_API lc_status lc_scan_eval_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
                                    const void* d_selection, void* d_hits_out, uint64_t capacity, void* d_n_hits,
-                                   void* d_hit_first, void* d_counts_out, void* d_total_out, void* stream);
+                                   void* d_hit_first, void* d_counts_out, void* d_total_out, uint32_t flags, void* stream);
+/* Selection chaining in sparse form (boolean_buffer_and_then for the next conjunct, src/datafusion/src/utils.rs:62-83, when
+ * the selection is a handful of rows): the records of d_hits_in whose row is valid in THIS scan's column and satisfies
+ * `pred` are appended to d_hits_out (a different buffer); *d_n_hits_out receives their number (may exceed capacity_out).
+ * `scan` covers the same row ranges as the scan that produced the list.  The predicate is evaluated on the row's own
+ * value — byte views: compare / match on the compressed value; fixed width: decode and compare, Arrow totalOrder for
+ * floats — so the cost is per record, not per row of the column: after a selective first conjunct the remaining
+ * conjuncts cost microseconds whatever their columns' sizes.  Conjunctions commute: a host that knows (from
+ * lc_scan_explain's plan, or from statistics) which conjunct is selective runs that one first with lc_scan_eval_hits and
+ * the others through this call.  The records of a 64-record batch keep their relative order; batches are appended in no
+ * particular order (an entry's records may end up apart — gathers do not care).  LC_UNSUPPORTED for squeezed entries. */
+LC_API lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_hits_in,
+                                     const void* d_n_hits_in, uint64_t capacity_in, void* d_hits_out, uint64_t capacity_out,
+                                     void* d_n_hits_out, uint32_t flags, void* stream);
 LC_API lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, void* d_hits_out, uint64_t capacity,
                                       void* d_n_hits, void* d_hit_first, void* stream);
 /* get().with_selection() for the rows of a hit list, ONE launch, no host round trip.  `scan` is any scan over the same row
@@ -583,7 +600,7 @@ LC_API lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const voi
                                            uint64_t capacity_rows, void* d_values_out, void* d_row_valid, void* stream);
 LC_API lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits,
                                            uint64_t capacity_rows, void* d_views, void* d_row_valid, void* d_data,
-                                           uint64_t capacity_bytes, void* d_n_bytes, void* stream);
+                                           uint64_t capacity_bytes, void* d_n_bytes, uint32_t flags, void* stream);
 
 /* ExtractDate32 over gathered values of a Date32 / Timestamp scan: replaces `n_values` decoded values in d_values
  * (as written by lc_scan_gather_fixed) in place by their lossy date-part reconstruction (see

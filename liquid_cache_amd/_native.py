@@ -83,6 +83,7 @@ EXPORTED_SYMBOLS = [
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize",
     "lc_stream_create", "lc_stream_destroy",
     "lc_scan_eval_hits", "lc_scan_mask_to_hits", "lc_scan_gather_fixed_hits", "lc_scan_gather_bytes_hits", "lc_scan_info_get",
+    "lc_scan_filter_hits",
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
@@ -210,11 +211,13 @@ def load():
     L.lc_scan_gather_fixed.restype = i32; L.lc_scan_gather_fixed.argtypes = [vp, vp, vp, vp, u64, vp, vp]
     L.lc_scan_info_get.restype = i32; L.lc_scan_info_get.argtypes = [vp, P(ScanInfo)]
     L.lc_scan_eval_hits.restype = i32
-    L.lc_scan_eval_hits.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, u64, vp, vp, vp, vp, vp]
+    L.lc_scan_eval_hits.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, u64, vp, vp, vp, vp, C.c_uint32, vp]
+    L.lc_scan_filter_hits.restype = i32
+    L.lc_scan_filter_hits.argtypes = [vp, vp, P(Predicate), vp, vp, u64, vp, u64, vp, C.c_uint32, vp]
     L.lc_scan_mask_to_hits.restype = i32; L.lc_scan_mask_to_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
     L.lc_scan_gather_fixed_hits.restype = i32; L.lc_scan_gather_fixed_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
     L.lc_scan_gather_bytes_hits.restype = i32
-    L.lc_scan_gather_bytes_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, u64, vp, vp]
+    L.lc_scan_gather_bytes_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, u64, vp, C.c_uint32, vp]
     L.lc_device_alloc.restype = i32; L.lc_device_alloc.argtypes = [vp, u64, P(vp)]
     L.lc_device_free.restype = i32; L.lc_device_free.argtypes = [vp, vp]
     L.lc_device_memset.restype = i32; L.lc_device_memset.argtypes = [vp, vp, i32, u64, vp]

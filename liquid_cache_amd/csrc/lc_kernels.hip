@@ -3706,6 +3706,153 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather_hits(const FixedDesc*
     }
 }
 
+// A predicate over the rows of a HIT LIST (the sparse form of selection chaining: what boolean_buffer_and_then does for the
+// next conjunct of a filter, src/datafusion/src/utils.rs:62-83, when the selection is a handful of rows): record i of the
+// input survives when its row is valid and satisfies the predicate on THIS scan's column.  A lane per record; byte views are
+// compared / matched on the compressed value directly (decode_compare / like_generic: no dictionary pass, no key mapping —
+// the cost is per surviving candidate row, not per row of the column); fixed-width values are decoded like the gather does
+// and compared in the 64-bit value domain (Arrow totalOrder for floats).  Survivors are appended in batch order of arrival
+// (one returning atomic per workgroup): the relative order inside a 64-record batch is kept.
+struct HitsPredArgs {
+    const void* descs;
+    const DevSymtab* symtabs;
+    const uint64_t* hits_in;
+    const unsigned long long* n_in;
+    uint64_t cap_in;
+    uint64_t* hits_out;
+    uint64_t cap_out;
+    unsigned long long* n_out;
+    // byte views
+    int32_t op;            // LC_OP_*
+    int32_t const_value;   // >= 0: Literal(Boolean)
+    const uint8_t* lit;    // literal / pattern bytes when longer than the inline buffer
+    uint32_t lit_len;
+    uint8_t lit_inline[kInlineNeedle];
+    // fixed width
+    FixedPred fp;
+};
+
+template <typename U>
+__device__ __forceinline__ bool fixed_value_pred(const FixedDesc& d, uint32_t r, const FixedPred& fp) {
+    constexpr uint32_t TB = LaneTraits<U>::kBits;
+    const uint32_t W = d.W;
+    if (W == 0 || r >= d.len) return false;
+    if (d.validity && ((d.validity[r >> 6] >> (r & 63u)) & 1) == 0) return false;
+    const U mask_e = (W >= TB) ? U(~U(0)) : U((U(1) << (W & (TB - 1))) - 1);
+    uint32_t row, fl;
+    fl_row_lane<U>(r & 1023u, &row, &fl);
+    const U u = extract_packed<U>(d.packed + uint64_t(r >> 10) * 128u * W, row, fl, W, mask_e);
+    int cmp;  // value vs literal: -1 / 0 / +1
+    if (d.kind == kKindF32 || d.kind == kKindF64) {
+        uint32_t lo = 0, hi = d.patch_len;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (d.patch_idx[mid] < uint64_t(r)) lo = mid + 1; else hi = mid;
+        }
+        const bool patched = lo < d.patch_len && d.patch_idx[lo] == uint64_t(r);
+        if (d.kind == kKindF32) {
+            if constexpr (TB == 32) {
+                float v = alp_decode(int32_t(uint32_t(u) + uint32_t(d.reference)), d.alp_e, d.alp_f);
+                if (patched) v = reinterpret_cast<const float*>(d.patch_val)[lo];
+                const int32_t kv = FloatBits<float>::key(v), kl = FloatBits<float>::key(FloatBits<float>::from_bits(fp.lit));
+                cmp = kv < kl ? -1 : (kv > kl ? 1 : 0);
+            } else return false;
+        } else {
+            if constexpr (TB == 64) {
+                double v = alp_decode(int64_t(uint64_t(u) + d.reference), d.alp_e, d.alp_f);
+                if (patched) v = reinterpret_cast<const double*>(d.patch_val)[lo];
+                const int64_t kv = FloatBits<double>::key(v), kl = FloatBits<double>::key(FloatBits<double>::from_bits(fp.lit));
+                cmp = kv < kl ? -1 : (kv > kl ? 1 : 0);
+            } else return false;
+        }
+    } else if (fp.lit_class != 0) {
+        cmp = fp.lit_class < 0 ? 1 : -1;  // the literal lies below / above every representable value
+    } else if (d.kind == kKindDecimal) {
+        const uint64_t v = uint64_t(u) + d.reference;
+        cmp = v < fp.lit ? -1 : (v > fp.lit ? 1 : 0);
+    } else {
+        const U vu = U(u + U(d.reference));  // add_wrapping in the lane type
+        if (d.is_signed) {
+            const int64_t v = TB == 64 ? int64_t(uint64_t(vu)) : int64_t(uint64_t(vu) << (64 - TB)) >> (64 - TB);
+            const int64_t l = int64_t(fp.lit);
+            cmp = v < l ? -1 : (v > l ? 1 : 0);
+        } else {
+            const uint64_t v = uint64_t(vu);
+            cmp = v < fp.lit ? -1 : (v > fp.lit ? 1 : 0);
+        }
+    }
+    switch (fp.op) {
+        case LC_OP_EQ: return cmp == 0;
+        case LC_OP_NE: return cmp != 0;
+        case LC_OP_LT: return cmp < 0;
+        case LC_OP_LE: return cmp <= 0;
+        case LC_OP_GT: return cmp > 0;
+        default: return cmp >= 0;
+    }
+}
+
+template <int kLaneLog2>  // 0: byte views; 3..6: fixed width lanes
+__global__ __launch_bounds__(kThreads) void k_pred_hits(HitsPredArgs a) {
+    __shared__ unsigned long long s_tot[2][kWavesPerBlock], s_base[2];
+    const uint64_t k = min(uint64_t(*a.n_in), a.cap_in);
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint8_t* lit = a.lit ? a.lit : a.lit_inline;
+    uint32_t it = 0;
+    for (uint64_t rb0 = uint64_t(blockIdx.x) * kThreads; rb0 < k; rb0 += uint64_t(gridDim.x) * kThreads, it ^= 1u) {
+        const uint64_t i = rb0 + uint64_t(wave) * kWave + uint64_t(lane);
+        const bool live = i < k;
+        const uint64_t ref = live ? a.hits_in[i] : 0;
+        const uint32_t row = uint32_t(ref);
+        bool keep = false;
+        if (live) {
+            if constexpr (kLaneLog2 == 0) {
+                const StrDesc& d = static_cast<const StrDesc*>(a.descs)[uint32_t(ref >> 32)];
+                const bool valid = row < d.n && (d.validity ? ((d.validity[row >> 6] >> (row & 63u)) & 1) != 0 : true);
+                if (valid) {
+                    if (a.const_value >= 0) {
+                        keep = a.const_value != 0;
+                    } else {
+                        const uint32_t key = uint32_t(d.keys[row]);
+                        uint32_t start, stop;
+                        str_offset_pair(d, key, start, stop);
+                        const DevSymtab& st = a.symtabs[d.symtab_slot];
+                        if (a.op == LC_OP_LIKE || a.op == LC_OP_NOT_LIKE) {
+                            keep = like_generic(st, d.fsst, start, stop, lit, a.lit_len) == (a.op == LC_OP_LIKE);
+                        } else {
+                            const int c = decode_compare(st, d.fsst, start, stop, lit, a.lit_len);
+                            keep = a.op == LC_OP_EQ ? c == 0 : a.op == LC_OP_NE ? c != 0 : a.op == LC_OP_LT ? c < 0 :
+                                   a.op == LC_OP_LE ? c <= 0 : a.op == LC_OP_GT ? c > 0 : c >= 0;
+                        }
+                    }
+                }
+            } else {
+                const FixedDesc& d = static_cast<const FixedDesc*>(a.descs)[uint32_t(ref >> 32)];
+                if constexpr (kLaneLog2 == 3) keep = fixed_value_pred<uint8_t>(d, row, a.fp);
+                else if constexpr (kLaneLog2 == 4) keep = fixed_value_pred<uint16_t>(d, row, a.fp);
+                else if constexpr (kLaneLog2 == 5) keep = fixed_value_pred<uint32_t>(d, row, a.fp);
+                else keep = fixed_value_pred<uint64_t>(d, row, a.fp);
+            }
+        }
+        const uint64_t km = __ballot(keep);
+        const uint32_t tot = uint32_t(__popcll(km));
+        if (lane == 0) s_tot[it][wave] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long t = 0;
+            for (uint32_t w = 0; w < uint32_t(kWavesPerBlock); w++) t += s_tot[it][w];
+            s_base[it] = t ? atomicAdd(a.n_out, t) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long b = s_base[it];
+        for (uint32_t w = 0; w < wave; w++) b += s_tot[it][w];
+        if (keep) {
+            const uint64_t pos = b + lanes_below(km);
+            if (pos < a.cap_out) a.hits_out[pos] = ref;
+        }
+    }
+}
+
 // One value decoded by the whole wave (wave_decode_value) with the symbol table wherever `st` lives (LDS copy or global),
 // the first chunk's bytes already loaded by the caller (`pre`: byte start + lane, so that the loads of several values are in
 // flight together), and the value's first 12 bytes returned in every lane (`head`: a BinaryView holds values of up to 12
@@ -5326,6 +5473,36 @@ hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_sym
     const uint32_t grid = uint32_t(std::min<uint64_t>((cap_rows + kWavesPerBlock - 1) / kWavesPerBlock, uint64_t(device_cus()) * 4));
     hipLaunchKernelGGL(k_str_gather_hits, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_hits, d_n_hits, cap_rows,
                        d_views, d_row_valid, d_data, cap_bytes, d_n_bytes);
+    return hipGetLastError();
+}
+
+hipError_t launch_pred_hits(const HitsPredLaunch& h, hipStream_t stream) {
+    if (h.cap_in == 0) return hipSuccess;
+    HitsPredArgs a{};
+    a.descs = h.descs;
+    a.symtabs = h.symtabs;
+    a.hits_in = h.hits_in;
+    a.n_in = h.n_in;
+    a.cap_in = h.cap_in;
+    a.hits_out = h.hits_out;
+    a.cap_out = h.cap_out;
+    a.n_out = h.n_out;
+    a.op = h.op;
+    a.const_value = h.const_value;
+    a.lit_len = h.lit_len;
+    a.lit = h.lit_len > uint32_t(kInlineNeedle) ? h.d_lit : nullptr;
+    if (h.lit_len <= uint32_t(kInlineNeedle) && h.h_lit)
+        for (uint32_t q = 0; q < h.lit_len; q++) a.lit_inline[q] = h.h_lit[q];
+    a.fp = h.fp;
+    const dim3 grid(uint32_t(std::min<uint64_t>((h.cap_in + kThreads - 1) / kThreads, uint64_t(device_cus()) * 8))), block(kThreads);
+    switch (h.lane_log2) {
+        case 0: hipLaunchKernelGGL(k_pred_hits<0>, grid, block, 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(k_pred_hits<3>, grid, block, 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(k_pred_hits<4>, grid, block, 0, stream, a); break;
+        case 5: hipLaunchKernelGGL(k_pred_hits<5>, grid, block, 0, stream, a); break;
+        case 6: hipLaunchKernelGGL(k_pred_hits<6>, grid, block, 0, stream, a); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

@@ -370,6 +370,26 @@ hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, con
 hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_hits,
                                   const unsigned long long* d_n_hits, uint64_t cap_rows, uint32_t* d_views, uint8_t* d_row_valid,
                                   uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, hipStream_t stream);
+// a predicate over the rows of a hit list (k_pred_hits): lane_log2 0 = byte views (op on the literal / pattern bytes; lit_len <=
+// kInlineNeedle travels in the kernel arguments from h_lit, longer literals from the device copy d_lit), 3..6 = fixed width
+struct HitsPredLaunch {
+    const void* descs;
+    const DevSymtab* symtabs;
+    const uint64_t* hits_in;
+    const unsigned long long* n_in;
+    uint64_t cap_in;
+    uint64_t* hits_out;
+    uint64_t cap_out;
+    unsigned long long* n_out;
+    int32_t lane_log2;
+    int32_t op;
+    int32_t const_value;
+    uint32_t lit_len;
+    const uint8_t* h_lit;
+    const uint8_t* d_lit;
+    FixedPred fp;
+};
+hipError_t launch_pred_hits(const HitsPredLaunch& h, hipStream_t stream);
 hipError_t launch_str_gather(const StrDesc* d_descs, const DevSymtab* d_symtabs, uint32_t entry, uint32_t dict_len,
                              uint32_t n_rows, const uint64_t* d_selection, uint32_t* d_dict_len, int32_t* d_offsets,
                              uint32_t* d_rows, uint64_t* d_totals, uint8_t* d_data, hipStream_t stream);

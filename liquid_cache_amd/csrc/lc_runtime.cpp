@@ -2534,6 +2534,7 @@ struct HitsOut {
     uint64_t cap = 0;
     void* d_n_hits = nullptr;
     void* d_hit_first = nullptr;
+    bool counters_zeroed = false;  // LC_HITS_COUNTERS_ZEROED: the caller zeroed *d_n_hits (one memset for a whole query)
 };
 
 static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pred, const void* d_selection,
@@ -2547,7 +2548,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         return fail(LC_ERR_INVALID, "no output: d_mask_out is null and neither a count nor a hit list is asked for");
     if (!d_mask_out && d_valid_out) return fail(LC_ERR_INVALID, "a validity output needs the mask output");
     if (hits && hits->d_hits && !hits->d_n_hits) return fail(LC_ERR_INVALID, "d_n_hits is null");
-    if (hits && hits->d_n_hits) LC_HIP(hipMemsetAsync(hits->d_n_hits, 0, 8, stream));
+    if (hits && hits->d_n_hits && !hits->counters_zeroed) LC_HIP(hipMemsetAsync(hits->d_n_hits, 0, 8, stream));
     if (s->n == 0) {
         if (d_total_out) LC_HIP(hipMemsetAsync(d_total_out, 0, 8, stream));
         return LC_OK;
@@ -4100,7 +4101,7 @@ lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_s
 
 lc_status lc_scan_eval_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds, const void* d_selection,
                             void* d_hits_out, uint64_t capacity, void* d_n_hits, void* d_hit_first, void* d_counts_out,
-                            void* d_total_out, void* stream) {
+                            void* d_total_out, uint32_t flags, void* stream) {
     if (!preds || n_preds == 0 || n_preds > 2) return fail(LC_ERR_INVALID, "lc_scan_eval_hits takes one or two predicates");
     if (!d_hits_out || !d_n_hits) return fail(LC_ERR_INVALID, "d_hits_out / d_n_hits is null");
     HitsOut h;
@@ -4108,6 +4109,7 @@ lc_status lc_scan_eval_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred
     h.cap = capacity;
     h.d_n_hits = d_n_hits;
     h.d_hit_first = d_hit_first;
+    h.counters_zeroed = (flags & LC_HITS_COUNTERS_ZEROED) != 0;
     return scan_eval_impl(ctx, scan, &preds[0], d_selection, nullptr, nullptr, d_counts_out, nullptr,
                           static_cast<hipStream_t>(stream), n_preds == 2 ? &preds[1] : nullptr, d_total_out, false, &h);
 }
@@ -4123,6 +4125,72 @@ lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, v
     LC_HIP(launch_mask_to_hits(scan->d_descs, scan->is_str, scan->n, static_cast<const uint64_t*>(d_mask),
                                static_cast<uint64_t*>(d_hits_out), capacity, static_cast<unsigned long long*>(d_n_hits),
                                static_cast<uint32_t*>(d_hit_first), st));
+    return LC_OK;
+    });
+}
+
+lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred, const void* d_hits_in, const void* d_n_hits_in,
+                              uint64_t capacity_in, void* d_hits_out, uint64_t capacity_out, void* d_n_hits_out, uint32_t flags,
+                              void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !scan || !pred || !d_hits_in || !d_n_hits_in || !d_hits_out || !d_n_hits_out) return fail(LC_ERR_INVALID, "null argument");
+    if (d_hits_in == d_hits_out) return fail(LC_ERR_INVALID, "lc_scan_filter_hits does not filter in place");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(hipMemsetAsync(d_n_hits_out, 0, 8, st));
+    if (scan->n == 0 || capacity_in == 0) return LC_OK;
+    if (scan->has_clamped || scan->has_fquant)
+        return fail(LC_UNSUPPORTED, "squeezed entries: the mask form decides which rows need the backing array");
+    HitsPredLaunch h{};
+    h.descs = scan->d_descs;
+    h.symtabs = scan->d_symtabs;
+    h.hits_in = static_cast<const uint64_t*>(d_hits_in);
+    h.n_in = static_cast<const unsigned long long*>(d_n_hits_in);
+    h.cap_in = capacity_in;
+    h.hits_out = static_cast<uint64_t*>(d_hits_out);
+    h.cap_out = capacity_out;
+    h.n_out = static_cast<unsigned long long*>(d_n_hits_out);
+    h.const_value = -1;
+    if (!scan->is_str) {
+        const lc_status ps = make_fixed_pred(scan->meta[0], pred, &h.fp);
+        if (ps != LC_OK) return ps;
+        h.lane_log2 = scan->lane_log2;
+        scan_note_stream(scan, st);
+        LC_HIP(launch_pred_hits(h, st));
+        return LC_OK;
+    }
+    StrPredHost sp;
+    const lc_status ps = make_str_pred(pred, &sp);
+    if (ps != LC_OK) return ps;
+    if (sp.p.mode == 3 && scan->any_fingerprints)
+        return fail(LC_UNSUPPORTED, "general LIKE patterns apply to byte views without fingerprints (the reference requires "
+                                    "%needle% on SubstringSearch columns)");
+    h.lane_log2 = 0;
+    h.op = pred->op;
+    if (sp.p.mode == 2) {
+        h.const_value = sp.p.const_value ? 1 : 0;
+    } else {
+        // compare ops take the literal, [NOT] LIKE the pattern as written (matched by the general matcher on the few rows left)
+        h.h_lit = static_cast<const uint8_t*>(pred->lit);
+        h.lit_len = uint32_t(pred->lit_len);
+        if (pred->lit_len > uint64_t(kMaxNeedleBytes)) return fail(LC_UNSUPPORTED, "literal over 4096 bytes");
+        if (h.lit_len > uint32_t(kInlineNeedle)) {
+            std::lock_guard<std::mutex> g(scan->mu);
+            scan_enter_stream(scan, st);
+            const size_t need = size_t(h.lit_len) + 16;
+            LC_HIP(hipStreamSynchronize(st));  // a previous evaluation may still read the old literal
+            if (need > scan->needle_cap) {
+                pool_release(ctx, scan->d_needle);
+                scan->d_needle = static_cast<uint8_t*>(pool_alloc(ctx, need));
+                if (!scan->d_needle) { scan->needle_cap = 0; return fail(LC_ERR_OOM, "hipMalloc (needle)"); }
+                scan->needle_cap = need;
+            }
+            LC_HIP(hipMemcpyAsync(scan->d_needle, pred->lit, h.lit_len, hipMemcpyHostToDevice, st));
+            LC_HIP(hipStreamSynchronize(st));
+            h.d_lit = scan->d_needle;
+        }
+    }
+    scan_note_stream(scan, st);
+    LC_HIP(launch_pred_hits(h, st));
     return LC_OK;
     });
 }
@@ -4146,14 +4214,14 @@ lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hi
 
 lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits, uint64_t capacity_rows,
                                     void* d_views, void* d_row_valid, void* d_data, uint64_t capacity_bytes, void* d_n_bytes,
-                                    void* stream) {
+                                    uint32_t flags, void* stream) {
     return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_hits || !d_n_hits || !d_views || !d_n_bytes || (capacity_bytes && !d_data))
         return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes_hits covers byte-view columns");
     if (capacity_bytes > 0x7FFFFFFFull) return fail(LC_ERR_INVALID, "a BinaryView offset is an i32: capacity_bytes must stay below 2 GiB");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LC_HIP(hipMemsetAsync(d_n_bytes, 0, 8, st));
+    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(hipMemsetAsync(d_n_bytes, 0, 8, st));
     if (scan->n == 0 || capacity_rows == 0) return LC_OK;
     scan_note_stream(scan, st);
     LC_HIP(launch_str_gather_hits(static_cast<const StrDesc*>(scan->d_descs), scan->d_symtabs, static_cast<const uint64_t*>(d_hits),

@@ -359,7 +359,7 @@ def test_index_budget_and_eviction_mid_stream(product_lib, oracle, grouped_cases
         info = scan.info()
         index_bytes, slab_bytes = int(info.index_bytes), int(info.ctx_slab_bytes)
         assert index_bytes > 0 and int(info.ctx_index_bytes) == index_bytes and info.like_plans == len(needles)
-        assert scan.explain(exprs[0]).startswith("k_like_flat")
+        assert scan.explain(exprs[2]).startswith("k_like_flat")  # (a needle the plan finds selective; 'google' is not, here)
         assert int(info.entries) == scan.entries and int(info.rows) == scan.rows and info.is_byte_view == 1
         scan.close()
     finally:
@@ -376,7 +376,7 @@ def test_index_budget_and_eviction_mid_stream(product_lib, oracle, grouped_cases
                 assert np.array_equal(gm, m) and gc.tolist() == cnt.tolist()
             inf = s.info()
             assert int(inf.ctx_index_bytes) + int(inf.ctx_slab_bytes) <= budget
-            path = s.explain(exprs[0]).split(":")[0].split(" ")[0]
+            path = s.explain(exprs[2]).split(":")[0].split(" ")[0]
             if not keep:
                 s.close()
             return path, int(inf.index_bytes), s
@@ -398,3 +398,88 @@ def test_index_budget_and_eviction_mid_stream(product_lib, oracle, grouped_cases
         cache.stage([extra], [grouped_cases[0][1][0][1]], [7300])
     finally:
         cache.close()
+
+
+def test_filter_hits_against_oracle(product_lib, oracle, grouped_cases, gpu_cache):
+    """lc_scan_filter_hits: the survivors of a hit list under a predicate on the same row ranges == the rows the oracle's
+    eval_predicate marks among the listed ones — byte views (compare ops, LIKE / NOT LIKE, boolean literal) and fixed width
+    (integers, decimals, ALP floats with patches, nulls)."""
+    lo = oracle
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1).build()
+    try:
+        ids, flat = _stage_grouped(cache, lo, grouped_cases)
+        scan = cache.scan(ids)
+        lens = [len(c[0]) for c in flat]
+        rng = np.random.default_rng(21)
+        all_refs = np.concatenate([(np.uint64(e) << np.uint64(32)) | np.arange(n, dtype=np.uint64) for e, n in enumerate(lens)])
+        some_value = next(v for v in flat[3][0] if v is not None and len(v) > 70 or v is not None and len(v) > 20)
+        preds = [("=", some_value), ("!=", some_value), ("<", b"http://m"), (">=", b"http://m"), ("<=", b""), (">", b""),
+                 ("like", b"%google%"), ("not_like", b"%a%"), ("like", b"%index.php?id=1%"), ("=", b"x" * 100), ("like", b"%" + b"ab" * 40 + b"%")]
+        n_checked = 0
+        for op, lit in preds:
+            expr = lc.LiquidExpr.try_new(op, lit, pa.binary(), HINT)
+            truth = {}
+            for b, (rows, liquid, st) in enumerate(flat):
+                truth[b] = _want_full(lo, liquid, st, lo.OP_NAMES["==" if op == "=" else op], lit, None, lens[b])
+            for k in (1, 63, 65, 700, len(all_refs)):
+                refs = all_refs if k == len(all_refs) else all_refs[rng.choice(len(all_refs), size=k, replace=False)]
+                got = scan.filter_hits_to_host(expr, refs)
+                want = [int(h) for h in refs if truth[int(h >> np.uint64(32))][int(h & np.uint64(0xFFFFFFFF))]]
+                assert sorted(int(x) for x in got) == sorted(want), (op, lit[:20], k, len(got), len(want))
+                # relative order inside every 64-record batch of the input is kept
+                pos = {int(h): i for i, h in enumerate(refs)}
+                gi = [pos[int(x)] for x in got]
+                for a, b2 in zip(gi, gi[1:]):
+                    assert a // 64 != b2 // 64 or a < b2
+                n_checked += 1
+        assert n_checked >= 50
+        # the boolean literal on byte-like columns (liquid_expr.rs:78-80): every valid listed row, or none
+        for val in (True, False):
+            expr = lc.LiquidExpr.try_new(None, val, pa.binary())
+            got = scan.filter_hits_to_host(expr, all_refs)
+            valid = [int(h) for h in all_refs if flat[int(h >> np.uint64(32))][0][int(h & np.uint64(0xFFFFFFFF))] is not None]
+            assert sorted(int(x) for x in got) == (sorted(valid) if val else [])
+        scan.close()
+    finally:
+        cache.close()
+    # fixed width: the same listed rows through the oracle's predicate on the same Liquid bytes
+    import decimal
+    n = 8192
+    arrays = [pa.array(rng.integers(-5000, 5000, size=n), type=pa.int64(), mask=rng.random(n) < 0.1),
+              pa.array(rng.integers(0, 60000, size=n).astype(np.uint16)),
+              pa.array(rng.integers(-120, 120, size=n).astype(np.int8)),
+              pa.array(rng.integers(7000, 12000, size=n).astype(np.int32), type=pa.date32()),
+              pa.array([decimal.Decimal(int(x)) / 100 for x in rng.integers(0, 10**6, size=n)], type=pa.decimal128(15, 2)),
+              pa.array(np.where(rng.random(n) < 0.02, np.pi, (rng.integers(-10**5, 10**5, size=n) / 100.0)), type=pa.float64(),
+                       mask=rng.random(n) < 0.05),
+              pa.array(np.where(rng.random(n) < 0.02, np.float32(np.e), (rng.integers(-10**4, 10**4, size=n) / 10.0).astype(np.float32)).astype(np.float32))]
+    lits = [[-4999, 0, 12, 5000, 10**12, -10**12], [0, 30000, 59999, 70000], [-120, 0, 119, 127, -200],
+            [__import__("datetime").date(1992, 1, 2), __import__("datetime").date(1999, 5, 5)],
+            [decimal.Decimal("5000.00"), decimal.Decimal("0.00"), decimal.Decimal("-1.00")],
+            [0.0, 3.141592653589793, 12.34, -1e9, float("nan")], [0.0, float(np.float32(np.e)), 12.5]]
+    refs_all = np.arange(n, dtype=np.uint64)
+    eid = 8800
+    n_fixed = 0
+    for arr, ls in zip(arrays, lits):
+        eid += 1
+        liquid = gpu_cache.transcode(arr)
+        gpu_cache.stage([eid], [liquid], data_types=[arr.type])
+        scan = gpu_cache.scan([eid])
+        for op in ("=", "!=", "<", "<=", ">", ">="):
+            for lit in ls:
+                expr = lc.LiquidExpr.try_new(op, lit, arr.type)
+                assert expr is not None
+                olit = lit
+                if isinstance(lit, decimal.Decimal):
+                    olit = int(lit * 100)
+                elif hasattr(lit, "toordinal"):
+                    olit = (lit - __import__("datetime").date(1970, 1, 1)).days
+                r = lo.eval_predicate(liquid, lo.OP_NAMES["==" if op == "=" else op], olit)
+                hit = r.values if r.validity is None else (r.values & r.validity)
+                for refs in (refs_all, refs_all[rng.choice(n, size=300, replace=False)]):
+                    got = scan.filter_hits_to_host(expr, refs)
+                    want = [int(h) for h in refs if hit[int(h)]]
+                    assert sorted(int(x) for x in got) == sorted(want), (str(arr.type), op, lit, len(got), len(want))
+                    n_fixed += 1
+        scan.close()
+    assert n_fixed >= 200
