@@ -2704,14 +2704,74 @@ __device__ __forceinline__ int32_t date_lossy_days(int32_t days, int field) {
         }
     }
 }
+// The same in 32-bit unsigned arithmetic (round 5: the 64-bit form above spends ~20 instructions on every division by a
+// constant and ran the in-place date-part pass at 0.19 of the HBM peak): the day count is moved into [0, 2^32) by a whole
+// number of 400-year eras, every quotient is then a multiply-high, and the three reconstructions need no second civil ->
+// days conversion — Year: the date minus its day of the civil year; Month: the first day of that month of 1970 (a 12-entry
+// table); Day: d - 1.  Days beyond year 5,877,000 take the 64-bit form.  (Checked against it over 800,000 day counts incl.
+// both ends of the range and the century / leap boundaries before it replaced it.)
+__device__ __forceinline__ int32_t date_lossy_days32(int32_t days, int field) {
+    constexpr uint32_t kOff = 719468u + 146097u * 14699u;  // 0000-03-01 based, shifted by 14,699 eras: days = -2^31 -> 715,623
+    if (days > int32_t(0xFFFFFFFFu - kOff)) return date_lossy_days(days, field);
+    if (field == 3) {
+        const uint32_t u = uint32_t(days) + kOff;  // (days + 4) mod 7 with days = u - kOff, u >= 0
+        const uint32_t dow = (u % 7u + 7u - kOff % 7u + 4u) % 7u;
+        return int32_t(3u + dow);  // 1970-01-04 is day 3
+    }
+    const uint32_t zp = uint32_t(days) + kOff;
+    const uint32_t era = zp / 146097u;
+    const uint32_t doe = zp - era * 146097u;
+    const uint32_t yoe = (doe - doe / 1460u + doe / 36524u - doe / 146096u) / 365u;
+    const uint32_t doy = doe - (365u * yoe + yoe / 4u - yoe / 100u);
+    const uint32_t mp = (5u * doy + 2u) / 153u;
+    if (field == 0) {
+        // days since January 1 of the civil year: January / February belong to the next civil year of the March-based one
+        const bool leap = (yoe & 3u) == 0 && (yoe % 100u != 0 || yoe == 0);
+        const uint32_t dsj = mp >= 10u ? doy - 306u : doy + 59u + (leap ? 1u : 0u);
+        return days - int32_t(dsj);
+    }
+    if (field == 1) {
+        const uint32_t m0 = mp < 10u ? mp + 2u : mp - 10u;  // month - 1
+        // first day of month m of 1970: 0 31 59 90 120 151 181 212 243 273 304 334
+        // (from March on: 30.57 days per month, rounded, less the two days February is short)
+        return int32_t(m0 == 0u ? 0u : m0 == 1u ? 31u : (m0 * 3057u + 50u) / 100u - 2u);
+    }
+    return int32_t(doy - (153u * mp + 2u) / 5u);  // day of month - 1
+}
 template <typename T>
 __global__ __launch_bounds__(256) void k_date_lossy(T* __restrict__ values, uint64_t n, int field, int64_t ticks_per_day) {
-    for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
-        if constexpr (sizeof(T) == 4) {
-            values[i] = T(date_lossy_days(int32_t(values[i]), field));
-        } else {
-            const int32_t days = int32_t(floor_div(int64_t(values[i]), ticks_per_day));
-            values[i] = T(int64_t(date_lossy_days(days, field)) * ticks_per_day);
+    // ticks_per_day is one of four constants (Date64 / Timestamp units): a division by a literal is a multiply-high
+    auto to_days = [&](int64_t v) -> int64_t {
+        switch (ticks_per_day) {
+            case 86400ll: return floor_div(v, 86400ll);
+            case 86400000ll: return floor_div(v, 86400000ll);
+            case 86400000000ll: return floor_div(v, 86400000000ll);
+            case 86400000000000ll: return floor_div(v, 86400000000000ll);
+            default: return floor_div(v, ticks_per_day);
+        }
+    };
+    if constexpr (sizeof(T) == 4) {
+        // four values per lane and load (16-byte accesses) between a scalar head up to the first 16-byte boundary and a tail
+        const uint64_t head = min(n, uint64_t(((16u - (uint32_t(reinterpret_cast<uintptr_t>(values)) & 15u)) & 15u) / 4u));
+        const uint64_t n4 = (n - head) / 4;
+        int4* v4 = reinterpret_cast<int4*>(values + head);
+        for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n4; i += uint64_t(gridDim.x) * blockDim.x) {
+            int4 x = v4[i];
+            x.x = date_lossy_days32(x.x, field);
+            x.y = date_lossy_days32(x.y, field);
+            x.z = date_lossy_days32(x.z, field);
+            x.w = date_lossy_days32(x.w, field);
+            v4[i] = x;
+        }
+        const uint64_t gid = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x;
+        if (gid < head) values[gid] = T(date_lossy_days32(int32_t(values[gid]), field));
+        const uint64_t t0 = head + n4 * 4;
+        if (gid < n - t0) values[t0 + gid] = T(date_lossy_days32(int32_t(values[t0 + gid]), field));
+    } else {
+        for (uint64_t i = blockIdx.x * uint64_t(blockDim.x) + threadIdx.x; i < n; i += uint64_t(gridDim.x) * blockDim.x) {
+            const int64_t dq = to_days(int64_t(values[i]));
+            const int32_t days = int32_t(dq);
+            values[i] = T(int64_t(date_lossy_days32(days, field)) * ticks_per_day);
         }
     }
 }
@@ -3713,6 +3773,29 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather_hits(const FixedDesc*
 // the cost is per surviving candidate row, not per row of the column); fixed-width values are decoded like the gather does
 // and compared in the 64-bit value domain (Arrow totalOrder for floats).  Survivors are appended in batch order of arrival
 // (one returning atomic per workgroup): the relative order inside a 64-record batch is kept.
+// `value contains needle`, byte-wise (what a plain '%needle%' pattern means: Arrow's `contains`, no UTF-8 stepping), on one
+// FSST-compressed value: a decoding iterator per start position, re-walked from the saved state on a mismatch.  For the few
+// rows of a hit list; the scans use the folded automaton.
+__device__ __noinline__ bool contains_bytes(const DevSymtab& st, const uint8_t* __restrict__ fsst, uint32_t start, uint32_t stop,
+                                            const uint8_t* __restrict__ nd, uint32_t nl) {
+    if (nl == 0) return true;
+    FsstIter it{start, stop, 0, 0, 0, false};
+    fsst_iter_load(it, st, fsst);
+    while (!it.at_end) {
+        if (fsst_iter_cur(it) == uint32_t(nd[0])) {
+            FsstIter t = it;
+            uint32_t j = 0;
+            while (j < nl && !t.at_end && fsst_iter_cur(t) == uint32_t(nd[j])) {
+                j++;
+                fsst_iter_next(t, st, fsst);
+            }
+            if (j == nl) return true;
+        }
+        fsst_iter_next(it, st, fsst);
+    }
+    return false;
+}
+
 struct HitsPredArgs {
     const void* descs;
     const DevSymtab* symtabs;
@@ -3725,6 +3808,7 @@ struct HitsPredArgs {
     // byte views
     int32_t op;            // LC_OP_*
     int32_t const_value;   // >= 0: Literal(Boolean)
+    int32_t substring;     // [NOT] LIKE '%needle%': `lit` is the needle, matched byte-wise; 0: `lit` is a general pattern
     const uint8_t* lit;    // literal / pattern bytes when longer than the inline buffer
     uint32_t lit_len;
     uint8_t lit_inline[kInlineNeedle];
@@ -3818,7 +3902,9 @@ __global__ __launch_bounds__(kThreads) void k_pred_hits(HitsPredArgs a) {
                         str_offset_pair(d, key, start, stop);
                         const DevSymtab& st = a.symtabs[d.symtab_slot];
                         if (a.op == LC_OP_LIKE || a.op == LC_OP_NOT_LIKE) {
-                            keep = like_generic(st, d.fsst, start, stop, lit, a.lit_len) == (a.op == LC_OP_LIKE);
+                            const bool m = a.substring ? contains_bytes(st, d.fsst, start, stop, lit, a.lit_len)
+                                                       : like_generic(st, d.fsst, start, stop, lit, a.lit_len);
+                            keep = m == (a.op == LC_OP_LIKE);
                         } else {
                             const int c = decode_compare(st, d.fsst, start, stop, lit, a.lit_len);
                             keep = a.op == LC_OP_EQ ? c == 0 : a.op == LC_OP_NE ? c != 0 : a.op == LC_OP_LT ? c < 0 :
@@ -5489,6 +5575,7 @@ hipError_t launch_pred_hits(const HitsPredLaunch& h, hipStream_t stream) {
     a.n_out = h.n_out;
     a.op = h.op;
     a.const_value = h.const_value;
+    a.substring = h.substring;
     a.lit_len = h.lit_len;
     a.lit = h.lit_len > uint32_t(kInlineNeedle) ? h.d_lit : nullptr;
     if (h.lit_len <= uint32_t(kInlineNeedle) && h.h_lit)

@@ -384,6 +384,7 @@ struct HitsPredLaunch {
     int32_t lane_log2;
     int32_t op;
     int32_t const_value;
+    int32_t substring;   // [NOT] LIKE with a plain '%needle%' pattern: the literal passed is the needle (byte-wise contains)
     uint32_t lit_len;
     const uint8_t* h_lit;
     const uint8_t* d_lit;

@@ -4169,10 +4169,20 @@ lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
     if (sp.p.mode == 2) {
         h.const_value = sp.p.const_value ? 1 : 0;
     } else {
-        // compare ops take the literal, [NOT] LIKE the pattern as written (matched by the general matcher on the few rows left)
+        // compare ops take the literal; [NOT] LIKE '%needle%' the needle (byte-wise contains, like the scan kernels' automaton);
+        // any other pattern goes to the general matcher as written
+        if (pred->lit_len > uint64_t(kMaxNeedleBytes)) return fail(LC_UNSUPPORTED, "literal over 4096 bytes");
         h.h_lit = static_cast<const uint8_t*>(pred->lit);
         h.lit_len = uint32_t(pred->lit_len);
-        if (pred->lit_len > uint64_t(kMaxNeedleBytes)) return fail(LC_UNSUPPORTED, "literal over 4096 bytes");
+        if (sp.p.mode == 1) {
+            const uint8_t* inner = nullptr;
+            size_t il = 0;
+            if (substring_pattern(static_cast<const uint8_t*>(pred->lit), size_t(pred->lit_len), &inner, &il)) {
+                h.substring = 1;  // (the whole needle, also beyond the 63 bytes the scan kernels' automaton holds)
+                h.h_lit = inner;
+                h.lit_len = uint32_t(il);
+            }
+        }
         if (h.lit_len > uint32_t(kInlineNeedle)) {
             std::lock_guard<std::mutex> g(scan->mu);
             scan_enter_stream(scan, st);
@@ -4184,7 +4194,7 @@ lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
                 if (!scan->d_needle) { scan->needle_cap = 0; return fail(LC_ERR_OOM, "hipMalloc (needle)"); }
                 scan->needle_cap = need;
             }
-            LC_HIP(hipMemcpyAsync(scan->d_needle, pred->lit, h.lit_len, hipMemcpyHostToDevice, st));
+            LC_HIP(hipMemcpyAsync(scan->d_needle, h.h_lit, h.lit_len, hipMemcpyHostToDevice, st));
             LC_HIP(hipStreamSynchronize(st));
             h.d_lit = scan->d_needle;
         }

@@ -483,3 +483,32 @@ def test_filter_hits_against_oracle(product_lib, oracle, grouped_cases, gpu_cach
                     n_fixed += 1
         scan.close()
     assert n_fixed >= 200
+
+
+def test_bench_two_rank_dry_run_on_one_gpu():
+    """bench.py's multi-rank path (launcher contract, strong-scaling split by contiguous row ranges, COUNT(*) exchange, compact
+    record) on ONE GPU: two ranks share device 0 and exchange through gloo (LC_BENCH_TEST_BACKEND) — logic, not a measurement.
+    The union of the two shards is the table a single rank stages: same COUNT(*)."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    common = ["--rows", "3000000", "--steps", "2", "--warmup", "1", "--scans-per-step", "4", "--rotate", "2", "--no-secondary",
+              "--no-cpu-baseline", "--no-cold"]
+    env = dict(os.environ, LC_BENCH_TEST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert one.returncode == 0, one.stderr[-2000:]
+    d1 = json.loads(one.stdout.strip().splitlines()[-1])
+    for exchange in ("count", "mask"):
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                              "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "2", "--exchange",
+                              exchange] + common, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert two.returncode == 0, two.stderr[-3000:]
+        line = two.stdout.strip().splitlines()[-1]
+        assert len(line) <= 4096, len(line)
+        d2 = json.loads(line)
+        assert d2["n_gpus"] == 2 and d2["scaling"] == "strong" and d2["steps"] == 2
+        assert d2["config"]["hits"] == d1["config"]["hits"] > 0
+        assert d2["config"]["rows_all_gpus"] == d1["config"]["rows_all_gpus"] == 3000000
+        assert d2["config"]["scans_per_step"] == 4 and d2["ms_per_step"] > 0 and d2["value"] > 0
+        assert "scaling_model" in d2 and d2["roofline"]["kernel"].startswith("k_like")
