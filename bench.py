@@ -380,6 +380,8 @@ def compact_line(out, detail_path):
                            ("url_like_no_signatures_ms", ("url_like_no_signatures", "kernel_ms")),
                            ("url_like_no_fingerprints_ms", ("url_like_no_fingerprints", "kernel_ms")),
                            ("clickbench_sweep_ms", ("clickbench_pushdown_sweep", "ms_all_queries")),
+                           ("like_stream_cached_ms_per_query", ("mixed_table_like_stream", "indexes_cached_between_queries", "ms_per_query_mean")),
+                           ("like_stream_rebuilt_ms_per_query", ("mixed_table_like_stream", "budget_of_3_indexes_lru_thrash", "ms_per_query_mean")),
                            ("rowgroup_rows_per_s", ("rowgroup_granularity", "rows_per_s")),
                            ("eval_predicate_call_us", ("rowgroup_granularity", "eval_predicate_call_us"))):
             node = sec
@@ -913,6 +915,60 @@ def secondary_rowgroup(cache, lc, N, args, ids, expr, whole_scan_hits, rows):
             out["eval_predicate_hits_first_%d_entries" % n_e] = int(hits.value)
         else:
             out["eval_predicate_call_error"] = rc
+    return out
+
+
+def secondary_like_stream(cache, lc, N, args, cols, expr, want_hits, torch, stream, index_bytes, live_indexes):
+    """Index residency under a mixed query stream (round 4's review: nothing exercised eviction): LIKE COUNT(*) queries round
+    robin over SIX resident string tables, a scan per query as DataFusion builds a reader per query — created, evaluated once,
+    destroyed.  What a query costs depends on where its table's scan-level index is: cached from the last query on that table
+    (adopted: records + one launch), gone (rebuilt: ~10 ms), or not allowed (budget held by live scans: the entry-level index
+    of k_like_lean serves).  Every COUNT(*) is checked."""
+    out = {"tables": len(cols), "index_bytes_per_table": int(index_bytes),
+           "query": "scan create + URL LIKE COUNT(*) (d_mask_out = NULL) + scan destroy, host wall clock, synchronised"}
+    total = torch.zeros((), dtype=torch.int64, device="cuda")
+
+    def query(c, keep=False):
+        t0 = time.perf_counter()
+        sc = cache.scan(cols[c])
+        sc.eval_count(expr, 0, total.data_ptr(), 0, 0, stream)
+        torch.cuda.synchronize()
+        got = int(total.item())
+        path = sc.explain(expr).split(":")[0].split(" ")[0]
+        if not keep:
+            sc.close()
+        dt = time.perf_counter() - t0
+        assert got == want_hits[c], "LIKE stream: table %d COUNT(*) %d != %d" % (c, got, want_hits[c])
+        return dt, path, sc
+
+    def run(label, budget_indexes, cache_n, rounds, held=()):
+        cache.set_option(N.OPT_LIKE_INDEX_CACHE, cache_n)
+        cache.set_option(N.OPT_LIKE_INDEX_BUDGET_BYTES, int((budget_indexes + live_indexes) * index_bytes * 1.02) if budget_indexes else 0)
+        live = [query(c, keep=True)[2] for c in held]
+        for c in range(len(cols)):  # one untimed round: whatever can be cached is
+            if c not in held:
+                query(c)
+        times, paths = [], {}
+        for _ in range(rounds):
+            for c in range(len(cols)):
+                if c in held:
+                    continue
+                dt, path, _ = query(c)
+                times.append(dt)
+                paths[path] = paths.get(path, 0) + 1
+        for sc in live:
+            sc.close()
+        out[label] = {"queries": len(times), "ms_per_query_mean": float(np.mean(times)) * 1e3,
+                      "ms_per_query_max": float(np.max(times)) * 1e3, "paths": paths}
+
+    try:
+        run("indexes_cached_between_queries", 0, 8, 5)                    # every query adopts its table's index
+        run("budget_of_3_indexes_lru_thrash", 3, 8, 2)                    # six tables through three slots: every query rebuilds
+        run("no_index_cache", 0, 0, 2)                                    # LC_OPT_LIKE_INDEX_CACHE = 0: rebuilt per query
+        run("budget_held_by_3_live_scans", 3, 8, 5, held=(0, 1, 2))       # the other three tables: k_like_lean (entry-level index)
+    finally:
+        cache.set_option(N.OPT_LIKE_INDEX_CACHE, 4)
+        cache.set_option(N.OPT_LIKE_INDEX_BUDGET_BYTES, 0)
     return out
 
 
@@ -1811,8 +1867,18 @@ def main():
         rot_counts.append(c_r)
     scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)  # (the mask / counts buffers hold column 0 again)
     torch.cuda.synchronize()
-    for r in range(1, n_rot):  # the other tables of the rotation have done their work: their HBM goes to the secondaries
+    for r in range(1, n_rot):  # the other tables of the rotation have done their work
         scans[r].close()
+    like_stream = None
+    if rank == 0 and world == 1 and args.workload == "url_like" and n_rot >= 7 and not args.no_secondary and not args.no_fingerprints \
+            and not args.no_signatures and "k_like_flat" in scan.explain(expr):
+        try:  # (while six of them are still resident)
+            inf0 = scan.info()
+            like_stream = secondary_like_stream(cache, lc, N, args, rot_ids[1:7], expr, rot_hits[1:7], torch, stream,
+                                                int(inf0.index_bytes), 1)
+        except Exception as e:  # noqa: BLE001
+            like_stream = {"error": "%s: %s" % (type(e).__name__, e)}
+    for r in range(1, n_rot):  # ... their HBM goes to the secondaries
         cache.evict(rot_ids[r])
     del scans[1:]
     if args.exchange == "mask" and world > 1:
@@ -2003,6 +2069,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_secondary:
         sec = {}
+        if like_stream is not None:
+            sec["mixed_table_like_stream"] = like_stream
         sec_rows = args.secondary_rows or args.rows
         groups = set(args.secondary_set.split(","))
         want = lambda g: "all" in groups or g in groups  # noqa: E731

@@ -172,6 +172,14 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
 #define LC_OPT_LIKE_PIPELINE_MIN_ENTRIES 4
 #define LC_OPT_LIKE_PATH 5
 #define LC_OPT_LIKE_MANY_HINT 6 /* A/B aid (default 1): needles the plan found unselective run k_str_pred's sequential walker */
+/* Residency of the scan-level LIKE indexes (lc_scan_info: 64 + 32 bytes per dictionary value of a scan, built on its first
+ * LIKE).  LC_OPT_LIKE_INDEX_BUDGET_BYTES (default 0 = none of its own): indexes alive in the context may not exceed this —
+ * when a scan's first LIKE would, the indexes cached for future scans are dropped first, and if live scans still hold the
+ * budget the scan evaluates with the entry-level index (k_like_lean, same results).  max_hbm_bytes (slabs + indexes) and
+ * "half of the free device memory" apply as well.  LC_OPT_LIKE_INDEX_CACHE (default 4): how many indexes of DESTROYED scans
+ * are kept for the next scan over the same publications of the same entries (oldest first out; 0: none). */
+#define LC_OPT_LIKE_INDEX_BUDGET_BYTES 7
+#define LC_OPT_LIKE_INDEX_CACHE 8
 LC_API lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value);
 LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
 LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);

@@ -503,6 +503,10 @@ class LiquidCache:
         for opt, val in builder.options.items():
             N.check(self._lib.lc_ctx_set_option(self._ctx, opt, val), self._ctx)
 
+    def set_option(self, option: int, value: int):
+        """lc_ctx_set_option: evaluation options may change at any time (N.OPT_LIKE_PATH, N.OPT_LIKE_INDEX_BUDGET_BYTES, ...)."""
+        N.check(self._lib.lc_ctx_set_option(self._ctx, int(option), int(value)), self._ctx)
+
     # -- lifecycle ---------------------------------------------------------------------------------
     def close(self):
         if getattr(self, "_ctx", None):

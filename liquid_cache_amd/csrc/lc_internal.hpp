@@ -116,6 +116,10 @@ struct lc_ctx {
     // options (lc_ctx_set_option): written under `mu`, read by evaluations and staging calls of other threads without it
     std::atomic<bool> build_signatures{true};   // LC_OPT_SIGNATURE_INDEX = 0 disables the bigram index (plain reference layout only)
     std::atomic<bool> signatures_on_host{false};  // LC_OPT_HOST_BUILT_INDEX = 1: build the index on the host (the device builder's oracle)
+    std::atomic<uint64_t> like_index_budget{0};  // LC_OPT_LIKE_INDEX_BUDGET_BYTES: scan-level LIKE index bytes allowed alive (0: no
+                                                 // bound of its own — max_hbm_bytes and free device memory still apply)
+    std::atomic<uint32_t> like_index_cache{4};   // LC_OPT_LIKE_INDEX_CACHE: indexes of destroyed scans kept for the next scan over
+                                                 // the same entries
     std::atomic<bool> like_many_hint{true};  // LC_OPT_LIKE_MANY_HINT (A/B aid): unselective planned needles take k_str_pred's sequential walker
     std::atomic<int> like_path{0};  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred, 2 auto without the scan-level index, 3 / 4 / 5 k_like_lean /
                                     // k_like_flat / k_like_scanall for every needle

@@ -1185,10 +1185,23 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
         like_orphans_clear(ctx);
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
     }
-    // the index is HBM the caller's budget must cover: max_hbm_bytes bounds slabs + indexes (the cached ones go first)
-    if (ctx->max_hbm && ctx->staged_bytes + ctx->index_bytes.load() + bytes > ctx->max_hbm) {
-        like_orphans_clear(ctx);
-        if (ctx->staged_bytes + ctx->index_bytes.load() + bytes > ctx->max_hbm) return LC_OK;  // k_like_lean serves
+    // the index is HBM the caller's budget must cover: max_hbm_bytes bounds slabs + indexes, LC_OPT_LIKE_INDEX_BUDGET_BYTES
+    // the indexes alone (the cached ones go first; what live scans hold stays: k_like_lean then serves this scan)
+    auto over_budget = [&]() {
+        const uint64_t ib = ctx->index_bytes.load(), lim = ctx->like_index_budget.load();
+        return (ctx->max_hbm && ctx->staged_bytes + ib + bytes > ctx->max_hbm) || (lim && ib + bytes > lim);
+    };
+    while (over_budget()) {  // oldest cached index first, one at a time
+        LikePipeline* victim = nullptr;
+        {
+            std::lock_guard<std::mutex> g(ctx->like_orphans_mu);
+            if (!ctx->like_orphans.empty()) {
+                victim = ctx->like_orphans.front();
+                ctx->like_orphans.erase(ctx->like_orphans.begin());
+            }
+        }
+        if (!victim) return LC_OK;  // what is left belongs to live scans: the entry-level index serves this one
+        like_pipeline_destroy(ctx, victim);
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
@@ -1462,9 +1475,9 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
 
 // A destroyed scan's pipeline that carries a scan-level index waits here for the next scan over the same publications of the
 // same entries (same uids in the same order: same blobs, same mask layout — the records hold pointers into the entries,
-// which the adopting scan pins like the scan that built them did).  At most kLikeOrphans of them and a quarter of the
+// which the adopting scan pins like the scan that built them did).  At most LC_OPT_LIKE_INDEX_CACHE of them and a quarter of the
 // device's memory; the oldest goes first.
-constexpr size_t kLikeOrphans = 4;
+// (LC_OPT_LIKE_INDEX_CACHE; default 4)
 static uint64_t pipeline_bytes(const LikePipeline* lp) {
     return lp->slices_bytes + (lp->d_uni ? lp->slice_words * 8u * 256u : 0u);
 }
@@ -1492,7 +1505,9 @@ void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp) {
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) total_b = 0;
         uint64_t held = 0;
         for (const LikePipeline* q : ctx->like_orphans) held += pipeline_bytes(q);
-        while (!ctx->like_orphans.empty() && (ctx->like_orphans.size() > kLikeOrphans || held > total_b / 4)) {
+        const uint64_t lim = ctx->like_index_budget.load();
+        while (!ctx->like_orphans.empty() && (ctx->like_orphans.size() > size_t(ctx->like_index_cache.load()) || held > total_b / 4 ||
+                                               (lim && ctx->index_bytes.load() > lim && held > 0))) {
             held -= pipeline_bytes(ctx->like_orphans.front());
             out.push_back(ctx->like_orphans.front());
             ctx->like_orphans.erase(ctx->like_orphans.begin());

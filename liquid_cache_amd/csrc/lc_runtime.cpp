@@ -883,6 +883,8 @@ lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
         case LC_OPT_ROW_LISTS: ctx->build_postings = value != 0; return LC_OK;
         case LC_OPT_HOST_BUILT_INDEX: ctx->signatures_on_host = value != 0; return LC_OK;
         case LC_OPT_LIKE_MANY_HINT: ctx->like_many_hint = value != 0; return LC_OK;
+        case LC_OPT_LIKE_INDEX_BUDGET_BYTES: ctx->like_index_budget = value < 0 ? 0 : uint64_t(value); return LC_OK;
+        case LC_OPT_LIKE_INDEX_CACHE: ctx->like_index_cache = uint32_t(std::max<int64_t>(0, std::min<int64_t>(value, 1024))); return LC_OK;
         case LC_OPT_LIKE_PATH:
             if (value < 0 || value > 5) return fail(LC_ERR_INVALID, "LC_OPT_LIKE_PATH takes 0 .. 5");
             ctx->like_path = int(value);
@@ -3414,9 +3416,10 @@ struct CallStream {
         if (p) host.push_back(p);
         return p;
     }
+    bool drained = false;  // set by a call whose LAST enqueued work has been waited for: the destructor then waits no second time
     hipError_t sync() { return hipStreamSynchronize(st); }
     ~CallStream() {
-        (void)hipStreamSynchronize(st);
+        if (!drained) (void)hipStreamSynchronize(st);
         for (void* p : dev) pool_release(ctx, p);
         for (void* p : host) host_pool_release(ctx, p);
         stream_release(ctx, st);
@@ -3571,6 +3574,7 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     }
     LC_PROF(3);
     LC_HIP(cs.sync());  // the call's one wait
+    cs.drained = true;  // (nothing is enqueued behind it)
     LC_PROF(4);
 #ifdef LC_CALL_PROFILE
     g_prof_calls++;
