@@ -927,6 +927,7 @@ def secondary_like_stream(cache, lc, N, args, cols, expr, want_hits, torch, stre
     out = {"tables": len(cols), "index_bytes_per_table": int(index_bytes),
            "query": "scan create + URL LIKE COUNT(*) (d_mask_out = NULL) + scan destroy, host wall clock, synchronised"}
     total = torch.zeros((), dtype=torch.int64, device="cuda")
+    cols = [np.ascontiguousarray(np.asarray([int(e) for e in ids_c], dtype=np.uint64)) for ids_c in cols]
 
     def query(c, keep=False):
         t0 = time.perf_counter()

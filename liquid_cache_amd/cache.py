@@ -839,7 +839,10 @@ class Scan:
     def __init__(self, cache: LiquidCache, entry_ids: Sequence[int]):
         self._cache = cache
         self._lib = cache._lib
-        ids = np.ascontiguousarray(np.asarray([int(e) for e in entry_ids], dtype=np.uint64))
+        if isinstance(entry_ids, np.ndarray) and entry_ids.dtype == np.uint64:
+            ids = np.ascontiguousarray(entry_ids)  # (a host that creates a scan per query keeps its id arrays)
+        else:
+            ids = np.ascontiguousarray(np.asarray([int(e) for e in entry_ids], dtype=np.uint64))
         h = C.c_void_p()
         N.check(self._lib.lc_scan_create(cache.handle, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint64)),
                                          C.byref(h)), cache.handle)
