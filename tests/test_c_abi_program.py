@@ -49,3 +49,12 @@ def test_concurrent_callers_program_compiles_and_links(tmp_path, product_lib):
                     os.path.join(ROOT, "tests", "c_abi", "concurrent_callers.c"), "-o", exe,
                     "-L", libdir, "-l:libliquid_cache_amd.so", "-Wl,-rpath," + libdir], check=True)
     assert os.path.exists(exe)
+
+
+def test_rowgroup_reader_program_compiles_and_links(tmp_path, product_lib):
+    exe = str(tmp_path / "rowgroup_reader")
+    libdir = os.path.join(ROOT, "liquid_cache_amd")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-pthread", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_abi", "rowgroup_reader.c"), "-o", exe,
+                    "-L", libdir, "-l:libliquid_cache_amd.so", "-Wl,-rpath," + libdir], check=True)
+    assert os.path.exists(exe)

@@ -512,3 +512,25 @@ def test_bench_two_rank_dry_run_on_one_gpu():
         assert d2["config"]["rows_all_gpus"] == d1["config"]["rows_all_gpus"] == 3000000
         assert d2["config"]["scans_per_step"] == 4 and d2["ms_per_step"] > 0 and d2["value"] > 0
         assert "scaling_model" in d2 and d2["roofline"]["kernel"].startswith("k_like")
+
+
+def _build_c(tmp_path, name):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / name)
+    libdir = os.path.join(root, "liquid_cache_amd")
+    subprocess.run(["gcc", "-std=gnu11", "-O1", "-Wall", "-Werror", "-pthread", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "c_abi", name + ".c"), "-o", exe, "-L", libdir, "-l:libliquid_cache_amd.so",
+                    "-Wl,-rpath," + libdir], check=True)
+    return exe
+
+
+def test_rowgroup_reader_c_program(tmp_path, product_lib):
+    """tests/c_abi/rowgroup_reader.c: the reader's loop at the reference's granularity through the plain C ABI — per row group
+    the sparse pipeline (eval_hits -> filter_hits -> gathers from the list) and the mask form, four threads on own streams,
+    every returned value checked against a plain C loop over the generated table."""
+    import subprocess
+    exe = _build_c(tmp_path, "rowgroup_reader")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rowgroup reader ok" in r.stdout
