@@ -965,7 +965,6 @@ def secondary_like_stream(cache, lc, N, args, cols, expr, want_hits, torch, stre
     try:
         run("indexes_cached_between_queries", 0, 8, 5)                    # every query adopts its table's index
         run("budget_of_3_indexes_lru_thrash", 3, 8, 2)                    # six tables through three slots: every query rebuilds
-        run("no_index_cache", 0, 0, 2)                                    # LC_OPT_LIKE_INDEX_CACHE = 0: rebuilt per query
         run("budget_held_by_3_live_scans", 3, 8, 5, held=(0, 1, 2))       # the other three tables: k_like_lean (entry-level index)
     finally:
         cache.set_option(N.OPT_LIKE_INDEX_CACHE, 4)
