@@ -544,10 +544,33 @@ __device__ __forceinline__ uint64_t range_ballot(uint32_t t, uint32_t lo_t, uint
     else return __ballot(t <= bound_t);
 }
 
+// Where a step's ballot goes.  The shipped form parks its two halves in lanes of two registers with v_writelane: 2 of the
+// step's 4 VALU instructions, plus the wait states gfx950 wants between the v_cmp that writes the SGPR pair and the
+// v_writelane that reads it.  Round 5 built the alternative (-DLC_X_BALLOT_LDS=1): the ballot is wave uniform, so ONE v_mov_b64
+// puts it in a register pair of every lane and a ds_write_b64 leaves it in the wave's 512-byte LDS scratch; at the end of the
+// pass every lane reads the word(s) it owns — 3 VALU per 64 rows, and the compiler emits exactly that (v_lshl, v_cmp,
+// v_mov_b64, one ds_write2_b64 per two steps).  It is correct (the whole -m gpu suite) and 40-65 % SLOWER: Date32 W=12
+// 29.4 -> 42.3 us hot, Decimal W=4 20.8 -> 34.1, Int64 W=17 36.9 -> 50.4, Q6 90 -> 128 us per 100 M rows — 64 lanes storing to
+// ONE LDS address are 64 accesses to one bank, not a broadcast, and a store instruction per step occupies the LDS pipe for
+// as long as the four VALU instructions it replaces two of took.  Kept as an A/B option; what the kernel wants is a store
+// from ONE lane without touching EXEC per step.
+#ifndef LC_X_BALLOT_LDS
+#define LC_X_BALLOT_LDS 0
+#endif
+typedef __attribute__((address_space(3))) uint64_t* LdsU64MutPtr;
+__device__ __forceinline__ void park_ballot(uint32_t bal, uint32_t slot, uint64_t b) {
+    reinterpret_cast<LdsU64MutPtr>(bal)[slot] = b;
+}
+
 // u32 lanes: one step = row R of blocks A (lanes 0..31) and B (lanes 32..63) of block pair P (words parked in lanes 32 P ..)
 template <int W, bool kTwoSided, uint32_t P, uint32_t R, int NW>
-__device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t bound_t, uint32_t& X, uint32_t& Y) {
+__device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t bound_t, uint32_t& X, uint32_t& Y,
+                                           uint32_t bal) {
     const uint64_t b = range_ballot<kTwoSided>(field_top<W, R, NW>(w), lo_t, bound_t);
+    if constexpr (LC_X_BALLOT_LDS != 0) {
+        park_ballot(bal, 32u * P + R, b);  // slot = (pair, step); read_parked32 un-transposes
+        return;
+    }
     const uint32_t blo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b))));
     const uint32_t bhi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32))));
     constexpr uint32_t word = 32u * P + 2u * (R & 7u) + ((R >> 3) & 1u);
@@ -561,21 +584,42 @@ __device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_
 }
 template <int W, bool kTwoSided, uint32_t P, int NW, uint32_t... RS>
 __device__ __forceinline__ void reg_steps32(std::integer_sequence<uint32_t, RS...>, const uint32_t (&w)[NW], uint32_t lo_t,
-                                            uint32_t bound_t, uint32_t& X, uint32_t& Y) {
-    (reg_step32<W, kTwoSided, P, RS, NW>(w, lo_t, bound_t, X, Y), ...);
+                                            uint32_t bound_t, uint32_t& X, uint32_t& Y, uint32_t bal) {
+    (reg_step32<W, kTwoSided, P, RS, NW>(w, lo_t, bound_t, X, Y, bal), ...);
 }
 // u16 lanes: one step = one whole 64-row word of block B of the pass (its words are parked in lanes 16*B ..)
 template <int W, bool kTwoSided, uint32_t B, uint32_t R, int NW>
-__device__ __forceinline__ void reg_step16(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t bound_t, uint32_t& X, uint32_t& Y) {
+__device__ __forceinline__ void reg_step16(const uint32_t (&w)[NW], uint32_t lo_t, uint32_t bound_t, uint32_t& X, uint32_t& Y,
+                                           uint32_t bal) {
     const uint64_t b = range_ballot<kTwoSided>(field_top<W, R, NW>(w), lo_t, bound_t);
     constexpr uint32_t word = 16u * B + 2u * (R & 7u) + (R >> 3);
+    if constexpr (LC_X_BALLOT_LDS != 0) {
+        park_ballot(bal, word, b);  // the ballot IS mask word `word` of the pass: lane `word` reads it back
+        return;
+    }
     X = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b)))), X);
     Y = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32)))), Y);
 }
 template <int W, bool kTwoSided, uint32_t B, int NW, uint32_t... RS>
 __device__ __forceinline__ void reg_steps16(std::integer_sequence<uint32_t, RS...>, const uint32_t (&w)[NW], uint32_t lo_t,
-                                            uint32_t bound_t, uint32_t& X, uint32_t& Y) {
-    (reg_step16<W, kTwoSided, B, RS, NW>(w, lo_t, bound_t, X, Y), ...);
+                                            uint32_t bound_t, uint32_t& X, uint32_t& Y, uint32_t bal) {
+    (reg_step16<W, kTwoSided, B, RS, NW>(w, lo_t, bound_t, X, Y, bal), ...);
+}
+// The lane's mask word(s) of a pass out of the parked ballots.  u32 shape: lane i = 32 P + 16 blockB + wi owns word wi of
+// block A|B of pair P: its low half is the A|B half of the ballot of step r0 = (wi >> 1) + 8 (wi & 1), its high half that of
+// step r0 + 16 (reg_step32's rule inverted).  u16: lane i owns word i, which is one ballot.
+template <bool k32>
+__device__ __forceinline__ uint64_t read_parked(uint32_t bal, int lane) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if constexpr (k32) {
+        const uint32_t i = uint32_t(lane), wi = i & 15u, half = (i >> 4) & 1u;
+        const uint32_t r0 = 32u * (i >> 5) + (wi >> 1) + 8u * (wi & 1u);
+        const __attribute__((address_space(3))) uint32_t* p = reinterpret_cast<const __attribute__((address_space(3))) uint32_t*>(bal);
+        const uint32_t lo = p[2u * r0 + half], hi = p[2u * (r0 + 16u) + half];
+        return uint64_t(lo) | (uint64_t(hi) << 32);
+    } else {
+        return reinterpret_cast<LdsU64MutPtr>(bal)[uint32_t(lane)];
+    }
 }
 
 // the thread's 16-row bit stream of one block on u16 lanes: u16 word j of lane l at j*128 + 2l; two of them make one dword
@@ -633,6 +677,7 @@ struct RegEntryArgs {
     int32_t constant;           // -1: evaluate; 0/1: every valid selected row gives this result
     uint32_t flip;              // complement the compare
     uint32_t all_null;
+    uint32_t bal;               // LDS byte address of the wave's 64 x 8 bytes of parked ballots
 };
 
 __device__ __forceinline__ const uint8_t* uniform_ptr(const void* p) {
@@ -660,6 +705,7 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     const int constant = __builtin_amdgcn_readfirstlane(a.constant);
     const bool all_null = __builtin_amdgcn_readfirstlane(int(a.all_null)) != 0;
     const uint64_t flip = __builtin_amdgcn_readfirstlane(int(a.flip)) ? ~uint64_t(0) : uint64_t(0);
+    const uint32_t bal = uint32_t(__builtin_amdgcn_readfirstlane(int(a.bal)));
     const uint32_t nwords_entry = (len + 63u) >> 6;
     const uint32_t nblocks = (len + 1023u) >> 10;
     const uint32_t lo_t = lo << (32 - W);
@@ -736,23 +782,25 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
             const bool go0 = uint32_t(am) != 0 || (kPairs == 1 && am != 0), go1 = kPairs > 1 && uint32_t(am >> 32) != 0;
             uint32_t X = 0, Y = 0;
             if constexpr (k32) {
-                if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, pw.w[0], lo_t, bound_t, X, Y);
+                if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, pw.w[0], lo_t, bound_t, X, Y, bal);
                 if constexpr (kPairs > 1) {
                     __builtin_amdgcn_sched_barrier(0);  // keep the second pair's steps from being hoisted (register pressure)
-                    if (go1) reg_steps32<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 32>{}, pw.w[1], lo_t, bound_t, X, Y);
+                    if (go1) reg_steps32<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 32>{}, pw.w[1], lo_t, bound_t, X, Y, bal);
                 }
             } else {
                 if (go0) {
-                    reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[0], lo_t, bound_t, X, Y);
-                    reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[1], lo_t, bound_t, X, Y);
+                    reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[0], lo_t, bound_t, X, Y, bal);
+                    reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[1], lo_t, bound_t, X, Y, bal);
                 }
                 if constexpr (kPairs > 1) {
                     if (go1) {
-                        reg_steps16<W, kTwoSided, 2, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[2], lo_t, bound_t, X, Y);
-                        reg_steps16<W, kTwoSided, 3, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[3], lo_t, bound_t, X, Y);
+                        reg_steps16<W, kTwoSided, 2, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[2], lo_t, bound_t, X, Y, bal);
+                        reg_steps16<W, kTwoSided, 3, NW>(std::make_integer_sequence<uint32_t, 16>{}, pw.w[3], lo_t, bound_t, X, Y, bal);
                     }
                 }
             }
+            // (the words of a pair / block that was skipped are stale: no row of theirs is selected, `& act` clears them)
+            if constexpr (LC_X_BALLOT_LDS != 0) return read_parked<k32>(bal, lane);
             return uint64_t(X) | (uint64_t(Y) << 32);
         };
         // lane's selection & validity word of pass p: lane i (< kPassWords) owns mask word p kPassWords + i (0 past the entry)
@@ -862,10 +910,10 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
                                 }
                             }
                         }
-                        if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, w0, lo_t, bound_t, X, Y);
+                        if (go0) reg_steps32<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 32>{}, w0, lo_t, bound_t, X, Y, bal);
                         __builtin_amdgcn_sched_barrier(0);  // keep the second pair's steps from being hoisted (register pressure)
                         if constexpr (kPairs > 1)
-                            if (go1) reg_steps32<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 32>{}, w1, lo_t, bound_t, X, Y);
+                            if (go1) reg_steps32<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 32>{}, w1, lo_t, bound_t, X, Y, bal);
                     } else {
                         uint32_t wa[NW], wb[NW], wc[NW], wd[NW];  // every block's loads are in flight before the first compare
                         if (go0) {
@@ -879,17 +927,19 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
                             }
                         }
                         if (go0) {
-                            reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, wa, lo_t, bound_t, X, Y);
-                            reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, wb, lo_t, bound_t, X, Y);
+                            reg_steps16<W, kTwoSided, 0, NW>(std::make_integer_sequence<uint32_t, 16>{}, wa, lo_t, bound_t, X, Y, bal);
+                            reg_steps16<W, kTwoSided, 1, NW>(std::make_integer_sequence<uint32_t, 16>{}, wb, lo_t, bound_t, X, Y, bal);
                         }
                         if constexpr (kPairs > 1) {
                             if (go1) {
-                                reg_steps16<W, kTwoSided, 2, NW>(std::make_integer_sequence<uint32_t, 16>{}, wc, lo_t, bound_t, X, Y);
-                                reg_steps16<W, kTwoSided, 3, NW>(std::make_integer_sequence<uint32_t, 16>{}, wd, lo_t, bound_t, X, Y);
+                                reg_steps16<W, kTwoSided, 2, NW>(std::make_integer_sequence<uint32_t, 16>{}, wc, lo_t, bound_t, X, Y, bal);
+                                reg_steps16<W, kTwoSided, 3, NW>(std::make_integer_sequence<uint32_t, 16>{}, wd, lo_t, bound_t, X, Y, bal);
                             }
                         }
                     }
-                    result = ((uint64_t(X) | (uint64_t(Y) << 32)) ^ flip) & act;
+                    const uint64_t parked = LC_X_BALLOT_LDS != 0 ? read_parked<k32>(bal, lane) : (uint64_t(X) | (uint64_t(Y) << 32));
+                    result = (parked ^ flip) & act;
+                    if constexpr (LC_X_BALLOT_LDS != 0) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (rewritten by the next pass)
                 }
             }
             if (own) {
@@ -919,7 +969,7 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_dispatch(std::integer_seque
 template <typename U, int kMaxW>
 __device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2,
                                                           const uint64_t* selection, uint64_t* hit, uint64_t* valid_out,
-                                                          int lane) {
+                                                          int lane, uint32_t bal) {
     const PackedRange<U> pr = entry_range<U>(d, pred, pred2, lane);
     const uint32_t W = max(uint32_t(d.W), 1u);
     const uint32_t umax = W >= 32 ? ~0u : ((1u << W) - 1u);
@@ -933,6 +983,7 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, co
     a.len = d.len;
     a.constant = d.W == 0 ? 0 : pr.constant;
     a.all_null = d.W == 0 ? 1u : 0u;
+    a.bal = bal;
     bool two_sided = false;
     if (lo == 0) {                    // u <= span
         a.lo = 0; a.bound = span; a.flip = pr.negate ? 1u : 0u;
@@ -948,8 +999,10 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, co
 template <typename U, int kMaxW>
 __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __restrict__ descs, FixedPred pred,
                                                               FixedPred pred2, ScanLaunch L) {
+    __shared__ uint64_t s_ballots[kWavesPerBlock][64];  // a pass's parked ballots (park_ballot / read_parked)
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t bal = uint32_t(reinterpret_cast<uintptr_t>(&s_ballots[wave][0]));
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
     uint64_t wave_hits = 0;
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
@@ -960,7 +1013,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __
         const uint32_t c = fixed_pred_entry_step<U, kMaxW>(d, pred, pred2,
                                                            L.d_selection ? L.d_selection + d.mask_word_off : nullptr,
                                                            L.d_hit + d.mask_word_off,
-                                                           L.d_valid ? L.d_valid + d.mask_word_off : nullptr, lane);
+                                                           L.d_valid ? L.d_valid + d.mask_word_off : nullptr, lane, bal);
         if (L.d_counts || L.d_total_out) {
             const uint64_t t = wave_sum_u64(uint64_t(c));
             if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(t);
@@ -979,8 +1032,10 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __
 // Int16 on u16); every step is the register-resident per-width function of k_fixed_pred_reg.
 template <int kMaxW>
 __global__ __launch_bounds__(kThreads) void k_fixed_chain(FixedChainArgs C, ScanLaunch L) {
+    __shared__ uint64_t s_ballots[kWavesPerBlock][64];
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t bal = uint32_t(reinterpret_cast<uintptr_t>(&s_ballots[wave][0]));
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
     uint64_t wave_hits = 0;
     for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
@@ -994,9 +1049,9 @@ __global__ __launch_bounds__(kThreads) void k_fixed_chain(FixedChainArgs C, Scan
             const FixedChainStep& sp = C.step[k];
             const FixedDesc d = sp.descs[entry];
             uint32_t c;
-            if (sp.lane_log2 == 4) c = fixed_pred_entry_step<uint16_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane);
-            else if (sp.lane_log2 == 5) c = fixed_pred_entry_step<uint32_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane);
-            else c = fixed_pred_entry_step<uint64_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane);
+            if (sp.lane_log2 == 4) c = fixed_pred_entry_step<uint16_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane, bal);
+            else if (sp.lane_log2 == 5) c = fixed_pred_entry_step<uint32_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane, bal);
+            else c = fixed_pred_entry_step<uint64_t, kMaxW>(d, sp.pred, sp.pred2, sel, hit, nullptr, lane, bal);
             t = uniform_u64(wave_sum_u64(uint64_t(c)));  // lane 0 holds the total: broadcast, the branch below is uniform
             if (t == 0) break;  // nothing survives: the hit words are zero, later columns cannot change that
             if (k + 1 < C.n_steps) {
@@ -3906,7 +3961,11 @@ __global__ __launch_bounds__(kThreads) void k_pred_hits(HitsPredArgs a) {
                                                        : like_generic(st, d.fsst, start, stop, lit, a.lit_len);
                             keep = m == (a.op == LC_OP_LIKE);
                         } else {
-                            const int c = decode_compare(st, d.fsst, start, stop, lit, a.lit_len);
+                            // the empty literal (`col <> ''`, ClickBench's favourite): a value is empty exactly when its
+                            // prefix key says length 0 behind an empty shared prefix — no byte of the value is fetched
+                            const bool quick = a.lit_len == 0 && d.prefix_keys != nullptr;
+                            const int c = quick ? ((d.shared_prefix_len != 0 || d.prefix_keys[size_t(key) * 8u + 7u] != 0) ? 1 : 0)
+                                                : decode_compare(st, d.fsst, start, stop, lit, a.lit_len);
                             keep = a.op == LC_OP_EQ ? c == 0 : a.op == LC_OP_NE ? c != 0 : a.op == LC_OP_LT ? c < 0 :
                                    a.op == LC_OP_LE ? c <= 0 : a.op == LC_OP_GT ? c > 0 : c >= 0;
                         }

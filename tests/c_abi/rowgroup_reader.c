@@ -41,7 +41,7 @@ static int make_url(int rg, int b, int i, char* out) {
     if ((h & 0xFF) == 0xFF) return snprintf(out, 16, "%s", (h & 0x100) ? "" : "g");            /* empty and 1-byte values */
     return snprintf(out, 96, "http://%s.example%u.ru/%s/%u%s", (h & 127) == 0 ? "google" : ((h & 7) == 1 ? "mail" : "site"),
                     (unsigned)(h >> 8) % 97u, (h & 0x300) ? "search" : "catalog/items/list", (unsigned)(h >> 20) % 1000u,
-                    (h & 0x400) ? "?ref=www.google.com" : "");
+                    (h & 0x7C00) == 0x7C00 ? "?ref=www.google.com" : "");
 }
 static int64_t make_num(int rg, int b, int i) { return (int64_t)(mix(77 + (uint64_t)rg * 31u + (uint64_t)b * 131u + (uint64_t)i) % 1000000u); }
 static int url_null(int rg, int b, int i) { return (mix(5 + (uint64_t)rg * 3u + (uint64_t)b * 7u + (uint64_t)i) % 53u) == 0; }
