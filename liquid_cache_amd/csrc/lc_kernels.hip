@@ -552,14 +552,26 @@ __device__ __forceinline__ uint64_t range_ballot(uint32_t t, uint32_t lo_t, uint
 // v_mov_b64, one ds_write2_b64 per two steps).  It is correct (the whole -m gpu suite) and 40-65 % SLOWER: Date32 W=12
 // 29.4 -> 42.3 us hot, Decimal W=4 20.8 -> 34.1, Int64 W=17 36.9 -> 50.4, Q6 90 -> 128 us per 100 M rows — 64 lanes storing to
 // ONE LDS address are 64 accesses to one bank, not a broadcast, and a store instruction per step occupies the LDS pipe for
-// as long as the four VALU instructions it replaces two of took.  Kept as an A/B option; what the kernel wants is a store
-// from ONE lane without touching EXEC per step.
+// as long as the four VALU instructions it replaces two of took?  No: -DLC_X_BALLOT_LDS=2 issues the store from ONE lane (EXEC = 1
+// around the move and the write, one asm block per step) and is as slow (Date32 W=12 44 us hot).  What the LDS forms lose
+// is the overlap: a step of the shipped form is pure VALU + SALU and the next pass's global loads stay in flight across it; an
+// LDS instruction per step (and the read-back at the pass end) puts 33 more waits on the wave's one in-order issue slot.
+// Both kept as A/B options with their numbers (profiles/r5/ablation_ballot_lds.txt).
 #ifndef LC_X_BALLOT_LDS
 #define LC_X_BALLOT_LDS 0
 #endif
 typedef __attribute__((address_space(3))) uint64_t* LdsU64MutPtr;
-__device__ __forceinline__ void park_ballot(uint32_t bal, uint32_t slot, uint64_t b) {
-    reinterpret_cast<LdsU64MutPtr>(bal)[slot] = b;
+template <uint32_t kSlot>
+__device__ __forceinline__ void park_ballot(uint32_t bal, uint64_t b) {
+#if LC_X_BALLOT_LDS == 2
+    // the store from ONE lane: EXEC = 1 around the move and the LDS write (the kernels' control flow is wave uniform, every
+    // lane is active here).  The s_nop + s_mov are the two wait states between the v_cmp that wrote `b` and its VALU reader.
+    uint64_t tmp;
+    asm volatile("s_nop 0\n\ts_mov_b64 exec, 1\n\tv_mov_b64 %0, %2\n\tds_write_b64 %1, %0 offset:%3\n\ts_mov_b64 exec, -1"
+                 : "=&v"(tmp) : "v"(bal), "s"(b), "n"(kSlot * 8u) : "memory");
+#else
+    reinterpret_cast<LdsU64MutPtr>(bal)[kSlot] = b;
+#endif
 }
 
 // u32 lanes: one step = row R of blocks A (lanes 0..31) and B (lanes 32..63) of block pair P (words parked in lanes 32 P ..)
@@ -568,7 +580,7 @@ __device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_
                                            uint32_t bal) {
     const uint64_t b = range_ballot<kTwoSided>(field_top<W, R, NW>(w), lo_t, bound_t);
     if constexpr (LC_X_BALLOT_LDS != 0) {
-        park_ballot(bal, 32u * P + R, b);  // slot = (pair, step); read_parked32 un-transposes
+        park_ballot<32u * P + R>(bal, b);  // slot = (pair, step); read_parked32 un-transposes
         return;
     }
     const uint32_t blo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b))));
@@ -594,7 +606,7 @@ __device__ __forceinline__ void reg_step16(const uint32_t (&w)[NW], uint32_t lo_
     const uint64_t b = range_ballot<kTwoSided>(field_top<W, R, NW>(w), lo_t, bound_t);
     constexpr uint32_t word = 16u * B + 2u * (R & 7u) + (R >> 3);
     if constexpr (LC_X_BALLOT_LDS != 0) {
-        park_ballot(bal, word, b);  // the ballot IS mask word `word` of the pass: lane `word` reads it back
+        park_ballot<word>(bal, b);  // the ballot IS mask word `word` of the pass: lane `word` reads it back
         return;
     }
     X = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b)))), X);
