@@ -553,10 +553,10 @@ __device__ __forceinline__ uint64_t range_ballot(uint32_t t, uint32_t lo_t, uint
 // 29.4 -> 42.3 us hot, Decimal W=4 20.8 -> 34.1, Int64 W=17 36.9 -> 50.4, Q6 90 -> 128 us per 100 M rows — 64 lanes storing to
 // ONE LDS address are 64 accesses to one bank, not a broadcast, and a store instruction per step occupies the LDS pipe for
 // as long as the four VALU instructions it replaces two of took?  No: -DLC_X_BALLOT_LDS=2 issues the store from ONE lane (EXEC = 1
-// around the move and the write, one asm block per step) and is as slow (Date32 W=12 44 us hot).  What the LDS forms lose
-// is the overlap: a step of the shipped form is pure VALU + SALU and the next pass's global loads stay in flight across it; an
-// LDS instruction per step (and the read-back at the pass end) puts 33 more waits on the wave's one in-order issue slot.
-// Both kept as A/B options with their numbers (profiles/r5/ablation_ballot_lds.txt).
+// around the move and the write, one asm block per step) and is exactly as slow (Date32 W=12 42.3 us hot in both), so the
+// store's width is not it either.  The ISA keeps the software pipeline (vmcnt(12) waits, the next pass's loads in flight) and
+// adds only the ds_read2 + lgkmcnt(0) at the pass end; why the two LDS forms land on the same time was not established in
+// the round.  Both kept as A/B options with their numbers (profiles/r5/ablation_ballot_lds.txt).
 #ifndef LC_X_BALLOT_LDS
 #define LC_X_BALLOT_LDS 0
 #endif
