@@ -2435,15 +2435,15 @@ lc_status lc_scan_info_get(lc_scan* s, lc_scan_info* out) {
     out->is_byte_view = s->is_str ? 1 : 0;
     out->max_bit_width = s->is_str ? 16 : int32_t(s->max_w);
     for (const Entry& e : s->meta) out->entry_bytes += e.device_bytes;
+    {  // (never nested inside the scan's lock: one order of locks everywhere)
+        std::shared_lock<std::shared_mutex> gc(s->ctx->mu);
+        out->ctx_slab_bytes = s->ctx->staged_bytes;
+    }
+    out->ctx_index_bytes = s->ctx->index_bytes.load();
     std::lock_guard<std::mutex> g(s->mu);
     uint32_t plans = 0;
     like_pipeline_info(s, &out->index_bytes, &out->unigram_index_bytes, &out->index_build_ms, &plans);
     out->like_plans = plans;
-    out->ctx_index_bytes = s->ctx->index_bytes.load();
-    {
-        std::shared_lock<std::shared_mutex> gc(s->ctx->mu);
-        out->ctx_slab_bytes = s->ctx->staged_bytes;
-    }
     return LC_OK;
     });
 }
