@@ -39,6 +39,16 @@ constexpr uint32_t kSaPasses = kSaChunkWords / kWave;    // 8
 #ifndef LC_SA_ILP
 #define LC_SA_ILP 4
 #endif
+// 1: words with and without a value end are walked separately (round 5, see the kernel: every word without the per-byte end
+// logic — 2 VALU per byte —, the 18 % that hold a value end again in dense passes); 0 (shipped): every word with the full
+// per-byte logic.  Measured on the 100 M-row URL column through LC_OPT_LIKE_PATH = 5, all ten needle classes bit-identical
+// to the oracle in both forms: 592 / 586 us hot / cold with the split against 610 / 582 without — the walk's VALU work fell
+// by ~40 % and the time did not move, so round 4's reading ("bound by instructions per byte") was wrong: what bounds the
+// kernel is the dependent ds_read_u16 per compressed byte (80 wave-wide lookups per 4 KB chunk into rows that sit in a few
+// banks).  Kept as an A/B option.
+#ifndef LC_SA_SPLIT
+#define LC_SA_SPLIT 0
+#endif
 // variant builds only (results WRONG): 1 = no table lookups, 2 = no corrections / attribution, 4 = no placement
 #ifndef LC_SA_ABL
 #define LC_SA_ABL 0
@@ -192,6 +202,120 @@ __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
             load_pair(v_next + uint32_t(lane), pf_start[0], pf_stop[0]);
             load_pair(v_next + uint32_t(kWave) + uint32_t(lane), pf_start[1], pf_stop[1]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#if LC_SA_SPLIT
+            // ---- round 5: the words of a chunk in TWO classes.  A value ends inside 18 % of the words (a URL is ~44 compressed
+            // bytes); the per-byte work those words need — end test, match record, reset: ~9 VALU per byte — was paid by every
+            // word, because every pass of 64 words holds some of them.  Now every word is walked WITHOUT looking at value ends
+            // (extract, add, lookup: 2 VALU per byte — right for the 82 % that hold none), and the words with an end are listed
+            // and walked again in dense passes with the full per-byte logic, their bytes fetched by index (L1 / L2: the chunk was
+            // just streamed).  The carries and the worklist below read the end states back from LDS.
+            uint32_t n_b = 0;
+            uint16_t* list_bw = list_b;  // (free until the corrections; they start after the dense passes)
+#pragma unroll
+            for (uint32_t q = 0; q < kSaPasses; q++) {
+                const uint32_t wi = q * kWave + uint32_t(lane);
+                const bool has = ends[wi] != 0;
+                const uint64_t bm = __ballot(has);
+                if (has) list_bw[n_b + lanes_below(bm)] = uint16_t(wi);
+                n_b += uint32_t(__popcll(bm));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // the first two dense passes' words are requested before the cheap walk starts
+            uint32_t bwi[2];
+            uint64_t bww[2];
+#pragma unroll
+            for (uint32_t u = 0; u < 2; u++) {
+                const uint32_t j = u * kWave + uint32_t(lane);
+                bwi[u] = j < n_b ? uint32_t(list_bw[j]) : 0u;
+                bww[u] = *reinterpret_cast<GlobalPtr<uint64_t>>(reinterpret_cast<uintptr_t>(fsst + min(c0 + 8u * bwi[u], last_word)));
+            }
+            // phase 1: every word from the start state, value ends ignored, kSaIlp passes in lock step
+#pragma unroll
+            for (uint32_t q0 = 0; q0 < kSaPasses; q0 += kSaIlp) {
+                uint32_t st[kSaIlp];
+#pragma unroll
+                for (uint32_t u = 0; u < kSaIlp; u++) st[u] = row0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+#pragma unroll
+                    for (uint32_t u = 0; u < kSaIlp; u++) {
+                        const uint64_t ww = w[q0 + u];
+                        const uint32_t code = (k < 4 ? uint32_t(ww) >> (8 * k) : uint32_t(ww >> 32) >> (8 * (k - 4))) & 0xFFu;
+                        st[u] = lds_u16(st[u] + 2u * code);
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < kSaIlp; u++) {
+                    const uint32_t wi = (q0 + u) * kWave + uint32_t(lane);
+                    out16[wi] = uint16_t(st[u]);
+                    hit8[wi] = 0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // phase 2: the words with a value end, densely, two passes in lock step
+            for (uint32_t b0 = 0; b0 < n_b; b0 += 2u * kWave) {
+                uint32_t st[2], hit[2], e8[2], wi2[2];
+                uint64_t ww2[2];
+                bool act[2];
+#pragma unroll
+                for (uint32_t u = 0; u < 2; u++) {
+                    const uint32_t j = b0 + u * kWave + uint32_t(lane);
+                    act[u] = j < n_b;
+                    wi2[u] = b0 == 0 ? bwi[u] : (act[u] ? uint32_t(list_bw[j]) : 0u);
+                    ww2[u] = b0 == 0 ? bww[u]
+                                     : *reinterpret_cast<GlobalPtr<uint64_t>>(reinterpret_cast<uintptr_t>(fsst + min(c0 + 8u * wi2[u], last_word)));
+                    e8[u] = act[u] ? uint32_t(ends[wi2[u]]) : 0u;
+                    st[u] = row0;
+                    hit[u] = 0;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 2; u++) {
+                        const uint64_t ww = ww2[u];
+                        const uint32_t code = (k < 4 ? uint32_t(ww) >> (8 * k) : uint32_t(ww >> 32) >> (8 * (k - 4))) & 0xFFu;
+                        const uint32_t t = lds_u16(st[u] + 2u * code);
+                        const bool is_end = ((e8[u] >> k) & 1u) != 0;
+                        hit[u] |= (is_end && t == hitrow) ? (1u << k) : 0u;
+                        st[u] = is_end ? row0 : t;
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 2; u++) {
+                    if (act[u]) {
+                        out16[wi2[u]] = uint16_t(st[u]);
+                        hit8[wi2[u]] = uint8_t(hit[u]);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // phase 3: the carries of the matched state and the worklist, pass by pass in buffer order
+            uint32_t n_list = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < kSaPasses; q++) {
+                const uint32_t wi = q * kWave + uint32_t(lane);
+                uint32_t stq = uint32_t(out16[wi]), hitq = uint32_t(hit8[wi]);
+                const uint32_t e8q = uint32_t(ends[wi]);
+                const bool has_end = e8q != 0;
+                const uint64_t M = __ballot(stq == hitrow), P = __ballot(!has_end);
+                const uint64_t A = M | P;
+                const unsigned __int128 sum = (unsigned __int128)A + M + (carry == hitrow ? 1u : 0u);
+                const uint64_t im = uint64_t(sum) ^ A ^ M;  // bit l: carry INTO word l = "starts matched"
+                if ((im >> lane) & 1u) {
+                    if (has_end) hitq |= 1u << (uint32_t(__ffs(int(e8q))) - 1u);
+                    else stq = hitrow;
+                }
+                const uint32_t prev = lane_shift_up1(stq, carry);  // end state of the word before
+                carry = read_lane(stq, kWave - 1);
+                const bool need = prev != row0 && prev != hitrow;
+                out16[wi] = uint16_t(stq);
+                in16[wi] = uint16_t(prev);
+                hit8[wi] = uint8_t(hitq);
+                const uint64_t m = __ballot(need);
+                if (need) list_a[n_list + lanes_below(m)] = uint16_t(wi);
+                n_list += uint32_t(__popcll(m));
+            }
+#else
             // ---- speculative walk: every word from the start state, kSaIlp passes in lock step
             uint32_t n_list = 0;
 #pragma unroll
@@ -244,6 +368,7 @@ __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
                     n_list += uint32_t(__popcll(m));
                 }
             }
+#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // ---- corrections: words whose true start state is not the start state, in dense batches, to a fixpoint
             uint16_t* cur = list_a;
