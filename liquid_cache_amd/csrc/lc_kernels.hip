@@ -527,6 +527,9 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
 template <int W, uint32_t R, int NW>
 __device__ __forceinline__ uint32_t field_top(const uint32_t (&w)[NW]) {
     constexpr uint32_t pos = R * uint32_t(W), k = pos >> 5, off = pos & 31u;
+#ifdef LC_X_NOSHIFT  // timing aid (wrong results): the compare without the field extraction — what a SWAR compare could save at most
+    return w[k] + R;
+#endif
     if constexpr (off + uint32_t(W) <= 32u) {
         constexpr uint32_t sh = 32u - off - uint32_t(W);
         if constexpr (sh == 0) return w[k];
@@ -583,6 +586,10 @@ __device__ __forceinline__ void reg_step32(const uint32_t (&w)[NW], uint32_t lo_
         park_ballot<32u * P + R>(bal, b);  // slot = (pair, step); read_parked32 un-transposes
         return;
     }
+#ifdef LC_X_NOPARK  // timing aid (wrong results): the ballots folded on the scalar unit, no lane writes
+    X ^= uint32_t(b); Y ^= uint32_t(b >> 32);
+    return;
+#endif
     const uint32_t blo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b))));
     const uint32_t bhi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32))));
     constexpr uint32_t word = 32u * P + 2u * (R & 7u) + ((R >> 3) & 1u);
@@ -609,6 +616,10 @@ __device__ __forceinline__ void reg_step16(const uint32_t (&w)[NW], uint32_t lo_
         park_ballot<word>(bal, b);  // the ballot IS mask word `word` of the pass: lane `word` reads it back
         return;
     }
+#ifdef LC_X_NOPARK
+    X ^= uint32_t(b); Y ^= uint32_t(b >> 32);
+    return;
+#endif
     X = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b)))), X);
     Y = writelane_c<word>(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(b >> 32)))), Y);
 }
@@ -687,10 +698,13 @@ struct RegEntryArgs {
     uint32_t len;
     uint32_t lo, bound;         // two sided: (u - lo) <= bound; one sided: u <= bound   (values fit 32 bits: W <= 32)
     int32_t constant;           // -1: evaluate; 0/1: every valid selected row gives this result
-    uint32_t flip;              // complement the compare
-    uint32_t all_null;
+    uint32_t flags;             // bit 0: complement the compare; bit 1: all-null entry
     uint32_t bal;               // LDS byte address of the wave's 64 x 8 bytes of parked ballots
 };
+// 16 dwords: what the calling convention passes in registers.  One more field and every call site of the per-width functions
+// gets its own by-value copy on the stack — 2.3-4.6 KB of scratch per lane, which caps the waves in flight: the narrow-integer
+// kernels ran 1.4x slower for it (Date32 W = 12 29.4 -> 40.9 us hot) while the instruction stream had not changed at all.
+static_assert(sizeof(RegEntryArgs) == 64, "RegEntryArgs must stay register-passed");
 
 __device__ __forceinline__ const uint8_t* uniform_ptr(const void* p) {
     return reinterpret_cast<const uint8_t*>(uintptr_t(uniform_u64(uint64_t(reinterpret_cast<uintptr_t>(p)))));
@@ -715,8 +729,9 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(a.lo)));
     const uint32_t bound = uint32_t(__builtin_amdgcn_readfirstlane(int(a.bound)));
     const int constant = __builtin_amdgcn_readfirstlane(a.constant);
-    const bool all_null = __builtin_amdgcn_readfirstlane(int(a.all_null)) != 0;
-    const uint64_t flip = __builtin_amdgcn_readfirstlane(int(a.flip)) ? ~uint64_t(0) : uint64_t(0);
+    const uint32_t flags = uint32_t(__builtin_amdgcn_readfirstlane(int(a.flags)));
+    const bool all_null = (flags & 2u) != 0;
+    const uint64_t flip = (flags & 1u) ? ~uint64_t(0) : uint64_t(0);
     const uint32_t bal = uint32_t(__builtin_amdgcn_readfirstlane(int(a.bal)));
     const uint32_t nwords_entry = (len + 63u) >> 6;
     const uint32_t nblocks = (len + 1023u) >> 10;
@@ -994,17 +1009,18 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, co
     a.valid_out = valid_out;
     a.len = d.len;
     a.constant = d.W == 0 ? 0 : pr.constant;
-    a.all_null = d.W == 0 ? 1u : 0u;
     a.bal = bal;
     bool two_sided = false;
+    uint32_t flip;
     if (lo == 0) {                    // u <= span
-        a.lo = 0; a.bound = span; a.flip = pr.negate ? 1u : 0u;
+        a.lo = 0; a.bound = span; flip = pr.negate ? 1u : 0u;
     } else if (lo + span == umax) {   // u >= lo  ==  not (u <= lo - 1)
-        a.lo = 0; a.bound = lo - 1u; a.flip = pr.negate ? 0u : 1u;
+        a.lo = 0; a.bound = lo - 1u; flip = pr.negate ? 0u : 1u;
     } else {
         two_sided = true;
-        a.lo = lo; a.bound = span; a.flip = pr.negate ? 1u : 0u;
+        a.lo = lo; a.bound = span; flip = pr.negate ? 1u : 0u;
     }
+    a.flags = flip | (d.W == 0 ? 2u : 0u);
     return fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, W, two_sided, a);
 }
 

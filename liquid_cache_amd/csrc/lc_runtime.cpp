@@ -3549,7 +3549,12 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     }
     // device scratch in two blocks, so that the results leave in ONE copy: [hit | valid] and (under a selection)
     // [selection | compacted hit | compacted valid | bit counts] — the host block [hit | valid | bits] mirrors the tail
-    uint64_t* d_hv = static_cast<uint64_t*>(cs.dalloc(words * 8 * 2));
+    // No selection and a small result: the predicate kernel stores its [hit | valid] words straight into the pinned block
+    // (plain stores over the fabric; the stream wait below is the release) — no device scratch, no copy-engine hop.  Only
+    // where every kernel of the evaluation WRITES the words: the ALP-patch / float-quantize / clamp passes re-read them.
+    const bool direct = !any_sel && words * 16 <= kPinnedResultMax &&
+                        (scan->is_str || (!scan->any_patch && !scan->has_fquant && !scan->has_clamped));
+    uint64_t* d_hv = direct ? h_hit : static_cast<uint64_t*>(cs.dalloc(words * 8 * 2));
     uint64_t* d_cmp = any_sel ? static_cast<uint64_t*>(cs.dalloc(words * 8 * 3 + size_t(m) * 4 + 64)) : nullptr;
     if (!d_hv || (any_sel && !d_cmp)) return fail(LC_ERR_OOM, "hipMalloc (predicate scratch)");
     uint64_t *d_hit = d_hv, *d_valid = d_hv + words;
@@ -3569,7 +3574,7 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         LC_HIP(launch_mask_compress(d_hit, d_sel, scan->d_seg_offsets, m, d_chit, d_bits, cs.st));
         LC_HIP(launch_mask_compress(d_valid, d_sel, scan->d_seg_offsets, m, d_cvalid, nullptr, cs.st));
         LC_HIP(hipMemcpyAsync(h_hit, d_chit, words * 8 * 2 + size_t(m) * 4, hipMemcpyDeviceToHost, cs.st));
-    } else {
+    } else if (!direct) {
         LC_HIP(hipMemcpyAsync(h_hit, d_hv, words * 8 * 2, hipMemcpyDeviceToHost, cs.st));
     }
     LC_PROF(3);
