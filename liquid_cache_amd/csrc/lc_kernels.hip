@@ -552,14 +552,12 @@ __device__ __forceinline__ uint64_t range_ballot(uint32_t t, uint32_t lo_t, uint
 // v_writelane that reads it.  Round 5 built the alternative (-DLC_X_BALLOT_LDS=1): the ballot is wave uniform, so ONE v_mov_b64
 // puts it in a register pair of every lane and a ds_write_b64 leaves it in the wave's 512-byte LDS scratch; at the end of the
 // pass every lane reads the word(s) it owns — 3 VALU per 64 rows, and the compiler emits exactly that (v_lshl, v_cmp,
-// v_mov_b64, one ds_write2_b64 per two steps).  It is correct (the whole -m gpu suite) and 40-65 % SLOWER: Date32 W=12
-// 29.4 -> 42.3 us hot, Decimal W=4 20.8 -> 34.1, Int64 W=17 36.9 -> 50.4, Q6 90 -> 128 us per 100 M rows — 64 lanes storing to
-// ONE LDS address are 64 accesses to one bank, not a broadcast, and a store instruction per step occupies the LDS pipe for
-// as long as the four VALU instructions it replaces two of took?  No: -DLC_X_BALLOT_LDS=2 issues the store from ONE lane (EXEC = 1
-// around the move and the write, one asm block per step) and is exactly as slow (Date32 W=12 42.3 us hot in both), so the
-// store's width is not it either.  The ISA keeps the software pipeline (vmcnt(12) waits, the next pass's loads in flight) and
-// adds only the ds_read2 + lgkmcnt(0) at the pass end; why the two LDS forms land on the same time was not established in
-// the round.  Both kept as A/B options with their numbers (profiles/r5/ablation_ballot_lds.txt).
+// v_mov_b64, one ds_write2_b64 per two steps).  -DLC_X_BALLOT_LDS=2 issues the store from ONE lane (EXEC = 1 around the move and
+// the write, one asm block per step).  Both are correct (the whole -m gpu suite) and both SLOWER, by the same amount: Date32 W=12
+// 29.7 -> 32.4 / 32.7 us hot, Int64 W=17 37.3 -> 39.2 / 39.0, Decimal W=4 20.8 -> 28.9 / 28.4 (profiles/r5/ablation_ballot_lds.txt;
+// the first measurement of this A/B said 40-65 % and was wrong: see RegEntryArgs below).  It could not have been faster either:
+// with BOTH v_writelane removed outright (-DLC_X_NOPARK) the kernels take the same time (profiles/r5/ablation_narrow_int_valu.txt)
+// — they wait for memory, not for the vector ALU.  Kept as A/B options with their numbers.
 #ifndef LC_X_BALLOT_LDS
 #define LC_X_BALLOT_LDS 0
 #endif

@@ -546,6 +546,19 @@ struct alignas(64) FlatGroup {
     FlatEntry e[kFlatMaxE];
 };
 constexpr uint32_t kFlatHotBytes = 64;
+// Layout of the scan-level slices.  Round 4 stored them slice major ([slice][group][word]: a slice is one array over all
+// groups); since round 5 they are GROUP major ([group][slice][word]): what the probe of a group reads (its words of 5-8
+// slices) and what a builder workgroup writes (its words of all 512 slices) lie inside the group's 0.3 MB instead of being
+// spread over 512 regions 3.8 MB apart — the builder's stores were bound by address translation (1.96 GB in 3.5 ms).
+#ifndef LC_FLAT_GROUP_MAJOR
+#define LC_FLAT_GROUP_MAJOR 1
+#endif
+inline uint64_t flat_slice_stride(uint32_t n_slots, uint32_t group_words) {
+    return LC_FLAT_GROUP_MAJOR ? uint64_t(group_words) : uint64_t(n_slots) * group_words;
+}
+inline uint64_t flat_group_stride(uint32_t n_bits, uint32_t group_words) {
+    return LC_FLAT_GROUP_MAJOR ? uint64_t(n_bits) * group_words : uint64_t(group_words);
+}
 static_assert(sizeof(FlatGroup) == kFlatHotBytes + 64 * kFlatMaxE, "FlatGroup layout");
 
 namespace {
@@ -554,7 +567,8 @@ struct FlatArgs {
     const FlatGroup* groups;
     uint32_t n_slots;                       // records (groups + padding)
     const uint64_t* slices;
-    uint64_t slice_words;                   // u64 words of one slice (= n_slots * group_words)
+    uint64_t slice_stride;                  // u64 words from a group's words of slice s to its words of slice s + 1
+    uint64_t group_stride;                  // ... from group g's words of a slice to group g + 1's
     uint32_t group_words;                   // words of a group inside a slice: the largest group of the scan, even
     uint32_t mask_bytes;                    // kBig: LDS bytes of one entry's mask words (a multiple of 1 KB)
     uint32_t eq_len;                        // != 0: `=` / `<>` (kNot) on the needle: a match must also have this length
@@ -611,15 +625,15 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
 #pragma unroll
     for (int k = 0; k < kMaxSigProbeWide - kMaxSigProbe; k++) xv[k] = u32x4{~0u, ~0u, ~0u, ~0u};
     if (live && 2u * uint32_t(lane) < a.group_words) {
-        const uint64_t* base = a.slices + size_t(gi) * a.group_words + size_t(lane) * 2u;
+        const uint64_t* base = a.slices + size_t(gi) * a.group_stride + size_t(lane) * 2u;
 #pragma unroll
         for (int k = 0; k < N; k++)
-            sv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(reinterpret_cast<uintptr_t>(base + size_t(a.sig_bits[k]) * a.slice_words));
+            sv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(reinterpret_cast<uintptr_t>(base + size_t(a.sig_bits[k]) * a.slice_stride));
         if (N == kMaxSigProbe && a.n_extra) {
 #pragma unroll
             for (int k = 0; k < kMaxSigProbeWide - kMaxSigProbe; k++)
                 xv[k] = *reinterpret_cast<GlobalPtr<u32x4>>(reinterpret_cast<uintptr_t>(
-                    base + size_t(a.sig_bits[kMaxSigProbe + min(uint32_t(k), a.n_extra - 1u)]) * a.slice_words));
+                    base + size_t(a.sig_bits[kMaxSigProbe + min(uint32_t(k), a.n_extra - 1u)]) * a.slice_stride));
         }
     }
     ConstFlatPtr G = reinterpret_cast<ConstFlatPtr>(reinterpret_cast<uintptr_t>(a.groups + (live ? gi : wg * kFlatWaves)));
@@ -1026,112 +1040,176 @@ hipError_t launch_flat(int n_sig, bool negated, const FlatArgs& a, hipStream_t s
     return hipGetLastError();
 }
 
-// Builder of the scan-level slices: workgroup (x, e) takes eight signature words (512 dictionary values) of entry e — a
-// lane decodes one value through the symbol table into kFlatBits bits in registers (as k_str_build_signatures), ballots
-// transpose 64 values to slice words staged in LDS, and the workgroup stores eight consecutive words of every slice.
+// Builder of the scan-level slices.  Workgroup (x, g) takes tile x of group g: kFbWords = 16 consecutive signature words
+// (1,024 dictionary values, of up to kFlatMaxE entries — a tile follows the group's words, not an entry's) and stores, for
+// every slice, those 16 words as ONE aligned 128-byte line.  That is the point of the shape: the first builders stored 32
+// or 64 bytes per slice and workgroup, 1.96 GB in 2.1-2.3 ms of a 4.7 ms build, while the same bytes stored as whole lines take
+// 0.3 ms (measured with the decode switched off, profiles/r5/ablation_flat_build.txt) — and since a group's tiles cover every
+// word of its slices, padding included, nothing has to be zeroed beforehand.
+// The decode: a lane walks a CHUNK of a value — at most kFbChunk compressed bytes — through the symbol table and sets the
+// value's bit of every slice word it touches straight in LDS (the transposition the index needs happens by addressing; an
+// LDS atomic, 32-bit: the 64-bit form runs at a fraction of the rate).  Chunks, not values, because a wave lasts as long as its
+// longest lane and a workgroup as long as its slowest wave: with a lane per value the 64 values of a wave hold URLs of 20 and of
+// 300 bytes (2.6x the mean); handing the values out sorted by length evens the lanes of a wave but leaves fifteen waves
+// waiting for the one with the longest URLs.  An FSST stream can be entered at any code boundary (the parity of the run of
+// escape bytes in front of a position says whether it is one), the bigram across the cut needs the last byte of the
+// symbol before it, and OR is idempotent — so the chunks of a value are independent work items of bounded, equal size.
 struct FlatBuildArgs {
-    const StrDesc* descs;
+    const FlatGroup* groups;
     const DevSymtab* symtabs;
-    const uint32_t* dst_word;  // per entry: its first word inside a slice
     uint64_t* slices;
-    uint64_t slice_words;
+    uint64_t slice_stride;  // words from a group's words of slice s to its words of slice s + 1
+    uint64_t group_stride;  // ... from group g's words of slice 0 to group g + 1's
 };
+constexpr uint32_t kFbWords = 16;                 // words of a tile: one 128-byte line per slice
+constexpr uint32_t kFbValues = 64u * kFbWords;    // values of a tile
+constexpr uint32_t kFbThreads = kFbValues;        // set-up: a lane per value
+#ifndef LC_FB_CHUNK
+#define LC_FB_CHUNK 16
+#endif
+constexpr uint32_t kFbChunk = LC_FB_CHUNK;        // compressed bytes of a work item
+struct FbOffsets {  // what str_offset_pair reads of an entry
+    const uint8_t* residuals;
+    int32_t slope, intercept;
+    uint32_t offset_bytes;
+};
+template <bool kUni> constexpr uint32_t fb_row_words() { return (kUni ? 256u : uint32_t(kFlatBits)) + 2u; }  // (+2: the store loop's bank spread)
+template <bool kUni> constexpr size_t fb_lds_bytes() {
+    return size_t(kFbWords) * fb_row_words<kUni>() * 8u + 256u * 8u + size_t(kFbValues) * 8u + size_t(kFbValues) * 4u + 256u + kFbValues;
+}
+// bytes equal to 255 immediately in front of position p of a value that starts at `start`: odd = p follows an escape marker
+__device__ __forceinline__ uint32_t fb_escape_run(const uint8_t* __restrict__ f, uint32_t start, uint32_t p) {
+    uint32_t k = 0;
+    while (p - k > start && f[p - 1u - k] == 255u) k++;
+    return k;
+}
+static_assert(kFbValues == 1024, "fb_value swaps the two 5-bit halves of a slot number");
+__device__ __forceinline__ uint32_t fb_value(uint32_t slot) { return ((slot & 31u) << 5) | (slot >> 5); }
 // kUni: the 256 unigram slices (bit = the byte itself) instead of the kFlatBits bigram slices.
 template <bool kUni>
-__global__ __launch_bounds__(256) void k_flat_build(FlatBuildArgs a) {
-    constexpr int kBits = kUni ? 256 : kFlatBits;
-    __shared__ uint64_t s_sym[256];
-    __shared__ uint8_t s_len[256];
-    // [column][slice]: bit (j & 63) of word [j >> 6][s] = value j of the tile has signature bit s.  Slice fastest: the words the
-    // lanes of a wave OR into sit 8 bytes apart — 32 banks — instead of 64 bytes apart (4 bank positions: the layout of round 4)
-    __shared__ uint64_t stage[8][kBits];
-    const StrDesc d = a.descs[blockIdx.y];
-    const uint32_t nw = (d.d + 63u) >> 6;
-    if (d.d == 0 || blockIdx.x * 8u >= nw) return;
-    const DevSymtab& st = a.symtabs[d.symtab_slot];
-    s_sym[threadIdx.x] = st.sym[threadIdx.x];
-    s_len[threadIdx.x] = st.len[threadIdx.x];
-    for (uint32_t i = threadIdx.x; i < uint32_t(kBits) * 8u; i += 256u) (&stage[0][0])[i] = 0;
-    __syncthreads();
-    const int lane = lane_id(), wave = wave_id();
-    // A lane decodes ONE value and sets its bit of the slice words straight in LDS (the transposition the index needs happens
-    // by addressing).  Round 5: the tile's 512 values are handed to the lanes IN ORDER OF THEIR COMPRESSED LENGTH.  A wave
-    // lasts as long as its longest value, and in dictionary order the 64 values of a wave hold URLs of 20 and of 300 bytes — 2.6x
-    // the mean, measured as 9.4 ms for the 100 M-row column whatever the LDS layout.  A counting sort by length / 4 (one
-    // histogram, one prefix sum, one scatter, all in LDS) gives every wave two runs of 64 neighbours of the sorted order, the
-    // runs paired short with long (w and 7 - w) so that the four waves finish together.  The price: a value's column is no
-    // longer its wave's own, so every bit goes through an LDS atomic (slice-fastest stage: 32 banks).
-    __shared__ uint32_t s_hist[65];
-    __shared__ uint16_t s_order[512];
-    __shared__ uint32_t s_range[512][2];  // (start, stop) of the tile's values: computed once, for the sort and the decode
-    const uint32_t v0 = blockIdx.x * 512u;
-    const uint32_t nv = min(512u, d.d - v0);
-    if (threadIdx.x < 65u) s_hist[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t my_bucket[2] = {0, 0};
-    for (uint32_t q = 0; q < 2; q++) {
-        const uint32_t j = threadIdx.x + q * 256u;
-        if (j < nv) {
-            uint32_t start, stop;
-            str_offset_pair(d, v0 + j, start, stop);
-            s_range[j][0] = start;
-            s_range[j][1] = stop;
-            my_bucket[q] = min((stop - start) >> 2, 63u);
-            atomicAdd(&s_hist[my_bucket[q]], 1u);
+__global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
+    constexpr uint32_t kBits = kUni ? 256u : uint32_t(kFlatBits);
+    constexpr uint32_t kRow = fb_row_words<kUni>();
+    extern __shared__ __align__(16) uint8_t fb_smem[];
+    // [column][slice]: bit (j & 63) of word [j >> 6][s] = value j of the tile has signature bit s (slice fastest: the words the
+    // lanes of a wave OR into sit 8 bytes apart)
+    uint64_t* stage = reinterpret_cast<uint64_t*>(fb_smem);
+    uint64_t* s_sym = stage + size_t(kFbWords) * kRow;
+    uint32_t* s_range = reinterpret_cast<uint32_t*>(s_sym + 256);   // (start, stop) of the tile's values
+    uint32_t* s_first = s_range + 2u * kFbValues;                   // first work item of value j (exclusive prefix of the chunk counts)
+    uint8_t* s_len = reinterpret_cast<uint8_t*>(s_first + kFbValues);
+    uint8_t* s_ent = s_len + 256;                                   // the entry (0 .. kFlatMaxE-1) value j belongs to
+    __shared__ uint32_t s_wave_tot[kFbThreads / 64u + 1u];
+    const uint32_t gi = blockIdx.y, tile = blockIdx.x, t = threadIdx.x;
+    const FlatGroup& G = a.groups[gi];
+    const uint32_t n_entries = G.n_entries;  // (0: a padding record — its lines are stored as zeros)
+    // Slot t holds value fb_value(t) of the tile: neighbouring slots — the lanes of a wave work on neighbouring items — hold
+    // values of DIFFERENT (column, half) words, so that the lanes that reach the same bigram at the same step (every URL starts
+    // with "http://") hit 32 LDS words, not one.
+    const uint32_t u = fb_value(t);
+    // this slot's value: bit (u & 63) of word gword of the group -> entry and value index
+    const uint32_t gword = tile * kFbWords + (u >> 6);
+    uint32_t ent = 0, v = 0;
+    bool valid = false;
+    for (uint32_t e = 0; e < kFlatMaxE; e++) {
+        if (e < n_entries) {
+            const uint32_t wo = G.word_off[e], de = G.e[e].d;
+            if (gword >= wo && gword < wo + ((de + 63u) >> 6)) {
+                ent = e;
+                v = (gword - wo) * 64u + (u & 63u);
+                valid = v < de;
+            }
         }
     }
-    __syncthreads();
-    if (wave == 0) {  // exclusive prefix over the 64 buckets
-        const uint32_t c = s_hist[lane];
-        const uint32_t incl = wave_inclusive_sum(c);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        s_hist[lane] = incl - c;
+    // the value's compressed range first: its loads are in flight while LDS is set up
+    uint32_t start0 = 0, stop0 = 0;
+    if (valid) {
+        const FlatEntry& fe = G.e[ent];
+        const FbOffsets od{fe.residuals, fe.slope, fe.intercept, fe.ob_sp & 0xFFu};
+        str_offset_pair(od, v, start0, stop0);
     }
-    __syncthreads();
-    for (uint32_t q = 0; q < 2; q++) {
-        const uint32_t j = threadIdx.x + q * 256u;
-        if (j < nv) s_order[atomicAdd(&s_hist[my_bucket[q]], 1u)] = uint16_t(j);
+    const DevSymtab& st = a.symtabs[G.slot];
+    if (t < 256u) {
+        s_sym[t] = st.sym[t];
+        s_len[t] = st.len[t];
     }
+    {
+        uint4* z = reinterpret_cast<uint4*>(stage);
+        for (uint32_t i = t; i < kFbWords * kRow / 2u; i += kFbThreads) z[i] = uint4{0, 0, 0, 0};
+    }
+    const int lane = lane_id(), wave = wave_id();
+    // work items: chunk c of value j covers compressed bytes [start + c kFbChunk, start + (c + 1) kFbChunk) of it
+    const uint32_t n_chunks = valid ? (stop0 - start0 + kFbChunk - 1u) / kFbChunk : 0u;
+    const uint32_t incl = wave_inclusive_sum(n_chunks);
+    if (lane == 63) s_wave_tot[wave] = incl;
+    s_range[2u * t] = start0;
+    s_range[2u * t + 1u] = stop0;
+    s_ent[t] = uint8_t(ent);
     __syncthreads();
-    for (uint32_t q = 0; q < 2; q++) {
-        const uint32_t run = q == 0 ? uint32_t(wave) : 7u - uint32_t(wave);  // runs of 64 sorted values: w and 7 - w
-        const uint32_t r = run * 64u + uint32_t(lane);
-        if (r < nv) {
-            const uint32_t j = s_order[r];
-            const uint32_t cc = j >> 6;                  // column of the stage
-            const uint64_t mybit = 1ull << (j & 63u);
-            const uint32_t start = s_range[j][0], stop = s_range[j][1];
-            int prev = -1;
-            bool escaped = false;
-            uint64_t w = start < stop ? load_unaligned<uint64_t>(d.fsst + start) : 0;
-            for (uint32_t p = start; p < stop; p += 8u) {
-                const uint64_t cur_w = w;
-                if (p + 8u < stop) w = load_unaligned<uint64_t>(d.fsst + p + 8u);
-                const uint32_t nb = min(8u, stop - p);
-                for (uint32_t k = 0; k < nb; k++) {
-                    const uint32_t code = uint32_t(cur_w >> (8u * k)) & 0xFFu;
-                    uint64_t sym;
-                    uint32_t len;
-                    if (escaped) { sym = code; len = 1; escaped = false; }
-                    else if (code == 255u) { escaped = true; continue; }
-                    else { sym = s_sym[code]; len = s_len[code]; }
-                    for (uint32_t t = 0; t < len; t++) {
-                        const int cur = int((sym >> (8u * t)) & 0xFFu);
-                        if (kUni || prev >= 0) {
-                            const uint32_t bit = kUni ? uint32_t(cur) : flat_bigram_bit(uint32_t(prev), uint32_t(cur));
-                            atomicOr(reinterpret_cast<unsigned long long*>(&stage[cc][bit]), mybit);
-                        }
-                        prev = cur;
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < kFbThreads / 64u; w++) {
+        const uint32_t x = s_wave_tot[w];
+        before += w < uint32_t(wave) ? x : 0u;
+        total += x;
+    }
+    s_first[t] = before + incl - n_chunks;
+    __syncthreads();
+#if defined(LC_FB_STOP) && LC_FB_STOP == 1  // timing aid (wrong index): no decode — set-up, zeroing and the stores
+    total = 0;
+#endif
+    for (uint32_t i = t; i < total; i += kFbThreads) {
+        // the value item i belongs to: the last j with s_first[j] <= i (values without bytes share their successor's first item)
+        uint32_t lo = 0, hi = kFbValues;
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_first[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t slot = lo, c = i - s_first[slot], j = fb_value(slot);
+        uint32_t* col = reinterpret_cast<uint32_t*>(stage + size_t(j >> 6) * kRow) + ((j >> 5) & 1u);  // the value's column, its half
+        const uint32_t mybit = 1u << (j & 31u);
+        const uint32_t start = s_range[2u * slot], stop = s_range[2u * slot + 1u];
+        const uint8_t* fsst = G.e[s_ent[slot]].fsst;
+        // cut positions move one byte back when they would fall between an escape marker and its literal
+        uint32_t p0 = start + c * kFbChunk, p1 = min(stop, p0 + kFbChunk);
+        if (c != 0) p0 -= fb_escape_run(fsst, start, p0) & 1u;
+        if (p1 < stop) p1 -= fb_escape_run(fsst, start, p1) & 1u;
+        int prev = -1;
+        if (!kUni && c != 0) {  // the last byte in front of the cut: a literal, or the last byte of a symbol
+            const uint32_t b = fsst[p0 - 1u];
+            const bool literal = (fb_escape_run(fsst, start, p0 - 1u) & 1u) != 0;
+            prev = literal ? int(b) : int((s_sym[b] >> (8u * (uint32_t(s_len[b]) - 1u))) & 0xFFu);
+        }
+        bool escaped = false;
+        uint64_t w = p0 < p1 ? load_unaligned<uint64_t>(fsst + p0) : 0;
+        for (uint32_t p = p0; p < p1; p += 8u) {
+            const uint64_t cur_w = w;
+            if (p + 8u < p1) w = load_unaligned<uint64_t>(fsst + p + 8u);
+            const uint32_t nb = min(8u, p1 - p);
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint32_t code = uint32_t(cur_w >> (8u * k)) & 0xFFu;
+                uint64_t sym;
+                uint32_t len;
+                if (escaped) { sym = code; len = 1; escaped = false; }
+                else if (code == 255u) { escaped = true; continue; }
+                else { sym = s_sym[code]; len = s_len[code]; }
+                for (uint32_t q = 0; q < len; q++) {
+                    const int cur = int((sym >> (8u * q)) & 0xFFu);
+                    if (kUni || prev >= 0) {
+                        const uint32_t bit = kUni ? uint32_t(cur) : flat_bigram_bit(uint32_t(prev), uint32_t(cur));
+                        atomicOr(col + 2u * bit, mybit);
                     }
+                    prev = cur;
                 }
             }
         }
     }
     __syncthreads();
-    const uint32_t cols = min(8u, nw - blockIdx.x * 8u);
-    const size_t dst = size_t(a.dst_word[blockIdx.y]) + size_t(blockIdx.x) * 8u;
-    for (uint32_t s = threadIdx.x; s < uint32_t(kBits); s += 256u)
-        for (uint32_t cc = 0; cc < cols; cc++) a.slices[size_t(s) * a.slice_words + dst + cc] = stage[cc][s];
+    // 16 lanes store the 16 words of one slice (a whole 128-byte line), a wave four slices per instruction
+    uint64_t* out = a.slices + size_t(gi) * a.group_stride + size_t(tile) * kFbWords;
+    for (uint32_t i = t; i < kBits * kFbWords; i += kFbThreads) {
+        const uint32_t s = i / kFbWords, cc = i % kFbWords;
+        out[size_t(s) * a.slice_stride + cc] = stage[size_t(cc) * kRow + s];
+    }
 }
 
 // The scan-level index of k_like_flat: groups of consecutive entries (one symbol table, <= kFlatMaxE entries, <= 128
@@ -1198,13 +1276,18 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     if (groups.empty()) return LC_OK;
     pad_batch();
     // every group takes the same number of words inside a slice (the wave's address follows from its index): the largest
-    // group of the scan, even (16-byte loads)
-    uint32_t gw = 2;
-    for (const FlatGroup& g : groups) gw = std::max(gw, (g.n_words + 1u) & ~1u);
+    // group of the scan, rounded up to whole 128-byte lines (the builder stores lines; the probe loads 16 bytes per lane)
+    uint32_t gw = kFbWords;
+    for (const FlatGroup& g : groups) gw = std::max(gw, (g.n_words + kFbWords - 1u) & ~(kFbWords - 1u));
     for (size_t gi = 0; gi < groups.size(); gi++)
         for (uint32_t j = 0; j < groups[gi].n_entries; j++)
-            dst_word[groups[gi].first_entry + j] = uint32_t(gi) * gw + groups[gi].word_off[j];
-    if (uint64_t(groups.size()) * gw > 0xFFFFFFFFull) return LC_OK;
+            dst_word[groups[gi].first_entry + j] = uint32_t(gi * flat_group_stride(kFlatBits, gw) + groups[gi].word_off[j]);
+    if (uint64_t(groups.size()) * flat_group_stride(kFlatBits, gw) > 0xFFFFFFFFull) return LC_OK;
+    // (the unigram index has 256 slices: its own first words, behind the bigram ones in the same device array)
+    dst_word.resize(size_t(s->n) * 2);
+    for (size_t gi = 0; gi < groups.size(); gi++)
+        for (uint32_t j = 0; j < groups[gi].n_entries; j++)
+            dst_word[s->n + groups[gi].first_entry + j] = uint32_t(gi * flat_group_stride(256u, gw) + groups[gi].word_off[j]);
     const uint64_t slice_words = uint64_t(groups.size()) * gw;
     const uint64_t bytes = slice_words * 8u * uint64_t(kFlatBits);
     size_t free_b = 0, total_b = 0;
@@ -1234,12 +1317,23 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
     (void)hipEventCreate(&ev1);
-    uint32_t* d_dst = static_cast<uint32_t*>(pool_alloc(ctx, size_t(s->n) * 4));  // (kept: the unigram index shares the layout)
+    uint32_t* d_dst = static_cast<uint32_t*>(pool_alloc(ctx, size_t(s->n) * 8));  // (kept: [bigram | unigram] first words)
+    // the group records (320 bytes each) and the word offsets go through ONE pinned block (copies from pageable vectors are
+    // staged by the runtime itself, in blocking pieces)
+    const size_t g_bytes = groups.size() * sizeof(FlatGroup), d_bytes = size_t(s->n) * 8;
+    uint8_t* h_stage = static_cast<uint8_t*>(host_pool_alloc(ctx, g_bytes + d_bytes));
     struct Tmp {
-        hipStream_t st; hipEvent_t a, b;
-        ~Tmp() { (void)hipStreamSynchronize(st); if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
-    } tmp{stream, ev0, ev1};
-    if (!d_dst) return fail(LC_ERR_OOM, "hipMalloc (flat index build)");
+        lc_ctx* c; hipStream_t st; hipEvent_t a, b; void* pinned;
+        ~Tmp() {
+            (void)hipStreamSynchronize(st);
+            if (a) (void)hipEventDestroy(a);
+            if (b) (void)hipEventDestroy(b);
+            host_pool_release(c, pinned);
+        }
+    } tmp{ctx, stream, ev0, ev1, h_stage};
+    if (!d_dst || !h_stage) return fail(LC_ERR_OOM, "flat index build: staging");
+    std::memcpy(h_stage, groups.data(), g_bytes);
+    std::memcpy(h_stage + g_bytes, dst_word.data(), d_bytes);
     lp->d_dst_word = d_dst;
     lp->slice_words = slice_words;
     if (hipMalloc(reinterpret_cast<void**>(&lp->d_slices), bytes) != hipSuccess) {
@@ -1250,12 +1344,15 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     lp->d_groups = static_cast<FlatGroup*>(pool_alloc(ctx, groups.size() * sizeof(FlatGroup)));
     if (!lp->d_groups) return fail(LC_ERR_OOM, "hipMalloc (flat group records)");
     if (ev0) LC_HIP(hipEventRecord(ev0, stream));
-    LC_HIP(hipMemsetAsync(lp->d_slices, 0, bytes, stream));
-    LC_HIP(hipMemcpyAsync(lp->d_groups, groups.data(), groups.size() * sizeof(FlatGroup), hipMemcpyHostToDevice, stream));
-    LC_HIP(hipMemcpyAsync(d_dst, dst_word.data(), size_t(s->n) * 4, hipMemcpyHostToDevice, stream));
-    FlatBuildArgs ba{static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, d_dst, lp->d_slices, slice_words};
-    const uint32_t max_nw = (std::max(s->max_dict_len, 1u) + 63u) / 64u;
-    hipLaunchKernelGGL(k_flat_build<false>, dim3((max_nw + 7u) / 8u, s->n), dim3(256), 0, stream, ba);
+    LC_HIP(hipMemcpyAsync(lp->d_groups, h_stage, g_bytes, hipMemcpyHostToDevice, stream));
+    LC_HIP(hipMemcpyAsync(d_dst, h_stage + g_bytes, d_bytes, hipMemcpyHostToDevice, stream));
+    // (no memset: the tiles of a group cover every word of its slices, padding included)
+    FlatBuildArgs ba{lp->d_groups, s->d_symtabs, lp->d_slices, flat_slice_stride(uint32_t(groups.size()), gw),
+                     flat_group_stride(kFlatBits, gw)};
+    LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_build<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(fb_lds_bytes<false>())));
+    hipLaunchKernelGGL(k_flat_build<false>, dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads), fb_lds_bytes<false>(),
+                       stream, ba);
     LC_HIP(hipGetLastError());
     if (ev1) LC_HIP(hipEventRecord(ev1, stream));
     LC_HIP(hipStreamSynchronize(stream));  // the vectors are locals
@@ -1298,10 +1395,10 @@ lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t s
     lp->d_uni = d_uni;  // (freed with the pipeline whatever happens below)
     ctx->index_bytes += bytes;
     if (ev0) LC_HIP(hipEventRecord(ev0, stream));
-    LC_HIP(hipMemsetAsync(d_uni, 0, bytes, stream));
-    FlatBuildArgs ba{static_cast<const StrDesc*>(s->d_descs), s->d_symtabs, lp->d_dst_word, d_uni, lp->slice_words};
-    const uint32_t max_nw = (std::max(s->max_dict_len, 1u) + 63u) / 64u;
-    hipLaunchKernelGGL(k_flat_build<true>, dim3((max_nw + 7u) / 8u, s->n), dim3(256), 0, stream, ba);
+    FlatBuildArgs ba{lp->d_groups, s->d_symtabs, d_uni, flat_slice_stride(lp->n_group_slots, lp->group_words),
+                     flat_group_stride(256u, lp->group_words)};
+    hipLaunchKernelGGL(k_flat_build<true>, dim3(lp->group_words / kFbWords, lp->n_group_slots), dim3(kFbThreads),
+                       fb_lds_bytes<true>(), stream, ba);
     LC_HIP(hipGetLastError());
     if (ev1) LC_HIP(hipEventRecord(ev1, stream));
     LC_HIP(hipStreamSynchronize(stream));
@@ -1414,7 +1511,8 @@ lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L,
     fa.groups = lp->d_groups;
     fa.n_slots = lp->n_group_slots;
     fa.slices = lp->d_slices;
-    fa.slice_words = uint64_t(lp->n_group_slots) * lp->group_words;
+    fa.slice_stride = flat_slice_stride(lp->n_group_slots, lp->group_words);
+    fa.group_stride = flat_group_stride(kFlatBits, lp->group_words);
     fa.group_words = lp->group_words;
     fa.mask_bytes = lp->flat_mask_bytes;
     fa.eq_len = force_like ? 0u : p.eq_len;
@@ -1700,7 +1798,8 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
             }
             if (lp->eligible && lp->flat && lp->d_uni) {
                 LC_HIP(launch_like_scanall(s->d_wg_ranges, s->n_wg_ranges, p, L, L.d_total_acc, stream,
-                                           lp->d_uni + uint64_t(sp.needle[0]) * lp->slice_words, lp->d_dst_word));
+                                           lp->d_uni + uint64_t(sp.needle[0]) * flat_slice_stride(lp->n_group_slots, lp->group_words),
+                                           lp->d_dst_word + s->n));
                 *handled = true;
                 return LC_OK;
             }

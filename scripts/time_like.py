@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--needle", default="google")
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--cold", action="store_true")
+    ap.add_argument("--rebuild", action="store_true", help="build the scan-level index a second time in the same process")
     a = ap.parse_args()
     args = bench.parse_args(["--rows", str(a.rows), "--needle", a.needle])
     import torch
@@ -34,10 +35,19 @@ def main():
     torch.cuda.synchronize()
     hot = scan.eval_timed(expr, mask.data_ptr(), a.iters, 0, counts.data_ptr(), stream)
     cold = scan.eval_timed_cold(expr, mask.data_ptr(), 5, bench.FLUSH_BYTES, 0, counts.data_ptr(), stream) if a.cold else float("nan")
-    print("%-8s path %d  hot %.2f us  cold %.2f us  hits %d  %s" % (
+    built = "%.2f" % scan.info().index_build_ms
+    print("%-8s path %d  hot %.2f us  cold %.2f us  index build %s ms  hits %d  %s" % (
         os.path.basename(os.environ.get("LC_LIB_PATH", "default")).replace("libliquid_cache_amd_", "").replace(".so", ""),
-        a.like_path, hot * 1e3, cold * 1e3, int(counts.sum(dtype=torch.int64).item()), scan.explain(expr)[-110:]), flush=True)
+        a.like_path, hot * 1e3, cold * 1e3, built, int(counts.sum(dtype=torch.int64).item()), scan.explain(expr)[-110:]), flush=True)
     scan.close()
+    if a.rebuild:
+        cache.set_option(N.OPT_LIKE_INDEX_CACHE, 0)  # (the first scan's index was kept for adoption: drop that behaviour)
+        for k in range(2):
+            scan2 = cache.scan(ids)
+            scan2.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)
+            torch.cuda.synchronize()
+            print("         build %d in the same process: %.2f ms" % (k + 2, scan2.info().index_build_ms), flush=True)
+            scan2.close()
     cache.close()
 
 
