@@ -42,10 +42,10 @@ constexpr uint32_t kSaPasses = kSaChunkWords / kWave;    // 8
 // 1: words with and without a value end are walked separately (round 5, see the kernel: every word without the per-byte end
 // logic — 2 VALU per byte —, the 18 % that hold a value end again in dense passes); 0 (shipped): every word with the full
 // per-byte logic.  Measured on the 100 M-row URL column through LC_OPT_LIKE_PATH = 5, all ten needle classes bit-identical
-// to the oracle in both forms: 592 / 586 us hot / cold with the split against 610 / 582 without — the walk's VALU work fell
-// by ~40 % and the time did not move, so round 4's reading ("bound by instructions per byte") was wrong: what bounds the
-// kernel is the dependent ds_read_u16 per compressed byte (80 wave-wide lookups per 4 KB chunk into rows that sit in a few
-// banks).  Kept as an A/B option.
+// to the oracle in both forms: 592-609 / 585 us hot / cold with the split against 584-610 / 565-582 without.  No gain — and no
+// surprise once the instructions are counted: the list of the words with an end, their second fetch and walk and a carry pass
+// that reads LDS instead of registers give back most of what the cheap walk saves (~660 against ~750 vector instructions per
+// 4 KB chunk).  Kept as an A/B option (profiles/r5/ablation_scanall_split.txt).
 #ifndef LC_SA_SPLIT
 #define LC_SA_SPLIT 0
 #endif
