@@ -704,6 +704,7 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
       * config 2 at selectivity {0.01 %, 1 %, 50 %} (Int64 W=62 / W=17, Date32 W=12);
       * ALP float predicate (float_array.rs:294-316), string Eq / ordering through the prefix keys
         (byte_view_array/comparisons.rs:21-151, 351-405), date-part extraction over decoded values."""
+    import ctypes as C
     import pyarrow as pa
     out = {}
 
@@ -814,13 +815,15 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                 assert int(n_h.item()) == k
                 lens_h = views_t[:k, 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0].astype(np.int64)
                 assert int(lens_h.sum()) == nbytes, "hit-list gather: lengths differ from the mask form's"
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(n_it):
-                    run_h()
-                e1.record()
-                torch.cuda.synchronize()
-                ms_h = e0.elapsed_time(e1) / n_it
+                # timed by a C loop (lc_bench_gather_bytes_hits_timed: events around back-to-back calls of the public entry point):
+                # a Python loop issues a call every ~15-20 us — longer than the kernel runs — and measured its own pace (35 us)
+                B = N.load_bench()
+                ms_c = C.c_float()
+                N.check(B.lc_bench_gather_bytes_hits_timed(cache._ctx, url_scan._h, C.c_void_p(hits_t.data_ptr()), C.c_void_p(n_h.data_ptr()),
+                                                           cap, C.c_void_p(views_t.data_ptr()), C.c_void_p(data.data_ptr()),
+                                                           min(data.numel(), (1 << 31) - 1), C.c_void_p(n_b.data_ptr()),
+                                                           C.c_void_p(stream or None), max(n_it, 20), C.byref(ms_c)), cache._ctx)
+                ms_h = float(ms_c.value)
                 # what it has to move: per row its record (8), key (2), offset pair (~8), prefix key (8), ~0.58 compressed
                 # bytes per decoded byte, the view (16) and the decoded bytes
                 need_h = k * (8 + 2 + 8 + 8 + 16) + int(nbytes * 0.58) + nbytes

@@ -88,7 +88,7 @@ EXPORTED_SYMBOLS = [
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
-                 "lc_calibrate_read", "lc_probe_stream_read", "lc_debug_row_lists", "lc_bench_eval_timed",
+                 "lc_calibrate_read", "lc_probe_stream_read", "lc_debug_row_lists", "lc_bench_eval_timed", "lc_bench_gather_bytes_hits_timed",
                  "lc_bench_rowgroup_run", "lc_bench_entry_calls"]
 
 
@@ -123,6 +123,8 @@ def load_bench():
     B.lc_probe_stream_read.argtypes = [vp, u64, i32, i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     B.lc_debug_row_lists.restype = sz
     B.lc_debug_row_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, sz]
+    B.lc_bench_gather_bytes_hits_timed.restype = i32
+    B.lc_bench_gather_bytes_hits_timed.argtypes = [vp, vp, vp, vp, u64, vp, vp, u64, vp, vp, i32, C.POINTER(C.c_float)]
     B.lc_bench_eval_timed.restype = i32
     B.lc_bench_eval_timed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, u64, C.POINTER(C.c_float)]
     B.lc_bench_rowgroup_run.restype = i32

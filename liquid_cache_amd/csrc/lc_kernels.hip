@@ -3962,7 +3962,21 @@ __global__ __launch_bounds__(kThreads) void k_pred_hits(HitsPredArgs a) {
     const uint64_t k = min(uint64_t(*a.n_in), a.cap_in);
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
-    const uint8_t* lit = a.lit ? a.lit : a.lit_inline;
+    // the inline literal -> LDS (a pointer into the kernel arguments would send the whole argument block to scratch: 232 bytes
+    // per lane and a scratch set-up in front of every launch — the kernel took 18 us with an EMPTY hit list)
+    __shared__ uint64_t s_lit[(kInlineNeedle + 7) / 8];
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int q = 0; q < (kInlineNeedle + 7) / 8; q++) {
+            uint64_t v = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++)
+                if (q * 8 + b < kInlineNeedle) v |= uint64_t(a.lit_inline[q * 8 + b]) << (8 * b);
+            s_lit[q] = v;
+        }
+    }
+    __syncthreads();
+    const uint8_t* lit = a.lit ? a.lit : reinterpret_cast<const uint8_t*>(s_lit);
     uint32_t it = 0;
     for (uint64_t rb0 = uint64_t(blockIdx.x) * kThreads; rb0 < k; rb0 += uint64_t(gridDim.x) * kThreads, it ^= 1u) {
         const uint64_t i = rb0 + uint64_t(wave) * kWave + uint64_t(lane);
@@ -5606,6 +5620,17 @@ hipError_t launch_mask_and_then(const uint64_t* d_left, uint64_t left_bits, cons
     return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(kWave) void k_zero_small(uint32_t* p, uint32_t words) {
+    for (uint32_t i = threadIdx.x; i < words; i += kWave) p[i] = 0;
+}
+}  // namespace
+hipError_t launch_zero_small(void* p, uint32_t bytes, hipStream_t stream) {
+    if (bytes == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_small, dim3(1), dim3(kWave), 0, stream, static_cast<uint32_t*>(p), bytes / 4u);
+    return hipGetLastError();
+}
+
 hipError_t launch_mask_to_hits(const void* d_descs, bool is_str, uint32_t n_entries, const uint64_t* d_mask, uint64_t* d_hits,
                                uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
@@ -5666,7 +5691,8 @@ hipError_t launch_pred_hits(const HitsPredLaunch& h, hipStream_t stream) {
     if (h.lit_len <= uint32_t(kInlineNeedle) && h.h_lit)
         for (uint32_t q = 0; q < h.lit_len; q++) a.lit_inline[q] = h.h_lit[q];
     a.fp = h.fp;
-    const dim3 grid(uint32_t(std::min<uint64_t>((h.cap_in + kThreads - 1) / kThreads, uint64_t(device_cus()) * 8))), block(kThreads);
+    // (the list is usually far shorter than its capacity: two workgroups per CU, looping, cover 131,072 records per round)
+    const dim3 grid(uint32_t(std::min<uint64_t>((h.cap_in + kThreads - 1) / kThreads, uint64_t(device_cus()) * 2))), block(kThreads);
     switch (h.lane_log2) {
         case 0: hipLaunchKernelGGL(k_pred_hits<0>, grid, block, 0, stream, a); break;
         case 3: hipLaunchKernelGGL(k_pred_hits<3>, grid, block, 0, stream, a); break;

@@ -718,14 +718,22 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
                 unsigned long long* bslot = reinterpret_cast<unsigned long long*>(smem + tbl_bytes + kFlatMaxE * kMaskBytes +
                                                                                   kFlatMaxE * 64u + kFlatCap * 4u);  // wave 0's hit flags
                 __syncthreads();
+#if defined(LC_FLAT_HITS_ABL) && (LC_FLAT_HITS_ABL & 1)  // timing aid (wrong positions): no list allocation
+                if (wave == 0 && lane == 0) *bslot = 0ull;
+#else
                 if (wave == 0 && lane == 0) *bslot = all ? atomicAdd(a.n_hits, all) : 0ull;
+#endif
                 __syncthreads();
                 b = uniform_u64(*bslot + before);
             } else if (wh) {
                 if (lane == 0) b = atomicAdd(a.n_hits, (unsigned long long)wh);
                 b = uniform_u64(b);
             }
+#if defined(LC_FLAT_HITS_ABL) && (LC_FLAT_HITS_ABL & 2)  // timing aid: no records written
+            if (wh == ~0ull) {
+#else
             if (wh != 0) {
+#endif
                 for (uint32_t j = 0; j < n_entries; j++) {
                     const uint32_t nr = j == 0 ? nr0 : j == 1 ? nr1 : j == 2 ? nr2 : nr3;
                     const uint32_t nwords = (nr + 63u) >> 6;

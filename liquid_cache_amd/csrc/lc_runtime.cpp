@@ -2550,7 +2550,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         return fail(LC_ERR_INVALID, "no output: d_mask_out is null and neither a count nor a hit list is asked for");
     if (!d_mask_out && d_valid_out) return fail(LC_ERR_INVALID, "a validity output needs the mask output");
     if (hits && hits->d_hits && !hits->d_n_hits) return fail(LC_ERR_INVALID, "d_n_hits is null");
-    if (hits && hits->d_n_hits && !hits->counters_zeroed) LC_HIP(hipMemsetAsync(hits->d_n_hits, 0, 8, stream));
+    if (hits && hits->d_n_hits && !hits->counters_zeroed) LC_HIP(launch_zero_small(hits->d_n_hits, 8, stream));
     if (s->n == 0) {
         if (d_total_out) LC_HIP(hipMemsetAsync(d_total_out, 0, 8, stream));
         return LC_OK;
@@ -3348,7 +3348,10 @@ lc_status lc_device_free(lc_ctx* ctx, void* p) {
 lc_status lc_device_memset(lc_ctx* ctx, void* p, int v, uint64_t bytes, void* stream) {
     return guarded([&]() -> lc_status {
     if (!ctx || !p) return fail(LC_ERR_INVALID, "null argument");
-    LC_HIP(hipMemsetAsync(p, v, bytes, static_cast<hipStream_t>(stream)));
+    if (v == 0 && bytes <= 4096 && (bytes & 3u) == 0 && (reinterpret_cast<uintptr_t>(p) & 3u) == 0)
+        LC_HIP(launch_zero_small(p, uint32_t(bytes), static_cast<hipStream_t>(stream)));  // (a query's counters)
+    else
+        LC_HIP(hipMemsetAsync(p, v, bytes, static_cast<hipStream_t>(stream)));
     return LC_OK;
     });
 }
@@ -4128,7 +4131,7 @@ lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, v
     return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_mask || !d_hits_out || !d_n_hits) return fail(LC_ERR_INVALID, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LC_HIP(hipMemsetAsync(d_n_hits, 0, 8, st));
+    LC_HIP(launch_zero_small(d_n_hits, 8, st));
     if (scan->n == 0) return LC_OK;
     scan_note_stream(scan, st);
     LC_HIP(launch_mask_to_hits(scan->d_descs, scan->is_str, scan->n, static_cast<const uint64_t*>(d_mask),
@@ -4145,7 +4148,7 @@ lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
     if (!ctx || !scan || !pred || !d_hits_in || !d_n_hits_in || !d_hits_out || !d_n_hits_out) return fail(LC_ERR_INVALID, "null argument");
     if (d_hits_in == d_hits_out) return fail(LC_ERR_INVALID, "lc_scan_filter_hits does not filter in place");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(hipMemsetAsync(d_n_hits_out, 0, 8, st));
+    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(launch_zero_small(d_n_hits_out, 8, st));
     if (scan->n == 0 || capacity_in == 0) return LC_OK;
     if (scan->has_clamped || scan->has_fquant)
         return fail(LC_UNSUPPORTED, "squeezed entries: the mask form decides which rows need the backing array");
@@ -4240,7 +4243,7 @@ lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hi
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes_hits covers byte-view columns");
     if (capacity_bytes > 0x7FFFFFFFull) return fail(LC_ERR_INVALID, "a BinaryView offset is an i32: capacity_bytes must stay below 2 GiB");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(hipMemsetAsync(d_n_bytes, 0, 8, st));
+    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(launch_zero_small(d_n_bytes, 8, st));
     if (scan->n == 0 || capacity_rows == 0) return LC_OK;
     scan_note_stream(scan, st);
     LC_HIP(launch_str_gather_hits(static_cast<const StrDesc*>(scan->d_descs), scan->d_symtabs, static_cast<const uint64_t*>(d_hits),
