@@ -815,15 +815,25 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                 assert int(n_h.item()) == k
                 lens_h = views_t[:k, 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0].astype(np.int64)
                 assert int(lens_h.sum()) == nbytes, "hit-list gather: lengths differ from the mask form's"
-                # timed by a C loop (lc_bench_gather_bytes_hits_timed: events around back-to-back calls of the public entry point):
-                # a Python loop issues a call every ~15-20 us — longer than the kernel runs — and measured its own pace (35 us)
+                # timed by a C loop (lc_bench_gather_bytes_hits_timed: events around back-to-back calls of the public entry point; a
+                # Python loop measures its own pace).  Two forms: the stand-alone call, which zeroes its byte counter with a one-wave
+                # kernel in front of the gather, and the gather kernel as a pipeline runs it (counters zeroed once up front; the
+                # calls append behind each other in the data buffer)
                 B = N.load_bench()
                 ms_c = C.c_float()
-                N.check(B.lc_bench_gather_bytes_hits_timed(cache._ctx, url_scan._h, C.c_void_p(hits_t.data_ptr()), C.c_void_p(n_h.data_ptr()),
-                                                           cap, C.c_void_p(views_t.data_ptr()), C.c_void_p(data.data_ptr()),
-                                                           min(data.numel(), (1 << 31) - 1), C.c_void_p(n_b.data_ptr()),
-                                                           C.c_void_p(stream or None), max(n_it, 20), C.byref(ms_c)), cache._ctx)
-                ms_h = float(ms_c.value)
+                n_c = max(n_it, 20)
+                cap_b = min(data.numel(), (1 << 31) - 1)
+                n_app = max(1, min(n_c, cap_b // max(nbytes + 64, 1) - 1))
+
+                def timed_c(flags, n):
+                    N.check(B.lc_bench_gather_bytes_hits_timed(cache._ctx, url_scan._h, C.c_void_p(hits_t.data_ptr()),
+                                                               C.c_void_p(n_h.data_ptr()), cap, C.c_void_p(views_t.data_ptr()),
+                                                               C.c_void_p(data.data_ptr()), cap_b, C.c_void_p(n_b.data_ptr()), flags,
+                                                               C.c_void_p(stream or None), n, C.byref(ms_c)), cache._ctx)
+                    return float(ms_c.value)
+                ms_call = timed_c(0, n_c)
+                ms_h = timed_c(1, n_app)
+                assert int(n_b.item()) == n_app * nbytes, "appended gathers: byte total differs"
                 # what it has to move: per row its record (8), key (2), offset pair (~8), prefix key (8), ~0.58 compressed
                 # bytes per decoded byte, the view (16) and the decoded bytes
                 need_h = k * (8 + 2 + 8 + 8 + 16) + int(nbytes * 0.58) + nbytes
@@ -831,7 +841,8 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                             "rows": int(url_scan.rows), "selected_rows": k, "bytes_out": nbytes,
                             "kernel_bytes_per_launch": int(need_h), "achieved": need_h / (ms_h * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": need_h / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "timing": "back_to_back",
-                            "traffic": None, "rows_out_per_s": k / (ms_h * 1e-3), "mask_form_ms": ms}
+                            "traffic": None, "rows_out_per_s": k / (ms_h * 1e-3), "mask_form_ms": ms,
+                            "call_ms_with_counter_reset": ms_call, "appended_calls_timed": n_app}
         except Exception as e:  # noqa: BLE001
             out["byte_view_gather"] = {"error": "%s: %s" % (type(e).__name__, e)}
     try:  # date-part extraction over decoded Date32 values, in place (k_date_component / lossy reconstruction)
@@ -1870,6 +1881,12 @@ def main():
         rot_counts.append(c_r)
     scan.eval(expr, mask.data_ptr(), 0, counts.data_ptr(), stream)  # (the mask / counts buffers hold column 0 again)
     torch.cuda.synchronize()
+    steady_build_ms = None
+    if n_rot > 1 and args.workload == "url_like":
+        try:  # the index build of the rotation's last table: a build that is not the process's first (no kernel code load)
+            steady_build_ms = round(float(scans[n_rot - 1].info().index_build_ms), 3)
+        except Exception:  # noqa: BLE001
+            steady_build_ms = None
     for r in range(1, n_rot):  # the other tables of the rotation have done their work
         scans[r].close()
     like_stream = None
@@ -1992,11 +2009,8 @@ def main():
         inf = scan.info()
         out["config"]["index_bytes"] = int(inf.index_bytes) + int(inf.unigram_index_bytes)
         out["config"]["index_build_ms"] = round(float(inf.index_build_ms), 3)  # (the first build of the process: + kernel code load)
-        if len(scans) > 1:
-            try:
-                out["config"]["index_build_ms_steady"] = round(float(scans[-1].info().index_build_ms), 3)  # the rotation's last table
-            except Exception:  # noqa: BLE001
-                pass
+        if steady_build_ms:
+            out["config"]["index_build_ms_steady"] = steady_build_ms
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_sample = args.cpu_batches or n_batches  # ~4 s (LIKE) / ~1 s (int) of single-thread CPU work at 100 M rows
         if args.workload == "url_like":

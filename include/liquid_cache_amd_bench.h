@@ -61,12 +61,15 @@ LC_BENCH_API int32_t lc_probe_stream_read(void* ctx, uint64_t bytes, int32_t ite
  * to back (hot: a column below the 256 MiB Infinity Cache stays resident); > 0: that many bytes of scratch are streamed
  * through the memory-side cache by a read-only kernel before every launch (>= 512 MiB defeats the Infinity Cache) — the
  * L3-cold kernel time of one evaluation.  Uses the public scan API only; the roofline figures of bench.py come from here. */
-/* `iters` back-to-back calls of the hit-list byte gather (each zeroes its own byte counter) between two events on `stream`:
- * average milliseconds per call as the device sees them (a Python loop issues a call every ~15-20 us, longer than the kernel
- * runs).  Same arguments as the public gather entry point. */
+/* `iters` back-to-back calls of the hit-list byte gather between two events on `stream`: average milliseconds per call as
+ * the device sees them.  Same arguments as the public gather entry point.  flags = 0: every call zeroes its byte counter (a
+ * one-wave kernel in front of the gather: the stand-alone call); LC_HITS_COUNTERS_ZEROED: the counter is zeroed once in front
+ * of the loop and the calls append behind each other in d_data (capacity_bytes must hold iters outputs): the gather kernel
+ * alone, as it runs inside a pipeline that zeroed its counters up front. */
 LC_BENCH_API int32_t lc_bench_gather_bytes_hits_timed(void* ctx, void* scan, const void* d_hits, const void* d_n_hits,
                                                       uint64_t capacity_rows, void* d_views, void* d_data, uint64_t capacity_bytes,
-                                                      void* d_n_bytes, void* stream, int32_t iters, float* out_avg_ms);
+                                                      void* d_n_bytes, uint32_t flags, void* stream, int32_t iters,
+                                                      float* out_avg_ms);
 LC_BENCH_API int32_t lc_bench_eval_timed(void* ctx, void* scan, const void* pred, const void* d_selection, void* d_mask_out,
                                          void* d_counts_out, void* stream, int32_t iters, uint64_t flush_bytes,
                                          float* out_avg_ms);

@@ -124,7 +124,7 @@ def load_bench():
     B.lc_debug_row_lists.restype = sz
     B.lc_debug_row_lists.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, sz]
     B.lc_bench_gather_bytes_hits_timed.restype = i32
-    B.lc_bench_gather_bytes_hits_timed.argtypes = [vp, vp, vp, vp, u64, vp, vp, u64, vp, vp, i32, C.POINTER(C.c_float)]
+    B.lc_bench_gather_bytes_hits_timed.argtypes = [vp, vp, vp, vp, u64, vp, vp, u64, vp, C.c_uint32, vp, i32, C.POINTER(C.c_float)]
     B.lc_bench_eval_timed.restype = i32
     B.lc_bench_eval_timed.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, u64, C.POINTER(C.c_float)]
     B.lc_bench_rowgroup_run.restype = i32

@@ -116,8 +116,8 @@ int32_t lc_probe_stream_read(void* ctx_, uint64_t bytes, int32_t iters, int32_t 
 // the cache ends up holding clean scratch lines only).  Through the PUBLIC scan API only: bench infrastructure, not part of
 // the product library.
 int32_t lc_bench_gather_bytes_hits_timed(void* ctx_, void* scan_, const void* d_hits, const void* d_n_hits, uint64_t capacity_rows,
-                                         void* d_views, void* d_data, uint64_t capacity_bytes, void* d_n_bytes, void* stream,
-                                         int32_t iters, float* out_avg_ms) {
+                                         void* d_views, void* d_data, uint64_t capacity_bytes, void* d_n_bytes, uint32_t flags,
+                                         void* stream, int32_t iters, float* out_avg_ms) {
     lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
     lc_scan* scan = static_cast<lc_scan*>(scan_);
     if (!ctx || !scan || !out_avg_ms || iters <= 0) return LC_ERR_INVALID;
@@ -127,10 +127,12 @@ int32_t lc_bench_gather_bytes_hits_timed(void* ctx_, void* scan_, const void* d_
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipEvent_t a = nullptr, b = nullptr;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return LC_ERR_DEVICE;
-    int32_t rc = hipEventRecord(a, st) == hipSuccess ? LC_OK : LC_ERR_DEVICE;
+    int32_t rc = LC_OK;
+    if (flags & LC_HITS_COUNTERS_ZEROED) rc = lc_device_memset(ctx, d_n_bytes, 0, 8, st);
+    if (rc == LC_OK && hipEventRecord(a, st) != hipSuccess) rc = LC_ERR_DEVICE;
     for (int i = 0; i < iters && rc == LC_OK; i++)
         rc = lc_scan_gather_bytes_hits(ctx, scan, d_hits, d_n_hits, capacity_rows, d_views, nullptr, d_data, capacity_bytes, d_n_bytes,
-                                       0, st);
+                                       flags, st);
     float ms = 0;
     if (rc == LC_OK && (hipEventRecord(b, st) != hipSuccess || hipEventSynchronize(b) != hipSuccess ||
                         hipEventElapsedTime(&ms, a, b) != hipSuccess))

@@ -106,7 +106,8 @@ struct LikePipeline {
     uint64_t* d_slices = nullptr;
     FlatGroup* d_groups = nullptr;
     uint32_t n_groups = 0, n_group_slots = 0;  // groups with entries / records incl. the padding of workgroup batches
-    uint32_t group_words = 0;                  // signature words of a group inside a slice (even, <= kFlatGroupWords)
+    uint32_t group_words = 0;                  // signature words of a group inside a slice: whole 128-byte lines (<= kFlatGroupWords)
+    uint32_t probe_words = 0;                  // ... of them in use by the largest group, even: what the probe of a group reads
     uint64_t slices_bytes = 0;
     double flat_build_ms = 0;
     // the unigram index (1-byte needles): 256 slices in the layout of the bigram slices — bit i of entry e's words in slice
@@ -569,7 +570,8 @@ struct FlatArgs {
     const uint64_t* slices;
     uint64_t slice_stride;                  // u64 words from a group's words of slice s to its words of slice s + 1
     uint64_t group_stride;                  // ... from group g's words of a slice to group g + 1's
-    uint32_t group_words;                   // words of a group inside a slice: the largest group of the scan, even
+    uint32_t group_words;                   // words of a group the probe reads: the largest group of the scan, even (the
+                                            // strides are rounded up to whole lines for the builder; the padding is not read)
     uint32_t mask_bytes;                    // kBig: LDS bytes of one entry's mask words (a multiple of 1 KB)
     uint32_t eq_len;                        // != 0: `=` / `<>` (kNot) on the needle: a match must also have this length
     const DevSymtab* symtabs;               // eq_len: lengths of values of 255 bytes and more are counted from their codes
@@ -1369,6 +1371,8 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     lp->n_groups = n_groups;
     lp->n_group_slots = uint32_t(groups.size());
     lp->group_words = gw;
+    lp->probe_words = 2;
+    for (const FlatGroup& g : groups) lp->probe_words = std::max(lp->probe_words, (g.n_words + 1u) & ~1u);
     lp->slices_bytes = bytes;
     ctx->index_bytes += bytes;
     lp->flat = true;
@@ -1521,7 +1525,7 @@ lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L,
     fa.slices = lp->d_slices;
     fa.slice_stride = flat_slice_stride(lp->n_group_slots, lp->group_words);
     fa.group_stride = flat_group_stride(kFlatBits, lp->group_words);
-    fa.group_words = lp->group_words;
+    fa.group_words = lp->probe_words;
     fa.mask_bytes = lp->flat_mask_bytes;
     fa.eq_len = force_like ? 0u : p.eq_len;
     fa.symtabs = lp->d_symtabs;
@@ -1759,7 +1763,7 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
                 const uint64_t nb = std::min<uint64_t>(flat_needle_bits(sp.needle, bits), q.n_probe ? q.n_probe : kMaxSigProbeWide);
                 // sparse_flags: 2 = the caller takes no mask (k_like_flat then stores no mask words), 4 = it takes the hit list
                 // (8 bytes per hit row)
-                uint64_t b = uint64_t(lp->n_group_slots) * (kFlatHotBytes + nb * lp->group_words * 8) +
+                uint64_t b = uint64_t(lp->n_group_slots) * (kFlatHotBytes + nb * lp->probe_words * 8) +
                              ((sparse_flags & 2u) ? 0 : s->seg_offsets.back() * 8) + ((sparse_flags & 4u) ? q.hits * 8 : 0) +
                              (with_counts ? uint64_t(s->n) * 4 : 0);
                 b += std::min<uint64_t>(q.n_cand, lp->n_groups) * 64 * kFlatMaxE + q.n_cand * 12 + q.cand_bytes + q.hits * 2;
