@@ -363,4 +363,9 @@ hipError_t launch_bv_pack(const BvEncodeDesc* d_descs, const BvPackDesc* d_packs
     return hipGetLastError();
 }
 
+hipError_t warm_code_object_bv_encode() {  // (see warm_code_object_kernels)
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_bv_pack));
+}
+
 }  // namespace lc

@@ -248,4 +248,9 @@ hipError_t launch_group_partials(const StrDesc* g_descs, const StrDesc* v_descs,
     return hipGetLastError();
 }
 
+hipError_t warm_code_object_groupby() {  // (see warm_code_object_kernels)
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_group_partials));
+}
+
 }  // namespace lc

@@ -5704,4 +5704,11 @@ hipError_t launch_pred_hits(const HitsPredLaunch& h, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// The code object of this translation unit is loaded by the runtime at the first use of one of its kernels — 1.5-2.3 ms for the
+// larger ones, which a query's first launch would otherwise pay (lc_ctx_create asks for one kernel's attributes per unit).
+hipError_t warm_code_object_kernels() {
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_zero_small));
+}
+
 }  // namespace lc

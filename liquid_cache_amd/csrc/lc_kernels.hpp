@@ -362,6 +362,12 @@ hipError_t launch_group_partials(const StrDesc* g_descs, const StrDesc* v_descs,
                                  uint32_t n_entries, int want_max, lc_group_partial* out, uint64_t capacity,
                                  unsigned long long* n_out, hipStream_t stream);
 // hit lists (sparse results): mask -> list, and get-with-selection for the rows of a list in ONE launch each
+// one per translation unit with kernels: makes the runtime load the unit's code object now instead of at a query's first launch
+hipError_t warm_code_object_kernels();
+hipError_t warm_code_object_like_pipeline();
+hipError_t warm_code_object_like_scanall();
+hipError_t warm_code_object_groupby();
+hipError_t warm_code_object_bv_encode();
 // `bytes` (a multiple of 4, <= 4096) at p <- 0 by one wave: the counters of a sparse query.  (hipMemsetAsync's fill kernel takes
 // 4-5 us for 32 bytes in front of a 10 us kernel.)
 hipError_t launch_zero_small(void* p, uint32_t bytes, hipStream_t stream);

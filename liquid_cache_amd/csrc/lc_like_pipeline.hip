@@ -1181,8 +1181,10 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
         const uint8_t* fsst = G.e[s_ent[slot]].fsst;
         // cut positions move one byte back when they would fall between an escape marker and its literal
         uint32_t p0 = start + c * kFbChunk, p1 = min(stop, p0 + kFbChunk);
+#ifndef LC_FB_MUTATE  // (-DLC_FB_MUTATE: the cuts left where they fall — the mutant tests/test_gpu_round5.py must catch)
         if (c != 0) p0 -= fb_escape_run(fsst, start, p0) & 1u;
         if (p1 < stop) p1 -= fb_escape_run(fsst, start, p1) & 1u;
+#endif
         int prev = -1;
         if (!kUni && c != 0) {  // the last byte in front of the cut: a literal, or the last byte of a symbol
             const uint32_t b = fsst[p0 - 1u];
@@ -1866,6 +1868,11 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         s->last_native_hits = use_flat && L.d_hits != nullptr;  // (k_like_flat appends the hit list itself)
     }
     return st;
+}
+
+hipError_t warm_code_object_like_pipeline() {  // (see warm_code_object_kernels)
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_flat_build<false>));
 }
 
 }  // namespace lc

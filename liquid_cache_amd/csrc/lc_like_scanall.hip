@@ -547,4 +547,9 @@ hipError_t launch_like_scanall(const StrWgRecord* d_recs, uint32_t n_recs, const
     return hipGetLastError();
 }
 
+hipError_t warm_code_object_like_scanall() {  // (see warm_code_object_kernels)
+    hipFuncAttributes a;
+    return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(k_like_scanall<false, false>));
+}
+
 }  // namespace lc

@@ -866,6 +866,14 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     ctx->device = dev;
     LC_HIP(hipGetDeviceProperties(&ctx->props, dev));
     ctx->max_hbm = max_hbm_bytes;
+    // the code objects of the kernels, now (best effort): the first LIKE of a process paid 2.3 ms for the load of the index
+    // builder's unit in front of its first launch
+    (void)warm_code_object_kernels();
+    (void)warm_code_object_like_pipeline();
+    (void)warm_code_object_like_scanall();
+    (void)warm_code_object_groupby();
+    (void)warm_code_object_bv_encode();
+    (void)hipGetLastError();
     // (no environment variable is read here: what the library stages and how it evaluates is decided by the caller
     // through lc_ctx_set_option, never by the process environment)
     ctx_register(ctx.get());

@@ -534,3 +534,76 @@ def test_rowgroup_reader_c_program(tmp_path, product_lib):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rowgroup reader ok" in r.stdout
+
+
+@pytest.mark.parametrize("like_path", [4, 0])
+def test_index_builder_chunk_cuts_inside_escape_runs(product_lib, oracle, like_path):
+    """k_flat_build walks a value in 16-byte chunks of its COMPRESSED bytes and enters the FSST stream at every cut: the parity
+    of the run of 255s in front of a cut decides whether it falls between an escape marker and its literal, and the bigram
+    across the cut needs the last byte of the symbol (or the literal) before it.  Values built so that runs of escaped bytes —
+    0xFF as data included: marker 255 + literal 255 — lie across every cut position, against a symbol table trained on
+    OTHER text (most bytes travel as escapes, two compressed bytes each).  A bigram the builder loses is a value the index
+    never offers as a candidate: every needle below occurs in the data, so a lost bit is a lost hit."""
+    lo = oracle
+    rng = np.random.default_rng(20250926)
+    other = [b"mail.google.com/inbox", b"yandex.ru/search?text=", b"http://example.org/index.php", b"aaaabbbbccccdddd"] * 50
+    o, dt, _ = lo.strings_to_arrow(other)
+    st = lo.fsst_train(o, dt)
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1, like_path=like_path or None).build()
+    try:
+        cache.set_symbol_table(7100, lo.symtab_bytes(st))
+        ids, cases = [], []
+        for b in range(6):
+            pool = []
+            for k in range(180):
+                v = bytearray()
+                # plain text the table compresses (1 byte per several), then escaped stretches of every length 0..11 so that the
+                # cut positions 16, 32, 48, ... of the compressed stream land on every phase of marker / literal pairs
+                v += other[int(rng.integers(len(other)))][: int(rng.integers(0, 22))]
+                for _ in range(int(rng.integers(1, 9))):
+                    run = int(rng.integers(0, 12))
+                    kind = rng.random()
+                    if kind < 0.4:
+                        v += b"\xff" * run
+                    elif kind < 0.8:
+                        v += bytes(rng.integers(128, 256, size=run, dtype=np.uint8).tobytes())
+                    else:
+                        v += bytes([0xFF, int(rng.integers(1, 255))] * (run // 2))
+                    v += [b"go", b"ogle", b"ma", b"il", b"", b"x"][int(rng.integers(6))]
+                pool.append(bytes(v) + bytes([k & 0x7F, b]))  # (distinct values)
+            rows = [pool[int(i)] for i in rng.integers(0, len(pool), size=700)]
+            liquid, _ = lo.encode_byte_view(rows, st=st, fingerprints=True, arrow_type=lo.BT_BINARY)
+            eid = lc.ParquetArrayID.new(31, b, 3, 0)
+            cache.stage([eid], [liquid], [7100])
+            ids.append(eid)
+            cases.append((rows, liquid))
+        scan = cache.scan(ids)
+        offs = scan.segment_offsets
+        needles = []
+        for rows, _ in cases:                               # 2..6-byte windows out of the values, biased to the escaped parts
+            for _ in range(14):
+                v = rows[int(rng.integers(len(rows)))]
+                ff = [i for i in range(len(v) - 1) if v[i] >= 128]
+                a = ff[int(rng.integers(len(ff)))] if ff and rng.random() < 0.8 else int(rng.integers(max(len(v) - 1, 1)))
+                a = max(0, a - int(rng.integers(0, 3)))
+                nd = bytes(c for c in v[a: a + int(rng.integers(2, 7))] if c not in b"%_\\")
+                if len(nd) >= 2:
+                    needles.append(nd)
+        needles += [b"\xff\xff", b"\xff\xff\xff", b"go\xff", b"\xffma", b"le\xff\xff"]
+        n_hits = 0
+        for nd in needles:
+            expr = lc.LiquidExpr.try_new("like", b"%" + nd + b"%", pa.binary(), lc.CacheExpression.SUBSTRING_SEARCH)
+            mask, counts = scan.eval_to_host(expr)
+            bits = np.unpackbits(mask.view(np.uint8), bitorder="little")
+            for b, (rows, liquid) in enumerate(cases):
+                got = bits[int(offs[b]) * 64: int(offs[b]) * 64 + len(rows)].astype(bool)
+                want = np.array([nd in r for r in rows])
+                assert np.array_equal(got, want), (like_path, b, nd, int(got.sum()), int(want.sum()))
+                assert int(counts[b]) == int(want.sum())
+                n_hits += int(want.sum())
+        assert n_hits > 500
+        if like_path == 4:
+            assert "k_like_flat" in scan.explain(lc.LiquidExpr.try_new("like", b"%\xff\xff%", pa.binary(),
+                                                                       lc.CacheExpression.SUBSTRING_SEARCH))
+    finally:
+        cache.close()
