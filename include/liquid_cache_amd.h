@@ -145,7 +145,8 @@ struct ArrowArray {
  * device_ids == NULL selects the current HIP device.  n_devices == 0 with device_ids == NULL creates a HOST-ONLY
  * context that can transcode Arrow -> Liquid bytes and hold symbol tables but fails every staging / evaluation
  * call with LC_ERR_DEVICE (there is no CPU fallback for the compute path).  `max_hbm_bytes` == 0 means "as much as is free"
- * (reference default max_memory_bytes is 1 GiB; HBM has 288 GB, the arena grows in slabs). */
+ * (reference default max_memory_bytes is 1 GiB; HBM has 288 GB, the arena grows in slabs).  A device context also makes the
+ * HIP runtime load the library's kernel code objects now (a few milliseconds) rather than in front of a query's first launch. */
 LC_API lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t max_hbm_bytes, lc_ctx** out);
 LC_API void lc_ctx_destroy(lc_ctx* ctx);
 /* Staging options of a context (set them before staging; entries already staged keep what they were staged with).  The
