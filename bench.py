@@ -377,6 +377,7 @@ def compact_line(out, detail_path):
                            ("tpch_q6_chain_frac", ("tpch_q6_pushdown", "full_size", "frac")),
                            ("q21_pipeline_ms", ("q21_pipeline", "ms")),
                            ("byte_view_gather_after_like_ms", ("micro", "byte_view_gather_after_like", "kernel_ms")),
+                           ("byte_view_gather_after_like_slotted_ms", ("micro", "byte_view_gather_after_like", "slotted_call_ms")),
                            ("url_like_no_signatures_ms", ("url_like_no_signatures", "kernel_ms")),
                            ("url_like_no_fingerprints_ms", ("url_like_no_fingerprints", "kernel_ms")),
                            ("clickbench_sweep_ms", ("clickbench_pushdown_sweep", "ms_all_queries")),
@@ -562,31 +563,37 @@ def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_ex
     ctr = torch.zeros(4, dtype=torch.int64, device="cuda")
     c_ptr = [ctr.data_ptr() + 8 * i for i in range(4)]
 
-    def run_sparse():
+    gcap = min(hcap, data[0].numel() // 256)  # rows the projections are sized for (slotted form: 128 bytes per row + long values)
+
+    def run_sparse(slotted=True):
         N.check(cache._lib.lc_device_memset(cache.handle, ctr.data_ptr(), 0, 32, stream), cache.handle)
         url_scan.eval_hits(like_expr, hits.data_ptr(), hcap, c_ptr[0], 0, 0, 0, 0, stream, counters_zeroed=True)
         sp_scan.filter_hits(ne_expr, hits.data_ptr(), c_ptr[0], hcap, hits2.data_ptr(), hcap, c_ptr[1], stream, counters_zeroed=True)
-        url_scan.gather_bytes_hits(hits2.data_ptr(), c_ptr[1], hcap, views[0].data_ptr(), data[0].data_ptr(),
-                                   min(data[0].numel(), (1 << 31) - 1), c_ptr[2], 0, stream, counters_zeroed=True)
-        sp_scan.gather_bytes_hits(hits2.data_ptr(), c_ptr[1], hcap, views[1].data_ptr(), data[1].data_ptr(),
-                                  min(data[1].numel(), (1 << 31) - 1), c_ptr[3], 0, stream, counters_zeroed=True)
+        url_scan.gather_bytes_hits(hits2.data_ptr(), c_ptr[1], gcap, views[0].data_ptr(), data[0].data_ptr(),
+                                   min(data[0].numel(), (1 << 31) - 1), c_ptr[2], 0, stream, counters_zeroed=True, slotted=slotted)
+        sp_scan.gather_bytes_hits(hits2.data_ptr(), c_ptr[1], gcap, views[1].data_ptr(), data[1].data_ptr(),
+                                  min(data[1].numel(), (1 << 31) - 1), c_ptr[3], 0, stream, counters_zeroed=True, slotted=slotted)
 
-    for _ in range(2):
-        run_sparse()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        run_sparse()
-    torch.cuda.synchronize()
-    ms_s = (time.perf_counter() - t0) / iters * 1e3
+    def time_sparse(slotted):
+        for _ in range(2):
+            run_sparse(slotted)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run_sparse(slotted)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    ms_dense = time_sparse(False)
+    ms_s = time_sparse(True)  # (the buffers checked below are the slotted run's)
     cv = ctr.cpu().numpy()
     hv2 = hits2[: int(cv[1])].cpu().numpy().view(np.uint64)
     assert int(cv[1]) == k_out and np.array_equal(np.sort(hv2), np.sort(want_rows)), "sparse pipeline: rows differ from the mask form's"
     for c in range(2):
         lens = views[c][: int(cv[1]), 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0]
         assert int(lens.astype(np.int64).sum()) == (out["url_bytes"], out["phrase_bytes"])[c], "sparse pipeline: gathered bytes differ"
-    res.update(ms=ms_s, rows_per_s=url_scan.rows / (ms_s * 1e-3), rows_after_like=int(cv[0]),
-               kernels="k_like_flat (hit list) + k_pred_hits (SearchPhrase <> '' on the listed rows) + 2 x k_str_gather_hits",
+    res.update(ms=ms_s, ms_dense_data_buffers=ms_dense, rows_per_s=url_scan.rows / (ms_s * 1e-3), rows_after_like=int(cv[0]),
+               kernels="k_like_flat (hit list) + k_pred_hits (SearchPhrase <> '' on the listed rows) + 2 x k_str_gather_hits "
+                       "(LC_GATHER_SLOTTED: a row's bytes in its 128-byte slot; ms_dense_data_buffers: the dense form)",
                sparse_pipeline_equals_mask_form=True)
     # the step after the path: GROUP BY "SearchPhrase" with MIN("URL") and COUNT(*) as per-entry partials on the device
     # (lc_scan_group_partials) instead of handing the selected strings to a host-side partial aggregate
@@ -773,7 +780,7 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
             row_offs = torch.zeros(url_scan.entries + 1, dtype=torch.int64, device="cuda")
             refs = torch.zeros(cap, dtype=torch.int64, device="cuda")
             voffs = torch.zeros(cap + 1, dtype=torch.int64, device="cuda")
-            data = torch.zeros(cap * 128, dtype=torch.uint8, device="cuda")
+            data = torch.zeros(cap * 128 + (64 << 20), dtype=torch.uint8, device="cuda")  # (slotted form: cap slots + long values)
             for tag, m in (("byte_view_gather_1.5pct", m_1pct), ("byte_view_gather_after_like", m_like)):
                 def run():
                     url_scan.gather_bytes_async(row_offs.data_ptr(), refs.data_ptr(), voffs.data_ptr(), cap, data.data_ptr(),
@@ -834,6 +841,13 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                 ms_call = timed_c(0, n_c)
                 ms_h = timed_c(1, n_app)
                 assert int(n_b.item()) == n_app * nbytes, "appended gathers: byte total differs"
+                # LC_GATHER_SLOTTED: record i's bytes at i * 128 (longer values behind the slots): nothing to claim for the common
+                # value, no barrier, no store stage — the same Arrow array over a sparse buffer
+                lens_dense = views_t[:k, 0].clone()
+                ms_slot = timed_c(2, n_c)
+                same = bool(((views_t[:k, 0] & 0xFFFFFFFF) == (lens_dense & 0xFFFFFFFF)).all().item())
+                assert same, "slotted gather: lengths differ from the dense form's"
+                long_bytes = int(n_b.item())
                 # what it has to move: per row its record (8), key (2), offset pair (~8), prefix key (8), ~0.58 compressed
                 # bytes per decoded byte, the view (16) and the decoded bytes
                 need_h = k * (8 + 2 + 8 + 8 + 16) + int(nbytes * 0.58) + nbytes
@@ -842,7 +856,9 @@ def secondary_micro(cache, lc, N, args, rows, threads, torch, stream, iters, url
                             "kernel_bytes_per_launch": int(need_h), "achieved": need_h / (ms_h * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                             "unit": "GB/s", "frac": need_h / (ms_h * 1e-3) / 1e9 / HBM_PEAK_GBS, "timing": "back_to_back",
                             "traffic": None, "rows_out_per_s": k / (ms_h * 1e-3), "mask_form_ms": ms,
-                            "call_ms_with_counter_reset": ms_call, "appended_calls_timed": n_app}
+                            "call_ms_with_counter_reset": ms_call, "appended_calls_timed": n_app,
+                            "slotted_call_ms": ms_slot, "slotted_bytes_behind_the_slots": long_bytes,
+                            "slotted_rows_out_per_s": k / (ms_slot * 1e-3)}
         except Exception as e:  # noqa: BLE001
             out["byte_view_gather"] = {"error": "%s: %s" % (type(e).__name__, e)}
     try:  # date-part extraction over decoded Date32 values, in place (k_date_component / lossy reconstruction)

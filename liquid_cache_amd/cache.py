@@ -1216,12 +1216,14 @@ class Scan:
 
     def gather_bytes_hits(self, hits_ptr: int, n_hits_ptr: int, capacity_rows: int, views_ptr: int, data_ptr: int,
                           capacity_bytes: int, n_bytes_ptr: int, row_valid_ptr: int = 0, stream: int = 0,
-                          counters_zeroed: bool = False):
-        """The same for a byte-view column: Arrow BinaryView records (16 bytes per row) + one data buffer, one launch."""
+                          counters_zeroed: bool = False, slotted: bool = False):
+        """The same for a byte-view column: Arrow BinaryView records (16 bytes per row) + one data buffer, one launch.
+        `slotted` (LC_GATHER_SLOTTED): record i's bytes at i * 128 when they fit, longer values behind capacity_rows * 128."""
         N.check(self._lib.lc_scan_gather_bytes_hits(self._cache.handle, self._h, C.c_void_p(hits_ptr), C.c_void_p(n_hits_ptr),
                                                     capacity_rows, C.c_void_p(views_ptr), C.c_void_p(row_valid_ptr or None),
                                                     C.c_void_p(data_ptr or None), capacity_bytes, C.c_void_p(n_bytes_ptr),
-                                                    1 if counters_zeroed else 0, C.c_void_p(stream or None)), self._cache.handle)
+                                                    (1 if counters_zeroed else 0) | (2 if slotted else 0),
+                                                    C.c_void_p(stream or None)), self._cache.handle)
 
     def _dev(self, nbytes: int) -> C.c_void_p:
         p = C.c_void_p()
@@ -1277,7 +1279,7 @@ class Scan:
                     lib.lc_device_free(ctx, p)
         return hits, n, counts, total, first
 
-    def gather_bytes_hits_to_host(self, hits: np.ndarray, capacity_bytes: Optional[int] = None):
+    def gather_bytes_hits_to_host(self, hits: np.ndarray, capacity_bytes: Optional[int] = None, slotted: bool = False):
         """Convenience for tests: list of bytes / None, row i = record i of `hits` — decoded from the BinaryView records."""
         lib, ctx = self._lib, self._cache.handle
         hits = np.ascontiguousarray(hits, dtype=np.uint64)
@@ -1290,13 +1292,15 @@ class Scan:
             d_valid = self._dev(max(k, 1)); ptrs.append(d_valid)
             d_nb = self._dev(8); ptrs.append(d_nb)
             cap_b = 1 << 16 if capacity_bytes is None else int(capacity_bytes)
+            slots = max(k, 1) * 128 if slotted else 0  # (LC_GATHER_SLOTTED: the slots, then the values that fit none)
+            cap_b = max(cap_b, slots)
             while True:
                 d_data = self._dev(max(cap_b, 1))
                 try:
                     self.gather_bytes_hits(d_hits.value, d_n.value, max(k, 1), d_views.value, d_data.value, cap_b, d_nb.value,
-                                           d_valid.value)
+                                           d_valid.value, slotted=slotted)
                     N.check(lib.lc_stream_synchronize(ctx, None), ctx)
-                    need = int(self._from_dev(d_nb, np.uint64, 1)[0])
+                    need = slots + int(self._from_dev(d_nb, np.uint64, 1)[0])
                     if need <= cap_b:
                         data = self._from_dev(d_data, np.uint8, need).tobytes()
                         break
@@ -1322,6 +1326,8 @@ class Scan:
             else:
                 buf, off = (int(x) for x in views[i, 8:16].view(np.int32))
                 assert buf == 0
+                if slotted:
+                    assert off == i * 128 if ln <= 128 else off >= slots, "slotted gather: value outside its place"
                 v = data[off: off + ln]
                 assert v[:4] == views[i, 4:8].tobytes(), "view prefix differs from the value"
                 out.append(v)

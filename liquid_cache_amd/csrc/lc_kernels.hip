@@ -4092,7 +4092,13 @@ struct alignas(16) LdsSymtab {
 };
 static_assert(sizeof(LdsSymtab) == sizeof(DevSymtab) && sizeof(LdsSymtab) == 2304, "LdsSymtab mirrors DevSymtab");
 constexpr uint32_t kGatherStage = 6144;
+// LC_GATHER_SLOTTED: record i's bytes start at i * kGatherSlot when they fit a slot; longer values are appended behind the
+// slots (capacity_rows * kGatherSlot) through the byte counter.  No space has to be claimed for the common value, so the
+// workgroup's two barriers and its returning atomic — the serialized part of the dense form — are gone, and with them the
+// 6 KB store stage per wave (16 workgroups per CU instead of 4).
+constexpr uint32_t kGatherSlot = LC_GATHER_SLOT_BYTES;
 
+template <bool kSlotted>
 __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __restrict__ descs,
                                                                const DevSymtab* __restrict__ symtabs,
                                                                const uint64_t* __restrict__ hits,
@@ -4101,7 +4107,7 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
                                                                uint8_t* __restrict__ data, uint64_t cap_bytes,
                                                                unsigned long long* __restrict__ n_bytes) {
     __shared__ LdsSymtab s_tab[kWavesPerBlock];
-    __shared__ __attribute__((aligned(16))) uint8_t s_out[kWavesPerBlock][kGatherStage + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_out[kSlotted ? 1 : kWavesPerBlock][kSlotted ? 16 : kGatherStage + 16];
     __shared__ unsigned long long s_tot[2][kWavesPerBlock], s_base[2];
     const uint64_t k = min(uint64_t(*n_hits), cap_rows);
     const uint64_t n_waves = uint64_t(gridDim.x) * kWavesPerBlock;
@@ -4179,21 +4185,29 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
                 }
             }
         }
-        // space in the data buffer: the batch's values are neighbours there
-        const uint32_t incl = wave_inclusive_sum(len);
-        const uint32_t tot = read_lane(incl, kWave - 1);
-        if (lane == 0) s_tot[it][wave] = tot;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned long long t = 0;
-            for (uint32_t w = 0; w < uint32_t(kWavesPerBlock); w++) t += s_tot[it][w];
-            s_base[it] = t ? atomicAdd(n_bytes, t) : 0ull;
+        // space in the data buffer: the batch's values are neighbours there (dense form), or every record has its slot
+        uint32_t tot = 0;
+        unsigned long long b = 0;
+        uint64_t off;
+        if constexpr (kSlotted) {
+            off = i * kGatherSlot;
+            if (live && len > kGatherSlot) off = cap_rows * uint64_t(kGatherSlot) + atomicAdd(n_bytes, (unsigned long long)len);
+        } else {
+            const uint32_t incl = wave_inclusive_sum(len);
+            tot = read_lane(incl, kWave - 1);
+            if (lane == 0) s_tot[it][wave] = tot;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned long long t = 0;
+                for (uint32_t w = 0; w < uint32_t(kWavesPerBlock); w++) t += s_tot[it][w];
+                s_base[it] = t ? atomicAdd(n_bytes, t) : 0ull;
+            }
+            __syncthreads();
+            b = s_base[it];
+            for (uint32_t w = 0; w < wave; w++) b += s_tot[it][w];
+            b = uniform_u64(b);
+            off = b + incl - len;
         }
-        __syncthreads();
-        unsigned long long b = s_base[it];
-        for (uint32_t w = 0; w < wave; w++) b += s_tot[it][w];
-        b = uniform_u64(b);
-        const uint64_t off = b + incl - len;
         const bool fits = off + len <= cap_bytes;
         uint32_t* v = views + 4u * i;
         if (live) {
@@ -4254,7 +4268,7 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
         // ---- 64 rows, a lane per row.  The batch's bytes are one range [b, b + tot) of the data buffer: decoded into LDS (byte
         // stores), they leave as whole 16-byte pieces — 8-byte stores straight from the lanes hit 64 different lines per
         // instruction, each a partial line for the memory system to merge (see k_str_decode_sel).
-        const bool staged = in_lds && tot <= kGatherStage && b + tot <= cap_bytes && todo == todo0;
+        const bool staged = !kSlotted && in_lds && tot <= kGatherStage && b + tot <= cap_bytes && todo == todo0;
         const uint64_t g0 = uint64_t(reinterpret_cast<uintptr_t>(data)) + b;
         const uint32_t mis = uint32_t(g0) & 15u;  // the LDS copy has the alignment of its place in memory
         uint32_t h0 = 0, h1 = 0, h2 = 0;
@@ -5663,11 +5677,24 @@ hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, con
 
 hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_hits,
                                   const unsigned long long* d_n_hits, uint64_t cap_rows, uint32_t* d_views, uint8_t* d_row_valid,
-                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, hipStream_t stream) {
+                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, bool slotted,
+                                  hipStream_t stream) {
     if (cap_rows == 0) return hipSuccess;
+    if (slotted) {
+        // 9 KB of LDS per workgroup, no barrier; 79 VGPRs: six workgroups per CU are resident, but a value per wave (R = 1) beats one
+        // round of longer batches: 6 / 8 / 12 / 16 / 24 workgroups per CU 25.3 / 25.4 / 22.1 / 22.7 / 21.7 us per stand-alone call
+#ifndef LC_GATHER_SLOT_WGS
+#define LC_GATHER_SLOT_WGS 16
+#endif
+        const uint32_t grid = uint32_t(std::min<uint64_t>((cap_rows + kWavesPerBlock - 1) / kWavesPerBlock,
+                                                          uint64_t(device_cus()) * LC_GATHER_SLOT_WGS));
+        hipLaunchKernelGGL(k_str_gather_hits<true>, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_hits, d_n_hits,
+                           cap_rows, d_views, d_row_valid, d_data, cap_bytes, d_n_bytes);
+        return hipGetLastError();
+    }
     // 34 KB of LDS per workgroup: four of them per CU are resident, and a latency-bound gather wants no second round
     const uint32_t grid = uint32_t(std::min<uint64_t>((cap_rows + kWavesPerBlock - 1) / kWavesPerBlock, uint64_t(device_cus()) * 4));
-    hipLaunchKernelGGL(k_str_gather_hits, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_hits, d_n_hits, cap_rows,
+    hipLaunchKernelGGL(k_str_gather_hits<false>, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_hits, d_n_hits, cap_rows,
                        d_views, d_row_valid, d_data, cap_bytes, d_n_bytes);
     return hipGetLastError();
 }

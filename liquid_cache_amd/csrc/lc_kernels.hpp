@@ -378,7 +378,7 @@ hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, con
                                     hipStream_t stream);
 hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_hits,
                                   const unsigned long long* d_n_hits, uint64_t cap_rows, uint32_t* d_views, uint8_t* d_row_valid,
-                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, hipStream_t stream);
+                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, bool slotted, hipStream_t stream);
 // a predicate over the rows of a hit list (k_pred_hits): lane_log2 0 = byte views (op on the literal / pattern bytes; lit_len <=
 // kInlineNeedle travels in the kernel arguments from h_lit, longer literals from the device copy d_lit), 3..6 = fixed width
 struct HitsPredLaunch {

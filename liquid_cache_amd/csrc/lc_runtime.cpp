@@ -4250,6 +4250,9 @@ lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hi
         return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes_hits covers byte-view columns");
     if (capacity_bytes > 0x7FFFFFFFull) return fail(LC_ERR_INVALID, "a BinaryView offset is an i32: capacity_bytes must stay below 2 GiB");
+    const bool slotted = (flags & LC_GATHER_SLOTTED) != 0;
+    if (slotted && capacity_rows > capacity_bytes / LC_GATHER_SLOT_BYTES)
+        return fail(LC_ERR_INVALID, "LC_GATHER_SLOTTED: capacity_bytes must hold capacity_rows slots of LC_GATHER_SLOT_BYTES");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(launch_zero_small(d_n_bytes, 8, st));
     if (scan->n == 0 || capacity_rows == 0) return LC_OK;
@@ -4257,7 +4260,7 @@ lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hi
     LC_HIP(launch_str_gather_hits(static_cast<const StrDesc*>(scan->d_descs), scan->d_symtabs, static_cast<const uint64_t*>(d_hits),
                                   static_cast<const unsigned long long*>(d_n_hits), capacity_rows, static_cast<uint32_t*>(d_views),
                                   static_cast<uint8_t*>(d_row_valid), static_cast<uint8_t*>(d_data), capacity_bytes,
-                                  static_cast<unsigned long long*>(d_n_bytes), st));
+                                  static_cast<unsigned long long*>(d_n_bytes), slotted, st));
     return LC_OK;
     });
 }

@@ -34,7 +34,7 @@ def main():
     ctr = torch.zeros(4, dtype=torch.int64, device="cuda")  # n_hits, n_hits2, n_bytes
     total = torch.zeros(1, dtype=torch.int64, device="cuda")
     views = torch.zeros((cap, 2), dtype=torch.int64, device="cuda")
-    data = torch.zeros(cap * 128, dtype=torch.uint8, device="cuda")
+    data = torch.zeros(cap * 128 + (64 << 20), dtype=torch.uint8, device="cuda")
     p = ctr.data_ptr()
 
     def ev():
@@ -49,6 +49,10 @@ def main():
     def gat():
         scan.gather_bytes_hits(hits.data_ptr(), p, cap, views.data_ptr(), data.data_ptr(), min(data.numel(), (1 << 31) - 1), p + 16,
                                0, stream, counters_zeroed=True)
+
+    def gat_slotted():
+        scan.gather_bytes_hits(hits.data_ptr(), p, cap, views.data_ptr(), data.data_ptr(), min(data.numel(), (1 << 31) - 1), p + 16,
+                               0, stream, counters_zeroed=True, slotted=True)
 
     def timed(fn, zero):
         ctr.zero_()
@@ -81,8 +85,9 @@ def main():
     if dbg: print("filter ok", t_f, int(ctr[1].item()), flush=True)
     # (timed() left n_hits from its last ev-less loop untouched: counters 0 is still the eval's)
     t_g = timed(gat, 16)
-    print("%-8s count-only %.2f us  eval_hits(+memset) %.2f us  filter_hits(+memset) %.2f us  gather_bytes_hits(+memset) %.2f us  hits %d"
-          % (tag, t_cnt, t_ev, t_f, t_g, n_hits), flush=True)
+    t_gs = timed(gat_slotted, 16)
+    print("%-8s count-only %.2f us  eval_hits(+memset) %.2f us  filter_hits(+memset) %.2f us  gather_bytes_hits(+memset) %.2f us  "
+          "slotted %.2f us  hits %d" % (tag, t_cnt, t_ev, t_f, t_g, t_gs, n_hits), flush=True)
     scan.close()
     cache.close()
 

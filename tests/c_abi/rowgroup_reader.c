@@ -133,19 +133,23 @@ static void* worker(void* arg) {
                 if (strstr(tmp, "google") && make_num(rg, b, i) > LIT && n_want < CAP) want[n_want++] = ((uint64_t)b << 32) | (uint64_t)i;
             }
         for (int rep = 0; rep < 3; rep++) {
-            /* ---- sparse form: four counters, one memset */
+            /* ---- sparse form: four counters, one memset.  The second repetition takes the URL projection with a SLOTTED data
+             * buffer (row r's bytes at r * LC_GATHER_SLOT_BYTES, longer values behind CAP slots): same views, checked the same way */
+            const int slotted = rep == 1;
             uint8_t* c = (uint8_t*)d_ctr;
             if (lc_device_memset(ctx, d_ctr, 0, 32, stream) != LC_OK) { w->rc = 3; return NULL; }
             if (lc_scan_eval_hits(ctx, us, &like, 1, NULL, d_hits1, CAP, c, NULL, NULL, NULL, LC_HITS_COUNTERS_ZEROED, stream) != LC_OK ||
                 lc_scan_filter_hits(ctx, ns, &gt, d_hits1, c, CAP, d_hits2, CAP, c + 8, LC_HITS_COUNTERS_ZEROED, stream) != LC_OK ||
-                lc_scan_gather_bytes_hits(ctx, us, d_hits2, c + 8, CAP, d_views, d_valid, d_data, CAP * 160, c + 16, LC_HITS_COUNTERS_ZEROED, stream) != LC_OK ||
+                lc_scan_gather_bytes_hits(ctx, us, d_hits2, c + 8, CAP, d_views, d_valid, d_data, CAP * 160, c + 16,
+                                          LC_HITS_COUNTERS_ZEROED | (slotted ? LC_GATHER_SLOTTED : 0u), stream) != LC_OK ||
                 lc_scan_gather_fixed_hits(ctx, ns, d_hits2, c + 8, CAP, d_vals, NULL, stream) != LC_OK) { w->rc = 4; return NULL; }
             uint64_t ctr[4];
             if (lc_device_to_host(ctx, ctr, d_ctr, 32, stream) != LC_OK) { w->rc = 5; return NULL; }
             const uint64_t k = ctr[1];
-            if (k != n_want || ctr[0] < k || ctr[0] > CAP || ctr[2] > CAP * 160) { fprintf(stderr, "rg %d: %llu rows, want %llu (like %llu)\n", rg, (unsigned long long)k, (unsigned long long)n_want, (unsigned long long)ctr[0]); w->rc = 6; return NULL; }
+            const uint64_t data_used = slotted ? (uint64_t)CAP * LC_GATHER_SLOT_BYTES + ctr[2] : ctr[2];
+            if (k != n_want || ctr[0] < k || ctr[0] > CAP || data_used > CAP * 160) { fprintf(stderr, "rg %d: %llu rows, want %llu (like %llu)\n", rg, (unsigned long long)k, (unsigned long long)n_want, (unsigned long long)ctr[0]); w->rc = 6; return NULL; }
             if (lc_device_to_host(ctx, hits, d_hits2, k * 8, stream) || lc_device_to_host(ctx, views, d_views, k * 16, stream) ||
-                lc_device_to_host(ctx, data, d_data, ctr[2] ? ctr[2] : 1, stream) || lc_device_to_host(ctx, vals, d_vals, k * 8, stream) ||
+                lc_device_to_host(ctx, data, d_data, data_used ? data_used : 1, stream) || lc_device_to_host(ctx, vals, d_vals, k * 8, stream) ||
                 lc_device_to_host(ctx, valid, d_valid, k ? k : 1, stream)) { w->rc = 7; return NULL; }
             uint64_t sorted[CAP];
             memcpy(sorted, hits, k * 8);
@@ -158,6 +162,9 @@ static void* worker(void* arg) {
                 memcpy(&vl, views + r * 16, 4);
                 memcpy(&vo, views + r * 16 + 12, 4);
                 const uint8_t* p = vl <= 12 ? views + r * 16 + 4 : data + vo;
+                if (slotted && vl > 12 && (vl <= (int32_t)LC_GATHER_SLOT_BYTES ? (uint64_t)vo != r * LC_GATHER_SLOT_BYTES
+                                                                                  : (uint64_t)vo < (uint64_t)CAP * LC_GATHER_SLOT_BYTES)) {
+                    fprintf(stderr, "rg %d row %llu: slotted value outside its place\n", rg, (unsigned long long)r); w->rc = 15; return NULL; }
                 if (!valid[r] || vl != n || memcmp(p, tmp, (size_t)n) != 0 || (vl > 12 && memcmp(views + r * 16 + 4, tmp, 4) != 0) ||
                     vals[r] != make_num(rg, b, i)) { fprintf(stderr, "rg %d row %llu: value mismatch\n", rg, (unsigned long long)r); w->rc = 9; return NULL; }
             }

@@ -179,6 +179,7 @@ def test_gather_bytes_from_hit_list(product_lib, oracle, grouped_cases):
             got = scan.gather_bytes_hits_to_host(hits)
             want = [truth[int(h >> np.uint64(32))][int(h & np.uint64(0xFFFFFFFF))] for h in hits]
             assert got == want and all(nd in v for v in got)
+            assert scan.gather_bytes_hits_to_host(hits, slotted=True) == want   # LC_GATHER_SLOTTED: same array, sparse buffer
         # (b) random rows incl. nulls, in list order (any order is legal input): small and large lists (lane-per-row decode)
         all_refs = np.concatenate([(np.uint64(e) << np.uint64(32)) | np.arange(n, dtype=np.uint64) for e, n in enumerate(lens)])
         for k in (1, 7, 63, 64, 65, 900, len(all_refs)):
@@ -186,6 +187,8 @@ def test_gather_bytes_from_hit_list(product_lib, oracle, grouped_cases):
             got = scan.gather_bytes_hits_to_host(refs, capacity_bytes=64)  # (too small at first: retried with *d_n_bytes)
             want = [truth[int(h >> np.uint64(32))][int(h & np.uint64(0xFFFFFFFF))] for h in refs]
             assert got == want, k
+            # (slotted: the slots always fit, the values longer than a slot are what the retry is for)
+            assert scan.gather_bytes_hits_to_host(refs, capacity_bytes=64, slotted=True) == want, k
         scan.close()
     finally:
         cache.close()
@@ -194,7 +197,7 @@ def test_gather_bytes_from_hit_list(product_lib, oracle, grouped_cases):
 def test_gather_bytes_hits_length_classes(gpu_cache, oracle):
     """Values of 0, 1..12 (inline views), 13, 254, 255 (length byte saturates) and 700 bytes, escapes, a shared prefix."""
     rng = np.random.default_rng(3)
-    lengths = [0, 1, 4, 11, 12, 13, 14, 100, 253, 254, 255, 256, 700]
+    lengths = [0, 1, 4, 11, 12, 13, 14, 100, 104, 105, 106, 127, 128, 129, 253, 254, 255, 256, 700]
     pool = [bytes(rng.integers(32, 127, size=n, dtype=np.uint8)) for n in lengths] + [b"\xff\xfe\x00\xff" * 5, "ÿñ".encode() * 9]
     for shared in (b"", b"http://www.example.com/"):
         vals = [shared + p for p in pool]
@@ -212,6 +215,8 @@ def test_gather_bytes_hits_length_classes(gpu_cache, oracle):
             got = scan.gather_bytes_hits_to_host(sub)
             want = [rows[int(h >> np.uint64(32)) * 1000 + int(h & np.uint64(0xFFFFFFFF))] for h in sub]
             assert got == want
+            # values of exactly 128 bytes and of 129 sit on the two sides of the slot size (shared prefix 23 + 105 / 106 ...)
+            assert scan.gather_bytes_hits_to_host(sub, slotted=True) == want
         scan.close()
 
 
