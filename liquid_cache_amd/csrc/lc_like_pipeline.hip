@@ -1149,7 +1149,8 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
     }
     const int lane = lane_id(), wave = wave_id();
     // work items: chunk c of value j covers compressed bytes [start + c kFbChunk, start + (c + 1) kFbChunk) of it
-    const uint32_t n_chunks = valid ? (stop0 - start0 + kFbChunk - 1u) / kFbChunk : 0u;
+    // (stop < start cannot pass staging's checks; should it ever, the value contributes nothing instead of 2^28 work items)
+    const uint32_t n_chunks = (valid && stop0 > start0) ? (stop0 - start0 + kFbChunk - 1u) / kFbChunk : 0u;
     const uint32_t incl = wave_inclusive_sum(n_chunks);
     if (lane == 63) s_wave_tot[wave] = incl;
     s_range[2u * t] = start0;
