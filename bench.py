@@ -106,7 +106,7 @@ def parse_args(argv=None):
                    help="skip the L3-cold timing (rocprofv3 --stats runs: the kernel average then only holds hot launches)")
     p.add_argument("--secondary-rows", type=int, default=0, help="rows of the secondary workloads (0 = --rows)")
     p.add_argument("--secondary-set", default="all",
-                   help="comma list of the secondary groups to run: q21,rowgroup,int,micro,q6,sweep,staging,like (kernel A/B runs)")
+                   help="comma list of the secondary groups to run: q21,rowgroup,int,micro,q6,sweep,staging,like,concurrent (kernel A/B runs)")
     p.add_argument("--sweep-rows", type=int, default=0,
                    help="rows of the ClickBench pushdown sweep (config 5); 0 = the whole table (--rows)")
     p.add_argument("--seed", type=int, default=42)
@@ -382,6 +382,7 @@ def compact_line(out, detail_path):
                            ("url_like_no_fingerprints_ms", ("url_like_no_fingerprints", "kernel_ms")),
                            ("clickbench_sweep_ms", ("clickbench_pushdown_sweep", "ms_all_queries")),
                            ("like_stream_cached_ms_per_query", ("mixed_table_like_stream", "indexes_cached_between_queries", "ms_per_query_mean")),
+                           ("concurrent_table_scans_rows_per_s", ("concurrent_table_scans", "rows_per_s")),
                            ("like_stream_rebuilt_ms_per_query", ("mixed_table_like_stream", "budget_of_3_indexes_lru_thrash", "ms_per_query_mean")),
                            ("rowgroup_rows_per_s", ("rowgroup_granularity", "rows_per_s")),
                            ("eval_predicate_call_us", ("rowgroup_granularity", "eval_predicate_call_us"))):
@@ -945,6 +946,44 @@ def secondary_rowgroup(cache, lc, N, args, ids, expr, whole_scan_hits, rows):
             out["eval_predicate_hits_first_%d_entries" % n_e] = int(hits.value)
         else:
             out["eval_predicate_call_error"] = rc
+    return out
+
+
+def secondary_concurrent_tables(cache, N, args, tables, expr, want_hits, rows_per_table):
+    """Throughput when several independent whole-table scans are in flight at once (what a server running queries of several
+    sessions does): one lc_scan_eval_count per TABLE and pass, T host threads on their own streams (lc_bench_rowgroup_run with a
+    table as the unit; the scans and their indexes are created in an untimed first pass).  The headline `value` stays the
+    ONE-stream figure — a scan is latency bound (one wave per group, ~1 round of the device), so a second stream fills what
+    the first leaves idle; this says by how much."""
+    import ctypes as C
+    B = N.load_bench()
+    ids_np = np.ascontiguousarray(np.concatenate([np.asarray([int(e) for e in t], dtype=np.uint64) for t in tables]))
+    begins = np.ascontiguousarray(np.cumsum([0] + [len(t) for t in tables]).astype(np.uint64))
+    pred = expr.as_predicate()
+    out = {"tables": len(tables), "rows_per_table": int(rows_per_table),
+           "driver": "lc_bench_rowgroup_run: unit = a whole table, one lc_scan_eval_count per unit and pass, T threads x own stream"}
+    runs = {}
+    for threads in (1, 2, 4, 8):
+        if threads > len(tables):
+            break
+        st = N.RowGroupStats()
+        rc = B.lc_bench_rowgroup_run(cache._ctx, len(tables), begins.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                     ids_np.ctypes.data_as(C.POINTER(C.c_uint64)), C.cast(C.byref(pred), C.c_void_p), threads, 16, 0, 1,
+                                     C.byref(st))
+        if rc != 0:
+            runs["t%d" % threads] = {"error": "lc_bench_rowgroup_run rc %d" % rc}
+            continue
+        assert int(st.hits) == int(want_hits), "concurrent table scans: COUNT(*) %d != %d" % (st.hits, want_hits)
+        n_scans = int(st.units) * int(st.passes)
+        runs["t%d" % threads] = {"threads": threads, "us_per_scan": st.wall_s / n_scans * 1e6,
+                                 "rows_per_s": rows_per_table * n_scans / st.wall_s}
+    out["runs"] = runs
+    ok = [r for r in runs.values() if "rows_per_s" in r]
+    if ok:
+        best = max(ok, key=lambda r: r["rows_per_s"])
+        out["rows_per_s"] = best["rows_per_s"]
+        out["best_threads"] = best["threads"]
+        out["us_per_scan"] = best["us_per_scan"]
     return out
 
 
@@ -1903,6 +1942,14 @@ def main():
             steady_build_ms = round(float(scans[n_rot - 1].info().index_build_ms), 3)
         except Exception:  # noqa: BLE001
             steady_build_ms = None
+    concurrent = None
+    if rank == 0 and world == 1 and args.workload == "url_like" and n_rot >= 4 and not args.no_secondary and (
+            args.secondary_set == "all" or "concurrent" in args.secondary_set.split(",")):
+        try:  # (while the rotation's tables are resident)
+            nt = min(8, n_rot)
+            concurrent = secondary_concurrent_tables(cache, N, args, rot_ids[:nt], expr, sum(rot_hits[:nt]), int(scan.rows))
+        except Exception as e:  # noqa: BLE001
+            concurrent = {"error": "%s: %s" % (type(e).__name__, e)}
     for r in range(1, n_rot):  # the other tables of the rotation have done their work
         scans[r].close()
     like_stream = None
@@ -2109,6 +2156,8 @@ def main():
         sec = {}
         if like_stream is not None:
             sec["mixed_table_like_stream"] = like_stream
+        if concurrent is not None:
+            sec["concurrent_table_scans"] = concurrent
         sec_rows = args.secondary_rows or args.rows
         groups = set(args.secondary_set.split(","))
         want = lambda g: "all" in groups or g in groups  # noqa: E731
