@@ -181,6 +181,22 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
  * are kept for the next scan over the same publications of the same entries (oldest first out; 0: none). */
 #define LC_OPT_LIKE_INDEX_BUDGET_BYTES 7
 #define LC_OPT_LIKE_INDEX_CACHE 8
+/* LC_OPT_LIKE_INDEX_ASYNC (default 1, round 6): the scan-level LIKE indexes are built OFF the query path — a scan's first LIKE
+ * is answered at once from the entry-level index (which exists since staging) while the context's builder thread builds the
+ * scan-level one on a stream of its own; evaluations switch when it is in place.  This is where the reference puts its
+ * prefilter construction as well: outside the read path (at insert time under the SubstringSearch hint,
+ * byte_view_array/conversions.rs:353-355).  A build that would have to EVICT another scan's cached index is only started once
+ * the asking scan has served 8 LIKE evaluations (an index costs ~4 ms of device time per 100 M rows and repays ~13 us per
+ * evaluation).  Results are identical before, during and after the build (tested).  0: the first LIKE of a scan waits for
+ * the build, as before round 6.  lc_scan_index_wait blocks until the builds in flight for a scan are in place
+ * (lc_scan_explain and lc_scan_info_get do the same, so that they describe the steady state).
+ * LC_OPT_SCAN_CACHE (default 8, round 6): scans given back with lc_scan_destroy are kept, and lc_scan_create over an entry-id
+ * list seen before returns the kept scan — no entry look-ups, no descriptor upload, no records / automata / plans to rebuild —
+ * as long as none of its entries has been replaced or evicted since (those scans are destroyed when that happens, and
+ * their pins with them).  The reference's reader names the entries of a row group per query and holds no scan objects
+ * (liquid_cache_reader.rs:264-339); a host that follows it creates a scan per query.  0: every lc_scan_destroy frees the scan. */
+#define LC_OPT_LIKE_INDEX_ASYNC 9
+#define LC_OPT_SCAN_CACHE 10
 LC_API lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value);
 LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
 LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);
@@ -460,6 +476,9 @@ typedef struct {
     int32_t reserved;
 } lc_scan_info;
 LC_API lc_status lc_scan_info_get(lc_scan* scan, lc_scan_info* out);
+/* Blocks until the index builds in flight for this scan (LC_OPT_LIKE_INDEX_ASYNC) have finished and their results are in place:
+ * the next evaluation runs on the scan-level index if the scan got one.  Returns at once when nothing is being built. */
+LC_API lc_status lc_scan_index_wait(lc_scan* scan);
 
 /* Byte accounting of ONE evaluation of `pred` over the scan, for roofline reports:
  *   *out_algorithmic  the reference algorithm's bytes: packed values / keys + selection + validity + output, and for
@@ -525,6 +544,29 @@ LC_API lc_status lc_scan_eval_or(lc_ctx* ctx, uint32_t n, lc_scan* const* scans,
 LC_API lc_status lc_scan_eval_count(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
                                     const void* d_selection, void* d_mask_out, void* d_counts_out, void* d_total_out,
                                     void* stream);
+
+/* MANY ROW GROUPS PER CALL (round 6).  The reference evaluates a pushed-down predicate per row group and batch
+ * (LiquidStream / LiquidCacheReader: liquid_stream.rs:358-430, liquid_cache_reader.rs:297-339); a device wants the launch to
+ * cover many of them.  lc_scan_eval_count_groups is lc_scan_eval_count with PER-ROW-GROUP results: the scan's entries are cut
+ * into n_groups consecutive groups — group g holds entries [group_ends[g - 1], group_ends[g]) with group_ends[-1] = 0 and
+ * group_ends[n_groups - 1] == lc_scan_entries(scan) (host array) — and d_group_counts_out (n_groups u64, device) receives each
+ * group's hit count from ONE evaluation launch plus one small reduction.  d_mask_out, d_counts_out (per entry) and
+ * d_total_out stay optional.  Asynchronous on `stream`. */
+LC_API lc_status lc_scan_eval_count_groups(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
+                                           const void* d_selection, uint32_t n_groups, const uint32_t* group_ends,
+                                           void* d_group_counts_out, void* d_mask_out, void* d_counts_out, void* d_total_out,
+                                           void* stream);
+/* The same in the reference's call shape, host in / host out: the entries of MANY row groups of one column named by id
+ * (row group g = entry_ids[group_ends[g - 1] .. group_ends[g])), no scan object in the caller's hands — the context's scan cache
+ * (LC_OPT_SCAN_CACHE) makes the second call over a list O(1).  out_group_counts: n_groups u64 (host).  out_mask (optional,
+ * host): the hit mask in scan layout — per entry ceil(len / 64) u64 words, entries concatenated — of out_mask_words words
+ * (the sum of ceil(len / 64) over the entries; LC_ERR_INVALID, with the number in the message, if too small; rows past an
+ * entry's length are zero).  out_total (optional): the COUNT(*) of the whole list.  Runs on the calling thread's stream
+ * and returns when the results are in the caller's buffers.  LC_NOT_STAGED when an entry is absent (the reference's `None`). */
+LC_API lc_status lc_eval_predicate_row_groups(lc_ctx* ctx, uint64_t n_entries, const uint64_t* entry_ids, uint32_t n_groups,
+                                              const uint32_t* group_ends, const lc_predicate* preds, uint32_t n_preds,
+                                              uint64_t* out_group_counts, uint64_t* out_mask, uint64_t out_mask_words,
+                                              uint64_t* out_total);
 
 /* get-with-selection over a whole scan for fixed-width columns: compacts the selected rows' decoded values
  * (original Arrow value width) into d_values_out in row order.  d_row_offsets (n+1 u64, device) receives the

@@ -19,6 +19,7 @@ LIT_I64, LIT_U64, LIT_F32, LIT_F64, LIT_BYTES, LIT_I128, LIT_BOOL = range(7)
 HINT_NONE, HINT_SUBSTRING_SEARCH, HINT_PREDICATE_COLUMN = 0, 1, 2
 OPT_SIGNATURE_INDEX, OPT_ROW_LISTS, OPT_HOST_BUILT_INDEX, OPT_LIKE_PIPELINE_MIN_ENTRIES, OPT_LIKE_PATH, OPT_LIKE_MANY_HINT = 1, 2, 3, 4, 5, 6
 OPT_LIKE_INDEX_BUDGET_BYTES, OPT_LIKE_INDEX_CACHE = 7, 8
+OPT_LIKE_INDEX_ASYNC, OPT_SCAN_CACHE = 9, 10
 HITS_COUNTERS_ZEROED, GATHER_SLOTTED, GATHER_SLOT_BYTES = 1, 2, 128  # flags of the hit-list calls
 
 
@@ -85,7 +86,7 @@ EXPORTED_SYMBOLS = [
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize",
     "lc_stream_create", "lc_stream_destroy",
     "lc_scan_eval_hits", "lc_scan_mask_to_hits", "lc_scan_gather_fixed_hits", "lc_scan_gather_bytes_hits", "lc_scan_info_get",
-    "lc_scan_filter_hits",
+    "lc_scan_filter_hits", "lc_scan_index_wait", "lc_scan_eval_count_groups", "lc_eval_predicate_row_groups",
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
@@ -214,6 +215,12 @@ def load():
     L.lc_scan_eval_count.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, vp, vp, vp]
     L.lc_scan_gather_fixed.restype = i32; L.lc_scan_gather_fixed.argtypes = [vp, vp, vp, vp, u64, vp, vp]
     L.lc_scan_info_get.restype = i32; L.lc_scan_info_get.argtypes = [vp, P(ScanInfo)]
+    L.lc_scan_index_wait.restype = i32; L.lc_scan_index_wait.argtypes = [vp]
+    L.lc_scan_eval_count_groups.restype = i32
+    L.lc_scan_eval_count_groups.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, C.c_uint32, P(C.c_uint32), vp, vp, vp, vp, vp]
+    L.lc_eval_predicate_row_groups.restype = i32
+    L.lc_eval_predicate_row_groups.argtypes = [vp, u64, P(u64), C.c_uint32, P(C.c_uint32), P(Predicate), C.c_uint32, P(u64), P(u64), u64,
+                                               P(u64)]
     L.lc_scan_eval_hits.restype = i32
     L.lc_scan_eval_hits.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, u64, vp, vp, vp, vp, C.c_uint32, vp]
     L.lc_scan_filter_hits.restype = i32

@@ -406,12 +406,22 @@ class LiquidCacheBuilder:
     """`LiquidCacheBuilder::new()...build()` — options that belong to the cache manager (policies, disk store) are
     out of scope here; batch size and the memory budget are kept."""
 
+    # process-wide defaults of `options` (a test session pins LC_OPT_LIKE_INDEX_ASYNC = 0 here so that WHICH kernel answers an
+    # evaluation does not depend on how far a background build has come; the library itself reads no environment variable)
+    default_options: dict = {}
+
     def __init__(self):
         self.batch_size = 8192
         self.max_memory_bytes = 0  # 0: bounded by HBM only (the reference default is 1 GiB of host RAM)
         self.device: Optional[int] = None
         self.host_only = False
-        self.options = {}  # lc_ctx_set_option(option, value) pairs applied right after the context is created
+        # lc_ctx_set_option(option, value) pairs applied right after the context is created
+        self.options = dict(LiquidCacheBuilder.default_options)
+
+    def with_option(self, option: int, value: int) -> "LiquidCacheBuilder":
+        """Any lc_ctx_set_option pair (N.OPT_*), applied when the context is created."""
+        self.options[int(option)] = int(value)
+        return self
 
     @staticmethod
     def new() -> "LiquidCacheBuilder":
@@ -826,6 +836,35 @@ class LiquidCache:
     def scan(self, entry_ids: Sequence[int]) -> "Scan":
         return Scan(self, entry_ids)
 
+    def eval_predicate_row_groups(self, entry_ids, group_ends, exprs, want_mask: bool = False):
+        """lc_eval_predicate_row_groups: the predicate over MANY row groups of one column in one call, host in / host out
+        (row group g = entry_ids[group_ends[g-1]:group_ends[g]]).  Returns (per-row-group hit counts, total, mask words or
+        None); the scan behind the call comes from the context's scan cache."""
+        if isinstance(exprs, LiquidExpr):
+            exprs = [exprs]
+        if isinstance(entry_ids, np.ndarray) and entry_ids.dtype == np.uint64:
+            ids = np.ascontiguousarray(entry_ids)
+        else:
+            ids = np.ascontiguousarray(np.asarray([int(e) for e in entry_ids], dtype=np.uint64))
+        ends = np.ascontiguousarray(group_ends, dtype=np.uint32)
+        preds = (N.Predicate * len(exprs))(*[e.as_predicate() for e in exprs])
+        counts = np.zeros(max(len(ends), 1), np.uint64)
+        total = C.c_uint64(0)
+        mask, words = None, 0
+        if want_mask:
+            infos = [self.entry_info(int(e)) for e in ids]
+            if any(i is None for i in infos):
+                raise N.LiquidCacheError(N.LC_NOT_STAGED, "an entry of the list is not staged")
+            words = int(sum((int(i.len) + 63) // 64 for i in infos))
+            mask = np.zeros(max(words, 1), np.uint64)
+        st = N.check(self._lib.lc_eval_predicate_row_groups(
+            self._ctx, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint64)), len(ends), ends.ctypes.data_as(C.POINTER(C.c_uint32)),
+            preds, len(exprs), counts.ctypes.data_as(C.POINTER(C.c_uint64)),
+            mask.ctypes.data_as(C.POINTER(C.c_uint64)) if want_mask else None, words, C.byref(total)), self._ctx)
+        if st == N.LC_NOT_STAGED:
+            raise N.LiquidCacheError(st, "an entry of the list is not staged")
+        return counts[:len(ends)], int(total.value), (mask[:words] if want_mask else None)
+
 
 def _release(c_arr: N.ArrowArray, c_schema: N.ArrowSchema):
     for s in (c_arr, c_schema):
@@ -844,8 +883,10 @@ class Scan:
         else:
             ids = np.ascontiguousarray(np.asarray([int(e) for e in entry_ids], dtype=np.uint64))
         h = C.c_void_p()
-        N.check(self._lib.lc_scan_create(cache.handle, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                         C.byref(h)), cache.handle)
+        st = N.check(self._lib.lc_scan_create(cache.handle, len(ids), ids.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                              C.byref(h)), cache.handle)
+        if st == N.LC_NOT_STAGED:  # (the reference's `None`: a scan needs every entry of its list)
+            raise N.LiquidCacheError(st, "an entry of the list is not staged")
         self._h = h
         if not hasattr(cache, "_scans"):
             cache._scans = []
@@ -872,6 +913,10 @@ class Scan:
         out = N.ScanInfo()
         N.check(self._lib.lc_scan_info_get(self._h, C.byref(out)), self._cache.handle)
         return out
+
+    def index_wait(self):
+        """lc_scan_index_wait: block until the index builds in flight for this scan are in place (LC_OPT_LIKE_INDEX_ASYNC)."""
+        N.check(self._lib.lc_scan_index_wait(self._h), self._cache.handle)
 
     def algorithmic_bytes(self, expr: LiquidExpr, with_selection: bool = False) -> int:
         pred = expr.as_predicate()
@@ -973,6 +1018,21 @@ class Scan:
                                              C.c_void_p(selection_ptr or None), C.c_void_p(mask_out_ptr),
                                              C.c_void_p(counts_ptr or None), C.c_void_p(total_out_ptr),
                                              C.c_void_p(stream or None)), self._cache.handle)
+
+    def eval_count_groups(self, exprs, group_ends, group_counts_ptr: int, mask_out_ptr: int = 0, total_out_ptr: int = 0,
+                          selection_ptr: int = 0, counts_ptr: int = 0, stream: int = 0):
+        """lc_scan_eval_count_groups: COUNT(*) per ROW GROUP (group g = entries [group_ends[g-1], group_ends[g]) of the scan)
+        from one evaluation launch; `group_counts_ptr`: len(group_ends) u64 on the device."""
+        if isinstance(exprs, LiquidExpr):
+            exprs = [exprs]
+        preds = (N.Predicate * len(exprs))(*[e.as_predicate() for e in exprs])
+        ends = np.ascontiguousarray(group_ends, dtype=np.uint32)
+        N.check(self._lib.lc_scan_eval_count_groups(self._cache.handle, self._h, preds, len(exprs),
+                                                    C.c_void_p(selection_ptr or None), len(ends),
+                                                    ends.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_void_p(group_counts_ptr),
+                                                    C.c_void_p(mask_out_ptr or None), C.c_void_p(counts_ptr or None),
+                                                    C.c_void_p(total_out_ptr or None), C.c_void_p(stream or None)),
+                self._cache.handle)
 
     @staticmethod
     def eval_or(scans: Sequence["Scan"], exprs: Sequence[LiquidExpr], mask_out_ptr: int, selection_ptr: int = 0,

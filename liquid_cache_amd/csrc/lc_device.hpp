@@ -78,6 +78,27 @@ __device__ __forceinline__ void async_copy16(const void* gsrc_lane, void* lds_ba
                                      16, 0, 0);
 }
 
+// The same for data that a scan reads exactly ONCE (packed column words): non-temporal (aux = 2).  Round 6's policy probe
+// (scripts/micro/stream_probe.hip, profiles/r6/stream_probe.txt): a 788 MB read stream runs at 6.0 TB/s with the default policy
+// and 6.7-6.8 TB/s non-temporal, LDS-DMA and 16-byte register loads alike.  Measured on the kernels (profiles/r6/ab_stream_nt.txt):
+// the LDS-DMA scan of a W = 62 column 150.6 -> 136.5 us L3-cold (-DLC_STREAM_NT=0 restores the default policy); the
+// register-resident narrow-integer kernels gain nothing cold (37.5 vs 36.8, 27.2 vs 25.9, 49.6 vs 52.7 us) and lose the
+// Infinity-Cache hits of a column that fits it (32.9 vs 29.5 us hot), so their loads keep the default policy
+// (-DLC_STREAM_NT_REG=1 is the A/B switch).
+#ifndef LC_STREAM_NT
+#define LC_STREAM_NT 1
+#endif
+#ifndef LC_STREAM_NT_REG
+#define LC_STREAM_NT_REG 0
+#endif
+__device__ __forceinline__ void async_copy16_stream(const void* gsrc_lane, void* lds_base) {
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
+                                         reinterpret_cast<uintptr_t>(gsrc_lane)),
+                                     reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                         uint32_t(reinterpret_cast<uintptr_t>(lds_base))),
+                                     16, 0, LC_STREAM_NT ? 2 : 0);
+}
+
 // v_writelane_b32 with a compile-time lane.  The LLVM intrinsic, not inline assembly: gfx950 needs two wait states
 // between a VALU instruction that writes an SGPR / VCC (v_cmp) and a v_writelane that reads it.  The compiler's hazard
 // recognizer provides them (s_nop, or independent work scheduled in between) for its own instructions only; a
@@ -95,6 +116,12 @@ template <typename T>
 using GlobalPtr = const __attribute__((address_space(1))) T*;
 template <typename T>
 __device__ __forceinline__ GlobalPtr<T> as_global(const T* p) { return (GlobalPtr<T>)p; }
+// a register load of read-once data (see async_copy16_stream)
+template <typename T>
+__device__ __forceinline__ T stream_load(GlobalPtr<T> p) {
+    if constexpr (LC_STREAM_NT_REG != 0) return __builtin_nontemporal_load(p);
+    else return *p;
+}
 // stores through a pointer the compiler cannot prove global would be FLAT stores: besides the slower path, a pending flat
 // access makes the compiler wait for ALL outstanding loads (vmcnt(0)) at the next use of any loaded value
 template <typename T>

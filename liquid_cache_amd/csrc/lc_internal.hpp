@@ -5,13 +5,18 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <deque>
+#include <functional>
+#include <future>
 #include <map>
 #include <memory>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -105,7 +110,8 @@ struct lc_ctx {
     std::unordered_map<uint64_t, lc::Entry> entries;
     std::vector<lc::Slab> slabs;
     uint64_t max_hbm = 0;
-    uint64_t staged_bytes = 0;  // slab capacity reserved on the device (what max_hbm bounds)
+    std::atomic<uint64_t> staged_bytes{0};  // slab capacity reserved on the device (what max_hbm bounds); written under `mu`,
+                                            // read by the index builders without it
     uint64_t entry_bytes = 0;   // sum of the staged entries' blobs (what lc_device_info reports)
     std::atomic<uint64_t> index_bytes{0};  // scan-level LIKE indexes alive (live scans + the ones kept for the next scan): derived
                                            // data outside the slabs, charged to max_hbm when one is built
@@ -120,6 +126,11 @@ struct lc_ctx {
                                                  // bound of its own — max_hbm_bytes and free device memory still apply)
     std::atomic<uint32_t> like_index_cache{4};   // LC_OPT_LIKE_INDEX_CACHE: indexes of destroyed scans kept for the next scan over
                                                  // the same entries
+    std::atomic<bool> like_index_async{true};    // LC_OPT_LIKE_INDEX_ASYNC: scan-level LIKE indexes are built by the context's builder
+                                                 // thread on its own stream while the entry-level index answers (0: the first
+                                                 // LIKE of a scan waits for the build, as before round 6)
+    std::atomic<uint32_t> scan_cache_max{8};     // LC_OPT_SCAN_CACHE: destroyed scans kept for the next lc_scan_create over the same
+                                                 // entry-id list (0: none)
     std::atomic<bool> like_many_hint{true};  // LC_OPT_LIKE_MANY_HINT (A/B aid): unselective planned needles take k_str_pred's sequential walker
     std::atomic<int> like_path{0};  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred, 2 auto without the scan-level index, 3 / 4 / 5 k_like_lean /
                                     // k_like_flat / k_like_scanall for every needle
@@ -157,10 +168,24 @@ struct lc_ctx {
     // entries gets the index (and the plans) of the previous one instead of rebuilding 2-3 GB in 13 ms
     std::mutex like_orphans_mu;
     std::vector<lc::LikePipeline*> like_orphans;  // most recently orphaned last
+    std::mutex index_reserve_mu;                  // one index reservation (budget check + eviction) at a time
     std::mutex scan_cache_mu;
     std::unordered_map<uint64_t, std::vector<lc_scan*>> scan_cache;
     size_t scan_cache_size = 0;
     std::vector<lc_scan*> scan_graveyard;
+    // Whole scans given back with lc_scan_destroy, kept for the next lc_scan_create over the SAME entry-id list while none of
+    // their entries has been replaced or evicted (the reference's reader holds no scan objects: it names entries per query,
+    // liquid_cache_reader.rs:264-339 — a host that follows it creates a scan per query).  Guarded by scan_cache_mu; most
+    // recently destroyed last; any replacement / eviction of an entry moves all of them to the graveyard.
+    std::vector<lc_scan*> list_cache;
+    std::atomic<uint64_t> evict_epoch{0};  // bumped (under `mu`, exclusively) whenever an entry is replaced or evicted
+    // The builder: ONE worker thread with its own (lowest-priority) stream runs the scan-level index builds off the query path.
+    std::mutex builder_mu;
+    std::condition_variable builder_cv;
+    std::deque<std::packaged_task<void()>> builder_q;
+    std::thread builder;
+    bool builder_started = false, builder_stop = false;
+    hipStream_t builder_stream = nullptr;  // created by the worker
 };
 
 struct lc_scan {
@@ -179,6 +204,13 @@ struct lc_scan {
     void* d_descs = nullptr;
     uint64_t* d_seg_offsets = nullptr;
     std::vector<lc::Entry> meta;  // copies of the entries' metadata (descs have mask_word_off filled in)
+    std::vector<uint64_t> ids;    // the entry ids the scan was created over (list_cache: an identical list gets this scan back)
+    std::vector<uint64_t> id_bloom;  // 2^17-bit Bloom filter of `ids` (two probes): does an evicted / replaced id concern this scan?
+    bool cacheable = false;       // created by lc_scan_create (not a one-entry scan of the per-entry calls)
+    uint64_t evict_epoch = 0;     // ctx->evict_epoch when the entries were captured (or last verified current)
+    uint32_t* d_group_ends = nullptr;       // lc_scan_eval_count_groups: the row groups' entry bounds on the device ...
+    std::vector<uint32_t> group_ends_host;  // ... as uploaded last
+    uint32_t* d_group_entry_counts = nullptr;  // ... and the per-entry counts its evaluation writes (n x u32)
     // LIKE scratch
     uint8_t* d_automata = nullptr;
     size_t automata_cap = 0;
@@ -249,6 +281,12 @@ lc_status make_str_pred(const lc_predicate* p, StrPredHost* out);
 lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
                              bool* handled, bool* many_candidates);
 void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp);
+// blocks until the scan's index builds in flight have finished and their results are in place (lc_scan_index_wait,
+// lc_scan_explain, lc_scan_info_get); caller holds s->mu
+void like_pipeline_wait(lc_scan* s);
+// the context's builder thread (lc_runtime.cpp): runs `fn` on the worker, the future completes when it returns
+std::future<void> builder_submit(lc_ctx* ctx, std::function<void(hipStream_t)> fn);
+void builder_shutdown(lc_ctx* ctx);
 // lc_scan_destroy: keeps a pipeline that has a scan-level index for the next scan over the same entries (bounded), destroys
 // the others.  like_orphans_clear: context teardown.
 void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp);

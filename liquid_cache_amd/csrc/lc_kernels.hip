@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred(const FixedDesc* __rest
                 for (int s = 0; s < kSteps; s++) {
                     if (uint32_t(s) * 64u < nchunks && !LC_ABL(pred.debug_flags & 2)) {
                         const uint32_t c = uint32_t(s) * 64u + uint32_t(lane);
-                        if (c < nchunks) async_copy16(src + c, buf + s * 1024);
+                        if (c < nchunks) async_copy16_stream(src + c, buf + s * 1024);
                     }
                 }
                 const U mask = (W >= TB) ? U(~U(0)) : U((U(1) << W) - 1);
@@ -650,8 +650,8 @@ __device__ __forceinline__ void load_stream16(const uint8_t* base, int lane, uin
     const uint16_t* p = reinterpret_cast<const uint16_t*>(base) + uint32_t(lane);
 #pragma unroll
     for (int k = 0; k < NW; k++) {
-        const uint32_t x = as_global(p)[(2 * k) * 64];
-        const uint32_t y = (2 * k + 1 < W) ? uint32_t(as_global(p)[(2 * k + 1) * 64]) : 0u;
+        const uint32_t x = stream_load(as_global(p) + (2 * k) * 64);
+        const uint32_t y = (2 * k + 1 < W) ? uint32_t(stream_load(as_global(p) + (2 * k + 1) * 64)) : 0u;
         w[k] = x | (y << 16);
     }
 }
@@ -671,7 +671,7 @@ __device__ __forceinline__ void load_stream64(const uint8_t* base, uint32_t lane
     const uint64_t* p = reinterpret_cast<const uint64_t*>(base + l * 8u + h * uint32_t(W / 2) * 128u);
 #pragma unroll
     for (int m = 0; m < NW / 2; m++) {
-        const uint64_t v = as_global(p)[m * 16];
+        const uint64_t v = stream_load(as_global(p) + m * 16);
         w[2 * m] = uint32_t(v);
         w[2 * m + 1] = uint32_t(v >> 32);
     }
@@ -787,12 +787,12 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
                 {
                     const uint32_t* p = reinterpret_cast<const uint32_t*>(base0 + half * off0) + l;
     #pragma unroll
-                    for (int k = 0; k < NW; k++) pw.w[0][k] = as_global(p)[k * 32];
+                    for (int k = 0; k < NW; k++) pw.w[0][k] = stream_load(as_global(p) + k * 32);
                 }
                 if constexpr (kPairs > 1) {
                     const uint32_t* p = reinterpret_cast<const uint32_t*>(base1 + half * off1) + l;
     #pragma unroll
-                    for (int k = 0; k < NW; k++) pw.w[1][k] = as_global(p)[k * 32];
+                    for (int k = 0; k < NW; k++) pw.w[1][k] = stream_load(as_global(p) + k * 32);
                 }
             } else {
                 load_stream16<U, W, NW>(base0, lane, pw.w[0]);
@@ -921,7 +921,7 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
                             } else {
                                 const uint32_t* p = reinterpret_cast<const uint32_t*>(base0 + half * off0) + l;
     #pragma unroll
-                                for (int k = 0; k < NW; k++) w0[k] = as_global(p)[k * 32];
+                                for (int k = 0; k < NW; k++) w0[k] = stream_load(as_global(p) + k * 32);
                             }
                         }
                         if constexpr (kPairs > 1) {
@@ -931,7 +931,7 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
                                 } else {
                                     const uint32_t* p = reinterpret_cast<const uint32_t*>(base1 + half * off1) + l;
     #pragma unroll
-                                    for (int k = 0; k < NW; k++) w1[k] = as_global(p)[k * 32];
+                                    for (int k = 0; k < NW; k++) w1[k] = stream_load(as_global(p) + k * 32);
                                 }
                             }
                         }
@@ -3200,7 +3200,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_gather(const FixedDesc* __re
         for (int s = 0; s < kSteps; s++) {
             if (uint32_t(s) * 64u < nchunks) {
                 const uint32_t c = uint32_t(s) * 64u + uint32_t(lane);
-                if (c < nchunks) async_copy16(src + c, buf + s * 1024);
+                if (c < nchunks) async_copy16_stream(src + c, buf + s * 1024);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -5277,7 +5277,7 @@ __global__ __launch_bounds__(kThreads) void k_fixed_agg(const FixedDesc* __restr
                 for (int st = 0; st < kSteps; st++) {
                     if (uint32_t(st) * 64u < nchunks) {
                         const uint32_t c = uint32_t(st) * 64u + uint32_t(lane);
-                        if (c < nchunks) async_copy16(src + c, buf + st * 1024);
+                        if (c < nchunks) async_copy16_stream(src + c, buf + st * 1024);
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -5642,6 +5642,28 @@ __global__ __launch_bounds__(kWave) void k_zero_small(uint32_t* p, uint32_t word
 hipError_t launch_zero_small(void* p, uint32_t bytes, hipStream_t stream) {
     if (bytes == 0) return hipSuccess;
     hipLaunchKernelGGL(k_zero_small, dim3(1), dim3(kWave), 0, stream, static_cast<uint32_t*>(p), bytes / 4u);
+    return hipGetLastError();
+}
+
+// Per-row-group COUNT(*) of a scan (lc_scan_eval_count_groups): group g holds the entries [ends[g - 1], ends[g]); one wave per
+// group sums the per-entry counts the predicate kernel wrote.  A reader's row group is ~8-64 batches, a table hundreds of groups.
+namespace {
+__global__ __launch_bounds__(kThreads) void k_group_counts(const uint32_t* __restrict__ entry_counts, const uint32_t* __restrict__ ends,
+                                                           uint32_t n_groups, uint64_t* __restrict__ out) {
+    const uint32_t g = blockIdx.x * kWavesPerBlock + uint32_t(wave_id());
+    if (g >= n_groups) return;
+    const uint32_t b = g ? ends[g - 1] : 0u, e = ends[g];
+    uint64_t sum = 0;
+    for (uint32_t i = b + uint32_t(lane_id()); i < e; i += kWave) sum += entry_counts[i];
+    sum = wave_sum_u64(sum);
+    if (lane_id() == 0) out[g] = sum;
+}
+}  // namespace
+hipError_t launch_group_counts(const uint32_t* d_entry_counts, const uint32_t* d_group_ends, uint32_t n_groups, uint64_t* d_out,
+                               hipStream_t stream) {
+    if (n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_group_counts, dim3((n_groups + kWavesPerBlock - 1) / kWavesPerBlock), dim3(kThreads), 0, stream, d_entry_counts,
+                       d_group_ends, n_groups, d_out);
     return hipGetLastError();
 }
 

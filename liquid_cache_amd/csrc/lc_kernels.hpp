@@ -371,6 +371,8 @@ hipError_t warm_code_object_bv_encode();
 // `bytes` (a multiple of 4, <= 4096) at p <- 0 by one wave: the counters of a sparse query.  (hipMemsetAsync's fill kernel takes
 // 4-5 us for 32 bytes in front of a 10 us kernel.)
 hipError_t launch_zero_small(void* p, uint32_t bytes, hipStream_t stream);
+hipError_t launch_group_counts(const uint32_t* d_entry_counts, const uint32_t* d_group_ends, uint32_t n_groups, uint64_t* d_out,
+                               hipStream_t stream);
 hipError_t launch_mask_to_hits(const void* d_descs, bool is_str, uint32_t n_entries, const uint64_t* d_mask, uint64_t* d_hits,
                                uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, hipStream_t stream);
 hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, const uint64_t* d_hits,

@@ -88,6 +88,8 @@ struct LikePlan {
     uint64_t hits = 0, n_cand = 0, cand_bytes = 0, matches = 0;  // of the trial run (byte accounting, EXPLAIN)
     uint64_t last_use = 0;
     uint32_t n_probe = 0;   // k_like_flat: slices probed (a long needle has more bigrams than are worth reading, see make_plan)
+    bool flat_planned = false;  // the trial ran on the scan-level index (a plan made while the index was still being built is
+                                // made again, once, when the index is in place: slices to probe, candidate statistics)
     float plan_ms = 0;      // what planning cost (trial launches + the host round trip)
 };
 
@@ -121,7 +123,23 @@ struct LikePipeline {
     std::vector<LikePlan> plans;
     uint64_t tick = 0;
     std::vector<uint64_t> uids;  // the publications (Entry::uid) of the scan's entries, in scan order: what the index describes
+    // Builds off the query path (round 6).  The scan-level index is built by the context's builder thread into `flat_pending`
+    // (a LikePipeline that only carries the flat fields) while evaluations go on over the entry-level index; the evaluating
+    // thread moves the finished fields in (promote_flat) the next time it holds the scan's lock.  States: 0 nothing started,
+    // 1 job in flight, 2 job finished (fields waiting in flat_pending), 3 settled (index in place, or this scan keeps the
+    // entry-level index).  The unigram index follows the same protocol (its job needs the bigram index in place).
+    std::atomic<int> flat_state{0}, uni_state{0};
+    LikePipeline* flat_pending = nullptr;
+    uint64_t* uni_pending = nullptr;
+    double uni_pending_ms = 0;
+    std::future<void> flat_job, uni_job;
+    bool flat_needs_evict = false;  // the last attempt found the budget full of cached indexes of other scans: one more attempt,
+                                    // with eviction, once this scan has proven hot (kEvictAfterEvals evaluations)
+    uint32_t like_evals = 0;        // LIKE evaluations this pipeline has served (its heat)
 };
+// LIKE evaluations a scan must have served from the entry-level index before its scan-level index may EVICT the cached
+// index of another scan (round 5's budget-of-3 stream rebuilt 4 ms of index per query; an index pays for itself after ~300)
+constexpr uint32_t kEvictAfterEvals = 8;
 
 namespace {
 
@@ -561,6 +579,8 @@ inline uint64_t flat_group_stride(uint32_t n_bits, uint32_t group_words) {
     return LC_FLAT_GROUP_MAJOR ? uint64_t(n_bits) * group_words : uint64_t(group_words);
 }
 static_assert(sizeof(FlatGroup) == kFlatHotBytes + 64 * kFlatMaxE, "FlatGroup layout");
+
+void drop_flat_index(lc_ctx* ctx, LikePipeline* lp);  // (defined with the index cache below)
 
 namespace {
 
@@ -1225,10 +1245,47 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
     }
 }
 
+// Index memory is HBM the caller's budget must cover: max_hbm_bytes bounds slabs + indexes, LC_OPT_LIKE_INDEX_BUDGET_BYTES the
+// indexes alone, and an index never takes more than half of what the device has free.  index_reserve answers "may `bytes` of
+// index be allocated now?" and, when yes, CHARGES them to ctx->index_bytes before the caller allocates (two builders cannot
+// both pass; the caller gives the bytes back if its hipMalloc fails).  allow_evict: the cached indexes of destroyed scans go
+// first, oldest first, one at a time — only their index memory, the pipeline (records, plans) stays cached; what live scans
+// hold stays, and the entry-level index then serves the asking scan.  *needs_evict: the answer was "no" only because
+// cached indexes of other scans fill the budget.
+bool index_reserve(lc_ctx* ctx, uint64_t bytes, bool allow_evict, bool* needs_evict) {
+    if (needs_evict) *needs_evict = false;
+    std::lock_guard<std::mutex> g(ctx->index_reserve_mu);
+    for (;;) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+        const uint64_t ib = ctx->index_bytes.load(), lim = ctx->like_index_budget.load();
+        const bool fits = bytes <= free_b / 2 && !(ctx->max_hbm && ctx->staged_bytes.load() + ib + bytes > ctx->max_hbm) &&
+                          !(lim && ib + bytes > lim);
+        if (fits) {
+            ctx->index_bytes += bytes;
+            return true;
+        }
+        LikePipeline* victim = nullptr;
+        {
+            std::lock_guard<std::mutex> g2(ctx->like_orphans_mu);
+            for (LikePipeline* q : ctx->like_orphans)
+                if (q->d_slices || q->d_uni) { victim = q; break; }
+            if (victim && allow_evict) drop_flat_index(ctx, victim);  // (under the orphans' lock: nobody adopts it meanwhile)
+        }
+        if (!victim) return false;  // what is left belongs to live scans
+        if (!allow_evict) {
+            if (needs_evict) *needs_evict = true;
+            return false;
+        }
+    }
+}
+
 // The scan-level index of k_like_flat: groups of consecutive entries (one symbol table, <= kFlatMaxE entries, <= 128
 // signature words), their records, and the kFlatBits slices built from the dictionary values.  A scan whose index does not
-// fit (more than half of the free device memory) keeps k_like_lean.
-lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
+// fit (more than half of the free device memory) keeps k_like_lean.  Fills the flat fields of `lp` — the scan's pipeline when
+// the caller waits for the build, a stand-in that the evaluating thread merges later when the builder thread runs it.
+lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream, bool allow_evict = true,
+                     bool* needs_evict = nullptr) {
     lp->flat = false;
     lp->flat_tried = true;
     std::vector<FlatGroup> groups;
@@ -1303,30 +1360,11 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
             dst_word[s->n + groups[gi].first_entry + j] = uint32_t(gi * flat_group_stride(256u, gw) + groups[gi].word_off[j]);
     const uint64_t slice_words = uint64_t(groups.size()) * gw;
     const uint64_t bytes = slice_words * 8u * uint64_t(kFlatBits);
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return LC_OK;
-    if (bytes > free_b / 2) {  // the indexes kept for scans that may never come make room for one that is needed now
-        like_orphans_clear(ctx);
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
-    }
-    // the index is HBM the caller's budget must cover: max_hbm_bytes bounds slabs + indexes, LC_OPT_LIKE_INDEX_BUDGET_BYTES
-    // the indexes alone (the cached ones go first; what live scans hold stays: k_like_lean then serves this scan)
-    auto over_budget = [&]() {
-        const uint64_t ib = ctx->index_bytes.load(), lim = ctx->like_index_budget.load();
-        return (ctx->max_hbm && ctx->staged_bytes + ib + bytes > ctx->max_hbm) || (lim && ib + bytes > lim);
-    };
-    while (over_budget()) {  // oldest cached index first, one at a time
-        LikePipeline* victim = nullptr;
-        {
-            std::lock_guard<std::mutex> g(ctx->like_orphans_mu);
-            if (!ctx->like_orphans.empty()) {
-                victim = ctx->like_orphans.front();
-                ctx->like_orphans.erase(ctx->like_orphans.begin());
-            }
-        }
-        if (!victim) return LC_OK;  // what is left belongs to live scans: the entry-level index serves this one
-        like_pipeline_destroy(ctx, victim);
-    }
+    if (!index_reserve(ctx, bytes, allow_evict, needs_evict)) return LC_OK;  // no room: the entry-level index serves
+    struct Reservation {  // given back unless the index ends up in place
+        lc_ctx* c; uint64_t b; bool keep;
+        ~Reservation() { if (!keep) c->index_bytes -= b; }
+    } reservation{ctx, bytes, false};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     (void)hipEventCreate(&ev0);
     (void)hipEventCreate(&ev1);
@@ -1377,7 +1415,7 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     lp->probe_words = 2;
     for (const FlatGroup& g : groups) lp->probe_words = std::max(lp->probe_words, (g.n_words + 1u) & ~1u);
     lp->slices_bytes = bytes;
-    ctx->index_bytes += bytes;
+    reservation.keep = true;
     lp->flat = true;
     lp->eq_ok = eq_ok;
     lp->d_symtabs = s->d_symtabs;
@@ -1388,16 +1426,17 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
 // dictionary value (0.98 GB and one more pass over the dictionaries for the 100 M-row URL column).  A value holds the byte b
 // exactly when its bit in slice b is set, so a 1-byte LIKE needs no walk: k_like_scanall<kUni> copies the entry's words of
 // ONE slice and maps the rows through the keys.
-lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
-    lp->uni_tried = true;
+lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream, uint64_t** out_uni, double* out_ms) {
+    *out_uni = nullptr;
+    *out_ms = 0;
     if (!lp->flat || !lp->d_dst_word || lp->slice_words == 0) return LC_OK;
     const uint64_t bytes = lp->slice_words * 8u * 256u;
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return LC_OK;
-    if (ctx->max_hbm && ctx->staged_bytes + ctx->index_bytes.load() + bytes > ctx->max_hbm) return LC_OK;  // (the walkers serve)
+    // (the cached indexes of other scans go first, like for the bigram index; what live scans hold stays: the walkers serve)
+    if (!index_reserve(ctx, bytes, true, nullptr)) return LC_OK;
     uint64_t* d_uni = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&d_uni), bytes) != hipSuccess) {
         (void)hipGetLastError();
+        ctx->index_bytes -= bytes;
         return LC_OK;  // no room: the walkers serve
     }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1407,8 +1446,7 @@ lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t s
         hipEvent_t a, b;
         ~Tmp() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
     } tmp{ev0, ev1};
-    lp->d_uni = d_uni;  // (freed with the pipeline whatever happens below)
-    ctx->index_bytes += bytes;
+    *out_uni = d_uni;  // (the caller owns it — and the bytes charged to the context — whatever happens below)
     if (ev0) LC_HIP(hipEventRecord(ev0, stream));
     FlatBuildArgs ba{lp->d_groups, s->d_symtabs, d_uni, flat_slice_stride(lp->n_group_slots, lp->group_words),
                      flat_group_stride(256u, lp->group_words)};
@@ -1418,7 +1456,7 @@ lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t s
     if (ev1) LC_HIP(hipEventRecord(ev1, stream));
     LC_HIP(hipStreamSynchronize(stream));
     float ms = 0;
-    if (ev0 && ev1 && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) lp->uni_build_ms = ms;
+    if (ev0 && ev1 && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) *out_ms = ms;
     return LC_OK;
 }
 
@@ -1585,6 +1623,7 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
     uint16_t bits[kMaxSigProbeWide];
     const uint32_t nb = use_flat ? flat_needle_bits(sp.needle, bits) : 0u;
     plan->n_probe = std::min<uint32_t>(nb, uint32_t(kMaxSigProbe));
+    plan->flat_planned = use_flat;
     lc_status rc = trial(use_flat ? plan->n_probe : 0u);
     if (rc != LC_OK) return rc;
     if (use_flat && nb > uint32_t(kMaxSigProbe)) {
@@ -1614,13 +1653,86 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
 
 }  // namespace
 
-// A destroyed scan's pipeline that carries a scan-level index waits here for the next scan over the same publications of the
-// same entries (same uids in the same order: same blobs, same mask layout — the records hold pointers into the entries,
-// which the adopting scan pins like the scan that built them did).  At most LC_OPT_LIKE_INDEX_CACHE of them and a quarter of the
-// device's memory; the oldest goes first.
-// (LC_OPT_LIKE_INDEX_CACHE; default 4)
+// A destroyed scan's pipeline waits here for the next scan over the same publications of the same entries (same uids in the
+// same order: same blobs, same mask layout — the records hold pointers into the entries, which the adopting scan pins like
+// the scan that built them did): its workgroup records, its plans, its heat and — when it has one — its scan-level index.  At
+// most LC_OPT_LIKE_INDEX_CACHE of them (default 4) and a quarter of the device's memory in indexes; the oldest goes first.
 static uint64_t pipeline_bytes(const LikePipeline* lp) {
-    return lp->slices_bytes + (lp->d_uni ? lp->slice_words * 8u * 256u : 0u);
+    return (lp->d_slices ? lp->slices_bytes : 0u) + (lp->d_uni ? lp->slice_words * 8u * 256u : 0u);
+}
+// the flat fields of `src` (a builder job's stand-in) move into `dst`
+static void adopt_flat_fields(LikePipeline* dst, LikePipeline* src) {
+    dst->flat_mask_bytes = src->flat_mask_bytes;
+    dst->flat = src->flat;
+    dst->flat_tried = true;
+    dst->eq_ok = src->eq_ok;
+    dst->d_symtabs = src->d_symtabs;
+    dst->d_slices = src->d_slices;
+    dst->d_groups = src->d_groups;
+    dst->n_groups = src->n_groups;
+    dst->n_group_slots = src->n_group_slots;
+    dst->group_words = src->group_words;
+    dst->probe_words = src->probe_words;
+    dst->slices_bytes = src->slices_bytes;
+    dst->flat_build_ms = src->flat_build_ms;
+    dst->d_dst_word = src->d_dst_word;
+    dst->slice_words = src->slice_words;
+    src->d_slices = nullptr;
+    src->d_groups = nullptr;
+    src->d_dst_word = nullptr;
+    src->slices_bytes = 0;
+}
+// The results of finished builder jobs move into the pipeline.  Caller holds the scan's lock (or owns the pipeline alone).
+static void promote_builds(lc_ctx* ctx, LikePipeline* lp) {
+    if (lp->flat_state.load(std::memory_order_acquire) == 2) {
+        if (lp->flat_job.valid()) lp->flat_job.get();
+        LikePipeline* pend = lp->flat_pending;
+        lp->flat_pending = nullptr;
+        if (pend) {
+            if (pend->flat) adopt_flat_fields(lp, pend);
+            like_pipeline_destroy(ctx, pend);  // (what a failed build left behind)
+        }
+        // an attempt that only found the budget full of other scans' cached indexes may be repeated (with eviction) once this
+        // scan has proven hot; every other outcome is final for this pipeline
+        lp->flat_state.store(lp->flat || !lp->flat_needs_evict ? 3 : 0, std::memory_order_release);
+        if (lp->flat) lp->flat_needs_evict = false;
+    }
+    if (lp->uni_state.load(std::memory_order_acquire) == 2) {
+        if (lp->uni_job.valid()) lp->uni_job.get();
+        lp->d_uni = lp->uni_pending;
+        lp->uni_build_ms = lp->uni_pending_ms;
+        lp->uni_pending = nullptr;
+        lp->uni_tried = true;
+        lp->uni_state.store(3, std::memory_order_release);
+    }
+}
+// blocks until the jobs in flight for this pipeline have finished, then moves their results in
+static void settle_builds(lc_ctx* ctx, LikePipeline* lp) {
+    if (lp->flat_job.valid()) lp->flat_job.wait();
+    if (lp->uni_job.valid()) lp->uni_job.wait();
+    promote_builds(ctx, lp);
+}
+void like_pipeline_wait(lc_scan* s) {
+    if (s->like) settle_builds(s->ctx, s->like);
+}
+// frees the index memory of a CACHED pipeline (index_reserve: budget eviction); the pipeline itself stays cached and may build
+// its index again.  Caller holds ctx->like_orphans_mu.
+void drop_flat_index(lc_ctx* ctx, LikePipeline* lp) {
+    if (lp->d_slices) { (void)hipFree(lp->d_slices); ctx->index_bytes -= lp->slices_bytes; }
+    if (lp->d_uni) { (void)hipFree(lp->d_uni); ctx->index_bytes -= lp->slice_words * 8u * 256u; }
+    pool_release(ctx, lp->d_groups);
+    pool_release(ctx, lp->d_dst_word);
+    lp->d_slices = nullptr;
+    lp->d_uni = nullptr;
+    lp->d_groups = nullptr;
+    lp->d_dst_word = nullptr;
+    lp->slices_bytes = 0;
+    lp->slice_words = 0;
+    lp->flat = lp->flat_tried = lp->uni_tried = false;
+    lp->flat_needs_evict = true;  // (it lost its index to the budget: it may take one back once it is hot again)
+    lp->like_evals = 0;
+    lp->flat_state.store(0);
+    lp->uni_state.store(0);
 }
 static LikePipeline* like_pipeline_adopt(lc_ctx* ctx, const lc_scan* s) {
     std::lock_guard<std::mutex> g(ctx->like_orphans_mu);
@@ -1637,7 +1749,8 @@ static LikePipeline* like_pipeline_adopt(lc_ctx* ctx, const lc_scan* s) {
 }
 void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp) {
     if (!lp) return;
-    if (!lp->built || !lp->flat) { like_pipeline_destroy(ctx, lp); return; }
+    settle_builds(ctx, lp);  // (the builder reads the scan that is going away)
+    if (!lp->built || !lp->eligible || ctx->like_index_cache.load() == 0) { like_pipeline_destroy(ctx, lp); return; }
     std::vector<LikePipeline*> out;
     {
         std::lock_guard<std::mutex> g(ctx->like_orphans_mu);
@@ -1647,9 +1760,12 @@ void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp) {
         uint64_t held = 0;
         for (const LikePipeline* q : ctx->like_orphans) held += pipeline_bytes(q);
         const uint64_t lim = ctx->like_index_budget.load();
+        uint64_t alive = ctx->index_bytes.load();  // (a running total: the victims are only destroyed below)
         while (!ctx->like_orphans.empty() && (ctx->like_orphans.size() > size_t(ctx->like_index_cache.load()) || held > total_b / 4 ||
-                                               (lim && ctx->index_bytes.load() > lim && held > 0))) {
-            held -= pipeline_bytes(ctx->like_orphans.front());
+                                               (lim && alive > lim && held > 0))) {
+            const uint64_t vb = pipeline_bytes(ctx->like_orphans.front());
+            held -= vb;
+            alive -= std::min(alive, vb);
             out.push_back(ctx->like_orphans.front());
             ctx->like_orphans.erase(ctx->like_orphans.begin());
         }
@@ -1667,6 +1783,7 @@ void like_orphans_clear(lc_ctx* ctx) {
 
 void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     if (!lp) return;
+    settle_builds(ctx, lp);
     pool_release(ctx, lp->d_lean);
     pool_release(ctx, lp->d_total_acc);
     pool_release(ctx, lp->d_groups);
@@ -1781,6 +1898,59 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
     return 0;
 }
 
+// The scan-level index of a scan that does not have it yet.  LC_OPT_LIKE_INDEX_ASYNC = 0: built now, the caller waits (the
+// behaviour before round 6).  Otherwise the context's builder thread builds it on its own stream while this and the next
+// evaluations run over the entry-level index, the way the reference keeps its prefilter construction out of the read path
+// (byte_view_array/conversions.rs:353-355: at insert time).  The first attempt never evicts another scan's cached index; a scan
+// that was turned away for that reason tries again, with eviction, once it has served kEvictAfterEvals evaluations.
+// Caller holds s->mu.
+static lc_status want_flat_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
+    if (!lp->eligible || lp->flat || lp->flat_state.load(std::memory_order_acquire) != 0) return LC_OK;
+    if (!ctx->like_index_async.load()) {
+        if (lp->flat_tried) return LC_OK;
+        const lc_status st = build_flat(ctx, s, lp, stream);
+        lp->flat_state.store(3, std::memory_order_release);
+        return st;
+    }
+    if (lp->flat_needs_evict && lp->like_evals < kEvictAfterEvals) return LC_OK;
+    const bool allow_evict = lp->flat_needs_evict;
+    LikePipeline* pend = new LikePipeline();
+    lp->flat_pending = pend;
+    lp->flat_state.store(1, std::memory_order_release);
+    lp->flat_job = builder_submit(ctx, [ctx, s, lp, pend, allow_evict](hipStream_t st) {
+        bool needs = false;
+        try {
+            (void)build_flat(ctx, s, pend, st, allow_evict, &needs);
+        } catch (...) {
+            pend->flat = false;
+        }
+        lp->flat_needs_evict = needs;
+        lp->flat_state.store(2, std::memory_order_release);
+    });
+    return LC_OK;
+}
+static lc_status want_unigram_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
+    if (!lp->eligible || !lp->flat || lp->d_uni || lp->uni_tried || lp->uni_state.load(std::memory_order_acquire) != 0) return LC_OK;
+    if (!ctx->like_index_async.load()) {
+        lp->uni_tried = true;
+        lp->uni_state.store(3, std::memory_order_release);
+        return build_unigram(ctx, s, lp, stream, &lp->d_uni, &lp->uni_build_ms);
+    }
+    lp->uni_state.store(1, std::memory_order_release);
+    lp->uni_job = builder_submit(ctx, [ctx, s, lp](hipStream_t st) {
+        uint64_t* u = nullptr;
+        double ms = 0;
+        try {
+            (void)build_unigram(ctx, s, lp, st, &u, &ms);
+        } catch (...) {
+        }
+        lp->uni_pending = u;
+        lp->uni_pending_ms = ms;
+        lp->uni_state.store(2, std::memory_order_release);
+    });
+    return LC_OK;
+}
+
 // Caller holds s->mu and has built the automata of `sp` (sp.p.automata).  *handled = true: the evaluation was launched.
 lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
                              bool* handled, bool* many_candidates) {
@@ -1803,12 +1973,11 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
                 const lc_status st = build_index(ctx, s, lp, stream);
                 if (st != LC_OK) return st;
             }
-            if (lp->eligible && !lp->flat_tried) {
-                const lc_status st = build_flat(ctx, s, lp, stream);
-                if (st != LC_OK) return st;
-            }
-            if (lp->eligible && lp->flat && !lp->uni_tried) {
-                const lc_status st = build_unigram(ctx, s, lp, stream);
+            promote_builds(ctx, lp);
+            lp->like_evals++;
+            {
+                lc_status st = want_flat_index(ctx, s, lp, stream);
+                if (st == LC_OK) st = want_unigram_index(ctx, s, lp, stream);
                 if (st != LC_OK) return st;
             }
             if (lp->eligible && lp->flat && lp->d_uni) {
@@ -1833,9 +2002,11 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         if (st != LC_OK) return st;
     }
     if (!lp->eligible) return LC_OK;
+    promote_builds(ctx, lp);
+    lp->like_evals++;
     const bool want_flat = ctx->like_path == 0 || ctx->like_path == 4;
-    if (want_flat && !lp->flat_tried) {
-        const lc_status st = build_flat(ctx, s, lp, stream);
+    if (want_flat) {
+        const lc_status st = want_flat_index(ctx, s, lp, stream);
         if (st != LC_OK) return st;
     }
     const bool use_flat = want_flat && lp->flat;
@@ -1856,6 +2027,12 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         if (st != LC_OK) return st;
         lp->plans.push_back(std::move(fresh));
         plan = &lp->plans.back();
+    }
+    if (use_flat && !plan->flat_planned) {  // planned over the entry-level index while the scan-level one was being built
+        LikePlan again;
+        const lc_status st = make_plan(ctx, s, lp, sp, stream, &again);
+        if (st != LC_OK) return st;
+        *plan = std::move(again);
     }
     plan->last_use = ++lp->tick;
     // a needle the plan found unselective: k_str_pred takes it, and with at least a wave of candidates per entry its

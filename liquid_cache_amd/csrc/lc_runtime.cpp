@@ -19,6 +19,8 @@
 
 using namespace lc;
 
+static void scan_destroy_now(lc_scan* s);  // lc_scan_destroy without the scan cache
+
 namespace lc {
 
 thread_local char g_last_error[512] = {0};
@@ -102,6 +104,67 @@ hipStream_t stream_acquire(lc_ctx* ctx) {
     return s;
 }
 void stream_release(lc_ctx*, hipStream_t) {}  // (the stream stays bound to the thread)
+
+// ---- the builder: one worker thread per context with a stream of its own at the lowest priority the device offers.  It runs
+// what a query should not wait for — the scan-level LIKE index of a scan (k_flat_build: ~4 ms and 2 GB per 100 M-row column)
+// — the way the reference derives its prefilter outside the read path (at insert time, byte_view_array/conversions.rs:353-355).
+// Started on first use, drained and joined by lc_ctx_destroy.
+static void builder_main(lc_ctx* ctx) {
+    (void)hipSetDevice(ctx->device);
+    int lo = 0, hi = 0;
+    hipStream_t st = nullptr;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+        hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> g(ctx->builder_mu);
+        ctx->builder_stream = st;
+    }
+    for (;;) {
+        std::packaged_task<void()> job;
+        {
+            std::unique_lock<std::mutex> g(ctx->builder_mu);
+            ctx->builder_cv.wait(g, [&] { return ctx->builder_stop || !ctx->builder_q.empty(); });
+            if (ctx->builder_q.empty()) break;  // (stop is honoured once the queue is drained: waiters hold futures)
+            job = std::move(ctx->builder_q.front());
+            ctx->builder_q.pop_front();
+        }
+        job();
+    }
+    if (st) (void)hipStreamDestroy(st);
+}
+std::future<void> builder_submit(lc_ctx* ctx, std::function<void(hipStream_t)> fn) {
+    std::packaged_task<void()> job([ctx, fn]() {
+        try {
+            fn(ctx->builder_stream);
+        } catch (...) {  // a failed build leaves the scan on the entry-level index
+        }
+    });
+    std::future<void> fut = job.get_future();
+    {
+        std::lock_guard<std::mutex> g(ctx->builder_mu);
+        if (!ctx->builder_started) {
+            ctx->builder_started = true;
+            ctx->builder = std::thread(builder_main, ctx);
+        }
+        ctx->builder_q.push_back(std::move(job));
+    }
+    ctx->builder_cv.notify_one();
+    return fut;
+}
+void builder_shutdown(lc_ctx* ctx) {
+    {
+        std::lock_guard<std::mutex> g(ctx->builder_mu);
+        if (!ctx->builder_started) return;
+        ctx->builder_stop = true;
+    }
+    ctx->builder_cv.notify_all();
+    if (ctx->builder.joinable()) ctx->builder.join();
+    std::lock_guard<std::mutex> g(ctx->builder_mu);
+    ctx->builder_started = false;
+}
 
 void* pool_alloc(lc_ctx* ctx, size_t bytes) {
     size_t cls = kPoolMinClass;
@@ -292,8 +355,32 @@ struct ArenaReservation {
 // ---- idle one-entry scans of the per-entry drop-in calls (lc_ctx::scan_cache)
 // Caller holds ctx->mu exclusively: the entry `id` is being replaced or evicted — its idle scans (which pin the old blob)
 // move to the graveyard; they are destroyed outside the lock (scan_cache_reap).
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+constexpr uint32_t kIdBloomBits = 1u << 17;
+static inline void id_bloom_add(std::vector<uint64_t>& b, uint64_t id) {
+    const uint64_t h = mix64(id);
+    const uint32_t a = uint32_t(h) & (kIdBloomBits - 1u), c = uint32_t(h >> 32) & (kIdBloomBits - 1u);
+    b[a >> 6] |= uint64_t(1) << (a & 63u);
+    b[c >> 6] |= uint64_t(1) << (c & 63u);
+}
+static inline bool id_bloom_has(const std::vector<uint64_t>& b, uint64_t id) {
+    if (b.empty()) return true;
+    const uint64_t h = mix64(id);
+    const uint32_t a = uint32_t(h) & (kIdBloomBits - 1u), c = uint32_t(h >> 32) & (kIdBloomBits - 1u);
+    return ((b[a >> 6] >> (a & 63u)) & (b[c >> 6] >> (c & 63u)) & 1u) != 0;
+}
 static void scan_cache_invalidate_locked(lc_ctx* ctx, uint64_t id) {
+    ctx->evict_epoch++;  // (scans in callers' hands notice when they are given back: lc_scan_destroy)
     std::lock_guard<std::mutex> g(ctx->scan_cache_mu);
+    // whole scans kept for the next lc_scan_create over their id list: the ones that (may) hold `id` pin its old blob
+    for (size_t i = ctx->list_cache.size(); i-- > 0;) {
+        if (!id_bloom_has(ctx->list_cache[i]->id_bloom, id)) continue;
+        ctx->scan_graveyard.push_back(ctx->list_cache[i]);
+        ctx->list_cache.erase(ctx->list_cache.begin() + long(i));
+    }
     auto it = ctx->scan_cache.find(id);
     if (it == ctx->scan_cache.end()) return;
     for (lc_scan* s : it->second) ctx->scan_graveyard.push_back(s);
@@ -307,7 +394,7 @@ static void scan_cache_reap(lc_ctx* ctx) {
         std::lock_guard<std::mutex> g(ctx->scan_cache_mu);
         dead.swap(ctx->scan_graveyard);
     }
-    for (lc_scan* s : dead) lc_scan_destroy(s);
+    for (lc_scan* s : dead) scan_destroy_now(s);
 }
 // Caller holds ctx->mu exclusively.  Publishes `e` under `id` (replacing what was there: scans that pinned the old blob
 // keep it alive) with a fresh uid.
@@ -893,6 +980,16 @@ lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
         case LC_OPT_LIKE_MANY_HINT: ctx->like_many_hint = value != 0; return LC_OK;
         case LC_OPT_LIKE_INDEX_BUDGET_BYTES: ctx->like_index_budget = value < 0 ? 0 : uint64_t(value); return LC_OK;
         case LC_OPT_LIKE_INDEX_CACHE: ctx->like_index_cache = uint32_t(std::max<int64_t>(0, std::min<int64_t>(value, 1024))); return LC_OK;
+        case LC_OPT_LIKE_INDEX_ASYNC: ctx->like_index_async = value != 0; return LC_OK;
+        case LC_OPT_SCAN_CACHE: {
+            ctx->scan_cache_max = uint32_t(std::max<int64_t>(0, std::min<int64_t>(value, 1024)));
+            std::lock_guard<std::mutex> g2(ctx->scan_cache_mu);  // what no longer fits goes (destroyed by the next reap)
+            while (ctx->list_cache.size() > size_t(ctx->scan_cache_max.load())) {
+                ctx->scan_graveyard.push_back(ctx->list_cache.front());
+                ctx->list_cache.erase(ctx->list_cache.begin());
+            }
+            return LC_OK;
+        }
         case LC_OPT_LIKE_PATH:
             if (value < 0 || value > 5) return fail(LC_ERR_INVALID, "LC_OPT_LIKE_PATH takes 0 .. 5");
             ctx->like_path = int(value);
@@ -921,10 +1018,13 @@ void lc_ctx_destroy(lc_ctx* ctx) {
             ctx->scan_cache_size = 0;
             for (lc_scan* sc : ctx->scan_graveyard) idle.push_back(sc);
             ctx->scan_graveyard.clear();
+            for (lc_scan* sc : ctx->list_cache) idle.push_back(sc);
+            ctx->list_cache.clear();
         }
-        for (lc_scan* sc : idle) lc_scan_destroy(sc);
+        for (lc_scan* sc : idle) scan_destroy_now(sc);
     }
     like_orphans_clear(ctx);
+    builder_shutdown(ctx);
     for (Slab& s : ctx->slabs)
         if (s.base) (void)hipFree(s.base);
     pool_destroy(ctx);
@@ -2287,8 +2387,47 @@ struct ProfDump { ~ProfDump() {
 static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed,
                                   hipStream_t st = nullptr);
 
+// lc_scan_create of a list seen before is O(1) on the device and a memcmp on the host: the scan that lc_scan_destroy gave back
+// (descriptors, workgroup records, automata, the LIKE pipeline's records and plans — everything but the caller's handle) is
+// handed out again as long as none of its entries has been replaced or evicted (publish_entry / lc_evict move the scans that
+// hold the id to the graveyard).  The reference's reader names entries per query and keeps no scan objects
+// (liquid_cache_reader.rs:264-339): a host that follows it pays the 0.3-1.4 ms of a cold creation once per list, not per query.
 lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out) {
-    return scan_create_impl(ctx, n, entry_ids, out, false);
+    if (ctx && out && entry_ids && n > 0 && ctx->scan_cache_max.load() > 0) {
+        lc_scan* hit = nullptr;
+        bool reap = false;
+        {
+            std::lock_guard<std::mutex> g(ctx->scan_cache_mu);
+            reap = !ctx->scan_graveyard.empty();
+            for (size_t i = ctx->list_cache.size(); i-- > 0;) {
+                lc_scan* c = ctx->list_cache[i];
+                if (c->ids.size() != n || c->ids[0] != entry_ids[0] || c->ids[n - 1] != entry_ids[n - 1] ||
+                    std::memcmp(c->ids.data(), entry_ids, size_t(n) * 8) != 0)
+                    continue;
+                hit = c;
+                ctx->list_cache.erase(ctx->list_cache.begin() + long(i));
+                break;
+            }
+        }
+        if (reap) scan_cache_reap(ctx);
+        if (hit) {
+            *out = hit;
+            return LC_OK;
+        }
+    }
+    const lc_status st = scan_create_impl(ctx, n, entry_ids, out, false);
+    if (st == LC_OK && *out && n > 0) {
+        lc_scan* s = *out;
+        try {
+            s->ids.assign(entry_ids, entry_ids + n);
+            s->id_bloom.assign(kIdBloomBits / 64, 0);
+            for (uint64_t i = 0; i < n; i++) id_bloom_add(s->id_bloom, entry_ids[i]);
+            s->cacheable = true;
+        } catch (...) {
+            s->cacheable = false;
+        }
+    }
+    return st;
 }
 
 static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out, bool allow_squeezed,
@@ -2311,6 +2450,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         // under another an lc_evict / re-stage could drain the slab and the scan would keep dangling device pointers.
         // The pins are taken after every entry has validated, so the error returns below leave nothing pinned.
         std::unique_lock<std::shared_mutex> g(ctx->mu);
+        s->evict_epoch = ctx->evict_epoch.load();
         uint32_t max_len = 0;
         for (uint64_t i = 0; i < n; i++) {
             auto it = ctx->entries.find(entry_ids[i]);
@@ -2404,6 +2544,63 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
 
 void lc_scan_destroy(lc_scan* s) {
     if (!s) return;
+    lc_ctx* ctx = s->ctx;
+    if (s->cacheable && ctx->scan_cache_max.load() > 0) {
+        // kept for the next lc_scan_create over the same list.  What the caller may rely on stays true: nothing of this scan is
+        // in flight when the call returns (its streams are drained), and the scan-level LIKE index goes to the context's index
+        // cache, where the budget can reclaim it (the next LIKE over the scan adopts it back by publication ids).
+        try {
+            (void)hipSetDevice(ctx->device);
+            std::vector<hipStream_t> used;
+            {
+                std::lock_guard<std::mutex> g(s->mu);
+                used = s->streams_used;
+            }
+            for (hipStream_t st : used) (void)hipStreamSynchronize(st);
+            LikePipeline* lp = nullptr;
+            {
+                std::lock_guard<std::mutex> g(s->mu);
+                lp = s->like;
+                s->like = nullptr;
+            }
+            like_pipeline_orphan(ctx, lp);
+            std::vector<lc_scan*> out;
+            bool kept = false;
+            {
+                // (under ctx->mu shared: an eviction that concerns this scan either ran before — then the entries' uids differ
+                // and the scan is not kept — or finds it in the cache afterwards)
+                std::shared_lock<std::shared_mutex> gc(ctx->mu);
+                // nothing was replaced or evicted since the scan captured its entries: it is current.  Otherwise its entries'
+                // publication ids decide (O(n), only after an eviction somewhere in the cache)
+                bool current = true;
+                const uint64_t epoch = ctx->evict_epoch.load();
+                if (s->evict_epoch != epoch) {
+                    for (size_t k = 0; current && k < s->ids.size(); k++) {
+                        auto it = ctx->entries.find(s->ids[k]);
+                        current = it != ctx->entries.end() && it->second.uid == s->meta[k].uid;
+                    }
+                    if (current) s->evict_epoch = epoch;
+                }
+                if (current) {
+                    std::lock_guard<std::mutex> g(ctx->scan_cache_mu);
+                    ctx->list_cache.push_back(s);
+                    kept = true;
+                    while (ctx->list_cache.size() > size_t(ctx->scan_cache_max.load())) {
+                        out.push_back(ctx->list_cache.front());
+                        ctx->list_cache.erase(ctx->list_cache.begin());
+                    }
+                }
+            }
+            for (lc_scan* q : out) scan_destroy_now(q);
+            if (kept) return;
+        } catch (...) {
+        }
+    }
+    scan_destroy_now(s);
+}
+
+static void scan_destroy_now(lc_scan* s) {
+    if (!s) return;
     LC_PROF_T0;
     try {
     (void)hipSetDevice(s->ctx->device);
@@ -2420,6 +2617,8 @@ void lc_scan_destroy(lc_scan* s) {
     pool_release(s->ctx, s->d_mask_scratch);
     pool_release(s->ctx, s->d_or_tmp);
     pool_release(s->ctx, s->d_agg_partials);
+    pool_release(s->ctx, s->d_group_ends);
+    pool_release(s->ctx, s->d_group_entry_counts);
     like_pipeline_orphan(s->ctx, s->like);
     pool_release(s->ctx, s->d_automata);
     pool_release(s->ctx, s->d_needle);
@@ -2447,11 +2646,21 @@ lc_status lc_scan_info_get(lc_scan* s, lc_scan_info* out) {
         std::shared_lock<std::shared_mutex> gc(s->ctx->mu);
         out->ctx_slab_bytes = s->ctx->staged_bytes;
     }
-    out->ctx_index_bytes = s->ctx->index_bytes.load();
     std::lock_guard<std::mutex> g(s->mu);
+    like_pipeline_wait(s);  // (a build in flight is waited for: the figures describe the steady state)
+    out->ctx_index_bytes = s->ctx->index_bytes.load();
     uint32_t plans = 0;
     like_pipeline_info(s, &out->index_bytes, &out->unigram_index_bytes, &out->index_build_ms, &plans);
     out->like_plans = plans;
+    return LC_OK;
+    });
+}
+
+lc_status lc_scan_index_wait(lc_scan* s) {
+    return guarded([&]() -> lc_status {
+    if (!s) return fail(LC_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> g(s->mu);
+    like_pipeline_wait(s);
     return LC_OK;
     });
 }
@@ -2882,6 +3091,65 @@ lc_status lc_scan_eval_count(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pre
                           static_cast<hipStream_t>(stream), n_preds == 2 ? &preds[1] : nullptr, d_total_out);
 }
 
+lc_status lc_scan_eval_count_groups(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds,
+                                    const void* d_selection, uint32_t n_groups, const uint32_t* group_ends,
+                                    void* d_group_counts_out, void* d_mask_out, void* d_counts_out, void* d_total_out,
+                                    void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !scan || !preds || n_preds == 0 || n_preds > 2) return fail(LC_ERR_INVALID, "lc_scan_eval_count_groups takes one or two predicates");
+    if (!d_group_counts_out || (n_groups && !group_ends)) return fail(LC_ERR_INVALID, "null argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (uint32_t g = 0; g < n_groups; g++)
+        if (group_ends[g] > scan->n || (g && group_ends[g] < group_ends[g - 1]))
+            return fail(LC_ERR_INVALID, "group_ends must be non-decreasing entry bounds inside the scan");
+    if (n_groups && group_ends[n_groups - 1] != scan->n) return fail(LC_ERR_INVALID, "the last group must end at the scan's last entry");
+    if (n_groups == 0) return LC_OK;
+    uint32_t* d_entry_counts = static_cast<uint32_t*>(d_counts_out);
+    {
+        // the groups' bounds on the device: uploaded when they differ from the last call's (a reader's row groups do not
+        // change between queries)
+        std::lock_guard<std::mutex> g(scan->mu);
+        scan_enter_stream(scan, st);
+        if (!d_entry_counts) {
+            if (!scan->d_group_entry_counts) {
+                scan->d_group_entry_counts = static_cast<uint32_t*>(pool_alloc(ctx, std::max<size_t>(scan->n, 1) * 4));
+                if (!scan->d_group_entry_counts) return fail(LC_ERR_OOM, "hipMalloc (per-entry counts)");
+            }
+            d_entry_counts = scan->d_group_entry_counts;
+        }
+        if (scan->group_ends_host.size() != n_groups ||
+            std::memcmp(scan->group_ends_host.data(), group_ends, size_t(n_groups) * 4) != 0) {
+            LC_HIP(hipStreamSynchronize(st));  // (a launch in flight may still read the previous bounds)
+            pool_release(ctx, scan->d_group_ends);
+            scan->group_ends_host.clear();
+            scan->d_group_ends = static_cast<uint32_t*>(pool_alloc(ctx, size_t(n_groups) * 4));
+            void* h = host_pool_alloc(ctx, size_t(n_groups) * 4);
+            if (!scan->d_group_ends || !h) {
+                host_pool_release(ctx, h);
+                return fail(LC_ERR_OOM, "row-group bounds: staging");
+            }
+            std::memcpy(h, group_ends, size_t(n_groups) * 4);
+            const hipError_t ec = hipMemcpyAsync(scan->d_group_ends, h, size_t(n_groups) * 4, hipMemcpyHostToDevice, st);
+            const hipError_t es = hipStreamSynchronize(st);
+            host_pool_release(ctx, h);
+            LC_HIP(ec);
+            LC_HIP(es);
+            scan->group_ends_host.assign(group_ends, group_ends + n_groups);
+        }
+    }
+    if (scan->n == 0) {
+        LC_HIP(hipMemsetAsync(d_group_counts_out, 0, size_t(n_groups) * 8, st));
+        if (d_total_out) LC_HIP(hipMemsetAsync(d_total_out, 0, 8, st));
+        return LC_OK;
+    }
+    const lc_status rc = scan_eval_impl(ctx, scan, &preds[0], d_selection, d_mask_out, nullptr, d_entry_counts, nullptr, st,
+                                        n_preds == 2 ? &preds[1] : nullptr, d_total_out);
+    if (rc != LC_OK) return rc;
+    LC_HIP(launch_group_counts(d_entry_counts, scan->d_group_ends, n_groups, static_cast<uint64_t*>(d_group_counts_out), st));
+    return LC_OK;
+    });
+}
+
 lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_out, void* stream) {
     return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_out) return fail(LC_ERR_INVALID, "null argument");
@@ -3304,6 +3572,7 @@ lc_status lc_scan_explain(lc_scan* s, const lc_predicate* pred, char* out, size_
         const lc_status st = make_str_pred(pred, &sp);
         if (st != LC_OK) return st;
         std::lock_guard<std::mutex> g(s->mu);
+        like_pipeline_wait(s);  // (an index build in flight is waited for: the line describes the steady state)
         if (sp.p.mode == 1) {
             text = like_pipeline_explain(s, sp);
             // (what the last evaluation of a LIKE on this scan really launched)
@@ -3611,6 +3880,58 @@ lc_status lc_eval_predicate_batch(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         if (out_validity && out_validity[i]) std::memcpy(out_validity[i], h_valid + scan->seg_offsets[k], nb);
         if (out_nullable) out_nullable[i] = e.nullable ? 1 : 0;
     }
+    return LC_OK;
+    });
+}
+
+// The predicate over MANY row groups of one column in one call, host in / host out: the reference's call shape (entries named
+// per row group, no scan object in the caller's hands: liquid_stream.rs:358-430, liquid_cache_reader.rs:297-339) at a
+// granularity a device can work with.  The scan behind it comes from the context's scan cache.
+lc_status lc_eval_predicate_row_groups(lc_ctx* ctx, uint64_t n_entries, const uint64_t* entry_ids, uint32_t n_groups,
+                                       const uint32_t* group_ends, const lc_predicate* preds, uint32_t n_preds,
+                                       uint64_t* out_group_counts, uint64_t* out_mask, uint64_t out_mask_words,
+                                       uint64_t* out_total) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !preds || n_preds == 0 || n_preds > 2 || (n_entries && !entry_ids) || (n_groups && (!group_ends || !out_group_counts)))
+        return fail(LC_ERR_INVALID, "null argument");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    if (out_total) *out_total = 0;
+    if (n_entries == 0) {
+        if (n_groups && group_ends[n_groups - 1] != 0) return fail(LC_ERR_INVALID, "group_ends names entries the call does not hold");
+        for (uint32_t g = 0; g < n_groups; g++) out_group_counts[g] = 0;
+        return LC_OK;
+    }
+    struct Lease {  // (declared before the stream: the call's work is drained before the scan goes back to the cache)
+        lc_scan* s = nullptr;
+        ~Lease() { if (s) lc_scan_destroy(s); }
+    } lease;
+    lc_status rc = lc_scan_create(ctx, n_entries, entry_ids, &lease.s);
+    if (rc != LC_OK) return rc;
+    lc_scan* scan = lease.s;
+    CallStream cs(ctx);
+    const uint64_t words = scan->seg_offsets.back();
+    if (out_mask && out_mask_words < words)
+        return fail(LC_ERR_INVALID, "out_mask is too small: " + std::to_string(words) + " words (sum of ceil(len / 64) over the entries) are needed");
+    const size_t g_bytes = (size_t(n_groups) + 1) * 8, m_bytes = out_mask ? size_t(words) * 8 : 0;
+    uint8_t* h = static_cast<uint8_t*>(cs.halloc(g_bytes + m_bytes));
+    uint64_t* d_g = static_cast<uint64_t*>(cs.dalloc(g_bytes));
+    uint64_t* d_m = out_mask ? static_cast<uint64_t*>(cs.dalloc(m_bytes)) : nullptr;
+    if (!h || !d_g || (out_mask && !d_m)) return fail(LC_ERR_OOM, "row-group call: staging");
+    uint64_t* d_total = d_g + n_groups;
+    if (n_groups) {
+        rc = lc_scan_eval_count_groups(ctx, scan, preds, n_preds, nullptr, n_groups, group_ends, d_g, d_m, nullptr, d_total, cs.st);
+    } else {
+        rc = lc_scan_eval_count(ctx, scan, preds, n_preds, nullptr, d_m, nullptr, d_total, cs.st);
+    }
+    if (rc != LC_OK) return rc;
+    LC_HIP(hipMemcpyAsync(h, d_g, g_bytes, hipMemcpyDeviceToHost, cs.st));
+    if (out_mask) LC_HIP(hipMemcpyAsync(h + g_bytes, d_m, m_bytes, hipMemcpyDeviceToHost, cs.st));
+    LC_HIP(cs.sync());
+    cs.drained = true;
+    if (n_groups) std::memcpy(out_group_counts, h, size_t(n_groups) * 8);
+    if (out_total) std::memcpy(out_total, h + size_t(n_groups) * 8, 8);
+    if (out_mask) std::memcpy(out_mask, h + g_bytes, m_bytes);
     return LC_OK;
     });
 }

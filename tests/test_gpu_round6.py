@@ -1,0 +1,312 @@
+"""Round 6: the headline in the reference's call shape.
+
+* LC_OPT_LIKE_INDEX_ASYNC: a scan's first LIKE is answered from the entry-level index while the scan-level index is built by
+  the context's builder thread; results are identical BEFORE, DURING and AFTER the build (the reference keeps its prefilter
+  construction out of the read path the same way: byte_view_array/conversions.rs:353-355, comparisons.rs:159-183).
+* LC_OPT_SCAN_CACHE: lc_scan_create over an entry-id list seen before returns the kept scan — never a stale one: replacing or
+  evicting an entry invalidates it (the reference's reader names entries per query, liquid_cache_reader.rs:264-339).
+* lc_scan_eval_count_groups / lc_eval_predicate_row_groups: many row groups per call with per-row-group counts
+  (liquid_stream.rs:358-430) == the per-entry results of the oracle summed per group.
+"""
+import os
+import sys
+
+import numpy as np
+import pyarrow as pa
+import pytest
+
+import liquid_cache_amd as lc
+from liquid_cache_amd import _native as N
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import fuzz_data as fz  # noqa: E402
+from test_gpu_round4 import RUNS, _want_full, grouped_cases  # noqa: E402,F401  (the grouped-entries fixture)
+
+pytestmark = pytest.mark.gpu
+HINT = lc.CacheExpression.SUBSTRING_SEARCH
+NEEDLES = [b"google", b"index.php?id=1", b"zzzzqqq", b"mail", b"a", b"#21", b"yandex.google", b"//"]
+
+
+def _stage(cache, lo, cases, file_id=40, path0=7600):
+    ids, flat = [], []
+    for r_i, (st, entries) in enumerate(cases):
+        path = path0 + r_i
+        cache.set_symbol_table(path, lo.symtab_bytes(st))
+        for e_i, (rows, liquid) in enumerate(entries):
+            eid = lc.ParquetArrayID.new(file_id, r_i, 5, e_i)
+            cache.stage([eid], [liquid], [path])
+            ids.append(eid)
+            flat.append((rows, liquid, st))
+    return ids, flat
+
+
+def _oracle_bits(lo, flat, op, pattern):
+    return [_want_full(lo, liquid, st, lo.OP_NAMES[op], pattern, None, len(rows)) for rows, liquid, st in flat]
+
+
+def _scan_bits(scan, mask, lens):
+    bits = np.unpackbits(mask.view(np.uint8), bitorder="little").astype(bool)
+    offs = scan.segment_offsets
+    return [bits[int(offs[b]) * 64: int(offs[b]) * 64 + n] for b, n in enumerate(lens)]
+
+
+def _async_cache(options=None):
+    b = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1).with_option(N.OPT_LIKE_INDEX_ASYNC, 1)
+    for k, v in (options or {}).items():
+        b = b.with_option(k, v)
+    return b.build()
+
+
+def test_results_identical_before_during_after_async_build(product_lib, oracle, grouped_cases):
+    lo = oracle
+    cache = _async_cache()
+    try:
+        ids, flat = _stage(cache, lo, grouped_cases)
+        lens = [len(c[0]) for c in flat]
+        want = {}
+        for nd in NEEDLES:
+            for op in ("like", "not_like"):
+                want[(nd, op)] = _oracle_bits(lo, flat, op, b"%" + nd + b"%")
+        for round_ in range(3):  # a fresh scan each round: the first evaluations race the builder
+            scan = cache.scan(ids)
+            phases = []
+            for phase in ("before/during", "during", "after"):
+                if phase == "after":
+                    scan.index_wait()
+                for nd in NEEDLES:
+                    for op in ("like", "not_like"):
+                        expr = lc.LiquidExpr.try_new(op, b"%" + nd + b"%", pa.binary(), HINT)
+                        mask, counts = scan.eval_to_host(expr)
+                        got = _scan_bits(scan, mask, lens)
+                        for b, w in enumerate(want[(nd, op)]):
+                            assert np.array_equal(got[b], w), (round_, phase, nd, op, b, int(got[b].sum()), int(w.sum()))
+                            assert int(counts[b]) == int(w.sum())
+                phases.append(phase)
+            info = scan.info()
+            assert int(info.index_bytes) > 0, "the scan-level index never arrived"
+            how = scan.explain(lc.LiquidExpr.try_new("like", b"%zzzzqqq%", pa.binary(), HINT))
+            assert how.startswith("k_like_flat"), how
+            # 1-byte needle: the unigram index arrives the same way
+            one = lc.LiquidExpr.try_new("like", b"%a%", pa.binary(), HINT)
+            m0, _ = scan.eval_to_host(one)
+            scan.index_wait()
+            m1, _ = scan.eval_to_host(one)
+            assert np.array_equal(m0, m1)
+            assert int(scan.info().unigram_index_bytes) > 0
+            assert scan.explain(one).startswith("k_like_scanall<unigram>")
+            if round_ == 1:
+                # the last round builds everything again on a scan that is really new
+                cache.set_option(N.OPT_SCAN_CACHE, 0)
+                cache.set_option(N.OPT_LIKE_INDEX_CACHE, 0)
+            scan.close()
+    finally:
+        cache.close()
+
+
+def test_scan_destroyed_while_its_index_is_being_built(product_lib, oracle, grouped_cases):
+    """lc_scan_destroy waits for the builder (which reads the scan); nothing leaks, the next scan adopts the finished index."""
+    lo = oracle
+    cache = _async_cache()
+    try:
+        ids, flat = _stage(cache, lo, grouped_cases, file_id=41, path0=7700)
+        lens = [len(c[0]) for c in flat]
+        expr = lc.LiquidExpr.try_new("like", b"%index.php?id=1%", pa.binary(), HINT)
+        want = _oracle_bits(lo, flat, "like", b"%index.php?id=1%")
+        for k in range(6):
+            scan = cache.scan(ids)
+            mask, _ = scan.eval_to_host(expr)
+            got = _scan_bits(scan, mask, lens)
+            for b, w in enumerate(want):
+                assert np.array_equal(got[b], w), (k, b)
+            scan.close()  # at once: the build of round 0 is most likely still in flight
+        scan = cache.scan(ids)
+        scan.eval_to_host(expr)
+        assert int(scan.info().index_bytes) > 0
+        scan.close()
+    finally:
+        cache.close()
+
+
+def test_scan_cache_returns_the_kept_scan_and_never_a_stale_one(product_lib, oracle, grouped_cases):
+    lo = oracle
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1).build()
+    try:
+        ids, flat = _stage(cache, lo, grouped_cases, file_id=42, path0=7800)
+        lens = [len(c[0]) for c in flat]
+        expr = lc.LiquidExpr.try_new("like", b"%google%", pa.binary(), HINT)
+        want = _oracle_bits(lo, flat, "like", b"%google%")
+
+        def check(scan, want_bits):
+            mask, counts = scan.eval_to_host(expr)
+            got = _scan_bits(scan, mask, lens)
+            for b, w in enumerate(want_bits):
+                assert np.array_equal(got[b], w), b
+                assert int(counts[b]) == int(w.sum())
+        s1 = cache.scan(ids)
+        h1 = s1._h.value
+        check(s1, want)
+        s1.close()
+        s2 = cache.scan(ids)
+        assert s2._h.value == h1, "the kept scan was not handed out again"
+        check(s2, want)
+        # two scans over one list at a time: the second is a new one, both are right
+        s3 = cache.scan(ids)
+        assert s3._h.value != h1
+        check(s3, want)
+        s3.close()
+        s2.close()
+        # a different list (a prefix) is a different scan
+        sp = cache.scan(ids[:5])
+        assert sp.entries == 5
+        sp.close()
+        # replace ONE entry (same id, other rows): the kept scans that hold it are gone, the next scan sees the new data
+        k = 2
+        rows_new = [r if i % 2 else (None if r is None else r + b"google") for i, r in enumerate(flat[k][0])]
+        liquid_new, _ = lo.encode_byte_view(rows_new, st=flat[k][2], fingerprints=True, arrow_type=lo.BT_BINARY)
+        cache.stage([ids[k]], [liquid_new], [7800])
+        flat2 = list(flat)
+        flat2[k] = (rows_new, liquid_new, flat[k][2])
+        want2 = _oracle_bits(lo, flat2, "like", b"%google%")
+        assert int(want2[k].sum()) != int(want[k].sum())
+        s4 = cache.scan(ids)
+        check(s4, want2)
+        # ... and a scan that was in a caller's hands while its entry was replaced is not kept when it is given back
+        liquid_back = flat[k][1]
+        cache.stage([ids[k]], [liquid_back], [7800])
+        check(s4, want2)  # (a live scan keeps the blob it captured, like the reference's Arc clone)
+        h4 = s4._h.value
+        s4.close()
+        s5 = cache.scan(ids)
+        check(s5, want)
+        s5.close()
+        del h4
+        # evicting an entry: the list is no longer complete
+        cache.evict([ids[0]])
+        with pytest.raises(N.LiquidCacheError) as ei:
+            cache.scan(ids)
+        assert ei.value.status == N.LC_NOT_STAGED
+        s6 = cache.scan(ids[1:])
+        mask, _ = s6.eval_to_host(expr)
+        got = _scan_bits(s6, mask, lens[1:])
+        for b, w in enumerate(want[1:]):
+            assert np.array_equal(got[b], w)
+        s6.close()
+        # LC_OPT_SCAN_CACHE = 0: every destroy frees
+        cache.set_option(N.OPT_SCAN_CACHE, 0)
+        s7 = cache.scan(ids[1:])
+        s7.close()
+    finally:
+        cache.close()
+
+
+def test_row_groups_per_call_against_oracle(product_lib, oracle, grouped_cases):
+    lo = oracle
+    cache = _async_cache()
+    try:
+        ids, flat = _stage(cache, lo, grouped_cases, file_id=43, path0=7900)
+        lens = [len(c[0]) for c in flat]
+        n = len(ids)
+        rng = np.random.default_rng(11)
+        groupings = [[n], list(range(1, n + 1)), [5, 17, n], [0, 3, 3, n]]  # one group; one per entry; row groups; empty groups
+        for nd in (b"google", b"zzzzqqq", b"a", b"index.php?id=1"):
+            for op in ("like", "not_like"):
+                pattern = b"%" + nd + b"%"
+                expr = lc.LiquidExpr.try_new(op, pattern, pa.binary(), HINT)
+                want = _oracle_bits(lo, flat, op, pattern)
+                per_entry = np.array([int(w.sum()) for w in want], np.uint64)
+                for ends in groupings:
+                    counts, total, mask = cache.eval_predicate_row_groups(ids, ends, expr, want_mask=True)
+                    b0 = 0
+                    for g, e in enumerate(ends):
+                        assert int(counts[g]) == int(per_entry[b0:e].sum()), (nd, op, ends, g)
+                        b0 = e
+                    assert total == int(per_entry.sum())
+                    bits = np.unpackbits(mask.view(np.uint8), bitorder="little").astype(bool)
+                    off = 0
+                    for b, w in enumerate(want):
+                        assert np.array_equal(bits[off * 64: off * 64 + lens[b]], w), (nd, op, b)
+                        off += (lens[b] + 63) // 64
+        # integers through the same call: row groups of a fixed-width column, one and two fused predicates
+        vals = rng.integers(-1000, 1000, size=9 * 8192 + 77, dtype=np.int64)
+        iids = []
+        for b in range(10):
+            eid = lc.ParquetArrayID.new(44, b // 4, 1, b % 4)
+            cache.insert(eid, pa.array(vals[b * 8192:(b + 1) * 8192]))
+            iids.append(eid)
+        ends = [4, 8, 10]
+        gt = lc.LiquidExpr.try_new(">", 12, pa.int64())
+        lt = lc.LiquidExpr.try_new("<", 500, pa.int64())
+        for exprs, fn in (([gt], lambda v: v > 12), ([gt, lt], lambda v: (v > 12) & (v < 500))):
+            counts, total, _ = cache.eval_predicate_row_groups(np.asarray([int(e) for e in iids], np.uint64), ends, exprs)
+            b0 = 0
+            for g, e in enumerate(ends):
+                assert int(counts[g]) == int(fn(vals[b0 * 8192:e * 8192]).sum())
+                b0 = e
+            assert total == int(fn(vals).sum())
+        # the device-resident form on a scan, with per-entry counts asked for as well
+        import ctypes as C
+        scan = cache.scan(iids)
+        d_g, d_c = C.c_void_p(), C.c_void_p()
+        N.check(cache._lib.lc_device_alloc(cache.handle, 8 * len(ends), C.byref(d_g)), cache.handle)
+        N.check(cache._lib.lc_device_alloc(cache.handle, 4 * len(iids), C.byref(d_c)), cache.handle)
+        scan.eval_count_groups(gt, ends, d_g.value, counts_ptr=d_c.value)
+        hg, hc = np.zeros(len(ends), np.uint64), np.zeros(len(iids), np.uint32)
+        N.check(cache._lib.lc_device_to_host(cache.handle, hg.ctypes.data_as(C.c_void_p), d_g, hg.nbytes, None), cache.handle)
+        N.check(cache._lib.lc_device_to_host(cache.handle, hc.ctypes.data_as(C.c_void_p), d_c, hc.nbytes, None), cache.handle)
+        assert hc.tolist() == [int((vals[b * 8192:(b + 1) * 8192] > 12).sum()) for b in range(10)]
+        assert hg.tolist() == [int(hc[:4].sum()), int(hc[4:8].sum()), int(hc[8:].sum())]
+        # bad groupings are refused
+        for bad in ([3, 2, 10], [4, 8], [4, 11]):
+            with pytest.raises(N.LiquidCacheError):
+                scan.eval_count_groups(gt, bad, d_g.value)
+        cache._lib.lc_device_free(cache.handle, d_g)
+        cache._lib.lc_device_free(cache.handle, d_c)
+        scan.close()
+        # an absent entry: the reference's `None`
+        with pytest.raises(N.LiquidCacheError) as ei:
+            cache.eval_predicate_row_groups([int(iids[0]), 123456789], [2], gt)
+        assert ei.value.status == N.LC_NOT_STAGED
+    finally:
+        cache.close()
+
+
+def test_async_build_does_not_evict_until_the_scan_is_hot(product_lib, oracle, grouped_cases):
+    """Under a budget of ONE index: column A has the index; column B's first evaluations run on the entry-level index and
+    leave A's cached index alone; after kEvictAfterEvals (8) evaluations B takes the room.  Results equal the oracle's
+    throughout."""
+    lo = oracle
+    probe = _async_cache()
+    try:
+        ids, flat = _stage(probe, lo, grouped_cases, file_id=45, path0=8000)
+        s = probe.scan(ids)
+        expr = lc.LiquidExpr.try_new("like", b"%zzzzqqq%", pa.binary(), HINT)
+        s.eval_to_host(expr)
+        index_bytes = int(s.info().index_bytes)
+        assert index_bytes > 0
+        s.close()
+    finally:
+        probe.close()
+    cache = _async_cache({N.OPT_LIKE_INDEX_BUDGET_BYTES: index_bytes * 3 // 2})
+    try:
+        ids_a, flat = _stage(cache, lo, grouped_cases, file_id=46, path0=8100)
+        ids_b, _ = _stage(cache, lo, grouped_cases, file_id=47, path0=8200)
+        lens = [len(c[0]) for c in flat]
+        want = _oracle_bits(lo, flat, "like", b"%zzzzqqq%")
+
+        def query(ids):
+            sc = cache.scan(ids)
+            mask, _ = sc.eval_to_host(expr)
+            got = _scan_bits(sc, mask, lens)
+            for b, w in enumerate(want):
+                assert np.array_equal(got[b], w)
+            ib = int(sc.info().index_bytes)  # (waits for a build in flight)
+            sc.close()
+            return ib
+        assert query(ids_a) == index_bytes
+        seen = [query(ids_b) for _ in range(7)]
+        assert seen == [0] * 7, seen  # A's cached index is not evicted for a scan that has not proven hot
+        assert query(ids_a) == index_bytes
+        later = [query(ids_b) for _ in range(4)]
+        assert later[-1] == index_bytes, later  # ... and is once B has served 8 evaluations
+    finally:
+        cache.close()
