@@ -189,11 +189,12 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
  * the asking scan has served 8 LIKE evaluations (an index costs ~4 ms of device time per 100 M rows and repays ~13 us per
  * evaluation).  Results are identical before, during and after the build (tested).  0: the first LIKE of a scan waits for
  * the build, as before round 6.  lc_scan_index_wait blocks until the builds in flight for a scan are in place
- * (lc_scan_explain and lc_scan_info_get do the same, so that they describe the steady state).
- * LC_OPT_SCAN_CACHE (default 8, round 6): scans given back with lc_scan_destroy are kept, and lc_scan_create over an entry-id
+ * (lc_scan_explain does the same, so that it describes the steady state; lc_scan_info_get does not wait and says whether a
+ * build is pending).
+ * LC_OPT_SCAN_CACHE (default 32, round 6): scans given back with lc_scan_destroy are kept, and lc_scan_create over an entry-id
  * list seen before returns the kept scan — no entry look-ups, no descriptor upload, no records / automata / plans to rebuild —
  * as long as none of its entries has been replaced or evicted since (those scans are destroyed when that happens, and
- * their pins with them).  The reference's reader names the entries of a row group per query and holds no scan objects
+ * their pins with them; the scan-level LIKE index of a kept scan stays evictable by the index budget).  The reference's reader names the entries of a row group per query and holds no scan objects
  * (liquid_cache_reader.rs:264-339); a host that follows it creates a scan per query.  0: every lc_scan_destroy frees the scan. */
 #define LC_OPT_LIKE_INDEX_ASYNC 9
 #define LC_OPT_SCAN_CACHE 10
@@ -473,8 +474,16 @@ typedef struct {
     uint32_t like_plans;           /* needles planned on this scan */
     int32_t is_byte_view;
     int32_t max_bit_width;
+    int32_t index_build_pending;   /* 1 while the builder thread is at work for this scan (LC_OPT_LIKE_INDEX_ASYNC); the call does not wait */
+    int32_t last_like_kernel;      /* which kernel answered the scan's last [NOT] LIKE / indexed string `=`: LC_LIKE_KERNEL_* */
     int32_t reserved;
 } lc_scan_info;
+#define LC_LIKE_KERNEL_NONE 0
+#define LC_LIKE_KERNEL_STR_PRED 1
+#define LC_LIKE_KERNEL_LEAN 2
+#define LC_LIKE_KERNEL_FLAT 3
+#define LC_LIKE_KERNEL_SCANALL 4
+#define LC_LIKE_KERNEL_UNIGRAM 5
 LC_API lc_status lc_scan_info_get(lc_scan* scan, lc_scan_info* out);
 /* Blocks until the index builds in flight for this scan (LC_OPT_LIKE_INDEX_ASYNC) have finished and their results are in place:
  * the next evaluation runs on the scan-level index if the scan got one.  Returns at once when nothing is being built. */

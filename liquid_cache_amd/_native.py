@@ -55,7 +55,10 @@ class ScanInfo(C.Structure):
     _fields_ = [("entries", C.c_uint64), ("rows", C.c_uint64), ("mask_words", C.c_uint64), ("entry_bytes", C.c_uint64),
                 ("index_bytes", C.c_uint64), ("unigram_index_bytes", C.c_uint64), ("ctx_index_bytes", C.c_uint64),
                 ("ctx_slab_bytes", C.c_uint64), ("index_build_ms", C.c_double), ("like_plans", C.c_uint32), ("is_byte_view", C.c_int32),
-                ("max_bit_width", C.c_int32), ("reserved", C.c_int32)]
+                ("max_bit_width", C.c_int32), ("index_build_pending", C.c_int32), ("last_like_kernel", C.c_int32), ("reserved", C.c_int32)]
+
+
+LIKE_KERNEL_NAMES = {0: "none", 1: "k_str_pred", 2: "k_like_lean", 3: "k_like_flat", 4: "k_like_scanall", 5: "k_like_scanall<unigram>"}
 
 
 class ArrowSchema(C.Structure):
@@ -91,7 +94,7 @@ EXPORTED_SYMBOLS = [
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
                  "lc_calibrate_read", "lc_probe_stream_read", "lc_debug_row_lists", "lc_bench_eval_timed", "lc_bench_gather_bytes_hits_timed",
-                 "lc_bench_rowgroup_run", "lc_bench_entry_calls"]
+                 "lc_bench_rowgroup_run", "lc_bench_entry_calls", "lc_bench_rowgroup_many"]
 
 
 class RowGroupStats(C.Structure):

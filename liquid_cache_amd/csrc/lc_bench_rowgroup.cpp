@@ -102,6 +102,101 @@ int32_t lc_bench_rowgroup_run(void* ctx_, uint64_t n_groups, const uint64_t* gro
     return LC_OK;
 }
 
+// MANY row groups per call (round 6): thread t owns the contiguous slice [t n / T, (t + 1) n / T) of the row groups — a
+// reader's partition — and evaluates ALL of them with one call per pass, per-row-group counts out:
+//   mode 0  lc_eval_predicate_row_groups: entry ids in, counts on the host out, no scan object in the caller's hands (the
+//           context's scan cache finds the scan of the previous pass) — the reference's call shape at a device's granularity
+//   mode 1  lc_scan_eval_count_groups on a scan the thread keeps, counts left on the device, one stream wait per pass
+int32_t lc_bench_rowgroup_many(void* ctx_, uint64_t n_groups, const uint64_t* group_begin, const uint64_t* entry_ids,
+                               const void* pred_, int32_t threads, int32_t passes, int32_t mode, lc_rowgroup_stats* out) {
+    lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);
+    const lc_predicate* pred = static_cast<const lc_predicate*>(pred_);
+    if (!ctx || !group_begin || !entry_ids || !pred || !out || n_groups == 0 || threads <= 0 || passes <= 0 || mode < 0 || mode > 1)
+        return LC_ERR_INVALID;
+    std::memset(out, 0, sizeof(*out));
+    threads = int32_t(std::min<uint64_t>(uint64_t(threads), n_groups));
+    std::atomic<int32_t> rc{LC_OK};
+    std::atomic<uint64_t> hits{0}, call_ns{0}, calls{0};
+    std::vector<double> first_s(size_t(threads), 0.0), wall_s(size_t(threads), 0.0);
+    auto worker = [&](int t) {
+        const uint64_t g0 = n_groups * uint64_t(t) / uint64_t(threads), g1 = n_groups * uint64_t(t + 1) / uint64_t(threads);
+        const uint64_t e0 = group_begin[g0], n_e = group_begin[g1] - e0;
+        std::vector<uint32_t> ends(g1 - g0);
+        for (uint64_t g = g0; g < g1; g++) ends[g - g0] = uint32_t(group_begin[g + 1] - e0);
+        std::vector<uint64_t> counts(g1 - g0, 0);
+        void* stream = nullptr;
+        lc_scan* scan = nullptr;
+        void* d_counts = nullptr;
+        if (mode == 1) {
+            if (lc_stream_create(ctx, &stream) != LC_OK) { rc = LC_ERR_DEVICE; return; }
+            if (lc_scan_create(ctx, n_e, entry_ids + e0, &scan) != LC_OK || lc_device_alloc(ctx, (g1 - g0) * 8, &d_counts) != LC_OK) {
+                rc = LC_ERR_DEVICE;
+                return;
+            }
+        }
+        auto pass = [&](bool timed) -> uint64_t {
+            const auto a = Clock::now();
+            lc_status st;
+            uint64_t total = 0;
+            if (mode == 0) {
+                st = lc_eval_predicate_row_groups(ctx, n_e, entry_ids + e0, uint32_t(ends.size()), ends.data(), pred, 1, counts.data(),
+                                                  nullptr, 0, &total);
+            } else {
+                st = lc_scan_eval_count_groups(ctx, scan, pred, 1, nullptr, uint32_t(ends.size()), ends.data(), d_counts, nullptr, nullptr,
+                                               nullptr, stream);
+                if (st == LC_OK) st = lc_stream_synchronize(ctx, stream);
+            }
+            if (st != LC_OK) { rc = st; return 0; }
+            if (timed) {
+                call_ns += uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - a).count());
+                calls++;
+            }
+            return total;
+        };
+        const auto t_first = Clock::now();
+        (void)pass(false);
+        if (mode == 1 && rc == LC_OK) (void)lc_scan_index_wait(scan);
+        if (mode == 0 && rc == LC_OK) {  // (steady state: the scan-level index is in place before the clock starts)
+            lc_scan* sc = nullptr;
+            if (lc_scan_create(ctx, n_e, entry_ids + e0, &sc) == LC_OK) {
+                (void)lc_scan_index_wait(sc);
+                lc_scan_destroy(sc);
+            }
+        }
+        (void)pass(false);  // (re-planned on the scan-level index)
+        first_s[size_t(t)] = seconds(t_first, Clock::now());
+        const auto t0 = Clock::now();
+        for (int p = 0; p < passes && rc == LC_OK; p++) (void)pass(true);
+        wall_s[size_t(t)] = seconds(t0, Clock::now());
+        if (rc == LC_OK) {
+            if (mode == 1 && lc_device_to_host(ctx, counts.data(), d_counts, counts.size() * 8, stream) != LC_OK) rc = LC_ERR_DEVICE;
+            uint64_t h = 0;
+            for (uint64_t c : counts) h += c;
+            hits += h;
+        }
+        if (d_counts) (void)lc_device_free(ctx, d_counts);
+        if (scan) lc_scan_destroy(scan);
+        if (stream) (void)lc_stream_destroy(ctx, stream);
+    };
+    const auto t_all = Clock::now();
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; t++) pool.emplace_back(worker, t);
+    for (auto& th : pool) th.join();
+    if (rc != LC_OK) return rc;
+    double wall = 0, first = 0;
+    for (int t = 0; t < threads; t++) { wall = std::max(wall, wall_s[size_t(t)]); first = std::max(first, first_s[size_t(t)]); }
+    out->wall_s = wall;
+    out->first_pass_s = first;
+    out->total_s = seconds(t_all, Clock::now());
+    out->calls = calls.load();
+    out->call_us_mean = out->calls ? double(call_ns.load()) / 1e3 / double(out->calls) : 0.0;
+    out->hits = hits.load();
+    out->units = uint64_t(threads);
+    out->passes = uint32_t(passes);
+    out->threads = uint32_t(threads);
+    return LC_OK;
+}
+
 int32_t lc_bench_entry_calls(void* ctx_, uint64_t n, const uint64_t* entry_ids, const void* pred_, int32_t threads, int32_t rounds,
                              uint32_t rows_per_entry, double* out_call_us, uint64_t* out_hits) {
     lc_ctx* ctx = static_cast<lc_ctx*>(ctx_);

@@ -129,7 +129,7 @@ struct lc_ctx {
     std::atomic<bool> like_index_async{true};    // LC_OPT_LIKE_INDEX_ASYNC: scan-level LIKE indexes are built by the context's builder
                                                  // thread on its own stream while the entry-level index answers (0: the first
                                                  // LIKE of a scan waits for the build, as before round 6)
-    std::atomic<uint32_t> scan_cache_max{8};     // LC_OPT_SCAN_CACHE: destroyed scans kept for the next lc_scan_create over the same
+    std::atomic<uint32_t> scan_cache_max{32};     // LC_OPT_SCAN_CACHE: destroyed scans kept for the next lc_scan_create over the same
                                                  // entry-id list (0: none)
     std::atomic<bool> like_many_hint{true};  // LC_OPT_LIKE_MANY_HINT (A/B aid): unselective planned needles take k_str_pred's sequential walker
     std::atomic<int> like_path{0};  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred, 2 auto without the scan-level index, 3 / 4 / 5 k_like_lean /
@@ -169,6 +169,8 @@ struct lc_ctx {
     std::mutex like_orphans_mu;
     std::vector<lc::LikePipeline*> like_orphans;  // most recently orphaned last
     std::mutex index_reserve_mu;                  // one index reservation (budget check + eviction) at a time
+    std::atomic<uint64_t> index_events{0};        // bumped whenever index memory is freed or becomes reclaimable (a scan that holds
+                                                  // an index is given back): a scan that found no room tries again only after one
     std::mutex scan_cache_mu;
     std::unordered_map<uint64_t, std::vector<lc_scan*>> scan_cache;
     size_t scan_cache_size = 0;
@@ -241,6 +243,7 @@ struct lc_scan {
     unsigned long long* d_total_acc = nullptr;  // fused COUNT(*) accumulator (kTotalWords u64, zero between launches)
     uint64_t* d_mask_scratch = nullptr;    // mask words of evaluations whose caller wants none (d_mask_out == NULL) but whose
                                            // kernel cannot skip them (allocated on first need)
+    int last_like_kernel = 0;              // LC_LIKE_KERNEL_*: what answered the last [NOT] LIKE / indexed `=` (lc_scan_info_get)
     bool last_native_hits = false;         // the last evaluation's kernel emitted the hit list itself (k_like_flat)
     lc::LikePipeline* like = nullptr;  // workgroup records + plans of k_like_lean (lc_like_pipeline.hip)
     bool pinned = false;  // the slabs of `meta` are pinned (arena_pin) until the scan is destroyed
@@ -294,6 +297,7 @@ void like_orphans_clear(lc_ctx* ctx);
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp);           // caller holds s->mu
 uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts, uint32_t sparse_flags = 0);  // caller holds s->mu
 // what the scan's pipeline holds (lc_scan_info_get); caller holds s->mu
-void like_pipeline_info(const lc_scan* s, uint64_t* bigram_bytes, uint64_t* unigram_bytes, double* build_ms, uint32_t* n_plans);
+void like_pipeline_info(const lc_scan* s, uint64_t* bigram_bytes, uint64_t* unigram_bytes, double* build_ms, uint32_t* n_plans,
+                        int32_t* build_pending);
 
 }  // namespace lc

@@ -135,6 +135,9 @@ struct LikePipeline {
     std::future<void> flat_job, uni_job;
     bool flat_needs_evict = false;  // the last attempt found the budget full of cached indexes of other scans: one more attempt,
                                     // with eviction, once this scan has proven hot (kEvictAfterEvals evaluations)
+    bool flat_no_room = false;      // the last attempt found the budget held by LIVE scans (or the device out of memory): tried
+    uint64_t flat_retry_events = 0; // again once ctx->index_events has moved past this value
+    int flat_why = 0;               // outcome of the last build_flat: 0 built / not eligible, 1 needs eviction, 2 no room
     uint32_t like_evals = 0;        // LIKE evaluations this pipeline has served (its heat)
 };
 // LIKE evaluations a scan must have served from the entry-level index before its scan-level index may EVICT the cached
@@ -1250,10 +1253,10 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
 // index be allocated now?" and, when yes, CHARGES them to ctx->index_bytes before the caller allocates (two builders cannot
 // both pass; the caller gives the bytes back if its hipMalloc fails).  allow_evict: the cached indexes of destroyed scans go
 // first, oldest first, one at a time — only their index memory, the pipeline (records, plans) stays cached; what live scans
-// hold stays, and the entry-level index then serves the asking scan.  *needs_evict: the answer was "no" only because
-// cached indexes of other scans fill the budget.
-bool index_reserve(lc_ctx* ctx, uint64_t bytes, bool allow_evict, bool* needs_evict) {
-    if (needs_evict) *needs_evict = false;
+// hold stays, and the entry-level index then serves the asking scan.  *why: 0 reserved, 1 the answer was "no" only because
+// cached indexes of other scans fill the budget (and allow_evict was not given), 2 no room.
+bool index_reserve(lc_ctx* ctx, uint64_t bytes, bool allow_evict, int* why) {
+    if (why) *why = 2;  // (no room, unless found otherwise below)
     std::lock_guard<std::mutex> g(ctx->index_reserve_mu);
     for (;;) {
         size_t free_b = 0, total_b = 0;
@@ -1263,18 +1266,36 @@ bool index_reserve(lc_ctx* ctx, uint64_t bytes, bool allow_evict, bool* needs_ev
                           !(lim && ib + bytes > lim);
         if (fits) {
             ctx->index_bytes += bytes;
+            if (why) *why = 0;
             return true;
         }
-        LikePipeline* victim = nullptr;
+        // victims, oldest first: the pipelines of destroyed scans, then those of the scans the context keeps for the next
+        // lc_scan_create over their list (idle by definition: handing one out takes the same lock)
+        bool victim = false;
         {
             std::lock_guard<std::mutex> g2(ctx->like_orphans_mu);
             for (LikePipeline* q : ctx->like_orphans)
-                if (q->d_slices || q->d_uni) { victim = q; break; }
-            if (victim && allow_evict) drop_flat_index(ctx, victim);  // (under the orphans' lock: nobody adopts it meanwhile)
+                if (q->d_slices || q->d_uni) {
+                    victim = true;
+                    if (allow_evict) drop_flat_index(ctx, q);  // (under the orphans' lock: nobody adopts it meanwhile)
+                    break;
+                }
+        }
+        if (!victim) {
+            std::lock_guard<std::mutex> g2(ctx->scan_cache_mu);
+            for (lc_scan* c : ctx->list_cache) {
+                LikePipeline* q = c->like;
+                if (!q || !(q->d_slices || q->d_uni) || q->flat_state.load() == 1 || q->flat_state.load() == 2 ||
+                    q->uni_state.load() == 1 || q->uni_state.load() == 2)
+                    continue;
+                victim = true;
+                if (allow_evict) drop_flat_index(ctx, q);
+                break;
+            }
         }
         if (!victim) return false;  // what is left belongs to live scans
         if (!allow_evict) {
-            if (needs_evict) *needs_evict = true;
+            if (why) *why = 1;
             return false;
         }
     }
@@ -1284,10 +1305,10 @@ bool index_reserve(lc_ctx* ctx, uint64_t bytes, bool allow_evict, bool* needs_ev
 // signature words), their records, and the kFlatBits slices built from the dictionary values.  A scan whose index does not
 // fit (more than half of the free device memory) keeps k_like_lean.  Fills the flat fields of `lp` — the scan's pipeline when
 // the caller waits for the build, a stand-in that the evaluating thread merges later when the builder thread runs it.
-lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream, bool allow_evict = true,
-                     bool* needs_evict = nullptr) {
+lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream, bool allow_evict = true) {
     lp->flat = false;
     lp->flat_tried = true;
+    lp->flat_why = 0;
     std::vector<FlatGroup> groups;
     std::vector<uint32_t> dst_word(s->n, 0);
     uint32_t n_groups = 0;
@@ -1360,7 +1381,7 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
             dst_word[s->n + groups[gi].first_entry + j] = uint32_t(gi * flat_group_stride(256u, gw) + groups[gi].word_off[j]);
     const uint64_t slice_words = uint64_t(groups.size()) * gw;
     const uint64_t bytes = slice_words * 8u * uint64_t(kFlatBits);
-    if (!index_reserve(ctx, bytes, allow_evict, needs_evict)) return LC_OK;  // no room: the entry-level index serves
+    if (!index_reserve(ctx, bytes, allow_evict, &lp->flat_why)) return LC_OK;  // no room: the entry-level index serves
     struct Reservation {  // given back unless the index ends up in place
         lc_ctx* c; uint64_t b; bool keep;
         ~Reservation() { if (!keep) c->index_bytes -= b; }
@@ -1390,6 +1411,7 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     if (hipMalloc(reinterpret_cast<void**>(&lp->d_slices), bytes) != hipSuccess) {
         (void)hipGetLastError();
         lp->d_slices = nullptr;
+        lp->flat_why = 2;
         return LC_OK;  // no room: the entry-level index serves
     }
     lp->d_groups = static_cast<FlatGroup*>(pool_alloc(ctx, groups.size() * sizeof(FlatGroup)));
@@ -1688,14 +1710,18 @@ static void promote_builds(lc_ctx* ctx, LikePipeline* lp) {
         if (lp->flat_job.valid()) lp->flat_job.get();
         LikePipeline* pend = lp->flat_pending;
         lp->flat_pending = nullptr;
+        int why = 0;
         if (pend) {
+            why = pend->flat_why;
             if (pend->flat) adopt_flat_fields(lp, pend);
             like_pipeline_destroy(ctx, pend);  // (what a failed build left behind)
         }
-        // an attempt that only found the budget full of other scans' cached indexes may be repeated (with eviction) once this
-        // scan has proven hot; every other outcome is final for this pipeline
-        lp->flat_state.store(lp->flat || !lp->flat_needs_evict ? 3 : 0, std::memory_order_release);
-        if (lp->flat) lp->flat_needs_evict = false;
+        // an attempt that only found the budget full of other scans' cached indexes is repeated (with eviction) once this scan
+        // has proven hot, one that found no room once index memory has been given back somewhere; every other outcome (built,
+        // not eligible) is final for this pipeline
+        lp->flat_needs_evict = !lp->flat && why == 1;
+        lp->flat_no_room = !lp->flat && why == 2;
+        lp->flat_state.store(lp->flat || why == 0 ? 3 : 0, std::memory_order_release);
     }
     if (lp->uni_state.load(std::memory_order_acquire) == 2) {
         if (lp->uni_job.valid()) lp->uni_job.get();
@@ -1716,8 +1742,9 @@ void like_pipeline_wait(lc_scan* s) {
     if (s->like) settle_builds(s->ctx, s->like);
 }
 // frees the index memory of a CACHED pipeline (index_reserve: budget eviction); the pipeline itself stays cached and may build
-// its index again.  Caller holds ctx->like_orphans_mu.
+// its index again.  Caller holds the lock that keeps the pipeline idle (ctx->like_orphans_mu / ctx->scan_cache_mu).
 void drop_flat_index(lc_ctx* ctx, LikePipeline* lp) {
+    ctx->index_events++;
     if (lp->d_slices) { (void)hipFree(lp->d_slices); ctx->index_bytes -= lp->slices_bytes; }
     if (lp->d_uni) { (void)hipFree(lp->d_uni); ctx->index_bytes -= lp->slice_words * 8u * 256u; }
     pool_release(ctx, lp->d_groups);
@@ -1750,6 +1777,7 @@ static LikePipeline* like_pipeline_adopt(lc_ctx* ctx, const lc_scan* s) {
 void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp) {
     if (!lp) return;
     settle_builds(ctx, lp);  // (the builder reads the scan that is going away)
+    if (lp->d_slices || lp->d_uni) ctx->index_events++;  // (its index memory is reclaimable from now on)
     if (!lp->built || !lp->eligible || ctx->like_index_cache.load() == 0) { like_pipeline_destroy(ctx, lp); return; }
     std::vector<LikePipeline*> out;
     {
@@ -1788,13 +1816,17 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     pool_release(ctx, lp->d_total_acc);
     pool_release(ctx, lp->d_groups);
     pool_release(ctx, lp->d_dst_word);
+    if (lp->d_slices || lp->d_uni) ctx->index_events++;
     if (lp->d_slices) { (void)hipFree(lp->d_slices); ctx->index_bytes -= lp->slices_bytes; }
     if (lp->d_uni) { (void)hipFree(lp->d_uni); ctx->index_bytes -= lp->slice_words * 8u * 256u; }
     delete lp;
 }
 
-void like_pipeline_info(const lc_scan* s, uint64_t* bigram_bytes, uint64_t* unigram_bytes, double* build_ms, uint32_t* n_plans) {
+void like_pipeline_info(const lc_scan* s, uint64_t* bigram_bytes, uint64_t* unigram_bytes, double* build_ms, uint32_t* n_plans,
+                        int32_t* build_pending) {
     const LikePipeline* lp = s->like;
+    // (results of a finished job that the next evaluation will move in count as pending: their fields are not in place yet)
+    *build_pending = lp && ((lp->flat_state.load() == 1 || lp->flat_state.load() == 2) || (lp->uni_state.load() == 1 || lp->uni_state.load() == 2)) ? 1 : 0;
     *bigram_bytes = lp && lp->d_slices ? lp->slices_bytes : 0;
     *unigram_bytes = lp && lp->d_uni ? lp->slice_words * 8u * 256u : 0;
     *build_ms = lp ? lp->flat_build_ms + lp->uni_build_ms : 0.0;
@@ -1905,10 +1937,20 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
 // that was turned away for that reason tries again, with eviction, once it has served kEvictAfterEvals evaluations.
 // Caller holds s->mu.
 static lc_status want_flat_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
-    if (!lp->eligible || lp->flat || lp->flat_state.load(std::memory_order_acquire) != 0) return LC_OK;
+    if (!lp->eligible || lp->flat) return LC_OK;
+    const uint64_t events = ctx->index_events.load();
+    if (lp->flat_no_room) {  // room is looked for again only after index memory has been given back somewhere
+        if (lp->flat_retry_events == events) return LC_OK;
+        lp->flat_no_room = false;
+        lp->flat_tried = false;
+        if (lp->flat_state.load(std::memory_order_acquire) == 3) lp->flat_state.store(0, std::memory_order_release);
+    }
+    if (lp->flat_state.load(std::memory_order_acquire) != 0) return LC_OK;
+    lp->flat_retry_events = events;
     if (!ctx->like_index_async.load()) {
         if (lp->flat_tried) return LC_OK;
         const lc_status st = build_flat(ctx, s, lp, stream);
+        lp->flat_no_room = !lp->flat && lp->flat_why == 2;
         lp->flat_state.store(3, std::memory_order_release);
         return st;
     }
@@ -1918,13 +1960,11 @@ static lc_status want_flat_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipS
     lp->flat_pending = pend;
     lp->flat_state.store(1, std::memory_order_release);
     lp->flat_job = builder_submit(ctx, [ctx, s, lp, pend, allow_evict](hipStream_t st) {
-        bool needs = false;
         try {
-            (void)build_flat(ctx, s, pend, st, allow_evict, &needs);
+            (void)build_flat(ctx, s, pend, st, allow_evict);
         } catch (...) {
             pend->flat = false;
         }
-        lp->flat_needs_evict = needs;
         lp->flat_state.store(2, std::memory_order_release);
     });
     return LC_OK;
@@ -1985,6 +2025,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
                                            lp->d_uni + uint64_t(sp.needle[0]) * flat_slice_stride(lp->n_group_slots, lp->group_words),
                                            lp->d_dst_word + s->n));
                 *handled = true;
+                s->last_like_kernel = LC_LIKE_KERNEL_UNIGRAM;
                 return LC_OK;
             }
         }
@@ -2044,6 +2085,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     if (st == LC_OK) {
         *handled = true;
         s->last_native_hits = use_flat && L.d_hits != nullptr;  // (k_like_flat appends the hit list itself)
+        s->last_like_kernel = use_flat ? LC_LIKE_KERNEL_FLAT : LC_LIKE_KERNEL_LEAN;
     }
     return st;
 }

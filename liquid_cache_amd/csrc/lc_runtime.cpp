@@ -2547,8 +2547,8 @@ void lc_scan_destroy(lc_scan* s) {
     lc_ctx* ctx = s->ctx;
     if (s->cacheable && ctx->scan_cache_max.load() > 0) {
         // kept for the next lc_scan_create over the same list.  What the caller may rely on stays true: nothing of this scan is
-        // in flight when the call returns (its streams are drained), and the scan-level LIKE index goes to the context's index
-        // cache, where the budget can reclaim it (the next LIKE over the scan adopts it back by publication ids).
+        // in flight when the call returns (its streams are drained, an index build for it has finished); the scan-level LIKE
+        // index stays with the kept scan, where the index budget can reclaim it (index_reserve).
         try {
             (void)hipSetDevice(ctx->device);
             std::vector<hipStream_t> used;
@@ -2557,13 +2557,13 @@ void lc_scan_destroy(lc_scan* s) {
                 used = s->streams_used;
             }
             for (hipStream_t st : used) (void)hipStreamSynchronize(st);
-            LikePipeline* lp = nullptr;
             {
+                // the builder reads the scan: a build in flight is waited for, so that a kept scan is idle (its index memory can
+                // then be reclaimed by the budget, index_reserve) and a destroyed one is not read any more
                 std::lock_guard<std::mutex> g(s->mu);
-                lp = s->like;
-                s->like = nullptr;
+                like_pipeline_wait(s);
             }
-            like_pipeline_orphan(ctx, lp);
+            ctx->index_events++;  // (whatever index this scan holds is reclaimable from now on)
             std::vector<lc_scan*> out;
             bool kept = false;
             {
@@ -2647,11 +2647,11 @@ lc_status lc_scan_info_get(lc_scan* s, lc_scan_info* out) {
         out->ctx_slab_bytes = s->ctx->staged_bytes;
     }
     std::lock_guard<std::mutex> g(s->mu);
-    like_pipeline_wait(s);  // (a build in flight is waited for: the figures describe the steady state)
     out->ctx_index_bytes = s->ctx->index_bytes.load();
     uint32_t plans = 0;
-    like_pipeline_info(s, &out->index_bytes, &out->unigram_index_bytes, &out->index_build_ms, &plans);
+    like_pipeline_info(s, &out->index_bytes, &out->unigram_index_bytes, &out->index_build_ms, &plans, &out->index_build_pending);
     out->like_plans = plans;
+    out->last_like_kernel = s->last_like_kernel;
     return LC_OK;
     });
 }
@@ -3000,6 +3000,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         if (ps != LC_OK) return ps;
         s->last_eq_flat = handled;
         if (handled) { s->last_like_scanall = false; return LC_OK; }
+        s->last_like_kernel = LC_LIKE_KERNEL_STR_PRED;
     } else {
         s->last_eq_flat = false;
     }
@@ -3051,6 +3052,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         // scans without fingerprints and without the signature index, or LC_OPT_LIKE_PATH = 5 (tests).
         const bool walk_all_scan = s->any_without_signatures && !s->any_fingerprints;
         s->last_like_scanall = scanall_ok && ((L.many_candidates && walk_all_scan) || ctx->like_path == 5);
+        s->last_like_kernel = s->last_like_scanall ? LC_LIKE_KERNEL_SCANALL : LC_LIKE_KERNEL_STR_PRED;
         if (s->last_like_scanall) {
             LC_HIP(launch_like_scanall(s->d_wg_ranges, s->n_wg_ranges, sp.p, L, L.d_total_acc, stream));
             return LC_OK;

@@ -370,7 +370,11 @@ def test_index_budget_and_eviction_mid_stream(product_lib, oracle, grouped_cases
     finally:
         cache.close()
     budget = slab_bytes + index_bytes * 3 // 2
-    cache = lc.LiquidCacheBuilder.new().with_max_memory_bytes(budget).with_index_options(like_pipeline_min_entries=1).build()
+    # (LC_OPT_LIKE_INDEX_ASYNC = 0: a query that needs room takes it at once here; the asynchronous policy — a scan must prove
+    # hot before its build evicts another scan's index — is what test_gpu_round6.py checks)
+    from liquid_cache_amd import _native as N
+    cache = (lc.LiquidCacheBuilder.new().with_max_memory_bytes(budget).with_index_options(like_pipeline_min_entries=1)
+             .with_option(N.OPT_LIKE_INDEX_ASYNC, 0).build())
     try:
         cols = stage_cols(cache)
 

@@ -121,7 +121,9 @@ def test_scan_destroyed_while_its_index_is_being_built(product_lib, oracle, grou
             scan.close()  # at once: the build of round 0 is most likely still in flight
         scan = cache.scan(ids)
         scan.eval_to_host(expr)
+        scan.index_wait()
         assert int(scan.info().index_bytes) > 0
+        assert scan.info().index_build_pending == 0
         scan.close()
     finally:
         cache.close()
@@ -281,6 +283,7 @@ def test_async_build_does_not_evict_until_the_scan_is_hot(product_lib, oracle, g
         s = probe.scan(ids)
         expr = lc.LiquidExpr.try_new("like", b"%zzzzqqq%", pa.binary(), HINT)
         s.eval_to_host(expr)
+        s.index_wait()
         index_bytes = int(s.info().index_bytes)
         assert index_bytes > 0
         s.close()
@@ -299,7 +302,8 @@ def test_async_build_does_not_evict_until_the_scan_is_hot(product_lib, oracle, g
             got = _scan_bits(sc, mask, lens)
             for b, w in enumerate(want):
                 assert np.array_equal(got[b], w)
-            ib = int(sc.info().index_bytes)  # (waits for a build in flight)
+            sc.index_wait()
+            ib = int(sc.info().index_bytes)
             sc.close()
             return ib
         assert query(ids_a) == index_bytes
