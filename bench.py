@@ -339,7 +339,7 @@ def compact_line(out, detail_path):
                 "hits_match_cpu_oracle", "hits_match_numpy", "needles_checked", "needle_masks_all_match_cpu_oracle",
                 "rotating_columns", "rotating_columns_checked_against_oracle", "scans_per_step", "us_per_scan",
                 "cycle_read_bytes", "index_bytes", "index_build_ms", "index_build_ms_steady", "first_evaluation_us", "next_scan_first_evaluation_us", "stage_seconds",
-                "exchange_by", "granularity")
+                "exchange_by", "granularity", "clickbench_protocol_us", "index_builds_wait_ms")
     c = {k: cfg[k] for k in keep_cfg if k in cfg}
     for k in ("parallelism", "evaluation_path", "step"):
         if k in cfg:
@@ -385,6 +385,7 @@ def compact_line(out, detail_path):
                            ("concurrent_table_scans_rows_per_s", ("concurrent_table_scans", "rows_per_s")),
                            ("like_stream_rebuilt_ms_per_query", ("mixed_table_like_stream", "budget_of_3_indexes_lru_thrash", "ms_per_query_mean")),
                            ("rowgroup_rows_per_s", ("rowgroup_granularity", "rows_per_s")),
+                           ("rowgroup_many_rows_per_s", ("rowgroup_granularity", "many_rows_per_s")),
                            ("eval_predicate_call_us", ("rowgroup_granularity", "eval_predicate_call_us"))):
             node = sec
             for k in keys:
@@ -421,13 +422,13 @@ def emit(out, args):
 
 def add_read_probe(r, cache, N):
     """The MEASURED ceiling next to the nominal one: time of a kernel that only reads the same number of bytes once
-    (lc_probe_stream_read: 16-byte loads, best of three grid sizes), hot and L3-cold.  `frac_of_read_probe` = probe time /
+    (lc_probe_stream_read: non-temporal 16-byte loads, eight in flight per lane, best of five grid sizes), hot and L3-cold.  `frac_of_read_probe` = probe time /
     kernel time: 1.0 means the scan kernel moves its bytes as fast as this device streams that many bytes at all."""
     import ctypes as C
     try:
         B = N.load_bench()
         best = None
-        for grid in (1024, 2048, 8192):
+        for grid in (256, 512, 1024, 2048, 8192):
             hot, cold = C.c_double(), C.c_double()
             if B.lc_probe_stream_read(cache._ctx, max(int(r["kernel_bytes_per_launch"]), 65536), 10, grid, C.byref(hot), C.byref(cold)) != 0:
                 return r
@@ -935,6 +936,34 @@ def secondary_rowgroup(cache, lc, N, args, ids, expr, whole_scan_hits, rows):
         out["rows_per_s"] = best["rows_per_s"]
         out["best_threads"] = best["threads"]
         out["hits_equal_whole_scan"] = True
+    # MANY row groups per call (round 6): a thread's partition of the row groups in ONE call per pass with per-row-group counts —
+    # mode 0: lc_eval_predicate_row_groups (ids in, host counts out, the scan from the context's scan cache);
+    # mode 1: lc_scan_eval_count_groups on a kept scan + one stream wait
+    B.lc_bench_rowgroup_many.restype = C.c_int32
+    B.lc_bench_rowgroup_many.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.c_int32,
+                                         C.c_int32, C.c_int32, C.POINTER(N.RowGroupStats)]
+    many = {}
+    best_many = None
+    for label, threads, mode in (("ids_t1", 1, 0), ("ids_t4", 4, 0), ("ids_t16", 16, 0), ("scan_t1", 1, 1), ("scan_t4", 4, 1),
+                                 ("scan_t16", 16, 1)):
+        st = N.RowGroupStats()
+        rc = B.lc_bench_rowgroup_many(cache._ctx, len(begins) - 1, gb.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      ids_np.ctypes.data_as(C.POINTER(C.c_uint64)), C.cast(C.byref(pred), C.c_void_p), threads, 20, mode,
+                                      C.byref(st))
+        if rc != 0:
+            many[label] = {"error": "lc_bench_rowgroup_many rc %d" % rc}
+            continue
+        assert int(st.hits) == whole_scan_hits, "many-row-group calls: COUNT(*) %d != the whole scan's %d" % (st.hits, whole_scan_hits)
+        r = {"threads": threads, "call": "lc_eval_predicate_row_groups" if mode == 0 else "lc_scan_eval_count_groups + stream wait",
+             "row_groups_per_call": (len(begins) - 1) // threads, "pass_us": st.wall_s / st.passes * 1e6,
+             "rows_per_s": rows * st.passes / st.wall_s, "call_us": st.call_us_mean, "first_pass_ms": st.first_pass_s * 1e3}
+        many[label] = r
+        if best_many is None or r["rows_per_s"] > best_many["rows_per_s"]:
+            best_many = dict(r, label=label)
+    out["many_row_groups_per_call"] = many
+    if best_many:
+        out["many_rows_per_s"] = best_many["rows_per_s"]
+        out["many_best"] = best_many["label"]
     # the per-entry drop-in call (host buffers out): what `impl LiquidArray for GpuLiquidArray` pays per batch
     n_e = min(len(ids), 2048)
     for threads in (1, 8):
@@ -987,6 +1016,61 @@ def secondary_concurrent_tables(cache, N, args, tables, expr, want_hits, rows_pe
     return out
 
 
+def clickbench_protocol(lc, N, args, rank, n_batches, threads, expr, want_hits, torch, stream, device):
+    """ClickBench's own protocol on a FRESH context (nothing cached, no index anywhere): the table is staged, then q20
+    (`SELECT COUNT(*) FROM hits WHERE URL LIKE '%google%'`) runs 5 times, and every run is what a host in the reference's call
+    shape does per query (liquid_cache_reader.rs:264-339: a reader per query names its entries) — lc_scan_create over the id
+    list, one COUNT(*) evaluation, the count read back, lc_scan_destroy — host wall clock, synchronised.  Run 1 is answered by
+    the entry-level index while the scan-level one is built off the path; the paper's figure is the mean of the last 3."""
+    fresh = (lc.LiquidCacheBuilder.new().with_device(device).with_batch_size(args.batch_size)
+             .with_index_options(signatures=not args.no_signatures, row_lists=not args.no_row_lists).build())
+    try:
+        ids = stage_url_column(fresh, lc, N, args, rank, n_batches, threads)
+        ids_np = np.ascontiguousarray(np.asarray([int(e) for e in ids], dtype=np.uint64))
+        total = torch.zeros((), dtype=torch.int64, device="cuda")
+        runs, paths = [], []
+        cur = torch.cuda.current_stream()
+        torch.cuda.synchronize()
+        for _ in range(5):
+            cur.synchronize()
+            t0 = time.perf_counter()
+            sc = fresh.scan(ids_np)
+            sc.eval_count(expr, 0, total.data_ptr(), 0, 0, stream)
+            # (the count is read back on the QUERY's stream: a device-wide synchronise would wait for the builder's stream too)
+            got = int(total.item())
+            k = int(sc.info().last_like_kernel)
+            sc.close()
+            runs.append((time.perf_counter() - t0) * 1e6)
+            paths.append(N.LIKE_KERNEL_NAMES.get(k, "?"))
+            assert got == want_hits, "clickbench protocol: COUNT(*) %d != %d" % (got, want_hits)
+        # ... and with the scan-level index in place (five back-to-back runs take ~6 ms, the build ~5: ClickBench's runs are
+        # seconds apart)
+        sc = fresh.scan(ids_np)
+        t_w = time.perf_counter()
+        sc.index_wait()
+        waited_ms = (time.perf_counter() - t_w) * 1e3
+        sc.close()
+        steady = []
+        for _ in range(4):
+            cur.synchronize()
+            t0 = time.perf_counter()
+            sc = fresh.scan(ids_np)
+            sc.eval_count(expr, 0, total.data_ptr(), 0, 0, stream)
+            got = int(total.item())
+            k = int(sc.info().last_like_kernel)
+            sc.close()
+            steady.append((time.perf_counter() - t0) * 1e6)
+            paths.append(N.LIKE_KERNEL_NAMES.get(k, "?"))
+            assert got == want_hits, "clickbench protocol: COUNT(*) %d != %d" % (got, want_hits)
+        return {"runs_us": [round(x, 1) for x in runs], "run1_us": round(runs[0], 1), "mean_last3_us": round(float(np.mean(runs[2:])), 1),
+                "index_in_place_runs_us": [round(x, 1) for x in steady], "index_in_place_mean_last3_us": round(float(np.mean(steady[1:])), 1),
+                "waited_for_the_builder_ms": round(waited_ms, 2),
+                "answered_by": paths, "query": "q20: scan create + COUNT(*) WHERE URL LIKE '%google%' + count read back + scan destroy",
+                "rows": int(args.rows)}
+    finally:
+        fresh.close()
+
+
 def secondary_like_stream(cache, lc, N, args, cols, expr, want_hits, torch, stream, index_bytes, live_indexes):
     """Index residency under a mixed query stream (round 4's review: nothing exercised eviction): LIKE COUNT(*) queries round
     robin over SIX resident string tables, a scan per query as DataFusion builds a reader per query — created, evaluated once,
@@ -1002,9 +1086,8 @@ def secondary_like_stream(cache, lc, N, args, cols, expr, want_hits, torch, stre
         t0 = time.perf_counter()
         sc = cache.scan(cols[c])
         sc.eval_count(expr, 0, total.data_ptr(), 0, 0, stream)
-        torch.cuda.synchronize()
-        got = int(total.item())
-        path = sc.explain(expr).split(":")[0].split(" ")[0]
+        got = int(total.item())  # (waits for the query's stream only: a builder at work on another table is not waited for)
+        path = N.LIKE_KERNEL_NAMES.get(int(sc.info().last_like_kernel), "?")  # (what answered; does not wait for a build)
         if not keep:
             sc.close()
         dt = time.perf_counter() - t0
@@ -1032,10 +1115,15 @@ def secondary_like_stream(cache, lc, N, args, cols, expr, want_hits, torch, stre
                       "ms_per_query_max": float(np.max(times)) * 1e3, "paths": paths}
 
     try:
-        run("indexes_cached_between_queries", 0, 8, 5)                    # every query adopts its table's index
-        run("budget_of_3_indexes_lru_thrash", 3, 8, 2)                    # six tables through three slots: every query rebuilds
+        run("indexes_cached_between_queries", 0, 8, 5)                    # every query finds its table's scan (and index) kept
+        run("budget_of_3_indexes_lru_thrash", 3, 8, 4)                    # six tables through three index slots: a table without
+        #                                                                   one is answered by k_like_lean, builds run off the path
         run("budget_held_by_3_live_scans", 3, 8, 5, held=(0, 1, 2))       # the other three tables: k_like_lean (entry-level index)
+        cache.set_option(N.OPT_SCAN_CACHE, 0)
+        run("scan_cache_off_indexes_cached", 0, 8, 3)                     # round 5's shape: a scan really created per query
+        cache.set_option(N.OPT_SCAN_CACHE, 32)
     finally:
+        cache.set_option(N.OPT_SCAN_CACHE, 32)
         cache.set_option(N.OPT_LIKE_INDEX_CACHE, 4)
         cache.set_option(N.OPT_LIKE_INDEX_BUDGET_BYTES, 0)
     return out
@@ -1786,7 +1874,7 @@ def main():
     torch.cuda.synchronize()
     t_first = time.perf_counter()
     scan.eval(expr, mask.data_ptr(), 0, 0, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    torch.cuda.current_stream().synchronize()  # (the query's stream: the scan-level index is being built on the builder's meanwhile)
     first_eval_us = (time.perf_counter() - t_first) * 1e6
     # The timed loop ROTATES through several resident tables of the same shape (other seeds), one per scan: a hot-cache
     # query never finds its column in the 256 MiB memory-side Infinity Cache, and back-to-back passes over ONE 40-160 MB
@@ -1874,6 +1962,14 @@ def main():
 
     for _ in range(n_rot):  # every table is scanned once before the clock starts (plans, automata, scan-level index)
         one_scan()
+    drain()
+    # the scan-level indexes are built off the query path (LC_OPT_LIKE_INDEX_ASYNC): the timed loop is the HOT-cache steady
+    # state, so the builds this first pass kicked off are waited for (what a first evaluation costs is reported on its own:
+    # first_evaluation_us, clickbench_protocol_us)
+    t_builds = time.perf_counter()
+    for sc in scans:
+        sc.index_wait()
+    index_builds_wait_ms = (time.perf_counter() - t_builds) * 1e3
     warm_steps = max(args.warmup, 1)
     for _ in range(warm_steps):
         step()
@@ -2203,14 +2299,24 @@ def main():
         # a NEW scan over the same entries (a host that creates a scan per query): the scan-level index and the plans of the
         # scan just destroyed are adopted, so its first evaluation is records + automata + one launch
         scan.close()
-        scan = cache.scan(ids)
+        ids_np0 = np.ascontiguousarray(np.asarray([int(e) for e in ids], dtype=np.uint64))
         torch.cuda.synchronize()
         t_next = time.perf_counter()
+        scan = cache.scan(ids_np0)  # (round 6: creation is timed too — the context's scan cache hands the kept scan back)
         scan.eval(expr, mask.data_ptr(), 0, 0, stream)
-        torch.cuda.synchronize()
+        torch.cuda.current_stream().synchronize()
         out["next_scan_first_evaluation_us"] = round((time.perf_counter() - t_next) * 1e6, 1)
         out["config"]["next_scan_first_evaluation_us"] = out["next_scan_first_evaluation_us"]
+    if args.workload == "url_like" and rank == 0 and world == 1 and not args.no_secondary and not args.no_fingerprints:
+        try:
+            proto = clickbench_protocol(lc, N, args, rank, n_batches, threads, expr, hits, torch, stream, local_rank)
+            out["clickbench_protocol"] = proto
+            out["config"]["clickbench_protocol_us"] = {"run1": proto["run1_us"], "mean_last3": proto["mean_last3_us"],
+                                                       "index_in_place_mean_last3": proto["index_in_place_mean_last3_us"]}
+        except Exception as e:  # noqa: BLE001
+            out["clickbench_protocol"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
+        out["config"]["index_builds_wait_ms"] = round(index_builds_wait_ms, 2)
         emit(out, args)
     scan.close()
     cache.close()

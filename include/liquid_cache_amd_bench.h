@@ -96,8 +96,8 @@ LC_BENCH_API int32_t lc_bench_rowgroup_run(void* ctx, uint64_t n_groups, const u
                                            const void* pred, int32_t threads, int32_t passes, int32_t with_mask,
                                            int32_t groups_per_scan, lc_rowgroup_stats* out);
 /* MANY row groups per call (round 6): thread t owns a contiguous slice of the row groups (a reader's partition) and evaluates
- * all of them with ONE call per pass and per-row-group counts: mode 0 = lc_eval_predicate_row_groups (ids in, host counts
- * out, the scan comes from the context's scan cache), mode 1 = lc_scan_eval_count_groups on a kept scan + one stream wait.
+ * all of them with ONE call per pass and per-row-group counts: mode 0 = the id-list call of the product ABI (ids in, host
+ * counts out, the scan comes from the context's scan cache), mode 1 = the scan call (a kept scan + one stream wait).
  * call_us_mean is the whole call here (results on the host / stream drained); units = threads. */
 LC_BENCH_API int32_t lc_bench_rowgroup_many(void* ctx, uint64_t n_groups, const uint64_t* group_begin, const uint64_t* entry_ids,
                                             const void* pred, int32_t threads, int32_t passes, int32_t mode, lc_rowgroup_stats* out);

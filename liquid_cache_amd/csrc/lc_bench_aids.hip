@@ -49,10 +49,15 @@ __global__ __launch_bounds__(256) void k_calib_read_scattered8(const uint8_t* __
     if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
 }
 
-// Streaming-read probe (lc_probe_stream_read): what a kernel that does nothing but read `bytes` once — 16 bytes per lane,
-// four independent loads in flight per lane, grid sized to fill the chip — achieves on this device, so that the scan
-// kernels' roofline fractions can be read against the MEASURED ceiling for their byte count, hot and L3-cold.
-__global__ __launch_bounds__(256) void k_probe_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
+// Streaming-read probe (lc_probe_stream_read): what a kernel that does nothing but read `bytes` once achieves on this device, so
+// that the scan kernels' roofline fractions can be read against the MEASURED ceiling for their byte count, hot and L3-cold.
+// Round 6 (scripts/micro/stream_probe.hip, profiles/r6/stream_probe.txt): 16 bytes per lane, EIGHT independent loads in flight
+// per lane, NON-TEMPORAL (the data is read once) — 788 MB in 114-117 us = 6.7-6.9 TB/s from a grid of one or two workgroups per
+// CU; the round-5 probe (four default-policy loads) stopped at 5.1-5.5 TB/s, below what the scan kernels themselves reached.
+typedef uint32_t probe_u32x4 __attribute__((ext_vector_type(4)));
+// The Infinity-Cache flush between "cold" launches reads its scratch with the DEFAULT policy: the lines must be allocated in
+// the cache to displace what is there (a non-temporal stream need not be).
+__global__ __launch_bounds__(256) void k_flush_read(const uint4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
     uint32_t acc = 0;
     const uint64_t stride = uint64_t(gridDim.x) * 256;
     uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -61,6 +66,21 @@ __global__ __launch_bounds__(256) void k_probe_read(const uint4* __restrict__ sr
         acc ^= a.x ^ a.y ^ a.z ^ a.w ^ b.x ^ b.y ^ b.z ^ b.w ^ c.x ^ c.y ^ c.z ^ c.w ^ d.x ^ d.y ^ d.z ^ d.w;
     }
     for (; i < n16; i += stride) { const uint4 a = src[i]; acc ^= a.x ^ a.y ^ a.z ^ a.w; }
+    if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_probe_read(const probe_u32x4* __restrict__ src, uint64_t n16, uint32_t* __restrict__ sink) {
+    constexpr int U = 8;
+    uint32_t acc = 0;
+    const uint64_t stride = uint64_t(gridDim.x) * 256;
+    uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        probe_u32x4 v[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < U; k++) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    for (; i < n16; i += stride) { const probe_u32x4 a = __builtin_nontemporal_load(src + i); acc ^= a.x ^ a.y ^ a.z ^ a.w; }
     if (acc == 0x9E3779B9u) sink[blockIdx.x] = acc;
 }
 
@@ -91,9 +111,9 @@ int32_t lc_probe_stream_read(void* ctx_, uint64_t bytes, int32_t iters, int32_t 
     for (int pass = 0; pass < 2 && rc == LC_OK; pass++) {  // 0: hot (back to back), 1: cold (flush before every launch)
         double sum = 0;
         for (int i = -2; i < iters && rc == LC_OK; i++) {
-            if (pass == 1) hipLaunchKernelGGL(k_probe_read, dim3(4096), block, 0, nullptr, reinterpret_cast<const uint4*>(f), flush_bytes / 16, fsink);
+            if (pass == 1) hipLaunchKernelGGL(k_flush_read, dim3(4096), block, 0, nullptr, reinterpret_cast<const uint4*>(f), flush_bytes / 16, fsink);
             (void)hipEventRecord(e0, nullptr);
-            hipLaunchKernelGGL(k_probe_read, grid, block, 0, nullptr, reinterpret_cast<const uint4*>(d), bytes / 16, sink);
+            hipLaunchKernelGGL(k_probe_read, grid, block, 0, nullptr, reinterpret_cast<const probe_u32x4*>(d), bytes / 16, sink);
             (void)hipEventRecord(e1, nullptr);
             if (hipEventSynchronize(e1) != hipSuccess) { rc = LC_ERR_DEVICE; break; }
             float ms = 0;
@@ -178,7 +198,7 @@ int32_t lc_bench_eval_timed(void* ctx_, void* scan_, const void* pred_, const vo
     }
     for (int i = 0; i < iters && rc == LC_OK && d_flush; i++) {
         for (int pass = 0; pass < 2; pass++)
-            hipLaunchKernelGGL(k_probe_read, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_flush), flush_bytes / 16,
+            hipLaunchKernelGGL(k_flush_read, dim3(2048), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_flush), flush_bytes / 16,
                                reinterpret_cast<uint32_t*>(d_flush + flush_bytes));
         if (hipGetLastError() != hipSuccess || hipEventRecord(a, st) != hipSuccess) { rc = LC_ERR_DEVICE; break; }
         rc = lc_scan_eval(ctx, scan, pred, d_selection, d_mask_out, d_counts_out, st);

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -45,6 +46,30 @@ lc_status guarded(F&& body) noexcept {
         return fail(LC_ERR_INVALID, "unexpected exception");
     }
 }
+
+// make VARIANT=trace EXTRA=-DLC_TRACE_PHASES: scoped wall-clock phases of the first evaluation of a scan on stderr (a
+// profiling aid of scripts/first_eval_profile.py; compiled out of the shipped library)
+#ifdef LC_TRACE_PHASES
+struct TracePhase {
+    const char* what;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    explicit TracePhase(const char* w) : what(w) {}
+    ~TracePhase() {
+        static const std::chrono::steady_clock::time_point epoch = std::chrono::steady_clock::now();
+        const auto t1 = std::chrono::steady_clock::now();
+#ifdef LC_TRACE_MIN_US
+        if (std::chrono::duration<double, std::micro>(t1 - t0).count() < double(LC_TRACE_MIN_US)) return;
+#endif
+        std::fprintf(stderr, "[phase] %-44s %9.1f us   (ends at %.1f us)\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                     std::chrono::duration<double, std::micro>(t1 - epoch).count());
+    }
+};
+#define LC_PHASE_CAT2(a, b) a##b
+#define LC_PHASE_CAT(a, b) LC_PHASE_CAT2(a, b)
+#define LC_PHASE(name) lc::TracePhase LC_PHASE_CAT(_phase_, __LINE__)(name)
+#else
+#define LC_PHASE(name)
+#endif
 
 #define LC_HIP(expr)                                                                              \
     do {                                                                                          \
@@ -145,6 +170,12 @@ struct lc_ctx {
     // Recycled device scratch for the per-call drop-in API (descriptor arrays, masks, gather buffers): hipMalloc /
     // hipFree cost 0.1-1 ms each and hipFree synchronises the device, which would dominate an 8192-row call.
     std::mutex pool_mu;
+    // Small and medium blocks are carved out of CHUNKS (64 MiB of device memory, 8 MiB pinned) that the context allocates when it
+    // is created and when one runs full: in a process with some allocation history a hipMalloc takes 0.5-1 ms, a hipHostMalloc
+    // 0.5-0.8 ms and a hipFree 3 ms — the first query of a fresh context made fifteen of them.  Carved blocks are recycled
+    // through the size-class lists for ever and go back to the driver with their chunk (lc_ctx_destroy).
+    std::vector<void*> pool_chunks, hpool_chunks;
+    uint8_t *pool_chunk_cur = nullptr, *pool_chunk_end = nullptr, *hpool_chunk_cur = nullptr, *hpool_chunk_end = nullptr;
     std::unordered_map<void*, size_t> pool_live;                // pointer -> size class (bytes)
     std::unordered_map<size_t, std::vector<void*>> pool_free;   // size class -> cached blocks
     // same for pinned host staging (pageable hipMemcpy runs at a fraction of the PCIe rate)
@@ -168,6 +199,15 @@ struct lc_ctx {
     // entries gets the index (and the plans) of the previous one instead of rebuilding 2-3 GB in 13 ms
     std::mutex like_orphans_mu;
     std::vector<lc::LikePipeline*> like_orphans;  // most recently orphaned last
+    // Slots for LIKE plans made on the fly (lc_like_pipeline.hip): device counters + their pinned mirror + an event each, carved
+    // out of two blocks allocated once (releasing per-plan allocations back to pools that were full cost a hipHostFree —
+    // 0.26 ms — on the query path of a host that walks hundreds of small scans)
+    std::mutex plan_slots_mu;
+    unsigned long long* plan_slots_d = nullptr;
+    uint64_t* plan_slots_h = nullptr;
+    std::vector<hipEvent_t> plan_slot_ev;   // created on first use, kept
+    std::vector<uint32_t> plan_slots_free;
+    bool plan_slots_tried = false;
     std::mutex index_reserve_mu;                  // one index reservation (budget check + eviction) at a time
     std::atomic<uint64_t> index_events{0};        // bumped whenever index memory is freed or becomes reclaimable (a scan that holds
                                                   // an index is given back): a scan that found no room tries again only after one
@@ -222,6 +262,8 @@ struct lc_scan {
     size_t needle_cap = 0;
     lc::StrWgRecord* d_wg_ranges = nullptr;  // byte views: one record per workgroup (<= 4 entries of one symbol table)
     uint32_t n_wg_ranges = 0;
+    uint32_t* d_wg_begins = nullptr;  // first entry of every record (device) and the pinned block it was uploaded from: kept
+    void* h_wg_begins = nullptr;      // until the scan goes, so that nothing waits for the copy
     uint8_t* d_gather = nullptr;  // scratch of lc_scan_gather_bytes_async (grow only)
     size_t gather_cap = 0;
     uint32_t* d_work = nullptr;  // kWorkGroupsMax x {next entry, finished waves} (64-byte stride): dynamic entry
@@ -294,6 +336,7 @@ void builder_shutdown(lc_ctx* ctx);
 // the others.  like_orphans_clear: context teardown.
 void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp);
 void like_orphans_clear(lc_ctx* ctx);
+void plan_slots_destroy(lc_ctx* ctx);
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp);           // caller holds s->mu
 uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts, uint32_t sparse_flags = 0);  // caller holds s->mu
 // what the scan's pipeline holds (lc_scan_info_get); caller holds s->mu

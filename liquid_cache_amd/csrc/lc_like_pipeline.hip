@@ -79,6 +79,11 @@ static_assert(kLeanWaves >= 1 && kLeanWaves <= 4, "a LeanRec holds eight entries
 #define LC_LEAN_XCD 1
 #endif
 constexpr uint32_t kMaxPlans = 8;
+// statistics of a planning run: [COUNT(*) | pad] then kStatShards x [candidates | candidate bytes | matching values | pad], a
+// 128-byte line per shard
+constexpr uint32_t kStatShards = 64;
+constexpr uint32_t kStatStride = 16;  // u64 words
+constexpr uint32_t kStatWords = kStatStride + kStatShards * kStatStride;
 // a needle is "selective" (worth this kernel) up to this many hit rows per 1024 rows of the scan
 constexpr uint32_t kMaxHitsPer1024 = 16;
 
@@ -88,6 +93,14 @@ struct LikePlan {
     uint64_t hits = 0, n_cand = 0, cand_bytes = 0, matches = 0;  // of the trial run (byte accounting, EXPLAIN)
     uint64_t last_use = 0;
     uint32_t n_probe = 0;   // k_like_flat: slices probed (a long needle has more bigrams than are worth reading, see make_plan)
+    // A plan made ON THE FLY (round 6): the first evaluation of a plain LIKE is launched for real with the statistics
+    // counters attached — no trial run, no host round trip — and the figures travel to pinned memory behind it; the plan is
+    // settled by the first later evaluation that finds the event complete (until then the kernel that ran keeps running).
+    bool pending = false;
+    int32_t slot = -1;                    // the context's plan slot (plan_slot_take) that holds the three below
+    hipEvent_t ev = nullptr;
+    unsigned long long* d_res = nullptr;  // device: kStatWords words (COUNT(*) + the sharded counters, see sum_stats)
+    uint64_t* h_res = nullptr;            // pinned: the same
     bool flat_planned = false;  // the trial ran on the scan-level index (a plan made while the index was still being built is
                                 // made again, once, when the index is in place: slices to probe, candidate statistics)
     float plan_ms = 0;      // what planning cost (trial launches + the host round trip)
@@ -98,6 +111,8 @@ struct LikePipeline {
     bool built = false, eligible = false;
     LeanRec* d_lean = nullptr;  // one record per workgroup
     uint32_t n_lean = 0;
+    uint32_t* d_lean_begins = nullptr;  // first entry of every record (+ the end): k_lean_records builds the records from the
+    void* h_lean_begins = nullptr;      // scan's descriptors on the device; the pinned source of the upload lives as long
     // the scan-level wide signature index of k_like_flat (see below): kFlatBits slices over the dictionary words of ALL
     // entries of the scan, slice-major; null when the scan is not eligible for it (or it did not fit)
     bool lean_ok = false;                      // every entry fits k_like_lean's 1 KB of mask words (<= kPostLdsRows rows)
@@ -339,9 +354,12 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
             if (a.stats) {
                 const uint64_t lb = wave_sum_u64(uint64_t(len));
                 if (lane == 0) {
-                    atomicAdd(a.stats, (unsigned long long)min(count - b0, uint32_t(kWave)));
-                    atomicAdd(a.stats + 1, (unsigned long long)lb);
-                    atomicAdd(a.stats + 2, (unsigned long long)__popcll(matched));
+                    // (kStatShards copies of the three counters, by workgroup: 36,000 atomics of a 12,207-entry scan on ONE
+                    // address took the kernel from 27 to 453 us — what round 5's 0.37 ms "plan" was made of)
+                    unsigned long long* st = a.stats + (blockIdx.x & (kStatShards - 1u)) * kStatStride;
+                    atomicAdd(st, (unsigned long long)min(count - b0, uint32_t(kWave)));
+                    atomicAdd(st + 1, (unsigned long long)lb);
+                    atomicAdd(st + 2, (unsigned long long)__popcll(matched));
                 }
             }
             if (kNot) {
@@ -484,6 +502,42 @@ __global__ __launch_bounds__(kLeanWaves * 64, 24 / kLeanWaves) void k_like_lean(
         }
     }
     if (a.total.d_total_out && lane == 0) total_contribute(a.total, blockIdx.x * kLeanWaves + wave, gridDim.x * kLeanWaves, wave_hits);
+}
+
+// The records of k_like_lean, built on the device from the scan's descriptors (round 6: the host used to fill 736 bytes per
+// record and copy 2.2 MB from pageable memory — 0.5 ms of a 12,207-entry scan's first LIKE).  One thread per (record, slot).
+__global__ __launch_bounds__(256) void k_lean_records(const StrDesc* __restrict__ descs, const uint32_t* __restrict__ begins,
+                                                      uint32_t n_recs, LeanRec* __restrict__ recs) {
+    constexpr uint32_t kSlots = 9;
+    const uint64_t t = uint64_t(blockIdx.x) * 256u + threadIdx.x;
+    const uint32_t r = uint32_t(t / kSlots), k = uint32_t(t % kSlots);
+    if (r >= n_recs) return;
+    const uint32_t begin = begins[r], end = begins[r + 1];
+    if (k == 0) {
+        recs[r].begin = begin;
+        recs[r].end = end;
+        recs[r].slot = descs[begin].symtab_slot;
+        recs[r].pad = 0;
+    }
+    LeanEntry e;
+    __builtin_memset(&e, 0, sizeof(e));
+    if (begin + k < end) {
+        const StrDesc& d = descs[begin + k];
+        e.sig = d.signatures;
+        e.residuals = d.residuals;
+        e.fsst = d.fsst;
+        e.postings = d.postings;
+        e.mask_word_off = d.mask_word_off;
+        e.slope = d.slope;
+        e.intercept = d.intercept;
+        e.d = d.d;
+        e.n = d.n;
+        e.offset_bytes = d.offset_bytes;
+        e.nw = (d.d + 63u) / 64u;
+        e.validity = d.validity;
+        e.fingerprints = d.fingerprints;
+    }
+    recs[r].e[k] = e;
 }
 
 hipError_t launch_lean(int n_sig, bool negated, const LeanArgs& a, uint32_t n_recs, hipStream_t stream) {
@@ -925,9 +979,12 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
             if (a.stats) {
                 const uint64_t lb = wave_sum_u64(uint64_t(len));
                 if (lane == 0) {
-                    atomicAdd(a.stats, (unsigned long long)min(count - b0, uint32_t(kWave)));
-                    atomicAdd(a.stats + 1, (unsigned long long)lb);
-                    atomicAdd(a.stats + 2, (unsigned long long)__popcll(matched));
+                    // (kStatShards copies of the three counters, by workgroup: 36,000 atomics of a 12,207-entry scan on ONE
+                    // address took the kernel from 27 to 453 us — what round 5's 0.37 ms "plan" was made of)
+                    unsigned long long* st = a.stats + (blockIdx.x & (kStatShards - 1u)) * kStatStride;
+                    atomicAdd(st, (unsigned long long)min(count - b0, uint32_t(kWave)));
+                    atomicAdd(st + 1, (unsigned long long)lb);
+                    atomicAdd(st + 2, (unsigned long long)__popcll(matched));
                 }
             }
             // rows of the matching dictionary values from the entries' inverted row lists, into the LDS mask words
@@ -1107,6 +1164,7 @@ struct FbOffsets {  // what str_offset_pair reads of an entry
     uint32_t offset_bytes;
 };
 template <bool kUni> constexpr uint32_t fb_row_words() { return (kUni ? 256u : uint32_t(kFlatBits)) + 2u; }  // (+2: the store loop's bank spread)
+constexpr size_t kFbPoliteLds = 2048;  // extra dynamic LDS of a "polite" build: 2 x (81,408 + 2,048) > 160 KiB, one workgroup per CU
 template <bool kUni> constexpr size_t fb_lds_bytes() {
     return size_t(kFbWords) * fb_row_words<kUni>() * 8u + 256u * 8u + size_t(kFbValues) * 8u + size_t(kFbValues) * 4u + 256u + kFbValues;
 }
@@ -1305,7 +1363,12 @@ bool index_reserve(lc_ctx* ctx, uint64_t bytes, bool allow_evict, int* why) {
 // signature words), their records, and the kFlatBits slices built from the dictionary values.  A scan whose index does not
 // fit (more than half of the free device memory) keeps k_like_lean.  Fills the flat fields of `lp` — the scan's pipeline when
 // the caller waits for the build, a stand-in that the evaluating thread merges later when the builder thread runs it.
-lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream, bool allow_evict = true) {
+// `polite` (the builder thread's builds): the kernel runs with ONE workgroup per CU instead of two.  A workgroup is 16 waves and
+// two of them take every wave slot of a CU for the ~4 ms the build of a 100 M-row column lasts — measured: a query launched
+// while the build ran waited until it had finished (4.2 ms for a 30 us kernel).  With one per CU (a kilobyte more of dynamic LDS
+// makes the second one not fit) half of the slots stay free for the queries the build must not hold up.
+lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream, bool allow_evict = true, bool polite = false) {
+    LC_PHASE("build_flat (all; builder thread when async)");
     lp->flat = false;
     lp->flat_tried = true;
     lp->flat_why = 0;
@@ -1381,6 +1444,9 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
             dst_word[s->n + groups[gi].first_entry + j] = uint32_t(gi * flat_group_stride(256u, gw) + groups[gi].word_off[j]);
     const uint64_t slice_words = uint64_t(groups.size()) * gw;
     const uint64_t bytes = slice_words * 8u * uint64_t(kFlatBits);
+    {
+        LC_PHASE("build_flat: host grouping done; reserve");
+    }
     if (!index_reserve(ctx, bytes, allow_evict, &lp->flat_why)) return LC_OK;  // no room: the entry-level index serves
     struct Reservation {  // given back unless the index ends up in place
         lc_ctx* c; uint64_t b; bool keep;
@@ -1408,7 +1474,13 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     std::memcpy(h_stage + g_bytes, dst_word.data(), d_bytes);
     lp->d_dst_word = d_dst;
     lp->slice_words = slice_words;
-    if (hipMalloc(reinterpret_cast<void**>(&lp->d_slices), bytes) != hipSuccess) {
+    LC_PHASE("build_flat: hipMalloc + launch + wait");
+    hipError_t e_malloc;
+    {
+        LC_PHASE("build_flat: hipMalloc of the slices");
+        e_malloc = hipMalloc(reinterpret_cast<void**>(&lp->d_slices), bytes);
+    }
+    if (e_malloc != hipSuccess) {
         (void)hipGetLastError();
         lp->d_slices = nullptr;
         lp->flat_why = 2;
@@ -1423,9 +1495,9 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     FlatBuildArgs ba{lp->d_groups, s->d_symtabs, lp->d_slices, flat_slice_stride(uint32_t(groups.size()), gw),
                      flat_group_stride(kFlatBits, gw)};
     LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_build<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               int(fb_lds_bytes<false>())));
-    hipLaunchKernelGGL(k_flat_build<false>, dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads), fb_lds_bytes<false>(),
-                       stream, ba);
+                               int(fb_lds_bytes<false>() + kFbPoliteLds)));
+    hipLaunchKernelGGL(k_flat_build<false>, dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads),
+                       fb_lds_bytes<false>() + (polite ? kFbPoliteLds : 0u), stream, ba);
     LC_HIP(hipGetLastError());
     if (ev1) LC_HIP(hipEventRecord(ev1, stream));
     LC_HIP(hipStreamSynchronize(stream));  // the vectors are locals
@@ -1484,6 +1556,7 @@ lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t s
 
 // per-workgroup records, built once per scan
 lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
+    LC_PHASE("like: workgroup records (lean)");
     lp->built = true;
     lp->eligible = false;
     lp->uids.clear();
@@ -1495,31 +1568,32 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
     }
     lp->lean_ok = true;  // (entries of more than 8,192 rows: only k_like_flat, whose LDS mask size is the scan's)
     for (const Entry& e : s->meta) lp->lean_ok = lp->lean_ok && e.sd.n <= kPostLdsRows;
-    // consecutive entries, at most kLeanWaves * kLeanE, never across a symbol-table change
-    std::vector<LeanRec> lean;
+    // consecutive entries, at most kLeanWaves * kLeanE, never across a symbol-table change: the host says where each record
+    // begins (through a pinned block that lives as long as the pipeline: no wait for the copy), k_lean_records fills them in
+    std::vector<uint32_t> begins;
     for (uint32_t b = 0, i = 1; i <= s->n; i++) {
         if (i == s->n || i - b == kLeanWaves * kLeanE || s->meta[i].sd.symtab_slot != s->meta[b].sd.symtab_slot) {
-            LeanRec r;
-            std::memset(&r, 0, sizeof(r));
-            r.begin = b;
-            r.end = i;
-            r.slot = s->meta[b].sd.symtab_slot;
-            for (uint32_t k = b; k < i; k++) {
-                const StrDesc& d = s->meta[k].sd;
-                r.e[k - b] = LeanEntry{d.signatures, d.residuals, d.fsst, d.postings, d.mask_word_off, d.slope, d.intercept,
-                                       d.d, d.n, d.offset_bytes, (d.d + 63u) / 64u, d.validity, d.fingerprints};
-            }
-            lean.push_back(r);
+            begins.push_back(b);
             b = i;
         }
     }
-    lp->n_lean = uint32_t(lean.size());
-    lp->d_lean = static_cast<LeanRec*>(pool_alloc(ctx, std::max<size_t>(lean.size(), 1) * sizeof(LeanRec)));
+    begins.push_back(s->n);
+    lp->n_lean = uint32_t(begins.size() - 1);
+    lp->d_lean = static_cast<LeanRec*>(pool_alloc(ctx, std::max<size_t>(lp->n_lean, 1) * sizeof(LeanRec)));
     lp->d_total_acc = static_cast<unsigned long long*>(pool_alloc(ctx, size_t(kTotalWords) * 8));
-    if (!lp->d_lean || !lp->d_total_acc) return fail(LC_ERR_OOM, "hipMalloc (LIKE records)");
-    LC_HIP(hipMemcpyAsync(lp->d_lean, lean.data(), lean.size() * sizeof(LeanRec), hipMemcpyHostToDevice, stream));
+    lp->d_lean_begins = static_cast<uint32_t*>(pool_alloc(ctx, begins.size() * 4));
+    lp->h_lean_begins = host_pool_alloc(ctx, begins.size() * 4);
+    if (!lp->d_lean || !lp->d_total_acc || !lp->d_lean_begins || !lp->h_lean_begins) return fail(LC_ERR_OOM, "hipMalloc (LIKE records)");
+    std::memcpy(lp->h_lean_begins, begins.data(), begins.size() * 4);
+    LC_HIP(hipMemcpyAsync(lp->d_lean_begins, lp->h_lean_begins, begins.size() * 4, hipMemcpyHostToDevice, stream));
     LC_HIP(hipMemsetAsync(lp->d_total_acc, 0, size_t(kTotalWords) * 8, stream));  // once: launches leave it zero
-    LC_HIP(hipStreamSynchronize(stream));  // `lean` is a local
+    {
+        const uint64_t threads = uint64_t(lp->n_lean) * 9u;
+        hipLaunchKernelGGL(k_lean_records, dim3(uint32_t((threads + 255u) / 256u)), dim3(256), 0, stream,
+                           static_cast<const StrDesc*>(s->d_descs), lp->d_lean_begins, lp->n_lean, lp->d_lean);
+        LC_HIP(hipGetLastError());
+    }
+    // (later evaluations on OTHER streams are ordered behind this one by scan_enter_stream's drain of the previous stream)
     lp->eligible = true;
     return LC_OK;
 }
@@ -1614,12 +1688,24 @@ lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L,
     return LC_OK;
 }
 
+// [COUNT(*), candidates, candidate bytes, matching values] out of a planning run's raw counters
+static void sum_stats(const uint64_t* raw, uint64_t (&res)[4]) {
+    res[0] = raw[0];
+    res[1] = res[2] = res[3] = 0;
+    for (uint32_t k = 0; k < kStatShards; k++) {
+        res[1] += raw[kStatStride + kStatStride * k];
+        res[2] += raw[kStatStride + kStatStride * k + 1];
+        res[3] += raw[kStatStride + kStatStride * k + 2];
+    }
+}
+
 // one trial evaluation into scratch: how many rows does the needle hit?
 lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost& sp, hipStream_t stream, LikePlan* plan) {
+    LC_PHASE("like: plan (trial + round trip)");
     plan->needle = sp.needle;
     plan->use_lean = false;
     const uint64_t words = std::max<uint64_t>(s->seg_offsets.back(), 1);
-    uint64_t* d_scratch = static_cast<uint64_t*>(pool_alloc(ctx, words * 8 + 32));  // mask | COUNT(*) | 3 statistics
+    uint64_t* d_scratch = static_cast<uint64_t*>(pool_alloc(ctx, (words + kStatWords) * 8));  // mask | COUNT(*) + the statistics
     struct Tmp {
         lc_ctx* c; void* p; hipStream_t st;
         ~Tmp() { (void)hipStreamSynchronize(st); pool_release(c, p); }
@@ -1628,18 +1714,25 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
     ScanLaunch L{};
     L.d_hit = d_scratch;
     L.d_total_out = d_scratch + words;
-    LC_HIP(hipMemsetAsync(d_scratch + words, 0, 32, stream));
+    LC_HIP(hipMemsetAsync(d_scratch + words, 0, kStatWords * 8, stream));
     // (always as LIKE: the plan belongs to the needle, NOT LIKE is selective exactly when LIKE is)
-    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(d_scratch + words + 1);
+    unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(d_scratch + words + kStatStride);
     const bool use_flat = lp->flat && (ctx->like_path == 0 || ctx->like_path == 4);
     const auto t_begin = std::chrono::steady_clock::now();
+    uint64_t* raw = static_cast<uint64_t*>(host_pool_alloc(ctx, kStatWords * 8));  // (pinned: a copy into pageable memory is staged and slow)
     uint64_t res[4] = {0, 0, 0, 0};
+    struct ResTmp {
+        lc_ctx* c; void* p;
+        ~ResTmp() { host_pool_release(c, p); }
+    } res_tmp{ctx, raw};
+    if (!raw) return fail(LC_ERR_OOM, "hipHostMalloc (LIKE plan)");
     auto trial = [&](uint32_t n_probe) -> lc_status {
-        LC_HIP(hipMemsetAsync(d_scratch + words, 0, 32, stream));
+        LC_HIP(hipMemsetAsync(d_scratch + words, 0, kStatWords * 8, stream));
         const lc_status rc = use_flat ? run_flat(lp, sp, L, stream, d_stats, true, n_probe) : run_lean(lp, sp.p, L, stream, d_stats, true);
         if (rc != LC_OK) return rc;
-        LC_HIP(hipMemcpyAsync(res, d_scratch + words, 32, hipMemcpyDeviceToHost, stream));
+        LC_HIP(hipMemcpyAsync(raw, d_scratch + words, kStatWords * 8, hipMemcpyDeviceToHost, stream));
         LC_HIP(hipStreamSynchronize(stream));
+        sum_stats(raw, res);
         return LC_OK;
     };
     uint16_t bits[kMaxSigProbeWide];
@@ -1674,6 +1767,83 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
 }
 
 }  // namespace
+
+// Plans made on the fly (LikePlan::pending): what they hold while the figures are under way, and their settlement.
+constexpr uint32_t kPlanSlots = 256;
+static bool plan_slot_take(lc_ctx* ctx, LikePlan* q) {
+    std::lock_guard<std::mutex> g(ctx->plan_slots_mu);
+    if (!ctx->plan_slots_tried) {
+        LC_PHASE("plan slots: first allocation");
+        ctx->plan_slots_tried = true;
+        void* d = nullptr;
+        void* h = nullptr;
+        if (hipMalloc(&d, size_t(kPlanSlots) * kStatWords * 8) == hipSuccess &&
+            hipHostMalloc(&h, size_t(kPlanSlots) * kStatWords * 8, hipHostMallocDefault) == hipSuccess) {
+            ctx->plan_slots_d = static_cast<unsigned long long*>(d);
+            ctx->plan_slots_h = static_cast<uint64_t*>(h);
+            ctx->plan_slot_ev.assign(kPlanSlots, nullptr);
+            for (uint32_t i = kPlanSlots; i-- > 0;) ctx->plan_slots_free.push_back(i);
+        } else {
+            (void)hipGetLastError();
+            if (d) (void)hipFree(d);
+        }
+    }
+    if (ctx->plan_slots_free.empty()) return false;  // (every slot is under way: this needle gets a trial run instead)
+    const uint32_t i = ctx->plan_slots_free.back();
+    if (!ctx->plan_slot_ev[i] && hipEventCreateWithFlags(&ctx->plan_slot_ev[i], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    ctx->plan_slots_free.pop_back();
+    q->slot = int32_t(i);
+    q->ev = ctx->plan_slot_ev[i];
+    q->d_res = ctx->plan_slots_d + size_t(i) * kStatWords;
+    q->h_res = ctx->plan_slots_h + size_t(i) * kStatWords;
+    return true;
+}
+static void release_pending_plan(lc_ctx* ctx, LikePlan* q) {
+    if (q->slot < 0) return;
+    if (q->pending) (void)hipEventSynchronize(q->ev);  // (the kernel may still be adding to d_res)
+    {
+        std::lock_guard<std::mutex> g(ctx->plan_slots_mu);
+        ctx->plan_slots_free.push_back(uint32_t(q->slot));
+    }
+    q->slot = -1;
+    q->ev = nullptr;
+    q->d_res = nullptr;
+    q->h_res = nullptr;
+    q->pending = false;
+}
+void plan_slots_destroy(lc_ctx* ctx) {  // lc_ctx_destroy
+    std::lock_guard<std::mutex> g(ctx->plan_slots_mu);
+    for (hipEvent_t e : ctx->plan_slot_ev)
+        if (e) (void)hipEventDestroy(e);
+    ctx->plan_slot_ev.clear();
+    if (ctx->plan_slots_d) (void)hipFree(ctx->plan_slots_d);
+    if (ctx->plan_slots_h) (void)hipHostFree(ctx->plan_slots_h);
+    ctx->plan_slots_d = nullptr;
+    ctx->plan_slots_h = nullptr;
+    ctx->plan_slots_free.clear();
+}
+// true when the plan's figures are in (block: wait for them)
+static bool settle_plan(lc_ctx* ctx, const lc_scan* s, LikePlan* q, bool block) {
+    if (!q->pending) return true;
+    if (!block) {
+        const hipError_t e = hipEventQuery(q->ev);
+        if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    } else {
+        (void)hipEventSynchronize(q->ev);
+    }
+    uint64_t res[4];
+    sum_stats(q->h_res, res);
+    q->hits = res[0];
+    q->n_cand = res[1];
+    q->cand_bytes = res[2];
+    q->matches = res[3];
+    q->use_lean = q->hits * 1024u <= uint64_t(kMaxHitsPer1024) * std::max<uint64_t>(s->total_rows, 1024);
+    release_pending_plan(ctx, q);
+    return true;
+}
 
 // A destroyed scan's pipeline waits here for the next scan over the same publications of the same entries (same uids in the
 // same order: same blobs, same mask layout — the records hold pointers into the entries, which the adopting scan pins like
@@ -1739,7 +1909,9 @@ static void settle_builds(lc_ctx* ctx, LikePipeline* lp) {
     promote_builds(ctx, lp);
 }
 void like_pipeline_wait(lc_scan* s) {
-    if (s->like) settle_builds(s->ctx, s->like);
+    if (!s->like) return;
+    settle_builds(s->ctx, s->like);
+    for (LikePlan& q : s->like->plans) (void)settle_plan(s->ctx, s, &q, true);
 }
 // frees the index memory of a CACHED pipeline (index_reserve: budget eviction); the pipeline itself stays cached and may build
 // its index again.  Caller holds the lock that keeps the pipeline idle (ctx->like_orphans_mu / ctx->scan_cache_mu).
@@ -1812,7 +1984,10 @@ void like_orphans_clear(lc_ctx* ctx) {
 void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     if (!lp) return;
     settle_builds(ctx, lp);
+    for (LikePlan& q : lp->plans) release_pending_plan(ctx, &q);
     pool_release(ctx, lp->d_lean);
+    pool_release(ctx, lp->d_lean_begins);
+    host_pool_release(ctx, lp->h_lean_begins);
     pool_release(ctx, lp->d_total_acc);
     pool_release(ctx, lp->d_groups);
     pool_release(ctx, lp->d_dst_word);
@@ -1938,6 +2113,7 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
 // Caller holds s->mu.
 static lc_status want_flat_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
     if (!lp->eligible || lp->flat) return LC_OK;
+    LC_PHASE("like: want_flat_index");
     const uint64_t events = ctx->index_events.load();
     if (lp->flat_no_room) {  // room is looked for again only after index memory has been given back somewhere
         if (lp->flat_retry_events == events) return LC_OK;
@@ -1961,7 +2137,7 @@ static lc_status want_flat_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipS
     lp->flat_state.store(1, std::memory_order_release);
     lp->flat_job = builder_submit(ctx, [ctx, s, lp, pend, allow_evict](hipStream_t st) {
         try {
-            (void)build_flat(ctx, s, pend, st, allow_evict);
+            (void)build_flat(ctx, s, pend, st, allow_evict, true);
         } catch (...) {
             pend->flat = false;
         }
@@ -2035,7 +2211,11 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         automaton_image_bytes(p.needle_len) == 0 || p.verify_len != 0 || L.d_valid || L.d_cand_bytes || L.d_own_bytes || LC_ABL(p.debug_flags != 0))
         return LC_OK;
     if (s->n < ctx->like_pipeline_min_entries || ctx->like_path == 1 || ctx->like_path == 5) return LC_OK;
-    if (!s->like) s->like = like_pipeline_adopt(ctx, s);
+    LC_PHASE("like_pipeline_eval (all)");
+    if (!s->like) {
+        LC_PHASE("like: adopt");
+        s->like = like_pipeline_adopt(ctx, s);
+    }
     if (!s->like) s->like = new LikePipeline();
     LikePipeline* lp = s->like;
     if (!lp->built) {
@@ -2043,7 +2223,10 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
         if (st != LC_OK) return st;
     }
     if (!lp->eligible) return LC_OK;
-    promote_builds(ctx, lp);
+    {
+        LC_PHASE("like: promote");
+        promote_builds(ctx, lp);
+    }
     lp->like_evals++;
     const bool want_flat = ctx->like_path == 0 || ctx->like_path == 4;
     if (want_flat) {
@@ -2056,23 +2239,62 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     LikePlan* plan = nullptr;
     for (LikePlan& q : lp->plans)
         if (q.needle == sp.needle) plan = &q;
-    if (!plan) {
+    if (plan) {
+        LC_PHASE("like: settle plan");
+        (void)settle_plan(ctx, s, plan, false);
+    }
+    // A plan is due for a needle the scan has not seen, and once more when the scan-level index has arrived under a plan made
+    // on the entry-level one.  Where the evaluation asked for IS what a trial would run — a plain LIKE over every row — it is
+    // launched with the statistics counters attached and the plan settles later (no trial, no host round trip: 0.37 ms of a
+    // 12,207-entry scan's first evaluation); a long needle on the scan-level index keeps the two-trial choice of its slices.
+    uint16_t nbits[kMaxSigProbeWide];
+    const uint32_t nb = use_flat ? flat_needle_bits(sp.needle, nbits) : 0u;
+    const bool due = !plan || (use_flat && !plan->flat_planned && !plan->pending);
+    bool on_the_fly = due && p.op == LC_OP_LIKE && !L.d_selection && p.eq_len == 0 && (!use_flat || nb <= uint32_t(kMaxSigProbe)) &&
+                      ctx->like_path != 3 && ctx->like_path != 4;
+    bool created = false;
+    if (due && !plan) {
+        created = true;
         if (lp->plans.size() >= kMaxPlans) {  // least recently used goes
             size_t victim = 0;
             for (size_t i = 1; i < lp->plans.size(); i++)
                 if (lp->plans[i].last_use < lp->plans[victim].last_use) victim = i;
+            release_pending_plan(ctx, &lp->plans[victim]);
             lp->plans.erase(lp->plans.begin() + long(victim));
         }
-        LikePlan fresh;
-        const lc_status st = make_plan(ctx, s, lp, sp, stream, &fresh);
-        if (st != LC_OK) return st;
-        lp->plans.push_back(std::move(fresh));
+        lp->plans.emplace_back();
         plan = &lp->plans.back();
+        plan->needle = sp.needle;
+        plan->use_lean = true;
     }
-    if (use_flat && !plan->flat_planned) {  // planned over the entry-level index while the scan-level one was being built
+    if (on_the_fly && !plan_slot_take(ctx, plan)) on_the_fly = false;  // (no slot free: a trial run plans this needle)
+    if (on_the_fly) {
+        LC_PHASE("like: on-the-fly plan + launch");
+        plan->pending = true;
+        plan->flat_planned = use_flat;
+        plan->n_probe = use_flat ? std::min<uint32_t>(nb, uint32_t(kMaxSigProbe)) : 0u;
+        plan->last_use = ++lp->tick;
+        LC_HIP(hipMemsetAsync(plan->d_res, 0, kStatWords * 8, stream));
+        ScanLaunch L2 = L;
+        if (!L2.d_total_out) L2.d_total_out = reinterpret_cast<uint64_t*>(plan->d_res);
+        const lc_status st = use_flat ? run_flat(lp, sp, L2, stream, plan->d_res + kStatStride, false, plan->n_probe)
+                                      : run_lean(lp, p, L2, stream, plan->d_res + kStatStride);
+        if (st != LC_OK) return st;
+        LC_HIP(hipMemcpyAsync(plan->h_res + 1, plan->d_res + 1, (kStatWords - 1u) * 8, hipMemcpyDeviceToHost, stream));
+        LC_HIP(hipMemcpyAsync(plan->h_res, L2.d_total_out, 8, hipMemcpyDeviceToHost, stream));
+        LC_HIP(hipEventRecord(plan->ev, stream));
+        *handled = true;
+        s->last_native_hits = use_flat && L.d_hits != nullptr;
+        s->last_like_kernel = use_flat ? LC_LIKE_KERNEL_FLAT : LC_LIKE_KERNEL_LEAN;
+        return LC_OK;
+    }
+    if (due) {
         LikePlan again;
         const lc_status st = make_plan(ctx, s, lp, sp, stream, &again);
-        if (st != LC_OK) return st;
+        if (st != LC_OK) {
+            if (created) lp->plans.pop_back();
+            return st;
+        }
         *plan = std::move(again);
     }
     plan->last_use = ++lp->tick;
@@ -2080,6 +2302,7 @@ lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, con
     // sequential walker (every lane works through its own share of the list) beats the lane-parallel one
     if (!plan->use_lean) *many_candidates = plan->n_cand >= uint64_t(kWave) * s->n;
     if (!plan->use_lean && ctx->like_path != 3 && ctx->like_path != 4) return LC_OK;
+    LC_PHASE("like: launch");
     const lc_status st = use_flat ? run_flat(lp, sp, L, stream, nullptr, false, plan->n_probe ? plan->n_probe : kMaxSigProbeWide)
                                   : run_lean(lp, p, L, stream);
     if (st == LC_OK) {

@@ -48,6 +48,51 @@ namespace lc {
 
 // ------------------------------------------------------------------ scratch pool
 constexpr size_t kPoolMinClass = 4096, kPoolMaxClass = size_t(64) << 20, kPoolKeepPerClass = 64;
+// blocks up to these classes are carved out of chunks (lc_ctx::pool_chunks); larger ones are allocations of their own
+constexpr size_t kChunkBytes = size_t(64) << 20, kChunkMaxClass = size_t(16) << 20;
+constexpr size_t kHostChunkBytes = size_t(8) << 20, kHostChunkMaxClass = size_t(2) << 20;
+// pointers inside a chunk are never given back one by one
+static bool in_chunks(const std::vector<void*>& chunks, size_t chunk_bytes, const void* p) {
+    for (void* c : chunks)
+        if (p >= c && p < static_cast<const uint8_t*>(c) + chunk_bytes) return true;
+    return false;
+}
+// Caller holds ctx->pool_mu.  A block of `cls` bytes from the current chunk (a new chunk when it is full), or null.
+static void* carve_device(lc_ctx* ctx, size_t cls) {
+    if (cls > kChunkMaxClass) return nullptr;
+    if (!ctx->pool_chunk_cur || size_t(ctx->pool_chunk_end - ctx->pool_chunk_cur) < cls) {
+        void* c = nullptr;
+        LC_PHASE("pool: new device chunk");
+        if (hipMalloc(&c, kChunkBytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        ctx->pool_chunks.push_back(c);
+        ctx->pool_chunk_cur = static_cast<uint8_t*>(c);
+        ctx->pool_chunk_end = ctx->pool_chunk_cur + kChunkBytes;
+    }
+    void* p = ctx->pool_chunk_cur;
+    ctx->pool_chunk_cur += cls;
+    return p;
+}
+static void* carve_host(lc_ctx* ctx, size_t cls) {
+    if (cls > kHostChunkMaxClass) return nullptr;
+    if (!ctx->hpool_chunk_cur || size_t(ctx->hpool_chunk_end - ctx->hpool_chunk_cur) < cls) {
+        void* c = nullptr;
+        LC_PHASE("pool: new pinned chunk");
+        if (hipHostMalloc(&c, kHostChunkBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        ctx->hpool_chunks.push_back(c);
+        ctx->hpool_chunk_cur = static_cast<uint8_t*>(c);
+        ctx->hpool_chunk_end = ctx->hpool_chunk_cur + kHostChunkBytes;
+    }
+    void* p = ctx->hpool_chunk_cur;
+    ctx->hpool_chunk_cur += cls;
+    return p;
+}
+void pool_prime(lc_ctx* ctx) {  // lc_ctx_create: the first chunks, off every query's path
+    std::lock_guard<std::mutex> g(ctx->pool_mu);
+    void* d = carve_device(ctx, kPoolMinClass);
+    void* h = carve_host(ctx, kPoolMinClass);
+    if (d) ctx->pool_free[kPoolMinClass].push_back(d);
+    if (h) ctx->hpool_free[kPoolMinClass].push_back(h);
+}
 
 // ---- per-thread streams
 void ctx_register(lc_ctx* ctx);
@@ -96,7 +141,13 @@ hipStream_t stream_acquire(lc_ctx* ctx) {
         }
     }
     if (!s) {
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;  // null stream as a fallback
+        // (the highest priority the device offers: the streams queries run on must not queue behind the builder's stream)
+        int lo = 0, hi = 0;
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) {
+            (void)hipGetLastError();
+            s = nullptr;
+        }
+        if (!s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;  // null stream as a fallback
         std::lock_guard<std::mutex> g(ctx->pool_mu);
         ctx->all_streams.push_back(s);
     }
@@ -178,8 +229,13 @@ void* pool_alloc(lc_ctx* ctx, size_t bytes) {
             ctx->pool_live[p] = cls;
             return p;
         }
+        if (void* p = carve_device(ctx, cls)) {
+            ctx->pool_live[p] = cls;
+            return p;
+        }
     }
     void* p = nullptr;
+    LC_PHASE("pool_alloc: hipMalloc");
     if (hipMalloc(&p, cls) != hipSuccess) {
         // the scan-level LIKE indexes kept for the NEXT scan over the same entries are a cache, outside the entry accounting:
         // they go before an allocation fails
@@ -203,11 +259,12 @@ void pool_release(lc_ctx* ctx, void* p) {
         cls = it->second;
         ctx->pool_live.erase(it);
         std::vector<void*>& fl = ctx->pool_free[cls];
-        if (cls <= kPoolMaxClass && fl.size() < kPoolKeepPerClass) {
+        if ((cls <= kPoolMaxClass && fl.size() < kPoolKeepPerClass) || in_chunks(ctx->pool_chunks, kChunkBytes, p)) {
             fl.push_back(p);
             return;
         }
     }
+    LC_PHASE("pool_release: hipFree");
     (void)hipFree(p);
 }
 
@@ -223,8 +280,13 @@ void* host_pool_alloc(lc_ctx* ctx, size_t bytes) {
             ctx->hpool_live[p] = cls;
             return p;
         }
+        if (void* p = carve_host(ctx, cls)) {
+            ctx->hpool_live[p] = cls;
+            return p;
+        }
     }
     void* p = nullptr;
+    LC_PHASE("host_pool_alloc: hipHostMalloc");
     if (hipHostMalloc(&p, cls, hipHostMallocDefault) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> g(ctx->pool_mu);
     ctx->hpool_live[p] = cls;
@@ -240,22 +302,32 @@ void host_pool_release(lc_ctx* ctx, void* p) {
         const size_t cls = it->second;
         ctx->hpool_live.erase(it);
         std::vector<void*>& fl = ctx->hpool_free[cls];
-        if (cls <= kPoolMaxClass && fl.size() < kPoolKeepPerClass) {
+        if ((cls <= kPoolMaxClass && fl.size() < kPoolKeepPerClass) || in_chunks(ctx->hpool_chunks, kHostChunkBytes, p)) {
             fl.push_back(p);
             return;
         }
     }
+    LC_PHASE("host_pool_release: hipHostFree");
     (void)hipHostFree(p);
 }
 
 void pool_destroy(lc_ctx* ctx) {
     std::lock_guard<std::mutex> g(ctx->pool_mu);
     for (auto& kv : ctx->pool_free)
-        for (void* p : kv.second) (void)hipFree(p);
-    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
+        for (void* p : kv.second)
+            if (!in_chunks(ctx->pool_chunks, kChunkBytes, p)) (void)hipFree(p);
+    for (auto& kv : ctx->pool_live)
+        if (!in_chunks(ctx->pool_chunks, kChunkBytes, kv.first)) (void)hipFree(kv.first);
     for (auto& kv : ctx->hpool_free)
-        for (void* p : kv.second) (void)hipHostFree(p);
-    for (auto& kv : ctx->hpool_live) (void)hipHostFree(kv.first);
+        for (void* p : kv.second)
+            if (!in_chunks(ctx->hpool_chunks, kHostChunkBytes, p)) (void)hipHostFree(p);
+    for (auto& kv : ctx->hpool_live)
+        if (!in_chunks(ctx->hpool_chunks, kHostChunkBytes, kv.first)) (void)hipHostFree(kv.first);
+    for (void* c : ctx->pool_chunks) (void)hipFree(c);
+    for (void* c : ctx->hpool_chunks) (void)hipHostFree(c);
+    ctx->pool_chunks.clear();
+    ctx->hpool_chunks.clear();
+    ctx->pool_chunk_cur = ctx->pool_chunk_end = ctx->hpool_chunk_cur = ctx->hpool_chunk_end = nullptr;
     ctx->pool_free.clear();
     ctx->pool_live.clear();
     ctx->hpool_free.clear();
@@ -964,6 +1036,10 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     // (no environment variable is read here: what the library stages and how it evaluates is decided by the caller
     // through lc_ctx_set_option, never by the process environment)
     ctx_register(ctx.get());
+    // the builder thread and its stream, now: creating a stream takes the runtime ~7 ms during which other threads' stream waits
+    // do not return — a first query that started the builder lazily waited 6.3 ms for its 40 us kernel
+    (void)builder_submit(ctx.get(), [](hipStream_t) {});
+    pool_prime(ctx.get());
     *out = ctx.release();
     return LC_OK;
     });
@@ -1025,6 +1101,7 @@ void lc_ctx_destroy(lc_ctx* ctx) {
     }
     like_orphans_clear(ctx);
     builder_shutdown(ctx);
+    plan_slots_destroy(ctx);
     for (Slab& s : ctx->slabs)
         if (s.base) (void)hipFree(s.base);
     pool_destroy(ctx);
@@ -2393,6 +2470,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
 // hold the id to the graveyard).  The reference's reader names entries per query and keeps no scan objects
 // (liquid_cache_reader.rs:264-339): a host that follows it pays the 0.3-1.4 ms of a cold creation once per list, not per query.
 lc_status lc_scan_create(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids, lc_scan** out) {
+    LC_PHASE("lc_scan_create");
     if (ctx && out && entry_ids && n > 0 && ctx->scan_cache_max.load() > 0) {
         lc_scan* hit = nullptr;
         bool reap = false;
@@ -2439,6 +2517,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
     LC_PROF_T0;
+    LC_PHASE("scan_create (all)");
     std::unique_ptr<lc_scan> s(new lc_scan());
     s->ctx = ctx;
     s->n = uint32_t(n);
@@ -2446,6 +2525,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     s->meta.reserve(n);
     s->lens.reserve(n);
     {
+        LC_PHASE("scan_create: capture entries");
         // ONE critical section captures the entries and pins their slabs: between a capture under one lock and a pin
         // under another an lc_evict / re-stage could drain the slab and the scan would keep dangling device pointers.
         // The pins are taken after every entry has validated, so the error returns below leave nothing pinned.
@@ -2544,25 +2624,26 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
 
 void lc_scan_destroy(lc_scan* s) {
     if (!s) return;
+    LC_PHASE("lc_scan_destroy");
     lc_ctx* ctx = s->ctx;
     if (s->cacheable && ctx->scan_cache_max.load() > 0) {
         // kept for the next lc_scan_create over the same list.  What the caller may rely on stays true: nothing of this scan is
-        // in flight when the call returns (its streams are drained, an index build for it has finished); the scan-level LIKE
-        // index stays with the kept scan, where the index budget can reclaim it (index_reserve).
+        // in flight on the caller's streams when the call returns (they are drained); the scan-level LIKE index — or the build
+        // of it that the builder thread is still running — stays with the kept scan, where the index budget can reclaim it.
         try {
             (void)hipSetDevice(ctx->device);
             std::vector<hipStream_t> used;
             {
+                // (the kept scan forgets the streams: the caller may destroy them once its scans are gone — "a stream must
+                // outlive the scans it was used with" — and the next holder of this scan brings its own)
                 std::lock_guard<std::mutex> g(s->mu);
-                used = s->streams_used;
+                used.swap(s->streams_used);
+                s->last_stream = nullptr;
+                s->used = false;
             }
             for (hipStream_t st : used) (void)hipStreamSynchronize(st);
-            {
-                // the builder reads the scan: a build in flight is waited for, so that a kept scan is idle (its index memory can
-                // then be reclaimed by the budget, index_reserve) and a destroyed one is not read any more
-                std::lock_guard<std::mutex> g(s->mu);
-                like_pipeline_wait(s);
-            }
+            // (an index build in flight for this scan goes on: the kept scan stays alive for the builder, which a scan that is
+            // really destroyed waits for; index_reserve leaves pipelines with a job in flight alone)
             ctx->index_events++;  // (whatever index this scan holds is reclaimable from now on)
             std::vector<lc_scan*> out;
             bool kept = false;
@@ -2617,6 +2698,8 @@ static void scan_destroy_now(lc_scan* s) {
     pool_release(s->ctx, s->d_mask_scratch);
     pool_release(s->ctx, s->d_or_tmp);
     pool_release(s->ctx, s->d_agg_partials);
+    pool_release(s->ctx, s->d_wg_begins);
+    host_pool_release(s->ctx, s->h_wg_begins);
     pool_release(s->ctx, s->d_group_ends);
     pool_release(s->ctx, s->d_group_entry_counts);
     like_pipeline_orphan(s->ctx, s->like);
@@ -2761,6 +2844,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
                                 hipStream_t stream, const lc_predicate* pred2 = nullptr, void* d_total_out = nullptr,
                                 bool tolerate_backing = false, const HitsOut* hits = nullptr) {
     return guarded([&]() -> lc_status {
+    LC_PHASE("scan_eval_impl");
     if (!ctx || !s || !pred) return fail(LC_ERR_INVALID, "null argument");
     // d_mask_out == NULL: the caller consumes COUNT(*), per-entry counts or the hit list and wants no mask
     if (!d_mask_out && !d_total_out && !d_counts_out && !(hits && hits->d_hits))
@@ -2913,7 +2997,9 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         }
     }
     std::lock_guard<std::mutex> g(s->mu);
+    LC_PHASE("eval: string path (all, host side)");
     if (!s->d_wg_ranges) {
+        LC_PHASE("eval: workgroup records");
         // workgroup records: consecutive entries, at most four, never across a symbol-table change (row-group boundary).
         // The host says where each begins; k_str_wg_records copies the descriptors into them on the device.
         std::vector<uint32_t> begins;
@@ -2929,22 +3015,14 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         s->n_wg_ranges = uint32_t(n_recs);
         s->d_wg_ranges = static_cast<StrWgRecord*>(pool_alloc(ctx, std::max<size_t>(n_recs, 1) * sizeof(StrWgRecord)));
         if (!s->d_wg_ranges) return fail(LC_ERR_OOM, "hipMalloc (scan workgroup records)");
-        uint32_t* d_begins = static_cast<uint32_t*>(pool_alloc(ctx, begins.size() * 4));
-        void* h_b = host_pool_alloc(ctx, begins.size() * 4);  // (through pinned staging: see scan_create_impl)
-        if (!d_begins || !h_b) {
-            pool_release(ctx, d_begins);
-            host_pool_release(ctx, h_b);
-            return fail(LC_ERR_OOM, "scan workgroup records: staging");
-        }
-        std::memcpy(h_b, begins.data(), begins.size() * 4);
-        const hipError_t ec = hipMemcpyAsync(d_begins, h_b, begins.size() * 4, hipMemcpyHostToDevice, stream);
-        const hipError_t ek = ec == hipSuccess ? launch_str_wg_records(static_cast<const StrDesc*>(s->d_descs), d_begins, uint32_t(n_recs),
-                                                                       s->d_wg_ranges, stream) : ec;
-        const hipError_t es = hipStreamSynchronize(stream);
-        host_pool_release(ctx, h_b);
-        pool_release(ctx, d_begins);
-        LC_HIP(ek);
-        LC_HIP(es);
+        // (the staging blocks stay with the scan: nothing waits for the copy — the first LIKE of a 12,207-entry scan spent 70-120 us
+        // here)
+        s->d_wg_begins = static_cast<uint32_t*>(pool_alloc(ctx, begins.size() * 4));
+        s->h_wg_begins = host_pool_alloc(ctx, begins.size() * 4);  // (through pinned staging: see scan_create_impl)
+        if (!s->d_wg_begins || !s->h_wg_begins) return fail(LC_ERR_OOM, "scan workgroup records: staging");
+        std::memcpy(s->h_wg_begins, begins.data(), begins.size() * 4);
+        LC_HIP(hipMemcpyAsync(s->d_wg_begins, s->h_wg_begins, begins.size() * 4, hipMemcpyHostToDevice, stream));
+        LC_HIP(launch_str_wg_records(static_cast<const StrDesc*>(s->d_descs), s->d_wg_begins, uint32_t(n_recs), s->d_wg_ranges, stream));
     }
     L.d_wg_ranges = s->d_wg_ranges;
     L.n_wg_ranges = s->n_wg_ranges;
@@ -2957,6 +3035,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     }
     L.d_work = s->d_work;
     auto build_automata = [&](StrPredHost& q) -> lc_status {
+        LC_PHASE("eval: automata");
         const uint32_t stride = automaton_stride(q.p.needle_len);
         const size_t nst = s->n_symtabs;
         const size_t need = size_t(stride) * std::max<size_t>(nst, 1);
@@ -3664,7 +3743,11 @@ lc_status lc_stream_create(lc_ctx* ctx, void** out_stream) {
     if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
     LC_HIP(hipSetDevice(ctx->device));
     hipStream_t s = nullptr;
-    LC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    int lo = 0, hi = 0;  // (query streams take the highest priority: see stream_acquire)
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s, hipStreamNonBlocking, hi) != hipSuccess) {
+        (void)hipGetLastError();
+        LC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
     *out_stream = s;
     return LC_OK;
     });
