@@ -1022,6 +1022,23 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, co
     return fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, W, two_sided, a);
 }
 
+// A run of an entry's 1024-row blocks as an entry of its own (ScanLaunch::entry_split_log2): part `part` of 2^sl.  The blocks
+// of an entry are independent — 128 W bytes of packed words and 16 mask words each — so a narrow entry (W = 4: 4 KB in all,
+// one dependent round trip after the other for a single wave) is spread over several waves.  false: the part is empty.
+__device__ __forceinline__ bool entry_part(FixedDesc& d, uint32_t part, uint32_t sl, uint32_t& word0) {
+    word0 = 0;
+    if (sl == 0) return true;
+    const uint32_t nblocks = (d.len + 1023u) >> 10, per = (nblocks + (1u << sl) - 1u) >> sl, b0 = part * per;
+    if (b0 >= nblocks) return false;
+    const uint32_t b1 = min(nblocks, b0 + per);
+    const uint32_t r0 = b0 << 10, r1 = min(d.len, b1 << 10);
+    d.packed += uint64_t(b0) * 128u * d.W;
+    if (d.validity) d.validity += b0 * 16u;
+    d.len = r1 - r0;
+    word0 = b0 * 16u;
+    return true;
+}
+
 template <typename U, int kMaxW>
 __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __restrict__ descs, FixedPred pred,
                                                               FixedPred pred2, ScanLaunch L) {
@@ -1030,19 +1047,25 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     const uint32_t bal = uint32_t(reinterpret_cast<uintptr_t>(&s_ballots[wave][0]));
     const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    const uint32_t sl = L.entry_split_log2, n_units = L.n_entries << sl;
     uint64_t wave_hits = 0;
-    for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
+    for (uint32_t unit = blockIdx.x * kWavesPerBlock + wave; unit < n_units; unit += total_waves) {
         // (measured and dropped: the next entry's descriptor fetched ahead — no change — and the whole entry requested at
         // once through an LDS scratch line so that the passes hit in L2: Date32 W = 12 36 -> 45 us cold, 29 -> 41 hot; the
         // second trip of every line through the L2 -> CU fabric costs more than the HBM latency it hides)
-        const FixedDesc d = descs[entry];
-        const uint32_t c = fixed_pred_entry_step<U, kMaxW>(d, pred, pred2,
-                                                           L.d_selection ? L.d_selection + d.mask_word_off : nullptr,
-                                                           L.d_hit + d.mask_word_off,
-                                                           L.d_valid ? L.d_valid + d.mask_word_off : nullptr, lane, bal);
+        const uint32_t entry = unit >> sl;
+        FixedDesc d = descs[entry];
+        uint32_t word0;
+        if (!entry_part(d, unit & ((1u << sl) - 1u), sl, word0)) continue;
+        const uint64_t woff = d.mask_word_off + word0;
+        const uint32_t c = fixed_pred_entry_step<U, kMaxW>(d, pred, pred2, L.d_selection ? L.d_selection + woff : nullptr,
+                                                           L.d_hit + woff, L.d_valid ? L.d_valid + woff : nullptr, lane, bal);
         if (L.d_counts || L.d_total_out) {
             const uint64_t t = wave_sum_u64(uint64_t(c));
-            if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(t);
+            if (lane == 0 && L.d_counts) {
+                if (sl) atomicAdd(L.d_counts + entry, uint32_t(t));  // (the launcher zeroed the counts of a split launch)
+                else L.d_counts[entry] = uint32_t(t);
+            }
             wave_hits += t;
         }
     }
@@ -5005,22 +5028,49 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
 #define LC_X_REG_GRID_FACTOR 1
 #endif
     const uint64_t wgs_resident = uint64_t(n_cus) * ((lane_log2 == 6 && !reg) ? 4 : 8) * (reg ? LC_X_REG_GRID_FACTOR : 1);
-    const dim3 grid(uint32_t(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), block(kThreads);
     if (reg) {
+        // A/B aid (round 6), OFF in the shipped build: an entry worked on by 2^k waves, each taking a run of its blocks
+        // (entry_part).  The idea — 12,207 entries over 8,192 resident waves leave half of the machine idle for the second
+        // round, and an 8192-row entry of W = 4 is only 4 KB — is wrong about where the time goes.  Measured, L3-cold, 100 M rows
+        // (profiles/r6/ab_entry_split.txt): Decimal W = 4 26.5 us unsplit, 40.0 in halves, 56.9 in quarters, 97.4 in eighths;
+        // Date32 W = 12 35.5 / 46.6 / 49.3 / 59.6; Int64 W = 17 50.8 / 63.4.  Fitting time = rounds x (F + blocks x B) gives a
+        // fixed cost per UNIT of about twelve block times: the descriptor, the first packed words and their stores are three
+        // dependent round trips that every unit pays, so more units per entry means more of them — a narrow entry wants FEWER
+        // dependent trips (everything of the entry requested at once), not more waves.
+#ifndef LC_X_SPLIT_W8
+#define LC_X_SPLIT_W8 0
+#endif
+#ifndef LC_X_SPLIT_W16
+#define LC_X_SPLIT_W16 0
+#endif
+#ifndef LC_X_SPLIT_W32
+#define LC_X_SPLIT_W32 0
+#endif
+        ScanLaunch L2 = L;
+        L2.entry_split_log2 = L.blocks_per_entry < 2 ? 0u : (max_width <= 8 ? LC_X_SPLIT_W8 : (max_width <= 16 ? LC_X_SPLIT_W16 : LC_X_SPLIT_W32));
+        while (L2.entry_split_log2 && (1u << L2.entry_split_log2) > L.blocks_per_entry) L2.entry_split_log2--;
+        if (L2.entry_split_log2 && L.d_counts) {  // the parts of an entry add their counts
+            const hipError_t ez = hipMemsetAsync(L.d_counts, 0, size_t(L.n_entries) * 4, stream);
+            if (ez != hipSuccess) return ez;
+        }
+        const uint64_t units = uint64_t(L.n_entries) << L2.entry_split_log2;
+        const uint64_t need = (units + kWavesPerBlock - 1) / kWavesPerBlock;
+        const dim3 grid(uint32_t(need < wgs_resident ? need : wgs_resident)), block(kThreads);
         const bool narrow = max_width <= 16;
         switch (lane_log2) {
-            case 4: hipLaunchKernelGGL((k_fixed_pred_reg<uint16_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L); break;
+            case 4: hipLaunchKernelGGL((k_fixed_pred_reg<uint16_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L2); break;
             case 5:
-                if (narrow) hipLaunchKernelGGL((k_fixed_pred_reg<uint32_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L);
-                else hipLaunchKernelGGL((k_fixed_pred_reg<uint32_t, 32>), grid, block, 0, stream, d_descs, pred, p2, L);
+                if (narrow) hipLaunchKernelGGL((k_fixed_pred_reg<uint32_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L2);
+                else hipLaunchKernelGGL((k_fixed_pred_reg<uint32_t, 32>), grid, block, 0, stream, d_descs, pred, p2, L2);
                 break;
             default:
-                if (narrow) hipLaunchKernelGGL((k_fixed_pred_reg<uint64_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L);
-                else hipLaunchKernelGGL((k_fixed_pred_reg<uint64_t, 32>), grid, block, 0, stream, d_descs, pred, p2, L);
+                if (narrow) hipLaunchKernelGGL((k_fixed_pred_reg<uint64_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L2);
+                else hipLaunchKernelGGL((k_fixed_pred_reg<uint64_t, 32>), grid, block, 0, stream, d_descs, pred, p2, L2);
                 break;
         }
         return hipGetLastError();
     }
+    const dim3 grid(uint32_t(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), block(kThreads);
     switch (lane_log2) {
         case 3: hipLaunchKernelGGL(k_fixed_pred<uint8_t>, grid, block, 0, stream, d_descs, pred, p2, L); break;
         case 4: hipLaunchKernelGGL(k_fixed_pred<uint16_t>, grid, block, 0, stream, d_descs, pred, p2, L); break;

@@ -263,7 +263,8 @@ struct ScanLaunch {
     uint32_t* d_hit_first;
     uint32_t mask_optional;           // d_hit is the scan's own scratch (the caller wants no mask): a kernel that can answer
                                       // d_counts / d_total_out / d_hits without storing mask words may skip them
-    uint32_t pad_sparse;
+    uint32_t entry_split_log2;        // fixed width, register-resident kernels: an entry is worked on by 2^this waves, each taking
+                                      // a run of its 1024-row blocks (set by the launcher; 0 when per-entry counts are asked for)
 };
 // accumulator layout: word 0 = top level, words 8, 16, ... = shards (one 64-byte line each).  A word packs
 // {arrivals : 24 | hits : 40}, so ONE returning atomic both adds a count and tells the caller whether it was the last.
