@@ -71,9 +71,11 @@ def parse_args(argv=None):
     p.add_argument("--int-base", type=int, default=None, help="int64_gt: smallest value (default: a large id-like base)")
     p.add_argument("--exchange", default="count", choices=["count", "mask"],
                    help="multi-GPU exchange step per scan: COUNT(*) all-reduce or all-gather of the hit-mask segments")
-    p.add_argument("--comm", default="torch", choices=["torch", "abi"],
-                   help="who runs the exchange step: torch.distributed (RCCL through PyTorch) or the library's own C ABI "
-                        "(lc_comm_*: RCCL directly, what a Rust host would bind); the unique id travels over torch's store")
+    p.add_argument("--comm", default="abi", choices=["torch", "abi"],
+                   help="who runs the exchange step: the library's own C ABI (lc_comm_*: RCCL directly, what a Rust host would "
+                        "bind; the unique id travels over torch's store; default since round 6 — checked by a known-answer "
+                        "all-reduce at start-up, torch.distributed takes over if that fails or does not return) or "
+                        "torch.distributed (RCCL through PyTorch)")
     p.add_argument("--cpu-batches", type=int, default=0, help="batches in the CPU-baseline sample (0 = whole column)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-fingerprints", action="store_true",
@@ -1016,6 +1018,54 @@ def secondary_concurrent_tables(cache, N, args, tables, expr, want_hits, rows_pe
     return out
 
 
+def make_abi_communicator(cache, N, Communicator, rank, world, torch, dist, dry_run):
+    """The library's own communicator (lc_comm_*: RCCL through the C ABI), its 128-byte id broadcast over the launcher's process
+    group — and PROVEN before it is used: a known-answer all-reduce (rank + 1 -> world (world + 1) / 2) runs in a helper thread
+    with a time limit, and the ranks agree (over torch.distributed) whether everyone passed.  One failure, wrong sum or rank that
+    did not return, and every rank falls back to torch.distributed: a scaling run is never lost to this path.  dry_run (ranks
+    sharing one GPU under LC_BENCH_TEST_BACKEND): the shared-memory test backend, which RCCL's refusal of duplicate devices
+    makes necessary."""
+    import threading
+    note = None
+    comm = None
+    ok = 1
+    try:
+        if dry_run:
+            cache.set_option(N.OPT_COMM_SHARED_MEMORY, 1)
+        uid = [Communicator.unique_id(cache) if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        comm = Communicator(cache, rank, world, uid[0])
+        result = {}
+
+        def probe():
+            try:
+                side = torch.cuda.Stream()
+                with torch.cuda.stream(side):
+                    t = torch.full((), rank + 1, dtype=torch.int64, device="cuda")
+                    side.synchronize()
+                    comm.allreduce_count(t.data_ptr(), side.cuda_stream)
+                    side.synchronize()
+                    result["sum"] = int(t.item())
+            except Exception as e:  # noqa: BLE001
+                result["error"] = "%s: %s" % (type(e).__name__, e)
+
+        th = threading.Thread(target=probe, daemon=True)
+        th.start()
+        th.join(60.0)
+        if th.is_alive():
+            ok, note = 0, "its known-answer all-reduce did not return within 60 s"
+        elif result.get("sum") != world * (world + 1) // 2:
+            ok, note = 0, "its known-answer all-reduce gave %s" % (result.get("error") or result.get("sum"))
+    except Exception as e:  # noqa: BLE001 — never lose the scaling run to this path
+        ok, note = 0, "%s: %s" % (type(e).__name__, e)
+    agreed = torch.tensor([ok], dtype=torch.int64, device="cuda")
+    dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+    if int(agreed.item()) == 1:
+        return comm, "lc_comm (%s through the C ABI), known-answer all-reduce passed on every rank" % (
+            "shared-memory test backend" if dry_run else "RCCL")
+    return None, "torch.distributed (lc_comm not used: %s)" % (note or "another rank failed its check")
+
+
 def clickbench_protocol(lc, N, args, rank, n_batches, threads, expr, want_hits, torch, stream, device):
     """ClickBench's own protocol on a FRESH context (nothing cached, no index anywhere): the table is staged, then q20
     (`SELECT COUNT(*) FROM hits WHERE URL LIKE '%google%'`) runs 5 times, and every run is what a host in the reference's call
@@ -1913,14 +1963,7 @@ def main():
     comm = None
     comm_used = "torch.distributed"
     if args.comm == "abi" and world > 1:
-        try:  # the library's own communicator; its 128-byte id is broadcast by the launcher's process group
-            uid = [Communicator.unique_id(cache) if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            comm = Communicator(cache, rank, world, uid[0])
-            comm_used = "lc_comm (RCCL through the C ABI)"
-        except Exception as e:  # noqa: BLE001 — never lose the scaling run to the optional path
-            comm = None
-            comm_used = "torch.distributed (lc_comm failed: %s)" % e
+        comm, comm_used = make_abi_communicator(cache, N, Communicator, rank, world, torch, dist, bool(test_backend))
     make_total = lambda: torch.zeros((), dtype=torch.int64, device="cuda")  # noqa: E731
     reducer = PipelinedAbiCountAllReduce(make_total, comm, torch) if comm else PipelinedCountAllReduce(make_total, world)
     stream = torch.cuda.current_stream().cuda_stream

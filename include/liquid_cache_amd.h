@@ -198,6 +198,10 @@ LC_API void lc_ctx_destroy(lc_ctx* ctx);
  * (liquid_cache_reader.rs:264-339); a host that follows it creates a scan per query.  0: every lc_scan_destroy frees the scan. */
 #define LC_OPT_LIKE_INDEX_ASYNC 9
 #define LC_OPT_SCAN_CACHE 10
+/* LC_OPT_COMM_SHARED_MEMORY (default 0): 1 = the lc_comm_* calls of this DEVICE context run over the shared-memory test backend
+ * of the host-only contexts (device pointers travel through host copies) instead of RCCL — for dry runs of a multi-rank job
+ * whose ranks share one GPU, which RCCL refuses.  Never a measurement. */
+#define LC_OPT_COMM_SHARED_MEMORY 11
 LC_API lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value);
 LC_API const char* lc_last_error(lc_ctx* ctx); /* thread-local message of the last failing call */
 LC_API lc_status lc_device_info_get(lc_ctx* ctx, lc_device_info* out);

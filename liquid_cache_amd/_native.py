@@ -19,7 +19,7 @@ LIT_I64, LIT_U64, LIT_F32, LIT_F64, LIT_BYTES, LIT_I128, LIT_BOOL = range(7)
 HINT_NONE, HINT_SUBSTRING_SEARCH, HINT_PREDICATE_COLUMN = 0, 1, 2
 OPT_SIGNATURE_INDEX, OPT_ROW_LISTS, OPT_HOST_BUILT_INDEX, OPT_LIKE_PIPELINE_MIN_ENTRIES, OPT_LIKE_PATH, OPT_LIKE_MANY_HINT = 1, 2, 3, 4, 5, 6
 OPT_LIKE_INDEX_BUDGET_BYTES, OPT_LIKE_INDEX_CACHE = 7, 8
-OPT_LIKE_INDEX_ASYNC, OPT_SCAN_CACHE = 9, 10
+OPT_LIKE_INDEX_ASYNC, OPT_SCAN_CACHE, OPT_COMM_SHARED_MEMORY = 9, 10, 11
 HITS_COUNTERS_ZEROED, GATHER_SLOTTED, GATHER_SLOT_BYTES = 1, 2, 128  # flags of the hit-list calls
 
 

@@ -10,7 +10,9 @@
 //     Variable-length mask segments are gathered with one ncclBroadcast per rank inside a group (all-gather-v).
 //   * a shared-memory backend for HOST-ONLY contexts (lc_ctx_create with n_devices = 0): the ranks of one node meet in
 //     a file under /dev/shm named by the unique id.  It exists so that the multi-rank logic (ids, offsets, ordering) is
-//     exercised by the CPU test suite; pointers are host pointers there.
+//     exercised by the CPU test suite; pointers are host pointers there.  A DEVICE context takes it under
+//     LC_OPT_COMM_SHARED_MEMORY = 1 (device pointers then travel through host copies): the dry run of a multi-rank job
+//     whose ranks share ONE GPU, which RCCL refuses (tests, scripts/scale_dryrun.sh) — never a measurement.
 #include <cerrno>
 #include <cstring>
 #include <dlfcn.h>
@@ -51,9 +53,15 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // a copy the process has loaded already comes first (PyTorch brings its own librccl: two instances of the library in
+        // one process would each keep their own topology and proxy threads), then the system's
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
             if (r.lib) break;
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!r.lib) return;
         auto sym = [&](const char* n) { return dlsym(r.lib, n); };
@@ -97,6 +105,7 @@ struct lc_comm {
     size_t shm_bytes = 0;
     std::string shm_name;
     uint32_t local_sense = 0;
+    bool device_ptrs = false;    // shared-memory backend of a DEVICE context: the callers' pointers are device pointers
     bool poisoned = false;       // a rank did not arrive in time: the barrier state is no longer consistent — every later
                                  // collective fails fast instead of hanging or answering from half-written slots
 };
@@ -137,8 +146,8 @@ lc_status lc_comm_unique_id(lc_ctx* ctx, uint8_t* out_id) {
     return guarded([&]() -> lc_status {
     if (!ctx || !out_id) return fail(LC_ERR_INVALID, "null argument");
     std::memset(out_id, 0, LC_COMM_ID_BYTES);
-    if (ctx->device < 0) {
-        // host-only context: the id names a file under /dev/shm
+    if (ctx->device < 0 || ctx->comm_shared_memory.load()) {
+        // host-only context (or a device context told to use the test backend): the id names a file under /dev/shm
         static std::atomic<uint32_t> seq{0};
         std::snprintf(reinterpret_cast<char*>(out_id), LC_COMM_ID_BYTES, "/lc_comm_%d_%u_%llu", int(getpid()), seq.fetch_add(1),
                       (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
@@ -164,8 +173,9 @@ lc_status lc_comm_init(lc_ctx* ctx, int32_t rank, int32_t world, const uint8_t* 
     c->ctx = ctx;
     c->rank = rank;
     c->world = world;
-    if (ctx->device < 0) {
+    if (ctx->device < 0 || ctx->comm_shared_memory.load()) {
         if (world > kMaxShmRanks) return fail(LC_ERR_INVALID, "the shared-memory backend takes at most 64 ranks");
+        c->device_ptrs = ctx->device >= 0;
         char name[LC_COMM_ID_BYTES + 1];
         std::memcpy(name, id, LC_COMM_ID_BYTES);
         name[LC_COMM_ID_BYTES] = 0;
@@ -226,14 +236,26 @@ lc_status lc_comm_allreduce_count(lc_comm* c, void* d_total, void* stream) {
     return guarded([&]() -> lc_status {
     if (!c || !d_total) return fail(LC_ERR_INVALID, "null argument");
     if (c->shm) {
+        hipStream_t st = static_cast<hipStream_t>(stream);
         uint64_t v;
-        std::memcpy(&v, d_total, 8);
+        if (c->device_ptrs) {
+            LC_HIP(hipSetDevice(c->ctx->device));
+            LC_HIP(hipMemcpyAsync(&v, d_total, 8, hipMemcpyDeviceToHost, st));
+            LC_HIP(hipStreamSynchronize(st));
+        } else {
+            std::memcpy(&v, d_total, 8);
+        }
         c->shm->slots[c->rank] = v;
         if (!shm_barrier(c)) return fail(LC_ERR_DEVICE, "shared-memory communicator: a rank did not arrive");
         uint64_t sum = 0;
         for (int r = 0; r < c->world; r++) sum += c->shm->slots[r];
         if (!shm_barrier(c)) return fail(LC_ERR_DEVICE, "shared-memory communicator: a rank did not arrive");  // (slots are reused)
-        std::memcpy(d_total, &sum, 8);
+        if (c->device_ptrs) {
+            LC_HIP(hipMemcpyAsync(d_total, &sum, 8, hipMemcpyHostToDevice, st));
+            LC_HIP(hipStreamSynchronize(st));
+        } else {
+            std::memcpy(d_total, &sum, 8);
+        }
         return LC_OK;
     }
     if (c->world == 1) return LC_OK;
@@ -256,9 +278,21 @@ lc_status lc_comm_allgather_mask(lc_comm* c, const void* d_mask_local, uint64_t 
     }
     if (c->shm) {
         if (total * 8 > kShmData) return fail(LC_ERR_INVALID, "mask too large for the shared-memory test backend");
-        std::memcpy(c->shm_data + my_off * 8, d_mask_local, size_t(local_words) * 8);
+        hipStream_t sst = static_cast<hipStream_t>(stream);
+        if (c->device_ptrs) {
+            LC_HIP(hipSetDevice(c->ctx->device));
+            if (local_words) LC_HIP(hipMemcpyAsync(c->shm_data + my_off * 8, d_mask_local, size_t(local_words) * 8, hipMemcpyDeviceToHost, sst));
+            LC_HIP(hipStreamSynchronize(sst));
+        } else {
+            std::memcpy(c->shm_data + my_off * 8, d_mask_local, size_t(local_words) * 8);
+        }
         if (!shm_barrier(c)) return fail(LC_ERR_DEVICE, "shared-memory communicator: a rank did not arrive");
-        std::memcpy(d_mask_all, c->shm_data, size_t(total) * 8);
+        if (c->device_ptrs) {
+            if (total) LC_HIP(hipMemcpyAsync(d_mask_all, c->shm_data, size_t(total) * 8, hipMemcpyHostToDevice, sst));
+            LC_HIP(hipStreamSynchronize(sst));
+        } else {
+            std::memcpy(d_mask_all, c->shm_data, size_t(total) * 8);
+        }
         if (!shm_barrier(c)) return fail(LC_ERR_DEVICE, "shared-memory communicator: a rank did not arrive");
         return LC_OK;
     }

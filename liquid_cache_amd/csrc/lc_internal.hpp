@@ -156,6 +156,8 @@ struct lc_ctx {
                                                  // LIKE of a scan waits for the build, as before round 6)
     std::atomic<uint32_t> scan_cache_max{32};     // LC_OPT_SCAN_CACHE: destroyed scans kept for the next lc_scan_create over the same
                                                  // entry-id list (0: none)
+    std::atomic<bool> comm_shared_memory{false};  // LC_OPT_COMM_SHARED_MEMORY: lc_comm_* of this DEVICE context run over the shared-memory
+                                                  // test backend (ranks that share one GPU: dry runs, never a measurement)
     std::atomic<bool> like_many_hint{true};  // LC_OPT_LIKE_MANY_HINT (A/B aid): unselective planned needles take k_str_pred's sequential walker
     std::atomic<int> like_path{0};  // LC_OPT_LIKE_PATH: 0 auto, 1 k_str_pred, 2 auto without the scan-level index, 3 / 4 / 5 k_like_lean /
                                     // k_like_flat / k_like_scanall for every needle

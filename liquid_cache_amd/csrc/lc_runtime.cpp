@@ -1057,6 +1057,7 @@ lc_status lc_ctx_set_option(lc_ctx* ctx, int32_t option, int64_t value) {
         case LC_OPT_LIKE_INDEX_BUDGET_BYTES: ctx->like_index_budget = value < 0 ? 0 : uint64_t(value); return LC_OK;
         case LC_OPT_LIKE_INDEX_CACHE: ctx->like_index_cache = uint32_t(std::max<int64_t>(0, std::min<int64_t>(value, 1024))); return LC_OK;
         case LC_OPT_LIKE_INDEX_ASYNC: ctx->like_index_async = value != 0; return LC_OK;
+        case LC_OPT_COMM_SHARED_MEMORY: ctx->comm_shared_memory = value != 0; return LC_OK;
         case LC_OPT_SCAN_CACHE: {
             ctx->scan_cache_max = uint32_t(std::max<int64_t>(0, std::min<int64_t>(value, 1024)));
             std::lock_guard<std::mutex> g2(ctx->scan_cache_mu);  // what no longer fits goes (destroyed by the next reap)

@@ -9,6 +9,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 O=${1:-$R/gpurun_out/scale}
 mkdir -p "$O"
+: > "$O/scale_lines.jsonl"
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 port=29500
 run() {  # n, tag, bench args...
@@ -20,17 +21,22 @@ run() {  # n, tag, bench args...
     python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port $port \
       "$R/bench.py" --gpus "$n" "$@" > "$O/${tag}_n$n.json" 2> "$O/${tag}_n$n.err"
   fi
-  python - "$O/${tag}_n$n.json" "$tag" "$n" <<'PY'
+  # the compact record of the run (bench.py's last stdout line, the one a driver parses) -> scale_lines.jsonl, one line per run
+  python - "$O/${tag}_n$n.json" "$tag" "$n" "$O/scale_lines.jsonl" <<'PY'
 import json, sys
 try:
-    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print("%-22s n=%s value %.4g %s  ms/step %.4f  exchange_by %s" % (sys.argv[2], sys.argv[3], d["value"], d["unit"], d["ms_per_step"],
-                                                                  d["config"].get("exchange_by")))
+    line = open(sys.argv[1]).read().strip().splitlines()[-1]
+    d = json.loads(line)
+    d["run"] = sys.argv[2]
+    open(sys.argv[4], "a").write(json.dumps(d) + "\n")
+    print("%-26s n=%s value %.4g %s  ms/step %.4f  exchange_by %s" % (sys.argv[2], sys.argv[3], d["value"], d["unit"], d["ms_per_step"],
+                                                                      str(d["config"].get("exchange_by"))[:60]))
 except Exception as e:  # noqa: BLE001
     print(sys.argv[2], "n=" + sys.argv[3], "FAILED", e)
 PY
 }
 for n in 1 2 4 8; do
+  run $n url_like_default --steps 20 --warmup 5 --no-secondary --no-cpu-baseline   # what the driver runs: strong split, --comm abi
   for comm in torch abi; do
     for ex in count mask; do
       run $n "url_like_strong_${ex}_${comm}" --steps 40 --warmup 8 --no-secondary --no-cpu-baseline --exchange $ex --comm $comm

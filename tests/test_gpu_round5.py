@@ -521,6 +521,9 @@ def test_bench_two_rank_dry_run_on_one_gpu():
         assert d2["config"]["rows_all_gpus"] == d1["config"]["rows_all_gpus"] == 3000000
         assert d2["config"]["scans_per_step"] == 4 and d2["ms_per_step"] > 0 and d2["value"] > 0
         assert "scaling_model" in d2 and d2["roofline"]["kernel"].startswith("k_like")
+        # round 6: the exchange runs through the library's own communicator by default (here its shared-memory test backend: two
+        # ranks on one GPU), proven by a known-answer all-reduce before it is used
+        assert d2["config"]["exchange_by"].startswith("lc_comm"), d2["config"]["exchange_by"]
 
 
 def _build_c(tmp_path, name):
