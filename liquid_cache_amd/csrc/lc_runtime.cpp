@@ -2530,11 +2530,13 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         // ONE critical section captures the entries and pins their slabs: between a capture under one lock and a pin
         // under another an lc_evict / re-stage could drain the slab and the scan would keep dangling device pointers.
         // The pins are taken after every entry has validated, so the error returns below leave nothing pinned.
+        std::vector<EntryMap::value_type*> found(n, nullptr);
         std::unique_lock<std::shared_mutex> g(ctx->mu);
         s->evict_epoch = ctx->evict_epoch.load();
+        ctx->entries.find_many(entry_ids, n, found.data());  // (slots and records of the ids ahead prefetched)
         uint32_t max_len = 0;
         for (uint64_t i = 0; i < n; i++) {
-            auto it = ctx->entries.find(entry_ids[i]);
+            EntryMap::iterator it(found[i]);
             if (it == ctx->entries.end()) return fail(LC_NOT_STAGED, "entry is not staged");
             s->meta.push_back(it->second);  // (one copy of the ~400-byte entry record, edited in place)
             Entry& e = s->meta.back();

@@ -7,6 +7,9 @@
  *   lc_eval_predicate_batch (all entries of the column)
  *   lc_scan_eval on the thread's stream + read-back
  *   lc_get_with_selection (per entry)
+ *   whole-column queries in the reference's call shape (round 6): lc_eval_predicate_row_groups (ids in, per-row-group counts
+ *   out: the scan behind it comes from the context's scan cache) and a scan created per query — lc_scan_create over the id
+ *   list, COUNT(*) without a mask, lc_scan_destroy — while other threads do the same on their columns
  * while a ninth thread keeps staging, re-staging and evicting entries of a scratch column.  Every answer must equal the
  * answer the same call gave single-threaded before the threads started, and the wall time of the eight threads together
  * must stay below twice the time one of them needs alone.
@@ -47,8 +50,8 @@ static uint64_t fnv(uint64_t h, const void* p, size_t n) {
 static lc_ctx* ctx;
 static int is_string_col(int col) { return col & 1; }
 /* diagnosis knobs (environment): CC_THREADS (default 8), CC_NO_CHURN, CC_MODE bit mask of the call kinds a pass makes
- * (1 lc_eval_predicate, 2 lc_get_with_selection, 4 lc_eval_predicate_batch, 8 lc_scan_eval; default all) */
-static int g_threads = N_COLS, g_mode = 15, g_no_churn = 0;
+ * (1 lc_eval_predicate, 2 lc_get_with_selection, 4 lc_eval_predicate_batch, 8 lc_scan_eval, 16 whole-column queries; default all) */
+static int g_threads = N_COLS, g_mode = 31, g_no_churn = 0;
 
 /* int64 column: pseudo-random values below 2^20; string column: URL-like values, some with "google" */
 static int stage_batch(int col, int batch, uint64_t id, uint64_t salt) {
@@ -150,6 +153,21 @@ static int column_pass(int col, void* stream, lc_scan* scan, void* d_mask, uint6
         if (lc_device_to_host(ctx, host_mask, d_mask, words * 8, stream) != LC_OK) return 5;
         if (lc_stream_synchronize(ctx, stream) != LC_OK) return 6;
         h = fnv(h, host_mask, words * 8);
+    }
+    if (g_mode & 16) {  /* whole-column queries the way a reader that holds no scan objects asks them */
+        uint64_t ids[N_BATCHES], counts[4], total = 0, total2 = 0;
+        const uint32_t ends[4] = {N_BATCHES / 4, N_BATCHES / 2, 3 * N_BATCHES / 4, N_BATCHES};
+        for (int b = 0; b < N_BATCHES; b++) ids[b] = entry_id(col, b);
+        if (lc_eval_predicate_row_groups(ctx, N_BATCHES, ids, 4, ends, &pred, 1, counts, NULL, 0, &total) != LC_OK) return 7;
+        if (counts[0] + counts[1] + counts[2] + counts[3] != total) return 8;
+        h = fnv(h, counts, sizeof(counts));
+        lc_scan* q = NULL;  /* a scan per query: the context hands the kept one back */
+        if (lc_scan_create(ctx, N_BATCHES, ids, &q) != LC_OK) return 9;
+        if (lc_scan_eval_count(ctx, q, &pred, 1, NULL, NULL, NULL, d_mask, stream) != LC_OK) return 10;
+        if (lc_device_to_host(ctx, &total2, d_mask, 8, stream) != LC_OK || lc_stream_synchronize(ctx, stream) != LC_OK) return 11;
+        lc_scan_destroy(q);
+        if (total2 != total) return 12;
+        h = fnv(h, &total2, 8);
     }
     *digest = h;
     return 0;

@@ -328,3 +328,14 @@ def test_inverted_row_lists_layout(product_lib):
     assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 65536, 10, out.ctypes.data, out.size) == 0  # u16 offsets
     assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 100, 0, out.ctypes.data, out.size) == 0
     assert N.load_bench().lc_debug_row_lists(big.ctypes.data, None, 100, 10, out.ctypes.data, 50) == 0
+
+
+def test_entry_map_against_unordered_map(tmp_path):
+    """csrc/lc_internal.hpp's EntryMap (open addressing + prefetching find_many behind lc_ctx::entries) == std::unordered_map
+    under 400,000 random emplace / erase / find / find_many operations over ParquetArrayID-shaped keys."""
+    import subprocess
+    exe = str(tmp_path / "entry_map_test")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "entry_map_test.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "entry map ok" in r.stdout, r.stdout + r.stderr
