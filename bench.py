@@ -378,6 +378,7 @@ def compact_line(out, detail_path):
                            ("decimal_gt_w4_frac", ("decimal_gt_w4", "frac")), ("int64_gt_w17_frac", ("int64_gt_w17", "frac")),
                            ("tpch_q6_chain_frac", ("tpch_q6_pushdown", "full_size", "frac")),
                            ("q21_pipeline_ms", ("q21_pipeline", "ms")),
+                           ("q21_pipeline_partitioned_ms", ("q21_pipeline", "ms_partitioned_lists")),
                            ("byte_view_gather_after_like_ms", ("micro", "byte_view_gather_after_like", "kernel_ms")),
                            ("byte_view_gather_after_like_slotted_ms", ("micro", "byte_view_gather_after_like", "slotted_call_ms")),
                            ("url_like_no_signatures_ms", ("url_like_no_signatures", "kernel_ms")),
@@ -569,24 +570,56 @@ def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_ex
 
     gcap = min(hcap, data[0].numel() // 256)  # rows the projections are sized for (slotted form: 128 bytes per row + long values)
 
-    def run_sparse(slotted=True):
-        N.check(cache._lib.lc_device_memset(cache.handle, ctr.data_ptr(), 0, 32, stream), cache.handle)
-        url_scan.eval_hits(like_expr, hits.data_ptr(), hcap, c_ptr[0], 0, 0, 0, 0, stream, counters_zeroed=True)
-        sp_scan.filter_hits(ne_expr, hits.data_ptr(), c_ptr[0], hcap, hits2.data_ptr(), hcap, c_ptr[1], stream, counters_zeroed=True)
-        url_scan.gather_bytes_hits(hits2.data_ptr(), c_ptr[1], gcap, views[0].data_ptr(), data[0].data_ptr(),
-                                   min(data[0].numel(), (1 << 31) - 1), c_ptr[2], 0, stream, counters_zeroed=True, slotted=slotted)
-        sp_scan.gather_bytes_hits(hits2.data_ptr(), c_ptr[1], gcap, views[1].data_ptr(), data[1].data_ptr(),
-                                  min(data[1].numel(), (1 << 31) - 1), c_ptr[3], 0, stream, counters_zeroed=True, slotted=slotted)
+    # round 6: the PARTITIONED list form (LC_HITS_PARTITIONED: 16 partitions, a counter per 128-byte line) — the producers claim
+    # list space on 16 addresses instead of one; [list 1 counters | list 2 counters | the two byte counters]
+    P, CS = N.HITS_PARTITIONS, N.HITS_COUNTER_STRIDE
+    pctr = torch.zeros(2 * P * CS + 2, dtype=torch.int64, device="cuda")
+    pc_ptr = [pctr.data_ptr(), pctr.data_ptr() + 8 * P * CS, pctr.data_ptr() + 16 * P * CS, pctr.data_ptr() + 16 * P * CS + 8]
 
-    def time_sparse(slotted):
+    def run_sparse(slotted=True, partitioned=False):
+        if partitioned:
+            N.check(cache._lib.lc_device_memset(cache.handle, pctr.data_ptr(), 0, pctr.numel() * 8, stream), cache.handle)
+            cp = pc_ptr
+        else:
+            N.check(cache._lib.lc_device_memset(cache.handle, ctr.data_ptr(), 0, 32, stream), cache.handle)
+            cp = c_ptr
+        url_scan.eval_hits(like_expr, hits.data_ptr(), hcap, cp[0], 0, 0, 0, 0, stream, counters_zeroed=True, partitioned=partitioned)
+        sp_scan.filter_hits(ne_expr, hits.data_ptr(), cp[0], hcap, hits2.data_ptr(), gcap if partitioned else hcap, cp[1], stream,
+                            counters_zeroed=True, partitioned=partitioned)
+        url_scan.gather_bytes_hits(hits2.data_ptr(), cp[1], gcap, views[0].data_ptr(), data[0].data_ptr(),
+                                   min(data[0].numel(), (1 << 31) - 1), cp[2], 0, stream, counters_zeroed=True, slotted=slotted,
+                                   partitioned=partitioned)
+        sp_scan.gather_bytes_hits(hits2.data_ptr(), cp[1], gcap, views[1].data_ptr(), data[1].data_ptr(),
+                                  min(data[1].numel(), (1 << 31) - 1), cp[3], 0, stream, counters_zeroed=True, slotted=slotted,
+                                  partitioned=partitioned)
+
+    def time_sparse(slotted, partitioned=False):
         for _ in range(2):
-            run_sparse(slotted)
+            run_sparse(slotted, partitioned)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(iters):
-            run_sparse(slotted)
+            run_sparse(slotted, partitioned)
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / iters * 1e3
+    ms_part = None
+    try:
+        ms_part = time_sparse(True, True)
+        pv = pctr.cpu().numpy()
+        n1 = int(pv[0: P * CS: CS].sum())
+        n2p = pv[P * CS: 2 * P * CS: CS]
+        stride2 = gcap // P
+        h2 = hits2.cpu().numpy().view(np.uint64)
+        got_p = np.concatenate([h2[p * stride2: p * stride2 + int(n2p[p])] for p in range(P)])
+        assert int(n2p.max()) <= stride2 and n1 == k_h, "partitioned pipeline: a partition overflowed / LIKE count differs"
+        assert np.array_equal(np.sort(got_p), np.sort(want_rows)), "partitioned sparse pipeline: rows differ from the mask form's"
+        for c in range(2):
+            lens = views[c][: len(got_p), 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0]
+            assert int(lens.astype(np.int64).sum()) == (out["url_bytes"], out["phrase_bytes"])[c], "partitioned pipeline: gathered bytes differ"
+    except AssertionError:
+        raise
+    except Exception as e:  # noqa: BLE001
+        res["partitioned_error"] = "%s: %s" % (type(e).__name__, e)
     ms_dense = time_sparse(False)
     ms_s = time_sparse(True)  # (the buffers checked below are the slotted run's)
     cv = ctr.cpu().numpy()
@@ -595,6 +628,9 @@ def q21_pipeline(cache, lc, N, args, rank, n_batches, threads, url_scan, like_ex
     for c in range(2):
         lens = views[c][: int(cv[1]), 0].cpu().numpy().view(np.int32).reshape(-1, 2)[:, 0]
         assert int(lens.astype(np.int64).sum()) == (out["url_bytes"], out["phrase_bytes"])[c], "sparse pipeline: gathered bytes differ"
+    if ms_part is not None:
+        res["ms_partitioned_lists"] = ms_part
+        res["partitioned_pipeline_equals_mask_form"] = True
     res.update(ms=ms_s, ms_dense_data_buffers=ms_dense, rows_per_s=url_scan.rows / (ms_s * 1e-3), rows_after_like=int(cv[0]),
                kernels="k_like_flat (hit list) + k_pred_hits (SearchPhrase <> '' on the listed rows) + 2 x k_str_gather_hits "
                        "(LC_GATHER_SLOTTED: a row's bytes in its 128-byte slot; ms_dense_data_buffers: the dense form)",

@@ -625,11 +625,26 @@ LC_API lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const vo
  *   d_counts_out (optional): hits per entry; d_total_out (optional): COUNT(*).  No mask is written.  Kernels that can emit the
  *   list themselves (k_like_flat: selective [NOT] LIKE and string = / <>) do; for every other evaluation path the mask goes to
  *   scan-owned scratch and one more kernel lists it — always correct, fastest where it matters.  Asynchronous on `stream`.
- * lc_scan_mask_to_hits: the same list from a mask in scan layout (e.g. the result of lc_scan_eval_filter).
+ * lc_scan_mask_to_hits: the same list from a mask in scan layout (e.g. the result of lc_scan_eval_filter); flags:
+ *   LC_HITS_COUNTERS_ZEROED, LC_HITS_PARTITIONED.
  * flags: LC_HITS_COUNTERS_ZEROED — the caller has zeroed the u64 device counters this call writes (*d_n_hits; for the
  *   gathers *d_n_bytes; for the filter *d_n_hits_out), typically all counters of a query with ONE lc_device_memset: the call
  *   then issues no memset of its own (each is a small kernel in front of the real one). */
 #define LC_HITS_COUNTERS_ZEROED 1u
+/* LC_HITS_PARTITIONED (round 6): the hit list in LC_HITS_PARTITIONS partitions.  A contiguous list is allocated by returning
+ * atomics on ONE address, which complete ~10 ns apart however many workgroups wait — 1,100 of them were 11 of the 23.7 us of a
+ * selective LIKE with a list.  Partitioned, workgroup b appends to partition b % 16: partition p holds the records
+ * d_hits[p * S .. p * S + min(n_p, S)) with S = capacity / LC_HITS_PARTITIONS, and its count n_p is the u64 at
+ * d_n_hits[p * LC_HITS_COUNTER_STRIDE] — d_n_hits points at LC_HITS_PARTITIONS * LC_HITS_COUNTER_STRIDE u64 (2 KB; every
+ * counter on a 128-byte line of its own).  n_p may exceed S (records beyond are dropped: compare and retry, as with
+ * `capacity`); d_hit_first holds positions in the buffer.  The calls that CONSUME a list (lc_scan_filter_hits,
+ * lc_scan_gather_fixed_hits, lc_scan_gather_bytes_hits) take the same flag and read the partitions as one list in partition
+ * order: row i of a gather's output is record i of that order, the outputs are as dense as with a contiguous list.
+ * lc_scan_filter_hits writes its output list in the form it reads.  lc_hits_compact copies the partitions, in that order,
+ * into a contiguous list (+ *d_n_hits_out) for a caller that wants to read one. */
+#define LC_HITS_PARTITIONED 4u
+#define LC_HITS_PARTITIONS 16u
+#define LC_HITS_COUNTER_STRIDE 16u
 /* lc_scan_gather_bytes_hits only: SLOTTED data buffer.  Record i's bytes start at i * LC_GATHER_SLOT_BYTES of d_data when the
  * value fits a slot; longer values are appended behind the slots, from capacity_rows * LC_GATHER_SLOT_BYTES on, and only they
  * are counted in *d_n_bytes.  A BinaryView's offset may point anywhere in its buffer, so the views are the same Arrow array;
@@ -656,7 +671,9 @@ LC_API lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predic
                                      const void* d_n_hits_in, uint64_t capacity_in, void* d_hits_out, uint64_t capacity_out,
                                      void* d_n_hits_out, uint32_t flags, void* stream);
 LC_API lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, void* d_hits_out, uint64_t capacity,
-                                      void* d_n_hits, void* d_hit_first, void* stream);
+                                      void* d_n_hits, void* d_hit_first, uint32_t flags, void* stream);
+LC_API lc_status lc_hits_compact(lc_ctx* ctx, const void* d_hits, const void* d_n_hits, uint64_t capacity, void* d_hits_out,
+                                 uint64_t capacity_out, void* d_n_hits_out, void* stream);
 /* get().with_selection() for the rows of a hit list, ONE launch, no host round trip.  `scan` is any scan over the same row
  * ranges as the scan that produced the list (the projection columns of the filtered batches).  Row i of the output is
  * record i of the list; k = min(*d_n_hits, capacity_rows) rows are produced.
@@ -668,10 +685,12 @@ LC_API lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_
  *                the ones of 12 bytes and less that live in their view (a batch's values are then ONE range of the
  *                buffer, which a wave stores coalesced).  A value that would end beyond capacity_bytes is not written
  *                (its view carries length and offset only): compare and retry.  capacity_bytes < 2 GiB.
- *                flags: LC_HITS_COUNTERS_ZEROED, LC_GATHER_SLOTTED (above).
+ *                flags: LC_HITS_COUNTERS_ZEROED, LC_GATHER_SLOTTED, LC_HITS_PARTITIONED (above; lc_scan_gather_fixed_hits:
+ *                LC_HITS_PARTITIONED).
  * LC_UNSUPPORTED for scans that hold squeezed entries (lc_scan_gather_fixed decides their reads). */
 LC_API lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits,
-                                           uint64_t capacity_rows, void* d_values_out, void* d_row_valid, void* stream);
+                                           uint64_t capacity_rows, void* d_values_out, void* d_row_valid, uint32_t flags,
+                                           void* stream);
 LC_API lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits,
                                            uint64_t capacity_rows, void* d_views, void* d_row_valid, void* d_data,
                                            uint64_t capacity_bytes, void* d_n_bytes, uint32_t flags, void* stream);

@@ -21,6 +21,7 @@ OPT_SIGNATURE_INDEX, OPT_ROW_LISTS, OPT_HOST_BUILT_INDEX, OPT_LIKE_PIPELINE_MIN_
 OPT_LIKE_INDEX_BUDGET_BYTES, OPT_LIKE_INDEX_CACHE = 7, 8
 OPT_LIKE_INDEX_ASYNC, OPT_SCAN_CACHE, OPT_COMM_SHARED_MEMORY = 9, 10, 11
 HITS_COUNTERS_ZEROED, GATHER_SLOTTED, GATHER_SLOT_BYTES = 1, 2, 128  # flags of the hit-list calls
+HITS_PARTITIONED, HITS_PARTITIONS, HITS_COUNTER_STRIDE = 4, 16, 16  # the partitioned list form (round 6)
 
 
 class LiquidCacheError(RuntimeError):
@@ -89,7 +90,7 @@ EXPORTED_SYMBOLS = [
     "lc_device_memset", "lc_device_to_host", "lc_host_to_device", "lc_stream_synchronize",
     "lc_stream_create", "lc_stream_destroy",
     "lc_scan_eval_hits", "lc_scan_mask_to_hits", "lc_scan_gather_fixed_hits", "lc_scan_gather_bytes_hits", "lc_scan_info_get",
-    "lc_scan_filter_hits", "lc_scan_index_wait", "lc_scan_eval_count_groups", "lc_eval_predicate_row_groups",
+    "lc_scan_filter_hits", "lc_scan_index_wait", "lc_scan_eval_count_groups", "lc_eval_predicate_row_groups", "lc_hits_compact",
 ]
 # include/liquid_cache_amd_bench.h: bench / test aids, built into their own library (never part of the product .so)
 BENCH_SYMBOLS = ["lc_synth_url_batch", "lc_synth_int64_batch", "lc_synth_phrase_batch", "lc_synth_title_batch",
@@ -228,8 +229,9 @@ def load():
     L.lc_scan_eval_hits.argtypes = [vp, vp, P(Predicate), C.c_uint32, vp, vp, u64, vp, vp, vp, vp, C.c_uint32, vp]
     L.lc_scan_filter_hits.restype = i32
     L.lc_scan_filter_hits.argtypes = [vp, vp, P(Predicate), vp, vp, u64, vp, u64, vp, C.c_uint32, vp]
-    L.lc_scan_mask_to_hits.restype = i32; L.lc_scan_mask_to_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
-    L.lc_scan_gather_fixed_hits.restype = i32; L.lc_scan_gather_fixed_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp]
+    L.lc_scan_mask_to_hits.restype = i32; L.lc_scan_mask_to_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, C.c_uint32, vp]
+    L.lc_scan_gather_fixed_hits.restype = i32; L.lc_scan_gather_fixed_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, C.c_uint32, vp]
+    L.lc_hits_compact.restype = i32; L.lc_hits_compact.argtypes = [vp, vp, vp, u64, vp, u64, vp, vp]
     L.lc_scan_gather_bytes_hits.restype = i32
     L.lc_scan_gather_bytes_hits.argtypes = [vp, vp, vp, vp, u64, vp, vp, vp, u64, vp, C.c_uint32, vp]
     L.lc_device_alloc.restype = i32; L.lc_device_alloc.argtypes = [vp, u64, P(vp)]

@@ -1219,27 +1219,30 @@ class Scan:
 
     # ---- sparse results: hit lists (lc_scan_eval_hits / lc_scan_gather_*_hits) -----------------------------------------
     def eval_hits(self, exprs, hits_ptr: int, capacity: int, n_hits_ptr: int, selection_ptr: int = 0, hit_first_ptr: int = 0,
-                  counts_ptr: int = 0, total_out_ptr: int = 0, stream: int = 0, counters_zeroed: bool = False):
+                  counts_ptr: int = 0, total_out_ptr: int = 0, stream: int = 0, counters_zeroed: bool = False,
+                  partitioned: bool = False):
         """The predicate's hit rows as (entry << 32 | row) u64 records instead of a mask (lc_scan_eval_hits).  Asynchronous.
-        `counters_zeroed`: the caller zeroed *n_hits (LC_HITS_COUNTERS_ZEROED: no memset kernel in front of the call)."""
+        `counters_zeroed`: the caller zeroed *n_hits (LC_HITS_COUNTERS_ZEROED: no memset kernel in front of the call).
+        `partitioned` (LC_HITS_PARTITIONED): 16 partitions of capacity / 16 records, n_hits_ptr -> 16 x 16 u64 (a counter per
+        128-byte line); the consuming calls take the same flag."""
         if isinstance(exprs, LiquidExpr):
             exprs = [exprs]
         preds = (N.Predicate * len(exprs))(*[e.as_predicate() for e in exprs])
         N.check(self._lib.lc_scan_eval_hits(self._cache.handle, self._h, preds, len(exprs), C.c_void_p(selection_ptr or None),
                                             C.c_void_p(hits_ptr), capacity, C.c_void_p(n_hits_ptr),
                                             C.c_void_p(hit_first_ptr or None), C.c_void_p(counts_ptr or None),
-                                            C.c_void_p(total_out_ptr or None), 1 if counters_zeroed else 0,
+                                            C.c_void_p(total_out_ptr or None), (1 if counters_zeroed else 0) | (4 if partitioned else 0),
                                             C.c_void_p(stream or None)), self._cache.handle)
 
     def filter_hits(self, expr: LiquidExpr, hits_in_ptr: int, n_in_ptr: int, capacity_in: int, hits_out_ptr: int,
-                    capacity_out: int, n_out_ptr: int, stream: int = 0, counters_zeroed: bool = False):
+                    capacity_out: int, n_out_ptr: int, stream: int = 0, counters_zeroed: bool = False, partitioned: bool = False):
         """The next conjunct over the rows of a hit list (lc_scan_filter_hits): records whose row satisfies `expr` on this
         scan's column are appended to `hits_out`.  Asynchronous."""
         pred = expr.as_predicate()
         N.check(self._lib.lc_scan_filter_hits(self._cache.handle, self._h, C.byref(pred), C.c_void_p(hits_in_ptr),
                                               C.c_void_p(n_in_ptr), capacity_in, C.c_void_p(hits_out_ptr), capacity_out,
-                                              C.c_void_p(n_out_ptr), 1 if counters_zeroed else 0, C.c_void_p(stream or None)),
-                self._cache.handle)
+                                              C.c_void_p(n_out_ptr), (1 if counters_zeroed else 0) | (4 if partitioned else 0),
+                                              C.c_void_p(stream or None)), self._cache.handle)
 
     def filter_hits_to_host(self, expr: LiquidExpr, hits: np.ndarray) -> np.ndarray:
         """Convenience for tests: the records of `hits` that survive `expr`, as written."""
@@ -1262,27 +1265,35 @@ class Scan:
                     lib.lc_device_free(ctx, p)
         return out
 
-    def mask_to_hits(self, mask_ptr: int, hits_ptr: int, capacity: int, n_hits_ptr: int, hit_first_ptr: int = 0, stream: int = 0):
+    def mask_to_hits(self, mask_ptr: int, hits_ptr: int, capacity: int, n_hits_ptr: int, hit_first_ptr: int = 0, stream: int = 0,
+                     partitioned: bool = False):
         N.check(self._lib.lc_scan_mask_to_hits(self._cache.handle, self._h, C.c_void_p(mask_ptr), C.c_void_p(hits_ptr), capacity,
-                                               C.c_void_p(n_hits_ptr), C.c_void_p(hit_first_ptr or None),
+                                               C.c_void_p(n_hits_ptr), C.c_void_p(hit_first_ptr or None), 4 if partitioned else 0,
                                                C.c_void_p(stream or None)), self._cache.handle)
 
+    def hits_compact(self, hits_ptr: int, n_hits_ptr: int, capacity: int, hits_out_ptr: int, capacity_out: int, n_out_ptr: int,
+                     stream: int = 0):
+        """lc_hits_compact: the partitions of a list, in partition order, as one contiguous list (+ its count)."""
+        N.check(self._lib.lc_hits_compact(self._cache.handle, C.c_void_p(hits_ptr), C.c_void_p(n_hits_ptr), capacity,
+                                          C.c_void_p(hits_out_ptr), capacity_out, C.c_void_p(n_out_ptr), C.c_void_p(stream or None)),
+                self._cache.handle)
+
     def gather_fixed_hits(self, hits_ptr: int, n_hits_ptr: int, capacity_rows: int, values_out_ptr: int, row_valid_ptr: int = 0,
-                          stream: int = 0):
+                          stream: int = 0, partitioned: bool = False):
         """get().with_selection() of a fixed-width column for the rows of a hit list, one launch."""
         N.check(self._lib.lc_scan_gather_fixed_hits(self._cache.handle, self._h, C.c_void_p(hits_ptr), C.c_void_p(n_hits_ptr),
                                                     capacity_rows, C.c_void_p(values_out_ptr), C.c_void_p(row_valid_ptr or None),
-                                                    C.c_void_p(stream or None)), self._cache.handle)
+                                                    4 if partitioned else 0, C.c_void_p(stream or None)), self._cache.handle)
 
     def gather_bytes_hits(self, hits_ptr: int, n_hits_ptr: int, capacity_rows: int, views_ptr: int, data_ptr: int,
                           capacity_bytes: int, n_bytes_ptr: int, row_valid_ptr: int = 0, stream: int = 0,
-                          counters_zeroed: bool = False, slotted: bool = False):
+                          counters_zeroed: bool = False, slotted: bool = False, partitioned: bool = False):
         """The same for a byte-view column: Arrow BinaryView records (16 bytes per row) + one data buffer, one launch.
         `slotted` (LC_GATHER_SLOTTED): record i's bytes at i * 128 when they fit, longer values behind capacity_rows * 128."""
         N.check(self._lib.lc_scan_gather_bytes_hits(self._cache.handle, self._h, C.c_void_p(hits_ptr), C.c_void_p(n_hits_ptr),
                                                     capacity_rows, C.c_void_p(views_ptr), C.c_void_p(row_valid_ptr or None),
                                                     C.c_void_p(data_ptr or None), capacity_bytes, C.c_void_p(n_bytes_ptr),
-                                                    (1 if counters_zeroed else 0) | (2 if slotted else 0),
+                                                    (1 if counters_zeroed else 0) | (2 if slotted else 0) | (4 if partitioned else 0),
                                                     C.c_void_p(stream or None)), self._cache.handle)
 
     def _dev(self, nbytes: int) -> C.c_void_p:

@@ -157,6 +157,38 @@ __device__ __forceinline__ void total_contribute(const ScanLaunch& L, uint32_t u
     atomicExch(reinterpret_cast<unsigned long long*>(L.d_total_out), (told + tinc) & kMask);
 }
 
+// A hit list as its consumers see it: `parts` partitions (1: the contiguous form) in partition order.  hitlist_prefix fills
+// s_prefix[0 .. kHitParts] (LDS, written by the first threads of the workgroup; ends with a workgroup barrier) with the
+// number of records in front of every partition and returns the total; hitlist_at maps an index of that order to its
+// position in the buffer.
+__device__ __forceinline__ uint64_t hitlist_prefix(const unsigned long long* n_hits, uint64_t cap, uint32_t parts, uint64_t* s_prefix) {
+    if (threadIdx.x == 0) {
+        if (parts <= 1) {
+            s_prefix[0] = 0;
+            s_prefix[1] = min(uint64_t(*n_hits), cap);
+        } else {
+            const uint64_t stride = cap / parts;
+            uint64_t run = 0;
+            for (uint32_t p = 0; p < parts; p++) {
+                s_prefix[p] = run;
+                run += min(uint64_t(n_hits[p * kHitCounterStride]), stride);
+            }
+            s_prefix[parts] = run;
+        }
+    }
+    __syncthreads();
+    return s_prefix[parts <= 1 ? 1 : parts];
+}
+__device__ __forceinline__ uint64_t hitlist_at(const uint64_t* s_prefix, uint64_t cap, uint32_t parts, uint64_t i) {
+    if (parts <= 1) return i;
+    static_assert(kHitParts == 16, "four halving steps");
+    uint32_t p = i >= s_prefix[8] ? 8u : 0u;
+    p += i >= s_prefix[p + 4] ? 4u : 0u;
+    p += i >= s_prefix[p + 2] ? 2u : 0u;
+    p += i >= s_prefix[p + 1] ? 1u : 0u;
+    return uint64_t(p) * (cap / parts) + (i - s_prefix[p]);
+}
+
 template <typename T>
 __device__ __forceinline__ T load_unaligned(const uint8_t* p) {
     T v;

@@ -3739,9 +3739,13 @@ template <typename Desc>
 __global__ __launch_bounds__(kThreads) void k_mask_to_hits(const Desc* __restrict__ descs, uint32_t n_entries,
                                                            const uint64_t* __restrict__ mask, uint64_t* __restrict__ hits,
                                                            uint64_t cap, unsigned long long* __restrict__ n_hits,
-                                                           uint32_t* __restrict__ hit_first) {
+                                                           uint32_t* __restrict__ hit_first, uint32_t parts) {
     __shared__ unsigned long long s_wave_tot[kWavesPerBlock];
     __shared__ unsigned long long s_base;
+    // (partitioned list: this workgroup's partition; one list: partition 0 of 1)
+    const uint32_t part = parts > 1u ? (blockIdx.x & (kHitParts - 1u)) : 0u;
+    const uint64_t plim = parts > 1u ? cap / kHitParts : cap, pbase = uint64_t(part) * plim;
+    n_hits += part * kHitCounterStride;
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     constexpr uint32_t kPerWg = kHitsEntriesPerWave * kWavesPerBlock;
@@ -3790,7 +3794,7 @@ __global__ __launch_bounds__(kThreads) void k_mask_to_hits(const Desc* __restric
             if (tot[q] == 0) continue;
             const uint32_t entry = e0 + wave * kHitsEntriesPerWave + q;
             const uint32_t nwords = (len[q] + 63u) >> 6;
-            if (hit_first && lane == 0) hit_first[entry] = uint32_t(b);
+            if (hit_first && lane == 0) hit_first[entry] = uint32_t(pbase + b);
             for (uint32_t w0 = 0; w0 < nwords; w0 += kWave) {
                 const uint32_t w = w0 + uint32_t(lane);
                 uint64_t m = w0 == 0 ? m0[q] : (w0 == uint32_t(kWave) ? m1[q] : 0);
@@ -3804,7 +3808,7 @@ __global__ __launch_bounds__(kThreads) void k_mask_to_hits(const Desc* __restric
                 while (m) {
                     const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
                     m &= m - 1;
-                    if (pos < cap) hits[pos] = (uint64_t(entry) << 32) | (w * 64u + bit);
+                    if (pos < plim) hits[pbase + pos] = (uint64_t(entry) << 32) | (w * 64u + bit);
                     pos++;
                 }
                 b += read_lane(incl, kWave - 1);
@@ -3817,11 +3821,13 @@ template <typename U>
 __global__ __launch_bounds__(kThreads) void k_fixed_gather_hits(const FixedDesc* __restrict__ descs,
                                                                  const uint64_t* __restrict__ hits,
                                                                  const unsigned long long* __restrict__ n_hits, uint64_t cap,
-                                                                 uint8_t* __restrict__ out, uint8_t* __restrict__ row_valid) {
+                                                                 uint8_t* __restrict__ out, uint8_t* __restrict__ row_valid,
+                                                                 uint32_t parts) {
     constexpr uint32_t TB = LaneTraits<U>::kBits;
-    const uint64_t k = min(uint64_t(*n_hits), cap);
+    __shared__ uint64_t s_prefix[kHitParts + 1];
+    const uint64_t k = hitlist_prefix(n_hits, cap, parts, s_prefix);
     for (uint64_t i = uint64_t(blockIdx.x) * kThreads + threadIdx.x; i < k; i += uint64_t(gridDim.x) * kThreads) {
-        const uint64_t ref = hits[i];
+        const uint64_t ref = hits[hitlist_at(s_prefix, cap, parts, i)];
         const uint32_t r = uint32_t(ref);
         const FixedDesc& d = descs[uint32_t(ref >> 32)];
         const uint32_t W = d.W, vw = d.value_width;
@@ -3909,6 +3915,8 @@ struct HitsPredArgs {
     uint64_t* hits_out;
     uint64_t cap_out;
     unsigned long long* n_out;
+    uint32_t parts;        // 1 / kHitParts: layout of both lists (lc_kernels.hpp)
+    uint32_t pad_parts;
     // byte views
     int32_t op;            // LC_OP_*
     int32_t const_value;   // >= 0: Literal(Boolean)
@@ -3982,7 +3990,12 @@ __device__ __forceinline__ bool fixed_value_pred(const FixedDesc& d, uint32_t r,
 template <int kLaneLog2>  // 0: byte views; 3..6: fixed width lanes
 __global__ __launch_bounds__(kThreads) void k_pred_hits(HitsPredArgs a) {
     __shared__ unsigned long long s_tot[2][kWavesPerBlock], s_base[2];
-    const uint64_t k = min(uint64_t(*a.n_in), a.cap_in);
+    __shared__ uint64_t s_prefix[kHitParts + 1];
+    const uint64_t k = hitlist_prefix(a.n_in, a.cap_in, a.parts, s_prefix);
+    // (the survivors go to this workgroup's partition of the output list; one list: partition 0 of 1)
+    const uint32_t part = a.parts > 1u ? (blockIdx.x & (kHitParts - 1u)) : 0u;
+    const uint64_t plim = a.parts > 1u ? a.cap_out / kHitParts : a.cap_out, pbase = uint64_t(part) * plim;
+    unsigned long long* const ctr = a.n_out + part * kHitCounterStride;
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
     // the inline literal -> LDS (a pointer into the kernel arguments would send the whole argument block to scratch: 232 bytes
@@ -4004,7 +4017,7 @@ __global__ __launch_bounds__(kThreads) void k_pred_hits(HitsPredArgs a) {
     for (uint64_t rb0 = uint64_t(blockIdx.x) * kThreads; rb0 < k; rb0 += uint64_t(gridDim.x) * kThreads, it ^= 1u) {
         const uint64_t i = rb0 + uint64_t(wave) * kWave + uint64_t(lane);
         const bool live = i < k;
-        const uint64_t ref = live ? a.hits_in[i] : 0;
+        const uint64_t ref = live ? a.hits_in[hitlist_at(s_prefix, a.cap_in, a.parts, i)] : 0;
         const uint32_t row = uint32_t(ref);
         bool keep = false;
         if (live) {
@@ -4049,14 +4062,14 @@ __global__ __launch_bounds__(kThreads) void k_pred_hits(HitsPredArgs a) {
         if (threadIdx.x == 0) {
             unsigned long long t = 0;
             for (uint32_t w = 0; w < uint32_t(kWavesPerBlock); w++) t += s_tot[it][w];
-            s_base[it] = t ? atomicAdd(a.n_out, t) : 0ull;
+            s_base[it] = t ? atomicAdd(ctr, t) : 0ull;
         }
         __syncthreads();
         unsigned long long b = s_base[it];
         for (uint32_t w = 0; w < wave; w++) b += s_tot[it][w];
         if (keep) {
             const uint64_t pos = b + lanes_below(km);
-            if (pos < a.cap_out) a.hits_out[pos] = ref;
+            if (pos < plim) a.hits_out[pbase + pos] = ref;
         }
     }
 }
@@ -4128,11 +4141,12 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
                                                                const unsigned long long* __restrict__ n_hits, uint64_t cap_rows,
                                                                uint32_t* __restrict__ views, uint8_t* __restrict__ row_valid,
                                                                uint8_t* __restrict__ data, uint64_t cap_bytes,
-                                                               unsigned long long* __restrict__ n_bytes) {
+                                                               unsigned long long* __restrict__ n_bytes, uint32_t parts) {
     __shared__ LdsSymtab s_tab[kWavesPerBlock];
     __shared__ __attribute__((aligned(16))) uint8_t s_out[kSlotted ? 1 : kWavesPerBlock][kSlotted ? 16 : kGatherStage + 16];
     __shared__ unsigned long long s_tot[2][kWavesPerBlock], s_base[2];
-    const uint64_t k = min(uint64_t(*n_hits), cap_rows);
+    __shared__ uint64_t s_prefix[kHitParts + 1];
+    const uint64_t k = hitlist_prefix(n_hits, cap_rows, parts, s_prefix);
     const uint64_t n_waves = uint64_t(gridDim.x) * kWavesPerBlock;
     const int lane = lane_id();
     const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
@@ -4158,7 +4172,7 @@ __global__ __launch_bounds__(kThreads) void k_str_gather_hits(const StrDesc* __r
         const uint64_t rb = rb0 + uint64_t(wave) * R;
         const uint64_t i = rb + uint64_t(lane);
         const bool live = uint32_t(lane) < R && i < k;
-        const uint64_t ref = live ? hits[i] : 0;
+        const uint64_t ref = live ? hits[hitlist_at(s_prefix, cap_rows, parts, i)] : 0;
         const uint32_t row = uint32_t(ref);
         const StrDesc* dp = descs + uint32_t(ref >> 32);
         const uint32_t slot = live ? dp->symtab_slot : 0u;
@@ -5717,31 +5731,49 @@ hipError_t launch_group_counts(const uint32_t* d_entry_counts, const uint32_t* d
     return hipGetLastError();
 }
 
+// The partitions of a hit list in partition order as ONE contiguous list (lc_hits_compact): for ABI users that read the list.
+namespace {
+__global__ __launch_bounds__(kThreads) void k_hits_compact(const uint64_t* __restrict__ hits, const unsigned long long* __restrict__ n_hits,
+                                                           uint64_t cap, uint64_t* __restrict__ out, uint64_t cap_out,
+                                                           unsigned long long* __restrict__ n_out) {
+    __shared__ uint64_t s_prefix[kHitParts + 1];
+    const uint64_t k = hitlist_prefix(n_hits, cap, kHitParts, s_prefix);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_out = k;
+    for (uint64_t i = uint64_t(blockIdx.x) * kThreads + threadIdx.x; i < k && i < cap_out; i += uint64_t(gridDim.x) * kThreads)
+        out[i] = hits[hitlist_at(s_prefix, cap, kHitParts, i)];
+}
+}  // namespace
+hipError_t launch_hits_compact(const uint64_t* d_hits, const unsigned long long* d_n_hits, uint64_t cap, uint64_t* d_out, uint64_t cap_out,
+                               unsigned long long* d_n_out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_hits_compact, dim3(uint32_t(device_cus())), dim3(kThreads), 0, stream, d_hits, d_n_hits, cap, d_out, cap_out, d_n_out);
+    return hipGetLastError();
+}
+
 hipError_t launch_mask_to_hits(const void* d_descs, bool is_str, uint32_t n_entries, const uint64_t* d_mask, uint64_t* d_hits,
-                               uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, hipStream_t stream) {
+                               uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, uint32_t parts, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
     const uint64_t per_wg = uint64_t(kHitsEntriesPerWave) * kWavesPerBlock;
     const uint64_t wgs_needed = (uint64_t(n_entries) + per_wg - 1) / per_wg;
     const dim3 grid(uint32_t(std::min<uint64_t>(wgs_needed, uint64_t(device_cus()) * 8)));
     if (is_str)
         hipLaunchKernelGGL(k_mask_to_hits<StrDesc>, grid, dim3(kThreads), 0, stream, static_cast<const StrDesc*>(d_descs), n_entries,
-                           d_mask, d_hits, cap, d_n_hits, d_hit_first);
+                           d_mask, d_hits, cap, d_n_hits, d_hit_first, parts);
     else
         hipLaunchKernelGGL(k_mask_to_hits<FixedDesc>, grid, dim3(kThreads), 0, stream, static_cast<const FixedDesc*>(d_descs), n_entries,
-                           d_mask, d_hits, cap, d_n_hits, d_hit_first);
+                           d_mask, d_hits, cap, d_n_hits, d_hit_first, parts);
     return hipGetLastError();
 }
 
 hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, const uint64_t* d_hits,
                                     const unsigned long long* d_n_hits, uint64_t cap, uint8_t* d_values_out, uint8_t* d_row_valid,
-                                    hipStream_t stream) {
+                                    uint32_t parts, hipStream_t stream) {
     if (cap == 0) return hipSuccess;
     const dim3 grid(uint32_t(std::min<uint64_t>((cap + kThreads - 1) / kThreads, uint64_t(device_cus()) * 8))), block(kThreads);
     switch (lane_log2) {
-        case 3: hipLaunchKernelGGL(k_fixed_gather_hits<uint8_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid); break;
-        case 4: hipLaunchKernelGGL(k_fixed_gather_hits<uint16_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid); break;
-        case 5: hipLaunchKernelGGL(k_fixed_gather_hits<uint32_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid); break;
-        case 6: hipLaunchKernelGGL(k_fixed_gather_hits<uint64_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid); break;
+        case 3: hipLaunchKernelGGL(k_fixed_gather_hits<uint8_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid, parts); break;
+        case 4: hipLaunchKernelGGL(k_fixed_gather_hits<uint16_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid, parts); break;
+        case 5: hipLaunchKernelGGL(k_fixed_gather_hits<uint32_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid, parts); break;
+        case 6: hipLaunchKernelGGL(k_fixed_gather_hits<uint64_t>, grid, block, 0, stream, d_descs, d_hits, d_n_hits, cap, d_values_out, d_row_valid, parts); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -5749,7 +5781,7 @@ hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, con
 
 hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_hits,
                                   const unsigned long long* d_n_hits, uint64_t cap_rows, uint32_t* d_views, uint8_t* d_row_valid,
-                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, bool slotted,
+                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, bool slotted, uint32_t parts,
                                   hipStream_t stream) {
     if (cap_rows == 0) return hipSuccess;
     if (slotted) {
@@ -5761,13 +5793,13 @@ hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_sym
         const uint32_t grid = uint32_t(std::min<uint64_t>((cap_rows + kWavesPerBlock - 1) / kWavesPerBlock,
                                                           uint64_t(device_cus()) * LC_GATHER_SLOT_WGS));
         hipLaunchKernelGGL(k_str_gather_hits<true>, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_hits, d_n_hits,
-                           cap_rows, d_views, d_row_valid, d_data, cap_bytes, d_n_bytes);
+                           cap_rows, d_views, d_row_valid, d_data, cap_bytes, d_n_bytes, parts);
         return hipGetLastError();
     }
     // 34 KB of LDS per workgroup: four of them per CU are resident, and a latency-bound gather wants no second round
     const uint32_t grid = uint32_t(std::min<uint64_t>((cap_rows + kWavesPerBlock - 1) / kWavesPerBlock, uint64_t(device_cus()) * 4));
     hipLaunchKernelGGL(k_str_gather_hits<false>, dim3(grid), dim3(kThreads), 0, stream, d_descs, d_symtabs, d_hits, d_n_hits, cap_rows,
-                       d_views, d_row_valid, d_data, cap_bytes, d_n_bytes);
+                       d_views, d_row_valid, d_data, cap_bytes, d_n_bytes, parts);
     return hipGetLastError();
 }
 
@@ -5778,6 +5810,7 @@ hipError_t launch_pred_hits(const HitsPredLaunch& h, hipStream_t stream) {
     a.symtabs = h.symtabs;
     a.hits_in = h.hits_in;
     a.n_in = h.n_in;
+    a.parts = h.parts > 1u ? kHitParts : 1u;
     a.cap_in = h.cap_in;
     a.hits_out = h.hits_out;
     a.cap_out = h.cap_out;

@@ -265,7 +265,16 @@ struct ScanLaunch {
                                       // d_counts / d_total_out / d_hits without storing mask words may skip them
     uint32_t entry_split_log2;        // fixed width, register-resident kernels: an entry is worked on by 2^this waves, each taking
                                       // a run of its 1024-row blocks (set by the launcher; 0 when per-entry counts are asked for)
+    uint32_t hits_parts;              // 0 / 1: d_hits is ONE list with ONE counter; kHitParts: the PARTITIONED form (below)
+    uint32_t pad_parts;
 };
+// The partitioned hit list (LC_HITS_PARTITIONED, round 6).  A contiguous list is allocated by returning atomics on ONE address,
+// which complete ~10 ns apart however many workgroups wait: 1,100 of them were 11 of the 23.7 us of a selective LIKE with a
+// list.  Partitioned, workgroup b appends to partition b % kHitParts: region p = records [p S, (p + 1) S) with S = capacity /
+// kHitParts, its counter the u64 at n_hits[p * kHitCounterStride] (a 128-byte line of its own).  Consumers see the partitions
+// as ONE list in partition order (hitlist_prefix / hitlist_at in lc_device.hpp): their outputs are as dense as before.
+constexpr uint32_t kHitParts = 16;
+constexpr uint32_t kHitCounterStride = 16;  // u64 words between two partitions' counters
 // accumulator layout: word 0 = top level, words 8, 16, ... = shards (one 64-byte line each).  A word packs
 // {arrivals : 24 | hits : 40}, so ONE returning atomic both adds a count and tells the caller whether it was the last.
 constexpr uint32_t kTotalShards = 64;
@@ -374,14 +383,19 @@ hipError_t warm_code_object_bv_encode();
 hipError_t launch_zero_small(void* p, uint32_t bytes, hipStream_t stream);
 hipError_t launch_group_counts(const uint32_t* d_entry_counts, const uint32_t* d_group_ends, uint32_t n_groups, uint64_t* d_out,
                                hipStream_t stream);
+// (`parts`: 1 = contiguous list, kHitParts = partitioned; the list's capacity is `cap` records either way)
 hipError_t launch_mask_to_hits(const void* d_descs, bool is_str, uint32_t n_entries, const uint64_t* d_mask, uint64_t* d_hits,
-                               uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, hipStream_t stream);
+                               uint64_t cap, unsigned long long* d_n_hits, uint32_t* d_hit_first, uint32_t parts, hipStream_t stream);
 hipError_t launch_fixed_gather_hits(const FixedDesc* d_descs, int lane_log2, const uint64_t* d_hits,
                                     const unsigned long long* d_n_hits, uint64_t cap, uint8_t* d_values_out, uint8_t* d_row_valid,
-                                    hipStream_t stream);
+                                    uint32_t parts, hipStream_t stream);
 hipError_t launch_str_gather_hits(const StrDesc* d_descs, const DevSymtab* d_symtabs, const uint64_t* d_hits,
                                   const unsigned long long* d_n_hits, uint64_t cap_rows, uint32_t* d_views, uint8_t* d_row_valid,
-                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, bool slotted, hipStream_t stream);
+                                  uint8_t* d_data, uint64_t cap_bytes, unsigned long long* d_n_bytes, bool slotted, uint32_t parts,
+                                  hipStream_t stream);
+// the partitions of a list in partition order -> one contiguous list (+ its count)
+hipError_t launch_hits_compact(const uint64_t* d_hits, const unsigned long long* d_n_hits, uint64_t cap, uint64_t* d_out, uint64_t cap_out,
+                               unsigned long long* d_n_out, hipStream_t stream);
 // a predicate over the rows of a hit list (k_pred_hits): lane_log2 0 = byte views (op on the literal / pattern bytes; lit_len <=
 // kInlineNeedle travels in the kernel arguments from h_lit, longer literals from the device copy d_lit), 3..6 = fixed width
 struct HitsPredLaunch {
@@ -393,6 +407,7 @@ struct HitsPredLaunch {
     uint64_t* hits_out;
     uint64_t cap_out;
     unsigned long long* n_out;
+    uint32_t parts;      // 1 / kHitParts: layout of BOTH lists
     int32_t lane_log2;
     int32_t op;
     int32_t const_value;

@@ -668,6 +668,8 @@ struct FlatArgs {
     uint64_t hits_cap;
     unsigned long long* n_hits;
     uint32_t* hit_first;
+    uint32_t hits_parts;   // 1: one list; kHitParts: partitioned (lc_kernels.hpp)
+    uint32_t pad_parts;
     ScanLaunch total;
 };
 using ConstFlatPtr = const __attribute__((address_space(4))) FlatGroup*;
@@ -779,6 +781,11 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
     // once by every wave of a workgroup that has records, after its sync_image() (the barriers are workgroup wide).
     auto finish = [&](uint64_t wh) {
         if (a.hits) {
+            // (partitioned list: this workgroup's partition — its counter, its region of the buffer; one list: partition 0 of 1)
+            const uint32_t part = a.hits_parts > 1u ? (blockIdx.x & (kHitParts - 1u)) : 0u;
+            const uint64_t plim = a.hits_parts > 1u ? a.hits_cap / kHitParts : a.hits_cap;
+            const uint64_t pbase = uint64_t(part) * plim;
+            unsigned long long* const ctr = a.n_hits + part * kHitCounterStride;
             unsigned long long b = 0;
             if (kFlatWaves > 1) {
                 auto slot_of = [&](uint32_t w) {
@@ -800,12 +807,12 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
 #if defined(LC_FLAT_HITS_ABL) && (LC_FLAT_HITS_ABL & 1)  // timing aid (wrong positions): no list allocation
                 if (wave == 0 && lane == 0) *bslot = 0ull;
 #else
-                if (wave == 0 && lane == 0) *bslot = all ? atomicAdd(a.n_hits, all) : 0ull;
+                if (wave == 0 && lane == 0) *bslot = all ? atomicAdd(ctr, all) : 0ull;
 #endif
                 __syncthreads();
                 b = uniform_u64(*bslot + before);
             } else if (wh) {
-                if (lane == 0) b = atomicAdd(a.n_hits, (unsigned long long)wh);
+                if (lane == 0) b = atomicAdd(ctr, (unsigned long long)wh);
                 b = uniform_u64(b);
             }
 #if defined(LC_FLAT_HITS_ABL) && (LC_FLAT_HITS_ABL & 2)  // timing aid: no records written
@@ -826,12 +833,12 @@ __global__ __launch_bounds__(kFlatWaves * 64) void k_like_flat(FlatArgs a) {
                         while (m) {
                             const uint32_t bit = uint32_t(__ffsll((long long)m)) - 1u;
                             m &= m - 1;
-                            if (pos < a.hits_cap) as_global_mut(a.hits)[pos] = (uint64_t(first_entry + j) << 32) | (w * 64u + bit);
+                            if (pos < plim) as_global_mut(a.hits)[pbase + pos] = (uint64_t(first_entry + j) << 32) | (w * 64u + bit);
                             pos++;
                         }
                         b += read_lane(incl, kWave - 1);
                     }
-                    if (a.hit_first && b != eb && lane == 0) as_global_mut(a.hit_first)[first_entry + j] = uint32_t(eb);
+                    if (a.hit_first && b != eb && lane == 0) as_global_mut(a.hit_first)[first_entry + j] = uint32_t(pbase + eb);
                 }
             }
         }
@@ -1682,6 +1689,7 @@ lc_status run_flat(LikePipeline* lp, const StrPredHost& sp, const ScanLaunch& L,
     fa.hits_cap = L.hits_cap;
     fa.n_hits = L.d_n_hits;
     fa.hit_first = L.d_hit_first;
+    fa.hits_parts = L.hits_parts > 1u ? kHitParts : 1u;
     fa.total.d_total_acc = lp->d_total_acc;
     fa.total.d_total_out = L.d_total_out;
     LC_HIP(launch_flat(int(std::min<uint32_t>(nb, uint32_t(kMaxSigProbe))), p.op == LC_OP_NOT_LIKE && !force_like, fa, stream));

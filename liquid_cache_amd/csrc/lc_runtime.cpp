@@ -2840,6 +2840,7 @@ struct HitsOut {
     void* d_n_hits = nullptr;
     void* d_hit_first = nullptr;
     bool counters_zeroed = false;  // LC_HITS_COUNTERS_ZEROED: the caller zeroed *d_n_hits (one memset for a whole query)
+    bool partitioned = false;      // LC_HITS_PARTITIONED
 };
 
 static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pred, const void* d_selection,
@@ -2854,7 +2855,8 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         return fail(LC_ERR_INVALID, "no output: d_mask_out is null and neither a count nor a hit list is asked for");
     if (!d_mask_out && d_valid_out) return fail(LC_ERR_INVALID, "a validity output needs the mask output");
     if (hits && hits->d_hits && !hits->d_n_hits) return fail(LC_ERR_INVALID, "d_n_hits is null");
-    if (hits && hits->d_n_hits && !hits->counters_zeroed) LC_HIP(launch_zero_small(hits->d_n_hits, 8, stream));
+    if (hits && hits->d_n_hits && !hits->counters_zeroed)
+        LC_HIP(launch_zero_small(hits->d_n_hits, hits->partitioned ? kHitParts * kHitCounterStride * 8u : 8u, stream));
     if (s->n == 0) {
         if (d_total_out) LC_HIP(hipMemsetAsync(d_total_out, 0, 8, stream));
         return LC_OK;
@@ -2879,6 +2881,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         L.hits_cap = hits->cap;
         L.d_n_hits = static_cast<unsigned long long*>(hits->d_n_hits);
         L.d_hit_first = static_cast<uint32_t*>(hits->d_hit_first);
+        L.hits_parts = hits->partitioned ? kHitParts : 1u;
     }
     // the evaluation proper; kernels that do not append the hit list themselves leave it to k_mask_to_hits below
     const lc_status est = [&]() -> lc_status {
@@ -3146,7 +3149,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     if (est != LC_OK) return est;
     if (want_hits && !s->last_native_hits)
         LC_HIP(launch_mask_to_hits(s->d_descs, s->is_str, s->n, static_cast<const uint64_t*>(d_mask_out), L.d_hits, L.hits_cap,
-                                   L.d_n_hits, L.d_hit_first, stream));
+                                   L.d_n_hits, L.d_hit_first, L.hits_parts, stream));
     return LC_OK;
     });
 }
@@ -4539,21 +4542,40 @@ lc_status lc_scan_eval_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred
     h.d_n_hits = d_n_hits;
     h.d_hit_first = d_hit_first;
     h.counters_zeroed = (flags & LC_HITS_COUNTERS_ZEROED) != 0;
+    h.partitioned = (flags & LC_HITS_PARTITIONED) != 0;
+    if (h.partitioned && capacity < LC_HITS_PARTITIONS) return fail(LC_ERR_INVALID, "a partitioned list needs a capacity of at least LC_HITS_PARTITIONS records");
     return scan_eval_impl(ctx, scan, &preds[0], d_selection, nullptr, nullptr, d_counts_out, nullptr,
                           static_cast<hipStream_t>(stream), n_preds == 2 ? &preds[1] : nullptr, d_total_out, false, &h);
 }
 
 lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, void* d_hits_out, uint64_t capacity,
-                               void* d_n_hits, void* d_hit_first, void* stream) {
+                               void* d_n_hits, void* d_hit_first, uint32_t flags, void* stream) {
     return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_mask || !d_hits_out || !d_n_hits) return fail(LC_ERR_INVALID, "null argument");
+    const bool parts = (flags & LC_HITS_PARTITIONED) != 0;
+    if (parts && capacity < LC_HITS_PARTITIONS) return fail(LC_ERR_INVALID, "a partitioned list needs a capacity of at least LC_HITS_PARTITIONS records");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    LC_HIP(launch_zero_small(d_n_hits, 8, st));
+    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(launch_zero_small(d_n_hits, parts ? kHitParts * kHitCounterStride * 8u : 8u, st));
     if (scan->n == 0) return LC_OK;
     scan_note_stream(scan, st);
     LC_HIP(launch_mask_to_hits(scan->d_descs, scan->is_str, scan->n, static_cast<const uint64_t*>(d_mask),
                                static_cast<uint64_t*>(d_hits_out), capacity, static_cast<unsigned long long*>(d_n_hits),
-                               static_cast<uint32_t*>(d_hit_first), st));
+                               static_cast<uint32_t*>(d_hit_first), parts ? kHitParts : 1u, st));
+    return LC_OK;
+    });
+}
+
+lc_status lc_hits_compact(lc_ctx* ctx, const void* d_hits, const void* d_n_hits, uint64_t capacity, void* d_hits_out,
+                          uint64_t capacity_out, void* d_n_hits_out, void* stream) {
+    return guarded([&]() -> lc_status {
+    if (!ctx || !d_hits || !d_n_hits || !d_hits_out || !d_n_hits_out) return fail(LC_ERR_INVALID, "null argument");
+    if (d_hits == d_hits_out) return fail(LC_ERR_INVALID, "lc_hits_compact does not compact in place");
+    if (capacity < LC_HITS_PARTITIONS) return fail(LC_ERR_INVALID, "a partitioned list has a capacity of at least LC_HITS_PARTITIONS records");
+    if (ctx->device < 0) return fail(LC_ERR_DEVICE, "host-only context: no HIP device (there is no CPU fallback)");
+    LC_HIP(hipSetDevice(ctx->device));
+    LC_HIP(launch_hits_compact(static_cast<const uint64_t*>(d_hits), static_cast<const unsigned long long*>(d_n_hits), capacity,
+                               static_cast<uint64_t*>(d_hits_out), capacity_out, static_cast<unsigned long long*>(d_n_hits_out),
+                               static_cast<hipStream_t>(stream)));
     return LC_OK;
     });
 }
@@ -4565,7 +4587,10 @@ lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
     if (!ctx || !scan || !pred || !d_hits_in || !d_n_hits_in || !d_hits_out || !d_n_hits_out) return fail(LC_ERR_INVALID, "null argument");
     if (d_hits_in == d_hits_out) return fail(LC_ERR_INVALID, "lc_scan_filter_hits does not filter in place");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(launch_zero_small(d_n_hits_out, 8, st));
+    const bool parts = (flags & LC_HITS_PARTITIONED) != 0;
+    if (parts && (capacity_in < LC_HITS_PARTITIONS || capacity_out < LC_HITS_PARTITIONS))
+        return fail(LC_ERR_INVALID, "a partitioned list needs a capacity of at least LC_HITS_PARTITIONS records");
+    if (!(flags & LC_HITS_COUNTERS_ZEROED)) LC_HIP(launch_zero_small(d_n_hits_out, parts ? kHitParts * kHitCounterStride * 8u : 8u, st));
     if (scan->n == 0 || capacity_in == 0) return LC_OK;
     if (scan->has_clamped || scan->has_fquant)
         return fail(LC_UNSUPPORTED, "squeezed entries: the mask form decides which rows need the backing array");
@@ -4578,6 +4603,7 @@ lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
     h.hits_out = static_cast<uint64_t*>(d_hits_out);
     h.cap_out = capacity_out;
     h.n_out = static_cast<unsigned long long*>(d_n_hits_out);
+    h.parts = parts ? kHitParts : 1u;
     h.const_value = -1;
     if (!scan->is_str) {
         const lc_status ps = make_fixed_pred(scan->meta[0], pred, &h.fp);
@@ -4635,7 +4661,7 @@ lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
 }
 
 lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits, uint64_t capacity_rows,
-                                    void* d_values_out, void* d_row_valid, void* stream) {
+                                    void* d_values_out, void* d_row_valid, uint32_t flags, void* stream) {
     return guarded([&]() -> lc_status {
     if (!ctx || !scan || !d_hits || !d_n_hits || !d_values_out) return fail(LC_ERR_INVALID, "null argument");
     if (scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_fixed_hits covers fixed-width columns (byte views: lc_scan_gather_bytes_hits)");
@@ -4646,7 +4672,8 @@ lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hi
     scan_note_stream(scan, st);
     LC_HIP(launch_fixed_gather_hits(static_cast<const FixedDesc*>(scan->d_descs), scan->lane_log2, static_cast<const uint64_t*>(d_hits),
                                     static_cast<const unsigned long long*>(d_n_hits), capacity_rows,
-                                    static_cast<uint8_t*>(d_values_out), static_cast<uint8_t*>(d_row_valid), st));
+                                    static_cast<uint8_t*>(d_values_out), static_cast<uint8_t*>(d_row_valid),
+                                    (flags & LC_HITS_PARTITIONED) ? kHitParts : 1u, st));
     return LC_OK;
     });
 }
@@ -4669,7 +4696,7 @@ lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hi
     LC_HIP(launch_str_gather_hits(static_cast<const StrDesc*>(scan->d_descs), scan->d_symtabs, static_cast<const uint64_t*>(d_hits),
                                   static_cast<const unsigned long long*>(d_n_hits), capacity_rows, static_cast<uint32_t*>(d_views),
                                   static_cast<uint8_t*>(d_row_valid), static_cast<uint8_t*>(d_data), capacity_bytes,
-                                  static_cast<unsigned long long*>(d_n_bytes), slotted, st));
+                                  static_cast<unsigned long long*>(d_n_bytes), slotted, (flags & LC_HITS_PARTITIONED) ? kHitParts : 1u, st));
     return LC_OK;
     });
 }

@@ -88,6 +88,45 @@ def main():
     t_gs = timed(gat_slotted, 16)
     print("%-8s count-only %.2f us  eval_hits(+memset) %.2f us  filter_hits(+memset) %.2f us  gather_bytes_hits(+memset) %.2f us  "
           "slotted %.2f us  hits %d" % (tag, t_cnt, t_ev, t_f, t_g, t_gs, n_hits), flush=True)
+    # the PARTITIONED list form (LC_HITS_PARTITIONED): 16 counters on their own cache lines
+    P, CS = N.HITS_PARTITIONS, N.HITS_COUNTER_STRIDE
+    pctr = torch.zeros(2 * P * CS + 2, dtype=torch.int64, device="cuda")
+    q = pctr.data_ptr()
+    q2, qb = q + 8 * P * CS, q + 16 * P * CS
+
+    def pzero(ptr, nbytes):
+        N.check(cache._lib.lc_device_memset(cache.handle, ptr, 0, nbytes, stream), cache.handle)
+
+    def ptimed(fn, zero_ptr, zero_bytes):
+        pctr.zero_()
+        scan.eval_hits(like, hits.data_ptr(), cap, q, 0, 0, 0, total.data_ptr(), stream, counters_zeroed=True, partitioned=True)
+        torch.cuda.synchronize()
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            pzero(zero_ptr, zero_bytes)
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.iters * 1e3
+    tp_ev = ptimed(lambda: scan.eval_hits(like, hits.data_ptr(), cap, q, 0, 0, 0, total.data_ptr(), stream, counters_zeroed=True,
+                                          partitioned=True), q, 8 * P * CS)
+    pctr.zero_()
+    scan.eval_hits(like, hits.data_ptr(), cap, q, 0, 0, 0, total.data_ptr(), stream, counters_zeroed=True, partitioned=True)
+    torch.cuda.synchronize()
+    n_p = int(pctr[0: P * CS: CS].sum().item())
+    tp_f = ptimed(lambda: scan.filter_hits(ne, hits.data_ptr(), q, cap, hits2.data_ptr(), cap, q2, stream, counters_zeroed=True,
+                                           partitioned=True), q2, 8 * P * CS)
+    tp_g = ptimed(lambda: scan.gather_bytes_hits(hits.data_ptr(), q, cap, views.data_ptr(), data.data_ptr(),
+                                                 min(data.numel(), (1 << 31) - 1), qb, 0, stream, counters_zeroed=True,
+                                                 partitioned=True), qb, 8)
+    tp_gs = ptimed(lambda: scan.gather_bytes_hits(hits.data_ptr(), q, cap, views.data_ptr(), data.data_ptr(),
+                                                  min(data.numel(), (1 << 31) - 1), qb, 0, stream, counters_zeroed=True, slotted=True,
+                                                  partitioned=True), qb, 8)
+    print("%-8s PARTITIONED: eval_hits(+memset) %.2f us  filter_hits(+memset) %.2f us  gather_bytes_hits(+memset) %.2f us  slotted %.2f us  "
+          "hits %d" % (tag, tp_ev, tp_f, tp_g, tp_gs, n_p), flush=True)
     scan.close()
     cache.close()
 

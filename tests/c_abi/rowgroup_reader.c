@@ -142,7 +142,7 @@ static void* worker(void* arg) {
                 lc_scan_filter_hits(ctx, ns, &gt, d_hits1, c, CAP, d_hits2, CAP, c + 8, LC_HITS_COUNTERS_ZEROED, stream) != LC_OK ||
                 lc_scan_gather_bytes_hits(ctx, us, d_hits2, c + 8, CAP, d_views, d_valid, d_data, CAP * 160, c + 16,
                                           LC_HITS_COUNTERS_ZEROED | (slotted ? LC_GATHER_SLOTTED : 0u), stream) != LC_OK ||
-                lc_scan_gather_fixed_hits(ctx, ns, d_hits2, c + 8, CAP, d_vals, NULL, stream) != LC_OK) { w->rc = 4; return NULL; }
+                lc_scan_gather_fixed_hits(ctx, ns, d_hits2, c + 8, CAP, d_vals, NULL, 0, stream) != LC_OK) { w->rc = 4; return NULL; }
             uint64_t ctr[4];
             if (lc_device_to_host(ctx, ctr, d_ctr, 32, stream) != LC_OK) { w->rc = 5; return NULL; }
             const uint64_t k = ctr[1];

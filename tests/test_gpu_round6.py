@@ -314,3 +314,144 @@ def test_async_build_does_not_evict_until_the_scan_is_hot(product_lib, oracle, g
         assert later[-1] == index_bytes, later  # ... and is once B has served 8 evaluations
     finally:
         cache.close()
+
+
+def _read_partitioned(scan, d_hits, d_n, cap):
+    """(records of partition 0, 1, ... concatenated — the order the consuming calls read them in —, per-partition counts)."""
+    ctrs = scan._from_dev(d_n, np.uint64, N.HITS_PARTITIONS * N.HITS_COUNTER_STRIDE)[::N.HITS_COUNTER_STRIDE]
+    stride = cap // N.HITS_PARTITIONS
+    buf = scan._from_dev(d_hits, np.uint64, cap)
+    parts = [buf[p * stride: p * stride + min(int(ctrs[p]), stride)] for p in range(N.HITS_PARTITIONS)]
+    return np.concatenate(parts) if parts else np.zeros(0, np.uint64), ctrs
+
+
+def test_partitioned_hit_lists_against_oracle(product_lib, oracle, grouped_cases):
+    """LC_HITS_PARTITIONED: the list in 16 partitions (producers claim space on 16 addresses instead of one).  The records of
+    all partitions are exactly the set bits of the oracle's mask — from k_like_flat itself and from the mask path —, the filter
+    on a partitioned list keeps exactly the oracle's survivors, the gathers read the partitions as one list in partition order
+    (row i of the output = record i of that order), lc_hits_compact gives that order back as a contiguous list."""
+    lo = oracle
+    cache = lc.LiquidCacheBuilder.new().with_index_options(like_pipeline_min_entries=1).build()
+    try:
+        ids, flat = _stage(cache, lo, grouped_cases, file_id=48, path0=8300)
+        lens = [len(c[0]) for c in flat]
+        scan = cache.scan(ids)
+        offs = scan.segment_offsets
+        n_bits = int(scan.mask_words) * 64
+        # (a partition holds capacity / 16 records and a small launch fills only as many partitions as it has workgroups: sized
+        # so that ONE partition can take every row — a caller sizes for its selectivity and retries on overflow)
+        cap = int(scan.rows) * N.HITS_PARTITIONS
+        lib, ctx = cache._lib, cache.handle
+        ptrs = []
+
+        def dev(nbytes):
+            p = scan._dev(nbytes)
+            ptrs.append(p)
+            return p
+        d_hits, d_hits2, d_flat = dev(cap * 8), dev(cap * 8), dev(cap * 8)
+        d_n, d_n2 = dev(2048), dev(2048)
+        d_nflat = dev(8)
+        d_first = dev(max(scan.entries, 1) * 4)
+        d_mask = dev(max(int(scan.mask_words), 1) * 8)
+        d_total = dev(8)
+        checked = 0
+        for nd, op in ((b"zzzzqqq", "like"), (b"index.php?id=1", "like"), (b"google", "like"), (b"a", "like"), (b"#21", "not_like"),
+                       (b"yandex.google", "like"), (b"//", "like")):
+            pattern = b"%" + nd + b"%"
+            expr = lc.LiquidExpr.try_new(op, pattern, pa.binary(), HINT)
+            want = _oracle_bits(lo, flat, op, pattern)
+            want_set = set()
+            for b, w in enumerate(want):
+                want_set.update((b << 32) | int(r) for r in np.flatnonzero(w))
+            for from_mask in (False, True):
+                N.check(lib.lc_host_to_device(ctx, d_first, np.full(max(scan.entries, 1), 0xFFFFFFFF, np.uint32).ctypes.data_as(
+                    __import__("ctypes").c_void_p), max(scan.entries, 1) * 4, None), ctx)
+                if from_mask:
+                    scan.eval_count(expr, d_mask.value, d_total.value)
+                    scan.mask_to_hits(d_mask.value, d_hits.value, cap, d_n.value, d_first.value, partitioned=True)
+                else:
+                    scan.eval_hits(expr, d_hits.value, cap, d_n.value, hit_first_ptr=d_first.value, total_out_ptr=d_total.value,
+                                   partitioned=True)
+                N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+                recs, ctrs = _read_partitioned(scan, d_hits, d_n, cap)
+                total = int(scan._from_dev(d_total, np.uint64, 1)[0])
+                assert int(ctrs.sum()) == len(recs) == total == len(want_set), (nd, op, from_mask, int(ctrs.sum()), len(want_set))
+                assert set(int(x) for x in recs) == want_set, (nd, op, from_mask)
+                # an entry's records are contiguous and ascending inside ONE partition; hit_first is its position in the buffer
+                first = scan._from_dev(d_first, np.uint32, scan.entries)
+                buf = scan._from_dev(d_hits, np.uint64, cap)
+                for b, w in enumerate(want):
+                    rows = np.flatnonzero(w)
+                    if len(rows) == 0:
+                        continue
+                    f = int(first[b])
+                    got = buf[f: f + len(rows)]
+                    assert [int(x) for x in got] == [(b << 32) | int(r) for r in rows], (nd, op, from_mask, b)
+                # the compaction: the same records, partition order, contiguous
+                scan.hits_compact(d_hits.value, d_n.value, cap, d_flat.value, cap, d_nflat.value)
+                N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+                nflat = int(scan._from_dev(d_nflat, np.uint64, 1)[0])
+                assert nflat == len(recs)
+                assert scan._from_dev(d_flat, np.uint64, nflat).tolist() == recs.tolist()
+                checked += 1
+            # the next conjunct on the partitioned list (same column, another pattern) == the oracle on the listed rows
+            e2 = lc.LiquidExpr.try_new("like", b"%ru%", pa.binary(), HINT)
+            w2 = _oracle_bits(lo, flat, "like", b"%ru%")
+            scan.filter_hits(e2, d_hits.value, d_n.value, cap, d_hits2.value, cap, d_n2.value, partitioned=True)
+            N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+            recs2, _ = _read_partitioned(scan, d_hits2, d_n2, cap)
+            surv = set(x for x in want_set if w2[x >> 32][x & 0xFFFFFFFF])
+            assert set(int(x) for x in recs2) == surv and len(recs2) == len(surv), (nd, op)
+            # the byte-view gather reads the partitions as one list: row i = record i of the partition order
+            if 0 < len(recs) <= 4000:
+                k = len(recs)
+                # (capacity_rows is the LIST's capacity — it fixes the partitions' places — and bounds the outputs as well)
+                cap_b = cap * 128 + (1 << 20)
+                d_views, d_valid, d_data, d_nb = scan._dev(cap * 16), scan._dev(cap), scan._dev(cap_b), scan._dev(8)
+                try:
+                    scan.gather_bytes_hits(d_hits.value, d_n.value, cap, d_views.value, d_data.value, cap_b, d_nb.value,
+                                           d_valid.value, slotted=True, partitioned=True)
+                    N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+                    views = scan._from_dev(d_views, np.uint8, k * 16).reshape(-1, 16)
+                    data = scan._from_dev(d_data, np.uint8, cap_b).tobytes()
+                    for i in range(0, k, max(1, k // 200)):
+                        b, r = int(recs[i]) >> 32, int(recs[i]) & 0xFFFFFFFF
+                        v = flat[b][0][r]
+                        ln = int(views[i, :4].view(np.int32)[0])
+                        assert ln == len(v), (i, ln, len(v))
+                        got = views[i, 4:4 + ln].tobytes() if ln <= 12 else data[int(views[i, 12:16].view(np.int32)[0]):][:ln]
+                        assert got == v, (nd, i)
+                finally:
+                    for p in (d_views, d_valid, d_data, d_nb):
+                        lib.lc_device_free(ctx, p)
+        assert checked == 14
+        for p in ptrs:
+            lib.lc_device_free(ctx, p)
+        scan.close()
+        # fixed width: hits of a predicate through the mask path, partitioned; the gather projects the same column
+        rng = np.random.default_rng(3)
+        vals = rng.integers(-10**6, 10**6, size=5 * 8192 - 77, dtype=np.int64)
+        iids = []
+        for b in range(5):
+            eid = lc.ParquetArrayID.new(49, 0, 1, b)
+            cache.insert(eid, pa.array(vals[b * 8192:(b + 1) * 8192]))
+            iids.append(eid)
+        s2 = cache.scan(iids)
+        gt = lc.LiquidExpr.try_new(">", 900000, pa.int64())
+        cap2 = int(s2.rows) * N.HITS_PARTITIONS
+        d_h, d_c = s2._dev(cap2 * 8), s2._dev(2048)
+        s2.eval_hits(gt, d_h.value, cap2, d_c.value, partitioned=True)
+        N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+        recs, ctrs = _read_partitioned(s2, d_h, d_c, cap2)
+        keep = np.flatnonzero(vals > 900000)
+        assert sorted((int(x) >> 32) * 8192 + (int(x) & 0xFFFFFFFF) for x in recs) == keep.tolist()
+        d_v = s2._dev(len(recs) * 8 + 64)
+        s2.gather_fixed_hits(d_h.value, d_c.value, cap2, d_v.value, partitioned=True)
+        N.check(lib.lc_stream_synchronize(ctx, None), ctx)
+        got = s2._from_dev(d_v, np.int64, len(recs))
+        assert got.tolist() == [int(vals[(int(x) >> 32) * 8192 + (int(x) & 0xFFFFFFFF)]) for x in recs]
+        for p in (d_h, d_c, d_v):
+            lib.lc_device_free(ctx, p)
+        s2.close()
+    finally:
+        cache.close()
