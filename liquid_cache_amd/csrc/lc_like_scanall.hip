@@ -46,6 +46,23 @@ constexpr uint32_t kSaPasses = kSaChunkWords / kWave;    // 8
 // surprise once the instructions are counted: the list of the words with an end, their second fetch and walk and a carry pass
 // that reads LDS instead of registers give back most of what the cheap walk saves (~660 against ~750 vector instructions per
 // 4 KB chunk).  Kept as an A/B option (profiles/r5/ablation_scanall_split.txt).
+// 2 (round 6, built, measured, NOT shipped): INERT WORDS ARE NOT WALKED.  The start state's row of the automaton image says for every code whether
+// it moves the automaton out of the start state; a word whose eight bytes all leave it there ends in the start state without
+// a hit whatever its value ends are — if it is ENTERED in the start state.  So every word is only CLASSIFIED (one look-up
+// per byte into ONE 512-byte row: two dwords per bank, next to conflict free, no dependency between the bytes, ~3 VALU per
+// byte against ~9 for the walk), the words with an interesting byte (25 % for '%google%' on URLs) are listed and walked in
+// dense passes with the full per-byte logic, and the words that are entered in another state than the start state come out of
+// the carry pass below and go through the correction worklist exactly as before (an inert word that is entered mid-match is
+// one of them).  The carry pass works on the passes' ballots in scalar registers; the attribution of matches to dictionary
+// values is skipped for a chunk without a hit.  Exact (the whole path-5 suite: 24 tests, every needle class).  Measured on the
+// 100 M-row URL column, hot / cold (profiles/r6/ab_scanall_inert.txt): '%google%' 587 / 578 us against 574 / 565 for mode 0,
+// '%mail%' 952 / 965 against 831 / 837, '%ru/%' 1,155 against 985, a needle whose first byte hardly occurs ('%zzzzqqq%': next
+// to every word inert) 544 / 534 against 562 / 549.  The counters say why: VALU wave-instructions per launch fall from
+// 2.90 x 10^8 to 2.25 x 10^8 (840 instead of 1,083 per 4 KB chunk) — but SALU ones double (6.4 -> 11.5 x 10^7: the ballots
+// and the 128-bit carry arithmetic), LDS instructions grow (4.05 -> 4.72 x 10^7) and with them LDS cycles (1.37 -> 1.59 x 10^8,
+// 40 % of them bank conflicts).  Even with NOTHING to walk the chunk costs ~800 instructions: classification 256, lists ~100,
+// the carry pass ~160, value ends ~50, addressing ~40, the two dense passes ~175.  The walk was never more than a third of this
+// kernel; what bounds it is the per-word bookkeeping of a lane-per-word formulation, whatever the words cost.
 #ifndef LC_SA_SPLIT
 #define LC_SA_SPLIT 0
 #endif
@@ -53,7 +70,7 @@ constexpr uint32_t kSaPasses = kSaChunkWords / kWave;    // 8
 #ifndef LC_SA_ABL
 #define LC_SA_ABL 0
 #endif
-constexpr uint32_t kSaIlp = LC_SA_ILP;                   // passes walked in lock step by a lane (independent lookup chains)
+[[maybe_unused]] constexpr uint32_t kSaIlp = LC_SA_ILP;  // passes walked in lock step by a lane (independent lookup chains)
 // per wave: [dictionary result bitmap (dres_bytes)][ends 512][hit8 512][out16 1024][in16 1024][list 2 x 1024][phase-C stage 512]
 // (the words of a chunk are NOT kept in LDS: 4 KB per wave cost two of five workgroups per CU — 12 instead of 20 waves — and
 // the few words the worklist re-walks come back from L2)
@@ -202,7 +219,113 @@ __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
             load_pair(v_next + uint32_t(lane), pf_start[0], pf_stop[0]);
             load_pair(v_next + uint32_t(kWave) + uint32_t(lane), pf_start[1], pf_stop[1]);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#if LC_SA_SPLIT
+#if LC_SA_SPLIT == 2
+            // ---- phase 1: classify.  interesting = some byte's transition out of the start state is not the start state
+            uint32_t n_b = 0;
+            uint16_t* list_bw = list_b;  // (free until the corrections; they start after the dense passes)
+#pragma unroll
+            for (uint32_t q = 0; q < kSaPasses; q++) {
+                const uint64_t ww = w[q];
+                uint32_t acc = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+                    const uint32_t code = (k < 4 ? uint32_t(ww) >> (8 * k) : uint32_t(ww >> 32) >> (8 * (k - 4))) & 0xFFu;
+                    acc |= lds_u16(row0 + 2u * code) ^ row0;
+                }
+                const uint32_t wi = q * kWave + uint32_t(lane);
+                const bool has = acc != 0;
+                const uint64_t bm = __ballot(has);
+                if (has) list_bw[n_b + lanes_below(bm)] = uint16_t(wi);
+                n_b += uint32_t(__popcll(bm));
+                out16[wi] = uint16_t(row0);  // (an inert word entered in the start state: start state out, no hit)
+                hit8[wi] = 0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // ---- phase 2: the interesting words, densely, two passes in lock step, from the start state with the full per-byte
+            // logic (value ends reset, matches recorded per end); their bytes come back by index (L1 / L2: just streamed)
+            uint32_t chunk_hit = 0;  // (lane-local OR of the hit flags written: is there anything to attribute?)
+            for (uint32_t b0 = 0; b0 < n_b; b0 += 2u * kWave) {
+                uint32_t st[2], hit[2], e8[2], wi2[2];
+                uint64_t ww2[2];
+                bool act[2];
+#pragma unroll
+                for (uint32_t u = 0; u < 2; u++) {
+                    const uint32_t j = b0 + u * kWave + uint32_t(lane);
+                    act[u] = j < n_b;
+                    wi2[u] = act[u] ? uint32_t(list_bw[j]) : 0u;
+                    ww2[u] = *reinterpret_cast<GlobalPtr<uint64_t>>(reinterpret_cast<uintptr_t>(fsst + min(c0 + 8u * wi2[u], last_word)));
+                    e8[u] = act[u] ? uint32_t(ends[wi2[u]]) : 0u;
+                    st[u] = row0;
+                    hit[u] = 0;
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) {
+#pragma unroll
+                    for (uint32_t u = 0; u < 2; u++) {
+                        const uint64_t ww = ww2[u];
+                        const uint32_t code = (k < 4 ? uint32_t(ww) >> (8 * k) : uint32_t(ww >> 32) >> (8 * (k - 4))) & 0xFFu;
+                        const uint32_t t = lds_u16(st[u] + 2u * code);
+                        const bool is_end = ((e8[u] >> k) & 1u) != 0;
+                        hit[u] |= (is_end && t == hitrow) ? (1u << k) : 0u;
+                        st[u] = is_end ? row0 : t;
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 2; u++) {
+                    if (act[u]) {
+                        out16[wi2[u]] = uint16_t(st[u]);
+                        hit8[wi2[u]] = uint8_t(hit[u]);
+                        chunk_hit |= hit[u];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // ---- phase 3: the carries of the matched state and the worklist, pass by pass in buffer order, on the passes' ballots.
+            // M: the word ends matched; P: it holds no value end (the matched state passes through it); O: it ends in a state
+            // that is neither the start nor the matched state (its successor has to be re-walked).  The carry of the matched
+            // state INTO word l is the carry chain of (M | P) + M; only lanes it reaches touch their word.
+            uint32_t n_list = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < kSaPasses; q++) {
+                const uint32_t wi = q * kWave + uint32_t(lane);
+                const uint32_t stq = uint32_t(out16[wi]);
+                const uint32_t e8q = uint32_t(ends[wi]);
+                const bool has_end = e8q != 0;
+                const uint64_t M = __ballot(stq == hitrow), P = __ballot(!has_end);
+                const uint64_t A = M | P;
+                const unsigned __int128 sum = (unsigned __int128)A + M + (carry == hitrow ? 1u : 0u);
+                const uint64_t im = uint64_t(sum) ^ A ^ M;  // bit l: carry INTO word l = "starts matched"
+                uint32_t st_new = stq;
+                if (im != 0) {  // (wave uniform: selective needles rarely get here)
+                    if ((im >> lane) & 1u) {
+                        if (has_end) {
+                            const uint32_t hq = uint32_t(hit8[wi]) | (1u << (uint32_t(__ffs(int(e8q))) - 1u));
+                            hit8[wi] = uint8_t(hq);
+                            chunk_hit |= hq;
+                        } else {
+                            st_new = hitrow;
+                            out16[wi] = uint16_t(hitrow);
+                        }
+                    }
+                }
+                // the end state of the word before: the start / matched state needs nothing (the carry chain covers "matched");
+                // anything else sends this word to the worklist with that state as its start state
+                const uint64_t O = __ballot(st_new != row0 && st_new != hitrow);  // (after the carry: a word the matched state
+                                                                                  // passed through ends matched, not odd)
+                const bool carry_odd = carry != row0 && carry != hitrow;
+                const uint64_t need_m = (O << 1) | (carry_odd ? 1ull : 0ull);
+                if (need_m != 0) {
+                    const uint32_t prev = lane_shift_up1(st_new, carry);
+                    const bool need = ((need_m >> lane) & 1u) != 0;
+                    if (need) {
+                        in16[wi] = uint16_t(prev);
+                        list_a[n_list + lanes_below(need_m)] = uint16_t(wi);
+                    }
+                    n_list += uint32_t(__popcll(need_m));
+                }
+                carry = read_lane(st_new, kWave - 1);
+            }
+#elif LC_SA_SPLIT
             // ---- round 5: the words of a chunk in TWO classes.  A value ends inside 18 % of the words (a URL is ~44 compressed
             // bytes); the per-byte work those words need — end test, match record, reset: ~9 VALU per byte — was paid by every
             // word, because every pass of 64 words holds some of them.  Now every word is walked WITHOUT looking at value ends
@@ -395,6 +518,9 @@ __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
                         if (e) {
                             const uint32_t h = (uint32_t(hit8[wi]) & ~(1u << fe)) | (s == hitrow ? (1u << fe) : 0u);
                             hit8[wi] = uint8_t(h);
+#if LC_SA_SPLIT == 2
+                            chunk_hit |= h;
+#endif
                         } else if (s != uint32_t(out16[wi])) {
                             out16[wi] = uint16_t(s);
                             if (wi + 1u < kSaChunkWords) {
@@ -418,7 +544,12 @@ __global__ __launch_bounds__(kThreads) void k_like_scanall(ScanAllArgs a) {
             carry = uint32_t(__builtin_amdgcn_readfirstlane(int(carry)));
             // ---- matches -> dictionary values: the r-th value end of the chunk is value va + r (+ 1 behind the empty value)
             uint32_t run = 0;
-            for (uint32_t q = 0; q < ((LC_SA_ABL & 2) ? 0u : kSaPasses); q++) {
+#if LC_SA_SPLIT == 2
+            const bool attribute = __ballot(chunk_hit != 0) != 0;  // (a chunk without a hit: nothing to attribute)
+#else
+            const bool attribute = true;
+#endif
+            for (uint32_t q = 0; q < (((LC_SA_ABL & 2) || !attribute) ? 0u : kSaPasses); q++) {
                 const uint32_t wi = q * kWave + uint32_t(lane);
                 const uint32_t e = ends[wi];
                 uint32_t h = hit8[wi];
