@@ -177,6 +177,30 @@ public:
         live_++;
         return {iterator(slots_[i].node), true};
     }
+    // visit(i, node of ids[i] or null) for i = 0 .. n - 1 in order, the slot of id i + 16 and the record of id i + 8 prefetched
+    // while id i is visited: the visitor finds its record in L1 / L2 (looked up first and copied afterwards, the 4.9 MB of
+    // 12,207 records had fallen back to L3 by the time they were copied — a cold lc_scan_create stayed at 1.3 ms).
+    // Returns false as soon as the visitor does.
+    template <typename F>
+    bool visit_many(const uint64_t* ids, size_t n, F&& visit) const {
+        constexpr size_t kAhead = 16, kNode = 8;
+        value_type* ring[kNode];
+        for (size_t i = 0; i < n + kAhead; i++) {
+            if (i < n) __builtin_prefetch(&slots_[home(ids[i])]);
+            if (i >= kAhead) {  // (the record probed kNode iterations ago)
+                if (!visit(i - kAhead, ring[(i - kAhead) % kNode])) return false;
+            }
+            if (i >= kNode && i - kNode < n) {
+                value_type* p = probe(ids[i - kNode]);
+                ring[(i - kNode) % kNode] = p;
+                if (p) {
+                    const char* c = reinterpret_cast<const char*>(p);
+                    for (size_t o = 0; o < sizeof(value_type); o += 64) __builtin_prefetch(c + o);
+                }
+            }
+        }
+        return true;
+    }
     // out[i] = the node of ids[i] or null, with the slots and nodes of the ids ahead prefetched
     void find_many(const uint64_t* ids, size_t n, value_type** out) const {
         constexpr size_t kAhead = 16, kNode = 8;

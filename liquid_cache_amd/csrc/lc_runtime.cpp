@@ -2530,24 +2530,26 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         // ONE critical section captures the entries and pins their slabs: between a capture under one lock and a pin
         // under another an lc_evict / re-stage could drain the slab and the scan would keep dangling device pointers.
         // The pins are taken after every entry has validated, so the error returns below leave nothing pinned.
-        std::vector<EntryMap::value_type*> found(n, nullptr);
         std::unique_lock<std::shared_mutex> g(ctx->mu);
         s->evict_epoch = ctx->evict_epoch.load();
-        ctx->entries.find_many(entry_ids, n, found.data());  // (slots and records of the ids ahead prefetched)
         uint32_t max_len = 0;
-        for (uint64_t i = 0; i < n; i++) {
-            EntryMap::iterator it(found[i]);
-            if (it == ctx->entries.end()) return fail(LC_NOT_STAGED, "entry is not staged");
-            s->meta.push_back(it->second);  // (one copy of the ~400-byte entry record, edited in place)
+        lc_status bad = LC_OK;
+        // (the slot of id i + 16 and the record of id i + 8 are prefetched while id i is copied: EntryMap::visit_many)
+        ctx->entries.visit_many(entry_ids, n, [&](size_t i, EntryMap::value_type* node) -> bool {
+            if (!node) { bad = fail(LC_NOT_STAGED, "entry is not staged"); return false; }
+            s->meta.push_back(node->second);  // (one copy of the ~400-byte entry record, edited in place)
             Entry& e = s->meta.back();
-            if (e.squeezed_field >= 0 && !allow_squeezed)
-                return fail(LC_NEEDS_BACKING, "entry is squeezed to one date component: predicates and plain reads need the "
-                                              "full array from the disk tier");
+            if (e.squeezed_field >= 0 && !allow_squeezed) {
+                bad = fail(LC_NEEDS_BACKING, "entry is squeezed to one date component: predicates and plain reads need the "
+                                             "full array from the disk tier");
+                return false;
+            }
             if (i == 0) {
                 s->is_str = e.is_str;
                 s->lane_log2 = e.is_str ? 4 : e.fd.lane_log2;
             } else if (e.is_str != s->is_str || (!e.is_str && e.fd.lane_log2 != s->lane_log2)) {
-                return fail(LC_ERR_INVALID, "a scan covers entries of ONE column (same encoding and lane width)");
+                bad = fail(LC_ERR_INVALID, "a scan covers entries of ONE column (same encoding and lane width)");
+                return false;
             }
             const uint64_t off = s->seg_offsets[i];
             if (e.is_str) e.sd.mask_word_off = off;
@@ -2571,7 +2573,9 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
                 s->any_patch |= (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) && e.fd.patch_len > 0;
                 s->any_float |= e.fd.kind == kKindF32 || e.fd.kind == kKindF64;
             }
-        }
+            return true;
+        });
+        if (bad != LC_OK) return bad;
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
         // pin the slabs of the scan's entries: evicting or re-staging an entry under a live scan is then safe (the scan
         // keeps the blob it captured; lc_scan_destroy drops the pins)

@@ -1,6 +1,7 @@
 // EntryMap (csrc/lc_internal.hpp) against std::unordered_map under a random stream of emplace / erase / find / find_many —
 // the table behind lc_ctx::entries.  Built and run by tests/test_host_logic.py (CPU tier).
 #include <cstdio>
+#include <cstdlib>
 #include <random>
 #include <unordered_map>
 
@@ -39,6 +40,15 @@ int main() {
             for (int k = 0; k < 5000; k++) ids.push_back(id_of(rng()));
             std::vector<lc::EntryMap::value_type*> out(ids.size());
             m.find_many(ids.data(), ids.size(), out.data());
+            size_t visited = 0;
+            const bool all = m.visit_many(ids.data(), ids.size(), [&](size_t k, lc::EntryMap::value_type* node) {
+                if (k != visited++ || node != out[k]) { std::printf("visit_many mismatch at %zu\n", k); std::exit(1); }
+                return true;
+            });
+            if (!all || visited != ids.size()) { std::printf("visit_many stopped early\n"); return 1; }
+            size_t stop_at = 0;
+            (void)m.visit_many(ids.data(), ids.size(), [&](size_t k, lc::EntryMap::value_type*) { stop_at = k; return k < 100; });
+            if (stop_at != 100) { std::printf("visit_many did not stop where told (%zu)\n", stop_at); return 1; }
             for (size_t k = 0; k < ids.size(); k++) {
                 const bool have_ref = ref.count(ids[k]) != 0;
                 if ((out[k] != nullptr) != have_ref || (out[k] && (out[k]->first != ids[k] || out[k]->second.len != ref[ids[k]]))) {
