@@ -463,7 +463,9 @@ LC_API uint64_t lc_scan_mask_words(const lc_scan* scan);  /* total u64 words of 
 LC_API uint64_t lc_scan_rows(const lc_scan* scan);
 LC_API uint64_t lc_scan_entries(const lc_scan* scan);
 /* What a scan holds.  index_bytes / unigram_index_bytes: the scan-level LIKE indexes built on this scan's first LIKE (first
- * 1-byte LIKE) — derived data outside the entries' blobs, 64 + 32 bytes per dictionary value; they count against the
+ * 1-byte LIKE) — derived data outside the entries' blobs, 64 + 32 bytes per dictionary value of a group of up to four entries,
+ * every group rounded up to whole 128-byte lines per slice (at least 1,024 values' worth: 64 KB + 32 KB per group — a scan of
+ * many small dictionaries pays up to 8x the per-value figure); they count against the
  * context's max_hbm_bytes when they are built (a scan whose index does not fit the budget evaluates with the entry-level
  * index instead), stay with the scan, and after lc_scan_destroy are kept (bounded, oldest first) for the next scan over the
  * same publications of the same entries.  ctx_index_bytes: all such indexes alive in the context, cached ones included. */

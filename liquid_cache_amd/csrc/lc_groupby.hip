@@ -18,6 +18,8 @@
 // than the table emits what it has and goes on — duplicate (entry, group) partials are still partials.
 #include <algorithm>
 #include <cstdio>
+#include <atomic>
+
 #include "lc_device.hpp"
 #include "lc_internal.hpp"
 
@@ -236,12 +238,16 @@ hipError_t launch_group_partials(const StrDesc* g_descs, const StrDesc* v_descs,
                                  unsigned long long* n_out, hipStream_t stream) {
     if (n_entries == 0) return hipSuccess;
     GroupArgs a{g_descs, v_descs, symtabs, selection, n_entries, want_max, out, capacity, n_out};
-    static int cus = 0;  // (queried once: hipGetDeviceProperties on every launch cost more host time than the launch)
+    // (queried once PER DEVICE: hipGetDeviceProperties on every launch cost more host time than the launch; an atomic per device
+    // slot, so that concurrent callers and contexts on different devices each get their own answer)
+    static std::atomic<int> cus_of[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    int cus = cus_of[dev].load(std::memory_order_relaxed);
     if (cus == 0) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-                  ? prop.multiProcessorCount : 256;
+        cus = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        cus_of[dev].store(cus, std::memory_order_relaxed);
     }
     const uint32_t wgs = std::min<uint32_t>((n_entries + kGroupWaves - 1u) / kGroupWaves, uint32_t(cus) * 5u);  // 5 x 32 KB of LDS per CU
     hipLaunchKernelGGL(k_group_partials, dim3(wgs), dim3(kGroupWaves * 64), 0, stream, a);

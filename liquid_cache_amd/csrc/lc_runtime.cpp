@@ -692,9 +692,12 @@ lc_status build_str(lc_ctx* ctx, const uint8_t* bytes, size_t len, uint64_t path
         if (it == ctx->symtab_slot.end())
             return fail(LC_ERR_NO_SYMTAB, "byte-view entry staged before lc_symtab_set for its path");
         slot = it->second;
-        // every code in the compressed bytes must exist in the table
-        const SymbolTable& st = *ctx->symtabs[slot];
-        host_st = ctx->symtabs[slot].get();  // unique_ptr targets are stable
+        host_st = ctx->symtabs[slot].get();  // unique_ptr targets are stable: the checks below run WITHOUT the lock (they are
+                                             // O(compressed bytes), and parallel staging threads used to queue on it)
+    }
+    {
+        const SymbolTable& st = *host_st;
+        // every code in the compressed bytes must exist in the table (bytes between the dictionary values included)
         for (uint32_t i = 0; i < v.fsst_len; i++) {
             const uint8_t c = v.fsst[i];
             if (c == kFsstEscape) { i++; continue; }
