@@ -313,6 +313,8 @@ struct lc_ctx {
     // through the size-class lists for ever and go back to the driver with their chunk (lc_ctx_destroy).
     std::vector<void*> pool_chunks, hpool_chunks;
     uint8_t *pool_chunk_cur = nullptr, *pool_chunk_end = nullptr, *hpool_chunk_cur = nullptr, *hpool_chunk_end = nullptr;
+    void* pool_chunk_spare = nullptr;    // the next device chunk, allocated ahead by the builder thread when the current one runs low
+    bool pool_spare_requested = false;  // (both under pool_mu)
     std::unordered_map<void*, size_t> pool_live;                // pointer -> size class (bytes)
     std::unordered_map<size_t, std::vector<void*>> pool_free;   // size class -> cached blocks
     // same for pinned host staging (pageable hipMemcpy runs at a fraction of the PCIe rate)
@@ -474,6 +476,7 @@ void builder_shutdown(lc_ctx* ctx);
 void like_pipeline_orphan(lc_ctx* ctx, LikePipeline* lp);
 void like_orphans_clear(lc_ctx* ctx);
 void plan_slots_destroy(lc_ctx* ctx);
+void plan_slots_prime(lc_ctx* ctx);  // lc_ctx_create (device contexts)
 std::string like_pipeline_explain(const lc_scan* s, const StrPredHost& sp);           // caller holds s->mu
 uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_counts, uint32_t sparse_flags = 0);  // caller holds s->mu
 // what the scan's pipeline holds (lc_scan_info_get); caller holds s->mu

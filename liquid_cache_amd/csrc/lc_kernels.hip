@@ -1117,6 +1117,246 @@ __global__ __launch_bounds__(kThreads) void k_fixed_chain(FixedChainArgs C, Scan
     if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, total_waves, wave_hits);
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_fixed_chain_lds: the same conjunction with the columns evaluated per PASS instead of per entry (round 6).
+//
+// k_fixed_chain takes an entry through its columns one after the other: per column four passes, each a dependent round trip
+// for 256 W bytes per wave, the next column's selection read back from the mask the last one stored.  The SQ counters put it
+// at ~60 % VALU issue with the memory pipe idle a third of the time (TPC-H Q6 over 600 M rows: 331 us of issue, 375 us of
+// bytes at the streaming rate, 521-541 us measured): too few bytes in flight per wave.  Here a pass of two 1024-row blocks
+// requests the packed words of ALL columns at once — global -> LDS DMA (no registers held while they fly, non-temporal), the
+// generic part of the kernel, which only needs W as a byte count — then every column's width-specific function (thread =
+// FastLanes lane, fields at compile-time positions: reg_steps32) reads its words out of LDS, and the columns' mask words
+// meet in registers: one selection / validity load, one store, one count per pass instead of one per column and pass, no
+// mask round trip through L2 between the columns.  Three times the bytes in flight per wave, a third of the round trips.
+// Columns on u32 or u64 lanes (the u64 lanes in the shape of u32 lanes, as load_stream64 does), W <= 16; everything else
+// stays with k_fixed_chain.  Results are identical by construction: final = selection & AND_k (valid_k & compare_k).
+// ------------------------------------------------------------------------------------------------
+// -DLC_X_CHAIN_LDS=1: the per-pass form of the chain (k_fixed_chain_lds).  Built, bit-identical (tests/test_gpu_round6.py::
+// test_chain_against_oracle passes with either kernel) and SLOWER — TPC-H Q6 over 600 M rows: 521 us with k_fixed_chain, 621 us
+// with one stage buffer per wave (16 waves per CU), 889 us double buffered (10 waves per CU); profiles/r6/ab_chain_lds.txt.  The
+// LDS a wave's stage takes is paid in waves per CU, and this VALU-heavy kernel needs the waves more than the bytes in flight.
+#ifndef LC_X_CHAIN_LDS
+#define LC_X_CHAIN_LDS 0
+#endif
+#if LC_X_CHAIN_LDS
+typedef const __attribute__((address_space(3))) uint32_t* LdsU32Ptr;
+
+// the thread's W dwords of one block pair of a column out of LDS (blocks 128 W bytes apart), then the 32 steps of the pass:
+// this lane's mask word of the pass (lanes 0..15: block A, 16..31: block B)
+template <typename U, int W, bool kTwoSided>
+__device__ __noinline__ uint64_t chain_pass_lds(uint32_t lds_v, uint32_t lo_t_v, uint32_t bound_t_v) {
+    static_assert(LaneTraits<U>::kBits == 32 || LaneTraits<U>::kBits == 64, "u32 / u64 lanes");
+    const uint32_t lds = uint32_t(__builtin_amdgcn_readfirstlane(int(lds_v)));
+    const uint32_t lo_t = uint32_t(__builtin_amdgcn_readfirstlane(int(lo_t_v)));
+    const uint32_t bound_t = uint32_t(__builtin_amdgcn_readfirstlane(int(bound_t_v)));
+    const uint32_t lane = uint32_t(lane_id()), half = lane >> 5, l = lane & 31u;
+    uint32_t w[W];
+    if constexpr (LaneTraits<U>::kBits == 32) {
+        // word k of FastLanes lane l at k * 128 + 4 l
+        const uint32_t a = lds + half * 128u * uint32_t(W) + 4u * l;
+#pragma unroll
+        for (int k = 0; k < W; k++) w[k] = *reinterpret_cast<LdsU32Ptr>(a + 128u * uint32_t(k));
+    } else {
+        // 16 lanes of 64 rows; thread (h, l16) owns rows 32 h .. of its lane: dwords h W + i (i < W) of the lane's W u64 words,
+        // dword m at (m >> 1) * 128 + (m & 1) * 4 + 8 l16.  Odd W = 2 q + 1 and h = 1: even i sit q * 128 + 4 further than for
+        // h = 0, odd i q * 128 + 124 — two base addresses, the rest is compile-time offsets.
+        const uint32_t h = l >> 4, l16 = l & 15u;
+        constexpr uint32_t q = uint32_t(W) >> 1, odd = uint32_t(W) & 1u;
+        const uint32_t base = lds + half * 128u * uint32_t(W) + 8u * l16;
+        const uint32_t base_e = base + h * (q * 128u + odd * 4u);
+        const uint32_t base_o = base + h * (q * 128u + odd * 124u);
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            const uint32_t off = (uint32_t(i) >> 1) * 128u + (uint32_t(i) & 1u) * 4u;
+            w[i] = *reinterpret_cast<LdsU32Ptr>(((i & 1) ? base_o : base_e) + off);
+        }
+    }
+    uint32_t X = 0, Y = 0;
+    reg_steps32<W, kTwoSided, 0, W>(std::make_integer_sequence<uint32_t, 32>{}, w, lo_t, bound_t, X, Y, 0u);
+    return uint64_t(X) | (uint64_t(Y) << 32);
+}
+template <typename U, int... WS>
+__device__ __forceinline__ uint64_t chain_pass_dispatch(std::integer_sequence<int, WS...>, uint32_t W, bool two_sided, uint32_t lds,
+                                                        uint32_t lo_t, uint32_t bound_t) {
+    uint64_t m = 0;
+    if (two_sided) ((int(W) == WS + 1 ? (void)(m = chain_pass_lds<U, WS + 1, true>(lds, lo_t, bound_t)) : (void)0), ...);
+    else ((int(W) == WS + 1 ? (void)(m = chain_pass_lds<U, WS + 1, false>(lds, lo_t, bound_t)) : (void)0), ...);
+    return m;
+}
+
+// what a pass needs to know about one column of the entry (wave uniform): kept in the wave's LDS table, so that the loops over
+// the columns are real loops (one set of call sites, no scalar registers held across them)
+struct alignas(16) ChainCol {
+    const uint8_t* packed;
+    const uint64_t* validity;
+    uint32_t W, lo_t, bound_t;
+    uint32_t bits;  // 0: u64 lanes, 1: two sided, 2: complement, 3: constant outcome, 4: its value, 5: all null
+};
+static_assert(sizeof(ChainCol) == 32, "ChainCol is read as two 16-byte LDS words");
+template <typename U>
+__device__ __forceinline__ ChainCol chain_col(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2, int lane) {
+    const PackedRange<U> pr = entry_range<U>(d, pred, pred2, lane);
+    const uint32_t W = max(uint32_t(d.W), 1u);
+    const uint32_t umax = W >= 32 ? ~0u : ((1u << W) - 1u);
+    const uint32_t lo = uint32_t(pr.lo), span = uint32_t(pr.span);
+    uint32_t a_lo, a_bound, flip, two = 0;
+    if (lo == 0) {                    // u <= span
+        a_lo = 0; a_bound = span; flip = pr.negate ? 1u : 0u;
+    } else if (lo + span == umax) {   // u >= lo  ==  not (u <= lo - 1)
+        a_lo = 0; a_bound = lo - 1u; flip = pr.negate ? 0u : 1u;
+    } else {
+        two = 1; a_lo = lo; a_bound = span; flip = pr.negate ? 1u : 0u;
+    }
+    const int constant = d.W == 0 ? 0 : pr.constant;
+    ChainCol c;
+    c.packed = d.packed;
+    c.validity = d.validity;
+    c.W = W;
+    c.lo_t = a_lo << (32u - W);
+    c.bound_t = (a_bound << (32u - W)) | (W == 32 ? 0u : ((1u << ((32u - W) & 31u)) - 1u));
+    c.bits = (sizeof(U) == 8 ? 1u : 0u) | (two << 1) | (flip << 2) | (constant >= 0 ? 8u : 0u) | (constant > 0 ? 16u : 0u) |
+             (d.W == 0 ? 32u : 0u);
+    return c;
+}
+typedef __attribute__((address_space(3))) u32x4* LdsV4MutPtr;
+typedef const __attribute__((address_space(3))) u32x4* LdsV4Ptr;
+__device__ __forceinline__ ChainCol chain_col_read(uint32_t table, uint32_t k) {
+    const u32x4 a = reinterpret_cast<LdsV4Ptr>(table + 32u * k)[0], b = reinterpret_cast<LdsV4Ptr>(table + 32u * k)[1];
+    auto u = [](uint32_t v) { return uint32_t(__builtin_amdgcn_readfirstlane(int(v))); };
+    ChainCol c;
+    c.packed = reinterpret_cast<const uint8_t*>(uintptr_t(uint64_t(u(a.x)) | (uint64_t(u(a.y)) << 32)));
+    c.validity = reinterpret_cast<const uint64_t*>(uintptr_t(uint64_t(u(a.z)) | (uint64_t(u(a.w)) << 32)));
+    c.W = u(b.x); c.lo_t = u(b.y); c.bound_t = u(b.z); c.bits = u(b.w);
+    return c;
+}
+
+struct ChainLdsLayout {
+    uint32_t col_off[kMaxChainSteps];  // byte offset of a column's two blocks inside one of a wave's two stage buffers
+    uint32_t buf_bytes;                // one stage buffer (a pass of every column)
+    uint32_t wave_bytes;               // table + two buffers
+};
+
+// kWB waves per workgroup: the stage is ~15 KB per wave for three columns, so the workgroup is kept small (LDS granularity)
+template <int kMaxW, int kWB>
+__global__ __launch_bounds__(kWave * kWB) void k_fixed_chain_lds(FixedChainArgs C, ScanLaunch L, ChainLdsLayout Y) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_chain_stage[];
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    uint8_t* mine = s_chain_stage + wave * Y.wave_bytes;
+    const uint32_t table = uint32_t(reinterpret_cast<uintptr_t>(mine));
+    uint8_t* stage = mine + 256;
+    const uint32_t stage_addr = table + 256u;
+    const uint32_t total_waves = gridDim.x * uint32_t(kWB);
+    const uint32_t n_steps = C.n_steps;
+    uint64_t wave_hits = 0;
+    for (uint32_t entry = blockIdx.x * uint32_t(kWB) + wave; entry < L.n_entries; entry += total_waves) {
+        uint32_t len = 0;
+        uint64_t word_off = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < uint32_t(kMaxChainSteps); k++) {  // unrolled: the steps are read from the kernel arguments
+            if (k >= n_steps) break;                                // with constant offsets (no private copy of C)
+            const FixedChainStep& sp = C.step[k];
+            const FixedDesc d = sp.descs[entry];
+            if (k == 0) {
+                len = d.len;
+                word_off = d.mask_word_off;  // the columns cover the same rows
+            }
+            ChainCol c;
+            if (sp.lane_log2 == 5) c = chain_col<uint32_t>(d, sp.pred, sp.pred2, lane);
+            else c = chain_col<uint64_t>(d, sp.pred, sp.pred2, lane);
+            if (lane == 0) {
+                u32x4 a, b;
+                const uint64_t pp = uint64_t(reinterpret_cast<uintptr_t>(c.packed)), pv = uint64_t(reinterpret_cast<uintptr_t>(c.validity));
+                a.x = uint32_t(pp); a.y = uint32_t(pp >> 32); a.z = uint32_t(pv); a.w = uint32_t(pv >> 32);
+                b.x = c.W; b.y = c.lo_t; b.z = c.bound_t; b.w = c.bits;
+                reinterpret_cast<LdsV4MutPtr>(table + 32u * k)[0] = a;
+                reinterpret_cast<LdsV4MutPtr>(table + 32u * k)[1] = b;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint64_t* sel = L.d_selection ? L.d_selection + word_off : nullptr;
+        uint64_t* hit = L.d_hit + word_off;
+        const uint32_t nwords = (len + 63u) >> 6, nblocks = (len + 1023u) >> 10, npass = (nblocks + 1u) >> 1;
+        // the requests of pass p: every column's packed words into stage buffer p & 1 (16 bytes per lane and instruction,
+        // non-temporal), and this lane's selection / validity words (lanes 0..31 own the pass's 32 mask words)
+        auto issue = [&](uint32_t p, uint64_t& act, uint64_t (&vw)[kMaxChainSteps]) {
+            const uint32_t widx = p * 32u + uint32_t(lane);
+            const bool own = uint32_t(lane) < 32u && widx < nwords;
+            const uint32_t wc = min(widx, nwords - 1u);  // every lane loads (no divergent region around the loads)
+            const uint32_t nb = min(2u, nblocks - 2u * p);
+            uint8_t* buf = stage + (p & 1u) * Y.buf_bytes;
+#pragma unroll 1
+            for (uint32_t k = 0; k < n_steps; k++) {
+                const ChainCol c = chain_col_read(table, k);
+                if (c.bits & (8u | 32u)) continue;  // constant outcome / all null: no packed data
+                const uint32_t nchunk = nb * 8u * c.W;  // 16-byte chunks
+                const uint8_t* src = c.packed + uint64_t(p) * 256u * c.W;
+                for (uint32_t c0 = 0; c0 < nchunk; c0 += 64u) {
+                    const uint32_t ch = c0 + uint32_t(lane);
+                    if (ch < nchunk) async_copy16_stream(src + uint64_t(ch) * 16u, buf + Y.col_off[k] + c0 * 16u);
+                }
+            }
+            act = ~uint64_t(0);
+            if (widx == nwords - 1u && (len & 63u)) act = (uint64_t(1) << (len & 63u)) - 1;
+            if (!own) act = 0;
+            if (sel) act &= as_global(sel)[wc];
+#pragma unroll
+            for (uint32_t k = 0; k < uint32_t(kMaxChainSteps); k++) {
+                vw[k] = ~uint64_t(0);
+                if (k >= n_steps) continue;
+                const uint64_t* v = reinterpret_cast<const uint64_t*>(uintptr_t(
+                    uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(reinterpret_cast<LdsU32Ptr>(table + 32u * k)[2])))) |
+                    (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(reinterpret_cast<LdsU32Ptr>(table + 32u * k)[3])))) << 32)));
+                if (v) vw[k] = as_global(v)[wc];
+            }
+        };
+        uint32_t count = 0;
+        uint64_t act_n = 0, vw_n[kMaxChainSteps];
+        if (npass) issue(0, act_n, vw_n);
+        for (uint32_t p = 0; p < npass; p++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // pass p has landed (DMA, selection and validity words)
+            __builtin_amdgcn_wave_barrier();
+            uint64_t act = act_n;
+#pragma unroll
+            for (uint32_t k = 0; k < uint32_t(kMaxChainSteps); k++) act &= vw_n[k];
+            // pass p + 1 flies while pass p is evaluated
+            if (p + 1u < npass) issue(p + 1u, act_n, vw_n);
+            __builtin_amdgcn_sched_barrier(0);
+            uint64_t result = act;
+            if (__ballot(act != 0) != 0) {  // (a pass without a selected valid row: nothing to evaluate)
+                const uint32_t buf_addr = stage_addr + (p & 1u) * Y.buf_bytes;
+#pragma unroll 1
+                for (uint32_t k = 0; k < n_steps; k++) {
+                    const ChainCol c = chain_col_read(table, k);
+                    if (c.bits & (8u | 32u)) {
+                        if (!(c.bits & 16u) || (c.bits & 32u)) result = 0;
+                        continue;
+                    }
+                    const uint32_t lds = buf_addr + Y.col_off[k];
+                    uint64_t m;
+                    if (c.bits & 1u) m = chain_pass_dispatch<uint64_t>(std::make_integer_sequence<int, kMaxW>{}, c.W, (c.bits & 2u) != 0, lds, c.lo_t, c.bound_t);
+                    else m = chain_pass_dispatch<uint32_t>(std::make_integer_sequence<int, kMaxW>{}, c.W, (c.bits & 2u) != 0, lds, c.lo_t, c.bound_t);
+                    if (c.bits & 4u) m = ~m;
+                    result &= m;
+                }
+            }
+            const uint32_t widx = p * 32u + uint32_t(lane);
+            if (uint32_t(lane) < 32u && widx < nwords) as_global_mut(hit)[widx] = result;
+            count += uint32_t(__popcll(result));
+        }
+        const uint64_t t = wave_sum_u64(uint64_t(count));
+        if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(t);
+        wave_hits += t;
+        // (the table is rewritten for the next entry: every read of it above has returned)
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * uint32_t(kWB) + wave, total_waves, wave_hits);
+}
+#endif  // LC_X_CHAIN_LDS
+
 // ALP exceptions: re-evaluate the rows whose value lives in the patch list (their packed slot holds a filler).
 // Runs after k_fixed_pred on the same stream; one wave per entry, one lane per patch.
 template <typename I>
@@ -5095,11 +5335,37 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
     return hipGetLastError();
 }
 
-hipError_t launch_fixed_chain(const FixedChainArgs& chain, uint32_t max_width, const ScanLaunch& L, hipStream_t stream) {
+hipError_t launch_fixed_chain(const FixedChainArgs& chain, uint32_t max_width, const uint32_t* col_max_w, const ScanLaunch& L,
+                              hipStream_t stream) {
     if (L.n_entries == 0 || chain.n_steps == 0) return hipSuccess;
     const uint64_t wgs_needed = (uint64_t(L.n_entries) + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint64_t wgs_resident = uint64_t(device_cus()) * 8;
     const dim3 grid(uint32_t(wgs_needed < wgs_resident ? wgs_needed : wgs_resident)), block(kThreads);
+#if LC_X_CHAIN_LDS
+    if (col_max_w && max_width <= 16) {
+        // every column on u32 / u64 lanes: the per-pass form (k_fixed_chain_lds); a wave's stage is a table of the entry's
+        // columns and two buffers, each holding two blocks of every column
+        constexpr int kWB = 2;
+        bool ok = true;
+        ChainLdsLayout Y{};
+        uint32_t off = 0;
+        for (uint32_t k = 0; k < chain.n_steps; k++) {
+            ok = ok && (chain.step[k].lane_log2 == 5 || chain.step[k].lane_log2 == 6);
+            Y.col_off[k] = off;
+            off += 256u * std::max(col_max_w[k], 1u);
+        }
+        Y.buf_bytes = off;
+        Y.wave_bytes = 256u + 2u * off;
+        const size_t lds = size_t(Y.wave_bytes) * kWB;
+        if (ok && lds <= 64u * 1024u) {
+            const uint64_t need = (uint64_t(L.n_entries) + kWB - 1) / kWB, cap = uint64_t(device_cus()) * 16;
+            hipLaunchKernelGGL((k_fixed_chain_lds<16, kWB>), dim3(uint32_t(need < cap ? need : cap)), dim3(kWave * kWB), lds, stream,
+                               chain, L, Y);
+            return hipGetLastError();
+        }
+    }
+#endif
+    (void)col_max_w;
     if (max_width <= 16) hipLaunchKernelGGL(k_fixed_chain<16>, grid, block, 0, stream, chain, L);
     else hipLaunchKernelGGL(k_fixed_chain<32>, grid, block, 0, stream, chain, L);
     return hipGetLastError();

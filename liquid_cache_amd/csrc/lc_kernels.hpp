@@ -327,7 +327,8 @@ hipError_t launch_fixed_sum_product(const FixedDesc* d_descs_a, const FixedDesc*
                                     void* d_partials, uint64_t* d_out, hipStream_t stream);
 hipError_t launch_fixed_agg(const FixedDesc* d_descs, int lane_log2, int is_signed, const ScanLaunch& L, void* d_partials,
                             uint64_t* d_out, hipStream_t stream);
-hipError_t launch_fixed_chain(const FixedChainArgs& chain, uint32_t max_width, const ScanLaunch& L, hipStream_t stream);
+hipError_t launch_fixed_chain(const FixedChainArgs& chain, uint32_t max_width, const uint32_t* col_max_w, const ScanLaunch& L,
+                              hipStream_t stream);
 hipError_t launch_fixed_gather(const FixedDesc* d_descs, int lane_log2, const ScanLaunch& L, uint32_t* d_block_counts,
                                uint64_t* d_block_offsets, uint64_t* d_entry_row_offsets, uint8_t* d_values_out,
                                uint64_t capacity_rows, hipStream_t stream);

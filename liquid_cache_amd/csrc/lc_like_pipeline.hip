@@ -107,8 +107,25 @@ struct LikePlan {
 };
 
 struct FlatGroup;
+// An index build asked for by an evaluation starts when that evaluation's kernels have run: the job waits for the gate, which
+// the asking call opens on its way out with an event recorded behind its launches (the 2 GB hipMalloc and the first waves of
+// k_flat_build used to land in the middle of the 40 us kernel that answers the scan's first LIKE: 180-320 us instead of 80).
+struct BuildGate {
+    std::atomic<int> open{0};
+    hipEvent_t ev = nullptr;
+};
+static void build_gate_pass(const std::shared_ptr<BuildGate>& g) {
+    if (!g) return;
+    while (!g->open.load(std::memory_order_acquire)) std::this_thread::yield();  // (microseconds: the asking call is on its way out)
+    if (g->ev) {
+        (void)hipEventSynchronize(g->ev);
+        (void)hipEventDestroy(g->ev);
+        g->ev = nullptr;
+    }
+}
 struct LikePipeline {
     bool built = false, eligible = false;
+    std::shared_ptr<BuildGate> gate;  // of the builds this evaluation submitted (opened by like_pipeline_eval before it returns)
     LeanRec* d_lean = nullptr;  // one record per workgroup
     uint32_t n_lean = 0;
     uint32_t* d_lean_begins = nullptr;  // first entry of every record (+ the end): k_lean_records builds the records from the
@@ -1778,24 +1795,31 @@ lc_status make_plan(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, const StrPredHost
 
 // Plans made on the fly (LikePlan::pending): what they hold while the figures are under way, and their settlement.
 constexpr uint32_t kPlanSlots = 256;
+// (caller holds ctx->plan_slots_mu) the arena: 4 MB of device and of pinned memory, once per context
+static void plan_slots_alloc_locked(lc_ctx* ctx) {
+    if (ctx->plan_slots_tried) return;
+    LC_PHASE("plan slots: first allocation");
+    ctx->plan_slots_tried = true;
+    void* d = pool_alloc(ctx, size_t(kPlanSlots) * kStatWords * 8);
+    void* h = d ? host_pool_alloc(ctx, size_t(kPlanSlots) * kStatWords * 8) : nullptr;
+    if (d && h) {
+        ctx->plan_slots_d = static_cast<unsigned long long*>(d);
+        ctx->plan_slots_h = static_cast<uint64_t*>(h);
+        ctx->plan_slot_ev.assign(kPlanSlots, nullptr);
+        for (uint32_t i = kPlanSlots; i-- > 0;) ctx->plan_slots_free.push_back(i);
+    } else if (d) {
+        pool_release(ctx, d);
+    }
+}
+// lc_ctx_create: the pinned half of the arena is a hipHostMalloc of its own (0.3-0.5 ms) — it was part of the first LIKE
+// evaluation of a context
+void plan_slots_prime(lc_ctx* ctx) {
+    std::lock_guard<std::mutex> g(ctx->plan_slots_mu);
+    plan_slots_alloc_locked(ctx);
+}
 static bool plan_slot_take(lc_ctx* ctx, LikePlan* q) {
     std::lock_guard<std::mutex> g(ctx->plan_slots_mu);
-    if (!ctx->plan_slots_tried) {
-        LC_PHASE("plan slots: first allocation");
-        ctx->plan_slots_tried = true;
-        void* d = nullptr;
-        void* h = nullptr;
-        if (hipMalloc(&d, size_t(kPlanSlots) * kStatWords * 8) == hipSuccess &&
-            hipHostMalloc(&h, size_t(kPlanSlots) * kStatWords * 8, hipHostMallocDefault) == hipSuccess) {
-            ctx->plan_slots_d = static_cast<unsigned long long*>(d);
-            ctx->plan_slots_h = static_cast<uint64_t*>(h);
-            ctx->plan_slot_ev.assign(kPlanSlots, nullptr);
-            for (uint32_t i = kPlanSlots; i-- > 0;) ctx->plan_slots_free.push_back(i);
-        } else {
-            (void)hipGetLastError();
-            if (d) (void)hipFree(d);
-        }
-    }
+    plan_slots_alloc_locked(ctx);
     if (ctx->plan_slots_free.empty()) return false;  // (every slot is under way: this needle gets a trial run instead)
     const uint32_t i = ctx->plan_slots_free.back();
     if (!ctx->plan_slot_ev[i] && hipEventCreateWithFlags(&ctx->plan_slot_ev[i], hipEventDisableTiming) != hipSuccess) {
@@ -1827,8 +1851,8 @@ void plan_slots_destroy(lc_ctx* ctx) {  // lc_ctx_destroy
     for (hipEvent_t e : ctx->plan_slot_ev)
         if (e) (void)hipEventDestroy(e);
     ctx->plan_slot_ev.clear();
-    if (ctx->plan_slots_d) (void)hipFree(ctx->plan_slots_d);
-    if (ctx->plan_slots_h) (void)hipHostFree(ctx->plan_slots_h);
+    if (ctx->plan_slots_d) pool_release(ctx, ctx->plan_slots_d);
+    if (ctx->plan_slots_h) host_pool_release(ctx, ctx->plan_slots_h);
     ctx->plan_slots_d = nullptr;
     ctx->plan_slots_h = nullptr;
     ctx->plan_slots_free.clear();
@@ -2143,7 +2167,10 @@ static lc_status want_flat_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipS
     LikePipeline* pend = new LikePipeline();
     lp->flat_pending = pend;
     lp->flat_state.store(1, std::memory_order_release);
-    lp->flat_job = builder_submit(ctx, [ctx, s, lp, pend, allow_evict](hipStream_t st) {
+    if (!lp->gate) lp->gate = std::make_shared<BuildGate>();
+    std::shared_ptr<BuildGate> gate = lp->gate;
+    lp->flat_job = builder_submit(ctx, [ctx, s, lp, pend, allow_evict, gate](hipStream_t st) {
+        build_gate_pass(gate);
         try {
             (void)build_flat(ctx, s, pend, st, allow_evict, true);
         } catch (...) {
@@ -2161,7 +2188,10 @@ static lc_status want_unigram_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, h
         return build_unigram(ctx, s, lp, stream, &lp->d_uni, &lp->uni_build_ms);
     }
     lp->uni_state.store(1, std::memory_order_release);
-    lp->uni_job = builder_submit(ctx, [ctx, s, lp](hipStream_t st) {
+    if (!lp->gate) lp->gate = std::make_shared<BuildGate>();
+    std::shared_ptr<BuildGate> gate = lp->gate;
+    lp->uni_job = builder_submit(ctx, [ctx, s, lp, gate](hipStream_t st) {
+        build_gate_pass(gate);
         uint64_t* u = nullptr;
         double ms = 0;
         try {
@@ -2176,8 +2206,31 @@ static lc_status want_unigram_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, h
 }
 
 // Caller holds s->mu and has built the automata of `sp` (sp.p.automata).  *handled = true: the evaluation was launched.
+static lc_status like_pipeline_eval_gated(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
+                                          bool* handled, bool* many_candidates);
 lc_status like_pipeline_eval(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
                              bool* handled, bool* many_candidates) {
+    struct OpenGate {  // whatever way the call leaves: a build it submitted may start once what it launched has run
+        lc_scan* s;
+        hipStream_t stream;
+        ~OpenGate() {
+            LikePipeline* lp = s->like;
+            if (!lp || !lp->gate) return;
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess && hipEventRecord(e, stream) == hipSuccess) {
+                lp->gate->ev = e;
+            } else {
+                (void)hipGetLastError();
+                if (e) (void)hipEventDestroy(e);
+            }
+            lp->gate->open.store(1, std::memory_order_release);
+            lp->gate.reset();
+        }
+    } open_gate{s, stream};
+    return like_pipeline_eval_gated(ctx, s, sp, L, stream, handled, many_candidates);
+}
+static lc_status like_pipeline_eval_gated(lc_ctx* ctx, lc_scan* s, const StrPredHost& sp, const ScanLaunch& L, hipStream_t stream,
+                                          bool* handled, bool* many_candidates) {
     *handled = false;
     *many_candidates = false;
     const StrPred& p = sp.p;

@@ -49,7 +49,7 @@ namespace lc {
 // ------------------------------------------------------------------ scratch pool
 constexpr size_t kPoolMinClass = 4096, kPoolMaxClass = size_t(64) << 20, kPoolKeepPerClass = 64;
 // blocks up to these classes are carved out of chunks (lc_ctx::pool_chunks); larger ones are allocations of their own
-constexpr size_t kChunkBytes = size_t(64) << 20, kChunkMaxClass = size_t(16) << 20;
+constexpr size_t kChunkBytes = size_t(128) << 20, kChunkMaxClass = size_t(16) << 20;
 constexpr size_t kHostChunkBytes = size_t(8) << 20, kHostChunkMaxClass = size_t(2) << 20;
 // pointers inside a chunk are never given back one by one
 static bool in_chunks(const std::vector<void*>& chunks, size_t chunk_bytes, const void* p) {
@@ -61,15 +61,35 @@ static bool in_chunks(const std::vector<void*>& chunks, size_t chunk_bytes, cons
 static void* carve_device(lc_ctx* ctx, size_t cls) {
     if (cls > kChunkMaxClass) return nullptr;
     if (!ctx->pool_chunk_cur || size_t(ctx->pool_chunk_end - ctx->pool_chunk_cur) < cls) {
-        void* c = nullptr;
-        LC_PHASE("pool: new device chunk");
-        if (hipMalloc(&c, kChunkBytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        void* c = ctx->pool_chunk_spare;  // allocated ahead, off every query's path
+        ctx->pool_chunk_spare = nullptr;
+        if (!c) {
+            LC_PHASE("pool: new device chunk");
+            if (hipMalloc(&c, kChunkBytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
         ctx->pool_chunks.push_back(c);
         ctx->pool_chunk_cur = static_cast<uint8_t*>(c);
         ctx->pool_chunk_end = ctx->pool_chunk_cur + kChunkBytes;
     }
     void* p = ctx->pool_chunk_cur;
     ctx->pool_chunk_cur += cls;
+    // The chunk after this one is allocated by the builder thread as soon as a quarter of this one is left: a hipMalloc takes
+    // 0.35 ms, and the allocation that crossed a chunk boundary used to be the records of a scan's first LIKE (0.09 -> 0.44 ms).
+    if (size_t(ctx->pool_chunk_end - ctx->pool_chunk_cur) < kChunkBytes / 4 && !ctx->pool_chunk_spare && !ctx->pool_spare_requested &&
+        ctx->device >= 0) {
+        ctx->pool_spare_requested = true;
+        try {
+            (void)builder_submit(ctx, [ctx](hipStream_t) {
+                void* c = nullptr;
+                if (hipMalloc(&c, kChunkBytes) != hipSuccess) { (void)hipGetLastError(); c = nullptr; }
+                std::lock_guard<std::mutex> g(ctx->pool_mu);
+                ctx->pool_chunk_spare = c;
+                ctx->pool_spare_requested = false;
+            });
+        } catch (...) {
+            ctx->pool_spare_requested = false;
+        }
+    }
     return p;
 }
 static void* carve_host(lc_ctx* ctx, size_t cls) {
@@ -324,6 +344,8 @@ void pool_destroy(lc_ctx* ctx) {
     for (auto& kv : ctx->hpool_live)
         if (!in_chunks(ctx->hpool_chunks, kHostChunkBytes, kv.first)) (void)hipHostFree(kv.first);
     for (void* c : ctx->pool_chunks) (void)hipFree(c);
+    if (ctx->pool_chunk_spare) (void)hipFree(ctx->pool_chunk_spare);
+    ctx->pool_chunk_spare = nullptr;
     for (void* c : ctx->hpool_chunks) (void)hipHostFree(c);
     ctx->pool_chunks.clear();
     ctx->hpool_chunks.clear();
@@ -1043,6 +1065,7 @@ lc_status lc_ctx_create(const int32_t* device_ids, int32_t n_devices, uint64_t m
     // do not return — a first query that started the builder lazily waited 6.3 ms for its 40 us kernel
     (void)builder_submit(ctx.get(), [](hipStream_t) {});
     pool_prime(ctx.get());
+    plan_slots_prime(ctx.get());
     *out = ctx.release();
     return LC_OK;
     });
@@ -3441,6 +3464,7 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
             if (run >= 2) {
                 FixedChainArgs chain{};
                 uint32_t max_w = 1;
+                uint32_t col_w[kMaxChainSteps] = {};
                 for (uint32_t j = 0; j < run; j++) {
                     const lc_filter_step& cj = steps[k + j];
                     lc_scan* s = cj.scans[0];
@@ -3456,6 +3480,7 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
                         if (rc != LC_OK) return rc;
                     }
                     max_w = std::max(max_w, s->max_w);
+                    col_w[j] = s->max_w;
                     // the chain kernel reads the descriptors and blobs of EVERY step's scan on `st`: each scan must drain that
                     // stream before its descriptors are recycled (lc_scan_destroy no longer synchronises the device)
                     scan_note_stream(s, st);
@@ -3480,7 +3505,7 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
                     L.d_total_acc = s_last->d_total_acc;
                     L.d_total_out = static_cast<uint64_t*>(d_total_out);
                 }
-                LC_HIP(launch_fixed_chain(chain, max_w, L, st));
+                LC_HIP(launch_fixed_chain(chain, max_w, col_w, L, st));
                 sel = out;
                 k += run - 1;
                 continue;

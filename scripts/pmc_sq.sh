@@ -13,7 +13,7 @@ G[3]="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 G[4]="SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_SALU"
 G[5]="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA"
 for i in ${GROUPS_SEL:-1 2 3 4 5}; do
-  timeout 240 rocprofv3 --pmc ${G[$i]} --kernel-trace --kernel-include-regex "k_str_pred|k_fixed_pred|k_like" --output-format csv -d $O/g$i -- $B "$@" > $O/g$i.log 2>&1
+  timeout 240 rocprofv3 --pmc ${G[$i]} --kernel-trace --kernel-include-regex "k_str_pred|k_fixed_pred|k_fixed_chain|k_like" --output-format csv -d $O/g$i -- $B "$@" > $O/g$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections

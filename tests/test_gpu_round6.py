@@ -455,3 +455,134 @@ def test_partitioned_hit_lists_against_oracle(product_lib, oracle, grouped_cases
         s2.close()
     finally:
         cache.close()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# lc_scan_eval_filter chains: a conjunction over several fixed-width columns in one launch
+# ------------------------------------------------------------------------------------------------------------------
+def _chain_column(rng, kind, n, W, null_frac, all_null):
+    """(arrow array, numpy values, validity) of one entry: values span exactly W bits above a random base."""
+    span = (1 << W) - 1
+    if kind == "date32":
+        base = int(rng.integers(0, 20000))
+        vals = (base + rng.integers(0, span + 1, size=n)).astype(np.int32)
+        vals[0], vals[-1] = base, base + span
+        dtype = pa.date32()
+    elif kind == "int32":
+        base = int(rng.integers(-100000, 100000))
+        vals = (base + rng.integers(0, span + 1, size=n)).astype(np.int32)
+        vals[0], vals[-1] = base, base + span
+        dtype = pa.int32()
+    else:
+        base = int(rng.integers(-(1 << 40), 1 << 40))
+        vals = (base + rng.integers(0, span + 1, size=n)).astype(np.int64)
+        vals[0], vals[-1] = base, base + span
+        dtype = pa.int64()
+    valid = np.ones(n, bool)
+    if all_null:
+        valid[:] = False
+    elif null_frac > 0:
+        valid = rng.random(n) >= null_frac
+        valid[0] = valid[-1] = True  # (the extremes keep the entry's width at W)
+    arr = pa.array(vals, type=dtype, mask=~valid) if not valid.all() else pa.array(vals, type=dtype)
+    return arr, vals, valid, base, dtype
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_chain_against_oracle(gpu_cache, oracle, seed):
+    """lc_scan_eval_filter over 2-4 columns on u32 / u64 lanes (k_fixed_chain, or k_fixed_chain_lds in a -DLC_X_CHAIN_LDS=1 build): every width 1..16, entries of ragged
+    lengths (1 row, one block, an odd number of blocks, tails), nulls, an all-null entry, literals outside an entry's range
+    (constant outcomes), fused range pairs, Ne, with and without a selection in front — final mask, per-entry counts and the
+    fused COUNT(*) against the oracle's evaluation of the same Liquid bytes, conjunct by conjunct."""
+    import ctypes as C
+    from liquid_cache_amd.pushdown import CompiledFilter
+    lo = oracle
+    rng = np.random.default_rng(1000 + seed)
+    lens = [8192, 1, 1024, 1025, 3000, 2048 + 70, 5000, 8192, 64, 4097]
+    kinds = [["date32", "int64", "int64"], ["int32", "int64"], ["int64", "date32", "int32", "int64"]][seed - 1]
+    n_cols = len(kinds)
+    widths = [[int(rng.integers(1, 17)) for _ in lens] for _ in range(n_cols)]
+    for c in range(n_cols):  # every width somewhere
+        for k in range(len(lens)):
+            widths[c][k] = 1 + (k * 5 + c * 7 + seed * 3) % 16
+    ids, liquids, info = [], [], []
+    for c, kind in enumerate(kinds):
+        ids.append([])
+        liquids.append([])
+        info.append([])
+        for k, n in enumerate(lens):
+            all_null = (c == 1 and k == 4)
+            arr, vals, valid, base, dtype = _chain_column(rng, kind, n, widths[c][k], 0.2 if (k + c) % 3 == 0 else 0.0, all_null)
+            eid = lc.ParquetArrayID.new(60 + seed, 0, c, k)
+            gpu_cache.insert(eid, arr)
+            ids[c].append(eid)
+            liquids[c].append(gpu_cache.transcode(arr))
+            info[c].append((base, widths[c][k], dtype))
+    scans = [gpu_cache.scan(ids[c]) for c in range(n_cols)]
+    E = lc.LiquidExpr.try_new
+    import datetime
+
+    def lit(c, v):
+        dtype = info[c][0][2]
+        return datetime.date(1970, 1, 1) + datetime.timedelta(days=int(v)) if dtype == pa.date32() else int(v)
+
+    for variant in range(4):
+        # per column: one predicate or a fused pair; literals around the middle of SOME entry's range, so that other entries
+        # see them outside theirs (constant outcomes)
+        steps, oracle_steps = [], []
+        for c in range(n_cols):
+            base, W, dtype = info[c][(variant * 3 + c) % len(lens)]
+            mid = base + (1 << W) // 2
+            if (variant + c) % 3 == 0:
+                ops = [("ge", mid - (1 << W) // 4), ("lt", mid + (1 << W) // 4 + 1)]
+            elif (variant + c) % 3 == 1:
+                ops = [(["lt", "le", "gt", "ge"][(variant + c) % 4], mid)]
+            else:
+                ops = [(["eq", "ne"][(variant + c) % 2], mid)]
+            exprs = [E(o, lit(c, v), dtype) for o, v in ops]
+            assert all(e is not None for e in exprs)
+            steps.append((scans[c], exprs))
+            oracle_steps.append((c, ops))
+        cf = CompiledFilter.from_conjunction(steps)
+        for with_sel in (False, True):
+            words = int(scans[0].mask_words)
+            sel = None
+            if with_sel:
+                sel_bits = [rng.random(n) < (0.0 if k == 2 else 0.3) for k, n in enumerate(lens)]
+                sel_bits[5][:2048] = False  # a whole pass without a selected row
+                sel = np.zeros(words, np.uint64)
+                for k, n in enumerate(lens):
+                    w0 = int(scans[0].segment_offsets[k])
+                    packed = np.packbits(sel_bits[k], bitorder="little")
+                    sel[w0: w0 + (n + 63) // 64] = np.frombuffer(packed.tobytes() + b"\0" * (-len(packed) % 8), np.uint64)
+            lib, ctx = scans[0]._lib, gpu_cache.handle
+            bufs = [C.c_void_p() for _ in range(5)]
+            for b, nbytes in zip(bufs, [words * 8, words * 8, len(lens) * 4, 8, words * 8]):
+                N.check(lib.lc_device_alloc(ctx, max(nbytes, 8), C.byref(b)), ctx)
+            if sel is not None:
+                N.check(lib.lc_host_to_device(ctx, bufs[4], sel.ctypes.data_as(C.c_void_p), sel.size * 8, None), ctx)
+            final = cf.run(bufs[0].value, bufs[1].value, bufs[2].value, bufs[4].value if sel is not None else 0, bufs[3].value)
+            mask = np.zeros(words, np.uint64)
+            counts = np.zeros(len(lens), np.uint32)
+            total = np.zeros(1, np.uint64)
+            N.check(lib.lc_device_to_host(ctx, mask.ctypes.data_as(C.c_void_p), C.c_void_p(final), words * 8, None), ctx)
+            N.check(lib.lc_device_to_host(ctx, counts.ctypes.data_as(C.c_void_p), bufs[2], counts.size * 4, None), ctx)
+            N.check(lib.lc_device_to_host(ctx, total.ctypes.data_as(C.c_void_p), bufs[3], 8, None), ctx)
+            for b in bufs:
+                lib.lc_device_free(ctx, b)
+            want_total = 0
+            for k, n in enumerate(lens):
+                w = None if sel is None else sel_bits[k]
+                for c, ops in oracle_steps:
+                    for o, v in ops:
+                        r = lo.eval_predicate(liquids[c][k], lo.OP_NAMES[o], int(v), None)
+                        hit = r.values if r.validity is None else (r.values & r.validity)
+                        w = hit if w is None else (w & hit)
+                w0 = int(scans[0].segment_offsets[k])
+                got = np.unpackbits(mask[w0: w0 + (n + 63) // 64].view(np.uint8), bitorder="little")[:n].astype(bool)
+                assert np.array_equal(got, w), (seed, variant, with_sel, k, widths)
+                assert int(counts[k]) == int(w.sum()), (seed, variant, with_sel, k)
+                want_total += int(w.sum())
+            assert int(total[0]) == want_total
+    for s in scans:
+        s.close()
