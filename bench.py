@@ -30,7 +30,20 @@ import json
 import os
 import sys
 import time
-from concurrent.futures import ThreadPoolExecutor
+from concurrent.futures import ThreadPoolExecutor as _ThreadPoolExecutor
+
+_THREAD_DEVICE = [None]  # the rank's device (set in main): HIP's current device is per thread and defaults to device 0
+
+
+def _bind_thread():
+    """Worker threads of a rank work on the rank's device (torch.cuda.set_device is per thread)."""
+    if _THREAD_DEVICE[0] is not None:
+        import torch
+        torch.cuda.set_device(_THREAD_DEVICE[0])
+
+
+def ThreadPoolExecutor(max_workers=None):  # noqa: N802 — the stdlib's, with every worker bound to the rank's device
+    return _ThreadPoolExecutor(max_workers=max_workers, initializer=_bind_thread)
 
 import numpy as np
 
@@ -1076,6 +1089,7 @@ def make_abi_communicator(cache, N, Communicator, rank, world, torch, dist, dry_
 
         def probe():
             try:
+                _bind_thread()  # (a new thread starts on device 0)
                 side = torch.cuda.Stream()
                 with torch.cuda.stream(side):
                     t = torch.full((), rank + 1, dtype=torch.int64, device="cuda")
@@ -1903,6 +1917,7 @@ def main():
     if test_backend:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    _THREAD_DEVICE[0] = local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if test_backend:

@@ -46,6 +46,14 @@ void scan_note_stream(lc_scan* s, hipStream_t stream) {
 
 namespace lc {
 
+// The calling thread works on the context's device from here on.  HIP's current device is per THREAD and defaults to device 0:
+// a host that runs one context per GPU and calls from worker threads (the reference's tokio workers) would otherwise launch
+// rank k's scans on device 0.  (A no-op for the device the thread is on already; null / host-only contexts are the callee's
+// business.)
+static inline void bind_device(const lc_ctx* ctx) {
+    if (ctx && ctx->device >= 0) (void)hipSetDevice(ctx->device);
+}
+
 // ------------------------------------------------------------------ scratch pool
 constexpr size_t kPoolMinClass = 4096, kPoolMaxClass = size_t(64) << 20, kPoolKeepPerClass = 64;
 // blocks up to these classes are carved out of chunks (lc_ctx::pool_chunks); larger ones are allocations of their own
@@ -2878,6 +2886,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
                                 hipStream_t stream, const lc_predicate* pred2 = nullptr, void* d_total_out = nullptr,
                                 bool tolerate_backing = false, const HitsOut* hits = nullptr) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     LC_PHASE("scan_eval_impl");
     if (!ctx || !s || !pred) return fail(LC_ERR_INVALID, "null argument");
     // d_mask_out == NULL: the caller consumes COUNT(*), per-entry counts or the hit list and wants no mask
@@ -3213,6 +3222,7 @@ lc_status lc_scan_eval_count_groups(lc_ctx* ctx, lc_scan* scan, const lc_predica
                                     void* d_group_counts_out, void* d_mask_out, void* d_counts_out, void* d_total_out,
                                     void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !preds || n_preds == 0 || n_preds > 2) return fail(LC_ERR_INVALID, "lc_scan_eval_count_groups takes one or two predicates");
     if (!d_group_counts_out || (n_groups && !group_ends)) return fail(LC_ERR_INVALID, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -3269,6 +3279,7 @@ lc_status lc_scan_eval_count_groups(lc_ctx* ctx, lc_scan* scan, const lc_predica
 
 lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_out, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !d_out) return fail(LC_ERR_INVALID, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (scan->n == 0) {
@@ -3302,6 +3313,7 @@ lc_status lc_scan_aggregate(lc_ctx* ctx, lc_scan* scan, const void* d_selection,
 lc_status lc_scan_group_partials(lc_ctx* ctx, lc_scan* group_scan, lc_scan* value_scan, int32_t want_max, const void* d_selection,
                                  void* d_partials, uint64_t capacity, void* d_n_partials, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !group_scan || !d_n_partials || (capacity && !d_partials)) return fail(LC_ERR_INVALID, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     LC_HIP(hipMemsetAsync(d_n_partials, 0, 8, st));
@@ -3327,6 +3339,7 @@ lc_status lc_scan_group_partials(lc_ctx* ctx, lc_scan* group_scan, lc_scan* valu
 lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, const void* d_selection, void* d_out,
                               void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan_a || !scan_b || !d_out) return fail(LC_ERR_INVALID, "null argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
     // entry LENGTHS, not word counts: entries of 60 and 64 rows share a mask layout but not a tail mask
@@ -3373,6 +3386,7 @@ lc_status lc_scan_sum_product(lc_ctx* ctx, lc_scan* scan_a, lc_scan* scan_b, con
 static lc_status scan_eval_or_impl(lc_ctx* ctx, uint32_t n, lc_scan* const* scans, const lc_predicate* preds,
                                    const void* d_selection, void* d_mask_out, void* d_valid_out, void* d_counts_out,
                                    hipStream_t stream) {
+    bind_device(ctx);
     if (!ctx || !scans || !preds || !d_mask_out || n == 0) return fail(LC_ERR_INVALID, "null argument");
     lc_scan* s0 = scans[0];
     if (!s0) return fail(LC_ERR_INVALID, "null scan");
@@ -3428,6 +3442,7 @@ lc_status lc_scan_eval_filter(lc_ctx* ctx, uint32_t n_steps, const lc_filter_ste
                               void* d_mask_a, void* d_mask_b, void* d_counts_out, void* d_total_out, void** d_final_mask,
                               void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || (n_steps && !steps) || !d_mask_a || !d_mask_b || d_mask_a == d_mask_b)
         return fail(LC_ERR_INVALID, "null argument (two distinct mask buffers are needed)");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -3561,6 +3576,7 @@ static bool fixed_entry_is_constant(const Entry& e, const FixedPred& fp) {
 lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t with_selection, uint64_t* out_algorithmic,
                                 uint64_t* out_kernel_bytes) {
     return guarded([&]() -> lc_status {
+    if (s) bind_device(s->ctx);
     if (!s || !pred || !out_algorithmic || !out_kernel_bytes) return fail(LC_ERR_INVALID, "null argument");
     *out_algorithmic = *out_kernel_bytes = 0;
     uint64_t alg = 0, own = 0;
@@ -3680,6 +3696,7 @@ lc_status lc_scan_traffic_model(lc_scan* s, const lc_predicate* pred, int32_t wi
 
 lc_status lc_scan_explain(lc_scan* s, const lc_predicate* pred, char* out, size_t cap) {
     return guarded([&]() -> lc_status {
+    if (s) bind_device(s->ctx);
     if (!s || !pred || !out || cap == 0) return fail(LC_ERR_INVALID, "null argument");
     std::string text;
     if (!s->is_str) {
@@ -4413,6 +4430,7 @@ static lc_status get_with_selection_impl(lc_ctx* ctx, uint64_t entry_id, const u
 lc_status lc_scan_gather_fixed(lc_ctx* ctx, lc_scan* scan, const void* d_selection, void* d_values_out,
                                uint64_t values_capacity_bytes, void* d_row_offsets, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !d_values_out || !d_row_offsets) return fail(LC_ERR_INVALID, "null argument");
     if (scan->is_str) return fail(LC_UNSUPPORTED, "scan-wide gather covers fixed-width columns");
     if (scan->n == 0) return LC_OK;
@@ -4456,6 +4474,7 @@ lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const void* d_se
                                     void* d_row_refs, void* d_value_offsets, void* d_row_valid, uint64_t capacity_rows,
                                     uint64_t* out_rows, uint64_t* out_bytes, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !d_row_offsets || !d_row_refs || !d_value_offsets || !out_rows || !out_bytes)
         return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
@@ -4509,6 +4528,7 @@ lc_status lc_scan_gather_bytes_plan(lc_ctx* ctx, lc_scan* scan, const void* d_se
 lc_status lc_scan_gather_bytes(lc_ctx* ctx, lc_scan* scan, const void* d_row_refs, const void* d_value_offsets,
                                uint64_t rows, void* d_data, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || (rows && (!d_row_refs || !d_value_offsets || !d_data))) return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
     scan_note_stream(scan, static_cast<hipStream_t>(stream));
@@ -4523,6 +4543,7 @@ lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_s
                                      void* d_row_refs, void* d_value_offsets, void* d_row_valid, uint64_t capacity_rows,
                                      void* d_data, uint64_t capacity_bytes, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !d_row_offsets || !d_row_refs || !d_value_offsets || !d_data || capacity_rows == 0)
         return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes covers byte-view columns");
@@ -4566,6 +4587,7 @@ lc_status lc_scan_gather_bytes_async(lc_ctx* ctx, lc_scan* scan, const void* d_s
 lc_status lc_scan_eval_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* preds, uint32_t n_preds, const void* d_selection,
                             void* d_hits_out, uint64_t capacity, void* d_n_hits, void* d_hit_first, void* d_counts_out,
                             void* d_total_out, uint32_t flags, void* stream) {
+    bind_device(ctx);
     if (!preds || n_preds == 0 || n_preds > 2) return fail(LC_ERR_INVALID, "lc_scan_eval_hits takes one or two predicates");
     if (!d_hits_out || !d_n_hits) return fail(LC_ERR_INVALID, "d_hits_out / d_n_hits is null");
     HitsOut h;
@@ -4583,6 +4605,7 @@ lc_status lc_scan_eval_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pred
 lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, void* d_hits_out, uint64_t capacity,
                                void* d_n_hits, void* d_hit_first, uint32_t flags, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !d_mask || !d_hits_out || !d_n_hits) return fail(LC_ERR_INVALID, "null argument");
     const bool parts = (flags & LC_HITS_PARTITIONED) != 0;
     if (parts && capacity < LC_HITS_PARTITIONS) return fail(LC_ERR_INVALID, "a partitioned list needs a capacity of at least LC_HITS_PARTITIONS records");
@@ -4600,6 +4623,7 @@ lc_status lc_scan_mask_to_hits(lc_ctx* ctx, lc_scan* scan, const void* d_mask, v
 lc_status lc_hits_compact(lc_ctx* ctx, const void* d_hits, const void* d_n_hits, uint64_t capacity, void* d_hits_out,
                           uint64_t capacity_out, void* d_n_hits_out, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !d_hits || !d_n_hits || !d_hits_out || !d_n_hits_out) return fail(LC_ERR_INVALID, "null argument");
     if (d_hits == d_hits_out) return fail(LC_ERR_INVALID, "lc_hits_compact does not compact in place");
     if (capacity < LC_HITS_PARTITIONS) return fail(LC_ERR_INVALID, "a partitioned list has a capacity of at least LC_HITS_PARTITIONS records");
@@ -4616,6 +4640,7 @@ lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
                               uint64_t capacity_in, void* d_hits_out, uint64_t capacity_out, void* d_n_hits_out, uint32_t flags,
                               void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !pred || !d_hits_in || !d_n_hits_in || !d_hits_out || !d_n_hits_out) return fail(LC_ERR_INVALID, "null argument");
     if (d_hits_in == d_hits_out) return fail(LC_ERR_INVALID, "lc_scan_filter_hits does not filter in place");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -4695,6 +4720,7 @@ lc_status lc_scan_filter_hits(lc_ctx* ctx, lc_scan* scan, const lc_predicate* pr
 lc_status lc_scan_gather_fixed_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hits, const void* d_n_hits, uint64_t capacity_rows,
                                     void* d_values_out, void* d_row_valid, uint32_t flags, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !d_hits || !d_n_hits || !d_values_out) return fail(LC_ERR_INVALID, "null argument");
     if (scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_fixed_hits covers fixed-width columns (byte views: lc_scan_gather_bytes_hits)");
     if (scan->has_clamped || scan->has_fquant)
@@ -4714,6 +4740,7 @@ lc_status lc_scan_gather_bytes_hits(lc_ctx* ctx, lc_scan* scan, const void* d_hi
                                     void* d_views, void* d_row_valid, void* d_data, uint64_t capacity_bytes, void* d_n_bytes,
                                     uint32_t flags, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !d_hits || !d_n_hits || !d_views || !d_n_bytes || (capacity_bytes && !d_data))
         return fail(LC_ERR_INVALID, "null argument");
     if (!scan->is_str) return fail(LC_UNSUPPORTED, "lc_scan_gather_bytes_hits covers byte-view columns");
@@ -5087,6 +5114,7 @@ lc_status lc_squeeze_quantize(lc_ctx* ctx, uint64_t n, const uint64_t* entry_ids
 
 lc_status lc_scan_date_part(lc_ctx* ctx, lc_scan* scan, void* d_values, uint64_t n_values, int32_t field, void* stream) {
     return guarded([&]() -> lc_status {
+    bind_device(ctx);
     if (!ctx || !scan || !d_values) return fail(LC_ERR_INVALID, "null argument");
     if (field < LC_DATE_YEAR || field > LC_DATE_DAY_OF_WEEK) return fail(LC_ERR_INVALID, "unknown date field");
     if (scan->n == 0 || n_values == 0) return LC_OK;
