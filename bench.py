@@ -1084,12 +1084,14 @@ def make_abi_communicator(cache, N, Communicator, rank, world, torch, dist, dry_
             cache.set_option(N.OPT_COMM_SHARED_MEMORY, 1)
         uid = [Communicator.unique_id(cache) if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
-        comm = Communicator(cache, rank, world, uid[0])
         result = {}
 
         def probe():
             try:
                 _bind_thread()  # (a new thread starts on device 0)
+                # (the communicator's creation is a collective as well: inside the time limit, like the all-reduce)
+                result["comm"] = Communicator(cache, rank, world, uid[0])
+                comm = result["comm"]
                 side = torch.cuda.Stream()
                 with torch.cuda.stream(side):
                     t = torch.full((), rank + 1, dtype=torch.int64, device="cuda")
@@ -1103,8 +1105,9 @@ def make_abi_communicator(cache, N, Communicator, rank, world, torch, dist, dry_
         th = threading.Thread(target=probe, daemon=True)
         th.start()
         th.join(60.0)
+        comm = result.get("comm")
         if th.is_alive():
-            ok, note = 0, "its known-answer all-reduce did not return within 60 s"
+            ok, note = 0, "its creation / known-answer all-reduce did not return within 60 s"
         elif result.get("sum") != world * (world + 1) // 2:
             ok, note = 0, "its known-answer all-reduce gave %s" % (result.get("error") or result.get("sum"))
     except Exception as e:  # noqa: BLE001 — never lose the scaling run to this path
