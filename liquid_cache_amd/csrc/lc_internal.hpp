@@ -385,6 +385,13 @@ struct lc_scan {
     void* d_descs = nullptr;
     uint64_t* d_seg_offsets = nullptr;
     std::vector<lc::Entry> meta;  // copies of the entries' metadata (descs have mask_word_off filled in)
+    // What later passes over ALL entries need, in compact arrays captured while an entry's 400-byte record is in cache: the loops
+    // of a scan's first LIKE walked `meta` four times (12,207 records: 0.13 + 0.17 ms when the records had left the cache again).
+    std::vector<uint64_t> uids;         // Entry::uid, in scan order
+    std::vector<uint32_t> symtab_slots; // byte views: StrDesc::symtab_slot, in scan order
+    bool str_index_everywhere = true;   // byte views: every entry with a dictionary carries signatures, row lists and fingerprints
+    uint32_t max_str_rows = 0;          // byte views: the largest StrDesc::n
+    uint32_t max_dict_rows = 0;         // ... among the entries that have a dictionary (an all-null entry has none)
     std::vector<uint64_t> ids;    // the entry ids the scan was created over (list_cache: an identical list gets this scan back)
     std::vector<uint64_t> id_bloom;  // 2^17-bit Bloom filter of `ids` (two probes): does an evicted / replaced id concern this scan?
     bool cacheable = false;       // created by lc_scan_create (not a one-entry scan of the per-entry calls)

@@ -1583,20 +1583,17 @@ lc_status build_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t str
     LC_PHASE("like: workgroup records (lean)");
     lp->built = true;
     lp->eligible = false;
-    lp->uids.clear();
-    for (const Entry& e : s->meta) lp->uids.push_back(e.uid);
+    lp->uids = s->uids;
     if (!s->is_str || s->n == 0) return LC_OK;
-    for (const Entry& e : s->meta) {
-        if (e.sd.d == 0) continue;  // an all-null entry has no dictionary: no candidates, its mask words are zero
-        if (!e.sd.signatures || !e.sd.postings || !e.sd.fingerprints || e.sd.n > kPostMaxRows) return LC_OK;
-    }
-    lp->lean_ok = true;  // (entries of more than 8,192 rows: only k_like_flat, whose LDS mask size is the scan's)
-    for (const Entry& e : s->meta) lp->lean_ok = lp->lean_ok && e.sd.n <= kPostLdsRows;
+    // (from the scan's compact arrays: an all-null entry has no dictionary — no candidates, its mask words are zero — and needs
+    // no index; every other entry must carry signatures, row lists and fingerprints)
+    if (!s->str_index_everywhere || s->max_dict_rows > kPostMaxRows) return LC_OK;
+    lp->lean_ok = s->max_str_rows <= kPostLdsRows;  // (entries of more than 8,192 rows: only k_like_flat, whose LDS mask size is the scan's)
     // consecutive entries, at most kLeanWaves * kLeanE, never across a symbol-table change: the host says where each record
     // begins (through a pinned block that lives as long as the pipeline: no wait for the copy), k_lean_records fills them in
     std::vector<uint32_t> begins;
     for (uint32_t b = 0, i = 1; i <= s->n; i++) {
-        if (i == s->n || i - b == kLeanWaves * kLeanE || s->meta[i].sd.symtab_slot != s->meta[b].sd.symtab_slot) {
+        if (i == s->n || i - b == kLeanWaves * kLeanE || s->symtab_slots[i] != s->symtab_slots[b]) {
             begins.push_back(b);
             b = i;
         }
@@ -1816,6 +1813,19 @@ static void plan_slots_alloc_locked(lc_ctx* ctx) {
 void plan_slots_prime(lc_ctx* ctx) {
     std::lock_guard<std::mutex> g(ctx->plan_slots_mu);
     plan_slots_alloc_locked(ctx);
+    // ... and the runtime's own first-use work for what a plan's evaluation issues besides kernels — a memset of device memory, a
+    // copy into pinned memory, an event — is done here, once, instead of behind the first LIKE of the process
+    if (ctx->plan_slots_d && ctx->plan_slots_h) {
+        hipEvent_t e = nullptr;
+        (void)hipMemsetAsync(ctx->plan_slots_d, 0, kStatWords * 8, nullptr);
+        (void)hipMemcpyAsync(ctx->plan_slots_h, ctx->plan_slots_d, kStatWords * 8, hipMemcpyDeviceToHost, nullptr);
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess) {
+            (void)hipEventRecord(e, nullptr);
+            (void)hipEventSynchronize(e);
+            (void)hipEventDestroy(e);
+        }
+        (void)hipGetLastError();
+    }
 }
 static bool plan_slot_take(lc_ctx* ctx, LikePlan* q) {
     std::lock_guard<std::mutex> g(ctx->plan_slots_mu);
@@ -1969,9 +1979,8 @@ static LikePipeline* like_pipeline_adopt(lc_ctx* ctx, const lc_scan* s) {
     std::lock_guard<std::mutex> g(ctx->like_orphans_mu);
     for (size_t i = ctx->like_orphans.size(); i-- > 0;) {
         LikePipeline* lp = ctx->like_orphans[i];
-        if (lp->uids.size() != s->meta.size()) continue;
-        bool same = true;
-        for (size_t k = 0; same && k < lp->uids.size(); k++) same = lp->uids[k] == s->meta[k].uid;
+        if (lp->uids.size() != s->uids.size()) continue;
+        const bool same = std::memcmp(lp->uids.data(), s->uids.data(), lp->uids.size() * 8) == 0;
         if (!same) continue;
         ctx->like_orphans.erase(ctx->like_orphans.begin() + long(i));
         return lp;

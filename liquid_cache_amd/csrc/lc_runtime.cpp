@@ -2559,6 +2559,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
     s->seg_offsets.assign(n + 1, 0);
     s->meta.reserve(n);
     s->lens.reserve(n);
+    s->uids.reserve(n);
     {
         LC_PHASE("scan_create: capture entries");
         // ONE critical section captures the entries and pins their slabs: between a capture under one lock and a pin
@@ -2590,6 +2591,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             else e.fd.mask_word_off = off;
             s->seg_offsets[i + 1] = off + (uint64_t(e.len) + 63) / 64;
             s->lens.push_back(e.len);
+            s->uids.push_back(e.uid);
             s->total_rows += e.len;
             max_len = std::max(max_len, e.len);
             if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
@@ -2603,6 +2605,10 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
                 s->any_multi_empty |= e.sd.multi_empty != 0;
                 if (i == 0) s->uniform_slot = int32_t(e.sd.symtab_slot);
                 else if (int32_t(e.sd.symtab_slot) != s->uniform_slot) s->uniform_slot = -1;
+                s->symtab_slots.push_back(e.sd.symtab_slot);
+                if (e.sd.d != 0 && (!e.sd.signatures || !e.sd.postings || !e.sd.fingerprints)) s->str_index_everywhere = false;
+                s->max_str_rows = std::max(s->max_str_rows, e.sd.n);
+                if (e.sd.d != 0) s->max_dict_rows = std::max(s->max_dict_rows, e.sd.n);
             } else {
                 s->any_patch |= (e.fd.kind == kKindF32 || e.fd.kind == kKindF64) && e.fd.patch_len > 0;
                 s->any_float |= e.fd.kind == kKindF32 || e.fd.kind == kKindF64;
@@ -3050,7 +3056,7 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         std::vector<uint32_t> begins;
         uint32_t begin = 0;
         for (uint32_t i = 1; i <= s->n; i++) {
-            if (i == s->n || i - begin == 4 || s->meta[i].sd.symtab_slot != s->meta[begin].sd.symtab_slot) {
+            if (i == s->n || i - begin == 4 || s->symtab_slots[i] != s->symtab_slots[begin]) {
                 begins.push_back(begin);
                 begin = i;
             }
