@@ -392,6 +392,8 @@ struct lc_scan {
     bool str_index_everywhere = true;   // byte views: every entry with a dictionary carries signatures, row lists and fingerprints
     uint32_t max_str_rows = 0;          // byte views: the largest StrDesc::n
     uint32_t max_dict_rows = 0;         // ... among the entries that have a dictionary (an all-null entry has none)
+    uint64_t entry_bytes_total = 0;     // sum of Entry::device_bytes
+    std::vector<std::pair<int, uint32_t>> slab_pins;  // (slab, number of this scan's entries in it): what arena_pin_counts took
     std::vector<uint64_t> ids;    // the entry ids the scan was created over (list_cache: an identical list gets this scan back)
     std::vector<uint64_t> id_bloom;  // 2^17-bit Bloom filter of `ids` (two probes): does an evicted / replaced id concern this scan?
     bool cacheable = false;       // created by lc_scan_create (not a one-entry scan of the per-entry calls)

@@ -421,17 +421,27 @@ lc_status arena_alloc(lc_ctx* ctx, size_t bytes, uint8_t** out, int* slab_idx) {
 void arena_pin(lc_ctx* ctx, int slab_idx) {
     if (slab_idx >= 0 && size_t(slab_idx) < ctx->slabs.size()) ctx->slabs[size_t(slab_idx)].live++;
 }
+// a scan's pins, slab by slab: (slab, number of the scan's entries in it)
+static void arena_pin_counts(lc_ctx* ctx, const std::vector<std::pair<int, uint32_t>>& pins) {
+    for (const auto& p : pins)
+        if (p.first >= 0 && size_t(p.first) < ctx->slabs.size()) ctx->slabs[size_t(p.first)].live += p.second;
+}
 
 // Caller holds ctx->mu exclusively and guarantees that no kernel still reads the slab's blobs.
-void arena_release(lc_ctx* ctx, int slab_idx) {
-    if (slab_idx < 0 || size_t(slab_idx) >= ctx->slabs.size()) return;
+static void arena_release_n(lc_ctx* ctx, int slab_idx, uint32_t n) {
+    if (slab_idx < 0 || size_t(slab_idx) >= ctx->slabs.size() || n == 0) return;
     Slab& s = ctx->slabs[size_t(slab_idx)];
-    if (--s.live == 0 && s.base) {
+    s.live -= n;
+    if (s.live == 0 && s.base) {
         (void)hipFree(s.base);
         ctx->staged_bytes -= s.size;
         s.base = nullptr;
         s.size = s.used = 0;  // a drained LAST slab is not bumped into again: the next entry opens a new slab
     }
+}
+void arena_release(lc_ctx* ctx, int slab_idx) { arena_release_n(ctx, slab_idx, 1); }
+static void arena_release_counts(lc_ctx* ctx, const std::vector<std::pair<int, uint32_t>>& pins) {
+    for (const auto& p : pins) arena_release_n(ctx, p.first, p.second);
 }
 
 // Live counts reserved for entries that are not published yet (lc_stage, the device encoders): if the call fails between
@@ -2592,6 +2602,14 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             s->seg_offsets[i + 1] = off + (uint64_t(e.len) + 63) / 64;
             s->lens.push_back(e.len);
             s->uids.push_back(e.uid);
+            s->entry_bytes_total += e.device_bytes;
+            if (s->slab_pins.empty() || s->slab_pins.back().first != e.slab) {  // (entries of a column sit in runs of one slab)
+                size_t k = 0;
+                while (k < s->slab_pins.size() && s->slab_pins[k].first != e.slab) k++;
+                if (k == s->slab_pins.size()) s->slab_pins.emplace_back(e.slab, 0u);
+                if (k + 1 != s->slab_pins.size()) std::swap(s->slab_pins[k], s->slab_pins.back());
+            }
+            s->slab_pins.back().second++;
             s->total_rows += e.len;
             max_len = std::max(max_len, e.len);
             if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
@@ -2619,7 +2637,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         s->bpe = std::max<uint32_t>(1, (max_len + 1023) / 1024);
         // pin the slabs of the scan's entries: evicting or re-staging an entry under a live scan is then safe (the scan
         // keeps the blob it captured; lc_scan_destroy drops the pins)
-        for (const Entry& e : s->meta) arena_pin(ctx, e.slab);
+        arena_pin_counts(ctx, s->slab_pins);
         s->pinned = true;
     }
     LC_PROF(8);
@@ -2661,7 +2679,7 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
         pool_release(ctx, s->d_descs);
         pool_release(ctx, s->d_seg_offsets);
         std::unique_lock<std::shared_mutex> g(ctx->mu);
-        for (const Entry& e : s->meta) arena_release(ctx, e.slab);
+        arena_release_counts(ctx, s->slab_pins);
         return st;
     }
     *out = s.release();
@@ -2754,7 +2772,7 @@ static void scan_destroy_now(lc_scan* s) {
     pool_release(s->ctx, s->d_needle);
     if (s->pinned) {
         std::unique_lock<std::shared_mutex> g(s->ctx->mu);
-        for (const Entry& e : s->meta) arena_release(s->ctx, e.slab);
+        arena_release_counts(s->ctx, s->slab_pins);
     }
     delete s;
     } catch (...) {
@@ -2771,7 +2789,7 @@ lc_status lc_scan_info_get(lc_scan* s, lc_scan_info* out) {
     out->mask_words = s->seg_offsets.back();
     out->is_byte_view = s->is_str ? 1 : 0;
     out->max_bit_width = s->is_str ? 16 : int32_t(s->max_w);
-    for (const Entry& e : s->meta) out->entry_bytes += e.device_bytes;
+    out->entry_bytes = s->entry_bytes_total;
     {  // (never nested inside the scan's lock: one order of locks everywhere)
         std::shared_lock<std::shared_mutex> gc(s->ctx->mu);
         out->ctx_slab_bytes = s->ctx->staged_bytes;
