@@ -1187,10 +1187,14 @@ struct FbOffsets {  // what str_offset_pair reads of an entry
     int32_t slope, intercept;
     uint32_t offset_bytes;
 };
-template <bool kUni> constexpr uint32_t fb_row_words() { return (kUni ? 256u : uint32_t(kFlatBits)) + 2u; }  // (+2: the store loop's bank spread)
-constexpr size_t kFbPoliteLds = 2048;  // extra dynamic LDS of a "polite" build: 2 x (81,408 + 2,048) > 160 KiB, one workgroup per CU
+#ifndef LC_FB_ROWPAD
+#define LC_FB_ROWPAD 2u
+#endif
+template <bool kUni> constexpr uint32_t fb_row_words() { return (kUni ? 256u : uint32_t(kFlatBits)) + LC_FB_ROWPAD; }  // (+2: the store loop's bank spread)
+constexpr size_t kFbPoliteLds = 2048;  // extra dynamic LDS of a "polite" build: 2 x (81,152 + 80 + 2,048) > 160 KiB, one workgroup per CU
 template <bool kUni> constexpr size_t fb_lds_bytes() {
-    return size_t(kFbWords) * fb_row_words<kUni>() * 8u + 256u * 8u + size_t(kFbValues) * 8u + size_t(kFbValues) * 4u + 256u + kFbValues;
+    // stage + per-code table (8 bytes) + value ranges + first items (entry index in the top bits) + per-code first | last | len
+    return size_t(kFbWords) * fb_row_words<kUni>() * 8u + 256u * 8u + size_t(kFbValues) * 8u + size_t(kFbValues) * 4u + 256u * 4u;
 }
 // bytes equal to 255 immediately in front of position p of a value that starts at `start`: odd = p follows an escape marker
 __device__ __forceinline__ uint32_t fb_escape_run(const uint8_t* __restrict__ f, uint32_t start, uint32_t p) {
@@ -1201,7 +1205,9 @@ __device__ __forceinline__ uint32_t fb_escape_run(const uint8_t* __restrict__ f,
 static_assert(kFbValues == 1024, "fb_value swaps the two 5-bit halves of a slot number");
 __device__ __forceinline__ uint32_t fb_value(uint32_t slot) { return ((slot & 31u) << 5) | (slot >> 5); }
 // kUni: the 256 unigram slices (bit = the byte itself) instead of the kFlatBits bigram slices.
-template <bool kUni>
+// kSlots: how the pairs INSIDE a symbol are set — seven predicated slots at compile-time bit positions, or a loop over the
+// symbol's length (see the decode below for which build takes which).
+template <bool kUni, bool kSlots = false>
 __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
     constexpr uint32_t kBits = kUni ? 256u : uint32_t(kFlatBits);
     constexpr uint32_t kRow = fb_row_words<kUni>();
@@ -1209,11 +1215,18 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
     // [column][slice]: bit (j & 63) of word [j >> 6][s] = value j of the tile has signature bit s (slice fastest: the words the
     // lanes of a wave OR into sit 8 bytes apart)
     uint64_t* stage = reinterpret_cast<uint64_t*>(fb_smem);
-    uint64_t* s_sym = stage + size_t(kFbWords) * kRow;
-    uint32_t* s_range = reinterpret_cast<uint32_t*>(s_sym + 256);   // (start, stop) of the tile's values
-    uint32_t* s_first = s_range + 2u * kFbValues;                   // first work item of value j (exclusive prefix of the chunk counts)
-    uint8_t* s_len = reinterpret_cast<uint8_t*>(s_first + kFbValues);
-    uint8_t* s_ent = s_len + 256;                                   // the entry (0 .. kFlatMaxE-1) value j belongs to
+    // Per code (round 6): what a code contributes is known before any value is read.  s_tab: the bigram slices INSIDE the symbol,
+    // 9 bits each, in order (unigram build: the symbol's bytes themselves); s_meta: first byte | last byte << 8 | length << 16.
+    // Walking the symbol's bytes and hashing every pair in the decode loop cost 14 instructions per byte — per LONGEST symbol
+    // among the wave's 64 lanes, since the loop diverges on the length; with the table it is 6 per inner bigram.
+    static_assert(kFlatBits <= 512, "9 bits per bigram slice in s_tab");
+    static_assert(kFlatMaxE <= 4, "the entry index of a value rides in the top two bits of s_first");
+    uint64_t* s_tab = stage + size_t(kFbWords) * kRow;
+    uint32_t* s_range = reinterpret_cast<uint32_t*>(s_tab + 256);   // (start, stop) of the tile's values
+    uint32_t* s_first = s_range + 2u * kFbValues;                   // first work item of value j (exclusive prefix of the chunk
+                                                                    // counts) | entry (0 .. kFlatMaxE-1) << 30
+    uint32_t* s_meta = s_first + kFbValues;
+    constexpr uint32_t kFirstMask = 0x3FFFFFFFu;
     __shared__ uint32_t s_wave_tot[kFbThreads / 64u + 1u];
     const uint32_t gi = blockIdx.y, tile = blockIdx.x, t = threadIdx.x;
     const FlatGroup& G = a.groups[gi];
@@ -1245,8 +1258,13 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
     }
     const DevSymtab& st = a.symtabs[G.slot];
     if (t < 256u) {
-        s_sym[t] = st.sym[t];
-        s_len[t] = st.len[t];
+        const uint64_t sym = st.sym[t];
+        const uint32_t len = st.len[t];
+        uint64_t packed = 0;
+        for (uint32_t k = 0; k + 1u < len; k++)
+            packed |= uint64_t(flat_bigram_bit(uint32_t(sym >> (8u * k)) & 0xFFu, uint32_t(sym >> (8u * k + 8u)) & 0xFFu)) << (9u * k);
+        s_tab[t] = kUni ? sym : packed;
+        s_meta[t] = (uint32_t(sym) & 0xFFu) | ((len ? uint32_t(sym >> (8u * (len - 1u))) & 0xFFu : 0u) << 8) | (len << 16);
     }
     {
         uint4* z = reinterpret_cast<uint4*>(stage);
@@ -1260,7 +1278,6 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
     if (lane == 63) s_wave_tot[wave] = incl;
     s_range[2u * t] = start0;
     s_range[2u * t + 1u] = stop0;
-    s_ent[t] = uint8_t(ent);
     __syncthreads();
     uint32_t before = 0, total = 0;
     for (uint32_t w = 0; w < kFbThreads / 64u; w++) {
@@ -1268,7 +1285,7 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
         before += w < uint32_t(wave) ? x : 0u;
         total += x;
     }
-    s_first[t] = before + incl - n_chunks;
+    s_first[t] = ((before + incl - n_chunks) & kFirstMask) | (ent << 30);
     __syncthreads();
 #if defined(LC_FB_STOP) && LC_FB_STOP == 1  // timing aid (wrong index): no decode — set-up, zeroing and the stores
     total = 0;
@@ -1278,47 +1295,146 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
         uint32_t lo = 0, hi = kFbValues;
         while (hi - lo > 1u) {
             const uint32_t mid = (lo + hi) >> 1;
-            if (s_first[mid] <= i) lo = mid; else hi = mid;
+            if ((s_first[mid] & kFirstMask) <= i) lo = mid; else hi = mid;
         }
-        const uint32_t slot = lo, c = i - s_first[slot], j = fb_value(slot);
+        const uint32_t first_ent = s_first[lo];
+        const uint32_t slot = lo, c = i - (first_ent & kFirstMask), j = fb_value(slot);
         uint32_t* col = reinterpret_cast<uint32_t*>(stage + size_t(j >> 6) * kRow) + ((j >> 5) & 1u);  // the value's column, its half
         const uint32_t mybit = 1u << (j & 31u);
         const uint32_t start = s_range[2u * slot], stop = s_range[2u * slot + 1u];
-        const uint8_t* fsst = G.e[s_ent[slot]].fsst;
+        const uint8_t* fsst = G.e[first_ent >> 30].fsst;
         // cut positions move one byte back when they would fall between an escape marker and its literal
-        uint32_t p0 = start + c * kFbChunk, p1 = min(stop, p0 + kFbChunk);
-#ifndef LC_FB_MUTATE  // (-DLC_FB_MUTATE: the cuts left where they fall — the mutant tests/test_gpu_round5.py must catch)
-        if (c != 0) p0 -= fb_escape_run(fsst, start, p0) & 1u;
-        if (p1 < stop) p1 -= fb_escape_run(fsst, start, p1) & 1u;
-#endif
+        const uint32_t q0 = start + c * kFbChunk;
+        uint32_t p0 = q0, p1 = min(stop, q0 + kFbChunk);
+        // Round 6: the item's bytes are requested ONCE, together — the 8 bytes in front of the cut and the chunk's 16 (three
+        // independent loads; a chunk behind the first begins at least 16 bytes into its value, so the window lies inside it, and
+        // every blob has 256 bytes of slack behind it) — and the cut logic works on registers.  It used to be a chain of
+        // dependent single-byte loads (the byte in front of each cut, the byte in front of that, then the chunk's words): ~4
+        // round trips per item at 5 items per lane, which is what the 3.4 ms of decode were made of.
+        static_assert(LC_FB_CHUNK == 16, "the register window of k_flat_build is 8 + 16 bytes");
+        const uint64_t wp = c != 0 ? load_unaligned<uint64_t>(fsst + q0 - 8u) : 0;
+        const uint64_t w0 = q0 < stop ? load_unaligned<uint64_t>(fsst + q0) : 0;
+        const uint64_t w1 = q0 + 8u < stop ? load_unaligned<uint64_t>(fsst + q0 + 8u) : 0;
+        // byte i of the window, i in [-8, 16) relative to q0 (the general form: only runs of escape bytes come here)
+        auto wbyte = [&](int i) -> uint32_t {
+            return uint32_t((i < 0 ? wp >> (8 * (i + 8)) : (i < 8 ? w0 >> (8 * i) : w1 >> (8 * (i - 8)))) & 0xFFu);
+        };
+        // bytes equal to 255 immediately in front of window position i; -1: the run reaches the window's first byte (for the
+        // first chunk the value's start bounds it, like fb_escape_run)
+        const int wlo = c != 0 ? -8 : 0;
+        auto wrun = [&](int i) -> int {
+            int k = 0;
+            while (i - 1 - k >= wlo && wbyte(i - 1 - k) == 255u) k++;
+            return (i - 1 - k < wlo && c != 0) ? -1 : k;
+        };
         int prev = -1;
-        if (!kUni && c != 0) {  // the last byte in front of the cut: a literal, or the last byte of a symbol
-            const uint32_t b = fsst[p0 - 1u];
-            const bool literal = (fb_escape_run(fsst, start, p0 - 1u) & 1u) != 0;
-            prev = literal ? int(b) : int((s_sym[b] >> (8u * (uint32_t(s_len[b]) - 1u))) & 0xFFu);
+        bool slow = false;  // a run of escape bytes longer than the window (never seen outside the fuzz tests): the old way
+        int i0 = 0, i1 = int(p1 - q0);
+        // the common case costs three byte compares: no escape byte next to either cut
+        const uint32_t b_m1 = uint32_t(wp >> 56), b_m2 = uint32_t(wp >> 48) & 0xFFu, b_15 = uint32_t(w1 >> 56);
+#ifndef LC_FB_MUTATE  // (-DLC_FB_MUTATE: the cuts left where they fall — the mutant tests/test_gpu_round5.py must catch)
+        if (c != 0 && b_m1 == 255u) {
+            const int r = wrun(0);
+            if (r < 0) slow = true; else i0 -= r & 1;
         }
-        bool escaped = false;
-        uint64_t w = p0 < p1 ? load_unaligned<uint64_t>(fsst + p0) : 0;
-        for (uint32_t p = p0; p < p1; p += 8u) {
-            const uint64_t cur_w = w;
-            if (p + 8u < p1) w = load_unaligned<uint64_t>(fsst + p + 8u);
-            const uint32_t nb = min(8u, p1 - p);
-            for (uint32_t k = 0; k < nb; k++) {
-                const uint32_t code = uint32_t(cur_w >> (8u * k)) & 0xFFu;
-                uint64_t sym;
-                uint32_t len;
-                if (escaped) { sym = code; len = 1; escaped = false; }
-                else if (code == 255u) { escaped = true; continue; }
-                else { sym = s_sym[code]; len = s_len[code]; }
+        if (p1 < stop && b_15 == 255u) {  // (p1 < stop: the chunk is whole, its last byte is window byte 15)
+            const int r = wrun(i1);
+            if (r < 0) slow = true; else i1 -= r & 1;
+        }
+#endif
+        if (!slow && !kUni && c != 0) {  // the last byte in front of the cut: a literal, or the last byte of a symbol
+            uint32_t bb = b_m1;
+            int r = 0;
+            if (i0 != 0 || b_m2 == 255u) {
+                bb = wbyte(i0 - 1);
+                r = wrun(i0 - 1);
+            }
+            if (r < 0) slow = true;
+            else prev = (r & 1) ? int(bb) : int((s_meta[bb] >> 8) & 0xFFu);
+        }
+        auto set_bit = [&](uint32_t bit) { atomicOr(col + 2u * bit, mybit); };
+        auto emit = [&](uint32_t code, bool& escaped) {
+            if (escaped) {  // a literal byte
+                escaped = false;
+                if (kUni) set_bit(code);
+                else if (prev >= 0) set_bit(flat_bigram_bit(uint32_t(prev), code));
+                prev = int(code);
+                return;
+            }
+            if (code == 255u) { escaped = true; return; }
+            const uint32_t m = s_meta[code], len = m >> 16;
+            if (len == 0) return;
+            const uint64_t tab = s_tab[code];
+            uint32_t lo = uint32_t(tab), hi = uint32_t(tab >> 32);
+            if constexpr (kUni) {
                 for (uint32_t q = 0; q < len; q++) {
-                    const int cur = int((sym >> (8u * q)) & 0xFFu);
-                    if (kUni || prev >= 0) {
-                        const uint32_t bit = kUni ? uint32_t(cur) : flat_bigram_bit(uint32_t(prev), uint32_t(cur));
-                        atomicOr(col + 2u * bit, mybit);
+                    set_bit(lo & 0xFFu);
+                    lo = __builtin_amdgcn_alignbyte(hi, lo, 1);
+                    hi >>= 8;
+                }
+            } else {
+                if (prev >= 0) set_bit(flat_bigram_bit(uint32_t(prev), m & 0xFFu));  // the pair across the code boundary
+                // The pairs inside the symbol.  A loop over len - 1 runs, for the whole wave, as long as its longest symbol and
+                // pays a shift pair and a branch per turn; seven predicated slots at compile-time bit positions execute 25 % fewer
+                // VALU instructions (1.36 against 1.83 x 10^9 per 100 M-row column).  Measured, 100 M-row URL column: with ONE
+                // workgroup per CU (the builder thread's polite form) the slots win, 4.8 against 5.3 ms; the two-per-CU form of a
+                // synchronous build runs at 3.2 ms with the loop and at 4.7 ms with the slots, where the SQ counters show the
+                // same wave-cycles as the one-per-CU form: the second workgroup is not resident, for a reason the kernel's
+                // resource record (60 VGPRs, 81 SGPRs, the same LDS) does not show.  So each build takes the form that is faster
+                // for it.
+                if constexpr (kSlots) {
+                    if (len > 1u) set_bit(lo & 0x1FFu);
+                    if (len > 2u) set_bit((lo >> 9) & 0x1FFu);
+                    if (len > 3u) set_bit((lo >> 18) & 0x1FFu);
+                    if (len > 4u) set_bit(__builtin_amdgcn_alignbit(hi, lo, 27) & 0x1FFu);
+                    if (len > 5u) set_bit((hi >> 4) & 0x1FFu);
+                    if (len > 6u) set_bit((hi >> 13) & 0x1FFu);
+                    if (len > 7u) set_bit((hi >> 22) & 0x1FFu);
+                } else {
+                    for (uint32_t q = 1; q < len; q++) {
+                        set_bit(lo & 0x1FFu);
+                        lo = __builtin_amdgcn_alignbit(hi, lo, 9);
+                        hi >>= 9;
                     }
-                    prev = cur;
                 }
             }
+            prev = int((m >> 8) & 0xFFu);
+        };
+        bool escaped = false;
+        if (!slow) {
+            // the chunk's bytes as dwords that begin at the (possibly moved) cut: four bytes per dword at compile-time positions
+            uint32_t d[5] = {uint32_t(w0), uint32_t(w0 >> 32), uint32_t(w1), uint32_t(w1 >> 32), 0u};
+            if (i0 != 0) {  // one byte earlier: everything moves up by a byte, the marker in front comes in
+                d[4] = d[3] >> 24;
+                d[3] = __builtin_amdgcn_alignbyte(d[3], d[2], 3);
+                d[2] = __builtin_amdgcn_alignbyte(d[2], d[1], 3);
+                d[1] = __builtin_amdgcn_alignbyte(d[1], d[0], 3);
+                d[0] = (d[0] << 8) | b_m1;
+            }
+            const uint32_t nbytes = uint32_t(i1 - i0);
+#pragma unroll
+            for (uint32_t k = 0; k < 5u; k++) {
+                if (4u * k >= nbytes) break;
+                const uint32_t x = d[k];
+                emit(x & 0xFFu, escaped);
+                if (4u * k + 1u < nbytes) emit((x >> 8) & 0xFFu, escaped);
+                if (4u * k + 2u < nbytes) emit((x >> 16) & 0xFFu, escaped);
+                if (4u * k + 3u < nbytes) emit(x >> 24, escaped);
+            }
+        } else {
+            p0 = q0;
+            p1 = min(stop, q0 + kFbChunk);
+            prev = -1;
+#ifndef LC_FB_MUTATE
+            if (c != 0) p0 -= fb_escape_run(fsst, start, p0) & 1u;
+            if (p1 < stop) p1 -= fb_escape_run(fsst, start, p1) & 1u;
+#endif
+            if (!kUni && c != 0) {
+                const uint32_t bb = fsst[p0 - 1u];
+                const bool literal = (fb_escape_run(fsst, start, p0 - 1u) & 1u) != 0;
+                prev = literal ? int(bb) : int((s_meta[bb] >> 8) & 0xFFu);
+            }
+            for (uint32_t pp = p0; pp < p1; pp++) emit(uint32_t(fsst[pp]), escaped);
         }
     }
     __syncthreads();
@@ -1518,10 +1634,16 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     // (no memset: the tiles of a group cover every word of its slices, padding included)
     FlatBuildArgs ba{lp->d_groups, s->d_symtabs, lp->d_slices, flat_slice_stride(uint32_t(groups.size()), gw),
                      flat_group_stride(kFlatBits, gw)};
+    LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_build<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               int(fb_lds_bytes<false>() + kFbPoliteLds)));
     LC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_flat_build<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                int(fb_lds_bytes<false>() + kFbPoliteLds)));
-    hipLaunchKernelGGL(k_flat_build<false>, dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads),
-                       fb_lds_bytes<false>() + (polite ? kFbPoliteLds : 0u), stream, ba);
+    if (polite)
+        hipLaunchKernelGGL((k_flat_build<false, true>), dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads),
+                           fb_lds_bytes<false>() + kFbPoliteLds, stream, ba);
+    else
+        hipLaunchKernelGGL((k_flat_build<false, false>), dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads),
+                           fb_lds_bytes<false>(), stream, ba);
     LC_HIP(hipGetLastError());
     if (ev1) LC_HIP(hipEventRecord(ev1, stream));
     LC_HIP(hipStreamSynchronize(stream));  // the vectors are locals
@@ -2152,6 +2274,16 @@ uint64_t like_pipeline_bytes(const lc_scan* s, const StrPredHost& sp, bool with_
 // (byte_view_array/conversions.rs:353-355: at insert time).  The first attempt never evicts another scan's cached index; a scan
 // that was turned away for that reason tries again, with eviction, once it has served kEvictAfterEvals evaluations.
 // Caller holds s->mu.
+// -DLC_FB_POLITE=1: the builder thread's builds run ONE workgroup per CU (build_flat's `polite`).  That form was this round's
+// first answer to "a query launched during a build waited 4.2 ms for its 30 us kernel"; the answer that holds is the streams'
+// priorities — queries run on streams of the highest priority, the builder's has the lowest, and a build workgroup lives ~50 us,
+// so a query's workgroups take the next free slots.  Measured with scripts/query_during_build.py (COUNT(*) queries on one table
+// while another table's index is built, 8 ms windows): two workgroups per CU — queries median 23-26 us (quiet device: 23.4), max
+// 66-81 us, build kernel 4.0 ms; one per CU — median 28-38 us, max 46-64 us, build kernel 5.0 ms.  The full-occupancy build
+// disturbs the median less (it is over sooner) and the worst query by 20 us more: it is the default.
+#ifndef LC_FB_POLITE
+#define LC_FB_POLITE 0
+#endif
 static lc_status want_flat_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stream) {
     if (!lp->eligible || lp->flat) return LC_OK;
     LC_PHASE("like: want_flat_index");
@@ -2181,7 +2313,7 @@ static lc_status want_flat_index(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipS
     lp->flat_job = builder_submit(ctx, [ctx, s, lp, pend, allow_evict, gate](hipStream_t st) {
         build_gate_pass(gate);
         try {
-            (void)build_flat(ctx, s, pend, st, allow_evict, true);
+            (void)build_flat(ctx, s, pend, st, allow_evict, LC_FB_POLITE != 0);
         } catch (...) {
             pend->flat = false;
         }
