@@ -1205,10 +1205,13 @@ __device__ __forceinline__ uint32_t fb_escape_run(const uint8_t* __restrict__ f,
 static_assert(kFbValues == 1024, "fb_value swaps the two 5-bit halves of a slot number");
 __device__ __forceinline__ uint32_t fb_value(uint32_t slot) { return ((slot & 31u) << 5) | (slot >> 5); }
 // kUni: the 256 unigram slices (bit = the byte itself) instead of the kFlatBits bigram slices.
+#ifndef LC_FB_SLOTS
+#define LC_FB_SLOTS 1
+#endif
 // kSlots: how the pairs INSIDE a symbol are set — seven predicated slots at compile-time bit positions, or a loop over the
-// symbol's length (see the decode below for which build takes which).
+// symbol's length (see the decode below).
 template <bool kUni, bool kSlots = false>
-__global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
+__global__ __launch_bounds__(kFbThreads) __attribute__((amdgpu_num_sgpr(80))) void k_flat_build(FlatBuildArgs a) {
     constexpr uint32_t kBits = kUni ? 256u : uint32_t(kFlatBits);
     constexpr uint32_t kRow = fb_row_words<kUni>();
     extern __shared__ __align__(16) uint8_t fb_smem[];
@@ -1376,12 +1379,11 @@ __global__ __launch_bounds__(kFbThreads) void k_flat_build(FlatBuildArgs a) {
                 if (prev >= 0) set_bit(flat_bigram_bit(uint32_t(prev), m & 0xFFu));  // the pair across the code boundary
                 // The pairs inside the symbol.  A loop over len - 1 runs, for the whole wave, as long as its longest symbol and
                 // pays a shift pair and a branch per turn; seven predicated slots at compile-time bit positions execute 25 % fewer
-                // VALU instructions (1.36 against 1.83 x 10^9 per 100 M-row column).  Measured, 100 M-row URL column: with ONE
-                // workgroup per CU (the builder thread's polite form) the slots win, 4.8 against 5.3 ms; the two-per-CU form of a
-                // synchronous build runs at 3.2 ms with the loop and at 4.7 ms with the slots, where the SQ counters show the
-                // same wave-cycles as the one-per-CU form: the second workgroup is not resident, for a reason the kernel's
-                // resource record (60 VGPRs, 81 SGPRs, the same LDS) does not show.  So each build takes the form that is faster
-                // for it.
+                // VALU instructions (1.36 against 1.83 x 10^9 per 100 M-row column) — and at first ran SLOWER at two workgroups
+                // per CU (4.7 against 3.2 ms) with the SQ counters showing the wave-cycles of ONE workgroup per CU: the slots
+                // took the kernel from 75 to 81 SGPRs, which are allocated as 96 (+16 for the trap handler) and leave a SIMD 7
+                // wave slots instead of the 8 that two 16-wave workgroups need.  Hence amdgpu_num_sgpr(80) on the kernel: 2.85 ms.
+                // (-DLC_FB_SLOTS=0: the loop, 3.2 ms.)
                 if constexpr (kSlots) {
                     if (len > 1u) set_bit(lo & 0x1FFu);
                     if (len > 2u) set_bit((lo >> 9) & 0x1FFu);
@@ -1642,7 +1644,7 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
         hipLaunchKernelGGL((k_flat_build<false, true>), dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads),
                            fb_lds_bytes<false>() + kFbPoliteLds, stream, ba);
     else
-        hipLaunchKernelGGL((k_flat_build<false, false>), dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads),
+        hipLaunchKernelGGL((k_flat_build<false, LC_FB_SLOTS != 0>), dim3(gw / kFbWords, uint32_t(groups.size())), dim3(kFbThreads),
                            fb_lds_bytes<false>(), stream, ba);
     LC_HIP(hipGetLastError());
     if (ev1) LC_HIP(hipEventRecord(ev1, stream));
