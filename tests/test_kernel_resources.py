@@ -52,3 +52,16 @@ def test_register_resident_kernels_use_no_lds(kernels):
     for name, k in kernels.items():
         if "k_fixed_pred_reg" in name:
             assert k["lds"] == 0, "%s: %d bytes of LDS" % (name, k["lds"])
+
+
+def test_index_builder_keeps_two_workgroups_per_cu(kernels):
+    """k_flat_build runs 16-wave workgroups, two per CU: that needs 8 wave slots per SIMD, i.e. at most 64 VGPRs AND at most 80
+    SGPRs — 81 are allocated as 96 (+16 for the trap handler) and leave a SIMD 7 slots.  Round 6 lost a third of the builder's
+    speed to six SGPRs (profiles/r6/ab_flat_build.txt); nothing but the SQ counters' wave-cycles showed it."""
+    seen = 0
+    for name, k in kernels.items():
+        if "k_flat_build" in name:
+            seen += 1
+            assert k["vgprs"] <= 64 and k["sgprs"] <= 80, "%s: %d VGPRs, %d SGPRs" % (name, k["vgprs"], k["sgprs"])
+            assert k["scratch"] == 0, name
+    assert seen >= 2
