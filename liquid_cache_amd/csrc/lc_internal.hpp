@@ -375,6 +375,7 @@ struct lc_scan {
     int lane_log2 = 0;
     uint32_t n = 0, bpe = 0;
     uint32_t max_w = 0;  // widest entry (fixed width): <= 32 selects the register-resident predicate kernel
+    uint32_t min_w = 0;  // narrowest entry that has packed data (W > 0); min_w == max_w: the kernel of that one width
     bool has_clamped = false;              // some entry is clamp-squeezed: evaluations first look for unresolved sentinels
     bool has_fquant = false;               // some entry is a float-quantized hybrid (k_float_quant_pred evaluates those)
     bool fquant_patches = false;           // ... and carries ALP exceptions: no selection can be applied (see lc_squeeze_quantize)

@@ -711,7 +711,7 @@ __device__ __forceinline__ const uint8_t* uniform_ptr(const void* p) {
 // All passes of one entry; a pass is two 1024-row blocks, whose 32 mask words end up in lanes 0..31.  Returns this lane's
 // share of the entry's hit count.
 template <typename U, int W, bool kTwoSided>
-__device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
+__device__ __forceinline__ uint32_t fixed_pred_entry_reg_body(const RegEntryArgs& a) {
     constexpr uint32_t TB = LaneTraits<U>::kBits;
     // dwords of the thread's stream: u32 / u64 threads hold 32 rows of their lane, u16 threads 16
     constexpr bool k32 = TB != 16;  // u32 lanes, and u64 lanes in their shape (load_stream64)
@@ -978,6 +978,12 @@ __device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
     }
 }
 
+// (the per-width function of the mixed-width kernels: one non-inlined copy of the body per width and sidedness)
+template <typename U, int W, bool kTwoSided>
+__device__ __noinline__ uint32_t fixed_pred_entry_reg(RegEntryArgs a) {
+    return fixed_pred_entry_reg_body<U, W, kTwoSided>(a);
+}
+
 template <typename U, int... WS>
 __device__ __forceinline__ uint32_t fixed_pred_entry_dispatch(std::integer_sequence<int, WS...>, uint32_t W, bool two_sided,
                                                               const RegEntryArgs& a) {
@@ -988,13 +994,11 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_dispatch(std::integer_seque
     return c;
 }
 
-// kMaxW: widest entry the instantiation handles (16 or 32).  The register allocation of a kernel is the maximum over the
-// per-width functions it can call, so scans of narrow columns get the instantiation with the smaller footprint.
-// one entry of one column: the predicate range of the entry, then the per-width function; returns the lane's hit count
-template <typename U, int kMaxW>
-__device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2,
-                                                          const uint64_t* selection, uint64_t* hit, uint64_t* valid_out,
-                                                          int lane, uint32_t bal) {
+// the entry's predicate as the per-width functions take it: one unsigned range, one or two sided, possibly complemented
+template <typename U>
+__device__ __forceinline__ RegEntryArgs fixed_pred_entry_args(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2,
+                                                              const uint64_t* selection, uint64_t* hit, uint64_t* valid_out,
+                                                              int lane, uint32_t bal, bool& two_sided) {
     const PackedRange<U> pr = entry_range<U>(d, pred, pred2, lane);
     const uint32_t W = max(uint32_t(d.W), 1u);
     const uint32_t umax = W >= 32 ? ~0u : ((1u << W) - 1u);
@@ -1008,7 +1012,7 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, co
     a.len = d.len;
     a.constant = d.W == 0 ? 0 : pr.constant;
     a.bal = bal;
-    bool two_sided = false;
+    two_sided = false;
     uint32_t flip;
     if (lo == 0) {                    // u <= span
         a.lo = 0; a.bound = span; flip = pr.negate ? 1u : 0u;
@@ -1019,7 +1023,27 @@ __device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, co
         a.lo = lo; a.bound = span; flip = pr.negate ? 1u : 0u;
     }
     a.flags = flip | (d.W == 0 ? 2u : 0u);
-    return fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, W, two_sided, a);
+    return a;
+}
+// kMaxW: widest entry the instantiation handles (16 or 32).  The register allocation of a kernel is the maximum over the
+// per-width functions it can call, so scans of narrow columns get the instantiation with the smaller footprint.
+// one entry of one column: the predicate range of the entry, then the per-width function; returns the lane's hit count
+template <typename U, int kMaxW>
+__device__ __forceinline__ uint32_t fixed_pred_entry_step(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2,
+                                                          const uint64_t* selection, uint64_t* hit, uint64_t* valid_out,
+                                                          int lane, uint32_t bal) {
+    bool two_sided;
+    const RegEntryArgs a = fixed_pred_entry_args<U>(d, pred, pred2, selection, hit, valid_out, lane, bal, two_sided);
+    return fixed_pred_entry_dispatch<U>(std::make_integer_sequence<int, kMaxW>{}, max(uint32_t(d.W), 1u), two_sided, a);
+}
+// ... of a scan whose entries all have width W (or no packed data at all): the body inlined, both sidednesses
+template <typename U, int W>
+__device__ __forceinline__ uint32_t fixed_pred_entry_step_w(const FixedDesc& d, const FixedPred& pred, const FixedPred& pred2,
+                                                            const uint64_t* selection, uint64_t* hit, uint64_t* valid_out,
+                                                            int lane, uint32_t bal) {
+    bool two_sided;
+    const RegEntryArgs a = fixed_pred_entry_args<U>(d, pred, pred2, selection, hit, valid_out, lane, bal, two_sided);
+    return two_sided ? fixed_pred_entry_reg_body<U, W, true>(a) : fixed_pred_entry_reg_body<U, W, false>(a);
 }
 
 // A run of an entry's 1024-row blocks as an entry of its own (ScanLaunch::entry_split_log2): part `part` of 2^sl.  The blocks
@@ -1066,6 +1090,36 @@ __global__ __launch_bounds__(kThreads) void k_fixed_pred_reg(const FixedDesc* __
                 if (sl) atomicAdd(L.d_counts + entry, uint32_t(t));  // (the launcher zeroed the counts of a split launch)
                 else L.d_counts[entry] = uint32_t(t);
             }
+            wave_hits += t;
+        }
+    }
+    if (L.d_total_out && lane == 0) total_contribute(L, blockIdx.x * kWavesPerBlock + wave, total_waves, wave_hits);
+}
+
+// The same for a scan whose entries ALL have width W (dates, small-range decimals, enums: the FoR width of a batch is the width
+// of its range, and regular columns have one).  The mixed-width kernel above calls one non-inlined function per width, and a
+// kernel that calls is allocated the callees' worst case: 82 / 68 / 55 VGPRs (u32 / u64 / u16 lanes) and — whatever the callees
+// really use — 106 SGPRs, which alone cap a SIMD at 6 waves (k_flat_build's lesson, profiles/r6/ab_flat_build.txt).  With the
+// width a template parameter of the KERNEL the body is inlined and the kernel gets what this one width needs (u64 lanes, W <= 6:
+// 39-55 VGPRs and, capped, 78 SGPRs: 8 waves per SIMD; no call, no argument marshalling).  Instantiated for the u64 lanes only:
+// that is where it pays (the launcher has the numbers).
+template <typename U, int W>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_num_sgpr(80))) void k_fixed_pred_reg_w(const FixedDesc* __restrict__ descs, FixedPred pred, FixedPred pred2,
+                                                                ScanLaunch L) {
+    __shared__ uint64_t s_ballots[LC_X_BALLOT_LDS != 0 ? kWavesPerBlock : 1][LC_X_BALLOT_LDS != 0 ? 64 : 1];
+    const int lane = lane_id();
+    const uint32_t wave = uint32_t(__builtin_amdgcn_readfirstlane(wave_id()));
+    const uint32_t bal = LC_X_BALLOT_LDS != 0 ? uint32_t(reinterpret_cast<uintptr_t>(&s_ballots[wave][0])) : 0u;
+    const uint32_t total_waves = gridDim.x * kWavesPerBlock;
+    uint64_t wave_hits = 0;
+    for (uint32_t entry = blockIdx.x * kWavesPerBlock + wave; entry < L.n_entries; entry += total_waves) {
+        const FixedDesc d = descs[entry];
+        const uint64_t woff = d.mask_word_off;
+        const uint32_t c = fixed_pred_entry_step_w<U, W>(d, pred, pred2, L.d_selection ? L.d_selection + woff : nullptr, L.d_hit + woff,
+                                                         L.d_valid ? L.d_valid + woff : nullptr, lane, bal);
+        if (L.d_counts || L.d_total_out) {
+            const uint64_t t = wave_sum_u64(uint64_t(c));
+            if (lane == 0 && L.d_counts) L.d_counts[entry] = uint32_t(t);
             wave_hits += t;
         }
     }
@@ -5311,6 +5365,32 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
         const uint64_t need = (units + kWavesPerBlock - 1) / kWavesPerBlock;
         const dim3 grid(uint32_t(need < wgs_resident ? need : wgs_resident)), block(kThreads);
         const bool narrow = max_width <= 16;
+#ifndef LC_X_UNIFORM_W
+#define LC_X_UNIFORM_W 1
+#endif
+        // every entry of the scan at one width (ScanLaunch::uniform_w, 1..16): the kernel of that width
+        if (LC_X_UNIFORM_W != 0 && L2.uniform_w >= 1 && L2.uniform_w <= 16 && L2.entry_split_log2 == 0) {
+            bool launched = true;
+            auto go = [&](auto u, auto w) {
+                using U = decltype(u);
+                hipLaunchKernelGGL((k_fixed_pred_reg_w<U, decltype(w)::value>), grid, block, 0, stream, d_descs, pred, p2, L2);
+            };
+            auto by_width = [&](auto u) {
+                switch (L2.uniform_w) {
+#define LC_W_CASE(N) case N: go(u, std::integral_constant<int, N>{}); break;
+                    LC_W_CASE(1) LC_W_CASE(2) LC_W_CASE(3) LC_W_CASE(4) LC_W_CASE(5) LC_W_CASE(6) LC_W_CASE(7) LC_W_CASE(8)
+                    LC_W_CASE(9) LC_W_CASE(10) LC_W_CASE(11) LC_W_CASE(12) LC_W_CASE(13) LC_W_CASE(14) LC_W_CASE(15) LC_W_CASE(16)
+#undef LC_W_CASE
+                    default: launched = false;
+                }
+            };
+            // Measured (scripts/ab_uniform_w.sh, 100 M rows, hot / L3-cold): u64 lanes W = 4 21.2 / 26.2 -> 18.5 / 22.2 us, W = 13
+            // 31.3 / 42.8 -> 29.4 / 40.9; u32 lanes W = 12 29.6 / 37.6 -> 30.5 / 37.5 and u16 lanes W = 12 27.4 / 37.8 -> 26.6 / 38.5
+            // — no gain from 7-8 waves per SIMD instead of 5-6 there, so only the u64 lanes have these kernels.
+            if (lane_log2 == 6) by_width(uint64_t{});
+            else launched = false;
+            if (launched) return hipGetLastError();
+        }
         switch (lane_log2) {
             case 4: hipLaunchKernelGGL((k_fixed_pred_reg<uint16_t, 16>), grid, block, 0, stream, d_descs, pred, p2, L2); break;
             case 5:

@@ -266,7 +266,7 @@ struct ScanLaunch {
     uint32_t entry_split_log2;        // fixed width, register-resident kernels: an entry is worked on by 2^this waves, each taking
                                       // a run of its 1024-row blocks (set by the launcher; 0 when per-entry counts are asked for)
     uint32_t hits_parts;              // 0 / 1: d_hits is ONE list with ONE counter; kHitParts: the PARTITIONED form (below)
-    uint32_t pad_parts;
+    uint32_t uniform_w;               // fixed width: every entry of the scan with packed data has this width (0: mixed widths)
 };
 // The partitioned hit list (LC_HITS_PARTITIONED, round 6).  A contiguous list is allocated by returning atomics on ONE address,
 // which complete ~10 ns apart however many workgroups wait: 1,100 of them were 11 of the 23.7 us of a selective LIKE with a

@@ -2612,7 +2612,10 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
             s->slab_pins.back().second++;
             s->total_rows += e.len;
             max_len = std::max(max_len, e.len);
-            if (!e.is_str) s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
+            if (!e.is_str) {
+                s->max_w = std::max<uint32_t>(s->max_w, uint32_t(e.W));
+                if (e.W > 0) s->min_w = s->min_w ? std::min<uint32_t>(s->min_w, uint32_t(e.W)) : uint32_t(e.W);
+            }
             s->has_clamped |= e.clamped || e.quantized;
             s->has_fquant |= e.fq_shift > 0;
             s->fquant_patches |= e.fq_shift > 0 && e.fd.patch_len > 0;
@@ -2997,6 +3000,8 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
             if (!s->needs_backing.empty() && !tolerate_backing)
                 return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry holds sentinel rows this predicate cannot decide");
         }
+        // (every entry with packed data at one width, no squeezed / float entries: the kernel of that width)
+        L.uniform_w = (s->min_w == s->max_w && !s->has_clamped && !s->has_fquant) ? s->max_w : 0u;
         LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, pred2 ? &fp2 : nullptr,
                                  s->max_w, L, stream));
         if (s->any_patch) {
