@@ -5368,8 +5368,11 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
 #ifndef LC_X_UNIFORM_W
 #define LC_X_UNIFORM_W 1
 #endif
-        // every entry of the scan at one width (ScanLaunch::uniform_w, 1..16): the kernel of that width
-        if (LC_X_UNIFORM_W != 0 && L2.uniform_w >= 1 && L2.uniform_w <= 16 && L2.entry_split_log2 == 0) {
+#ifndef LC_X_UNIFORM_MAXW
+#define LC_X_UNIFORM_MAXW 32
+#endif
+        // every entry of the scan at one width (ScanLaunch::uniform_w, 1..32): the kernel of that width
+        if (LC_X_UNIFORM_W != 0 && L2.uniform_w >= 1 && L2.uniform_w <= LC_X_UNIFORM_MAXW && L2.entry_split_log2 == 0) {
             bool launched = true;
             auto go = [&](auto u, auto w) {
                 using U = decltype(u);
@@ -5380,13 +5383,19 @@ hipError_t launch_fixed_pred(const FixedDesc* d_descs, int lane_log2, const Fixe
 #define LC_W_CASE(N) case N: go(u, std::integral_constant<int, N>{}); break;
                     LC_W_CASE(1) LC_W_CASE(2) LC_W_CASE(3) LC_W_CASE(4) LC_W_CASE(5) LC_W_CASE(6) LC_W_CASE(7) LC_W_CASE(8)
                     LC_W_CASE(9) LC_W_CASE(10) LC_W_CASE(11) LC_W_CASE(12) LC_W_CASE(13) LC_W_CASE(14) LC_W_CASE(15) LC_W_CASE(16)
+#if LC_X_UNIFORM_MAXW > 16
+                    LC_W_CASE(17) LC_W_CASE(18) LC_W_CASE(19) LC_W_CASE(20) LC_W_CASE(21) LC_W_CASE(22) LC_W_CASE(23) LC_W_CASE(24)
+                    LC_W_CASE(25) LC_W_CASE(26) LC_W_CASE(27) LC_W_CASE(28) LC_W_CASE(29) LC_W_CASE(30) LC_W_CASE(31) LC_W_CASE(32)
+#endif
 #undef LC_W_CASE
                     default: launched = false;
                 }
             };
             // Measured (scripts/ab_uniform_w.sh, 100 M rows, hot / L3-cold): u64 lanes W = 4 21.2 / 26.2 -> 18.5 / 22.2 us, W = 13
             // 31.3 / 42.8 -> 29.4 / 40.9; u32 lanes W = 12 29.6 / 37.6 -> 30.5 / 37.5 and u16 lanes W = 12 27.4 / 37.8 -> 26.6 / 38.5
-            // — no gain from 7-8 waves per SIMD instead of 5-6 there, so only the u64 lanes have these kernels.
+            // — no gain from 7-8 waves per SIMD instead of 5-6 there, so only the u64 lanes have these kernels.  W = 17 .. 32 on u64
+            // lanes (66-72 VGPRs: 7 waves instead of 6): W = 17 37.3 / 53.6 -> 37.1 / 51.9, W = 26 70.2 / 75.6 -> 67.1 / 72.3, W = 31
+            // 84.3 / 87.7 -> 81.0 / 82.6 (scripts/ab_uniform_w32.sh).
             if (lane_log2 == 6) by_width(uint64_t{});
             else launched = false;
             if (launched) return hipGetLastError();
