@@ -2207,8 +2207,13 @@ using ConstDescPtr = const __attribute__((address_space(4))) StrDesc*;
 // kSigOnly: `LIKE '%needle%'` over a scan whose entries ALL carry the bigram signature index (the launcher checks):
 // the candidates are exactly the set bits of the signature AND, so the fingerprint / prefix-key round of phase A, the
 // NOT LIKE candidate rule and the dictionary inversion are compiled out of the headline kernel.
+// (A/B: the occupancy the compiler aims for.  4 workgroups per CU = 128 VGPRs; 5 / 6 = 96 / 80 VGPRs with 152 / 216 bytes of scratch:
+// the many-candidate walk of the URL column 468 -> 491 / 502 us — scripts/ab_str_minblocks.sh)
+#ifndef LC_X_STR_MINBLOCKS
+#define LC_X_STR_MINBLOCKS 4
+#endif
 template <bool kBytes, bool kSub, bool kMany, bool kInstr, bool kSigOnly = false>
-__global__ __launch_bounds__(kThreads, 4) void k_str_pred(const StrDesc* __restrict__ descs,
+__global__ __launch_bounds__(kThreads, LC_X_STR_MINBLOCKS) void k_str_pred(const StrDesc* __restrict__ descs,
                                                            const DevSymtab* __restrict__ symtabs, StrPred pred,
                                                            ScanLaunch L, uint32_t dres_bytes, uint32_t cmask_bytes) {
     // dynamic LDS: [automaton (u16 row addresses)][role table]   (kSub with a short needle only)
