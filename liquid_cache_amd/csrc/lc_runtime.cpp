@@ -3000,7 +3000,8 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
             if (!s->needs_backing.empty() && !tolerate_backing)
                 return fail(LC_NEEDS_BACKING, "a clamp-squeezed entry holds sentinel rows this predicate cannot decide");
         }
-        // (every entry with packed data at one width, no squeezed / float entries: the kernel of that width)
+        // (every entry with packed data at one width, none of them squeezed: the kernel of that width — ALP floats included, their
+        // packed-domain range is found the same way)
         L.uniform_w = (s->min_w == s->max_w && !s->has_clamped && !s->has_fquant) ? s->max_w : 0u;
         LC_HIP(launch_fixed_pred(static_cast<const FixedDesc*>(s->d_descs), s->lane_log2, fp, pred2 ? &fp2 : nullptr,
                                  s->max_w, L, stream));
