@@ -390,6 +390,7 @@ struct lc_scan {
     // of a scan's first LIKE walked `meta` four times (12,207 records: 0.13 + 0.17 ms when the records had left the cache again).
     std::vector<uint64_t> uids;         // Entry::uid, in scan order
     std::vector<uint32_t> symtab_slots; // byte views: StrDesc::symtab_slot, in scan order
+    uint32_t slot_lo = 0, slot_hi = 0;  // ... their range: the LIKE automata are folded for these tables only
     bool str_index_everywhere = true;   // byte views: every entry with a dictionary carries signatures, row lists and fingerprints
     uint32_t max_str_rows = 0;          // byte views: the largest StrDesc::n
     uint32_t max_dict_rows = 0;         // ... among the entries that have a dictionary (an all-null entry has none)
@@ -455,6 +456,7 @@ hipStream_t stream_acquire(lc_ctx* ctx);
 void stream_release(lc_ctx* ctx, hipStream_t s);
 void* pool_alloc(lc_ctx* ctx, size_t bytes);
 void pool_release(lc_ctx* ctx, void* p);  // the caller guarantees that nothing in flight still uses `p`
+bool pool_release_if_owned(lc_ctx* ctx, void* p);  // false: not a block of the pool
 void* host_pool_alloc(lc_ctx* ctx, size_t bytes);
 void host_pool_release(lc_ctx* ctx, void* p);
 void arena_pin(lc_ctx* ctx, int slab_idx);

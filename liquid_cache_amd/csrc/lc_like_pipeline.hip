@@ -1448,6 +1448,21 @@ __global__ __launch_bounds__(kFbThreads) __attribute__((amdgpu_num_sgpr(80))) vo
     }
 }
 
+// Where index memory comes from.  The index of a whole column is gigabytes and is an allocation of its own; the index of a
+// scan over ONE row group (the reference's granularity: a reader per row group) is a few megabytes, and a host that works at
+// that granularity creates and drops hundreds of such scans: as allocations of their own those were a hipMalloc per build and a
+// hipFree — 3 ms, device-wide — per dropped index.  Up to kIndexPoolMax they come out of the context's scratch chunks instead.
+constexpr uint64_t kIndexPoolMax = uint64_t(16) << 20;
+static void* index_mem_alloc(lc_ctx* ctx, uint64_t bytes) {
+    if (bytes <= kIndexPoolMax) return pool_alloc(ctx, size_t(bytes));
+    void* p = nullptr;
+    if (hipMalloc(&p, size_t(bytes)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+static void index_mem_free(lc_ctx* ctx, void* p) {  // (by ownership, not by size: a build that failed half way has recorded none)
+    if (p && !pool_release_if_owned(ctx, p)) (void)hipFree(p);
+}
+
 // Index memory is HBM the caller's budget must cover: max_hbm_bytes bounds slabs + indexes, LC_OPT_LIKE_INDEX_BUDGET_BYTES the
 // indexes alone, and an index never takes more than half of what the device has free.  index_reserve answers "may `bytes` of
 // index be allocated now?" and, when yes, CHARGES them to ctx->index_bytes before the caller allocates (two builders cannot
@@ -1620,10 +1635,10 @@ lc_status build_flat(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t stre
     hipError_t e_malloc;
     {
         LC_PHASE("build_flat: hipMalloc of the slices");
-        e_malloc = hipMalloc(reinterpret_cast<void**>(&lp->d_slices), bytes);
+        lp->d_slices = static_cast<uint64_t*>(index_mem_alloc(ctx, bytes));
+        e_malloc = lp->d_slices ? hipSuccess : hipErrorOutOfMemory;
     }
     if (e_malloc != hipSuccess) {
-        (void)hipGetLastError();
         lp->d_slices = nullptr;
         lp->flat_why = 2;
         return LC_OK;  // no room: the entry-level index serves
@@ -1675,9 +1690,8 @@ lc_status build_unigram(lc_ctx* ctx, lc_scan* s, LikePipeline* lp, hipStream_t s
     const uint64_t bytes = lp->slice_words * 8u * 256u;
     // (the cached indexes of other scans go first, like for the bigram index; what live scans hold stays: the walkers serve)
     if (!index_reserve(ctx, bytes, true, nullptr)) return LC_OK;
-    uint64_t* d_uni = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&d_uni), bytes) != hipSuccess) {
-        (void)hipGetLastError();
+    uint64_t* d_uni = static_cast<uint64_t*>(index_mem_alloc(ctx, bytes));
+    if (!d_uni) {
         ctx->index_bytes -= bytes;
         return LC_OK;  // no room: the walkers serve
     }
@@ -2083,8 +2097,8 @@ void like_pipeline_wait(lc_scan* s) {
 // its index again.  Caller holds the lock that keeps the pipeline idle (ctx->like_orphans_mu / ctx->scan_cache_mu).
 void drop_flat_index(lc_ctx* ctx, LikePipeline* lp) {
     ctx->index_events++;
-    if (lp->d_slices) { (void)hipFree(lp->d_slices); ctx->index_bytes -= lp->slices_bytes; }
-    if (lp->d_uni) { (void)hipFree(lp->d_uni); ctx->index_bytes -= lp->slice_words * 8u * 256u; }
+    if (lp->d_slices) { index_mem_free(ctx, lp->d_slices); ctx->index_bytes -= lp->slices_bytes; }
+    if (lp->d_uni) { index_mem_free(ctx, lp->d_uni); ctx->index_bytes -= lp->slice_words * 8u * 256u; }
     pool_release(ctx, lp->d_groups);
     pool_release(ctx, lp->d_dst_word);
     lp->d_slices = nullptr;
@@ -2157,8 +2171,8 @@ void like_pipeline_destroy(lc_ctx* ctx, LikePipeline* lp) {
     pool_release(ctx, lp->d_groups);
     pool_release(ctx, lp->d_dst_word);
     if (lp->d_slices || lp->d_uni) ctx->index_events++;
-    if (lp->d_slices) { (void)hipFree(lp->d_slices); ctx->index_bytes -= lp->slices_bytes; }
-    if (lp->d_uni) { (void)hipFree(lp->d_uni); ctx->index_bytes -= lp->slice_words * 8u * 256u; }
+    if (lp->d_slices) { index_mem_free(ctx, lp->d_slices); ctx->index_bytes -= lp->slices_bytes; }
+    if (lp->d_uni) { index_mem_free(ctx, lp->d_uni); ctx->index_bytes -= lp->slice_words * 8u * 256u; }
     delete lp;
 }
 

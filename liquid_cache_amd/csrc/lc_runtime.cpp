@@ -264,6 +264,9 @@ void* pool_alloc(lc_ctx* ctx, size_t bytes) {
     }
     void* p = nullptr;
     LC_PHASE("pool_alloc: hipMalloc");
+#ifdef LC_TRACE_PHASES
+    std::fprintf(stderr, "[pool] hipMalloc of class %zu for %zu bytes\n", cls, bytes);
+#endif
     if (hipMalloc(&p, cls) != hipSuccess) {
         // the scan-level LIKE indexes kept for the NEXT scan over the same entries are a cache, outside the entry accounting:
         // they go before an allocation fails
@@ -274,6 +277,17 @@ void* pool_alloc(lc_ctx* ctx, size_t bytes) {
     std::lock_guard<std::mutex> g(ctx->pool_mu);
     ctx->pool_live[p] = cls;
     return p;
+}
+
+// true: `p` is a block of the pool and has been released; false: it is not the pool's (the caller frees it its own way)
+bool pool_release_if_owned(lc_ctx* ctx, void* p) {
+    if (!p) return true;
+    {
+        std::lock_guard<std::mutex> g(ctx->pool_mu);
+        if (ctx->pool_live.find(p) == ctx->pool_live.end()) return false;
+    }
+    pool_release(ctx, p);
+    return true;
 }
 
 // The caller guarantees that no kernel or copy still uses `p` (the per-call API synchronises before it returns).
@@ -2627,6 +2641,8 @@ static lc_status scan_create_impl(lc_ctx* ctx, uint64_t n, const uint64_t* entry
                 if (i == 0) s->uniform_slot = int32_t(e.sd.symtab_slot);
                 else if (int32_t(e.sd.symtab_slot) != s->uniform_slot) s->uniform_slot = -1;
                 s->symtab_slots.push_back(e.sd.symtab_slot);
+                s->slot_lo = (i == 0) ? e.sd.symtab_slot : std::min(s->slot_lo, e.sd.symtab_slot);
+                s->slot_hi = (i == 0) ? e.sd.symtab_slot : std::max(s->slot_hi, e.sd.symtab_slot);
                 if (e.sd.d != 0 && (!e.sd.signatures || !e.sd.postings || !e.sd.fingerprints)) s->str_index_everywhere = false;
                 s->max_str_rows = std::max(s->max_str_rows, e.sd.n);
                 if (e.sd.d != 0) s->max_dict_rows = std::max(s->max_dict_rows, e.sd.n);
@@ -3112,7 +3128,14 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
     auto build_automata = [&](StrPredHost& q) -> lc_status {
         LC_PHASE("eval: automata");
         const uint32_t stride = automaton_stride(q.p.needle_len);
-        const size_t nst = s->n_symtabs;
+        // Folded over the symbol tables THIS scan's entries use — the slots [slot_lo, slot_hi] captured at scan creation — not
+        // over every table of the context: a context that holds a few hundred row groups of a few dozen tables has thousands of
+        // symbol tables, and a scan over one row group was allocating (70 MB: a hipMalloc, later a 3 ms hipFree) and folding
+        // the automata of all of them.  The kernels index by the absolute slot: they get the base of slot 0, which lies in front
+        // of the allocation.
+        const size_t nst_ctx = s->n_symtabs;
+        const bool sub = !s->symtab_slots.empty() && s->slot_hi < nst_ctx;
+        const size_t lo = sub ? s->slot_lo : 0, nst = sub ? size_t(s->slot_hi - s->slot_lo) + 1 : nst_ctx;
         const size_t need = size_t(stride) * std::max<size_t>(nst, 1);
         if (need > s->automata_cap) {
             LC_HIP(hipStreamSynchronize(stream));
@@ -3125,11 +3148,11 @@ static lc_status scan_eval_impl(lc_ctx* ctx, lc_scan* s, const lc_predicate* pre
         // a query evaluates one pattern over and over: the folded automata are rebuilt only when the needle or the
         // set of symbol tables changed (stream order keeps earlier launches valid)
         if (s->automata_symtabs != nst || s->automata_needle != q.needle) {
-            LC_HIP(launch_str_automata(s->d_symtabs, uint32_t(nst), q.needle.data(), q.p.needle_len, s->d_automata, stream));
+            LC_HIP(launch_str_automata(s->d_symtabs + lo, uint32_t(nst), q.needle.data(), q.p.needle_len, s->d_automata, stream));
             s->automata_needle = q.needle;
             s->automata_symtabs = nst;
         }
-        q.p.automata = s->d_automata;
+        q.p.automata = s->d_automata - lo * size_t(stride);
         q.p.automaton_stride = stride;
         return LC_OK;
     };
@@ -4076,7 +4099,12 @@ lc_status lc_eval_predicate_row_groups(lc_ctx* ctx, uint64_t n_entries, const ui
         lc_scan* s = nullptr;
         ~Lease() { if (s) lc_scan_destroy(s); }
     } lease;
-    lc_status rc = lc_scan_create(ctx, n_entries, entry_ids, &lease.s);
+    LC_PHASE("row groups by id (all)");
+    lc_status rc;
+    {
+        LC_PHASE("row groups by id: scan");
+        rc = lc_scan_create(ctx, n_entries, entry_ids, &lease.s);
+    }
     if (rc != LC_OK) return rc;
     lc_scan* scan = lease.s;
     CallStream cs(ctx);
@@ -4089,16 +4117,30 @@ lc_status lc_eval_predicate_row_groups(lc_ctx* ctx, uint64_t n_entries, const ui
     uint64_t* d_m = out_mask ? static_cast<uint64_t*>(cs.dalloc(m_bytes)) : nullptr;
     if (!h || !d_g || (out_mask && !d_m)) return fail(LC_ERR_OOM, "row-group call: staging");
     uint64_t* d_total = d_g + n_groups;
-    if (n_groups) {
-        rc = lc_scan_eval_count_groups(ctx, scan, preds, n_preds, nullptr, n_groups, group_ends, d_g, d_m, nullptr, d_total, cs.st);
-    } else {
-        rc = lc_scan_eval_count(ctx, scan, preds, n_preds, nullptr, d_m, nullptr, d_total, cs.st);
+    {
+        LC_PHASE("row groups by id: evaluation calls");
+        if (n_groups) {
+            rc = lc_scan_eval_count_groups(ctx, scan, preds, n_preds, nullptr, n_groups, group_ends, d_g, d_m, nullptr, d_total, cs.st);
+        } else {
+            rc = lc_scan_eval_count(ctx, scan, preds, n_preds, nullptr, d_m, nullptr, d_total, cs.st);
+        }
     }
     if (rc != LC_OK) return rc;
-    LC_HIP(hipMemcpyAsync(h, d_g, g_bytes, hipMemcpyDeviceToHost, cs.st));
-    if (out_mask) LC_HIP(hipMemcpyAsync(h + g_bytes, d_m, m_bytes, hipMemcpyDeviceToHost, cs.st));
-    LC_HIP(cs.sync());
+    {
+        LC_PHASE("row groups by id: copies back + wait");
+        LC_HIP(hipMemcpyAsync(h, d_g, g_bytes, hipMemcpyDeviceToHost, cs.st));
+        if (out_mask) LC_HIP(hipMemcpyAsync(h + g_bytes, d_m, m_bytes, hipMemcpyDeviceToHost, cs.st));
+        LC_HIP(cs.sync());
+    }
     cs.drained = true;
+    {
+        // (the call's stream — the only one this lease of the scan ran on — has just been drained: lc_scan_destroy, which
+        // synchronises every stream a scan was used on before it keeps the scan, finds nothing left to wait for; from sixteen
+        // threads every HIP call counts)
+        std::lock_guard<std::mutex> g(scan->mu);
+        scan->streams_used.clear();
+        scan->last_stream = nullptr;
+    }
     if (n_groups) std::memcpy(out_group_counts, h, size_t(n_groups) * 8);
     if (out_total) std::memcpy(out_total, h + size_t(n_groups) * 8, 8);
     if (out_mask) std::memcpy(out_mask, h + g_bytes, m_bytes);
